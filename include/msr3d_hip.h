@@ -1,0 +1,99 @@
+/*
+ * msr3d_hip.h -- C ABI of libmsr3d_hip.so, the MI355X (gfx950) implementation of
+ * MSR3D's point-cloud hot path.
+ *
+ * This is the drop-in boundary: plain device pointers and sizes, a HIP stream,
+ * an int status.  No torch types, no hidden allocation, no host sync, never
+ * exit().  Every entry point replaces one `*_kernel_wrapper` the reference's
+ * pybind layer calls (paths relative to
+ * /root/reference/modules/third_party/pointnet2/_ext_src/); the binding a
+ * maintainer adds on the reference side is in INTEGRATION.md.
+ *
+ * Conventions
+ *   - all tensors are dense, row-major, f32 or i32, resident on the current device;
+ *   - outputs are caller-allocated and FULLY written by the call (the reference
+ *     relies on torch::zeros for ball_query no-hit rows and for the *_grad
+ *     accumulators; here the callee establishes that state itself);
+ *   - `stream` is a hipStream_t (NULL = default stream); launches are asynchronous;
+ *   - return 0 on success, MSR3D_EINVAL for bad arguments, otherwise the
+ *     hipError_t of the failed launch (the reference prints and exit(-1)s,
+ *     include/cuda_utils.h:30-39).
+ */
+#ifndef MSR3D_HIP_H
+#define MSR3D_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSR3D_ABI_VERSION 1
+#define MSR3D_EINVAL (-22)
+
+typedef void *msr3d_stream_t; /* hipStream_t */
+
+int msr3d_abi_version(void);
+/* Static string for a status returned by any entry point. */
+const char *msr3d_status_string(int status);
+
+/* ---------------------------------------------------------------------------
+ * B1: the nine ops of `pointnet2._ext` (src/bindings.cpp:6-19)
+ * ------------------------------------------------------------------------- */
+
+/* furthest_point_sampling_kernel_wrapper (src/sampling_gpu.cu:175-229; host
+ * src/sampling.cpp:66-87).  xyz (b,n,3) f32 -> idx (b,m) i32.  idx[.,0] = 0.
+ * Bit-exact with the reference's block reduction, including its tie-break
+ * (which depends on the REFERENCE's block size opt_n_threads(n)), the
+ * |p|^2 <= 1e-3 skip and the all-skipped -> 0 case.  The reference's `temp`
+ * (b,n) scratch is not needed: distances live in registers.
+ * new_xyz (b,m,3) is optional (NULL to skip): the gathered centroids, i.e. what
+ * gather_points(xyz^T, idx)^T returns, produced in the same launch. */
+int msr3d_furthest_point_sampling(int b, int n, int m, const float *xyz, int *idx,
+                                  float *new_xyz, msr3d_stream_t stream);
+
+/* gather_points_kernel_wrapper (src/sampling_gpu.cu:22-30).
+ * points (b,c,n), idx (b,m) -> out (b,c,m). */
+int msr3d_gather_points(int b, int c, int n, int m, const float *points, const int *idx,
+                        float *out, msr3d_stream_t stream);
+
+/* gather_points_grad_kernel_wrapper (src/sampling_gpu.cu:49-57).
+ * grad_out (b,c,m), idx (b,m) -> grad_points (b,c,n), zeroed then accumulated. */
+int msr3d_gather_points_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                             float *grad_points, msr3d_stream_t stream);
+
+/* query_ball_point_kernel_wrapper (src/ball_query_gpu.cu:46-54).
+ * new_xyz (b,m,3) centres, xyz (b,n,3) -> idx (b,m,nsample): the first nsample
+ * points in index order with d^2 < radius^2 (f32, strict); remaining slots hold
+ * the first hit; rows without a hit are zero. */
+int msr3d_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                     const float *xyz, int *idx, msr3d_stream_t stream);
+
+/* group_points_kernel_wrapper (src/group_points_gpu.cu:30-39).
+ * points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample). */
+int msr3d_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                       const int *idx, float *out, msr3d_stream_t stream);
+
+/* group_points_grad_kernel_wrapper (src/group_points_gpu.cu:66-75).
+ * grad_out (b,c,npoints,nsample) -> grad_points (b,c,n), zeroed then accumulated. */
+int msr3d_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                            const int *idx, float *grad_points, msr3d_stream_t stream);
+
+/* three_nn_kernel_wrapper (src/interpolate_gpu.cu:61-68).
+ * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) f32 (SQUARED), idx (b,n,3) i32. */
+int msr3d_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                   int *idx, msr3d_stream_t stream);
+
+/* three_interpolate_kernel_wrapper (src/interpolate_gpu.cu:103-111).
+ * points (b,c,m), idx (b,n,3), weight (b,n,3) -> out (b,c,n). */
+int msr3d_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                            const float *weight, float *out, msr3d_stream_t stream);
+
+/* three_interpolate_grad_kernel_wrapper (src/interpolate_gpu.cu:145-154).
+ * grad_out (b,c,n) -> grad_points (b,c,m), zeroed then accumulated. */
+int msr3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                                 const int *idx, const float *weight, float *grad_points,
+                                 msr3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSR3D_HIP_H */

@@ -1,0 +1,74 @@
+"""ctypes loader for libmsr3d_hip.so -- the only door from Python to the HIP kernels.
+
+There is no CPU fallback anywhere in this package: if the library cannot be
+loaded the import fails loudly.  torch is imported first so that the library's
+`libamdhip64.so.7` dependency resolves to the HIP runtime torch already loaded
+(one runtime per process: torch's streams must be valid handles for our
+launches).
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsr3d_hip.so")
+
+_c_int = ctypes.c_int
+_c_float = ctypes.c_float
+_ptr = ctypes.c_void_p
+
+# name -> argtypes; every entry point returns int status and ends with the stream.
+_SIGNATURES = {
+    "msr3d_furthest_point_sampling": [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_gather_points": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_gather_points_grad": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_ball_query": [_c_int, _c_int, _c_int, _c_float, _c_int, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_group_points": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_group_points_grad": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_three_nn": [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_three_interpolate": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_three_interpolate_grad": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Every symbol include/msr3d_hip.h declares (checked by the CPU test-suite)."""
+    return ["msr3d_abi_version", "msr3d_status_string"] + list(_SIGNATURES)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        # the in-tree build is part of the product; build it rather than limp along
+        from . import build as _build
+        _build.build()
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise ImportError(
+            f"msr3d_amd: cannot load {LIB_PATH} ({e}). Build it with `python -m msr3d_amd.build`; "
+            "there is no CPU fallback.") from e
+    lib.msr3d_abi_version.restype = _c_int
+    lib.msr3d_status_string.restype = ctypes.c_char_p
+    lib.msr3d_status_string.argtypes = [_c_int]
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _c_int
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().msr3d_status_string(status).decode()
+        raise RuntimeError(f"{what} failed: {msg} (status {status})")
+
+
+def current_stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

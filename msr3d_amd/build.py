@@ -1,0 +1,69 @@
+"""Build libmsr3d_hip.so (gfx950) in-tree with hipcc.  `python -m msr3d_amd.build`.
+
+hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels
+to the GPU box with the tree.  Objects are cached under msr3d_amd/csrc/build/ and
+rebuilt when the source (or a header) is newer.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libmsr3d_hip.so")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+ARCH = "gfx950"
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+          "-Wall", "-Wno-unused-function", "-I", INCLUDE]
+
+# (source, extra flags).  The index ops pin their fma chains explicitly, so the
+# compiler must not contract anything further there.
+SOURCES = [
+    ("pn2_ops.hip", ["-ffp-contract=off"]),
+]
+
+
+def hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: cannot build libmsr3d_hip.so")
+
+
+def _newest_header():
+    t = 0.0
+    for d in (CSRC, INCLUDE):
+        for f in os.listdir(d):
+            if f.endswith((".h", ".hpp")):
+                t = max(t, os.path.getmtime(os.path.join(d, f)))
+    return max(t, os.path.getmtime(os.path.abspath(__file__)))
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    hdr_t = _newest_header()
+    objs, rebuilt = [], False
+    for src, extra in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_t):
+            cmd = [cc] + COMMON + extra + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            rebuilt = True
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,565 @@
+// pn2_ops.hip -- the nine pointnet2 ops for gfx950 (MI355X), behind the C ABI of
+// include/msr3d_hip.h.  Written for CDNA4 wave64: no block-size emulation of the
+// reference's CUDA launch shapes, only of its RESULTS.
+//
+// Reference semantics (paths relative to
+// /root/reference/modules/third_party/pointnet2/_ext_src/):
+//   src/sampling_gpu.cu, src/ball_query_gpu.cu, src/group_points_gpu.cu,
+//   src/interpolate_gpu.cu, include/cuda_utils.h
+//
+// Compiled with -ffp-contract=off: the distance is the explicit chain
+// fma(dz,dz, fma(dx,dx, dy*dy)) shared with oracle/pn2_oracle.c (see its header).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "../../include/msr3d_hip.h"
+
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float sq3(float a, float b, float c) {
+  return __builtin_fmaf(c, c, __builtin_fmaf(a, a, b * b));
+}
+
+// ---- wave64 integer max, all lanes -> uniform ---------------------------------
+template <int CTRL>
+__device__ __forceinline__ int dpp_max_i32(int v) {
+  const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+  return o > v ? o : v;
+}
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+  v = dpp_max_i32<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_max_i32<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_max_i32<0x141>(v);  // row_half_mirror
+  v = dpp_max_i32<0x140>(v);  // row_mirror  -> every lane holds its 16-lane row max
+  const int r0 = __builtin_amdgcn_readlane(v, 0);
+  const int r1 = __builtin_amdgcn_readlane(v, 16);
+  const int r2 = __builtin_amdgcn_readlane(v, 32);
+  const int r3 = __builtin_amdgcn_readlane(v, 48);
+  const int a = r0 > r1 ? r0 : r1;
+  const int b = r2 > r3 ? r2 : r3;
+  return a > b ? a : b;
+}
+
+// host + device: include/cuda_utils.h:13-19 (the reference's block size enters the FPS tie-break)
+inline int ref_opt_n_threads(int work_size) {
+  const int pow_2 = (int)(std::log((double)work_size) / std::log(2.0));
+  int v = 1 << pow_2;
+  if (v > 512) v = 512;
+  if (v < 1) v = 1;
+  return v;
+}
+
+// =================================================================================
+// Furthest point sampling.
+//
+// The reference (sampling_gpu.cu:69-173) runs one block of bs = opt_n_threads(n)
+// threads per cloud: thread t scans k = t, t+bs, ... with a strict '>' (lowest k
+// wins inside a thread), then a shared-memory halving tree keeps the LOWER slot on
+// ties.  Two tied threads meet at the stride equal to their lowest differing tid
+// bit and the one with that bit clear survives, so among equal maxima the winner
+// minimises (bitrev(k mod bs), k / bs).
+//
+// Here each cloud is owned by NW waves and every lane keeps PPT points in
+// registers (coordinates + running min distance), laid out in exactly that rank
+// order: slot p = tid*PPT + i holds the point of rank p.  One iteration is then
+//   per-lane strict-'>' scan (first max in rank order inside the lane)
+//   -> DPP wave max of the f32 bit pattern (values are >= +0 or the -1 sentinel)
+//   -> ballot of the lanes that hold the max, lowest set lane = lowest rank
+//   -> v_readlane of that lane's point index, LDS broadcast read of its coordinates.
+// No LDS traffic or barrier inside an iteration when NW == 1.
+// =================================================================================
+template <int PPT, int NW, bool STAGE>
+__global__ __launch_bounds__(kWave * NW) void fps_kernel(int n, int m, int bs, int log2bs, int q,
+                                                         const float *__restrict__ xyz,
+                                                         int *__restrict__ idxs,
+                                                         float *__restrict__ new_xyz) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int *red_bits = reinterpret_cast<int *>(smem);          // [2][NW]
+  int *red_k = red_bits + 2 * NW;                         // [2][NW]
+  float *sx = reinterpret_cast<float *>(red_k + 2 * NW);  // [n*3] when STAGE
+
+  const int obj = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid >> 6;
+  const float *P = xyz + (size_t)obj * n * 3;
+  int *out = idxs + (size_t)obj * m;
+  float *oxyz = new_xyz ? new_xyz + (size_t)obj * m * 3 : nullptr;
+
+  if (STAGE) {
+    for (int i = tid; i < n * 3; i += kWave * NW) sx[i] = P[i];
+    __syncthreads();
+  }
+  const float *src = STAGE ? sx : P;
+
+  float px[PPT], py[PPT], pz[PPT], tmp[PPT];
+  int kk[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int p = tid * PPT + i;       // rank slot
+    const int tr = p / q;              // bit-reversed reference thread id
+    const int j = p - tr * q;          // that thread's j-th point
+    const int t = log2bs ? (int)(__brev((unsigned)tr) >> (32 - log2bs)) : 0;
+    const int k = t + j * bs;
+    const bool valid = (tr < bs) && (k < n);
+    float x = 0.f, y = 0.f, z = 0.f;
+    bool live = false;
+    if (valid) {
+      x = src[k * 3 + 0];
+      y = src[k * 3 + 1];
+      z = src[k * 3 + 2];
+      const float mag = sq3(x, y, z);
+      live = !((double)mag <= 1e-3);   // sampling_gpu.cu:100-101 (double compare)
+    }
+    px[i] = x; py[i] = y; pz[i] = z;
+    kk[i] = valid ? k : 0;
+    // skipped / padding slots: min(d, -inf) = -inf never beats the -1 sentinel
+    tmp[i] = live ? 1e10f : -INFINITY;
+  }
+
+  int old = 0;
+  float ox = src[0], oy = src[1], oz = src[2];
+  if (tid == 0) {
+    out[0] = 0;
+    if (oxyz) { oxyz[0] = ox; oxyz[1] = oy; oxyz[2] = oz; }
+  }
+
+  int par = 0;
+  for (int jj = 1; jj < m; ++jj) {
+    float best = -1.0f;
+    int bk = 0;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const float d = sq3(px[i] - ox, py[i] - oy, pz[i] - oz);
+      const float d2 = fminf(d, tmp[i]);
+      tmp[i] = d2;
+      const bool gt = d2 > best;
+      bk = gt ? kk[i] : bk;
+      best = gt ? d2 : best;
+    }
+    const int bits = __float_as_int(best);   // >= +0.0 or -1.0f: int order == float order
+    int vmax = wave_max_i32(bits);
+    const unsigned long long hit = __ballot(bits == vmax);
+    const int first = __ffsll((long long)hit) - 1;
+    int kw = __builtin_amdgcn_readlane(bk, first);
+    if (NW > 1) {
+      if (lane == 0) {
+        red_bits[par * NW + wave] = vmax;
+        red_k[par * NW + wave] = kw;
+      }
+      __syncthreads();
+      vmax = red_bits[par * NW];
+      kw = red_k[par * NW];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) {
+        const int vb = red_bits[par * NW + w];
+        const int vk = red_k[par * NW + w];
+        const bool gt = vb > vmax;   // strict: the lower wave (= lower rank) wins ties
+        kw = gt ? vk : kw;
+        vmax = gt ? vb : vmax;
+      }
+      par ^= 1;
+    }
+    old = vmax < 0 ? 0 : kw;   // every candidate skipped: all threads report (-1, 0)
+    ox = src[old * 3 + 0];
+    oy = src[old * 3 + 1];
+    oz = src[old * 3 + 2];
+    if (tid == 0) {
+      out[jj] = old;
+      if (oxyz) { oxyz[jj * 3 + 0] = ox; oxyz[jj * 3 + 1] = oy; oxyz[jj * 3 + 2] = oz; }
+    }
+  }
+}
+
+template <int PPT, int NW>
+hipError_t launch_fps(int b, int n, int m, int bs, int log2bs, int q, const float *xyz, int *idx,
+                      float *new_xyz, hipStream_t s) {
+  const bool stage = (size_t)n * 12 <= 64 * 1024;
+  const size_t red = sizeof(int) * 4 * NW;
+  if (stage) {
+    fps_kernel<PPT, NW, true><<<b, kWave * NW, red + (size_t)n * 12, s>>>(n, m, bs, log2bs, q, xyz,
+                                                                         idx, new_xyz);
+  } else {
+    fps_kernel<PPT, NW, false><<<b, kWave * NW, red, s>>>(n, m, bs, log2bs, q, xyz, idx, new_xyz);
+  }
+  return hipGetLastError();
+}
+
+// =================================================================================
+// Ball query (ball_query_gpu.cu:9-44).  The reference gives each centre ONE thread
+// that walks all n points.  Here a wave owns a centre and tests 64 points per step:
+// ballot -> prefix popcount gives every hit its output slot in index order, and the
+// wave stops as soon as nsample hits are placed.  The cloud is staged in LDS once
+// per block and shared by the block's centres.
+// =================================================================================
+template <int NW, bool STAGE>
+__global__ __launch_bounds__(kWave * NW) void ball_query_kernel(int n, int m, float radius2,
+                                                                int nsample,
+                                                                const float *__restrict__ new_xyz,
+                                                                const float *__restrict__ xyz,
+                                                                int *__restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *sx = reinterpret_cast<float *>(smem);
+  const int obj = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid >> 6;
+  const float *P = xyz + (size_t)obj * n * 3;
+  if (STAGE) {
+    for (int i = tid; i < n * 3; i += kWave * NW) sx[i] = P[i];
+    __syncthreads();
+  }
+  const float *src = STAGE ? sx : P;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+
+  for (int j = blockIdx.y * NW + wave; j < m; j += NW * gridDim.y) {
+    const float *c = new_xyz + ((size_t)obj * m + j) * 3;
+    const float cx = c[0], cy = c[1], cz = c[2];
+    int *row = idx + ((size_t)obj * m + j) * nsample;
+    int cnt = 0, first = 0;
+    for (int base = 0; base < n && cnt < nsample; base += kWave) {
+      const int k = base + lane;
+      bool hit = false;
+      if (k < n) {
+        const float d2 = sq3(cx - src[k * 3 + 0], cy - src[k * 3 + 1], cz - src[k * 3 + 2]);
+        hit = d2 < radius2;
+      }
+      const unsigned long long mask = __ballot(hit);
+      if (mask) {
+        if (cnt == 0) first = base + __ffsll((long long)mask) - 1;
+        const int slot = cnt + __popcll(mask & lt);
+        if (hit && slot < nsample) row[slot] = k;
+        cnt += __popcll(mask);
+      }
+    }
+    // slots never reached: the first hit (pre-fill at :32-36) or 0 (host zero-init)
+    const int filled = cnt < nsample ? cnt : nsample;
+    const int fill = cnt > 0 ? first : 0;
+    for (int l = filled + lane; l < nsample; l += kWave) row[l] = fill;
+  }
+}
+
+// ---- gather / group: exact copies, one thread per output element ----------------
+__global__ void gather_points_kernel(long long total, int c, int n, int m,
+                                     const float *__restrict__ points,
+                                     const int *__restrict__ idx, float *__restrict__ out) {
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(t % m);
+    const long long bc = t / m;       // b*c + l
+    const long long bi = bc / c;
+    out[t] = points[bc * n + idx[bi * m + j]];
+  }
+}
+
+__global__ void gather_points_grad_kernel(long long total, int c, int n, int m,
+                                          const float *__restrict__ grad_out,
+                                          const int *__restrict__ idx,
+                                          float *__restrict__ grad_points) {
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(t % m);
+    const long long bc = t / m;
+    const long long bi = bc / c;
+    atomicAdd(grad_points + bc * n + idx[bi * m + j], grad_out[t]);
+  }
+}
+
+// out (b,c,npoints,nsample); thread = one (b,l,j) row segment of VEC samples
+template <int VEC>
+__global__ void group_points_kernel(long long total, int c, int n, int npoints, int nsample,
+                                    const float *__restrict__ points,
+                                    const int *__restrict__ idx, float *__restrict__ out) {
+  const int per_row = nsample / VEC;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int kq = (int)(t % per_row);
+    long long r = t / per_row;
+    const int j = (int)(r % npoints);
+    r /= npoints;                      // b*c + l
+    const long long bi = r / c;
+    const int *ip = idx + (bi * npoints + j) * nsample + kq * VEC;
+    const float *pp = points + r * n;
+    float *op = out + (r * npoints + j) * (long long)nsample + kq * VEC;
+    if (VEC == 4) {
+      const int4 ii = *reinterpret_cast<const int4 *>(ip);
+      float4 v;
+      v.x = pp[ii.x]; v.y = pp[ii.y]; v.z = pp[ii.z]; v.w = pp[ii.w];
+      *reinterpret_cast<float4 *>(op) = v;
+    } else {
+      op[0] = pp[ip[0]];
+    }
+  }
+}
+
+__global__ void group_points_grad_kernel(long long total, int c, int n, int npoints, int nsample,
+                                         const float *__restrict__ grad_out,
+                                         const int *__restrict__ idx,
+                                         float *__restrict__ grad_points) {
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(t % nsample);
+    long long r = t / nsample;
+    const int j = (int)(r % npoints);
+    r /= npoints;
+    const long long bi = r / c;
+    atomicAdd(grad_points + r * n + idx[(bi * npoints + j) * nsample + k], grad_out[t]);
+  }
+}
+
+// ---- three_nn (interpolate_gpu.cu:9-59): thread per unknown, known staged in LDS tiles
+constexpr int kNNTile = 1024;
+__global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
+                                                       const float *__restrict__ unknown,
+                                                       const float *__restrict__ known,
+                                                       float *__restrict__ dist2,
+                                                       int *__restrict__ idx) {
+  __shared__ float sk[kNNTile * 3];
+  const int obj = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const float *U = unknown + (size_t)obj * n * 3;
+  const float *K = known + (size_t)obj * m * 3;
+  float ux = 0.f, uy = 0.f, uz = 0.f;
+  if (j < n) { ux = U[j * 3 + 0]; uy = U[j * 3 + 1]; uz = U[j * 3 + 2]; }
+  // the reference keeps doubles initialised to 1e40; every comparison is against an f32 d,
+  // so f32 bests initialised to +inf order identically and (float)1e40 == +inf on output.
+  float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+  int i1 = 0, i2 = 0, i3 = 0;
+  for (int base = 0; base < m; base += kNNTile) {
+    const int cnt = (m - base) < kNNTile ? (m - base) : kNNTile;
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt * 3; i += blockDim.x) sk[i] = K[(size_t)base * 3 + i];
+    __syncthreads();
+    if (j < n) {
+      for (int k = 0; k < cnt; ++k) {
+        const float d = sq3(ux - sk[k * 3 + 0], uy - sk[k * 3 + 1], uz - sk[k * 3 + 2]);
+        const int kg = base + k;
+        if (d < b1) {
+          b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = kg;
+        } else if (d < b2) {
+          b3 = b2; i3 = i2; b2 = d; i2 = kg;
+        } else if (d < b3) {
+          b3 = d; i3 = kg;
+        }
+      }
+    }
+  }
+  if (j < n) {
+    float *D = dist2 + ((size_t)obj * n + j) * 3;
+    int *I = idx + ((size_t)obj * n + j) * 3;
+    D[0] = b1; D[1] = b2; D[2] = b3;
+    I[0] = i1; I[1] = i2; I[2] = i3;
+  }
+}
+
+// out (b,c,n): (p1*w1 + p2*w2) + p3*w3 contracted as fma(p3,w3, fma(p1,w1, p2*w2))
+__global__ void three_interpolate_kernel(long long total, int c, int m, int n,
+                                         const float *__restrict__ points,
+                                         const int *__restrict__ idx,
+                                         const float *__restrict__ weight,
+                                         float *__restrict__ out) {
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(t % n);
+    const long long bc = t / n;
+    const long long bi = bc / c;
+    const long long o = (bi * n + j) * 3;
+    const float *pp = points + bc * m;
+    const float p1 = pp[idx[o + 0]], p2 = pp[idx[o + 1]], p3 = pp[idx[o + 2]];
+    out[t] = __builtin_fmaf(p3, weight[o + 2], __builtin_fmaf(p1, weight[o + 0], p2 * weight[o + 1]));
+  }
+}
+
+__global__ void three_interpolate_grad_kernel(long long total, int c, int n, int m,
+                                              const float *__restrict__ grad_out,
+                                              const int *__restrict__ idx,
+                                              const float *__restrict__ weight,
+                                              float *__restrict__ grad_points) {
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(t % n);
+    const long long bc = t / n;
+    const long long bi = bc / c;
+    const long long o = (bi * n + j) * 3;
+    const float g = grad_out[t];
+    float *gp = grad_points + bc * m;
+    atomicAdd(gp + idx[o + 0], g * weight[o + 0]);
+    atomicAdd(gp + idx[o + 1], g * weight[o + 1]);
+    atomicAdd(gp + idx[o + 2], g * weight[o + 2]);
+  }
+}
+
+inline int grid_for(long long total, int block) {
+  long long g = (total + block - 1) / block;
+  const long long cap = 256LL * 8;   // 256 CUs x 8 blocks, grid-stride beyond that
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+// =================================================================================
+// C ABI
+// =================================================================================
+extern "C" {
+
+int msr3d_abi_version(void) { return MSR3D_ABI_VERSION; }
+
+const char *msr3d_status_string(int status) {
+  if (status == 0) return "ok";
+  if (status == MSR3D_EINVAL) return "invalid argument";
+  return hipGetErrorString((hipError_t)status);
+}
+
+int msr3d_furthest_point_sampling(int b, int n, int m, const float *xyz, int *idx,
+                                  float *new_xyz, msr3d_stream_t stream) {
+  if (b < 0 || n <= 0 || m < 0 || !xyz || (!idx && b * m > 0)) return MSR3D_EINVAL;
+  if (b == 0 || m == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int bs = ref_opt_n_threads(n);
+  int log2bs = 0;
+  while ((1 << log2bs) < bs) ++log2bs;
+  const int q = (n + bs - 1) / bs;          // points per reference thread (upper bound)
+  const long long slots = (long long)bs * q;  // rank slots incl. holes (< 2n)
+  hipError_t e;
+  if (slots <= 64) e = launch_fps<1, 1>(b, n, m, bs, log2bs, q, xyz, idx, new_xyz, s);
+  else if (slots <= 256) e = launch_fps<4, 1>(b, n, m, bs, log2bs, q, xyz, idx, new_xyz, s);
+  else if (slots <= 1024) e = launch_fps<16, 1>(b, n, m, bs, log2bs, q, xyz, idx, new_xyz, s);
+  else if (slots <= 2048) e = launch_fps<16, 2>(b, n, m, bs, log2bs, q, xyz, idx, new_xyz, s);
+  else if (slots <= 4096) e = launch_fps<16, 4>(b, n, m, bs, log2bs, q, xyz, idx, new_xyz, s);
+  else if (slots <= 8192) e = launch_fps<16, 8>(b, n, m, bs, log2bs, q, xyz, idx, new_xyz, s);
+  else if (slots <= 16384) e = launch_fps<16, 16>(b, n, m, bs, log2bs, q, xyz, idx, new_xyz, s);
+  else if (slots <= 32768) e = launch_fps<32, 16>(b, n, m, bs, log2bs, q, xyz, idx, new_xyz, s);
+  else return MSR3D_EINVAL;  // > 32768 rank slots per cloud: not a configuration of this path
+  return (int)e;
+}
+
+int msr3d_gather_points(int b, int c, int n, int m, const float *points, const int *idx,
+                        float *out, msr3d_stream_t stream) {
+  if (b < 0 || c < 0 || n <= 0 || m < 0) return MSR3D_EINVAL;
+  const long long total = (long long)b * c * m;
+  if (total == 0) return 0;
+  if (!points || !idx || !out) return MSR3D_EINVAL;
+  gather_points_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(total, c, n, m,
+                                                                              points, idx, out);
+  return (int)hipGetLastError();
+}
+
+int msr3d_gather_points_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                             float *grad_points, msr3d_stream_t stream) {
+  if (b < 0 || c < 0 || n <= 0 || m < 0) return MSR3D_EINVAL;
+  const long long total = (long long)b * c * m;
+  const size_t obytes = sizeof(float) * (size_t)b * c * n;
+  if (obytes == 0) return 0;
+  if (!grad_points) return MSR3D_EINVAL;
+  hipError_t e = hipMemsetAsync(grad_points, 0, obytes, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  if (total == 0) return 0;
+  if (!grad_out || !idx) return MSR3D_EINVAL;
+  gather_points_grad_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
+      total, c, n, m, grad_out, idx, grad_points);
+  return (int)hipGetLastError();
+}
+
+int msr3d_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                     const float *xyz, int *idx, msr3d_stream_t stream) {
+  if (b < 0 || n <= 0 || m < 0 || nsample < 0) return MSR3D_EINVAL;
+  if ((long long)b * m * nsample == 0) return 0;
+  if (!new_xyz || !xyz || !idx) return MSR3D_EINVAL;
+  const float radius2 = radius * radius;   // ball_query_gpu.cu:22, f32 product
+  constexpr int NW = 4;
+  int ysplit = (1024 + b - 1) / b;          // enough blocks to cover 256 CUs at small b
+  const int ymax = (m + NW - 1) / NW;
+  if (ysplit > ymax) ysplit = ymax;
+  if (ysplit < 1) ysplit = 1;
+  dim3 grid(b, ysplit);
+  const bool stage = (size_t)n * 12 <= 64 * 1024;
+  if (stage) {
+    ball_query_kernel<NW, true><<<grid, kWave * NW, (size_t)n * 12, (hipStream_t)stream>>>(
+        n, m, radius2, nsample, new_xyz, xyz, idx);
+  } else {
+    ball_query_kernel<NW, false><<<grid, kWave * NW, 0, (hipStream_t)stream>>>(
+        n, m, radius2, nsample, new_xyz, xyz, idx);
+  }
+  return (int)hipGetLastError();
+}
+
+int msr3d_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                       const int *idx, float *out, msr3d_stream_t stream) {
+  if (b < 0 || c < 0 || n <= 0 || npoints < 0 || nsample < 0) return MSR3D_EINVAL;
+  const long long elems = (long long)b * c * npoints * nsample;
+  if (elems == 0) return 0;
+  if (!points || !idx || !out) return MSR3D_EINVAL;
+  if (nsample % 4 == 0 && aligned16(idx) && aligned16(out)) {
+    const long long total = elems / 4;
+    group_points_kernel<4><<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
+        total, c, n, npoints, nsample, points, idx, out);
+  } else {
+    group_points_kernel<1><<<grid_for(elems, 256), 256, 0, (hipStream_t)stream>>>(
+        elems, c, n, npoints, nsample, points, idx, out);
+  }
+  return (int)hipGetLastError();
+}
+
+int msr3d_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                            const int *idx, float *grad_points, msr3d_stream_t stream) {
+  if (b < 0 || c < 0 || n <= 0 || npoints < 0 || nsample < 0) return MSR3D_EINVAL;
+  const size_t obytes = sizeof(float) * (size_t)b * c * n;
+  if (obytes == 0) return 0;
+  if (!grad_points) return MSR3D_EINVAL;
+  hipError_t e = hipMemsetAsync(grad_points, 0, obytes, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  const long long total = (long long)b * c * npoints * nsample;
+  if (total == 0) return 0;
+  if (!grad_out || !idx) return MSR3D_EINVAL;
+  group_points_grad_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
+      total, c, n, npoints, nsample, grad_out, idx, grad_points);
+  return (int)hipGetLastError();
+}
+
+int msr3d_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                   int *idx, msr3d_stream_t stream) {
+  if (b < 0 || n < 0 || m < 0) return MSR3D_EINVAL;
+  if ((long long)b * n == 0) return 0;
+  if (!unknown || (!known && m > 0) || !dist2 || !idx) return MSR3D_EINVAL;
+  dim3 grid((n + 255) / 256, b);
+  three_nn_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx);
+  return (int)hipGetLastError();
+}
+
+int msr3d_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                            const float *weight, float *out, msr3d_stream_t stream) {
+  if (b < 0 || c < 0 || m <= 0 || n < 0) return MSR3D_EINVAL;
+  const long long total = (long long)b * c * n;
+  if (total == 0) return 0;
+  if (!points || !idx || !weight || !out) return MSR3D_EINVAL;
+  three_interpolate_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
+      total, c, m, n, points, idx, weight, out);
+  return (int)hipGetLastError();
+}
+
+int msr3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                                 const int *idx, const float *weight, float *grad_points,
+                                 msr3d_stream_t stream) {
+  if (b < 0 || c < 0 || m <= 0 || n < 0) return MSR3D_EINVAL;
+  const size_t obytes = sizeof(float) * (size_t)b * c * m;
+  if (obytes == 0) return 0;
+  if (!grad_points) return MSR3D_EINVAL;
+  hipError_t e = hipMemsetAsync(grad_points, 0, obytes, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  const long long total = (long long)b * c * n;
+  if (total == 0) return 0;
+  if (!grad_out || !idx || !weight) return MSR3D_EINVAL;
+  three_interpolate_grad_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
+      total, c, n, m, grad_out, idx, weight, grad_points);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+"""Set-abstraction modules (the part of
+/root/reference/modules/third_party/pointnet2/pointnet2_modules.py:26-161 MSR3D uses).
+
+`forward` is the composite path: HIP index ops + torch conv/BN/ReLU/max, usable
+with autograd and BN in train mode.  The frozen, eval-mode encoder does not come
+through here level by level: PointNetPP routes it to the fused SA kernels.
+"""
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from . import pointnet2_utils
+from . import pytorch_utils as pt_utils
+
+
+class _PointnetSAModuleBase(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.npoint = None
+        self.groupers = None
+        self.mlps = None
+
+    def sample_centres(self, xyz):
+        """(B,N,3) -> (B,npoint,3) by FPS + gather, or None for a group-all level."""
+        if self.npoint is None:
+            return None
+        idx = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        flipped = xyz.transpose(1, 2).contiguous()
+        return pointnet2_utils.gather_operation(flipped, idx).transpose(1, 2).contiguous()
+
+    def forward(self, xyz, features=None):
+        new_xyz = self.sample_centres(xyz)
+        pooled = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            x = mlp(grouper(xyz, new_xyz, features))      # (B, C_out, npoint, nsample)
+            pooled.append(torch.amax(x, dim=3))           # max over the neighbourhood
+        return new_xyz, torch.cat(pooled, dim=1)
+
+
+class PointnetSAModuleMSG(_PointnetSAModuleBase):
+    def __init__(self, *, npoint: int, radii: List[float], nsamples: List[int],
+                 mlps: List[List[int]], bn: bool = True, use_xyz: bool = True,
+                 sample_uniformly: bool = False):
+        super().__init__()
+        if not (len(radii) == len(nsamples) == len(mlps)):
+            raise AssertionError("radii / nsamples / mlps must have one entry per scale")
+        self.npoint = npoint
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        for radius, nsample, spec in zip(radii, nsamples, mlps):
+            if npoint is not None:
+                self.groupers.append(pointnet2_utils.QueryAndGroup(
+                    radius, nsample, use_xyz=use_xyz, sample_uniformly=sample_uniformly))
+            else:
+                self.groupers.append(pointnet2_utils.GroupAll(use_xyz))
+            if use_xyz:
+                spec[0] += 3   # in place, like pointnet2_modules.py:120-122 (callers see it)
+            self.mlps.append(pt_utils.SharedMLP(spec, bn=bn))
+
+
+class PointnetSAModule(PointnetSAModuleMSG):
+    def __init__(self, *, mlp: List[int], npoint: int = None, radius: float = None,
+                 nsample: int = None, bn: bool = True, use_xyz: bool = True):
+        super().__init__(mlps=[mlp], npoint=npoint, radii=[radius], nsamples=[nsample], bn=bn,
+                         use_xyz=use_xyz)
