@@ -1,0 +1,61 @@
+"""The two lines of `MSR3D.build_embeds` that belong to the hot path
+(/root/reference/model/msr3d/msr3d.py:84-86 `llm_proj`, :277-287 projection, cast and
+scatter of the scene tokens into the LLM's `inputs_embeds` / `attention_mask`).
+
+`MSR3DHotPath` carries the reference's parameter names (`visual_prompter.*`,
+`llm_proj.*`), so the trainable tensors of a reference checkpoint
+(`pytorch_model.bin`, leo_trainer.py:445-454) load into it unchanged.
+"""
+import torch
+import torch.nn as nn
+
+from ..modules.utils import disabled_train
+from .build import MODEL_REGISTRY, build_model
+
+SCENE_SP_TOKEN = 31495   # vicuna id of the scene placeholder (msr3d.py:213)
+
+
+def scatter_scene_embeds(inputs_embeds, attention_mask, input_ids, scene_embeds, scene_mask,
+                         scene_sp_token=SCENE_SP_TOKEN):
+    """Write scene_embeds (B,L,E) / scene_mask (B,L) at the positions where
+    input_ids == scene_sp_token (row-major order, L placeholders per row), as
+    msr3d.py:279-287 does with torch.where + indexed assignment -- but without the
+    host sync: the k-th placeholder (global running count) takes the k-th scene token.
+    Returns (inputs_embeds, attention_mask) as new tensors."""
+    B, T = input_ids.shape
+    hit = input_ids == scene_sp_token                                  # (B,T)
+    flat_hit = hit.reshape(-1)
+    rank = torch.cumsum(flat_hit.to(torch.int64), 0) - 1               # k-th placeholder -> k
+    rank = rank.clamp_(min=0, max=scene_embeds.shape[0] * scene_embeds.shape[1] - 1)
+    src = scene_embeds.reshape(-1, scene_embeds.shape[-1]).to(inputs_embeds.dtype)
+    picked = src.index_select(0, rank).reshape(B, T, -1)
+    out_embeds = torch.where(hit.unsqueeze(-1), picked, inputs_embeds)
+    m = scene_mask.reshape(-1).index_select(0, rank).reshape(B, T)
+    out_mask = torch.where(hit, m, attention_mask.to(m.dtype))
+    return out_embeds, out_mask
+
+
+@MODEL_REGISTRY.register()
+class MSR3DHotPath(nn.Module):
+    """visual_prompter (OSE3DSituation) + llm_proj: the trainable, LLM-independent part of
+    `MODEL_REGISTRY["MSR3D"]`.  `cfg.prompter` is the prompter block; `cfg.llm_hidden_size`
+    replaces `llm_model.config.hidden_size` (4096 for Vicuna-7B, 5120 for 13B)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.visual_prompter = build_model(cfg.prompter)
+        if cfg.prompter.model.vision.args.freeze:
+            self.visual_prompter.obj_encoder.train = disabled_train.__get__(
+                self.visual_prompter.obj_encoder)
+        self.llm_proj = nn.Linear(cfg.prompter.model.hidden_size, cfg.llm_hidden_size)
+
+    def get_opt_params(self):
+        return [p for p in self.parameters() if p.requires_grad]
+
+    def forward(self, scene_dict):
+        """-> scene_dict with obj_tokens, obj_masks (from the prompter) and scene_embeds (B,L,E)."""
+        if "obj_tokens" not in scene_dict:
+            scene_dict = self.visual_prompter(scene_dict)
+        scene_dict["scene_embeds"] = self.llm_proj(scene_dict["obj_tokens"])
+        return scene_dict

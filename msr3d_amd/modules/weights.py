@@ -1,0 +1,17 @@
+"""BERT-style initialisation (/root/reference/modules/weights.py:3-19)."""
+import torch.nn as nn
+
+
+def _init_weights_bert(module, std=0.02):
+    if isinstance(module, nn.Linear):
+        nn.init.normal_(module.weight, mean=0.0, std=std)
+        if module.bias is not None:
+            nn.init.zeros_(module.bias)
+    elif isinstance(module, nn.Embedding):
+        nn.init.normal_(module.weight, mean=0.0, std=std)
+        if module.padding_idx is not None:
+            with __import__("torch").no_grad():
+                module.weight[module.padding_idx].zero_()
+    elif isinstance(module, nn.LayerNorm):
+        nn.init.zeros_(module.bias)
+        nn.init.ones_(module.weight)

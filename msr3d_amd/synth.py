@@ -1,0 +1,59 @@
+"""Seeded synthetic MSQA scenes in the dataset's conventions.
+
+What the reference's host pipeline hands the model, restated as a generator (there
+is no dataset on the box):
+  * per object `n_raw ~ U{200..5000}` points in a box of size U(0.1,2.0)^3 m somewhere in an
+    8x8x3 m room; subsampled to P points, WITH replacement iff n_raw < P; centred on the mean
+    and scaled to max-norm 1 (data/datasets/msr3d.py:199-209); colours U(-1,1)
+    (data/datasets/scannet_base.py:61);
+  * `n_valid ~ U{20..O}` real objects, the rest padded with the constant 1.0 and mask False,
+    padded obj_locs rows 0 (data/datasets/dataset_wrapper.py:155-158);
+  * obj_locs = [centre xyz, size xyz] in scene metres; anchor position U(room), anchor
+    orientation a yaw quaternion in scipy (x,y,z,w) order (data/data_utils.py:544-552).
+Generated with numpy on the host (identical on every machine), then moved to `device`.
+"""
+import numpy as np
+import torch
+
+ROOM = np.array([8.0, 8.0, 3.0])
+
+
+def synth_scene(rng, O=60, P=1024, n_valid=None):
+    if n_valid is None:
+        n_valid = int(rng.integers(min(20, O), O + 1))
+    fts = np.ones((O, P, 6), np.float32)
+    locs = np.zeros((O, 6), np.float32)
+    mask = np.zeros((O,), bool)
+    for o in range(n_valid):
+        size = rng.uniform(0.1, 2.0, 3)
+        centre = rng.uniform(0, 1, 3) * ROOM
+        n_raw = int(rng.integers(200, 5001))
+        raw = (rng.uniform(-0.5, 0.5, (n_raw, 3)) * size + centre).astype(np.float32)
+        sel = rng.choice(n_raw, P, replace=n_raw < P)
+        pts = raw[sel]
+        box_c = (raw.max(0) + raw.min(0)) / 2
+        box_s = raw.max(0) - raw.min(0)
+        pts = pts - pts.mean(0)
+        pts = pts / max(float(np.sqrt((pts ** 2).sum(1)).max()), 1e-6)
+        fts[o, :, :3] = pts
+        fts[o, :, 3:] = rng.uniform(-1, 1, (P, 3))
+        locs[o, :3] = box_c
+        locs[o, 3:] = box_s
+        mask[o] = True
+    anchor = (rng.uniform(0, 1, 3) * ROOM).astype(np.float32)
+    yaw = rng.uniform(-np.pi, np.pi)
+    quat = np.array([0.0, 0.0, np.sin(yaw / 2), np.cos(yaw / 2)], np.float32)
+    return fts, mask, locs, anchor, quat
+
+
+def synth_batch(seed, B, O=60, P=1024, n_valid=None, device="cpu"):
+    """-> dict of torch tensors: obj_fts (B,O,P,6) f32, obj_masks (B,O) bool, obj_locs (B,O,6),
+    anchor_locs (B,3), anchor_orientation (B,4).  `n_valid`: int or per-sample list."""
+    rng = np.random.default_rng(seed)
+    cols = [[], [], [], [], []]
+    for i in range(B):
+        nv = n_valid[i] if isinstance(n_valid, (list, tuple)) else n_valid
+        for c, v in zip(cols, synth_scene(rng, O, P, nv)):
+            c.append(v)
+    names = ["obj_fts", "obj_masks", "obj_locs", "anchor_locs", "anchor_orientation"]
+    return {n: torch.from_numpy(np.stack(c)).to(device) for n, c in zip(names, cols)}

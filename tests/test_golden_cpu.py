@@ -1,0 +1,157 @@
+"""CPU suite: (1) the oracle reproduces the index vectors stored in the goldens, (2) the
+host-side mirror (everything above `_ext`) reproduces the REFERENCE's outputs captured
+in tests/golden/ when the oracle stands in for the HIP ops.  fp32, tolerance 2e-5 rel-L2
+(same torch kernels, different op formulation)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pn2
+from tests.helpers import (VARIANTS, build_prompter, fill_state_dict, golden_inputs, load_golden,
+                           rel_l2)
+
+TOL = 2e-5
+
+
+@pytest.fixture()
+def oracle_ext(monkeypatch):
+    from msr3d_amd.pointnet2 import pointnet2_utils
+    monkeypatch.setattr(pointnet2_utils, "_ext", pn2.ext_module())
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+@pytest.mark.parametrize("seed", [0, 1])
+def test_oracle_matches_golden_indices(variant, seed):
+    g = load_golden(variant, seed)
+    fts = g["obj_fts"]
+    xyz = np.ascontiguousarray(fts.reshape(-1, fts.shape[2], 6)[..., :3])
+    i0 = pn2.furthest_point_sampling(xyz, 32)
+    assert np.array_equal(i0, g["sa0_fps_idx"])
+    new_xyz = np.take_along_axis(xyz, i0[..., None].astype(np.int64).repeat(3, -1), 1)
+    assert np.array_equal(pn2.ball_query(new_xyz, xyz, 0.2, 32), g["sa0_ball_idx"])
+    i1 = pn2.furthest_point_sampling(new_xyz, 16)
+    assert np.array_equal(i1, g["sa1_fps_idx"])
+    new_xyz2 = np.take_along_axis(new_xyz, i1[..., None].astype(np.int64).repeat(3, -1), 1)
+    assert np.array_equal(pn2.ball_query(new_xyz2, new_xyz, 0.4, 32), g["sa1_ball_idx"])
+    # padded objects (all ones): FPS all zero, ball rows 0..31 (SURVEY §8(c) KAT (i))
+    pad = ~g["obj_masks"].reshape(-1)
+    assert pad.any()
+    assert (i0[pad] == 0).all()
+    assert (g["sa0_ball_idx"][pad] == np.arange(32)).all()
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_state_dict_keys_match_reference(variant):
+    g = load_golden(variant, 0)
+    model = build_prompter(variant, 0)
+    assert sorted(model.state_dict().keys()) == list(g["state_keys"])
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+@pytest.mark.parametrize("seed", [0, 1])
+def test_mirror_reproduces_reference_cpu(oracle_ext, variant, seed):
+    g = load_golden(variant, seed)
+    model = build_prompter(variant, seed)
+    dd = golden_inputs(g)
+
+    with torch.no_grad():
+        enc, sem = model.obj_encoder(dd["obj_fts"])
+    assert rel_l2(enc.numpy(), g["enc_out"]) < TOL
+    assert rel_l2(sem[:, :2].numpy(), g["sem_cls_first"]) < TOL
+
+    layer_out, attn0 = [], []
+    for l in model.spatial_encoder:
+        l.register_forward_hook(lambda m, i, o: layer_out.append(o[0].detach().numpy()))
+    model.spatial_encoder[0].self_attn.register_forward_hook(
+        lambda m, i, o: attn0.append(o[1].detach().numpy()))
+
+    proj = torch.nn.Linear(256, 512)
+    proj.load_state_dict(fill_state_dict(proj.state_dict(), seed + 100))
+    out = model(dd)
+    tokens = out["obj_tokens"]
+    scene = proj(tokens)
+    gr = torch.from_numpy(np.random.default_rng(int(g["loss_grad_seed"])).standard_normal(
+        tuple(scene.shape)).astype(np.float32))
+    loss = (scene * gr).sum()
+    loss.backward()
+
+    assert np.array_equal(out["obj_masks"].numpy(), g["obj_masks_out"])
+    assert rel_l2(tokens.detach().numpy(), g["obj_tokens"]) < TOL
+    assert rel_l2(scene.detach().numpy(), g["scene_embeds"]) < TOL
+    for i, lo in enumerate(layer_out):
+        assert rel_l2(lo, g[f"layer{i}_out"]) < TOL, i
+    assert rel_l2(attn0[0], g["layer0_fused_attn"]) < TOL
+    assert abs(loss.item() - float(g["loss"])) < 1e-3 * max(1.0, abs(float(g["loss"])))
+
+    named = dict(model.named_parameters())
+    named.update({"llm_proj." + k: v for k, v in proj.named_parameters()})
+    got_names = sorted(n for n, p in named.items() if p.grad is not None)
+    assert got_names == sorted(g["grad_names"].tolist())     # same set of params receive grads
+    for n, norm, s, head in zip(g["grad_names"], g["grad_norms"], g["grad_sums"], g["grad_heads"]):
+        gflat = named[str(n)].grad.double().flatten()
+        if str(n).endswith("w_ks.bias"):
+            # mathematically ZERO gradient (softmax is invariant to a key bias): both sides hold
+            # rounding noise only; check that it is noise-sized and move on
+            assert gflat.norm().item() < 1e-3 and norm < 1e-3, n
+            continue
+        assert abs(gflat.norm().item() - norm) <= 1e-4 * norm + 2e-6, n
+        k = min(8, gflat.numel())
+        assert np.allclose(gflat[:k].numpy(), head[:k], rtol=1e-3, atol=1e-5 * norm + 2e-6), n
+
+
+def test_pairwise_locs_and_fourier_match_reference():
+    from msr3d_amd.model.ose3d_situation import generate_fourier_features
+    from msr3d_amd.modules.utils import calc_pairwise_locs
+    g = load_golden("transform", 0)
+    locs = torch.from_numpy(g["obj_locs"])
+    pw = calc_pairwise_locs(locs[:, :, :3], locs[:, :, 3:])
+    assert rel_l2(pw.numpy(), g["pairwise_locs"]) < 1e-6
+    # closed-form check of the fourier layout: [pos, sin(pi p f) (coord-major), cos(...)]
+    pos = torch.tensor([[[0.25, -0.5, 1.0]]])
+    f = generate_fourier_features(pos)
+    assert f.shape == (1, 1, 63)
+    freqs = np.linspace(1, 15, 10)
+    want = np.concatenate([[0.25, -0.5, 1.0],
+                           np.sin(np.pi * np.outer([0.25, -0.5, 1.0], freqs)).ravel(),
+                           np.cos(np.pi * np.outer([0.25, -0.5, 1.0], freqs)).ravel()])
+    assert np.allclose(f[0, 0].numpy(), want, atol=2e-5)
+    assert generate_fourier_features(torch.zeros(2, 1, 4)).shape == (2, 1, 84)
+
+
+def test_scatter_scene_embeds_matches_indexed_assignment():
+    from msr3d_amd.model.scene_embeds import SCENE_SP_TOKEN, scatter_scene_embeds
+    torch.manual_seed(0)
+    B, T, L, E = 3, 40, 6, 16
+    ids = torch.randint(0, 1000, (B, T))
+    for b in range(B):
+        pos = torch.randperm(T)[:L].sort()[0]
+        ids[b, pos] = SCENE_SP_TOKEN
+    emb = torch.randn(B, T, E).half()
+    am = torch.ones(B, T, dtype=torch.long)
+    scene = torch.randn(B, L, E)
+    smask = torch.rand(B, L) > 0.3
+    # the reference's two statements (msr3d.py:279-287)
+    want_e = emb.clone()
+    where = torch.where(ids == SCENE_SP_TOKEN)
+    want_e[where] = scene.to(emb.dtype).reshape(-1, E)
+    want_m = am.unsqueeze(-1).to(smask.dtype)
+    want_m[where] = smask.unsqueeze(-1).reshape(-1, 1)
+    got_e, got_m = scatter_scene_embeds(emb, am, ids, scene, smask)
+    assert torch.equal(got_e, want_e)
+    assert torch.equal(got_m, want_m.squeeze(-1))
+
+
+def test_registry_and_build_module_surface():
+    import msr3d_amd.model as model
+    import msr3d_amd.modules as modules
+    from msr3d_amd.config import default_prompter_cfg
+    assert "PcdObjEncoder" in modules.VISION_REGISTRY
+    assert "OSE3DSituation" in model.MODEL_REGISTRY
+    cfg = default_prompter_cfg()
+    enc = modules.build_module("vision", cfg.model.vision)
+    assert type(enc).__name__ == "PcdObjEncoder" and enc.freeze
+    assert all(not p.requires_grad for p in enc.parameters())
+    with pytest.raises(NotImplementedError):
+        modules.build_module("audio", cfg.model.vision)
+    # the in-place `mlp_spec[0] += 3` quirk is visible to the caller (pointnet2_modules.py:120-122)
+    assert cfg.model.vision.args.sa_mlps[0][0] == 3
