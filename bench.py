@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py -- MSQA hot-path training throughput on N MI355X of one node.
+
+A "step" is one pass of the hot path over one batch of synthetic scenes, resident in
+HBM before the timed region:
+    obj_fts -> PointNet++ set abstraction (frozen) -> situated spatial-attention encoder
+    -> llm_proj -> synthetic scalar loss on the projector output -> backward
+    -> (N>1) RCCL gradient all-reduce overlapped with backward -> global-norm clip -> AdamW
+(SURVEY.md §8(d) "primary metric").  The frozen LLM is NOT part of this path.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W   [torchrun for N>1]
+prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3       # f32-input MFMA dense peak
+O, P = 60, 1024                # objects per scene, points per object (configs/msr3d.yaml:60,153)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="scenes per GPU per step "
+                    "(global 128 on 8 GPUs = configs/msr3d_3_dataset.yaml DDP shape)")
+    ap.add_argument("--llm-hidden", type=int, default=4096, help="Vicuna-7B hidden size")
+    ap.add_argument("--situation-type", default="as_transform_for_objects")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def build(args, device):
+    import msr3d_amd.model  # noqa: F401
+    import msr3d_amd.modules  # noqa: F401
+    from msr3d_amd.config import AttrDict, default_prompter_cfg
+    from msr3d_amd.model import build_model
+    torch.manual_seed(1234)     # identical initial weights on every rank
+    cfg = AttrDict({"prompter": default_prompter_cfg(situation_type=args.situation_type),
+                    "llm_hidden_size": args.llm_hidden, "model": {"name": "MSR3DHotPath"}})
+    model = build_model(cfg).to(device)
+    model.train()               # dropout active, as in training; frozen backbone stays eval
+    return model
+
+
+class Trainer:
+    """The hot-path step.  Optimiser settings: optim/build.py + configs/msr3d.yaml:43-47
+    (AdamW lr 3e-5, betas (0.9, 0.999), wd 0.05), grad clip 5.0 (leo_trainer.py:192-193)."""
+
+    def __init__(self, model, device, batch_shape_E):
+        from msr3d_amd.dp import FlatGradAllReduce
+        self.model = model
+        params = [p for p in model.parameters() if p.requires_grad]
+        self.dp = FlatGradAllReduce(params)
+        self.opt = torch.optim.AdamW(params, lr=3e-5, betas=(0.9, 0.999), weight_decay=0.05)
+        g = torch.Generator(device="cpu").manual_seed(99)
+        self.loss_w = torch.randn(batch_shape_E, generator=g).to(device)
+        self.inv_n = 1.0 / self.loss_w.numel()
+
+    def step(self, batch):
+        self.dp.zero_grad()
+        out = self.model(dict(batch))
+        loss = (out["scene_embeds"] * self.loss_w).sum() * self.inv_n
+        loss.backward()
+        self.dp.finish()
+        self.dp.clip_grad_norm_(5.0)
+        self.opt.step()
+        return loss
+
+
+def cpu_baseline(args, seconds):
+    """The oracle (C, OpenMP over objects) + the torch-CPU mirror, same step, batch 1,
+    bounded to ~`seconds` of work.  kind = "port": the reference's own ops have no CPU path."""
+    from msr3d_amd.pointnet2 import pointnet2_utils
+    from msr3d_amd.synth import synth_batch
+    from oracle import pn2
+    saved = pointnet2_utils._ext
+    pointnet2_utils._ext = pn2.ext_module()
+    try:
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        pn2.set_threads(cores)
+        model = build(args, torch.device("cpu"))
+        tr = Trainer(model, torch.device("cpu"), (1, O, args.llm_hidden))
+        batches = [synth_batch(10_000 + i, 1, O=O, P=P) for i in range(2)]
+        tr.step(batches[0])                       # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            tr.step(batches[n % 2])
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= seconds or n >= 400:
+                break
+        return {"value": n / el, "unit": "samples/s", "cores": cores, "kind": "port",
+                "sample": f"{n} steps of batch 1 ({O} obj x {P} pts) in {el:.1f}s: C oracle "
+                          "(OpenMP) for the 9 ops + torch-CPU mirror, fwd+bwd+AdamW"}
+    finally:
+        pointnet2_utils._ext = saved
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from msr3d_amd import _lib
+    from msr3d_amd.synth import synth_batch
+    model = build(args, device)
+    B = args.batch
+    tr = Trainer(model, device, (B, O, args.llm_hidden))
+    # distinct resident batches per rank, cycled (weak scaling: per-GPU work fixed)
+    n_resident = 4
+    batches = [synth_batch(1000 * rank + i, B, O=O, P=P, device=device) for i in range(n_resident)]
+
+    for i in range(args.warmup):
+        tr.step(batches[i % n_resident])
+
+    dominant = "msr3d_furthest_point_sampling"
+    sink = {dominant: []}
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    _lib.set_timing_sink(sink)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        tr.step(batches[i % n_resident])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _lib.set_timing_sink(None)
+
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = B * world * args.steps / elapsed
+        # dominant kernel of this revision: SA1 furthest-point sampling (first of the two FPS
+        # launches per forward).  Algorithmic bytes per cloud: 12,288 read + 128 written.
+        recs = sink[dominant][0::2]
+        k_ms = sum(a.elapsed_time(b) for a, b in recs) / max(1, len(recs))
+        alg_bytes = B * O * (P * 12 + 32 * 4)
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        line = {
+            "metric": "MSQA train samples/sec (whole node), 60 obj x 1024 pts",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs/msr3d.yaml hot path (OSE3DSituation + llm_proj, "
+                                   "frozen PointNet++), synthetic ScanNet-like scenes",
+                       "objects": O, "points": P, "per_gpu_batch": B, "global_batch": B * world,
+                       "llm_hidden": args.llm_hidden, "situation_type": args.situation_type,
+                       "step": "fwd+bwd+allreduce+clip+AdamW, LLM excluded",
+                       "parallelism": f"dp{world}"},
+            "roofline": {"bound": "hbm", "kernel": "fps_kernel<16,1> (SA1)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": k_ms, "launches": len(recs)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,3 +72,35 @@ def check(status, what):
 
 def current_stream_ptr(device=None):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+# ---------------------------------------------------------------------------------------
+# Per-launch timing with HIP events on the launching stream (bench.py's roofline leg).
+# Disabled unless bench.py installs a sink: {entry_point_name: [(start_event, end_event)]}.
+# ---------------------------------------------------------------------------------------
+_timing_sink = None
+
+
+def set_timing_sink(sink):
+    global _timing_sink
+    _timing_sink = sink
+
+
+class kernel_timer:
+    __slots__ = ("rec", "e0")
+
+    def __init__(self, name):
+        self.rec = _timing_sink.get(name) if _timing_sink is not None else None
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()          # torch's current stream == the stream we launch on
+        return self
+
+    def __exit__(self, *exc):
+        if self.rec is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.rec.append((self.e0, e1))
+        return False

@@ -41,7 +41,8 @@ def _p(t):
 def _run(fn_name, device, *args):
     lib = _lib.load()
     with torch.cuda.device(device):
-        st = getattr(lib, fn_name)(*args, _lib.current_stream_ptr(device))
+        with _lib.kernel_timer(fn_name):
+            st = getattr(lib, fn_name)(*args, _lib.current_stream_ptr(device))
     _lib.check(st, fn_name)
 
 
