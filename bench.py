@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--situation-type", default="as_transform_for_objects")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=32, help="threads of the CPU baseline leg "
+                    "(small GEMMs stop scaling well before a 2-socket host's 256 HW threads)")
     return ap.parse_args()
 
 
@@ -90,7 +92,8 @@ def cpu_baseline(args, seconds):
     saved = pointnet2_utils._ext
     pointnet2_utils._ext = pn2.ext_module()
     try:
-        cores = os.cpu_count() or 1
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = max(1, min(avail, args.cpu_threads))
         torch.set_num_threads(cores)
         pn2.set_threads(cores)
         model = build(args, torch.device("cpu"))
@@ -135,8 +138,8 @@ def main():
     for i in range(args.warmup):
         tr.step(batches[i % n_resident])
 
-    dominant = "msr3d_furthest_point_sampling"
-    sink = {dominant: []}
+    timed = ["msr3d_sa_fps2", "msr3d_sa_level1", "msr3d_sa_level2", "msr3d_sa_level3"]
+    sink = {k: [] for k in timed}
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -160,12 +163,16 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = B * world * args.steps / elapsed
-        # dominant kernel of this revision: SA1 furthest-point sampling (first of the two FPS
-        # launches per forward).  Algorithmic bytes per cloud: 12,288 read + 128 written.
-        recs = sink[dominant][0::2]
-        k_ms = sum(a.elapsed_time(b) for a, b in recs) / max(1, len(recs))
-        alg_bytes = B * O * (P * 12 + 32 * 4)
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        # Per-launch durations from HIP events on the launching stream (msr3d_amd/_lib.py).
+        kern_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / len(v) if v else None)
+                   for k, v in sink.items()}
+        # Dominant kernel: sa2_kernel (level-2 set abstraction, 59 % of the path's FLOPs).
+        # Algorithmic work per object: 16 centres x 32 neighbours = 512
+        # positions x (131*128 + 128*128 + 128*256) MACs x 2 = 67.50 MFLOP; one launch = B*O objects.
+        k_ms = kern_ms["msr3d_sa_level2"] or 0.0
+        flop_per_obj = 512 * (131 * 128 + 128 * 128 + 128 * 256) * 2
+        alg_flop = B * O * flop_per_obj
+        achieved = alg_flop / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         line = {
             "metric": "MSQA train samples/sec (whole node), 60 obj x 1024 pts",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -177,10 +184,12 @@ def main():
                        "llm_hidden": args.llm_hidden, "situation_type": args.situation_type,
                        "step": "fwd+bwd+allreduce+clip+AdamW, LLM excluded",
                        "parallelism": f"dp{world}"},
-            "roofline": {"bound": "hbm", "kernel": "fps_kernel<16,1> (SA1)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel_ms": k_ms, "launches": len(recs)},
+            "roofline": {"bound": "mfma", "kernel": "sa2_kernel (msr3d_sa_level level 2)",
+                         "achieved": achieved, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_F32_PEAK_TF, "traffic": None,
+                         "kernel_ms": k_ms, "launches": len(sink["msr3d_sa_level2"]),
+                         "dtype": "f32-input MFMA (v_mfma_f32_16x16x4_f32)"},
+            "kernels_ms": kern_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)

@@ -93,6 +93,38 @@ int msr3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_o
                                  const int *idx, const float *weight, float *grad_points,
                                  msr3d_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * Fused set-abstraction levels (frozen / eval-mode backbone).  They replace, per level,
+ * the launch sequence of _PointnetSAModuleBase.forward
+ * (/root/reference/modules/third_party/pointnet2/pointnet2_modules.py:34-75) and
+ * QueryAndGroup.forward (pointnet2_utils.py:314-373): FPS -> gather -> ball_query ->
+ * group(xyz) -> recentre -> group(feat) -> cat -> 3 x [conv1x1, BN(eval), ReLU] -> max.
+ * ------------------------------------------------------------------------- */
+
+/* FPS of two consecutive levels in one launch: level 1 picks m1 of the n points of
+ * pts (b, n, point_stride) (xyz = the first 3 floats of each point row; stride 6 reads the
+ * dataset's xyz+rgb rows in place), level 2 picks m2 (<= m1 <= 64; 0 = skip) of those m1.
+ * idx1 (b,m1) / idx2 (b,m2) are optional (NULL); new_xyz1 (b,m1,3) / new_xyz2 (b,m2,3) are
+ * the gathered centroids.  Same bit-exact semantics as msr3d_furthest_point_sampling. */
+int msr3d_sa_fps2(int b, int n, int point_stride, int m1, int m2, const float *pts, int *idx1,
+                  float *new_xyz1, int *idx2, float *new_xyz2, msr3d_stream_t stream);
+
+/* One fused level.  `dims` = {C_in(+3), C1, C2, C3} must be one of the shipped
+ * configurations (configs/msr3d.yaml:198-201) else MSR3D_EINVAL:
+ *   level 1: dims {6,64,64,128};    pts (b,n,6) [xyz,rgb], feat = NULL, new_xyz (b,m,3),
+ *            nsample 32; out (b,m,128) point-major
+ *   level 2: dims {131,128,128,256}; pts = xyz (b,n,3) n<=64, feat (b,n,128) point-major,
+ *            new_xyz (b,m,3), nsample 32; out (b,m,256)
+ *   level 3: dims {259,256,512,768}; group-all over n = 16 points: pts = xyz (b,16,3),
+ *            feat (b,16,256); new_xyz unused; out (b,768)
+ * paramsL: layer L packed by the host as [N][KP] weights (K order: level 1 [dxyz,rgb],
+ * levels 2/3 [feat, (d)xyz]; zero-padded to KP = 16 / 144 / 272 for the first layer),
+ * then scale[N], shift[N] (the eval-mode BN affine).  dbg_ball_idx (b,m,32) optional. */
+int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pts,
+                   const float *feat, const float *new_xyz, const int *dims,
+                   const float *params1, const float *params2, const float *params3, float *out,
+                   int *dbg_ball_idx, msr3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,9 @@ _SIGNATURES = {
     "msr3d_three_nn": [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_three_interpolate": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_three_interpolate_grad": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_sa_fps2": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_sa_level": [_c_int, _c_int, _c_int, _c_int, _c_float, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                       _ptr, _ptr, _ptr, _ptr],
 }
 
 _lib = None

@@ -23,6 +23,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-a
 # compiler must not contract anything further there.
 SOURCES = [
     ("pn2_ops.hip", ["-ffp-contract=off"]),
+    ("sa_fused.hip", ["-ffp-contract=off"]),
 ]
 
 

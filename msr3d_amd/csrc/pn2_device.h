@@ -1,0 +1,256 @@
+// pn2_device.h -- device helpers shared by pn2_ops.hip and sa_fused.hip: the pinned
+// distance chain, the wave64 DPP max, the reference's block-size rule and the FPS kernel.
+// Both translation units are compiled with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+namespace msr3d {
+
+constexpr int kWave = 64;
+
+// (a*a + b*b) + c*c as an LLVM-based device compiler contracts it (see oracle/pn2_oracle.c)
+__device__ __forceinline__ float sq3(float a, float b, float c) {
+  return __builtin_fmaf(c, c, __builtin_fmaf(a, a, b * b));
+}
+
+// ---- wave64 integer max, all lanes -> uniform ---------------------------------
+template <int CTRL>
+__device__ __forceinline__ int dpp_max_i32(int v) {
+  const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+  return o > v ? o : v;
+}
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+  v = dpp_max_i32<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_max_i32<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_max_i32<0x141>(v);  // row_half_mirror
+  v = dpp_max_i32<0x140>(v);  // row_mirror  -> every lane holds its 16-lane row max
+  const int r0 = __builtin_amdgcn_readlane(v, 0);
+  const int r1 = __builtin_amdgcn_readlane(v, 16);
+  const int r2 = __builtin_amdgcn_readlane(v, 32);
+  const int r3 = __builtin_amdgcn_readlane(v, 48);
+  const int a = r0 > r1 ? r0 : r1;
+  const int b = r2 > r3 ? r2 : r3;
+  return a > b ? a : b;
+}
+
+// include/cuda_utils.h:13-19 of the reference (its block size enters the FPS tie-break)
+inline int ref_opt_n_threads(int work_size) {
+  const int pow_2 = (int)(std::log((double)work_size) / std::log(2.0));
+  int v = 1 << pow_2;
+  if (v > 512) v = 512;
+  if (v < 1) v = 1;
+  return v;
+}
+
+struct FpsShape {   // host-computed description of the reference's launch for n points
+  int n, bs, log2bs, q;
+  long long slots;
+};
+
+inline FpsShape fps_shape(int n) {
+  FpsShape s;
+  s.n = n;
+  s.bs = ref_opt_n_threads(n);
+  s.log2bs = 0;
+  while ((1 << s.log2bs) < s.bs) ++s.log2bs;
+  s.q = (n + s.bs - 1) / s.bs;            // points per reference thread (upper bound)
+  s.slots = (long long)s.bs * s.q;        // rank slots incl. holes (< 2n)
+  return s;
+}
+
+// =================================================================================
+// Furthest point sampling.
+//
+// The reference (sampling_gpu.cu:69-173) runs one block of bs = opt_n_threads(n)
+// threads per cloud: thread t scans k = t, t+bs, ... with a strict '>' (lowest k
+// wins inside a thread), then a shared-memory halving tree keeps the LOWER slot on
+// ties.  Two tied threads meet at the stride equal to their lowest differing tid
+// bit and the one with that bit clear survives, so among equal maxima the winner
+// minimises (bitrev(k mod bs), k / bs).
+//
+// Here each cloud is owned by NW waves and every lane keeps PPT points in
+// registers (coordinates + running min distance), laid out in exactly that rank
+// order: slot p = tid*PPT + i holds the point of rank p.  One iteration is then
+//   per-lane strict-'>' scan (first max in rank order inside the lane)
+//   -> DPP wave max of the f32 bit pattern (values are >= +0 or the -1 sentinel)
+//   -> ballot of the lanes that hold the max, lowest set lane = lowest rank
+//   -> v_readlane of that lane's point index, LDS broadcast read of its coordinates.
+// No LDS traffic or barrier inside an iteration when NW == 1.
+//
+// `src` holds the cloud with `ps` floats per point (3 = packed xyz; 6 = the
+// dataset's xyz+rgb rows read in place).  Winners are appended to out_idx /
+// out_xyz (global, optional) and to `keep` (LDS, optional, packed xyz).
+// =================================================================================
+template <int PPT, int NW>
+__device__ __forceinline__ void fps_level(const float *src, int ps, int n, int m, int bs,
+                                          int log2bs, int q, int *red_bits, int *red_k,
+                                          int *__restrict__ out_idx, float *__restrict__ out_xyz,
+                                          float *keep) {
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid >> 6;
+
+  float px[PPT], py[PPT], pz[PPT], tmp[PPT];
+  int kk[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int p = tid * PPT + i;       // rank slot
+    const int tr = p / q;              // bit-reversed reference thread id
+    const int j = p - tr * q;          // that thread's j-th point
+    const int t = log2bs ? (int)(__brev((unsigned)tr) >> (32 - log2bs)) : 0;
+    const int k = t + j * bs;
+    const bool valid = (tr < bs) && (k < n);
+    float x = 0.f, y = 0.f, z = 0.f;
+    bool live = false;
+    if (valid) {
+      x = src[k * ps + 0];
+      y = src[k * ps + 1];
+      z = src[k * ps + 2];
+      const float mag = sq3(x, y, z);
+      live = !((double)mag <= 1e-3);   // sampling_gpu.cu:100-101 (double compare)
+    }
+    px[i] = x; py[i] = y; pz[i] = z;
+    kk[i] = valid ? k : 0;
+    // skipped / padding slots: min(d, -inf) = -inf never beats the -1 sentinel
+    tmp[i] = live ? 1e10f : -INFINITY;
+  }
+
+  int old = 0;
+  float ox = src[0], oy = src[1], oz = src[2];
+  if (tid == 0) {
+    if (out_idx) out_idx[0] = 0;
+    if (out_xyz) { out_xyz[0] = ox; out_xyz[1] = oy; out_xyz[2] = oz; }
+    if (keep) { keep[0] = ox; keep[1] = oy; keep[2] = oz; }
+  }
+
+  int par = 0;
+  for (int jj = 1; jj < m; ++jj) {
+    float best = -1.0f;
+    int bk = 0;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const float d = sq3(px[i] - ox, py[i] - oy, pz[i] - oz);
+      const float d2 = fminf(d, tmp[i]);
+      tmp[i] = d2;
+      const bool gt = d2 > best;
+      bk = gt ? kk[i] : bk;
+      best = gt ? d2 : best;
+    }
+    const int bits = __float_as_int(best);   // >= +0.0 or -1.0f: int order == float order
+    int vmax = wave_max_i32(bits);
+    const unsigned long long hit = __ballot(bits == vmax);
+    const int first = __ffsll((long long)hit) - 1;
+    int kw = __builtin_amdgcn_readlane(bk, first);
+    if (NW > 1) {
+      if (lane == 0) {
+        red_bits[par * NW + wave] = vmax;
+        red_k[par * NW + wave] = kw;
+      }
+      __syncthreads();
+      vmax = red_bits[par * NW];
+      kw = red_k[par * NW];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) {
+        const int vb = red_bits[par * NW + w];
+        const int vk = red_k[par * NW + w];
+        const bool gt = vb > vmax;   // strict: the lower wave (= lower rank) wins ties
+        kw = gt ? vk : kw;
+        vmax = gt ? vb : vmax;
+      }
+      par ^= 1;
+    }
+    old = vmax < 0 ? 0 : kw;   // every candidate skipped: all threads report (-1, 0)
+    ox = src[old * ps + 0];
+    oy = src[old * ps + 1];
+    oz = src[old * ps + 2];
+    if (tid == 0) {
+      if (out_idx) out_idx[jj] = old;
+      if (out_xyz) { out_xyz[jj * 3 + 0] = ox; out_xyz[jj * 3 + 1] = oy; out_xyz[jj * 3 + 2] = oz; }
+      if (keep) { keep[jj * 3 + 0] = ox; keep[jj * 3 + 1] = oy; keep[jj * 3 + 2] = oz; }
+    }
+  }
+}
+
+// One cloud per block.  pts: (b, n, ps) f32.  Optional second level (m2 > 0): FPS over the
+// m winners of the first level (what the next set-abstraction level does), same launch,
+// wave 0 only; requires m <= 64.
+template <int PPT, int NW, bool STAGE>
+__global__ __launch_bounds__(kWave * NW) void fps_kernel(
+    int n, int ps, int m, int bs, int log2bs, int q, const float *__restrict__ pts,
+    int *__restrict__ idxs, float *__restrict__ new_xyz,
+    int m2, int bs2, int log2bs2, int *__restrict__ idxs2, float *__restrict__ new_xyz2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int *red_bits = reinterpret_cast<int *>(smem);          // [2][NW]
+  int *red_k = red_bits + 2 * NW;                         // [2][NW]
+  float *keep = reinterpret_cast<float *>(red_k + 2 * NW);  // [64*3] winners (level-2 input)
+  float *sx = keep + 64 * 3;                              // [n*ps] when STAGE
+
+  const int obj = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float *P = pts + (size_t)obj * n * ps;
+  if (STAGE) {
+    for (int i = tid; i < n * ps; i += kWave * NW) sx[i] = P[i];
+    __syncthreads();
+  }
+  const float *src = STAGE ? sx : P;
+  fps_level<PPT, NW>(src, ps, n, m, bs, log2bs, q, red_bits, red_k,
+                     idxs ? idxs + (size_t)obj * m : nullptr,
+                     new_xyz ? new_xyz + (size_t)obj * m * 3 : nullptr, m2 > 0 ? keep : nullptr);
+  if (m2 > 0) {
+    __syncthreads();                 // `keep` written by thread 0
+    if (tid < kWave) {
+      fps_level<1, 1>(keep, 3, m, m2, bs2, log2bs2, 1, red_bits, red_k,
+                      idxs2 ? idxs2 + (size_t)obj * m2 : nullptr,
+                      new_xyz2 ? new_xyz2 + (size_t)obj * m2 * 3 : nullptr, nullptr);
+    }
+  }
+}
+
+constexpr size_t kFpsLdsFixed(int NW) { return sizeof(int) * 4 * NW + sizeof(float) * 64 * 3; }
+
+template <int PPT, int NW>
+inline hipError_t launch_fps(int b, const FpsShape &s, int ps, int m, const float *pts, int *idx,
+                             float *new_xyz, int m2, int *idx2, float *new_xyz2,
+                             hipStream_t st) {
+  const size_t cloud = (size_t)s.n * ps * sizeof(float);
+  const bool stage = cloud <= 64 * 1024;
+  int bs2 = 1, log2bs2 = 0;
+  if (m2 > 0) {
+    const FpsShape s2 = fps_shape(m);
+    bs2 = s2.bs;
+    log2bs2 = s2.log2bs;
+  }
+  if (stage) {
+    fps_kernel<PPT, NW, true><<<b, kWave * NW, kFpsLdsFixed(NW) + cloud, st>>>(
+        s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, bs2, log2bs2, idx2, new_xyz2);
+  } else {
+    fps_kernel<PPT, NW, false><<<b, kWave * NW, kFpsLdsFixed(NW), st>>>(
+        s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, bs2, log2bs2, idx2, new_xyz2);
+  }
+  return hipGetLastError();
+}
+
+// Dispatch on the number of rank slots.  Returns hipErrorInvalidValue above 32768 slots.
+inline hipError_t dispatch_fps(int b, int n, int ps, int m, const float *pts, int *idx,
+                               float *new_xyz, int m2, int *idx2, float *new_xyz2,
+                               hipStream_t st) {
+  const FpsShape s = fps_shape(n);
+  if (m2 > 0 && (m > 64 || m2 > m)) return hipErrorInvalidValue;
+#define MSR3D_FPS(PPT, NW) \
+  return launch_fps<PPT, NW>(b, s, ps, m, pts, idx, new_xyz, m2, idx2, new_xyz2, st)
+  if (s.slots <= 64) MSR3D_FPS(1, 1);
+  if (s.slots <= 256) MSR3D_FPS(4, 1);
+  if (s.slots <= 1024) MSR3D_FPS(16, 1);
+  if (s.slots <= 2048) MSR3D_FPS(16, 2);
+  if (s.slots <= 4096) MSR3D_FPS(16, 4);
+  if (s.slots <= 8192) MSR3D_FPS(16, 8);
+  if (s.slots <= 16384) MSR3D_FPS(16, 16);
+  if (s.slots <= 32768) MSR3D_FPS(32, 16);
+#undef MSR3D_FPS
+  return hipErrorInvalidValue;   // > 32768 rank slots per cloud: not a configuration of this path
+}
+
+}  // namespace msr3d

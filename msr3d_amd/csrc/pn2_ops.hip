@@ -14,180 +14,11 @@
 #include <cmath>
 
 #include "../../include/msr3d_hip.h"
+#include "pn2_device.h"
 
 namespace {
 
-constexpr int kWave = 64;
-
-__device__ __forceinline__ float sq3(float a, float b, float c) {
-  return __builtin_fmaf(c, c, __builtin_fmaf(a, a, b * b));
-}
-
-// ---- wave64 integer max, all lanes -> uniform ---------------------------------
-template <int CTRL>
-__device__ __forceinline__ int dpp_max_i32(int v) {
-  const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
-  return o > v ? o : v;
-}
-
-__device__ __forceinline__ int wave_max_i32(int v) {
-  v = dpp_max_i32<0xB1>(v);   // quad_perm [1,0,3,2]
-  v = dpp_max_i32<0x4E>(v);   // quad_perm [2,3,0,1]
-  v = dpp_max_i32<0x141>(v);  // row_half_mirror
-  v = dpp_max_i32<0x140>(v);  // row_mirror  -> every lane holds its 16-lane row max
-  const int r0 = __builtin_amdgcn_readlane(v, 0);
-  const int r1 = __builtin_amdgcn_readlane(v, 16);
-  const int r2 = __builtin_amdgcn_readlane(v, 32);
-  const int r3 = __builtin_amdgcn_readlane(v, 48);
-  const int a = r0 > r1 ? r0 : r1;
-  const int b = r2 > r3 ? r2 : r3;
-  return a > b ? a : b;
-}
-
-// host + device: include/cuda_utils.h:13-19 (the reference's block size enters the FPS tie-break)
-inline int ref_opt_n_threads(int work_size) {
-  const int pow_2 = (int)(std::log((double)work_size) / std::log(2.0));
-  int v = 1 << pow_2;
-  if (v > 512) v = 512;
-  if (v < 1) v = 1;
-  return v;
-}
-
-// =================================================================================
-// Furthest point sampling.
-//
-// The reference (sampling_gpu.cu:69-173) runs one block of bs = opt_n_threads(n)
-// threads per cloud: thread t scans k = t, t+bs, ... with a strict '>' (lowest k
-// wins inside a thread), then a shared-memory halving tree keeps the LOWER slot on
-// ties.  Two tied threads meet at the stride equal to their lowest differing tid
-// bit and the one with that bit clear survives, so among equal maxima the winner
-// minimises (bitrev(k mod bs), k / bs).
-//
-// Here each cloud is owned by NW waves and every lane keeps PPT points in
-// registers (coordinates + running min distance), laid out in exactly that rank
-// order: slot p = tid*PPT + i holds the point of rank p.  One iteration is then
-//   per-lane strict-'>' scan (first max in rank order inside the lane)
-//   -> DPP wave max of the f32 bit pattern (values are >= +0 or the -1 sentinel)
-//   -> ballot of the lanes that hold the max, lowest set lane = lowest rank
-//   -> v_readlane of that lane's point index, LDS broadcast read of its coordinates.
-// No LDS traffic or barrier inside an iteration when NW == 1.
-// =================================================================================
-template <int PPT, int NW, bool STAGE>
-__global__ __launch_bounds__(kWave * NW) void fps_kernel(int n, int m, int bs, int log2bs, int q,
-                                                         const float *__restrict__ xyz,
-                                                         int *__restrict__ idxs,
-                                                         float *__restrict__ new_xyz) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int *red_bits = reinterpret_cast<int *>(smem);          // [2][NW]
-  int *red_k = red_bits + 2 * NW;                         // [2][NW]
-  float *sx = reinterpret_cast<float *>(red_k + 2 * NW);  // [n*3] when STAGE
-
-  const int obj = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int lane = tid & (kWave - 1);
-  const int wave = tid >> 6;
-  const float *P = xyz + (size_t)obj * n * 3;
-  int *out = idxs + (size_t)obj * m;
-  float *oxyz = new_xyz ? new_xyz + (size_t)obj * m * 3 : nullptr;
-
-  if (STAGE) {
-    for (int i = tid; i < n * 3; i += kWave * NW) sx[i] = P[i];
-    __syncthreads();
-  }
-  const float *src = STAGE ? sx : P;
-
-  float px[PPT], py[PPT], pz[PPT], tmp[PPT];
-  int kk[PPT];
-#pragma unroll
-  for (int i = 0; i < PPT; ++i) {
-    const int p = tid * PPT + i;       // rank slot
-    const int tr = p / q;              // bit-reversed reference thread id
-    const int j = p - tr * q;          // that thread's j-th point
-    const int t = log2bs ? (int)(__brev((unsigned)tr) >> (32 - log2bs)) : 0;
-    const int k = t + j * bs;
-    const bool valid = (tr < bs) && (k < n);
-    float x = 0.f, y = 0.f, z = 0.f;
-    bool live = false;
-    if (valid) {
-      x = src[k * 3 + 0];
-      y = src[k * 3 + 1];
-      z = src[k * 3 + 2];
-      const float mag = sq3(x, y, z);
-      live = !((double)mag <= 1e-3);   // sampling_gpu.cu:100-101 (double compare)
-    }
-    px[i] = x; py[i] = y; pz[i] = z;
-    kk[i] = valid ? k : 0;
-    // skipped / padding slots: min(d, -inf) = -inf never beats the -1 sentinel
-    tmp[i] = live ? 1e10f : -INFINITY;
-  }
-
-  int old = 0;
-  float ox = src[0], oy = src[1], oz = src[2];
-  if (tid == 0) {
-    out[0] = 0;
-    if (oxyz) { oxyz[0] = ox; oxyz[1] = oy; oxyz[2] = oz; }
-  }
-
-  int par = 0;
-  for (int jj = 1; jj < m; ++jj) {
-    float best = -1.0f;
-    int bk = 0;
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const float d = sq3(px[i] - ox, py[i] - oy, pz[i] - oz);
-      const float d2 = fminf(d, tmp[i]);
-      tmp[i] = d2;
-      const bool gt = d2 > best;
-      bk = gt ? kk[i] : bk;
-      best = gt ? d2 : best;
-    }
-    const int bits = __float_as_int(best);   // >= +0.0 or -1.0f: int order == float order
-    int vmax = wave_max_i32(bits);
-    const unsigned long long hit = __ballot(bits == vmax);
-    const int first = __ffsll((long long)hit) - 1;
-    int kw = __builtin_amdgcn_readlane(bk, first);
-    if (NW > 1) {
-      if (lane == 0) {
-        red_bits[par * NW + wave] = vmax;
-        red_k[par * NW + wave] = kw;
-      }
-      __syncthreads();
-      vmax = red_bits[par * NW];
-      kw = red_k[par * NW];
-#pragma unroll
-      for (int w = 1; w < NW; ++w) {
-        const int vb = red_bits[par * NW + w];
-        const int vk = red_k[par * NW + w];
-        const bool gt = vb > vmax;   // strict: the lower wave (= lower rank) wins ties
-        kw = gt ? vk : kw;
-        vmax = gt ? vb : vmax;
-      }
-      par ^= 1;
-    }
-    old = vmax < 0 ? 0 : kw;   // every candidate skipped: all threads report (-1, 0)
-    ox = src[old * 3 + 0];
-    oy = src[old * 3 + 1];
-    oz = src[old * 3 + 2];
-    if (tid == 0) {
-      out[jj] = old;
-      if (oxyz) { oxyz[jj * 3 + 0] = ox; oxyz[jj * 3 + 1] = oy; oxyz[jj * 3 + 2] = oz; }
-    }
-  }
-}
-
-template <int PPT, int NW>
-hipError_t launch_fps(int b, int n, int m, int bs, int log2bs, int q, const float *xyz, int *idx,
-                      float *new_xyz, hipStream_t s) {
-  const bool stage = (size_t)n * 12 <= 64 * 1024;
-  const size_t red = sizeof(int) * 4 * NW;
-  if (stage) {
-    fps_kernel<PPT, NW, true><<<b, kWave * NW, red + (size_t)n * 12, s>>>(n, m, bs, log2bs, q, xyz,
-                                                                         idx, new_xyz);
-  } else {
-    fps_kernel<PPT, NW, false><<<b, kWave * NW, red, s>>>(n, m, bs, log2bs, q, xyz, idx, new_xyz);
-  }
-  return hipGetLastError();
-}
+using namespace msr3d;
 
 // =================================================================================
 // Ball query (ball_query_gpu.cu:9-44).  The reference gives each centre ONE thread
@@ -422,23 +253,9 @@ int msr3d_furthest_point_sampling(int b, int n, int m, const float *xyz, int *id
                                   float *new_xyz, msr3d_stream_t stream) {
   if (b < 0 || n <= 0 || m < 0 || !xyz || (!idx && b * m > 0)) return MSR3D_EINVAL;
   if (b == 0 || m == 0) return 0;
-  hipStream_t s = (hipStream_t)stream;
-  const int bs = ref_opt_n_threads(n);
-  int log2bs = 0;
-  while ((1 << log2bs) < bs) ++log2bs;
-  const int q = (n + bs - 1) / bs;          // points per reference thread (upper bound)
-  const long long slots = (long long)bs * q;  // rank slots incl. holes (< 2n)
-  hipError_t e;
-  if (slots <= 64) e = launch_fps<1, 1>(b, n, m, bs, log2bs, q, xyz, idx, new_xyz, s);
-  else if (slots <= 256) e = launch_fps<4, 1>(b, n, m, bs, log2bs, q, xyz, idx, new_xyz, s);
-  else if (slots <= 1024) e = launch_fps<16, 1>(b, n, m, bs, log2bs, q, xyz, idx, new_xyz, s);
-  else if (slots <= 2048) e = launch_fps<16, 2>(b, n, m, bs, log2bs, q, xyz, idx, new_xyz, s);
-  else if (slots <= 4096) e = launch_fps<16, 4>(b, n, m, bs, log2bs, q, xyz, idx, new_xyz, s);
-  else if (slots <= 8192) e = launch_fps<16, 8>(b, n, m, bs, log2bs, q, xyz, idx, new_xyz, s);
-  else if (slots <= 16384) e = launch_fps<16, 16>(b, n, m, bs, log2bs, q, xyz, idx, new_xyz, s);
-  else if (slots <= 32768) e = launch_fps<32, 16>(b, n, m, bs, log2bs, q, xyz, idx, new_xyz, s);
-  else return MSR3D_EINVAL;  // > 32768 rank slots per cloud: not a configuration of this path
-  return (int)e;
+  const hipError_t e = dispatch_fps(b, n, 3, m, xyz, idx, new_xyz, 0, nullptr, nullptr,
+                                     (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MSR3D_EINVAL : (int)e;
 }
 
 int msr3d_gather_points(int b, int c, int n, int m, const float *points, const int *idx,

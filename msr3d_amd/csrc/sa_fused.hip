@@ -1,0 +1,486 @@
+// sa_fused.hip -- fused PointNet++ set-abstraction levels for gfx950 (MI355X).
+//
+// What the reference does per level with ~25 launches
+// (/root/reference/modules/third_party/pointnet2/pointnet2_modules.py:34-75:
+//  FPS -> gather -> ball_query -> group(xyz) -> subtract -> group(feat) -> cat ->
+//  3 x [conv1x1, BN, ReLU] -> max_pool -> squeeze), each intermediate a round trip
+// through HBM, is here ONE launch per level plus one index launch:
+//
+//   msr3d_sa_fps2   FPS of level 1 and of level 2 (on level 1's winners), one wave per cloud
+//   msr3d_sa_level  ball query (wave ballot) -> neighbourhood gather + recentre straight
+//                   into LDS -> three GEMM layers on f32-input MFMA (16x16x4) with the
+//                   BN(eval) affine + ReLU applied on the accumulators, activations kept
+//                   in LDS -> max over the neighbourhood taken on the accumulators ->
+//                   only the pooled (centres x C_out) tile is written.
+//
+// Arithmetic is fp32 end to end (the reference runs the backbone in fp32): products and
+// sums are exact-f32 fma chains on the matrix cores, the k-order of a dot product differs
+// from MIOpen's, hence a tolerance (not bit-exactness) on the features; the INDEX part
+// (FPS, ball query) is bit-exact and shares its code with pn2_ops.hip.
+//
+// Layout choices: features between levels are POINT-major (b, points, C) so a
+// neighbour's feature row is one contiguous 512 B / 1 KB read; weights are pre-packed
+// by the host as [N][KP] rows (K permuted "features first, xyz last", zero-padded to a
+// multiple of 16) followed by scale[N], shift[N].
+#include <hip/hip_runtime.h>
+
+#include "../../include/msr3d_hip.h"
+#include "pn2_device.h"
+
+namespace {
+
+using namespace msr3d;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kLdsPad = 8;   // row stride = K + 8 floats (K % 16 == 0): stride/4 == 2 (mod 4)
+                             // makes every 16-lane group of a ds_read_b128 fragment read hit
+                             // 16 distinct 16-B slots of the 256-B bank row
+
+struct Layer {
+  const float *w;       // [N][KP]
+  const float *scale;   // [N]
+  const float *shift;   // [N]
+};
+
+__host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// ---------------------------------------------------------------------------------
+// acc[RM][RN] (16x16 tiles) += X[rows][k] * W[cols][k]^T over k in [0, KP).
+// X: LDS, row-major, leading dim ldx.  W: global (L2-resident), row-major [N][KP].
+// K is consumed in slabs of 16: lane (i = lane&15, g = lane>>4) loads k = 4g..4g+3 of
+// row i with ONE 16-byte read for A (LDS) and for B (global); MFMA step s of the slab
+// multiplies the k = 4g+s elements, i.e. a fixed permutation of k inside the slab --
+// legal because a dot product does not care, and it turns 4+4 scalar fragment loads into
+// 1+1 vector loads.
+// ---------------------------------------------------------------------------------
+template <int RM, int RN, int KP>
+__device__ __forceinline__ void gemm_lds_global(const float *xs, int ldx,
+                                                const float *__restrict__ wg,
+                                                f32x4 (&acc)[RM][RN], int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const float *xp = xs + i * ldx + 4 * g;
+  const float *wp = wg + (size_t)i * KP + 4 * g;
+  float4 bcur[RN];
+#pragma unroll
+  for (int rn = 0; rn < RN; ++rn) bcur[rn] = *reinterpret_cast<const float4 *>(wp + (size_t)rn * 16 * KP);
+#pragma unroll 2
+  for (int k0 = 0; k0 < KP; k0 += 16) {
+    float4 bnext[RN];
+    const int kn = (k0 + 16 < KP) ? k0 + 16 : k0;   // last slab: harmless re-read
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn)
+      bnext[rn] = *reinterpret_cast<const float4 *>(wp + (size_t)rn * 16 * KP + kn);
+    float4 a[RM];
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+      a[rm] = *reinterpret_cast<const float4 *>(xp + rm * 16 * ldx + k0);
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) {
+        acc[rm][rn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rm].x, bcur[rn].x, acc[rm][rn], 0, 0, 0);
+        acc[rm][rn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rm].y, bcur[rn].y, acc[rm][rn], 0, 0, 0);
+        acc[rm][rn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rm].z, bcur[rn].z, acc[rm][rn], 0, 0, 0);
+        acc[rm][rn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rm].w, bcur[rn].w, acc[rm][rn], 0, 0, 0);
+      }
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn) bcur[rn] = bnext[rn];
+  }
+}
+
+template <int RM, int RN>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[RM][RN]) {
+#pragma unroll
+  for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn) acc[rm][rn] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// y = relu(acc * scale[col] + shift[col]) -> LDS tile.  C/D map of the 16x16 MFMA:
+// col = lane & 15, row = (lane >> 4) * 4 + reg.
+template <int RM, int RN>
+__device__ __forceinline__ void store_bn_relu_lds(const f32x4 (&acc)[RM][RN],
+                                                  const float *__restrict__ scale,
+                                                  const float *__restrict__ shift, float *ys,
+                                                  int ldy, int lane) {
+  const int c = lane & 15, r4 = (lane >> 4) * 4;
+#pragma unroll
+  for (int rn = 0; rn < RN; ++rn) {
+    const float sc = scale[rn * 16 + c], sh = shift[rn * 16 + c];
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        ys[(rm * 16 + r4 + r) * ldy + rn * 16 + c] =
+            fmaxf(__builtin_fmaf(acc[rm][rn][r], sc, sh), 0.0f);
+  }
+}
+
+// max over groups of GT*16 consecutive rows of relu(acc*scale+shift) -> global (group, col).
+// Starting the running max at 0 IS the ReLU (max and ReLU commute).
+template <int RM, int RN, int GT>
+__device__ __forceinline__ void store_bn_relu_groupmax(const f32x4 (&acc)[RM][RN],
+                                                       const float *__restrict__ scale,
+                                                       const float *__restrict__ shift,
+                                                       float *__restrict__ out, int ldo,
+                                                       int groups_valid, int lane) {
+  const int c = lane & 15;
+#pragma unroll
+  for (int rn = 0; rn < RN; ++rn) {
+    const float sc = scale[rn * 16 + c], sh = shift[rn * 16 + c];
+#pragma unroll
+    for (int gq = 0; gq < RM / GT; ++gq) {
+      float m = 0.0f;
+#pragma unroll
+      for (int t = 0; t < GT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          m = fmaxf(m, __builtin_fmaf(acc[gq * GT + t][rn][r], sc, sh));
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      if (lane < 16 && gq < groups_valid) out[(size_t)gq * ldo + rn * 16 + c] = m;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Three chained layers on a TM-row tile held in LDS.  bufA holds the input tile
+// [TM][K0P+8] and is re-used for layer 2's output [TM][N2+8]; bufB holds layer 1's
+// output [TM][N1+8].  4 waves as WM x WN; every wave owns TM/WM rows x N/WN columns.
+// ---------------------------------------------------------------------------------
+template <int TM, int K0P, int N1, int N2, int N3, int G, int WM, int WN>
+struct Chain {
+  static constexpr int RM = TM / (16 * WM);
+  static constexpr int LDA = cmax(K0P, N2) + kLdsPad;
+  static constexpr int LDB = N1 + kLdsPad;
+  static constexpr int GT = G / 16;
+  static_assert(WM * WN == 4 && RM * 16 * WM == TM, "tile / wave grid mismatch");
+  static_assert(N1 % (16 * WN) == 0 && N2 % (16 * WN) == 0 && N3 % (16 * WN) == 0, "N split");
+  static_assert(K0P % 16 == 0 && N1 % 16 == 0 && N2 % 16 == 0, "K must be a multiple of 16");
+  static_assert(RM % GT == 0, "a pooling group must live inside one wave");
+  static constexpr int LDS_FLOATS = TM * LDA + TM * LDB;
+
+  // out: first pooled row of this block; `groups_valid`: pooled rows of this WAVE that exist
+  __device__ static void run(float *bufA, float *bufB, const Layer &l1, const Layer &l2,
+                             const Layer &l3, float *__restrict__ out, int groups_valid_block) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int row0 = wm * RM * 16;
+    {
+      constexpr int RN = N1 / (16 * WN);
+      const int col0 = wn * RN * 16;
+      f32x4 acc[RM][RN];
+      zero_acc(acc);
+      gemm_lds_global<RM, RN, K0P>(bufA + row0 * LDA, LDA, l1.w + (size_t)col0 * K0P, acc, lane);
+      store_bn_relu_lds<RM, RN>(acc, l1.scale + col0, l1.shift + col0, bufB + row0 * LDB + col0,
+                                LDB, lane);
+    }
+    __syncthreads();
+    {
+      constexpr int RN = N2 / (16 * WN);
+      const int col0 = wn * RN * 16;
+      f32x4 acc[RM][RN];
+      zero_acc(acc);
+      gemm_lds_global<RM, RN, N1>(bufB + row0 * LDB, LDB, l2.w + (size_t)col0 * N1, acc, lane);
+      store_bn_relu_lds<RM, RN>(acc, l2.scale + col0, l2.shift + col0, bufA + row0 * LDA + col0,
+                                LDA, lane);
+    }
+    __syncthreads();
+    {
+      constexpr int RN = N3 / (16 * WN);
+      const int col0 = wn * RN * 16;
+      f32x4 acc[RM][RN];
+      zero_acc(acc);
+      gemm_lds_global<RM, RN, N2>(bufA + row0 * LDA, LDA, l3.w + (size_t)col0 * N2, acc, lane);
+      const int g0 = wm * (RM / GT);            // first pooled row owned by this wave
+      int gv = groups_valid_block - g0;
+      store_bn_relu_groupmax<RM, RN, GT>(acc, l3.scale + col0, l3.shift + col0,
+                                         out + (size_t)g0 * N3 + col0, N3, gv, lane);
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------
+// Ball query of ONE centre by ONE wave over a cloud staged in LDS (packed xyz), result in
+// an LDS row of `nsample` ints.  Same semantics as ball_query_kernel in pn2_ops.hip
+// (ball_query_gpu.cu:9-44): index order, strict '<', first-hit fill, zeros when empty.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_ball_query(const float *sx, int n, float cx, float cy, float cz,
+                                                float radius2, int nsample, int *row, int lane) {
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int cnt = 0, first = 0;
+  for (int base = 0; base < n && cnt < nsample; base += kWave) {
+    const int k = base + lane;
+    bool hit = false;
+    if (k < n) {
+      const float d2 = sq3(cx - sx[k * 3 + 0], cy - sx[k * 3 + 1], cz - sx[k * 3 + 2]);
+      hit = d2 < radius2;
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (mask) {
+      if (cnt == 0) first = base + __ffsll((long long)mask) - 1;
+      const int slot = cnt + __popcll(mask & lt);
+      if (hit && slot < nsample) row[slot] = k;
+      cnt += __popcll(mask);
+    }
+  }
+  const int filled = cnt < nsample ? cnt : nsample;
+  const int fill = cnt > 0 ? first : 0;
+  for (int l = filled + lane; l < nsample; l += kWave) row[l] = fill;
+}
+
+// =================================================================================
+// Level 1: points (b, n, 6) = [xyz, rgb] as the dataset stores them; centres (b, m, 3).
+// Block = 4 centres x 32 neighbours = 128 rows.  MLP 6 -> 64 -> 64 -> 128.
+// out: (b, m, 128) point-major.
+// =================================================================================
+constexpr int kNS = 32;   // neighbours per centre in both query levels (configs/msr3d.yaml:199)
+using Chain1 = Chain<128, 16, 64, 64, 128, kNS, 2, 2>;
+
+__global__ __launch_bounds__(256) void sa1_kernel(int n, int m, float radius2,
+                                                  const float *__restrict__ pts,
+                                                  const float *__restrict__ new_xyz, Layer l1,
+                                                  Layer l2, Layer l3, float *__restrict__ out,
+                                                  int *__restrict__ dbg_idx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *bufA = reinterpret_cast<float *>(smem);
+  float *bufB = bufA + 128 * Chain1::LDA;
+  int *nbr = reinterpret_cast<int *>(bufB + 128 * Chain1::LDB);   // [4][32]
+  float *ctr = reinterpret_cast<float *>(nbr + 4 * kNS);          // [4][4]
+  float *sx = ctr + 16;                                            // [n][3]
+
+  const int obj = blockIdx.y, c0 = blockIdx.x * 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *P = pts + (size_t)obj * n * 6;
+  for (int i = tid; i < n * 3; i += 256) {
+    const int p = i / 3, c = i - p * 3;
+    sx[i] = P[p * 6 + c];
+  }
+  if (tid < 12) {
+    const int w = tid / 3, c = tid - w * 3;
+    ctr[w * 4 + c] = (c0 + w < m) ? new_xyz[((size_t)obj * m + c0 + w) * 3 + c] : 0.f;
+  }
+  __syncthreads();
+  if (c0 + wave < m)
+    wave_ball_query(sx, n, ctr[wave * 4 + 0], ctr[wave * 4 + 1], ctr[wave * 4 + 2], radius2, kNS,
+                    nbr + wave * kNS, lane);
+  else if (lane < kNS)
+    nbr[wave * kNS + lane] = 0;
+  __syncthreads();
+  if (dbg_idx && tid < 4 * kNS && c0 + tid / kNS < m)
+    dbg_idx[((size_t)obj * m + c0) * kNS + tid] = nbr[tid];
+  // gather: row = (centre w, sample k); cols [x-cx, y-cy, z-cz, r, g, b, 0 x10]
+  for (int e = tid; e < 128 * 16; e += 256) {
+    const int row = e >> 4, c = e & 15;
+    const int p = nbr[row];
+    float v = 0.f;
+    if (c < 3) v = sx[p * 3 + c] - ctr[(row >> 5) * 4 + c];
+    else if (c < 6) v = P[p * 6 + c];
+    bufA[row * Chain1::LDA + c] = v;
+  }
+  __syncthreads();
+  const int groups = (m - c0) < 4 ? (m - c0) : 4;
+  Chain1::run(bufA, bufB, l1, l2, l3, out + ((size_t)obj * m + c0) * 128, groups);
+}
+
+// =================================================================================
+// Level 2: xyz (b, n<=64, 3) = level-1 centres, feat (b, n, 128) point-major; centres
+// (b, m, 3).  Block = 4 centres x 32 neighbours.  MLP 131 -> 128 -> 128 -> 256 with the
+// K order [feat(128), dxyz(3), 0 x13].  out: (b, m, 256).
+// =================================================================================
+using Chain2 = Chain<128, 144, 128, 128, 256, kNS, 2, 2>;
+
+__global__ __launch_bounds__(256) void sa2_kernel(int n, int m, float radius2,
+                                                  const float *__restrict__ xyz,
+                                                  const float *__restrict__ feat,
+                                                  const float *__restrict__ new_xyz, Layer l1,
+                                                  Layer l2, Layer l3, float *__restrict__ out,
+                                                  int *__restrict__ dbg_idx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *bufA = reinterpret_cast<float *>(smem);
+  float *bufB = bufA + 128 * Chain2::LDA;
+  int *nbr = reinterpret_cast<int *>(bufB + 128 * Chain2::LDB);   // [4][32]
+  float *ctr = reinterpret_cast<float *>(nbr + 4 * kNS);          // [4][4]
+  float *sx = ctr + 16;                                            // [n][3], n <= 64
+
+  const int obj = blockIdx.y, c0 = blockIdx.x * 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < n * 3) sx[tid] = xyz[(size_t)obj * n * 3 + tid];
+  if (tid >= 192 && tid < 204) {
+    const int t = tid - 192, w = t / 3, c = t - w * 3;
+    ctr[w * 4 + c] = (c0 + w < m) ? new_xyz[((size_t)obj * m + c0 + w) * 3 + c] : 0.f;
+  }
+  __syncthreads();
+  if (c0 + wave < m)
+    wave_ball_query(sx, n, ctr[wave * 4 + 0], ctr[wave * 4 + 1], ctr[wave * 4 + 2], radius2, kNS,
+                    nbr + wave * kNS, lane);
+  else if (lane < kNS)
+    nbr[wave * kNS + lane] = 0;
+  __syncthreads();
+  if (dbg_idx && tid < 4 * kNS && c0 + tid / kNS < m)
+    dbg_idx[((size_t)obj * m + c0) * kNS + tid] = nbr[tid];
+  const float *F = feat + (size_t)obj * n * 128;
+  for (int e = tid; e < 128 * 32; e += 256) {          // 32 float4 per row
+    const int row = e >> 5, c4 = e & 31;
+    const int p = nbr[row];
+    *reinterpret_cast<float4 *>(bufA + row * Chain2::LDA + c4 * 4) =
+        *reinterpret_cast<const float4 *>(F + (size_t)p * 128 + c4 * 4);
+  }
+  if (tid < 128) {
+    const int row = tid, p = nbr[row], w = row >> 5;
+    float *d = bufA + row * Chain2::LDA + 128;
+    d[0] = sx[p * 3 + 0] - ctr[w * 4 + 0];
+    d[1] = sx[p * 3 + 1] - ctr[w * 4 + 1];
+    d[2] = sx[p * 3 + 2] - ctr[w * 4 + 2];
+#pragma unroll
+    for (int c = 3; c < 16; ++c) d[c] = 0.f;
+  }
+  __syncthreads();
+  const int groups = (m - c0) < 4 ? (m - c0) : 4;
+  Chain2::run(bufA, bufB, l1, l2, l3, out + ((size_t)obj * m + c0) * 256, groups);
+}
+
+// =================================================================================
+// Level 3 (GroupAll): every object's 16 points form one group.  rows = (object, point),
+// block = 2 objects = 32 rows.  MLP 259 -> 256 -> 512 -> 768 with the K order
+// [feat(256), xyz(3), 0 x13].  out: (b, 768).  A third LDS buffer is needed because
+// N2 = 512 does not fit the input tile's buffer.
+// =================================================================================
+constexpr int kN3Pts = 16;
+struct Chain3Cfg {
+  static constexpr int TM = 32, K0P = 272, N1 = 256, N2 = 512, N3 = 768;
+  static constexpr int LDX = K0P + kLdsPad, LD1 = N1 + kLdsPad, LD2 = N2 + kLdsPad;
+  static constexpr int LDS_FLOATS = TM * (LDX + LD1 + LD2);
+};
+
+__global__ __launch_bounds__(256) void sa3_kernel(int b, const float *__restrict__ xyz,
+                                                  const float *__restrict__ feat, Layer l1,
+                                                  Layer l2, Layer l3, float *__restrict__ out) {
+  using C = Chain3Cfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *bufX = reinterpret_cast<float *>(smem);
+  float *buf1 = bufX + C::TM * C::LDX;
+  float *buf2 = buf1 + C::TM * C::LD1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int obj0 = blockIdx.x * 2;
+  for (int e = tid; e < C::TM * 64; e += 256) {        // 64 float4 of features per row
+    const int row = e >> 6, c4 = e & 63;
+    const int obj = obj0 + (row >> 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (obj < b)
+      v = *reinterpret_cast<const float4 *>(feat + ((size_t)obj * kN3Pts + (row & 15)) * 256 + c4 * 4);
+    *reinterpret_cast<float4 *>(bufX + row * C::LDX + c4 * 4) = v;
+  }
+  if (tid < C::TM) {
+    const int row = tid, obj = obj0 + (row >> 4);
+    float *d = bufX + row * C::LDX + 256;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      d[c] = (c < 3 && obj < b) ? xyz[((size_t)obj * kN3Pts + (row & 15)) * 3 + c] : 0.f;
+  }
+  __syncthreads();
+  constexpr int RM = 2;    // 32 rows, all waves; waves split N four ways
+  {
+    constexpr int RN = C::N1 / 64;
+    const int col0 = wave * RN * 16;
+    f32x4 acc[RM][RN];
+    zero_acc(acc);
+    gemm_lds_global<RM, RN, C::K0P>(bufX, C::LDX, l1.w + (size_t)col0 * C::K0P, acc, lane);
+    store_bn_relu_lds<RM, RN>(acc, l1.scale + col0, l1.shift + col0, buf1 + col0, C::LD1, lane);
+  }
+  __syncthreads();
+  {
+    constexpr int RN = C::N2 / 64;
+    const int col0 = wave * RN * 16;
+    f32x4 acc[RM][RN];
+    zero_acc(acc);
+    gemm_lds_global<RM, RN, C::N1>(buf1, C::LD1, l2.w + (size_t)col0 * C::N1, acc, lane);
+    store_bn_relu_lds<RM, RN>(acc, l2.scale + col0, l2.shift + col0, buf2 + col0, C::LD2, lane);
+  }
+  __syncthreads();
+  {
+    constexpr int RN = C::N3 / 64;
+    const int col0 = wave * RN * 16;
+    f32x4 acc[RM][RN];
+    zero_acc(acc);
+    gemm_lds_global<RM, RN, C::N2>(buf2, C::LD2, l3.w + (size_t)col0 * C::N2, acc, lane);
+    const int gv = (b - obj0) < 2 ? (b - obj0) : 2;
+    store_bn_relu_groupmax<RM, RN, 1>(acc, l3.scale + col0, l3.shift + col0,
+                                      out + (size_t)obj0 * C::N3 + col0, C::N3, gv, lane);
+  }
+}
+
+inline Layer make_layer(const float *packed, int n, int kp) {
+  Layer l;
+  l.w = packed;
+  l.scale = packed + (size_t)n * kp;
+  l.shift = l.scale + n;
+  return l;
+}
+
+template <typename K>
+inline hipError_t allow_lds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace
+
+extern "C" {
+
+int msr3d_sa_fps2(int b, int n, int point_stride, int m1, int m2, const float *pts, int *idx1,
+                  float *new_xyz1, int *idx2, float *new_xyz2, msr3d_stream_t stream) {
+  if (b < 0 || n <= 0 || m1 <= 0 || m2 < 0 || point_stride < 3 || !pts) return MSR3D_EINVAL;
+  if (b == 0) return 0;
+  const hipError_t e = dispatch_fps(b, n, point_stride, m1, pts, idx1, new_xyz1, m2, idx2,
+                                    new_xyz2, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MSR3D_EINVAL : (int)e;
+}
+
+int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pts,
+                   const float *feat, const float *new_xyz, const int *dims,
+                   const float *params1, const float *params2, const float *params3, float *out,
+                   int *dbg_ball_idx, msr3d_stream_t stream) {
+  if (b < 0 || !dims || !params1 || !params2 || !params3 || !out) return MSR3D_EINVAL;
+  if (b == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const float r2 = radius * radius;   // f32 product, as ball_query_gpu.cu:22
+  hipError_t e;
+  if (level == 1) {
+    // pts (b,n,6); dims = {6, 64, 64, 128}
+    if (!(dims[0] == 6 && dims[1] == 64 && dims[2] == 64 && dims[3] == 128)) return MSR3D_EINVAL;
+    if (!pts || !new_xyz || n <= 0 || m <= 0) return MSR3D_EINVAL;
+    const size_t lds = sizeof(float) * (Chain1::LDS_FLOATS + 4 * kNS + 16 + (size_t)n * 3);
+    if (lds > 160 * 1024) return MSR3D_EINVAL;
+    if ((e = allow_lds(sa1_kernel, lds)) != hipSuccess) return (int)e;
+    dim3 grid((m + 3) / 4, b);
+    sa1_kernel<<<grid, 256, lds, st>>>(n, m, r2, pts, new_xyz, make_layer(params1, 64, 16),
+                                       make_layer(params2, 64, 64), make_layer(params3, 128, 64),
+                                       out, dbg_ball_idx);
+  } else if (level == 2) {
+    // pts = xyz (b,n,3), feat (b,n,128); dims = {131, 128, 128, 256}
+    if (!(dims[0] == 131 && dims[1] == 128 && dims[2] == 128 && dims[3] == 256)) return MSR3D_EINVAL;
+    if (!pts || !feat || !new_xyz || n <= 0 || n > 64 || m <= 0) return MSR3D_EINVAL;
+    const size_t lds = sizeof(float) * (Chain2::LDS_FLOATS + 4 * kNS + 16 + 64 * 3);
+    if ((e = allow_lds(sa2_kernel, lds)) != hipSuccess) return (int)e;
+    dim3 grid((m + 3) / 4, b);
+    sa2_kernel<<<grid, 256, lds, st>>>(n, m, r2, pts, feat, new_xyz, make_layer(params1, 128, 144),
+                                       make_layer(params2, 128, 128), make_layer(params3, 256, 128),
+                                       out, dbg_ball_idx);
+  } else if (level == 3) {
+    // group-all over n = 16 points: pts = xyz (b,16,3), feat (b,16,256); dims = {259,256,512,768}
+    if (!(dims[0] == 259 && dims[1] == 256 && dims[2] == 512 && dims[3] == 768)) return MSR3D_EINVAL;
+    if (!pts || !feat || n != kN3Pts) return MSR3D_EINVAL;
+    const size_t lds = sizeof(float) * Chain3Cfg::LDS_FLOATS;
+    if ((e = allow_lds(sa3_kernel, lds)) != hipSuccess) return (int)e;
+    sa3_kernel<<<(b + 1) / 2, 256, lds, st>>>(b, pts, feat, make_layer(params1, 256, 272),
+                                              make_layer(params2, 512, 256),
+                                              make_layer(params3, 768, 512), out);
+  } else {
+    return MSR3D_EINVAL;
+  }
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

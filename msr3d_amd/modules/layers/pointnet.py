@@ -2,6 +2,7 @@
 three set-abstraction levels + `fc`.  State-dict keys `encoder.{i}.mlps.0.layer{j}.*`, `fc.*`."""
 import torch.nn as nn
 
+from ...pointnet2 import fused
 from ...pointnet2.pointnet2_modules import PointnetSAModule
 
 
@@ -27,7 +28,10 @@ class PointNetPP(nn.Module):
         self.fc = nn.Linear(out_n_points * sa_mlps[-1][-1], sa_mlps[-1][-1])
 
     def forward(self, features):
-        """(b, P, 3+C) -> (b, D).  Composite path (autograd-capable)."""
+        """(b, P, 3+C) -> (b, D).  Frozen/eval backbone on the GPU: the fused set-abstraction
+        kernels (pointnet2/fused.py).  Otherwise the composite, autograd-capable path."""
+        if fused.can_fuse(self, features):
+            return fused.forward(self, features)
         xyz, features = break_up_pc(features)
         for sa in self.encoder:
             xyz, features = sa(xyz, features)

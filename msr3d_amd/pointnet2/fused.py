@@ -1,0 +1,156 @@
+"""Fused set-abstraction path for the frozen PointNet++ encoder.
+
+Host side of msr3d_sa_fps2 / msr3d_sa_level (include/msr3d_hip.h): decides when the
+fused kernels apply, packs the per-layer parameters once (conv weight with the K order
+the kernels use, zero-padded; eval-mode BN folded to scale/shift) and issues the four
+launches + the `fc` GEMM.  Anything that does not match the shipped configuration falls
+back to the composite path (still the HIP ops, never the CPU).
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from .. import _lib
+from . import pointnet2_utils as pu
+
+_LEVEL_DIMS = ([6, 64, 64, 128], [131, 128, 128, 256], [259, 256, 512, 768])
+_KP0 = (16, 144, 272)
+_NSAMPLE = 32
+
+
+def _level_spec(sa):
+    """(dims, conv/bn pairs) of a single-scale SA module or None."""
+    if len(sa.mlps) != 1:
+        return None
+    pairs = sa.mlps[0].conv_bn_pairs()
+    if len(pairs) != 3 or any(c is None or c.kernel_size != (1, 1) for c, _ in pairs):
+        return None
+    dims = [pairs[0][0].in_channels] + [c.out_channels for c, _ in pairs]
+    return dims, pairs
+
+
+def can_fuse(net, pts):
+    if not getattr(net, "use_fused", True) or not pts.is_cuda or pts.dtype != torch.float32:
+        return False
+    if pts.dim() != 3 or pts.size(-1) != 6 or len(net.encoder) != 3:
+        return False
+    if torch.is_grad_enabled() and (pts.requires_grad or any(p.requires_grad for p in net.parameters())):
+        return False          # training the backbone needs autograd: composite path
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d) and m.training:
+            return False      # batch statistics: composite path
+    sa1, sa2, sa3 = net.encoder
+    for sa, want in zip(net.encoder, _LEVEL_DIMS):
+        spec = _level_spec(sa)
+        if spec is None or spec[0] != want:
+            return False
+    g1, g2, g3 = sa1.groupers[0], sa2.groupers[0], sa3.groupers[0]
+    if not (isinstance(g1, pu.QueryAndGroup) and isinstance(g2, pu.QueryAndGroup)
+            and isinstance(g3, pu.GroupAll)):
+        return False
+    if not (g1.use_xyz and g2.use_xyz and g3.use_xyz) or g1.normalize_xyz or g2.normalize_xyz:
+        return False
+    if g1.nsample != _NSAMPLE or g2.nsample != _NSAMPLE:
+        return False
+    if sa1.npoint is None or sa2.npoint != 16 or sa3.npoint is not None or sa1.npoint > 64:
+        return False
+    if pts.size(1) * 12 > 64 * 1024:      # level-1 cloud is staged in LDS
+        return False
+    return True
+
+
+def _pack_layer(conv, bn, kp, feat_first):
+    w = conv.weight.detach().reshape(conv.out_channels, conv.in_channels).float()
+    n, k = w.shape
+    wp = w.new_zeros((n, kp))
+    if feat_first:            # kernel K order: [features, xyz]; reference: [xyz, features]
+        wp[:, :k - 3] = w[:, 3:]
+        wp[:, k - 3:k] = w[:, :3]
+    else:
+        wp[:, :k] = w
+    if bn is not None:
+        scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+        shift = bn.bias.detach().float() - bn.running_mean.float() * scale
+        if conv.bias is not None:
+            shift = shift + conv.bias.detach().float() * scale
+    else:
+        scale = torch.ones(n, device=w.device)
+        shift = conv.bias.detach().float() if conv.bias is not None else torch.zeros(n, device=w.device)
+    return torch.cat([wp.reshape(-1), scale, shift]).contiguous()
+
+
+def _state_key(net):
+    return tuple((t.data_ptr(), t._version) for t in list(net.parameters()) + list(net.buffers()))
+
+
+def get_plan(net):
+    key = _state_key(net)
+    plan = getattr(net, "_fused_plan", None)
+    if plan is not None and plan["key"] == key:
+        return plan
+    levels = []
+    for li, sa in enumerate(net.encoder):
+        _, pairs = _level_spec(sa)
+        packed = []
+        for j, (conv, bn) in enumerate(pairs):
+            kp = _KP0[li] if j == 0 else conv.in_channels
+            packed.append(_pack_layer(conv, bn, kp, feat_first=(j == 0 and li > 0)))
+        levels.append(packed)
+    dims = [(ctypes.c_int * 4)(*d) for d in _LEVEL_DIMS]
+    plan = {"key": key, "levels": levels, "dims": dims}
+    net._fused_plan = plan
+    return plan
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def forward(net, pts, return_internals=False):
+    """pts (b, P, 6) f32 contiguous -> (b, 768).  Four kernel launches + one GEMM."""
+    pts = pts.contiguous()
+    b, n, _ = pts.shape
+    dev = pts.device
+    plan = get_plan(net)
+    lib = _lib.load()
+    sa1, sa2, _ = net.encoder
+    m1, m2 = sa1.npoint, sa2.npoint
+    new1 = torch.empty((b, m1, 3), dtype=torch.float32, device=dev)
+    new2 = torch.empty((b, m2, 3), dtype=torch.float32, device=dev)
+    feat1 = torch.empty((b, m1, 128), dtype=torch.float32, device=dev)
+    feat2 = torch.empty((b, m2, 256), dtype=torch.float32, device=dev)
+    pooled = torch.empty((b, 768), dtype=torch.float32, device=dev)
+    dbg = {}
+    if return_internals:
+        dbg = {"idx1": torch.empty((b, m1), dtype=torch.int32, device=dev),
+               "idx2": torch.empty((b, m2), dtype=torch.int32, device=dev),
+               "ball1": torch.empty((b, m1, _NSAMPLE), dtype=torch.int32, device=dev),
+               "ball2": torch.empty((b, m2, _NSAMPLE), dtype=torch.int32, device=dev)}
+    with torch.cuda.device(dev):
+        st = _lib.current_stream_ptr(dev)
+        with _lib.kernel_timer("msr3d_sa_fps2"):
+            rc = lib.msr3d_sa_fps2(b, n, 6, m1, m2, _p(pts), _p(dbg.get("idx1")), _p(new1),
+                                   _p(dbg.get("idx2")), _p(new2), st)
+        _lib.check(rc, "msr3d_sa_fps2")
+        L = plan["levels"]
+        with _lib.kernel_timer("msr3d_sa_level1"):
+            rc = lib.msr3d_sa_level(1, b, n, m1, ctypes.c_float(sa1.groupers[0].radius), _p(pts),
+                                    _p(None), _p(new1), plan["dims"][0], _p(L[0][0]), _p(L[0][1]),
+                                    _p(L[0][2]), _p(feat1), _p(dbg.get("ball1")), st)
+        _lib.check(rc, "msr3d_sa_level(1)")
+        with _lib.kernel_timer("msr3d_sa_level2"):
+            rc = lib.msr3d_sa_level(2, b, m1, m2, ctypes.c_float(sa2.groupers[0].radius), _p(new1),
+                                    _p(feat1), _p(new2), plan["dims"][1], _p(L[1][0]), _p(L[1][1]),
+                                    _p(L[1][2]), _p(feat2), _p(dbg.get("ball2")), st)
+        _lib.check(rc, "msr3d_sa_level(2)")
+        with _lib.kernel_timer("msr3d_sa_level3"):
+            rc = lib.msr3d_sa_level(3, b, m2, 1, ctypes.c_float(0.0), _p(new2), _p(feat2),
+                                    _p(None), plan["dims"][2], _p(L[2][0]), _p(L[2][1]),
+                                    _p(L[2][2]), _p(pooled), _p(None), st)
+        _lib.check(rc, "msr3d_sa_level(3)")
+    out = F.linear(pooled, net.fc.weight, net.fc.bias)
+    if return_internals:
+        dbg.update(new_xyz1=new1, new_xyz2=new2, feat1=feat1, feat2=feat2, pooled=pooled)
+        return out, dbg
+    return out
