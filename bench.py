@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--situation-type", default="as_transform_for_objects")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue the trainable part eagerly "
+                    "instead of replaying the captured HIP graph")
     ap.add_argument("--cpu-threads", type=int, default=32, help="threads of the CPU baseline leg "
                     "(small GEMMs stop scaling well before a 2-socket host's 256 HW threads)")
     return ap.parse_args()
@@ -62,25 +64,30 @@ class Trainer:
     """The hot-path step.  Optimiser settings: optim/build.py + configs/msr3d.yaml:43-47
     (AdamW lr 3e-5, betas (0.9, 0.999), wd 0.05), grad clip 5.0 (leo_trainer.py:192-193)."""
 
-    def __init__(self, model, device, batch_shape_E):
+    def __init__(self, model, device, example_batch, E, use_graph):
         from msr3d_amd.dp import FlatGradAllReduce
+        from msr3d_amd.train_step import HotPathTrainStep
         self.model = model
         params = [p for p in model.parameters() if p.requires_grad]
         self.dp = FlatGradAllReduce(params)
-        self.opt = torch.optim.AdamW(params, lr=3e-5, betas=(0.9, 0.999), weight_decay=0.05)
+        on_gpu = device.type == "cuda"
+        self.opt = torch.optim.AdamW(params, lr=3e-5, betas=(0.9, 0.999), weight_decay=0.05,
+                                     capturable=on_gpu and use_graph, foreach=True)
+        B, L = example_batch["obj_masks"].shape
         g = torch.Generator(device="cpu").manual_seed(99)
-        self.loss_w = torch.randn(batch_shape_E, generator=g).to(device)
-        self.inv_n = 1.0 / self.loss_w.numel()
+        loss_w = torch.randn((B, L, E), generator=g).to(device)
+        inv_n = 1.0 / loss_w.numel()
+
+        def loss_fn(out):       # synthetic scalar loss on the projector output
+            return (out["scene_embeds"] * loss_w).sum() * inv_n
+
+        self.stepper = HotPathTrainStep(model, self.opt, self.dp, loss_fn, example_batch,
+                                        use_graph=use_graph)
+        if on_gpu and use_graph:
+            self.stepper.capture(example_batch)
 
     def step(self, batch):
-        self.dp.zero_grad()
-        out = self.model(dict(batch))
-        loss = (out["scene_embeds"] * self.loss_w).sum() * self.inv_n
-        loss.backward()
-        self.dp.finish()
-        self.dp.clip_grad_norm_(5.0)
-        self.opt.step()
-        return loss
+        return self.stepper(batch)
 
 
 def cpu_baseline(args, seconds):
@@ -97,8 +104,8 @@ def cpu_baseline(args, seconds):
         torch.set_num_threads(cores)
         pn2.set_threads(cores)
         model = build(args, torch.device("cpu"))
-        tr = Trainer(model, torch.device("cpu"), (1, O, args.llm_hidden))
         batches = [synth_batch(10_000 + i, 1, O=O, P=P) for i in range(2)]
+        tr = Trainer(model, torch.device("cpu"), batches[0], args.llm_hidden, use_graph=False)
         tr.step(batches[0])                       # warm-up
         n, t0 = 0, time.perf_counter()
         while True:
@@ -130,10 +137,10 @@ def main():
     from msr3d_amd.synth import synth_batch
     model = build(args, device)
     B = args.batch
-    tr = Trainer(model, device, (B, O, args.llm_hidden))
     # distinct resident batches per rank, cycled (weak scaling: per-GPU work fixed)
     n_resident = 4
     batches = [synth_batch(1000 * rank + i, B, O=O, P=P, device=device) for i in range(n_resident)]
+    tr = Trainer(model, device, batches[0], args.llm_hidden, use_graph=not args.no_graph)
 
     for i in range(args.warmup):
         tr.step(batches[i % n_resident])
@@ -183,6 +190,7 @@ def main():
                        "objects": O, "points": P, "per_gpu_batch": B, "global_batch": B * world,
                        "llm_hidden": args.llm_hidden, "situation_type": args.situation_type,
                        "step": "fwd+bwd+allreduce+clip+AdamW, LLM excluded",
+                       "hip_graph": not args.no_graph,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": "sa2_kernel (msr3d_sa_level level 2)",
                          "achieved": achieved, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",

@@ -115,8 +115,17 @@ class OSE3DSituation(BaseModel):
         return next(self.parameters()).device
 
     # ------------------------------------------------------------------ pieces
+    def encode_objects(self, obj_fts):
+        """Frozen/eval backbone features (B,O,768).  Uses the encoder's `embed` (no dead
+        classification head) when it has one, else `forward(...)[0]` like the reference."""
+        enc = self.obj_encoder
+        return enc.embed(obj_fts) if hasattr(enc, "embed") else enc(obj_fts)[0]
+
     def forward_gtpcd(self, data_dict):
-        return self.obj_linear_projection(self.obj_encoder(data_dict["obj_fts"])[0])
+        embeds = data_dict.get("obj_embeds")          # precomputed by a split (graphed) step
+        if embeds is None:
+            embeds = self.encode_objects(data_dict["obj_fts"])
+        return self.obj_linear_projection(embeds)
 
     def _with_anchor_token(self, data_dict, feat, mask, loc, type_emb, ori_feat):
         """Prepend the agent ("self") token: learnt feature, fourier-encoded orientation,

@@ -41,12 +41,16 @@ class PcdObjEncoder(nn.Module):
         flat = obj_pcds.reshape(B * O, obj_pcds.size(2), obj_pcds.size(3))
         return self.pcd_net(flat).reshape(B, O, -1)
 
-    def forward(self, obj_pcds, obj_locs=None, obj_masks=None, obj_sem_masks=None, **kwargs):
+    def embed(self, obj_pcds):
+        """obj_embeds only: what OSE3DSituation consumes (it takes `[0]` of forward and
+        discards the 607-way logits, ose3d_situation.py:285), without the dead head."""
         if self.freeze:
             self.freeze_bn(self.pcd_net)
             with torch.no_grad():
-                obj_embeds = self.encode(obj_pcds).detach()
-        else:
-            obj_embeds = self.encode(obj_pcds)
+                return self.encode(obj_pcds).detach()
+        return self.encode(obj_pcds)
+
+    def forward(self, obj_pcds, obj_locs=None, obj_masks=None, obj_sem_masks=None, **kwargs):
+        obj_embeds = self.embed(obj_pcds)
         obj_sem_cls = self.obj3d_clf_pre_head(obj_embeds)
         return obj_embeds, obj_sem_cls
