@@ -125,6 +125,28 @@ int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pt
                    const float *params1, const float *params2, const float *params3, float *out,
                    int *dbg_ball_idx, msr3d_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * Token GEMMs of the trainable part (situated encoder, projector): the nn.Linear calls of
+ * /root/reference/modules/layers/transformers.py:200-252,314-329, model/ose3d_situation.py
+ * :192,399-404 and model/msr3d/msr3d.py:84-86,277, forward and both backward products.
+ * fp32 on f32-input MFMA.
+ * ------------------------------------------------------------------------- */
+
+/* C[m][n] = beta*C[m][n] + bias[n] + sum_k a(m,k)*b(n,k),  a(m,k) = a_kc ? A[m*lda+k] : A[k*lda+m],
+ * b(n,k) = b_kc ? B[n*ldb+k] : B[k*ldb+n].  flags bit0: C = gelu(.) (exact erf form) and, if
+ * C_pre != NULL, C_pre = the pre-activation (saved for backward).  bias / C_pre may be NULL. */
+int msr3d_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float *A, int lda,
+                   const float *B, int ldb, float *C, int ldc, const float *bias, float *C_pre,
+                   int flags, float beta, msr3d_stream_t stream);
+
+/* out[n] (+)= sum_m X[m*ldx + n]  (bias gradient). */
+int msr3d_colsum_f32(int M, int N, const float *X, int ldx, float *out, int accumulate,
+                     msr3d_stream_t stream);
+
+/* out = dy * gelu'(pre), n % 4 == 0, 16-byte aligned. */
+int msr3d_gelu_bwd_f32(long long n, const float *dy, const float *pre, float *out,
+                       msr3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

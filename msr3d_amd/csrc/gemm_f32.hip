@@ -1,0 +1,264 @@
+// gemm_f32.hip -- token GEMMs of the trainable part (situated encoder + projector) on
+// f32-input MFMA (v_mfma_f32_16x16x4_f32): exact fp32 products/sums, like the reference,
+// which runs this part with autocast disabled (model/ose3d_situation.py:377).
+//
+// One kernel, three operand layouts, so that forward AND both backward products read the
+// tensors where they already are (no transposed copies):
+//     C[m][n] (+)= sum_k a(m,k) * b(n,k)
+//     a(m,k) = A_KC ? A[m*lda + k] : A[k*lda + m]        (KC = reduction index contiguous)
+//     b(n,k) = B_KC ? B[n*ldb + k] : B[k*ldb + n]
+//   forward  y  = x W^T + b      : A = x  (KC),  B = W (KC)         (nn.Linear layout W[N][K])
+//   backward dx = dy W           : A = dy (KC),  B = W (not KC)     reduction over N
+//   backward dW = dy^T x         : A = dy (not KC), B = x (not KC)  reduction over tokens
+//
+// These are SMALL problems (M = 960 tokens at 16 scenes/GPU; 0.1 - 2 GFLOP each): what
+// matters is that every launch fills the chip for its few microseconds, so the tile is
+// 64x64 (4 waves x 32x32) with BK = 32, LDS double-buffered, operands staged
+// global -> registers -> LDS with 16-byte accesses.  hipBLASLt's heuristic picks a
+// 256x256 macro-tile = ONE workgroup for the (960 x 256 x 256) fp32 linears of this path
+// (215 us each, profiles/r01_v2_bench_kernel_stats.csv); this kernel is the replacement.
+#include <hip/hip_runtime.h>
+
+#include "../../include/msr3d_hip.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int LD_KC = BK + 8;    // [64][40]: stride/4 == 2 (mod 4) -> conflict-free ds_read_b128 fragments
+constexpr int LD_MC = BM + 4;    // [32][68]: half-wave (g = 0,1) lands on disjoint bank halves
+constexpr int TILE_FLOATS = 64 * LD_KC;   // >= 32 * LD_MC
+
+__device__ __forceinline__ float gelu_f(float x) {     // exact erf GELU (F.gelu default)
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// ---- global -> registers: one 64 x 32 operand tile = 2 float4 per thread -------------
+// KC tile: rows = output index (64), cols = k (32).   thread t: row = t/8 + 32p, k4 = (t%8)*4
+// MC tile: rows = k (32), cols = output index (64).   thread t: krow = t/16 + 16p, c4 = (t%16)*4
+template <bool KC>
+__device__ __forceinline__ void load_tile(const float *__restrict__ P, int ld, int o0, int k0,
+                                          int O, int K, bool vec_ok, float4 (&r)[2]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    int row, col;          // row/col in GLOBAL matrix terms
+    if (KC) { row = o0 + (t >> 3) + 32 * p; col = k0 + (t & 7) * 4; }
+    else    { row = k0 + (t >> 4) + 16 * p; col = o0 + (t & 15) * 4; }
+    const int R = KC ? O : K, Cn = KC ? K : O;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < R) {
+      const float *src = P + (size_t)row * ld + col;
+      if (vec_ok && col + 3 < Cn) {
+        v = *reinterpret_cast<const float4 *>(src);
+      } else {
+        if (col + 0 < Cn) v.x = src[0];
+        if (col + 1 < Cn) v.y = src[1];
+        if (col + 2 < Cn) v.z = src[2];
+        if (col + 3 < Cn) v.w = src[3];
+      }
+    }
+    r[p] = v;
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(float *s, const float4 (&r)[2]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (KC) *reinterpret_cast<float4 *>(s + ((t >> 3) + 32 * p) * LD_KC + (t & 7) * 4) = r[p];
+    else    *reinterpret_cast<float4 *>(s + ((t >> 4) + 16 * p) * LD_MC + (t & 15) * 4) = r[p];
+  }
+}
+
+// fragment for MFMA step s of 16-wide sub-slab `sub`: element (row = base + i, k = 16 sub + 4g + s)
+template <bool KC>
+__device__ __forceinline__ void read_frag(const float *s, int base, int sub, int i, int g,
+                                          float (&f)[4]) {
+  if (KC) {
+    const float4 v = *reinterpret_cast<const float4 *>(s + (base + i) * LD_KC + sub * 16 + 4 * g);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) f[q] = s[(sub * 16 + 4 * g + q) * LD_MC + base + i];
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
+                                                       const float *__restrict__ A, int lda,
+                                                       const float *__restrict__ B, int ldb,
+                                                       float *__restrict__ C, int ldc,
+                                                       const float *__restrict__ bias,
+                                                       float *__restrict__ Cpre, int flags,
+                                                       float beta, int a_vec, int b_vec) {
+  __shared__ __attribute__((aligned(16))) float smem[4 * TILE_FLOATS];
+  float *const As = smem;                       // [2][TILE_FLOATS]
+  float *const Bs = smem + 2 * TILE_FLOATS;     // [2][TILE_FLOATS]
+
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;          // 2 x 2 waves, 32 x 32 each
+  const int i = lane & 15, g = lane >> 4;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float4 ra[2], rb[2];
+  load_tile<A_KC>(A, lda, m0, 0, M, K, a_vec, ra);
+  load_tile<B_KC>(B, ldb, n0, 0, N, K, b_vec, rb);
+  store_tile<A_KC>(As, ra);
+  store_tile<B_KC>(Bs, rb);
+  __syncthreads();
+
+  const int nk = (K + BK - 1) / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {                               // prefetch the next slab into registers
+      load_tile<A_KC>(A, lda, m0, (kt + 1) * BK, M, K, a_vec, ra);
+      load_tile<B_KC>(B, ldb, n0, (kt + 1) * BK, N, K, b_vec, rb);
+    }
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      float fa[2][4], fb[2][4];
+#pragma unroll
+      for (int rm = 0; rm < 2; ++rm) read_frag<A_KC>(As + cur * TILE_FLOATS, wm * 32 + rm * 16, sub, i, g, fa[rm]);
+#pragma unroll
+      for (int rn = 0; rn < 2; ++rn) read_frag<B_KC>(Bs + cur * TILE_FLOATS, wn * 32 + rn * 16, sub, i, g, fb[rn]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+          for (int rn = 0; rn < 2; ++rn)
+            acc[rm][rn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[rm][s], fb[rn][s], acc[rm][rn], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      store_tile<A_KC>(As + (cur ^ 1) * TILE_FLOATS, ra);             // other buffer: nobody reads it this round
+      store_tile<B_KC>(Bs + (cur ^ 1) * TILE_FLOATS, rb);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int rn = 0; rn < 2; ++rn) {
+    const int col = n0 + wn * 32 + rn * 16 + i;
+    if (col >= N) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 32 + rm * 16 + g * 4 + r;
+        if (row >= M) continue;
+        float v = acc[rm][rn][r] + bv;
+        const size_t o = (size_t)row * ldc + col;
+        if (beta != 0.f) v += beta * C[o];
+        if (flags & 1) {
+          if (Cpre) Cpre[o] = v;
+          v = gelu_f(v);
+        }
+        C[o] = v;
+      }
+  }
+}
+
+// out[n] (+)= sum_m X[m][n]   (bias gradients).  One wave per 64 columns, rows split over
+// gridDim.y with one atomicAdd per (column, row-chunk) unless a single chunk covers M.
+__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float *__restrict__ X,
+                                                     int ldx, float *__restrict__ out) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  float s = 0.f;
+  if (col < N)
+    for (int r = r0 + wave; r < r1; r += 4) s += X[(size_t)r * ldx + col];
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && col < N) {
+    const float v = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+    atomicAdd(out + col, v);
+  }
+}
+
+// dpre = dy * gelu'(pre)   (exact erf form), elementwise, float4
+__global__ void gelu_bwd_kernel(long long n4, const float4 *__restrict__ dy,
+                                const float4 *__restrict__ pre, float4 *__restrict__ out) {
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n4;
+       t += (long long)gridDim.x * blockDim.x) {
+    const float4 d = dy[t], x = pre[t];
+    float4 o;
+    const float k0 = 0.70710678118654752440f, k1 = 0.39894228040143267794f;   // 1/sqrt2, 1/sqrt(2pi)
+#define GB(c) o.c = d.c * (0.5f * (1.0f + erff(x.c * k0)) + x.c * k1 * __expf(-0.5f * x.c * x.c))
+    GB(x); GB(y); GB(z); GB(w);
+#undef GB
+    out[t] = o;
+  }
+}
+
+inline bool vec_ok(const float *p, int ld) {
+  return ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) && (ld % 4 == 0);
+}
+
+}  // namespace
+
+extern "C" {
+
+int msr3d_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float *A, int lda,
+                   const float *B, int ldb, float *C, int ldc, const float *bias, float *C_pre,
+                   int flags, float beta, msr3d_stream_t stream) {
+  if (M < 0 || N < 0 || K < 0 || lda <= 0 || ldb <= 0 || ldc <= 0) return MSR3D_EINVAL;
+  if (M == 0 || N == 0) return 0;
+  if (!A || !B || !C) return MSR3D_EINVAL;
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
+  const int av = vec_ok(A, lda), bv = vec_ok(B, ldb);
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(AK, BKc) \
+  gemm_f32_kernel<AK, BKc><<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags, beta, av, bv)
+  if (a_kc && b_kc) LAUNCH(true, true);
+  else if (a_kc && !b_kc) LAUNCH(true, false);
+  else if (!a_kc && !b_kc) LAUNCH(false, false);
+  else LAUNCH(false, true);
+#undef LAUNCH
+  return (int)hipGetLastError();
+}
+
+int msr3d_colsum_f32(int M, int N, const float *X, int ldx, float *out, int accumulate,
+                     msr3d_stream_t stream) {
+  if (M < 0 || N <= 0 || !out || (M > 0 && !X)) return MSR3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (M == 0) return 0;
+  int chunks = (M + 127) / 128;
+  if (chunks > 64) chunks = 64;
+  dim3 grid((N + 63) / 64, chunks);
+  colsum_kernel<<<grid, 256, 0, st>>>(M, N, X, ldx, out);
+  return (int)hipGetLastError();
+}
+
+int msr3d_gelu_bwd_f32(long long n, const float *dy, const float *pre, float *out,
+                       msr3d_stream_t stream) {
+  if (n < 0 || (n % 4) != 0) return MSR3D_EINVAL;
+  if (n == 0) return 0;
+  if (!dy || !pre || !out) return MSR3D_EINVAL;
+  const long long n4 = n / 4;
+  long long g = (n4 + 255) / 256;
+  if (g > 2048) g = 2048;
+  gelu_bwd_kernel<<<(int)g, 256, 0, (hipStream_t)stream>>>(
+      n4, reinterpret_cast<const float4 *>(dy), reinterpret_cast<const float4 *>(pre),
+      reinterpret_cast<float4 *>(out));
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

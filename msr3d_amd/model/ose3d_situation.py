@@ -17,6 +17,7 @@ import math
 import torch
 import torch.nn as nn
 
+from .. import hipops
 from ..modules.build import build_module
 from ..modules.layers.transformers import (TransformerEncoderLayer,
                                            TransformerSpatialEncoderLayer)
@@ -125,7 +126,7 @@ class OSE3DSituation(BaseModel):
         embeds = data_dict.get("obj_embeds")          # precomputed by a split (graphed) step
         if embeds is None:
             embeds = self.encode_objects(data_dict["obj_fts"])
-        return self.obj_linear_projection(embeds)
+        return hipops.module_linear(self.obj_linear_projection, embeds)
 
     def _with_anchor_token(self, data_dict, feat, mask, loc, type_emb, ori_feat):
         """Prepend the agent ("self") token: learnt feature, fourier-encoded orientation,
@@ -144,35 +145,44 @@ class OSE3DSituation(BaseModel):
         loc = torch.cat((a_loc, loc), dim=1)
         type_emb = torch.cat((a_type, type_emb), dim=1)
         if self.use_orientation:
-            a_ori = self.orientation_encoder(
+            a_ori = hipops.module_linear(
+                self.orientation_encoder,
                 generate_fourier_features(data_dict["anchor_orientation"].unsqueeze(1)))
             ori_feat = torch.cat((a_ori, ori_feat), dim=1)
         return feat, mask, loc, type_emb, ori_feat
+
+    @staticmethod
+    def _lin_ln(seq, x):
+        """nn.Sequential(Linear, LayerNorm) with the Linear on the HIP GEMM."""
+        return seq[1](hipops.module_linear(seq[0], x))
 
     def _query_pos(self, layer_idx, loc, data_dict):
         """Positional term added to the tokens before a layer."""
         se = self.cfg.spatial_encoder
         if se.obj_loc_encoding == "diff_all":
-            return self.loc_layers[layer_idx](loc)
+            return self._lin_ln(self.loc_layers[layer_idx], loc)
         st = self.situation_type
         centre, size = loc[:, :, :3], loc[:, :, 3:]
+        loc_enc, size_enc = (getattr(self, "loc_embedding_encoder", None),
+                             getattr(self, "size_embedding_encoder", None))
         if st == "as_object_add_loc":
-            return (self.loc_embedding_encoder(generate_fourier_features(centre))
-                    + self.size_embedding_encoder(size))
+            return (self._lin_ln(loc_enc, generate_fourier_features(centre))
+                    + self._lin_ln(size_enc, size))
         if st == "as_embedding":
             L = loc.size(1)
             sit_loc = data_dict["anchor_locs"].unsqueeze(1).expand(-1, L, -1)
             sit_ori = data_dict["anchor_orientation"].unsqueeze(1).expand(-1, L, -1)
-            return (self.loc_embedding_encoder(generate_fourier_features(centre))
-                    + self.size_embedding_encoder(size)
-                    + self.orientation_encoder(generate_fourier_features(sit_ori))
-                    + self.loc_embedding_encoder(generate_fourier_features(sit_loc)))
+            return (self._lin_ln(loc_enc, generate_fourier_features(centre))
+                    + self._lin_ln(size_enc, size)
+                    + hipops.module_linear(self.orientation_encoder,
+                                           generate_fourier_features(sit_ori))
+                    + self._lin_ln(loc_enc, generate_fourier_features(sit_loc)))
         if st == "as_transform_for_objects":
             agent = transform_to_agent_coor(centre, data_dict["anchor_locs"],
                                             data_dict["anchor_orientation"])
-            return (self.loc_embedding_encoder(generate_fourier_features(agent))
-                    + self.size_embedding_encoder(size))
-        return self.loc_layers[0](loc)
+            return (self._lin_ln(loc_enc, generate_fourier_features(agent))
+                    + self._lin_ln(size_enc, size))
+        return self._lin_ln(self.loc_layers[0], loc)
 
     # ------------------------------------------------------------------ forward
     def forward(self, data_dict):
@@ -206,9 +216,17 @@ class OSE3DSituation(BaseModel):
 
         x = feat
         with maybe_autocast(self, enabled=False):          # the encoder always runs in fp32
+            # 'same_*': the positional term does not depend on the layer (same inputs, shared
+            # weights) -- the reference recomputes it three times (ose3d_situation.py:380-410),
+            # here it is computed once and autograd sums the three uses.
+            shared_pos = None
+            if se.obj_loc_encoding != "diff_all":
+                shared_pos = self._query_pos(0, loc, data_dict)
             for i, layer in enumerate(self.spatial_encoder):
-                if se.obj_loc_encoding in ("same_all", "diff_all") or i == 0:
+                if se.obj_loc_encoding == "diff_all":
                     x = x + self._query_pos(i, loc, data_dict)
+                elif se.obj_loc_encoding == "same_all" or i == 0:
+                    x = x + shared_pos
                 if self.cfg.use_spatial_attn:
                     x, _ = layer(x, pairwise_locs, tgt_key_padding_mask=mask)
                 else:

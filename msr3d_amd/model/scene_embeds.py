@@ -9,6 +9,7 @@ scatter of the scene tokens into the LLM's `inputs_embeds` / `attention_mask`).
 import torch
 import torch.nn as nn
 
+from .. import hipops
 from ..modules.utils import disabled_train
 from .build import MODEL_REGISTRY, build_model
 
@@ -57,5 +58,5 @@ class MSR3DHotPath(nn.Module):
         """-> scene_dict with obj_tokens, obj_masks (from the prompter) and scene_embeds (B,L,E)."""
         if "obj_tokens" not in scene_dict:
             scene_dict = self.visual_prompter(scene_dict)
-        scene_dict["scene_embeds"] = self.llm_proj(scene_dict["obj_tokens"])
+        scene_dict["scene_embeds"] = hipops.module_linear(self.llm_proj, scene_dict["obj_tokens"])
         return scene_dict

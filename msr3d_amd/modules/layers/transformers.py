@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
 
+from ... import hipops
 from ..utils import get_activation_fn
 
 
@@ -56,7 +57,7 @@ class MultiHeadAttentionSpatial(nn.Module):
         """Spatial term per (head, batch, query, key)."""
         fusion = self.spatial_attn_fusion
         if fusion in ("mul", "bias", "add"):
-            loc = self.pairwise_loc_fc(pairwise_locs).permute(3, 0, 1, 2)        # (h?, B, L, T)
+            loc = hipops.module_linear(self.pairwise_loc_fc, pairwise_locs).permute(3, 0, 1, 2)
             if fusion == "mul":
                 loc = F.relu(loc)
             if not self.spatial_multihead:
@@ -64,11 +65,13 @@ class MultiHeadAttentionSpatial(nn.Module):
             return loc
         if fusion == "ctx":
             B, L, T, _ = pairwise_locs.shape
-            loc = self.pairwise_loc_fc(pairwise_locs).view(B, L, T, self.n_head, self.d_per_head)
+            loc = hipops.module_linear(self.pairwise_loc_fc, pairwise_locs).view(
+                B, L, T, self.n_head, self.d_per_head)
             return torch.einsum("hblk,blthk->hblt", q, loc) / math.sqrt(self.d_per_head)
         # 'cond': per-token weights over the spatial features + a per-token bias, then sigmoid
         B, L, _ = residual.shape
-        w = self.lang_cond_fc(residual).view(B, L, self.spatial_n_head, self.spatial_dim + 1)
+        w = hipops.module_linear(self.lang_cond_fc, residual).view(
+            B, L, self.spatial_n_head, self.spatial_dim + 1)
         w = w.permute(2, 0, 1, 3)                                                 # (h?, B, L, 1+S)
         if self.spatial_n_head == 1:
             w = w.expand(self.n_head, -1, -1, -1)
@@ -77,9 +80,9 @@ class MultiHeadAttentionSpatial(nn.Module):
 
     def forward(self, q, k, v, pairwise_locs, key_padding_mask=None, txt_embeds=None):
         residual = q
-        qh = self._heads(self.w_qs(q))
-        kh = self._heads(self.w_ks(k))
-        vh = self._heads(self.w_vs(v))
+        qh = self._heads(hipops.module_linear(self.w_qs, q))
+        kh = self._heads(hipops.module_linear(self.w_ks, k))
+        vh = self._heads(hipops.module_linear(self.w_vs, v))
         attn = torch.einsum("hblk,hbtk->hblt", qh, kh) / math.sqrt(self.d_per_head)
         loc = self._loc_term(residual, qh, pairwise_locs)
         multiplicative = self.spatial_attn_fusion in ("mul", "cond")
@@ -100,7 +103,7 @@ class MultiHeadAttentionSpatial(nn.Module):
         out = torch.einsum("hblt,hbtv->hblv", fused, vh)
         B, L = q.shape[:2]
         out = out.permute(1, 2, 0, 3).reshape(B, L, self.d_model)
-        out = self.dropout(self.fc(out))
+        out = self.dropout(hipops.module_linear(self.fc, out))
         out = self.layer_norm(out + residual)
         return out, fused
 
@@ -126,7 +129,11 @@ class TransformerEncoderLayer(nn.Module):
         self.prenorm = prenorm
 
     def _ffn(self, x):
-        return self.linear2(self.dropout(self.activation(self.linear1(x))))
+        if self.activation is F.gelu:     # GELU rides in the first GEMM's epilogue
+            h = hipops.module_linear(self.linear1, x, gelu=True)
+        else:
+            h = self.activation(hipops.module_linear(self.linear1, x))
+        return hipops.module_linear(self.linear2, self.dropout(h))
 
     def forward(self, tgt, tgt_mask: Optional[Tensor] = None,
                 tgt_key_padding_mask: Optional[Tensor] = None):
