@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
                                                        float *__restrict__ C, int ldc,
                                                        const float *__restrict__ bias,
                                                        float *__restrict__ Cpre, int flags,
-                                                       float beta, int a_vec, int b_vec) {
+                                                       float beta, int a_vec, int b_vec,
+                                                       int slabs_per_split) {
   __shared__ __attribute__((aligned(16))) float smem[4 * TILE_FLOATS];
   float *const As = smem;                       // [2][TILE_FLOATS]
   float *const Bs = smem + 2 * TILE_FLOATS;     // [2][TILE_FLOATS]
@@ -109,19 +110,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // split-K: blockIdx.z owns slabs [kbeg, kend); partial sums meet in C by atomicAdd
+  const int nk_all = (K + BK - 1) / BK;
+  const int kbeg = blockIdx.z * slabs_per_split;
+  const int kend = min(nk_all, kbeg + slabs_per_split);
+  const int nk = kend - kbeg;
+  if (nk <= 0) return;
+
   float4 ra[2], rb[2];
-  load_tile<A_KC>(A, lda, m0, 0, M, K, a_vec, ra);
-  load_tile<B_KC>(B, ldb, n0, 0, N, K, b_vec, rb);
+  load_tile<A_KC>(A, lda, m0, kbeg * BK, M, K, a_vec, ra);
+  load_tile<B_KC>(B, ldb, n0, kbeg * BK, N, K, b_vec, rb);
   store_tile<A_KC>(As, ra);
   store_tile<B_KC>(Bs, rb);
   __syncthreads();
 
-  const int nk = (K + BK - 1) / BK;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {                               // prefetch the next slab into registers
-      load_tile<A_KC>(A, lda, m0, (kt + 1) * BK, M, K, a_vec, ra);
-      load_tile<B_KC>(B, ldb, n0, (kt + 1) * BK, N, K, b_vec, rb);
+      load_tile<A_KC>(A, lda, m0, (kbeg + kt + 1) * BK, M, K, a_vec, ra);
+      load_tile<B_KC>(B, ldb, n0, (kbeg + kt + 1) * BK, N, K, b_vec, rb);
     }
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
   for (int rn = 0; rn < 2; ++rn) {
     const int col = n0 + wn * 32 + rn * 16 + i;
     if (col >= N) continue;
-    const float bv = bias ? bias[col] : 0.f;
+    const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
 #pragma unroll
     for (int rm = 0; rm < 2; ++rm)
 #pragma unroll
@@ -159,6 +166,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
         if (row >= M) continue;
         float v = acc[rm][rn][r] + bv;
         const size_t o = (size_t)row * ldc + col;
+        if (gridDim.z > 1) {          // C was zeroed (beta == 0) or holds the value to add to
+          atomicAdd(C + o, v);
+          continue;
+        }
         if (beta != 0.f) v += beta * C[o];
         if (flags & 1) {
           if (Cpre) Cpre[o] = v;
@@ -218,11 +229,29 @@ int msr3d_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float *A, int 
   if (M < 0 || N < 0 || K < 0 || lda <= 0 || ldb <= 0 || ldc <= 0) return MSR3D_EINVAL;
   if (M == 0 || N == 0) return 0;
   if (!A || !B || !C) return MSR3D_EINVAL;
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
-  const int av = vec_ok(A, lda), bv = vec_ok(B, ldb);
+  const int tiles = ((N + BN - 1) / BN) * ((M + BM - 1) / BM);
+  const int slabs = (K + BK - 1) / BK;
+  // Every GEMM of this path has one short side (256) and M = 960 tokens: few tiles, long K.
+  // Split K until ~2 workgroups per CU exist, keeping >= 2 slabs per split.  The fused GELU
+  // needs the complete sum, and beta must be 0 or 1 for the atomic meeting point.
+  int splits = 1;
+  if (!(flags & 1) && (beta == 0.f || beta == 1.f) && tiles < 256 && slabs >= 4) {
+    splits = (512 + tiles - 1) / tiles;
+    if (splits > slabs / 2) splits = slabs / 2;
+    if (splits < 1) splits = 1;
+  }
+  const int per = (slabs + splits - 1) / splits;
+  splits = (slabs + per - 1) / per;
   hipStream_t st = (hipStream_t)stream;
+  if (splits > 1 && beta == 0.f) {
+    if (ldc != N) return MSR3D_EINVAL;          // split path zeroes a dense C
+    hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits);
+  const int av = vec_ok(A, lda), bv = vec_ok(B, ldb);
 #define LAUNCH(AK, BKc) \
-  gemm_f32_kernel<AK, BKc><<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags, beta, av, bv)
+  gemm_f32_kernel<AK, BKc><<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags, beta, av, bv, per)
   if (a_kc && b_kc) LAUNCH(true, true);
   else if (a_kc && !b_kc) LAUNCH(true, false);
   else if (!a_kc && !b_kc) LAUNCH(false, false);
