@@ -147,6 +147,28 @@ int msr3d_colsum_f32(int M, int N, const float *X, int ldx, float *out, int accu
 int msr3d_gelu_bwd_f32(long long n, const float *dy, const float *pre, float *out,
                        msr3d_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * Core of MultiHeadAttentionSpatial, 'cond' fusion
+ * (/root/reference/modules/layers/transformers.py:205-248): scores, spatial term
+ * sigmoid(w . pairwise_locs + bias), log-clamp, key-padding mask, softmax, P V.
+ * q, k, v: token-major (B*L, ld_qkv) with head h in columns [h*dh, (h+1)*dh);
+ * cond (B*L, H*(spatial_dim+1)) = lang_cond_fc(x) as [bias, w_0..w_4] per head;
+ * pairwise_locs (B, L, L, spatial_dim); key_padding_mask (B, L) bytes, non-zero = padded;
+ * ctx (B*L, H*dh); probs (B, H, L, L) (may be NULL in forward-only use).
+ * Supported: L <= 64, dh = 32, spatial_dim = 5; anything else -> MSR3D_EINVAL.
+ * ------------------------------------------------------------------------- */
+int msr3d_spatial_attn_fwd(int B, int L, int H, int dh, int spatial_dim, const float *q,
+                           const float *k, const float *v, int ld_qkv, const float *cond,
+                           const float *pairwise_locs, const unsigned char *key_padding_mask,
+                           float *ctx, float *probs, msr3d_stream_t stream);
+
+/* Gradients w.r.t. q, k, v (token-major, ld_grad) and cond, given dctx (B*L, H*dh). */
+int msr3d_spatial_attn_bwd(int B, int L, int H, int dh, int spatial_dim, const float *q,
+                           const float *k, const float *v, int ld_qkv, const float *cond,
+                           const float *pairwise_locs, const unsigned char *key_padding_mask,
+                           const float *probs, const float *dctx, float *dq, float *dk, float *dv,
+                           int ld_grad, float *dcond, msr3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

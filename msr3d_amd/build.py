@@ -25,6 +25,7 @@ SOURCES = [
     ("pn2_ops.hip", ["-ffp-contract=off"]),
     ("sa_fused.hip", ["-ffp-contract=off"]),
     ("gemm_f32.hip", []),
+    ("attn_spatial.hip", []),
 ]
 
 

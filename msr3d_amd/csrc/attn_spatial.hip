@@ -1,0 +1,344 @@
+// attn_spatial.hip -- the core of MultiHeadAttentionSpatial with 'cond' fusion
+// (/root/reference/modules/layers/transformers.py:200-252), forward and backward, one
+// workgroup per (sample, head):
+//
+//   s[l,t]   = (q_l . k_t) / sqrt(dh)                                       (:205)
+//   z[l,t]   = bias[l] + sum_d w[l,d] * pairwise_locs[b,l,t,d]              (:225-226)
+//   loc      = sigmoid(z);  padded keys: s = -inf, loc = 0                   (:227,229-235)
+//   P        = softmax_t( log(max(loc, 1e-6)) + s )                          (:241-244)
+//   ctx_l    = sum_t P[l,t] v_t                                              (:248)
+//
+// The reference spends ~25 launches per layer on this (einsum / rearrange / masked_fill /
+// sigmoid / clamp / log / softmax / einsum) and a host sync (`assert isnan`, :246); here it
+// is one launch forward and one backward.  The four small matrix products of each
+// direction run on f32-input MFMA (16x16x4) from LDS tiles; softmax and the spatial
+// term are applied on the accumulators (row statistics by DPP inside the 16-lane rows of
+// the MFMA C/D layout).  fp32 like the reference (autocast is disabled around the
+// encoder, model/ose3d_situation.py:377).
+//
+// Shapes: L <= 64 tokens (60 objects, or 61 with the agent token), dh = 32, spatial_dim = 5,
+// one (bias, w[5]) sextet per (token, head) in `cond` (B*L, H*6).  Larger L takes the
+// composite path on the host side.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "../../include/msr3d_hip.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int LT = 64;        // token tile (queries and keys)
+constexpr int DH = 32;        // head dim
+constexpr int SD = 5;         // spatial dims
+constexpr int LD32 = DH + 4;  // [64][36] tiles
+constexpr int LD64 = LT + 4;  // [64][68] tiles
+constexpr float kSqrtDh = 5.656854249492381f;   // sqrt(32): s = dot / this (a division, as :205)
+
+// acc[rn] += sum_{k<KD} a(row0+i.., k) * b(rn*16+.., k) for this wave's 16-row strip.
+// a(r,k) = A_KC ? As[r*lda + k] : As[k*lda + r];  b(c,k) likewise.  Standard 16x16x4 operand
+// map: lane (i = lane&15, g = lane>>4) supplies element (i, k0+g).
+template <int RN, int KD, bool A_KC, bool B_KC>
+__device__ __forceinline__ void strip_mma(const float *As, int lda, const float *Bs, int ldb,
+                                          int row0, f32x4 (&acc)[RN], int lane) {
+  const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int k0 = 0; k0 < KD; k0 += 4) {
+    const int k = k0 + g;
+    const float a = A_KC ? As[(row0 + i) * lda + k] : As[k * lda + row0 + i];
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn) {
+      const float b = B_KC ? Bs[(rn * 16 + i) * ldb + k] : Bs[k * ldb + rn * 16 + i];
+      acc[rn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[rn], 0, 0, 0);
+    }
+  }
+}
+
+// reductions over the 16 lanes of a DPP row (= one row group of the C/D layout)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL,
+                                                    0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return v;
+}
+
+// token-major (B*L, ld) head slice -> LDS [64][36], rows >= L zero
+__device__ __forceinline__ void load_head_tile(const float *__restrict__ src, int ld, int b, int h,
+                                               int L, float *dst) {
+  for (int e = threadIdx.x; e < LT * (DH / 4); e += 256) {
+    const int row = e >> 3, c4 = (e & 7) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < L) v = *reinterpret_cast<const float4 *>(src + ((size_t)b * L + row) * ld + h * DH + c4);
+    *reinterpret_cast<float4 *>(dst + row * LD32 + c4) = v;
+  }
+}
+
+struct RowCond { float bias, w[SD]; };
+
+__device__ __forceinline__ RowCond load_cond(const float *__restrict__ cond, int H, int b, int h,
+                                             int L, int row) {
+  RowCond c;
+  c.bias = 0.f;
+#pragma unroll
+  for (int d = 0; d < SD; ++d) c.w[d] = 0.f;
+  if (row < L) {
+    const float *p = cond + ((size_t)b * L + row) * (H * (SD + 1)) + h * (SD + 1);
+    c.bias = p[0];
+#pragma unroll
+    for (int d = 0; d < SD; ++d) c.w[d] = p[1 + d];
+  }
+  return c;
+}
+
+// =================================================================================
+// forward.  grid (H, B), 256 threads; wave w owns query rows [16w, 16w+16).
+// =================================================================================
+__global__ __launch_bounds__(256) void attn_fwd_kernel(int B, int L, int H,
+                                                       const float *__restrict__ q,
+                                                       const float *__restrict__ k,
+                                                       const float *__restrict__ v, int ldqkv,
+                                                       const float *__restrict__ cond,
+                                                       const float *__restrict__ ploc,
+                                                       const unsigned char *__restrict__ pad,
+                                                       float *__restrict__ ctx,
+                                                       float *__restrict__ probs) {
+  __shared__ __attribute__((aligned(16))) float sq[LT * LD32], sk[LT * LD32], sv[LT * LD32];
+  __shared__ __attribute__((aligned(16))) float sp[LT * LD64];
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4, row0 = wave * 16;
+  load_head_tile(q, ldqkv, b, h, L, sq);
+  load_head_tile(k, ldqkv, b, h, L, sk);
+  load_head_tile(v, ldqkv, b, h, L, sv);
+  __syncthreads();
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int rn = 0; rn < 4; ++rn) acc[rn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  strip_mma<4, DH, true, true>(sq, LD32, sk, LD32, row0, acc, lane);
+
+  // logits on the accumulators: element (row = row0 + 4g + r, col = 16 rn + i)
+  float mx[4], sm[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + 4 * g + r;
+    const RowCond c = load_cond(cond, H, b, h, L, row);
+    float m = -INFINITY;
+#pragma unroll
+    for (int rn = 0; rn < 4; ++rn) {
+      const int col = rn * 16 + i;
+      float lg = -INFINITY;
+      if (row < L && col < L && !pad[(size_t)b * L + col]) {
+        const float *pl = ploc + (((size_t)b * L + row) * L + col) * SD;
+        float z = c.bias;
+#pragma unroll
+        for (int d = 0; d < SD; ++d) z = fmaf(c.w[d], pl[d], z);
+        const float loc = 1.0f / (1.0f + expf(-z));
+        lg = logf(fmaxf(loc, 1e-6f)) + acc[rn][r] / kSqrtDh;
+      }
+      acc[rn][r] = lg;
+      m = fmaxf(m, lg);
+    }
+    mx[r] = row16_max(m);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int rn = 0; rn < 4; ++rn) {
+      const float e = (acc[rn][r] == -INFINITY) ? 0.f : expf(acc[rn][r] - mx[r]);
+      acc[rn][r] = e;
+      s += e;
+    }
+    sm[r] = row16_sum(s);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + 4 * g + r;
+    const float inv = 1.0f / sm[r];      // a fully padded row gives NaN, as the reference would
+#pragma unroll
+    for (int rn = 0; rn < 4; ++rn) {
+      const int col = rn * 16 + i;
+      const float p = (row < L) ? acc[rn][r] * inv : 0.f;
+      sp[row * LD64 + col] = p;
+      if (probs && row < L && col < L) probs[(((size_t)b * H + h) * L + row) * L + col] = p;
+    }
+  }
+  __syncthreads();
+
+  f32x4 o[2];
+  o[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  o[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  strip_mma<2, LT, true, false>(sp, LD64, sv, LD32, row0, o, lane);   // ctx = P V
+#pragma unroll
+  for (int rn = 0; rn < 2; ++rn)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * g + r;
+      if (row < L) ctx[((size_t)b * L + row) * (H * DH) + h * DH + rn * 16 + i] = o[rn][r];
+    }
+}
+
+// =================================================================================
+// backward.  Inputs as forward + probs (saved) + dctx; outputs dq, dk, dv (token-major,
+// ld = ldg) and dcond (B*L, H*6).  pairwise_locs and the mask get no gradient.
+// =================================================================================
+__global__ __launch_bounds__(256) void attn_bwd_kernel(int B, int L, int H,
+                                                       const float *__restrict__ q,
+                                                       const float *__restrict__ k,
+                                                       const float *__restrict__ v, int ldqkv,
+                                                       const float *__restrict__ cond,
+                                                       const float *__restrict__ ploc,
+                                                       const unsigned char *__restrict__ pad,
+                                                       const float *__restrict__ probs,
+                                                       const float *__restrict__ dctx,
+                                                       float *__restrict__ dq,
+                                                       float *__restrict__ dk,
+                                                       float *__restrict__ dv, int ldg,
+                                                       float *__restrict__ dcond) {
+  __shared__ __attribute__((aligned(16))) float sq[LT * LD32], sk[LT * LD32], sv[LT * LD32],
+      sdo[LT * LD32];
+  __shared__ __attribute__((aligned(16))) float sp[LT * LD64];   // P, then dS in place
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4, row0 = wave * 16;
+  load_head_tile(q, ldqkv, b, h, L, sq);
+  load_head_tile(k, ldqkv, b, h, L, sk);
+  load_head_tile(v, ldqkv, b, h, L, sv);
+  load_head_tile(dctx, H * DH, b, h, L, sdo);
+  for (int e = threadIdx.x; e < LT * LT; e += 256) {
+    const int row = e >> 6, col = e & 63;
+    sp[row * LD64 + col] = (row < L && col < L) ? probs[(((size_t)b * H + h) * L + row) * L + col] : 0.f;
+  }
+  __syncthreads();
+
+  // dP = dctx V^T   (rows = queries, cols = keys)
+  f32x4 acc[4];
+#pragma unroll
+  for (int rn = 0; rn < 4; ++rn) acc[rn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  strip_mma<4, DH, true, true>(sdo, LD32, sv, LD32, row0, acc, lane);
+  // dv = P^T dctx (rows = keys) while P is still intact
+  f32x4 ov[2];
+  ov[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  ov[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  strip_mma<2, LT, false, false>(sp, LD64, sdo, LD32, row0, ov, lane);
+  __syncthreads();                       // every wave is done reading P as a matrix operand
+
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + 4 * g + r;
+    float dot = 0.f;
+    float p[4];
+#pragma unroll
+    for (int rn = 0; rn < 4; ++rn) {
+      p[rn] = sp[row * LD64 + rn * 16 + i];
+      dot = fmaf(p[rn], acc[rn][r], dot);
+    }
+    dot = row16_sum(dot);
+    const RowCond c = load_cond(cond, H, b, h, L, row);
+    float gb = 0.f, gw[SD];
+#pragma unroll
+    for (int d = 0; d < SD; ++d) gw[d] = 0.f;
+#pragma unroll
+    for (int rn = 0; rn < 4; ++rn) {
+      const int col = rn * 16 + i;
+      const float dlogit = p[rn] * (acc[rn][r] - dot);     // softmax backward
+      sp[row * LD64 + col] = dlogit;         // in place: this lane owns the element
+      if (row < L && col < L && !pad[(size_t)b * L + col]) {
+        const float *pl = ploc + (((size_t)b * L + row) * L + col) * SD;
+        float z = c.bias;
+#pragma unroll
+        for (int d = 0; d < SD; ++d) z = fmaf(c.w[d], pl[d], z);
+        const float loc = 1.0f / (1.0f + expf(-z));
+        // d log(max(loc,1e-6)) / dz = (1 - loc) where the clamp is inactive, else 0
+        const float dz = (loc >= 1e-6f) ? dlogit * (1.0f - loc) : 0.f;
+        gb += dz;
+#pragma unroll
+        for (int d = 0; d < SD; ++d) gw[d] = fmaf(dz, pl[d], gw[d]);
+      }
+    }
+    gb = row16_sum(gb);
+#pragma unroll
+    for (int d = 0; d < SD; ++d) gw[d] = row16_sum(gw[d]);
+    if (i == 0 && row < L) {
+      float *o = dcond + ((size_t)b * L + row) * (H * (SD + 1)) + h * (SD + 1);
+      o[0] = gb;
+#pragma unroll
+      for (int d = 0; d < SD; ++d) o[1 + d] = gw[d];
+    }
+  }
+  __syncthreads();
+
+  // dq = (dS K) / sqrt(dh): rows = queries;  dk = (dS^T Q) / sqrt(dh), dv = P^T dctx: rows = keys
+  f32x4 oq[2], ok[2];
+#pragma unroll
+  for (int rn = 0; rn < 2; ++rn) {
+    oq[rn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ok[rn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  strip_mma<2, LT, true, false>(sp, LD64, sk, LD32, row0, oq, lane);
+  strip_mma<2, LT, false, false>(sp, LD64, sq, LD32, row0, ok, lane);
+#pragma unroll
+  for (int rn = 0; rn < 2; ++rn)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * g + r;
+      if (row < L) {
+        const size_t o = ((size_t)b * L + row) * ldg + h * DH + rn * 16 + i;
+        dq[o] = oq[rn][r] / kSqrtDh;
+        dk[o] = ok[rn][r] / kSqrtDh;
+        dv[o] = ov[rn][r];
+      }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int msr3d_spatial_attn_fwd(int B, int L, int H, int dh, int spatial_dim, const float *q,
+                           const float *k, const float *v, int ld_qkv, const float *cond,
+                           const float *pairwise_locs, const unsigned char *key_padding_mask,
+                           float *ctx, float *probs, msr3d_stream_t stream) {
+  if (B < 0 || L <= 0 || L > LT || H <= 0 || dh != DH || spatial_dim != SD) return MSR3D_EINVAL;
+  if (B == 0) return 0;
+  if (!q || !k || !v || !cond || !pairwise_locs || !key_padding_mask || !ctx) return MSR3D_EINVAL;
+  if (ld_qkv % 4 != 0) return MSR3D_EINVAL;
+  attn_fwd_kernel<<<dim3(H, B), 256, 0, (hipStream_t)stream>>>(B, L, H, q, k, v, ld_qkv, cond,
+                                                             pairwise_locs, key_padding_mask, ctx,
+                                                             probs);
+  return (int)hipGetLastError();
+}
+
+int msr3d_spatial_attn_bwd(int B, int L, int H, int dh, int spatial_dim, const float *q,
+                           const float *k, const float *v, int ld_qkv, const float *cond,
+                           const float *pairwise_locs, const unsigned char *key_padding_mask,
+                           const float *probs, const float *dctx, float *dq, float *dk, float *dv,
+                           int ld_grad, float *dcond, msr3d_stream_t stream) {
+  if (B < 0 || L <= 0 || L > LT || H <= 0 || dh != DH || spatial_dim != SD) return MSR3D_EINVAL;
+  if (B == 0) return 0;
+  if (!q || !k || !v || !cond || !pairwise_locs || !key_padding_mask || !probs || !dctx || !dq ||
+      !dk || !dv || !dcond)
+    return MSR3D_EINVAL;
+  if (ld_qkv % 4 != 0) return MSR3D_EINVAL;
+  attn_bwd_kernel<<<dim3(H, B), 256, 0, (hipStream_t)stream>>>(
+      B, L, H, q, k, v, ld_qkv, cond, pairwise_locs, key_padding_mask, probs, dctx, dq, dk, dv,
+      ld_grad, dcond);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

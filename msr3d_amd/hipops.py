@@ -85,9 +85,9 @@ class _HipLinear(torch.autograd.Function):
 
 def linear(x, weight, bias=None, gelu=False):
     """F.linear (optionally followed by exact GELU) on the HIP GEMM for GPU fp32 tensors."""
-    if x.is_cuda:
-        if x.dtype != torch.float32 or weight.dtype != torch.float32:
-            raise RuntimeError("msr3d_amd.hipops.linear: fp32 tensors expected on the GPU path")
+    if x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32:
+        # (the path is fp32; other dtypes -- e.g. the float64 references of the tests -- are not
+        # part of it and use torch's own GEMM)
         if gelu and weight.shape[0] % 4 != 0:
             raise RuntimeError("fused GELU needs an output width that is a multiple of 4")
         return _HipLinear.apply(x, weight, bias, gelu)
@@ -98,3 +98,59 @@ def linear(x, weight, bias=None, gelu=False):
 def module_linear(mod, x, gelu=False):
     """Apply an nn.Linear module through `linear` (its parameters stay where they are)."""
     return linear(x, mod.weight, mod.bias, gelu=gelu)
+
+
+# ---------------------------------------------------------------------------------------
+# fused spatial attention core ('cond' fusion)
+# ---------------------------------------------------------------------------------------
+class _SpatialAttnCond(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, cond, pairwise_locs, pad_mask, n_head):
+        B, L, D = q.shape
+        dh = D // n_head
+        q2, k2, v2 = (t.reshape(B * L, D).contiguous() for t in (q, k, v))
+        cond2 = cond.reshape(B * L, -1).contiguous()
+        pl = pairwise_locs.contiguous()
+        pad = pad_mask.contiguous().view(torch.uint8)
+        out = torch.empty((B * L, D), dtype=torch.float32, device=q.device)
+        probs = torch.empty((B, n_head, L, L), dtype=torch.float32, device=q.device)
+        lib = _lib.load()
+        with torch.cuda.device(q.device):
+            rc = lib.msr3d_spatial_attn_fwd(B, L, n_head, dh, pl.shape[-1], _p(q2), _p(k2), _p(v2), D,
+                                            _p(cond2), _p(pl), _p(pad), _p(out), _p(probs),
+                                            _lib.current_stream_ptr(q.device))
+        _lib.check(rc, "msr3d_spatial_attn_fwd")
+        ctx.save_for_backward(q2, k2, v2, cond2, pl, pad, probs)
+        ctx.dims = (B, L, D, n_head, dh)
+        ctx.mark_non_differentiable(probs)
+        return out.view(B, L, D), probs
+
+    @staticmethod
+    def backward(ctx, dout, _dprobs):
+        q2, k2, v2, cond2, pl, pad, probs = ctx.saved_tensors
+        B, L, D, H, dh = ctx.dims
+        do = dout.reshape(B * L, D).contiguous()
+        dq, dk, dv = (torch.empty_like(q2) for _ in range(3))
+        dcond = torch.empty_like(cond2)
+        lib = _lib.load()
+        with torch.cuda.device(do.device):
+            rc = lib.msr3d_spatial_attn_bwd(B, L, H, dh, pl.shape[-1], _p(q2), _p(k2), _p(v2), D,
+                                            _p(cond2), _p(pl), _p(pad), _p(probs), _p(do), _p(dq),
+                                            _p(dk), _p(dv), D, _p(dcond),
+                                            _lib.current_stream_ptr(do.device))
+        _lib.check(rc, "msr3d_spatial_attn_bwd")
+        shp = (B, L, D)
+        return dq.view(shp), dk.view(shp), dv.view(shp), dcond.view(B, L, -1), None, None, None
+
+
+def spatial_attn_cond_supported(q, n_head, spatial_dim, spatial_n_head):
+    B, L, D = q.shape
+    return (q.is_cuda and q.dtype == torch.float32 and L <= 64 and D // n_head == 32
+            and spatial_dim == 5 and spatial_n_head == n_head)
+
+
+def spatial_attn_cond(q, k, v, cond, pairwise_locs, key_padding_mask, n_head):
+    """q,k,v (B,L,D) already projected; cond (B,L,H*6); -> ctx (B,L,D), probs (B,H,L,L)."""
+    if key_padding_mask is None:
+        key_padding_mask = torch.zeros(q.shape[:2], dtype=torch.bool, device=q.device)
+    return _SpatialAttnCond.apply(q, k, v, cond, pairwise_locs, key_padding_mask, n_head)

@@ -80,6 +80,16 @@ class MultiHeadAttentionSpatial(nn.Module):
 
     def forward(self, q, k, v, pairwise_locs, key_padding_mask=None, txt_embeds=None):
         residual = q
+        if (self.spatial_attn_fusion == "cond" and getattr(self, "use_fused_core", True)
+                and hipops.spatial_attn_cond_supported(
+                    q, self.n_head, self.spatial_dim, self.spatial_n_head)):
+            # fused HIP core: scores + spatial term + mask + softmax + PV in one launch
+            ctx, probs = hipops.spatial_attn_cond(
+                hipops.module_linear(self.w_qs, q), hipops.module_linear(self.w_ks, k),
+                hipops.module_linear(self.w_vs, v), hipops.module_linear(self.lang_cond_fc, residual),
+                pairwise_locs, key_padding_mask, self.n_head)
+            out = self.dropout(hipops.module_linear(self.fc, ctx))
+            return self.layer_norm(out + residual), probs.permute(1, 0, 2, 3)
         qh = self._heads(hipops.module_linear(self.w_qs, q))
         kh = self._heads(hipops.module_linear(self.w_ks, k))
         vh = self._heads(hipops.module_linear(self.w_vs, v))
