@@ -139,6 +139,12 @@ int msr3d_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float *A, int 
                    const float *B, int ldb, float *C, int ldc, const float *bias, float *C_pre,
                    int flags, float beta, msr3d_stream_t stream);
 
+/* Weight AND bias gradient of y = x W^T + b in one launch: dw_db is a dense buffer of
+ * N_out*K_in + N_out floats; on return dw_db[0 .. N_out*K_in) = dy^T x  (N_out x K_in) and
+ * dw_db[N_out*K_in ..) = column sums of dy.  dy (M_tokens x N_out), x (M_tokens x K_in). */
+int msr3d_linear_wgrad_f32(int M_tokens, int N_out, int K_in, const float *dy, const float *x,
+                           float *dw_db, msr3d_stream_t stream);
+
 /* out[n] (+)= sum_m X[m*ldx + n]  (bias gradient). */
 int msr3d_colsum_f32(int M, int N, const float *X, int ldx, float *out, int accumulate,
                      msr3d_stream_t stream);
@@ -152,22 +158,25 @@ int msr3d_gelu_bwd_f32(long long n, const float *dy, const float *pre, float *ou
  * (/root/reference/modules/layers/transformers.py:205-248): scores, spatial term
  * sigmoid(w . pairwise_locs + bias), log-clamp, key-padding mask, softmax, P V.
  * q, k, v: token-major (B*L, ld_qkv) with head h in columns [h*dh, (h+1)*dh);
- * cond (B*L, H*(spatial_dim+1)) = lang_cond_fc(x) as [bias, w_0..w_4] per head;
+ * cond (B*L, ld_cond >= H*(spatial_dim+1)) = lang_cond_fc(x) as [bias, w_0..w_4] per head
+ * (q, k, v and cond may be column blocks of ONE packed projection output);
  * pairwise_locs (B, L, L, spatial_dim); key_padding_mask (B, L) bytes, non-zero = padded;
  * ctx (B*L, H*dh); probs (B, H, L, L) (may be NULL in forward-only use).
  * Supported: L <= 64, dh = 32, spatial_dim = 5; anything else -> MSR3D_EINVAL.
  * ------------------------------------------------------------------------- */
 int msr3d_spatial_attn_fwd(int B, int L, int H, int dh, int spatial_dim, const float *q,
                            const float *k, const float *v, int ld_qkv, const float *cond,
-                           const float *pairwise_locs, const unsigned char *key_padding_mask,
-                           float *ctx, float *probs, msr3d_stream_t stream);
+                           int ld_cond, const float *pairwise_locs,
+                           const unsigned char *key_padding_mask, float *ctx, float *probs,
+                           msr3d_stream_t stream);
 
 /* Gradients w.r.t. q, k, v (token-major, ld_grad) and cond, given dctx (B*L, H*dh). */
 int msr3d_spatial_attn_bwd(int B, int L, int H, int dh, int spatial_dim, const float *q,
                            const float *k, const float *v, int ld_qkv, const float *cond,
-                           const float *pairwise_locs, const unsigned char *key_padding_mask,
-                           const float *probs, const float *dctx, float *dq, float *dk, float *dv,
-                           int ld_grad, float *dcond, msr3d_stream_t stream);
+                           int ld_cond, const float *pairwise_locs,
+                           const unsigned char *key_padding_mask, const float *probs,
+                           const float *dctx, float *dq, float *dk, float *dv, int ld_grad,
+                           float *dcond, int ld_dcond, msr3d_stream_t stream);
 
 #ifdef __cplusplus
 }

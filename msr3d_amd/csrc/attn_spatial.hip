@@ -89,14 +89,14 @@ __device__ __forceinline__ void load_head_tile(const float *__restrict__ src, in
 
 struct RowCond { float bias, w[SD]; };
 
-__device__ __forceinline__ RowCond load_cond(const float *__restrict__ cond, int H, int b, int h,
+__device__ __forceinline__ RowCond load_cond(const float *__restrict__ cond, int ldc, int b, int h,
                                              int L, int row) {
   RowCond c;
   c.bias = 0.f;
 #pragma unroll
   for (int d = 0; d < SD; ++d) c.w[d] = 0.f;
   if (row < L) {
-    const float *p = cond + ((size_t)b * L + row) * (H * (SD + 1)) + h * (SD + 1);
+    const float *p = cond + ((size_t)b * L + row) * ldc + h * (SD + 1);
     c.bias = p[0];
 #pragma unroll
     for (int d = 0; d < SD; ++d) c.w[d] = p[1 + d];
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int B, int L, int H,
                                                        const float *__restrict__ q,
                                                        const float *__restrict__ k,
                                                        const float *__restrict__ v, int ldqkv,
-                                                       const float *__restrict__ cond,
+                                                       const float *__restrict__ cond, int ldc,
                                                        const float *__restrict__ ploc,
                                                        const unsigned char *__restrict__ pad,
                                                        float *__restrict__ ctx,
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int B, int L, int H,
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = row0 + 4 * g + r;
-    const RowCond c = load_cond(cond, H, b, h, L, row);
+    const RowCond c = load_cond(cond, ldc, b, h, L, row);
     float m = -INFINITY;
 #pragma unroll
     for (int rn = 0; rn < 4; ++rn) {
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(int B, int L, int H,
                                                        const float *__restrict__ q,
                                                        const float *__restrict__ k,
                                                        const float *__restrict__ v, int ldqkv,
-                                                       const float *__restrict__ cond,
+                                                       const float *__restrict__ cond, int ldc,
                                                        const float *__restrict__ ploc,
                                                        const unsigned char *__restrict__ pad,
                                                        const float *__restrict__ probs,
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(int B, int L, int H,
                                                        float *__restrict__ dq,
                                                        float *__restrict__ dk,
                                                        float *__restrict__ dv, int ldg,
-                                                       float *__restrict__ dcond) {
+                                                       float *__restrict__ dcond, int lddc) {
   __shared__ __attribute__((aligned(16))) float sq[LT * LD32], sk[LT * LD32], sv[LT * LD32],
       sdo[LT * LD32];
   __shared__ __attribute__((aligned(16))) float sp[LT * LD64];   // P, then dS in place
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(int B, int L, int H,
       dot = fmaf(p[rn], acc[rn][r], dot);
     }
     dot = row16_sum(dot);
-    const RowCond c = load_cond(cond, H, b, h, L, row);
+    const RowCond c = load_cond(cond, ldc, b, h, L, row);
     float gb = 0.f, gw[SD];
 #pragma unroll
     for (int d = 0; d < SD; ++d) gw[d] = 0.f;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(int B, int L, int H,
 #pragma unroll
     for (int d = 0; d < SD; ++d) gw[d] = row16_sum(gw[d]);
     if (i == 0 && row < L) {
-      float *o = dcond + ((size_t)b * L + row) * (H * (SD + 1)) + h * (SD + 1);
+      float *o = dcond + ((size_t)b * L + row) * lddc + h * (SD + 1);
       o[0] = gb;
 #pragma unroll
       for (int d = 0; d < SD; ++d) o[1 + d] = gw[d];
@@ -312,23 +312,24 @@ extern "C" {
 
 int msr3d_spatial_attn_fwd(int B, int L, int H, int dh, int spatial_dim, const float *q,
                            const float *k, const float *v, int ld_qkv, const float *cond,
-                           const float *pairwise_locs, const unsigned char *key_padding_mask,
-                           float *ctx, float *probs, msr3d_stream_t stream) {
+                           int ld_cond, const float *pairwise_locs,
+                           const unsigned char *key_padding_mask, float *ctx, float *probs,
+                           msr3d_stream_t stream) {
   if (B < 0 || L <= 0 || L > LT || H <= 0 || dh != DH || spatial_dim != SD) return MSR3D_EINVAL;
   if (B == 0) return 0;
   if (!q || !k || !v || !cond || !pairwise_locs || !key_padding_mask || !ctx) return MSR3D_EINVAL;
   if (ld_qkv % 4 != 0) return MSR3D_EINVAL;
-  attn_fwd_kernel<<<dim3(H, B), 256, 0, (hipStream_t)stream>>>(B, L, H, q, k, v, ld_qkv, cond,
-                                                             pairwise_locs, key_padding_mask, ctx,
-                                                             probs);
+  attn_fwd_kernel<<<dim3(H, B), 256, 0, (hipStream_t)stream>>>(
+      B, L, H, q, k, v, ld_qkv, cond, ld_cond, pairwise_locs, key_padding_mask, ctx, probs);
   return (int)hipGetLastError();
 }
 
 int msr3d_spatial_attn_bwd(int B, int L, int H, int dh, int spatial_dim, const float *q,
                            const float *k, const float *v, int ld_qkv, const float *cond,
-                           const float *pairwise_locs, const unsigned char *key_padding_mask,
-                           const float *probs, const float *dctx, float *dq, float *dk, float *dv,
-                           int ld_grad, float *dcond, msr3d_stream_t stream) {
+                           int ld_cond, const float *pairwise_locs,
+                           const unsigned char *key_padding_mask, const float *probs,
+                           const float *dctx, float *dq, float *dk, float *dv, int ld_grad,
+                           float *dcond, int ld_dcond, msr3d_stream_t stream) {
   if (B < 0 || L <= 0 || L > LT || H <= 0 || dh != DH || spatial_dim != SD) return MSR3D_EINVAL;
   if (B == 0) return 0;
   if (!q || !k || !v || !cond || !pairwise_locs || !key_padding_mask || !probs || !dctx || !dq ||
@@ -336,8 +337,8 @@ int msr3d_spatial_attn_bwd(int B, int L, int H, int dh, int spatial_dim, const f
     return MSR3D_EINVAL;
   if (ld_qkv % 4 != 0) return MSR3D_EINVAL;
   attn_bwd_kernel<<<dim3(H, B), 256, 0, (hipStream_t)stream>>>(
-      B, L, H, q, k, v, ld_qkv, cond, pairwise_locs, key_padding_mask, probs, dctx, dq, dk, dv,
-      ld_grad, dcond);
+      B, L, H, q, k, v, ld_qkv, cond, ld_cond, pairwise_locs, key_padding_mask, probs, dctx, dq, dk,
+      dv, ld_grad, dcond, ld_dcond);
   return (int)hipGetLastError();
 }
 

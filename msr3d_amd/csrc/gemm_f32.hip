@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
                                                        const float *__restrict__ bias,
                                                        float *__restrict__ Cpre, int flags,
                                                        float beta, int a_vec, int b_vec,
-                                                       int slabs_per_split) {
+                                                       int slabs_per_split,
+                                                       float *__restrict__ a_colsum) {
   __shared__ __attribute__((aligned(16))) float smem[4 * TILE_FLOATS];
   float *const As = smem;                       // [2][TILE_FLOATS]
   float *const Bs = smem + 2 * TILE_FLOATS;     // [2][TILE_FLOATS]
@@ -124,6 +125,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
   store_tile<B_KC>(Bs, rb);
   __syncthreads();
 
+  // bias gradient for free: in the dW product (A = dy, k-strided) the A tiles of the first
+  // column of workgroups stream every dy element exactly once; thread t owns 4 columns
+  // (t & 15) * 4 .. +3 of the tile for 2 of the 32 k-rows per slab.
+  const bool do_colsum = (!A_KC) && a_colsum != nullptr && blockIdx.x == 0;
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (do_colsum) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) { csum.x += ra[p].x; csum.y += ra[p].y; csum.z += ra[p].z; csum.w += ra[p].w; }
+  }
+
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {                               // prefetch the next slab into registers
@@ -146,10 +157,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
             acc[rm][rn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[rm][s], fb[rn][s], acc[rm][rn], 0, 0, 0);
     }
     if (kt + 1 < nk) {
+      if (do_colsum) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { csum.x += ra[p].x; csum.y += ra[p].y; csum.z += ra[p].z; csum.w += ra[p].w; }
+      }
       store_tile<A_KC>(As + (cur ^ 1) * TILE_FLOATS, ra);             // other buffer: nobody reads it this round
       store_tile<B_KC>(Bs + (cur ^ 1) * TILE_FLOATS, rb);
     }
     __syncthreads();
+  }
+
+  if (do_colsum) {
+    // 16 threads (same t & 15) x 4 columns: reduce the 16 partial sums through LDS
+    float *red = smem;                               // all MFMA reads are behind the last barrier
+    *reinterpret_cast<float4 *>(red + threadIdx.x * 4) = csum;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int c = threadIdx.x;                     // column of the tile
+      float tot = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) tot += red[(j * 16 + (c >> 2)) * 4 + (c & 3)];
+      if (m0 + c < M) atomicAdd(a_colsum + m0 + c, tot);
+    }
   }
 
   // epilogue: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -223,9 +252,10 @@ inline bool vec_ok(const float *p, int ld) {
 
 extern "C" {
 
-int msr3d_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float *A, int lda,
-                   const float *B, int ldb, float *C, int ldc, const float *bias, float *C_pre,
-                   int flags, float beta, msr3d_stream_t stream) {
+static int gemm_f32_impl(int a_kc, int b_kc, int M, int N, int K, const float *A, int lda,
+                         const float *B, int ldb, float *C, int ldc, const float *bias,
+                         float *C_pre, int flags, float beta, float *a_colsum,
+                         msr3d_stream_t stream) {
   if (M < 0 || N < 0 || K < 0 || lda <= 0 || ldb <= 0 || ldc <= 0) return MSR3D_EINVAL;
   if (M == 0 || N == 0) return 0;
   if (!A || !B || !C) return MSR3D_EINVAL;
@@ -240,24 +270,46 @@ int msr3d_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float *A, int 
     if (splits > slabs / 2) splits = slabs / 2;
     if (splits < 1) splits = 1;
   }
-  const int per = (slabs + splits - 1) / splits;
-  splits = (slabs + per - 1) / per;
   hipStream_t st = (hipStream_t)stream;
-  if (splits > 1 && beta == 0.f) {
+  if (a_colsum) {
+    // dW + db in one launch: C (M x N, dense) is immediately followed by the M column sums,
+    // one memset establishes the zero both accumulate into
+    if (a_kc || ldc != N || a_colsum != C + (size_t)M * N || beta != 0.f) return MSR3D_EINVAL;
+    hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * ((size_t)M * N + M), st);
+    if (e != hipSuccess) return (int)e;
+    if (splits == 1) splits = slabs >= 2 ? 2 : 1;   // keep the atomic meeting point semantics
+    if (splits == 1) beta = 1.f;                    // single split: add onto the zeroed C
+  } else if (splits > 1 && beta == 0.f) {
     if (ldc != N) return MSR3D_EINVAL;          // split path zeroes a dense C
     hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, st);
     if (e != hipSuccess) return (int)e;
   }
+  const int per = (slabs + splits - 1) / splits;
+  splits = (slabs + per - 1) / per;
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits);
   const int av = vec_ok(A, lda), bv = vec_ok(B, ldb);
 #define LAUNCH(AK, BKc) \
-  gemm_f32_kernel<AK, BKc><<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags, beta, av, bv, per)
+  gemm_f32_kernel<AK, BKc><<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags, beta, av, bv, per, a_colsum)
   if (a_kc && b_kc) LAUNCH(true, true);
   else if (a_kc && !b_kc) LAUNCH(true, false);
   else if (!a_kc && !b_kc) LAUNCH(false, false);
   else LAUNCH(false, true);
 #undef LAUNCH
   return (int)hipGetLastError();
+}
+
+int msr3d_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float *A, int lda,
+                   const float *B, int ldb, float *C, int ldc, const float *bias, float *C_pre,
+                   int flags, float beta, msr3d_stream_t stream) {
+  return gemm_f32_impl(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags, beta,
+                       nullptr, stream);
+}
+
+int msr3d_linear_wgrad_f32(int M_tokens, int N_out, int K_in, const float *dy, const float *x,
+                           float *dw_db, msr3d_stream_t stream) {
+  if (!dw_db) return MSR3D_EINVAL;
+  return gemm_f32_impl(0, 0, N_out, K_in, M_tokens, dy, N_out, x, K_in, dw_db, K_in, nullptr,
+                       nullptr, 0, 0.f, dw_db + (size_t)N_out * K_in, stream);
 }
 
 int msr3d_colsum_f32(int M, int N, const float *X, int ldx, float *out, int accumulate,

@@ -74,12 +74,23 @@ class _HipLinear(torch.autograd.Function):
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
             _gemm(True, False, M, K, N, dy2, N, w, K, dx, K)          # dx = dy @ W
             dx = dx.reshape(ctx.x_shape)
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-            _gemm(False, False, N, K, M, dy2, N, x2, K, dw, K)        # dW = dy^T @ x
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty((N,), dtype=torch.float32, device=dy.device)
-            _colsum(dy2, M, N, db)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] and want_db:
+            # dW = dy^T @ x and db = colsum(dy) from ONE launch into one buffer
+            buf = torch.empty((N * K + N,), dtype=torch.float32, device=dy.device)
+            lib = _lib.load()
+            with torch.cuda.device(dy.device):
+                rc = lib.msr3d_linear_wgrad_f32(M, N, K, _p(dy2), _p(x2), _p(buf),
+                                                _lib.current_stream_ptr(dy.device))
+            _lib.check(rc, "msr3d_linear_wgrad_f32")
+            dw, db = buf[:N * K].view(N, K), buf[N * K:]
+        else:
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+                _gemm(False, False, N, K, M, dy2, N, x2, K, dw, K)        # dW = dy^T @ x
+            if want_db:
+                db = torch.empty((N,), dtype=torch.float32, device=dy.device)
+                _colsum(dy2, M, N, db)
         return dx, dw, db, None
 
 
@@ -104,43 +115,52 @@ def module_linear(mod, x, gelu=False):
 # fused spatial attention core ('cond' fusion)
 # ---------------------------------------------------------------------------------------
 class _SpatialAttnCond(torch.autograd.Function):
+    """Operates on the PACKED projection output qkvc (B*L, 3D + H*6) = [q | k | v | cond]: the
+    kernels read the four column blocks in place (leading dimension = packed width) and the
+    backward writes the four gradients into one packed buffer -- no split / cat copies."""
+
     @staticmethod
-    def forward(ctx, q, k, v, cond, pairwise_locs, pad_mask, n_head):
-        B, L, D = q.shape
+    def forward(ctx, qkvc, pairwise_locs, pad_mask, B, L, D, n_head):
         dh = D // n_head
-        q2, k2, v2 = (t.reshape(B * L, D).contiguous() for t in (q, k, v))
-        cond2 = cond.reshape(B * L, -1).contiguous()
+        W = qkvc.shape[-1]
+        x = qkvc.reshape(B * L, W)
+        if not x.is_contiguous():
+            x = x.contiguous()
         pl = pairwise_locs.contiguous()
         pad = pad_mask.contiguous().view(torch.uint8)
-        out = torch.empty((B * L, D), dtype=torch.float32, device=q.device)
-        probs = torch.empty((B, n_head, L, L), dtype=torch.float32, device=q.device)
+        out = torch.empty((B * L, D), dtype=torch.float32, device=x.device)
+        probs = torch.empty((B, n_head, L, L), dtype=torch.float32, device=x.device)
         lib = _lib.load()
-        with torch.cuda.device(q.device):
-            rc = lib.msr3d_spatial_attn_fwd(B, L, n_head, dh, pl.shape[-1], _p(q2), _p(k2), _p(v2), D,
-                                            _p(cond2), _p(pl), _p(pad), _p(out), _p(probs),
-                                            _lib.current_stream_ptr(q.device))
+        base, fs = x.data_ptr(), 4
+        with torch.cuda.device(x.device):
+            rc = lib.msr3d_spatial_attn_fwd(
+                B, L, n_head, dh, pl.shape[-1], ctypes.c_void_p(base), ctypes.c_void_p(base + D * fs),
+                ctypes.c_void_p(base + 2 * D * fs), W, ctypes.c_void_p(base + 3 * D * fs), W, _p(pl),
+                _p(pad), _p(out), _p(probs), _lib.current_stream_ptr(x.device))
         _lib.check(rc, "msr3d_spatial_attn_fwd")
-        ctx.save_for_backward(q2, k2, v2, cond2, pl, pad, probs)
-        ctx.dims = (B, L, D, n_head, dh)
+        ctx.save_for_backward(x, pl, pad, probs)
+        ctx.dims = (B, L, D, n_head, dh, W)
         ctx.mark_non_differentiable(probs)
         return out.view(B, L, D), probs
 
     @staticmethod
     def backward(ctx, dout, _dprobs):
-        q2, k2, v2, cond2, pl, pad, probs = ctx.saved_tensors
-        B, L, D, H, dh = ctx.dims
-        do = dout.reshape(B * L, D).contiguous()
-        dq, dk, dv = (torch.empty_like(q2) for _ in range(3))
-        dcond = torch.empty_like(cond2)
+        x, pl, pad, probs = ctx.saved_tensors
+        B, L, D, H, dh, W = ctx.dims
+        do = dout.reshape(B * L, D)
+        if not do.is_contiguous():
+            do = do.contiguous()
+        g = torch.empty_like(x)
         lib = _lib.load()
+        base, gb, fs = x.data_ptr(), g.data_ptr(), 4
+        vp = ctypes.c_void_p
         with torch.cuda.device(do.device):
-            rc = lib.msr3d_spatial_attn_bwd(B, L, H, dh, pl.shape[-1], _p(q2), _p(k2), _p(v2), D,
-                                            _p(cond2), _p(pl), _p(pad), _p(probs), _p(do), _p(dq),
-                                            _p(dk), _p(dv), D, _p(dcond),
-                                            _lib.current_stream_ptr(do.device))
+            rc = lib.msr3d_spatial_attn_bwd(
+                B, L, H, dh, pl.shape[-1], vp(base), vp(base + D * fs), vp(base + 2 * D * fs), W,
+                vp(base + 3 * D * fs), W, _p(pl), _p(pad), _p(probs), _p(do), vp(gb), vp(gb + D * fs),
+                vp(gb + 2 * D * fs), W, vp(gb + 3 * D * fs), W, _lib.current_stream_ptr(do.device))
         _lib.check(rc, "msr3d_spatial_attn_bwd")
-        shp = (B, L, D)
-        return dq.view(shp), dk.view(shp), dv.view(shp), dcond.view(B, L, -1), None, None, None
+        return g.view(B, L, W), None, None, None, None, None, None
 
 
 def spatial_attn_cond_supported(q, n_head, spatial_dim, spatial_n_head):
@@ -149,8 +169,9 @@ def spatial_attn_cond_supported(q, n_head, spatial_dim, spatial_n_head):
             and spatial_dim == 5 and spatial_n_head == n_head)
 
 
-def spatial_attn_cond(q, k, v, cond, pairwise_locs, key_padding_mask, n_head):
-    """q,k,v (B,L,D) already projected; cond (B,L,H*6); -> ctx (B,L,D), probs (B,H,L,L)."""
+def spatial_attn_cond(qkvc, pairwise_locs, key_padding_mask, n_head, d_model):
+    """qkvc (B,L,3D+H*6) = packed [q|k|v|cond] projections -> ctx (B,L,D), probs (B,H,L,L)."""
+    B, L = qkvc.shape[:2]
     if key_padding_mask is None:
-        key_padding_mask = torch.zeros(q.shape[:2], dtype=torch.bool, device=q.device)
-    return _SpatialAttnCond.apply(q, k, v, cond, pairwise_locs, key_padding_mask, n_head)
+        key_padding_mask = torch.zeros((B, L), dtype=torch.bool, device=qkvc.device)
+    return _SpatialAttnCond.apply(qkvc, pairwise_locs, key_padding_mask, B, L, d_model, n_head)

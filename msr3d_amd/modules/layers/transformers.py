@@ -83,11 +83,20 @@ class MultiHeadAttentionSpatial(nn.Module):
         if (self.spatial_attn_fusion == "cond" and getattr(self, "use_fused_core", True)
                 and hipops.spatial_attn_cond_supported(
                     q, self.n_head, self.spatial_dim, self.spatial_n_head)):
-            # fused HIP core: scores + spatial term + mask + softmax + PV in one launch
-            ctx, probs = hipops.spatial_attn_cond(
-                hipops.module_linear(self.w_qs, q), hipops.module_linear(self.w_ks, k),
-                hipops.module_linear(self.w_vs, v), hipops.module_linear(self.lang_cond_fc, residual),
-                pairwise_locs, key_padding_mask, self.n_head)
+            # ONE projection GEMM for [q | k | v | cond] (self-attention: q is k is v), then
+            # the fused HIP core: scores + spatial term + mask + softmax + PV in one launch
+            if q is k and k is v:
+                w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight,
+                               self.lang_cond_fc.weight], 0)
+                bias = torch.cat([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias,
+                                  self.lang_cond_fc.bias], 0)
+                qkvc = hipops.linear(q, w, bias)
+            else:
+                qkvc = torch.cat([hipops.module_linear(self.w_qs, q), hipops.module_linear(self.w_ks, k),
+                                  hipops.module_linear(self.w_vs, v),
+                                  hipops.module_linear(self.lang_cond_fc, residual)], -1)
+            ctx, probs = hipops.spatial_attn_cond(qkvc, pairwise_locs, key_padding_mask, self.n_head,
+                                                  self.d_model)
             out = self.dropout(hipops.module_linear(self.fc, ctx))
             return self.layer_norm(out + residual), probs.permute(1, 0, 2, 3)
         qh = self._heads(hipops.module_linear(self.w_qs, q))
