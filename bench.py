@@ -71,8 +71,12 @@ class Trainer:
         params = [p for p in model.parameters() if p.requires_grad]
         self.dp = FlatGradAllReduce(params)
         on_gpu = device.type == "cuda"
-        self.opt = torch.optim.AdamW(params, lr=3e-5, betas=(0.9, 0.999), weight_decay=0.05,
-                                     capturable=on_gpu and use_graph, foreach=True)
+        if on_gpu:
+            from msr3d_amd.optim import FlatAdamW
+            self.opt = FlatAdamW(self.dp, lr=3e-5, betas=(0.9, 0.999), weight_decay=0.05,
+                                 max_grad_norm=5.0)
+        else:
+            self.opt = torch.optim.AdamW(params, lr=3e-5, betas=(0.9, 0.999), weight_decay=0.05)
         B, L = example_batch["obj_masks"].shape
         g = torch.Generator(device="cpu").manual_seed(99)
         loss_w = torch.randn((B, L, E), generator=g).to(device)

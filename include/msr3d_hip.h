@@ -178,6 +178,20 @@ int msr3d_spatial_attn_bwd(int B, int L, int H, int dh, int spatial_dim, const f
                            const float *dctx, float *dq, float *dk, float *dv, int ld_grad,
                            float *dcond, int ld_dcond, msr3d_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * Optimiser step of the hot path: global-norm clip + AdamW over flat buffers
+ * (/root/reference/optim/build.py:7-17, trainer/leo_trainer.py:189-195,
+ * optim/scheduler.py:17-25).  All buffers hold n floats (n % 4 == 0, 16-byte aligned).
+ * sumsq_scratch (1 float) and step_counter (1 int) are device words owned by the caller,
+ * zero-initialised once; the call leaves sumsq at 0 and step_counter incremented.
+ * schedule: 0 = constant lr, 1 = warmup_cosine_instructblip(warmup_steps, total_steps).
+ * max_grad_norm <= 0 disables clipping; zero_grad != 0 clears grads after use.
+ * ------------------------------------------------------------------------- */
+int msr3d_adamw_flat(long long n, float *params, float *grads, float *exp_avg, float *exp_avg_sq,
+                     float *sumsq_scratch, int *step_counter, float base_lr, float beta1,
+                     float beta2, float eps, float weight_decay, float max_grad_norm, int schedule,
+                     int warmup_steps, int total_steps, int zero_grad, msr3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,7 @@ SOURCES = [
     ("sa_fused.hip", ["-ffp-contract=off"]),
     ("gemm_f32.hip", []),
     ("attn_spatial.hip", []),
+    ("optim_flat.hip", ["-ffp-contract=off"]),
 ]
 
 

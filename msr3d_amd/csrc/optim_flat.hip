@@ -1,0 +1,128 @@
+// optim_flat.hip -- global-norm clipping + AdamW over ONE flat parameter / gradient / state
+// buffer: two launches per step instead of the ~300 tiny kernels torch's capturable foreach
+// AdamW issues for this model's 52 tensors (bias-correction math on 0-dim step tensors runs
+// one elementwise kernel per parameter: 156 divisions per step in profiles/r01 traces).
+//
+// Semantics follow the reference's optimiser stack exactly
+// (/root/reference/optim/build.py:7-17 -> torch.optim.AdamW, one param group, lr 3e-5,
+// betas (0.9, 0.999), weight_decay 0.05, configs/msr3d.yaml:43-47;
+// accelerator.clip_grad_norm_(5.0), trainer/leo_trainer.py:192-193;
+// LambdaLR(warmup_cosine_instructblip), optim/scheduler.py:17-20,23-25):
+//   coef = min(1, max_norm / (||g||_2 + 1e-6));  g *= coef
+//   p *= 1 - lr*wd;  m += (1-b1)(g - m);  v = b2 v + (1-b2) g^2
+//   p -= (lr / (1 - b1^t)) * m / (sqrt(v)/sqrt(1 - b2^t) + eps)
+// The step counter and the squared norm live on the device so the pair can be replayed
+// from a HIP graph.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "../../include/msr3d_hip.h"
+
+namespace {
+
+// state[0] = sum of squares (float), state[1] = step (as float bits of an int), state[2] = last lr
+__global__ __launch_bounds__(256) void sumsq_kernel(long long n4, const float4 *__restrict__ g,
+                                                    float *__restrict__ sumsq) {
+  float s = 0.f;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n4;
+       t += (long long)gridDim.x * blockDim.x) {
+    const float4 v = g[t];
+    s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(sumsq, part[0] + part[1] + part[2] + part[3]);
+}
+
+__device__ __forceinline__ float lr_lambda(int sched, int step, int warmup, int total) {
+  if (sched == 1) {   // warmup_cosine_instructblip (optim/scheduler.py:17-20)
+    if (step <= warmup) return 1e-3f + (float)step / (float)warmup * (1.0f - 1e-3f);
+    const double x = (double)(step - warmup) / (double)(total - warmup) * 3.14159265358979323846;
+    return (float)(0.5 * (1.0 + cos(x)));
+  }
+  return 1.0f;
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(long long n4, float4 *__restrict__ p,
+                                                    float4 *__restrict__ g, float4 *__restrict__ m,
+                                                    float4 *__restrict__ v,
+                                                    const float *__restrict__ sumsq,
+                                                    int *__restrict__ step_ctr, float base_lr,
+                                                    float beta1, float beta2, float eps, float wd,
+                                                    float max_norm, int sched, int warmup, int total,
+                                                    int zero_grad) {
+  __shared__ float sh[4];
+  if (threadIdx.x == 0) {
+    const int t = *step_ctr + 1;                         // this update's 1-based index
+    const float lr = base_lr * lr_lambda(sched, t - 1, warmup, total);   // LambdaLR: lambda(t-1)
+    const double bc1 = 1.0 - pow((double)beta1, (double)t);
+    const double bc2 = 1.0 - pow((double)beta2, (double)t);
+    float coef = 1.0f;
+    if (max_norm > 0.f) {
+      const float nrm = sqrtf(*sumsq);
+      coef = fminf(max_norm / (nrm + 1e-6f), 1.0f);
+    }
+    sh[0] = lr;
+    sh[1] = (float)((double)lr / bc1);                   // step_size
+    sh[2] = (float)sqrt(bc2);                            // bias_correction2_sqrt
+    sh[3] = coef;
+  }
+  __syncthreads();
+  const float lr = sh[0], step_size = sh[1], bc2s = sh[2], coef = sh[3];
+  const float decay = 1.0f - lr * wd, w1 = 1.0f - beta1, w2 = 1.0f - beta2;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n4;
+       t += (long long)gridDim.x * blockDim.x) {
+    float4 pp = p[t], gg = g[t], mm = m[t], vv = v[t];
+#define UPD(c)                                                  \
+    {                                                           \
+      const float gr = gg.c * coef;                             \
+      float pv = pp.c * decay;                                  \
+      mm.c = mm.c + w1 * (gr - mm.c);                           \
+      vv.c = vv.c * beta2 + w2 * gr * gr;                       \
+      const float denom = sqrtf(vv.c) / bc2s + eps;             \
+      pp.c = pv - step_size * (mm.c / denom);                   \
+    }
+    UPD(x) UPD(y) UPD(z) UPD(w)
+#undef UPD
+    p[t] = pp; m[t] = mm; v[t] = vv;
+    if (zero_grad) g[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// runs after adamw_kernel on the same stream: bump the counter, clear the norm accumulator
+__global__ void adamw_tick_kernel(int *step_ctr, float *sumsq) {
+  *step_ctr += 1;
+  *sumsq = 0.f;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msr3d_adamw_flat(long long n, float *params, float *grads, float *exp_avg, float *exp_avg_sq,
+                     float *sumsq_scratch, int *step_counter, float base_lr, float beta1,
+                     float beta2, float eps, float weight_decay, float max_grad_norm, int schedule,
+                     int warmup_steps, int total_steps, int zero_grad, msr3d_stream_t stream) {
+  if (n < 0 || (n % 4) != 0) return MSR3D_EINVAL;
+  if (n == 0) return 0;
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !sumsq_scratch || !step_counter)
+    return MSR3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const long long n4 = n / 4;
+  long long gsz = (n4 + 255) / 256;
+  if (gsz > 1024) gsz = 1024;
+  if (max_grad_norm > 0.f)
+    sumsq_kernel<<<(int)gsz, 256, 0, st>>>(n4, reinterpret_cast<const float4 *>(grads), sumsq_scratch);
+  adamw_kernel<<<(int)gsz, 256, 0, st>>>(
+      n4, reinterpret_cast<float4 *>(params), reinterpret_cast<float4 *>(grads),
+      reinterpret_cast<float4 *>(exp_avg), reinterpret_cast<float4 *>(exp_avg_sq), sumsq_scratch,
+      step_counter, base_lr, beta1, beta2, eps, weight_decay, max_grad_norm, schedule, warmup_steps,
+      total_steps, zero_grad);
+  adamw_tick_kernel<<<1, 1, 0, st>>>(step_counter, sumsq_scratch);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

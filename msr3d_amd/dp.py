@@ -42,7 +42,9 @@ class FlatGradAllReduce:
 
         order = list(reversed(self.params))                 # ~ backward order
         total = sum(p.numel() for p in order)
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        total_padded = (total + 3) // 4 * 4       # float4 kernels (fused optimiser) see whole vectors
+        self.flat = torch.zeros(total_padded, dtype=torch.float32, device=dev)
+        self.numel = total
         self.buckets = []                                   # (start, end) element ranges
         self._bucket_of = {}
         self._pending = []

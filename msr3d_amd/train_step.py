@@ -34,8 +34,11 @@ class HotPathTrainStep:
         loss = self.loss_fn(out)
         loss.backward()
         self.dp.finish()
-        self.dp.clip_grad_norm_(5.0)
-        self.opt.step()
+        if getattr(self.opt, "fused_clip", False):
+            self.opt.step()                       # clip + AdamW in the flat-buffer kernels
+        else:
+            self.dp.clip_grad_norm_(5.0)
+            self.opt.step()
         return loss.detach()
 
     def _load(self, batch):
