@@ -117,9 +117,11 @@ int msr3d_sa_fps2(int b, int n, int point_stride, int m1, int m2, const float *p
  *            new_xyz (b,m,3), nsample 32; out (b,m,256)
  *   level 3: dims {259,256,512,768}; group-all over n = 16 points: pts = xyz (b,16,3),
  *            feat (b,16,256); new_xyz unused; out (b,768)
- * paramsL: layer L packed by the host as [N][KP] weights (K order: level 1 [dxyz,rgb],
- * levels 2/3 [feat, (d)xyz]; zero-padded to KP = 16 / 144 / 272 for the first layer),
- * then scale[N], shift[N] (the eval-mode BN affine).  dbg_ball_idx (b,m,32) optional. */
+ * paramsL: layer L packed by the host as [N][KP + MSR3D_SA_WPAD] weight rows (K order: level 1
+ * [dxyz,rgb], levels 2/3 [feat, (d)xyz]; zero-padded to KP = 16 / 144 / 272 for the first
+ * layer, KP = K otherwise; the extra MSR3D_SA_WPAD floats per row are padding), then
+ * scale[N], shift[N] (the eval-mode BN affine).  dbg_ball_idx (b,m,32) optional. */
+#define MSR3D_SA_WPAD 16
 int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pts,
                    const float *feat, const float *new_xyz, const int *dims,
                    const float *params1, const float *params2, const float *params3, float *out,

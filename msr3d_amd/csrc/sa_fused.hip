@@ -32,6 +32,15 @@ namespace {
 using namespace msr3d;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+#ifndef MSR3D_SA1_CPB
+#define MSR3D_SA1_CPB 2
+#endif
+#ifndef MSR3D_SA2_CPB
+#define MSR3D_SA2_CPB 2
+#endif
+
+constexpr int kWPad = MSR3D_SA_WPAD;   // packed weight rows are [N][K + kWPad]: a 16-row B-fragment load then
+                              // spreads over channels instead of hitting one power-of-two stride
 constexpr int kLdsPad = 8;   // row stride = K + 8 floats (K % 16 == 0): stride/4 == 2 (mod 4)
                              // makes every 16-lane group of a ds_read_b128 fragment read hit
                              // 16 distinct 16-B slots of the 256-B bank row
@@ -53,36 +62,63 @@ __host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // legal because a dot product does not care, and it turns 4+4 scalar fragment loads into
 // 1+1 vector loads.
 // ---------------------------------------------------------------------------------
+// first B slab of a layer, issued early (before the previous layer's epilogue / the loader's
+// barrier) so its L2 latency is off the critical path
+template <int RN, int KP>
+__device__ __forceinline__ void load_b_first(const float *__restrict__ wg, int lane,
+                                             float4 (&b)[RN]) {
+  constexpr int LDW = KP + kWPad;
+  const float *wp = wg + (size_t)(lane & 15) * LDW + 4 * (lane >> 4);
+#pragma unroll
+  for (int rn = 0; rn < RN; ++rn) b[rn] = *reinterpret_cast<const float4 *>(wp + (size_t)rn * 16 * LDW);
+}
+
+// per-lane BN affine of this wave's columns (col = 16 rn + (lane & 15)), fetched with the B prefetch
+template <int RN>
+__device__ __forceinline__ void load_affine(const float *__restrict__ scale,
+                                            const float *__restrict__ shift, int lane,
+                                            float (&sc)[RN], float (&sh)[RN]) {
+#pragma unroll
+  for (int rn = 0; rn < RN; ++rn) {
+    sc[rn] = scale[rn * 16 + (lane & 15)];
+    sh[rn] = shift[rn * 16 + (lane & 15)];
+  }
+}
+
 template <int RM, int RN, int KP>
 __device__ __forceinline__ void gemm_lds_global(const float *xs, int ldx,
                                                 const float *__restrict__ wg,
-                                                f32x4 (&acc)[RM][RN], int lane) {
+                                                f32x4 (&acc)[RM][RN], int lane,
+                                                const float4 (&bfirst)[RN]) {
+  constexpr int LDW = KP + kWPad;
   const int i = lane & 15, g = lane >> 4;
   const float *xp = xs + i * ldx + 4 * g;
-  const float *wp = wg + (size_t)i * KP + 4 * g;
+  const float *wp = wg + (size_t)i * LDW + 4 * g;
   float4 bcur[RN];
 #pragma unroll
-  for (int rn = 0; rn < RN; ++rn) bcur[rn] = *reinterpret_cast<const float4 *>(wp + (size_t)rn * 16 * KP);
+  for (int rn = 0; rn < RN; ++rn) bcur[rn] = bfirst[rn];
 #pragma unroll 2
   for (int k0 = 0; k0 < KP; k0 += 16) {
     float4 bnext[RN];
     const int kn = (k0 + 16 < KP) ? k0 + 16 : k0;   // last slab: harmless re-read
 #pragma unroll
     for (int rn = 0; rn < RN; ++rn)
-      bnext[rn] = *reinterpret_cast<const float4 *>(wp + (size_t)rn * 16 * KP + kn);
+      bnext[rn] = *reinterpret_cast<const float4 *>(wp + (size_t)rn * 16 * LDW + kn);
     float4 a[RM];
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm)
       a[rm] = *reinterpret_cast<const float4 *>(xp + rm * 16 * ldx + k0);
-#pragma unroll
-    for (int rm = 0; rm < RM; ++rm)
-#pragma unroll
-      for (int rn = 0; rn < RN; ++rn) {
-        acc[rm][rn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rm].x, bcur[rn].x, acc[rm][rn], 0, 0, 0);
-        acc[rm][rn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rm].y, bcur[rn].y, acc[rm][rn], 0, 0, 0);
-        acc[rm][rn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rm].z, bcur[rn].z, acc[rm][rn], 0, 0, 0);
-        acc[rm][rn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rm].w, bcur[rn].w, acc[rm][rn], 0, 0, 0);
-      }
+    // step-major order: consecutive MFMAs hit DIFFERENT accumulators (RM*RN of them), so the
+    // 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 never gates its 32-cycle issue rate
+#define MSR3D_STEP(c)                                                                           \
+    _Pragma("unroll") for (int rm = 0; rm < RM; ++rm)                                           \
+    _Pragma("unroll") for (int rn = 0; rn < RN; ++rn)                                           \
+        acc[rm][rn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rm].c, bcur[rn].c, acc[rm][rn], 0, 0, 0);
+    MSR3D_STEP(x)
+    MSR3D_STEP(y)
+    MSR3D_STEP(z)
+    MSR3D_STEP(w)
+#undef MSR3D_STEP
 #pragma unroll
     for (int rn = 0; rn < RN; ++rn) bcur[rn] = bnext[rn];
   }
@@ -100,13 +136,12 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[RM][RN]) {
 // col = lane & 15, row = (lane >> 4) * 4 + reg.
 template <int RM, int RN>
 __device__ __forceinline__ void store_bn_relu_lds(const f32x4 (&acc)[RM][RN],
-                                                  const float *__restrict__ scale,
-                                                  const float *__restrict__ shift, float *ys,
-                                                  int ldy, int lane) {
+                                                  const float (&scv)[RN], const float (&shv)[RN],
+                                                  float *ys, int ldy, int lane) {
   const int c = lane & 15, r4 = (lane >> 4) * 4;
 #pragma unroll
   for (int rn = 0; rn < RN; ++rn) {
-    const float sc = scale[rn * 16 + c], sh = shift[rn * 16 + c];
+    const float sc = scv[rn], sh = shv[rn];
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
@@ -120,14 +155,14 @@ __device__ __forceinline__ void store_bn_relu_lds(const f32x4 (&acc)[RM][RN],
 // Starting the running max at 0 IS the ReLU (max and ReLU commute).
 template <int RM, int RN, int GT>
 __device__ __forceinline__ void store_bn_relu_groupmax(const f32x4 (&acc)[RM][RN],
-                                                       const float *__restrict__ scale,
-                                                       const float *__restrict__ shift,
+                                                       const float (&scv)[RN],
+                                                       const float (&shv)[RN],
                                                        float *__restrict__ out, int ldo,
                                                        int groups_valid, int lane) {
   const int c = lane & 15;
 #pragma unroll
   for (int rn = 0; rn < RN; ++rn) {
-    const float sc = scale[rn * 16 + c], sh = shift[rn * 16 + c];
+    const float sc = scv[rn], sh = shv[rn];
 #pragma unroll
     for (int gq = 0; gq < RM / GT; ++gq) {
       float m = 0.0f;
@@ -160,42 +195,62 @@ struct Chain {
   static_assert(RM % GT == 0, "a pooling group must live inside one wave");
   static constexpr int LDS_FLOATS = TM * LDA + TM * LDB;
 
-  // out: first pooled row of this block; `groups_valid`: pooled rows of this WAVE that exist
-  __device__ static void run(float *bufA, float *bufB, const Layer &l1, const Layer &l2,
-                             const Layer &l3, float *__restrict__ out, int groups_valid_block) {
+  static constexpr int RN1 = N1 / (16 * WN), RN2 = N2 / (16 * WN), RN3 = N3 / (16 * WN);
+
+  struct Pre1 {            // layer-1 operands fetched before the loader phase
+    float4 b[RN1];
+    float sc[RN1], sh[RN1];
+  };
+  __device__ static void preload(const Layer &l1, Pre1 &p) {
+    const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) % WN;
+    const int col0 = wn * RN1 * 16;
+    load_b_first<RN1, K0P>(l1.w + (size_t)col0 * (K0P + kWPad), lane, p.b);
+    load_affine<RN1>(l1.scale + col0, l1.shift + col0, lane, p.sc, p.sh);
+  }
+
+  // out: first pooled row of this block; `groups_valid_block`: pooled rows of this block that exist
+  __device__ static void run(float *bufA, float *bufB, const Pre1 &p1, const Layer &l1,
+                             const Layer &l2, const Layer &l3, float *__restrict__ out, int groups_valid_block,
+                             long long *tstamp = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int row0 = wm * RM * 16;
+    float4 b2[RN2], b3[RN3];
+    float sc2[RN2], sh2[RN2], sc3[RN3], sh3[RN3];
     {
-      constexpr int RN = N1 / (16 * WN);
-      const int col0 = wn * RN * 16;
-      f32x4 acc[RM][RN];
+      const int col0 = wn * RN1 * 16;
+      f32x4 acc[RM][RN1];
       zero_acc(acc);
-      gemm_lds_global<RM, RN, K0P>(bufA + row0 * LDA, LDA, l1.w + (size_t)col0 * K0P, acc, lane);
-      store_bn_relu_lds<RM, RN>(acc, l1.scale + col0, l1.shift + col0, bufB + row0 * LDB + col0,
-                                LDB, lane);
+      gemm_lds_global<RM, RN1, K0P>(bufA + row0 * LDA, LDA, l1.w + (size_t)col0 * (K0P + kWPad), acc, lane, p1.b);
+      // next layer's first operands fly while this layer's epilogue and barrier run
+      load_b_first<RN2, N1>(l2.w + (size_t)(wn * RN2 * 16) * (N1 + kWPad), lane, b2);
+      load_affine<RN2>(l2.scale + wn * RN2 * 16, l2.shift + wn * RN2 * 16, lane, sc2, sh2);
+      if (tstamp) tstamp[0] = clock64();
+      store_bn_relu_lds<RM, RN1>(acc, p1.sc, p1.sh, bufB + row0 * LDB + col0, LDB, lane);
     }
     __syncthreads();
+    if (tstamp) tstamp[1] = clock64();
     {
-      constexpr int RN = N2 / (16 * WN);
-      const int col0 = wn * RN * 16;
-      f32x4 acc[RM][RN];
+      const int col0 = wn * RN2 * 16;
+      f32x4 acc[RM][RN2];
       zero_acc(acc);
-      gemm_lds_global<RM, RN, N1>(bufB + row0 * LDB, LDB, l2.w + (size_t)col0 * N1, acc, lane);
-      store_bn_relu_lds<RM, RN>(acc, l2.scale + col0, l2.shift + col0, bufA + row0 * LDA + col0,
-                                LDA, lane);
+      gemm_lds_global<RM, RN2, N1>(bufB + row0 * LDB, LDB, l2.w + (size_t)col0 * (N1 + kWPad), acc, lane, b2);
+      load_b_first<RN3, N2>(l3.w + (size_t)(wn * RN3 * 16) * (N2 + kWPad), lane, b3);
+      load_affine<RN3>(l3.scale + wn * RN3 * 16, l3.shift + wn * RN3 * 16, lane, sc3, sh3);
+      if (tstamp) tstamp[2] = clock64();
+      store_bn_relu_lds<RM, RN2>(acc, sc2, sh2, bufA + row0 * LDA + col0, LDA, lane);
     }
     __syncthreads();
+    if (tstamp) tstamp[3] = clock64();
     {
-      constexpr int RN = N3 / (16 * WN);
-      const int col0 = wn * RN * 16;
-      f32x4 acc[RM][RN];
+      const int col0 = wn * RN3 * 16;
+      f32x4 acc[RM][RN3];
       zero_acc(acc);
-      gemm_lds_global<RM, RN, N2>(bufA + row0 * LDA, LDA, l3.w + (size_t)col0 * N2, acc, lane);
+      gemm_lds_global<RM, RN3, N2>(bufA + row0 * LDA, LDA, l3.w + (size_t)col0 * (N2 + kWPad), acc, lane, b3);
+      if (tstamp) tstamp[4] = clock64();
       const int g0 = wm * (RM / GT);            // first pooled row owned by this wave
       int gv = groups_valid_block - g0;
-      store_bn_relu_groupmax<RM, RN, GT>(acc, l3.scale + col0, l3.shift + col0,
-                                         out + (size_t)g0 * N3 + col0, N3, gv, lane);
+      store_bn_relu_groupmax<RM, RN3, GT>(acc, sc3, sh3, out + (size_t)g0 * N3 + col0, N3, gv, lane);
     }
   }
 };
@@ -235,42 +290,51 @@ __device__ __forceinline__ void wave_ball_query(const float *sx, int n, float cx
 // out: (b, m, 128) point-major.
 // =================================================================================
 constexpr int kNS = 32;   // neighbours per centre in both query levels (configs/msr3d.yaml:199)
-using Chain1 = Chain<128, 16, 64, 64, 128, kNS, 2, 2>;
+// CPB centres per block: 4 -> 128-row tile, one block per CU (LDS 87 KB); 2 -> 64-row tile, three
+// blocks per CU, so one block's ball-query / gather phase hides under the others' MFMA phases.
+template <int CPB> struct Sa1 { using C = Chain<CPB * kNS, 16, 64, 64, 128, kNS, 2, 2>; };
 
+template <int CPB>
 __global__ __launch_bounds__(256) void sa1_kernel(int n, int m, float radius2,
                                                   const float *__restrict__ pts,
                                                   const float *__restrict__ new_xyz, Layer l1,
                                                   Layer l2, Layer l3, float *__restrict__ out,
                                                   int *__restrict__ dbg_idx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  using Chain1 = typename Sa1<CPB>::C;
+  constexpr int TM = CPB * kNS;
   float *bufA = reinterpret_cast<float *>(smem);
-  float *bufB = bufA + 128 * Chain1::LDA;
-  int *nbr = reinterpret_cast<int *>(bufB + 128 * Chain1::LDB);   // [4][32]
+  float *bufB = bufA + TM * Chain1::LDA;
+  int *nbr = reinterpret_cast<int *>(bufB + TM * Chain1::LDB);   // [CPB][32]
   float *ctr = reinterpret_cast<float *>(nbr + 4 * kNS);          // [4][4]
   float *sx = ctr + 16;                                            // [n][3]
 
-  const int obj = blockIdx.y, c0 = blockIdx.x * 4;
+  const int obj = blockIdx.y, c0 = blockIdx.x * CPB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  typename Chain1::Pre1 pre;
+  Chain1::preload(l1, pre);          // layer-1 weights/affine in flight during staging + ball query
   const float *P = pts + (size_t)obj * n * 6;
   for (int i = tid; i < n * 3; i += 256) {
     const int p = i / 3, c = i - p * 3;
     sx[i] = P[p * 6 + c];
   }
-  if (tid < 12) {
+  if (tid < 3 * CPB) {
     const int w = tid / 3, c = tid - w * 3;
     ctr[w * 4 + c] = (c0 + w < m) ? new_xyz[((size_t)obj * m + c0 + w) * 3 + c] : 0.f;
   }
   __syncthreads();
-  if (c0 + wave < m)
-    wave_ball_query(sx, n, ctr[wave * 4 + 0], ctr[wave * 4 + 1], ctr[wave * 4 + 2], radius2, kNS,
-                    nbr + wave * kNS, lane);
-  else if (lane < kNS)
-    nbr[wave * kNS + lane] = 0;
+  if (wave < CPB) {
+    if (c0 + wave < m)
+      wave_ball_query(sx, n, ctr[wave * 4 + 0], ctr[wave * 4 + 1], ctr[wave * 4 + 2], radius2, kNS,
+                      nbr + wave * kNS, lane);
+    else if (lane < kNS)
+      nbr[wave * kNS + lane] = 0;
+  }
   __syncthreads();
-  if (dbg_idx && tid < 4 * kNS && c0 + tid / kNS < m)
+  if (dbg_idx && tid < CPB * kNS && c0 + tid / kNS < m)
     dbg_idx[((size_t)obj * m + c0) * kNS + tid] = nbr[tid];
   // gather: row = (centre w, sample k); cols [x-cx, y-cy, z-cz, r, g, b, 0 x10]
-  for (int e = tid; e < 128 * 16; e += 256) {
+  for (int e = tid; e < TM * 16; e += 256) {
     const int row = e >> 4, c = e & 15;
     const int p = nbr[row];
     float v = 0.f;
@@ -279,8 +343,8 @@ __global__ __launch_bounds__(256) void sa1_kernel(int n, int m, float radius2,
     bufA[row * Chain1::LDA + c] = v;
   }
   __syncthreads();
-  const int groups = (m - c0) < 4 ? (m - c0) : 4;
-  Chain1::run(bufA, bufB, l1, l2, l3, out + ((size_t)obj * m + c0) * 128, groups);
+  const int groups = (m - c0) < CPB ? (m - c0) : CPB;
+  Chain1::run(bufA, bufB, pre, l1, l2, l3, out + ((size_t)obj * m + c0) * 128, groups);
 }
 
 // =================================================================================
@@ -288,8 +352,9 @@ __global__ __launch_bounds__(256) void sa1_kernel(int n, int m, float radius2,
 // (b, m, 3).  Block = 4 centres x 32 neighbours.  MLP 131 -> 128 -> 128 -> 256 with the
 // K order [feat(128), dxyz(3), 0 x13].  out: (b, m, 256).
 // =================================================================================
-using Chain2 = Chain<128, 144, 128, 128, 256, kNS, 2, 2>;
+template <int CPB> struct Sa2 { using C = Chain<CPB * kNS, 144, 128, 128, 256, kNS, 2, 2>; };
 
+template <int CPB>
 __global__ __launch_bounds__(256) void sa2_kernel(int n, int m, float radius2,
                                                   const float *__restrict__ xyz,
                                                   const float *__restrict__ feat,
@@ -297,36 +362,60 @@ __global__ __launch_bounds__(256) void sa2_kernel(int n, int m, float radius2,
                                                   Layer l2, Layer l3, float *__restrict__ out,
                                                   int *__restrict__ dbg_idx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  using Chain2 = typename Sa2<CPB>::C;
+  constexpr int TM = CPB * kNS;
   float *bufA = reinterpret_cast<float *>(smem);
-  float *bufB = bufA + 128 * Chain2::LDA;
-  int *nbr = reinterpret_cast<int *>(bufB + 128 * Chain2::LDB);   // [4][32]
+  float *bufB = bufA + TM * Chain2::LDA;
+  int *nbr = reinterpret_cast<int *>(bufB + TM * Chain2::LDB);   // [CPB][32]
   float *ctr = reinterpret_cast<float *>(nbr + 4 * kNS);          // [4][4]
   float *sx = ctr + 16;                                            // [n][3], n <= 64
 
-  const int obj = blockIdx.y, c0 = blockIdx.x * 4;
+  const int obj = blockIdx.y, c0 = blockIdx.x * CPB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef MSR3D_PROF
+  long long ts[8];
+  ts[0] = clock64();
+#endif
+  typename Chain2::Pre1 pre;
+  Chain2::preload(l1, pre);          // layer-1 weights/affine in flight during the loader phase
   if (tid < n * 3) sx[tid] = xyz[(size_t)obj * n * 3 + tid];
-  if (tid >= 192 && tid < 204) {
+  if (tid >= 192 && tid < 192 + 3 * CPB) {
     const int t = tid - 192, w = t / 3, c = t - w * 3;
     ctr[w * 4 + c] = (c0 + w < m) ? new_xyz[((size_t)obj * m + c0 + w) * 3 + c] : 0.f;
   }
   __syncthreads();
-  if (c0 + wave < m)
-    wave_ball_query(sx, n, ctr[wave * 4 + 0], ctr[wave * 4 + 1], ctr[wave * 4 + 2], radius2, kNS,
-                    nbr + wave * kNS, lane);
-  else if (lane < kNS)
-    nbr[wave * kNS + lane] = 0;
-  __syncthreads();
-  if (dbg_idx && tid < 4 * kNS && c0 + tid / kNS < m)
-    dbg_idx[((size_t)obj * m + c0) * kNS + tid] = nbr[tid];
-  const float *F = feat + (size_t)obj * n * 128;
-  for (int e = tid; e < 128 * 32; e += 256) {          // 32 float4 per row
-    const int row = e >> 5, c4 = e & 31;
-    const int p = nbr[row];
-    *reinterpret_cast<float4 *>(bufA + row * Chain2::LDA + c4 * 4) =
-        *reinterpret_cast<const float4 *>(F + (size_t)p * 128 + c4 * 4);
+  if (wave < CPB) {
+    if (c0 + wave < m)
+      wave_ball_query(sx, n, ctr[wave * 4 + 0], ctr[wave * 4 + 1], ctr[wave * 4 + 2], radius2, kNS,
+                      nbr + wave * kNS, lane);
+    else if (lane < kNS)
+      nbr[wave * kNS + lane] = 0;
   }
-  if (tid < 128) {
+  __syncthreads();
+#ifndef MSR3D_PROF
+  if (dbg_idx && tid < CPB * kNS && c0 + tid / kNS < m)
+    dbg_idx[((size_t)obj * m + c0) * kNS + tid] = nbr[tid];
+#endif
+#ifdef MSR3D_PROF
+  ts[1] = clock64();
+#endif
+  const float *F = feat + (size_t)obj * n * 128;
+  {   // 32 float4 per row; indices first, then ALL loads, then the LDS stores: one L2 round trip
+    constexpr int IT = TM * 32 / 256;
+    int pidx[IT];
+    float4 val[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) pidx[it] = nbr[(tid + it * 256) >> 5];
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+      val[it] = *reinterpret_cast<const float4 *>(F + (size_t)pidx[it] * 128 + ((tid + it * 256) & 31) * 4);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = tid + it * 256;
+      *reinterpret_cast<float4 *>(bufA + (e >> 5) * Chain2::LDA + (e & 31) * 4) = val[it];
+    }
+  }
+  if (tid < TM) {
     const int row = tid, p = nbr[row], w = row >> 5;
     float *d = bufA + row * Chain2::LDA + 128;
     d[0] = sx[p * 3 + 0] - ctr[w * 4 + 0];
@@ -336,8 +425,26 @@ __global__ __launch_bounds__(256) void sa2_kernel(int n, int m, float radius2,
     for (int c = 3; c < 16; ++c) d[c] = 0.f;
   }
   __syncthreads();
-  const int groups = (m - c0) < 4 ? (m - c0) : 4;
-  Chain2::run(bufA, bufB, l1, l2, l3, out + ((size_t)obj * m + c0) * 256, groups);
+  const int groups = (m - c0) < CPB ? (m - c0) : CPB;
+#ifdef MSR3D_PROF
+  ts[2] = clock64();
+  long long tl[5];
+  Chain2::run(bufA, bufB, pre, l1, l2, l3, out + ((size_t)obj * m + c0) * 256, groups, tl);
+  ts[7] = clock64();
+  if (dbg_idx && tid == 0) {   // PROF build: dbg buffer carries phase durations instead of indices
+    int *o = dbg_idx + ((size_t)obj * gridDim.x + blockIdx.x) * 8;
+    o[0] = (int)(ts[1] - ts[0]);   // stage + ball query
+    o[1] = (int)(ts[2] - ts[1]);   // gather
+    o[2] = (int)(tl[0] - ts[2]);   // layer 1 mfma
+    o[3] = (int)(tl[1] - tl[0]);   // layer 1 epilogue + barrier
+    o[4] = (int)(tl[2] - tl[1]);   // layer 2 mfma
+    o[5] = (int)(tl[3] - tl[2]);   // layer 2 epilogue + barrier
+    o[6] = (int)(tl[4] - tl[3]);   // layer 3 mfma
+    o[7] = (int)(ts[7] - tl[4]);   // layer 3 epilogue
+  }
+#else
+  Chain2::run(bufA, bufB, pre, l1, l2, l3, out + ((size_t)obj * m + c0) * 256, groups);
+#endif
 }
 
 // =================================================================================
@@ -363,6 +470,11 @@ __global__ __launch_bounds__(256) void sa3_kernel(int b, const float *__restrict
   float *buf2 = buf1 + C::TM * C::LD1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int obj0 = blockIdx.x * 2;
+  float4 b1[C::N1 / 64];
+  float sc1[C::N1 / 64], sh1[C::N1 / 64];
+  load_b_first<C::N1 / 64, C::K0P>(l1.w + (size_t)(wave * (C::N1 / 64) * 16) * (C::K0P + kWPad), lane, b1);
+  load_affine<C::N1 / 64>(l1.scale + wave * (C::N1 / 64) * 16, l1.shift + wave * (C::N1 / 64) * 16,
+                          lane, sc1, sh1);
   for (int e = tid; e < C::TM * 64; e += 256) {        // 64 float4 of features per row
     const int row = e >> 6, c4 = e & 63;
     const int obj = obj0 + (row >> 4);
@@ -380,40 +492,44 @@ __global__ __launch_bounds__(256) void sa3_kernel(int b, const float *__restrict
   }
   __syncthreads();
   constexpr int RM = 2;    // 32 rows, all waves; waves split N four ways
+  constexpr int RN1 = C::N1 / 64, RN2 = C::N2 / 64, RN3 = C::N3 / 64;
+  float4 b2[RN2], b3[RN3];
+  float sc2[RN2], sh2[RN2], sc3[RN3], sh3[RN3];
   {
-    constexpr int RN = C::N1 / 64;
-    const int col0 = wave * RN * 16;
-    f32x4 acc[RM][RN];
+    const int col0 = wave * RN1 * 16;
+    f32x4 acc[RM][RN1];
     zero_acc(acc);
-    gemm_lds_global<RM, RN, C::K0P>(bufX, C::LDX, l1.w + (size_t)col0 * C::K0P, acc, lane);
-    store_bn_relu_lds<RM, RN>(acc, l1.scale + col0, l1.shift + col0, buf1 + col0, C::LD1, lane);
+    gemm_lds_global<RM, RN1, C::K0P>(bufX, C::LDX, l1.w + (size_t)col0 * (C::K0P + kWPad), acc, lane, b1);
+    load_b_first<RN2, C::N1>(l2.w + (size_t)(wave * RN2 * 16) * (C::N1 + kWPad), lane, b2);
+    load_affine<RN2>(l2.scale + wave * RN2 * 16, l2.shift + wave * RN2 * 16, lane, sc2, sh2);
+    store_bn_relu_lds<RM, RN1>(acc, sc1, sh1, buf1 + col0, C::LD1, lane);
   }
   __syncthreads();
   {
-    constexpr int RN = C::N2 / 64;
-    const int col0 = wave * RN * 16;
-    f32x4 acc[RM][RN];
+    const int col0 = wave * RN2 * 16;
+    f32x4 acc[RM][RN2];
     zero_acc(acc);
-    gemm_lds_global<RM, RN, C::N1>(buf1, C::LD1, l2.w + (size_t)col0 * C::N1, acc, lane);
-    store_bn_relu_lds<RM, RN>(acc, l2.scale + col0, l2.shift + col0, buf2 + col0, C::LD2, lane);
+    gemm_lds_global<RM, RN2, C::N1>(buf1, C::LD1, l2.w + (size_t)col0 * (C::N1 + kWPad), acc, lane, b2);
+    load_b_first<RN3, C::N2>(l3.w + (size_t)(wave * RN3 * 16) * (C::N2 + kWPad), lane, b3);
+    load_affine<RN3>(l3.scale + wave * RN3 * 16, l3.shift + wave * RN3 * 16, lane, sc3, sh3);
+    store_bn_relu_lds<RM, RN2>(acc, sc2, sh2, buf2 + col0, C::LD2, lane);
   }
   __syncthreads();
   {
-    constexpr int RN = C::N3 / 64;
-    const int col0 = wave * RN * 16;
-    f32x4 acc[RM][RN];
+    const int col0 = wave * RN3 * 16;
+    f32x4 acc[RM][RN3];
     zero_acc(acc);
-    gemm_lds_global<RM, RN, C::N2>(buf2, C::LD2, l3.w + (size_t)col0 * C::N2, acc, lane);
+    gemm_lds_global<RM, RN3, C::N2>(buf2, C::LD2, l3.w + (size_t)col0 * (C::N2 + kWPad), acc, lane, b3);
     const int gv = (b - obj0) < 2 ? (b - obj0) : 2;
-    store_bn_relu_groupmax<RM, RN, 1>(acc, l3.scale + col0, l3.shift + col0,
-                                      out + (size_t)obj0 * C::N3 + col0, C::N3, gv, lane);
+    store_bn_relu_groupmax<RM, RN3, 1>(acc, sc3, sh3, out + (size_t)obj0 * C::N3 + col0, C::N3, gv,
+                                       lane);
   }
 }
 
 inline Layer make_layer(const float *packed, int n, int kp) {
   Layer l;
   l.w = packed;
-  l.scale = packed + (size_t)n * kp;
+  l.scale = packed + (size_t)n * (kp + kWPad);
   l.shift = l.scale + n;
   return l;
 }
@@ -451,23 +567,26 @@ int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pt
     // pts (b,n,6); dims = {6, 64, 64, 128}
     if (!(dims[0] == 6 && dims[1] == 64 && dims[2] == 64 && dims[3] == 128)) return MSR3D_EINVAL;
     if (!pts || !new_xyz || n <= 0 || m <= 0) return MSR3D_EINVAL;
-    const size_t lds = sizeof(float) * (Chain1::LDS_FLOATS + 4 * kNS + 16 + (size_t)n * 3);
+    constexpr int CPB = MSR3D_SA1_CPB;
+    const size_t lds = sizeof(float) * (Sa1<CPB>::C::LDS_FLOATS + 4 * kNS + 16 + (size_t)n * 3);
     if (lds > 160 * 1024) return MSR3D_EINVAL;
-    if ((e = allow_lds(sa1_kernel, lds)) != hipSuccess) return (int)e;
-    dim3 grid((m + 3) / 4, b);
-    sa1_kernel<<<grid, 256, lds, st>>>(n, m, r2, pts, new_xyz, make_layer(params1, 64, 16),
-                                       make_layer(params2, 64, 64), make_layer(params3, 128, 64),
-                                       out, dbg_ball_idx);
+    if ((e = allow_lds(sa1_kernel<CPB>, lds)) != hipSuccess) return (int)e;
+    dim3 grid((m + CPB - 1) / CPB, b);
+    sa1_kernel<CPB><<<grid, 256, lds, st>>>(n, m, r2, pts, new_xyz, make_layer(params1, 64, 16),
+                                            make_layer(params2, 64, 64),
+                                            make_layer(params3, 128, 64), out, dbg_ball_idx);
   } else if (level == 2) {
     // pts = xyz (b,n,3), feat (b,n,128); dims = {131, 128, 128, 256}
     if (!(dims[0] == 131 && dims[1] == 128 && dims[2] == 128 && dims[3] == 256)) return MSR3D_EINVAL;
     if (!pts || !feat || !new_xyz || n <= 0 || n > 64 || m <= 0) return MSR3D_EINVAL;
-    const size_t lds = sizeof(float) * (Chain2::LDS_FLOATS + 4 * kNS + 16 + 64 * 3);
-    if ((e = allow_lds(sa2_kernel, lds)) != hipSuccess) return (int)e;
-    dim3 grid((m + 3) / 4, b);
-    sa2_kernel<<<grid, 256, lds, st>>>(n, m, r2, pts, feat, new_xyz, make_layer(params1, 128, 144),
-                                       make_layer(params2, 128, 128), make_layer(params3, 256, 128),
-                                       out, dbg_ball_idx);
+    constexpr int CPB = MSR3D_SA2_CPB;
+    const size_t lds = sizeof(float) * (Sa2<CPB>::C::LDS_FLOATS + 4 * kNS + 16 + 64 * 3);
+    if ((e = allow_lds(sa2_kernel<CPB>, lds)) != hipSuccess) return (int)e;
+    dim3 grid((m + CPB - 1) / CPB, b);
+    sa2_kernel<CPB><<<grid, 256, lds, st>>>(n, m, r2, pts, feat, new_xyz,
+                                            make_layer(params1, 128, 144),
+                                            make_layer(params2, 128, 128),
+                                            make_layer(params3, 256, 128), out, dbg_ball_idx);
   } else if (level == 3) {
     // group-all over n = 16 points: pts = xyz (b,16,3), feat (b,16,256); dims = {259,256,512,768}
     if (!(dims[0] == 259 && dims[1] == 256 && dims[2] == 512 && dims[3] == 768)) return MSR3D_EINVAL;

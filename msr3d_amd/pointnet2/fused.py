@@ -17,6 +17,7 @@ from . import pointnet2_utils as pu
 _LEVEL_DIMS = ([6, 64, 64, 128], [131, 128, 128, 256], [259, 256, 512, 768])
 _KP0 = (16, 144, 272)
 _NSAMPLE = 32
+_WPAD = 16            # MSR3D_SA_WPAD in include/msr3d_hip.h: padding floats per packed weight row
 
 
 def _level_spec(sa):
@@ -63,7 +64,7 @@ def can_fuse(net, pts):
 def _pack_layer(conv, bn, kp, feat_first):
     w = conv.weight.detach().reshape(conv.out_channels, conv.in_channels).float()
     n, k = w.shape
-    wp = w.new_zeros((n, kp))
+    wp = w.new_zeros((n, kp + _WPAD))
     if feat_first:            # kernel K order: [features, xyz]; reference: [xyz, features]
         wp[:, :k - 3] = w[:, 3:]
         wp[:, k - 3:k] = w[:, :3]
