@@ -147,6 +147,12 @@ int msr3d_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float *A, int 
 int msr3d_linear_wgrad_f32(int M_tokens, int N_out, int K_in, const float *dy, const float *x,
                            float *dw_db, msr3d_stream_t stream);
 
+/* Same products ACCUMULATED onto dw (N_out x K_in, dense) and db (N_out; may be NULL): for
+ * gradient buffers that were zeroed once for the whole step (the flat buffer of the
+ * data-parallel engine), no memset, no temporary. */
+int msr3d_linear_wgrad_acc_f32(int M_tokens, int N_out, int K_in, const float *dy, const float *x,
+                               float *dw, float *db, msr3d_stream_t stream);
+
 /* out[n] (+)= sum_m X[m*ldx + n]  (bias gradient). */
 int msr3d_colsum_f32(int M, int N, const float *X, int ldx, float *out, int accumulate,
                      msr3d_stream_t stream);

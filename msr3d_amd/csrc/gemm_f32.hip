@@ -272,13 +272,20 @@ static int gemm_f32_impl(int a_kc, int b_kc, int M, int N, int K, const float *A
   }
   hipStream_t st = (hipStream_t)stream;
   if (a_colsum) {
-    // dW + db in one launch: C (M x N, dense) is immediately followed by the M column sums,
-    // one memset establishes the zero both accumulate into
-    if (a_kc || ldc != N || a_colsum != C + (size_t)M * N || beta != 0.f) return MSR3D_EINVAL;
-    hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * ((size_t)M * N + M), st);
-    if (e != hipSuccess) return (int)e;
+    // dW + db in one launch.  beta == 0: C (M x N, dense) is immediately followed by the M
+    // column sums and ONE memset establishes the zero both accumulate into; beta == 1: both
+    // destinations already hold the values to add to (e.g. slices of a zeroed flat gradient
+    // buffer) and may live anywhere.
+    if (a_kc || ldc != N) return MSR3D_EINVAL;
+    if (beta == 0.f) {
+      if (a_colsum != C + (size_t)M * N) return MSR3D_EINVAL;
+      hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * ((size_t)M * N + M), st);
+      if (e != hipSuccess) return (int)e;
+    } else if (beta != 1.f) {
+      return MSR3D_EINVAL;
+    }
     if (splits == 1) splits = slabs >= 2 ? 2 : 1;   // keep the atomic meeting point semantics
-    if (splits == 1) beta = 1.f;                    // single split: add onto the zeroed C
+    if (splits == 1) beta = 1.f;                    // single split: add onto what C holds
   } else if (splits > 1 && beta == 0.f) {
     if (ldc != N) return MSR3D_EINVAL;          // split path zeroes a dense C
     hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, st);
@@ -310,6 +317,13 @@ int msr3d_linear_wgrad_f32(int M_tokens, int N_out, int K_in, const float *dy, c
   if (!dw_db) return MSR3D_EINVAL;
   return gemm_f32_impl(0, 0, N_out, K_in, M_tokens, dy, N_out, x, K_in, dw_db, K_in, nullptr,
                        nullptr, 0, 0.f, dw_db + (size_t)N_out * K_in, stream);
+}
+
+int msr3d_linear_wgrad_acc_f32(int M_tokens, int N_out, int K_in, const float *dy, const float *x,
+                               float *dw, float *db, msr3d_stream_t stream) {
+  if (!dw) return MSR3D_EINVAL;
+  return gemm_f32_impl(0, 0, N_out, K_in, M_tokens, dy, N_out, x, K_in, dw, K_in, nullptr,
+                       nullptr, 0, 1.f, db, stream);
 }
 
 int msr3d_colsum_f32(int M, int N, const float *X, int ldx, float *out, int accumulate,

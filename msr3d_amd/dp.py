@@ -53,6 +53,9 @@ class FlatGradAllReduce:
         for p in order:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
+            # lets the HIP linear backward accumulate dW/db straight into these views (no
+            # temporary, no AccumulateGrad add) and report readiness itself: hipops._HipLinear
+            p._msr3d_dp = self
             self._bucket_of[id(p)] = len(self.buckets)
             off += n
             if off - b_start >= per_bucket:
@@ -73,6 +76,12 @@ class FlatGradAllReduce:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
     # ------------------------------------------------------------------ hooks
+    def mark_ready(self, p):
+        """A producer wrote p's gradient into the flat buffer directly (bypassing autograd's
+        AccumulateGrad, hence its hook): same bookkeeping as the hook."""
+        if self.world > 1:
+            self._on_grad(p)
+
     def _on_grad(self, p):
         b = self._bucket_of[id(p)]
         self._ready[b] += 1

@@ -51,6 +51,12 @@ class _HipLinear(torch.autograd.Function):
         ctx.save_for_backward(x2, w, pre)
         ctx.has_bias = bias is not None
         ctx.x_shape = x.shape
+        # leaf parameters whose .grad lives in the data-parallel engine's flat buffer
+        dpw = getattr(weight, "_msr3d_dp", None)
+        ok = dpw is not None and weight.is_leaf and weight.grad is not None and weight.is_contiguous()
+        if ok and bias is not None:
+            ok = getattr(bias, "_msr3d_dp", None) is dpw and bias.is_leaf and bias.grad is not None
+        ctx.direct = (dpw, weight, bias) if ok else None
         return y.reshape(*x.shape[:-1], N)
 
     @staticmethod
@@ -75,6 +81,19 @@ class _HipLinear(torch.autograd.Function):
             _gemm(True, False, M, K, N, dy2, N, w, K, dx, K)          # dx = dy @ W
             dx = dx.reshape(ctx.x_shape)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.direct is not None and ctx.needs_input_grad[1]:
+            # accumulate dW (+ db) straight into the flat gradient buffer's views
+            dpw, wparam, bparam = ctx.direct
+            lib = _lib.load()
+            with torch.cuda.device(dy.device):
+                rc = lib.msr3d_linear_wgrad_acc_f32(M, N, K, _p(dy2), _p(x2), _p(wparam.grad),
+                                                    _p(bparam.grad if bparam is not None else None),
+                                                    _lib.current_stream_ptr(dy.device))
+            _lib.check(rc, "msr3d_linear_wgrad_acc_f32")
+            dpw.mark_ready(wparam)
+            if bparam is not None:
+                dpw.mark_ready(bparam)
+            return dx, None, None, None
         if ctx.needs_input_grad[1] and want_db:
             # dW = dy^T @ x and db = colsum(dy) from ONE launch into one buffer
             buf = torch.empty((N * K + N,), dtype=torch.float32, device=dy.device)
