@@ -187,6 +187,29 @@ int msr3d_spatial_attn_bwd(int B, int L, int H, int dh, int spatial_dim, const f
                            float *dcond, int ld_dcond, msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Row-wise tails of the spatial encoder layer: y = LayerNorm(dropout(a) + r) * gamma + beta
+ * (/root/reference/modules/layers/transformers.py:250-251,324-328; r may be NULL and
+ * p_drop 0 for the plain Linear->LayerNorm encoders of model/ose3d_situation.py:399-404).
+ * D in {256,512,768,1024}.  s_out (M,D) = the pre-norm sum and stats (M,2) = {mean, rstd}
+ * are what backward needs (may be NULL in inference).  The dropout mask is a hash of
+ * (*seed, salt, element index): pass the same (seed, salt) to backward.
+ * ------------------------------------------------------------------------- */
+int msr3d_dropout_add_ln_fwd(int M, int D, const float *a, const float *r, const float *gamma,
+                             const float *beta, float eps, float p_drop,
+                             const unsigned long long *seed, unsigned salt, float *y, float *s_out,
+                             float *stats, msr3d_stream_t stream);
+
+/* da (M,D; NULL if a needs no grad) and dr (M,D; NULL if r was NULL) are written;
+ * dgamma_acc / dbeta_acc (D) are ACCUMULATED into (atomicAdd). */
+int msr3d_dropout_add_ln_bwd(int M, int D, const float *dy, const float *s, const float *stats,
+                             const float *gamma, float p_drop, const unsigned long long *seed,
+                             unsigned salt, float *da, float *dr, float *dgamma_acc,
+                             float *dbeta_acc, msr3d_stream_t stream);
+
+/* Advance the device-resident dropout seed word (once per training step, inside the graph). */
+int msr3d_bump_seed(unsigned long long *seed, msr3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Optimiser step of the hot path: global-norm clip + AdamW over flat buffers
  * (/root/reference/optim/build.py:7-17, trainer/leo_trainer.py:189-195,
  * optim/scheduler.py:17-25).  All buffers hold n floats (n % 4 == 0, 16-byte aligned).

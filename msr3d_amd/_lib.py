@@ -39,6 +39,11 @@ _SIGNATURES = {
                                               _ptr, _ptr],
     "msr3d_spatial_attn_bwd": [_c_int] * 5 + [_ptr, _ptr, _ptr, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr,
                                               _ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _c_int, _ptr],
+    "msr3d_dropout_add_ln_fwd": [_c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_float, _c_float, _ptr,
+                                 ctypes.c_uint, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_dropout_add_ln_bwd": [_c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_float, _ptr, ctypes.c_uint,
+                                 _ptr, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_bump_seed": [_ptr, _ptr],
     "msr3d_adamw_flat": [ctypes.c_longlong, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_float,
                          _c_float, _c_float, _c_float, _c_float, _c_int, _c_int, _c_int, _c_int, _ptr],
     "msr3d_sa_fps2": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],

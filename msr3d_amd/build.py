@@ -27,6 +27,7 @@ SOURCES = [
     ("gemm_f32.hip", []),
     ("attn_spatial.hip", []),
     ("optim_flat.hip", ["-ffp-contract=off"]),
+    ("rowops.hip", []),
 ]
 
 

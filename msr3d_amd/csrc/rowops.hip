@@ -1,0 +1,225 @@
+// rowops.hip -- row-wise fused pieces of the spatial encoder layer:
+//     y = LayerNorm( dropout(a) + r ) * gamma + beta          (forward)
+// and its backward, one wave per row.  Three call sites per layer in the reference
+// (/root/reference/modules/layers/transformers.py:250-251 attention tail, :324-325 and
+// :326-328 layer tails) and the two embedding encoders (model/ose3d_situation.py:399-404,
+// Linear -> LayerNorm, no residual, no dropout).  Replaces dropout + add + layer_norm
+// (3 launches forward, 5 backward) by one launch each way.
+//
+// Dropout mask: counter-based hash of (seed word on the device, call-site salt, element
+// index), regenerated in backward, so a captured HIP graph draws a fresh mask on every
+// replay (the seed word is bumped inside the graph) and nothing but the pre-norm sum is
+// saved.  Inverted-dropout scaling 1/(1-p) like torch.
+#include <hip/hip_runtime.h>
+
+#include "../../include/msr3d_hip.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned mix32(unsigned h) {   // murmur3 finaliser
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ bool keep_elem(unsigned long long seed, unsigned salt, unsigned idx,
+                                          unsigned thresh) {
+  const unsigned h = mix32(idx * 0x9E3779B1u + mix32((unsigned)seed ^ (salt * 0x7FEB352Du)) +
+                           (unsigned)(seed >> 32));
+  return mix32(h) >= thresh;       // P(keep) = 1 - thresh / 2^32
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// D = 256 * VPL floats per row; lane holds VPL float4 at columns (j*64 + lane)*4
+template <int VPL>
+__global__ __launch_bounds__(256) void dal_fwd_kernel(int M, const float *__restrict__ a,
+                                                      const float *__restrict__ r,
+                                                      const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta, float eps,
+                                                      float p_drop,
+                                                      const unsigned long long *__restrict__ seed,
+                                                      unsigned salt, float *__restrict__ y,
+                                                      float *__restrict__ s_out,
+                                                      float *__restrict__ stats) {
+  constexpr int D = 256 * VPL;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const bool drop = p_drop > 0.f;
+  const unsigned thresh = drop ? (unsigned)(p_drop * 4294967296.0) : 0u;
+  const float scale = drop ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const unsigned long long sd = drop ? *seed : 0ull;
+  float4 v[VPL];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    float4 x = *reinterpret_cast<const float4 *>(a + (size_t)row * D + c);
+    if (drop) {
+      const unsigned base = (unsigned)row * D + c;
+      x.x = keep_elem(sd, salt, base + 0, thresh) ? x.x * scale : 0.f;
+      x.y = keep_elem(sd, salt, base + 1, thresh) ? x.y * scale : 0.f;
+      x.z = keep_elem(sd, salt, base + 2, thresh) ? x.z * scale : 0.f;
+      x.w = keep_elem(sd, salt, base + 3, thresh) ? x.w * scale : 0.f;
+    }
+    if (r) {
+      const float4 q = *reinterpret_cast<const float4 *>(r + (size_t)row * D + c);
+      x.x += q.x; x.y += q.y; x.z += q.z; x.w += q.w;
+    }
+    v[j] = x;
+    sum += (x.x + x.y) + (x.z + x.w);
+  }
+  const float mean = wave_sum(sum) * (1.0f / D);
+  float var = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const float dx = v[j].x - mean, dy = v[j].y - mean, dz = v[j].z - mean, dw = v[j].w - mean;
+    var += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+  }
+  const float rstd = rsqrtf(wave_sum(var) * (1.0f / D) + eps);
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    const float4 g = *reinterpret_cast<const float4 *>(gamma + c);
+    const float4 b = *reinterpret_cast<const float4 *>(beta + c);
+    float4 o;
+    o.x = (v[j].x - mean) * rstd * g.x + b.x;
+    o.y = (v[j].y - mean) * rstd * g.y + b.y;
+    o.z = (v[j].z - mean) * rstd * g.z + b.z;
+    o.w = (v[j].w - mean) * rstd * g.w + b.w;
+    *reinterpret_cast<float4 *>(y + (size_t)row * D + c) = o;
+    if (s_out) *reinterpret_cast<float4 *>(s_out + (size_t)row * D + c) = v[j];
+  }
+  if (stats && lane == 0) { stats[row * 2 + 0] = mean; stats[row * 2 + 1] = rstd; }
+}
+
+// ROWS rows per block (4 waves x ROWS/4 iterations); dgamma/dbeta partials reduced in LDS,
+// then one atomicAdd per column per block onto the (pre-zeroed or accumulating) destinations.
+template <int VPL>
+__global__ __launch_bounds__(256) void dal_bwd_kernel(int M, int rows_per_block,
+                                                      const float *__restrict__ dy,
+                                                      const float *__restrict__ s,
+                                                      const float *__restrict__ stats,
+                                                      const float *__restrict__ gamma, float p_drop,
+                                                      const unsigned long long *__restrict__ seed,
+                                                      unsigned salt, float *__restrict__ da,
+                                                      float *__restrict__ dr,
+                                                      float *__restrict__ dgamma,
+                                                      float *__restrict__ dbeta) {
+  constexpr int D = 256 * VPL;
+  __shared__ float red[2][4][D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool drop = p_drop > 0.f;
+  const unsigned thresh = drop ? (unsigned)(p_drop * 4294967296.0) : 0u;
+  const float scale = drop ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const unsigned long long sd = drop ? *seed : 0ull;
+  float4 gg[VPL], accg[VPL], accb[VPL];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    gg[j] = *reinterpret_cast<const float4 *>(gamma + (j * 64 + lane) * 4);
+    accg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    accb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int r0 = blockIdx.x * rows_per_block;
+  for (int row = r0 + wave; row < min(M, r0 + rows_per_block); row += 4) {
+    const float mean = stats[row * 2 + 0], rstd = stats[row * 2 + 1];
+    float4 xh[VPL], g[VPL];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      const float4 d = *reinterpret_cast<const float4 *>(dy + (size_t)row * D + c);
+      const float4 sv = *reinterpret_cast<const float4 *>(s + (size_t)row * D + c);
+      xh[j].x = (sv.x - mean) * rstd; xh[j].y = (sv.y - mean) * rstd;
+      xh[j].z = (sv.z - mean) * rstd; xh[j].w = (sv.w - mean) * rstd;
+      g[j].x = d.x * gg[j].x; g[j].y = d.y * gg[j].y; g[j].z = d.z * gg[j].z; g[j].w = d.w * gg[j].w;
+      c1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+      c2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
+      accg[j].x += d.x * xh[j].x; accg[j].y += d.y * xh[j].y;
+      accg[j].z += d.z * xh[j].z; accg[j].w += d.w * xh[j].w;
+      accb[j].x += d.x; accb[j].y += d.y; accb[j].z += d.z; accb[j].w += d.w;
+    }
+    c1 = wave_sum(c1) * (1.0f / D);
+    c2 = wave_sum(c2) * (1.0f / D);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      float4 dx;
+      dx.x = rstd * (g[j].x - c1 - xh[j].x * c2);
+      dx.y = rstd * (g[j].y - c1 - xh[j].y * c2);
+      dx.z = rstd * (g[j].z - c1 - xh[j].z * c2);
+      dx.w = rstd * (g[j].w - c1 - xh[j].w * c2);
+      if (dr) *reinterpret_cast<float4 *>(dr + (size_t)row * D + c) = dx;
+      if (da) {
+        if (drop) {
+          const unsigned base = (unsigned)row * D + c;
+          dx.x = keep_elem(sd, salt, base + 0, thresh) ? dx.x * scale : 0.f;
+          dx.y = keep_elem(sd, salt, base + 1, thresh) ? dx.y * scale : 0.f;
+          dx.z = keep_elem(sd, salt, base + 2, thresh) ? dx.z * scale : 0.f;
+          dx.w = keep_elem(sd, salt, base + 3, thresh) ? dx.w * scale : 0.f;
+        }
+        *reinterpret_cast<float4 *>(da + (size_t)row * D + c) = dx;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    *reinterpret_cast<float4 *>(&red[0][wave][c]) = accg[j];
+    *reinterpret_cast<float4 *>(&red[1][wave][c]) = accb[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
+}
+
+__global__ void bump_seed_kernel(unsigned long long *seed) { *seed = *seed * 6364136223846793005ull + 1442695040888963407ull; }
+
+}  // namespace
+
+extern "C" {
+
+int msr3d_dropout_add_ln_fwd(int M, int D, const float *a, const float *r, const float *gamma,
+                             const float *beta, float eps, float p_drop,
+                             const unsigned long long *seed, unsigned salt, float *y, float *s_out,
+                             float *stats, msr3d_stream_t stream) {
+  if (M < 0 || (D != 256 && D != 512 && D != 768 && D != 1024)) return MSR3D_EINVAL;
+  if (p_drop < 0.f || p_drop >= 1.f) return MSR3D_EINVAL;
+  if (M == 0) return 0;
+  if (!a || !gamma || !beta || !y || (p_drop > 0.f && !seed)) return MSR3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = (M + 3) / 4;
+#define L(V) dal_fwd_kernel<V><<<grid, 256, 0, st>>>(M, a, r, gamma, beta, eps, p_drop, seed, salt, y, s_out, stats)
+  switch (D / 256) { case 1: L(1); break; case 2: L(2); break; case 3: L(3); break; default: L(4); }
+#undef L
+  return (int)hipGetLastError();
+}
+
+int msr3d_dropout_add_ln_bwd(int M, int D, const float *dy, const float *s, const float *stats,
+                             const float *gamma, float p_drop, const unsigned long long *seed,
+                             unsigned salt, float *da, float *dr, float *dgamma_acc,
+                             float *dbeta_acc, msr3d_stream_t stream) {
+  if (M < 0 || (D != 256 && D != 512 && D != 768 && D != 1024)) return MSR3D_EINVAL;
+  if (M == 0) return 0;
+  if (!dy || !s || !stats || !gamma || !dgamma_acc || !dbeta_acc || (p_drop > 0.f && !seed))
+    return MSR3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int rpb = 16;
+  const int grid = (M + rpb - 1) / rpb;
+#define L(V) dal_bwd_kernel<V><<<grid, 256, 0, st>>>(M, rpb, dy, s, stats, gamma, p_drop, seed, salt, da, dr, dgamma_acc, dbeta_acc)
+  switch (D / 256) { case 1: L(1); break; case 2: L(2); break; case 3: L(3); break; default: L(4); }
+#undef L
+  return (int)hipGetLastError();
+}
+
+int msr3d_bump_seed(unsigned long long *seed, msr3d_stream_t stream) {
+  if (!seed) return MSR3D_EINVAL;
+  bump_seed_kernel<<<1, 1, 0, (hipStream_t)stream>>>(seed);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

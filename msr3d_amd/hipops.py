@@ -194,3 +194,112 @@ def spatial_attn_cond(qkvc, pairwise_locs, key_padding_mask, n_head, d_model):
     if key_padding_mask is None:
         key_padding_mask = torch.zeros((B, L), dtype=torch.bool, device=qkvc.device)
     return _SpatialAttnCond.apply(qkvc, pairwise_locs, key_padding_mask, B, L, d_model, n_head)
+
+
+# ---------------------------------------------------------------------------------------
+# y = LayerNorm(dropout(a) + r): fused row kernels (csrc/rowops.hip)
+# ---------------------------------------------------------------------------------------
+_seed_words = {}
+_salt_counter = [0]
+
+
+def seed_word(device):
+    """Device-resident 64-bit dropout seed (one per device), initialised from torch's seed."""
+    key = (device.type, device.index)
+    if key not in _seed_words:
+        _seed_words[key] = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF],
+                                        dtype=torch.int64, device=device)
+    return _seed_words[key]
+
+
+def bump_seed(device):
+    """Advance the seed word on the device (call once per step; capturable)."""
+    w = seed_word(device)
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        rc = lib.msr3d_bump_seed(_p(w), _lib.current_stream_ptr(device))
+    _lib.check(rc, "msr3d_bump_seed")
+
+
+def _next_salt():
+    _salt_counter[0] = (_salt_counter[0] + 1) & 0x7FFFFFFF
+    return _salt_counter[0]
+
+
+class _DropoutAddLN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, r, gamma, beta, eps, p_drop):
+        shape = a.shape
+        D = shape[-1]
+        a2 = a.reshape(-1, D)
+        a2 = a2 if a2.is_contiguous() else a2.contiguous()
+        r2 = None
+        if r is not None:
+            r2 = r.reshape(-1, D)
+            r2 = r2 if r2.is_contiguous() else r2.contiguous()
+        M = a2.shape[0]
+        y = torch.empty_like(a2)
+        need_bwd = any(ctx.needs_input_grad[:4])
+        s = torch.empty_like(a2) if need_bwd else None
+        stats = torch.empty((M, 2), dtype=torch.float32, device=a.device) if need_bwd else None
+        salt = _next_salt() if p_drop > 0 else 0
+        seed = seed_word(a.device) if p_drop > 0 else None
+        lib = _lib.load()
+        with torch.cuda.device(a.device):
+            rc = lib.msr3d_dropout_add_ln_fwd(M, D, _p(a2), _p(r2), _p(gamma), _p(beta),
+                                              ctypes.c_float(eps), ctypes.c_float(p_drop), _p(seed),
+                                              salt, _p(y), _p(s), _p(stats),
+                                              _lib.current_stream_ptr(a.device))
+        _lib.check(rc, "msr3d_dropout_add_ln_fwd")
+        ctx.save_for_backward(s, stats, gamma)
+        ctx.cfg = (M, D, p_drop, salt, r is not None, shape)
+        dpg = getattr(gamma, "_msr3d_dp", None)
+        ok = (dpg is not None and getattr(beta, "_msr3d_dp", None) is dpg and gamma.is_leaf
+              and beta.is_leaf and gamma.grad is not None and beta.grad is not None)
+        ctx.direct = (dpg, gamma, beta) if ok else None
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        s, stats, gamma = ctx.saved_tensors
+        M, D, p_drop, salt, has_r, shape = ctx.cfg
+        dy2 = dy.reshape(M, D)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        want_a, want_r = ctx.needs_input_grad[0], has_r and ctx.needs_input_grad[1]
+        # without dropout d(a) == d(r): write once
+        same = p_drop == 0 and want_a and want_r
+        da = torch.empty_like(dy2) if want_a else None
+        dr = torch.empty_like(dy2) if (want_r and not same) else None
+        if ctx.direct is not None:
+            dpg, gparam, bparam = ctx.direct
+            dg, db = gparam.grad, bparam.grad
+        else:
+            dg = torch.zeros(D, dtype=torch.float32, device=dy.device)
+            db = torch.zeros(D, dtype=torch.float32, device=dy.device)
+        seed = seed_word(dy.device) if p_drop > 0 else None
+        lib = _lib.load()
+        with torch.cuda.device(dy.device):
+            rc = lib.msr3d_dropout_add_ln_bwd(M, D, _p(dy2), _p(s), _p(stats), _p(gamma),
+                                              ctypes.c_float(p_drop), _p(seed), salt, _p(da), _p(dr),
+                                              _p(dg), _p(db), _lib.current_stream_ptr(dy.device))
+        _lib.check(rc, "msr3d_dropout_add_ln_bwd")
+        ga = da.view(shape) if da is not None else None
+        gr = (ga if same else (dr.view(shape) if dr is not None else None))
+        if ctx.direct is not None:
+            dpg.mark_ready(gparam)
+            dpg.mark_ready(bparam)
+            return ga, gr, None, None, None, None
+        return ga, gr, dg, db, None, None
+
+
+def dropout_add_layernorm(a, r, ln, p_drop=0.0, training=False):
+    """ln(dropout(a) + r) for an nn.LayerNorm `ln` over the last dim; r may be None."""
+    p = float(p_drop) if training else 0.0
+    D = a.shape[-1]
+    if (a.is_cuda and a.dtype == torch.float32 and D in (256, 512, 768, 1024)
+            and ln.elementwise_affine and ln.bias is not None and tuple(ln.normalized_shape) == (D,)):
+        return _DropoutAddLN.apply(a, r, ln.weight, ln.bias, ln.eps, p)
+    x = F.dropout(a, p, True) if p > 0 else a
+    if r is not None:
+        x = x + r
+    return ln(x)

@@ -154,7 +154,7 @@ class OSE3DSituation(BaseModel):
     @staticmethod
     def _lin_ln(seq, x):
         """nn.Sequential(Linear, LayerNorm) with the Linear on the HIP GEMM."""
-        return seq[1](hipops.module_linear(seq[0], x))
+        return hipops.dropout_add_layernorm(hipops.module_linear(seq[0], x), None, seq[1])
 
     def _query_pos(self, layer_idx, loc, data_dict):
         """Positional term added to the tokens before a layer."""

@@ -97,8 +97,9 @@ class MultiHeadAttentionSpatial(nn.Module):
                                   hipops.module_linear(self.lang_cond_fc, residual)], -1)
             ctx, probs = hipops.spatial_attn_cond(qkvc, pairwise_locs, key_padding_mask, self.n_head,
                                                   self.d_model)
-            out = self.dropout(hipops.module_linear(self.fc, ctx))
-            return self.layer_norm(out + residual), probs.permute(1, 0, 2, 3)
+            out = hipops.dropout_add_layernorm(hipops.module_linear(self.fc, ctx), residual,
+                                               self.layer_norm, self.dropout.p, self.training)
+            return out, probs.permute(1, 0, 2, 3)
         qh = self._heads(hipops.module_linear(self.w_qs, q))
         kh = self._heads(hipops.module_linear(self.w_ks, k))
         vh = self._heads(hipops.module_linear(self.w_vs, v))
@@ -122,8 +123,8 @@ class MultiHeadAttentionSpatial(nn.Module):
         out = torch.einsum("hblt,hbtv->hblv", fused, vh)
         B, L = q.shape[:2]
         out = out.permute(1, 2, 0, 3).reshape(B, L, self.d_model)
-        out = self.dropout(hipops.module_linear(self.fc, out))
-        out = self.layer_norm(out + residual)
+        out = hipops.dropout_add_layernorm(hipops.module_linear(self.fc, out), residual,
+                                           self.layer_norm, self.dropout.p, self.training)
         return out, fused
 
 
@@ -183,6 +184,7 @@ class TransformerSpatialEncoderLayer(TransformerEncoderLayer):
         # normalises (transformers.py:251 then :324-325) -- a double residual, kept as is.
         a, attn_w = self.self_attn(tgt, tgt, tgt, tgt_pairwise_locs,
                                    key_padding_mask=tgt_key_padding_mask)
-        tgt = self.norm1(tgt + self.dropout1(a))
-        tgt = self.norm2(tgt + self.dropout2(self._ffn(tgt)))
+        tgt = hipops.dropout_add_layernorm(a, tgt, self.norm1, self.dropout1.p, self.training)
+        tgt = hipops.dropout_add_layernorm(self._ffn(tgt), tgt, self.norm2, self.dropout2.p,
+                                           self.training)
         return tgt, attn_w

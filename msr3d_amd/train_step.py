@@ -11,6 +11,8 @@ kernels with HIP events inside the timed region.
 """
 import torch
 
+from . import hipops
+
 
 class HotPathTrainStep:
     def __init__(self, model, optimizer, dp, loss_fn, example_batch, use_graph=True):
@@ -29,6 +31,8 @@ class HotPathTrainStep:
 
     # ---- the trainable part, on static buffers -------------------------------------
     def _train_part(self):
+        if self.static["obj_embeds"].is_cuda:
+            hipops.bump_seed(self.static["obj_embeds"].device)   # fresh dropout masks per replay
         self.dp.zero_grad()
         out = self.model(dict(self.static))
         loss = self.loss_fn(out)

@@ -1,0 +1,64 @@
+"""GPU: fused dropout + residual + LayerNorm row kernels vs torch in float64 (p = 0), and
+the dropout statistics / forward-backward mask consistency (p > 0)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("M,D,with_r", [(960, 256, True), (61 * 3, 256, True), (7, 256, False),
+                                        (130, 768, True), (33, 1024, False)])
+def test_add_layernorm_matches_torch(M, D, with_r):
+    from msr3d_amd import hipops
+    torch.manual_seed(M + D)
+    ln = torch.nn.LayerNorm(D).cuda()
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.normal_()
+    a = torch.randn(M, D, device="cuda", requires_grad=True)
+    r = torch.randn(M, D, device="cuda", requires_grad=True) if with_r else None
+    g = torch.randn(M, D, device="cuda")
+    y = hipops.dropout_add_layernorm(a, r, ln, 0.3, training=False)      # eval: no dropout
+    (y * g).sum().backward()
+    ad = a.detach().double().requires_grad_()
+    rd = r.detach().double().requires_grad_() if with_r else None
+    lnd = torch.nn.LayerNorm(D).cuda().double()
+    lnd.load_state_dict({k: v.double() for k, v in ln.state_dict().items()})
+    yd = lnd(ad + rd if with_r else ad)
+    (yd * g.double()).sum().backward()
+    assert rel(y, yd) < 1e-5
+    assert rel(a.grad, ad.grad) < 2e-5
+    if with_r:
+        assert rel(r.grad, rd.grad) < 2e-5
+    assert rel(ln.weight.grad, lnd.weight.grad) < 2e-5
+    assert rel(ln.bias.grad, lnd.bias.grad) < 2e-5
+
+
+def test_dropout_mask_statistics_and_backward_consistency():
+    from msr3d_amd import hipops
+    torch.manual_seed(0)
+    M, D, p = 2048, 256, 0.1
+    ln = torch.nn.LayerNorm(D).cuda()
+    # make LN the identity map on centred/normalised rows impossible to confuse: use r = None and
+    # a = large constant + tiny noise, so y ~ pattern of kept/dropped elements
+    a = torch.ones(M, D, device="cuda", requires_grad=True)
+    y1 = hipops.dropout_add_layernorm(a, None, ln, p, training=True)
+    y2 = hipops.dropout_add_layernorm(a, None, ln, p, training=True)     # new salt -> new mask
+    kept1 = (y1 > 0).float()          # rows are {0, 1/(1-p)} patterns: kept elements land above the mean
+    frac = 1.0 - kept1.mean().item()
+    assert abs(frac - p) < 0.01, frac
+    assert (kept1 != (y2 > 0).float()).float().mean().item() > 0.05
+    # backward uses the SAME mask as forward: d(sum y * w)/da is zero exactly where dropped
+    w = torch.randn(M, D, device="cuda")
+    (y1 * w).sum().backward()
+    assert torch.equal((a.grad != 0).float(), kept1)
+    # bump_seed changes the masks of identical call sites
+    before = hipops.seed_word(a.device).clone()
+    hipops.bump_seed(a.device)
+    assert not torch.equal(before, hipops.seed_word(a.device))
