@@ -213,11 +213,13 @@ int msr3d_bump_seed(unsigned long long *seed, msr3d_stream_t stream);
  * Optimiser step of the hot path: global-norm clip + AdamW over flat buffers
  * (/root/reference/optim/build.py:7-17, trainer/leo_trainer.py:189-195,
  * optim/scheduler.py:17-25).  All buffers hold n floats (n % 4 == 0, 16-byte aligned).
- * sumsq_scratch (1 float) and step_counter (1 int) are device words owned by the caller,
- * zero-initialised once; the call leaves sumsq at 0 and step_counter incremented.
+ * sumsq_scratch (MSR3D_ADAMW_SCRATCH_FLOATS floats: per-block partial sums, reduced in a fixed
+ * order so every data-parallel rank derives the identical clip coefficient) and step_counter
+ * (1 int, zero-initialised once, incremented by the call) are device memory owned by the caller.
  * schedule: 0 = constant lr, 1 = warmup_cosine_instructblip(warmup_steps, total_steps).
  * max_grad_norm <= 0 disables clipping; zero_grad != 0 clears grads after use.
  * ------------------------------------------------------------------------- */
+#define MSR3D_ADAMW_SCRATCH_FLOATS 1024
 int msr3d_adamw_flat(long long n, float *params, float *grads, float *exp_avg, float *exp_avg_sq,
                      float *sumsq_scratch, int *step_counter, float base_lr, float beta1,
                      float beta2, float eps, float weight_decay, float max_grad_norm, int schedule,

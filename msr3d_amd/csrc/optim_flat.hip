@@ -21,9 +21,14 @@
 
 namespace {
 
-// state[0] = sum of squares (float), state[1] = step (as float bits of an int), state[2] = last lr
+constexpr int kMaxBlocks = 1024;   // == MSR3D_ADAMW_SCRATCH_FLOATS
+
+// Deterministic global norm: every block writes ITS partial sum of squares to partial[block]
+// (no atomics); adamw_kernel then adds the partials in a fixed order.  All data-parallel
+// ranks hold identical gradients after the all-reduce and must derive the identical clip
+// coefficient, or their weights drift apart.
 __global__ __launch_bounds__(256) void sumsq_kernel(long long n4, const float4 *__restrict__ g,
-                                                    float *__restrict__ sumsq) {
+                                                    float *__restrict__ partial) {
   float s = 0.f;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n4;
        t += (long long)gridDim.x * blockDim.x) {
@@ -34,7 +39,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(long long n4, const float4 *
   __shared__ float part[4];
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(sumsq, part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
 __device__ __forceinline__ float lr_lambda(int sched, int step, int warmup, int total) {
@@ -49,12 +54,24 @@ __device__ __forceinline__ float lr_lambda(int sched, int step, int warmup, int 
 __global__ __launch_bounds__(256) void adamw_kernel(long long n4, float4 *__restrict__ p,
                                                     float4 *__restrict__ g, float4 *__restrict__ m,
                                                     float4 *__restrict__ v,
-                                                    const float *__restrict__ sumsq,
+                                                    const float *__restrict__ partial,
+                                                    int n_partial,
                                                     int *__restrict__ step_ctr, float base_lr,
                                                     float beta1, float beta2, float eps, float wd,
                                                     float max_norm, int sched, int warmup, int total,
                                                     int zero_grad) {
   __shared__ float sh[4];
+  __shared__ float red[256];
+  if (max_norm > 0.f) {        // fixed-order sum of the block partials (same in every block)
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n_partial; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+  }
   if (threadIdx.x == 0) {
     const int t = *step_ctr + 1;                         // this update's 1-based index
     const float lr = base_lr * lr_lambda(sched, t - 1, warmup, total);   // LambdaLR: lambda(t-1)
@@ -62,7 +79,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(long long n4, float4 *__rest
     const double bc2 = 1.0 - pow((double)beta2, (double)t);
     float coef = 1.0f;
     if (max_norm > 0.f) {
-      const float nrm = sqrtf(*sumsq);
+      const float nrm = sqrtf(red[0]);
       coef = fminf(max_norm / (nrm + 1e-6f), 1.0f);
     }
     sh[0] = lr;
@@ -92,11 +109,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(long long n4, float4 *__rest
   }
 }
 
-// runs after adamw_kernel on the same stream: bump the counter, clear the norm accumulator
-__global__ void adamw_tick_kernel(int *step_ctr, float *sumsq) {
-  *step_ctr += 1;
-  *sumsq = 0.f;
-}
+// runs after adamw_kernel on the same stream: bump the counter
+__global__ void adamw_tick_kernel(int *step_ctr) { *step_ctr += 1; }
 
 }  // namespace
 
@@ -113,15 +127,15 @@ int msr3d_adamw_flat(long long n, float *params, float *grads, float *exp_avg, f
   hipStream_t st = (hipStream_t)stream;
   const long long n4 = n / 4;
   long long gsz = (n4 + 255) / 256;
-  if (gsz > 1024) gsz = 1024;
+  if (gsz > kMaxBlocks) gsz = kMaxBlocks;
   if (max_grad_norm > 0.f)
     sumsq_kernel<<<(int)gsz, 256, 0, st>>>(n4, reinterpret_cast<const float4 *>(grads), sumsq_scratch);
   adamw_kernel<<<(int)gsz, 256, 0, st>>>(
       n4, reinterpret_cast<float4 *>(params), reinterpret_cast<float4 *>(grads),
       reinterpret_cast<float4 *>(exp_avg), reinterpret_cast<float4 *>(exp_avg_sq), sumsq_scratch,
-      step_counter, base_lr, beta1, beta2, eps, weight_decay, max_grad_norm, schedule, warmup_steps,
+      (int)gsz, step_counter, base_lr, beta1, beta2, eps, weight_decay, max_grad_norm, schedule, warmup_steps,
       total_steps, zero_grad);
-  adamw_tick_kernel<<<1, 1, 0, st>>>(step_counter, sumsq_scratch);
+  adamw_tick_kernel<<<1, 1, 0, st>>>(step_counter);
   return (int)hipGetLastError();
 }
 

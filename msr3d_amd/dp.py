@@ -8,9 +8,12 @@ engine shaped for this model and for MI355X's point-to-point xGMI:
   * ONE flat fp32 gradient buffer; every trainable parameter's `.grad` is a view into it,
     laid out in reverse registration order (~ the order backward produces them), so a bucket
     is a contiguous slice and needs no copy in or out;
-  * buckets are all-reduced as soon as their last gradient has been accumulated
-    (post-accumulate-grad hooks), on a SIDE stream that waits on the producing stream's
-    event -- communication overlaps the rest of backward;
+  * buckets are all-reduced on a SIDE stream that waits on the producing stream's event;
+    by default all of them right after backward (`finish()`): the exchange is 21 MB, tens of
+    microseconds on xGMI against a ~3 ms step, and the step's forward/backward is replayed
+    from a HIP graph, which must not contain host-driven collectives.  `overlap=True` launches
+    each bucket from post-accumulate-grad hooks as soon as its last gradient exists, so
+    communication overlaps the rest of backward (eager mode);
   * parameters that receive no gradient in a step (`anchor_feat`, `loc_layers` in
     'as_transform_for_objects' mode -- the reason the reference needs
     find_unused_parameters) simply leave zeros in the buffer: `finish()` flushes the
@@ -28,7 +31,7 @@ import torch.distributed as dist
 
 
 class FlatGradAllReduce:
-    def __init__(self, params, bucket_bytes=8 << 20, process_group=None):
+    def __init__(self, params, bucket_bytes=8 << 20, process_group=None, overlap=False):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -70,6 +73,11 @@ class FlatGradAllReduce:
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self.comm_stream = torch.cuda.Stream(device=dev) if self.on_gpu else None
+        # defer_comm (default): collectives are issued by finish(), after backward has been
+        # enqueued -- required when backward is replayed from a HIP graph, and the safe choice
+        # with producers that write the flat buffer directly (hipops).  overlap=True launches
+        # each bucket from the gradient hooks as soon as it is complete instead.
+        self.defer_comm = not overlap
         self._handles = []
         if self.world > 1:
             for p in self.params:
@@ -85,7 +93,7 @@ class FlatGradAllReduce:
     def _on_grad(self, p):
         b = self._bucket_of[id(p)]
         self._ready[b] += 1
-        if self._ready[b] == self._bucket_size[b]:
+        if self._ready[b] == self._bucket_size[b] and not self.defer_comm:
             self._launch(b)
 
     def _launch(self, b):
@@ -114,6 +122,8 @@ class FlatGradAllReduce:
         """Call after backward: flush buckets that never completed (unused params keep their
         zeros) and make the compute stream wait for the exchange."""
         if self.world > 1:
+            if self.defer_comm:                     # hooks ran under capture: nothing is in flight
+                self._launched = [False] * len(self.buckets)
             for b in range(len(self.buckets)):
                 self._launch(b)
             if self.on_gpu:

@@ -14,6 +14,10 @@ import torch.nn.functional as F
 from . import _lib
 
 
+import os as _os
+_NO_DIRECT = bool(int(_os.environ.get("MSR3D_NO_DIRECT_GRAD", "0")))   # debugging aid
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
 
@@ -56,7 +60,7 @@ class _HipLinear(torch.autograd.Function):
         ok = dpw is not None and weight.is_leaf and weight.grad is not None and weight.is_contiguous()
         if ok and bias is not None:
             ok = getattr(bias, "_msr3d_dp", None) is dpw and bias.is_leaf and bias.grad is not None
-        ctx.direct = (dpw, weight, bias) if ok else None
+        ctx.direct = (dpw, weight, bias) if (ok and not _NO_DIRECT) else None
         return y.reshape(*x.shape[:-1], N)
 
     @staticmethod
@@ -256,7 +260,7 @@ class _DropoutAddLN(torch.autograd.Function):
         dpg = getattr(gamma, "_msr3d_dp", None)
         ok = (dpg is not None and getattr(beta, "_msr3d_dp", None) is dpg and gamma.is_leaf
               and beta.is_leaf and gamma.grad is not None and beta.grad is not None)
-        ctx.direct = (dpg, gamma, beta) if ok else None
+        ctx.direct = (dpg, gamma, beta) if (ok and not _NO_DIRECT) else None
         return y.view(shape)
 
     @staticmethod

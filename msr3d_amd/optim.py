@@ -40,7 +40,7 @@ class FlatAdamW:
                 off += k
         self.exp_avg = torch.zeros_like(flat_g)
         self.exp_avg_sq = torch.zeros_like(flat_g)
-        self.sumsq = torch.zeros(1, dtype=torch.float32, device=flat_g.device)
+        self.sumsq = torch.zeros(1024, dtype=torch.float32, device=flat_g.device)   # block partials
         self.step_ctr = torch.zeros(1, dtype=torch.int32, device=flat_g.device)
         self.fused_clip = True
 

@@ -28,22 +28,30 @@ class HotPathTrainStep:
             dtype=torch.float32, device=example_batch["obj_fts"].device)
         self.loss = None
         self.graph = None
+        self.split = False
 
     # ---- the trainable part, on static buffers -------------------------------------
-    def _train_part(self):
+    def _fwd_bwd(self):
         if self.static["obj_embeds"].is_cuda:
             hipops.bump_seed(self.static["obj_embeds"].device)   # fresh dropout masks per replay
         self.dp.zero_grad()
         out = self.model(dict(self.static))
         loss = self.loss_fn(out)
         loss.backward()
+        return loss.detach()
+
+    def _update(self):
         self.dp.finish()
         if getattr(self.opt, "fused_clip", False):
             self.opt.step()                       # clip + AdamW in the flat-buffer kernels
         else:
             self.dp.clip_grad_norm_(5.0)
             self.opt.step()
-        return loss.detach()
+
+    def _train_part(self):
+        loss = self._fwd_bwd()
+        self._update()
+        return loss
 
     def _load(self, batch):
         with torch.no_grad():
@@ -66,13 +74,21 @@ class HotPathTrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         self._load(batch)
+        # world > 1: the gradient exchange stays OUTSIDE the graph (RCCL calls are issued eagerly
+        # between the captured forward/backward and the 3-launch optimiser) -- a handful of host
+        # launches per step, and no dependence on collective capture support.
+        self.split = self.dp.world > 1
+        if self.split:
+            self.dp.defer_comm = True
         with torch.cuda.graph(self.graph):
-            self.loss = self._train_part()
+            self.loss = self._fwd_bwd() if self.split else self._train_part()
 
     def __call__(self, batch):
         self._load(batch)
         if self.graph is not None:
             self.graph.replay()
+            if self.split:
+                self._update()
             return self.loss
         self.loss = self._train_part()
         return self.loss

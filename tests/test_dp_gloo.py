@@ -36,7 +36,7 @@ def _worker(rank, world, port, q):
     from msr3d_amd.dp import FlatGradAllReduce
     torch.manual_seed(0)
     model = Toy()
-    eng = FlatGradAllReduce(model.parameters(), bucket_bytes=256)   # several small buckets
+    eng = FlatGradAllReduce(model.parameters(), bucket_bytes=256, overlap=(rank >= 0 and os.environ.get("MSR3D_TEST_OVERLAP", "1") == "1"))   # several small buckets
     assert len(eng.buckets) > 1
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-2)
     torch.manual_seed(100 + rank)

@@ -44,7 +44,7 @@ def test_flat_adamw_matches_torch(sched):
         sch.step()
         for pa, pb in zip(a.parameters(), b.parameters()):
             assert torch.allclose(pa, pb, rtol=2e-5, atol=2e-6), it
-    assert int(opt_a.step_ctr.item()) == 7 and float(opt_a.sumsq.item()) == 0.0
+    assert int(opt_a.step_ctr.item()) == 7
     # parameters are views of the flat buffer and the module still works / saves
     assert all(p.data_ptr() >= opt_a.flat_p.data_ptr() for p in a.parameters())
     assert set(a.state_dict().keys()) == set(b.state_dict().keys())
