@@ -131,10 +131,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    # test hooks (tests/test_bench_ranks_gpu.py): run several ranks on ONE GPU over gloo to
+    # exercise the multi-rank code path where only a single device exists
+    if os.environ.get("MSR3D_BENCH_SINGLE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("MSR3D_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from msr3d_amd import _lib

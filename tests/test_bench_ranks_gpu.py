@@ -1,0 +1,44 @@
+"""GPU: bench.py's multi-rank path end to end (torchrun, 2 ranks).  Only one GPU is
+available to the tests, so both ranks use cuda:0 and the collective runs over gloo; the
+launch line, env handling, barrier / max-over-ranks timing, split-graph step and the JSON
+contract are the real ones."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_json_contract():
+    env = dict(os.environ, MSR3D_BENCH_SINGLE_DEVICE="1", MSR3D_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29671", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "4"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # rank 0 prints ONE JSON line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["warmup"] == 2
+    assert j["scaling"] == "weak" and j["higher_is_better"] is True
+    assert j["config"]["global_batch"] == 8 and j["config"]["parallelism"] == "dp2"
+    assert j["value"] > 0 and j["roofline"]["frac"] > 0
+    assert "cpu_baseline" not in j                      # N=1 only
+
+
+def test_bench_single_rank_json_contract():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+                          "--batch", "2", "--cpu-baseline-seconds", "1"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(j["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert j["vs_baseline"] is None and j["data"] == "synthetic"
