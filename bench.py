@@ -68,13 +68,15 @@ class Trainer:
         from msr3d_amd.dp import FlatGradAllReduce
         from msr3d_amd.train_step import HotPathTrainStep
         self.model = model
+        from msr3d_amd import hipops
         params = [p for p in model.parameters() if p.requires_grad]
-        self.dp = FlatGradAllReduce(params)
         on_gpu = device.type == "cuda"
+        self.dp = FlatGradAllReduce(params, pack_groups=hipops.collect_pack_groups(model) if on_gpu else None)
         if on_gpu:
             from msr3d_amd.optim import FlatAdamW
             self.opt = FlatAdamW(self.dp, lr=3e-5, betas=(0.9, 0.999), weight_decay=0.05,
                                  max_grad_norm=5.0)
+            hipops.attach_packed_views(model, self.dp, self.opt)
         else:
             self.opt = torch.optim.AdamW(params, lr=3e-5, betas=(0.9, 0.999), weight_decay=0.05)
         B, L = example_batch["obj_masks"].shape

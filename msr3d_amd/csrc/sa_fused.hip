@@ -378,7 +378,6 @@ __global__ __launch_bounds__(256) void sa2_kernel(int n, int m, float radius2,
 #endif
   typename Chain2::Pre1 pre;
   Chain2::preload(l1, pre);          // layer-1 weights/affine in flight during the loader phase
-
   if (tid < n * 3) sx[tid] = xyz[(size_t)obj * n * 3 + tid];
   if (tid >= 192 && tid < 192 + 3 * CPB) {
     const int t = tid - 192, w = t / 3, c = t - w * 3;

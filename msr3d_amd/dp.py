@@ -31,7 +31,11 @@ import torch.distributed as dist
 
 
 class FlatGradAllReduce:
-    def __init__(self, params, bucket_bytes=8 << 20, process_group=None, overlap=False):
+    def __init__(self, params, bucket_bytes=8 << 20, process_group=None, overlap=False,
+                 pack_groups=None):
+        """pack_groups: lists of parameters that must sit back to back (in the given order) in the
+        flat buffer, e.g. the q/k/v/cond projection weights of one attention block, so that a
+        consumer can treat them as ONE tensor (hipops.linear_packed) -- see collect_pack_groups."""
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -43,7 +47,21 @@ class FlatGradAllReduce:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.on_gpu = dev.type == "cuda"
 
-        order = list(reversed(self.params))                 # ~ backward order
+        group_of = {}
+        for g in (pack_groups or []):
+            g = [p for p in g if p.requires_grad]
+            for p in g:
+                group_of[id(p)] = g
+        order, seen = [], set()
+        for p in reversed(self.params):                     # ~ backward order
+            if id(p) in seen:
+                continue
+            for q in group_of.get(id(p), [p]):              # a group is emitted whole, in its order
+                if id(q) not in seen:
+                    seen.add(id(q))
+                    order.append(q)
+        self.order = order
+        self.offset = {}
         total = sum(p.numel() for p in order)
         total_padded = (total + 3) // 4 * 4       # float4 kernels (fused optimiser) see whole vectors
         self.flat = torch.zeros(total_padded, dtype=torch.float32, device=dev)
@@ -56,6 +74,7 @@ class FlatGradAllReduce:
         for p in order:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
+            self.offset[id(p)] = off
             # lets the HIP linear backward accumulate dW/db straight into these views (no
             # temporary, no AccumulateGrad add) and report readiness itself: hipops._HipLinear
             p._msr3d_dp = self
@@ -84,6 +103,16 @@ class FlatGradAllReduce:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
     # ------------------------------------------------------------------ hooks
+    def packed_range(self, group):
+        """(start, length) of a pack group inside the flat buffer (asserts it is contiguous)."""
+        start = self.offset[id(group[0])]
+        pos = start
+        for p in group:
+            if self.offset[id(p)] != pos:
+                raise RuntimeError("parameters of a pack group are not contiguous in the flat buffer")
+            pos += p.numel()
+        return start, pos - start
+
     def mark_ready(self, p):
         """A producer wrote p's gradient into the flat buffer directly (bypassing autograd's
         AccumulateGrad, hence its hook): same bookkeeping as the hook."""

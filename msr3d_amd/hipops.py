@@ -129,6 +129,82 @@ def linear(x, weight, bias=None, gelu=False):
     return F.gelu(y) if gelu else y
 
 
+class _HipLinearPacked(torch.autograd.Function):
+    """y = x Wp^T + bp where Wp / bp are VIEWS of the flat parameter buffer spanning several
+    nn.Linear modules laid out back to back (q | k | v | cond projections), and their gradient
+    views in the flat gradient buffer.  One forward GEMM, one dx GEMM, one dW+db launch
+    accumulating straight into the flat gradients; no cat, no split, no AccumulateGrad adds.
+    `members` (the real Parameters) are passed only so that autograd schedules this node."""
+
+    @staticmethod
+    def forward(ctx, x, packed, *members):
+        wv, bv, gwv, gbv, dp = packed
+        x2 = x.reshape(-1, x.shape[-1])
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        M, K = x2.shape
+        N = wv.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        _gemm(True, True, M, N, K, x2, K, wv, K, y, N, bias=bv)
+        ctx.save_for_backward(x2)
+        ctx.packed = packed
+        ctx.members = members
+        ctx.x_shape = x.shape
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        wv, bv, gwv, gbv, dp = ctx.packed
+        M, K = x2.shape
+        N = wv.shape[0]
+        dy2 = dy.reshape(M, N)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+            _gemm(True, False, M, K, N, dy2, N, wv, K, dx, K)
+            dx = dx.reshape(ctx.x_shape)
+        lib = _lib.load()
+        with torch.cuda.device(dy.device):
+            rc = lib.msr3d_linear_wgrad_acc_f32(M, N, K, _p(dy2), _p(x2), _p(gwv), _p(gbv),
+                                                _lib.current_stream_ptr(dy.device))
+        _lib.check(rc, "msr3d_linear_wgrad_acc_f32")
+        for p in ctx.members:
+            dp.mark_ready(p)
+        return (dx, None) + (None,) * len(ctx.members)
+
+
+def linear_packed(x, packed, members):
+    return _HipLinearPacked.apply(x, packed, *members)
+
+
+def collect_pack_groups(model):
+    """Pack groups requested by the model's modules (see FlatGradAllReduce pack_groups)."""
+    groups = []
+    for m in model.modules():
+        if hasattr(m, "pack_groups"):
+            groups.extend(m.pack_groups())
+    return groups
+
+
+def attach_packed_views(model, dp, opt):
+    """After the data-parallel engine and the flat optimiser own the storage: hand every
+    module that asked for packing its (weight, bias, grad-weight, grad-bias) views."""
+    flat_p = getattr(opt, "flat_p", None)
+    if flat_p is None or _NO_DIRECT:
+        return 0
+    n = 0
+    for m in model.modules():
+        if hasattr(m, "pack_groups") and hasattr(m, "set_packed"):
+            wg, bg = m.pack_groups()
+            (ws, wl), (bs, bl) = dp.packed_range(wg), dp.packed_range(bg)
+            K = wg[0].shape[1]
+            m.set_packed((flat_p[ws:ws + wl].view(-1, K), flat_p[bs:bs + bl],
+                          dp.flat[ws:ws + wl].view(-1, K), dp.flat[bs:bs + bl], dp), wg + bg)
+            n += 1
+    return n
+
+
 def module_linear(mod, x, gelu=False):
     """Apply an nn.Linear module through `linear` (its parameters stay where they are)."""
     return linear(x, mod.weight, mod.bias, gelu=gelu)

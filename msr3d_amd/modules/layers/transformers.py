@@ -48,6 +48,18 @@ class MultiHeadAttentionSpatial(nn.Module):
         else:
             raise NotImplementedError("unsupported spatial_attn_fusion %s" % spatial_attn_fusion)
 
+    # ---- packed q|k|v|cond projection (self-attention with 'cond' fusion) --------------
+    def pack_groups(self):
+        """Weights, then biases, that should be contiguous in the flat parameter/gradient
+        buffers so the four projections run as ONE GEMM on zero-copy views."""
+        if self.spatial_attn_fusion != "cond":
+            return []
+        mods = (self.w_qs, self.w_ks, self.w_vs, self.lang_cond_fc)
+        return [[m.weight for m in mods], [m.bias for m in mods]]
+
+    def set_packed(self, packed, members):
+        self._packed, self._packed_members = packed, members
+
     def _heads(self, x):
         """(B, T, H*dh) -> (H, B, T, dh)"""
         B, T, _ = x.shape
@@ -85,7 +97,10 @@ class MultiHeadAttentionSpatial(nn.Module):
                     q, self.n_head, self.spatial_dim, self.spatial_n_head)):
             # ONE projection GEMM for [q | k | v | cond] (self-attention: q is k is v), then
             # the fused HIP core: scores + spatial term + mask + softmax + PV in one launch
-            if q is k and k is v:
+            packed = getattr(self, "_packed", None)
+            if q is k and k is v and packed is not None and torch.is_grad_enabled():
+                qkvc = hipops.linear_packed(q, packed, self._packed_members)
+            elif q is k and k is v:
                 w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight,
                                self.lang_cond_fc.weight], 0)
                 bias = torch.cat([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias,

@@ -32,7 +32,7 @@ class FlatAdamW:
         # same element order as the gradient buffer: reversed(params)
         off = 0
         with torch.no_grad():
-            for p in reversed(dp.params):
+            for p in dp.order:
                 k = p.numel()
                 view = self.flat_p[off:off + k].view_as(p)
                 view.copy_(p.data)

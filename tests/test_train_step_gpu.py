@@ -49,3 +49,45 @@ def test_graph_replay_equals_eager():
         if k.endswith("w_ks.bias"):
             continue
         assert torch.allclose(pe[k], pg[k], rtol=1e-3, atol=3e-3 * 1e-1), k
+
+
+def _grads(packed):
+    import msr3d_amd.model  # noqa: F401
+    import msr3d_amd.modules  # noqa: F401
+    from msr3d_amd import hipops
+    from msr3d_amd.config import AttrDict, default_prompter_cfg
+    from msr3d_amd.dp import FlatGradAllReduce
+    from msr3d_amd.model import build_model
+    from msr3d_amd.optim import FlatAdamW
+    from msr3d_amd.synth import synth_batch
+    torch.manual_seed(0)
+    cfg = AttrDict({"prompter": default_prompter_cfg(dropout=0.0), "llm_hidden_size": 128,
+                    "model": {"name": "MSR3DHotPath"}})
+    model = build_model(cfg).cuda().train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    dp = FlatGradAllReduce(params, pack_groups=hipops.collect_pack_groups(model) if packed else None)
+    opt = FlatAdamW(dp, lr=1e-3)
+    n = hipops.attach_packed_views(model, dp, opt) if packed else 0
+    batch = synth_batch(77, 2, O=10, P=1024, device="cuda")
+    dp.zero_grad()
+    out = model(dict(batch))
+    out["scene_embeds"].pow(2).mean().backward()
+    dp.finish()
+    torch.cuda.synchronize()
+    return n, {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.requires_grad}, model, opt
+
+
+def test_packed_projection_views_match_separate_linears():
+    n0, g0, _, _ = _grads(False)
+    n1, g1, model, opt = _grads(True)
+    assert n0 == 0 and n1 == 3                      # three attention blocks packed
+    for k in g0:
+        if k.endswith("w_ks.bias"):                 # zero gradient up to rounding noise
+            continue
+        ref = g0[k].double()
+        assert float((g1[k].double() - ref).norm()) <= 2e-5 * float(ref.norm()) + 1e-9, k
+    # the packed weight view aliases the four parameters' storage (zero copy)
+    attn = model.visual_prompter.spatial_encoder[0].self_attn
+    wv = attn._packed[0]
+    assert wv.shape == (816, 256) and wv.data_ptr() == attn.w_qs.weight.data_ptr()
+    assert torch.equal(wv[256:512], attn.w_ks.weight) and torch.equal(wv[768:], attn.lang_cond_fc.weight)
