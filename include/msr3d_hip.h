@@ -187,6 +187,26 @@ int msr3d_spatial_attn_bwd(int B, int L, int H, int dh, int spatial_dim, const f
                            float *dcond, int ld_dcond, msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Data-only front of the situated encoder (inputs are dataset tensors, no gradients).
+ * ------------------------------------------------------------------------- */
+
+/* calc_pairwise_locs, 'center' / spatial_dim 5 / spatial_dist_norm
+ * (/root/reference/modules/utils.py:88-137).  loc (B, L, ld_loc): object centres in the first
+ * three floats of each row (ld_loc = 6 reads obj_locs in place); out (B, L, L, 5) =
+ * [d/max d, dz/d, d_xy/d, dy/d_xy, dx/d_xy] for c_l - c_t, d = sqrt(sum^2 + eps), the max over
+ * ALL L*L pairs of the sample.  L <= 128. */
+int msr3d_pairwise_locs(int B, int L, const float *loc, int ld_loc, float eps, float *out,
+                        msr3d_stream_t stream);
+
+/* transform_to_agent_coor (modules/utils.py:60-82; skipped when transform == 0) followed by
+ * generate_fourier_features (model/ose3d_situation.py:31-59): out (B, L, 3 + 6*num_bands) =
+ * [p', sin(pi p' f), cos(pi p' f)], (coordinate, band) order inside each block; freqs
+ * (num_bands) on the device (torch.linspace(1, max_freq, num_bands)); anchor_ori xyzw. */
+int msr3d_agent_fourier(int B, int L, const float *loc, int ld_loc, const float *anchor_loc,
+                        const float *anchor_ori, const float *freqs, int num_bands, int transform,
+                        float *out, msr3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Row-wise tails of the spatial encoder layer: y = LayerNorm(dropout(a) + r) * gamma + beta
  * (/root/reference/modules/layers/transformers.py:250-251,324-328; r may be NULL and
  * p_drop 0 for the plain Linear->LayerNorm encoders of model/ose3d_situation.py:399-404).

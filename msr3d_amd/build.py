@@ -28,6 +28,7 @@ SOURCES = [
     ("attn_spatial.hip", []),
     ("optim_flat.hip", ["-ffp-contract=off"]),
     ("rowops.hip", []),
+    ("prologue.hip", ["-ffp-contract=off"]),
 ]
 
 

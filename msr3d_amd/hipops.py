@@ -383,3 +383,43 @@ def dropout_add_layernorm(a, r, ln, p_drop=0.0, training=False):
     if r is not None:
         x = x + r
     return ln(x)
+
+
+# ---------------------------------------------------------------------------------------
+# data-only front of the encoder (csrc/prologue.hip)
+# ---------------------------------------------------------------------------------------
+def pairwise_locs_center5(obj_loc, eps=1e-10):
+    """obj_loc (B,L,>=3) f32 contiguous (centres first) -> (B,L,L,5); GPU fp32 only."""
+    B, L, W = obj_loc.shape
+    x = obj_loc if obj_loc.is_contiguous() else obj_loc.contiguous()
+    out = torch.empty((B, L, L, 5), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        rc = lib.msr3d_pairwise_locs(B, L, _p(x), W, ctypes.c_float(eps), _p(out),
+                                     _lib.current_stream_ptr(x.device))
+    _lib.check(rc, "msr3d_pairwise_locs")
+    return out
+
+
+_freq_cache = {}
+
+
+def agent_fourier(obj_loc, anchor_loc=None, anchor_ori=None, num_bands=10, max_freq=15):
+    """Fourier features of the object centres, optionally first moved into the agent frame.
+    obj_loc (B,L,>=3); anchor_loc (B,3), anchor_ori (B,4 xyzw) or None -> (B,L,3+6*num_bands)."""
+    B, L, W = obj_loc.shape
+    x = obj_loc if obj_loc.is_contiguous() else obj_loc.contiguous()
+    key = (x.device, num_bands, max_freq)
+    if key not in _freq_cache:
+        _freq_cache[key] = torch.linspace(1.0, max_freq, steps=num_bands, device=x.device)
+    freqs = _freq_cache[key]
+    transform = anchor_loc is not None
+    al = anchor_loc.contiguous() if transform else None
+    ao = anchor_ori.contiguous() if transform else None
+    out = torch.empty((B, L, 3 + 6 * num_bands), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        rc = lib.msr3d_agent_fourier(B, L, _p(x), W, _p(al), _p(ao), _p(freqs), num_bands,
+                                     int(transform), _p(out), _lib.current_stream_ptr(x.device))
+    _lib.check(rc, "msr3d_agent_fourier")
+    return out

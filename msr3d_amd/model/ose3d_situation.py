@@ -178,10 +178,15 @@ class OSE3DSituation(BaseModel):
                                            generate_fourier_features(sit_ori))
                     + self._lin_ln(loc_enc, generate_fourier_features(sit_loc)))
         if st == "as_transform_for_objects":
-            agent = transform_to_agent_coor(centre, data_dict["anchor_locs"],
-                                            data_dict["anchor_orientation"])
-            return (self._lin_ln(loc_enc, generate_fourier_features(agent))
-                    + self._lin_ln(size_enc, size))
+            if loc.is_cuda and loc.dtype == torch.float32 and not loc.requires_grad:
+                # one HIP launch: agent-frame transform + Fourier features (data only, no grad)
+                feats = hipops.agent_fourier(loc, data_dict["anchor_locs"],
+                                             data_dict["anchor_orientation"])
+            else:
+                agent = transform_to_agent_coor(centre, data_dict["anchor_locs"],
+                                                data_dict["anchor_orientation"])
+                feats = generate_fourier_features(agent)
+            return self._lin_ln(loc_enc, feats) + self._lin_ln(size_enc, size)
         return self._lin_ln(self.loc_layers[0], loc)
 
     # ------------------------------------------------------------------ forward
@@ -212,9 +217,14 @@ class OSE3DSituation(BaseModel):
         se = self.cfg.spatial_encoder
         pairwise_locs = None
         if self.cfg.use_spatial_attn:
-            pairwise_locs = calc_pairwise_locs(
-                loc[:, :, :3], loc[:, :, 3:], pairwise_rel_type=se.pairwise_rel_type,
-                spatial_dist_norm=se.spatial_dist_norm, spatial_dim=se.spatial_dim)
+            if (loc.is_cuda and loc.dtype == torch.float32 and not loc.requires_grad
+                    and se.pairwise_rel_type == "center" and se.spatial_dist_norm
+                    and se.spatial_dim == 5 and loc.size(1) <= 128):
+                pairwise_locs = hipops.pairwise_locs_center5(loc)      # one HIP launch
+            else:
+                pairwise_locs = calc_pairwise_locs(
+                    loc[:, :, :3], loc[:, :, 3:], pairwise_rel_type=se.pairwise_rel_type,
+                    spatial_dist_norm=se.spatial_dist_norm, spatial_dim=se.spatial_dim)
 
         x = feat
         with maybe_autocast(self, enabled=False):          # the encoder always runs in fp32
