@@ -241,6 +241,8 @@ inline hipError_t dispatch_fps(int b, int n, int ps, int m, const float *pts, in
   if (m2 > 0 && (m > 64 || m2 > m)) return hipErrorInvalidValue;
 #define MSR3D_FPS(PPT, NW) \
   return launch_fps<PPT, NW>(b, s, ps, m, pts, idx, new_xyz, m2, idx2, new_xyz2, st)
+  // (measured: 4 waves x 4 points/lane per cloud times the same as 1 wave x 16 at 960 clouds --
+  // the iteration is a dependent chain scan -> reduce -> readlane -> LDS read, not VALU-bound)
   if (s.slots <= 64) MSR3D_FPS(1, 1);
   if (s.slots <= 256) MSR3D_FPS(4, 1);
   if (s.slots <= 1024) MSR3D_FPS(16, 1);
