@@ -112,7 +112,8 @@ int msr3d_sa_fps2(int b, int n, int point_stride, int m1, int m2, const float *p
 /* One fused level.  `dims` = {C_in(+3), C1, C2, C3} must be one of the shipped
  * configurations (configs/msr3d.yaml:198-201) else MSR3D_EINVAL:
  *   level 1: dims {6,64,64,128};    pts (b,n,6) [xyz,rgb], feat = NULL, new_xyz (b,m,3),
- *            nsample 32; out (b,m,128) point-major
+ *            nsample 32; out (b,m,128) point-major; ball_idx (b,m,32) REQUIRED (workspace and
+ *            output of the level's ball query, which runs as a first launch)
  *   level 2: dims {131,128,128,256}; pts = xyz (b,n,3) n<=64, feat (b,n,128) point-major,
  *            new_xyz (b,m,3), nsample 32; out (b,m,256)
  *   level 3: dims {259,256,512,768}; group-all over n = 16 points: pts = xyz (b,16,3),
@@ -120,7 +121,7 @@ int msr3d_sa_fps2(int b, int n, int point_stride, int m1, int m2, const float *p
  * paramsL: layer L packed by the host as [N][KP + MSR3D_SA_WPAD] weight rows (K order: level 1
  * [dxyz,rgb], levels 2/3 [feat, (d)xyz]; zero-padded to KP = 16 / 144 / 272 for the first
  * layer, KP = K otherwise; the extra MSR3D_SA_WPAD floats per row are padding), then
- * scale[N], shift[N] (the eval-mode BN affine).  dbg_ball_idx (b,m,32) optional. */
+ * scale[N], shift[N] (the eval-mode BN affine).  ball_idx (b,m,32): optional output at level 2. */
 #define MSR3D_SA_WPAD 16
 int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pts,
                    const float *feat, const float *new_xyz, const int *dims,

@@ -255,4 +255,83 @@ inline hipError_t dispatch_fps(int b, int n, int ps, int m, const float *pts, in
   return hipErrorInvalidValue;   // > 32768 rank slots per cloud: not a configuration of this path
 }
 
+// =================================================================================
+// Ball query (ball_query_gpu.cu:9-44).  The reference gives each centre ONE thread
+// that walks all n points.  Here a wave owns a centre and tests 64 points per step:
+// ballot -> prefix popcount gives every hit its output slot in index order, and the
+// wave stops as soon as nsample hits are placed.  The cloud is staged in LDS once
+// per block and shared by the block's centres.
+// =================================================================================
+template <int NW, bool STAGE>
+__global__ __launch_bounds__(kWave * NW) void ball_query_kernel(int n, int m, float radius2,
+                                                                int nsample,
+                                                                const float *__restrict__ new_xyz,
+                                                                const float *__restrict__ xyz,
+                                                                int ps, int *__restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *sx = reinterpret_cast<float *>(smem);
+  const int obj = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid >> 6;
+  const float *P = xyz + (size_t)obj * n * ps;   // ps floats per point, xyz first
+  if (STAGE) {
+    for (int i = tid; i < n * 3; i += kWave * NW) {
+      const int p = i / 3;
+      sx[i] = P[p * ps + (i - p * 3)];
+    }
+    __syncthreads();
+  }
+  const float *src = STAGE ? sx : P;
+  const int st = STAGE ? 3 : ps;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+
+  for (int j = blockIdx.y * NW + wave; j < m; j += NW * gridDim.y) {
+    const float *c = new_xyz + ((size_t)obj * m + j) * 3;
+    const float cx = c[0], cy = c[1], cz = c[2];
+    int *row = idx + ((size_t)obj * m + j) * nsample;
+    int cnt = 0, first = 0;
+    for (int base = 0; base < n && cnt < nsample; base += kWave) {
+      const int k = base + lane;
+      bool hit = false;
+      if (k < n) {
+        const float d2 = sq3(cx - src[k * st + 0], cy - src[k * st + 1], cz - src[k * st + 2]);
+        hit = d2 < radius2;
+      }
+      const unsigned long long mask = __ballot(hit);
+      if (mask) {
+        if (cnt == 0) first = base + __ffsll((long long)mask) - 1;
+        const int slot = cnt + __popcll(mask & lt);
+        if (hit && slot < nsample) row[slot] = k;
+        cnt += __popcll(mask);
+      }
+    }
+    // slots never reached: the first hit (pre-fill at :32-36) or 0 (host zero-init)
+    const int filled = cnt < nsample ? cnt : nsample;
+    const int fill = cnt > 0 ? first : 0;
+    for (int l = filled + lane; l < nsample; l += kWave) row[l] = fill;
+  }
+}
+
+
+inline hipError_t launch_ball_query(int b, int n, int ps, int m, float radius2, int nsample,
+                                    const float *new_xyz, const float *xyz, int *idx,
+                                    hipStream_t st) {
+  constexpr int NW = 4;
+  int ysplit = (1024 + b - 1) / b;          // enough blocks to cover 256 CUs at small b
+  const int ymax = (m + NW - 1) / NW;
+  if (ysplit > ymax) ysplit = ymax;
+  if (ysplit < 1) ysplit = 1;
+  dim3 grid(b, ysplit);
+  const bool stage = (size_t)n * 12 <= 64 * 1024;
+  if (stage) {
+    ball_query_kernel<NW, true><<<grid, kWave * NW, (size_t)n * 12, st>>>(n, m, radius2, nsample,
+                                                                         new_xyz, xyz, ps, idx);
+  } else {
+    ball_query_kernel<NW, false><<<grid, kWave * NW, 0, st>>>(n, m, radius2, nsample, new_xyz, xyz,
+                                                              ps, idx);
+  }
+  return hipGetLastError();
+}
+
 }  // namespace msr3d

@@ -20,60 +20,6 @@ namespace {
 
 using namespace msr3d;
 
-// =================================================================================
-// Ball query (ball_query_gpu.cu:9-44).  The reference gives each centre ONE thread
-// that walks all n points.  Here a wave owns a centre and tests 64 points per step:
-// ballot -> prefix popcount gives every hit its output slot in index order, and the
-// wave stops as soon as nsample hits are placed.  The cloud is staged in LDS once
-// per block and shared by the block's centres.
-// =================================================================================
-template <int NW, bool STAGE>
-__global__ __launch_bounds__(kWave * NW) void ball_query_kernel(int n, int m, float radius2,
-                                                                int nsample,
-                                                                const float *__restrict__ new_xyz,
-                                                                const float *__restrict__ xyz,
-                                                                int *__restrict__ idx) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float *sx = reinterpret_cast<float *>(smem);
-  const int obj = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int lane = tid & (kWave - 1);
-  const int wave = tid >> 6;
-  const float *P = xyz + (size_t)obj * n * 3;
-  if (STAGE) {
-    for (int i = tid; i < n * 3; i += kWave * NW) sx[i] = P[i];
-    __syncthreads();
-  }
-  const float *src = STAGE ? sx : P;
-  const unsigned long long lt = (1ull << lane) - 1ull;
-
-  for (int j = blockIdx.y * NW + wave; j < m; j += NW * gridDim.y) {
-    const float *c = new_xyz + ((size_t)obj * m + j) * 3;
-    const float cx = c[0], cy = c[1], cz = c[2];
-    int *row = idx + ((size_t)obj * m + j) * nsample;
-    int cnt = 0, first = 0;
-    for (int base = 0; base < n && cnt < nsample; base += kWave) {
-      const int k = base + lane;
-      bool hit = false;
-      if (k < n) {
-        const float d2 = sq3(cx - src[k * 3 + 0], cy - src[k * 3 + 1], cz - src[k * 3 + 2]);
-        hit = d2 < radius2;
-      }
-      const unsigned long long mask = __ballot(hit);
-      if (mask) {
-        if (cnt == 0) first = base + __ffsll((long long)mask) - 1;
-        const int slot = cnt + __popcll(mask & lt);
-        if (hit && slot < nsample) row[slot] = k;
-        cnt += __popcll(mask);
-      }
-    }
-    // slots never reached: the first hit (pre-fill at :32-36) or 0 (host zero-init)
-    const int filled = cnt < nsample ? cnt : nsample;
-    const int fill = cnt > 0 ? first : 0;
-    for (int l = filled + lane; l < nsample; l += kWave) row[l] = fill;
-  }
-}
-
 // ---- gather / group: exact copies, one thread per output element ----------------
 __global__ void gather_points_kernel(long long total, int c, int n, int m,
                                      const float *__restrict__ points,
@@ -291,21 +237,7 @@ int msr3d_ball_query(int b, int n, int m, float radius, int nsample, const float
   if ((long long)b * m * nsample == 0) return 0;
   if (!new_xyz || !xyz || !idx) return MSR3D_EINVAL;
   const float radius2 = radius * radius;   // ball_query_gpu.cu:22, f32 product
-  constexpr int NW = 4;
-  int ysplit = (1024 + b - 1) / b;          // enough blocks to cover 256 CUs at small b
-  const int ymax = (m + NW - 1) / NW;
-  if (ysplit > ymax) ysplit = ymax;
-  if (ysplit < 1) ysplit = 1;
-  dim3 grid(b, ysplit);
-  const bool stage = (size_t)n * 12 <= 64 * 1024;
-  if (stage) {
-    ball_query_kernel<NW, true><<<grid, kWave * NW, (size_t)n * 12, (hipStream_t)stream>>>(
-        n, m, radius2, nsample, new_xyz, xyz, idx);
-  } else {
-    ball_query_kernel<NW, false><<<grid, kWave * NW, 0, (hipStream_t)stream>>>(
-        n, m, radius2, nsample, new_xyz, xyz, idx);
-  }
-  return (int)hipGetLastError();
+  return (int)launch_ball_query(b, n, 3, m, radius2, nsample, new_xyz, xyz, idx, (hipStream_t)stream);
 }
 
 int msr3d_group_points(int b, int c, int n, int npoints, int nsample, const float *points,

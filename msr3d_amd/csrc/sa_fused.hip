@@ -7,7 +7,8 @@
 // through HBM, is here ONE launch per level plus one index launch:
 //
 //   msr3d_sa_fps2   FPS of level 1 and of level 2 (on level 1's winners), one wave per cloud
-//   msr3d_sa_level  ball query (wave ballot) -> neighbourhood gather + recentre straight
+//   msr3d_sa_level  ball query (wave ballot; level 1: its own launch over the 1024-point clouds,
+//                   level 2: inside the block) -> neighbourhood gather + recentre straight
 //                   into LDS -> three GEMM layers on f32-input MFMA (16x16x4) with the
 //                   BN(eval) affine + ReLU applied on the accumulators, activations kept
 //                   in LDS -> max over the neighbourhood taken on the accumulators ->
@@ -295,52 +296,36 @@ constexpr int kNS = 32;   // neighbours per centre in both query levels (configs
 template <int CPB> struct Sa1 { using C = Chain<CPB * kNS, 16, 64, 64, 128, kNS, 2, 2>; };
 
 template <int CPB>
-__global__ __launch_bounds__(256) void sa1_kernel(int n, int m, float radius2,
-                                                  const float *__restrict__ pts,
-                                                  const float *__restrict__ new_xyz, Layer l1,
-                                                  Layer l2, Layer l3, float *__restrict__ out,
-                                                  int *__restrict__ dbg_idx) {
+__global__ __launch_bounds__(256) void sa1_kernel(int n, int m, const float *__restrict__ pts,
+                                                  const float *__restrict__ new_xyz,
+                                                  const int *__restrict__ ball_idx, Layer l1,
+                                                  Layer l2, Layer l3, float *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using Chain1 = typename Sa1<CPB>::C;
   constexpr int TM = CPB * kNS;
   float *bufA = reinterpret_cast<float *>(smem);
   float *bufB = bufA + TM * Chain1::LDA;
-  int *nbr = reinterpret_cast<int *>(bufB + TM * Chain1::LDB);   // [CPB][32]
-  float *ctr = reinterpret_cast<float *>(nbr + 4 * kNS);          // [4][4]
-  float *sx = ctr + 16;                                            // [n][3]
 
   const int obj = blockIdx.y, c0 = blockIdx.x * CPB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   typename Chain1::Pre1 pre;
-  Chain1::preload(l1, pre);          // layer-1 weights/affine in flight during staging + ball query
+  Chain1::preload(l1, pre);          // layer-1 weights/affine in flight during the gather
   const float *P = pts + (size_t)obj * n * 6;
-  for (int i = tid; i < n * 3; i += 256) {
-    const int p = i / 3, c = i - p * 3;
-    sx[i] = P[p * 6 + c];
-  }
-  if (tid < 3 * CPB) {
-    const int w = tid / 3, c = tid - w * 3;
-    ctr[w * 4 + c] = (c0 + w < m) ? new_xyz[((size_t)obj * m + c0 + w) * 3 + c] : 0.f;
-  }
-  __syncthreads();
-  if (wave < CPB) {
-    if (c0 + wave < m)
-      wave_ball_query(sx, n, ctr[wave * 4 + 0], ctr[wave * 4 + 1], ctr[wave * 4 + 2], radius2, kNS,
-                      nbr + wave * kNS, lane);
-    else if (lane < kNS)
-      nbr[wave * kNS + lane] = 0;
-  }
-  __syncthreads();
-  if (dbg_idx && tid < CPB * kNS && c0 + tid / kNS < m)
-    dbg_idx[((size_t)obj * m + c0) * kNS + tid] = nbr[tid];
-  // gather: row = (centre w, sample k); cols [x-cx, y-cy, z-cz, r, g, b, 0 x10]
-  for (int e = tid; e < TM * 16; e += 256) {
-    const int row = e >> 4, c = e & 15;
-    const int p = nbr[row];
-    float v = 0.f;
-    if (c < 3) v = sx[p * 3 + c] - ctr[(row >> 5) * 4 + c];
-    else if (c < 6) v = P[p * 6 + c];
-    bufA[row * Chain1::LDA + c] = v;
+  // gather: row = (centre w, sample k); cols [x-cx, y-cy, z-cz, r, g, b, 0 x10].  The ball
+  // indices come from the wave-ballot query launched just before (msr3d_sa_level does both);
+  // each point row is 24 B = three 8-byte loads.
+  for (int e = tid; e < TM * 8; e += 256) {
+    const int row = e >> 3, c2 = e & 7;
+    const int cj = c0 + (row >> 5);
+    float2 v = make_float2(0.f, 0.f);
+    if (c2 < 3 && cj < m) {
+      const int p = ball_idx[((size_t)obj * m + cj) * kNS + (row & 31)];
+      v = *reinterpret_cast<const float2 *>(P + (size_t)p * 6 + c2 * 2);
+      const float *c = new_xyz + ((size_t)obj * m + cj) * 3;
+      if (c2 == 0) { v.x -= c[0]; v.y -= c[1]; }
+      else if (c2 == 1) { v.x -= c[2]; }
+    }
+    *reinterpret_cast<float2 *>(bufA + row * Chain1::LDA + c2 * 2) = v;
   }
   __syncthreads();
   const int groups = (m - c0) < CPB ? (m - c0) : CPB;
@@ -567,14 +552,19 @@ int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pt
     // pts (b,n,6); dims = {6, 64, 64, 128}
     if (!(dims[0] == 6 && dims[1] == 64 && dims[2] == 64 && dims[3] == 128)) return MSR3D_EINVAL;
     if (!pts || !new_xyz || n <= 0 || m <= 0) return MSR3D_EINVAL;
+    // two launches: the wave-ballot ball query over the in-place (stride 6) point rows into
+    // ball_idx (required here: it is this level's workspace), then gather + MLP + max.  Keeping
+    // the query out of the MLP kernel leaves it 37 KB of LDS -> 4 blocks per CU.
+    if (!dbg_ball_idx) return MSR3D_EINVAL;
+    if ((e = launch_ball_query(b, n, 6, m, r2, kNS, new_xyz, pts, dbg_ball_idx, st)) != hipSuccess)
+      return (int)e;
     constexpr int CPB = MSR3D_SA1_CPB;
-    const size_t lds = sizeof(float) * (Sa1<CPB>::C::LDS_FLOATS + 4 * kNS + 16 + (size_t)n * 3);
-    if (lds > 160 * 1024) return MSR3D_EINVAL;
+    const size_t lds = sizeof(float) * Sa1<CPB>::C::LDS_FLOATS;
     if ((e = allow_lds(sa1_kernel<CPB>, lds)) != hipSuccess) return (int)e;
     dim3 grid((m + CPB - 1) / CPB, b);
-    sa1_kernel<CPB><<<grid, 256, lds, st>>>(n, m, r2, pts, new_xyz, make_layer(params1, 64, 16),
-                                            make_layer(params2, 64, 64),
-                                            make_layer(params3, 128, 64), out, dbg_ball_idx);
+    sa1_kernel<CPB><<<grid, 256, lds, st>>>(n, m, pts, new_xyz, dbg_ball_idx,
+                                            make_layer(params1, 64, 16), make_layer(params2, 64, 64),
+                                            make_layer(params3, 128, 64), out);
   } else if (level == 2) {
     // pts = xyz (b,n,3), feat (b,n,128); dims = {131, 128, 128, 256}
     if (!(dims[0] == 131 && dims[1] == 128 && dims[2] == 128 && dims[3] == 256)) return MSR3D_EINVAL;

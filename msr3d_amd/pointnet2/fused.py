@@ -122,11 +122,12 @@ def forward(net, pts, return_internals=False):
     feat1 = torch.empty((b, m1, 128), dtype=torch.float32, device=dev)
     feat2 = torch.empty((b, m2, 256), dtype=torch.float32, device=dev)
     pooled = torch.empty((b, 768), dtype=torch.float32, device=dev)
+    ball1 = torch.empty((b, m1, _NSAMPLE), dtype=torch.int32, device=dev)   # level-1 workspace
     dbg = {}
     if return_internals:
         dbg = {"idx1": torch.empty((b, m1), dtype=torch.int32, device=dev),
                "idx2": torch.empty((b, m2), dtype=torch.int32, device=dev),
-               "ball1": torch.empty((b, m1, _NSAMPLE), dtype=torch.int32, device=dev),
+               "ball1": ball1,
                "ball2": torch.empty((b, m2, _NSAMPLE), dtype=torch.int32, device=dev)}
     with torch.cuda.device(dev):
         st = _lib.current_stream_ptr(dev)
@@ -138,7 +139,7 @@ def forward(net, pts, return_internals=False):
         with _lib.kernel_timer("msr3d_sa_level1"):
             rc = lib.msr3d_sa_level(1, b, n, m1, ctypes.c_float(sa1.groupers[0].radius), _p(pts),
                                     _p(None), _p(new1), plan["dims"][0], _p(L[0][0]), _p(L[0][1]),
-                                    _p(L[0][2]), _p(feat1), _p(dbg.get("ball1")), st)
+                                    _p(L[0][2]), _p(feat1), _p(ball1), st)
         _lib.check(rc, "msr3d_sa_level(1)")
         with _lib.kernel_timer("msr3d_sa_level2"):
             rc = lib.msr3d_sa_level(2, b, m1, m2, ctypes.c_float(sa2.groupers[0].radius), _p(new1),
