@@ -12,12 +12,15 @@
 //   backward dW = dy^T x         : A = dy (not KC), B = x (not KC)  reduction over tokens
 //
 // These are SMALL problems (M = 960 tokens at 16 scenes/GPU; 0.1 - 2 GFLOP each): what
-// matters is that every launch fills the chip for its few microseconds, so the tile is
-// 64x64 (4 waves x 32x32) with BK = 32, LDS double-buffered, operands staged
-// global -> registers -> LDS with 16-byte accesses.  hipBLASLt's heuristic picks a
+// matters is that every launch fills the chip for its few microseconds: 64x64 tiles (4 waves
+// x 32x32) with split-K for the 256-wide outputs, 128-row / 128-column tiles where a side is
+// long; BK = 32, LDS double-buffered, operands staged global -> registers -> LDS with 16-byte
+// accesses.  hipBLASLt's heuristic picks a
 // 256x256 macro-tile = ONE workgroup for the (960 x 256 x 256) fp32 linears of this path
 // (215 us each, profiles/r01_v2_bench_kernel_stats.csv); this kernel is the replacement.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "../../include/msr3d_hip.h"
 
@@ -25,27 +28,30 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int BM = 64, BN = 64, BK = 32;
-constexpr int LD_KC = BK + 8;    // [64][40]: stride/4 == 2 (mod 4) -> conflict-free ds_read_b128 fragments
-constexpr int LD_MC = BM + 4;    // [32][68]: half-wave (g = 0,1) lands on disjoint bank halves
-constexpr int TILE_FLOATS = 64 * LD_KC;   // >= 32 * LD_MC
+constexpr int BK = 32;
+constexpr int LD_KC = BK + 8;    // [TR][40]: stride/4 == 2 (mod 4) -> conflict-free ds_read_b128 fragments
+
+__host__ __device__ constexpr int ld_mc(int tr) { return tr + 4; }   // [32][TR+4]: half-waves on disjoint banks
+__host__ __device__ constexpr int tile_floats(int tr) { return tr * LD_KC; }   // >= 32 * (tr + 4) for tr >= 64
 
 __device__ __forceinline__ float gelu_f(float x) {     // exact erf GELU (F.gelu default)
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-// ---- global -> registers: one 64 x 32 operand tile = 2 float4 per thread -------------
-// KC tile: rows = output index (64), cols = k (32).   thread t: row = t/8 + 32p, k4 = (t%8)*4
-// MC tile: rows = k (32), cols = output index (64).   thread t: krow = t/16 + 16p, c4 = (t%16)*4
-template <bool KC>
+// ---- global -> registers: one TR x 32 operand tile = TR/32 float4 per thread ------------
+// KC tile: rows = output index (TR), cols = k (32).   thread t: row = t/8 + 32p, k4 = (t%8)*4
+// MC tile: rows = k (32), cols = output index (TR).   thread t: krow = t/(TR/4) + (1024/TR) p,
+//                                                                 c4 = (t % (TR/4)) * 4
+template <bool KC, int TR>
 __device__ __forceinline__ void load_tile(const float *__restrict__ P, int ld, int o0, int k0,
-                                          int O, int K, bool vec_ok, float4 (&r)[2]) {
+                                          int O, int K, bool vec_ok, float4 (&r)[TR / 32]) {
   const int t = threadIdx.x;
+  constexpr int TPR = TR / 4;            // threads per k-row in the MC layout
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < TR / 32; ++p) {
     int row, col;          // row/col in GLOBAL matrix terms
     if (KC) { row = o0 + (t >> 3) + 32 * p; col = k0 + (t & 7) * 4; }
-    else    { row = k0 + (t >> 4) + 16 * p; col = o0 + (t & 15) * 4; }
+    else    { row = k0 + t / TPR + (256 / TPR) * p; col = o0 + (t % TPR) * 4; }
     const int R = KC ? O : K, Cn = KC ? K : O;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < R) {
@@ -63,18 +69,19 @@ __device__ __forceinline__ void load_tile(const float *__restrict__ P, int ld, i
   }
 }
 
-template <bool KC>
-__device__ __forceinline__ void store_tile(float *s, const float4 (&r)[2]) {
+template <bool KC, int TR>
+__device__ __forceinline__ void store_tile(float *s, const float4 (&r)[TR / 32]) {
   const int t = threadIdx.x;
+  constexpr int TPR = TR / 4;
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < TR / 32; ++p) {
     if (KC) *reinterpret_cast<float4 *>(s + ((t >> 3) + 32 * p) * LD_KC + (t & 7) * 4) = r[p];
-    else    *reinterpret_cast<float4 *>(s + ((t >> 4) + 16 * p) * LD_MC + (t & 15) * 4) = r[p];
+    else    *reinterpret_cast<float4 *>(s + (t / TPR + (256 / TPR) * p) * ld_mc(TR) + (t % TPR) * 4) = r[p];
   }
 }
 
 // fragment for MFMA step s of 16-wide sub-slab `sub`: element (row = base + i, k = 16 sub + 4g + s)
-template <bool KC>
+template <bool KC, int TR>
 __device__ __forceinline__ void read_frag(const float *s, int base, int sub, int i, int g,
                                           float (&f)[4]) {
   if (KC) {
@@ -82,11 +89,12 @@ __device__ __forceinline__ void read_frag(const float *s, int base, int sub, int
     f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
   } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) f[q] = s[(sub * 16 + 4 * g + q) * LD_MC + base + i];
+    for (int q = 0; q < 4; ++q) f[q] = s[(sub * 16 + 4 * g + q) * ld_mc(TR) + base + i];
   }
 }
 
-template <bool A_KC, bool B_KC>
+// Workgroup tile (32 RM) x (32 RN): 2 x 2 waves of (16 RM) x (16 RN) each.
+template <bool A_KC, bool B_KC, int RM, int RN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
                                                        const float *__restrict__ A, int lda,
                                                        const float *__restrict__ B, int ldb,
@@ -96,20 +104,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
                                                        float beta, int a_vec, int b_vec,
                                                        int slabs_per_split,
                                                        float *__restrict__ a_colsum) {
-  __shared__ __attribute__((aligned(16))) float smem[4 * TILE_FLOATS];
-  float *const As = smem;                       // [2][TILE_FLOATS]
-  float *const Bs = smem + 2 * TILE_FLOATS;     // [2][TILE_FLOATS]
+  constexpr int BM = 32 * RM, BN = 32 * RN;
+  constexpr int TA = tile_floats(BM), TB = tile_floats(BN);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *const As = smem;                 // [2][TA]
+  float *const Bs = smem + 2 * TA;        // [2][TB]
 
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;          // 2 x 2 waves, 32 x 32 each
+  const int wm = wave >> 1, wn = wave & 1;
   const int i = lane & 15, g = lane >> 4;
 
-  f32x4 acc[2][2];
+  f32x4 acc[RM][RN];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < RM; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < RN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // split-K: blockIdx.z owns slabs [kbeg, kend); partial sums meet in C by atomicAdd
   const int nk_all = (K + BK - 1) / BK;
@@ -118,80 +128,83 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
   const int nk = kend - kbeg;
   if (nk <= 0) return;
 
-  float4 ra[2], rb[2];
-  load_tile<A_KC>(A, lda, m0, kbeg * BK, M, K, a_vec, ra);
-  load_tile<B_KC>(B, ldb, n0, kbeg * BK, N, K, b_vec, rb);
-  store_tile<A_KC>(As, ra);
-  store_tile<B_KC>(Bs, rb);
+  float4 ra[BM / 32], rb[BN / 32];
+  load_tile<A_KC, BM>(A, lda, m0, kbeg * BK, M, K, a_vec, ra);
+  load_tile<B_KC, BN>(B, ldb, n0, kbeg * BK, N, K, b_vec, rb);
+  store_tile<A_KC, BM>(As, ra);
+  store_tile<B_KC, BN>(Bs, rb);
   __syncthreads();
 
   // bias gradient for free: in the dW product (A = dy, k-strided) the A tiles of the first
   // column of workgroups stream every dy element exactly once; thread t owns 4 columns
-  // (t & 15) * 4 .. +3 of the tile for 2 of the 32 k-rows per slab.
+  // (t % (BM/4)) * 4 .. +3 of the tile for BM/32 of the 32 k-rows per slab.
   const bool do_colsum = (!A_KC) && a_colsum != nullptr && blockIdx.x == 0;
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
   if (do_colsum) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) { csum.x += ra[p].x; csum.y += ra[p].y; csum.z += ra[p].z; csum.w += ra[p].w; }
+    for (int p = 0; p < BM / 32; ++p) { csum.x += ra[p].x; csum.y += ra[p].y; csum.z += ra[p].z; csum.w += ra[p].w; }
   }
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {                               // prefetch the next slab into registers
-      load_tile<A_KC>(A, lda, m0, (kbeg + kt + 1) * BK, M, K, a_vec, ra);
-      load_tile<B_KC>(B, ldb, n0, (kbeg + kt + 1) * BK, N, K, b_vec, rb);
+      load_tile<A_KC, BM>(A, lda, m0, (kbeg + kt + 1) * BK, M, K, a_vec, ra);
+      load_tile<B_KC, BN>(B, ldb, n0, (kbeg + kt + 1) * BK, N, K, b_vec, rb);
     }
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
-      float fa[2][4], fb[2][4];
+      float fa[RM][4], fb[RN][4];
 #pragma unroll
-      for (int rm = 0; rm < 2; ++rm) read_frag<A_KC>(As + cur * TILE_FLOATS, wm * 32 + rm * 16, sub, i, g, fa[rm]);
+      for (int rm = 0; rm < RM; ++rm)
+        read_frag<A_KC, BM>(As + cur * TA, wm * (16 * RM) + rm * 16, sub, i, g, fa[rm]);
 #pragma unroll
-      for (int rn = 0; rn < 2; ++rn) read_frag<B_KC>(Bs + cur * TILE_FLOATS, wn * 32 + rn * 16, sub, i, g, fb[rn]);
+      for (int rn = 0; rn < RN; ++rn)
+        read_frag<B_KC, BN>(Bs + cur * TB, wn * (16 * RN) + rn * 16, sub, i, g, fb[rn]);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int rm = 0; rm < 2; ++rm)
+        for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
-          for (int rn = 0; rn < 2; ++rn)
+          for (int rn = 0; rn < RN; ++rn)
             acc[rm][rn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[rm][s], fb[rn][s], acc[rm][rn], 0, 0, 0);
     }
     if (kt + 1 < nk) {
       if (do_colsum) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) { csum.x += ra[p].x; csum.y += ra[p].y; csum.z += ra[p].z; csum.w += ra[p].w; }
+        for (int p = 0; p < BM / 32; ++p) { csum.x += ra[p].x; csum.y += ra[p].y; csum.z += ra[p].z; csum.w += ra[p].w; }
       }
-      store_tile<A_KC>(As + (cur ^ 1) * TILE_FLOATS, ra);             // other buffer: nobody reads it this round
-      store_tile<B_KC>(Bs + (cur ^ 1) * TILE_FLOATS, rb);
+      store_tile<A_KC, BM>(As + (cur ^ 1) * TA, ra);   // other buffer: nobody reads it this round
+      store_tile<B_KC, BN>(Bs + (cur ^ 1) * TB, rb);
     }
     __syncthreads();
   }
 
   if (do_colsum) {
-    // 16 threads (same t & 15) x 4 columns: reduce the 16 partial sums through LDS
+    // 256 / (BM/4) threads share each group of 4 columns: reduce their partial sums through LDS
+    constexpr int TPR = BM / 4;
     float *red = smem;                               // all MFMA reads are behind the last barrier
     *reinterpret_cast<float4 *>(red + threadIdx.x * 4) = csum;
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < BM) {
       const int c = threadIdx.x;                     // column of the tile
       float tot = 0.f;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) tot += red[(j * 16 + (c >> 2)) * 4 + (c & 3)];
+      for (int j = 0; j < 256 / TPR; ++j) tot += red[(j * TPR + (c >> 2)) * 4 + (c & 3)];
       if (m0 + c < M) atomicAdd(a_colsum + m0 + c, tot);
     }
   }
 
   // epilogue: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
-  for (int rn = 0; rn < 2; ++rn) {
-    const int col = n0 + wn * 32 + rn * 16 + i;
+  for (int rn = 0; rn < RN; ++rn) {
+    const int col = n0 + wn * (16 * RN) + rn * 16 + i;
     if (col >= N) continue;
     const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
 #pragma unroll
-    for (int rm = 0; rm < 2; ++rm)
+    for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 32 + rm * 16 + g * 4 + r;
+        const int row = m0 + wm * (16 * RM) + rm * 16 + g * 4 + r;
         if (row >= M) continue;
         float v = acc[rm][rn][r] + bv;
         const size_t o = (size_t)row * ldc + col;
@@ -248,9 +261,26 @@ inline bool vec_ok(const float *p, int ld) {
   return ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) && (ld % 4 == 0);
 }
 
-}  // namespace
-
-extern "C" {
+template <bool AK, bool BKc, int RM, int RN>
+static hipError_t launch_gemm(dim3 grid, hipStream_t st, int M, int N, int K, const float *A,
+                              int lda, const float *B, int ldb, float *C, int ldc,
+                              const float *bias, float *C_pre, int flags, float beta, int av, int bv,
+                              int per, float *a_colsum) {
+  constexpr size_t lds = sizeof(float) * 2 * (tile_floats(32 * RM) + tile_floats(32 * RN));
+  auto kern = gemm_f32_kernel<AK, BKc, RM, RN>;
+  if (lds > 64 * 1024) {
+    static bool done = false;
+    if (!done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      done = true;
+    }
+  }
+  kern<<<grid, 256, lds, st>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags, beta, av, bv, per,
+                               a_colsum);
+  return hipGetLastError();
+}
 
 static int gemm_f32_impl(int a_kc, int b_kc, int M, int N, int K, const float *A, int lda,
                          const float *B, int ldb, float *C, int ldc, const float *bias,
@@ -259,14 +289,30 @@ static int gemm_f32_impl(int a_kc, int b_kc, int M, int N, int K, const float *A
   if (M < 0 || N < 0 || K < 0 || lda <= 0 || ldb <= 0 || ldc <= 0) return MSR3D_EINVAL;
   if (M == 0 || N == 0) return 0;
   if (!A || !B || !C) return MSR3D_EINVAL;
-  const int tiles = ((N + BN - 1) / BN) * ((M + BM - 1) / BM);
+  // Tile choice.  Measured on the path's shapes (tools/bench_gemm.py, tools/ablate_gemm.py): the
+  // staging path sustains ~10 B/clk/CU, so a 64x64 tile (16 FLOP/B) is load-bound at ~60 TFLOP/s
+  // in steady state; 128-wide tiles halve the traffic but these problems (M = 960 tokens, 0.1-2
+  // GFLOP) then have too few workgroups to cover the load latency and time WORSE (ffn1 forward
+  // 27 -> 51 us).  So: 64x64 everywhere, split-K only when there are fewer than 256 tiles.  The
+  // larger tiles stay selectable (MSR3D_GEMM_BIG_TILES=1) for bigger batches.
+  auto ntiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+  int rm = 2, rn = 2;
+  constexpr int target_wgs = 512;
+  static const int big_tiles = getenv("MSR3D_GEMM_BIG_TILES") ? atoi(getenv("MSR3D_GEMM_BIG_TILES")) : 0;
+  if (big_tiles) {
+    if (ntiles(128, 128) >= 192) { rm = 4; rn = 4; }
+    else if (N >= M && ntiles(64, 128) >= 192) { rm = 2; rn = 4; }
+    else if (ntiles(128, 64) >= 192) { rm = 4; rn = 2; }
+    else if (ntiles(64, 128) >= 192) { rm = 2; rn = 4; }
+  }
+  const int BM = 32 * rm, BN = 32 * rn;
+  const int tiles = ntiles(BM, BN);
   const int slabs = (K + BK - 1) / BK;
-  // Every GEMM of this path has one short side (256) and M = 960 tokens: few tiles, long K.
   // Split K until ~2 workgroups per CU exist, keeping >= 2 slabs per split.  The fused GELU
   // needs the complete sum, and beta must be 0 or 1 for the atomic meeting point.
   int splits = 1;
   if (!(flags & 1) && (beta == 0.f || beta == 1.f) && tiles < 256 && slabs >= 4) {
-    splits = (512 + tiles - 1) / tiles;
+    splits = (target_wgs + tiles - 1) / tiles;
     if (splits > slabs / 2) splits = slabs / 2;
     if (splits < 1) splits = 1;
   }
@@ -295,15 +341,27 @@ static int gemm_f32_impl(int a_kc, int b_kc, int M, int N, int K, const float *A
   splits = (slabs + per - 1) / per;
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits);
   const int av = vec_ok(A, lda), bv = vec_ok(B, ldb);
-#define LAUNCH(AK, BKc) \
-  gemm_f32_kernel<AK, BKc><<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags, beta, av, bv, per, a_colsum)
-  if (a_kc && b_kc) LAUNCH(true, true);
-  else if (a_kc && !b_kc) LAUNCH(true, false);
-  else if (!a_kc && !b_kc) LAUNCH(false, false);
-  else LAUNCH(false, true);
-#undef LAUNCH
-  return (int)hipGetLastError();
+  hipError_t e = hipErrorInvalidValue;
+#define ARGS grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags, beta, av, bv, per, a_colsum
+#define PICK(AK, BKc)                                                       \
+  do {                                                                      \
+    if (rm == 2 && rn == 2) e = launch_gemm<AK, BKc, 2, 2>(ARGS);           \
+    else if (rm == 4 && rn == 2) e = launch_gemm<AK, BKc, 4, 2>(ARGS);      \
+    else if (rm == 2 && rn == 4) e = launch_gemm<AK, BKc, 2, 4>(ARGS);      \
+    else e = launch_gemm<AK, BKc, 4, 4>(ARGS);                              \
+  } while (0)
+  if (a_kc && b_kc) PICK(true, true);
+  else if (a_kc && !b_kc) PICK(true, false);
+  else if (!a_kc && !b_kc) PICK(false, false);
+  else PICK(false, true);
+#undef PICK
+#undef ARGS
+  return (int)e;
 }
+
+}  // namespace
+
+extern "C" {
 
 int msr3d_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float *A, int lda,
                    const float *B, int ldb, float *C, int ldc, const float *bias, float *C_pre,
