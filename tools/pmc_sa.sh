@@ -18,18 +18,20 @@ run fetch FETCH_SIZE GRBM_GUI_ACTIVE
 run write WRITE_SIZE
 run tcc TCC_HIT TCC_MISS TCC_REQ
 python - "$ROOT/$OUT" <<'PY'
-import csv, glob, sys, collections, os
+import csv, glob, sys, collections
 out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for d in sorted(glob.glob(out + "/*/")):
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0].split("::")[-1][:40]
-            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        for key in ("sa1_kernel", "sa2_kernel", "sa3_kernel", "fps_kernel", "ball_query_kernel"):
+            if key in r["Kernel_Name"]:
+                agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as fo:
-    for k, cs in agg.items():
-        if not any(s in k for s in ("sa1_kernel", "sa2_kernel", "sa3_kernel", "fps_kernel")):
-            continue
-        line = k + ": " + ", ".join(f"{c}={sum(v)/len(v):.4g}" for c, v in sorted(cs.items()))
-        print(line); fo.write(line + "\n")
+    fo.write("# rocprofv3 --pmc passes over tools/bench_sa.py (960 objects per launch), per-launch means\n")
+    fo.write("# FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE under-reports wide streams by 2x on gfx950)\n")
+    for k, cs in sorted(agg.items()):
+        fo.write(k + "\n")
+        for c, v in sorted(cs.items()):
+            fo.write(f"    {c:32s} {sum(v) / len(v):.6g}\n")
+print(open(out + "/summary.txt").read())
 PY
