@@ -39,6 +39,9 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #ifndef MSR3D_SA2_CPB
 #define MSR3D_SA2_CPB 2
 #endif
+#ifndef MSR3D_SA2_NG
+#define MSR3D_SA2_NG 1   // 2 = two phase-offset tile groups per block: measured 9 % SLOWER (see sa2_kernel)
+#endif
 
 constexpr int kWPad = MSR3D_SA_WPAD;   // packed weight rows are [N][K + kWPad]: a 16-row B-fragment load then
                               // spreads over channels instead of hitting one power-of-two stride
@@ -202,18 +205,22 @@ struct Chain {
     float4 b[RN1];
     float sc[RN1], sh[RN1];
   };
-  __device__ static void preload(const Layer &l1, Pre1 &p) {
-    const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) % WN;
+  __device__ static void preload(const Layer &l1, Pre1 &p, int tid) {
+    const int lane = tid & 63, wn = (tid >> 6) % WN;
     const int col0 = wn * RN1 * 16;
     load_b_first<RN1, K0P>(l1.w + (size_t)col0 * (K0P + kWPad), lane, p.b);
     load_affine<RN1>(l1.scale + col0, l1.shift + col0, lane, p.sc, p.sh);
   }
 
   // out: first pooled row of this block; `groups_valid_block`: pooled rows of this block that exist
+  // `tid`: thread index inside the 256-thread tile group.  SPLIT: put a block barrier between
+  // each layer's MFMA phase and its epilogue, so that two tile groups running one barrier
+  // interval apart alternate "MFMA" and "epilogue / loader" intervals (see sa2_kernel).
+  template <bool SPLIT = false>
   __device__ static void run(float *bufA, float *bufB, const Pre1 &p1, const Layer &l1,
-                             const Layer &l2, const Layer &l3, float *__restrict__ out, int groups_valid_block,
-                             long long *tstamp = nullptr) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                             const Layer &l2, const Layer &l3, float *__restrict__ out,
+                             int groups_valid_block, int tid, long long *tstamp = nullptr) {
+    const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int row0 = wm * RM * 16;
     float4 b2[RN2], b3[RN3];
@@ -227,6 +234,7 @@ struct Chain {
       load_b_first<RN2, N1>(l2.w + (size_t)(wn * RN2 * 16) * (N1 + kWPad), lane, b2);
       load_affine<RN2>(l2.scale + wn * RN2 * 16, l2.shift + wn * RN2 * 16, lane, sc2, sh2);
       if (tstamp) tstamp[0] = clock64();
+      if (SPLIT) __syncthreads();
       store_bn_relu_lds<RM, RN1>(acc, p1.sc, p1.sh, bufB + row0 * LDB + col0, LDB, lane);
     }
     __syncthreads();
@@ -239,6 +247,7 @@ struct Chain {
       load_b_first<RN3, N2>(l3.w + (size_t)(wn * RN3 * 16) * (N2 + kWPad), lane, b3);
       load_affine<RN3>(l3.scale + wn * RN3 * 16, l3.shift + wn * RN3 * 16, lane, sc3, sh3);
       if (tstamp) tstamp[2] = clock64();
+      if (SPLIT) __syncthreads();
       store_bn_relu_lds<RM, RN2>(acc, sc2, sh2, bufA + row0 * LDA + col0, LDA, lane);
     }
     __syncthreads();
@@ -249,6 +258,7 @@ struct Chain {
       zero_acc(acc);
       gemm_lds_global<RM, RN3, N2>(bufA + row0 * LDA, LDA, l3.w + (size_t)col0 * (N2 + kWPad), acc, lane, b3);
       if (tstamp) tstamp[4] = clock64();
+      if (SPLIT) __syncthreads();
       const int g0 = wm * (RM / GT);            // first pooled row owned by this wave
       int gv = groups_valid_block - g0;
       store_bn_relu_groupmax<RM, RN3, GT>(acc, sc3, sh3, out + (size_t)g0 * N3 + col0, N3, gv, lane);
@@ -309,7 +319,7 @@ __global__ __launch_bounds__(256) void sa1_kernel(int n, int m, const float *__r
   const int obj = blockIdx.y, c0 = blockIdx.x * CPB;
   const int tid = threadIdx.x;
   typename Chain1::Pre1 pre;
-  Chain1::preload(l1, pre);          // layer-1 weights/affine in flight during the gather
+  Chain1::preload(l1, pre, tid);     // layer-1 weights/affine in flight during the gather
   const float *P = pts + (size_t)obj * n * 6;
   // gather: row = (centre w, sample k); cols [x-cx, y-cy, z-cz, r, g, b, 0 x10].  The ball
   // indices come from the wave-ballot query launched just before (msr3d_sa_level does both);
@@ -329,7 +339,7 @@ __global__ __launch_bounds__(256) void sa1_kernel(int n, int m, const float *__r
   }
   __syncthreads();
   const int groups = (m - c0) < CPB ? (m - c0) : CPB;
-  Chain1::run(bufA, bufB, pre, l1, l2, l3, out + ((size_t)obj * m + c0) * 128, groups);
+  Chain1::run(bufA, bufB, pre, l1, l2, l3, out + ((size_t)obj * m + c0) * 128, groups, tid);
 }
 
 // =================================================================================
@@ -339,30 +349,41 @@ __global__ __launch_bounds__(256) void sa1_kernel(int n, int m, const float *__r
 // =================================================================================
 template <int CPB> struct Sa2 { using C = Chain<CPB * kNS, 144, 128, 128, 256, kNS, 2, 2>; };
 
-template <int CPB>
-__global__ __launch_bounds__(256) void sa2_kernel(int n, int m, float radius2,
-                                                  const float *__restrict__ xyz,
-                                                  const float *__restrict__ feat,
-                                                  const float *__restrict__ new_xyz, Layer l1,
-                                                  Layer l2, Layer l3, float *__restrict__ out,
-                                                  int *__restrict__ dbg_idx) {
+// NG = 2: the block holds TWO independent 64-row tiles (8 waves, two per SIMD).  Both tile groups
+// run the same program -- [stage] [ball query] [gather] [MFMA 1] [epi 1] [MFMA 2] [epi 2] [MFMA 3]
+// [epi 3], a block barrier after each -- but group 1 starts one barrier interval late (one extra
+// leading barrier for group 1, one extra trailing barrier for group 0).  From then on the groups
+// alternate: while one issues a layer's MFMAs, the other runs its epilogue / loader interval on
+// the same SIMDs' VALU, LDS and memory pipes, instead of both hitting the matrix pipe together
+// and both leaving it idle together (identical blocks sharing a CU march in lockstep; measured:
+// 64-row tiles at 2 blocks/CU timed exactly like 128-row tiles at 1 block/CU).
+// RESULT (MI355X, 960 objects): NG = 2 runs 693 us vs 637 us for NG = 1 at 2 blocks/CU -- with only
+// one group in its MFMA interval at a time each SIMD has a single wave to cover the B-fragment
+// load latency (RM = 2: one 16-byte load per 8 MFMAs), which costs more than the hidden
+// epilogues give back.  Kept selectable (MSR3D_SA2_NG) as a measured dead end; default NG = 1.
+template <int CPB, int NG>
+__global__ __launch_bounds__(256 * NG) void sa2_kernel(int n, int m, float radius2,
+                                                       const float *__restrict__ xyz,
+                                                       const float *__restrict__ feat,
+                                                       const float *__restrict__ new_xyz, Layer l1,
+                                                       Layer l2, Layer l3, float *__restrict__ out,
+                                                       int *__restrict__ dbg_idx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using Chain2 = typename Sa2<CPB>::C;
   constexpr int TM = CPB * kNS;
-  float *bufA = reinterpret_cast<float *>(smem);
+  constexpr int GROUP_FLOATS = Chain2::LDS_FLOATS + 4 * kNS + 16 + 64 * 3;
+  const int gid = NG > 1 ? (int)(threadIdx.x >> 8) : 0;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  float *bufA = reinterpret_cast<float *>(smem) + (size_t)gid * GROUP_FLOATS;
   float *bufB = bufA + TM * Chain2::LDA;
   int *nbr = reinterpret_cast<int *>(bufB + TM * Chain2::LDB);   // [CPB][32]
   float *ctr = reinterpret_cast<float *>(nbr + 4 * kNS);          // [4][4]
   float *sx = ctr + 16;                                            // [n][3], n <= 64
 
-  const int obj = blockIdx.y, c0 = blockIdx.x * CPB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef MSR3D_PROF
-  long long ts[8];
-  ts[0] = clock64();
-#endif
+  const int obj = blockIdx.y, c0 = (blockIdx.x * NG + gid) * CPB;   // may be >= m: barriers still run
   typename Chain2::Pre1 pre;
-  Chain2::preload(l1, pre);          // layer-1 weights/affine in flight during the loader phase
+  Chain2::preload(l1, pre, tid);     // layer-1 weights/affine in flight during the loader phase
+  if (NG > 1 && gid == 1) __syncthreads();          // the one-interval phase offset
   if (tid < n * 3) sx[tid] = xyz[(size_t)obj * n * 3 + tid];
   if (tid >= 192 && tid < 192 + 3 * CPB) {
     const int t = tid - 192, w = t / 3, c = t - w * 3;
@@ -377,13 +398,8 @@ __global__ __launch_bounds__(256) void sa2_kernel(int n, int m, float radius2,
       nbr[wave * kNS + lane] = 0;
   }
   __syncthreads();
-#ifndef MSR3D_PROF
   if (dbg_idx && tid < CPB * kNS && c0 + tid / kNS < m)
     dbg_idx[((size_t)obj * m + c0) * kNS + tid] = nbr[tid];
-#endif
-#ifdef MSR3D_PROF
-  ts[1] = clock64();
-#endif
   const float *F = feat + (size_t)obj * n * 128;
   {   // 32 float4 per row; indices first, then ALL loads, then the LDS stores: one L2 round trip
     constexpr int IT = TM * 32 / 256;
@@ -410,26 +426,11 @@ __global__ __launch_bounds__(256) void sa2_kernel(int n, int m, float radius2,
     for (int c = 3; c < 16; ++c) d[c] = 0.f;
   }
   __syncthreads();
-  const int groups = (m - c0) < CPB ? (m - c0) : CPB;
-#ifdef MSR3D_PROF
-  ts[2] = clock64();
-  long long tl[5];
-  Chain2::run(bufA, bufB, pre, l1, l2, l3, out + ((size_t)obj * m + c0) * 256, groups, tl);
-  ts[7] = clock64();
-  if (dbg_idx && tid == 0) {   // PROF build: dbg buffer carries phase durations instead of indices
-    int *o = dbg_idx + ((size_t)obj * gridDim.x + blockIdx.x) * 8;
-    o[0] = (int)(ts[1] - ts[0]);   // stage + ball query
-    o[1] = (int)(ts[2] - ts[1]);   // gather
-    o[2] = (int)(tl[0] - ts[2]);   // layer 1 mfma
-    o[3] = (int)(tl[1] - tl[0]);   // layer 1 epilogue + barrier
-    o[4] = (int)(tl[2] - tl[1]);   // layer 2 mfma
-    o[5] = (int)(tl[3] - tl[2]);   // layer 2 epilogue + barrier
-    o[6] = (int)(tl[4] - tl[3]);   // layer 3 mfma
-    o[7] = (int)(ts[7] - tl[4]);   // layer 3 epilogue
-  }
-#else
-  Chain2::run(bufA, bufB, pre, l1, l2, l3, out + ((size_t)obj * m + c0) * 256, groups);
-#endif
+  int groups = m - c0;
+  groups = groups < 0 ? 0 : (groups < CPB ? groups : CPB);
+  Chain2::template run<(NG > 1)>(bufA, bufB, pre, l1, l2, l3, out + ((size_t)obj * m + c0) * 256,
+                                 groups, tid);
+  if (NG > 1 && gid == 0) __syncthreads();          // matches group 1's leading barrier
 }
 
 // =================================================================================
@@ -569,14 +570,14 @@ int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pt
     // pts = xyz (b,n,3), feat (b,n,128); dims = {131, 128, 128, 256}
     if (!(dims[0] == 131 && dims[1] == 128 && dims[2] == 128 && dims[3] == 256)) return MSR3D_EINVAL;
     if (!pts || !feat || !new_xyz || n <= 0 || n > 64 || m <= 0) return MSR3D_EINVAL;
-    constexpr int CPB = MSR3D_SA2_CPB;
-    const size_t lds = sizeof(float) * (Sa2<CPB>::C::LDS_FLOATS + 4 * kNS + 16 + 64 * 3);
-    if ((e = allow_lds(sa2_kernel<CPB>, lds)) != hipSuccess) return (int)e;
-    dim3 grid((m + CPB - 1) / CPB, b);
-    sa2_kernel<CPB><<<grid, 256, lds, st>>>(n, m, r2, pts, feat, new_xyz,
-                                            make_layer(params1, 128, 144),
-                                            make_layer(params2, 128, 128),
-                                            make_layer(params3, 256, 128), out, dbg_ball_idx);
+    constexpr int CPB = MSR3D_SA2_CPB, NG = MSR3D_SA2_NG;
+    const size_t lds = sizeof(float) * NG * (Sa2<CPB>::C::LDS_FLOATS + 4 * kNS + 16 + 64 * 3);
+    if ((e = allow_lds(sa2_kernel<CPB, NG>, lds)) != hipSuccess) return (int)e;
+    dim3 grid((m + CPB * NG - 1) / (CPB * NG), b);
+    sa2_kernel<CPB, NG><<<grid, 256 * NG, lds, st>>>(n, m, r2, pts, feat, new_xyz,
+                                                     make_layer(params1, 128, 144),
+                                                     make_layer(params2, 128, 128),
+                                                     make_layer(params3, 256, 128), out, dbg_ball_idx);
   } else if (level == 3) {
     // group-all over n = 16 points: pts = xyz (b,16,3), feat (b,16,256); dims = {259,256,512,768}
     if (!(dims[0] == 259 && dims[1] == 256 && dims[2] == 512 && dims[3] == 768)) return MSR3D_EINVAL;
