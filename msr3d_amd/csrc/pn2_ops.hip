@@ -197,8 +197,9 @@ const char *msr3d_status_string(int status) {
 
 int msr3d_furthest_point_sampling(int b, int n, int m, const float *xyz, int *idx,
                                   float *new_xyz, msr3d_stream_t stream) {
-  if (b < 0 || n <= 0 || m < 0 || !xyz || (!idx && b * m > 0)) return MSR3D_EINVAL;
-  if (b == 0 || m == 0) return 0;
+  if (b < 0 || n <= 0 || m < 0) return MSR3D_EINVAL;
+  if (b == 0 || m == 0) return 0;              // empty problem: nothing to write
+  if (!xyz || !idx) return MSR3D_EINVAL;
   const hipError_t e = dispatch_fps(b, n, 3, m, xyz, idx, new_xyz, 0, nullptr, nullptr,
                                      (hipStream_t)stream);
   return e == hipErrorInvalidValue ? MSR3D_EINVAL : (int)e;

@@ -533,8 +533,9 @@ extern "C" {
 
 int msr3d_sa_fps2(int b, int n, int point_stride, int m1, int m2, const float *pts, int *idx1,
                   float *new_xyz1, int *idx2, float *new_xyz2, msr3d_stream_t stream) {
-  if (b < 0 || n <= 0 || m1 <= 0 || m2 < 0 || point_stride < 3 || !pts) return MSR3D_EINVAL;
+  if (b < 0 || n <= 0 || m1 <= 0 || m2 < 0 || point_stride < 3) return MSR3D_EINVAL;
   if (b == 0) return 0;
+  if (!pts) return MSR3D_EINVAL;
   const hipError_t e = dispatch_fps(b, n, point_stride, m1, pts, idx1, new_xyz1, m2, idx2,
                                     new_xyz2, (hipStream_t)stream);
   return e == hipErrorInvalidValue ? MSR3D_EINVAL : (int)e;
@@ -544,8 +545,9 @@ int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pt
                    const float *feat, const float *new_xyz, const int *dims,
                    const float *params1, const float *params2, const float *params3, float *out,
                    int *dbg_ball_idx, msr3d_stream_t stream) {
-  if (b < 0 || !dims || !params1 || !params2 || !params3 || !out) return MSR3D_EINVAL;
+  if (b < 0 || !dims) return MSR3D_EINVAL;
   if (b == 0) return 0;
+  if (!params1 || !params2 || !params3 || !out) return MSR3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const float r2 = radius * radius;   // f32 product, as ball_query_gpu.cu:22
   hipError_t e;

@@ -26,6 +26,7 @@ def test_invalid_arguments_are_rejected_without_a_device():
     # n <= 0 / null pointers -> MSR3D_EINVAL, never a crash or an exit()
     assert h.msr3d_furthest_point_sampling(1, 0, 4, null, null, null, null) == -22
     assert h.msr3d_furthest_point_sampling(1, 8, 4, null, null, null, null) == -22
+    assert h.msr3d_furthest_point_sampling(0, 8, 4, null, null, null, null) == 0      # empty batch
     assert h.msr3d_ball_query(-1, 8, 4, ctypes.c_float(0.2), 4, null, null, null, null) == -22
     assert h.msr3d_group_points(1, 1, 8, 2, 2, null, null, null, null) == -22
     assert h.msr3d_status_string(-22) == b"invalid argument"

@@ -1,0 +1,107 @@
+"""GPU: BASELINE.json's full sizes (16 scenes x 60 objects x 1024 points = 960 clouds per
+launch; stress shape 2048 points) through size-independent properties, plus a sampled
+comparison with the oracle, plus the empty / degenerate inputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pn2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def batch():
+    from msr3d_amd.synth import synth_batch
+    return synth_batch(2024, 16, O=60, P=1024, device="cuda")
+
+
+def test_fps_ball_group_properties_full_batch(batch):
+    from msr3d_amd.pointnet2 import _ext
+    fts = batch["obj_fts"].reshape(-1, 1024, 6)
+    xyz = fts[..., :3].contiguous()
+    b = xyz.shape[0]
+    assert b == 960
+    idx = _ext.furthest_point_sampling(xyz, 32)
+    assert idx.shape == (b, 32) and idx.dtype == torch.int32
+    assert (idx[:, 0] == 0).all() and (idx >= 0).all() and (idx < 1024).all()
+    pad = ~batch["obj_masks"].reshape(-1)
+    assert (idx[pad] == 0).all()                                  # all-ones padding objects
+    real = idx[~pad].long()
+    # a real object's winners are pairwise distinct POINTS (duplicates of one point may repeat an
+    # index only if the cloud has < 32 distinct points, which the generator never produces)
+    pts = torch.gather(xyz[~pad], 1, real.unsqueeze(-1).expand(-1, -1, 3))
+    d = torch.cdist(pts, pts) + torch.eye(32, device="cuda") * 10
+    assert (d.min(-1)[0] > 0).all()
+    # sampled exact comparison with the oracle
+    sel = torch.arange(0, b, 37, device="cuda")
+    want = pn2.furthest_point_sampling(xyz[sel].cpu().numpy(), 32)
+    assert np.array_equal(idx[sel].cpu().numpy(), want)
+
+    new_xyz = torch.gather(xyz, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    g = _ext.gather_points(xyz.transpose(1, 2).contiguous(), idx)
+    assert torch.equal(g.transpose(1, 2), new_xyz)                # exact copy == torch.gather
+    bq = _ext.ball_query(new_xyz, xyz, 0.2, 32)
+    # rows: strictly increasing prefix of hits, then the first hit repeated; every hit in radius
+    inc = bq[:, :, 1:] > bq[:, :, :-1]
+    first = bq[:, :, :1]
+    tail_ok = inc | (bq[:, :, 1:] == first)
+    assert tail_ok.all()
+    assert ((~inc).cumsum(-1)[:, :, -1:] >= (~inc).sum(-1, keepdim=True)).all()
+    nb = torch.gather(xyz.unsqueeze(1).expand(-1, 32, -1, -1), 2,
+                      bq.long().unsqueeze(-1).expand(-1, -1, -1, 3))
+    d2 = ((nb - new_xyz.unsqueeze(2)) ** 2).sum(-1)
+    assert (d2 < 0.2 * 0.2 + 1e-6).all()                          # the centre itself always hits
+    want = pn2.ball_query(new_xyz[sel].cpu().numpy(), xyz[sel].cpu().numpy(), 0.2, 32)
+    assert np.array_equal(bq[sel].cpu().numpy(), want)
+    grouped = _ext.group_points(xyz.transpose(1, 2).contiguous(), bq)
+    assert torch.equal(grouped.permute(0, 2, 3, 1), nb)
+
+
+def test_fused_encoder_full_batch_matches_composite(batch):
+    from msr3d_amd.modules.layers.pointnet import PointNetPP
+    from tests.helpers import fill_state_dict, rel_l2
+    net = PointNetPP(sa_n_points=[32, 16, None], sa_n_samples=[32, 32, None], sa_radii=[0.2, 0.4, None],
+                     sa_mlps=[[3, 64, 64, 128], [128, 128, 128, 256], [256, 256, 512, 768]])
+    net.load_state_dict(fill_state_dict(net.state_dict(), 5))
+    net = net.cuda().eval()
+    pts = batch["obj_fts"].reshape(-1, 1024, 6)
+    with torch.no_grad():
+        fused_out = net(pts)
+        net.use_fused = False
+        ref = net(pts[:120])                        # composite path on a slice (it is slow)
+    assert rel_l2(fused_out[:120].cpu().numpy(), ref.cpu().numpy()) < 2e-5
+    # object independence: permuting the clouds permutes the features
+    perm = torch.randperm(pts.shape[0], device="cuda")
+    net.use_fused = True
+    with torch.no_grad():
+        assert torch.equal(net(pts[perm]), fused_out[perm])
+
+
+def test_stress_shape_2048_points():
+    """BASELINE config 5 shape (2048 points per object): FPS uses the 2-wave path."""
+    from msr3d_amd.pointnet2 import _ext
+    rng = np.random.default_rng(3)
+    xyz = rng.uniform(-1, 1, (24, 2048, 3)).astype(np.float32)
+    got = _ext.furthest_point_sampling(torch.from_numpy(xyz).cuda(), 32).cpu().numpy()
+    assert np.array_equal(got, pn2.furthest_point_sampling(xyz, 32))
+
+
+def test_empty_and_degenerate_inputs():
+    from msr3d_amd.pointnet2 import _ext
+    dev = "cuda"
+    assert _ext.furthest_point_sampling(torch.zeros(0, 16, 3, device=dev), 4).shape == (0, 4)
+    assert _ext.ball_query(torch.zeros(0, 4, 3, device=dev), torch.zeros(0, 16, 3, device=dev), 0.2, 8).shape == (0, 4, 8)
+    assert _ext.group_points(torch.zeros(2, 0, 16, device=dev), torch.zeros(2, 4, 8, dtype=torch.int32, device=dev)).shape == (2, 0, 4, 8)
+    assert _ext.gather_points(torch.zeros(2, 3, 16, device=dev), torch.zeros(2, 0, dtype=torch.int32, device=dev)).shape == (2, 3, 0)
+    g = _ext.group_points_grad(torch.zeros(2, 3, 0, 8, device=dev), torch.zeros(2, 0, 8, dtype=torch.int32, device=dev), 16)
+    assert g.shape == (2, 3, 16) and (g == 0).all()              # no contributions: zeros, defined
+    # m == n: every point selected exactly once when all points are distinct and none is skipped
+    x = torch.rand(3, 40, 3, device=dev) + 0.5
+    idx = _ext.furthest_point_sampling(x, 40)
+    assert (idx.sort(-1)[0] == torch.arange(40, device=dev, dtype=torch.int32)).all()
+    # a single point
+    assert (_ext.furthest_point_sampling(x[:, :1].contiguous(), 1) == 0).all()
+    # nsample larger than n
+    bq = _ext.ball_query(x[:, :2].contiguous(), x, 100.0, 64)
+    assert (bq[:, :, :40] == torch.arange(40, device=dev, dtype=torch.int32)).all() and (bq[:, :, 40:] == 0).all()
