@@ -231,6 +231,23 @@ int msr3d_dropout_add_ln_bwd(int M, int D, const float *dy, const float *s, cons
 int msr3d_bump_seed(unsigned long long *seed, msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Hand-off to the LLM: write the projected scene tokens into `inputs_embeds` / `attention_mask`
+ * at the scene placeholders (/root/reference/model/msr3d/msr3d.py:279-287), without the host
+ * sync of torch.where.  input_ids (B,T) int64; scene_embeds (n_scene, E) f32 (= llm_proj
+ * output, B*L rows); scene_mask (n_scene) bytes (obj_masks, may be NULL with attention_mask);
+ * inputs_embeds (B*T, E) of out_dtype 0 = f32, 1 = f16, 2 = bf16, updated IN PLACE;
+ * attention_mask (B,T) int64 updated in place (may be NULL).  The k-th placeholder in
+ * row-major order receives scene token k (k < n_scene).  map_ws: n_scene ints of workspace;
+ * count_out: 1 int, receives the number of placeholders found (the reference errors out when
+ * it differs from n_scene; the caller may check it without stalling the stream).
+ * ------------------------------------------------------------------------- */
+int msr3d_scene_scatter(int B, int T, int n_scene, int E, const long long *input_ids,
+                        long long scene_token, const float *scene_embeds,
+                        const unsigned char *scene_mask, int out_dtype, void *inputs_embeds,
+                        long long *attention_mask, int *map_ws, int *count_out,
+                        msr3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Optimiser step of the hot path: global-norm clip + AdamW over flat buffers
  * (/root/reference/optim/build.py:7-17, trainer/leo_trainer.py:189-195,
  * optim/scheduler.py:17-25).  All buffers hold n floats (n % 4 == 0, 16-byte aligned).

@@ -29,6 +29,7 @@ SOURCES = [
     ("optim_flat.hip", ["-ffp-contract=off"]),
     ("rowops.hip", []),
     ("prologue.hip", ["-ffp-contract=off"]),
+    ("scene_scatter.hip", []),
 ]
 
 

@@ -520,11 +520,16 @@ inline Layer make_layer(const float *packed, int n, int kp) {
   return l;
 }
 
+// Raise a kernel's dynamic-LDS limit above the 64 KB default, once per (kernel, size).
 template <typename K>
 inline hipError_t allow_lds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  static size_t granted = 0;        // one static per instantiation = per kernel
+  if (bytes <= granted) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) granted = bytes;
+  return e;
 }
 
 }  // namespace

@@ -68,7 +68,6 @@ class FlatGradAllReduce:
         self.numel = total
         self.buckets = []                                   # (start, end) element ranges
         self._bucket_of = {}
-        self._pending = []
         off = b_start = 0
         per_bucket = max(1, bucket_bytes // 4)
         for p in order:
@@ -97,7 +96,6 @@ class FlatGradAllReduce:
         # with producers that write the flat buffer directly (hipops).  overlap=True launches
         # each bucket from the gradient hooks as soon as it is complete instead.
         self.defer_comm = not overlap
-        self._handles = []
         if self.world > 1:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)

@@ -36,6 +36,40 @@ def scatter_scene_embeds(inputs_embeds, attention_mask, input_ids, scene_embeds,
     return out_embeds, out_mask
 
 
+_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def scatter_scene_embeds_(inputs_embeds, attention_mask, input_ids, scene_embeds, scene_mask,
+                          scene_sp_token=SCENE_SP_TOKEN):
+    """In-place HIP version of the same hand-off (msr3d_scene_scatter): two launches, no host
+    sync.  inputs_embeds (B,T,E) f32/f16/bf16 contiguous, attention_mask (B,T) int64 (or None),
+    input_ids (B,T) int64, scene_embeds (B,L,E) f32, scene_mask (B,L) bool.  Returns the device
+    int holding the number of placeholders found (== B*L in a well-formed batch)."""
+    import ctypes
+
+    from .. import _lib
+    B, T = input_ids.shape
+    E = scene_embeds.shape[-1]
+    n = scene_embeds.shape[0] * scene_embeds.shape[1]
+    if not (inputs_embeds.is_cuda and inputs_embeds.is_contiguous() and input_ids.dtype == torch.int64):
+        raise RuntimeError("scatter_scene_embeds_: contiguous GPU tensors and int64 ids expected")
+    if attention_mask is not None and (attention_mask.dtype != torch.int64 or not attention_mask.is_contiguous()):
+        raise RuntimeError("attention_mask must be contiguous int64")
+    src = scene_embeds.reshape(n, E).float().contiguous()
+    msk = scene_mask.reshape(n).contiguous().view(torch.uint8) if scene_mask is not None else None
+    ws = torch.empty(n, dtype=torch.int32, device=input_ids.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=input_ids.device)
+    p = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+    lib = _lib.load()
+    with torch.cuda.device(input_ids.device):
+        rc = lib.msr3d_scene_scatter(B, T, n, E, p(input_ids.contiguous()), int(scene_sp_token), p(src), p(msk),
+                                     _DTYPE_CODE[inputs_embeds.dtype], p(inputs_embeds),
+                                     p(attention_mask), p(ws), p(cnt),
+                                     _lib.current_stream_ptr(input_ids.device))
+    _lib.check(rc, "msr3d_scene_scatter")
+    return cnt
+
+
 @MODEL_REGISTRY.register()
 class MSR3DHotPath(nn.Module):
     """visual_prompter (OSE3DSituation) + llm_proj: the trainable, LLM-independent part of

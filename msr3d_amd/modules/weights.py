@@ -1,4 +1,5 @@
 """BERT-style initialisation (/root/reference/modules/weights.py:3-19)."""
+import torch
 import torch.nn as nn
 
 
@@ -10,7 +11,7 @@ def _init_weights_bert(module, std=0.02):
     elif isinstance(module, nn.Embedding):
         nn.init.normal_(module.weight, mean=0.0, std=std)
         if module.padding_idx is not None:
-            with __import__("torch").no_grad():
+            with torch.no_grad():
                 module.weight[module.padding_idx].zero_()
     elif isinstance(module, nn.LayerNorm):
         nn.init.zeros_(module.bias)

@@ -1,0 +1,57 @@
+"""GPU: msr3d_scene_scatter against the reference's own two statements
+(model/msr3d/msr3d.py:279-287: torch.where + indexed assignment), for the three embed dtypes,
+ragged placeholder positions, and placeholder counts that differ per row."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOKEN = 31495
+
+
+def reference_statements(inputs_embeds, attention_mask, input_ids, scene_embeds, scene_mask):
+    e = inputs_embeds.clone()
+    where = torch.where(input_ids == TOKEN)                                  # host sync in the reference
+    e[where] = scene_embeds.to(e.dtype).reshape(-1, scene_embeds.shape[-1])
+    m = attention_mask.unsqueeze(-1).to(scene_mask.dtype)
+    m[where] = scene_mask.unsqueeze(-1).reshape(-1, 1)
+    return e, m.squeeze(-1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,T,L,E", [(4, 300, 60, 512), (3, 700, 61, 4096), (2, 64, 5, 64)])
+def test_scatter_matches_reference_statements(dtype, B, T, L, E):
+    from msr3d_amd.model.scene_embeds import scatter_scene_embeds, scatter_scene_embeds_
+    torch.manual_seed(B * T + L)
+    ids = torch.randint(0, 30000, (B, T), device="cuda")
+    counts = [L] * B
+    if B >= 3:                       # total stays B*L but rows differ (global row-major order matters)
+        counts[0], counts[1] = L + 3, L - 3
+    for b in range(B):
+        pos = torch.randperm(T, device="cuda")[:counts[b]]
+        ids[b, pos] = TOKEN
+    emb = torch.randn(B, T, E, device="cuda").to(dtype)
+    am = torch.ones(B, T, dtype=torch.int64, device="cuda")
+    scene = torch.randn(B, L, E, device="cuda")
+    smask = torch.rand(B, L, device="cuda") > 0.3
+    want_e, want_m = reference_statements(emb, am, ids, scene, smask)
+
+    got_e, got_m = emb.clone(), am.clone()
+    cnt = scatter_scene_embeds_(got_e, got_m, ids, scene, smask)
+    assert int(cnt.item()) == B * L
+    assert torch.equal(got_e, want_e)
+    assert torch.equal(got_m.bool(), want_m)
+    # the functional torch version agrees as well
+    fe, fm = scatter_scene_embeds(emb, am, ids, scene, smask)
+    assert torch.equal(fe, want_e) and torch.equal(fm, want_m)
+
+
+def test_scatter_reports_wrong_placeholder_count_without_writing_out_of_range():
+    from msr3d_amd.model.scene_embeds import scatter_scene_embeds_
+    B, T, L, E = 2, 50, 4, 32
+    ids = torch.zeros(B, T, dtype=torch.int64, device="cuda")
+    ids[0, :6] = TOKEN                     # 6 placeholders for 8 scene tokens
+    emb = torch.zeros(B, T, E, device="cuda")
+    scene = torch.ones(B, L, E, device="cuda")
+    cnt = scatter_scene_embeds_(emb, None, ids, scene, None)
+    assert int(cnt.item()) == 6
+    assert emb[0, :6].eq(1).all() and emb[0, 6:].eq(0).all() and emb[1].eq(0).all()
