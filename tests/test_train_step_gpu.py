@@ -91,3 +91,35 @@ def test_packed_projection_views_match_separate_linears():
     wv = attn._packed[0]
     assert wv.shape == (816, 256) and wv.data_ptr() == attn.w_qs.weight.data_ptr()
     assert torch.equal(wv[256:512], attn.w_ks.weight) and torch.equal(wv[768:], attn.lang_cond_fc.weight)
+
+
+def test_prefetched_encoder_gives_identical_steps():
+    """step(batch, next_batch) (encoder of the next batch on the side stream) == sequential."""
+    import msr3d_amd.model  # noqa: F401
+    import msr3d_amd.modules  # noqa: F401
+    from msr3d_amd.config import AttrDict, default_prompter_cfg
+    from msr3d_amd.dp import FlatGradAllReduce
+    from msr3d_amd.model import build_model
+    from msr3d_amd.optim import FlatAdamW
+    from msr3d_amd.synth import synth_batch
+    from msr3d_amd.train_step import HotPathTrainStep
+
+    def run(pipelined):
+        torch.manual_seed(0)
+        cfg = AttrDict({"prompter": default_prompter_cfg(dropout=0.0), "llm_hidden_size": 64,
+                        "model": {"name": "MSR3DHotPath"}})
+        model = build_model(cfg).cuda().train()
+        dp = FlatGradAllReduce([p for p in model.parameters() if p.requires_grad])
+        opt = FlatAdamW(dp, lr=1e-3)
+        batches = [synth_batch(200 + i, 2, O=8, P=1024, device="cuda") for i in range(3)]
+        w = torch.randn(2, 8, 64, generator=torch.Generator().manual_seed(1)).cuda()
+        step = HotPathTrainStep(model, opt, dp, lambda o: (o["scene_embeds"] * w).mean(), batches[0],
+                                use_graph=False)
+        losses = []
+        for i in range(5):
+            nb = batches[(i + 1) % 3] if pipelined else None
+            losses.append(float(step(batches[i % 3], nb)))
+        torch.cuda.synchronize()
+        return losses
+
+    assert run(True) == pytest.approx(run(False), rel=1e-4, abs=1e-6)
