@@ -147,10 +147,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
+#ifdef MSR3D_GEMM_ABLATE   // tools/ablate_gemm.py: flags >> 8 switches phases of the main loop off
+    const int abl = flags >> 8;
+    if (kt + 1 < nk && !(abl & 1)) {
+#else
     if (kt + 1 < nk) {                               // prefetch the next slab into registers
+#endif
       load_tile<A_KC, BM>(A, lda, m0, (kbeg + kt + 1) * BK, M, K, a_vec, ra);
       load_tile<B_KC, BN>(B, ldb, n0, (kbeg + kt + 1) * BK, N, K, b_vec, rb);
     }
+#ifdef MSR3D_GEMM_ABLATE
+    if (!(abl & 2))
+#endif
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       float fa[RM][4], fb[RN][4];
@@ -173,9 +181,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
 #pragma unroll
         for (int p = 0; p < BM / 32; ++p) { csum.x += ra[p].x; csum.y += ra[p].y; csum.z += ra[p].z; csum.w += ra[p].w; }
       }
-      store_tile<A_KC, BM>(As + (cur ^ 1) * TA, ra);   // other buffer: nobody reads it this round
-      store_tile<B_KC, BN>(Bs + (cur ^ 1) * TB, rb);
+#ifdef MSR3D_GEMM_ABLATE
+      if (!(abl & 4))
+#endif
+      {
+        store_tile<A_KC, BM>(As + (cur ^ 1) * TA, ra);   // other buffer: nobody reads it this round
+        store_tile<B_KC, BN>(Bs + (cur ^ 1) * TB, rb);
+      }
     }
+#ifdef MSR3D_GEMM_ABLATE
+    if (!(abl & 8))
+#endif
     __syncthreads();
   }
 

@@ -381,6 +381,10 @@ __global__ __launch_bounds__(256 * NG) void sa2_kernel(int n, int m, float radiu
   float *sx = ctr + 16;                                            // [n][3], n <= 64
 
   const int obj = blockIdx.y, c0 = (blockIdx.x * NG + gid) * CPB;   // may be >= m: barriers still run
+#ifdef MSR3D_PROF      // phase stamps for tools/prof_sa2.py (build with -DMSR3D_PROF, NG = 1)
+  long long ts[4];
+  ts[0] = clock64();
+#endif
   typename Chain2::Pre1 pre;
   Chain2::preload(l1, pre, tid);     // layer-1 weights/affine in flight during the loader phase
   if (NG > 1 && gid == 1) __syncthreads();          // the one-interval phase offset
@@ -398,8 +402,12 @@ __global__ __launch_bounds__(256 * NG) void sa2_kernel(int n, int m, float radiu
       nbr[wave * kNS + lane] = 0;
   }
   __syncthreads();
+#ifndef MSR3D_PROF
   if (dbg_idx && tid < CPB * kNS && c0 + tid / kNS < m)
     dbg_idx[((size_t)obj * m + c0) * kNS + tid] = nbr[tid];
+#else
+  ts[1] = clock64();
+#endif
   const float *F = feat + (size_t)obj * n * 128;
   {   // 32 float4 per row; indices first, then ALL loads, then the LDS stores: one L2 round trip
     constexpr int IT = TM * 32 / 256;
@@ -428,8 +436,27 @@ __global__ __launch_bounds__(256 * NG) void sa2_kernel(int n, int m, float radiu
   __syncthreads();
   int groups = m - c0;
   groups = groups < 0 ? 0 : (groups < CPB ? groups : CPB);
+#ifdef MSR3D_PROF
+  ts[2] = clock64();
+  long long tl[5];
+  Chain2::template run<(NG > 1)>(bufA, bufB, pre, l1, l2, l3, out + ((size_t)obj * m + c0) * 256,
+                                 groups, tid, tl);
+  ts[3] = clock64();
+  if (dbg_idx && tid == 0) {   // PROF build: the debug buffer carries phase durations instead
+    int *o = dbg_idx + ((size_t)obj * gridDim.x + blockIdx.x) * 8;
+    o[0] = (int)(ts[1] - ts[0]);   // stage + ball query
+    o[1] = (int)(ts[2] - ts[1]);   // gather
+    o[2] = (int)(tl[0] - ts[2]);   // layer 1 mfma
+    o[3] = (int)(tl[1] - tl[0]);   // layer 1 epilogue + barrier
+    o[4] = (int)(tl[2] - tl[1]);   // layer 2 mfma
+    o[5] = (int)(tl[3] - tl[2]);   // layer 2 epilogue + barrier
+    o[6] = (int)(tl[4] - tl[3]);   // layer 3 mfma
+    o[7] = (int)(ts[3] - tl[4]);   // layer 3 epilogue
+  }
+#else
   Chain2::template run<(NG > 1)>(bufA, bufB, pre, l1, l2, l3, out + ((size_t)obj * m + c0) * 256,
                                  groups, tid);
+#endif
   if (NG > 1 && gid == 0) __syncthreads();          // matches group 1's leading barrier
 }
 

@@ -1,4 +1,7 @@
-"""Main-loop ablation of gemm_f32_kernel (MSR3D_GEMM_ABLATE build in tools/_prof/)."""
+"""Main-loop ablation of gemm_f32_kernel.  Build, from msr3d_amd/csrc:
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -I ../../include \\
+        -DMSR3D_GEMM_ABLATE -shared -o ../../tools/_prof/libgemm_ablate.so gemm_f32.hip
+"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,8 @@
 """Phase timing of sa2_kernel from an MSR3D_PROF build (clock64 stamps written to the debug
-buffer).  Build:  hipcc ... -DMSR3D_PROF -DMSR3D_SA2_CPB=<2|4> -shared -o tools/_prof/libprof_cpbN.so sa_fused.hip"""
+buffer).  Build, from msr3d_amd/csrc:
+    for c in 2 4; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I ../../include -ffp-contract=off \\
+        -DMSR3D_PROF -DMSR3D_SA2_CPB=$c -shared -o ../../tools/_prof/libprof_cpb$c.so sa_fused.hip; done
+"""
 import ctypes
 import os
 import sys
