@@ -171,7 +171,8 @@ int msr3d_gelu_bwd_f32(long long n, const float *dy, const float *pre, float *ou
  * (q, k, v and cond may be column blocks of ONE packed projection output);
  * pairwise_locs (B, L, L, spatial_dim); key_padding_mask (B, L) bytes, non-zero = padded;
  * ctx (B*L, H*dh); probs (B, H, L, L) (may be NULL in forward-only use).
- * Supported: L <= 64, dh = 32, spatial_dim = 5; anything else -> MSR3D_EINVAL.
+ * Supported: L <= 128 (a 64-token tile for L <= 64, a 128-token tile above), dh = 32,
+ * spatial_dim = 5; anything else -> MSR3D_EINVAL.
  * ------------------------------------------------------------------------- */
 int msr3d_spatial_attn_fwd(int B, int L, int H, int dh, int spatial_dim, const float *q,
                            const float *k, const float *v, int ld_qkv, const float *cond,

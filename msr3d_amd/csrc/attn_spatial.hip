@@ -16,8 +16,10 @@
 // the MFMA C/D layout).  fp32 like the reference (autocast is disabled around the
 // encoder, model/ose3d_situation.py:377).
 //
-// Shapes: L <= 64 tokens (60 objects, or 61 with the agent token), dh = 32, spatial_dim = 5,
-// one (bias, w[5]) sextet per (token, head) in `cond` (B*L, H*6).  Larger L takes the
+// Shapes: L <= 128 tokens, dh = 32, spatial_dim = 5, one (bias, w[5]) sextet per (token, head)
+// in `cond` (B*L, H*6).  Two instantiations: a 64-token tile (60 objects, or 61 with the agent
+// token: every shipped config; 4 waves) and a 128-token tile (the 120-object stress config,
+// BASELINE.json configs[4]; 8 waves, LDS tiles in dynamic shared memory).  Larger L takes the
 // composite path on the host side.
 #include <hip/hip_runtime.h>
 
@@ -29,11 +31,10 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int LT = 64;        // token tile (queries and keys)
 constexpr int DH = 32;        // head dim
 constexpr int SD = 5;         // spatial dims
-constexpr int LD32 = DH + 4;  // [64][36] tiles
-constexpr int LD64 = LT + 4;  // [64][68] tiles
+constexpr int LD32 = DH + 4;  // [LT][36] tiles
+constexpr int kMaxL = 128;
 constexpr float kSqrtDh = 5.656854249492381f;   // sqrt(32): s = dot / this (a division, as :205)
 
 // acc[rn] += sum_{k<KD} a(row0+i.., k) * b(rn*16+.., k) for this wave's 16-row strip.
@@ -76,10 +77,11 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-// token-major (B*L, ld) head slice -> LDS [64][36], rows >= L zero
+// token-major (B*L, ld) head slice -> LDS [LT][36], rows >= L zero
+template <int LT>
 __device__ __forceinline__ void load_head_tile(const float *__restrict__ src, int ld, int b, int h,
                                                int L, float *dst) {
-  for (int e = threadIdx.x; e < LT * (DH / 4); e += 256) {
+  for (int e = threadIdx.x; e < LT * (DH / 4); e += LT * 4) {
     const int row = e >> 3, c4 = (e & 7) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < L) v = *reinterpret_cast<const float4 *>(src + ((size_t)b * L + row) * ld + h * DH + c4);
@@ -105,9 +107,10 @@ __device__ __forceinline__ RowCond load_cond(const float *__restrict__ cond, int
 }
 
 // =================================================================================
-// forward.  grid (H, B), 256 threads; wave w owns query rows [16w, 16w+16).
+// forward.  grid (H, B), LT/16 waves; wave w owns query rows [16w, 16w+16).
 // =================================================================================
-__global__ __launch_bounds__(256) void attn_fwd_kernel(int B, int L, int H,
+template <int LT>
+__global__ __launch_bounds__(LT * 4) void attn_fwd_kernel(int B, int L, int H,
                                                        const float *__restrict__ q,
                                                        const float *__restrict__ k,
                                                        const float *__restrict__ v, int ldqkv,
@@ -116,20 +119,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int B, int L, int H,
                                                        const unsigned char *__restrict__ pad,
                                                        float *__restrict__ ctx,
                                                        float *__restrict__ probs) {
-  __shared__ __attribute__((aligned(16))) float sq[LT * LD32], sk[LT * LD32], sv[LT * LD32];
-  __shared__ __attribute__((aligned(16))) float sp[LT * LD64];
+  constexpr int NT = LT / 16, LDP = LT + 4;      // key tiles per row strip; [LT][LT+4] P tile
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *sq = smem, *sk = sq + LT * LD32, *sv = sk + LT * LD32, *sp = sv + LT * LD32;
   const int h = blockIdx.x, b = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4, row0 = wave * 16;
-  load_head_tile(q, ldqkv, b, h, L, sq);
-  load_head_tile(k, ldqkv, b, h, L, sk);
-  load_head_tile(v, ldqkv, b, h, L, sv);
+  load_head_tile<LT>(q, ldqkv, b, h, L, sq);
+  load_head_tile<LT>(k, ldqkv, b, h, L, sk);
+  load_head_tile<LT>(v, ldqkv, b, h, L, sv);
   __syncthreads();
 
-  f32x4 acc[4];
+  f32x4 acc[NT];
 #pragma unroll
-  for (int rn = 0; rn < 4; ++rn) acc[rn] = f32x4{0.f, 0.f, 0.f, 0.f};
-  strip_mma<4, DH, true, true>(sq, LD32, sk, LD32, row0, acc, lane);
+  for (int rn = 0; rn < NT; ++rn) acc[rn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  strip_mma<NT, DH, true, true>(sq, LD32, sk, LD32, row0, acc, lane);
 
   // logits on the accumulators: element (row = row0 + 4g + r, col = 16 rn + i)
   float mx[4], sm[4];
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int B, int L, int H,
     const RowCond c = load_cond(cond, ldc, b, h, L, row);
     float m = -INFINITY;
 #pragma unroll
-    for (int rn = 0; rn < 4; ++rn) {
+    for (int rn = 0; rn < NT; ++rn) {
       const int col = rn * 16 + i;
       float lg = -INFINITY;
       if (row < L && col < L && !pad[(size_t)b * L + col]) {
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int B, int L, int H,
   for (int r = 0; r < 4; ++r) {
     float s = 0.f;
 #pragma unroll
-    for (int rn = 0; rn < 4; ++rn) {
+    for (int rn = 0; rn < NT; ++rn) {
       const float e = (acc[rn][r] == -INFINITY) ? 0.f : expf(acc[rn][r] - mx[r]);
       acc[rn][r] = e;
       s += e;
@@ -171,10 +175,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int B, int L, int H,
     const int row = row0 + 4 * g + r;
     const float inv = 1.0f / sm[r];      // a fully padded row gives NaN, as the reference would
 #pragma unroll
-    for (int rn = 0; rn < 4; ++rn) {
+    for (int rn = 0; rn < NT; ++rn) {
       const int col = rn * 16 + i;
       const float p = (row < L) ? acc[rn][r] * inv : 0.f;
-      sp[row * LD64 + col] = p;
+      sp[row * LDP + col] = p;
       if (probs && row < L && col < L) probs[(((size_t)b * H + h) * L + row) * L + col] = p;
     }
   }
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int B, int L, int H,
   f32x4 o[2];
   o[0] = f32x4{0.f, 0.f, 0.f, 0.f};
   o[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  strip_mma<2, LT, true, false>(sp, LD64, sv, LD32, row0, o, lane);   // ctx = P V
+  strip_mma<2, LT, true, false>(sp, LDP, sv, LD32, row0, o, lane);   // ctx = P V
 #pragma unroll
   for (int rn = 0; rn < 2; ++rn)
 #pragma unroll
@@ -197,7 +201,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int B, int L, int H,
 // backward.  Inputs as forward + probs (saved) + dctx; outputs dq, dk, dv (token-major,
 // ld = ldg) and dcond (B*L, H*6).  pairwise_locs and the mask get no gradient.
 // =================================================================================
-__global__ __launch_bounds__(256) void attn_bwd_kernel(int B, int L, int H,
+template <int LT>
+__global__ __launch_bounds__(LT * 4) void attn_bwd_kernel(int B, int L, int H,
                                                        const float *__restrict__ q,
                                                        const float *__restrict__ k,
                                                        const float *__restrict__ v, int ldqkv,
@@ -210,42 +215,43 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(int B, int L, int H,
                                                        float *__restrict__ dk,
                                                        float *__restrict__ dv, int ldg,
                                                        float *__restrict__ dcond, int lddc) {
-  __shared__ __attribute__((aligned(16))) float sq[LT * LD32], sk[LT * LD32], sv[LT * LD32],
-      sdo[LT * LD32];
-  __shared__ __attribute__((aligned(16))) float sp[LT * LD64];   // P, then dS in place
+  constexpr int NT = LT / 16, LDP = LT + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *sq = smem, *sk = sq + LT * LD32, *sv = sk + LT * LD32, *sdo = sv + LT * LD32;
+  float *sp = sdo + LT * LD32;                    // P, then dS in place
   const int h = blockIdx.x, b = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4, row0 = wave * 16;
-  load_head_tile(q, ldqkv, b, h, L, sq);
-  load_head_tile(k, ldqkv, b, h, L, sk);
-  load_head_tile(v, ldqkv, b, h, L, sv);
-  load_head_tile(dctx, H * DH, b, h, L, sdo);
-  for (int e = threadIdx.x; e < LT * LT; e += 256) {
-    const int row = e >> 6, col = e & 63;
-    sp[row * LD64 + col] = (row < L && col < L) ? probs[(((size_t)b * H + h) * L + row) * L + col] : 0.f;
+  load_head_tile<LT>(q, ldqkv, b, h, L, sq);
+  load_head_tile<LT>(k, ldqkv, b, h, L, sk);
+  load_head_tile<LT>(v, ldqkv, b, h, L, sv);
+  load_head_tile<LT>(dctx, H * DH, b, h, L, sdo);
+  for (int e = threadIdx.x; e < LT * LT; e += LT * 4) {
+    const int row = e / LT, col = e % LT;
+    sp[row * LDP + col] = (row < L && col < L) ? probs[(((size_t)b * H + h) * L + row) * L + col] : 0.f;
   }
   __syncthreads();
 
   // dP = dctx V^T   (rows = queries, cols = keys)
-  f32x4 acc[4];
+  f32x4 acc[NT];
 #pragma unroll
-  for (int rn = 0; rn < 4; ++rn) acc[rn] = f32x4{0.f, 0.f, 0.f, 0.f};
-  strip_mma<4, DH, true, true>(sdo, LD32, sv, LD32, row0, acc, lane);
+  for (int rn = 0; rn < NT; ++rn) acc[rn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  strip_mma<NT, DH, true, true>(sdo, LD32, sv, LD32, row0, acc, lane);
   // dv = P^T dctx (rows = keys) while P is still intact
   f32x4 ov[2];
   ov[0] = f32x4{0.f, 0.f, 0.f, 0.f};
   ov[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  strip_mma<2, LT, false, false>(sp, LD64, sdo, LD32, row0, ov, lane);
+  strip_mma<2, LT, false, false>(sp, LDP, sdo, LD32, row0, ov, lane);
   __syncthreads();                       // every wave is done reading P as a matrix operand
 
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = row0 + 4 * g + r;
     float dot = 0.f;
-    float p[4];
+    float p[NT];
 #pragma unroll
-    for (int rn = 0; rn < 4; ++rn) {
-      p[rn] = sp[row * LD64 + rn * 16 + i];
+    for (int rn = 0; rn < NT; ++rn) {
+      p[rn] = sp[row * LDP + rn * 16 + i];
       dot = fmaf(p[rn], acc[rn][r], dot);
     }
     dot = row16_sum(dot);
@@ -254,10 +260,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(int B, int L, int H,
 #pragma unroll
     for (int d = 0; d < SD; ++d) gw[d] = 0.f;
 #pragma unroll
-    for (int rn = 0; rn < 4; ++rn) {
+    for (int rn = 0; rn < NT; ++rn) {
       const int col = rn * 16 + i;
       const float dlogit = p[rn] * (acc[rn][r] - dot);     // softmax backward
-      sp[row * LD64 + col] = dlogit;         // in place: this lane owns the element
+      sp[row * LDP + col] = dlogit;         // in place: this lane owns the element
       if (row < L && col < L && !pad[(size_t)b * L + col]) {
         const float *pl = ploc + (((size_t)b * L + row) * L + col) * SD;
         float z = c.bias;
@@ -290,8 +296,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(int B, int L, int H,
     oq[rn] = f32x4{0.f, 0.f, 0.f, 0.f};
     ok[rn] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  strip_mma<2, LT, true, false>(sp, LD64, sk, LD32, row0, oq, lane);
-  strip_mma<2, LT, false, false>(sp, LD64, sq, LD32, row0, ok, lane);
+  strip_mma<2, LT, true, false>(sp, LDP, sk, LD32, row0, oq, lane);
+  strip_mma<2, LT, false, false>(sp, LDP, sq, LD32, row0, ok, lane);
 #pragma unroll
   for (int rn = 0; rn < 2; ++rn)
 #pragma unroll
@@ -306,6 +312,30 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(int B, int L, int H,
     }
 }
 
+// dynamic LDS: forward 3 head tiles + P, backward 4 head tiles + P
+template <int LT> constexpr size_t fwd_lds() { return sizeof(float) * (3 * LT * LD32 + LT * (LT + 4)); }
+template <int LT> constexpr size_t bwd_lds() { return sizeof(float) * (4 * LT * LD32 + LT * (LT + 4)); }
+
+template <int LT, typename... Args>
+hipError_t launch_fwd(int B, int H, hipStream_t stream, Args... args) {
+  static const hipError_t attr = hipFuncSetAttribute(
+      reinterpret_cast<const void *>(&attn_fwd_kernel<LT>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds<LT>());
+  if (attr != hipSuccess) return attr;
+  attn_fwd_kernel<LT><<<dim3(H, B), LT * 4, fwd_lds<LT>(), stream>>>(B, args...);
+  return hipGetLastError();
+}
+
+template <int LT, typename... Args>
+hipError_t launch_bwd(int B, int H, hipStream_t stream, Args... args) {
+  static const hipError_t attr = hipFuncSetAttribute(
+      reinterpret_cast<const void *>(&attn_bwd_kernel<LT>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<LT>());
+  if (attr != hipSuccess) return attr;
+  attn_bwd_kernel<LT><<<dim3(H, B), LT * 4, bwd_lds<LT>(), stream>>>(B, args...);
+  return hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
@@ -315,13 +345,16 @@ int msr3d_spatial_attn_fwd(int B, int L, int H, int dh, int spatial_dim, const f
                            int ld_cond, const float *pairwise_locs,
                            const unsigned char *key_padding_mask, float *ctx, float *probs,
                            msr3d_stream_t stream) {
-  if (B < 0 || L <= 0 || L > LT || H <= 0 || dh != DH || spatial_dim != SD) return MSR3D_EINVAL;
+  if (B < 0 || L <= 0 || L > kMaxL || H <= 0 || dh != DH || spatial_dim != SD) return MSR3D_EINVAL;
   if (B == 0) return 0;
   if (!q || !k || !v || !cond || !pairwise_locs || !key_padding_mask || !ctx) return MSR3D_EINVAL;
   if (ld_qkv % 4 != 0) return MSR3D_EINVAL;
-  attn_fwd_kernel<<<dim3(H, B), 256, 0, (hipStream_t)stream>>>(
-      B, L, H, q, k, v, ld_qkv, cond, ld_cond, pairwise_locs, key_padding_mask, ctx, probs);
-  return (int)hipGetLastError();
+  hipStream_t s = (hipStream_t)stream;
+  if (L <= 64)
+    return (int)launch_fwd<64>(B, H, s, L, H, q, k, v, ld_qkv, cond, ld_cond, pairwise_locs,
+                               key_padding_mask, ctx, probs);
+  return (int)launch_fwd<128>(B, H, s, L, H, q, k, v, ld_qkv, cond, ld_cond, pairwise_locs,
+                              key_padding_mask, ctx, probs);
 }
 
 int msr3d_spatial_attn_bwd(int B, int L, int H, int dh, int spatial_dim, const float *q,
@@ -330,16 +363,18 @@ int msr3d_spatial_attn_bwd(int B, int L, int H, int dh, int spatial_dim, const f
                            const unsigned char *key_padding_mask, const float *probs,
                            const float *dctx, float *dq, float *dk, float *dv, int ld_grad,
                            float *dcond, int ld_dcond, msr3d_stream_t stream) {
-  if (B < 0 || L <= 0 || L > LT || H <= 0 || dh != DH || spatial_dim != SD) return MSR3D_EINVAL;
+  if (B < 0 || L <= 0 || L > kMaxL || H <= 0 || dh != DH || spatial_dim != SD) return MSR3D_EINVAL;
   if (B == 0) return 0;
   if (!q || !k || !v || !cond || !pairwise_locs || !key_padding_mask || !probs || !dctx || !dq ||
       !dk || !dv || !dcond)
     return MSR3D_EINVAL;
   if (ld_qkv % 4 != 0) return MSR3D_EINVAL;
-  attn_bwd_kernel<<<dim3(H, B), 256, 0, (hipStream_t)stream>>>(
-      B, L, H, q, k, v, ld_qkv, cond, ld_cond, pairwise_locs, key_padding_mask, probs, dctx, dq, dk,
-      dv, ld_grad, dcond, ld_dcond);
-  return (int)hipGetLastError();
+  hipStream_t s = (hipStream_t)stream;
+  if (L <= 64)
+    return (int)launch_bwd<64>(B, H, s, L, H, q, k, v, ld_qkv, cond, ld_cond, pairwise_locs,
+                               key_padding_mask, probs, dctx, dq, dk, dv, ld_grad, dcond, ld_dcond);
+  return (int)launch_bwd<128>(B, H, s, L, H, q, k, v, ld_qkv, cond, ld_cond, pairwise_locs,
+                              key_padding_mask, probs, dctx, dq, dk, dv, ld_grad, dcond, ld_dcond);
 }
 
 }  // extern "C"

@@ -264,7 +264,7 @@ class _SpatialAttnCond(torch.autograd.Function):
 
 def spatial_attn_cond_supported(q, n_head, spatial_dim, spatial_n_head):
     B, L, D = q.shape
-    return (q.is_cuda and q.dtype == torch.float32 and L <= 64 and D // n_head == 32
+    return (q.is_cuda and q.dtype == torch.float32 and L <= 128 and D // n_head == 32
             and spatial_dim == 5 and spatial_n_head == n_head)
 
 

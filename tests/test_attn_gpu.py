@@ -12,7 +12,8 @@ def rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("B,L,pad_frac", [(4, 60, 0.3), (3, 61, 0.0), (2, 64, 0.5), (5, 17, 0.2), (1, 1, 0.0)])
+@pytest.mark.parametrize("B,L,pad_frac", [(4, 60, 0.3), (3, 61, 0.0), (2, 64, 0.5), (5, 17, 0.2), (1, 1, 0.0),
+                                          (2, 121, 0.3), (2, 128, 0.0), (3, 65, 0.5), (1, 120, 0.1)])
 def test_fused_attention_matches_composite_fp64(B, L, pad_frac):
     from msr3d_amd.modules.layers.transformers import MultiHeadAttentionSpatial
     torch.manual_seed(B * 100 + L)
@@ -54,14 +55,15 @@ def test_fused_core_is_used_and_composite_still_available():
     m = MultiHeadAttentionSpatial(256, 8, dropout=0.0, spatial_dim=5, spatial_attn_fusion="cond").cuda()
     x = torch.randn(2, 60, 256, device="cuda")
     assert hipops.spatial_attn_cond_supported(x, 8, 5, 8)
-    assert not hipops.spatial_attn_cond_supported(torch.randn(2, 121, 256, device="cuda"), 8, 5, 8)
+    assert hipops.spatial_attn_cond_supported(torch.randn(2, 121, 256, device="cuda"), 8, 5, 8)
+    assert not hipops.spatial_attn_cond_supported(torch.randn(2, 129, 256, device="cuda"), 8, 5, 8)
     pl = torch.randn(2, 60, 60, 5, device="cuda")
     y1, _ = m(x, x, x, pl)
     m.use_fused_core = False
     y2, _ = m(x, x, x, pl)
     assert rel(y1, y2) < 2e-5
-    # L = 121 (stress config with the agent token) takes the composite path
-    x3 = torch.randn(1, 121, 256, device="cuda")
+    # L > 128 (beyond the stress config) takes the composite path
+    x3 = torch.randn(1, 130, 256, device="cuda")
     m.use_fused_core = True
-    y3, p3 = m(x3, x3, x3, torch.randn(1, 121, 121, 5, device="cuda"))
-    assert y3.shape == (1, 121, 256) and p3.shape == (8, 1, 121, 121)
+    y3, p3 = m(x3, x3, x3, torch.randn(1, 130, 130, 5, device="cuda"))
+    assert y3.shape == (1, 130, 256) and p3.shape == (8, 1, 130, 130)
