@@ -264,6 +264,43 @@ int msr3d_adamw_flat(long long n, float *params, float *grads, float *exp_avg, f
                      float beta2, float eps, float weight_decay, float max_grad_norm, int schedule,
                      int warmup_steps, int total_steps, int zero_grad, msr3d_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * Scene-sample construction on the device: replaces the host-side
+ * per-instance masks of /root/reference/data/datasets/scannet_base.py:57-67 (and
+ * scan_data_loader.py:83-94), `MSR3DBase.preprocess_pcd` (data/datasets/msr3d.py:181-216) and the
+ * wrapper's padding (data/datasets/dataset_wrapper.py:141-158).
+ *
+ * msr3d_segment_scan -- once per scan.  instance_labels (n_points) int64 as stored in
+ * <scan>.pth; slot_of_label (n_labels) int32 maps a label to its object slot (-1 / out of range:
+ * point dropped), n_slots <= MSR3D_SEG_MAX_SLOTS.  Writes points_sorted (.,3) f32 and
+ * colors_sorted (.,3) u8 so that slot s owns the contiguous rows
+ * [inst_offsets[s], inst_offsets[s+1]) in ascending original order (== pcds[labels == id]);
+ * order (optional) receives the original row of every sorted row; inst_offsets has n_slots+1
+ * ints.  workspace: ceil(n_points / MSR3D_SEG_CHUNK) * n_slots ints.
+ *
+ * msr3d_preprocess_pcd -- once per batch, grid (O, B).  Object slot (b,o) is the rows
+ * [obj_begin, obj_begin + obj_count) of points/colors (any arena of sorted scans); obj_count <= 0
+ * marks a padding slot (obj_fts = 1.0, obj_locs = 0, obj_masks = 0).  rot (B,9) row-major f32
+ * scene rotation or NULL; pcd_idxs (B,O,P) int32 = the subsample drawn by the caller, or NULL
+ * to draw on the device from `seed` (without replacement when obj_count >= P, with replacement
+ * otherwise, like np.random.choice at msr3d.py:200-201); idx_out (B,O,P) optional, receives the
+ * indices used.  Outputs: obj_fts (B,O,P,6) f32 [xyz centred on the subsample mean and scaled
+ * by its largest norm (1 if < 1e-6); rgb = c/127.5-1], obj_locs (B,O,6) f32 [centre, box size
+ * of the whole rotated object], obj_masks (B,O) bytes.  float64 arithmetic like the reference;
+ * P even, <= 4096.
+ * ------------------------------------------------------------------------- */
+#define MSR3D_SEG_CHUNK 256
+#define MSR3D_SEG_MAX_SLOTS 8192
+int msr3d_segment_scan(int n_points, const long long *instance_labels, const int *slot_of_label,
+                       int n_labels, int n_slots, const float *points, const unsigned char *colors,
+                       float *points_sorted, unsigned char *colors_sorted, int *order,
+                       int *inst_offsets, int *workspace, msr3d_stream_t stream);
+int msr3d_preprocess_pcd(int B, int O, int P, const float *points, const unsigned char *colors,
+                         const long long *obj_begin, const int *obj_count, const float *rot,
+                         const int *pcd_idxs, unsigned long long seed, float *obj_fts,
+                         float *obj_locs, unsigned char *obj_masks, int *idx_out,
+                         msr3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,7 @@ SOURCES = [
     ("rowops.hip", []),
     ("prologue.hip", ["-ffp-contract=off"]),
     ("scene_scatter.hip", []),
+    ("preprocess.hip", ["-ffp-contract=off"]),
 ]
 
 
