@@ -28,6 +28,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
 #include "../../include/msr3d_hip.h"
 
@@ -35,7 +36,6 @@ namespace {
 
 constexpr int kSegChunk = MSR3D_SEG_CHUNK;   // points per segmentation block (= block size)
 constexpr int kMaxSlots = MSR3D_SEG_MAX_SLOTS;   // LDS histogram bins
-constexpr int kNT = 256;
 
 // ------------------------------------------------------------------ segmentation
 __device__ __forceinline__ int slot_of(const long long *labels, const int *slot_of_label,
@@ -132,28 +132,32 @@ __device__ __forceinline__ uint32_t object_key(unsigned long long seed, int b, i
   return k;
 }
 
-__device__ __forceinline__ uint32_t feistel(uint32_t x, uint32_t key, int half_bits) {
-  const uint32_t mask = (1u << half_bits) - 1u;
-  uint32_t left = (x >> half_bits) & mask, right = x & mask;
+// 6-round alternating Feistel permutation of [0, 2^bits): high bits/2 and low bits - bits/2 bits
+// take turns being whitened by a hash of the other half (every round is a bijection, so the
+// composition is a permutation for any split).
+__device__ __forceinline__ uint32_t feistel(uint32_t x, uint32_t key, int bits) {
+  const int lb = bits >> 1, rb = bits - lb;
+  const uint32_t lmask = (1u << lb) - 1u, rmask = (1u << rb) - 1u;
+  uint32_t left = (x >> rb) & lmask, right = x & rmask;
 #pragma unroll
   for (uint32_t r = 0; r < 6; ++r) {
-    const uint32_t f = mix32(right ^ key ^ (r * 0x9E3779B1u)) & mask;
-    const uint32_t t = right;
-    right = left ^ f;
-    left = t;
+    if ((r & 1u) == 0)
+      left ^= mix32(right ^ key ^ (r * 0x9E3779B1u)) & lmask;
+    else
+      right ^= mix32(left ^ key ^ (r * 0x9E3779B1u)) & rmask;
   }
-  return (left << half_bits) | right;
+  return (left << rb) | right;
 }
 
 // n >= P: image of j under a keyed permutation of [0, n) (distinct for distinct j);
 // n <  P: an independent uniform draw.
-__device__ __forceinline__ int draw_index(uint32_t key, uint32_t j, int n, int P, int half_bits) {
+__device__ __forceinline__ int draw_index(uint32_t key, uint32_t j, int n, int P, int bits) {
   if (n < P) {
     const uint32_t u = mix32(mix32(j ^ key) + 0x68E31DA4u);
     return (int)(((unsigned long long)u * (unsigned long long)n) >> 32);
   }
-  uint32_t y = feistel(j, key, half_bits);
-  while (y >= (uint32_t)n) y = feistel(y, key, half_bits);      // cycle walk back into range
+  uint32_t y = feistel(j, key, bits);
+  while (y >= (uint32_t)n) y = feistel(y, key, bits);      // cycle walk back into range
   return (int)y;
 }
 
@@ -175,7 +179,7 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 
 // reduces K values per thread over the block; op: 0 sum, 1 min, 2 max.  Result in every thread.
-template <int K>
+template <int K, int kNT>
 __device__ __forceinline__ void block_reduce(double (&v)[K], const int (&op)[K], double *scratch) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -198,7 +202,9 @@ __device__ __forceinline__ void block_reduce(double (&v)[K], const int (&op)[K],
 }
 
 // ------------------------------------------------------------------ preprocess_pcd
-// grid (O, B), 256 threads; dynamic LDS = P * (3 doubles + 3 floats) + 64 doubles.
+// grid (O, B), kNT threads; dynamic LDS = P * (3 doubles + 3 floats) + 160 doubles + 256 floats.  Loads are
+// issued four deep (independent points per thread) to keep enough HBM requests in flight.
+template <int kNT>
 __global__ __launch_bounds__(kNT) void preprocess_pcd_kernel(
     int O, int P, const float *__restrict__ points, const unsigned char *__restrict__ colors,
     const long long *__restrict__ obj_begin, const int *__restrict__ obj_count,
@@ -206,9 +212,10 @@ __global__ __launch_bounds__(kNT) void preprocess_pcd_kernel(
     float *__restrict__ obj_fts, float *__restrict__ obj_locs, unsigned char *__restrict__ obj_masks,
     int *__restrict__ idx_out) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double *scratch = lds;                       // 64
-  double *sub = lds + 64;                      // P x 3, the rotated subsample
+  double *scratch = lds;                       // 160 >= 16 waves x 9
+  double *sub = lds + 160;                     // P x 3, the rotated subsample
   float *rgb = reinterpret_cast<float *>(sub + (size_t)P * 3);   // P x 3
+  float *lut = rgb + (size_t)P * 3;            // 256: (float)(c / 127.5 - 1) for every byte value
   const int o = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const size_t slot = (size_t)b * O + o;
   const int n = obj_count[slot];
@@ -223,6 +230,7 @@ __global__ __launch_bounds__(kNT) void preprocess_pcd_kernel(
       for (int j = tid; j < P; j += kNT) idx_out[slot * P + j] = -1;
     return;
   }
+  for (int c = tid; c < 256; c += kNT) lut[c] = (float)((double)c / 127.5 - 1.0);   // scannet_base.py:60
   const float *pts = points + (size_t)obj_begin[slot] * 3;
   const unsigned char *col = colors + (size_t)obj_begin[slot] * 3;
   double r[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -247,15 +255,23 @@ __global__ __launch_bounds__(kNT) void preprocess_pcd_kernel(
   // pass 1: centre and box of the whole object (msr3d.py:192-194)
   {
     double v[9] = {0, 0, 0, INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    for (int i = tid; i < n; i += kNT) {
-      double x, y, z;
-      load_point(i, x, y, z);
-      v[0] += x; v[1] += y; v[2] += z;
-      v[3] = fmin(v[3], x); v[4] = fmin(v[4], y); v[5] = fmin(v[5], z);
-      v[6] = fmax(v[6], x); v[7] = fmax(v[7], y); v[8] = fmax(v[8], z);
+    for (int i0 = tid; i0 < n; i0 += 4 * kNT) {
+      double x[4], y[4], z[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * kNT;
+        load_point(i < n ? i : i0, x[u], y[u], z[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + u * kNT < n) {
+          v[0] += x[u]; v[1] += y[u]; v[2] += z[u];
+          v[3] = fmin(v[3], x[u]); v[4] = fmin(v[4], y[u]); v[5] = fmin(v[5], z[u]);
+          v[6] = fmax(v[6], x[u]); v[7] = fmax(v[7], y[u]); v[8] = fmax(v[8], z[u]);
+        }
     }
     const int op[9] = {0, 0, 0, 1, 1, 1, 2, 2, 2};
-    block_reduce<9>(v, op, scratch);
+    block_reduce<9, kNT>(v, op, scratch);
     if (tid < 3) {
       loc[tid] = (float)(v[tid] / (double)n);
       loc[3 + tid] = (float)(v[6 + tid] - v[3 + tid]);
@@ -264,29 +280,47 @@ __global__ __launch_bounds__(kNT) void preprocess_pcd_kernel(
   }
 
   // pass 2: gather the subsample (msr3d.py:200-202), its mean (:205)
-  int half_bits = 1;
-  while ((1ll << (2 * half_bits)) < (long long)n) ++half_bits;
+  int bits = 1;
+  while ((1ll << bits) < (long long)n) ++bits;
   const uint32_t key = object_key(seed, b, o);
   double m[3] = {0, 0, 0};
-  for (int j = tid; j < P; j += kNT) {
-    int idx;
-    if (pcd_idxs) {
-      idx = pcd_idxs[slot * P + j];
-      idx = idx < 0 ? 0 : (idx >= n ? n - 1 : idx);        // memory safety only
-    } else {
-      idx = draw_index(key, (uint32_t)j, n, P, half_bits);
-    }
-    if (idx_out) idx_out[slot * P + j] = idx;
-    double x, y, z;
-    load_point(idx, x, y, z);
-    sub[j * 3] = x; sub[j * 3 + 1] = y; sub[j * 3 + 2] = z;
-    m[0] += x; m[1] += y; m[2] += z;
+  for (int j0 = tid; j0 < P; j0 += 4 * kNT) {
+    int idx[4];
 #pragma unroll
-    for (int d = 0; d < 3; ++d)                               // scannet_base.py:60
-      rgb[j * 3 + d] = (float)((double)col[(size_t)idx * 3 + d] / 127.5 - 1.0);
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * kNT;
+      idx[u] = 0;
+      if (j < P) {
+        if (pcd_idxs) {
+          const int t = pcd_idxs[slot * P + j];
+          idx[u] = t < 0 ? 0 : (t >= n ? n - 1 : t);        // memory safety only
+        } else {
+          idx[u] = draw_index(key, (uint32_t)j, n, P, bits);
+        }
+        if (idx_out) idx_out[slot * P + j] = idx[u];
+      }
+    }
+    double x[4], y[4], z[4];
+    unsigned char c[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      load_point(idx[u], x[u], y[u], z[u]);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) c[u][d] = col[(size_t)idx[u] * 3 + d];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * kNT;
+      if (j < P) {
+        sub[j * 3] = x[u]; sub[j * 3 + 1] = y[u]; sub[j * 3 + 2] = z[u];
+        m[0] += x[u]; m[1] += y[u]; m[2] += z[u];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) rgb[j * 3 + d] = lut[c[u][d]];
+      }
+    }
   }
   const int op3[3] = {0, 0, 0};
-  block_reduce<3>(m, op3, scratch);
+  block_reduce<3, kNT>(m, op3, scratch);
 #pragma unroll
   for (int d = 0; d < 3; ++d) m[d] = m[d] / (double)P;
 
@@ -298,7 +332,7 @@ __global__ __launch_bounds__(kNT) void preprocess_pcd_kernel(
     d2[0] = fmax(d2[0], (x * x + y * y) + z * z);
   }
   const int op1[1] = {2};
-  block_reduce<1>(d2, op1, scratch);
+  block_reduce<1, kNT>(d2, op1, scratch);
   double max_dist = sqrt(d2[0]);           // sqrt is monotone: max of sqrt == sqrt of max
   if (max_dist < 1e-6) max_dist = 1.0;
 
@@ -345,14 +379,19 @@ int msr3d_preprocess_pcd(int B, int O, int P, const float *points, const unsigne
   if (B == 0 || O == 0) return 0;
   if (!points || !colors || !obj_begin || !obj_count || !obj_fts || !obj_locs || !obj_masks)
     return MSR3D_EINVAL;
-  const size_t lds = sizeof(double) * (64 + (size_t)P * 3) + sizeof(float) * (size_t)P * 3;
-  static const hipError_t attr = hipFuncSetAttribute(
-      reinterpret_cast<const void *>(&preprocess_pcd_kernel),
-      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (attr != hipSuccess) return (int)attr;
-  preprocess_pcd_kernel<<<dim3(O, B), kNT, lds, (hipStream_t)stream>>>(
-      O, P, points, colors, obj_begin, obj_count, rot, pcd_idxs, seed, obj_fts, obj_locs, obj_masks,
-      idx_out);
+  const size_t lds = sizeof(double) * (160 + (size_t)P * 3) + sizeof(float) * ((size_t)P * 3 + 256);
+  static const int nt = getenv("MSR3D_PRE_NT") ? atoi(getenv("MSR3D_PRE_NT")) : 256;
+#define LAUNCH_PRE(NT)                                                                              \
+  {                                                                                                 \
+    static const hipError_t attr = hipFuncSetAttribute(                                             \
+        reinterpret_cast<const void *>(&preprocess_pcd_kernel<NT>),                                 \
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                    \
+    if (attr != hipSuccess) return (int)attr;                                                       \
+    preprocess_pcd_kernel<NT><<<dim3(O, B), NT, lds, (hipStream_t)stream>>>(                        \
+        O, P, points, colors, obj_begin, obj_count, rot, pcd_idxs, seed, obj_fts, obj_locs,         \
+        obj_masks, idx_out);                                                                        \
+  }
+  if (nt == 1024) LAUNCH_PRE(1024) else if (nt == 512) LAUNCH_PRE(512) else LAUNCH_PRE(256)
   return (int)hipGetLastError();
 }
 

@@ -33,15 +33,51 @@ def build_rotate_mat(split, rot_aug=True, rand_angle="axis"):
     return None
 
 
+def _quat_to_matrix(q):
+    """Rotation matrix of a quaternion (x, y, z, w), normalised first (what
+    scipy.spatial.transform.Rotation.from_quat(q).as_matrix() returns)."""
+    x, y, z, w = np.asarray(q, np.float64) / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _matrix_to_quat(m):
+    """Quaternion (x, y, z, w) of a rotation matrix with the branch / sign convention of
+    scipy's Rotation.from_matrix(m).as_quat() (Markley's method: the largest of the diagonal
+    entries and the trace picks the component that is computed directly and comes out positive),
+    which the reference uses at msr3d.py:235-238 -- the sign matters downstream, the quaternion's
+    Fourier features feed `orientation_encoder`.  tests/test_sample_input_cpu.py checks it
+    against scipy."""
+    m = np.asarray(m, np.float64)
+    trace = m[0, 0] + m[1, 1] + m[2, 2]
+    decision = [m[0, 0], m[1, 1], m[2, 2], trace]
+    choice = int(np.argmax(decision))
+    q = np.empty(4)
+    if choice != 3:
+        i = choice
+        j = (i + 1) % 3
+        k = (j + 1) % 3
+        q[i] = 1 - trace + 2 * m[i, i]
+        q[j] = m[j, i] + m[i, j]
+        q[k] = m[k, i] + m[i, k]
+        q[3] = m[k, j] - m[j, k]
+    else:
+        q[0] = m[2, 1] - m[1, 2]
+        q[1] = m[0, 2] - m[2, 0]
+        q[2] = m[1, 0] - m[0, 1]
+        q[3] = 1 + trace
+    return q / np.linalg.norm(q)
+
+
 def rotate_situation(situation, rot_matrix):
     """msr3d.py:224-240: agent position and orientation quaternion (x, y, z, w) follow the scene
     rotation."""
-    from scipy.spatial.transform import Rotation as R      # as the reference (msr3d.py:18)
     if rot_matrix is None:
         return situation
     pos, ori = situation
     pos_new = (np.array(pos).reshape(1, 3) @ rot_matrix.transpose()).reshape(-1)
-    ori_new = R.from_matrix(rot_matrix @ R.from_quat(np.array(ori)).as_matrix()).as_quat().reshape(-1)
+    ori_new = _matrix_to_quat(rot_matrix @ _quat_to_matrix(np.array(ori)))
     return pos_new, ori_new
 
 
@@ -96,9 +132,9 @@ class SceneInputBuilder:
                                                                                    smp.get("insts", []))
             if len(sel) > O:
                 raise ValueError("more objects selected than max_obj_len")
-            for o, i in enumerate(sel):
-                begin[b, o] = scan["begin"][i]
-                count[b, o] = scan["count"][i]
+            k = len(sel)
+            begin[b, :k] = [scan["begin"][i] for i in sel]
+            count[b, :k] = [scan["count"][i] for i in sel]
             m = rot_matrices[b] if rot_matrices is not None else build_rotate_mat(self.split,
                                                                                   rot_aug=self.use_rotate)
             if m is not None:

@@ -57,3 +57,20 @@ def synth_batch(seed, B, O=60, P=1024, n_valid=None, device="cpu"):
             c.append(v)
     names = ["obj_fts", "obj_masks", "obj_locs", "anchor_locs", "anchor_orientation"]
     return {n: torch.from_numpy(np.stack(c)).to(device) for n, c in zip(names, cols)}
+
+
+def synth_scan(rng, n_inst, n_points):
+    """A scan in the on-disk layout of scan_data/pcd_with_global_alignment/<scan>.pth:
+    points f32 (N,3), colors u8 (N,3), instance_labels i64 (N,) with -100 = unlabelled."""
+    centres = rng.uniform([-4, -4, 0], [4, 4, 2.5], (n_inst, 3))
+    sizes = rng.uniform(0.1, 2.0, (n_inst, 3))
+    weights = rng.uniform(0.2, 5.0, n_inst)
+    weights[rng.integers(0, n_inst)] = 0.02          # one tiny object (fewer points than P)
+    labels = rng.choice(n_inst, size=n_points, p=weights / weights.sum()).astype(np.int64)
+    pts = centres[labels] + (rng.random((n_points, 3)) - 0.5) * sizes[labels]
+    unl = rng.random(n_points) < 0.1
+    labels[unl] = -100
+    # one degenerate object: all its points coincide (max_dist < 1e-6 branch)
+    deg = labels == 3
+    pts[deg] = centres[3]
+    return pts.astype(np.float32), rng.integers(0, 256, (n_points, 3)).astype(np.uint8), labels

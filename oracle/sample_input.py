@@ -153,33 +153,39 @@ def object_key(seed, b, o):
     return k
 
 
-def _feistel(x, key, half_bits):
-    """6-round balanced Feistel permutation of [0, 4^half_bits)."""
-    mask = np.uint64((1 << half_bits) - 1)
-    left, right = (x >> np.uint64(half_bits)) & mask, x & mask
+def _feistel(x, key, bits):
+    """6-round alternating (unbalanced) Feistel permutation of [0, 2^bits): the low `bits - bits//2`
+    bits and the high `bits//2` bits take turns being whitened by a hash of the other half."""
+    lb = bits // 2
+    rb = bits - lb
+    lmask, rmask = np.uint64((1 << lb) - 1), np.uint64((1 << rb) - 1)
+    left, right = (x >> np.uint64(rb)) & lmask, x & rmask
     for r in range(6):
-        f = _mix32(right ^ key ^ np.uint64((r * 0x9E3779B1) & 0xFFFFFFFF)) & mask
-        left, right = right, left ^ f
-    return (left << np.uint64(half_bits)) | right
+        c = np.uint64((r * 0x9E3779B1) & 0xFFFFFFFF)
+        if r % 2 == 0:
+            left = left ^ (_mix32(right ^ key ^ c) & lmask)
+        else:
+            right = right ^ (_mix32(left ^ key ^ c) & rmask)
+    return (left << np.uint64(rb)) | right
 
 
 def draw_indices(seed, b, o, n, P):
     """The subsample of np.random.choice(n, P, replace=n < P) (msr3d.py:200-201), as the device
     draws it: n >= P -> the first P images of a keyed permutation of [0, n) (Feistel network on
-    the enclosing power of four, cycle-walked back into range: distinct by construction);
+    the enclosing power of two, cycle-walked back into range: distinct by construction);
     n < P -> P independent uniform draws (32-bit multiply-high)."""
     key = object_key(seed, b, o)
     j = np.arange(P, dtype=np.uint64)
     if n < P:
         u = _mix32(_mix32(j ^ key) + np.uint64(0x68E31DA4))
         return ((u * np.uint64(n)) >> np.uint64(32)).astype(np.int32)
-    half_bits = 1
-    while (1 << (2 * half_bits)) < n:
-        half_bits += 1
-    y = _feistel(j, key, half_bits)
+    bits = 1
+    while (1 << bits) < n:
+        bits += 1
+    y = _feistel(j, key, bits)
     while True:
         out = y >= np.uint64(n)
         if not out.any():
             break
-        y = np.where(out, _feistel(y, key, half_bits), y)
+        y = np.where(out, _feistel(y, key, bits), y)
     return y.astype(np.int32)

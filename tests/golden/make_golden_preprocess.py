@@ -27,6 +27,7 @@ from scipy.spatial.transform import Rotation as R
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from msr3d_amd.synth import synth_scan  # noqa: E402  (seeded synthetic scan in the on-disk layout)
 
 
 def _extract(path, cls, names):
@@ -48,23 +49,6 @@ def reference_functions():
     exec(_extract(os.path.join(REF, "data/datasets/msr3d.py"), "MSR3DBase",
                   ["preprocess_pcd", "_get_scene_encoder_input"]), ns)
     return ns
-
-
-def synth_scan(rng, n_inst, n_points):
-    """A scan in the on-disk layout of scan_data/pcd_with_global_alignment/<scan>.pth:
-    points f32 (N,3), colors u8 (N,3), instance_labels i64 (N,) with -100 = unlabelled."""
-    centres = rng.uniform([-4, -4, 0], [4, 4, 2.5], (n_inst, 3))
-    sizes = rng.uniform(0.1, 2.0, (n_inst, 3))
-    weights = rng.uniform(0.2, 5.0, n_inst)
-    weights[rng.integers(0, n_inst)] = 0.02          # one tiny object (fewer points than P)
-    labels = rng.choice(n_inst, size=n_points, p=weights / weights.sum()).astype(np.int64)
-    pts = centres[labels] + (rng.random((n_points, 3)) - 0.5) * sizes[labels]
-    unl = rng.random(n_points) < 0.1
-    labels[unl] = -100
-    # one degenerate object: all its points coincide (max_dist < 1e-6 branch)
-    deg = labels == 3
-    pts[deg] = centres[3]
-    return pts.astype(np.float32), rng.integers(0, 256, (n_points, 3)).astype(np.uint8), labels
 
 
 def scan_obj_pcds(points, colors, labels):

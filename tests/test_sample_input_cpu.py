@@ -105,3 +105,40 @@ def test_device_draw_full_permutation_and_uniformity():
     for o in range(400):
         hits[si.draw_indices(7, 0, o, 64, 16)] += 1
     assert abs(hits - 100).max() < 45
+
+
+def test_host_mirror_situation_rotation_matches_scipy_and_the_reference_run():
+    """msr3d_amd.data.rotate_situation restates scipy's from_quat/as_matrix/from_matrix/as_quat chain
+    (msr3d.py:228-240) in numpy, signs included."""
+    from scipy.spatial.transform import Rotation as R
+    from msr3d_amd.data.scene_input import ROTATE_ANGLES, _matrix_to_quat, _quat_to_matrix, rotate_situation
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        q = rng.standard_normal(4)
+        if rng.random() < 0.3:                      # the dataset's orientations are yaw-only
+            q[:2] = 0
+        for th in ROTATE_ANGLES[1:]:
+            m = si.rotate_mat(th)
+            assert np.allclose(_quat_to_matrix(q), R.from_quat(q).as_matrix(), atol=1e-14)
+            want = R.from_matrix(m @ R.from_quat(q).as_matrix()).as_quat()
+            got = _matrix_to_quat(m @ _quat_to_matrix(q))
+            assert np.allclose(got, want, atol=1e-12), (q, th)
+    for seed in SEEDS:
+        g = load(seed)
+        rot = None if g["rot_is_none"] else g["rot_matrix"]
+        pos, ori = rotate_situation((g["situation_pos"], g["situation_ori"]), rot)
+        assert np.allclose(pos, g["situation_pos_out"], atol=1e-12)
+        assert np.allclose(ori, g["situation_ori_out"], atol=1e-12)
+
+
+def test_host_mirror_build_rotate_mat_draws_like_the_reference():
+    import random
+    from msr3d_amd.data import build_rotate_mat
+    random.seed(5)
+    thetas = [random.choice(si.ROTATE_ANGLES) for _ in range(20)]
+    random.seed(5)
+    for th in thetas:
+        m = build_rotate_mat("train")
+        want = si.rotate_mat(th)
+        assert (m is None and want is None) or np.array_equal(m, want)
+    assert build_rotate_mat("val") is None and build_rotate_mat("train", rot_aug=False) is None

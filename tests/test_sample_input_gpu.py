@@ -183,7 +183,7 @@ def test_full_batch_properties_and_encoder_consumes_it():
     """BASELINE sizes (16 scenes x 60 objects x 1024 points) from large synthetic scans:
     size-independent properties of the normalisation, determinism, and the encoder runs on it."""
     from msr3d_amd.data import SceneInputBuilder, SceneStore
-    from tests.golden.make_golden_preprocess import synth_scan
+    from msr3d_amd.synth import synth_scan
     rng = np.random.default_rng(11)
     st = SceneStore("cuda")
     for s in range(4):
