@@ -73,7 +73,9 @@ int msr3d_group_points(int b, int c, int n, int npoints, int nsample, const floa
                        const int *idx, float *out, msr3d_stream_t stream);
 
 /* group_points_grad_kernel_wrapper (src/group_points_gpu.cu:66-75).
- * grad_out (b,c,npoints,nsample) -> grad_points (b,c,n), zeroed then accumulated. */
+ * grad_out (b,c,npoints,nsample) -> grad_points (b,c,n); every element is written.  Unlike the
+ * reference's atomicAdd scatter the three *_grad entries sum each destination's sources in
+ * ascending source order (bit-reproducible) whenever 2*n_dst + n_src + 1 <= 36864. */
 int msr3d_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
                             const int *idx, float *grad_points, msr3d_stream_t stream);
 

@@ -180,6 +180,114 @@ inline int grid_for(long long total, int block) {
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+
+// ---- deterministic backward of gather / group / interpolate ---------------------------
+// The reference scatters with atomicAdd (sampling_gpu.cu:36-57, group_points_gpu.cu:42-75,
+// interpolate_gpu.cu:117-154): the sum order, hence the low bits of the gradient, changes from
+// run to run.  Here every (batch, row tile) workgroup first inverts the index in LDS -- a STABLE
+// counting sort of the E source entries by destination -- and then each destination sums its
+// entries in ascending entry order, the order of the sequential oracle: bit-reproducible, equal
+// to oracle/pn2_oracle.c bit for bit, no atomics on floats and no memset (every output is
+// written).  out[b][r][d] = sum_{e: idx[b][e] == d} src[b][r][e / DIV] * (w ? w[b][e] : 1).
+constexpr int kDetRows = 32;             // rows (channels) per workgroup
+constexpr int kDetMaxInts = 36 * 1024;   // LDS ints available to the inverted index
+
+template <int DIV>
+__global__ __launch_bounds__(256) void scatter_rows_det_kernel(
+    int c, int n_dst, int E, const float *__restrict__ src, const int *__restrict__ idx,
+    const float *__restrict__ w, float *__restrict__ out) {
+  extern __shared__ int det_lds[];
+  int *start = det_lds;                  // n_dst + 1
+  int *cursor = start + n_dst + 1;       // n_dst
+  int *list = cursor + n_dst;            // E
+  __shared__ int chunk_dst[256];
+  __shared__ int partial[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int *I = idx + (size_t)b * E;
+
+  for (int d = tid; d < n_dst; d += 256) cursor[d] = 0;
+  __syncthreads();
+  for (int e = tid; e < E; e += 256) {
+    const int d = I[e];
+    if (d >= 0 && d < n_dst) atomicAdd(&cursor[d], 1);          // integer counts: order-free
+  }
+  __syncthreads();
+  // exclusive scan of the counts: contiguous strip per thread, then a scan of the 256 strip sums
+  const int per = (n_dst + 255) / 256, d0 = min(n_dst, tid * per), d1 = min(n_dst, d0 + per);
+  int sum = 0;
+  for (int d = d0; d < d1; ++d) sum += cursor[d];
+  partial[tid] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int t = 0; t < 256; ++t) {
+      const int v = partial[t];
+      partial[t] = run;
+      run += v;
+    }
+    start[n_dst] = run;
+  }
+  __syncthreads();
+  int run = partial[tid];
+  for (int d = d0; d < d1; ++d) {
+    const int v = cursor[d];
+    start[d] = run;
+    cursor[d] = run;
+    run += v;
+  }
+  __syncthreads();
+  // stable placement, 256 entries at a time
+  for (int e0 = 0; e0 < E; e0 += 256) {
+    const int e = e0 + tid;
+    int d = -1;
+    if (e < E) {
+      d = I[e];
+      if (d < 0 || d >= n_dst) d = -1;
+    }
+    chunk_dst[tid] = d;
+    __syncthreads();
+    if (d >= 0) {
+      int rank = 0;
+      for (int t = 0; t < tid; ++t) rank += (chunk_dst[t] == d);
+      list[cursor[d] + rank] = e;
+    }
+    __syncthreads();
+    if (d >= 0) atomicAdd(&cursor[d], 1);
+    __syncthreads();
+  }
+  // ordered sums
+  const int S = E / DIV;
+  const int r_end = min(c, ((int)blockIdx.y + 1) * kDetRows);
+  for (int r = blockIdx.y * kDetRows; r < r_end; ++r) {
+    const float *G = src + ((size_t)b * c + r) * S;
+    float *O = out + ((size_t)b * c + r) * n_dst;
+    for (int d = tid; d < n_dst; d += 256) {
+      float acc = 0.f;
+      for (int q = start[d]; q < start[d + 1]; ++q) {
+        const int e = list[q];
+        acc += w ? G[e / DIV] * w[(size_t)b * E + e] : G[e / DIV];
+      }
+      O[d] = acc;
+    }
+  }
+}
+
+// true when the inverted index of one batch item fits in LDS
+inline bool det_fits(long long n_dst, long long E) { return 2 * n_dst + 1 + E <= kDetMaxInts; }
+
+template <int DIV>
+hipError_t launch_scatter_det(int b, int c, int n_dst, int E, const float *src, const int *idx,
+                              const float *w, float *out, hipStream_t stream) {
+  const size_t lds = sizeof(int) * (size_t)(2 * n_dst + 1 + E);
+  static const hipError_t attr = hipFuncSetAttribute(
+      reinterpret_cast<const void *>(&scatter_rows_det_kernel<DIV>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(int) * kDetMaxInts));
+  if (attr != hipSuccess) return attr;
+  scatter_rows_det_kernel<DIV><<<dim3(b, (c + kDetRows - 1) / kDetRows), 256, lds, stream>>>(
+      c, n_dst, E, src, idx, w, out);
+  return hipGetLastError();
+}
+
 }  // namespace
 
 // =================================================================================
@@ -223,6 +331,11 @@ int msr3d_gather_points_grad(int b, int c, int n, int m, const float *grad_out, 
   const size_t obytes = sizeof(float) * (size_t)b * c * n;
   if (obytes == 0) return 0;
   if (!grad_points) return MSR3D_EINVAL;
+  if (total > 0 && det_fits(n, m)) {
+    if (!grad_out || !idx) return MSR3D_EINVAL;
+    return (int)launch_scatter_det<1>(b, c, n, m, grad_out, idx, nullptr, grad_points,
+                                      (hipStream_t)stream);
+  }
   hipError_t e = hipMemsetAsync(grad_points, 0, obytes, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   if (total == 0) return 0;
@@ -264,9 +377,14 @@ int msr3d_group_points_grad(int b, int c, int n, int npoints, int nsample, const
   const size_t obytes = sizeof(float) * (size_t)b * c * n;
   if (obytes == 0) return 0;
   if (!grad_points) return MSR3D_EINVAL;
+  const long long total = (long long)b * c * npoints * nsample;
+  if (total > 0 && det_fits(n, (long long)npoints * nsample)) {
+    if (!grad_out || !idx) return MSR3D_EINVAL;
+    return (int)launch_scatter_det<1>(b, c, n, npoints * nsample, grad_out, idx, nullptr,
+                                      grad_points, (hipStream_t)stream);
+  }
   hipError_t e = hipMemsetAsync(grad_points, 0, obytes, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
-  const long long total = (long long)b * c * npoints * nsample;
   if (total == 0) return 0;
   if (!grad_out || !idx) return MSR3D_EINVAL;
   group_points_grad_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
@@ -302,9 +420,14 @@ int msr3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_o
   const size_t obytes = sizeof(float) * (size_t)b * c * m;
   if (obytes == 0) return 0;
   if (!grad_points) return MSR3D_EINVAL;
+  const long long total = (long long)b * c * n;
+  if (total > 0 && det_fits(m, 3ll * n)) {
+    if (!grad_out || !idx || !weight) return MSR3D_EINVAL;
+    return (int)launch_scatter_det<3>(b, c, m, 3 * n, grad_out, idx, weight, grad_points,
+                                      (hipStream_t)stream);
+  }
   hipError_t e = hipMemsetAsync(grad_points, 0, obytes, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
-  const long long total = (long long)b * c * n;
   if (total == 0) return 0;
   if (!grad_out || !idx || !weight) return MSR3D_EINVAL;
   three_interpolate_grad_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(

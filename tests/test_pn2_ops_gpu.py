@@ -119,13 +119,14 @@ def test_group_gather_exact(ext, b, c, n, npoint, ns):
     gidx = rng.integers(0, n, (b, npoint)).astype(np.int32)
     got = ext.gather_points(dev(pts), dev(gidx)).cpu().numpy()
     assert np.array_equal(got, pn2.gather_points(pts, gidx))
-    # grads (atomic order differs): tolerance
+    # grads: the kernels sum every destination's contributions in ascending source order, the
+    # order of the sequential oracle -> bit-exact (the reference's atomicAdd order is arbitrary)
     go = rng.standard_normal((b, c, npoint, ns)).astype(np.float32)
     got = ext.group_points_grad(dev(go), dev(idx), n).cpu().numpy()
-    assert np.allclose(got, pn2.group_points_grad(go, idx, n), rtol=1e-5, atol=1e-5)
+    assert np.array_equal(got, pn2.group_points_grad(go, idx, n))
     go = rng.standard_normal((b, c, npoint)).astype(np.float32)
     got = ext.gather_points_grad(dev(go), dev(gidx), n).cpu().numpy()
-    assert np.allclose(got, pn2.gather_points_grad(go, gidx, n), rtol=1e-5, atol=1e-5)
+    assert np.array_equal(got, pn2.gather_points_grad(go, gidx, n))
 
 
 @pytest.mark.parametrize("b,n,m,c", [(3, 500, 64, 16), (2, 64, 2, 4), (2, 1300, 1100, 3), (1, 5, 1, 2)])
@@ -145,7 +146,26 @@ def test_three_nn_interpolate(ext, b, n, m, c):
     assert np.array_equal(got, pn2.three_interpolate(feats, iw, w))
     go = rng.standard_normal((b, c, n)).astype(np.float32)
     got = ext.three_interpolate_grad(dev(go), dev(iw), dev(w), m).cpu().numpy()
-    assert np.allclose(got, pn2.three_interpolate_grad(go, iw, w, m), rtol=1e-4, atol=1e-4)
+    assert np.array_equal(got, pn2.three_interpolate_grad(go, iw, w, m))       # ordered sums: bit-exact
+
+
+def test_grads_heavy_collisions_and_oversize_fallback(ext):
+    """All sources hitting a handful of destinations (long ordered sums, bit-exact), repeated runs
+    identical; and a problem whose inverted index does not fit in LDS (atomic path, tolerance)."""
+    rng = np.random.default_rng(21)
+    b, c, n, npoint, ns = 3, 40, 1024, 32, 32
+    idx = rng.integers(0, 4, (b, npoint, ns)).astype(np.int32)        # 1024 entries -> 4 destinations
+    go = rng.standard_normal((b, c, npoint, ns)).astype(np.float32)
+    want = pn2.group_points_grad(go, idx, n)
+    first = ext.group_points_grad(dev(go), dev(idx), n)
+    assert np.array_equal(first.cpu().numpy(), want)
+    for _ in range(3):
+        assert torch.equal(ext.group_points_grad(dev(go), dev(idx), n), first)
+    n_big = 30000                                                      # 2n+1+E > 36 K ints
+    idx = rng.integers(0, n_big, (1, 64, 32)).astype(np.int32)
+    go = rng.standard_normal((1, 5, 64, 32)).astype(np.float32)
+    got = ext.group_points_grad(dev(go), dev(idx), n_big).cpu().numpy()
+    assert np.allclose(got, pn2.group_points_grad(go, idx, n_big), rtol=1e-5, atol=1e-5)
 
 
 def test_reference_interpolate_test_input(ext):
