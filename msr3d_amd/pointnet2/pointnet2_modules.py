@@ -54,8 +54,12 @@ class PointnetSAModuleMSG(_PointnetSAModuleBase):
                     radius, nsample, use_xyz=use_xyz, sample_uniformly=sample_uniformly))
             else:
                 self.groupers.append(pointnet2_utils.GroupAll(use_xyz))
+            spec = list(spec)
             if use_xyz:
-                spec[0] += 3   # in place, like pointnet2_modules.py:120-122 (callers see it)
+                # the reference adds the 3 in place (pointnet2_modules.py:120-122), which corrupts the
+                # caller's list -- PcdObjEncoder's mutable default included, so a second construction
+                # with defaults fails there; a private copy gives the same module without that
+                spec[0] += 3
             self.mlps.append(pt_utils.SharedMLP(spec, bn=bn))
 
 
