@@ -22,11 +22,13 @@
 #ifndef MSR3D_HIP_H
 #define MSR3D_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 1
+#define MSR3D_ABI_VERSION 2
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -139,22 +141,33 @@ int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pt
 
 /* C[m][n] = beta*C[m][n] + bias[n] + sum_k a(m,k)*b(n,k),  a(m,k) = a_kc ? A[m*lda+k] : A[k*lda+m],
  * b(n,k) = b_kc ? B[n*ldb+k] : B[k*ldb+n].  flags bit0: C = gelu(.) (exact erf form) and, if
- * C_pre != NULL, C_pre = the pre-activation (saved for backward).  bias / C_pre may be NULL. */
+ * C_pre != NULL, C_pre = the pre-activation (saved for backward).  bias / C_pre may be NULL.
+ *
+ * workspace (may be NULL): device memory for the split-K meeting point, used by launches that are
+ * ordered on one stream.  Layout: MSR3D_GEMM_WS_COUNTERS ints that must be ZERO before the first
+ * use (every launch leaves them zero), followed by the partial-sum records; 16 MiB covers every
+ * shape of the path.  With a workspace the last workgroup of each tile adds the splits in a fixed
+ * order and applies the epilogue: no zero-fill of C, no float atomics, results bit-reproducible
+ * from run to run.  Without one the splits meet by memset + atomicAdd (order-dependent rounding). */
+#define MSR3D_GEMM_WS_COUNTERS 1024
 int msr3d_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float *A, int lda,
                    const float *B, int ldb, float *C, int ldc, const float *bias, float *C_pre,
-                   int flags, float beta, msr3d_stream_t stream);
+                   int flags, float beta, void *workspace, size_t workspace_bytes,
+                   msr3d_stream_t stream);
 
 /* Weight AND bias gradient of y = x W^T + b in one launch: dw_db is a dense buffer of
  * N_out*K_in + N_out floats; on return dw_db[0 .. N_out*K_in) = dy^T x  (N_out x K_in) and
  * dw_db[N_out*K_in ..) = column sums of dy.  dy (M_tokens x N_out), x (M_tokens x K_in). */
 int msr3d_linear_wgrad_f32(int M_tokens, int N_out, int K_in, const float *dy, const float *x,
-                           float *dw_db, msr3d_stream_t stream);
+                           float *dw_db, void *workspace, size_t workspace_bytes,
+                           msr3d_stream_t stream);
 
 /* Same products ACCUMULATED onto dw (N_out x K_in, dense) and db (N_out; may be NULL): for
  * gradient buffers that were zeroed once for the whole step (the flat buffer of the
  * data-parallel engine), no memset, no temporary. */
 int msr3d_linear_wgrad_acc_f32(int M_tokens, int N_out, int K_in, const float *dy, const float *x,
-                               float *dw, float *db, msr3d_stream_t stream);
+                               float *dw, float *db, void *workspace, size_t workspace_bytes,
+                               msr3d_stream_t stream);
 
 /* out[n] (+)= sum_m X[m*ldx + n]  (bias gradient). */
 int msr3d_colsum_f32(int M, int N, const float *X, int ldx, float *out, int accumulate,

@@ -15,7 +15,12 @@
 // matters is that every launch fills the chip for its few microseconds: 64x64 tiles (4 waves
 // x 32x32) with split-K for the 256-wide outputs, 128-row / 128-column tiles where a side is
 // long; BK = 32, LDS double-buffered, operands staged global -> registers -> LDS with 16-byte
-// accesses.  hipBLASLt's heuristic picks a
+// accesses.  Split-K partial sums meet in C by atomicAdd (default: fastest, rounding depends on
+// arrival order) or, when the caller passes a workspace, in an ORDERED hand-over: every split
+// stores its accumulators, takes a ticket, and the last workgroup to arrive adds the partials in
+// split order and runs the epilogue -- no zero-fill of C, no float atomics, bit-reproducible
+// results, at +5 % step time (the records cross the 8 L2s through device-coherent accesses).
+// hipBLASLt's heuristic picks a
 // 256x256 macro-tile = ONE workgroup for the (960 x 256 x 256) fp32 linears of this path
 // (215 us each, profiles/r01_v2_bench_kernel_stats.csv); this kernel is the replacement.
 #include <hip/hip_runtime.h>
@@ -36,6 +41,26 @@ __host__ __device__ constexpr int tile_floats(int tr) { return tr * LD_KC; }   /
 
 __device__ __forceinline__ float gelu_f(float x) {     // exact erf GELU (F.gelu default)
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// ---- split-K workspace accesses: relaxed, agent scope (coherent across the XCDs' L2s) -----
+__device__ __forceinline__ void ws_store(float *p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ws_load(const float *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ws_store2(float *p, float a, float b) {     // p 8-byte aligned
+  const unsigned long long bits =
+      (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), bits, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ws_load2(const float *p, float &a, float &b) {
+  const unsigned long long bits = __hip_atomic_load(
+      reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  a = __uint_as_float((unsigned)bits);
+  b = __uint_as_float((unsigned)(bits >> 32));
 }
 
 // ---- global -> registers: one TR x 32 operand tile = TR/32 float4 per thread ------------
@@ -103,7 +128,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
                                                        float *__restrict__ Cpre, int flags,
                                                        float beta, int a_vec, int b_vec,
                                                        int slabs_per_split,
-                                                       float *__restrict__ a_colsum) {
+                                                       float *__restrict__ a_colsum,
+                                                       float *__restrict__ ws_part,
+                                                       int *__restrict__ ws_count) {
   constexpr int BM = 32 * RM, BN = 32 * RN;
   constexpr int TA = tile_floats(BM), TB = tile_floats(BN);
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -121,12 +148,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
 #pragma unroll
     for (int b = 0; b < RN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // split-K: blockIdx.z owns slabs [kbeg, kend); partial sums meet in C by atomicAdd
+  // split-K: blockIdx.z owns slabs [kbeg, kend) (never empty: the host sizes gridDim.z so)
   const int nk_all = (K + BK - 1) / BK;
   const int kbeg = blockIdx.z * slabs_per_split;
   const int kend = min(nk_all, kbeg + slabs_per_split);
   const int nk = kend - kbeg;
-  if (nk <= 0) return;
 
   float4 ra[BM / 32], rb[BN / 32];
   load_tile<A_KC, BM>(A, lda, m0, kbeg * BK, M, K, a_vec, ra);
@@ -195,6 +221,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
     __syncthreads();
   }
 
+  const bool ordered = gridDim.z > 1 && ws_part != nullptr;   // workspace meeting point
+  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+  constexpr int REC = BM * BN + BM;                  // one split's record: accumulators + column sums
+  float *const rec0 = ordered ? ws_part + (size_t)tile * gridDim.z * REC : nullptr;
+  float col_tot = 0.f;                               // thread c < BM: sum of column m0 + c
   if (do_colsum) {
     // 256 / (BM/4) threads share each group of 4 columns: reduce their partial sums through LDS
     constexpr int TPR = BM / 4;
@@ -203,11 +234,63 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
     __syncthreads();
     if (threadIdx.x < BM) {
       const int c = threadIdx.x;                     // column of the tile
-      float tot = 0.f;
 #pragma unroll
-      for (int j = 0; j < 256 / TPR; ++j) tot += red[(j * TPR + (c >> 2)) * 4 + (c & 3)];
-      if (m0 + c < M) atomicAdd(a_colsum + m0 + c, tot);
+      for (int j = 0; j < 256 / TPR; ++j) col_tot += red[(j * TPR + (c >> 2)) * 4 + (c & 3)];
+      if (ordered) ws_store(rec0 + (size_t)blockIdx.z * REC + BM * BN + c, col_tot);
+      else if (gridDim.z > 1) { if (m0 + c < M) atomicAdd(a_colsum + m0 + c, col_tot); }
     }
+  }
+
+  if (ordered) {
+    // The record travels through device-coherent (agent-scope, write-through / cache-bypassing)
+    // accesses, so the hand-over needs no L2 write-back + invalidate -- a __threadfence() pair per
+    // workgroup costs more than the whole GEMM on this 8-L2 part.
+    float *mine = rec0 + (size_t)blockIdx.z * REC;
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) {
+        const f32x4 a = acc[rm][rn];
+        float *d = mine + ((rm * RN + rn) * 256 + threadIdx.x) * 4;
+        ws_store2(d, a[0], a[1]);
+        ws_store2(d + 2, a[2], a[3]);
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores complete (vmcnt 0)
+    __syncthreads();
+    __shared__ int ticket;
+    if (threadIdx.x == 0)
+      ticket = __hip_atomic_fetch_add(ws_count + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket != (int)gridDim.z - 1) return;        // not the last split of this tile
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (threadIdx.x == 0)                            // ready for the next launch
+      __hip_atomic_store(ws_count + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) acc[rm][rn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < (int)gridDim.z; ++z) {       // fixed order: bit-reproducible
+      const float *part = rec0 + (size_t)z * REC;
+#pragma unroll
+      for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+        for (int rn = 0; rn < RN; ++rn) {
+          const float *q = part + ((rm * RN + rn) * 256 + threadIdx.x) * 4;
+          float v0, v1, v2, v3;
+          ws_load2(q, v0, v1);
+          ws_load2(q + 2, v2, v3);
+          acc[rm][rn][0] += v0; acc[rm][rn][1] += v1; acc[rm][rn][2] += v2; acc[rm][rn][3] += v3;
+        }
+    }
+    if (do_colsum && threadIdx.x < BM) {
+      col_tot = 0.f;
+      for (int z = 0; z < (int)gridDim.z; ++z) col_tot += ws_load(rec0 + (size_t)z * REC + BM * BN + threadIdx.x);
+    }
+  }
+  // single writer per column from here on (one split, or the last arriver of the ordered path)
+  if (do_colsum && threadIdx.x < BM && (ordered || gridDim.z == 1) && m0 + (int)threadIdx.x < M) {
+    float *dst = a_colsum + m0 + threadIdx.x;
+    *dst = (flags & 2) ? *dst + col_tot : col_tot;   // flags bit 1: accumulate onto db
   }
 
   // epilogue: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -215,7 +298,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
   for (int rn = 0; rn < RN; ++rn) {
     const int col = n0 + wn * (16 * RN) + rn * 16 + i;
     if (col >= N) continue;
-    const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
+    const float bv = (bias && (ordered || blockIdx.z == 0)) ? bias[col] : 0.f;
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
@@ -224,7 +307,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
         if (row >= M) continue;
         float v = acc[rm][rn][r] + bv;
         const size_t o = (size_t)row * ldc + col;
-        if (gridDim.z > 1) {          // C was zeroed (beta == 0) or holds the value to add to
+        if (gridDim.z > 1 && !ordered) {   // C was zeroed (beta == 0) or holds the value to add to
           atomicAdd(C + o, v);
           continue;
         }
@@ -281,7 +364,7 @@ template <bool AK, bool BKc, int RM, int RN>
 static hipError_t launch_gemm(dim3 grid, hipStream_t st, int M, int N, int K, const float *A,
                               int lda, const float *B, int ldb, float *C, int ldc,
                               const float *bias, float *C_pre, int flags, float beta, int av, int bv,
-                              int per, float *a_colsum) {
+                              int per, float *a_colsum, float *ws_part, int *ws_count) {
   constexpr size_t lds = sizeof(float) * 2 * (tile_floats(32 * RM) + tile_floats(32 * RN));
   auto kern = gemm_f32_kernel<AK, BKc, RM, RN>;
   if (lds > 64 * 1024) {
@@ -294,14 +377,14 @@ static hipError_t launch_gemm(dim3 grid, hipStream_t st, int M, int N, int K, co
     }
   }
   kern<<<grid, 256, lds, st>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags, beta, av, bv, per,
-                               a_colsum);
+                               a_colsum, ws_part, ws_count);
   return hipGetLastError();
 }
 
 static int gemm_f32_impl(int a_kc, int b_kc, int M, int N, int K, const float *A, int lda,
                          const float *B, int ldb, float *C, int ldc, const float *bias,
-                         float *C_pre, int flags, float beta, float *a_colsum,
-                         msr3d_stream_t stream) {
+                         float *C_pre, int flags, float beta, float *a_colsum, void *workspace,
+                         size_t workspace_bytes, msr3d_stream_t stream) {
   if (M < 0 || N < 0 || K < 0 || lda <= 0 || ldb <= 0 || ldc <= 0) return MSR3D_EINVAL;
   if (M == 0 || N == 0) return 0;
   if (!A || !B || !C) return MSR3D_EINVAL;
@@ -328,38 +411,59 @@ static int gemm_f32_impl(int a_kc, int b_kc, int M, int N, int K, const float *A
   // needs the complete sum, and beta must be 0 or 1 for the atomic meeting point.
   int splits = 1;
   // (measured in the full step: requiring >= 9 / 17 / 33 slabs before splitting costs 1 / 2 / 16 %)
-  if (!(flags & 1) && (beta == 0.f || beta == 1.f) && tiles < 256 && slabs >= 4) {
+  if ((beta == 0.f || beta == 1.f) && tiles <= 256 && slabs >= 4) {
     splits = (target_wgs + tiles - 1) / tiles;
     if (splits > slabs / 2) splits = slabs / 2;
     if (splits < 1) splits = 1;
   }
+  // Meeting point of the splits.  With a workspace ([MSR3D_GEMM_WS_COUNTERS ints, zero before the
+  // first use and left zero by every launch][records]) the last workgroup of a tile adds the
+  // partials in order and runs the epilogue; without one the splits atomicAdd into a zeroed C.
+  float *ws_part = nullptr;
+  int *ws_count = nullptr;
+  const size_t rec_bytes = sizeof(float) * ((size_t)BM * BN + BM);
+  const size_t ws_head = sizeof(int) * MSR3D_GEMM_WS_COUNTERS;
+  if (splits > 1 && workspace && workspace_bytes > ws_head && tiles <= MSR3D_GEMM_WS_COUNTERS) {
+    const size_t fit = (workspace_bytes - ws_head) / (rec_bytes * (size_t)tiles);
+    if (fit >= 2) {
+      if ((size_t)splits > fit) splits = (int)fit;
+      ws_count = reinterpret_cast<int *>(workspace);
+      ws_part = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + ws_head);
+    }
+  }
+  if (!ws_part && (flags & 1)) splits = 1;          // fused GELU needs the complete sum
+  int per = (slabs + splits - 1) / splits;
+  if (per < 1) per = 1;                             // K == 0: C = bias + beta * C
+  splits = slabs > 0 ? (slabs + per - 1) / per : 1;
+  if (splits == 1) ws_part = nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (a_colsum) {
     // dW + db in one launch.  beta == 0: C (M x N, dense) is immediately followed by the M
-    // column sums and ONE memset establishes the zero both accumulate into; beta == 1: both
-    // destinations already hold the values to add to (e.g. slices of a zeroed flat gradient
-    // buffer) and may live anywhere.
+    // column sums; beta == 1: both destinations already hold the values to add to (e.g. slices of
+    // a zeroed flat gradient buffer) and may live anywhere.
     if (a_kc || ldc != N) return MSR3D_EINVAL;
     if (beta == 0.f) {
       if (a_colsum != C + (size_t)M * N) return MSR3D_EINVAL;
-      hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * ((size_t)M * N + M), st);
-      if (e != hipSuccess) return (int)e;
     } else if (beta != 1.f) {
       return MSR3D_EINVAL;
     }
-    if (splits == 1) splits = slabs >= 2 ? 2 : 1;   // keep the atomic meeting point semantics
-    if (splits == 1) beta = 1.f;                    // single split: add onto what C holds
-  } else if (splits > 1 && beta == 0.f) {
-    if (ldc != N) return MSR3D_EINVAL;          // split path zeroes a dense C
+    if (beta == 1.f) flags |= 2;                    // column sums accumulate as well
+    if (splits > 1 && !ws_part) {                   // atomic meeting point
+      if (beta == 0.f) {
+        hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * ((size_t)M * N + M), st);
+        if (e != hipSuccess) return (int)e;
+      }
+    }
+  } else if (splits > 1 && !ws_part && beta == 0.f) {
+    if (ldc != N) return MSR3D_EINVAL;          // atomic split path zeroes a dense C
     hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, st);
     if (e != hipSuccess) return (int)e;
   }
-  const int per = (slabs + splits - 1) / splits;
-  splits = (slabs + per - 1) / per;
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits);
   const int av = vec_ok(A, lda), bv = vec_ok(B, ldb);
   hipError_t e = hipErrorInvalidValue;
-#define ARGS grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags, beta, av, bv, per, a_colsum
+#define ARGS grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags, beta, av, bv, per, a_colsum, \
+             ws_part, ws_count
 #define PICK(AK, BKc)                                                       \
   do {                                                                      \
     if (rm == 2 && rn == 2) e = launch_gemm<AK, BKc, 2, 2>(ARGS);           \
@@ -382,23 +486,27 @@ extern "C" {
 
 int msr3d_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float *A, int lda,
                    const float *B, int ldb, float *C, int ldc, const float *bias, float *C_pre,
-                   int flags, float beta, msr3d_stream_t stream) {
-  return gemm_f32_impl(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags, beta,
-                       nullptr, stream);
+                   int flags, float beta, void *workspace, size_t workspace_bytes,
+                   msr3d_stream_t stream) {
+  return gemm_f32_impl(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags & ~2, beta,
+                       nullptr, workspace, workspace_bytes, stream);
 }
 
 int msr3d_linear_wgrad_f32(int M_tokens, int N_out, int K_in, const float *dy, const float *x,
-                           float *dw_db, msr3d_stream_t stream) {
+                           float *dw_db, void *workspace, size_t workspace_bytes,
+                           msr3d_stream_t stream) {
   if (!dw_db) return MSR3D_EINVAL;
   return gemm_f32_impl(0, 0, N_out, K_in, M_tokens, dy, N_out, x, K_in, dw_db, K_in, nullptr,
-                       nullptr, 0, 0.f, dw_db + (size_t)N_out * K_in, stream);
+                       nullptr, 0, 0.f, dw_db + (size_t)N_out * K_in, workspace, workspace_bytes,
+                       stream);
 }
 
 int msr3d_linear_wgrad_acc_f32(int M_tokens, int N_out, int K_in, const float *dy, const float *x,
-                               float *dw, float *db, msr3d_stream_t stream) {
+                               float *dw, float *db, void *workspace, size_t workspace_bytes,
+                               msr3d_stream_t stream) {
   if (!dw) return MSR3D_EINVAL;
   return gemm_f32_impl(0, 0, N_out, K_in, M_tokens, dy, N_out, x, K_in, dw, K_in, nullptr,
-                       nullptr, 0, 1.f, db, stream);
+                       nullptr, 0, 1.f, db, workspace, workspace_bytes, stream);
 }
 
 int msr3d_colsum_f32(int M, int N, const float *X, int ldx, float *out, int accumulate,

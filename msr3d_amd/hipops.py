@@ -22,12 +22,60 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
 
 
+# ---- split-K workspace (include/msr3d_hip.h, msr3d_gemm_f32) ---------------------------------
+# MSR3D_GEMM_DETERMINISTIC=1 (or set_deterministic(True)) selects the ordered split-K meeting point:
+# bit-reproducible GEMMs at ~5 % step time; default is the atomic one.
+# One persistent buffer per (device, lane).  Launches that share a lane must be ordered on one
+# stream; work issued concurrently on a second stream (the encoder prefetch of train_step.py)
+# selects another lane with `gemm_lane(1)`.  Allocated (and zeroed, once) at first use -- before
+# any HIP-graph capture, since the eager warm-up steps run the same GEMMs.
+GEMM_WS_BYTES = 16 << 20
+_ws = {}
+_lane = [0]
+
+
+class gemm_lane:
+    def __init__(self, lane):
+        self.lane = lane
+
+    def __enter__(self):
+        self.prev = _lane[0]
+        _lane[0] = self.lane
+
+    def __exit__(self, *a):
+        _lane[0] = self.prev
+
+
+def _workspace(dev):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _lane[0])
+    ws = _ws.get(key)
+    if ws is None:
+        ws = _ws[key] = torch.zeros(GEMM_WS_BYTES // 4, dtype=torch.int32, device=dev)
+    return ws
+
+
+_deterministic = [_os.environ.get("MSR3D_GEMM_DETERMINISTIC", "0") == "1"]
+
+
+def set_deterministic(on):
+    """Ordered (bit-reproducible) split-K for every GEMM issued from now on."""
+    _deterministic[0] = bool(on)
+
+
+def _ws_args(dev):
+    if not _deterministic[0]:
+        return ctypes.c_void_p(0), ctypes.c_size_t(0)
+    ws = _workspace(dev)
+    return ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(GEMM_WS_BYTES)
+
+
 def _gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, bias=None, c_pre=None, flags=0, beta=0.0):
     lib = _lib.load()
     dev = C.device
+    wp, wb = _ws_args(dev)
     with torch.cuda.device(dev):
         rc = lib.msr3d_gemm_f32(int(a_kc), int(b_kc), M, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc,
-                                _p(bias), _p(c_pre), flags, ctypes.c_float(beta),
+                                _p(bias), _p(c_pre), flags, ctypes.c_float(beta), wp, wb,
                                 _lib.current_stream_ptr(dev))
     _lib.check(rc, "msr3d_gemm_f32")
 
@@ -89,10 +137,11 @@ class _HipLinear(torch.autograd.Function):
             # accumulate dW (+ db) straight into the flat gradient buffer's views
             dpw, wparam, bparam = ctx.direct
             lib = _lib.load()
+            wp, wb = _ws_args(dy.device)
             with torch.cuda.device(dy.device):
                 rc = lib.msr3d_linear_wgrad_acc_f32(M, N, K, _p(dy2), _p(x2), _p(wparam.grad),
                                                     _p(bparam.grad if bparam is not None else None),
-                                                    _lib.current_stream_ptr(dy.device))
+                                                    wp, wb, _lib.current_stream_ptr(dy.device))
             _lib.check(rc, "msr3d_linear_wgrad_acc_f32")
             dpw.mark_ready(wparam)
             if bparam is not None:
@@ -102,8 +151,9 @@ class _HipLinear(torch.autograd.Function):
             # dW = dy^T @ x and db = colsum(dy) from ONE launch into one buffer
             buf = torch.empty((N * K + N,), dtype=torch.float32, device=dy.device)
             lib = _lib.load()
+            wp, wb = _ws_args(dy.device)
             with torch.cuda.device(dy.device):
-                rc = lib.msr3d_linear_wgrad_f32(M, N, K, _p(dy2), _p(x2), _p(buf),
+                rc = lib.msr3d_linear_wgrad_f32(M, N, K, _p(dy2), _p(x2), _p(buf), wp, wb,
                                                 _lib.current_stream_ptr(dy.device))
             _lib.check(rc, "msr3d_linear_wgrad_f32")
             dw, db = buf[:N * K].view(N, K), buf[N * K:]
@@ -165,8 +215,9 @@ class _HipLinearPacked(torch.autograd.Function):
             _gemm(True, False, M, K, N, dy2, N, wv, K, dx, K)
             dx = dx.reshape(ctx.x_shape)
         lib = _lib.load()
+        wp, wb = _ws_args(dy.device)
         with torch.cuda.device(dy.device):
-            rc = lib.msr3d_linear_wgrad_acc_f32(M, N, K, _p(dy2), _p(x2), _p(gwv), _p(gbv),
+            rc = lib.msr3d_linear_wgrad_acc_f32(M, N, K, _p(dy2), _p(x2), _p(gwv), _p(gbv), wp, wb,
                                                 _lib.current_stream_ptr(dy.device))
         _lib.check(rc, "msr3d_linear_wgrad_acc_f32")
         for p in ctx.members:

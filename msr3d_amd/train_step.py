@@ -70,7 +70,8 @@ class HotPathTrainStep:
             return
         main = torch.cuda.current_stream()
         self._enc_stream.wait_stream(main)          # inputs exist; previous prefetch consumed
-        with torch.cuda.stream(self._enc_stream), torch.no_grad():
+        # (the encoder's fc GEMM runs concurrently with the main stream's: its own split-K workspace)
+        with torch.cuda.stream(self._enc_stream), torch.no_grad(), hipops.gemm_lane(1):
             self._pref["feats"].copy_(self.prompter.encode_objects(batch["obj_fts"]))
             ev = torch.cuda.Event()
             ev.record(self._enc_stream)

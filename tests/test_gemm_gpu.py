@@ -54,3 +54,83 @@ def test_linear_batched_leading_dims_and_no_bias():
     # non-contiguous input (a transposed view) is handled
     xt = torch.randn(256, 60, device="cuda").t()
     assert rel(hipops.linear(xt, w), F.linear(xt.double(), w.double())) < 1e-5
+
+
+def test_split_k_is_bit_reproducible_and_matches_the_atomic_path(monkeypatch):
+    """The workspace meeting point adds the K-splits in a fixed order: repeated launches are
+    bit-identical (forward, dx, dW, db); the memset + atomicAdd path (no workspace) agrees to
+    rounding; counters are left zero."""
+    from msr3d_amd import hipops
+    monkeypatch.setattr(hipops, "_deterministic", [True])
+    torch.manual_seed(0)
+    outs = []
+    for rep in range(3):
+        x = torch.randn(960, 2048, device="cuda").requires_grad_()
+        w = torch.randn(256, 2048, device="cuda").requires_grad_()
+        b = torch.randn(256, device="cuda").requires_grad_()
+        torch.manual_seed(1)
+        x.data.normal_(); w.data.normal_(); b.data.normal_()
+        y = hipops.linear(x, w, b)
+        y.backward(torch.ones_like(y) * 0.5)
+        outs.append((y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone()))
+    for t0, t1, t2 in zip(*outs):
+        assert torch.equal(t0, t1) and torch.equal(t0, t2)
+    ws = hipops._workspace(torch.device("cuda", torch.cuda.current_device()))
+    assert int(ws[:1024].abs().sum()) == 0
+    monkeypatch.setattr(hipops, "_deterministic", [False])
+    x = torch.randn(960, 2048, device="cuda").requires_grad_()
+    w = torch.randn(256, 2048, device="cuda").requires_grad_()
+    b = torch.randn(256, device="cuda").requires_grad_()
+    torch.manual_seed(1)
+    x.data.normal_(); w.data.normal_(); b.data.normal_()
+    y = hipops.linear(x, w, b)
+    y.backward(torch.ones_like(y) * 0.5)
+    for got, want in zip((y, x.grad, w.grad, b.grad), outs[0]):
+        assert rel(got, want) < 1e-6
+
+
+def test_split_k_with_fused_gelu_and_small_workspace():
+    """Raw C-ABI: GELU epilogue after an ordered split-K sum; a workspace too small for the
+    preferred split count is used with fewer splits; NULL workspace still works."""
+    import ctypes
+    from msr3d_amd import _lib
+    lib = _lib.load()
+    M, N, K = 128, 64, 4096
+    A = torch.randn(M, K, device="cuda")
+    B = torch.randn(N, K, device="cuda") / K ** 0.5
+    bias = torch.randn(N, device="cuda")
+    want = F.gelu(F.linear(A.double(), B.double(), bias.double()))
+    p = lambda t: ctypes.c_void_p(t.data_ptr())     # noqa: E731
+    for ws_bytes in (16 << 20, 4096 + 2 * (64 * 64 + 64) * 4 * 2 + 64, 0):
+        ws = torch.zeros(max(ws_bytes, 4) // 4, dtype=torch.int32, device="cuda")
+        C = torch.full((M, N), float("nan"), device="cuda")
+        pre = torch.empty_like(C)
+        rc = lib.msr3d_gemm_f32(1, 1, M, N, K, p(A), K, p(B), K, p(C), N, p(bias), p(pre), 1,
+                                ctypes.c_float(0.0), p(ws) if ws_bytes else None,
+                                ctypes.c_size_t(ws_bytes), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert rel(C, want) < 1e-5, ws_bytes
+        assert rel(F.gelu(pre.double()), want) < 1e-5
+        assert int(ws[:1024].abs().sum()) == 0
+
+
+def test_two_streams_with_separate_lanes_do_not_interfere(monkeypatch):
+    from msr3d_amd import hipops
+    monkeypatch.setattr(hipops, "_deterministic", [True])
+    x = torch.randn(960, 768, device="cuda")
+    w = torch.randn(768, 768, device="cuda") / 28
+    want = F.linear(x.double(), w.double())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    res = []
+    for _ in range(20):
+        a = hipops.linear(x, w)
+        with torch.cuda.stream(side), hipops.gemm_lane(1):
+            b = hipops.linear(x, w)
+        res += [a, b]
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for r in res:
+        assert torch.equal(r, res[0])
+    assert rel(res[0], want) < 1e-5
