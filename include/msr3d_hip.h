@@ -142,6 +142,8 @@ int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pt
 /* C[m][n] = beta*C[m][n] + bias[n] + sum_k a(m,k)*b(n,k),  a(m,k) = a_kc ? A[m*lda+k] : A[k*lda+m],
  * b(n,k) = b_kc ? B[n*ldb+k] : B[k*ldb+n].  flags bit0: C = gelu(.) (exact erf form) and, if
  * C_pre != NULL, C_pre = the pre-activation (saved for backward).  bias / C_pre may be NULL.
+ * p_drop > 0: inverted dropout on the final value (after GELU), mask = hash(*seed, salt, m*N+n)
+ * like msr3d_dropout_add_ln_fwd (needs ldc == N); msr3d_gelu_bwd_f32 regenerates it.
  *
  * workspace (may be NULL): device memory for the split-K meeting point, used by launches that are
  * ordered on one stream.  Layout: MSR3D_GEMM_WS_COUNTERS ints that must be ZERO before the first
@@ -152,8 +154,8 @@ int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pt
 #define MSR3D_GEMM_WS_COUNTERS 1024
 int msr3d_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float *A, int lda,
                    const float *B, int ldb, float *C, int ldc, const float *bias, float *C_pre,
-                   int flags, float beta, void *workspace, size_t workspace_bytes,
-                   msr3d_stream_t stream);
+                   int flags, float beta, float p_drop, const unsigned long long *seed,
+                   unsigned salt, void *workspace, size_t workspace_bytes, msr3d_stream_t stream);
 
 /* Weight AND bias gradient of y = x W^T + b in one launch: dw_db is a dense buffer of
  * N_out*K_in + N_out floats; on return dw_db[0 .. N_out*K_in) = dy^T x  (N_out x K_in) and
@@ -173,9 +175,10 @@ int msr3d_linear_wgrad_acc_f32(int M_tokens, int N_out, int K_in, const float *d
 int msr3d_colsum_f32(int M, int N, const float *X, int ldx, float *out, int accumulate,
                      msr3d_stream_t stream);
 
-/* out = dy * gelu'(pre), n % 4 == 0, 16-byte aligned. */
-int msr3d_gelu_bwd_f32(long long n, const float *dy, const float *pre, float *out,
-                       msr3d_stream_t stream);
+/* out = dropmask(dy) * gelu'(pre), n % 4 == 0, 16-byte aligned.  p_drop > 0 re-applies the
+ * epilogue dropout of the forward msr3d_gemm_f32 call (same seed word, same salt). */
+int msr3d_gelu_bwd_f32(long long n, const float *dy, const float *pre, float *out, float p_drop,
+                       const unsigned long long *seed, unsigned salt, msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Core of MultiHeadAttentionSpatial, 'cond' fusion
@@ -236,12 +239,13 @@ int msr3d_dropout_add_ln_fwd(int M, int D, const float *a, const float *r, const
                              const unsigned long long *seed, unsigned salt, float *y, float *s_out,
                              float *stats, msr3d_stream_t stream);
 
-/* da (M,D; NULL if a needs no grad) and dr (M,D; NULL if r was NULL) are written;
- * dgamma_acc / dbeta_acc (D) are ACCUMULATED into (atomicAdd). */
+/* da (M,D; NULL if a needs no grad) is written; dr (M,D; NULL if r was NULL) is written, or
+ * added to when dr_accumulate != 0 (a residual consumed by several blocks: the gradients meet in
+ * one buffer without a separate add); dgamma_acc / dbeta_acc (D) are ACCUMULATED into (atomicAdd). */
 int msr3d_dropout_add_ln_bwd(int M, int D, const float *dy, const float *s, const float *stats,
                              const float *gamma, float p_drop, const unsigned long long *seed,
-                             unsigned salt, float *da, float *dr, float *dgamma_acc,
-                             float *dbeta_acc, msr3d_stream_t stream);
+                             unsigned salt, float *da, float *dr, int dr_accumulate,
+                             float *dgamma_acc, float *dbeta_acc, msr3d_stream_t stream);
 
 /* Advance the device-resident dropout seed word (once per training step, inside the graph). */
 int msr3d_bump_seed(unsigned long long *seed, msr3d_stream_t stream);

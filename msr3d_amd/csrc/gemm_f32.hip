@@ -28,6 +28,7 @@
 #include <cstdlib>
 
 #include "../../include/msr3d_hip.h"
+#include "dropout_rng.h"
 
 namespace {
 
@@ -130,7 +131,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
                                                        int slabs_per_split,
                                                        float *__restrict__ a_colsum,
                                                        float *__restrict__ ws_part,
-                                                       int *__restrict__ ws_count) {
+                                                       int *__restrict__ ws_count, float p_drop,
+                                                       const unsigned long long *__restrict__ seed,
+                                                       unsigned salt) {
   constexpr int BM = 32 * RM, BN = 32 * RN;
   constexpr int TA = tile_floats(BM), TB = tile_floats(BN);
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -294,6 +297,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
   }
 
   // epilogue: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
+  const bool drop = (flags & 4) != 0;                 // dropout on the final value (after GELU)
+  const unsigned thresh = msr3d::drop_thresh(drop ? p_drop : 0.f);
+  const float dscale = drop ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const unsigned long long sd = drop ? *seed : 0ull;
 #pragma unroll
   for (int rn = 0; rn < RN; ++rn) {
     const int col = n0 + wn * (16 * RN) + rn * 16 + i;
@@ -316,6 +323,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
           if (Cpre) Cpre[o] = v;
           v = gelu_f(v);
         }
+        if (drop) v = msr3d::keep_elem(sd, salt, (unsigned)o, thresh) ? v * dscale : 0.f;
         C[o] = v;
       }
   }
@@ -343,10 +351,24 @@ __global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float *
 
 // dpre = dy * gelu'(pre)   (exact erf form), elementwise, float4
 __global__ void gelu_bwd_kernel(long long n4, const float4 *__restrict__ dy,
-                                const float4 *__restrict__ pre, float4 *__restrict__ out) {
+                                const float4 *__restrict__ pre, float4 *__restrict__ out,
+                                float p_drop, const unsigned long long *__restrict__ seed,
+                                unsigned salt) {
+  const bool drop = p_drop > 0.f;                    // the forward's epilogue dropout, regenerated
+  const unsigned thresh = msr3d::drop_thresh(p_drop);
+  const float dscale = drop ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const unsigned long long sd = drop ? *seed : 0ull;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n4;
        t += (long long)gridDim.x * blockDim.x) {
-    const float4 d = dy[t], x = pre[t];
+    float4 d = dy[t];
+    const float4 x = pre[t];
+    if (drop) {
+      const unsigned base = (unsigned)(t * 4);
+      d.x = msr3d::keep_elem(sd, salt, base + 0, thresh) ? d.x * dscale : 0.f;
+      d.y = msr3d::keep_elem(sd, salt, base + 1, thresh) ? d.y * dscale : 0.f;
+      d.z = msr3d::keep_elem(sd, salt, base + 2, thresh) ? d.z * dscale : 0.f;
+      d.w = msr3d::keep_elem(sd, salt, base + 3, thresh) ? d.w * dscale : 0.f;
+    }
     float4 o;
     const float k0 = 0.70710678118654752440f, k1 = 0.39894228040143267794f;   // 1/sqrt2, 1/sqrt(2pi)
 #define GB(c) o.c = d.c * (0.5f * (1.0f + erff(x.c * k0)) + x.c * k1 * __expf(-0.5f * x.c * x.c))
@@ -364,7 +386,8 @@ template <bool AK, bool BKc, int RM, int RN>
 static hipError_t launch_gemm(dim3 grid, hipStream_t st, int M, int N, int K, const float *A,
                               int lda, const float *B, int ldb, float *C, int ldc,
                               const float *bias, float *C_pre, int flags, float beta, int av, int bv,
-                              int per, float *a_colsum, float *ws_part, int *ws_count) {
+                              int per, float *a_colsum, float *ws_part, int *ws_count, float p_drop,
+                              const unsigned long long *seed, unsigned salt) {
   constexpr size_t lds = sizeof(float) * 2 * (tile_floats(32 * RM) + tile_floats(32 * RN));
   auto kern = gemm_f32_kernel<AK, BKc, RM, RN>;
   if (lds > 64 * 1024) {
@@ -377,14 +400,15 @@ static hipError_t launch_gemm(dim3 grid, hipStream_t st, int M, int N, int K, co
     }
   }
   kern<<<grid, 256, lds, st>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags, beta, av, bv, per,
-                               a_colsum, ws_part, ws_count);
+                               a_colsum, ws_part, ws_count, p_drop, seed, salt);
   return hipGetLastError();
 }
 
 static int gemm_f32_impl(int a_kc, int b_kc, int M, int N, int K, const float *A, int lda,
                          const float *B, int ldb, float *C, int ldc, const float *bias,
                          float *C_pre, int flags, float beta, float *a_colsum, void *workspace,
-                         size_t workspace_bytes, msr3d_stream_t stream) {
+                         size_t workspace_bytes, float p_drop, const unsigned long long *seed,
+                         unsigned salt, msr3d_stream_t stream) {
   if (M < 0 || N < 0 || K < 0 || lda <= 0 || ldb <= 0 || ldc <= 0) return MSR3D_EINVAL;
   if (M == 0 || N == 0) return 0;
   if (!A || !B || !C) return MSR3D_EINVAL;
@@ -431,7 +455,13 @@ static int gemm_f32_impl(int a_kc, int b_kc, int M, int N, int K, const float *A
       ws_part = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + ws_head);
     }
   }
-  if (!ws_part && (flags & 1)) splits = 1;          // fused GELU needs the complete sum
+  if (p_drop > 0.f) {
+    if (p_drop >= 1.f || !seed || ldc != N) return MSR3D_EINVAL;   // mask index = row * N + col
+    flags |= 4;
+  } else {
+    flags &= ~4;
+  }
+  if (!ws_part && (flags & 5)) splits = 1;          // fused GELU / dropout need the complete sum
   int per = (slabs + splits - 1) / splits;
   if (per < 1) per = 1;                             // K == 0: C = bias + beta * C
   splits = slabs > 0 ? (slabs + per - 1) / per : 1;
@@ -463,7 +493,7 @@ static int gemm_f32_impl(int a_kc, int b_kc, int M, int N, int K, const float *A
   const int av = vec_ok(A, lda), bv = vec_ok(B, ldb);
   hipError_t e = hipErrorInvalidValue;
 #define ARGS grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags, beta, av, bv, per, a_colsum, \
-             ws_part, ws_count
+             ws_part, ws_count, p_drop, seed, salt
 #define PICK(AK, BKc)                                                       \
   do {                                                                      \
     if (rm == 2 && rn == 2) e = launch_gemm<AK, BKc, 2, 2>(ARGS);           \
@@ -486,10 +516,10 @@ extern "C" {
 
 int msr3d_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float *A, int lda,
                    const float *B, int ldb, float *C, int ldc, const float *bias, float *C_pre,
-                   int flags, float beta, void *workspace, size_t workspace_bytes,
-                   msr3d_stream_t stream) {
-  return gemm_f32_impl(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags & ~2, beta,
-                       nullptr, workspace, workspace_bytes, stream);
+                   int flags, float beta, float p_drop, const unsigned long long *seed,
+                   unsigned salt, void *workspace, size_t workspace_bytes, msr3d_stream_t stream) {
+  return gemm_f32_impl(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags & ~6, beta,
+                       nullptr, workspace, workspace_bytes, p_drop, seed, salt, stream);
 }
 
 int msr3d_linear_wgrad_f32(int M_tokens, int N_out, int K_in, const float *dy, const float *x,
@@ -497,8 +527,8 @@ int msr3d_linear_wgrad_f32(int M_tokens, int N_out, int K_in, const float *dy, c
                            msr3d_stream_t stream) {
   if (!dw_db) return MSR3D_EINVAL;
   return gemm_f32_impl(0, 0, N_out, K_in, M_tokens, dy, N_out, x, K_in, dw_db, K_in, nullptr,
-                       nullptr, 0, 0.f, dw_db + (size_t)N_out * K_in, workspace, workspace_bytes,
-                       stream);
+                       nullptr, 0, 0.f, dw_db + (size_t)N_out * K_in, workspace, workspace_bytes, 0.f,
+                       nullptr, 0, stream);
 }
 
 int msr3d_linear_wgrad_acc_f32(int M_tokens, int N_out, int K_in, const float *dy, const float *x,
@@ -506,7 +536,7 @@ int msr3d_linear_wgrad_acc_f32(int M_tokens, int N_out, int K_in, const float *d
                                msr3d_stream_t stream) {
   if (!dw) return MSR3D_EINVAL;
   return gemm_f32_impl(0, 0, N_out, K_in, M_tokens, dy, N_out, x, K_in, dw, K_in, nullptr,
-                       nullptr, 0, 1.f, db, workspace, workspace_bytes, stream);
+                       nullptr, 0, 1.f, db, workspace, workspace_bytes, 0.f, nullptr, 0, stream);
 }
 
 int msr3d_colsum_f32(int M, int N, const float *X, int ldx, float *out, int accumulate,
@@ -525,9 +555,9 @@ int msr3d_colsum_f32(int M, int N, const float *X, int ldx, float *out, int accu
   return (int)hipGetLastError();
 }
 
-int msr3d_gelu_bwd_f32(long long n, const float *dy, const float *pre, float *out,
-                       msr3d_stream_t stream) {
-  if (n < 0 || (n % 4) != 0) return MSR3D_EINVAL;
+int msr3d_gelu_bwd_f32(long long n, const float *dy, const float *pre, float *out, float p_drop,
+                       const unsigned long long *seed, unsigned salt, msr3d_stream_t stream) {
+  if (n < 0 || (n % 4) != 0 || p_drop >= 1.f || (p_drop > 0.f && !seed)) return MSR3D_EINVAL;
   if (n == 0) return 0;
   if (!dy || !pre || !out) return MSR3D_EINVAL;
   const long long n4 = n / 4;
@@ -535,7 +565,7 @@ int msr3d_gelu_bwd_f32(long long n, const float *dy, const float *pre, float *ou
   if (g > 2048) g = 2048;
   gelu_bwd_kernel<<<(int)g, 256, 0, (hipStream_t)stream>>>(
       n4, reinterpret_cast<const float4 *>(dy), reinterpret_cast<const float4 *>(pre),
-      reinterpret_cast<float4 *>(out));
+      reinterpret_cast<float4 *>(out), p_drop, seed, salt);
   return (int)hipGetLastError();
 }
 

@@ -13,19 +13,11 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/msr3d_hip.h"
+#include "dropout_rng.h"
 
 namespace {
 
-__device__ __forceinline__ unsigned mix32(unsigned h) {   // murmur3 finaliser
-  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-  return h;
-}
-__device__ __forceinline__ bool keep_elem(unsigned long long seed, unsigned salt, unsigned idx,
-                                          unsigned thresh) {
-  const unsigned h = mix32(idx * 0x9E3779B1u + mix32((unsigned)seed ^ (salt * 0x7FEB352Du)) +
-                           (unsigned)(seed >> 32));
-  return mix32(h) >= thresh;       // P(keep) = 1 - thresh / 2^32
-}
+using msr3d::keep_elem;
 
 __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -105,7 +97,7 @@ __global__ __launch_bounds__(256) void dal_bwd_kernel(int M, int rows_per_block,
                                                       const float *__restrict__ gamma, float p_drop,
                                                       const unsigned long long *__restrict__ seed,
                                                       unsigned salt, float *__restrict__ da,
-                                                      float *__restrict__ dr,
+                                                      float *__restrict__ dr, int dr_accumulate,
                                                       float *__restrict__ dgamma,
                                                       float *__restrict__ dbeta) {
   constexpr int D = 256 * VPL;
@@ -151,7 +143,15 @@ __global__ __launch_bounds__(256) void dal_bwd_kernel(int M, int rows_per_block,
       dx.y = rstd * (g[j].y - c1 - xh[j].y * c2);
       dx.z = rstd * (g[j].z - c1 - xh[j].z * c2);
       dx.w = rstd * (g[j].w - c1 - xh[j].w * c2);
-      if (dr) *reinterpret_cast<float4 *>(dr + (size_t)row * D + c) = dx;
+      if (dr) {
+        float4 *o = reinterpret_cast<float4 *>(dr + (size_t)row * D + c);
+        if (dr_accumulate) {           // the residual's gradient joins one that is already there
+          const float4 e = *o;
+          *o = make_float4(e.x + dx.x, e.y + dx.y, e.z + dx.z, e.w + dx.w);
+        } else {
+          *o = dx;
+        }
+      }
       if (da) {
         if (drop) {
           const unsigned base = (unsigned)row * D + c;
@@ -201,8 +201,8 @@ int msr3d_dropout_add_ln_fwd(int M, int D, const float *a, const float *r, const
 
 int msr3d_dropout_add_ln_bwd(int M, int D, const float *dy, const float *s, const float *stats,
                              const float *gamma, float p_drop, const unsigned long long *seed,
-                             unsigned salt, float *da, float *dr, float *dgamma_acc,
-                             float *dbeta_acc, msr3d_stream_t stream) {
+                             unsigned salt, float *da, float *dr, int dr_accumulate,
+                             float *dgamma_acc, float *dbeta_acc, msr3d_stream_t stream) {
   if (M < 0 || (D != 256 && D != 512 && D != 768 && D != 1024)) return MSR3D_EINVAL;
   if (M == 0) return 0;
   if (!dy || !s || !stats || !gamma || !dgamma_acc || !dbeta_acc || (p_drop > 0.f && !seed))
@@ -210,7 +210,7 @@ int msr3d_dropout_add_ln_bwd(int M, int D, const float *dy, const float *s, cons
   hipStream_t st = (hipStream_t)stream;
   const int rpb = 16;
   const int grid = (M + rpb - 1) / rpb;
-#define L(V) dal_bwd_kernel<V><<<grid, 256, 0, st>>>(M, rpb, dy, s, stats, gamma, p_drop, seed, salt, da, dr, dgamma_acc, dbeta_acc)
+#define L(V) dal_bwd_kernel<V><<<grid, 256, 0, st>>>(M, rpb, dy, s, stats, gamma, p_drop, seed, salt, da, dr, dr_accumulate, dgamma_acc, dbeta_acc)
   switch (D / 256) { case 1: L(1); break; case 2: L(2); break; case 3: L(3); break; default: L(4); }
 #undef L
   return (int)hipGetLastError();

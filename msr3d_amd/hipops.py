@@ -69,15 +69,30 @@ def _ws_args(dev):
     return ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(GEMM_WS_BYTES)
 
 
-def _gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, bias=None, c_pre=None, flags=0, beta=0.0):
+def _gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, bias=None, c_pre=None, flags=0, beta=0.0,
+          p_drop=0.0, salt=0):
+    """p_drop > 0: epilogue dropout keyed by (seed word of the device, salt)."""
     lib = _lib.load()
     dev = C.device
     wp, wb = _ws_args(dev)
+    seed = seed_word(dev) if p_drop > 0 else None
     with torch.cuda.device(dev):
         rc = lib.msr3d_gemm_f32(int(a_kc), int(b_kc), M, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc,
-                                _p(bias), _p(c_pre), flags, ctypes.c_float(beta), wp, wb,
+                                _p(bias), _p(c_pre), flags, ctypes.c_float(beta),
+                                ctypes.c_float(p_drop), _p(seed), salt, wp, wb,
                                 _lib.current_stream_ptr(dev))
     _lib.check(rc, "msr3d_gemm_f32")
+
+
+def _gelu_bwd(dy2, pre, p_drop=0.0, salt=0):
+    lib = _lib.load()
+    g = torch.empty_like(dy2)
+    seed = seed_word(dy2.device) if p_drop > 0 else None
+    with torch.cuda.device(dy2.device):
+        rc = lib.msr3d_gelu_bwd_f32(dy2.numel(), _p(dy2), _p(pre), _p(g), ctypes.c_float(p_drop),
+                                    _p(seed), salt, _lib.current_stream_ptr(dy2.device))
+    _lib.check(rc, "msr3d_gelu_bwd_f32")
+    return g
 
 
 def _colsum(X, M, N, out, accumulate=False):
@@ -120,13 +135,7 @@ class _HipLinear(torch.autograd.Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         if pre is not None:
-            lib = _lib.load()
-            g = torch.empty_like(dy2)
-            with torch.cuda.device(dy2.device):
-                rc = lib.msr3d_gelu_bwd_f32(dy2.numel(), _p(dy2), _p(pre), _p(g),
-                                            _lib.current_stream_ptr(dy2.device))
-            _lib.check(rc, "msr3d_gelu_bwd_f32")
-            dy2 = g
+            dy2 = _gelu_bwd(dy2, pre)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
@@ -411,7 +420,7 @@ class _DropoutAddLN(torch.autograd.Function):
         lib = _lib.load()
         with torch.cuda.device(dy.device):
             rc = lib.msr3d_dropout_add_ln_bwd(M, D, _p(dy2), _p(s), _p(stats), _p(gamma),
-                                              ctypes.c_float(p_drop), _p(seed), salt, _p(da), _p(dr),
+                                              ctypes.c_float(p_drop), _p(seed), salt, _p(da), _p(dr), 0,
                                               _p(dg), _p(db), _lib.current_stream_ptr(dy.device))
         _lib.check(rc, "msr3d_dropout_add_ln_bwd")
         ga = da.view(shape) if da is not None else None

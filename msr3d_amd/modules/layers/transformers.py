@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
 
-from ... import hipops
+from ... import fused_layer, hipops
 from ..utils import get_activation_fn
 
 
@@ -197,6 +197,9 @@ class TransformerSpatialEncoderLayer(TransformerEncoderLayer):
                 tgt_key_padding_mask: Optional[Tensor] = None):
         # NB the attention block already returns LN(out + x); the layer then adds x AGAIN and
         # normalises (transformers.py:251 then :324-325) -- a double residual, kept as is.
+        if fused_layer.eligible(self, tgt, tgt_pairwise_locs):
+            # training on the flat-buffer engine: the whole layer as one hand-scheduled node
+            return fused_layer.spatial_layer(self, tgt, tgt_pairwise_locs, tgt_key_padding_mask)
         a, attn_w = self.self_attn(tgt, tgt, tgt, tgt_pairwise_locs,
                                    key_padding_mask=tgt_key_padding_mask)
         tgt = hipops.dropout_add_layernorm(a, tgt, self.norm1, self.dropout1.p, self.training)

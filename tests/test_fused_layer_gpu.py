@@ -1,0 +1,113 @@
+"""The hand-scheduled encoder-layer node (msr3d_amd/fused_layer.py) against the modular path
+(separate autograd nodes over the same kernels): same forward, same gradients, with and
+without dropout (masks are regenerated from the same counter-based hash, so with identical
+salts / seed the two paths would even agree bit for bit; here they draw at different call sites,
+so dropout runs are checked statistically and for fwd/bwd mask consistency)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def _setup(dropout, seed=0):
+    import msr3d_amd.model  # noqa: F401
+    import msr3d_amd.modules  # noqa: F401
+    from msr3d_amd import hipops
+    from msr3d_amd.config import AttrDict, default_prompter_cfg
+    from msr3d_amd.dp import FlatGradAllReduce
+    from msr3d_amd.model import build_model
+    from msr3d_amd.optim import FlatAdamW
+    from msr3d_amd.synth import synth_batch
+    torch.manual_seed(seed)
+    cfg = AttrDict({"prompter": default_prompter_cfg(dropout=dropout), "llm_hidden_size": 128,
+                    "model": {"name": "MSR3DHotPath"}})
+    model = build_model(cfg).cuda().train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    dp = FlatGradAllReduce(params, pack_groups=hipops.collect_pack_groups(model))
+    opt = FlatAdamW(dp, lr=1e-3)
+    assert hipops.attach_packed_views(model, dp, opt) == 3
+    batch = synth_batch(31, 3, O=20, P=1024, device="cuda")
+    return model, dp, batch
+
+
+def _run(model, dp, batch, fused):
+    for l in model.visual_prompter.spatial_encoder:
+        l.use_fused_layer = fused
+    dp.zero_grad()
+    out = model(dict(batch))
+    w = torch.linspace(-1, 1, out["scene_embeds"].numel(), device="cuda").view_as(out["scene_embeds"])
+    (out["scene_embeds"] * w).sum().backward()
+    dp.finish()
+    torch.cuda.synchronize()
+    return out["scene_embeds"].detach().clone(), {k: v.grad.detach().clone()
+                                                  for k, v in model.named_parameters() if v.requires_grad}
+
+
+def test_fused_layer_matches_modular_path_without_dropout():
+    from msr3d_amd import fused_layer
+    model, dp, batch = _setup(0.0)
+    layer = model.visual_prompter.spatial_encoder[0]
+    x = torch.randn(3, 20, 256, device="cuda")
+    assert fused_layer.eligible(layer, x, None)
+    y1, g1 = _run(model, dp, batch, True)
+    y0, g0 = _run(model, dp, batch, False)
+    assert rel(y1, y0) < 1e-6
+    assert sorted(g1) == sorted(g0)
+    for k in g0:
+        if k.endswith("w_ks.bias"):              # mathematically zero
+            assert g1[k].abs().max() < 1e-3
+            continue
+        assert rel(g1[k], g0[k]) < 2e-5, k
+    # eval / no_grad keeps the modular path (no packed training state needed)
+    model.eval()
+    with torch.no_grad():
+        assert not fused_layer.eligible(layer, x, None)
+        ye = model(dict(batch))["scene_embeds"]
+    assert rel(ye, y0) < 1e-6
+
+
+def test_fused_layer_dropout_is_consistent_between_forward_and_backward():
+    """With dropout the loss is a deterministic function of (weights, seed word): a central
+    difference along a random direction in linear2.weight must match the analytic gradient, which
+    only holds if backward regenerates exactly the masks the forward drew."""
+    from msr3d_amd import hipops
+    model, dp, batch = _setup(0.1, seed=1)
+    lin = model.visual_prompter.spatial_encoder[1].linear2
+    w = torch.linspace(-1, 1, 3 * 20 * 128, device="cuda").view(3, 20, 128)
+    seed = hipops.seed_word(torch.device("cuda", torch.cuda.current_device()))
+    seed0 = seed.clone()
+
+    def loss():
+        seed.copy_(seed0)                        # same masks on every evaluation
+        hipops._salt_counter[0] = 1000
+        torch.manual_seed(5)                     # (torch's own dropout on the object features)
+        dp.zero_grad()
+        return (model(dict(batch))["scene_embeds"].double() * w).sum()
+
+    l0 = loss()
+    l0.backward()
+    g = lin.weight.grad.detach().clone().double()
+    d = torch.randn_like(lin.weight)
+    d /= d.norm()
+    eps = 1e-2
+    def shifted(step):                           # (grad mode stays on: same code path, same masks)
+        with torch.no_grad():
+            lin.weight.add_(step * d)
+        val = loss().item()
+        with torch.no_grad():
+            lin.weight.add_(-step * d)
+        return val
+
+    lp, lm = shifted(eps), shifted(-eps)
+    fd = (lp - lm) / (2 * eps)
+    an = float((g * d.double()).sum())
+    assert abs(fd - an) <= 2e-2 * max(abs(an), 1e-3), (fd, an)
+    # and dropout is really active: two different seeds give different outputs
+    y_a = model(dict(batch))["scene_embeds"].detach().clone()
+    hipops.bump_seed(seed.device)
+    y_b = model(dict(batch))["scene_embeds"].detach()
+    assert rel(y_a, y_b) > 1e-3

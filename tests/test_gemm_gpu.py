@@ -106,7 +106,8 @@ def test_split_k_with_fused_gelu_and_small_workspace():
         C = torch.full((M, N), float("nan"), device="cuda")
         pre = torch.empty_like(C)
         rc = lib.msr3d_gemm_f32(1, 1, M, N, K, p(A), K, p(B), K, p(C), N, p(bias), p(pre), 1,
-                                ctypes.c_float(0.0), p(ws) if ws_bytes else None,
+                                ctypes.c_float(0.0), ctypes.c_float(0.0), None, 0,
+                                p(ws) if ws_bytes else None,
                                 ctypes.c_size_t(ws_bytes), None)
         assert rc == 0
         torch.cuda.synchronize()

@@ -16,7 +16,7 @@ for abl, nm in names.items():
     for _ in range(8):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        rc = lib.msr3d_gemm_f32(1, 1, M, N, K, p(A), K, p(B), K, p(C), N, None, None, abl << 8, ctypes.c_float(0.0), None, ctypes.c_size_t(0), st)
+        rc = lib.msr3d_gemm_f32(1, 1, M, N, K, p(A), K, p(B), K, p(C), N, None, None, abl << 8, ctypes.c_float(0.0), ctypes.c_float(0.0), None, 0, None, ctypes.c_size_t(0), st)
         e1.record(); torch.cuda.synchronize(); assert rc == 0
         ts.append(e0.elapsed_time(e1) * 1e3)
     t = sorted(ts)[len(ts) // 2]
