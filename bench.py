@@ -100,8 +100,18 @@ class Trainer:
         loss_w = torch.randn((B, L, E), generator=g).to(device)
         inv_n = 1.0 / loss_w.numel()
 
-        def loss_fn(out):       # synthetic scalar loss on the projector output
-            return (out["scene_embeds"] * loss_w).sum() * inv_n
+        loss_g = loss_w * inv_n
+
+        def loss_fn(out):
+            # synthetic scalar loss on the projector output, L = mean(scene_embeds * w); its gradient
+            # dL/dscene = w / n is handed to backward directly, the way the language model's
+            # backward would deliver it (value and gradient identical to autograd's on `L`)
+            y = out["scene_embeds"]
+            if not y.is_cuda:
+                return (y * loss_w).sum() * inv_n
+            with torch.no_grad():
+                loss = torch.dot(y.reshape(-1), loss_g.reshape(-1))
+            return loss, y, loss_g
 
         self.stepper = HotPathTrainStep(model, self.opt, self.dp, loss_fn, example_batch,
                                         use_graph=use_graph)

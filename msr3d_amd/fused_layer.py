@@ -115,11 +115,13 @@ class _SpatialLayerFn(torch.autograd.Function):
         pl = pairwise_locs.contiguous()
         pad = pad_mask.contiguous().view(torch.uint8)
 
-        # the three split-K meeting points of the forward, zeroed by one fill
-        zero = torch.zeros(M * (W + 2 * D), dtype=torch.float32, device=dev)
+        # the three split-K meeting points of the forward and the one of the backward (fc's dx),
+        # zeroed by one fill
+        zero = torch.zeros(M * (W + 3 * D), dtype=torch.float32, device=dev)
         qkvc = zero[:M * W].view(M, W)
         fc_out = zero[M * W:M * (W + D)].view(M, D)
-        ffn_out = zero[M * (W + D):].view(M, D)
+        ffn_out = zero[M * (W + D):M * (W + 2 * D)].view(M, D)
+        d_attn = zero[M * (W + 2 * D):].view(M, D)
 
         _gemm(True, True, M, W, D, x2, D, wv, D, qkvc, W, bias=bv, beta=1.0)
         attn = torch.empty((M, D), dtype=torch.float32, device=dev)
@@ -143,7 +145,9 @@ class _SpatialLayerFn(torch.autograd.Function):
               bias=layer.linear2.bias, beta=1.0)
         out, s3, st3 = _dal_fwd(ffn_out, t, layer.norm2, p2, salts[2])          # :327-328
 
-        ctx.save_for_backward(x2, qkvc, pl, pad, probs, attn, s1, st1, s2, st2, t, pre, h, s3, st3)
+        ctx.save_for_backward(x2, qkvc, pl, pad, probs, attn, s1, st1, s2, st2, t, pre, h, s3, st3,
+                              d_attn)
+        ctx.set_materialize_grads(False)          # no zero tensor for the probabilities' gradient
         ctx.layer = layer
         ctx.cfg = (B, L, D, M, W, H, FF, p_attn, p1, p2, p_ffn, salts)
         ctx.mark_non_differentiable(probs)
@@ -151,11 +155,15 @@ class _SpatialLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out, _d_probs):
-        x2, qkvc, pl, pad, probs, attn, s1, st1, s2, st2, t, pre, h, s3, st3 = ctx.saved_tensors
+        (x2, qkvc, pl, pad, probs, attn, s1, st1, s2, st2, t, pre, h, s3, st3,
+         d_attn) = ctx.saved_tensors
         layer = ctx.layer
         sa = layer.self_attn
         wv, bv, gwv, gbv, dp = sa._packed
         B, L, D, M, W, H, FF, p_attn, p1, p2, p_ffn, salts = ctx.cfg
+        n_params = len(layer_params(layer))
+        if d_out is None:                          # tokens unused downstream
+            return (None,) * (4 + n_params)
         dev = d_out.device
         g = d_out.reshape(M, D)
         g = g if g.is_contiguous() else g.contiguous()
@@ -174,8 +182,7 @@ class _SpatialLayerFn(torch.autograd.Function):
         _dal_bwd(d_t, s2, st2, layer.norm1, p1, salts[1], d_a, d_x, False)
         d_fc = new(M, D)
         _dal_bwd(d_a, s1, st1, sa.layer_norm, p_attn, salts[0], d_fc, d_x, True)             # joins d_x
-        d_attn = new(M, D)
-        _gemm(True, False, M, D, D, d_fc, D, sa.fc.weight, D, d_attn, D)
+        _gemm(True, False, M, D, D, d_fc, D, sa.fc.weight, D, d_attn, D, beta=1.0)   # onto the zeros
         _wgrad_acc(M, D, D, d_fc, attn, sa.fc.weight.grad, sa.fc.bias.grad)
         d_qkvc = new(M, W)
         lib = _lib.load()
@@ -192,7 +199,6 @@ class _SpatialLayerFn(torch.autograd.Function):
 
         for p in layer_params(layer):
             dp.mark_ready(p)
-        n_params = len(layer_params(layer))
         return (d_x.view(B, L, D), None, None, None) + (None,) * n_params
 
 

@@ -300,12 +300,15 @@ class _SpatialAttnCond(torch.autograd.Function):
         ctx.save_for_backward(x, pl, pad, probs)
         ctx.dims = (B, L, D, n_head, dh, W)
         ctx.mark_non_differentiable(probs)
+        ctx.set_materialize_grads(False)          # no zero tensor for the probabilities' gradient
         return out.view(B, L, D), probs
 
     @staticmethod
     def backward(ctx, dout, _dprobs):
         x, pl, pad, probs = ctx.saved_tensors
         B, L, D, H, dh, W = ctx.dims
+        if dout is None:
+            return (None,) * 7
         do = dout.reshape(B * L, D)
         if not do.is_contiguous():
             do = do.contiguous()

@@ -25,7 +25,8 @@ from . import hipops
 class HotPathTrainStep:
     def __init__(self, model, optimizer, dp, loss_fn, example_batch, use_graph=True):
         """model: MSR3DHotPath; dp: FlatGradAllReduce over its trainable params;
-        loss_fn(scene_dict) -> scalar; example_batch fixes the (static) shapes."""
+        loss_fn(scene_dict) -> scalar, or (scalar, tensor, d scalar / d tensor) when the caller
+        already holds the upstream gradient; example_batch fixes the (static) shapes."""
         self.model, self.opt, self.dp, self.loss_fn = model, optimizer, dp, loss_fn
         self.prompter = model.visual_prompter
         self.use_graph = use_graph and example_batch["obj_fts"].is_cuda
@@ -47,8 +48,15 @@ class HotPathTrainStep:
             hipops.bump_seed(self.static["obj_embeds"].device)   # fresh dropout masks per replay
         self.dp.zero_grad()
         out = self.model(dict(self.static))
-        loss = self.loss_fn(out)
-        loss.backward()
+        res = self.loss_fn(out)
+        if isinstance(res, tuple):
+            # (loss value, tensor, upstream gradient): how the path is driven in the real model --
+            # the gradient of `scene_embeds` arrives from the language model's backward
+            loss, y, gy = res
+            torch.autograd.backward([y], [gy])
+        else:
+            loss = res
+            loss.backward()
         return loss.detach()
 
     def _update(self):
