@@ -2,7 +2,6 @@
 the dropout statistics / forward-backward mask consistency (p > 0)."""
 import pytest
 import torch
-import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 

@@ -4,7 +4,6 @@ backward against (1) the same ops expressed in torch on the same device and (2) 
 on the CPU with the oracle standing in for the ops.  Tolerances are stated in the test."""
 import copy
 
-import numpy as np
 import pytest
 import torch
 
