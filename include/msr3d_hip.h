@@ -171,6 +171,13 @@ int msr3d_linear_wgrad_acc_f32(int M_tokens, int N_out, int K_in, const float *d
                                float *dw, float *db, void *workspace, size_t workspace_bytes,
                                msr3d_stream_t stream);
 
+/* Both backward products of y = x W^T + b in ONE launch (they are independent and each too small
+ * to fill the chip): dx (M_tokens x K_in) = dx_beta * dx + dy W with dx_beta 0 or 1, and the
+ * accumulation dw += dy^T x, db += colsum(dy) (db may be NULL) of msr3d_linear_wgrad_acc_f32. */
+int msr3d_linear_bwd_f32(int M_tokens, int N_out, int K_in, const float *dy, const float *x,
+                         const float *w, float *dx, float dx_beta, float *dw, float *db,
+                         void *workspace, size_t workspace_bytes, msr3d_stream_t stream);
+
 /* out[n] (+)= sum_m X[m*ldx + n]  (bias gradient). */
 int msr3d_colsum_f32(int M, int N, const float *X, int ldx, float *out, int accumulate,
                      msr3d_stream_t stream);

@@ -33,6 +33,8 @@ _SIGNATURES = {
                        _ptr, _ptr, _c_int, _c_float, _c_float, _ptr, ctypes.c_uint, _ptr, ctypes.c_size_t, _ptr],
     "msr3d_linear_wgrad_f32": [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, ctypes.c_size_t, _ptr],
     "msr3d_linear_wgrad_acc_f32": [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, ctypes.c_size_t, _ptr],
+    "msr3d_linear_bwd_f32": [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_float, _ptr, _ptr, _ptr,
+                             ctypes.c_size_t, _ptr],
     "msr3d_colsum_f32": [_c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr],
     "msr3d_gelu_bwd_f32": [ctypes.c_longlong, _ptr, _ptr, _ptr, _c_float, _ptr, ctypes.c_uint, _ptr],
     "msr3d_spatial_attn_fwd": [_c_int] * 5 + [_ptr, _ptr, _ptr, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr,

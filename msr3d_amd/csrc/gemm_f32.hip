@@ -119,28 +119,47 @@ __device__ __forceinline__ void read_frag(const float *s, int base, int sub, int
   }
 }
 
-// Workgroup tile (32 RM) x (32 RN): 2 x 2 waves of (16 RM) x (16 RN) each.
+// One problem of a launch: operands, epilogue switches and the (virtual) grid it was sized for.
+struct GemmP {
+  int M, N, K;
+  const float *A; int lda;
+  const float *B; int ldb;
+  float *C; int ldc;
+  const float *bias;
+  float *Cpre;
+  int flags;            // bit0 GELU, bit1 column sums accumulate, bit2 dropout
+  float beta;
+  int a_vec, b_vec, slabs_per_split;
+  float *a_colsum;
+  float *ws_part; int *ws_count;
+  float p_drop; const unsigned long long *seed; unsigned salt;
+  int gx, gy, gz;       // tiles along N, tiles along M, K-splits
+};
+
+// Workgroup tile (32 RM) x (32 RN): 2 x 2 waves of (16 RM) x (16 RN) each.  (bx, by, bz) is the
+// workgroup's place in the problem's own grid, so several problems can share one launch.
 template <bool A_KC, bool B_KC, int RM, int RN>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
-                                                       const float *__restrict__ A, int lda,
-                                                       const float *__restrict__ B, int ldb,
-                                                       float *__restrict__ C, int ldc,
-                                                       const float *__restrict__ bias,
-                                                       float *__restrict__ Cpre, int flags,
-                                                       float beta, int a_vec, int b_vec,
-                                                       int slabs_per_split,
-                                                       float *__restrict__ a_colsum,
-                                                       float *__restrict__ ws_part,
-                                                       int *__restrict__ ws_count, float p_drop,
-                                                       const unsigned long long *__restrict__ seed,
-                                                       unsigned salt) {
+__device__ __forceinline__ void gemm_body(const GemmP &p, const int bx, const int by, const int bz) {
+  const int M = p.M, N = p.N, K = p.K, lda = p.lda, ldb = p.ldb, ldc = p.ldc;
+  const float *__restrict__ A = p.A;
+  const float *__restrict__ B = p.B;
+  float *__restrict__ C = p.C;
+  const float *__restrict__ bias = p.bias;
+  float *__restrict__ Cpre = p.Cpre;
+  const int flags = p.flags, a_vec = p.a_vec, b_vec = p.b_vec, slabs_per_split = p.slabs_per_split;
+  const float beta = p.beta, p_drop = p.p_drop;
+  float *__restrict__ a_colsum = p.a_colsum;
+  float *__restrict__ ws_part = p.ws_part;
+  int *__restrict__ ws_count = p.ws_count;
+  const unsigned long long *__restrict__ seed = p.seed;
+  const unsigned salt = p.salt;
   constexpr int BM = 32 * RM, BN = 32 * RN;
   constexpr int TA = tile_floats(BM), TB = tile_floats(BN);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *const As = smem;                 // [2][TA]
   float *const Bs = smem + 2 * TA;        // [2][TB]
 
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = by * BM, n0 = bx * BN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int i = lane & 15, g = lane >> 4;
@@ -151,9 +170,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
 #pragma unroll
     for (int b = 0; b < RN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // split-K: blockIdx.z owns slabs [kbeg, kend) (never empty: the host sizes gridDim.z so)
+  // split-K: bz owns slabs [kbeg, kend) (never empty: the host sizes p.gz so)
   const int nk_all = (K + BK - 1) / BK;
-  const int kbeg = blockIdx.z * slabs_per_split;
+  const int kbeg = bz * slabs_per_split;
   const int kend = min(nk_all, kbeg + slabs_per_split);
   const int nk = kend - kbeg;
 
@@ -167,7 +186,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
   // bias gradient for free: in the dW product (A = dy, k-strided) the A tiles of the first
   // column of workgroups stream every dy element exactly once; thread t owns 4 columns
   // (t % (BM/4)) * 4 .. +3 of the tile for BM/32 of the 32 k-rows per slab.
-  const bool do_colsum = (!A_KC) && a_colsum != nullptr && blockIdx.x == 0;
+  const bool do_colsum = (!A_KC) && a_colsum != nullptr && bx == 0;
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
   if (do_colsum) {
 #pragma unroll
@@ -224,10 +243,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
     __syncthreads();
   }
 
-  const bool ordered = gridDim.z > 1 && ws_part != nullptr;   // workspace meeting point
-  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+  const bool ordered = p.gz > 1 && ws_part != nullptr;   // workspace meeting point
+  const int tile = by * p.gx + bx;
   constexpr int REC = BM * BN + BM;                  // one split's record: accumulators + column sums
-  float *const rec0 = ordered ? ws_part + (size_t)tile * gridDim.z * REC : nullptr;
+  float *const rec0 = ordered ? ws_part + (size_t)tile * p.gz * REC : nullptr;
   float col_tot = 0.f;                               // thread c < BM: sum of column m0 + c
   if (do_colsum) {
     // 256 / (BM/4) threads share each group of 4 columns: reduce their partial sums through LDS
@@ -239,8 +258,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
       const int c = threadIdx.x;                     // column of the tile
 #pragma unroll
       for (int j = 0; j < 256 / TPR; ++j) col_tot += red[(j * TPR + (c >> 2)) * 4 + (c & 3)];
-      if (ordered) ws_store(rec0 + (size_t)blockIdx.z * REC + BM * BN + c, col_tot);
-      else if (gridDim.z > 1) { if (m0 + c < M) atomicAdd(a_colsum + m0 + c, col_tot); }
+      if (ordered) ws_store(rec0 + (size_t)bz * REC + BM * BN + c, col_tot);
+      else if (p.gz > 1) { if (m0 + c < M) atomicAdd(a_colsum + m0 + c, col_tot); }
     }
   }
 
@@ -248,7 +267,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
     // The record travels through device-coherent (agent-scope, write-through / cache-bypassing)
     // accesses, so the hand-over needs no L2 write-back + invalidate -- a __threadfence() pair per
     // workgroup costs more than the whole GEMM on this 8-L2 part.
-    float *mine = rec0 + (size_t)blockIdx.z * REC;
+    float *mine = rec0 + (size_t)bz * REC;
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
@@ -264,7 +283,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
     if (threadIdx.x == 0)
       ticket = __hip_atomic_fetch_add(ws_count + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (ticket != (int)gridDim.z - 1) return;        // not the last split of this tile
+    if (ticket != p.gz - 1) return;        // not the last split of this tile
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (threadIdx.x == 0)                            // ready for the next launch
       __hip_atomic_store(ws_count + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -272,7 +291,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
     for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
       for (int rn = 0; rn < RN; ++rn) acc[rm][rn] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < (int)gridDim.z; ++z) {       // fixed order: bit-reproducible
+    for (int z = 0; z < p.gz; ++z) {       // fixed order: bit-reproducible
       const float *part = rec0 + (size_t)z * REC;
 #pragma unroll
       for (int rm = 0; rm < RM; ++rm)
@@ -287,11 +306,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
     }
     if (do_colsum && threadIdx.x < BM) {
       col_tot = 0.f;
-      for (int z = 0; z < (int)gridDim.z; ++z) col_tot += ws_load(rec0 + (size_t)z * REC + BM * BN + threadIdx.x);
+      for (int z = 0; z < p.gz; ++z) col_tot += ws_load(rec0 + (size_t)z * REC + BM * BN + threadIdx.x);
     }
   }
   // single writer per column from here on (one split, or the last arriver of the ordered path)
-  if (do_colsum && threadIdx.x < BM && (ordered || gridDim.z == 1) && m0 + (int)threadIdx.x < M) {
+  if (do_colsum && threadIdx.x < BM && (ordered || p.gz == 1) && m0 + (int)threadIdx.x < M) {
     float *dst = a_colsum + m0 + threadIdx.x;
     *dst = (flags & 2) ? *dst + col_tot : col_tot;   // flags bit 1: accumulate onto db
   }
@@ -305,7 +324,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
   for (int rn = 0; rn < RN; ++rn) {
     const int col = n0 + wn * (16 * RN) + rn * 16 + i;
     if (col >= N) continue;
-    const float bv = (bias && (ordered || blockIdx.z == 0)) ? bias[col] : 0.f;
+    const float bv = (bias && (ordered || bz == 0)) ? bias[col] : 0.f;
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
@@ -314,7 +333,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
         if (row >= M) continue;
         float v = acc[rm][rn][r] + bv;
         const size_t o = (size_t)row * ldc + col;
-        if (gridDim.z > 1 && !ordered) {   // C was zeroed (beta == 0) or holds the value to add to
+        if (p.gz > 1 && !ordered) {   // C was zeroed (beta == 0) or holds the value to add to
           atomicAdd(C + o, v);
           continue;
         }
@@ -326,6 +345,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K,
         if (drop) v = msr3d::keep_elem(sd, salt, (unsigned)o, thresh) ? v * dscale : 0.f;
         C[o] = v;
       }
+  }
+}
+
+template <bool A_KC, bool B_KC, int RM, int RN>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
+  gemm_body<A_KC, B_KC, RM, RN>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Both backward products of a linear layer in ONE launch: dx = dy W (first p1's workgroups) and
+// dW += dy^T x, db += colsum(dy) (then p2's).  They are independent, each too small to fill the
+// chip, and every launch inside the captured graph costs ~5 us whatever it does.
+__global__ __launch_bounds__(256) void gemm_linear_bwd_kernel(const GemmP p1, const GemmP p2) {
+  int id = blockIdx.x;
+  const int n1 = p1.gx * p1.gy * p1.gz;
+  if (id < n1) {
+    gemm_body<true, false, 2, 2>(p1, id % p1.gx, (id / p1.gx) % p1.gy, id / (p1.gx * p1.gy));
+  } else {
+    id -= n1;
+    gemm_body<false, false, 2, 2>(p2, id % p2.gx, (id / p2.gx) % p2.gy, id / (p2.gx * p2.gy));
   }
 }
 
@@ -383,11 +421,7 @@ inline bool vec_ok(const float *p, int ld) {
 }
 
 template <bool AK, bool BKc, int RM, int RN>
-static hipError_t launch_gemm(dim3 grid, hipStream_t st, int M, int N, int K, const float *A,
-                              int lda, const float *B, int ldb, float *C, int ldc,
-                              const float *bias, float *C_pre, int flags, float beta, int av, int bv,
-                              int per, float *a_colsum, float *ws_part, int *ws_count, float p_drop,
-                              const unsigned long long *seed, unsigned salt) {
+static hipError_t launch_gemm(const GemmP &p, hipStream_t st) {
   constexpr size_t lds = sizeof(float) * 2 * (tile_floats(32 * RM) + tile_floats(32 * RN));
   auto kern = gemm_f32_kernel<AK, BKc, RM, RN>;
   if (lds > 64 * 1024) {
@@ -399,30 +433,33 @@ static hipError_t launch_gemm(dim3 grid, hipStream_t st, int M, int N, int K, co
       done = true;
     }
   }
-  kern<<<grid, 256, lds, st>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags, beta, av, bv, per,
-                               a_colsum, ws_part, ws_count, p_drop, seed, salt);
+  kern<<<dim3(p.gx, p.gy, p.gz), 256, lds, st>>>(p);
   return hipGetLastError();
 }
 
-static int gemm_f32_impl(int a_kc, int b_kc, int M, int N, int K, const float *A, int lda,
-                         const float *B, int ldb, float *C, int ldc, const float *bias,
-                         float *C_pre, int flags, float beta, float *a_colsum, void *workspace,
-                         size_t workspace_bytes, float p_drop, const unsigned long long *seed,
-                         unsigned salt, msr3d_stream_t stream) {
+// Sizes one problem: tile shape, K-splits, meeting point, and the zero-fill the atomic meeting
+// point needs (issued here).  Returns 0, MSR3D_EINVAL or a hipError_t; *empty = nothing to launch.
+static int plan_gemm(int a_kc, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+                     float *C, int ldc, const float *bias, float *C_pre, int flags, float beta,
+                     float *a_colsum, void *workspace, size_t workspace_bytes, float p_drop,
+                     const unsigned long long *seed, unsigned salt, bool allow_big_tiles,
+                     hipStream_t st, GemmP *out, int *rm_out, int *rn_out, bool *empty) {
+  *empty = true;
   if (M < 0 || N < 0 || K < 0 || lda <= 0 || ldb <= 0 || ldc <= 0) return MSR3D_EINVAL;
   if (M == 0 || N == 0) return 0;
   if (!A || !B || !C) return MSR3D_EINVAL;
+  *empty = false;
   // Tile choice.  Measured on the path's shapes (tools/bench_gemm.py, tools/ablate_gemm.py): the
   // staging path sustains ~10 B/clk/CU, so a 64x64 tile (16 FLOP/B) is load-bound at ~60 TFLOP/s
   // in steady state; 128-wide tiles halve the traffic but these problems (M = 960 tokens, 0.1-2
   // GFLOP) then have too few workgroups to cover the load latency and time WORSE (ffn1 forward
-  // 27 -> 51 us).  So: 64x64 everywhere, split-K only when there are fewer than 256 tiles.  The
+  // 27 -> 51 us).  So: 64x64 everywhere, split-K only when there are at most 256 tiles.  The
   // larger tiles stay selectable (MSR3D_GEMM_BIG_TILES=1) for bigger batches.
   auto ntiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
   int rm = 2, rn = 2;
   constexpr int target_wgs = 512;
   static const int big_tiles = getenv("MSR3D_GEMM_BIG_TILES") ? atoi(getenv("MSR3D_GEMM_BIG_TILES")) : 0;
-  if (big_tiles) {
+  if (big_tiles && allow_big_tiles) {
     if (ntiles(128, 128) >= 192) { rm = 4; rn = 4; }
     else if (N >= M && ntiles(64, 128) >= 192) { rm = 2; rn = 4; }
     else if (ntiles(128, 64) >= 192) { rm = 4; rn = 2; }
@@ -431,8 +468,8 @@ static int gemm_f32_impl(int a_kc, int b_kc, int M, int N, int K, const float *A
   const int BM = 32 * rm, BN = 32 * rn;
   const int tiles = ntiles(BM, BN);
   const int slabs = (K + BK - 1) / BK;
-  // Split K until ~2 workgroups per CU exist, keeping >= 2 slabs per split.  The fused GELU
-  // needs the complete sum, and beta must be 0 or 1 for the atomic meeting point.
+  // Split K until ~2 workgroups per CU exist, keeping >= 2 slabs per split; beta must be 0 or 1
+  // for the atomic meeting point.
   int splits = 1;
   // (measured in the full step: requiring >= 9 / 17 / 33 slabs before splitting costs 1 / 2 / 16 %)
   if ((beta == 0.f || beta == 1.f) && tiles <= 256 && slabs >= 4) {
@@ -466,7 +503,6 @@ static int gemm_f32_impl(int a_kc, int b_kc, int M, int N, int K, const float *A
   if (per < 1) per = 1;                             // K == 0: C = bias + beta * C
   splits = slabs > 0 ? (slabs + per - 1) / per : 1;
   if (splits == 1) ws_part = nullptr;
-  hipStream_t st = (hipStream_t)stream;
   if (a_colsum) {
     // dW + db in one launch.  beta == 0: C (M x N, dense) is immediately followed by the M
     // column sums; beta == 1: both destinations already hold the values to add to (e.g. slices of
@@ -489,24 +525,42 @@ static int gemm_f32_impl(int a_kc, int b_kc, int M, int N, int K, const float *A
     hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, st);
     if (e != hipSuccess) return (int)e;
   }
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits);
-  const int av = vec_ok(A, lda), bv = vec_ok(B, ldb);
+  GemmP g;
+  g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.bias = bias; g.Cpre = C_pre; g.flags = flags; g.beta = beta;
+  g.a_vec = vec_ok(A, lda); g.b_vec = vec_ok(B, ldb); g.slabs_per_split = per;
+  g.a_colsum = a_colsum; g.ws_part = ws_part; g.ws_count = ws_count;
+  g.p_drop = p_drop; g.seed = seed; g.salt = salt;
+  g.gx = (N + BN - 1) / BN; g.gy = (M + BM - 1) / BM; g.gz = splits;
+  *out = g; *rm_out = rm; *rn_out = rn;
+  return 0;
+}
+
+static int gemm_f32_impl(int a_kc, int b_kc, int M, int N, int K, const float *A, int lda,
+                         const float *B, int ldb, float *C, int ldc, const float *bias,
+                         float *C_pre, int flags, float beta, float *a_colsum, void *workspace,
+                         size_t workspace_bytes, float p_drop, const unsigned long long *seed,
+                         unsigned salt, msr3d_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GemmP g;
+  int rm, rn;
+  bool empty;
+  const int rc = plan_gemm(a_kc, M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags, beta, a_colsum,
+                           workspace, workspace_bytes, p_drop, seed, salt, true, st, &g, &rm, &rn, &empty);
+  if (rc != 0 || empty) return rc;
   hipError_t e = hipErrorInvalidValue;
-#define ARGS grid, st, M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags, beta, av, bv, per, a_colsum, \
-             ws_part, ws_count, p_drop, seed, salt
-#define PICK(AK, BKc)                                                       \
-  do {                                                                      \
-    if (rm == 2 && rn == 2) e = launch_gemm<AK, BKc, 2, 2>(ARGS);           \
-    else if (rm == 4 && rn == 2) e = launch_gemm<AK, BKc, 4, 2>(ARGS);      \
-    else if (rm == 2 && rn == 4) e = launch_gemm<AK, BKc, 2, 4>(ARGS);      \
-    else e = launch_gemm<AK, BKc, 4, 4>(ARGS);                              \
+#define PICK(AK, BKc)                                                     \
+  do {                                                                    \
+    if (rm == 2 && rn == 2) e = launch_gemm<AK, BKc, 2, 2>(g, st);        \
+    else if (rm == 4 && rn == 2) e = launch_gemm<AK, BKc, 4, 2>(g, st);   \
+    else if (rm == 2 && rn == 4) e = launch_gemm<AK, BKc, 2, 4>(g, st);   \
+    else e = launch_gemm<AK, BKc, 4, 4>(g, st);                           \
   } while (0)
   if (a_kc && b_kc) PICK(true, true);
   else if (a_kc && !b_kc) PICK(true, false);
   else if (!a_kc && !b_kc) PICK(false, false);
   else PICK(false, true);
 #undef PICK
-#undef ARGS
   return (int)e;
 }
 
@@ -537,6 +591,37 @@ int msr3d_linear_wgrad_acc_f32(int M_tokens, int N_out, int K_in, const float *d
   if (!dw) return MSR3D_EINVAL;
   return gemm_f32_impl(0, 0, N_out, K_in, M_tokens, dy, N_out, x, K_in, dw, K_in, nullptr,
                        nullptr, 0, 1.f, db, workspace, workspace_bytes, 0.f, nullptr, 0, stream);
+}
+
+int msr3d_linear_bwd_f32(int M_tokens, int N_out, int K_in, const float *dy, const float *x,
+                         const float *w, float *dx, float dx_beta, float *dw, float *db,
+                         void *workspace, size_t workspace_bytes, msr3d_stream_t stream) {
+  if (!dx || !dw) return MSR3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  // the two problems share the workspace: halves, each with its own counters
+  void *ws1 = nullptr, *ws2 = nullptr;
+  size_t wsb = 0;
+  if (workspace && workspace_bytes >= 2 * (sizeof(int) * MSR3D_GEMM_WS_COUNTERS + (1u << 20))) {
+    wsb = (workspace_bytes / 2) & ~(size_t)255;
+    ws1 = workspace;
+    ws2 = reinterpret_cast<char *>(workspace) + wsb;
+  }
+  GemmP p1, p2;
+  int rm, rn;
+  bool e1, e2;
+  // dx (M x K_in) = dy (M x N_out) W (N_out x K_in): reduction over N_out
+  int rc = plan_gemm(1, M_tokens, K_in, N_out, dy, N_out, w, K_in, dx, K_in, nullptr, nullptr, 0,
+                     dx_beta, nullptr, ws1, wsb, 0.f, nullptr, 0, false, st, &p1, &rm, &rn, &e1);
+  if (rc != 0) return rc;
+  // dW (N_out x K_in) += dy^T x, db += colsum(dy): reduction over tokens
+  rc = plan_gemm(0, N_out, K_in, M_tokens, dy, N_out, x, K_in, dw, K_in, nullptr, nullptr, 0, 1.f, db,
+                 ws2, wsb, 0.f, nullptr, 0, false, st, &p2, &rm, &rn, &e2);
+  if (rc != 0) return rc;
+  if (e1 || e2) return 0;                            // M_tokens, N_out or K_in is zero
+  constexpr size_t lds = sizeof(float) * 2 * (tile_floats(64) + tile_floats(64));
+  const int blocks = p1.gx * p1.gy * p1.gz + p2.gx * p2.gy * p2.gz;
+  gemm_linear_bwd_kernel<<<blocks, 256, lds, st>>>(p1, p2);
+  return (int)hipGetLastError();
 }
 
 int msr3d_colsum_f32(int M, int N, const float *X, int ldx, float *out, int accumulate,

@@ -13,7 +13,9 @@ glue autograd would insert disappears from the captured graph:
     GELU backward kernel: no mask tensor, no dropout / masked-scale kernels;
   * every dW/db goes straight into the flat gradient buffer of the data-parallel engine.
 
-Per layer this is 10 launches forward and 14 backward instead of 13 and 22.  Numerics are those of
+  * each linear's two backward products (dx, and dW/db) are one launch.
+
+Per layer this is 10 launches forward and 9 backward instead of 13 and 22.  Numerics are those of
 the modular path (same kernels, same order of floating-point operations inside them); the dropout
 masks differ only in which call site draws them.
 """
@@ -23,7 +25,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, hipops
-from .hipops import _gemm, _gelu_bwd, _next_salt, _p, seed_word
+from .hipops import _gemm, _gelu_bwd, _linear_bwd, _next_salt, _p, seed_word
 
 
 def _dal_fwd(a, r, ln, p, salt):
@@ -51,15 +53,6 @@ def _dal_bwd(dy, s, stats, ln, p, salt, da, dr, accumulate):
                                           int(accumulate), _p(ln.weight.grad), _p(ln.bias.grad),
                                           _lib.current_stream_ptr(dy.device))
     _lib.check(rc, "msr3d_dropout_add_ln_bwd")
-
-
-def _wgrad_acc(M, N, K, dy, x, dw, db):
-    lib = _lib.load()
-    wp, wb = hipops._ws_args(dy.device)
-    with torch.cuda.device(dy.device):
-        rc = lib.msr3d_linear_wgrad_acc_f32(M, N, K, _p(dy), _p(x), _p(dw), _p(db), wp, wb,
-                                            _lib.current_stream_ptr(dy.device))
-    _lib.check(rc, "msr3d_linear_wgrad_acc_f32")
 
 
 def _direct(dp, *params):
@@ -171,19 +164,20 @@ class _SpatialLayerFn(torch.autograd.Function):
 
         d_t, d_ffn = new(M, D), new(M, D)
         _dal_bwd(g, s3, st3, layer.norm2, p2, salts[2], d_ffn, d_t, False)
+        # each linear's dx and dW/db are one launch (msr3d_linear_bwd_f32)
         d_h = new(M, FF)
-        _gemm(True, False, M, FF, D, d_ffn, D, layer.linear2.weight, FF, d_h, FF)
-        _wgrad_acc(M, D, FF, d_ffn, h, layer.linear2.weight.grad, layer.linear2.bias.grad)
+        _linear_bwd(M, D, FF, d_ffn, h, layer.linear2.weight, d_h, 0.0,
+                    layer.linear2.weight.grad, layer.linear2.bias.grad)
         d_pre = _gelu_bwd(d_h, pre, p_ffn, salts[3])
-        _gemm(True, False, M, D, FF, d_pre, FF, layer.linear1.weight, D, d_t, D, beta=1.0)   # joins d_t
-        _wgrad_acc(M, FF, D, d_pre, t, layer.linear1.weight.grad, layer.linear1.bias.grad)
+        _linear_bwd(M, FF, D, d_pre, t, layer.linear1.weight, d_t, 1.0,                       # joins d_t
+                    layer.linear1.weight.grad, layer.linear1.bias.grad)
 
         d_x, d_a = new(M, D), new(M, D)
         _dal_bwd(d_t, s2, st2, layer.norm1, p1, salts[1], d_a, d_x, False)
         d_fc = new(M, D)
         _dal_bwd(d_a, s1, st1, sa.layer_norm, p_attn, salts[0], d_fc, d_x, True)             # joins d_x
-        _gemm(True, False, M, D, D, d_fc, D, sa.fc.weight, D, d_attn, D, beta=1.0)   # onto the zeros
-        _wgrad_acc(M, D, D, d_fc, attn, sa.fc.weight.grad, sa.fc.bias.grad)
+        _linear_bwd(M, D, D, d_fc, attn, sa.fc.weight, d_attn, 1.0,                           # onto the zeros
+                    sa.fc.weight.grad, sa.fc.bias.grad)
         d_qkvc = new(M, W)
         lib = _lib.load()
         base, gb, fs, vp = qkvc.data_ptr(), d_qkvc.data_ptr(), 4, ctypes.c_void_p
@@ -194,8 +188,7 @@ class _SpatialLayerFn(torch.autograd.Function):
                 vp(gb + D * fs), vp(gb + 2 * D * fs), W, vp(gb + 3 * D * fs), W,
                 _lib.current_stream_ptr(dev))
         _lib.check(rc, "msr3d_spatial_attn_bwd")
-        _gemm(True, False, M, D, W, d_qkvc, W, wv, D, d_x, D, beta=1.0)                      # joins d_x
-        _wgrad_acc(M, W, D, d_qkvc, x2, gwv, gbv)
+        _linear_bwd(M, W, D, d_qkvc, x2, wv, d_x, 1.0, gwv, gbv)                              # joins d_x
 
         for p in layer_params(layer):
             dp.mark_ready(p)

@@ -84,6 +84,16 @@ def _gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, bias=None, c_pre=None, fl
     _lib.check(rc, "msr3d_gemm_f32")
 
 
+def _linear_bwd(M, N, K, dy, x, w, dx, dx_beta, dw, db):
+    """dx (M,K) = dx_beta*dx + dy (M,N) @ w (N,K);  dw += dy^T x;  db += colsum(dy): one launch."""
+    lib = _lib.load()
+    wp, wb = _ws_args(dy.device)
+    with torch.cuda.device(dy.device):
+        rc = lib.msr3d_linear_bwd_f32(M, N, K, _p(dy), _p(x), _p(w), _p(dx), ctypes.c_float(dx_beta),
+                                      _p(dw), _p(db), wp, wb, _lib.current_stream_ptr(dy.device))
+    _lib.check(rc, "msr3d_linear_bwd_f32")
+
+
 def _gelu_bwd(dy2, pre, p_drop=0.0, salt=0):
     lib = _lib.load()
     g = torch.empty_like(dy2)
@@ -137,12 +147,23 @@ class _HipLinear(torch.autograd.Function):
         if pre is not None:
             dy2 = _gelu_bwd(dy2, pre)
         dx = dw = db = None
+        direct = ctx.direct is not None and ctx.needs_input_grad[1]
+        if direct and ctx.needs_input_grad[0]:
+            # dx, and dW (+ db) straight into the flat gradient buffer's views: ONE launch
+            dpw, wparam, bparam = ctx.direct
+            dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+            _linear_bwd(M, N, K, dy2, x2, w, dx, 0.0, wparam.grad,
+                        bparam.grad if bparam is not None else None)
+            dpw.mark_ready(wparam)
+            if bparam is not None:
+                dpw.mark_ready(bparam)
+            return dx.reshape(ctx.x_shape), None, None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
             _gemm(True, False, M, K, N, dy2, N, w, K, dx, K)          # dx = dy @ W
             dx = dx.reshape(ctx.x_shape)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.direct is not None and ctx.needs_input_grad[1]:
+        if direct:
             # accumulate dW (+ db) straight into the flat gradient buffer's views
             dpw, wparam, bparam = ctx.direct
             lib = _lib.load()
@@ -221,14 +242,15 @@ class _HipLinearPacked(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-            _gemm(True, False, M, K, N, dy2, N, wv, K, dx, K)
+            _linear_bwd(M, N, K, dy2, x2, wv, dx, 0.0, gwv, gbv)
             dx = dx.reshape(ctx.x_shape)
-        lib = _lib.load()
-        wp, wb = _ws_args(dy.device)
-        with torch.cuda.device(dy.device):
-            rc = lib.msr3d_linear_wgrad_acc_f32(M, N, K, _p(dy2), _p(x2), _p(gwv), _p(gbv), wp, wb,
-                                                _lib.current_stream_ptr(dy.device))
-        _lib.check(rc, "msr3d_linear_wgrad_acc_f32")
+        else:
+            lib = _lib.load()
+            wp, wb = _ws_args(dy.device)
+            with torch.cuda.device(dy.device):
+                rc = lib.msr3d_linear_wgrad_acc_f32(M, N, K, _p(dy2), _p(x2), _p(gwv), _p(gbv), wp, wb,
+                                                    _lib.current_stream_ptr(dy.device))
+            _lib.check(rc, "msr3d_linear_wgrad_acc_f32")
         for p in ctx.members:
             dp.mark_ready(p)
         return (dx, None) + (None,) * len(ctx.members)
