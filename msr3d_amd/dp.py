@@ -8,9 +8,9 @@ engine shaped for this model and for MI355X's point-to-point xGMI:
   * ONE flat fp32 gradient buffer; every trainable parameter's `.grad` is a view into it,
     laid out in reverse registration order (~ the order backward produces them), so a bucket
     is a contiguous slice and needs no copy in or out;
-  * buckets are all-reduced on a SIDE stream that waits on the producing stream's event;
-    by default all of them right after backward (`finish()`): the exchange is 21 MB, tens of
-    microseconds on xGMI against a ~3 ms step, and the step's forward/backward is replayed
+  * the exchange runs on a SIDE stream that waits on the producing stream; by default as ONE
+    all-reduce of the whole buffer right after backward (`finish()`): 21 MB is tens of
+    microseconds on xGMI against a ~2.6 ms step, and the step's forward/backward is replayed
     from a HIP graph, which must not contain host-driven collectives.  `overlap=True` launches
     each bucket from post-accumulate-grad hooks as soon as its last gradient exists, so
     communication overlaps the rest of backward (eager mode);
@@ -123,20 +123,25 @@ class FlatGradAllReduce:
         if self._ready[b] == self._bucket_size[b] and not self.defer_comm:
             self._launch(b)
 
+    def _reduce(self, view):
+        # SUM then scale: works on every backend (gloo has no AVG), one tiny launch
+        dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+        view.mul_(1.0 / self.world)
+
+    def _exchange(self, view):
+        if self.on_gpu:
+            self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.comm_stream):
+                self._reduce(view)
+        else:
+            self._reduce(view)
+
     def _launch(self, b):
         if self._launched[b] or self.world == 1:
             return
         self._launched[b] = True
         s, e = self.buckets[b]
-        view = self.flat[s:e]
-        if self.on_gpu:
-            self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-                view.mul_(1.0 / self.world)
-        else:
-            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-            view.mul_(1.0 / self.world)
+        self._exchange(self.flat[s:e])
 
     # ------------------------------------------------------------------ step API
     def zero_grad(self):
@@ -149,10 +154,15 @@ class FlatGradAllReduce:
         """Call after backward: flush buckets that never completed (unused params keep their
         zeros) and make the compute stream wait for the exchange."""
         if self.world > 1:
-            if self.defer_comm:                     # hooks ran under capture: nothing is in flight
-                self._launched = [False] * len(self.buckets)
-            for b in range(len(self.buckets)):
-                self._launch(b)
+            if self.defer_comm:
+                # nothing is in flight and nothing is left to overlap with: ONE collective over the
+                # whole buffer (21 MB) instead of one per bucket -- fewer launches, and a ring over
+                # point-to-point xGMI links is latency-bound per call at this size
+                self._exchange(self.flat[:self.numel])
+                self._launched = [True] * len(self.buckets)
+            else:
+                for b in range(len(self.buckets)):
+                    self._launch(b)
             if self.on_gpu:
                 torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
 
