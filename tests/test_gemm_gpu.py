@@ -15,7 +15,7 @@ SHAPES = [  # (M, K, N)
 
 
 def rel(a, b):
-    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    return float((a.detach().double() - b.detach().double()).norm() / b.detach().double().norm().clamp_min(1e-30))
 
 
 @pytest.mark.parametrize("M,K,N", SHAPES)
