@@ -274,6 +274,18 @@ int msr3d_scene_scatter(int B, int T, int n_scene, int E, const long long *input
                         long long *attention_mask, int *map_ws, int *count_out,
                         msr3d_stream_t stream);
 
+/* The same hand-off with the projector fused in: for the k-th placeholder
+ * inputs_embeds[pos_k] = cast(tokens[k] . weight^T + bias), tokens (n_scene, K) f32 (obj_tokens),
+ * weight (E, K) / bias (E) f32 = llm_proj (/root/reference/model/msr3d/msr3d.py:84-86,277); the
+ * fp32 (n_scene, E) projector output is never written.  The product runs on bf16 MFMA with fp32
+ * accumulation (operands rounded to bf16 on the way in): use it where the result is consumed in
+ * a 16-bit embedding dtype.  E % 128 == 0, K % 32 == 0, 16-byte aligned pointers. */
+int msr3d_project_scatter_bf16(int B, int T, int n_scene, int E, int K, const long long *input_ids,
+                               long long scene_token, const float *tokens, const float *weight,
+                               const float *bias, const unsigned char *scene_mask, int out_dtype,
+                               void *inputs_embeds, long long *attention_mask, int *map_ws,
+                               int *count_out, msr3d_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Optimiser step of the hot path: global-norm clip + AdamW over flat buffers
  * (/root/reference/optim/build.py:7-17, trainer/leo_trainer.py:189-195,

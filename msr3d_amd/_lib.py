@@ -50,6 +50,8 @@ _SIGNATURES = {
     "msr3d_bump_seed": [_ptr, _ptr],
     "msr3d_scene_scatter": [_c_int, _c_int, _c_int, _c_int, _ptr, ctypes.c_longlong, _ptr, _ptr, _c_int,
                             _ptr, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_project_scatter_bf16": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, ctypes.c_longlong, _ptr, _ptr,
+                                   _ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_adamw_flat": [ctypes.c_longlong, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_float,
                          _c_float, _c_float, _c_float, _c_float, _c_int, _c_int, _c_int, _c_int, _ptr],
     "msr3d_sa_fps2": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],

@@ -70,6 +70,42 @@ def scatter_scene_embeds_(inputs_embeds, attention_mask, input_ids, scene_embeds
     return cnt
 
 
+def project_and_scatter_(inputs_embeds, attention_mask, input_ids, obj_tokens, llm_proj, scene_mask,
+                         scene_sp_token=SCENE_SP_TOKEN):
+    """`llm_proj` + cast + scatter in ONE kernel (msr3d_project_scatter_bf16):
+    inputs_embeds[placeholder k] = cast(obj_tokens[k] @ W^T + b), attention_mask likewise; the fp32
+    (B*L, E) projector output of msr3d.py:277 is never written.  bf16 MFMA with fp32 accumulation,
+    for 16-bit `inputs_embeds` (the LLM's dtype); inference / generation path -- no autograd.
+    obj_tokens (B,L,K) f32, llm_proj an nn.Linear(K, E).  Returns the device placeholder count."""
+    import ctypes
+
+    from .. import _lib
+    B, T = input_ids.shape
+    n, K = obj_tokens.shape[0] * obj_tokens.shape[1], obj_tokens.shape[-1]
+    E = llm_proj.out_features
+    if not (inputs_embeds.is_cuda and inputs_embeds.is_contiguous() and input_ids.dtype == torch.int64):
+        raise RuntimeError("project_and_scatter_: contiguous GPU tensors and int64 ids expected")
+    if attention_mask is not None and (attention_mask.dtype != torch.int64 or not attention_mask.is_contiguous()):
+        raise RuntimeError("attention_mask must be contiguous int64")
+    if E % 128 or K % 32 or llm_proj.weight.dtype != torch.float32:
+        raise RuntimeError("project_and_scatter_: E % 128 == 0, K % 32 == 0 and fp32 llm_proj expected")
+    tok = obj_tokens.detach().reshape(n, K).float().contiguous()
+    w = llm_proj.weight.detach().contiguous()
+    b = llm_proj.bias.detach().contiguous() if llm_proj.bias is not None else None
+    msk = scene_mask.reshape(n).contiguous().view(torch.uint8) if scene_mask is not None else None
+    ws = torch.empty(n, dtype=torch.int32, device=input_ids.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=input_ids.device)
+    p = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else 0)   # noqa: E731
+    lib = _lib.load()
+    with torch.cuda.device(input_ids.device):
+        rc = lib.msr3d_project_scatter_bf16(B, T, n, E, K, p(input_ids.contiguous()), int(scene_sp_token),
+                                            p(tok), p(w), p(b), p(msk), _DTYPE_CODE[inputs_embeds.dtype],
+                                            p(inputs_embeds), p(attention_mask), p(ws), p(cnt),
+                                            _lib.current_stream_ptr(input_ids.device))
+    _lib.check(rc, "msr3d_project_scatter_bf16")
+    return cnt
+
+
 @MODEL_REGISTRY.register()
 class MSR3DHotPath(nn.Module):
     """visual_prompter (OSE3DSituation) + llm_proj: the trainable, LLM-independent part of

@@ -55,3 +55,39 @@ def test_scatter_reports_wrong_placeholder_count_without_writing_out_of_range():
     cnt = scatter_scene_embeds_(emb, None, ids, scene, None)
     assert int(cnt.item()) == 6
     assert emb[0, :6].eq(1).all() and emb[0, 6:].eq(0).all() and emb[1].eq(0).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("B,T,L,K,E", [(16, 256, 60, 256, 4096), (3, 400, 61, 256, 5120), (2, 90, 7, 64, 128)])
+def test_fused_project_and_scatter(dtype, B, T, L, K, E):
+    """msr3d_project_scatter_bf16 == reference statements applied to a projector evaluated on
+    bf16-rounded operands with exact accumulation (the kernel's arithmetic: bf16 MFMA, fp32
+    accumulate): tolerance 1e-5 relative before the cast, i.e. at most one unit of the output dtype
+    after it; against the full-fp32 projector the bf16 rounding of the operands shows: 1e-2."""
+    from msr3d_amd.model.scene_embeds import project_and_scatter_
+    torch.manual_seed(B + T + E)
+    ids = torch.randint(0, 30000, (B, T), device="cuda")
+    for b in range(B):
+        ids[b, torch.randperm(T, device="cuda")[:L]] = TOKEN
+    proj = torch.nn.Linear(K, E).cuda()
+    tokens = torch.randn(B, L, K, device="cuda")               # obj_tokens are LayerNorm outputs: O(1)
+    smask = torch.rand(B, L, device="cuda") > 0.3
+    emb = torch.randn(B, T, E, device="cuda").to(dtype)
+    am = torch.ones(B, T, dtype=torch.int64, device="cuda")
+
+    tb, wb = tokens.bfloat16().double(), proj.weight.detach().bfloat16().double()
+    exact = (tb @ wb.T + proj.bias.detach().double()).float()
+    want_e, want_m = reference_statements(emb, am, ids, exact, smask)
+    got_e, got_m = emb.clone(), am.clone()
+    cnt = project_and_scatter_(got_e, got_m, ids, tokens, proj, smask)
+    assert int(cnt.item()) == B * L
+    assert torch.equal(got_m.bool(), want_m)
+    hit = ids == TOKEN
+    assert torch.equal(got_e[~hit], emb[~hit])                  # nothing else is touched
+    g, w = got_e[hit].double(), want_e[hit].double()
+    ulp = {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10, torch.float32: 1e-5}[dtype]   # spacing / |w|
+    assert ((g - w).abs() <= ulp * w.abs().clamp_min(1e-2) * 1.01 + 1e-6).all()
+    if dtype != torch.float32:
+        assert (g != w).double().mean() < 0.02                  # rounding-boundary cases only
+    full, _ = reference_statements(emb, am, ids, proj(tokens).detach(), smask)
+    assert float((g - full[hit].double()).norm() / full[hit].double().norm()) < 1e-2
