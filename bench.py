@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="scenes per GPU per step "
                     "(global 128 on 8 GPUs = configs/msr3d_3_dataset.yaml DDP shape)")
     ap.add_argument("--llm-hidden", type=int, default=4096, help="Vicuna-7B hidden size")
+    ap.add_argument("--objects", type=int, default=60, help="objects per scene (120: BASELINE stress config)")
+    ap.add_argument("--points", type=int, default=1024, help="points per object (2048: stress config)")
     ap.add_argument("--situation-type", default="as_transform_for_objects")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -95,23 +97,22 @@ class Trainer:
             hipops.attach_packed_views(model, self.dp, self.opt)
         else:
             self.opt = torch.optim.AdamW(params, lr=3e-5, betas=(0.9, 0.999), weight_decay=0.05)
-        B, L = example_batch["obj_masks"].shape
-        g = torch.Generator(device="cpu").manual_seed(99)
-        loss_w = torch.randn((B, L, E), generator=g).to(device)
-        inv_n = 1.0 / loss_w.numel()
-
-        loss_g = loss_w * inv_n
+        state = {}
 
         def loss_fn(out):
             # synthetic scalar loss on the projector output, L = mean(scene_embeds * w); its gradient
             # dL/dscene = w / n is handed to backward directly, the way the language model's
             # backward would deliver it (value and gradient identical to autograd's on `L`)
             y = out["scene_embeds"]
+            if "w" not in state:                  # first (eager warm-up) call: the output shape is known
+                g = torch.Generator(device="cpu").manual_seed(99)
+                state["w"] = torch.randn(tuple(y.shape), generator=g).to(y.device)
+                state["g"] = state["w"] / y.numel()
             if not y.is_cuda:
-                return (y * loss_w).sum() * inv_n
+                return (y * state["w"]).sum() / y.numel()
             with torch.no_grad():
-                loss = torch.dot(y.reshape(-1), loss_g.reshape(-1))
-            return loss, y, loss_g
+                loss = torch.dot(y.reshape(-1), state["g"].reshape(-1))
+            return loss, y, state["g"]
 
         self.stepper = HotPathTrainStep(model, self.opt, self.dp, loss_fn, example_batch,
                                         use_graph=use_graph)
@@ -154,7 +155,9 @@ def cpu_baseline(args, seconds):
 
 
 def main():
+    global O, P
     args = parse()
+    O, P = args.objects, args.points
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -259,7 +262,7 @@ def main():
         alg_flop = B * O * flop_per_obj
         achieved = alg_flop / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         line = {
-            "metric": "MSQA train samples/sec (whole node), 60 obj x 1024 pts",
+            "metric": f"MSQA train samples/sec (whole node), {O} obj x {P} pts",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
