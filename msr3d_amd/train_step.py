@@ -117,7 +117,9 @@ class HotPathTrainStep:
         self.split = self.dp.world > 1
         if self.split:
             self.dp.defer_comm = True
-        with torch.cuda.graph(self.graph):
+        # thread_local: other threads (RCCL's watchdog polling its events, loader threads) may keep
+        # calling the HIP runtime while this thread captures
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss = self._fwd_bwd() if self.split else self._train_part()
 
     def __call__(self, batch, next_batch=None):
