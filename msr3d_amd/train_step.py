@@ -23,10 +23,15 @@ from . import hipops
 
 
 class HotPathTrainStep:
-    def __init__(self, model, optimizer, dp, loss_fn, example_batch, use_graph=True):
+    def __init__(self, model, optimizer, dp, loss_fn, example_batch, use_graph=True, accum_steps=1):
         """model: MSR3DHotPath; dp: FlatGradAllReduce over its trainable params;
         loss_fn(scene_dict) -> scalar, or (scalar, tensor, d scalar / d tensor) when the caller
-        already holds the upstream gradient; example_batch fixes the (static) shapes."""
+        already holds the upstream gradient; example_batch fixes the (static) shapes.
+        accum_steps: gradient accumulation as the reference trains (`gradient_accumulation_steps: 5`,
+        configs/msr3d.yaml:33; accelerate scales each micro-batch loss by 1/accum_steps and
+        synchronises / steps on the last one, trainer/leo_trainer.py:180-195): every call is one
+        micro-batch; gradients add up in the flat buffer, the exchange, clip and AdamW run on every
+        accum_steps-th call."""
         self.model, self.opt, self.dp, self.loss_fn = model, optimizer, dp, loss_fn
         self.prompter = model.visual_prompter
         self.use_graph = use_graph and example_batch["obj_fts"].is_cuda
@@ -38,25 +43,31 @@ class HotPathTrainStep:
         self.loss = None
         self.graph = None
         self.split = False
+        self.accum_steps = int(accum_steps)
+        if self.accum_steps < 1:
+            raise ValueError("accum_steps must be >= 1")
+        self._micro = 0
         # encoder prefetch (software pipelining over steps)
         self._enc_stream = torch.cuda.Stream() if self.static["obj_embeds"].is_cuda else None
         self._pref = {"key": None, "feats": torch.empty_like(self.static["obj_embeds"]), "event": None}
 
     # ---- the trainable part, on static buffers -------------------------------------
-    def _fwd_bwd(self):
+    def _fwd_bwd(self, zero=True):
         if self.static["obj_embeds"].is_cuda:
             hipops.bump_seed(self.static["obj_embeds"].device)   # fresh dropout masks per replay
-        self.dp.zero_grad()
+        if zero:
+            self.dp.zero_grad()
         out = self.model(dict(self.static))
         res = self.loss_fn(out)
+        scale = 1.0 / self.accum_steps
         if isinstance(res, tuple):
             # (loss value, tensor, upstream gradient): how the path is driven in the real model --
             # the gradient of `scene_embeds` arrives from the language model's backward
             loss, y, gy = res
-            torch.autograd.backward([y], [gy])
+            torch.autograd.backward([y], [gy if self.accum_steps == 1 else gy * scale])
         else:
             loss = res
-            loss.backward()
+            (loss if self.accum_steps == 1 else loss * scale).backward()
         return loss.detach()
 
     def _update(self):
@@ -70,6 +81,18 @@ class HotPathTrainStep:
     def _train_part(self):
         loss = self._fwd_bwd()
         self._update()
+        return loss
+
+    def _micro_step(self, run):
+        """Split schedule: zero the gradients before the first micro-batch, `run` forward/backward
+        (eagerly or by graph replay), exchange + optimiser after the last one."""
+        if self._micro == 0:
+            self.dp.zero_grad()
+        loss = run()
+        self._micro += 1
+        if self._micro == self.accum_steps:
+            self._micro = 0
+            self._update()
         return loss
 
     def prefetch(self, batch):
@@ -104,9 +127,12 @@ class HotPathTrainStep:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for _ in range(warmup):
+            for _ in range(warmup * self.accum_steps):
                 self._load(batch)
-                self._train_part()
+                if self.accum_steps > 1:
+                    self._micro_step(lambda: self._fwd_bwd(zero=False))
+                else:
+                    self._train_part()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
@@ -114,13 +140,14 @@ class HotPathTrainStep:
         # world > 1: the gradient exchange stays OUTSIDE the graph (RCCL calls are issued eagerly
         # between the captured forward/backward and the 3-launch optimiser) -- a handful of host
         # launches per step, and no dependence on collective capture support.
-        self.split = self.dp.world > 1
+        # Gradient accumulation likewise: the graph holds one micro-batch's forward/backward.
+        self.split = self.dp.world > 1 or self.accum_steps > 1
         if self.split:
             self.dp.defer_comm = True
         # thread_local: other threads (RCCL's watchdog polling its events, loader threads) may keep
         # calling the HIP runtime while this thread captures
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.loss = self._fwd_bwd() if self.split else self._train_part()
+            self.loss = self._fwd_bwd(zero=False) if self.split else self._train_part()
 
     def __call__(self, batch, next_batch=None):
         """One training step on `batch`; if `next_batch` is given its encoder pass is started on
@@ -129,9 +156,12 @@ class HotPathTrainStep:
         if next_batch is not None:
             self.prefetch(next_batch)
         if self.graph is not None:
-            self.graph.replay()
             if self.split:
-                self._update()
+                return self._micro_step(lambda: (self.graph.replay(), self.loss)[1])
+            self.graph.replay()
             return self.loss
-        self.loss = self._train_part()
+        if self.accum_steps > 1:
+            self.loss = self._micro_step(lambda: self._fwd_bwd(zero=False))
+        else:
+            self.loss = self._train_part()
         return self.loss
