@@ -58,8 +58,6 @@ def parse():
                     "device from HBM-resident scans (msr3d_amd.data: object selection, rotation, "
                     "subsample, normalise, padding) inside the timed region; default: batches "
                     "already resident, as the metric is defined")
-    ap.add_argument("--accum", type=int, default=1, help="gradient accumulation steps (the reference "
-                    "trains with 5 micro-batches of 4 per GPU); a bench step stays one micro-batch")
     ap.add_argument("--no-graph", action="store_true", help="issue the trainable part eagerly "
                     "instead of replaying the captured HIP graph")
     ap.add_argument("--cpu-threads", type=int, default=32, help="threads of the CPU baseline leg "
