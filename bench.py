@@ -189,7 +189,10 @@ def main():
     # side stream while batch k trains.  Every timed step still encodes exactly one batch and
     # trains exactly one batch; the first timed batch's features come from the last warm-up step,
     # the last timed step encodes the batch that would follow.
-    pipe = args.pipeline
+    # With several ranks the next batch is ALWAYS handed to the step: its frozen encoder is then
+    # issued on the compute stream between the start of the gradient all-reduce and the optimiser,
+    # which hides the exchange (msr3d_amd/train_step.py) -- no side stream, kernels do not share CUs.
+    pipe = args.pipeline or world > 1
 
     def nxt(i):
         return batches[(i + 1) % n_resident] if pipe else None
@@ -272,6 +275,7 @@ def main():
                        "llm_hidden": args.llm_hidden, "situation_type": args.situation_type,
                        "step": "fwd+bwd+allreduce+clip+AdamW, LLM excluded",
                        "hip_graph": not args.no_graph, "encoder_prefetch": args.pipeline,
+                       "allreduce_hidden_behind_next_encoder": world > 1,
                        "inputs": ("built per step on the device from HBM-resident scans "
                                   "(msr3d_preprocess_pcd)" if args.from_store else "resident in HBM"),
                        "parallelism": f"dp{world}"},

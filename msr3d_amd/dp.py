@@ -153,6 +153,18 @@ class FlatGradAllReduce:
     def finish(self):
         """Call after backward: flush buckets that never completed (unused params keep their
         zeros) and make the compute stream wait for the exchange."""
+        self.start()
+        self.wait()
+
+    def wait(self):
+        """The compute stream waits for the exchange started by start()."""
+        if self.world > 1 and self.on_gpu:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+
+    def start(self):
+        """Launch the exchange on the communication stream and return: work that does not touch
+        the gradients (the next batch's frozen encoder) can be enqueued on the compute stream
+        before wait()."""
         if self.world > 1:
             if self.defer_comm:
                 # nothing is in flight and nothing is left to overlap with: ONE collective over the
@@ -163,8 +175,6 @@ class FlatGradAllReduce:
             else:
                 for b in range(len(self.buckets)):
                     self._launch(b)
-            if self.on_gpu:
-                torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
 
     def grad_norm(self):
         return torch.linalg.vector_norm(self.flat)
