@@ -254,6 +254,24 @@ int msr3d_dropout_add_ln_bwd(int M, int D, const float *dy, const float *s, cons
                              unsigned salt, float *da, float *dr, int dr_accumulate,
                              float *dgamma_acc, float *dbeta_acc, msr3d_stream_t stream);
 
+/* Two chained tails sharing one residual, t = LN2(drop2(LN1(drop1(a) + r)) + r): the attention
+ * block's residual + LayerNorm followed by the encoder layer's first one
+ * (/root/reference/modules/layers/transformers.py:250-251 then :324-325), one launch each way.
+ * s1 / stats1 and s2 / stats2 are the pre-norm sums and {mean, rstd} of the two LayerNorms; the
+ * backward writes da and dr (the residual's total gradient) and accumulates both LayerNorms'
+ * dgamma / dbeta.  D in {256, 512}. */
+int msr3d_dropout_add_ln2_fwd(int M, int D, const float *a, const float *r, const float *gamma1,
+                              const float *beta1, float eps1, float p1, unsigned salt1,
+                              const float *gamma2, const float *beta2, float eps2, float p2,
+                              unsigned salt2, const unsigned long long *seed, float *y, float *s1,
+                              float *stats1, float *s2, float *stats2, msr3d_stream_t stream);
+int msr3d_dropout_add_ln2_bwd(int M, int D, const float *dy, const float *s1, const float *stats1,
+                              const float *gamma1, float p1, unsigned salt1, const float *s2,
+                              const float *stats2, const float *gamma2, float p2, unsigned salt2,
+                              const unsigned long long *seed, float *da, float *dr,
+                              float *dgamma1_acc, float *dbeta1_acc, float *dgamma2_acc,
+                              float *dbeta2_acc, msr3d_stream_t stream);
+
 /* Advance the device-resident dropout seed word (once per training step, inside the graph). */
 int msr3d_bump_seed(unsigned long long *seed, msr3d_stream_t stream);
 

@@ -177,6 +177,190 @@ __global__ __launch_bounds__(256) void dal_bwd_kernel(int M, int rows_per_block,
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Two chained tails in one launch: t = LN2( drop2( LN1( drop1(a) + r ) ) + r ) -- the attention
+// block's own residual + LayerNorm followed by the encoder layer's first one, which adds the SAME
+// residual again (/root/reference/modules/layers/transformers.py:250-251 then :324-325).  Row-local,
+// so forward and backward each need one pass over the row instead of two launches.
+// ---------------------------------------------------------------------------------------
+template <int VPL>
+__device__ __forceinline__ void row_dropout(float4 (&v)[VPL], bool drop, unsigned long long sd,
+                                            unsigned salt, unsigned thresh, float scale, int row,
+                                            int lane) {
+  if (!drop) return;
+  constexpr int D = 256 * VPL;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const unsigned base = (unsigned)row * D + (j * 64 + lane) * 4;
+    v[j].x = keep_elem(sd, salt, base + 0, thresh) ? v[j].x * scale : 0.f;
+    v[j].y = keep_elem(sd, salt, base + 1, thresh) ? v[j].y * scale : 0.f;
+    v[j].z = keep_elem(sd, salt, base + 2, thresh) ? v[j].z * scale : 0.f;
+    v[j].w = keep_elem(sd, salt, base + 3, thresh) ? v[j].w * scale : 0.f;
+  }
+}
+
+// v (the pre-norm sum, kept) -> y = LN(v) * gamma + beta; returns mean / rstd
+template <int VPL>
+__device__ __forceinline__ void row_layernorm(const float4 (&v)[VPL], const float *__restrict__ gamma,
+                                              const float *__restrict__ beta, float eps, int lane,
+                                              float4 (&y)[VPL], float &mean, float &rstd) {
+  constexpr int D = 256 * VPL;
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  mean = wave_sum(sum) * (1.0f / D);
+  float var = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const float dx = v[j].x - mean, dy = v[j].y - mean, dz = v[j].z - mean, dw = v[j].w - mean;
+    var += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+  }
+  rstd = rsqrtf(wave_sum(var) * (1.0f / D) + eps);
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    const float4 g = *reinterpret_cast<const float4 *>(gamma + c);
+    const float4 b = *reinterpret_cast<const float4 *>(beta + c);
+    y[j].x = (v[j].x - mean) * rstd * g.x + b.x;
+    y[j].y = (v[j].y - mean) * rstd * g.y + b.y;
+    y[j].z = (v[j].z - mean) * rstd * g.z + b.z;
+    y[j].w = (v[j].w - mean) * rstd * g.w + b.w;
+  }
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void dal2_fwd_kernel(
+    int M, const float *__restrict__ a, const float *__restrict__ r, const float *__restrict__ g1,
+    const float *__restrict__ b1, float eps1, float p1, unsigned salt1, const float *__restrict__ g2,
+    const float *__restrict__ b2, float eps2, float p2, unsigned salt2,
+    const unsigned long long *__restrict__ seed, float *__restrict__ y, float *__restrict__ s1_out,
+    float *__restrict__ stats1, float *__restrict__ s2_out, float *__restrict__ stats2) {
+  constexpr int D = 256 * VPL;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const unsigned long long sd = (p1 > 0.f || p2 > 0.f) ? *seed : 0ull;
+  float4 v[VPL], res[VPL], mid[VPL], out[VPL];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    v[j] = *reinterpret_cast<const float4 *>(a + (size_t)row * D + c);
+    res[j] = *reinterpret_cast<const float4 *>(r + (size_t)row * D + c);
+  }
+  row_dropout<VPL>(v, p1 > 0.f, sd, salt1, msr3d::drop_thresh(p1), p1 > 0.f ? 1.0f / (1.0f - p1) : 1.0f, row, lane);
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) { v[j].x += res[j].x; v[j].y += res[j].y; v[j].z += res[j].z; v[j].w += res[j].w; }
+  float mean, rstd;
+  row_layernorm<VPL>(v, g1, b1, eps1, lane, mid, mean, rstd);
+#pragma unroll
+  for (int j = 0; j < VPL; ++j)
+    *reinterpret_cast<float4 *>(s1_out + (size_t)row * D + (j * 64 + lane) * 4) = v[j];
+  if (lane == 0) { stats1[row * 2 + 0] = mean; stats1[row * 2 + 1] = rstd; }
+  row_dropout<VPL>(mid, p2 > 0.f, sd, salt2, msr3d::drop_thresh(p2), p2 > 0.f ? 1.0f / (1.0f - p2) : 1.0f, row, lane);
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) { mid[j].x += res[j].x; mid[j].y += res[j].y; mid[j].z += res[j].z; mid[j].w += res[j].w; }
+  row_layernorm<VPL>(mid, g2, b2, eps2, lane, out, mean, rstd);
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    *reinterpret_cast<float4 *>(s2_out + (size_t)row * D + c) = mid[j];
+    *reinterpret_cast<float4 *>(y + (size_t)row * D + c) = out[j];
+  }
+  if (lane == 0) { stats2[row * 2 + 0] = mean; stats2[row * 2 + 1] = rstd; }
+}
+
+// dx of one LayerNorm row; accumulates this row's dgamma / dbeta contributions
+template <int VPL>
+__device__ __forceinline__ void row_layernorm_bwd(const float4 (&d)[VPL], const float *__restrict__ s,
+                                                  float mean, float rstd, const float4 (&gg)[VPL],
+                                                  int row, int lane, float4 (&dx)[VPL],
+                                                  float4 (&accg)[VPL], float4 (&accb)[VPL]) {
+  constexpr int D = 256 * VPL;
+  float4 xh[VPL], g[VPL];
+  float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const float4 sv = *reinterpret_cast<const float4 *>(s + (size_t)row * D + (j * 64 + lane) * 4);
+    xh[j].x = (sv.x - mean) * rstd; xh[j].y = (sv.y - mean) * rstd;
+    xh[j].z = (sv.z - mean) * rstd; xh[j].w = (sv.w - mean) * rstd;
+    g[j].x = d[j].x * gg[j].x; g[j].y = d[j].y * gg[j].y; g[j].z = d[j].z * gg[j].z; g[j].w = d[j].w * gg[j].w;
+    c1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+    c2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
+    accg[j].x += d[j].x * xh[j].x; accg[j].y += d[j].y * xh[j].y;
+    accg[j].z += d[j].z * xh[j].z; accg[j].w += d[j].w * xh[j].w;
+    accb[j].x += d[j].x; accb[j].y += d[j].y; accb[j].z += d[j].z; accb[j].w += d[j].w;
+  }
+  c1 = wave_sum(c1) * (1.0f / D);
+  c2 = wave_sum(c2) * (1.0f / D);
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    dx[j].x = rstd * (g[j].x - c1 - xh[j].x * c2);
+    dx[j].y = rstd * (g[j].y - c1 - xh[j].y * c2);
+    dx[j].z = rstd * (g[j].z - c1 - xh[j].z * c2);
+    dx[j].w = rstd * (g[j].w - c1 - xh[j].w * c2);
+  }
+}
+
+// dy = d t;  outputs da (gradient of `a`, both masks applied in turn) and dr (the residual's
+// gradient: both tails feed it); dgamma / dbeta of both LayerNorms are accumulated into.
+template <int VPL>
+__global__ __launch_bounds__(256) void dal2_bwd_kernel(
+    int M, int rows_per_block, const float *__restrict__ dy, const float *__restrict__ s1,
+    const float *__restrict__ stats1, const float *__restrict__ g1, float p1, unsigned salt1,
+    const float *__restrict__ s2, const float *__restrict__ stats2, const float *__restrict__ g2,
+    float p2, unsigned salt2, const unsigned long long *__restrict__ seed, float *__restrict__ da,
+    float *__restrict__ dr, float *__restrict__ dgamma1, float *__restrict__ dbeta1,
+    float *__restrict__ dgamma2, float *__restrict__ dbeta2) {
+  constexpr int D = 256 * VPL;
+  __shared__ float red[4][4][D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long sd = (p1 > 0.f || p2 > 0.f) ? *seed : 0ull;
+  float4 gg1[VPL], gg2[VPL], ag1[VPL], ab1[VPL], ag2[VPL], ab2[VPL];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    gg1[j] = *reinterpret_cast<const float4 *>(g1 + (j * 64 + lane) * 4);
+    gg2[j] = *reinterpret_cast<const float4 *>(g2 + (j * 64 + lane) * 4);
+    ag1[j] = ab1[j] = ag2[j] = ab2[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int r0 = blockIdx.x * rows_per_block;
+  for (int row = r0 + wave; row < min(M, r0 + rows_per_block); row += 4) {
+    float4 d[VPL], dx2[VPL], dx1[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j)
+      d[j] = *reinterpret_cast<const float4 *>(dy + (size_t)row * D + (j * 64 + lane) * 4);
+    row_layernorm_bwd<VPL>(d, s2, stats2[row * 2], stats2[row * 2 + 1], gg2, row, lane, dx2, ag2, ab2);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) d[j] = dx2[j];
+    row_dropout<VPL>(d, p2 > 0.f, sd, salt2, msr3d::drop_thresh(p2), p2 > 0.f ? 1.0f / (1.0f - p2) : 1.0f, row, lane);
+    row_layernorm_bwd<VPL>(d, s1, stats1[row * 2], stats1[row * 2 + 1], gg1, row, lane, dx1, ag1, ab1);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      *reinterpret_cast<float4 *>(dr + (size_t)row * D + c) =
+          make_float4(dx2[j].x + dx1[j].x, dx2[j].y + dx1[j].y, dx2[j].z + dx1[j].z, dx2[j].w + dx1[j].w);
+    }
+    row_dropout<VPL>(dx1, p1 > 0.f, sd, salt1, msr3d::drop_thresh(p1), p1 > 0.f ? 1.0f / (1.0f - p1) : 1.0f, row, lane);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j)
+      *reinterpret_cast<float4 *>(da + (size_t)row * D + (j * 64 + lane) * 4) = dx1[j];
+  }
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    *reinterpret_cast<float4 *>(&red[0][wave][c]) = ag1[j];
+    *reinterpret_cast<float4 *>(&red[1][wave][c]) = ab1[j];
+    *reinterpret_cast<float4 *>(&red[2][wave][c]) = ag2[j];
+    *reinterpret_cast<float4 *>(&red[3][wave][c]) = ab2[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    atomicAdd(dgamma1 + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(dbeta1 + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    atomicAdd(dgamma2 + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
+    atomicAdd(dbeta2 + c, red[3][0][c] + red[3][1][c] + red[3][2][c] + red[3][3][c]);
+  }
+}
+
 __global__ void bump_seed_kernel(unsigned long long *seed) { *seed = *seed * 6364136223846793005ull + 1442695040888963407ull; }
 
 }  // namespace
@@ -212,6 +396,44 @@ int msr3d_dropout_add_ln_bwd(int M, int D, const float *dy, const float *s, cons
   const int grid = (M + rpb - 1) / rpb;
 #define L(V) dal_bwd_kernel<V><<<grid, 256, 0, st>>>(M, rpb, dy, s, stats, gamma, p_drop, seed, salt, da, dr, dr_accumulate, dgamma_acc, dbeta_acc)
   switch (D / 256) { case 1: L(1); break; case 2: L(2); break; case 3: L(3); break; default: L(4); }
+#undef L
+  return (int)hipGetLastError();
+}
+
+int msr3d_dropout_add_ln2_fwd(int M, int D, const float *a, const float *r, const float *gamma1,
+                              const float *beta1, float eps1, float p1, unsigned salt1,
+                              const float *gamma2, const float *beta2, float eps2, float p2,
+                              unsigned salt2, const unsigned long long *seed, float *y, float *s1,
+                              float *stats1, float *s2, float *stats2, msr3d_stream_t stream) {
+  if (M < 0 || (D != 256 && D != 512)) return MSR3D_EINVAL;     // red[][] of the backward: D <= 512
+  if (M == 0) return 0;
+  if (!a || !r || !gamma1 || !beta1 || !gamma2 || !beta2 || !y || !s1 || !stats1 || !s2 || !stats2 ||
+      ((p1 > 0.f || p2 > 0.f) && !seed) || p1 >= 1.f || p2 >= 1.f)
+    return MSR3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = (M + 3) / 4;
+#define L(V) dal2_fwd_kernel<V><<<grid, 256, 0, st>>>(M, a, r, gamma1, beta1, eps1, p1, salt1, gamma2, beta2, eps2, p2, salt2, seed, y, s1, stats1, s2, stats2)
+  if (D == 256) L(1); else L(2);
+#undef L
+  return (int)hipGetLastError();
+}
+
+int msr3d_dropout_add_ln2_bwd(int M, int D, const float *dy, const float *s1, const float *stats1,
+                              const float *gamma1, float p1, unsigned salt1, const float *s2,
+                              const float *stats2, const float *gamma2, float p2, unsigned salt2,
+                              const unsigned long long *seed, float *da, float *dr,
+                              float *dgamma1_acc, float *dbeta1_acc, float *dgamma2_acc,
+                              float *dbeta2_acc, msr3d_stream_t stream) {
+  if (M < 0 || (D != 256 && D != 512)) return MSR3D_EINVAL;
+  if (M == 0) return 0;
+  if (!dy || !s1 || !stats1 || !gamma1 || !s2 || !stats2 || !gamma2 || !da || !dr || !dgamma1_acc ||
+      !dbeta1_acc || !dgamma2_acc || !dbeta2_acc || ((p1 > 0.f || p2 > 0.f) && !seed))
+    return MSR3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int rpb = 16;
+  const int grid = (M + rpb - 1) / rpb;
+#define L(V) dal2_bwd_kernel<V><<<grid, 256, 0, st>>>(M, rpb, dy, s1, stats1, gamma1, p1, salt1, s2, stats2, gamma2, p2, salt2, seed, da, dr, dgamma1_acc, dbeta1_acc, dgamma2_acc, dbeta2_acc)
+  if (D == 256) L(1); else L(2);
 #undef L
   return (int)hipGetLastError();
 }

@@ -55,6 +55,39 @@ def _dal_bwd(dy, s, stats, ln, p, salt, da, dr, accumulate):
     _lib.check(rc, "msr3d_dropout_add_ln_bwd")
 
 
+def _dal2_fwd(a, r, ln1, p1, salt1, ln2, p2, salt2):
+    """t = ln2(drop2(ln1(drop1(a) + r)) + r) in one launch (msr3d_dropout_add_ln2_fwd)."""
+    M, D = a.shape
+    dev = a.device
+    y, s1, s2 = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+    st1 = torch.empty((M, 2), dtype=torch.float32, device=dev)
+    st2 = torch.empty((M, 2), dtype=torch.float32, device=dev)
+    seed = seed_word(dev) if (p1 > 0 or p2 > 0) else None
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        rc = lib.msr3d_dropout_add_ln2_fwd(M, D, _p(a), _p(r), _p(ln1.weight), _p(ln1.bias),
+                                           ctypes.c_float(ln1.eps), ctypes.c_float(p1), salt1,
+                                           _p(ln2.weight), _p(ln2.bias), ctypes.c_float(ln2.eps),
+                                           ctypes.c_float(p2), salt2, _p(seed), _p(y), _p(s1), _p(st1),
+                                           _p(s2), _p(st2), _lib.current_stream_ptr(dev))
+    _lib.check(rc, "msr3d_dropout_add_ln2_fwd")
+    return y, s1, st1, s2, st2
+
+
+def _dal2_bwd(dy, s1, st1, ln1, p1, salt1, s2, st2, ln2, p2, salt2, da, dr):
+    M, D = dy.shape
+    dev = dy.device
+    seed = seed_word(dev) if (p1 > 0 or p2 > 0) else None
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        rc = lib.msr3d_dropout_add_ln2_bwd(M, D, _p(dy), _p(s1), _p(st1), _p(ln1.weight),
+                                           ctypes.c_float(p1), salt1, _p(s2), _p(st2), _p(ln2.weight),
+                                           ctypes.c_float(p2), salt2, _p(seed), _p(da), _p(dr),
+                                           _p(ln1.weight.grad), _p(ln1.bias.grad), _p(ln2.weight.grad),
+                                           _p(ln2.bias.grad), _lib.current_stream_ptr(dev))
+    _lib.check(rc, "msr3d_dropout_add_ln2_bwd")
+
+
 def _direct(dp, *params):
     return all(p is not None and getattr(p, "_msr3d_dp", None) is dp and p.is_leaf and p.grad is not None
                and p.is_contiguous() for p in params)
@@ -128,8 +161,12 @@ class _SpatialLayerFn(torch.autograd.Function):
                 _lib.current_stream_ptr(dev))
         _lib.check(rc, "msr3d_spatial_attn_fwd")
         _gemm(True, True, M, D, D, attn, D, sa.fc.weight, D, fc_out, D, bias=sa.fc.bias, beta=1.0)
-        a, s1, st1 = _dal_fwd(fc_out, x2, sa.layer_norm, p_attn, salts[0])     # transformers.py:250-251
-        t, s2, st2 = _dal_fwd(a, x2, layer.norm1, p1, salts[1])                 # :324-325
+        if D in (256, 512):     # transformers.py:250-251 then :324-325, one launch
+            t, s1, st1, s2, st2 = _dal2_fwd(fc_out, x2, sa.layer_norm, p_attn, salts[0], layer.norm1, p1,
+                                            salts[1])
+        else:
+            a, s1, st1 = _dal_fwd(fc_out, x2, sa.layer_norm, p_attn, salts[0])
+            t, s2, st2 = _dal_fwd(a, x2, layer.norm1, p1, salts[1])
         h = torch.empty((M, FF), dtype=torch.float32, device=dev)
         pre = torch.empty((M, FF), dtype=torch.float32, device=dev)
         _gemm(True, True, M, FF, D, t, D, layer.linear1.weight, D, h, FF, bias=layer.linear1.bias,
@@ -172,10 +209,14 @@ class _SpatialLayerFn(torch.autograd.Function):
         _linear_bwd(M, FF, D, d_pre, t, layer.linear1.weight, d_t, 1.0,                       # joins d_t
                     layer.linear1.weight.grad, layer.linear1.bias.grad)
 
-        d_x, d_a = new(M, D), new(M, D)
-        _dal_bwd(d_t, s2, st2, layer.norm1, p1, salts[1], d_a, d_x, False)
-        d_fc = new(M, D)
-        _dal_bwd(d_a, s1, st1, sa.layer_norm, p_attn, salts[0], d_fc, d_x, True)             # joins d_x
+        d_x, d_fc = new(M, D), new(M, D)
+        if D in (256, 512):
+            _dal2_bwd(d_t, s1, st1, sa.layer_norm, p_attn, salts[0], s2, st2, layer.norm1, p1, salts[1],
+                      d_fc, d_x)
+        else:
+            d_a = new(M, D)
+            _dal_bwd(d_t, s2, st2, layer.norm1, p1, salts[1], d_a, d_x, False)
+            _dal_bwd(d_a, s1, st1, sa.layer_norm, p_attn, salts[0], d_fc, d_x, True)         # joins d_x
         _linear_bwd(M, D, D, d_fc, attn, sa.fc.weight, d_attn, 1.0,                           # onto the zeros
                     sa.fc.weight.grad, sa.fc.bias.grad)
         d_qkvc = new(M, W)

@@ -61,3 +61,44 @@ def test_dropout_mask_statistics_and_backward_consistency():
     before = hipops.seed_word(a.device).clone()
     hipops.bump_seed(a.device)
     assert not torch.equal(before, hipops.seed_word(a.device))
+
+
+@pytest.mark.parametrize("D", [256, 512])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_double_tail_equals_two_single_tails(D, p):
+    """msr3d_dropout_add_ln2_fwd/bwd == two chained msr3d_dropout_add_ln calls with the same salts
+    (forward bit-identical; backward to rounding)."""
+    import torch.nn as nn
+    from msr3d_amd import fused_layer as fl
+    torch.manual_seed(D + int(p * 100))
+    M = 203
+    a = torch.randn(M, D, device="cuda")
+    r = torch.randn(M, D, device="cuda")
+    dy = torch.randn(M, D, device="cuda")
+    ln1, ln2 = nn.LayerNorm(D).cuda(), nn.LayerNorm(D).cuda()
+    for ln in (ln1, ln2):
+        ln.weight.data.uniform_(0.5, 1.5)
+        ln.bias.data.normal_()
+        ln.weight.grad = torch.zeros_like(ln.weight)
+        ln.bias.grad = torch.zeros_like(ln.bias)
+    y1, s1, st1 = fl._dal_fwd(a, r, ln1, p, 11)
+    y2, s2, st2 = fl._dal_fwd(y1, r, ln2, p, 12)
+    d_a, d_x, d_fc = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+    fl._dal_bwd(dy, s2, st2, ln2, p, 12, d_a, d_x, False)
+    fl._dal_bwd(d_a, s1, st1, ln1, p, 11, d_fc, d_x, True)
+    ref = [t.clone() for t in (y2, s1, st1, s2, st2, d_fc, d_x, ln1.weight.grad, ln1.bias.grad,
+                               ln2.weight.grad, ln2.bias.grad)]
+    for ln in (ln1, ln2):
+        ln.weight.grad.zero_()
+        ln.bias.grad.zero_()
+    t, f1, ft1, f2, ft2 = fl._dal2_fwd(a, r, ln1, p, 11, ln2, p, 12)
+    g_fc, g_x = torch.empty_like(a), torch.empty_like(a)
+    fl._dal2_bwd(dy, f1, ft1, ln1, p, 11, f2, ft2, ln2, p, 12, g_fc, g_x)
+    got = [t, f1, ft1, f2, ft2, g_fc, g_x, ln1.weight.grad, ln1.bias.grad, ln2.weight.grad, ln2.bias.grad]
+    for i, (g, w) in enumerate(zip(got, ref)):
+        if i < 5:                           # forward: bit-identical
+            assert torch.equal(g, w), i
+        else:                               # backward: fma contraction / add order / atomics differ
+            assert torch.allclose(g, w, rtol=1e-5, atol=1e-5), i
+    if p > 0:
+        assert (f1 != a + r).any()          # dropout really applied
