@@ -233,6 +233,11 @@ int msr3d_agent_fourier(int B, int L, const float *loc, int ld_loc, const float 
                         const float *anchor_ori, const float *freqs, int num_bands, int transform,
                         float *out, msr3d_stream_t stream);
 
+/* out (M,D) = x (M,D) + v1 (D) + v2 (D; may be NULL): the type / orientation embeddings that every
+ * object token receives (model/ose3d_situation.py:327-365).  D % 4 == 0, 16-byte aligned. */
+int msr3d_add_row_vectors(int M, int D, const float *x, const float *v1, const float *v2,
+                          float *out, msr3d_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Row-wise tails of the spatial encoder layer: y = LayerNorm(dropout(a) + r) * gamma + beta
  * (/root/reference/modules/layers/transformers.py:250-251,324-328; r may be NULL and

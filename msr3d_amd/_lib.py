@@ -43,6 +43,7 @@ _SIGNATURES = {
                                               _ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _c_int, _ptr],
     "msr3d_pairwise_locs": [_c_int, _c_int, _ptr, _c_int, _c_float, _ptr, _ptr],
     "msr3d_agent_fourier": [_c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr, _ptr],
+    "msr3d_add_row_vectors": [_c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_dropout_add_ln_fwd": [_c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_float, _c_float, _ptr,
                                  ctypes.c_uint, _ptr, _ptr, _ptr, _ptr],
     "msr3d_dropout_add_ln_bwd": [_c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_float, _ptr, ctypes.c_uint,

@@ -11,6 +11,8 @@
 // last bits except for the 3-term matmul order.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 #include <cmath>
 
 #include "../../include/msr3d_hip.h"
@@ -54,6 +56,25 @@ __global__ __launch_bounds__(256) void pairwise_locs_kernel(int L, const float *
     o[2] = d2 / d;
     o[3] = dy / d2;
     o[4] = dx / d2;
+  }
+}
+
+// out[m][c] = x[m][c] + v1[c] (+ v2[c]): the constant type / orientation embeddings broadcast onto
+// every object token (model/ose3d_situation.py:327-365), float4 per thread
+__global__ void add_row_vectors_kernel(long long n4, int D4, const float4 *__restrict__ x,
+                                       const float4 *__restrict__ v1, const float4 *__restrict__ v2,
+                                       float4 *__restrict__ out) {
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n4;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(t % D4);
+    float4 a = x[t];
+    const float4 p = v1[c];
+    a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+    if (v2) {
+      const float4 q = v2[c];
+      a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+    }
+    out[t] = a;
   }
 }
 
@@ -118,6 +139,23 @@ int msr3d_agent_fourier(int B, int L, const float *loc, int ld_loc, const float 
   const int n = B * L;
   agent_fourier_kernel<<<(n + 127) / 128, 128, 0, (hipStream_t)stream>>>(
       B, L, loc, ld_loc, anchor_loc, anchor_ori, freqs, num_bands, transform, out);
+  return (int)hipGetLastError();
+}
+
+int msr3d_add_row_vectors(int M, int D, const float *x, const float *v1, const float *v2,
+                          float *out, msr3d_stream_t stream) {
+  if (M < 0 || D <= 0 || D % 4 != 0) return MSR3D_EINVAL;
+  if (M == 0) return 0;
+  if (!x || !v1 || !out) return MSR3D_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(v1) | reinterpret_cast<uintptr_t>(v2) |
+       reinterpret_cast<uintptr_t>(out)) & 15u)
+    return MSR3D_EINVAL;
+  const long long n4 = (long long)M * (D / 4);
+  long long g = (n4 + 255) / 256;
+  if (g > 2048) g = 2048;
+  add_row_vectors_kernel<<<(int)g, 256, 0, (hipStream_t)stream>>>(
+      n4, D / 4, reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(v1),
+      reinterpret_cast<const float4 *>(v2), reinterpret_cast<float4 *>(out));
   return (int)hipGetLastError();
 }
 

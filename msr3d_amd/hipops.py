@@ -471,6 +471,68 @@ def dropout_add_layernorm(a, r, ln, p_drop=0.0, training=False):
 
 
 # ---------------------------------------------------------------------------------------
+# constant embeddings broadcast onto every token (csrc/prologue.hip)
+# ---------------------------------------------------------------------------------------
+class _AddTokenConstants(torch.autograd.Function):
+    """out = x + table[row] + extra: every object token receives the same type-embedding row and
+    the same learnt orientation vector (model/ose3d_situation.py:327-365).  Autograd's version
+    costs two broadcast adds forward and eight launches backward (two reductions with their
+    memsets, a zero table for the embedding row, copies, adds); here: one launch forward, and the
+    column sum of the upstream gradient goes straight onto the two parameters' gradients."""
+
+    @staticmethod
+    def forward(ctx, x, table, row, extra):
+        shape = x.shape
+        D = shape[-1]
+        x2 = x.reshape(-1, D)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        v1 = table[row]
+        v2 = extra.reshape(-1) if extra is not None else None
+        out = torch.empty_like(x2)
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            rc = lib.msr3d_add_row_vectors(x2.shape[0], D, _p(x2), _p(v1), _p(v2), _p(out),
+                                           _lib.current_stream_ptr(x.device))
+        _lib.check(rc, "msr3d_add_row_vectors")
+        ctx.row, ctx.shape = row, shape
+        ctx.params = (table, extra)
+        dpt = getattr(table, "_msr3d_dp", None)
+        ok = dpt is not None and table.is_leaf and table.grad is not None
+        if ok and extra is not None:
+            ok = getattr(extra, "_msr3d_dp", None) is dpt and extra.is_leaf and extra.grad is not None
+        ctx.direct = dpt if (ok and not _NO_DIRECT) else None
+        return out.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        table, extra = ctx.params
+        D = ctx.shape[-1]
+        d2 = dy.reshape(-1, D)
+        d2 = d2 if d2.is_contiguous() else d2.contiguous()
+        M = d2.shape[0]
+        if ctx.direct is not None:
+            _colsum(d2, M, D, table.grad[ctx.row], accumulate=True)
+            ctx.direct.mark_ready(table)
+            if extra is not None:
+                _colsum(d2, M, D, extra.grad.view(-1), accumulate=True)
+                ctx.direct.mark_ready(extra)
+            return dy, None, None, None
+        col = torch.empty((D,), dtype=torch.float32, device=dy.device)
+        _colsum(d2, M, D, col)
+        gt = torch.zeros_like(table)
+        gt[ctx.row] = col
+        return dy, gt, None, (col.view_as(extra).clone() if extra is not None else None)
+
+
+def add_token_constants(x, table, row, extra=None):
+    """x (..., D) + table[row] + extra (any shape with D elements; optional)."""
+    if x.is_cuda and x.dtype == torch.float32 and table.dtype == torch.float32 and x.shape[-1] % 4 == 0:
+        return _AddTokenConstants.apply(x, table, row, extra)
+    out = x + table[row]
+    return out + extra.reshape(-1) if extra is not None else out
+
+
+# ---------------------------------------------------------------------------------------
 # data-only front of the encoder (csrc/prologue.hip)
 # ---------------------------------------------------------------------------------------
 def pairwise_locs_center5(obj_loc, eps=1e-10):

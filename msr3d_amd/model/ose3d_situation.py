@@ -203,16 +203,22 @@ class OSE3DSituation(BaseModel):
         B, N = feat.shape[:2]
         dev = feat.device
         loc = data_dict["obj_locs"]
+        valid_out = data_dict["obj_masks"]                 # returned as is unless a token is prepended
         # every object has type id 0: row 0 of the table, broadcast (an nn.Embedding lookup of a
         # constant would cost a gather forward and a 90 us scatter kernel backward)
-        type_emb = self.object_type_embedding.weight[0].expand(B, N, -1)
-        ori_feat = self.object_orientation_feat.expand(B, N, -1) if self.use_orientation else None
-
         if self.use_anchor and self.situation_type in _ANCHOR_TOKEN_TYPES:
+            type_emb = self.object_type_embedding.weight[0].expand(B, N, -1)
+            ori_feat = self.object_orientation_feat.expand(B, N, -1) if self.use_orientation else None
             feat, mask, loc, type_emb, ori_feat = self._with_anchor_token(
                 data_dict, feat, mask, loc, type_emb, ori_feat)
-
-        feat = feat + ori_feat + type_emb if self.use_orientation else feat + type_emb
+            feat = feat + ori_feat + type_emb if self.use_orientation else feat + type_emb
+            valid_out = ~mask
+        else:
+            # same sum, one launch each way: the two constants go on in one kernel, and their
+            # gradients (column sums of d feat) straight onto the parameters' gradients
+            feat = hipops.add_token_constants(
+                feat, self.object_type_embedding.weight, 0,
+                self.object_orientation_feat if self.use_orientation else None)
 
         se = self.cfg.spatial_encoder
         pairwise_locs = None
@@ -246,5 +252,5 @@ class OSE3DSituation(BaseModel):
 
         data_dict["oatt"] = None
         data_dict["obj_tokens"] = x
-        data_dict["obj_masks"] = ~mask
+        data_dict["obj_masks"] = valid_out
         return data_dict
