@@ -1,3 +1,6 @@
+"""Where a step's wall time goes without a profiler attached: HIP events around the eager encoder
+(+ input copies), the captured graph, and the GPU idle gap between one step's last kernel and the
+next step's first (host run-ahead check).  python tools/gap_probe.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
