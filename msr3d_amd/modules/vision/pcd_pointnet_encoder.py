@@ -20,37 +20,38 @@ class PcdObjEncoder(nn.Module):
                  sa_mlps=[[3, 64, 64, 128], [128, 128, 128, 256], [256, 256, 512, 768]],
                  dropout=0.1, path=None, freeze=False):
         super().__init__()
+        self.freeze = bool(freeze)
         self.pcd_net = PointNetPP(sa_n_points=sa_n_points, sa_n_samples=sa_n_samples,
                                   sa_radii=sa_radii, sa_mlps=sa_mlps)
+        # 607 ScanNet classes behind a 384-wide hidden layer, as in the checkpoints (:30)
         self.obj3d_clf_pre_head = get_mlp_head(sa_mlps[-1][-1], 384, 607, dropout=0.3)
         self.dropout = nn.Dropout(dropout)
-        if path:   # the shipped yaml carries `path: ""`; only a real path is loaded
-            self.load_state_dict(torch.load(path, map_location="cpu"), strict=False)
-        self.freeze = freeze
-        if freeze:
-            for p in self.parameters():
-                p.requires_grad = False
+        if path:   # the shipped yaml carries `path: ""`; only a real checkpoint path is loaded
+            state = torch.load(path, map_location="cpu")
+            self.load_state_dict(state, strict=False)
+        if self.freeze:
+            self.requires_grad_(False)
 
-    def freeze_bn(self, m):
-        for layer in m.modules():
-            if isinstance(layer, nn.BatchNorm2d):
-                layer.eval()
+    @staticmethod
+    def freeze_bn(m):
+        """BatchNorm layers of `m` onto their running statistics."""
+        for bn in (l for l in m.modules() if isinstance(l, nn.BatchNorm2d)):
+            bn.eval()
 
     def encode(self, obj_pcds):
-        B, O = obj_pcds.shape[:2]
-        flat = obj_pcds.reshape(B * O, obj_pcds.size(2), obj_pcds.size(3))
-        return self.pcd_net(flat).reshape(B, O, -1)
+        """(B, O, P, C) -> (B, O, D): objects are independent clouds for the backbone."""
+        B, O, P, C = obj_pcds.shape
+        return self.pcd_net(obj_pcds.reshape(B * O, P, C)).reshape(B, O, -1)
 
     def embed(self, obj_pcds):
         """obj_embeds only: what OSE3DSituation consumes (it takes `[0]` of forward and
         discards the 607-way logits, ose3d_situation.py:285), without the dead head."""
-        if self.freeze:
-            self.freeze_bn(self.pcd_net)
-            with torch.no_grad():
-                return self.encode(obj_pcds).detach()
-        return self.encode(obj_pcds)
+        if not self.freeze:
+            return self.encode(obj_pcds)
+        self.freeze_bn(self.pcd_net)
+        with torch.no_grad():
+            return self.encode(obj_pcds).detach()
 
     def forward(self, obj_pcds, obj_locs=None, obj_masks=None, obj_sem_masks=None, **kwargs):
         obj_embeds = self.embed(obj_pcds)
-        obj_sem_cls = self.obj3d_clf_pre_head(obj_embeds)
-        return obj_embeds, obj_sem_cls
+        return obj_embeds, self.obj3d_clf_pre_head(obj_embeds)
