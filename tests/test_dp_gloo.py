@@ -5,6 +5,7 @@ find_unused_parameters=True for, leo_trainer.py:50)."""
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -57,21 +58,23 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_gradient_exchange():
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_rank_gloo_gradient_exchange(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(2))
+    res = dict(q.get(timeout=180) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     # identical weights and identical (averaged) flat gradients on both ranks after 3 steps
     import numpy as np
-    for k in res[0]:
-        assert np.allclose(res[0][k], res[1][k], atol=1e-7), k
+    for r in range(1, world):
+        for k in res[0]:
+            assert np.allclose(res[0][k], res[r][k], atol=1e-7), (r, k)
     assert np.count_nonzero(res[0]["__flat__"]) > 0
     # the unused parameter's gradient stayed exactly zero and the parameter only saw weight decay
     assert res[0]["unused"].max() < 1.0 and np.allclose(res[0]["unused"], res[0]["unused"][0])
