@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdint>
 
 #include "../../include/msr3d_hip.h"
 
@@ -89,6 +90,28 @@ __device__ __forceinline__ void load_head_tile(const float *__restrict__ src, in
   }
 }
 
+// pairwise_locs of one sample, (L, L, SD) floats, is one contiguous slab: the 64-token tile copies
+// it into LDS with coalesced 16-byte loads (the logits loop reads 5 floats per (query, key) pair:
+// straight from global memory that is 80 uncoalesced 4-byte loads per lane; from LDS the stride-5
+// pattern is bank-conflict-free).  The 128-token tile (328 KB slab) keeps reading global memory.
+template <int LT>
+__device__ __forceinline__ const float *stage_ploc(const float *__restrict__ ploc, int b, int L,
+                                                   float *spl) {
+  const float *src = ploc + (size_t)b * L * L * SD;
+  if (LT != 64) return src;
+  const int n = L * L * SD, n4 = n >> 2;
+  const bool vec = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
+  if (vec) {
+#pragma unroll 4
+    for (int e = threadIdx.x; e < n4; e += LT * 4)
+      reinterpret_cast<float4 *>(spl)[e] = reinterpret_cast<const float4 *>(src)[e];
+    for (int e = n4 * 4 + threadIdx.x; e < n; e += LT * 4) spl[e] = src[e];
+  } else {
+    for (int e = threadIdx.x; e < n; e += LT * 4) spl[e] = src[e];
+  }
+  return spl;      // valid after the caller's next __syncthreads()
+}
+
 struct RowCond { float bias, w[SD]; };
 
 __device__ __forceinline__ RowCond load_cond(const float *__restrict__ cond, int ldc, int b, int h,
@@ -128,6 +151,7 @@ __global__ __launch_bounds__(LT * 4) void attn_fwd_kernel(int B, int L, int H,
   load_head_tile<LT>(q, ldqkv, b, h, L, sq);
   load_head_tile<LT>(k, ldqkv, b, h, L, sk);
   load_head_tile<LT>(v, ldqkv, b, h, L, sv);
+  const float *plb = stage_ploc<LT>(ploc, b, L, sp + LT * LDP);
   __syncthreads();
 
   f32x4 acc[NT];
@@ -147,7 +171,7 @@ __global__ __launch_bounds__(LT * 4) void attn_fwd_kernel(int B, int L, int H,
       const int col = rn * 16 + i;
       float lg = -INFINITY;
       if (row < L && col < L && !pad[(size_t)b * L + col]) {
-        const float *pl = ploc + (((size_t)b * L + row) * L + col) * SD;
+        const float *pl = plb + ((size_t)row * L + col) * SD;
         float z = c.bias;
 #pragma unroll
         for (int d = 0; d < SD; ++d) z = fmaf(c.w[d], pl[d], z);
@@ -219,6 +243,7 @@ __global__ __launch_bounds__(LT * 4) void attn_bwd_kernel(int B, int L, int H,
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *sq = smem, *sk = sq + LT * LD32, *sv = sk + LT * LD32, *sdo = sv + LT * LD32;
   float *sp = sdo + LT * LD32;                    // P, then dS in place
+  const float *plb = stage_ploc<LT>(ploc, blockIdx.y, L, sp + LT * LDP);
   const int h = blockIdx.x, b = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4, row0 = wave * 16;
@@ -265,7 +290,7 @@ __global__ __launch_bounds__(LT * 4) void attn_bwd_kernel(int B, int L, int H,
       const float dlogit = p[rn] * (acc[rn][r] - dot);     // softmax backward
       sp[row * LDP + col] = dlogit;         // in place: this lane owns the element
       if (row < L && col < L && !pad[(size_t)b * L + col]) {
-        const float *pl = ploc + (((size_t)b * L + row) * L + col) * SD;
+        const float *pl = plb + ((size_t)row * L + col) * SD;
         float z = c.bias;
 #pragma unroll
         for (int d = 0; d < SD; ++d) z = fmaf(c.w[d], pl[d], z);
@@ -313,8 +338,9 @@ __global__ __launch_bounds__(LT * 4) void attn_bwd_kernel(int B, int L, int H,
 }
 
 // dynamic LDS: forward 3 head tiles + P, backward 4 head tiles + P
-template <int LT> constexpr size_t fwd_lds() { return sizeof(float) * (3 * LT * LD32 + LT * (LT + 4)); }
-template <int LT> constexpr size_t bwd_lds() { return sizeof(float) * (4 * LT * LD32 + LT * (LT + 4)); }
+template <int LT> constexpr size_t ploc_lds() { return LT == 64 ? sizeof(float) * 64 * 64 * SD : 0; }
+template <int LT> constexpr size_t fwd_lds() { return sizeof(float) * (3 * LT * LD32 + LT * (LT + 4)) + ploc_lds<LT>(); }
+template <int LT> constexpr size_t bwd_lds() { return sizeof(float) * (4 * LT * LD32 + LT * (LT + 4)) + ploc_lds<LT>(); }
 
 template <int LT, typename... Args>
 hipError_t launch_fwd(int B, int H, hipStream_t stream, Args... args) {
