@@ -178,7 +178,8 @@ int msr3d_linear_bwd_f32(int M_tokens, int N_out, int K_in, const float *dy, con
                          const float *w, float *dx, float dx_beta, float *dw, float *db,
                          void *workspace, size_t workspace_bytes, msr3d_stream_t stream);
 
-/* out[n] (+)= sum_m X[m*ldx + n]  (bias gradient). */
+/* out[n] (+)= sum_m X[m*ldx + n]  (bias gradient).  accumulate bit0: add onto out; bit1: sum every
+ * column in one workgroup (fixed order, bit-reproducible) instead of row chunks meeting by atomicAdd. */
 int msr3d_colsum_f32(int M, int N, const float *X, int ldx, float *out, int accumulate,
                      msr3d_stream_t stream);
 
@@ -253,11 +254,15 @@ int msr3d_dropout_add_ln_fwd(int M, int D, const float *a, const float *r, const
 
 /* da (M,D; NULL if a needs no grad) is written; dr (M,D; NULL if r was NULL) is written, or
  * added to when dr_accumulate != 0 (a residual consumed by several blocks: the gradients meet in
- * one buffer without a separate add); dgamma_acc / dbeta_acc (D) are ACCUMULATED into (atomicAdd). */
+ * one buffer without a separate add); dgamma_acc / dbeta_acc (D) are ACCUMULATED into: by atomicAdd,
+ * or -- partial_ws != NULL, ceil(M / MSR3D_LN_BWD_ROWS) * 2 * D floats (4 * D for the ln2 variant) --
+ * through per-workgroup partials summed in a fixed order (bit-reproducible, one more tiny launch). */
+#define MSR3D_LN_BWD_ROWS 16
 int msr3d_dropout_add_ln_bwd(int M, int D, const float *dy, const float *s, const float *stats,
                              const float *gamma, float p_drop, const unsigned long long *seed,
                              unsigned salt, float *da, float *dr, int dr_accumulate,
-                             float *dgamma_acc, float *dbeta_acc, msr3d_stream_t stream);
+                             float *dgamma_acc, float *dbeta_acc, float *partial_ws,
+                             msr3d_stream_t stream);
 
 /* Two chained tails sharing one residual, t = LN2(drop2(LN1(drop1(a) + r)) + r): the attention
  * block's residual + LayerNorm followed by the encoder layer's first one
@@ -275,7 +280,7 @@ int msr3d_dropout_add_ln2_bwd(int M, int D, const float *dy, const float *s1, co
                               const float *stats2, const float *gamma2, float p2, unsigned salt2,
                               const unsigned long long *seed, float *da, float *dr,
                               float *dgamma1_acc, float *dbeta1_acc, float *dgamma2_acc,
-                              float *dbeta2_acc, msr3d_stream_t stream);
+                              float *dbeta2_acc, float *partial_ws, msr3d_stream_t stream);
 
 /* Advance the device-resident dropout seed word (once per training step, inside the graph). */
 int msr3d_bump_seed(unsigned long long *seed, msr3d_stream_t stream);

@@ -47,13 +47,13 @@ _SIGNATURES = {
     "msr3d_dropout_add_ln_fwd": [_c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_float, _c_float, _ptr,
                                  ctypes.c_uint, _ptr, _ptr, _ptr, _ptr],
     "msr3d_dropout_add_ln_bwd": [_c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_float, _ptr, ctypes.c_uint,
-                                 _ptr, _ptr, _c_int, _ptr, _ptr, _ptr],
+                                 _ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr],
     "msr3d_dropout_add_ln2_fwd": [_c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_float, _c_float, ctypes.c_uint,
                                   _ptr, _ptr, _c_float, _c_float, ctypes.c_uint, _ptr, _ptr, _ptr, _ptr,
                                   _ptr, _ptr, _ptr],
     "msr3d_dropout_add_ln2_bwd": [_c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_float, ctypes.c_uint, _ptr, _ptr,
                                   _ptr, _c_float, ctypes.c_uint, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
-                                  _ptr],
+                                  _ptr, _ptr],
     "msr3d_bump_seed": [_ptr, _ptr],
     "msr3d_scene_scatter": [_c_int, _c_int, _c_int, _c_int, _ptr, ctypes.c_longlong, _ptr, _ptr, _c_int,
                             _ptr, _ptr, _ptr, _ptr, _ptr],

@@ -628,13 +628,14 @@ int msr3d_colsum_f32(int M, int N, const float *X, int ldx, float *out, int accu
                      msr3d_stream_t stream) {
   if (M < 0 || N <= 0 || !out || (M > 0 && !X)) return MSR3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (!accumulate) {
+  if (!(accumulate & 1)) {
     hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, st);
     if (e != hipSuccess) return (int)e;
   }
   if (M == 0) return 0;
   int chunks = (M + 127) / 128;
   if (chunks > 64) chunks = 64;
+  if (accumulate & 2) chunks = 1;       // ordered: one workgroup owns a column's whole sum
   dim3 grid((N + 63) / 64, chunks);
   colsum_kernel<<<grid, 256, 0, st>>>(M, N, X, ldx, out);
   return (int)hipGetLastError();

@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void dal_bwd_kernel(int M, int rows_per_block,
                                                       unsigned salt, float *__restrict__ da,
                                                       float *__restrict__ dr, int dr_accumulate,
                                                       float *__restrict__ dgamma,
-                                                      float *__restrict__ dbeta) {
+                                                      float *__restrict__ dbeta,
+                                                      float *__restrict__ partials) {
   constexpr int D = 256 * VPL;
   __shared__ float red[2][4][D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -172,8 +173,29 @@ __global__ __launch_bounds__(256) void dal_bwd_kernel(int M, int rows_per_block,
   }
   __syncthreads();
   for (int c = threadIdx.x; c < D; c += 256) {
-    atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-    atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    const float sg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    if (partials) {        // ordered mode: per-block partials, summed in block order by reduce_partials
+      partials[((size_t)blockIdx.x * 2 + 0) * D + c] = sg;
+      partials[((size_t)blockIdx.x * 2 + 1) * D + c] = sb;
+    } else {
+      atomicAdd(dgamma + c, sg);
+      atomicAdd(dbeta + c, sb);
+    }
+  }
+}
+
+// dst_k[c] += sum over blocks (ascending) of partials[block][k][c], k < NP: the bit-reproducible
+// meeting point of the LayerNorm parameter gradients (the default one is atomicAdd)
+struct PartialDst { float *p[4]; };
+__global__ void reduce_partials_kernel(int n_blocks, int NP, int D, const float *__restrict__ partials,
+                                       PartialDst dst) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  for (int k = 0; k < NP; ++k) {
+    float acc = 0.f;
+    for (int blk = 0; blk < n_blocks; ++blk) acc += partials[((size_t)blk * NP + k) * D + c];
+    dst.p[k][c] += acc;
   }
 }
 
@@ -310,7 +332,7 @@ __global__ __launch_bounds__(256) void dal2_bwd_kernel(
     const float *__restrict__ s2, const float *__restrict__ stats2, const float *__restrict__ g2,
     float p2, unsigned salt2, const unsigned long long *__restrict__ seed, float *__restrict__ da,
     float *__restrict__ dr, float *__restrict__ dgamma1, float *__restrict__ dbeta1,
-    float *__restrict__ dgamma2, float *__restrict__ dbeta2) {
+    float *__restrict__ dgamma2, float *__restrict__ dbeta2, float *__restrict__ partials) {
   constexpr int D = 256 * VPL;
   __shared__ float red[4][4][D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -353,11 +375,14 @@ __global__ __launch_bounds__(256) void dal2_bwd_kernel(
     *reinterpret_cast<float4 *>(&red[3][wave][c]) = ab2[j];
   }
   __syncthreads();
+  float *const dsts[4] = {dgamma1, dbeta1, dgamma2, dbeta2};
   for (int c = threadIdx.x; c < D; c += 256) {
-    atomicAdd(dgamma1 + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-    atomicAdd(dbeta1 + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
-    atomicAdd(dgamma2 + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
-    atomicAdd(dbeta2 + c, red[3][0][c] + red[3][1][c] + red[3][2][c] + red[3][3][c]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float sum = red[k][0][c] + red[k][1][c] + red[k][2][c] + red[k][3][c];
+      if (partials) partials[((size_t)blockIdx.x * 4 + k) * D + c] = sum;
+      else atomicAdd(dsts[k] + c, sum);
+    }
   }
 }
 
@@ -386,17 +411,22 @@ int msr3d_dropout_add_ln_fwd(int M, int D, const float *a, const float *r, const
 int msr3d_dropout_add_ln_bwd(int M, int D, const float *dy, const float *s, const float *stats,
                              const float *gamma, float p_drop, const unsigned long long *seed,
                              unsigned salt, float *da, float *dr, int dr_accumulate,
-                             float *dgamma_acc, float *dbeta_acc, msr3d_stream_t stream) {
+                             float *dgamma_acc, float *dbeta_acc, float *partial_ws,
+                             msr3d_stream_t stream) {
   if (M < 0 || (D != 256 && D != 512 && D != 768 && D != 1024)) return MSR3D_EINVAL;
   if (M == 0) return 0;
   if (!dy || !s || !stats || !gamma || !dgamma_acc || !dbeta_acc || (p_drop > 0.f && !seed))
     return MSR3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int rpb = 16;
+  const int rpb = MSR3D_LN_BWD_ROWS;
   const int grid = (M + rpb - 1) / rpb;
-#define L(V) dal_bwd_kernel<V><<<grid, 256, 0, st>>>(M, rpb, dy, s, stats, gamma, p_drop, seed, salt, da, dr, dr_accumulate, dgamma_acc, dbeta_acc)
+#define L(V) dal_bwd_kernel<V><<<grid, 256, 0, st>>>(M, rpb, dy, s, stats, gamma, p_drop, seed, salt, da, dr, dr_accumulate, dgamma_acc, dbeta_acc, partial_ws)
   switch (D / 256) { case 1: L(1); break; case 2: L(2); break; case 3: L(3); break; default: L(4); }
 #undef L
+  if (partial_ws) {
+    PartialDst dst = {{dgamma_acc, dbeta_acc, nullptr, nullptr}};
+    reduce_partials_kernel<<<(D + 255) / 256, 256, 0, st>>>(grid, 2, D, partial_ws, dst);
+  }
   return (int)hipGetLastError();
 }
 
@@ -423,18 +453,22 @@ int msr3d_dropout_add_ln2_bwd(int M, int D, const float *dy, const float *s1, co
                               const float *stats2, const float *gamma2, float p2, unsigned salt2,
                               const unsigned long long *seed, float *da, float *dr,
                               float *dgamma1_acc, float *dbeta1_acc, float *dgamma2_acc,
-                              float *dbeta2_acc, msr3d_stream_t stream) {
+                              float *dbeta2_acc, float *partial_ws, msr3d_stream_t stream) {
   if (M < 0 || (D != 256 && D != 512)) return MSR3D_EINVAL;
   if (M == 0) return 0;
   if (!dy || !s1 || !stats1 || !gamma1 || !s2 || !stats2 || !gamma2 || !da || !dr || !dgamma1_acc ||
       !dbeta1_acc || !dgamma2_acc || !dbeta2_acc || ((p1 > 0.f || p2 > 0.f) && !seed))
     return MSR3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int rpb = 16;
+  const int rpb = MSR3D_LN_BWD_ROWS;
   const int grid = (M + rpb - 1) / rpb;
-#define L(V) dal2_bwd_kernel<V><<<grid, 256, 0, st>>>(M, rpb, dy, s1, stats1, gamma1, p1, salt1, s2, stats2, gamma2, p2, salt2, seed, da, dr, dgamma1_acc, dbeta1_acc, dgamma2_acc, dbeta2_acc)
+#define L(V) dal2_bwd_kernel<V><<<grid, 256, 0, st>>>(M, rpb, dy, s1, stats1, gamma1, p1, salt1, s2, stats2, gamma2, p2, salt2, seed, da, dr, dgamma1_acc, dbeta1_acc, dgamma2_acc, dbeta2_acc, partial_ws)
   if (D == 256) L(1); else L(2);
 #undef L
+  if (partial_ws) {
+    PartialDst dst = {{dgamma1_acc, dbeta1_acc, dgamma2_acc, dbeta2_acc}};
+    reduce_partials_kernel<<<(D + 255) / 256, 256, 0, st>>>(grid, 4, D, partial_ws, dst);
+  }
   return (int)hipGetLastError();
 }
 

@@ -51,6 +51,7 @@ def _dal_bwd(dy, s, stats, ln, p, salt, da, dr, accumulate):
         rc = lib.msr3d_dropout_add_ln_bwd(M, D, _p(dy), _p(s), _p(stats), _p(ln.weight),
                                           ctypes.c_float(p), _p(seed), salt, _p(da), _p(dr),
                                           int(accumulate), _p(ln.weight.grad), _p(ln.bias.grad),
+                                          _p(hipops.ln_partials(M, D, 2, dy.device)),
                                           _lib.current_stream_ptr(dy.device))
     _lib.check(rc, "msr3d_dropout_add_ln_bwd")
 
@@ -84,7 +85,8 @@ def _dal2_bwd(dy, s1, st1, ln1, p1, salt1, s2, st2, ln2, p2, salt2, da, dr):
                                            ctypes.c_float(p1), salt1, _p(s2), _p(st2), _p(ln2.weight),
                                            ctypes.c_float(p2), salt2, _p(seed), _p(da), _p(dr),
                                            _p(ln1.weight.grad), _p(ln1.bias.grad), _p(ln2.weight.grad),
-                                           _p(ln2.bias.grad), _lib.current_stream_ptr(dev))
+                                           _p(ln2.bias.grad), _p(hipops.ln_partials(M, D, 4, dev)),
+                                           _lib.current_stream_ptr(dev))
     _lib.check(rc, "msr3d_dropout_add_ln2_bwd")
 
 

@@ -54,12 +54,26 @@ def _workspace(dev):
     return ws
 
 
-_deterministic = [_os.environ.get("MSR3D_GEMM_DETERMINISTIC", "0") == "1"]
+_deterministic = [_os.environ.get("MSR3D_GEMM_DETERMINISTIC", "0") == "1"
+                  or _os.environ.get("MSR3D_DETERMINISTIC", "0") == "1"]
 
 
 def set_deterministic(on):
-    """Ordered (bit-reproducible) split-K for every GEMM issued from now on."""
+    """Bit-reproducible reductions from now on: ordered split-K in every GEMM, LayerNorm parameter
+    gradients and bias column sums summed in a fixed order (instead of meeting by float atomics).
+    Same seed + same data => identical weights, run after run; ~5 % slower."""
     _deterministic[0] = bool(on)
+
+
+LN_BWD_ROWS = 16     # MSR3D_LN_BWD_ROWS
+
+
+def ln_partials(M, D, n_arrays, device):
+    """Workspace for the ordered LayerNorm-gradient reduction (None in the default atomic mode)."""
+    if not _deterministic[0]:
+        return None
+    return torch.empty(((M + LN_BWD_ROWS - 1) // LN_BWD_ROWS) * n_arrays * D, dtype=torch.float32,
+                       device=device)
 
 
 def _ws_args(dev):
@@ -108,7 +122,7 @@ def _gelu_bwd(dy2, pre, p_drop=0.0, salt=0):
 def _colsum(X, M, N, out, accumulate=False):
     lib = _lib.load()
     with torch.cuda.device(X.device):
-        rc = lib.msr3d_colsum_f32(M, N, _p(X), N, _p(out), int(accumulate),
+        rc = lib.msr3d_colsum_f32(M, N, _p(X), N, _p(out), int(accumulate) | (2 if _deterministic[0] else 0),
                                   _lib.current_stream_ptr(X.device))
     _lib.check(rc, "msr3d_colsum_f32")
 
@@ -446,7 +460,8 @@ class _DropoutAddLN(torch.autograd.Function):
         with torch.cuda.device(dy.device):
             rc = lib.msr3d_dropout_add_ln_bwd(M, D, _p(dy2), _p(s), _p(stats), _p(gamma),
                                               ctypes.c_float(p_drop), _p(seed), salt, _p(da), _p(dr), 0,
-                                              _p(dg), _p(db), _lib.current_stream_ptr(dy.device))
+                                              _p(dg), _p(db), _p(ln_partials(M, D, 2, dy.device)),
+                                              _lib.current_stream_ptr(dy.device))
         _lib.check(rc, "msr3d_dropout_add_ln_bwd")
         ga = da.view(shape) if da is not None else None
         gr = (ga if same else (dr.view(shape) if dr is not None else None))
