@@ -1,6 +1,7 @@
 """A/B timing of msr3d_sa_level across alternative builds of sa_fused.hip
 (tools/_prof/lib*.so), interleaved in one process.
-    python tools/ab_sa2.py <level> "<glob>" """
+    python tools/ab_sa2.py <level> "<glob>"      (default glob: libsa*.so; build variants with e.g.
+    hipcc ... -DMSR3D_SA2_CPB=4 -shared -o tools/_prof/libsa_cpb4.so msr3d_amd/csrc/sa_fused.hip)"""
 import ctypes
 import glob
 import os
@@ -14,7 +15,7 @@ from msr3d_amd.pointnet2 import fused  # noqa: E402
 from msr3d_amd.synth import synth_batch  # noqa: E402
 
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-pat = sys.argv[2] if len(sys.argv) > 2 else "lib*.so"
+pat = sys.argv[2] if len(sys.argv) > 2 else "libsa*.so"
 torch.manual_seed(0)
 net = PointNetPP(sa_n_points=[32, 16, None], sa_n_samples=[32, 32, None], sa_radii=[0.2, 0.4, None],
                  sa_mlps=[[3, 64, 64, 128], [128, 128, 128, 256], [256, 256, 512, 768]]).cuda().eval()
