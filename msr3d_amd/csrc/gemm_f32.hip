@@ -35,7 +35,12 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int BK = 32;
-constexpr int LD_KC = BK + 8;    // [TR][40]: stride/4 == 2 (mod 4) -> conflict-free ds_read_b128 fragments
+// [TR][36]: 16 consecutive rows start 36 floats apart = banks {0,36,8,44,...} mod 64, sixteen distinct
+// multiples of 4 -> a 16-lane ds_read_b128 phase covers all 64 banks once.  (A stride of 40 is
+// conflict-free too but makes the 64x64 double buffer exactly 40 KB, i.e. 4 x 40 KB = ALL of the
+// CU's LDS: with the kernel's few static bytes only 3 workgroups fitted; at 36 KB four do, and the
+// kernel is held to 128 registers so that four waves per SIMD are resident: 2.45 -> 2.35 ms/step.)
+constexpr int LD_KC = BK + 4;
 
 __host__ __device__ constexpr int ld_mc(int tr) { return tr + 4; }   // [32][TR+4]: half-waves on disjoint banks
 __host__ __device__ constexpr int tile_floats(int tr) { return tr * LD_KC; }   // >= 32 * (tr + 4) for tr >= 64
@@ -349,14 +354,14 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int bx, const in
 }
 
 template <bool A_KC, bool B_KC, int RM, int RN>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_f32_kernel(const GemmP p) {
   gemm_body<A_KC, B_KC, RM, RN>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Both backward products of a linear layer in ONE launch: dx = dy W (first p1's workgroups) and
 // dW += dy^T x, db += colsum(dy) (then p2's).  They are independent, each too small to fill the
 // chip, and every launch inside the captured graph costs ~5 us whatever it does.
-__global__ __launch_bounds__(256) void gemm_linear_bwd_kernel(const GemmP p1, const GemmP p2) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_linear_bwd_kernel(const GemmP p1, const GemmP p2) {
   int id = blockIdx.x;
   const int n1 = p1.gx * p1.gy * p1.gz;
   if (id < n1) {
