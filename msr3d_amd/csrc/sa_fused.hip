@@ -297,12 +297,12 @@ __device__ __forceinline__ void wave_ball_query(const float *sx, int n, float cx
 
 // =================================================================================
 // Level 1: points (b, n, 6) = [xyz, rgb] as the dataset stores them; centres (b, m, 3).
-// Block = 4 centres x 32 neighbours = 128 rows.  MLP 6 -> 64 -> 64 -> 128.
-// out: (b, m, 128) point-major.
+// Block = CPB centres x 32 neighbours (default 2 -> 64 rows).  MLP 6 -> 64 -> 64 -> 128.  The ball
+// query runs as its own launch and hands its indices over in `ball_idx`.  out: (b, m, 128) point-major.
 // =================================================================================
 constexpr int kNS = 32;   // neighbours per centre in both query levels (configs/msr3d.yaml:199)
-// CPB centres per block: 4 -> 128-row tile, one block per CU (LDS 87 KB); 2 -> 64-row tile, three
-// blocks per CU, so one block's ball-query / gather phase hides under the others' MFMA phases.
+// CPB centres per block: 2 -> 64-row tile, 37 KB of LDS and 102 registers: four blocks per CU, so one
+// block's gather phase hides under the others' MFMA phases (4 -> 128-row tile, two per CU: 298 vs 305 us).
 template <int CPB> struct Sa1 { using C = Chain<CPB * kNS, 16, 64, 64, 128, kNS, 2, 2>; };
 
 template <int CPB>
