@@ -109,9 +109,14 @@ int msr3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_o
  * pts (b, n, point_stride) (xyz = the first 3 floats of each point row; stride 6 reads the
  * dataset's xyz+rgb rows in place), level 2 picks m2 (<= m1 <= 64; 0 = skip) of those m1.
  * idx1 (b,m1) / idx2 (b,m2) are optional (NULL); new_xyz1 (b,m1,3) / new_xyz2 (b,m2,3) are
- * the gathered centroids.  Same bit-exact semantics as msr3d_furthest_point_sampling. */
+ * the gathered centroids.  Same bit-exact semantics as msr3d_furthest_point_sampling.
+ * valid (b bytes, may be NULL): objects with valid[i] == 0 are skipped -- their outputs are left
+ * untouched here and in msr3d_sa_level (the dataset pads scenes to 60 objects with a constant
+ * cloud, /root/reference/data/datasets/dataset_wrapper.py:156-158, whose feature the caller
+ * computes once instead of once per padding slot). */
 int msr3d_sa_fps2(int b, int n, int point_stride, int m1, int m2, const float *pts, int *idx1,
-                  float *new_xyz1, int *idx2, float *new_xyz2, msr3d_stream_t stream);
+                  float *new_xyz1, int *idx2, float *new_xyz2, const unsigned char *valid,
+                  msr3d_stream_t stream);
 
 /* One fused level.  `dims` = {C_in(+3), C1, C2, C3} must be one of the shipped
  * configurations (configs/msr3d.yaml:198-201) else MSR3D_EINVAL:
@@ -125,12 +130,14 @@ int msr3d_sa_fps2(int b, int n, int point_stride, int m1, int m2, const float *p
  * paramsL: layer L packed by the host as [N][KP + MSR3D_SA_WPAD] weight rows (K order: level 1
  * [dxyz,rgb], levels 2/3 [feat, (d)xyz]; zero-padded to KP = 16 / 144 / 272 for the first
  * layer, KP = K otherwise; the extra MSR3D_SA_WPAD floats per row are padding), then
- * scale[N], shift[N] (the eval-mode BN affine).  ball_idx (b,m,32): optional output at level 2. */
+ * scale[N], shift[N] (the eval-mode BN affine).  ball_idx (b,m,32): optional output at level 2.
+ * valid: as in msr3d_sa_fps2 (level 3 handles two objects per workgroup: a padding object sharing
+ * a workgroup with a valid one is computed too). */
 #define MSR3D_SA_WPAD 16
 int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pts,
                    const float *feat, const float *new_xyz, const int *dims,
                    const float *params1, const float *params2, const float *params3, float *out,
-                   int *dbg_ball_idx, msr3d_stream_t stream);
+                   int *dbg_ball_idx, const unsigned char *valid, msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Token GEMMs of the trainable part (situated encoder, projector): the nn.Linear calls of

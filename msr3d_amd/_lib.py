@@ -61,9 +61,9 @@ _SIGNATURES = {
                                    _ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_adamw_flat": [ctypes.c_longlong, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_float,
                          _c_float, _c_float, _c_float, _c_float, _c_int, _c_int, _c_int, _c_int, _ptr],
-    "msr3d_sa_fps2": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_sa_fps2": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_sa_level": [_c_int, _c_int, _c_int, _c_int, _c_float, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
-                       _ptr, _ptr, _ptr, _ptr],
+                       _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_segment_scan": [_c_int, _ptr, _ptr, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_preprocess_pcd": [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, ctypes.c_ulonglong,
                              _ptr, _ptr, _ptr, _ptr, _ptr],

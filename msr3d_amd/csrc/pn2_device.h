@@ -181,7 +181,9 @@ template <int PPT, int NW, bool STAGE>
 __global__ __launch_bounds__(kWave * NW) void fps_kernel(
     int n, int ps, int m, int bs, int log2bs, int q, const float *__restrict__ pts,
     int *__restrict__ idxs, float *__restrict__ new_xyz,
-    int m2, int bs2, int log2bs2, int *__restrict__ idxs2, float *__restrict__ new_xyz2) {
+    int m2, int bs2, int log2bs2, int *__restrict__ idxs2, float *__restrict__ new_xyz2,
+    const unsigned char *__restrict__ valid) {
+  if (valid && !valid[blockIdx.x]) return;                // padding object: nothing downstream reads it
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int *red_bits = reinterpret_cast<int *>(smem);          // [2][NW]
   int *red_k = red_bits + 2 * NW;                         // [2][NW]
@@ -214,7 +216,7 @@ constexpr size_t kFpsLdsFixed(int NW) { return sizeof(int) * 4 * NW + sizeof(flo
 template <int PPT, int NW>
 inline hipError_t launch_fps(int b, const FpsShape &s, int ps, int m, const float *pts, int *idx,
                              float *new_xyz, int m2, int *idx2, float *new_xyz2,
-                             hipStream_t st) {
+                             hipStream_t st, const unsigned char *valid) {
   const size_t cloud = (size_t)s.n * ps * sizeof(float);
   const bool stage = cloud <= 64 * 1024;
   int bs2 = 1, log2bs2 = 0;
@@ -225,10 +227,10 @@ inline hipError_t launch_fps(int b, const FpsShape &s, int ps, int m, const floa
   }
   if (stage) {
     fps_kernel<PPT, NW, true><<<b, kWave * NW, kFpsLdsFixed(NW) + cloud, st>>>(
-        s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, bs2, log2bs2, idx2, new_xyz2);
+        s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, bs2, log2bs2, idx2, new_xyz2, valid);
   } else {
     fps_kernel<PPT, NW, false><<<b, kWave * NW, kFpsLdsFixed(NW), st>>>(
-        s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, bs2, log2bs2, idx2, new_xyz2);
+        s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, bs2, log2bs2, idx2, new_xyz2, valid);
   }
   return hipGetLastError();
 }
@@ -236,11 +238,11 @@ inline hipError_t launch_fps(int b, const FpsShape &s, int ps, int m, const floa
 // Dispatch on the number of rank slots.  Returns hipErrorInvalidValue above 32768 slots.
 inline hipError_t dispatch_fps(int b, int n, int ps, int m, const float *pts, int *idx,
                                float *new_xyz, int m2, int *idx2, float *new_xyz2,
-                               hipStream_t st) {
+                               hipStream_t st, const unsigned char *valid = nullptr) {
   const FpsShape s = fps_shape(n);
   if (m2 > 0 && (m > 64 || m2 > m)) return hipErrorInvalidValue;
 #define MSR3D_FPS(PPT, NW) \
-  return launch_fps<PPT, NW>(b, s, ps, m, pts, idx, new_xyz, m2, idx2, new_xyz2, st)
+  return launch_fps<PPT, NW>(b, s, ps, m, pts, idx, new_xyz, m2, idx2, new_xyz2, st, valid)
   // (measured: 4 waves x 4 points/lane per cloud times the same as 1 wave x 16 at 960 clouds --
   // the iteration is a dependent chain scan -> reduce -> readlane -> LDS read, not VALU-bound)
   if (s.slots <= 64) MSR3D_FPS(1, 1);
@@ -267,7 +269,9 @@ __global__ __launch_bounds__(kWave * NW) void ball_query_kernel(int n, int m, fl
                                                                 int nsample,
                                                                 const float *__restrict__ new_xyz,
                                                                 const float *__restrict__ xyz,
-                                                                int ps, int *__restrict__ idx) {
+                                                                int ps, int *__restrict__ idx,
+                                                                const unsigned char *__restrict__ valid) {
+  if (valid && !valid[blockIdx.x]) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *sx = reinterpret_cast<float *>(smem);
   const int obj = blockIdx.x;
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(kWave * NW) void ball_query_kernel(int n, int m, fl
 
 inline hipError_t launch_ball_query(int b, int n, int ps, int m, float radius2, int nsample,
                                     const float *new_xyz, const float *xyz, int *idx,
-                                    hipStream_t st) {
+                                    hipStream_t st, const unsigned char *valid = nullptr) {
   constexpr int NW = 4;
   int ysplit = (1024 + b - 1) / b;          // enough blocks to cover 256 CUs at small b
   const int ymax = (m + NW - 1) / NW;
@@ -326,10 +330,10 @@ inline hipError_t launch_ball_query(int b, int n, int ps, int m, float radius2, 
   const bool stage = (size_t)n * 12 <= 64 * 1024;
   if (stage) {
     ball_query_kernel<NW, true><<<grid, kWave * NW, (size_t)n * 12, st>>>(n, m, radius2, nsample,
-                                                                         new_xyz, xyz, ps, idx);
+                                                                         new_xyz, xyz, ps, idx, valid);
   } else {
     ball_query_kernel<NW, false><<<grid, kWave * NW, 0, st>>>(n, m, radius2, nsample, new_xyz, xyz,
-                                                              ps, idx);
+                                                              ps, idx, valid);
   }
   return hipGetLastError();
 }

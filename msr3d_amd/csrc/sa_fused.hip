@@ -309,7 +309,9 @@ template <int CPB>
 __global__ __launch_bounds__(256) void sa1_kernel(int n, int m, const float *__restrict__ pts,
                                                   const float *__restrict__ new_xyz,
                                                   const int *__restrict__ ball_idx, Layer l1,
-                                                  Layer l2, Layer l3, float *__restrict__ out) {
+                                                  Layer l2, Layer l3, float *__restrict__ out,
+                                                  const unsigned char *__restrict__ valid) {
+  if (valid && !valid[blockIdx.y]) return;          // padding object (see msr3d_sa_level)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using Chain1 = typename Sa1<CPB>::C;
   constexpr int TM = CPB * kNS;
@@ -367,7 +369,9 @@ __global__ __launch_bounds__(256 * NG) void sa2_kernel(int n, int m, float radiu
                                                        const float *__restrict__ feat,
                                                        const float *__restrict__ new_xyz, Layer l1,
                                                        Layer l2, Layer l3, float *__restrict__ out,
-                                                       int *__restrict__ dbg_idx) {
+                                                       int *__restrict__ dbg_idx,
+                                                       const unsigned char *__restrict__ valid) {
+  if (valid && !valid[blockIdx.y]) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using Chain2 = typename Sa2<CPB>::C;
   constexpr int TM = CPB * kNS;
@@ -475,7 +479,12 @@ struct Chain3Cfg {
 
 __global__ __launch_bounds__(256) void sa3_kernel(int b, const float *__restrict__ xyz,
                                                   const float *__restrict__ feat, Layer l1,
-                                                  Layer l2, Layer l3, float *__restrict__ out) {
+                                                  Layer l2, Layer l3, float *__restrict__ out,
+                                                  const unsigned char *__restrict__ valid) {
+  if (valid) {      // both objects of the block are padding: skip (one valid: the other rides along)
+    const int o0 = blockIdx.x * 2;
+    if (!valid[o0] && !(o0 + 1 < b && valid[o0 + 1])) return;
+  }
   using C = Chain3Cfg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *bufX = reinterpret_cast<float *>(smem);
@@ -564,19 +573,20 @@ inline hipError_t allow_lds(K kernel, size_t bytes) {
 extern "C" {
 
 int msr3d_sa_fps2(int b, int n, int point_stride, int m1, int m2, const float *pts, int *idx1,
-                  float *new_xyz1, int *idx2, float *new_xyz2, msr3d_stream_t stream) {
+                  float *new_xyz1, int *idx2, float *new_xyz2, const unsigned char *valid,
+                  msr3d_stream_t stream) {
   if (b < 0 || n <= 0 || m1 <= 0 || m2 < 0 || point_stride < 3) return MSR3D_EINVAL;
   if (b == 0) return 0;
   if (!pts) return MSR3D_EINVAL;
   const hipError_t e = dispatch_fps(b, n, point_stride, m1, pts, idx1, new_xyz1, m2, idx2,
-                                    new_xyz2, (hipStream_t)stream);
+                                    new_xyz2, (hipStream_t)stream, valid);
   return e == hipErrorInvalidValue ? MSR3D_EINVAL : (int)e;
 }
 
 int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pts,
                    const float *feat, const float *new_xyz, const int *dims,
                    const float *params1, const float *params2, const float *params3, float *out,
-                   int *dbg_ball_idx, msr3d_stream_t stream) {
+                   int *dbg_ball_idx, const unsigned char *valid, msr3d_stream_t stream) {
   if (b < 0 || !dims) return MSR3D_EINVAL;
   if (b == 0) return 0;
   if (!params1 || !params2 || !params3 || !out) return MSR3D_EINVAL;
@@ -591,7 +601,7 @@ int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pt
     // ball_idx (required here: it is this level's workspace), then gather + MLP + max.  Keeping
     // the query out of the MLP kernel leaves it 37 KB of LDS -> 4 blocks per CU.
     if (!dbg_ball_idx) return MSR3D_EINVAL;
-    if ((e = launch_ball_query(b, n, 6, m, r2, kNS, new_xyz, pts, dbg_ball_idx, st)) != hipSuccess)
+    if ((e = launch_ball_query(b, n, 6, m, r2, kNS, new_xyz, pts, dbg_ball_idx, st, valid)) != hipSuccess)
       return (int)e;
     constexpr int CPB = MSR3D_SA1_CPB;
     const size_t lds = sizeof(float) * Sa1<CPB>::C::LDS_FLOATS;
@@ -599,7 +609,7 @@ int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pt
     dim3 grid((m + CPB - 1) / CPB, b);
     sa1_kernel<CPB><<<grid, 256, lds, st>>>(n, m, pts, new_xyz, dbg_ball_idx,
                                             make_layer(params1, 64, 16), make_layer(params2, 64, 64),
-                                            make_layer(params3, 128, 64), out);
+                                            make_layer(params3, 128, 64), out, valid);
   } else if (level == 2) {
     // pts = xyz (b,n,3), feat (b,n,128); dims = {131, 128, 128, 256}
     if (!(dims[0] == 131 && dims[1] == 128 && dims[2] == 128 && dims[3] == 256)) return MSR3D_EINVAL;
@@ -611,7 +621,8 @@ int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pt
     sa2_kernel<CPB, NG><<<grid, 256 * NG, lds, st>>>(n, m, r2, pts, feat, new_xyz,
                                                      make_layer(params1, 128, 144),
                                                      make_layer(params2, 128, 128),
-                                                     make_layer(params3, 256, 128), out, dbg_ball_idx);
+                                                     make_layer(params3, 256, 128), out, dbg_ball_idx,
+                                                     valid);
   } else if (level == 3) {
     // group-all over n = 16 points: pts = xyz (b,16,3), feat (b,16,256); dims = {259,256,512,768}
     if (!(dims[0] == 259 && dims[1] == 256 && dims[2] == 512 && dims[3] == 768)) return MSR3D_EINVAL;
@@ -620,7 +631,7 @@ int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pt
     if ((e = allow_lds(sa3_kernel, lds)) != hipSuccess) return (int)e;
     sa3_kernel<<<(b + 1) / 2, 256, lds, st>>>(b, pts, feat, make_layer(params1, 256, 272),
                                               make_layer(params2, 512, 256),
-                                              make_layer(params3, 768, 512), out);
+                                              make_layer(params3, 768, 512), out, valid);
   } else {
     return MSR3D_EINVAL;
   }

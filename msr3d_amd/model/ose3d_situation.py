@@ -116,16 +116,19 @@ class OSE3DSituation(BaseModel):
         return next(self.parameters()).device
 
     # ------------------------------------------------------------------ pieces
-    def encode_objects(self, obj_fts):
+    def encode_objects(self, obj_fts, obj_masks=None):
         """Frozen/eval backbone features (B,O,768).  Uses the encoder's `embed` (no dead
-        classification head) when it has one, else `forward(...)[0]` like the reference."""
+        classification head) when it has one, else `forward(...)[0]` like the reference.
+        obj_masks only matters to an encoder with `skip_padded` set."""
         enc = self.obj_encoder
-        return enc.embed(obj_fts) if hasattr(enc, "embed") else enc(obj_fts)[0]
+        if hasattr(enc, "embed"):
+            return enc.embed(obj_fts, obj_masks) if getattr(enc, "skip_padded", False) else enc.embed(obj_fts)
+        return enc(obj_fts)[0]
 
     def forward_gtpcd(self, data_dict):
         embeds = data_dict.get("obj_embeds")          # precomputed by a split (graphed) step
         if embeds is None:
-            embeds = self.encode_objects(data_dict["obj_fts"])
+            embeds = self.encode_objects(data_dict["obj_fts"], data_dict.get("obj_masks"))
         return hipops.module_linear(self.obj_linear_projection, embeds)
 
     def _with_anchor_token(self, data_dict, feat, mask, loc, type_emb, ori_feat):

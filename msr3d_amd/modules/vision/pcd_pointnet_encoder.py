@@ -38,20 +38,27 @@ class PcdObjEncoder(nn.Module):
         for bn in (l for l in m.modules() if isinstance(l, nn.BatchNorm2d)):
             bn.eval()
 
-    def encode(self, obj_pcds):
+    # Opt-in: do not re-encode padding slots.  The dataset pads every scene to 60 objects with one
+    # constant cloud (dataset_wrapper.py:156-158) and the reference encodes it again in every slot;
+    # with `skip_padded` and `obj_masks` given, masked slots receive the (cached) feature of that
+    # cloud instead -- identical values as long as masked slots hold the padding cloud.
+    skip_padded = False
+
+    def encode(self, obj_pcds, obj_masks=None):
         """(B, O, P, C) -> (B, O, D): objects are independent clouds for the backbone."""
         B, O, P, C = obj_pcds.shape
-        return self.pcd_net(obj_pcds.reshape(B * O, P, C)).reshape(B, O, -1)
+        valid = obj_masks.reshape(B * O) if (self.skip_padded and obj_masks is not None) else None
+        return self.pcd_net(obj_pcds.reshape(B * O, P, C), valid=valid).reshape(B, O, -1)
 
-    def embed(self, obj_pcds):
+    def embed(self, obj_pcds, obj_masks=None):
         """obj_embeds only: what OSE3DSituation consumes (it takes `[0]` of forward and
         discards the 607-way logits, ose3d_situation.py:285), without the dead head."""
         if not self.freeze:
-            return self.encode(obj_pcds)
+            return self.encode(obj_pcds, obj_masks)
         self.freeze_bn(self.pcd_net)
         with torch.no_grad():
-            return self.encode(obj_pcds).detach()
+            return self.encode(obj_pcds, obj_masks).detach()
 
     def forward(self, obj_pcds, obj_locs=None, obj_masks=None, obj_sem_masks=None, **kwargs):
-        obj_embeds = self.embed(obj_pcds)
+        obj_embeds = self.embed(obj_pcds, obj_masks)
         return obj_embeds, self.obj3d_clf_pre_head(obj_embeds)

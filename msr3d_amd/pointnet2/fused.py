@@ -108,12 +108,34 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
 
 
-def forward(net, pts, return_internals=False):
-    """pts (b, P, 6) f32 contiguous -> (b, 768).  Four kernel launches + one GEMM."""
+PAD_VALUE = 1.0       # the dataset wrapper's padding cloud (dataset_wrapper.py:156-158)
+
+
+def padding_feature(net, n_points, device):
+    """Encoder output of the padding cloud (every coordinate and colour = 1.0), computed once per
+    weight version and point count: what every padded object slot encodes to."""
+    plan = get_plan(net)
+    cache = plan.setdefault("pad_feat", {})
+    key = (int(n_points), str(device))
+    if key not in cache:
+        ones = torch.full((1, n_points, 6), PAD_VALUE, dtype=torch.float32, device=device)
+        cache[key] = forward(net, ones)[0].clone()
+    return cache[key]
+
+
+def forward(net, pts, return_internals=False, valid=None):
+    """pts (b, P, 6) f32 contiguous -> (b, 768).  Four kernel launches + one GEMM.
+    valid (b,) bool, optional: objects marked False are PADDING slots holding the constant cloud;
+    the kernels skip them and their rows receive `padding_feature` -- the same values the encoder
+    would produce, without encoding the same cloud once per slot."""
     pts = pts.contiguous()
     b, n, _ = pts.shape
     dev = pts.device
     plan = get_plan(net)
+    vmask = None
+    if valid is not None:
+        pad_feat = padding_feature(net, n, dev)
+        vmask = valid.reshape(b).contiguous().view(torch.uint8)
     lib = _lib.load()
     sa1, sa2, _ = net.encoder
     m1, m2 = sa1.npoint, sa2.npoint
@@ -133,25 +155,31 @@ def forward(net, pts, return_internals=False):
         st = _lib.current_stream_ptr(dev)
         with _lib.kernel_timer("msr3d_sa_fps2"):
             rc = lib.msr3d_sa_fps2(b, n, 6, m1, m2, _p(pts), _p(dbg.get("idx1")), _p(new1),
-                                   _p(dbg.get("idx2")), _p(new2), st)
+                                   _p(dbg.get("idx2")), _p(new2), _p(vmask), st)
         _lib.check(rc, "msr3d_sa_fps2")
         L = plan["levels"]
         with _lib.kernel_timer("msr3d_sa_level1"):
             rc = lib.msr3d_sa_level(1, b, n, m1, ctypes.c_float(sa1.groupers[0].radius), _p(pts),
                                     _p(None), _p(new1), plan["dims"][0], _p(L[0][0]), _p(L[0][1]),
-                                    _p(L[0][2]), _p(feat1), _p(ball1), st)
+                                    _p(L[0][2]), _p(feat1), _p(ball1), _p(vmask), st)
         _lib.check(rc, "msr3d_sa_level(1)")
         with _lib.kernel_timer("msr3d_sa_level2"):
             rc = lib.msr3d_sa_level(2, b, m1, m2, ctypes.c_float(sa2.groupers[0].radius), _p(new1),
                                     _p(feat1), _p(new2), plan["dims"][1], _p(L[1][0]), _p(L[1][1]),
-                                    _p(L[1][2]), _p(feat2), _p(dbg.get("ball2")), st)
+                                    _p(L[1][2]), _p(feat2), _p(dbg.get("ball2")), _p(vmask), st)
         _lib.check(rc, "msr3d_sa_level(2)")
         with _lib.kernel_timer("msr3d_sa_level3"):
             rc = lib.msr3d_sa_level(3, b, m2, 1, ctypes.c_float(0.0), _p(new2), _p(feat2),
                                     _p(None), plan["dims"][2], _p(L[2][0]), _p(L[2][1]),
-                                    _p(L[2][2]), _p(pooled), _p(None), st)
+                                    _p(L[2][2]), _p(pooled), _p(None), _p(vmask), st)
         _lib.check(rc, "msr3d_sa_level(3)")
+    if vmask is not None:
+        # skipped rows of `pooled` are uninitialised memory: neutralise them before the GEMM (a NaN
+        # would be harmless -- rows are independent -- but Inf * 0 noise in debuggers is not)
+        pooled = torch.where(valid.reshape(b, 1), pooled, torch.zeros((), device=dev))
     out = F.linear(pooled, net.fc.weight, net.fc.bias)
+    if vmask is not None:
+        out = torch.where(valid.reshape(b, 1), out, pad_feat)
     if return_internals:
         dbg.update(new_xyz1=new1, new_xyz2=new2, feat1=feat1, feat2=feat2, pooled=pooled)
         return out, dbg

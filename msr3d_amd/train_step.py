@@ -107,7 +107,7 @@ class HotPathTrainStep:
         """Run the frozen encoder for `batch` NOW on the compute stream; the step that later
         receives this batch finds its features ready (same hand-over as prefetch())."""
         with torch.no_grad():
-            self._pref["feats"].copy_(self.prompter.encode_objects(batch["obj_fts"]))
+            self._pref["feats"].copy_(self.prompter.encode_objects(batch["obj_fts"], batch.get("obj_masks")))
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self._pref["key"], self._pref["event"] = id(batch["obj_fts"]), ev
@@ -120,7 +120,7 @@ class HotPathTrainStep:
         self._enc_stream.wait_stream(main)          # inputs exist; previous prefetch consumed
         # (the encoder's fc GEMM runs concurrently with the main stream's: its own split-K workspace)
         with torch.cuda.stream(self._enc_stream), torch.no_grad(), hipops.gemm_lane(1):
-            self._pref["feats"].copy_(self.prompter.encode_objects(batch["obj_fts"]))
+            self._pref["feats"].copy_(self.prompter.encode_objects(batch["obj_fts"], batch.get("obj_masks")))
             ev = torch.cuda.Event()
             ev.record(self._enc_stream)
         self._pref["key"], self._pref["event"] = id(batch["obj_fts"]), ev
@@ -132,7 +132,7 @@ class HotPathTrainStep:
                 self.static["obj_embeds"].copy_(self._pref["feats"])
                 self._pref["key"] = None
             else:
-                self.static["obj_embeds"].copy_(self.prompter.encode_objects(batch["obj_fts"]))
+                self.static["obj_embeds"].copy_(self.prompter.encode_objects(batch["obj_fts"], batch.get("obj_masks")))
             for k, v in self.static.items():
                 if k != "obj_embeds":
                     v.copy_(batch[k])

@@ -104,3 +104,35 @@ def test_fused_falls_back_when_backbone_trains():
     out = net(pts)                                 # composite path, autograd works
     out.sum().backward()
     assert net.encoder[0].mlps[0][0][0].weight.grad is not None
+
+
+def test_padding_slots_skipped_gives_identical_features():
+    """`skip_padded`: masked slots (the dataset's constant padding cloud) are not encoded again;
+    every row -- real objects and padding -- is bit-identical to the full encoding, for mask
+    patterns incl. all-valid, all-padding, odd/even pairs (level 3 shares a workgroup between two
+    objects)."""
+    import msr3d_amd.modules  # noqa: F401
+    from msr3d_amd.modules.vision.pcd_pointnet_encoder import PcdObjEncoder
+    from msr3d_amd.synth import synth_batch
+    from tests.helpers import fill_state_dict
+    enc = PcdObjEncoder(None, freeze=True)
+    enc.load_state_dict(fill_state_dict(enc.state_dict(), 4))
+    enc = enc.cuda().eval()
+    batch = synth_batch(17, 4, O=15, P=1024, n_valid=[15, 0, 7, 8], device="cuda")
+    fts, masks = batch["obj_fts"], batch["obj_masks"]
+    assert masks.sum(1).tolist() == [15, 0, 7, 8]
+    full = enc.embed(fts)
+    enc.skip_padded = True
+    got = enc.embed(fts, masks)
+    assert torch.equal(got, full)
+    # interleaved pattern (padding between real objects) on real data only in the valid slots
+    m2 = masks.clone()
+    m2[0, ::2] = False
+    f2 = fts.clone()
+    f2[0, ::2] = 1.0
+    enc.skip_padded = False
+    want = enc.embed(f2)
+    enc.skip_padded = True
+    assert torch.equal(enc.embed(f2, m2), want)
+    # without masks the flag changes nothing
+    assert torch.equal(enc.embed(fts), full)
