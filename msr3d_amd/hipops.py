@@ -1,8 +1,9 @@
 """Autograd-level ops of the trainable part, over the C ABI (include/msr3d_hip.h).
 
 `linear` is nn.Linear's functional form on the HIP f32-MFMA GEMM (msr3d_gemm_f32): forward
-y = x W^T + b [+ GELU], backward dx = dy W, dW = dy^T x, db = colsum(dy) -- three launches of
-the same kernel reading x / W / dy in place.  GPU fp32 tensors take the HIP kernels; CPU
+y = x W^T + b [+ GELU] [+ dropout], backward dx = dy W, dW = dy^T x, db = colsum(dy) -- the same
+kernel body reading x / W / dy in place; dx and dW+db share one launch when the gradients live in
+the flat buffer of the data-parallel engine.  GPU fp32 tensors take the HIP kernels; CPU
 tensors (the host-logic unit tests) take torch's own ops.  There is no silent GPU fallback:
 a GPU tensor either runs the HIP kernel or raises.
 """

@@ -1,21 +1,26 @@
 """The hot-path training step as the GPU sees it:
 
-    [eager]  frozen PointNet++ encoder: 4 fused HIP launches + the fc GEMM  (obj_fts -> (B,O,768))
+    [eager]  frozen PointNet++ encoder: FPS, ball query, three fused set-abstraction launches and
+             the fc GEMM  (obj_fts -> (B,O,768)), then the inputs are copied into static buffers
     [graph]  zero grads -> prompter forward from the encoder features -> llm_proj -> loss
-             -> backward -> bucketed RCCL all-reduce on the side stream -> clip -> AdamW
+             -> backward -> clip -> AdamW                      (one GPU: ~95 kernels, one submission)
+    world > 1 or gradient accumulation: the graph holds forward/backward of one micro-batch; zeroing,
+             the RCCL all-reduce of the flat gradient buffer and the 3-launch optimiser are issued
+             eagerly around it (no host-driven collective inside a graph)
 
-The trainable part is ~700 small launches per step when issued eagerly (host-bound: ~12 us
-each); captured once into a HIP graph it replays as one submission.  The encoder stays
-eager: it is five launches, and keeping it outside the graph lets bench.py time its
-kernels with HIP events inside the timed region.
+Issued eagerly the trainable part is host-bound; captured once into a HIP graph it replays as one
+submission and the host runs ahead of the GPU (tools/gap_probe.py).  The encoder stays eager:
+it is a handful of launches, and keeping it outside the graph lets bench.py time its kernels with
+HIP events inside the timed region.
 
-Software pipelining: the encoder is frozen, so the features of batch k+1 do not depend on
-the update of step k.  `step(batch, next_batch)` therefore runs the encoder for `next_batch`
-on a side HIP stream while the graph of `batch` replays on the main stream (the trainable part
-is a chain of small latency-bound kernels that leaves most of the chip idle; measured +6.5 %
-end to end -- the encoder's blocks hold most of the LDS, so the small kernels still queue
-behind them; CU-masked and priority streams measured worse).  Results are identical to the
-sequential order: every step still encodes and trains exactly one batch.
+The encoder is frozen, so the features of batch k+1 depend neither on the gradients nor on the
+update of step k.  `step(batch, next_batch)` uses that in two ways:
+  * one GPU: the encoder of `next_batch` runs on a side HIP stream while the graph of `batch`
+    replays (optional; +6 % end to end -- the trainable part is a chain of small latency-bound
+    kernels that leaves most of the chip idle; CU-masked and priority streams measured worse);
+  * data-parallel: it is issued on the compute stream between the start of the all-reduce and the
+    optimiser, so the exchange over xGMI is hidden behind 1.2 ms of independent work.
+Results are identical to the sequential order: every step still encodes and trains one batch.
 """
 import torch
 
