@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 2
+#define MSR3D_ABI_VERSION 3
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -206,12 +206,24 @@ int msr3d_gelu_bwd_f32(long long n, const float *dy, const float *pre, float *ou
  * ctx (B*L, H*dh); probs (B, H, L, L) (may be NULL in forward-only use).
  * Supported: L <= 128 (a 64-token tile for L <= 64, a 128-token tile above), dh = 32,
  * spatial_dim = 5; anything else -> MSR3D_EINVAL.
+ *
+ * mma: operand precision of the matrix products (QK^T, PV and the four backward products).
+ * Softmax, the spatial term and all accumulation are fp32 in every mode; inputs/outputs stay fp32.
+ *   MSR3D_MMA_F32   f32-input MFMA: the reference's arithmetic (autocast is disabled around the
+ *                   encoder, model/ose3d_situation.py:377).  Default of the host side.
+ *   MSR3D_MMA_BF16  operands rounded to bf16 (RNE) as they are fetched, bf16 MFMA, fp32 accumulate.
+ *   MSR3D_MMA_FP8   operands rounded to OCP e4m3, fp8 MFMA, fp32 accumulate; forward only
+ *                   (msr3d_spatial_attn_bwd returns MSR3D_EINVAL).
  * ------------------------------------------------------------------------- */
+#define MSR3D_MMA_F32 0
+#define MSR3D_MMA_BF16 1
+#define MSR3D_MMA_FP8 2
+
 int msr3d_spatial_attn_fwd(int B, int L, int H, int dh, int spatial_dim, const float *q,
                            const float *k, const float *v, int ld_qkv, const float *cond,
                            int ld_cond, const float *pairwise_locs,
                            const unsigned char *key_padding_mask, float *ctx, float *probs,
-                           msr3d_stream_t stream);
+                           int mma, msr3d_stream_t stream);
 
 /* Gradients w.r.t. q, k, v (token-major, ld_grad) and cond, given dctx (B*L, H*dh). */
 int msr3d_spatial_attn_bwd(int B, int L, int H, int dh, int spatial_dim, const float *q,
@@ -219,7 +231,7 @@ int msr3d_spatial_attn_bwd(int B, int L, int H, int dh, int spatial_dim, const f
                            int ld_cond, const float *pairwise_locs,
                            const unsigned char *key_padding_mask, const float *probs,
                            const float *dctx, float *dq, float *dk, float *dv, int ld_grad,
-                           float *dcond, int ld_dcond, msr3d_stream_t stream);
+                           float *dcond, int ld_dcond, int mma, msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Data-only front of the situated encoder (inputs are dataset tensors, no gradients).

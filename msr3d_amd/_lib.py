@@ -38,9 +38,9 @@ _SIGNATURES = {
     "msr3d_colsum_f32": [_c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr],
     "msr3d_gelu_bwd_f32": [ctypes.c_longlong, _ptr, _ptr, _ptr, _c_float, _ptr, ctypes.c_uint, _ptr],
     "msr3d_spatial_attn_fwd": [_c_int] * 5 + [_ptr, _ptr, _ptr, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr,
-                                              _ptr, _ptr],
+                                              _ptr, _c_int, _ptr],
     "msr3d_spatial_attn_bwd": [_c_int] * 5 + [_ptr, _ptr, _ptr, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr,
-                                              _ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _c_int, _ptr],
+                                              _ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _c_int, _c_int, _ptr],
     "msr3d_pairwise_locs": [_c_int, _c_int, _ptr, _c_int, _c_float, _ptr, _ptr],
     "msr3d_agent_fourier": [_c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr, _ptr],
     "msr3d_add_row_vectors": [_c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
@@ -77,6 +77,9 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string"] + list(_SIGNATURES)
 
 
+ABI_VERSION = 3        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -92,6 +95,10 @@ def load():
             f"msr3d_amd: cannot load {LIB_PATH} ({e}). Build it with `python -m msr3d_amd.build`; "
             "there is no CPU fallback.") from e
     lib.msr3d_abi_version.restype = _c_int
+    if lib.msr3d_abi_version() != ABI_VERSION:
+        raise ImportError(
+            f"msr3d_amd: {LIB_PATH} has ABI version {lib.msr3d_abi_version()}, this package binds "
+            f"version {ABI_VERSION} (include/msr3d_hip.h). Rebuild it with `python -m msr3d_amd.build`.")
     lib.msr3d_status_string.restype = ctypes.c_char_p
     lib.msr3d_status_string.argtypes = [_c_int]
     for name, argtypes in _SIGNATURES.items():

@@ -310,6 +310,31 @@ def module_linear(mod, x, gelu=False):
 # ---------------------------------------------------------------------------------------
 # fused spatial attention core ('cond' fusion)
 # ---------------------------------------------------------------------------------------
+# Operand precision of the attention kernels' matrix products (include/msr3d_hip.h, MSR3D_MMA_*).
+# "f32" is the reference's arithmetic and the default; "bf16" (forward + backward) and "fp8"
+# (OCP e4m3, forward only) are opt-in: MSR3D_ATTN_MMA=bf16 or set_attention_mma("bf16").
+ATTN_MMA = {"f32": 0, "bf16": 1, "fp8": 2}
+_attn_mma = [_os.environ.get("MSR3D_ATTN_MMA", "f32")]
+if _attn_mma[0] not in ATTN_MMA:
+    raise ValueError("MSR3D_ATTN_MMA must be one of %s" % sorted(ATTN_MMA))
+
+
+def set_attention_mma(name):
+    """Select the operand precision of QK^T / PV (and the backward products): 'f32' | 'bf16' | 'fp8'.
+    Returns the previous setting."""
+    if name not in ATTN_MMA:
+        raise ValueError("attention mma must be one of %s" % sorted(ATTN_MMA))
+    prev, _attn_mma[0] = _attn_mma[0], name
+    return prev
+
+
+def attention_mma(backward=False):
+    """The MSR3D_MMA_* code to pass to the kernels."""
+    if backward and _attn_mma[0] == "fp8":
+        raise RuntimeError("fp8 attention is forward-only (inference); train with 'f32' or 'bf16'")
+    return ATTN_MMA[_attn_mma[0]]
+
+
 class _SpatialAttnCond(torch.autograd.Function):
     """Operates on the PACKED projection output qkvc (B*L, 3D + H*6) = [q | k | v | cond]: the
     kernels read the four column blocks in place (leading dimension = packed width) and the
@@ -332,7 +357,7 @@ class _SpatialAttnCond(torch.autograd.Function):
             rc = lib.msr3d_spatial_attn_fwd(
                 B, L, n_head, dh, pl.shape[-1], ctypes.c_void_p(base), ctypes.c_void_p(base + D * fs),
                 ctypes.c_void_p(base + 2 * D * fs), W, ctypes.c_void_p(base + 3 * D * fs), W, _p(pl),
-                _p(pad), _p(out), _p(probs), _lib.current_stream_ptr(x.device))
+                _p(pad), _p(out), _p(probs), attention_mma(), _lib.current_stream_ptr(x.device))
         _lib.check(rc, "msr3d_spatial_attn_fwd")
         ctx.save_for_backward(x, pl, pad, probs)
         ctx.dims = (B, L, D, n_head, dh, W)
@@ -357,7 +382,8 @@ class _SpatialAttnCond(torch.autograd.Function):
             rc = lib.msr3d_spatial_attn_bwd(
                 B, L, H, dh, pl.shape[-1], vp(base), vp(base + D * fs), vp(base + 2 * D * fs), W,
                 vp(base + 3 * D * fs), W, _p(pl), _p(pad), _p(probs), _p(do), vp(gb), vp(gb + D * fs),
-                vp(gb + 2 * D * fs), W, vp(gb + 3 * D * fs), W, _lib.current_stream_ptr(do.device))
+                vp(gb + 2 * D * fs), W, vp(gb + 3 * D * fs), W, attention_mma(True),
+                _lib.current_stream_ptr(do.device))
         _lib.check(rc, "msr3d_spatial_attn_bwd")
         return g.view(B, L, W), None, None, None, None, None, None
 
