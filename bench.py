@@ -172,7 +172,17 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    # second test hook: MSR3D_BENCH_FORCE_DIST=1 with ONE rank initialises RCCL anyway and takes the
+    # multi-rank schedule (split graph, all-reduce on the communication stream hidden behind the
+    # next batch's encoder) over a one-rank communicator -- the real backend on a one-GPU box
+    dist_on = world > 1 or os.environ.get("MSR3D_BENCH_FORCE_DIST") == "1"
+    if dist_on and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ["MSR3D_DP_FORCE_EXCHANGE"] = "1"
+    if dist_on:
         backend = os.environ.get("MSR3D_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -198,7 +208,7 @@ def main():
     # With several ranks the next batch is ALWAYS handed to the step: its frozen encoder is then
     # issued on the compute stream between the start of the gradient all-reduce and the optimiser,
     # which hides the exchange (msr3d_amd/train_step.py) -- no side stream, kernels do not share CUs.
-    pipe = args.pipeline or world > 1
+    pipe = args.pipeline or dist_on
 
     def nxt(i):
         return batches[(i + 1) % n_resident] if pipe else None
@@ -238,7 +248,7 @@ def main():
     timed = ["msr3d_sa_fps2", "msr3d_sa_level1", "msr3d_sa_level2", "msr3d_sa_level3"]
     sink = {k: [] for k in timed}
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     _lib.set_timing_sink(sink)
@@ -246,14 +256,14 @@ def main():
     for i in range(args.steps):
         tr.step(batches[(args.warmup + i) % n_resident], nxt(args.warmup + i))
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     _lib.set_timing_sink(None)
 
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -288,7 +298,7 @@ def main():
                        "hip_graph": not args.no_graph, "encoder_prefetch": args.pipeline,
                        "padded_slots_skipped": args.skip_padded,
                        "objects_encoded_per_step": objs_per_launch,
-                       "allreduce_hidden_behind_next_encoder": world > 1,
+                       "allreduce_hidden_behind_next_encoder": dist_on,
                        "inputs": ("built per step on the device from HBM-resident scans "
                                   "(msr3d_preprocess_pcd)" if args.from_store else "resident in HBM"),
                        "parallelism": f"dp{world}"},
@@ -304,7 +314,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -26,6 +26,8 @@ chosen large (default 8 MiB -> 3 buckets) so each collective is bandwidth- not
 latency-bound, while still letting the first (llm_proj) bucket fly during the prompter's
 backward.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -45,6 +47,12 @@ class FlatGradAllReduce:
         self.device = dev
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # `distributed`: the exchange path is taken.  MSR3D_DP_FORCE_EXCHANGE=1 takes it with a
+        # single rank too (an all-reduce over a one-rank communicator): the way to run the real
+        # RCCL + side-stream + graph-replay schedule on a box with one GPU
+        # (tests/test_bench_ranks_gpu.py)
+        self.distributed = self.world > 1 or (
+            dist.is_initialized() and os.environ.get("MSR3D_DP_FORCE_EXCHANGE") == "1")
         self.on_gpu = dev.type == "cuda"
 
         group_of = {}
@@ -96,7 +104,7 @@ class FlatGradAllReduce:
         # with producers that write the flat buffer directly (hipops).  overlap=True launches
         # each bucket from the gradient hooks as soon as it is complete instead.
         self.defer_comm = not overlap
-        if self.world > 1:
+        if self.distributed:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
@@ -114,7 +122,7 @@ class FlatGradAllReduce:
     def mark_ready(self, p):
         """A producer wrote p's gradient into the flat buffer directly (bypassing autograd's
         AccumulateGrad, hence its hook): same bookkeeping as the hook."""
-        if self.world > 1:
+        if self.distributed:
             self._on_grad(p)
 
     def _on_grad(self, p):
@@ -137,7 +145,7 @@ class FlatGradAllReduce:
             self._reduce(view)
 
     def _launch(self, b):
-        if self._launched[b] or self.world == 1:
+        if self._launched[b] or not self.distributed:
             return
         self._launched[b] = True
         s, e = self.buckets[b]
@@ -158,14 +166,14 @@ class FlatGradAllReduce:
 
     def wait(self):
         """The compute stream waits for the exchange started by start()."""
-        if self.world > 1 and self.on_gpu:
+        if self.distributed and self.on_gpu:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
 
     def start(self):
         """Launch the exchange on the communication stream and return: work that does not touch
         the gradients (the next batch's frozen encoder) can be enqueued on the compute stream
         before wait()."""
-        if self.world > 1:
+        if self.distributed:
             if self.defer_comm:
                 # nothing is in flight and nothing is left to overlap with: ONE collective over the
                 # whole buffer (21 MB) instead of one per bucket -- fewer launches, and a ring over

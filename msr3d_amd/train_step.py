@@ -163,7 +163,7 @@ class HotPathTrainStep:
         # between the captured forward/backward and the 3-launch optimiser) -- a handful of host
         # launches per step, and no dependence on collective capture support.
         # Gradient accumulation likewise: the graph holds one micro-batch's forward/backward.
-        self.split = self.dp.world > 1 or self.accum_steps > 1
+        self.split = self.dp.distributed or self.accum_steps > 1
         if self.split:
             self.dp.defer_comm = True
         # thread_local: other threads (RCCL's watchdog polling its events, loader threads) may keep
@@ -177,7 +177,7 @@ class HotPathTrainStep:
         (world > 1) on the compute stream right after backward, where it hides the gradient
         all-reduce."""
         self._load(batch)
-        hide_comm = next_batch is not None and self.dp.world > 1 and self.static["obj_embeds"].is_cuda
+        hide_comm = next_batch is not None and self.dp.distributed and self.static["obj_embeds"].is_cuda
         if next_batch is not None and not hide_comm:
             self.prefetch(next_batch)
         between = (lambda: self.encode_ahead(next_batch)) if hide_comm else None

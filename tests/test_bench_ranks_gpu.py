@@ -30,6 +30,22 @@ def test_bench_two_ranks_json_contract():
     assert "cpu_baseline" not in j                      # N=1 only
 
 
+def test_bench_multi_rank_schedule_over_rccl_with_one_rank():
+    """The multi-rank schedule on the REAL backend: RCCL communicator (one rank -- the box has one
+    GPU), all-reduce of the flat gradient buffer on the communication stream between the replayed
+    forward/backward graph and the optimiser, the next batch's encoder issued in between."""
+    env = dict(os.environ, MSR3D_BENCH_FORCE_DIST="1", MASTER_PORT="29672", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "3",
+                          "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 1 and j["config"]["parallelism"] == "dp1"
+    assert j["config"]["allreduce_hidden_behind_next_encoder"] is True and j["config"]["hip_graph"] is True
+    assert j["value"] > 0 and j["roofline"]["launches"] == 6
+
+
 def test_bench_single_rank_json_contract():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
                           "--batch", "2", "--cpu-baseline-seconds", "1"], cwd=ROOT,
