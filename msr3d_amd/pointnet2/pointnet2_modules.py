@@ -68,3 +68,32 @@ class PointnetSAModule(PointnetSAModuleMSG):
                  nsample: int = None, bn: bool = True, use_xyz: bool = True):
         super().__init__(mlps=[mlp], npoint=npoint, radii=[radius], nsamples=[nsample], bn=bn,
                          use_xyz=use_xyz)
+
+
+class PointnetFPModule(nn.Module):
+    """Feature propagation: carry `known_feats` (B, C2, m) from the `known` points (B, m, 3) to the
+    `unknown` points (B, n, 3) by inverse-distance weighting over the three nearest known points,
+    stack with the unknown points' own features and run the SharedMLP
+    (/root/reference/modules/third_party/pointnet2/pointnet2_modules.py:331-393).  The only consumer
+    of three_nn / three_interpolate; not instantiated by any MSR3D config, kept so
+    `pointnet2_modules` offers the reference's decoder-side module next to the SA modules."""
+
+    def __init__(self, *, mlp: List[int], bn: bool = True):
+        super().__init__()
+        self.mlp = pt_utils.SharedMLP(mlp, bn=bn)
+
+    @staticmethod
+    def propagate(unknown, known, known_feats):
+        """(B, C2, n): three-NN interpolation, or a broadcast when there are no known positions."""
+        if known is None:
+            return known_feats.expand(known_feats.size(0), known_feats.size(1), unknown.size(1))
+        dist, idx = pointnet2_utils.three_nn(unknown, known)       # Euclidean (the wrapper takes the root)
+        inv = 1.0 / (dist + 1e-8)
+        weight = inv / inv.sum(dim=2, keepdim=True)
+        return pointnet2_utils.three_interpolate(known_feats, idx, weight)
+
+    def forward(self, unknown, known, unknow_feats, known_feats):
+        feats = self.propagate(unknown, known, known_feats)
+        if unknow_feats is not None:
+            feats = torch.cat([feats, unknow_feats], dim=1)          # (B, C2 + C1, n)
+        return self.mlp(feats.unsqueeze(-1)).squeeze(-1)

@@ -1,0 +1,101 @@
+"""GPU: the two checks the reference itself ships for pointnet2, restated against this build --
+the `gradcheck` of three_interpolate (/root/reference/modules/third_party/pointnet2/
+pointnet2_test.py:18-33: 1 x 2 x 4 features, its idx / weight vectors, atol = rtol = 1e-1) and the
+`__main__` smoke of pointnet2_modules.py:499-518 (a two-scale PointnetSAModuleMSG, npoint 2, radii
+5 / 10, nsamples 6 / 3, on 2 x 9 points, forward + backward to xyz and the features) -- plus
+PointnetFPModule, the consumer of three_nn / three_interpolate.  Where the reference only prints,
+these compare with the same modules on the CPU over the oracle ops."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pn2
+from tests.helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def test_interpolation_grad_reference_case():
+    from torch.autograd import gradcheck
+    from msr3d_amd.pointnet2 import pointnet2_utils
+    torch.manual_seed(0)
+    feats = torch.randn(1, 2, 4).float().cuda().requires_grad_()
+    idx = torch.from_numpy(np.array([[[0, 1, 2], [1, 2, 3]]])).int().cuda()
+    weight = torch.from_numpy(np.array([[[1, 1, 1], [2, 2, 2]]])).float().cuda()
+
+    def interpolate(inputs):
+        return pointnet2_utils.three_interpolate(inputs, idx, weight)
+
+    assert gradcheck(interpolate, feats, atol=1e-1, rtol=1e-1)      # the reference's bar (fp32 input)
+    # and exactly: out[c, j] = sum_k w[j, k] f[c, idx[j, k]]  =>  d sum(out) / d f[c, p] = sum of w over hits
+    out = interpolate(feats)
+    want = torch.stack([feats[0, :, :3].sum(1), 2 * feats[0, :, 1:].sum(1)], dim=1)[None]
+    assert torch.allclose(out, want, atol=1e-6)
+    out.sum().backward()
+    assert torch.equal(feats.grad, torch.tensor([[[1., 3., 3., 2.]] * 2]).cuda())
+
+
+def _on(ext, monkeypatch):
+    from msr3d_amd.pointnet2 import pointnet2_utils
+    monkeypatch.setattr(pointnet2_utils, "_ext", ext)
+
+
+def test_sa_module_msg_smoke_matches_cpu_oracle(monkeypatch):
+    from msr3d_amd.pointnet2 import _ext as hip_ext
+    from msr3d_amd.pointnet2.pointnet2_modules import PointnetSAModuleMSG
+    torch.manual_seed(1)
+    xyz = torch.randn(2, 9, 3)
+    feats = torch.randn(2, 6, 9)                        # (B, C, N)
+    mlps = [[6, 3], [6, 6]]
+    cpu = PointnetSAModuleMSG(npoint=2, radii=[5.0, 10.0], nsamples=[6, 3], mlps=mlps)
+    assert mlps == [[6, 3], [6, 6]]                     # the caller's lists are left alone
+    cpu.train()                                         # BN on batch statistics, as the smoke runs it
+    gpu = copy.deepcopy(cpu).cuda()
+
+    def run(mod, x, f, ext):
+        _on(ext, monkeypatch)
+        x = x.clone().requires_grad_()
+        f = f.clone().requires_grad_()
+        new_xyz, new_f = mod(x, f)
+        new_f.backward(torch.ones_like(new_f))
+        return new_xyz.detach(), new_f.detach(), x.grad, f.grad
+
+    cx, cf, cgx, cgf = run(cpu, xyz, feats, pn2.ext_module())
+    gx, gf, ggx, ggf = run(gpu, xyz.cuda(), feats.cuda(), hip_ext)
+    assert gf.shape == (2, 9, 2) and gx.shape == (2, 2, 3)
+    assert torch.equal(gx.cpu(), cx)                                 # FPS picks + gather: exact
+    assert rel_l2(gf.cpu().numpy(), cf.numpy()) < 1e-5
+    assert rel_l2(ggf.cpu().numpy(), cgf.numpy()) < 1e-4
+    assert rel_l2(ggx.cpu().numpy(), cgx.numpy()) < 1e-4             # xyz.grad: via the recentred coordinates
+
+
+@pytest.mark.parametrize("with_known_xyz,with_unknown_feats", [(True, True), (True, False), (False, True)])
+def test_fp_module_matches_cpu_oracle(monkeypatch, with_known_xyz, with_unknown_feats):
+    from msr3d_amd.pointnet2 import _ext as hip_ext
+    from msr3d_amd.pointnet2.pointnet2_modules import PointnetFPModule
+    torch.manual_seed(2)
+    B, n, m, C1, C2 = 3, 50, 1 if not with_known_xyz else 17, 5, 7
+    unknown, known = torch.rand(B, n, 3), torch.rand(B, m, 3)
+    unknown[0, 0] = known[0, 3 % m]                                   # a coincident pair: 1 / (0 + 1e-8)
+    f1 = torch.randn(B, C1, n) if with_unknown_feats else None
+    f2 = torch.randn(B, C2, m)
+    cpu = PointnetFPModule(mlp=[C2 + (C1 if with_unknown_feats else 0), 16, 8]).eval()
+    gpu = copy.deepcopy(cpu).cuda()
+
+    def run(mod, dev, ext):
+        _on(ext, monkeypatch)
+        k2 = f2.detach().clone().to(dev).requires_grad_()
+        k1 = f1.detach().clone().to(dev).requires_grad_() if f1 is not None else None
+        out = mod(unknown.to(dev), known.to(dev) if with_known_xyz else None, k1, k2)
+        out.square().sum().backward()
+        return out.detach().cpu(), k2.grad.cpu(), (k1.grad.cpu() if k1 is not None else None)
+
+    co, cg2, cg1 = run(cpu, "cpu", pn2.ext_module())
+    go, gg2, gg1 = run(gpu, "cuda", hip_ext)
+    assert go.shape == (B, 8, n)
+    assert rel_l2(go.numpy(), co.numpy()) < 1e-5
+    assert rel_l2(gg2.numpy(), cg2.numpy()) < 1e-4
+    if cg1 is not None:
+        assert rel_l2(gg1.numpy(), cg1.numpy()) < 1e-4
