@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 3
+#define MSR3D_ABI_VERSION 4
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -127,13 +127,18 @@ int msr3d_sa_fps2(int b, int n, int point_stride, int m1, int m2, const float *p
  *            new_xyz (b,m,3), nsample 32; out (b,m,256)
  *   level 3: dims {259,256,512,768}; group-all over n = 16 points: pts = xyz (b,16,3),
  *            feat (b,16,256); new_xyz unused; out (b,768)
- * paramsL: layer L packed by the host as [N][KP + MSR3D_SA_WPAD] weight rows (K order: level 1
- * [dxyz,rgb], levels 2/3 [feat, (d)xyz]; zero-padded to KP = 16 / 144 / 272 for the first
- * layer, KP = K otherwise; the extra MSR3D_SA_WPAD floats per row are padding), then
- * scale[N], shift[N] (the eval-mode BN affine).  ball_idx (b,m,32): optional output at level 2.
+ * paramsL: layer L packed by the host as W'[KP/16][N/16][64][4], scale[N], shift[N] (floats):
+ *   - K order: level 1 [dxyz, rgb], levels 2/3 [feat, (d)xyz]; zero-padded to KP = 16 / 144 / 272
+ *     for the first layer, KP = K otherwise;
+ *   - W' is the weight matrix in MFMA-fragment order: block (s, t) holds the 16 k x 16 columns of
+ *     K-slab s and column tile t as 64 lanes x 4 floats,
+ *         W'[s][t][lane][j] = W[16 t + (lane & 15)][16 s + 4 (lane >> 4) + j],
+ *     i.e. exactly the 16 bytes lane `lane` feeds the matrix pipe, so a wave's operand load is one
+ *     contiguous 1 KB read;
+ *   - scale / shift: the eval-mode BN affine (conv bias folded into shift).
+ * ball_idx (b,m,32): optional output at level 2.
  * valid: as in msr3d_sa_fps2 (level 3 handles two objects per workgroup: a padding object sharing
  * a workgroup with a valid one is computed too). */
-#define MSR3D_SA_WPAD 16
 int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pts,
                    const float *feat, const float *new_xyz, const int *dims,
                    const float *params1, const float *params2, const float *params3, float *out,

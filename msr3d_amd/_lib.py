@@ -77,7 +77,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 3        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 4        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():

@@ -43,8 +43,13 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #define MSR3D_SA2_NG 1   // 2 = two phase-offset tile groups per block: measured 9 % SLOWER (see sa2_kernel)
 #endif
 
-constexpr int kWPad = MSR3D_SA_WPAD;   // packed weight rows are [N][K + kWPad]: a 16-row B-fragment load then
-                              // spreads over channels instead of hitting one power-of-two stride
+// Weights arrive in MFMA-fragment order (include/msr3d_hip.h, msr3d_sa_level): the 16 columns x 16 k
+// of (slab, column tile) are ONE contiguous 1 KB block whose lane-th 16 bytes are what lane `lane`
+// feeds the matrix pipe, so a wave's B-fragment load is a single fully coalesced 1 KB read (8 cache
+// lines).  Row-major weights made the same load touch 16 rows x 64 B: 64 tag look-ups of 16 B each per
+// instruction, and the vector L1 -- one look-up per clock -- capped all three kernels at ~10 B/clk/CU
+// of operand traffic, i.e. at 60-67 % of the matrix peak with RM = 2 row tiles per wave.
+constexpr int kFrag = 256;   // floats per (slab, column tile) block: 64 lanes x 4
 constexpr int kLdsPad = 8;   // row stride = K + 8 floats (K % 16 == 0): stride/4 == 2 (mod 4)
                              // makes every 16-lane group of a ds_read_b128 fragment read hit
                              // 16 distinct 16-B slots of the 256-B bank row
@@ -59,22 +64,22 @@ __host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 // ---------------------------------------------------------------------------------
 // acc[RM][RN] (16x16 tiles) += X[rows][k] * W[cols][k]^T over k in [0, KP).
-// X: LDS, row-major, leading dim ldx.  W: global (L2-resident), row-major [N][KP].
-// K is consumed in slabs of 16: lane (i = lane&15, g = lane>>4) loads k = 4g..4g+3 of
-// row i with ONE 16-byte read for A (LDS) and for B (global); MFMA step s of the slab
+// X: LDS, row-major, leading dim ldx.  W: global (L2-resident), fragment-ordered
+// [KP/16][NT][64][4] with NT = N/16 column tiles; `wg` points at this wave's first column tile.
+// K is consumed in slabs of 16: lane (i = lane&15, g = lane>>4) holds k = 4g..4g+3 of
+// row i, ONE 16-byte read for A (LDS) and for B (global); MFMA step s of the slab
 // multiplies the k = 4g+s elements, i.e. a fixed permutation of k inside the slab --
 // legal because a dot product does not care, and it turns 4+4 scalar fragment loads into
 // 1+1 vector loads.
 // ---------------------------------------------------------------------------------
 // first B slab of a layer, issued early (before the previous layer's epilogue / the loader's
 // barrier) so its L2 latency is off the critical path
-template <int RN, int KP>
+template <int RN>
 __device__ __forceinline__ void load_b_first(const float *__restrict__ wg, int lane,
                                              float4 (&b)[RN]) {
-  constexpr int LDW = KP + kWPad;
-  const float *wp = wg + (size_t)(lane & 15) * LDW + 4 * (lane >> 4);
+  const float *wp = wg + lane * 4;
 #pragma unroll
-  for (int rn = 0; rn < RN; ++rn) b[rn] = *reinterpret_cast<const float4 *>(wp + (size_t)rn * 16 * LDW);
+  for (int rn = 0; rn < RN; ++rn) b[rn] = *reinterpret_cast<const float4 *>(wp + rn * kFrag);
 }
 
 // per-lane BN affine of this wave's columns (col = 16 rn + (lane & 15)), fetched with the B prefetch
@@ -89,15 +94,14 @@ __device__ __forceinline__ void load_affine(const float *__restrict__ scale,
   }
 }
 
-template <int RM, int RN, int KP>
+template <int RM, int RN, int KP, int NT>
 __device__ __forceinline__ void gemm_lds_global(const float *xs, int ldx,
                                                 const float *__restrict__ wg,
                                                 f32x4 (&acc)[RM][RN], int lane,
                                                 const float4 (&bfirst)[RN]) {
-  constexpr int LDW = KP + kWPad;
   const int i = lane & 15, g = lane >> 4;
   const float *xp = xs + i * ldx + 4 * g;
-  const float *wp = wg + (size_t)i * LDW + 4 * g;
+  const float *wp = wg + lane * 4;
   float4 bcur[RN];
 #pragma unroll
   for (int rn = 0; rn < RN; ++rn) bcur[rn] = bfirst[rn];
@@ -107,7 +111,7 @@ __device__ __forceinline__ void gemm_lds_global(const float *xs, int ldx,
     const int kn = (k0 + 16 < KP) ? k0 + 16 : k0;   // last slab: harmless re-read
 #pragma unroll
     for (int rn = 0; rn < RN; ++rn)
-      bnext[rn] = *reinterpret_cast<const float4 *>(wp + (size_t)rn * 16 * LDW + kn);
+      bnext[rn] = *reinterpret_cast<const float4 *>(wp + (size_t)(kn / 16) * (NT * kFrag) + rn * kFrag);
     float4 a[RM];
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm)
@@ -208,7 +212,7 @@ struct Chain {
   __device__ static void preload(const Layer &l1, Pre1 &p, int tid) {
     const int lane = tid & 63, wn = (tid >> 6) % WN;
     const int col0 = wn * RN1 * 16;
-    load_b_first<RN1, K0P>(l1.w + (size_t)col0 * (K0P + kWPad), lane, p.b);
+    load_b_first<RN1>(l1.w + (col0 / 16) * kFrag, lane, p.b);
     load_affine<RN1>(l1.scale + col0, l1.shift + col0, lane, p.sc, p.sh);
   }
 
@@ -229,9 +233,9 @@ struct Chain {
       const int col0 = wn * RN1 * 16;
       f32x4 acc[RM][RN1];
       zero_acc(acc);
-      gemm_lds_global<RM, RN1, K0P>(bufA + row0 * LDA, LDA, l1.w + (size_t)col0 * (K0P + kWPad), acc, lane, p1.b);
+      gemm_lds_global<RM, RN1, K0P, N1 / 16>(bufA + row0 * LDA, LDA, l1.w + (col0 / 16) * kFrag, acc, lane, p1.b);
       // next layer's first operands fly while this layer's epilogue and barrier run
-      load_b_first<RN2, N1>(l2.w + (size_t)(wn * RN2 * 16) * (N1 + kWPad), lane, b2);
+      load_b_first<RN2>(l2.w + (wn * RN2) * kFrag, lane, b2);
       load_affine<RN2>(l2.scale + wn * RN2 * 16, l2.shift + wn * RN2 * 16, lane, sc2, sh2);
       if (tstamp) tstamp[0] = clock64();
       if (SPLIT) __syncthreads();
@@ -243,8 +247,8 @@ struct Chain {
       const int col0 = wn * RN2 * 16;
       f32x4 acc[RM][RN2];
       zero_acc(acc);
-      gemm_lds_global<RM, RN2, N1>(bufB + row0 * LDB, LDB, l2.w + (size_t)col0 * (N1 + kWPad), acc, lane, b2);
-      load_b_first<RN3, N2>(l3.w + (size_t)(wn * RN3 * 16) * (N2 + kWPad), lane, b3);
+      gemm_lds_global<RM, RN2, N1, N2 / 16>(bufB + row0 * LDB, LDB, l2.w + (col0 / 16) * kFrag, acc, lane, b2);
+      load_b_first<RN3>(l3.w + (wn * RN3) * kFrag, lane, b3);
       load_affine<RN3>(l3.scale + wn * RN3 * 16, l3.shift + wn * RN3 * 16, lane, sc3, sh3);
       if (tstamp) tstamp[2] = clock64();
       if (SPLIT) __syncthreads();
@@ -256,7 +260,7 @@ struct Chain {
       const int col0 = wn * RN3 * 16;
       f32x4 acc[RM][RN3];
       zero_acc(acc);
-      gemm_lds_global<RM, RN3, N2>(bufA + row0 * LDA, LDA, l3.w + (size_t)col0 * (N2 + kWPad), acc, lane, b3);
+      gemm_lds_global<RM, RN3, N2, N3 / 16>(bufA + row0 * LDA, LDA, l3.w + (col0 / 16) * kFrag, acc, lane, b3);
       if (tstamp) tstamp[4] = clock64();
       if (SPLIT) __syncthreads();
       const int g0 = wm * (RM / GT);            // first pooled row owned by this wave
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(256) void sa3_kernel(int b, const float *__restrict
   const int obj0 = blockIdx.x * 2;
   float4 b1[C::N1 / 64];
   float sc1[C::N1 / 64], sh1[C::N1 / 64];
-  load_b_first<C::N1 / 64, C::K0P>(l1.w + (size_t)(wave * (C::N1 / 64) * 16) * (C::K0P + kWPad), lane, b1);
+  load_b_first<C::N1 / 64>(l1.w + (wave * (C::N1 / 64)) * kFrag, lane, b1);
   load_affine<C::N1 / 64>(l1.scale + wave * (C::N1 / 64) * 16, l1.shift + wave * (C::N1 / 64) * 16,
                           lane, sc1, sh1);
   for (int e = tid; e < C::TM * 64; e += 256) {        // 64 float4 of features per row
@@ -521,8 +525,8 @@ __global__ __launch_bounds__(256) void sa3_kernel(int b, const float *__restrict
     const int col0 = wave * RN1 * 16;
     f32x4 acc[RM][RN1];
     zero_acc(acc);
-    gemm_lds_global<RM, RN1, C::K0P>(bufX, C::LDX, l1.w + (size_t)col0 * (C::K0P + kWPad), acc, lane, b1);
-    load_b_first<RN2, C::N1>(l2.w + (size_t)(wave * RN2 * 16) * (C::N1 + kWPad), lane, b2);
+    gemm_lds_global<RM, RN1, C::K0P, C::N1 / 16>(bufX, C::LDX, l1.w + (col0 / 16) * kFrag, acc, lane, b1);
+    load_b_first<RN2>(l2.w + (wave * RN2) * kFrag, lane, b2);
     load_affine<RN2>(l2.scale + wave * RN2 * 16, l2.shift + wave * RN2 * 16, lane, sc2, sh2);
     store_bn_relu_lds<RM, RN1>(acc, sc1, sh1, buf1 + col0, C::LD1, lane);
   }
@@ -531,8 +535,8 @@ __global__ __launch_bounds__(256) void sa3_kernel(int b, const float *__restrict
     const int col0 = wave * RN2 * 16;
     f32x4 acc[RM][RN2];
     zero_acc(acc);
-    gemm_lds_global<RM, RN2, C::N1>(buf1, C::LD1, l2.w + (size_t)col0 * (C::N1 + kWPad), acc, lane, b2);
-    load_b_first<RN3, C::N2>(l3.w + (size_t)(wave * RN3 * 16) * (C::N2 + kWPad), lane, b3);
+    gemm_lds_global<RM, RN2, C::N1, C::N2 / 16>(buf1, C::LD1, l2.w + (col0 / 16) * kFrag, acc, lane, b2);
+    load_b_first<RN3>(l3.w + (wave * RN3) * kFrag, lane, b3);
     load_affine<RN3>(l3.scale + wave * RN3 * 16, l3.shift + wave * RN3 * 16, lane, sc3, sh3);
     store_bn_relu_lds<RM, RN2>(acc, sc2, sh2, buf2 + col0, C::LD2, lane);
   }
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(256) void sa3_kernel(int b, const float *__restrict
     const int col0 = wave * RN3 * 16;
     f32x4 acc[RM][RN3];
     zero_acc(acc);
-    gemm_lds_global<RM, RN3, C::N2>(buf2, C::LD2, l3.w + (size_t)col0 * (C::N2 + kWPad), acc, lane, b3);
+    gemm_lds_global<RM, RN3, C::N2, C::N3 / 16>(buf2, C::LD2, l3.w + (col0 / 16) * kFrag, acc, lane, b3);
     const int gv = (b - obj0) < 2 ? (b - obj0) : 2;
     store_bn_relu_groupmax<RM, RN3, 1>(acc, sc3, sh3, out + (size_t)obj0 * C::N3 + col0, C::N3, gv,
                                        lane);
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(256) void sa3_kernel(int b, const float *__restrict
 inline Layer make_layer(const float *packed, int n, int kp) {
   Layer l;
   l.w = packed;
-  l.scale = packed + (size_t)n * (kp + kWPad);
+  l.scale = packed + (size_t)n * kp;
   l.shift = l.scale + n;
   return l;
 }

@@ -17,7 +17,6 @@ from . import pointnet2_utils as pu
 _LEVEL_DIMS = ([6, 64, 64, 128], [131, 128, 128, 256], [259, 256, 512, 768])
 _KP0 = (16, 144, 272)
 _NSAMPLE = 32
-_WPAD = 16            # MSR3D_SA_WPAD in include/msr3d_hip.h: padding floats per packed weight row
 
 
 def _level_spec(sa):
@@ -64,7 +63,7 @@ def can_fuse(net, pts):
 def _pack_layer(conv, bn, kp, feat_first):
     w = conv.weight.detach().reshape(conv.out_channels, conv.in_channels).float()
     n, k = w.shape
-    wp = w.new_zeros((n, kp + _WPAD))
+    wp = w.new_zeros((n, kp))
     if feat_first:            # kernel K order: [features, xyz]; reference: [xyz, features]
         wp[:, :k - 3] = w[:, 3:]
         wp[:, k - 3:k] = w[:, :3]
@@ -78,7 +77,10 @@ def _pack_layer(conv, bn, kp, feat_first):
     else:
         scale = torch.ones(n, device=w.device)
         shift = conv.bias.detach().float() if conv.bias is not None else torch.zeros(n, device=w.device)
-    return torch.cat([wp.reshape(-1), scale, shift]).contiguous()
+    # MFMA-fragment order (include/msr3d_hip.h): [slab s][column tile t][lane = 16 g + i][j] =
+    # W[16 t + i][16 s + 4 g + j] -- one contiguous 1 KB block per (slab, tile)
+    frag = wp.view(n // 16, 16, kp // 16, 4, 4).permute(2, 0, 3, 1, 4)      # (s, t, g, i, j)
+    return torch.cat([frag.reshape(-1), scale, shift]).contiguous()
 
 
 def _state_key(net):

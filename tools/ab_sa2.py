@@ -35,13 +35,13 @@ def call(lib, out):
     L = plan["levels"][level - 1]
     if level == 1:
         return lib.msr3d_sa_level(1, b, 1024, 32, ctypes.c_float(0.2), p(pts), p(None), p(d["new_xyz1"]),
-                                  plan["dims"][0], p(L[0]), p(L[1]), p(L[2]), p(out), p(None), st)
+                                  plan["dims"][0], p(L[0]), p(L[1]), p(L[2]), p(out), p(d["ball1"]) if "ball1" in d else p(None), p(None), st)
     if level == 2:
         return lib.msr3d_sa_level(2, b, 32, 16, ctypes.c_float(0.4), p(d["new_xyz1"]), p(d["feat1"]),
                                   p(d["new_xyz2"]), plan["dims"][1], p(L[0]), p(L[1]), p(L[2]), p(out),
-                                  p(None), st)
+                                  p(None), p(None), st)
     return lib.msr3d_sa_level(3, b, 16, 1, ctypes.c_float(0.0), p(d["new_xyz2"]), p(d["feat2"]), p(None),
-                              plan["dims"][2], p(L[0]), p(L[1]), p(L[2]), p(out), p(None), st)
+                              plan["dims"][2], p(L[0]), p(L[1]), p(L[2]), p(out), p(None), p(None), st)
 
 
 ref = {1: d["feat1"], 2: d["feat2"], 3: d["pooled"]}[level]
