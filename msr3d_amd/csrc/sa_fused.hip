@@ -39,6 +39,15 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #ifndef MSR3D_SA2_CPB
 #define MSR3D_SA2_CPB 2
 #endif
+#ifndef MSR3D_SA_PIPE
+#define MSR3D_SA_PIPE 0
+#endif
+#ifndef MSR3D_SA2_PADLDS
+#define MSR3D_SA2_PADLDS 0     // experiment: extra dynamic LDS bytes (forces one block per CU)
+#endif
+#ifndef MSR3D_SA2_SKEW
+#define MSR3D_SA2_SKEW 0       // experiment: delay (x s_sleep 127) of the second block a CU receives
+#endif
 #ifndef MSR3D_SA2_NG
 #define MSR3D_SA2_NG 1   // 2 = two phase-offset tile groups per block: measured 9 % SLOWER (see sa2_kernel)
 #endif
@@ -102,6 +111,40 @@ __device__ __forceinline__ void gemm_lds_global(const float *xs, int ldx,
   const int i = lane & 15, g = lane >> 4;
   const float *xp = xs + i * ldx + 4 * g;
   const float *wp = wg + lane * 4;
+#if MSR3D_SA_PIPE
+  // explicit two-stage register pipeline, pinned: slab s+1's A (LDS) and B (L2) fragments are
+  // issued before slab s's first MFMA, so ONE wave can keep the matrix pipe busy on its own
+  constexpr int NS = KP / 16;
+  float4 a[2][RM], b[2][RN];
+#pragma unroll
+  for (int rn = 0; rn < RN; ++rn) b[0][rn] = bfirst[rn];
+#pragma unroll
+  for (int rm = 0; rm < RM; ++rm) a[0][rm] = *reinterpret_cast<const float4 *>(xp + rm * 16 * ldx);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int cur = s & 1, nxt = cur ^ 1;
+    if (s + 1 < NS) {
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn)
+        b[nxt][rn] = *reinterpret_cast<const float4 *>(wp + (size_t)(s + 1) * (NT * kFrag) + rn * kFrag);
+#pragma unroll
+      for (int rm = 0; rm < RM; ++rm)
+        a[nxt][rm] = *reinterpret_cast<const float4 *>(xp + rm * 16 * ldx + (s + 1) * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#define MSR3D_PSTEP(c)                                                                          \
+    _Pragma("unroll") for (int rm = 0; rm < RM; ++rm)                                           \
+    _Pragma("unroll") for (int rn = 0; rn < RN; ++rn)                                           \
+        acc[rm][rn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][rm].c, b[cur][rn].c, acc[rm][rn], 0, 0, 0);
+    MSR3D_PSTEP(x)
+    MSR3D_PSTEP(y)
+    MSR3D_PSTEP(z)
+    MSR3D_PSTEP(w)
+#undef MSR3D_PSTEP
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return;
+#endif
   float4 bcur[RN];
 #pragma unroll
   for (int rn = 0; rn < RN; ++rn) bcur[rn] = bfirst[rn];
@@ -307,7 +350,12 @@ __device__ __forceinline__ void wave_ball_query(const float *sx, int n, float cx
 constexpr int kNS = 32;   // neighbours per centre in both query levels (configs/msr3d.yaml:199)
 // CPB centres per block: 2 -> 64-row tile, 37 KB of LDS and 102 registers: four blocks per CU, so one
 // block's gather phase hides under the others' MFMA phases (4 -> 128-row tile, two per CU: 298 vs 305 us).
-template <int CPB> struct Sa1 { using C = Chain<CPB * kNS, 16, 64, 64, 128, kNS, 2, 2>; };
+#ifndef MSR3D_SA1_WM
+#define MSR3D_SA1_WM 2
+#endif
+template <int CPB> struct Sa1 {
+  using C = Chain<CPB * kNS, 16, 64, 64, 128, kNS, MSR3D_SA1_WM, 4 / MSR3D_SA1_WM>;
+};
 
 template <int CPB>
 __global__ __launch_bounds__(256) void sa1_kernel(int n, int m, const float *__restrict__ pts,
@@ -353,7 +401,15 @@ __global__ __launch_bounds__(256) void sa1_kernel(int n, int m, const float *__r
 // (b, m, 3).  Block = 4 centres x 32 neighbours.  MLP 131 -> 128 -> 128 -> 256 with the
 // K order [feat(128), dxyz(3), 0 x13].  out: (b, m, 256).
 // =================================================================================
-template <int CPB> struct Sa2 { using C = Chain<CPB * kNS, 144, 128, 128, 256, kNS, 2, 2>; };
+#ifndef MSR3D_SA2_WM
+#define MSR3D_SA2_WM 1     // waves as 1 x 4: every wave owns all 64 rows (RM = 4) and a quarter of the columns,
+#endif                     // so each weight fragment is fetched once per block: 621 -> 537 us (tools/ab_sa2.py)
+template <int CPB> struct Sa2 {
+  using C = Chain<CPB * kNS, 144, 128, 128, 256, kNS, MSR3D_SA2_WM, 4 / MSR3D_SA2_WM>;
+};
+#if MSR3D_SA2_SKEW
+__device__ unsigned g_cu_tickets[4096];
+#endif
 
 // NG = 2: the block holds TWO independent 64-row tiles (8 waves, two per SIMD).  Both tile groups
 // run the same program -- [stage] [ball query] [gather] [MFMA 1] [epi 1] [MFMA 2] [epi 2] [MFMA 3]
@@ -376,6 +432,16 @@ __global__ __launch_bounds__(256 * NG) void sa2_kernel(int n, int m, float radiu
                                                        int *__restrict__ dbg_idx,
                                                        const unsigned char *__restrict__ valid) {
   if (valid && !valid[blockIdx.y]) return;
+#if MSR3D_SA2_SKEW
+  if (threadIdx.x == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);      // HW_REG_XCC_ID[3:0]
+    const unsigned key = (xcc << 8) | ((hw >> 8) & 0xffu);                // (xcc, se, sh, cu)
+    if (atomicAdd(&g_cu_tickets[key], 1u) == 1u)
+      for (int t = 0; t < MSR3D_SA2_SKEW; ++t) __builtin_amdgcn_s_sleep(127);
+  }
+  __syncthreads();
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using Chain2 = typename Sa2<CPB>::C;
   constexpr int TM = CPB * kNS;
@@ -619,8 +685,15 @@ int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pt
     if (!(dims[0] == 131 && dims[1] == 128 && dims[2] == 128 && dims[3] == 256)) return MSR3D_EINVAL;
     if (!pts || !feat || !new_xyz || n <= 0 || n > 64 || m <= 0) return MSR3D_EINVAL;
     constexpr int CPB = MSR3D_SA2_CPB, NG = MSR3D_SA2_NG;
-    const size_t lds = sizeof(float) * NG * (Sa2<CPB>::C::LDS_FLOATS + 4 * kNS + 16 + 64 * 3);
+    const size_t lds = sizeof(float) * NG * (Sa2<CPB>::C::LDS_FLOATS + 4 * kNS + 16 + 64 * 3) + MSR3D_SA2_PADLDS;
     if ((e = allow_lds(sa2_kernel<CPB, NG>, lds)) != hipSuccess) return (int)e;
+#if MSR3D_SA2_SKEW
+    {
+      void *sym = nullptr;
+      if ((e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g_cu_tickets))) != hipSuccess) return (int)e;
+      if ((e = hipMemsetAsync(sym, 0, sizeof(unsigned) * 4096, st)) != hipSuccess) return (int)e;
+    }
+#endif
     dim3 grid((m + CPB * NG - 1) / (CPB * NG), b);
     sa2_kernel<CPB, NG><<<grid, 256 * NG, lds, st>>>(n, m, r2, pts, feat, new_xyz,
                                                      make_layer(params1, 128, 144),
