@@ -357,8 +357,15 @@ template <int CPB> struct Sa1 {
   using C = Chain<CPB * kNS, 16, 64, 64, 128, kNS, MSR3D_SA1_WM, 4 / MSR3D_SA1_WM>;
 };
 
+#ifndef MSR3D_SA1_WAVES
+#define MSR3D_SA1_WAVES 4     // 128-register cap: the 37 KB of LDS allow four blocks per CU, 136 registers did not
+#endif
 template <int CPB>
-__global__ __launch_bounds__(256) void sa1_kernel(int n, int m, const float *__restrict__ pts,
+__global__ __launch_bounds__(256)
+#if MSR3D_SA1_WAVES
+__attribute__((amdgpu_waves_per_eu(MSR3D_SA1_WAVES, MSR3D_SA1_WAVES)))
+#endif
+void sa1_kernel(int n, int m, const float *__restrict__ pts,
                                                   const float *__restrict__ new_xyz,
                                                   const int *__restrict__ ball_idx, Layer l1,
                                                   Layer l2, Layer l3, float *__restrict__ out,

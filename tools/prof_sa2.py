@@ -35,7 +35,7 @@ for cpb in (2, 4):
     for it in range(3):
         rc = lib.msr3d_sa_level(2, b, 32, 16, ctypes.c_float(0.4), p(d["new_xyz1"]), p(d["feat1"]),
                                 p(d["new_xyz2"]), plan["dims"][1], p(L[0]), p(L[1]), p(L[2]), p(out),
-                                p(dbg), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                p(dbg), p(None), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0, rc
     torch.cuda.synchronize()
     nwg = b * (16 // cpb)
