@@ -30,9 +30,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM traffic of one sa2_kernel launch at the bench's shape (960 objects), from the PMC passes
 # committed under profiles/ (tools/pmc_sa.sh: FETCH_SIZE and WRITE_SIZE in separate passes, KiB
 # units, FETCH_SIZE doubled per the gfx950 calibration in MI355X_MICROARCH.md §HBM):
-#   (28932 * 2 + 15360) KiB = 75.0 MB  vs  algorithmic 15.7 MB in (feat1) + 15.7 MB out (feat2);
+#   (28797 * 2 + 15360) KiB = 74.7 MB  vs  algorithmic 15.7 MB in (feat1) + 15.7 MB out (feat2);
 #   WRITE_SIZE is exactly the output, the read side carries the per-block weight stream's L2 misses
-SA2_TRAFFIC_BYTES_PER_OBJECT = (28931.9 * 2 + 15360) * 1024 / 960.0
+SA2_TRAFFIC_BYTES_PER_OBJECT = (28797.3 * 2 + 15360) * 1024 / 960.0
 MFMA_F32_PEAK_TF = 157.3       # f32-input MFMA dense peak
 O, P = 60, 1024                # objects per scene, points per object (configs/msr3d.yaml:60,153)
 
@@ -306,7 +306,7 @@ def main():
                          "achieved": achieved, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F32_PEAK_TF,
                          "traffic": SA2_TRAFFIC_BYTES_PER_OBJECT * objs_per_launch,
-                         "traffic_unit": "bytes/launch (PMC passes of tools/pmc_sa.sh, profiles/r01_v12_pmc_sa.txt)",
+                         "traffic_unit": "bytes/launch (PMC passes of tools/pmc_sa.sh, profiles/r01_v13_pmc_sa.txt)",
                          "kernel_ms": k_ms, "launches": len(sink["msr3d_sa_level2"]),
                          "dtype": "f32-input MFMA (v_mfma_f32_16x16x4_f32)"},
             "kernels_ms": kern_ms,
