@@ -15,7 +15,8 @@
 // matters is that every launch fills the chip for its few microseconds: 64x64 tiles (4 waves
 // x 32x32) with split-K for the 256-wide outputs, 128-row / 128-column tiles where a side is
 // long; BK = 32, LDS double-buffered, operands staged global -> registers -> LDS with 16-byte
-// accesses.  Split-K partial sums meet in C by atomicAdd (default: fastest, rounding depends on
+// accesses.  Forward linears with K <= 256 and N >= 512 take gemm_nt_ares_kernel instead (x strip
+// resident in LDS, W fragments straight from L2, no per-slab barrier).  Split-K partial sums meet in C by atomicAdd (default: fastest, rounding depends on
 // arrival order) or, when the caller passes a workspace, in an ORDERED hand-over: every split
 // stores its accumulators, takes a ticket, and the last workgroup to arrive adds the partials in
 // split order and runs the epilogue -- no zero-fill of C, no float atomics, bit-reproducible
@@ -358,6 +359,134 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   gemm_body<A_KC, B_KC, RM, RN>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Forward linears with a short reduction (K <= 256: q/k/v/cond, fc, linear1, llm_proj), A-resident:
+// the workgroup's 64-row strip of x is staged in LDS ONCE (all its loads in flight together, one
+// barrier), then the K loop runs barrier-free with the W fragments read straight from L2 into
+// registers -- the structure of the set-abstraction kernels (sa_fused.hip).  No per-slab staging of
+// W through LDS, no per-slab barrier: what these launches pay for is latency, not bandwidth.
+// Waves are laid out 1 x 4: each owns all 64 rows (RM = 4) and 16 RN of the workgroup's 64 RN columns.
+// ---------------------------------------------------------------------------------------------
+template <int RN>
+__global__ __launch_bounds__(256) void gemm_nt_ares_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int RM = 4;
+  const int M = p.M, N = p.N, K = p.K, LDA = K + 8;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * (64 * RN);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const float *__restrict__ A = p.A;
+  const float *__restrict__ W = p.B;
+
+  // this lane's W rows (column tiles of the output); columns past N re-read row N-1, results dropped
+  const int colbase = n0 + wave * (16 * RN);
+  const float *wp[RN];
+  float4 bcur[RN];
+#pragma unroll
+  for (int rn = 0; rn < RN; ++rn) {
+    int col = colbase + rn * 16 + i;
+    col = col < N ? col : N - 1;
+    wp[rn] = W + (size_t)col * p.ldb + 4 * g;
+    bcur[rn] = *reinterpret_cast<const float4 *>(wp[rn]);
+  }
+  // A strip: 64 x K floats, K/4 float4 per row, batches of 8 loads per thread
+  const int k4 = K >> 2, total = 64 * k4;
+  for (int e0 = 0; e0 < total; e0 += 256 * 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * 256 + tid;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < total) {
+        const int row = e / k4, c4 = e - row * k4;
+        if (m0 + row < M) v[u] = *reinterpret_cast<const float4 *>(A + (size_t)(m0 + row) * p.lda + c4 * 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * 256 + tid;
+      if (e < total) {
+        const int row = e / k4, c4 = e - row * k4;
+        *reinterpret_cast<float4 *>(smem + row * LDA + c4 * 4) = v[u];
+      }
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[RM][RN];
+#pragma unroll
+  for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn) acc[rm][rn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float *xp = smem + i * LDA + 4 * g;
+#pragma unroll 2
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    float4 bnext[RN], a[RM];
+    const int kn = (k0 + 16 < K) ? k0 + 16 : k0;
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn) bnext[rn] = *reinterpret_cast<const float4 *>(wp[rn] + kn);
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm) a[rm] = *reinterpret_cast<const float4 *>(xp + rm * 16 * LDA + k0);
+#define MSR3D_STEP(c)                                                                           \
+    _Pragma("unroll") for (int rm = 0; rm < RM; ++rm)                                           \
+    _Pragma("unroll") for (int rn = 0; rn < RN; ++rn)                                           \
+        acc[rm][rn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rm].c, bcur[rn].c, acc[rm][rn], 0, 0, 0);
+    MSR3D_STEP(x)
+    MSR3D_STEP(y)
+    MSR3D_STEP(z)
+    MSR3D_STEP(w)
+#undef MSR3D_STEP
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn) bcur[rn] = bnext[rn];
+  }
+
+  // epilogue (same order of operations as gemm_body's): bias, beta * C, GELU (+ pre-activation), dropout
+  const int flags = p.flags;
+  const bool drop = (flags & 4) != 0;
+  const unsigned thresh = msr3d::drop_thresh(drop ? p.p_drop : 0.f);
+  const float dscale = drop ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+  const unsigned long long sd = drop ? *p.seed : 0ull;
+  float *__restrict__ C = p.C;
+  float *__restrict__ Cpre = p.Cpre;
+#pragma unroll
+  for (int rn = 0; rn < RN; ++rn) {
+    const int col = colbase + rn * 16 + i;
+    if (col >= N) continue;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + rm * 16 + g * 4 + r;
+        if (row >= M) continue;
+        float v = acc[rm][rn][r] + bv;
+        const size_t o = (size_t)row * p.ldc + col;
+        if (p.beta != 0.f) v += p.beta * C[o];
+        if (flags & 1) {
+          if (Cpre) Cpre[o] = v;
+          v = gelu_f(v);
+        }
+        if (drop) v = msr3d::keep_elem(sd, p.salt, (unsigned)o, thresh) ? v * dscale : 0.f;
+        C[o] = v;
+      }
+  }
+}
+
+template <int RN>
+static hipError_t launch_ares(const GemmP &p, hipStream_t st) {
+  const size_t lds = sizeof(float) * 64 * (size_t)(p.K + 8);
+  static size_t granted = 0;
+  if (lds > 64 * 1024 && lds > granted) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_nt_ares_kernel<RN>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    granted = lds;
+  }
+  dim3 grid((p.N + 64 * RN - 1) / (64 * RN), (p.M + 63) / 64);
+  gemm_nt_ares_kernel<RN><<<grid, 256, lds, st>>>(p);
+  return hipGetLastError();
+}
+
 // Both backward products of a linear layer in ONE launch: dx = dy W (first p1's workgroups) and
 // dW += dy^T x, db += colsum(dy) (then p2's).  They are independent, each too small to fill the
 // chip, and every launch inside the captured graph costs ~5 us whatever it does.
@@ -550,6 +679,24 @@ static int gemm_f32_impl(int a_kc, int b_kc, int M, int N, int K, const float *A
   GemmP g;
   int rm, rn;
   bool empty;
+  // short-reduction forward linears: A-resident kernel (no split-K, no meeting point, no zero-fill)
+  static const int ares_min_n = getenv("MSR3D_GEMM_ARES_MIN_N") ? atoi(getenv("MSR3D_GEMM_ARES_MIN_N")) : 512;
+  if (a_kc && b_kc && !a_colsum && M > 0 && N >= ares_min_n && K >= 16 && K <= 256 && K % 16 == 0 && A && B && C &&
+      vec_ok(A, lda) && vec_ok(B, ldb)) {
+    if (p_drop > 0.f) {
+      if (p_drop >= 1.f || !seed || ldc != N) return MSR3D_EINVAL;
+      flags |= 4;
+    } else {
+      flags &= ~4;
+    }
+    g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.bias = bias; g.Cpre = C_pre; g.flags = flags; g.beta = beta; g.a_vec = 1; g.b_vec = 1;
+    g.slabs_per_split = 0; g.a_colsum = nullptr; g.ws_part = nullptr; g.ws_count = nullptr;
+    g.p_drop = p_drop; g.seed = seed; g.salt = salt; g.gx = g.gy = g.gz = 1;
+    const int strips = (M + 63) / 64;
+    const bool wide = strips * ((N + 127) / 128) >= 384;      // enough workgroups with 128 columns each
+    return (int)(wide ? launch_ares<2>(g, st) : launch_ares<1>(g, st));
+  }
   const int rc = plan_gemm(a_kc, M, N, K, A, lda, B, ldb, C, ldc, bias, C_pre, flags, beta, a_colsum,
                            workspace, workspace_bytes, p_drop, seed, salt, true, st, &g, &rm, &rn, &empty);
   if (rc != 0 || empty) return rc;

@@ -11,6 +11,8 @@ SHAPES = [  # (M, K, N)
     (960, 256, 256), (960, 256, 816), (960, 256, 2048), (960, 2048, 256), (960, 256, 4096),
     (960, 768, 256), (960, 63, 256), (960, 3, 256), (61 * 3, 256, 48), (7, 5, 3), (64, 32, 64),
     (65, 33, 67), (1, 256, 256), (130, 84, 256),
+    # short reduction, wide output: the A-resident forward kernel, ragged in M and N
+    (1000, 144, 520), (70, 16, 600), (129, 256, 1028), (3, 240, 4100),
 ]
 
 
