@@ -55,16 +55,16 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // Weights arrive in MFMA-fragment order (include/msr3d_hip.h, msr3d_sa_level): the 16 columns x 16 k
 // of (slab, column tile) are ONE contiguous 1 KB block whose lane-th 16 bytes are what lane `lane`
 // feeds the matrix pipe, so a wave's B-fragment load is a single fully coalesced 1 KB read (8 cache
-// lines).  Row-major weights made the same load touch 16 rows x 64 B: 64 tag look-ups of 16 B each per
-// instruction, and the vector L1 -- one look-up per clock -- capped all three kernels at ~10 B/clk/CU
-// of operand traffic, i.e. at 60-67 % of the matrix peak with RM = 2 row tiles per wave.
+// lines).  Row-major weights made the same load touch 16 rows x 64 B, i.e. 64 tag look-ups of 16 B per
+// instruction: measured on the layout change alone, sa1 302 -> 280 us and sa3 190 -> 170 us (sa2
+// unchanged until its waves were re-laid 1 x 4, which the contiguous blocks made worthwhile).
 constexpr int kFrag = 256;   // floats per (slab, column tile) block: 64 lanes x 4
 constexpr int kLdsPad = 8;   // row stride = K + 8 floats (K % 16 == 0): stride/4 == 2 (mod 4)
                              // makes every 16-lane group of a ds_read_b128 fragment read hit
                              // 16 distinct 16-B slots of the 256-B bank row
 
 struct Layer {
-  const float *w;       // [N][KP]
+  const float *w;       // [KP/16][N/16][64][4], fragment order
   const float *scale;   // [N]
   const float *shift;   // [N]
 };
@@ -348,8 +348,9 @@ __device__ __forceinline__ void wave_ball_query(const float *sx, int n, float cx
 // query runs as its own launch and hands its indices over in `ball_idx`.  out: (b, m, 128) point-major.
 // =================================================================================
 constexpr int kNS = 32;   // neighbours per centre in both query levels (configs/msr3d.yaml:199)
-// CPB centres per block: 2 -> 64-row tile, 37 KB of LDS and 102 registers: four blocks per CU, so one
-// block's gather phase hides under the others' MFMA phases (4 -> 128-row tile, two per CU: 298 vs 305 us).
+// CPB centres per block: 2 -> 64-row tile, 37 KB of LDS and (capped) <= 128 registers: four blocks per
+// CU, so one block's gather phase hides under the others' MFMA phases (128- / 256-row tiles: 297 / 358 us
+// against 279; waves 1 x 4: 300 us).
 #ifndef MSR3D_SA1_WM
 #define MSR3D_SA1_WM 2
 #endif
