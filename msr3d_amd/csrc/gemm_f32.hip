@@ -591,7 +591,10 @@ static int plan_gemm(int a_kc, int M, int N, int K, const float *A, int lda, con
   // larger tiles stay selectable (MSR3D_GEMM_BIG_TILES=1) for bigger batches.
   auto ntiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
   int rm = 2, rn = 2;
-  constexpr int target_wgs = 512;
+  // ~2 workgroups per CU; the 2-GFLOP problems (llm_proj's dx and dW) time better with 4 per CU
+  // (54.6 -> 47.8 us, 52.8 -> 46.6 us), the 1-GFLOP ones do not care, more than that is worse for all
+  static const int target_env = getenv("MSR3D_GEMM_TARGET_WGS") ? atoi(getenv("MSR3D_GEMM_TARGET_WGS")) : 0;
+  const int target_wgs = target_env > 0 ? target_env : ((double)M * N * K >= 0.75e9 ? 1024 : 512);
   static const int big_tiles = getenv("MSR3D_GEMM_BIG_TILES") ? atoi(getenv("MSR3D_GEMM_BIG_TILES")) : 0;
   if (big_tiles && allow_big_tiles) {
     if (ntiles(128, 128) >= 192) { rm = 4; rn = 4; }
