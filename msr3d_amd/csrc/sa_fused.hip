@@ -386,18 +386,34 @@ void sa1_kernel(int n, int m, const float *__restrict__ pts,
   // gather: row = (centre w, sample k); cols [x-cx, y-cy, z-cz, r, g, b, 0 x10].  The ball
   // indices come from the wave-ballot query launched just before (msr3d_sa_level does both);
   // each point row is 24 B = three 8-byte loads.
-  for (int e = tid; e < TM * 8; e += 256) {
-    const int row = e >> 3, c2 = e & 7;
-    const int cj = c0 + (row >> 5);
-    float2 v = make_float2(0.f, 0.f);
-    if (c2 < 3 && cj < m) {
-      const int p = ball_idx[((size_t)obj * m + cj) * kNS + (row & 31)];
-      v = *reinterpret_cast<const float2 *>(P + (size_t)p * 6 + c2 * 2);
-      const float *c = new_xyz + ((size_t)obj * m + cj) * 3;
-      if (c2 == 0) { v.x -= c[0]; v.y -= c[1]; }
-      else if (c2 == 1) { v.x -= c[2]; }
+  {   // indices first, then ALL point loads, then the LDS stores: two L2 round trips per block in all
+    constexpr int IT = TM * 8 / 256;
+    int pidx[IT];
+    float2 v[IT];
+    float cx[IT], cy[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = tid + it * 256, row = e >> 3, c2 = e & 7, cj = c0 + (row >> 5);
+      pidx[it] = -1;
+      cx[it] = cy[it] = 0.f;
+      if (c2 < 3 && cj < m) {
+        pidx[it] = ball_idx[((size_t)obj * m + cj) * kNS + (row & 31)];
+        const float *c = new_xyz + ((size_t)obj * m + cj) * 3;
+        if (c2 == 0) { cx[it] = c[0]; cy[it] = c[1]; }
+        else if (c2 == 1) { cx[it] = c[2]; }
+      }
     }
-    *reinterpret_cast<float2 *>(bufA + row * Chain1::LDA + c2 * 2) = v;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int c2 = (tid + it * 256) & 7;
+      v[it] = make_float2(0.f, 0.f);
+      if (pidx[it] >= 0) v[it] = *reinterpret_cast<const float2 *>(P + (size_t)pidx[it] * 6 + c2 * 2);
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = tid + it * 256, row = e >> 3, c2 = e & 7;
+      *reinterpret_cast<float2 *>(bufA + row * Chain1::LDA + c2 * 2) = make_float2(v[it].x - cx[it], v[it].y - cy[it]);
+    }
   }
   __syncthreads();
   const int groups = (m - c0) < CPB ? (m - c0) : CPB;
