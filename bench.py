@@ -343,7 +343,7 @@ def main():
                          "achieved": achieved, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F32_PEAK_TF,
                          "traffic": SA2_TRAFFIC_BYTES_PER_OBJECT * objs_per_launch,
-                         "traffic_unit": "bytes/launch (PMC passes of tools/pmc_sa.sh, profiles/r01_v13_pmc_sa.txt)",
+                         "traffic_unit": "bytes/launch (PMC passes of tools/pmc_sa.sh, profiles/r01_v14_pmc_sa.txt)",
                          "kernel_ms": k_ms, "launches": len(sink["msr3d_sa_level2"]),
                          "dtype": "f32-input MFMA (v_mfma_f32_16x16x4_f32)"},
             "kernels_ms": kern_ms,
