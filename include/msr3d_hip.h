@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 4
+#define MSR3D_ABI_VERSION 5
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -237,6 +237,28 @@ int msr3d_spatial_attn_bwd(int B, int L, int H, int dh, int spatial_dim, const f
                            const unsigned char *key_padding_mask, const float *probs,
                            const float *dctx, float *dq, float *dk, float *dv, int ld_grad,
                            float *dcond, int ld_dcond, int mma, msr3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * BatchNorm (training mode) + ReLU over a token-major (rows, C) tensor, forward and backward:
+ * the normalisation of the unfrozen backbone's SharedMLP layers
+ * (/root/reference/modules/third_party/pointnet2/pytorch_utils.py:39-66, nn.BatchNorm2d over
+ * (b, C, npoint, nsample) = per-channel statistics over rows = b * npoint * nsample).
+ *   fwd: y = relu((x - mean) * rstd * gamma + beta), mean / biased var over the rows; running_mean /
+ *        running_var (may be NULL) updated as torch does (momentum, unbiased variance); save_mean,
+ *        save_rstd (C) are kept for the backward.
+ *   bwd: dx, and dgamma / dbeta (C, WRITTEN).
+ * C % 4 == 0, C <= 1024.  partial_ws: 2 * C * ceil(rows / MSR3D_BN_CHUNK_ROWS) floats of scratch; the reductions
+ * are two-stage and ordered (no float atomics: results are run-to-run bit-identical).
+ * ------------------------------------------------------------------------- */
+#define MSR3D_BN_CHUNK_ROWS 512
+int msr3d_bn_relu_train_fwd(long long rows, int C, const float *x, const float *gamma,
+                            const float *beta, float eps, float momentum, float *running_mean,
+                            float *running_var, float *y, float *save_mean, float *save_rstd,
+                            float *partial_ws, msr3d_stream_t stream);
+int msr3d_bn_relu_train_bwd(long long rows, int C, const float *x, const float *dy, const float *gamma,
+                            const float *beta, const float *save_mean, const float *save_rstd,
+                            float *dx, float *dgamma, float *dbeta, float *partial_ws,
+                            msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Data-only front of the situated encoder (inputs are dataset tensors, no gradients).

@@ -41,6 +41,10 @@ _SIGNATURES = {
                                               _ptr, _c_int, _ptr],
     "msr3d_spatial_attn_bwd": [_c_int] * 5 + [_ptr, _ptr, _ptr, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr,
                                               _ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _c_int, _c_int, _ptr],
+    "msr3d_bn_relu_train_fwd": [ctypes.c_longlong, _c_int, _ptr, _ptr, _ptr, _c_float, _c_float, _ptr, _ptr, _ptr,
+                                _ptr, _ptr, _ptr, _ptr],
+    "msr3d_bn_relu_train_bwd": [ctypes.c_longlong, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                _ptr, _ptr],
     "msr3d_pairwise_locs": [_c_int, _c_int, _ptr, _c_int, _c_float, _ptr, _ptr],
     "msr3d_agent_fourier": [_c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr, _ptr],
     "msr3d_add_row_vectors": [_c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
@@ -77,7 +81,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 4        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 5        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():

@@ -31,6 +31,7 @@ SOURCES = [
     ("prologue.hip", ["-ffp-contract=off"]),
     ("scene_scatter.hip", []),
     ("preprocess.hip", ["-ffp-contract=off"]),
+    ("bn_train.hip", []),
 ]
 
 

@@ -1,0 +1,238 @@
+// bn_train.hip -- BatchNorm in TRAINING mode fused with ReLU, forward and backward, over a
+// token-major (rows, C) tensor: the normalisation of the unfrozen backbone's SharedMLP layers
+// (/root/reference/modules/third_party/pointnet2/pytorch_utils.py:39-66 BatchNorm2d over
+// (b, C, npoint, nsample) == statistics per channel over b*npoint*nsample rows; SURVEY.md §8(f)
+// rank 3).  The 1x1 convolutions around it are the token GEMMs of gemm_f32.hip, so in training the
+// SharedMLP runs on this build's kernels end to end.
+//
+// Statistics are two-stage and ordered: every workgroup reduces a chunk of rows into a partial per
+// channel (fp32 inside a chunk of MSR3D_BN_CHUNK_ROWS rows), a second stage adds the partials
+// in a fixed order in double -- no float atomics, run-to-run bit-identical, and
+// the variance E[x^2] - mean^2 is formed in double.
+//
+//   forward : mean, var (biased) -> y = relu((x - mean) * rstd * gamma + beta);
+//             running_mean / running_var updated with `momentum` (unbiased variance, as torch)
+//   backward: g = dy * [gamma * xhat + beta > 0];  dbeta = sum g;  dgamma = sum g * xhat;
+//             dx = gamma * rstd * (g - dbeta / R - xhat * dgamma / R)
+#include <hip/hip_runtime.h>
+
+#include "../../include/msr3d_hip.h"
+
+namespace {
+
+constexpr int kChunk = MSR3D_BN_CHUNK_ROWS;     // rows per workgroup of the reduction passes
+
+// grid (chunks); 256 threads = RL row-lanes x C/4 float4 columns (RL = 256 / (C/4), C <= 1024): every
+// thread streams float4s of its 4 channels down the chunk's rows, the row-lanes then meet in LDS and
+// are added in lane order.  partial[chunk][2][C].
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_partial_kernel(long long R, int C, const float *__restrict__ x,
+                                                         const float *__restrict__ dy,
+                                                         const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta,
+                                                         const float *__restrict__ mean,
+                                                         const float *__restrict__ rstd,
+                                                         float *__restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float red[];      // [2][RL][C]
+  const int C4 = C >> 2, RL = 256 / C4;
+  const int rl = threadIdx.x / C4, c4 = threadIdx.x - rl * C4;
+  const long long r0 = (long long)blockIdx.x * kChunk;
+  const long long r1 = r0 + kChunk < R ? r0 + kChunk : R;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (rl < RL) {
+    float4 mu = s1, rs = s1, ga = s1, be = s1;
+    if (BWD) {
+      mu = reinterpret_cast<const float4 *>(mean)[c4];
+      rs = reinterpret_cast<const float4 *>(rstd)[c4];
+      ga = reinterpret_cast<const float4 *>(gamma)[c4];
+      be = reinterpret_cast<const float4 *>(beta)[c4];
+    }
+    const float4 *X = reinterpret_cast<const float4 *>(x);
+    const float4 *D = reinterpret_cast<const float4 *>(dy);
+#pragma unroll 4
+    for (long long r = r0 + rl; r < r1; r += RL) {
+      const float4 v = X[r * C4 + c4];
+      if (BWD) {
+        const float4 d = D[r * C4 + c4];
+#define BNP(k)                                                             \
+        {                                                                  \
+          const float xh = (v.k - mu.k) * rs.k;                            \
+          const float g = (__builtin_fmaf(ga.k, xh, be.k) > 0.f) ? d.k : 0.f; \
+          s1.k += g;                                                       \
+          s2.k = __builtin_fmaf(g, xh, s2.k);                              \
+        }
+        BNP(x) BNP(y) BNP(z) BNP(w)
+#undef BNP
+      } else {
+        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+        s2.x = __builtin_fmaf(v.x, v.x, s2.x); s2.y = __builtin_fmaf(v.y, v.y, s2.y);
+        s2.z = __builtin_fmaf(v.z, v.z, s2.z); s2.w = __builtin_fmaf(v.w, v.w, s2.w);
+      }
+    }
+    reinterpret_cast<float4 *>(red)[rl * C4 + c4] = s1;
+    reinterpret_cast<float4 *>(red)[(RL + rl) * C4 + c4] = s2;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, q = 0.f;
+    for (int l = 0; l < RL; ++l) {            // fixed order
+      a += red[l * C + c];
+      q += red[(RL + l) * C + c];
+    }
+    float *p = partial + ((size_t)blockIdx.x * 2) * C + c;
+    p[0] = a;
+    p[C] = q;
+  }
+}
+
+// Second stage: 64 channels per workgroup, 4 chunk-lanes per channel (lane l adds chunks l, l+4, ...
+// in order, in double; the four lane sums are then added in lane order): a fixed summation tree.
+__device__ __forceinline__ void bn_sum_partials(int C, int chunks, const float *__restrict__ partial, int c,
+                                                int l, double (*red)[4][64], double &s, double &q) {
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+#pragma unroll 8
+    for (int k = l; k < chunks; k += 4) {
+      a += (double)partial[((size_t)k * 2) * C + c];
+      b += (double)partial[((size_t)k * 2 + 1) * C + c];
+    }
+  }
+  red[0][l][threadIdx.x & 63] = a;
+  red[1][l][threadIdx.x & 63] = b;
+  __syncthreads();
+  const int j = threadIdx.x & 63;
+  s = (red[0][0][j] + red[0][1][j]) + (red[0][2][j] + red[0][3][j]);
+  q = (red[1][0][j] + red[1][1][j]) + (red[1][2][j] + red[1][3][j]);
+}
+
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
+    long long R, int C, int chunks, const float *__restrict__ partial, float eps, float momentum,
+    float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ save_mean,
+    float *__restrict__ save_rstd) {
+  __shared__ double red[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), l = threadIdx.x >> 6;
+  double s, q;
+  bn_sum_partials(C, chunks, partial, c, l, red, s, q);
+  if (l != 0 || c >= C) return;
+  const double mu = s / (double)R;
+  double var = q / (double)R - mu * mu;
+  var = var > 0.0 ? var : 0.0;
+  save_mean[c] = (float)mu;
+  save_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+  if (running_var) {
+    const double unbiased = R > 1 ? var * ((double)R / (double)(R - 1)) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, int chunks,
+                                                              const float *__restrict__ partial,
+                                                              float *__restrict__ dgamma,
+                                                              float *__restrict__ dbeta) {
+  __shared__ double red[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), l = threadIdx.x >> 6;
+  double s, q;
+  bn_sum_partials(C, chunks, partial, c, l, red, s, q);
+  if (l != 0 || c >= C) return;
+  dbeta[c] = (float)s;
+  dgamma[c] = (float)q;
+}
+
+// elementwise, float4 over channels (C % 4 == 0)
+__global__ void bn_relu_apply_kernel(long long n4, int C4, const float4 *__restrict__ x,
+                                     const float4 *__restrict__ gamma, const float4 *__restrict__ beta,
+                                     const float4 *__restrict__ mean, const float4 *__restrict__ rstd,
+                                     float4 *__restrict__ y) {
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n4;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(t % C4);
+    const float4 v = x[t], ga = gamma[c4], be = beta[c4], mu = mean[c4], rs = rstd[c4];
+    float4 o;
+#define BNF(k) o.k = fmaxf(__builtin_fmaf(ga.k, (v.k - mu.k) * rs.k, be.k), 0.f)
+    BNF(x); BNF(y); BNF(z); BNF(w);
+#undef BNF
+    y[t] = o;
+  }
+}
+
+__global__ void bn_relu_bwd_apply_kernel(long long n4, int C4, float inv_rows,
+                                         const float4 *__restrict__ x, const float4 *__restrict__ dy,
+                                         const float4 *__restrict__ gamma, const float4 *__restrict__ beta,
+                                         const float4 *__restrict__ mean, const float4 *__restrict__ rstd,
+                                         const float4 *__restrict__ dgamma, const float4 *__restrict__ dbeta,
+                                         float4 *__restrict__ dx) {
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n4;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(t % C4);
+    const float4 v = x[t], d = dy[t], ga = gamma[c4], be = beta[c4], mu = mean[c4], rs = rstd[c4];
+    const float4 dg = dgamma[c4], db = dbeta[c4];
+    float4 o;
+#define BNB(k)                                                                        \
+    {                                                                                 \
+      const float xh = (v.k - mu.k) * rs.k;                                           \
+      const float g = (__builtin_fmaf(ga.k, xh, be.k) > 0.f) ? d.k : 0.f;             \
+      o.k = ga.k * rs.k * (g - db.k * inv_rows - xh * (dg.k * inv_rows));             \
+    }
+    BNB(x) BNB(y) BNB(z) BNB(w)
+#undef BNB
+    dx[t] = o;
+  }
+}
+
+inline int chunks_of(long long R) { return (int)((R + kChunk - 1) / kChunk); }
+inline size_t partial_lds(int C) { return sizeof(float) * 2 * (size_t)(256 / (C / 4)) * C; }
+inline int ew_grid(long long n4) {
+  long long g = (n4 + 255) / 256;
+  return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int msr3d_bn_relu_train_fwd(long long rows, int C, const float *x, const float *gamma,
+                            const float *beta, float eps, float momentum, float *running_mean,
+                            float *running_var, float *y, float *save_mean, float *save_rstd,
+                            float *partial_ws, msr3d_stream_t stream) {
+  if (rows < 0 || C <= 0 || (C % 4) != 0 || C > 1024) return MSR3D_EINVAL;
+  if (rows == 0) return 0;
+  if (!x || !gamma || !beta || !y || !save_mean || !save_rstd || !partial_ws) return MSR3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = chunks_of(rows);
+  bn_partial_kernel<false><<<chunks, 256, partial_lds(C), st>>>(rows, C, x, nullptr, nullptr, nullptr, nullptr,
+                                                                nullptr, partial_ws);
+  bn_fwd_finalize_kernel<<<(C + 63) / 64, 256, 0, st>>>(rows, C, chunks, partial_ws, eps, momentum,
+                                                       running_mean, running_var, save_mean, save_rstd);
+  const long long n4 = rows * (C / 4);
+  bn_relu_apply_kernel<<<ew_grid(n4), 256, 0, st>>>(
+      n4, C / 4, reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(gamma),
+      reinterpret_cast<const float4 *>(beta), reinterpret_cast<const float4 *>(save_mean),
+      reinterpret_cast<const float4 *>(save_rstd), reinterpret_cast<float4 *>(y));
+  return (int)hipGetLastError();
+}
+
+int msr3d_bn_relu_train_bwd(long long rows, int C, const float *x, const float *dy, const float *gamma,
+                            const float *beta, const float *save_mean, const float *save_rstd,
+                            float *dx, float *dgamma, float *dbeta, float *partial_ws,
+                            msr3d_stream_t stream) {
+  if (rows < 0 || C <= 0 || (C % 4) != 0 || C > 1024) return MSR3D_EINVAL;
+  if (rows == 0) return 0;
+  if (!x || !dy || !gamma || !beta || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !partial_ws)
+    return MSR3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = chunks_of(rows);
+  bn_partial_kernel<true><<<chunks, 256, partial_lds(C), st>>>(rows, C, x, dy, gamma, beta, save_mean, save_rstd,
+                                                               partial_ws);
+  bn_bwd_finalize_kernel<<<(C + 63) / 64, 256, 0, st>>>(C, chunks, partial_ws, dgamma, dbeta);
+  const long long n4 = rows * (C / 4);
+  bn_relu_bwd_apply_kernel<<<ew_grid(n4), 256, 0, st>>>(
+      n4, C / 4, 1.0f / (float)rows, reinterpret_cast<const float4 *>(x),
+      reinterpret_cast<const float4 *>(dy), reinterpret_cast<const float4 *>(gamma),
+      reinterpret_cast<const float4 *>(beta), reinterpret_cast<const float4 *>(save_mean),
+      reinterpret_cast<const float4 *>(save_rstd), reinterpret_cast<const float4 *>(dgamma),
+      reinterpret_cast<const float4 *>(dbeta), reinterpret_cast<float4 *>(dx));
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

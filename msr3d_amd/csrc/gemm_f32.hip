@@ -419,7 +419,6 @@ __global__ __launch_bounds__(256) void gemm_nt_ares_kernel(const GemmP p) {
 #pragma unroll
     for (int rn = 0; rn < RN; ++rn) acc[rm][rn] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float *xp = smem + i * LDA + 4 * g;
-#pragma unroll 2
   for (int k0 = 0; k0 < K; k0 += 16) {
     float4 bnext[RN], a[RM];
     const int kn = (k0 + 16 < K) ? k0 + 16 : k0;

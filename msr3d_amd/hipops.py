@@ -62,8 +62,10 @@ _deterministic = [_os.environ.get("MSR3D_GEMM_DETERMINISTIC", "0") == "1"
 def set_deterministic(on):
     """Bit-reproducible reductions from now on: ordered split-K in every GEMM, LayerNorm parameter
     gradients and bias column sums summed in a fixed order (instead of meeting by float atomics).
-    Same seed + same data => identical weights, run after run; ~5 % slower."""
-    _deterministic[0] = bool(on)
+    Same seed + same data => identical weights, run after run; ~5 % slower.  Returns the previous
+    setting."""
+    was, _deterministic[0] = _deterministic[0], bool(on)
+    return was
 
 
 LN_BWD_ROWS = 16     # MSR3D_LN_BWD_ROWS
@@ -305,6 +307,103 @@ def attach_packed_views(model, dp, opt):
 def module_linear(mod, x, gelu=False):
     """Apply an nn.Linear module through `linear` (its parameters stay where they are)."""
     return linear(x, mod.weight, mod.bias, gelu=gelu)
+
+
+# ---------------------------------------------------------------------------------------
+# SharedMLP in TRAINING mode (unfrozen backbone, SURVEY.md §8(f) rank 3): conv1x1 -> BatchNorm
+# (batch statistics) -> ReLU per layer, then the max over the neighbourhood.  The convolutions are
+# the token GEMMs above on a token-major copy of the grouped tensor; the normalisation is
+# csrc/bn_train.hip (ordered two-stage statistics: bit-reproducible).
+# ---------------------------------------------------------------------------------------
+BN_CHUNK_ROWS = 512        # MSR3D_BN_CHUNK_ROWS
+
+
+class _BNReLUTrain(torch.autograd.Function):
+    """y = relu(batch_norm(x)) over the rows of x (R, C), training mode; updates the module's
+    running statistics like nn.BatchNorm2d.forward does."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn):
+        R, C = x.shape
+        if R <= 1:          # as torch.nn.functional.batch_norm in training mode
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {x.shape}")
+        x = x if x.is_contiguous() else x.contiguous()
+        g, b = gamma.contiguous(), beta.contiguous()
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ws = torch.empty(2 * C * max(1, -(-R // BN_CHUNK_ROWS)), dtype=torch.float32, device=x.device)
+        rm = rv = None
+        momentum = 0.0
+        if bn.track_running_stats and bn.running_mean is not None:
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+            # momentum None = cumulative average; the factor then depends on a device counter the
+            # host would have to read -- nn.BatchNorm2d's default (0.1) is what the backbone uses
+            if bn.momentum is None:
+                raise NotImplementedError("cumulative-average BatchNorm is not on this path")
+            momentum, rm, rv = float(bn.momentum), bn.running_mean, bn.running_var
+        with torch.cuda.device(x.device):
+            rc = _lib.load().msr3d_bn_relu_train_fwd(
+                R, C, _p(x), _p(g), _p(b), float(bn.eps), momentum, _p(rm), _p(rv), _p(y), _p(mean),
+                _p(rstd), _p(ws), _lib.current_stream_ptr(x.device))
+        _lib.check(rc, "msr3d_bn_relu_train_fwd")
+        ctx.save_for_backward(x, g, b, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, b, mean, rstd = ctx.saved_tensors
+        R, C = x.shape
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty_like(dg)
+        ws = torch.empty(2 * C * max(1, -(-R // BN_CHUNK_ROWS)), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().msr3d_bn_relu_train_bwd(
+                R, C, _p(x), _p(dy), _p(g), _p(b), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), _p(ws),
+                _lib.current_stream_ptr(x.device))
+        _lib.check(rc, "msr3d_bn_relu_train_bwd")
+        return dx, dg, db, None
+
+
+def shared_mlp_train_supported(mlp, x):
+    """GPU fp32 input, module in training mode, every layer a bias-free 1x1 convolution followed
+    by an affine, statistics-tracking BatchNorm2d and a ReLU, channel counts the kernels take."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and mlp.training
+            and getattr(mlp, "use_hip_train", True)):
+        return False
+    pairs = mlp.conv_bn_pairs()
+    for layer, (conv, bn) in zip(mlp, pairs):
+        if conv is None or bn is None or conv.bias is not None or not bn.affine or bn.momentum is None:
+            return False
+        if conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.padding != (0, 0) or conv.groups != 1:
+            return False
+        if conv.out_channels % 4 or conv.out_channels > 1024 or not isinstance(list(layer.children())[-1], torch.nn.ReLU):
+            return False
+        if list(layer.children())[0] is not conv:          # pre-activation order is not on this path
+            return False
+    return len(pairs) > 0
+
+
+def shared_mlp_train(mlp, x):
+    """x (B, C, npoint, nsample) -> max over nsample of the SharedMLP's output, (B, C_out, npoint).
+    Same values as `torch.amax(mlp(x), dim=3)` in training mode (batch statistics, running
+    statistics updated), computed on a token-major copy: rows = (b, point, sample)."""
+    B, C, NP, NS = x.shape
+    t = x.permute(0, 2, 3, 1).reshape(B * NP * NS, C)
+    for conv, bn in mlp.conv_bn_pairs():
+        w = conv.weight.view(conv.out_channels, conv.in_channels)
+        if t.shape[1] != w.shape[1] or w.shape[1] % 4:
+            # 16-byte rows for the GEMM's vector loads: zero columns on both operands
+            pad = (-w.shape[1]) % 4
+            w = F.pad(w, (0, pad))
+            if t.shape[1] != w.shape[1]:
+                t = F.pad(t, (0, w.shape[1] - t.shape[1]))
+        t = _BNReLUTrain.apply(linear(t, w), bn.weight, bn.bias, bn)
+    pooled = t.view(B, NP, NS, t.shape[1]).amax(dim=2)
+    return pooled.permute(0, 2, 1).contiguous()
 
 
 # ---------------------------------------------------------------------------------------

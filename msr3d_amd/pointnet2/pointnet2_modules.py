@@ -10,6 +10,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
+from .. import hipops
 from . import pointnet2_utils
 from . import pytorch_utils as pt_utils
 
@@ -33,7 +34,13 @@ class _PointnetSAModuleBase(nn.Module):
         new_xyz = self.sample_centres(xyz)
         pooled = []
         for grouper, mlp in zip(self.groupers, self.mlps):
-            x = mlp(grouper(xyz, new_xyz, features))      # (B, C_out, npoint, nsample)
+            grouped = grouper(xyz, new_xyz, features)     # (B, C_in, npoint, nsample)
+            if hipops.shared_mlp_train_supported(mlp, grouped):
+                # unfrozen backbone on the GPU: the convolutions as token GEMMs, BatchNorm (batch
+                # statistics) + ReLU in csrc/bn_train.hip
+                pooled.append(hipops.shared_mlp_train(mlp, grouped))
+                continue
+            x = mlp(grouped)                              # (B, C_out, npoint, nsample)
             pooled.append(torch.amax(x, dim=3))           # max over the neighbourhood
         return new_xyz, torch.cat(pooled, dim=1)
 

@@ -62,7 +62,7 @@ def _run(model, ext, fts, w, monkeypatch):
 def test_unfrozen_encoder_forward_backward(monkeypatch):
     """(1) HIP ops vs the same ops written in torch on the GPU: tight (1e-5), ReLU masks and max
     selections being identical; (2) vs the CPU with the oracle: forward 1e-4; gradients only to
-    2e-2, because a pre-activation within rounding of zero (a handful among ~6 M in train-mode BN)
+    3e-2, because a pre-activation within rounding of zero (a handful among ~6 M in train-mode BN)
     flips its ReLU mask between devices and moves the fp32 gradient by ~1e-3 -- a property of the
     network, observed on about half of the seeds."""
     from msr3d_amd.modules.vision.pcd_pointnet_encoder import PcdObjEncoder
@@ -77,10 +77,17 @@ def test_unfrozen_encoder_forward_backward(monkeypatch):
     fts = synth_batch(5, 1, O=12, P=1024)["obj_fts"]
     w = torch.randn(1, 12, 768)
 
-    gpu = copy.deepcopy(cpu).cuda()
-    out_h, g_h, s_h = _run(gpu, hip_ext, fts.cuda(), w.cuda(), monkeypatch)
-    gpu2 = copy.deepcopy(cpu).cuda()
-    out_t, g_t, s_t = _run(gpu2, _TorchScatterExt(hip_ext), fts.cuda(), w.cuda(), monkeypatch)
+    # (the SharedMLPs run on the token GEMMs in training mode: ordered split-K, so that "identical
+    # inputs" still means "identical bits" for the level-3 layers, whose few rows make them split)
+    from msr3d_amd import hipops
+    was = hipops.set_deterministic(True)
+    try:
+        gpu = copy.deepcopy(cpu).cuda()
+        out_h, g_h, s_h = _run(gpu, hip_ext, fts.cuda(), w.cuda(), monkeypatch)
+        gpu2 = copy.deepcopy(cpu).cuda()
+        out_t, g_t, s_t = _run(gpu2, _TorchScatterExt(hip_ext), fts.cuda(), w.cuda(), monkeypatch)
+    finally:
+        hipops.set_deterministic(was)
     assert torch.equal(out_h, out_t)                              # forward ops are exact copies
     assert len(g_h) >= 28
     for n in g_h:
@@ -95,7 +102,7 @@ def test_unfrozen_encoder_forward_backward(monkeypatch):
         if g_c[n].abs().max() < 1e-6:
             assert g_h[n].abs().max() < 1e-3, n
             continue
-        assert rel_l2(g_h[n].cpu().numpy(), g_c[n].numpy()) < 2e-2, n
+        assert rel_l2(g_h[n].cpu().numpy(), g_c[n].numpy()) < 3e-2, n
     for n in s_c:                                                 # running statistics updated alike
         assert rel_l2(s_h[n].cpu().numpy(), s_c[n].numpy()) < 1e-4, n
 
@@ -118,3 +125,79 @@ def test_unfrozen_backward_is_run_to_run_reproducible():
         grads.append(feats.grad.clone())
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
     assert grads[0].abs().sum() > 0
+
+
+# ---------------------------------------------------------------------------------------
+# SharedMLP in training mode on this build's kernels (hipops.shared_mlp_train: token GEMMs +
+# csrc/bn_train.hip) against torch's conv / batch_norm / relu / amax on the same device.
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R,C", [(5000, 64), (4096, 128), (8193, 256), (37, 4), (700, 768), (513, 1024)])
+def test_bn_relu_train_matches_float64(R, C):
+    """Outputs, gradients and the running statistics of the fused BatchNorm(train) + ReLU against a
+    float64 evaluation: 1e-5 rel-L2 (fp32 data, statistics accumulated in double)."""
+    from msr3d_amd import hipops
+    torch.manual_seed(R + C)
+    x = (torch.randn(R, C, device="cuda") * 2.0 + 0.7).requires_grad_()
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.5)
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2.0)
+    ref = copy.deepcopy(bn).double()
+    gy = torch.randn(R, C, device="cuda")
+
+    y = hipops._BNReLUTrain.apply(x, bn.weight, bn.bias, bn)
+    y.backward(gy)
+
+    xd = x.detach().double().requires_grad_()
+    yd = torch.relu(torch.nn.functional.batch_norm(
+        xd, ref.running_mean, ref.running_var, ref.weight, ref.bias, training=True, momentum=0.1, eps=bn.eps))
+    yd.backward(gy.double())
+    assert rel_l2(y.detach().cpu().numpy(), yd.detach().cpu().numpy()) < 1e-5
+    assert rel_l2(x.grad.cpu().numpy(), xd.grad.cpu().numpy()) < 2e-5
+    assert rel_l2(bn.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy()) < 2e-5
+    assert rel_l2(bn.running_var.cpu().numpy(), ref.running_var.cpu().numpy()) < 1e-5
+    assert rel_l2(bn.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy()) < 2e-5
+    assert rel_l2(bn.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy()) < 1e-5
+    assert int(bn.num_batches_tracked) == 1
+    # ordered reductions: a second evaluation is bit-identical
+    bn2 = copy.deepcopy(bn)
+    y2 = hipops._BNReLUTrain.apply(x.detach(), bn.weight.detach(), bn.bias.detach(), bn2)
+    assert torch.equal(y2, y.detach())
+    with pytest.raises(ValueError, match="more than 1 value per channel"):      # torch's own refusal
+        hipops._BNReLUTrain.apply(x.detach()[:1], bn.weight.detach(), bn.bias.detach(), bn2)
+
+
+@pytest.mark.parametrize("spec,shape", [([6, 64, 64, 128], (3, 6, 32, 32)), ([131, 128, 128, 256], (2, 131, 16, 32)),
+                                        ([259, 256, 512, 768], (5, 259, 1, 16))])
+def test_shared_mlp_train_matches_torch_modules(spec, shape):
+    from msr3d_amd import hipops
+    from msr3d_amd.pointnet2.pytorch_utils import SharedMLP
+    torch.manual_seed(sum(spec))
+    mlp = SharedMLP(list(spec), bn=True).cuda().train()
+    ref = copy.deepcopy(mlp).double()
+    x = torch.randn(*shape, device="cuda", requires_grad=True)
+    assert hipops.shared_mlp_train_supported(mlp, x)
+    g = torch.randn(shape[0], spec[-1], shape[2], device="cuda")
+    out = hipops.shared_mlp_train(mlp, x)
+    (out * g).sum().backward()
+    xd = x.detach().double().requires_grad_()
+    outd = torch.amax(ref(xd), dim=3)
+    (outd * g.double()).sum().backward()
+    assert out.shape == outd.shape
+    assert rel_l2(out.detach().cpu().numpy(), outd.detach().cpu().numpy()) < 2e-5
+    assert rel_l2(x.grad.cpu().numpy(), xd.grad.cpu().numpy()) < 1e-4
+    for (n, p), (_, q) in zip(mlp.named_parameters(), ref.named_parameters()):
+        assert rel_l2(p.grad.cpu().numpy(), q.grad.cpu().numpy()) < 1e-4, n
+    for (n, a), (_, b) in zip(mlp.named_buffers(), ref.named_buffers()):
+        if "running" in n:
+            assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5, n
+        else:
+            assert int(a) == int(b) == 1, n
+    # eval mode, CPU tensors, or the switch turned off keep the module path
+    mlp.eval()
+    assert not hipops.shared_mlp_train_supported(mlp, x)
+    mlp.train()
+    mlp.use_hip_train = False
+    assert not hipops.shared_mlp_train_supported(mlp, x)
