@@ -81,7 +81,9 @@ def test_fused_layer_matches_modular_path_with_bf16_attention():
         y0, g0 = _run(model, dp, batch, False)
     finally:
         hipops.set_attention_mma(prev)
-    assert rel(y1, y0) < 1e-6
+    # (fp32 mode: < 1e-6; here the split-K rounding noise of the projections in front of the attention
+    # occasionally crosses a bf16 rounding boundary of an operand: 1.04e-6 seen in 2 of 8 runs)
+    assert rel(y1, y0) < 2e-5
     assert 1e-6 < rel(y1, y32) < 1e-2             # bf16 mode is in effect, and close to fp32
     # the two schedules sum the attention block's incoming gradient in different orders; in bf16
     # mode those last-bit differences occasionally move an operand across a rounding boundary
