@@ -9,11 +9,12 @@ engine shaped for this model and for MI355X's point-to-point xGMI:
     laid out in reverse registration order (~ the order backward produces them), so a bucket
     is a contiguous slice and needs no copy in or out;
   * the exchange runs on a SIDE stream that waits on the producing stream; by default as ONE
-    all-reduce of the whole buffer right after backward (`finish()`): 21 MB is tens of
-    microseconds on xGMI against a ~2.6 ms step, and the step's forward/backward is replayed
-    from a HIP graph, which must not contain host-driven collectives.  `overlap=True` launches
-    each bucket from post-accumulate-grad hooks as soon as its last gradient exists, so
-    communication overlaps the rest of backward (eager mode);
+    all-reduce of the whole buffer right after backward (`start()` / `wait()`, or `finish()`):
+    the step's forward/backward is replayed from a HIP graph, which must not contain host-driven
+    collectives, and the caller (train_step.HotPathTrainStep) enqueues the NEXT batch's frozen
+    encoder between `start()` and `wait()`, so the 21 MB exchange is hidden behind 1 ms of
+    independent work.  `overlap=True` launches each bucket from post-accumulate-grad hooks as soon
+    as its last gradient exists, so communication overlaps the rest of backward (eager mode);
   * parameters that receive no gradient in a step (`anchor_feat`, `loc_layers` in
     'as_transform_for_objects' mode -- the reason the reference needs
     find_unused_parameters) simply leave zeros in the buffer: `finish()` flushes the
@@ -21,10 +22,9 @@ engine shaped for this model and for MI355X's point-to-point xGMI:
   * BN is frozen/eval on this path, so there is no buffer broadcast in forward.
 
 The hot-path gradient is 5.28 M params = 21.1 MB: with 7 x ~153 GB/s links per GPU a
-direct reduce-scatter/all-gather moves 2*S/8 per link (~35 us); bucket size is therefore
-chosen large (default 8 MiB -> 3 buckets) so each collective is bandwidth- not
-latency-bound, while still letting the first (llm_proj) bucket fly during the prompter's
-backward.
+direct reduce-scatter/all-gather moves 2*S/8 per link (~35 us).  A ring over point-to-point xGMI
+links is latency-bound per call at this size, hence one collective in the default mode; in overlap
+mode the bucket size is chosen large (8 MiB -> 3 buckets) for the same reason.
 """
 import os
 
