@@ -239,6 +239,22 @@ int msr3d_spatial_attn_bwd(int B, int L, int H, int dh, int spatial_dim, const f
                            float *dcond, int ld_dcond, int mma, msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * QueryAndGroup.forward (pointnet2_utils.py:314-373, use_xyz) written token-major, the operand layout of
+ * the training-mode SharedMLP: rows (b*m*nsample, KP), row ((b*m + j)*nsample + r) =
+ * [xyz[b][p] - new_xyz[b][j] (3), feats[b][:, p] (C), zeros (KP - 3 - C)] with p = idx[b][j][r].
+ * xyz (b,n,3), new_xyz (b,m,3), feats (b,C,n) channel-major as the reference keeps them (NULL when
+ * C == 0), idx (b,m,nsample) from msr3d_ball_query.
+ * _grad: d_feats (b,C,n) from d_rows, every element written, each a sum in ascending (j, r) order
+ * (deterministic, the order of the sequential oracle); MSR3D_EINVAL when the inverted index of one
+ * batch item (2n + 1 + m*nsample ints) exceeds 144 KB of LDS.  No gradient reaches xyz / new_xyz here.
+ * ------------------------------------------------------------------------- */
+int msr3d_group_rows(int b, int n, int m, int nsample, int C, int KP, const float *xyz,
+                     const float *new_xyz, const float *feats, const int *idx, float *rows,
+                     msr3d_stream_t stream);
+int msr3d_group_rows_grad(int b, int n, int m, int nsample, int C, int KP, const float *d_rows,
+                          const int *idx, float *d_feats, msr3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * BatchNorm (training mode) + ReLU over a token-major (rows, C) tensor, forward and backward:
  * the normalisation of the unfrozen backbone's SharedMLP layers
  * (/root/reference/modules/third_party/pointnet2/pytorch_utils.py:39-66, nn.BatchNorm2d over

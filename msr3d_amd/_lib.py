@@ -41,6 +41,8 @@ _SIGNATURES = {
                                               _ptr, _c_int, _ptr],
     "msr3d_spatial_attn_bwd": [_c_int] * 5 + [_ptr, _ptr, _ptr, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr,
                                               _ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _c_int, _c_int, _ptr],
+    "msr3d_group_rows": [_c_int] * 6 + [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_group_rows_grad": [_c_int] * 6 + [_ptr, _ptr, _ptr, _ptr],
     "msr3d_bn_relu_train_fwd": [ctypes.c_longlong, _c_int, _ptr, _ptr, _ptr, _c_float, _c_float, _ptr, _ptr, _ptr,
                                 _ptr, _ptr, _ptr, _ptr],
     "msr3d_bn_relu_train_bwd": [ctypes.c_longlong, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,

@@ -192,19 +192,11 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 constexpr int kDetRows = 32;             // rows (channels) per workgroup
 constexpr int kDetMaxInts = 36 * 1024;   // LDS ints available to the inverted index
 
-template <int DIV>
-__global__ __launch_bounds__(256) void scatter_rows_det_kernel(
-    int c, int n_dst, int E, const float *__restrict__ src, const int *__restrict__ idx,
-    const float *__restrict__ w, float *__restrict__ out) {
-  extern __shared__ int det_lds[];
-  int *start = det_lds;                  // n_dst + 1
-  int *cursor = start + n_dst + 1;       // n_dst
-  int *list = cursor + n_dst;            // E
-  __shared__ int chunk_dst[256];
-  __shared__ int partial[256];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int *I = idx + (size_t)b * E;
-
+// Stable counting sort of the E entries of one batch item by destination, in LDS:
+// list[start[d] .. start[d+1]) = the entries e with I[e] == d, in ascending e.
+__device__ __forceinline__ void build_inverted_index(const int *__restrict__ I, int E, int n_dst, int *start,
+                                                     int *cursor, int *list, int *chunk_dst, int *partial) {
+  const int tid = threadIdx.x;
   for (int d = tid; d < n_dst; d += 256) cursor[d] = 0;
   __syncthreads();
   for (int e = tid; e < E; e += 256) {
@@ -255,6 +247,20 @@ __global__ __launch_bounds__(256) void scatter_rows_det_kernel(
     if (d >= 0) atomicAdd(&cursor[d], 1);
     __syncthreads();
   }
+}
+
+template <int DIV>
+__global__ __launch_bounds__(256) void scatter_rows_det_kernel(
+    int c, int n_dst, int E, const float *__restrict__ src, const int *__restrict__ idx,
+    const float *__restrict__ w, float *__restrict__ out) {
+  extern __shared__ int det_lds[];
+  int *start = det_lds;                  // n_dst + 1
+  int *cursor = start + n_dst + 1;       // n_dst
+  int *list = cursor + n_dst;            // E
+  __shared__ int chunk_dst[256];
+  __shared__ int partial[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  build_inverted_index(idx + (size_t)b * E, E, n_dst, start, cursor, list, chunk_dst, partial);
   // ordered sums
   const int S = E / DIV;
   const int r_end = min(c, ((int)blockIdx.y + 1) * kDetRows);
@@ -286,6 +292,58 @@ hipError_t launch_scatter_det(int b, int c, int n_dst, int E, const float *src, 
   scatter_rows_det_kernel<DIV><<<dim3(b, (c + kDetRows - 1) / kDetRows), 256, lds, stream>>>(
       c, n_dst, E, src, idx, w, out);
   return hipGetLastError();
+}
+
+// ---- token-major neighbourhood rows (training-mode SharedMLP operand) -------------------------
+// rows[((b*m + j)*ns + r)][k] = k < 3 ? xyz[b][idx][k] - new_xyz[b][j][k] : k < 3+C ? feats[b][k-3][idx] : 0
+// with idx = idx[b][j][r]: QueryAndGroup.forward (pointnet2_utils.py:314-373; K order [xyz, features],
+// use_xyz) written straight in the layout the token GEMM reads, KP >= 3 + C columns (zero padded).
+__global__ __launch_bounds__(256) void group_rows_kernel(int n, int m, int ns, int C, int KP,
+                                                         const float *__restrict__ xyz,
+                                                         const float *__restrict__ new_xyz,
+                                                         const float *__restrict__ feats,
+                                                         const int *__restrict__ idx,
+                                                         float *__restrict__ rows) {
+  const int j = blockIdx.x, b = blockIdx.y;
+  const int *I = idx + ((size_t)b * m + j) * ns;
+  const float *ctr = new_xyz + ((size_t)b * m + j) * 3;
+  const float *X = xyz + (size_t)b * n * 3;
+  const float *F = feats ? feats + (size_t)b * C * n : nullptr;
+  float *O = rows + ((size_t)b * m + j) * ns * KP;
+  for (int e = threadIdx.x; e < ns * KP; e += 256) {
+    const int r = e / KP, k = e - r * KP;
+    const int p = I[r];
+    float v = 0.f;
+    if (k < 3) v = X[(size_t)p * 3 + k] - ctr[k];
+    else if (k < 3 + C) v = F[(size_t)(k - 3) * n + p];
+    O[e] = v;
+  }
+}
+
+// d_feats[b][c][p] = sum over the entries e (ascending) with idx[b][e] == p of d_rows[b*E + e][3 + c]:
+// the order of the sequential oracle, as in scatter_rows_det_kernel; no atomics, every output written.
+__global__ __launch_bounds__(256) void group_rows_grad_kernel(int n, int E, int C, int KP,
+                                                              const float *__restrict__ d_rows,
+                                                              const int *__restrict__ idx,
+                                                              float *__restrict__ d_feats) {
+  extern __shared__ int det_lds[];
+  int *start = det_lds;
+  int *cursor = start + n + 1;
+  int *list = cursor + n;
+  __shared__ int chunk_dst[256];
+  __shared__ int partial[256];
+  const int b = blockIdx.x;
+  build_inverted_index(idx + (size_t)b * E, E, n, start, cursor, list, chunk_dst, partial);
+  const float *G = d_rows + (size_t)b * E * KP + 3;
+  float *O = d_feats + (size_t)b * C * n;
+  const int c0 = blockIdx.y * 64;                 // 64 channels per workgroup
+  const int cw = min(64, C - c0);
+  for (int item = threadIdx.x; item < n * cw; item += 256) {
+    const int p = item / cw, c = c0 + item - p * cw;
+    float acc = 0.f;
+    for (int q = start[p]; q < start[p + 1]; ++q) acc += G[(size_t)list[q] * KP + c];
+    O[(size_t)c * n + p] = acc;
+  }
 }
 
 }  // namespace
@@ -432,6 +490,36 @@ int msr3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_o
   if (!grad_out || !idx || !weight) return MSR3D_EINVAL;
   three_interpolate_grad_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
       total, c, n, m, grad_out, idx, weight, grad_points);
+  return (int)hipGetLastError();
+}
+
+int msr3d_group_rows(int b, int n, int m, int nsample, int C, int KP, const float *xyz,
+                     const float *new_xyz, const float *feats, const int *idx, float *rows,
+                     msr3d_stream_t stream) {
+  if (b < 0 || n <= 0 || m < 0 || nsample < 0 || C < 0 || KP < 3 + C) return MSR3D_EINVAL;
+  if (b == 0 || m == 0 || nsample == 0) return 0;
+  if (!xyz || !new_xyz || !idx || !rows || (C > 0 && !feats)) return MSR3D_EINVAL;
+  group_rows_kernel<<<dim3(m, b), 256, 0, (hipStream_t)stream>>>(n, m, nsample, C, KP, xyz, new_xyz, feats,
+                                                                  idx, rows);
+  return (int)hipGetLastError();
+}
+
+int msr3d_group_rows_grad(int b, int n, int m, int nsample, int C, int KP, const float *d_rows,
+                          const int *idx, float *d_feats, msr3d_stream_t stream) {
+  if (b < 0 || n <= 0 || m < 0 || nsample < 0 || C <= 0 || KP < 3 + C) return MSR3D_EINVAL;
+  if (b == 0) return 0;
+  if (!d_feats) return MSR3D_EINVAL;
+  const int E = m * nsample;
+  if (E == 0) return (int)hipMemsetAsync(d_feats, 0, sizeof(float) * (size_t)b * C * n, (hipStream_t)stream);
+  if (!d_rows || !idx) return MSR3D_EINVAL;
+  if (!det_fits(n, E)) return MSR3D_EINVAL;          // the caller keeps the composite path
+  const size_t lds = sizeof(int) * (size_t)(2 * n + 1 + E);
+  static const hipError_t attr = hipFuncSetAttribute(
+      reinterpret_cast<const void *>(&group_rows_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+      (int)(sizeof(int) * kDetMaxInts));
+  if (attr != hipSuccess) return (int)attr;
+  group_rows_grad_kernel<<<dim3(b, (C + 63) / 64), 256, lds, (hipStream_t)stream>>>(n, E, C, KP, d_rows, idx,
+                                                                                   d_feats);
   return (int)hipGetLastError();
 }
 

@@ -368,11 +368,10 @@ class _BNReLUTrain(torch.autograd.Function):
         return dx, dg, db, None
 
 
-def shared_mlp_train_supported(mlp, x):
-    """GPU fp32 input, module in training mode, every layer a bias-free 1x1 convolution followed
-    by an affine, statistics-tracking BatchNorm2d and a ReLU, channel counts the kernels take."""
-    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and mlp.training
-            and getattr(mlp, "use_hip_train", True)):
+def _mlp_train_ok(mlp):
+    """Module in training mode, every layer a bias-free 1x1 convolution followed by an affine,
+    statistics-tracking BatchNorm2d and a ReLU, channel counts the kernels take."""
+    if not (mlp.training and getattr(mlp, "use_hip_train", True)):
         return False
     pairs = mlp.conv_bn_pairs()
     for layer, (conv, bn) in zip(mlp, pairs):
@@ -380,11 +379,27 @@ def shared_mlp_train_supported(mlp, x):
             return False
         if conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.padding != (0, 0) or conv.groups != 1:
             return False
-        if conv.out_channels % 4 or conv.out_channels > 1024 or not isinstance(list(layer.children())[-1], torch.nn.ReLU):
+        if conv.out_channels % 4 or conv.out_channels > 1024 or not isinstance(
+                list(layer.children())[-1], torch.nn.ReLU):
             return False
         if list(layer.children())[0] is not conv:          # pre-activation order is not on this path
             return False
     return len(pairs) > 0
+
+
+def shared_mlp_train_supported(mlp, x):
+    """GPU fp32 (B, C, npoint, nsample) input and a SharedMLP `_mlp_train_ok` accepts."""
+    return bool(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and _mlp_train_ok(mlp))
+
+
+def _mlp_rows(mlp, t):
+    """The SharedMLP on token-major rows t (R, K >= C_in, zero-padded) -> (R, C_out)."""
+    for conv, bn in mlp.conv_bn_pairs():
+        w = conv.weight.view(conv.out_channels, conv.in_channels)
+        if t.shape[1] != w.shape[1]:
+            w = F.pad(w, (0, t.shape[1] - w.shape[1]))      # zero columns against the operand's padding
+        t = _BNReLUTrain.apply(linear(t, w), bn.weight, bn.bias, bn)
+    return t
 
 
 def shared_mlp_train(mlp, x):
@@ -393,15 +408,66 @@ def shared_mlp_train(mlp, x):
     statistics updated), computed on a token-major copy: rows = (b, point, sample)."""
     B, C, NP, NS = x.shape
     t = x.permute(0, 2, 3, 1).reshape(B * NP * NS, C)
-    for conv, bn in mlp.conv_bn_pairs():
-        w = conv.weight.view(conv.out_channels, conv.in_channels)
-        if t.shape[1] != w.shape[1] or w.shape[1] % 4:
-            # 16-byte rows for the GEMM's vector loads: zero columns on both operands
-            pad = (-w.shape[1]) % 4
-            w = F.pad(w, (0, pad))
-            if t.shape[1] != w.shape[1]:
-                t = F.pad(t, (0, w.shape[1] - t.shape[1]))
-        t = _BNReLUTrain.apply(linear(t, w), bn.weight, bn.bias, bn)
+    if C % 4:
+        t = F.pad(t, (0, (-C) % 4))          # 16-byte rows for the GEMM's vector loads
+    t = _mlp_rows(mlp, t)
+    pooled = t.view(B, NP, NS, t.shape[1]).amax(dim=2)
+    return pooled.permute(0, 2, 1).contiguous()
+
+
+class _GroupRows(torch.autograd.Function):
+    """QueryAndGroup's output as token-major rows (msr3d_group_rows), gradient to the features by
+    the deterministic ordered scatter (msr3d_group_rows_grad)."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feats, idx, KP):
+        b, n, _ = xyz.shape
+        m, ns = idx.shape[1], idx.shape[2]
+        C = 0 if feats is None else feats.shape[1]
+        xyz, new_xyz, idx = xyz.contiguous(), new_xyz.contiguous(), idx.contiguous()
+        f = None if feats is None else feats.contiguous()
+        rows = torch.empty((b * m * ns, KP), dtype=torch.float32, device=xyz.device)
+        with torch.cuda.device(xyz.device):
+            rc = _lib.load().msr3d_group_rows(b, n, m, ns, C, KP, _p(xyz), _p(new_xyz), _p(f), _p(idx),
+                                              _p(rows), _lib.current_stream_ptr(xyz.device))
+        _lib.check(rc, "msr3d_group_rows")
+        ctx.save_for_backward(idx)
+        ctx.dims = (b, n, m, ns, C, KP)
+        return rows
+
+    @staticmethod
+    def backward(ctx, d_rows):
+        (idx,) = ctx.saved_tensors
+        b, n, m, ns, C, KP = ctx.dims
+        if C == 0 or not ctx.needs_input_grad[2]:
+            return None, None, None, None, None
+        d_rows = d_rows if d_rows.is_contiguous() else d_rows.contiguous()
+        d_feats = torch.empty((b, C, n), dtype=torch.float32, device=d_rows.device)
+        with torch.cuda.device(d_rows.device):
+            rc = _lib.load().msr3d_group_rows_grad(b, n, m, ns, C, KP, _p(d_rows), _p(idx), _p(d_feats),
+                                                   _lib.current_stream_ptr(d_rows.device))
+        _lib.check(rc, "msr3d_group_rows_grad")
+        return None, None, d_feats, None, None
+
+
+def group_rows_supported(xyz, new_xyz, feats, nsample):
+    """fp32 GPU tensors, coordinates that need no gradient (the level's inputs in MSR3D), and an
+    inverted index of one cloud that fits the backward kernel's LDS."""
+    if not (xyz.is_cuda and xyz.dtype == torch.float32 and new_xyz is not None and not xyz.requires_grad
+            and not new_xyz.requires_grad):
+        return False
+    if feats is not None and (feats.dtype != torch.float32 or feats.dim() != 3):
+        return False
+    return 2 * xyz.shape[1] + 1 + new_xyz.shape[1] * nsample <= 36 * 1024
+
+
+def sa_level_train(mlp, xyz, new_xyz, feats, idx):
+    """One set-abstraction scale in training mode: grouped rows -> SharedMLP -> max over the
+    neighbourhood, (B, C_out, npoint); idx (B, npoint, nsample) from ball_query."""
+    B, NP, NS = idx.shape
+    C = 0 if feats is None else feats.shape[1]
+    rows = _GroupRows.apply(xyz, new_xyz, feats, idx, (3 + C + 3) // 4 * 4)
+    t = _mlp_rows(mlp, rows)
     pooled = t.view(B, NP, NS, t.shape[1]).amax(dim=2)
     return pooled.permute(0, 2, 1).contiguous()
 

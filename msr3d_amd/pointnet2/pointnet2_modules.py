@@ -34,6 +34,14 @@ class _PointnetSAModuleBase(nn.Module):
         new_xyz = self.sample_centres(xyz)
         pooled = []
         for grouper, mlp in zip(self.groupers, self.mlps):
+            if (isinstance(grouper, pointnet2_utils.QueryAndGroup) and grouper.use_xyz
+                    and not grouper.normalize_xyz and not grouper.ret_grouped_xyz and hipops._mlp_train_ok(mlp)
+                    and hipops.group_rows_supported(xyz, new_xyz, features, grouper.nsample)):
+                # unfrozen backbone on the GPU: neighbourhood rows written token-major, straight into
+                # the layout the SharedMLP's token GEMMs read
+                idx = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
+                pooled.append(hipops.sa_level_train(mlp, xyz, new_xyz, features, idx))
+                continue
             grouped = grouper(xyz, new_xyz, features)     # (B, C_in, npoint, nsample)
             if hipops.shared_mlp_train_supported(mlp, grouped):
                 # unfrozen backbone on the GPU: the convolutions as token GEMMs, BatchNorm (batch

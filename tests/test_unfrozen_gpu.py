@@ -201,3 +201,57 @@ def test_shared_mlp_train_matches_torch_modules(spec, shape):
     mlp.train()
     mlp.use_hip_train = False
     assert not hipops.shared_mlp_train_supported(mlp, x)
+
+
+@pytest.mark.parametrize("n,m,ns,C,radius", [(1024, 32, 32, 3, 0.2), (32, 16, 32, 128, 0.4), (50, 7, 5, 0, 0.5)])
+def test_group_rows_is_query_and_group_token_major(n, m, ns, C, radius):
+    """msr3d_group_rows = QueryAndGroup's output permuted to (b, point, sample, channel), bit for bit;
+    its backward = the deterministic group_points_grad, bit for bit (same ascending-entry sums)."""
+    from msr3d_amd import hipops
+    from msr3d_amd.pointnet2 import pointnet2_utils as pu
+    torch.manual_seed(n + C)
+    b = 5
+    xyz = torch.rand(b, n, 3, device="cuda")
+    new_xyz = pu.gather_operation(xyz.transpose(1, 2).contiguous(), pu.furthest_point_sample(xyz, m)
+                                  ).transpose(1, 2).contiguous()
+    feats = torch.randn(b, C, n, device="cuda").requires_grad_() if C else None
+    assert hipops.group_rows_supported(xyz, new_xyz, feats, ns)
+    idx = pu.ball_query(radius, ns, xyz, new_xyz)
+    KP = (3 + C + 3) // 4 * 4
+    rows = hipops._GroupRows.apply(xyz, new_xyz, feats, idx, KP)
+    grouped = pu.QueryAndGroup(radius, ns, use_xyz=True)(xyz, new_xyz, feats)       # (b, 3+C, m, ns)
+    want = grouped.permute(0, 2, 3, 1).reshape(b * m * ns, 3 + C)
+    assert torch.equal(rows[:, :3 + C], want.detach())
+    assert int(rows[:, 3 + C:].abs().sum()) == 0
+    if C:
+        g = torch.randn_like(rows)
+        rows.backward(g)
+        got = feats.grad.clone()
+        feats.grad = None
+        grouped.backward(g[:, :3 + C].reshape(b, m, ns, 3 + C).permute(0, 3, 1, 2).contiguous())
+        assert torch.equal(got, feats.grad)
+    # coordinates that need a gradient keep the composite path
+    assert not hipops.group_rows_supported(xyz.clone().requires_grad_(), new_xyz, feats, ns)
+
+
+def test_sa_module_train_rows_path_matches_grouped_path():
+    """A PointnetSAModule in training mode: the token-major rows path against the same kernels fed
+    by the channel-major grouper (forced by coordinates that require a gradient)."""
+    from msr3d_amd.pointnet2.pointnet2_modules import PointnetSAModule
+    torch.manual_seed(4)
+    sa = PointnetSAModule(mlp=[128, 128, 128, 256], npoint=16, radius=0.4, nsample=32).cuda().train()
+    sb = copy.deepcopy(sa)
+    xyz = torch.rand(6, 32, 3, device="cuda")
+    f1 = torch.randn(6, 128, 32, device="cuda").requires_grad_()
+    f2 = f1.detach().clone().requires_grad_()
+    w = torch.randn(6, 256, 16, device="cuda")
+    _, out1 = sa(xyz, f1)
+    (out1 * w).sum().backward()
+    _, out2 = sb(xyz.clone().requires_grad_(), f2)          # composite grouper, same SharedMLP kernels
+    (out2 * w).sum().backward()
+    assert rel_l2(out1.detach().cpu().numpy(), out2.detach().cpu().numpy()) < 1e-6
+    assert rel_l2(f1.grad.cpu().numpy(), f2.grad.cpu().numpy()) < 1e-5
+    for (n, p), (_, q) in zip(sa.named_parameters(), sb.named_parameters()):
+        assert rel_l2(p.grad.cpu().numpy(), q.grad.cpu().numpy()) < 1e-5, n
+    for (n, a), (_, c) in zip(sa.named_buffers(), sb.named_buffers()):
+        assert rel_l2(a.float().cpu().numpy(), c.float().cpu().numpy()) < 1e-6, n
