@@ -25,14 +25,35 @@ constexpr int kChunk = MSR3D_BN_CHUNK_ROWS;     // rows per workgroup of the red
 // grid (chunks); 256 threads = RL row-lanes x C/4 float4 columns (RL = 256 / (C/4), C <= 1024): every
 // thread streams float4s of its 4 channels down the chunk's rows, the row-lanes then meet in LDS and
 // are added in lane order.  partial[chunk][2][C].
-template <bool BWD>
+// Upstream gradient of the fused max-pool variant: only the arg-max row of a (group, channel) carries
+// one, and only if the pooled value is positive (ReLU).  ns rows per group.
+struct Pooled {
+  int ns;
+  const float4 *dpooled;     // (G, C)
+  const float4 *pooled;      // (G, C)
+  const int4 *argmax;        // (G, C): row inside the group
+};
+__device__ __forceinline__ float4 pooled_grad(const Pooled &pg, long long r, int C4, int c4) {
+  const long long grp = r / pg.ns;
+  const int rloc = (int)(r - grp * pg.ns);
+  const int4 a = pg.argmax[grp * C4 + c4];
+  const float4 d = pg.dpooled[grp * C4 + c4], v = pg.pooled[grp * C4 + c4];
+  float4 g;
+  g.x = (a.x == rloc && v.x > 0.f) ? d.x : 0.f;
+  g.y = (a.y == rloc && v.y > 0.f) ? d.y : 0.f;
+  g.z = (a.z == rloc && v.z > 0.f) ? d.z : 0.f;
+  g.w = (a.w == rloc && v.w > 0.f) ? d.w : 0.f;
+  return g;
+}
+
+template <bool BWD, bool POOLED = false>
 __global__ __launch_bounds__(256) void bn_partial_kernel(long long R, int C, const float *__restrict__ x,
                                                          const float *__restrict__ dy,
                                                          const float *__restrict__ gamma,
                                                          const float *__restrict__ beta,
                                                          const float *__restrict__ mean,
                                                          const float *__restrict__ rstd,
-                                                         float *__restrict__ partial) {
+                                                         float *__restrict__ partial, Pooled pg = Pooled()) {
   extern __shared__ __attribute__((aligned(16))) float red[];      // [2][RL][C]
   const int C4 = C >> 2, RL = 256 / C4;
   const int rl = threadIdx.x / C4, c4 = threadIdx.x - rl * C4;
@@ -52,7 +73,17 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(long long R, int C, con
 #pragma unroll 4
     for (long long r = r0 + rl; r < r1; r += RL) {
       const float4 v = X[r * C4 + c4];
-      if (BWD) {
+      if (BWD && POOLED) {
+        const float4 g = pooled_grad(pg, r, C4, c4);
+#define BNQ(k)                                              \
+        {                                                   \
+          const float xh = (v.k - mu.k) * rs.k;             \
+          s1.k += g.k;                                      \
+          s2.k = __builtin_fmaf(g.k, xh, s2.k);             \
+        }
+        BNQ(x) BNQ(y) BNQ(z) BNQ(w)
+#undef BNQ
+      } else if (BWD) {
         const float4 d = D[r * C4 + c4];
 #define BNP(k)                                                             \
         {                                                                  \
@@ -156,18 +187,32 @@ __global__ void bn_relu_apply_kernel(long long n4, int C4, const float4 *__restr
   }
 }
 
+template <bool POOLED>
 __global__ void bn_relu_bwd_apply_kernel(long long n4, int C4, float inv_rows,
                                          const float4 *__restrict__ x, const float4 *__restrict__ dy,
                                          const float4 *__restrict__ gamma, const float4 *__restrict__ beta,
                                          const float4 *__restrict__ mean, const float4 *__restrict__ rstd,
                                          const float4 *__restrict__ dgamma, const float4 *__restrict__ dbeta,
-                                         float4 *__restrict__ dx) {
+                                         float4 *__restrict__ dx, Pooled pg) {
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n4;
        t += (long long)gridDim.x * blockDim.x) {
     const int c4 = (int)(t % C4);
-    const float4 v = x[t], d = dy[t], ga = gamma[c4], be = beta[c4], mu = mean[c4], rs = rstd[c4];
+    const float4 v = x[t], ga = gamma[c4], be = beta[c4], mu = mean[c4], rs = rstd[c4];
     const float4 dg = dgamma[c4], db = dbeta[c4];
     float4 o;
+    if (POOLED) {
+      const float4 g = pooled_grad(pg, t / C4, C4, c4);
+#define BNC(k)                                                                        \
+      {                                                                               \
+        const float xh = (v.k - mu.k) * rs.k;                                         \
+        o.k = ga.k * rs.k * (g.k - db.k * inv_rows - xh * (dg.k * inv_rows));         \
+      }
+      BNC(x) BNC(y) BNC(z) BNC(w)
+#undef BNC
+      dx[t] = o;
+      continue;
+    }
+    const float4 d = dy[t];
 #define BNB(k)                                                                        \
     {                                                                                 \
       const float xh = (v.k - mu.k) * rs.k;                                           \
@@ -178,6 +223,40 @@ __global__ void bn_relu_bwd_apply_kernel(long long n4, int C4, float inv_rows,
 #undef BNB
     dx[t] = o;
   }
+}
+
+// y = relu(bn(x)) and max over the ns rows of a group in one pass: pooled (G, C), argmax (G, C) =
+// FIRST row holding the maximum (F.max_pool2d's choice, pointnet2_modules.py:66-68).  The (R, C)
+// activation of the last layer is never written.  256 threads = GL groups x C/4 float4 columns.
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(long long G, int ns, int C4,
+                                                              const float4 *__restrict__ x,
+                                                              const float4 *__restrict__ gamma,
+                                                              const float4 *__restrict__ beta,
+                                                              const float4 *__restrict__ mean,
+                                                              const float4 *__restrict__ rstd,
+                                                              float4 *__restrict__ pooled,
+                                                              int4 *__restrict__ argmax) {
+  const int GL = 256 / C4;
+  const int gl = threadIdx.x / C4, c4 = threadIdx.x - gl * C4;
+  const long long grp = (long long)blockIdx.x * GL + gl;
+  if (gl >= GL || grp >= G) return;
+  const float4 ga = gamma[c4], be = beta[c4], mu = mean[c4], rs = rstd[c4];
+  float4 best = make_float4(-1.f, -1.f, -1.f, -1.f);       // relu(...) >= 0 > -1: row 0 always enters
+  int4 arg = make_int4(0, 0, 0, 0);
+  const float4 *X = x + grp * ns * C4 + c4;
+#pragma unroll 4
+  for (int r = 0; r < ns; ++r) {
+    const float4 v = X[(long long)r * C4];
+#define BNM(k)                                                                     \
+    {                                                                              \
+      const float y = fmaxf(__builtin_fmaf(ga.k, (v.k - mu.k) * rs.k, be.k), 0.f); \
+      if (y > best.k) { best.k = y; arg.k = r; }                                   \
+    }
+    BNM(x) BNM(y) BNM(z) BNM(w)
+#undef BNM
+  }
+  pooled[grp * C4 + c4] = best;
+  argmax[grp * C4 + c4] = arg;
 }
 
 inline int chunks_of(long long R) { return (int)((R + kChunk - 1) / kChunk); }
@@ -226,12 +305,66 @@ int msr3d_bn_relu_train_bwd(long long rows, int C, const float *x, const float *
                                                                partial_ws);
   bn_bwd_finalize_kernel<<<(C + 63) / 64, 256, 0, st>>>(C, chunks, partial_ws, dgamma, dbeta);
   const long long n4 = rows * (C / 4);
-  bn_relu_bwd_apply_kernel<<<ew_grid(n4), 256, 0, st>>>(
+  bn_relu_bwd_apply_kernel<false><<<ew_grid(n4), 256, 0, st>>>(
       n4, C / 4, 1.0f / (float)rows, reinterpret_cast<const float4 *>(x),
       reinterpret_cast<const float4 *>(dy), reinterpret_cast<const float4 *>(gamma),
       reinterpret_cast<const float4 *>(beta), reinterpret_cast<const float4 *>(save_mean),
       reinterpret_cast<const float4 *>(save_rstd), reinterpret_cast<const float4 *>(dgamma),
-      reinterpret_cast<const float4 *>(dbeta), reinterpret_cast<float4 *>(dx));
+      reinterpret_cast<const float4 *>(dbeta), reinterpret_cast<float4 *>(dx), Pooled());
+  return (int)hipGetLastError();
+}
+
+int msr3d_bn_relu_maxpool_train_fwd(long long rows, int C, int nsample, const float *x,
+                                    const float *gamma, const float *beta, float eps, float momentum,
+                                    float *running_mean, float *running_var, float *pooled, int *argmax,
+                                    float *save_mean, float *save_rstd, float *partial_ws,
+                                    msr3d_stream_t stream) {
+  if (rows < 0 || C <= 0 || (C % 4) != 0 || C > 1024 || nsample <= 0 || rows % nsample) return MSR3D_EINVAL;
+  if (rows == 0) return 0;
+  if (!x || !gamma || !beta || !pooled || !argmax || !save_mean || !save_rstd || !partial_ws) return MSR3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = chunks_of(rows);
+  bn_partial_kernel<false><<<chunks, 256, partial_lds(C), st>>>(rows, C, x, nullptr, nullptr, nullptr, nullptr,
+                                                                nullptr, partial_ws);
+  bn_fwd_finalize_kernel<<<(C + 63) / 64, 256, 0, st>>>(rows, C, chunks, partial_ws, eps, momentum,
+                                                        running_mean, running_var, save_mean, save_rstd);
+  const long long G = rows / nsample;
+  const int GL = 256 / (C / 4);
+  bn_relu_maxpool_kernel<<<(unsigned)((G + GL - 1) / GL), 256, 0, st>>>(
+      G, nsample, C / 4, reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(gamma),
+      reinterpret_cast<const float4 *>(beta), reinterpret_cast<const float4 *>(save_mean),
+      reinterpret_cast<const float4 *>(save_rstd), reinterpret_cast<float4 *>(pooled),
+      reinterpret_cast<int4 *>(argmax));
+  return (int)hipGetLastError();
+}
+
+int msr3d_bn_relu_maxpool_train_bwd(long long rows, int C, int nsample, const float *x,
+                                    const float *dpooled, const float *pooled, const int *argmax,
+                                    const float *gamma, const float *save_mean, const float *save_rstd,
+                                    float *dx, float *dgamma, float *dbeta, float *partial_ws,
+                                    msr3d_stream_t stream) {
+  if (rows < 0 || C <= 0 || (C % 4) != 0 || C > 1024 || nsample <= 0 || rows % nsample) return MSR3D_EINVAL;
+  if (rows == 0) return 0;
+  if (!x || !dpooled || !pooled || !argmax || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !dbeta ||
+      !partial_ws)
+    return MSR3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = chunks_of(rows);
+  Pooled pg;
+  pg.ns = nsample;
+  pg.dpooled = reinterpret_cast<const float4 *>(dpooled);
+  pg.pooled = reinterpret_cast<const float4 *>(pooled);
+  pg.argmax = reinterpret_cast<const int4 *>(argmax);
+  bn_partial_kernel<true, true><<<chunks, 256, partial_lds(C), st>>>(rows, C, x, nullptr, gamma, gamma, save_mean,
+                                                                     save_rstd, partial_ws, pg);
+  bn_bwd_finalize_kernel<<<(C + 63) / 64, 256, 0, st>>>(C, chunks, partial_ws, dgamma, dbeta);
+  const long long n4 = rows * (C / 4);
+  bn_relu_bwd_apply_kernel<true><<<ew_grid(n4), 256, 0, st>>>(
+      n4, C / 4, 1.0f / (float)rows, reinterpret_cast<const float4 *>(x), nullptr,
+      reinterpret_cast<const float4 *>(gamma), reinterpret_cast<const float4 *>(gamma),
+      reinterpret_cast<const float4 *>(save_mean), reinterpret_cast<const float4 *>(save_rstd),
+      reinterpret_cast<const float4 *>(dgamma), reinterpret_cast<const float4 *>(dbeta),
+      reinterpret_cast<float4 *>(dx), pg);
   return (int)hipGetLastError();
 }
 

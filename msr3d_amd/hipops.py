@@ -325,24 +325,13 @@ class _BNReLUTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, bn):
         R, C = x.shape
-        if R <= 1:          # as torch.nn.functional.batch_norm in training mode
-            raise ValueError(f"Expected more than 1 value per channel when training, got input size {x.shape}")
+        momentum, rm, rv = _bn_train_args(bn, x)
         x = x if x.is_contiguous() else x.contiguous()
         g, b = gamma.contiguous(), beta.contiguous()
         y = torch.empty_like(x)
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         ws = torch.empty(2 * C * max(1, -(-R // BN_CHUNK_ROWS)), dtype=torch.float32, device=x.device)
-        rm = rv = None
-        momentum = 0.0
-        if bn.track_running_stats and bn.running_mean is not None:
-            with torch.no_grad():
-                bn.num_batches_tracked += 1
-            # momentum None = cumulative average; the factor then depends on a device counter the
-            # host would have to read -- nn.BatchNorm2d's default (0.1) is what the backbone uses
-            if bn.momentum is None:
-                raise NotImplementedError("cumulative-average BatchNorm is not on this path")
-            momentum, rm, rv = float(bn.momentum), bn.running_mean, bn.running_var
         with torch.cuda.device(x.device):
             rc = _lib.load().msr3d_bn_relu_train_fwd(
                 R, C, _p(x), _p(g), _p(b), float(bn.eps), momentum, _p(rm), _p(rv), _p(y), _p(mean),
@@ -366,6 +355,64 @@ class _BNReLUTrain(torch.autograd.Function):
                 _lib.current_stream_ptr(x.device))
         _lib.check(rc, "msr3d_bn_relu_train_bwd")
         return dx, dg, db, None
+
+
+def _bn_train_args(bn, x):
+    """(momentum, running_mean, running_var) for the kernels; bumps num_batches_tracked like
+    nn.BatchNorm2d.forward."""
+    if x.shape[0] <= 1:          # as torch.nn.functional.batch_norm in training mode
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size {x.shape}")
+    if not (bn.track_running_stats and bn.running_mean is not None):
+        return 0.0, None, None
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+    # momentum None = cumulative average; the factor then depends on a device counter the host would
+    # have to read -- nn.BatchNorm2d's default (0.1) is what the backbone uses
+    if bn.momentum is None:
+        raise NotImplementedError("cumulative-average BatchNorm is not on this path")
+    return float(bn.momentum), bn.running_mean, bn.running_var
+
+
+class _BNReLUMaxPoolTrain(torch.autograd.Function):
+    """pooled (R / ns, C) = max over each group of ns consecutive rows of relu(batch_norm(x)): the last
+    SharedMLP layer fused with the neighbourhood max-pool (first maximum wins, as F.max_pool2d);
+    neither the (R, C) activation nor its gradient is materialised."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, ns):
+        R, C = x.shape
+        momentum, rm, rv = _bn_train_args(bn, x)
+        x = x if x.is_contiguous() else x.contiguous()
+        g, b = gamma.contiguous(), beta.contiguous()
+        pooled = torch.empty((R // ns, C), dtype=torch.float32, device=x.device)
+        arg = torch.empty((R // ns, C), dtype=torch.int32, device=x.device)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ws = torch.empty(2 * C * max(1, -(-R // BN_CHUNK_ROWS)), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().msr3d_bn_relu_maxpool_train_fwd(
+                R, C, ns, _p(x), _p(g), _p(b), float(bn.eps), momentum, _p(rm), _p(rv), _p(pooled), _p(arg),
+                _p(mean), _p(rstd), _p(ws), _lib.current_stream_ptr(x.device))
+        _lib.check(rc, "msr3d_bn_relu_maxpool_train_fwd")
+        ctx.save_for_backward(x, g, mean, rstd, pooled, arg)
+        ctx.ns = ns
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        x, g, mean, rstd, pooled, arg = ctx.saved_tensors
+        R, C = x.shape
+        dpooled = dpooled if dpooled.is_contiguous() else dpooled.contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty_like(dg)
+        ws = torch.empty(2 * C * max(1, -(-R // BN_CHUNK_ROWS)), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().msr3d_bn_relu_maxpool_train_bwd(
+                R, C, ctx.ns, _p(x), _p(dpooled), _p(pooled), _p(arg), _p(g), _p(mean), _p(rstd), _p(dx),
+                _p(dg), _p(db), _p(ws), _lib.current_stream_ptr(x.device))
+        _lib.check(rc, "msr3d_bn_relu_maxpool_train_bwd")
+        return dx, dg, db, None, None
 
 
 def _mlp_train_ok(mlp):
@@ -392,26 +439,32 @@ def shared_mlp_train_supported(mlp, x):
     return bool(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and _mlp_train_ok(mlp))
 
 
-def _mlp_rows(mlp, t):
-    """The SharedMLP on token-major rows t (R, K >= C_in, zero-padded) -> (R, C_out)."""
-    for conv, bn in mlp.conv_bn_pairs():
+def _mlp_rows(mlp, t, pool_ns):
+    """The SharedMLP on token-major rows t (R, K >= C_in, zero-padded), then the max over every
+    pool_ns consecutive rows -> (R / pool_ns, C_out); the last layer's normalisation and the pooling
+    are one kernel."""
+    pairs = mlp.conv_bn_pairs()
+    for j, (conv, bn) in enumerate(pairs):
         w = conv.weight.view(conv.out_channels, conv.in_channels)
         if t.shape[1] != w.shape[1]:
             w = F.pad(w, (0, t.shape[1] - w.shape[1]))      # zero columns against the operand's padding
-        t = _BNReLUTrain.apply(linear(t, w), bn.weight, bn.bias, bn)
+        z = linear(t, w)
+        if j + 1 < len(pairs):
+            t = _BNReLUTrain.apply(z, bn.weight, bn.bias, bn)
+        else:
+            t = _BNReLUMaxPoolTrain.apply(z, bn.weight, bn.bias, bn, pool_ns)
     return t
 
 
 def shared_mlp_train(mlp, x):
     """x (B, C, npoint, nsample) -> max over nsample of the SharedMLP's output, (B, C_out, npoint).
-    Same values as `torch.amax(mlp(x), dim=3)` in training mode (batch statistics, running
+    Same values as `F.max_pool2d(mlp(x), [1, nsample])` in training mode (batch statistics, running
     statistics updated), computed on a token-major copy: rows = (b, point, sample)."""
     B, C, NP, NS = x.shape
     t = x.permute(0, 2, 3, 1).reshape(B * NP * NS, C)
     if C % 4:
         t = F.pad(t, (0, (-C) % 4))          # 16-byte rows for the GEMM's vector loads
-    t = _mlp_rows(mlp, t)
-    pooled = t.view(B, NP, NS, t.shape[1]).amax(dim=2)
+    pooled = _mlp_rows(mlp, t, NS).view(B, NP, -1)
     return pooled.permute(0, 2, 1).contiguous()
 
 
@@ -467,8 +520,7 @@ def sa_level_train(mlp, xyz, new_xyz, feats, idx):
     B, NP, NS = idx.shape
     C = 0 if feats is None else feats.shape[1]
     rows = _GroupRows.apply(xyz, new_xyz, feats, idx, (3 + C + 3) // 4 * 4)
-    t = _mlp_rows(mlp, rows)
-    pooled = t.view(B, NP, NS, t.shape[1]).amax(dim=2)
+    pooled = _mlp_rows(mlp, rows, NS).view(B, NP, -1)
     return pooled.permute(0, 2, 1).contiguous()
 
 

@@ -255,3 +255,39 @@ def test_sa_module_train_rows_path_matches_grouped_path():
         assert rel_l2(p.grad.cpu().numpy(), q.grad.cpu().numpy()) < 1e-5, n
     for (n, a), (_, c) in zip(sa.named_buffers(), sb.named_buffers()):
         assert rel_l2(a.float().cpu().numpy(), c.float().cpu().numpy()) < 1e-6, n
+
+
+@pytest.mark.parametrize("G,ns,C", [(300, 32, 128), (64, 16, 768), (7, 5, 4), (1000, 32, 64)])
+def test_bn_relu_maxpool_train_matches_max_pool2d_float64(G, ns, C):
+    """The last SharedMLP layer fused with the neighbourhood max-pool against float64
+    batch_norm -> relu -> F.max_pool2d([1, nsample]) (the reference's pooling, first maximum wins):
+    pooled values, dx, dgamma, dbeta, running statistics; duplicated rows (what ball_query's padding
+    produces) exercise the tie rule."""
+    import torch.nn.functional as F
+    from msr3d_amd import hipops
+    torch.manual_seed(G + ns + C)
+    x = torch.randn(G, ns, C, device="cuda") * 1.5 + 0.3
+    x[::3, ns - 1] = x[::3, 0]                       # exact duplicates: the maximum may be tied
+    x[1::3, ns // 2] = x[1::3, 1]
+    x = x.reshape(G * ns, C).requires_grad_()
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.5)
+    ref = copy.deepcopy(bn).double()
+    gp = torch.randn(G, C, device="cuda")
+
+    pooled = hipops._BNReLUMaxPoolTrain.apply(x, bn.weight, bn.bias, bn, ns)
+    pooled.backward(gp)
+
+    xd = x.detach().double().requires_grad_()
+    yd = torch.relu(F.batch_norm(xd, ref.running_mean, ref.running_var, ref.weight, ref.bias, training=True,
+                                 momentum=0.1, eps=bn.eps))
+    pd = F.max_pool2d(yd.view(G, ns, C).permute(2, 0, 1)[None], kernel_size=[1, ns])[0, :, :, 0].t()   # (G, C)
+    pd.backward(gp.double())
+    assert rel_l2(pooled.detach().cpu().numpy(), pd.detach().cpu().numpy()) < 1e-5
+    assert rel_l2(x.grad.cpu().numpy(), xd.grad.cpu().numpy()) < 5e-5
+    assert rel_l2(bn.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy()) < 5e-5
+    assert rel_l2(bn.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy()) < 5e-5
+    assert rel_l2(bn.running_var.cpu().numpy(), ref.running_var.cpu().numpy()) < 1e-5
+    assert int(bn.num_batches_tracked) == 1
