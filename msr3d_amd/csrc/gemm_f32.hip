@@ -683,7 +683,10 @@ static int gemm_f32_impl(int a_kc, int b_kc, int M, int N, int K, const float *A
   bool empty;
   // short-reduction forward linears: A-resident kernel (no split-K, no meeting point, no zero-fill)
   static const int ares_min_n = getenv("MSR3D_GEMM_ARES_MIN_N") ? atoi(getenv("MSR3D_GEMM_ARES_MIN_N")) : 512;
-  if (a_kc && b_kc && !a_colsum && M > 0 && N >= ares_min_n && K >= 16 && K <= 256 && K % 16 == 0 && A && B && C &&
+  // (wide outputs, or tall problems -- the unfrozen backbone's SharedMLP layers, up to 983 k rows -- whose
+  // row strips alone fill the chip)
+  if (a_kc && b_kc && !a_colsum && M > 0 && (N >= ares_min_n || (M >= 8192 && N >= 64)) && K >= 16 && K <= 256 &&
+      K % 16 == 0 && A && B && C &&
       vec_ok(A, lda) && vec_ok(B, ldb)) {
     if (p_drop > 0.f) {
       if (p_drop >= 1.f || !seed || ldc != N) return MSR3D_EINVAL;

@@ -519,7 +519,7 @@ def sa_level_train(mlp, xyz, new_xyz, feats, idx):
     neighbourhood, (B, C_out, npoint); idx (B, npoint, nsample) from ball_query."""
     B, NP, NS = idx.shape
     C = 0 if feats is None else feats.shape[1]
-    rows = _GroupRows.apply(xyz, new_xyz, feats, idx, (3 + C + 3) // 4 * 4)
+    rows = _GroupRows.apply(xyz, new_xyz, feats, idx, (3 + C + 15) // 16 * 16)   # whole 16-wide K slabs
     pooled = _mlp_rows(mlp, rows, NS).view(B, NP, -1)
     return pooled.permute(0, 2, 1).contiguous()
 
