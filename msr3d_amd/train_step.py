@@ -52,6 +52,7 @@ class HotPathTrainStep:
         if self.accum_steps < 1:
             raise ValueError("accum_steps must be >= 1")
         self._micro = 0
+        self._zero_in_graph = False
         # encoder prefetch (software pipelining over steps)
         self._enc_stream = torch.cuda.Stream() if self.static["obj_embeds"].is_cuda else None
         self._pref = {"key": None, "feats": torch.empty_like(self.static["obj_embeds"]), "event": None}
@@ -97,7 +98,7 @@ class HotPathTrainStep:
     def _micro_step(self, run, between=None):
         """Split schedule: zero the gradients before the first micro-batch, `run` forward/backward
         (eagerly or by graph replay), exchange + optimiser after the last one."""
-        if self._micro == 0:
+        if self._micro == 0 and not self._zero_in_graph:
             self.dp.zero_grad()
         loss = run()
         self._micro += 1
@@ -168,8 +169,10 @@ class HotPathTrainStep:
             self.dp.defer_comm = True
         # thread_local: other threads (RCCL's watchdog polling its events, loader threads) may keep
         # calling the HIP runtime while this thread captures
+        # one micro-batch per optimiser step: the gradient zero-fill rides in the graph as well
+        self._zero_in_graph = self.split and self.accum_steps == 1
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.loss = self._fwd_bwd(zero=False) if self.split else self._train_part()
+            self.loss = self._fwd_bwd(zero=self._zero_in_graph) if self.split else self._train_part()
 
     def __call__(self, batch, next_batch=None):
         """One training step on `batch`.  If `next_batch` is given its frozen-encoder pass is run
