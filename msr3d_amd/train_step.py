@@ -39,6 +39,10 @@ class HotPathTrainStep:
         accum_steps-th call."""
         self.model, self.opt, self.dp, self.loss_fn = model, optimizer, dp, loss_fn
         self.prompter = model.visual_prompter
+        if any(p.requires_grad for p in self.prompter.obj_encoder.parameters()):
+            # the encoder pass is hoisted out of autograd here (frozen in every shipped config); an
+            # unfrozen backbone trains through the modules' own forward/backward in a plain loop
+            raise NotImplementedError("HotPathTrainStep expects a frozen object encoder (freeze: True)")
         self.use_graph = use_graph and example_batch["obj_fts"].is_cuda
         self.static = {k: torch.empty_like(v) for k, v in example_batch.items() if k != "obj_fts"}
         B, O = example_batch["obj_fts"].shape[:2]
