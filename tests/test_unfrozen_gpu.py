@@ -291,3 +291,42 @@ def test_bn_relu_maxpool_train_matches_max_pool2d_float64(G, ns, C):
     assert rel_l2(bn.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy()) < 5e-5
     assert rel_l2(bn.running_var.cpu().numpy(), ref.running_var.cpu().numpy()) < 1e-5
     assert int(bn.num_batches_tracked) == 1
+
+
+def test_hot_path_model_trains_an_unfrozen_backbone_in_a_plain_loop():
+    """`freeze: False` end to end: MSR3DHotPath forward / backward / AdamW in an ordinary torch loop --
+    backbone, situated encoder and projector all receive gradients, the loss goes down, BN running
+    statistics move; the hoisted train step says it does not take this configuration."""
+    import msr3d_amd.model  # noqa: F401
+    import msr3d_amd.modules  # noqa: F401
+    from msr3d_amd.config import AttrDict, default_prompter_cfg
+    from msr3d_amd.dp import FlatGradAllReduce
+    from msr3d_amd.model import build_model
+    from msr3d_amd.synth import synth_batch
+    from msr3d_amd.train_step import HotPathTrainStep
+    torch.manual_seed(0)
+    cfg = AttrDict({"prompter": default_prompter_cfg(freeze=False, dropout=0.0), "llm_hidden_size": 64,
+                    "model": {"name": "MSR3DHotPath"}})
+    model = build_model(cfg).cuda().train()
+    enc = model.visual_prompter.obj_encoder
+    assert not enc.freeze and all(p.requires_grad for p in enc.pcd_net.parameters())
+    batch = synth_batch(9, 2, O=12, P=1024, device="cuda")
+    rm0 = enc.pcd_net.encoder[0].mlps[0].layer0.bn.bn.running_mean.clone()
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    target = torch.randn(2, 12, 64, device="cuda")
+    losses = []
+    for _ in range(6):
+        opt.zero_grad(set_to_none=True)
+        out = model(dict(batch))["scene_embeds"]
+        loss = (out - target).square().mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    w = enc.pcd_net.encoder[0].mlps[0].layer0.conv.weight
+    assert w.grad is not None and float(w.grad.abs().sum()) > 0
+    assert model.llm_proj.weight.grad is not None
+    assert losses[-1] < losses[0]
+    assert not torch.equal(rm0, enc.pcd_net.encoder[0].mlps[0].layer0.bn.bn.running_mean)
+    dp = FlatGradAllReduce([p for p in model.parameters() if p.requires_grad])
+    with pytest.raises(NotImplementedError, match="frozen object encoder"):
+        HotPathTrainStep(model, opt, dp, lambda o: o["scene_embeds"].sum(), batch)
