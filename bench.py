@@ -350,9 +350,16 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
-        print(json.dumps(line), flush=True)
+    else:
+        line = None
     if dist_on:
         dist.destroy_process_group()
+        # RCCL's rank 0 writes a version banner through C stdio, which sits in its buffer until exit:
+        # push it out now so that the JSON line below is the LAST thing on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    if line is not None:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
