@@ -177,7 +177,14 @@ class _HipLinear(torch.autograd.Function):
             return dx.reshape(ctx.x_shape), None, None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-            _gemm(True, False, M, K, N, dy2, N, w, K, dx, K)          # dx = dy @ W
+            if M >= 8192 and K >= 64 and 16 <= N <= 256 and N % 16 == 0:
+                # tall and skinny (the unfrozen backbone's SharedMLP layers, up to 983 k rows): against a
+                # transposed copy of the small weight this is a forward-shaped product with a short
+                # reduction, which the A-resident kernel takes (one strip of dy in LDS, no per-slab barrier)
+                wt = w.t().contiguous()
+                _gemm(True, True, M, K, N, dy2, N, wt, N, dx, K)
+            else:
+                _gemm(True, False, M, K, N, dy2, N, w, K, dx, K)          # dx = dy @ W
             dx = dx.reshape(ctx.x_shape)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if direct:

@@ -13,6 +13,8 @@ SHAPES = [  # (M, K, N)
     (65, 33, 67), (1, 256, 256), (130, 84, 256),
     # short reduction, wide output: the A-resident forward kernel, ragged in M and N
     (1000, 144, 520), (70, 16, 600), (129, 256, 1028), (3, 240, 4100),
+    # tall and skinny (SharedMLP layers of the unfrozen backbone): forward and dx on the A-resident kernel
+    (9000, 64, 128), (8200, 144, 64), (8192, 16, 64),
 ]
 
 
