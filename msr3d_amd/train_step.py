@@ -139,13 +139,20 @@ class HotPathTrainStep:
         with torch.no_grad():
             if self._pref["key"] == id(batch["obj_fts"]):     # features were prefetched
                 torch.cuda.current_stream().wait_event(self._pref["event"])
-                self.static["obj_embeds"].copy_(self._pref["feats"])
+                feats = self._pref["feats"]
                 self._pref["key"] = None
             else:
-                self.static["obj_embeds"].copy_(self.prompter.encode_objects(batch["obj_fts"], batch.get("obj_masks")))
-            for k, v in self.static.items():
-                if k != "obj_embeds":
-                    v.copy_(batch[k])
+                feats = self.prompter.encode_objects(batch["obj_fts"], batch.get("obj_masks"))
+            # all inputs into the static buffers with one multi-tensor copy per dtype (two launches
+            # instead of five: every launch costs the step ~5 us)
+            keys = [k for k in self.static if k != "obj_embeds"]
+            dst = [self.static["obj_embeds"]] + [self.static[k] for k in keys]
+            src = [feats] + [batch[k] for k in keys]
+            if all(d.is_cuda and s.is_cuda and d.dtype == s.dtype and d.shape == s.shape for d, s in zip(dst, src)):
+                torch._foreach_copy_(dst, src)
+            else:
+                for d, s in zip(dst, src):
+                    d.copy_(s)
 
     def capture(self, batch, warmup=3):
         """Warm up on a side stream (allocator, autotune, lazy inits), then capture."""
