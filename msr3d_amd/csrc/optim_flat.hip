@@ -42,7 +42,13 @@ __global__ __launch_bounds__(256) void sumsq_kernel(long long n4, const float4 *
   if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
+// `sched` = schedule id | (scheduler steps per optimiser update << 8): accelerate's
+// AcceleratedScheduler steps the LambdaLR num_processes times per update, so with N ranks the
+// reference's lambda sees step * N (0 in the high bits = 1).
 __device__ __forceinline__ float lr_lambda(int sched, int step, int warmup, int total) {
+  const int mult = (sched >> 8) > 0 ? (sched >> 8) : 1;
+  sched &= 0xff;
+  step *= mult;
   if (sched == 1) {   // warmup_cosine_instructblip (optim/scheduler.py:17-20)
     if (step <= warmup) return 1e-3f + (float)step / (float)warmup * (1.0f - 1e-3f);
     const double x = (double)(step - warmup) / (double)(total - warmup) * 3.14159265358979323846;
@@ -124,6 +130,7 @@ int msr3d_adamw_flat(long long n, float *params, float *grads, float *exp_avg, f
   if (n == 0) return 0;
   if (!params || !grads || !exp_avg || !exp_avg_sq || !sumsq_scratch || !step_counter)
     return MSR3D_EINVAL;
+  if ((schedule & 0xff) == 1 && !(total_steps > warmup_steps && warmup_steps >= 1)) return MSR3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const long long n4 = n / 4;
   long long gsz = (n4 + 255) / 256;

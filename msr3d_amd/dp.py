@@ -34,10 +34,13 @@ import torch.distributed as dist
 
 class FlatGradAllReduce:
     def __init__(self, params, bucket_bytes=8 << 20, process_group=None, overlap=False,
-                 pack_groups=None):
+                 pack_groups=None, sync_params=True):
         """pack_groups: lists of parameters that must sit back to back (in the given order) in the
         flat buffer, e.g. the q/k/v/cond projection weights of one attention block, so that a
-        consumer can treat them as ONE tensor (hipops.linear_packed) -- see collect_pack_groups."""
+        consumer can treat them as ONE tensor (hipops.linear_packed) -- see collect_pack_groups.
+        sync_params: broadcast rank 0's parameter values at construction, as torch DDP's wrap does
+        (the reference gets it from accelerate.prepare, trainer/leo_trainer.py:135): replicas start
+        identical whatever each rank seeded or loaded."""
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -96,8 +99,13 @@ class FlatGradAllReduce:
         for p in order:
             counts[self._bucket_of[id(p)]] += 1
         self._bucket_size = counts
-        self._ready = [0] * len(self.buckets)
+        # readiness is counted per DISTINCT parameter: a module applied twice in one forward
+        # (loc_embedding_encoder in 'as_embedding') reports its gradient twice
+        self._ready = [set() for _ in self.buckets]
         self._launched = [False] * len(self.buckets)
+        # hold: gradient accumulation -- micro-batches before the last one must not exchange
+        # (begin_micro); the buckets then launch from the LAST micro-batch's hooks, or from start()
+        self.hold = False
         self.comm_stream = torch.cuda.Stream(device=dev) if self.on_gpu else None
         # defer_comm (default): collectives are issued by finish(), after backward has been
         # enqueued -- required when backward is replayed from a HIP graph, and the safe choice
@@ -107,6 +115,8 @@ class FlatGradAllReduce:
         if self.distributed:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
+        if sync_params:
+            self.broadcast_params()
 
     # ------------------------------------------------------------------ hooks
     def packed_range(self, group):
@@ -127,9 +137,45 @@ class FlatGradAllReduce:
 
     def _on_grad(self, p):
         b = self._bucket_of[id(p)]
-        self._ready[b] += 1
-        if self._ready[b] == self._bucket_size[b] and not self.defer_comm:
+        self._ready[b].add(id(p))
+        if len(self._ready[b]) == self._bucket_size[b] and not self.defer_comm and not self.hold:
             self._launch(b)
+
+    def begin_micro(self, last):
+        """Gradient accumulation: call before every micro-batch's backward.  Gradients add up in the
+        flat buffer; only the LAST micro-batch may exchange (overlap mode would otherwise send a
+        bucket after the first micro-batch and never again: replicas diverge silently)."""
+        self._ready = [set() for _ in self.buckets]
+        self.hold = not last
+
+    # ------------------------------------------------------------------ replica consistency
+    def broadcast_params(self, src=0):
+        """Every rank takes rank `src`'s parameter values (one flat broadcast)."""
+        if not (dist.is_initialized() and self.world > 1):
+            return
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1) for p in self.order])
+            dist.broadcast(flat, src=src, group=self.group)
+            off = 0
+            for p in self.order:
+                n = p.numel()
+                p.copy_(flat[off:off + n].view_as(p))
+                off += n
+
+    def replica_checksum(self, tensor=None):
+        """(sum, sum of squares) in float64 of the parameters (or of `tensor`), and the largest
+        difference of that pair across ranks -- 0.0 when the replicas hold identical bits' worth of
+        values.  Costs one tiny all-reduce pair; used by bench.py and the tests."""
+        with torch.no_grad():
+            t = tensor if tensor is not None else torch.cat([p.detach().reshape(-1) for p in self.order])
+            t = t.double()
+            mine = torch.stack([t.sum(), (t * t).sum()])
+        if not (dist.is_initialized() and self.world > 1):
+            return mine.tolist(), 0.0
+        hi, lo = mine.clone(), mine.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        return mine.tolist(), float((hi - lo).abs().max())
 
     def _reduce(self, view):
         # SUM then scale: works on every backend (gloo has no AVG), one tiny launch
@@ -155,7 +201,7 @@ class FlatGradAllReduce:
     def zero_grad(self):
         """One memset for every gradient; `.grad` views stay attached."""
         self.flat.zero_()
-        self._ready = [0] * len(self.buckets)
+        self._ready = [set() for _ in self.buckets]
         self._launched = [False] * len(self.buckets)
 
     def finish(self):

@@ -39,12 +39,49 @@ def scatter_scene_embeds(inputs_embeds, attention_mask, input_ids, scene_embeds,
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 
-def scatter_scene_embeds_(inputs_embeds, attention_mask, input_ids, scene_embeds, scene_mask,
-                          scene_sp_token=SCENE_SP_TOKEN):
-    """In-place HIP version of the same hand-off (msr3d_scene_scatter): two launches, no host
-    sync.  inputs_embeds (B,T,E) f32/f16/bf16 contiguous, attention_mask (B,T) int64 (or None),
-    input_ids (B,T) int64, scene_embeds (B,L,E) f32, scene_mask (B,L) bool.  Returns the device
-    int holding the number of placeholders found (== B*L in a well-formed batch)."""
+class _ScatterSceneEmbeds(torch.autograd.Function):
+    """The training-time form of the hand-off: in place like msr3d.py:279-287, with the gradient
+    the reference's indexed assignment has -- d scene_embeds = the placeholder rows of
+    d inputs_embeds, and those rows of the overwritten embeddings receive none."""
+
+    @staticmethod
+    def forward(ctx, inputs_embeds, scene_embeds, attention_mask, input_ids, scene_mask, token):
+        cnt, ws = _scatter_launch(inputs_embeds, attention_mask, input_ids, scene_embeds.detach(),
+                                  scene_mask, token)
+        ctx.mark_dirty(inputs_embeds)
+        ctx.save_for_backward(ws, cnt)
+        ctx.shape = tuple(scene_embeds.shape)
+        ctx.cnt = cnt
+        return inputs_embeds
+
+    @staticmethod
+    def backward(ctx, g):
+        ws, cnt = ctx.saved_tensors
+        n = ws.numel()
+        E = g.shape[-1]
+        g2 = g.reshape(-1, E)
+        BT = g2.shape[0]
+        # map entries beyond the count (malformed batch) carry no gradient; no host sync: they are
+        # routed to a scratch row past the end
+        live = torch.arange(n, device=ws.device) < cnt.to(torch.int64)
+        rows = torch.where(live, ws.long().clamp(0, BT - 1), torch.full_like(ws, BT, dtype=torch.int64))
+        ext = torch.cat([g2, g2.new_zeros(1, E)], 0)
+        d_scene = ext.index_select(0, rows).to(torch.float32).reshape(ctx.shape)
+        ext.index_fill_(0, rows, 0)
+        return ext[:BT].view_as(g), d_scene, None, None, None, None
+
+
+def scatter_scene_embeds_train_(inputs_embeds, attention_mask, input_ids, scene_embeds, scene_mask,
+                                scene_sp_token=SCENE_SP_TOKEN):
+    """In-place HIP hand-off WITH autograd (use this one where msr3d.py:279-287 sits in the
+    training forward): returns inputs_embeds; gradients reach scene_embeds (hence llm_proj and the
+    prompter).  The placeholder count stays on the device: `placeholder_count(inputs_embeds)`."""
+    out = _ScatterSceneEmbeds.apply(inputs_embeds, scene_embeds, attention_mask, input_ids, scene_mask,
+                                    scene_sp_token)
+    return out
+
+
+def _scatter_launch(inputs_embeds, attention_mask, input_ids, scene_embeds, scene_mask, scene_sp_token):
     import ctypes
 
     from .. import _lib
@@ -67,6 +104,32 @@ def scatter_scene_embeds_(inputs_embeds, attention_mask, input_ids, scene_embeds
                                      p(attention_mask), p(ws), p(cnt),
                                      _lib.current_stream_ptr(input_ids.device))
     _lib.check(rc, "msr3d_scene_scatter")
+    return cnt, ws
+
+
+def scatter_scene_embeds_(inputs_embeds, attention_mask, input_ids, scene_embeds, scene_mask,
+                          scene_sp_token=SCENE_SP_TOKEN, validate=False):
+    """In-place HIP version of the same hand-off (msr3d_scene_scatter): two launches, no host
+    sync.  inputs_embeds (B,T,E) f32/f16/bf16 contiguous, attention_mask (B,T) int64 (or None),
+    input_ids (B,T) int64, scene_embeds (B,L,E) f32, scene_mask (B,L) bool.  Returns the device
+    int holding the number of placeholders found (== B*L in a well-formed batch).
+
+    INFERENCE / no-grad only: the kernel writes through raw pointers, autograd does not see it.
+    Called with gradients enabled on a scene_embeds that requires grad it raises (silently cutting
+    the trainable hot path off from the loss is the failure mode this guards against) -- training
+    uses scatter_scene_embeds_train_ (same kernels, autograd node) or scatter_scene_embeds.
+    validate=True syncs and raises if the placeholder count differs from B*L, as the reference's
+    indexed assignment does on a shape mismatch (msr3d.py:285)."""
+    if torch.is_grad_enabled() and (scene_embeds.requires_grad or inputs_embeds.requires_grad):
+        raise RuntimeError("scatter_scene_embeds_ has no autograd: use scatter_scene_embeds_train_ "
+                           "(or run under torch.no_grad() for inference)")
+    cnt, _ = _scatter_launch(inputs_embeds, attention_mask, input_ids, scene_embeds, scene_mask,
+                             scene_sp_token)
+    if validate:
+        n = scene_embeds.shape[0] * scene_embeds.shape[1]
+        found = int(cnt.item())
+        if found != n:
+            raise RuntimeError(f"{found} scene placeholders in input_ids but {n} scene tokens")
     return cnt
 
 

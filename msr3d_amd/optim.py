@@ -17,7 +17,21 @@ SCHEDULES = {"constant": 0, "warmup_cosine_instructblip": 1}
 
 class FlatAdamW:
     def __init__(self, dp, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05,
-                 max_grad_norm=5.0, schedule="constant", warmup_steps=400, total_steps=1):
+                 max_grad_norm=5.0, schedule="constant", warmup_steps=400, total_steps=1,
+                 sched_steps_per_update=1):
+        """schedule 'warmup_cosine_instructblip' follows optim/scheduler.py:17-20 in units of
+        SCHEDULER steps.  In the reference accelerate's AcceleratedScheduler advances the LambdaLR
+        `num_processes` times per optimiser step (split_batches False), so on N GPUs the 400-step
+        warm-up lasts 400/N optimiser steps: pass sched_steps_per_update=N (and the reference's
+        total = epochs * len(loader) * N scheduler steps) to reproduce its learning-rate curve."""
+        if schedule not in SCHEDULES:
+            raise ValueError("schedule must be one of %s" % sorted(SCHEDULES))
+        if SCHEDULES[schedule] == 1 and not total_steps > warmup_steps >= 1:
+            raise ValueError("warmup_cosine_instructblip needs total_steps > warmup_steps >= 1 "
+                             f"(got total_steps={total_steps}, warmup_steps={warmup_steps})")
+        if sched_steps_per_update < 1:
+            raise ValueError("sched_steps_per_update must be >= 1")
+        self.sched_mult = int(sched_steps_per_update)
         self.dp = dp
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
@@ -43,6 +57,16 @@ class FlatAdamW:
         self.sumsq = torch.zeros(1024, dtype=torch.float32, device=flat_g.device)   # block partials
         self.step_ctr = torch.zeros(1, dtype=torch.int32, device=flat_g.device)
         self.fused_clip = True
+        self.sync_replicas()
+
+    def sync_replicas(self, src=0):
+        """Every rank takes rank `src`'s parameters, moments and step counter (what torch DDP's wrap
+        does for the parameters; call it again after a rank-0-only checkpoint load)."""
+        import torch.distributed as dist
+        if not (dist.is_initialized() and self.dp.world > 1):
+            return
+        for t in (self.flat_p, self.exp_avg, self.exp_avg_sq, self.step_ctr):
+            dist.broadcast(t, src=src, group=self.dp.group)
 
     def step(self, zero_grad=False):
         lib = _lib.load()
@@ -54,15 +78,34 @@ class FlatAdamW:
                                       p(self.exp_avg), p(self.exp_avg_sq), p(self.sumsq),
                                       p(self.step_ctr), f(self.lr), f(self.betas[0]), f(self.betas[1]),
                                       f(self.eps), f(self.wd), f(self.max_grad_norm or 0.0),
-                                      self.schedule, self.warmup_steps, self.total_steps,
-                                      int(zero_grad), _lib.current_stream_ptr(dev))
+                                      self.schedule | (self.sched_mult << 8), self.warmup_steps,
+                                      self.total_steps, int(zero_grad), _lib.current_stream_ptr(dev))
         _lib.check(rc, "msr3d_adamw_flat")
 
-    def state_dict(self):
-        return {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
-                "step": int(self.step_ctr.item())}
+    def state_dict(self, names=None):
+        """Per-parameter moments keyed by position in `dp.order` (or by `names[i]`, the parameter
+        names in that order): independent of the flat layout, so it survives a change of pack groups
+        or of the trainable set."""
+        keys = list(names) if names is not None else [str(i) for i in range(len(self.dp.order))]
+        if len(keys) != len(self.dp.order):
+            raise ValueError("names must have one entry per parameter of dp.order")
+        state, off = {}, 0
+        for k, p in zip(keys, self.dp.order):
+            n = p.numel()
+            state[k] = {"exp_avg": self.exp_avg[off:off + n].view_as(p).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + n].view_as(p).clone()}
+            off += n
+        return {"state": state, "step": int(self.step_ctr.item())}
 
-    def load_state_dict(self, sd):
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+    def load_state_dict(self, sd, names=None):
+        keys = list(names) if names is not None else [str(i) for i in range(len(self.dp.order))]
+        off = 0
+        for k, p in zip(keys, self.dp.order):
+            n = p.numel()
+            if k in sd["state"]:
+                if tuple(sd["state"][k]["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state of {k}: shape mismatch")
+                self.exp_avg[off:off + n].copy_(sd["state"][k]["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + n].copy_(sd["state"][k]["exp_avg_sq"].reshape(-1))
+            off += n
         self.step_ctr.fill_(int(sd["step"]))

@@ -104,6 +104,8 @@ class HotPathTrainStep:
         (eagerly or by graph replay), exchange + optimiser after the last one."""
         if self._micro == 0 and not self._zero_in_graph:
             self.dp.zero_grad()
+        # only the last micro-batch may exchange (overlap mode launches buckets from the hooks)
+        self.dp.begin_micro(last=self._micro + 1 == self.accum_steps)
         loss = run()
         self._micro += 1
         if self._micro == self.accum_steps:
@@ -154,10 +156,45 @@ class HotPathTrainStep:
                 for d, s in zip(dst, src):
                     d.copy_(s)
 
+    def _snapshot(self):
+        """Everything the warm-up steps move: weights, optimiser moments and step counter (LR
+        schedule / bias-correction phase), the device dropout seed, the accumulation phase."""
+        opt = self.opt
+        snap = {"micro": self._micro}
+        if hasattr(opt, "flat_p"):
+            snap["flat"] = [t.clone() for t in (opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.step_ctr)]
+        else:
+            import copy
+            snap["params"] = [p.detach().clone() for p in self.dp.order]
+            snap["opt"] = copy.deepcopy(opt.state_dict())
+        dev = self.static["obj_embeds"].device
+        if dev.type == "cuda":
+            snap["seed"] = hipops.seed_word(dev).clone()
+        return snap
+
+    def _restore(self, snap):
+        opt = self.opt
+        with torch.no_grad():
+            if "flat" in snap:
+                for t, v in zip((opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.step_ctr), snap["flat"]):
+                    t.copy_(v)
+            else:
+                for p, v in zip(self.dp.order, snap["params"]):
+                    p.copy_(v)
+                opt.load_state_dict(snap["opt"])
+            if "seed" in snap:
+                hipops.seed_word(self.static["obj_embeds"].device).copy_(snap["seed"])
+        self._micro = snap["micro"]
+        self.dp.zero_grad()
+
     def capture(self, batch, warmup=3):
-        """Warm up on a side stream (allocator, autotune, lazy inits), then capture."""
+        """Warm up on a side stream (allocator, autotune, lazy inits), then capture.  The warm-up
+        runs REAL steps (with world > 1: real all-reduces, the same on every rank); their effect on
+        the weights, the optimiser state, the step counter and the dropout seed is rolled back
+        before the capture, so training starts from exactly the state the caller prepared."""
         if not self.use_graph:
             return
+        snap = self._snapshot()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -168,6 +205,8 @@ class HotPathTrainStep:
                 else:
                     self._train_part()
         torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self._restore(snap)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         self._load(batch)

@@ -95,3 +95,75 @@ def test_single_process_average_matches_manual():
     n = eng.clip_grad_norm_(5.0)
     assert n > 5.0 and abs(eng.grad_norm().item() - 5.0) < 1e-3
     assert m.a.weight.grad.data_ptr() >= eng.flat.data_ptr()      # still a view of the flat buffer
+
+
+class Twice(torch.nn.Module):
+    """`enc` is applied twice in one forward (like loc_embedding_encoder in 'as_embedding'): its
+    gradient hook fires once, a direct-write producer would report it twice."""
+
+    def __init__(self):
+        super().__init__()
+        self.enc = torch.nn.Linear(8, 8)
+        self.head = torch.nn.Linear(8, 4)
+
+    def forward(self, x):
+        return self.head(torch.tanh(self.enc(x)) + self.enc(2 * x))
+
+
+def _data(rank, micro):
+    g = torch.Generator().manual_seed(1000 + 10 * rank + micro)
+    return torch.randn(5, 8, generator=g)
+
+
+def _worker_accum(rank, world, port, q, accum):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from msr3d_amd.dp import FlatGradAllReduce
+    torch.manual_seed(rank)                      # rank-dependent init: the engine must broadcast rank 0's
+    model = Twice()
+    eng = FlatGradAllReduce(model.parameters(), bucket_bytes=64, overlap=True)
+    assert len(eng.buckets) > 1
+    _, spread = eng.replica_checksum()
+    assert spread == 0.0
+    eng.zero_grad()
+    for micro in range(accum):
+        eng.begin_micro(last=micro + 1 == accum)
+        (model(_data(rank, micro)).pow(2).mean() / accum).backward()
+        for p in model.enc.parameters():         # a producer reporting the same parameter again
+            eng.mark_ready(p)
+        if micro + 1 < accum:
+            assert not any(eng._launched), "a bucket was exchanged before the last micro-batch"
+    eng.finish()
+    q.put((rank, eng.flat.numpy().copy(), [p.detach().numpy().copy() for p in eng.order]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("accum", [1, 3])
+def test_overlap_with_accumulation_exchanges_once_and_params_are_broadcast(accum):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_accum, args=(r, world, port, q, accum)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: (f, ps) for r, f, ps in (q.get(timeout=180) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import numpy as np
+    # reference: rank 0's weights, gradient = mean over ranks of the sum over micro-batches
+    from msr3d_amd.dp import FlatGradAllReduce
+    torch.manual_seed(0)
+    model = Twice()
+    eng = FlatGradAllReduce(model.parameters(), bucket_bytes=64)
+    eng.zero_grad()
+    for r in range(world):
+        for micro in range(accum):
+            (model(_data(r, micro)).pow(2).mean() / accum / world).backward()
+    want = eng.flat.numpy()
+    for r in range(world):
+        assert np.allclose(res[r][0], want, rtol=1e-5, atol=1e-7), r
+        for a, b in zip(res[r][1], [p.detach().numpy() for p in eng.order]):
+            assert np.array_equal(a, b)          # every rank holds rank 0's initial weights

@@ -91,3 +91,47 @@ def test_fused_project_and_scatter(dtype, B, T, L, K, E):
         assert (g != w).double().mean() < 0.02                  # rounding-boundary cases only
     full, _ = reference_statements(emb, am, ids, proj(tokens).detach(), smask)
     assert float((g - full[hit].double()).norm() / full[hit].double().norm()) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_training_handoff_carries_the_reference_gradients(dtype):
+    """scatter_scene_embeds_train_: same values as the reference's indexed assignment AND its
+    gradients (d scene_embeds = placeholder rows of d inputs_embeds, overwritten embedding rows get
+    none); the raw in-place kernel refuses to run where autograd would be cut."""
+    from msr3d_amd.model.scene_embeds import scatter_scene_embeds_, scatter_scene_embeds_train_
+    B, T, L, E = 3, 120, 7, 64
+    torch.manual_seed(5)
+    ids = torch.randint(0, 30000, (B, T), device="cuda")
+    for b in range(B):
+        ids[b, torch.randperm(T, device="cuda")[:L]] = TOKEN
+    table = torch.randn(B, T, E, device="cuda", requires_grad=True)
+    scene = torch.randn(B, L, E, device="cuda", requires_grad=True)
+    smask = torch.rand(B, L, device="cuda") > 0.3
+    w = torch.randn(B, T, E, device="cuda")
+
+    def run(fn):
+        table.grad = scene.grad = None
+        emb = (table * 1.0).to(dtype)                      # non-leaf, like an embedding lookup
+        am = torch.ones(B, T, dtype=torch.int64, device="cuda")
+        out = fn(emb, am, scene)
+        (out.float() * w).sum().backward()
+        return out.detach().clone(), table.grad.clone(), scene.grad.clone()
+
+    def ref(emb, am, sc):
+        where = torch.where(ids == TOKEN)
+        e = emb.clone()
+        e[where] = sc.to(e.dtype).reshape(-1, E)
+        return e
+
+    want = run(ref)
+    got = run(lambda emb, am, sc: scatter_scene_embeds_train_(emb, am, ids, sc, smask))
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError, match="no autograd"):
+        scatter_scene_embeds_((table * 1.0).to(dtype), None, ids, scene, smask)
+    with torch.no_grad():
+        scatter_scene_embeds_(table.detach().clone().to(dtype), None, ids, scene, smask, validate=True)
+    bad = ids.clone()
+    bad[0, :] = 0
+    with torch.no_grad(), pytest.raises(RuntimeError, match="placeholders"):
+        scatter_scene_embeds_(table.detach().clone().to(dtype), None, bad, scene, smask, validate=True)
