@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 5
+#define MSR3D_ABI_VERSION 6
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -392,6 +392,104 @@ int msr3d_project_scatter_bf16(int B, int T, int n_scene, int E, int K, const lo
                                const float *bias, const unsigned char *scene_mask, int out_dtype,
                                void *inputs_embeds, long long *attention_mask, int *map_ws,
                                int *count_out, msr3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * The trainable part as a fixed schedule of fused launches (msr3d_amd/fused_model.py):
+ * strip GEMMs with the row-local work of /root/reference/modules/layers/transformers.py:250-251,
+ * 324-328 (dropout + residual + LayerNorm chains and their backward) applied while the operand is
+ * staged, multi-problem split-K launches for the long reductions and the weight gradients, and the
+ * row kernels around the layers (model/ose3d_situation.py:327-365,399-404; modules/utils.py:60-137).
+ * ------------------------------------------------------------------------- */
+
+/* prologue applied to the 64-row operand strip (K = 256 = row width) */
+#define MSR3D_PRO_PLAIN 0   /* A = a0 */
+#define MSR3D_PRO_ADD 1     /* A = a0 + a1 (+ column vectors g1, b1 if given);            o1 = A */
+#define MSR3D_PRO_LN 2      /* v = drop(a0; p1, salt1) + a1; A = LN(v; g1, b1, eps1) (+ a2);
+                               o0 = v, ost1 = (mean, rstd) per row, o1 = A (each optional)  */
+#define MSR3D_PRO_LN2 3     /* v1 = drop(a0; p1) + a1; y = LN(v1; g1, b1); v2 = drop(y; p2) + a1;
+                               A = LN(v2; g2, b2); o0 = v1, ost1, o2 = v2, ost2, o1 = A     */
+#define MSR3D_PRO_LNBWD 4   /* a0 = dy, a1 = v, st1: dx = LN-bwd; o1 = dx; A = drop-bwd(dx; p1, salt1);
+                               o0 = A; dg1 / db1 += the strip's column sums                */
+#define MSR3D_PRO_LN2BWD 5  /* backward of PRO_LN2: a0 = dt, a1 = v1, a2 = v2, st1, st2;
+                               o1 = d(a1) (both tails), A = o0 = d(a0); dg1, db1, dg2, db2 */
+/* epilogue */
+#define MSR3D_EPI_BIAS 0    /* C = acc + bias (bias may be NULL) */
+#define MSR3D_EPI_GELU 1    /* Cpre = acc + bias; C = drop(gelu(Cpre); p_drop, salt), mask index row*N+col */
+#define MSR3D_EPI_GELUBWD 2 /* C = drop-bwd(acc; p_drop, salt) * gelu'(pre_in[row*N+col])  (b_kc = 0 only) */
+
+typedef struct msr3d_strip_gemm {
+  int M, N;                     /* token rows, output columns; the reduction length is 256 */
+  int pro, epi;
+  int b_kc;                     /* 1: b(n,k) = W[n*ldw + k] (forward);  0: b(n,k) = W[k*ldw + n] (dx = dy W) */
+  int groups_per_wg;            /* 64-column groups per workgroup; <= 0: chosen for ~1 workgroup per CU */
+  const float *a0, *a1, *a2;    /* (M,256) inputs of the prologue */
+  const float *st1, *st2;       /* (M,2) saved (mean, rstd) for the backward prologues */
+  const float *g1, *b1, *g2, *b2;
+  float eps1, eps2, p1, p2;
+  unsigned salt1, salt2;
+  const unsigned long long *seed;   /* device dropout seed word (msr3d_bump_seed) */
+  float *o0, *o1, *o2, *ost1, *ost2;    /* row results, written once per strip */
+  float *dg1, *db1, *dg2, *db2;         /* LayerNorm parameter gradients: accumulated into (atomics) */
+  const float *W; int ldw;
+  const float *bias;
+  float *C; int ldc;
+  float *Cpre;
+  const float *pre_in;
+  float p_drop; unsigned salt;
+} msr3d_strip_gemm_t;
+
+/* C (M,N) = epilogue(prologue(a0, a1, a2) . b): see the MSR3D_PRO_ / MSR3D_EPI_ codes.  All row
+ * tensors are dense (M,256) f32, 16-byte aligned.  b_kc = 0 needs N % 64 == 0, even ldw / ldc. */
+int msr3d_strip_gemm_f32(const msr3d_strip_gemm_t *p, msr3d_stream_t stream);
+
+#define MSR3D_GEMM_MULTI_MAX 4
+typedef struct msr3d_gemm_problem {
+  int a_kc, b_kc;               /* operand layouts as msr3d_gemm_f32 */
+  int M, N, K;
+  const float *A; int lda;
+  const float *B; int ldb;
+  float *C; int ldc;
+  const float *bias;            /* added once (forward products) */
+  float beta;                   /* 0 or 1; K-splits meet by atomicAdd, so with beta = 1 C holds the value
+                                   to add to (e.g. zeros from msr3d_step_begin, or a residual gradient) */
+  float *colsum;                /* a_kc = 0, beta = 1 only: colsum[m] += sum_k a(m,k)  (bias gradient) */
+} msr3d_gemm_problem_t;
+
+/* Up to MSR3D_GEMM_MULTI_MAX independent products in one launch (dx, dW + db of a linear layer and
+ * whatever other weight gradient is ready at that point of the schedule). */
+int msr3d_gemm_multi_f32(int n, const msr3d_gemm_problem_t *problems, msr3d_stream_t stream);
+
+/* Data-only front of the prompter for one batch, ONE launch: pad_out = !obj_valid, locs_out = obj_locs
+ * (B,L,6), pairwise_out (B,L,L,5) = msr3d_pairwise_locs, fourier_out (B,L,3+6*num_bands) =
+ * msr3d_agent_fourier(transform).  L <= 128. */
+int msr3d_scene_prologue(int B, int L, const float *obj_locs, const unsigned char *obj_valid,
+                         const float *anchor_loc, const float *anchor_ori, const float *freqs,
+                         int num_bands, int transform, float eps, float *pairwise_out,
+                         float *fourier_out, float *locs_out, unsigned char *pad_out,
+                         msr3d_stream_t stream);
+
+/* zero_region[0..n_floats) = 0 (n_floats % 4 == 0) and, if seed != NULL, the dropout seed bump of
+ * msr3d_bump_seed -- the step's one fill for all split-K meeting points. */
+int msr3d_step_begin(float *zero_region, long long n_floats, unsigned long long *seed,
+                     msr3d_stream_t stream);
+
+/* pos (M,256) = LN_a(fourier (M,KF) Wa^T + ba) + LN_b(locs[:,3:6] Wb^T + bb): loc_embedding_encoder +
+ * size_embedding_encoder (model/ose3d_situation.py:399-404); locs (M,6); KF <= 64; saves the
+ * pre-norm values s_a, s_b (M,256) and statistics (M,2) for the backward. */
+int msr3d_pos_embed_fwd(int M, int KF, const float *fourier, const float *locs, const float *Wa,
+                        const float *ba, const float *gamma_a, const float *beta_a, float eps_a,
+                        const float *Wb, const float *bb, const float *gamma_b, const float *beta_b,
+                        float eps_b, float *pos, float *s_a, float *stats_a, float *s_b,
+                        float *stats_b, msr3d_stream_t stream);
+
+/* Row-wise backward of msr3d_pos_embed_fwd: d pos = d0 + d1 + d2 (d1, d2 optional);
+ * d_lin_a / d_lin_b (M,256) = gradients of the two linear outputs; the LayerNorm parameter
+ * gradients and colsum(d0) (added to colsum1 and colsum2, each optional) are accumulated into. */
+int msr3d_pos_embed_bwd(int M, const float *d0, const float *d1, const float *d2, const float *s_a,
+                        const float *stats_a, const float *gamma_a, const float *s_b,
+                        const float *stats_b, const float *gamma_b, float *d_lin_a, float *d_lin_b,
+                        float *dgamma_a, float *dbeta_a, float *dgamma_b, float *dbeta_b,
+                        float *colsum1, float *colsum2, msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Optimiser step of the hot path: global-norm clip + AdamW over flat buffers

@@ -18,8 +18,41 @@ _c_int = ctypes.c_int
 _c_float = ctypes.c_float
 _ptr = ctypes.c_void_p
 
+_fp = ctypes.POINTER(ctypes.c_float)
+
+
+class StripGemm(ctypes.Structure):
+    """msr3d_strip_gemm_t (include/msr3d_hip.h)."""
+    _fields_ = ([("M", _c_int), ("N", _c_int), ("pro", _c_int), ("epi", _c_int), ("b_kc", _c_int),
+                 ("groups_per_wg", _c_int)]
+                + [(k, _ptr) for k in ("a0", "a1", "a2", "st1", "st2", "g1", "b1", "g2", "b2")]
+                + [("eps1", _c_float), ("eps2", _c_float), ("p1", _c_float), ("p2", _c_float),
+                   ("salt1", ctypes.c_uint), ("salt2", ctypes.c_uint), ("seed", _ptr)]
+                + [(k, _ptr) for k in ("o0", "o1", "o2", "ost1", "ost2", "dg1", "db1", "dg2", "db2")]
+                + [("W", _ptr), ("ldw", _c_int), ("bias", _ptr), ("C", _ptr), ("ldc", _c_int),
+                   ("Cpre", _ptr), ("pre_in", _ptr), ("p_drop", _c_float), ("salt", ctypes.c_uint)])
+
+
+class GemmProblem(ctypes.Structure):
+    """msr3d_gemm_problem_t (include/msr3d_hip.h)."""
+    _fields_ = [("a_kc", _c_int), ("b_kc", _c_int), ("M", _c_int), ("N", _c_int), ("K", _c_int),
+                ("A", _ptr), ("lda", _c_int), ("B", _ptr), ("ldb", _c_int), ("C", _ptr), ("ldc", _c_int),
+                ("bias", _ptr), ("beta", _c_float), ("colsum", _ptr)]
+
+
+GEMM_MULTI_MAX = 4
+PRO = {"plain": 0, "add": 1, "ln": 2, "ln2": 3, "lnbwd": 4, "ln2bwd": 5}
+EPI = {"bias": 0, "gelu": 1, "gelubwd": 2}
+
 # name -> argtypes; every entry point returns int status and ends with the stream.
 _SIGNATURES = {
+    "msr3d_strip_gemm_f32": [ctypes.POINTER(StripGemm), _ptr],
+    "msr3d_gemm_multi_f32": [_c_int, ctypes.POINTER(GemmProblem), _ptr],
+    "msr3d_scene_prologue": [_c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_float, _ptr, _ptr,
+                             _ptr, _ptr, _ptr],
+    "msr3d_step_begin": [_ptr, ctypes.c_longlong, _ptr, _ptr],
+    "msr3d_pos_embed_fwd": [_c_int, _c_int] + [_ptr] * 6 + [_c_float] + [_ptr] * 4 + [_c_float] + [_ptr] * 5 + [_ptr],
+    "msr3d_pos_embed_bwd": [_c_int] + [_ptr] * 17 + [_ptr],
     "msr3d_furthest_point_sampling": [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
     "msr3d_gather_points": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
     "msr3d_gather_points_grad": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
@@ -87,7 +120,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 5        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 6        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():

@@ -32,6 +32,8 @@ SOURCES = [
     ("scene_scatter.hip", []),
     ("preprocess.hip", ["-ffp-contract=off"]),
     ("bn_train.hip", []),
+    ("strip_gemm.hip", []),
+    ("prompter_rows.hip", ["-ffp-contract=off"]),
 ]
 
 

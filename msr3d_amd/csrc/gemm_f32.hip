@@ -500,6 +500,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
 }
 
+// Up to MSR3D_GEMM_MULTI_MAX independent problems in ONE launch (any mix of the three operand
+// layouts): the backward of a linear layer -- dx, dW + db -- together with whatever other weight
+// gradient is ready at that point of the schedule.  Each problem alone is too small to fill the
+// chip; the workgroup index picks the problem, then its tile and K-split.
+struct GemmBatch {
+  GemmP p[MSR3D_GEMM_MULTI_MAX];
+  int first[MSR3D_GEMM_MULTI_MAX + 1];   // first workgroup of each problem, then the total
+  int kind[MSR3D_GEMM_MULTI_MAX];        // a_kc * 2 + b_kc
+  int n;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_multi_kernel(const GemmBatch gb) {
+  int id = blockIdx.x, q = 0;
+#pragma unroll
+  for (int j = 1; j < MSR3D_GEMM_MULTI_MAX; ++j)
+    if (j < gb.n && id >= gb.first[j]) q = j;
+  id -= gb.first[q];
+  const GemmP &p = gb.p[q];
+  const int bx = id % p.gx, by = (id / p.gx) % p.gy, bz = id / (p.gx * p.gy);
+  switch (gb.kind[q]) {
+    case 3: gemm_body<true, true, 2, 2>(p, bx, by, bz); break;
+    case 2: gemm_body<true, false, 2, 2>(p, bx, by, bz); break;
+    case 1: gemm_body<false, true, 2, 2>(p, bx, by, bz); break;
+    default: gemm_body<false, false, 2, 2>(p, bx, by, bz); break;
+  }
+}
+
 // out[n] (+)= sum_m X[m][n]   (bias gradients).  One wave per 64 columns, rows split over
 // gridDim.y with one atomicAdd per (column, row-chunk) unless a single chunk covers M.
 __global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float *__restrict__ X,
@@ -778,6 +805,39 @@ int msr3d_linear_bwd_f32(int M_tokens, int N_out, int K_in, const float *dy, con
   constexpr size_t lds = sizeof(float) * 2 * (tile_floats(64) + tile_floats(64));
   const int blocks = p1.gx * p1.gy * p1.gz + p2.gx * p2.gy * p2.gz;
   gemm_linear_bwd_kernel<<<blocks, 256, lds, st>>>(p1, p2);
+  return (int)hipGetLastError();
+}
+
+int msr3d_gemm_multi_f32(int n, const msr3d_gemm_problem_t *pr, msr3d_stream_t stream) {
+  if (n < 0 || n > MSR3D_GEMM_MULTI_MAX || (n > 0 && !pr)) return MSR3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  GemmBatch gb;
+  gb.n = 0;
+  int blocks = 0;
+  for (int j = 0; j < n; ++j) {
+    const msr3d_gemm_problem_t &q = pr[j];
+    // atomic meeting point only: C (and the column-sum destination) hold the values to add to, or
+    // zeros -- the caller's one zero-fill per step covers them; beta = 0 is allowed where no K-split
+    // happens, and plan_gemm zero-fills otherwise
+    if (q.beta != 0.f && q.beta != 1.f) return MSR3D_EINVAL;
+    if (q.colsum && (q.a_kc || q.beta != 1.f)) return MSR3D_EINVAL;
+    GemmP g;
+    int rm, rn;
+    bool empty;
+    const int rc = plan_gemm(q.a_kc, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.bias, nullptr, 0,
+                             q.beta, q.colsum, nullptr, 0, 0.f, nullptr, 0, false, st, &g, &rm, &rn, &empty);
+    if (rc != 0) return rc;
+    if (empty) continue;
+    gb.p[gb.n] = g;
+    gb.kind[gb.n] = (q.a_kc ? 2 : 0) + (q.b_kc ? 1 : 0);
+    gb.first[gb.n] = blocks;
+    blocks += g.gx * g.gy * g.gz;
+    ++gb.n;
+  }
+  if (gb.n == 0) return 0;
+  for (int j = gb.n; j <= MSR3D_GEMM_MULTI_MAX; ++j) gb.first[j] = blocks;
+  constexpr size_t lds = sizeof(float) * 2 * (tile_floats(64) + tile_floats(64));
+  gemm_multi_kernel<<<blocks, 256, lds, st>>>(gb);
   return (int)hipGetLastError();
 }
 

@@ -1,0 +1,417 @@
+"""The whole trainable part of the hot path -- obj_linear_projection, constant token embeddings,
+positional encoders, three TransformerSpatialEncoderLayers, llm_proj -- as ONE autograd node
+running a fixed schedule of fused launches, forward and backward
+(/root/reference/model/ose3d_situation.py:284-439, modules/layers/transformers.py:200-252,314-329,
+model/msr3d/msr3d.py:84-86,277).
+
+Why a schedule and not a persistent kernel: on this part an in-kernel grid barrier costs 4-7 us
+(MI355X_MICROARCH.md price list, barrier-xcd) against ~2 us for a kernel boundary
+(tools/probe/launch_floor.hip: 1.7-2.3 us per dependent kernel inside a graph), so the chain is cut
+at every all-to-all seam (projection -> attention -> projection -> FFN), and everything row-local is
+folded into the GEMM that consumes it (csrc/strip_gemm.hip): per layer 5 launches forward and
+5 backward instead of 10 + 9, 41 for the whole trainable forward + backward instead of 88.
+
+    forward   step_begin | proj | pos | 3 x [LN+pos -> qkvc | attention | fc | LN,LN -> linear1+GELU | linear2] | LN -> llm_proj
+    backward  llm_proj (dx, dW) | 3 x [LN-bwd -> dW2^T.. -> GELU-bwd | dx1, dW2, dW1 | LN,LN-bwd -> d_fc Wfc
+              | attention-bwd | dx_qkvc, dW_qkvc, dW_fc] | pos-bwd | dW_loc, dW_size, dW_proj
+
+All activations live in one arena allocated once per (batch, tokens) shape: addresses are fixed, so
+the schedule is graph-capturable and allocates nothing per step.  Split-K meeting points share one
+zero region filled by the first launch (which also bumps the dropout seed).  Weight gradients go
+straight into the flat gradient buffer of the data-parallel engine (msr3d_amd/dp.py).
+
+Numerics: the same arithmetic as the modular path (rowmath.h restates rowops.hip's row kernels; the
+products are f32-input MFMA chains), dropout masks keyed by the same (seed, salt, element index), so
+with equal salts the two paths draw identical masks.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, hipops
+from ._lib import EPI, PRO, GemmProblem, StripGemm
+
+_vp = ctypes.c_void_p
+
+
+def _ptr(t, offset_floats=0):
+    if t is None:
+        return None
+    return _vp(t.data_ptr() + 4 * offset_floats)
+
+
+class _Arena:
+    """Bump allocator over one fp32 tensor; `zero=True` allocations are contiguous at the front."""
+
+    def __init__(self, device):
+        self.device = device
+        self.specs = []          # (name, numel, zero)
+        self.buf = None
+        self.views = {}
+
+    def want(self, name, *shape, zero=False):
+        n = 1
+        for s in shape:
+            n *= s
+        self.specs.append((name, (n + 3) // 4 * 4, zero, tuple(shape)))
+
+    def build(self):
+        order = [s for s in self.specs if s[2]] + [s for s in self.specs if not s[2]]
+        total = sum(s[1] for s in order)
+        self.buf = torch.zeros(total, dtype=torch.float32, device=self.device)
+        off = 0
+        for name, n, zero, shape in order:
+            k = 1
+            for s in shape:
+                k *= s
+            self.views[name] = self.buf[off:off + k].view(shape)
+            off += n
+        self.zero_floats = sum(s[1] for s in order if s[2])
+
+    def __getitem__(self, k):
+        return self.views[k]
+
+
+def _direct(dp, params):
+    return all(p is not None and getattr(p, "_msr3d_dp", None) is dp and p.is_leaf and p.grad is not None
+               and p.is_contiguous() for p in params)
+
+
+class PrompterSchedule:
+    """Built by `attach(model, dp)` once the data-parallel engine and the flat optimiser own the
+    parameter storage; `MSR3DHotPath.forward` routes through it while `eligible()` holds."""
+
+    def __init__(self, model, dp):
+        self.model, self.dp = model, dp
+        self.pr = model.visual_prompter
+        self.arena = None
+        self.shape = None
+        self.enabled = True
+        # the step's first launch can also advance the dropout seed word (HotPathTrainStep sets this
+        # and drops its own msr3d_bump_seed launch); off: the caller owns the seed
+        self.bump_seed = False
+
+    # ------------------------------------------------------------------ eligibility
+    def eligible(self, d):
+        pr, cfg = self.pr, self.pr.cfg
+        se = cfg.spatial_encoder
+        e = d.get("obj_embeds")
+        if not (self.enabled and torch.is_grad_enabled() and self.model.training and e is not None
+                and e.is_cuda and e.dtype == torch.float32):
+            return False
+        if hipops._deterministic[0]:
+            # bit-reproducible mode (ordered split-K, ordered LayerNorm-gradient sums) lives in the
+            # per-layer path; this schedule's K-splits and column sums meet by float atomics
+            return False
+        if not (pr.situation_type == "as_transform_for_objects" and cfg.use_spatial_attn
+                and se.obj_loc_encoding in ("same_all", "same_0") and se.pairwise_rel_type == "center"
+                and se.spatial_dist_norm and se.spatial_dim == 5 and cfg.hidden_size == 256
+                and se.spatial_attn_fusion == "cond" and se.activation == "gelu"
+                and "single_obj" not in d):
+            return False
+        B, L = e.shape[:2]
+        if L > 128 or e.shape[-1] % 4 or cfg.loc_fourier_dim > 64:
+            return False
+        for layer in pr.spatial_encoder:
+            sa = layer.self_attn
+            if getattr(sa, "_packed", None) is None or sa.n_head * 32 != 256 or not sa.spatial_multihead:
+                return False
+            if layer.linear1.out_features % 64 or not getattr(layer, "use_fused_layer", True):
+                return False
+        return _direct(self.dp, self._params())
+
+    def _params(self):
+        pr, m = self.pr, self.model
+        ps = [pr.obj_linear_projection.weight, pr.obj_linear_projection.bias, pr.object_type_embedding.weight,
+              pr.loc_embedding_encoder[0].weight, pr.loc_embedding_encoder[0].bias,
+              pr.loc_embedding_encoder[1].weight, pr.loc_embedding_encoder[1].bias,
+              pr.size_embedding_encoder[0].weight, pr.size_embedding_encoder[0].bias,
+              pr.size_embedding_encoder[1].weight, pr.size_embedding_encoder[1].bias,
+              m.llm_proj.weight, m.llm_proj.bias]
+        if pr.use_orientation:
+            ps.append(pr.object_orientation_feat)
+        for layer in pr.spatial_encoder:
+            sa = layer.self_attn
+            ps += list(sa._packed_members) + [sa.fc.weight, sa.fc.bias, sa.layer_norm.weight, sa.layer_norm.bias,
+                                              layer.norm1.weight, layer.norm1.bias, layer.norm2.weight,
+                                              layer.norm2.bias, layer.linear1.weight, layer.linear1.bias,
+                                              layer.linear2.weight, layer.linear2.bias]
+        return ps
+
+    # ------------------------------------------------------------------ storage
+    def _ensure(self, B, L, KE, device):
+        key = (B, L, KE, str(device))
+        if self.shape == key:
+            return
+        pr, m = self.pr, self.model
+        D, M = 256, B * L
+        nl = len(pr.spatial_encoder)
+        sa0 = pr.spatial_encoder[0].self_attn
+        W = sa0._packed[0].shape[0]
+        H = sa0.n_head
+        FF = pr.spatial_encoder[0].linear1.out_features
+        E = m.llm_proj.out_features
+        KF = pr.loc_embedding_encoder[0].in_features
+        a = _Arena(device)
+        a.want("x0", M, D, zero=True)
+        for i in range(nl):
+            a.want(f"ffn{i}", M, D, zero=True)
+        a.want("d_tok", M, D, zero=True)
+        a.want("loc6", M, 6)
+        a.want("ff", M, KF)
+        a.want("pw", B, L, L, 5)
+        a.want("pos", M, D); a.want("sa", M, D); a.want("sta", M, 2); a.want("sb", M, D); a.want("stb", M, 2)
+        for i in range(nl):
+            a.want(f"xin{i}", M, D); a.want(f"qkvc{i}", M, W); a.want(f"probs{i}", B, H, L, L)
+            a.want(f"ctx{i}", M, D); a.want(f"fc{i}", M, D)
+            a.want(f"s1_{i}", M, D); a.want(f"st1_{i}", M, 2); a.want(f"s2_{i}", M, D); a.want(f"st2_{i}", M, 2)
+            a.want(f"t{i}", M, D); a.want(f"pre{i}", M, FF); a.want(f"h{i}", M, FF)
+            a.want(f"s3_{i}", M, D); a.want(f"st3_{i}", M, 2)
+            a.want(f"d_xin{i}", M, D)
+        a.want("tok", M, D)
+        a.want("scene", M, E)
+        # backward temporaries (one layer's worth, reused)
+        a.want("d_ffn", M, D); a.want("d_t", M, D); a.want("d_pre", M, FF); a.want("d_fc", M, D)
+        a.want("d_ctx", M, D); a.want("d_qkvc", M, W); a.want("d_la", M, D); a.want("d_lb", M, D)
+        a.build()
+        self.arena = a
+        self.pad = torch.zeros(M, dtype=torch.uint8, device=device)
+        self.freqs = torch.linspace(1.0, 15, steps=10, device=device)
+        self.dims = dict(B=B, L=L, M=M, D=D, W=W, H=H, FF=FF, E=E, KF=KF, KE=KE, nl=nl)
+        self.shape = key
+        self.staged_for = None
+
+    # ------------------------------------------------------------------ launch helpers
+    def _strip(self, **kw):
+        s = StripGemm()
+        for k, v in kw.items():
+            if isinstance(v, torch.Tensor):
+                v = v.data_ptr()
+            elif isinstance(v, _vp):
+                v = v.value
+            setattr(s, k, v if v is not None else 0)
+        rc = self.lib.msr3d_strip_gemm_f32(ctypes.byref(s), self.stream)
+        _lib.check(rc, "msr3d_strip_gemm_f32")
+
+    def _multi(self, probs):
+        arr = (GemmProblem * len(probs))()
+        for q, kw in zip(arr, probs):
+            for k, v in kw.items():
+                if isinstance(v, torch.Tensor):
+                    v = v.data_ptr()
+                elif isinstance(v, _vp):
+                    v = v.value
+                setattr(q, k, v if v is not None else 0)
+        rc = self.lib.msr3d_gemm_multi_f32(len(probs), arr, self.stream)
+        _lib.check(rc, "msr3d_gemm_multi_f32")
+
+    @staticmethod
+    def _dw(dy, n_out, x, k_in, m_tok, dw, db):
+        """dW (n_out, k_in) += dy^T x, db += colsum(dy): reduction over the tokens."""
+        return dict(a_kc=0, b_kc=0, M=n_out, N=k_in, K=m_tok, A=dy, lda=n_out, B=x, ldb=k_in, C=dw, ldc=k_in,
+                    beta=1.0, colsum=db)
+
+    # ------------------------------------------------------------------ data-only front
+    def stage(self, d):
+        """pad mask, pairwise features, Fourier features, obj_locs copy: one launch, reading the
+        batch tensors where they are.  HotPathTrainStep calls it eagerly per batch (outside the
+        graph); forward() calls it itself otherwise."""
+        e = d["obj_embeds"]
+        B, L = e.shape[:2]
+        self._ensure(B, L, e.shape[-1], e.device)
+        a = self.arena
+        dev = e.device
+        loc = d["obj_locs"].contiguous()
+        valid = d["obj_masks"].contiguous().view(torch.uint8)
+        al, ao = d["anchor_locs"].contiguous(), d["anchor_orientation"].contiguous()
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            rc = lib.msr3d_scene_prologue(B, L, _ptr(loc), _ptr(valid), _ptr(al), _ptr(ao), _ptr(self.freqs), 10, 1,
+                                          ctypes.c_float(1e-10), _ptr(a["pw"]), _ptr(a["ff"]), _ptr(a["loc6"]),
+                                          _ptr(self.pad), _lib.current_stream_ptr(dev))
+        _lib.check(rc, "msr3d_scene_prologue")
+
+    # ------------------------------------------------------------------ forward / backward
+    def forward(self, embeds):
+        pr, m, a, dm = self.pr, self.model, self.arena, self.dims
+        B, L, M, D, W, H, FF, E, KF, KE, nl = (dm[k] for k in ("B", "L", "M", "D", "W", "H", "FF", "E", "KF", "KE", "nl"))
+        dev = embeds.device
+        self.lib = lib = _lib.load()
+        self.stream = st = _lib.current_stream_ptr(dev)
+        train = m.training
+        seed = hipops.seed_word(dev)
+        e2 = embeds.reshape(M, KE)
+        e2 = e2 if e2.is_contiguous() else e2.contiguous()
+        self.saved_embeds = e2
+        layers = list(pr.spatial_encoder)
+        self.salts = [[hipops._next_salt() for _ in range(4)] for _ in layers]
+        self.ps = []
+        for layer in layers:
+            sa = layer.self_attn
+            self.ps.append((float(sa.dropout.p) if train else 0.0, float(layer.dropout1.p) if train else 0.0,
+                            float(layer.dropout2.p) if train else 0.0, float(layer.dropout.p) if train else 0.0))
+        same_all = pr.cfg.spatial_encoder.obj_loc_encoding == "same_all"
+        with torch.cuda.device(dev):
+            rc = lib.msr3d_step_begin(_ptr(a.buf), a.zero_floats, _ptr(seed) if self.bump_seed else None, st)
+            _lib.check(rc, "msr3d_step_begin")
+            lp = pr.obj_linear_projection
+            self._multi([dict(a_kc=1, b_kc=1, M=M, N=D, K=KE, A=e2, lda=KE, B=lp.weight, ldb=KE, C=a["x0"], ldc=D,
+                              bias=lp.bias, beta=1.0)])
+            le, se = pr.loc_embedding_encoder, pr.size_embedding_encoder
+            rc = lib.msr3d_pos_embed_fwd(M, KF, _ptr(a["ff"]), _ptr(a["loc6"]), _ptr(le[0].weight), _ptr(le[0].bias),
+                                         _ptr(le[1].weight), _ptr(le[1].bias), ctypes.c_float(le[1].eps),
+                                         _ptr(se[0].weight), _ptr(se[0].bias), _ptr(se[1].weight), _ptr(se[1].bias),
+                                         ctypes.c_float(se[1].eps), _ptr(a["pos"]), _ptr(a["sa"]), _ptr(a["sta"]),
+                                         _ptr(a["sb"]), _ptr(a["stb"]), st)
+            _lib.check(rc, "msr3d_pos_embed_fwd")
+            for i, layer in enumerate(layers):
+                sa = layer.self_attn
+                wv, bv = sa._packed[0], sa._packed[1]
+                p_attn, p1, p2, p_ffn = self.ps[i]
+                s_attn, s_1, s_2, s_ffn = self.salts[i]
+                if i == 0:
+                    self._strip(M=M, N=W, pro=PRO["add"], epi=EPI["bias"], b_kc=1, a0=a["x0"], a1=a["pos"],
+                                g1=_ptr(pr.object_type_embedding.weight),        # row 0: every object has type id 0
+                                b1=_ptr(pr.object_orientation_feat) if pr.use_orientation else None,
+                                o1=a["xin0"], W=wv, ldw=D, bias=bv, C=a["qkvc0"], ldc=W)
+                else:
+                    prev = layers[i - 1]
+                    self._strip(M=M, N=W, pro=PRO["ln"], epi=EPI["bias"], b_kc=1, a0=a[f"ffn{i-1}"], a1=a[f"t{i-1}"],
+                                a2=a["pos"] if same_all else None, g1=prev.norm2.weight, b1=prev.norm2.bias,
+                                eps1=prev.norm2.eps, p1=self.ps[i - 1][2], salt1=self.salts[i - 1][2], seed=seed,
+                                o0=a[f"s3_{i-1}"], ost1=a[f"st3_{i-1}"], o1=a[f"xin{i}"], W=wv, ldw=D, bias=bv,
+                                C=a[f"qkvc{i}"], ldc=W)
+                q = a[f"qkvc{i}"]
+                base, fs = q.data_ptr(), 4
+                rc = lib.msr3d_spatial_attn_fwd(B, L, H, D // H, 5, _vp(base), _vp(base + D * fs), _vp(base + 2 * D * fs),
+                                                W, _vp(base + 3 * D * fs), W, _ptr(a["pw"]), _ptr(self.pad),
+                                                _ptr(a[f"ctx{i}"]), _ptr(a[f"probs{i}"]), hipops.attention_mma(True), st)
+                _lib.check(rc, "msr3d_spatial_attn_fwd")
+                self._strip(M=M, N=D, pro=PRO["plain"], epi=EPI["bias"], b_kc=1, a0=a[f"ctx{i}"], W=sa.fc.weight,
+                            ldw=D, bias=sa.fc.bias, C=a[f"fc{i}"], ldc=D)
+                self._strip(M=M, N=FF, pro=PRO["ln2"], epi=EPI["gelu"], b_kc=1, a0=a[f"fc{i}"], a1=a[f"xin{i}"],
+                            g1=sa.layer_norm.weight, b1=sa.layer_norm.bias, eps1=sa.layer_norm.eps, p1=p_attn,
+                            salt1=s_attn, g2=layer.norm1.weight, b2=layer.norm1.bias, eps2=layer.norm1.eps, p2=p1,
+                            salt2=s_1, seed=seed, o0=a[f"s1_{i}"], ost1=a[f"st1_{i}"], o2=a[f"s2_{i}"],
+                            ost2=a[f"st2_{i}"], o1=a[f"t{i}"], W=layer.linear1.weight, ldw=D, bias=layer.linear1.bias,
+                            C=a[f"h{i}"], ldc=FF, Cpre=a[f"pre{i}"], p_drop=p_ffn, salt=s_ffn)
+                self._multi([dict(a_kc=1, b_kc=1, M=M, N=D, K=FF, A=a[f"h{i}"], lda=FF, B=layer.linear2.weight, ldb=FF,
+                                  C=a[f"ffn{i}"], ldc=D, bias=layer.linear2.bias, beta=1.0)])
+            last = layers[-1]
+            self._strip(M=M, N=E, pro=PRO["ln"], epi=EPI["bias"], b_kc=1, a0=a[f"ffn{nl-1}"], a1=a[f"t{nl-1}"],
+                        g1=last.norm2.weight, b1=last.norm2.bias, eps1=last.norm2.eps, p1=self.ps[-1][2],
+                        salt1=self.salts[-1][2], seed=seed, o0=a[f"s3_{nl-1}"], ost1=a[f"st3_{nl-1}"], o1=a["tok"],
+                        W=m.llm_proj.weight, ldw=D, bias=m.llm_proj.bias, C=a["scene"], ldc=E)
+        return a["tok"].view(B, L, D), a["scene"].view(B, L, E)
+
+    def backward(self, g_scene, g_tok):
+        pr, m, a, dm = self.pr, self.model, self.arena, self.dims
+        B, L, M, D, W, H, FF, E, KF, KE, nl = (dm[k] for k in ("B", "L", "M", "D", "W", "H", "FF", "E", "KF", "KE", "nl"))
+        dev = a.buf.device
+        lib = self.lib
+        self.stream = st = _lib.current_stream_ptr(dev)
+        seed = hipops.seed_word(dev)
+        layers = list(pr.spatial_encoder)
+        same_all = pr.cfg.spatial_encoder.obj_loc_encoding == "same_all"
+        with torch.cuda.device(dev):
+            if g_tok is not None:            # a consumer of obj_tokens besides llm_proj
+                a["d_tok"].add_(g_tok.reshape(M, D))
+            if g_scene is not None:
+                g = g_scene.reshape(M, E)
+                g = g if g.is_contiguous() else g.contiguous()
+                lp = m.llm_proj
+                self._multi([dict(a_kc=1, b_kc=0, M=M, N=D, K=E, A=g, lda=E, B=lp.weight, ldb=D, C=a["d_tok"], ldc=D,
+                                  beta=1.0),
+                             self._dw(g, E, a["tok"], D, M, lp.weight.grad, lp.bias.grad)])
+            d_out = a["d_tok"]
+            for i in range(nl - 1, -1, -1):
+                layer = layers[i]
+                sa = layer.self_attn
+                wv, bv, gwv, gbv, _dp = sa._packed
+                p_attn, p1, p2, p_ffn = self.ps[i]
+                s_attn, s_1, s_2, s_ffn = self.salts[i]
+                l1, l2 = layer.linear1, layer.linear2
+                # LN(norm2)-bwd -> d_ffn; d_h = d_ffn W2; d_pre = dropout-bwd(d_h) * gelu'(pre)
+                self._strip(M=M, N=FF, pro=PRO["lnbwd"], epi=EPI["gelubwd"], b_kc=0, a0=d_out, a1=a[f"s3_{i}"],
+                            st1=a[f"st3_{i}"], g1=layer.norm2.weight, p1=p2, salt1=s_2, seed=seed, o0=a["d_ffn"],
+                            o1=a["d_t"], dg1=layer.norm2.weight.grad, db1=layer.norm2.bias.grad, W=l2.weight, ldw=FF,
+                            C=a["d_pre"], ldc=FF, pre_in=a[f"pre{i}"], p_drop=p_ffn, salt=s_ffn)
+                self._multi([dict(a_kc=1, b_kc=0, M=M, N=D, K=FF, A=a["d_pre"], lda=FF, B=l1.weight, ldb=D, C=a["d_t"],
+                                  ldc=D, beta=1.0),
+                             self._dw(a["d_ffn"], D, a[f"h{i}"], FF, M, l2.weight.grad, l2.bias.grad),
+                             self._dw(a["d_pre"], FF, a[f"t{i}"], D, M, l1.weight.grad, l1.bias.grad)])
+                # LN(norm1), LN(attention tail) bwd -> d_fc, residual gradient; d_ctx = d_fc Wfc
+                self._strip(M=M, N=D, pro=PRO["ln2bwd"], epi=EPI["bias"], b_kc=0, a0=a["d_t"], a1=a[f"s1_{i}"],
+                            a2=a[f"s2_{i}"], st1=a[f"st1_{i}"], st2=a[f"st2_{i}"], g1=sa.layer_norm.weight,
+                            g2=layer.norm1.weight, p1=p_attn, salt1=s_attn, p2=p1, salt2=s_1, seed=seed,
+                            o0=a["d_fc"], o1=a[f"d_xin{i}"], dg1=sa.layer_norm.weight.grad, db1=sa.layer_norm.bias.grad,
+                            dg2=layer.norm1.weight.grad, db2=layer.norm1.bias.grad, W=sa.fc.weight, ldw=D,
+                            C=a["d_ctx"], ldc=D)
+                q, gq = a[f"qkvc{i}"], a["d_qkvc"]
+                base, gb, fs = q.data_ptr(), gq.data_ptr(), 4
+                rc = lib.msr3d_spatial_attn_bwd(B, L, H, D // H, 5, _vp(base), _vp(base + D * fs), _vp(base + 2 * D * fs),
+                                                W, _vp(base + 3 * D * fs), W, _ptr(a["pw"]), _ptr(self.pad),
+                                                _ptr(a[f"probs{i}"]), _ptr(a["d_ctx"]), _vp(gb), _vp(gb + D * fs),
+                                                _vp(gb + 2 * D * fs), W, _vp(gb + 3 * D * fs), W,
+                                                hipops.attention_mma(True), st)
+                _lib.check(rc, "msr3d_spatial_attn_bwd")
+                self._multi([dict(a_kc=1, b_kc=0, M=M, N=D, K=W, A=gq, lda=W, B=wv, ldb=D, C=a[f"d_xin{i}"], ldc=D,
+                                  beta=1.0),
+                             self._dw(gq, W, a[f"xin{i}"], D, M, gwv, gbv),
+                             self._dw(a["d_fc"], D, a[f"ctx{i}"], D, M, sa.fc.weight.grad, sa.fc.bias.grad)])
+                d_out = a[f"d_xin{i}"]
+            le, se = pr.loc_embedding_encoder, pr.size_embedding_encoder
+            more = same_all and nl > 1
+            rc = lib.msr3d_pos_embed_bwd(
+                M, _ptr(a["d_xin0"]), _ptr(a["d_xin1"]) if more else None,
+                _ptr(a["d_xin2"]) if (more and nl > 2) else None, _ptr(a["sa"]), _ptr(a["sta"]), _ptr(le[1].weight),
+                _ptr(a["sb"]), _ptr(a["stb"]), _ptr(se[1].weight), _ptr(a["d_la"]), _ptr(a["d_lb"]),
+                _ptr(le[1].weight.grad), _ptr(le[1].bias.grad), _ptr(se[1].weight.grad), _ptr(se[1].bias.grad),
+                _ptr(pr.object_type_embedding.weight.grad),
+                _ptr(pr.object_orientation_feat.grad) if pr.use_orientation else None, st)
+            _lib.check(rc, "msr3d_pos_embed_bwd")
+            lp = pr.obj_linear_projection
+            self._multi([self._dw(a["d_la"], D, a["ff"], KF, M, le[0].weight.grad, le[0].bias.grad),
+                         dict(a_kc=0, b_kc=0, M=D, N=3, K=M, A=a["d_lb"], lda=D, B=_ptr(a["loc6"], 3), ldb=6,
+                              C=se[0].weight.grad, ldc=3, beta=1.0, colsum=se[0].bias.grad),
+                         self._dw(a["d_xin0"], D, self.saved_embeds, KE, M, lp.weight.grad, lp.bias.grad)])
+        for p in self._params():
+            self.dp.mark_ready(p)
+
+
+class _PrompterFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sched, embeds, *params):
+        tok, scene = sched.forward(embeds)
+        ctx.sched = sched
+        ctx.n = len(params)
+        ctx.set_materialize_grads(False)
+        return tok, scene
+
+    @staticmethod
+    def backward(ctx, g_tok, g_scene):
+        if g_tok is not None or g_scene is not None:
+            ctx.sched.backward(g_scene, g_tok)
+        return (None, None) + (None,) * ctx.n
+
+
+def attach(model, dp):
+    """Give `model` (MSR3DHotPath) its schedule; call after hipops.attach_packed_views."""
+    model._schedule = PrompterSchedule(model, dp)
+    return model._schedule
+
+
+def run(model, d):
+    """-> d with obj_tokens / scene_embeds / obj_masks / oatt, through the fused schedule."""
+    sched = model._schedule
+    e = d["obj_embeds"]
+    B, L = e.shape[:2]
+    sched._ensure(B, L, e.shape[-1], e.device)
+    if not d.get("_staged", False):
+        sched.stage(d)
+    tok, scene = _PrompterFn.apply(sched, e, *sched._params())
+    d["oatt"] = None
+    d["obj_tokens"] = tok
+    d["scene_embeds"] = scene
+    return d

@@ -308,6 +308,9 @@ def attach_packed_views(model, dp, opt):
             m.set_packed((flat_p[ws:ws + wl].view(-1, K), flat_p[bs:bs + bl],
                           dp.flat[ws:ws + wl].view(-1, K), dp.flat[bs:bs + bl], dp), wg + bg)
             n += 1
+    if n and hasattr(model, "visual_prompter") and hasattr(model, "llm_proj"):
+        from . import fused_model
+        fused_model.attach(model, dp)         # MSR3DHotPath: the whole trainable part as one schedule
     return n
 
 

@@ -189,6 +189,19 @@ class MSR3DHotPath(nn.Module):
 
     def forward(self, scene_dict):
         """-> scene_dict with obj_tokens, obj_masks (from the prompter) and scene_embeds (B,L,E)."""
+        sched = getattr(self, "_schedule", None)
+        if sched is not None and "obj_tokens" not in scene_dict:
+            # training on the flat-buffer engine: the whole trainable part as one fixed schedule of
+            # fused launches (msr3d_amd/fused_model.py); anything it does not cover falls through
+            enc = self.visual_prompter.obj_encoder
+            if "obj_embeds" not in scene_dict and scene_dict.get("obj_fts") is not None \
+                    and scene_dict["obj_fts"].is_cuda and "single_obj" not in scene_dict \
+                    and not any(p.requires_grad for p in enc.parameters()):
+                scene_dict["obj_embeds"] = self.visual_prompter.encode_objects(
+                    scene_dict["obj_fts"], scene_dict.get("obj_masks"))
+            if sched.eligible(scene_dict):
+                from .. import fused_model
+                return fused_model.run(self, scene_dict)
         if "obj_tokens" not in scene_dict:
             scene_dict = self.visual_prompter(scene_dict)
         scene_dict["scene_embeds"] = hipops.module_linear(self.llm_proj, scene_dict["obj_tokens"])

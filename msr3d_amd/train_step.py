@@ -63,7 +63,12 @@ class HotPathTrainStep:
 
     # ---- the trainable part, on static buffers -------------------------------------
     def _fwd_bwd(self, zero=True):
-        if self.static["obj_embeds"].is_cuda:
+        sched = getattr(self.model, "_schedule", None)
+        if sched is not None and sched.enabled and sched.eligible(self.static):
+            sched.bump_seed = True      # fresh dropout masks per replay, from the schedule's first launch
+        elif self.static["obj_embeds"].is_cuda:
+            if sched is not None:
+                sched.bump_seed = False
             hipops.bump_seed(self.static["obj_embeds"].device)   # fresh dropout masks per replay
         if zero:
             self.dp.zero_grad()

@@ -1,0 +1,138 @@
+"""The whole-trainable-part schedule (msr3d_amd/fused_model.py) against the per-layer node
+(msr3d_amd/fused_layer.py) and the modular path (separate autograd nodes): same forward, same
+gradients for EVERY trainable parameter.  Without dropout: <= 2e-5 rel-L2 against the modular path
+(different split-K arrival orders and fusion boundaries, same arithmetic).  With dropout the schedule and
+the per-layer node draw their masks from the same (seed, salt, index) hash at the same call-site
+order, so with the salt counter reset they must agree just as tightly; the modular path draws at
+other call sites and is not comparable there."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def _setup(dropout, seed=0, B=3, O=20, E=128):
+    import msr3d_amd.model  # noqa: F401
+    import msr3d_amd.modules  # noqa: F401
+    from msr3d_amd import hipops
+    from msr3d_amd.config import AttrDict, default_prompter_cfg
+    from msr3d_amd.dp import FlatGradAllReduce
+    from msr3d_amd.model import build_model
+    from msr3d_amd.optim import FlatAdamW
+    from msr3d_amd.synth import synth_batch
+    torch.manual_seed(seed)
+    cfg = AttrDict({"prompter": default_prompter_cfg(dropout=dropout), "llm_hidden_size": E,
+                    "model": {"name": "MSR3DHotPath"}})
+    model = build_model(cfg).cuda().train()
+    # the zero-initialised constants would hide their gradient paths' forward effect
+    with torch.no_grad():
+        model.visual_prompter.object_orientation_feat.normal_(std=0.5)
+    params = [p for p in model.parameters() if p.requires_grad]
+    dp = FlatGradAllReduce(params, pack_groups=hipops.collect_pack_groups(model))
+    opt = FlatAdamW(dp, lr=1e-3)
+    assert hipops.attach_packed_views(model, dp, opt) == 3
+    assert model._schedule is not None
+    model._test_opt = opt
+    batch = synth_batch(31, B, O=O, P=1024, device="cuda")
+    with torch.no_grad():
+        batch["obj_embeds"] = model.visual_prompter.encode_objects(batch["obj_fts"]).clone()
+    return model, dp, batch
+
+
+def _run(model, dp, batch, mode):
+    from msr3d_amd import hipops
+    model._schedule.enabled = mode == "schedule"
+    for l in model.visual_prompter.spatial_encoder:
+        l.use_fused_layer = mode != "modular"
+    seed = hipops.seed_word(torch.device("cuda", torch.cuda.current_device()))
+    seed.fill_(12345)
+    hipops._salt_counter[0] = 500
+    dp.zero_grad()
+    out = model(dict(batch))
+    y = out["scene_embeds"]
+    w = torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)
+    (y * w).sum().backward()
+    dp.finish()
+    torch.cuda.synchronize()
+    return (y.detach().clone(), out["obj_tokens"].detach().clone(),
+            {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.requires_grad})
+
+
+def _compare(a, b, tol):
+    (ya, ta, ga), (yb, tb, gb) = a, b
+    assert rel(ya, yb) < tol and rel(ta, tb) < tol
+    assert sorted(ga) == sorted(gb)
+    for k in gb:
+        if k.endswith("w_ks.bias"):              # mathematically zero (softmax shift invariance)
+            assert ga[k].abs().max() < 1e-3
+            continue
+        if gb[k].abs().max() == 0:               # parameters this configuration does not use
+            assert ga[k].abs().max() == 0, k
+            continue
+        assert rel(ga[k], gb[k]) < tol, (k, rel(ga[k], gb[k]))
+
+
+@pytest.mark.parametrize("B,O", [(3, 20), (2, 60), (5, 13)])
+def test_schedule_matches_modular_and_per_layer_paths_without_dropout(B, O):
+    model, dp, batch = _setup(0.0, B=B, O=O)
+    assert model._schedule.eligible(dict(batch))
+    s = _run(model, dp, batch, "schedule")
+    m = _run(model, dp, batch, "modular")
+    l = _run(model, dp, batch, "layer")
+    _compare(s, m, 2e-5)
+    _compare(s, l, 2e-5)
+    # every parameter the configuration uses received a gradient
+    used = [k for k, v in m[2].items() if v.abs().max() > 0]
+    assert len(used) >= 60
+
+
+def test_schedule_draws_the_per_layer_nodes_masks_with_dropout():
+    model, dp, batch = _setup(0.1, seed=2)
+    s = _run(model, dp, batch, "schedule")
+    l = _run(model, dp, batch, "layer")
+    _compare(s, l, 5e-5)
+    s2 = _run(model, dp, batch, "schedule")       # same seed word, same salts: same masks
+    assert rel(s2[0], s[0]) < 1e-5
+    from msr3d_amd import hipops
+    model._schedule.enabled = True
+    hipops._salt_counter[0] = 500                 # but a bumped seed word draws new ones
+    hipops.bump_seed(torch.device("cuda", torch.cuda.current_device()))
+    y = model(dict(batch))["scene_embeds"].detach()
+    assert rel(y, s[0]) > 1e-3
+
+
+def test_schedule_is_skipped_where_it_does_not_apply():
+    model, dp, batch = _setup(0.0)
+    model.eval()
+    with torch.no_grad():
+        assert not model._schedule.eligible(dict(batch))
+        y = model(dict(batch))["scene_embeds"]
+    model.train()
+    s = _run(model, dp, batch, "schedule")
+    assert rel(y, s[0]) < 1e-5                    # dropout 0: eval == train forward
+
+
+def test_train_step_through_the_schedule_in_a_graph():
+    """HotPathTrainStep captures the schedule; replayed steps equal eager steps."""
+    from msr3d_amd.synth import synth_batch
+    from msr3d_amd.train_step import HotPathTrainStep
+    results = []
+    for use_graph in (False, True):
+        model, dp, _ = _setup(0.0, seed=4, B=2, O=12, E=64)
+        opt = model._test_opt
+        batches = [synth_batch(70 + i, 2, O=12, P=1024, device="cuda") for i in range(3)]
+
+        def loss_fn(out):
+            y = out["scene_embeds"]
+            return (y * y).mean()
+        step = HotPathTrainStep(model, opt, dp, loss_fn, batches[0], use_graph=use_graph)
+        step.capture(batches[0])
+        losses = [float(step(b)) for b in batches]
+        results.append((losses, opt.flat_p.clone()))
+    (l0, p0), (l1, p1) = results
+    assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
+    assert rel(p1, p0) < 1e-5
