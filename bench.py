@@ -127,7 +127,7 @@ class Trainer:
             return loss, y, state["g"]
 
         self.stepper = HotPathTrainStep(model, self.opt, self.dp, loss_fn, example_batch,
-                                        use_graph=use_graph)
+                                        use_graph=use_graph, zero_in_optimizer=True)
         if on_gpu and use_graph:
             self.stepper.capture(example_batch)
 

@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void scene_prologue_kernel(
     int L, const float *__restrict__ loc, const unsigned char *__restrict__ valid,
     const float *__restrict__ anchor_loc, const float *__restrict__ anchor_ori,
     const float *__restrict__ freqs, int nb, int transform, float eps, float *__restrict__ pw,
-    float *__restrict__ ff, float *__restrict__ loc_out, unsigned char *__restrict__ pad) {
+    float *__restrict__ ff, float *__restrict__ loc_out, unsigned char *__restrict__ pad,
+    unsigned char *__restrict__ valid_out) {
   __shared__ float cx[128], cy[128], cz[128];
   __shared__ float wmax[4];
   // grid (B, 4): the four blocks of a sample each find the sample's largest distance (cheap, all
@@ -48,7 +49,9 @@ __global__ __launch_bounds__(256) void scene_prologue_kernel(
     if (part == 0) {
       float *q = loc_out + ((size_t)b * L + i) * 6;
       q[0] = x; q[1] = y; q[2] = z; q[3] = p[3]; q[4] = p[4]; q[5] = p[5];
-      pad[(size_t)b * L + i] = valid[(size_t)b * L + i] ? 0 : 1;
+      const unsigned char ok = valid[(size_t)b * L + i] ? 1 : 0;
+      pad[(size_t)b * L + i] = ok ^ 1;
+      if (valid_out) valid_out[(size_t)b * L + i] = ok;
     }
   }
   __syncthreads();
@@ -253,7 +256,7 @@ int msr3d_scene_prologue(int B, int L, const float *obj_locs, const unsigned cha
                          const float *anchor_loc, const float *anchor_ori, const float *freqs,
                          int num_bands, int transform, float eps, float *pairwise_out,
                          float *fourier_out, float *locs_out, unsigned char *pad_out,
-                         msr3d_stream_t stream) {
+                         unsigned char *valid_out, msr3d_stream_t stream) {
   if (B < 0 || L <= 0 || L > 128 || num_bands <= 0) return MSR3D_EINVAL;
   if (B == 0) return 0;
   if (!obj_locs || !obj_valid || !freqs || !pairwise_out || !fourier_out || !locs_out || !pad_out ||
@@ -261,7 +264,7 @@ int msr3d_scene_prologue(int B, int L, const float *obj_locs, const unsigned cha
     return MSR3D_EINVAL;
   scene_prologue_kernel<<<dim3(B, 4), 256, 0, (hipStream_t)stream>>>(L, obj_locs, obj_valid, anchor_loc, anchor_ori,
                                                            freqs, num_bands, transform, eps, pairwise_out,
-                                                           fourier_out, locs_out, pad_out);
+                                                           fourier_out, locs_out, pad_out, valid_out);
   return (int)hipGetLastError();
 }
 

@@ -93,11 +93,11 @@ class PrompterSchedule:
         self.bump_seed = False
 
     # ------------------------------------------------------------------ eligibility
-    def eligible(self, d):
+    def eligible(self, d, ignore_grad_mode=False):
         pr, cfg = self.pr, self.pr.cfg
         se = cfg.spatial_encoder
         e = d.get("obj_embeds")
-        if not (self.enabled and torch.is_grad_enabled() and self.model.training and e is not None
+        if not (self.enabled and (ignore_grad_mode or torch.is_grad_enabled()) and self.model.training and e is not None
                 and e.is_cuda and e.dtype == torch.float32):
             return False
         if hipops._deterministic[0]:
@@ -177,6 +177,7 @@ class PrompterSchedule:
         a.build()
         self.arena = a
         self.pad = torch.zeros(M, dtype=torch.uint8, device=device)
+        self.valid = torch.zeros((B, L), dtype=torch.bool, device=device)      # static copy of obj_masks
         self.freqs = torch.linspace(1.0, 15, steps=10, device=device)
         self.dims = dict(B=B, L=L, M=M, D=D, W=W, H=H, FF=FF, E=E, KF=KF, KE=KE, nl=nl)
         self.shape = key
@@ -229,7 +230,7 @@ class PrompterSchedule:
         with torch.cuda.device(dev):
             rc = lib.msr3d_scene_prologue(B, L, _ptr(loc), _ptr(valid), _ptr(al), _ptr(ao), _ptr(self.freqs), 10, 1,
                                           ctypes.c_float(1e-10), _ptr(a["pw"]), _ptr(a["ff"]), _ptr(a["loc6"]),
-                                          _ptr(self.pad), _lib.current_stream_ptr(dev))
+                                          _ptr(self.pad), _ptr(self.valid), _lib.current_stream_ptr(dev))
         _lib.check(rc, "msr3d_scene_prologue")
 
     # ------------------------------------------------------------------ forward / backward

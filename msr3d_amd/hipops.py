@@ -79,19 +79,21 @@ def ln_partials(M, D, n_arrays, device):
                        device=device)
 
 
-def _ws_args(dev):
-    if not _deterministic[0]:
+def _ws_args(dev, force=False):
+    if not (_deterministic[0] or force):
         return ctypes.c_void_p(0), ctypes.c_size_t(0)
     ws = _workspace(dev)
     return ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(GEMM_WS_BYTES)
 
 
 def _gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, bias=None, c_pre=None, flags=0, beta=0.0,
-          p_drop=0.0, salt=0):
-    """p_drop > 0: epilogue dropout keyed by (seed word of the device, salt)."""
+          p_drop=0.0, salt=0, ordered=False):
+    """p_drop > 0: epilogue dropout keyed by (seed word of the device, salt).  ordered: K-splits meet in
+    a fixed order through the workspace (bit-reproducible, every output row independent of the
+    others) whatever the global deterministic switch says."""
     lib = _lib.load()
     dev = C.device
-    wp, wb = _ws_args(dev)
+    wp, wb = _ws_args(dev, ordered)
     seed = seed_word(dev) if p_drop > 0 else None
     with torch.cuda.device(dev):
         rc = lib.msr3d_gemm_f32(int(a_kc), int(b_kc), M, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc,

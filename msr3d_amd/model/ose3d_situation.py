@@ -116,14 +116,16 @@ class OSE3DSituation(BaseModel):
         return next(self.parameters()).device
 
     # ------------------------------------------------------------------ pieces
-    def encode_objects(self, obj_fts, obj_masks=None):
+    def encode_objects(self, obj_fts, obj_masks=None, out=None):
         """Frozen/eval backbone features (B,O,768).  Uses the encoder's `embed` (no dead
         classification head) when it has one, else `forward(...)[0]` like the reference.
         obj_masks only matters to an encoder with `skip_padded` set."""
         enc = self.obj_encoder
         if hasattr(enc, "embed"):
-            return enc.embed(obj_fts, obj_masks) if getattr(enc, "skip_padded", False) else enc.embed(obj_fts)
-        return enc(obj_fts)[0]
+            masks = obj_masks if getattr(enc, "skip_padded", False) else None
+            return enc.embed(obj_fts, masks, out) if out is not None else enc.embed(obj_fts, masks)
+        res = enc(obj_fts)[0]
+        return out.copy_(res) if out is not None else res
 
     def forward_gtpcd(self, data_dict):
         embeds = data_dict.get("obj_embeds")          # precomputed by a split (graphed) step

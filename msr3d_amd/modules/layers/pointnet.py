@@ -32,11 +32,14 @@ class PointNetPP(nn.Module):
         pooled_points = sa_n_points[-1] or 1           # None = group-all: one pooled point
         self.fc = nn.Linear(pooled_points * width, width)
 
-    def forward(self, features, valid=None):
+    def forward(self, features, valid=None, out=None):
         """(b, P, 3+C) -> (b, D).  valid (b,) bool: padding slots to skip (fused path only; see
-        fused.forward) -- ignored by the composite path, which encodes whatever the slots hold."""
+        fused.forward) -- ignored by the composite path, which encodes whatever the slots hold.
+        out (b, D): optional destination (fused path writes it directly)."""
         if fused.can_fuse(self, features):
-            return fused.forward(self, features, valid=valid)
+            return fused.forward(self, features, valid=valid, out=out)
+        if out is not None:
+            return out.copy_(self.forward(features, valid=valid))
         xyz, feats = break_up_pc(features)
         for level in self.encoder:
             xyz, feats = level(xyz, feats)

@@ -44,20 +44,21 @@ class PcdObjEncoder(nn.Module):
     # cloud instead -- identical values as long as masked slots hold the padding cloud.
     skip_padded = False
 
-    def encode(self, obj_pcds, obj_masks=None):
+    def encode(self, obj_pcds, obj_masks=None, out=None):
         """(B, O, P, C) -> (B, O, D): objects are independent clouds for the backbone."""
         B, O, P, C = obj_pcds.shape
         valid = obj_masks.reshape(B * O) if (self.skip_padded and obj_masks is not None) else None
-        return self.pcd_net(obj_pcds.reshape(B * O, P, C), valid=valid).reshape(B, O, -1)
+        o2 = out.view(B * O, -1) if out is not None else None
+        return self.pcd_net(obj_pcds.reshape(B * O, P, C), valid=valid, out=o2).reshape(B, O, -1)
 
-    def embed(self, obj_pcds, obj_masks=None):
+    def embed(self, obj_pcds, obj_masks=None, out=None):
         """obj_embeds only: what OSE3DSituation consumes (it takes `[0]` of forward and
         discards the 607-way logits, ose3d_situation.py:285), without the dead head."""
         if not self.freeze:
-            return self.encode(obj_pcds, obj_masks)
+            return self.encode(obj_pcds, obj_masks, out)
         self.freeze_bn(self.pcd_net)
         with torch.no_grad():
-            return self.encode(obj_pcds, obj_masks).detach()
+            return self.encode(obj_pcds, obj_masks, out).detach()
 
     def forward(self, obj_pcds, obj_locs=None, obj_masks=None, obj_sem_masks=None, **kwargs):
         obj_embeds = self.embed(obj_pcds, obj_masks)

@@ -125,8 +125,9 @@ def padding_feature(net, n_points, device):
     return cache[key]
 
 
-def forward(net, pts, return_internals=False, valid=None):
-    """pts (b, P, 6) f32 contiguous -> (b, 768).  Four kernel launches + one GEMM.
+def forward(net, pts, return_internals=False, valid=None, out=None):
+    """pts (b, P, 6) f32 contiguous -> (b, 768).  Four kernel launches + one GEMM (msr3d_gemm_f32);
+    `out` (b, 768) f32 contiguous, optional: the result is written there (a step's static buffer).
     valid (b,) bool, optional: objects marked False are PADDING slots holding the constant cloud;
     the kernels skip them and their rows receive `padding_feature` -- the same values the encoder
     would produce, without encoding the same cloud once per slot."""
@@ -179,9 +180,22 @@ def forward(net, pts, return_internals=False, valid=None):
         # skipped rows of `pooled` are uninitialised memory: neutralise them before the GEMM (a NaN
         # would be harmless -- rows are independent -- but Inf * 0 noise in debuggers is not)
         pooled = torch.where(valid.reshape(b, 1), pooled, torch.zeros((), device=dev))
-    out = F.linear(pooled, net.fc.weight, net.fc.bias)
+    # `fc` (/root/reference/modules/layers/pointnet.py:52-63) on the f32-MFMA token GEMM: the vendor
+    # library's heuristic kernel was the last foreign launch of the encoder
+    from .. import hipops
+    fc = net.fc
+    n_out, k_in = fc.weight.shape
+    res = out if (out is not None and vmask is None) else torch.empty((b, n_out), dtype=torch.float32, device=dev)
+    if res.shape != (b, n_out) or not res.is_contiguous() or res.dtype != torch.float32:
+        raise ValueError("out must be a contiguous (b, %d) float32 tensor" % n_out)
+    # (ordered K-splits: an object's feature must not depend on which other objects share the launch)
+    hipops._gemm(True, True, b, n_out, k_in, pooled, k_in, fc.weight, k_in, res, n_out, bias=fc.bias, ordered=True)
     if vmask is not None:
-        out = torch.where(valid.reshape(b, 1), out, pad_feat)
+        res = torch.where(valid.reshape(b, 1), res, pad_feat)
+        if out is not None:
+            out.copy_(res)
+            res = out
+    out = res
     if return_internals:
         dbg.update(new_xyz1=new1, new_xyz2=new2, feat1=feat1, feat2=feat2, pooled=pooled)
         return out, dbg

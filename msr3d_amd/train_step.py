@@ -28,7 +28,8 @@ from . import hipops
 
 
 class HotPathTrainStep:
-    def __init__(self, model, optimizer, dp, loss_fn, example_batch, use_graph=True, accum_steps=1):
+    def __init__(self, model, optimizer, dp, loss_fn, example_batch, use_graph=True, accum_steps=1,
+                 zero_in_optimizer=False):
         """model: MSR3DHotPath; dp: FlatGradAllReduce over its trainable params;
         loss_fn(scene_dict) -> scalar, or (scalar, tensor, d scalar / d tensor) when the caller
         already holds the upstream gradient; example_batch fixes the (static) shapes.
@@ -57,6 +58,13 @@ class HotPathTrainStep:
             raise ValueError("accum_steps must be >= 1")
         self._micro = 0
         self._zero_in_graph = False
+        # zero_in_optimizer: the fused AdamW kernel clears each gradient as it consumes it (its
+        # zero_grad flag) instead of a separate 21 MB fill at the start of the next step; only in the
+        # single-graph schedule (one rank, no accumulation), and the gradients are then NOT readable
+        # after a step
+        self._opt_zeroes = bool(zero_in_optimizer) and self.accum_steps == 1 and not dp.distributed \
+            and getattr(optimizer, "fused_clip", False)
+        self._sched_direct = False
         # encoder prefetch (software pipelining over steps)
         self._enc_stream = torch.cuda.Stream() if self.static["obj_embeds"].is_cuda else None
         self._pref = {"key": None, "feats": torch.empty_like(self.static["obj_embeds"]), "event": None}
@@ -100,8 +108,13 @@ class HotPathTrainStep:
             self.opt.step()
 
     def _train_part(self):
-        loss = self._fwd_bwd()
-        self._update()
+        loss = self._fwd_bwd(zero=not self._opt_zeroes)
+        if self._opt_zeroes:
+            self.dp.start()
+            self.dp.wait()
+            self.opt.step(zero_grad=True)
+        else:
+            self._update()
         return loss
 
     def _micro_step(self, run, between=None):
@@ -124,7 +137,7 @@ class HotPathTrainStep:
         """Run the frozen encoder for `batch` NOW on the compute stream; the step that later
         receives this batch finds its features ready (same hand-over as prefetch())."""
         with torch.no_grad():
-            self._pref["feats"].copy_(self.prompter.encode_objects(batch["obj_fts"], batch.get("obj_masks")))
+            self.prompter.encode_objects(batch["obj_fts"], batch.get("obj_masks"), out=self._pref["feats"])
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self._pref["key"], self._pref["event"] = id(batch["obj_fts"]), ev
@@ -137,29 +150,45 @@ class HotPathTrainStep:
         self._enc_stream.wait_stream(main)          # inputs exist; previous prefetch consumed
         # (the encoder's fc GEMM runs concurrently with the main stream's: its own split-K workspace)
         with torch.cuda.stream(self._enc_stream), torch.no_grad(), hipops.gemm_lane(1):
-            self._pref["feats"].copy_(self.prompter.encode_objects(batch["obj_fts"], batch.get("obj_masks")))
+            self.prompter.encode_objects(batch["obj_fts"], batch.get("obj_masks"), out=self._pref["feats"])
             ev = torch.cuda.Event()
             ev.record(self._enc_stream)
         self._pref["key"], self._pref["event"] = id(batch["obj_fts"]), ev
 
     def _load(self, batch):
+        sched = getattr(self.model, "_schedule", None)
         with torch.no_grad():
             if self._pref["key"] == id(batch["obj_fts"]):     # features were prefetched
                 torch.cuda.current_stream().wait_event(self._pref["event"])
-                feats = self._pref["feats"]
+                self.static["obj_embeds"].copy_(self._pref["feats"])
                 self._pref["key"] = None
             else:
-                feats = self.prompter.encode_objects(batch["obj_fts"], batch.get("obj_masks"))
-            # all inputs into the static buffers with one multi-tensor copy per dtype (two launches
-            # instead of five: every launch costs the step ~5 us)
-            keys = [k for k in self.static if k != "obj_embeds"]
-            dst = [self.static["obj_embeds"]] + [self.static[k] for k in keys]
-            src = [feats] + [batch[k] for k in keys]
-            if all(d.is_cuda and s.is_cuda and d.dtype == s.dtype and d.shape == s.shape for d, s in zip(dst, src)):
-                torch._foreach_copy_(dst, src)
+                # the encoder's last GEMM writes the static buffer itself
+                self.prompter.encode_objects(batch["obj_fts"], batch.get("obj_masks"),
+                                             out=self.static["obj_embeds"])
+            direct = sched is not None and sched.enabled and self.static["obj_embeds"].is_cuda and \
+                sched.eligible(dict(batch, obj_embeds=self.static["obj_embeds"]), ignore_grad_mode=True)
+            if direct:
+                # the schedule's one-launch prologue reads the batch's small tensors where they are
+                # and writes every derived static buffer (key mask, pairwise / Fourier features,
+                # obj_locs and obj_masks copies): no input copies at all
+                sched.stage(dict(batch, obj_embeds=self.static["obj_embeds"]))
+                self.static["obj_masks"] = sched.valid
+                self.static["obj_locs"] = sched.arena["loc6"].view(sched.valid.shape[0], sched.valid.shape[1], 6)
+                self.static["_staged"] = True
             else:
-                for d, s in zip(dst, src):
-                    d.copy_(s)
+                self.static.pop("_staged", None)
+                keys = [k for k in self.static if k not in ("obj_embeds", "_staged")]
+                dst = [self.static[k] for k in keys]
+                src = [batch[k] for k in keys]
+                if all(d.is_cuda and s.is_cuda and d.dtype == s.dtype and d.shape == s.shape for d, s in zip(dst, src)):
+                    torch._foreach_copy_(dst, src)
+                else:
+                    for d, s in zip(dst, src):
+                        d.copy_(s)
+            if direct != self._sched_direct and self.graph is not None:
+                raise RuntimeError("the captured step was built for the other input-staging mode")
+            self._sched_direct = direct
 
     def _snapshot(self):
         """Everything the warm-up steps move: weights, optimiser moments and step counter (LR
@@ -169,9 +198,9 @@ class HotPathTrainStep:
         if hasattr(opt, "flat_p"):
             snap["flat"] = [t.clone() for t in (opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.step_ctr)]
         else:
-            import copy
             snap["params"] = [p.detach().clone() for p in self.dp.order]
-            snap["opt"] = copy.deepcopy(opt.state_dict())
+            snap["opt"] = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                           for p, st in opt.state.items()}
         dev = self.static["obj_embeds"].device
         if dev.type == "cuda":
             snap["seed"] = hipops.seed_word(dev).clone()
@@ -186,7 +215,16 @@ class HotPathTrainStep:
             else:
                 for p, v in zip(self.dp.order, snap["params"]):
                     p.copy_(v)
-                opt.load_state_dict(snap["opt"])
+                # in place: the state tensors the warm-up created stay allocated (a capturable
+                # optimiser must not initialise its state inside the capture); state that did not
+                # exist before the warm-up goes back to its initial zeros
+                for p, st in opt.state.items():
+                    before = snap["opt"].get(id(p), {})
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            v.copy_(before[k]) if k in before else v.zero_()
+                        elif k in before:
+                            st[k] = before[k]
             if "seed" in snap:
                 hipops.seed_word(self.static["obj_embeds"].device).copy_(snap["seed"])
         self._micro = snap["micro"]
