@@ -33,6 +33,7 @@ SOURCES = [
     ("preprocess.hip", ["-ffp-contract=off"]),
     ("bn_train.hip", []),
     ("strip_gemm.hip", []),
+    ("panel_gemm.hip", []),
     ("prompter_rows.hip", ["-ffp-contract=off"]),
 ]
 

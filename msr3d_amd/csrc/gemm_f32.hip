@@ -30,6 +30,7 @@
 
 #include "../../include/msr3d_hip.h"
 #include "dropout_rng.h"
+#include "panel_gemm.h"
 
 namespace {
 
@@ -603,7 +604,7 @@ static int plan_gemm(int a_kc, int M, int N, int K, const float *A, int lda, con
                      float *C, int ldc, const float *bias, float *C_pre, int flags, float beta,
                      float *a_colsum, void *workspace, size_t workspace_bytes, float p_drop,
                      const unsigned long long *seed, unsigned salt, bool allow_big_tiles,
-                     hipStream_t st, GemmP *out, int *rm_out, int *rn_out, bool *empty) {
+                     hipStream_t st, GemmP *out, int *rm_out, int *rn_out, bool *empty, int target_override = 0) {
   *empty = true;
   if (M < 0 || N < 0 || K < 0 || lda <= 0 || ldb <= 0 || ldc <= 0) return MSR3D_EINVAL;
   if (M == 0 || N == 0) return 0;
@@ -620,7 +621,8 @@ static int plan_gemm(int a_kc, int M, int N, int K, const float *A, int lda, con
   // ~2 workgroups per CU; the 2-GFLOP problems (llm_proj's dx and dW) time better with 4 per CU
   // (54.6 -> 47.8 us, 52.8 -> 46.6 us), the 1-GFLOP ones do not care, more than that is worse for all
   static const int target_env = getenv("MSR3D_GEMM_TARGET_WGS") ? atoi(getenv("MSR3D_GEMM_TARGET_WGS")) : 0;
-  const int target_wgs = target_env > 0 ? target_env : ((double)M * N * K >= 0.75e9 ? 1024 : 512);
+  const int target_wgs = target_override > 0 ? target_override
+                         : target_env > 0 ? target_env : ((double)M * N * K >= 0.75e9 ? 1024 : 512);
   static const int big_tiles = getenv("MSR3D_GEMM_BIG_TILES") ? atoi(getenv("MSR3D_GEMM_BIG_TILES")) : 0;
   if (big_tiles && allow_big_tiles) {
     if (ntiles(128, 128) >= 192) { rm = 4; rn = 4; }
@@ -811,21 +813,67 @@ int msr3d_linear_bwd_f32(int M_tokens, int N_out, int K_in, const float *dy, con
 int msr3d_gemm_multi_f32(int n, const msr3d_gemm_problem_t *pr, msr3d_stream_t stream) {
   if (n < 0 || n > MSR3D_GEMM_MULTI_MAX || (n > 0 && !pr)) return MSR3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  static const bool no_panel = getenv("MSR3D_GEMM_NO_PANEL") != nullptr;     // A/B switch (tools/)
+  static const int run_env = getenv("MSR3D_PANEL_RUN_STAGES") ? atoi(getenv("MSR3D_PANEL_RUN_STAGES")) : 0;
+  // The problems of one launch share the chip.  Panel problems (panel_gemm.hip) are cut into K runs
+  // of equal LENGTH across the launch -- total (tiles x stages) over ~1.5 workgroups per CU, at least
+  // 4 stages -- so that a problem with few tiles and a long reduction is split and one with many tiles
+  // is not (each K run beyond the first costs the output's size in atomic traffic, and the chip
+  // retires only ~1.1 TB/s of float atomics: tools/bench_multi.py, tools/prof_panel.py).  Tiled
+  // problems (gemm_f32.hip's kernel) get their share of ~3 workgroups per CU.
+  int live = 0;
+  long long units = 0;
+  for (int j = 0; j < n; ++j) live += (pr[j].M > 0 && pr[j].N > 0) ? 1 : 0;
+  // Measured (tools/bench_multi.py, 960 tokens): a problem that has the chip to itself is 30-40 %
+  // faster on the panel kernel (ffn2 27.9 -> 17.3 us, proj 15.3 -> 12.3 us); launches that mix a dx
+  // with weight gradients are not (B4 55.5 vs 60.8 us, B2 24.3 vs 28.1 us) -- co-resident panel
+  // workgroups gain nothing from each other -- and stay on the tiled kernel with a per-problem share
+  // of the workgroup budget.  MSR3D_GEMM_PANEL=all / MSR3D_GEMM_NO_PANEL=1 override for A/B runs.
+  static const bool panel_all = getenv("MSR3D_GEMM_PANEL") && getenv("MSR3D_GEMM_PANEL")[0] == 'a';
+  const bool use_panel = !no_panel && (live == 1 || panel_all);
+  for (int j = 0; j < n; ++j) {
+    if (pr[j].M <= 0 || pr[j].N <= 0) continue;
+    if (use_panel && msr3d::panel_eligible(pr[j])) {
+      int tiles, stages;
+      msr3d::panel_shape(pr[j], &tiles, &stages);
+      units += (long long)tiles * stages;
+    }
+  }
+  const int target = live > 1 ? (768 / live < 192 ? 192 : 768 / live) : 0;
+  int run_stages = (int)((units + 383) / 384);
+  if (run_stages < 4) run_stages = 4;
+  if (run_env > 0) run_stages = run_env;
   GemmBatch gb;
-  gb.n = 0;
-  int blocks = 0;
+  msr3d::PanelBatch pb;
+  gb.n = pb.n = 0;
+  int blocks = 0, pblocks = 0;
   for (int j = 0; j < n; ++j) {
     const msr3d_gemm_problem_t &q = pr[j];
     // atomic meeting point only: C (and the column-sum destination) hold the values to add to, or
     // zeros -- the caller's one zero-fill per step covers them; beta = 0 is allowed where no K-split
-    // happens, and plan_gemm zero-fills otherwise
+    // happens, and the planners zero-fill otherwise
     if (q.beta != 0.f && q.beta != 1.f) return MSR3D_EINVAL;
     if (q.colsum && (q.a_kc || q.beta != 1.f)) return MSR3D_EINVAL;
+    if (q.M < 0 || q.N < 0 || q.K < 0 || q.lda <= 0 || q.ldb <= 0 || q.ldc <= 0) return MSR3D_EINVAL;
+    if (q.M == 0 || q.N == 0) continue;
+    if (!q.A || !q.B || !q.C) return MSR3D_EINVAL;
+    if (use_panel && msr3d::panel_eligible(q)) {
+      // long reductions and weight gradients: one K chunk per workgroup, operands staged once
+      // (panel_gemm.hip)
+      msr3d::PanelP pp;
+      const int rc = msr3d::panel_plan(q, run_stages, &pp, st);
+      if (rc != 0) return rc;
+      pb.p[pb.n] = pp;
+      pb.first[pb.n] = pblocks;
+      pblocks += pp.gx * pp.gy * pp.gz;
+      ++pb.n;
+      continue;
+    }
     GemmP g;
     int rm, rn;
     bool empty;
     const int rc = plan_gemm(q.a_kc, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.bias, nullptr, 0,
-                             q.beta, q.colsum, nullptr, 0, 0.f, nullptr, 0, false, st, &g, &rm, &rn, &empty);
+                             q.beta, q.colsum, nullptr, 0, 0.f, nullptr, 0, false, st, &g, &rm, &rn, &empty, target);
     if (rc != 0) return rc;
     if (empty) continue;
     gb.p[gb.n] = g;
@@ -833,6 +881,11 @@ int msr3d_gemm_multi_f32(int n, const msr3d_gemm_problem_t *pr, msr3d_stream_t s
     gb.first[gb.n] = blocks;
     blocks += g.gx * g.gy * g.gz;
     ++gb.n;
+  }
+  if (pb.n > 0) {
+    for (int j = pb.n; j <= MSR3D_GEMM_MULTI_MAX; ++j) pb.first[j] = pblocks;
+    const int rc = msr3d::panel_launch(pb, pblocks, st);
+    if (rc != 0) return rc;
   }
   if (gb.n == 0) return 0;
   for (int j = gb.n; j <= MSR3D_GEMM_MULTI_MAX; ++j) gb.first[j] = blocks;

@@ -277,3 +277,41 @@ def test_pos_embed_and_scene_prologue_match_the_module_formulation():
     # d_lin: check through the weight gradients they imply
     assert rel(da.double().T @ ff.double().view(M, KF), enc_a[0].weight.grad) < 2e-5
     assert rel(db.double().sum(0), enc_b[0].bias.grad) < 2e-5
+
+
+def test_gemm_multi_ragged_problems_panel_and_tiled():
+    """The schedule's other launch groups, including the ragged ones (816 output rows / 816-long
+    reduction, a 64-long tail chunk at K = 960, N = 63 / 3 weight gradients that stay on the tiled
+    kernel), through both kernels behind msr3d_gemm_multi_f32 (subprocess-free: the switch is read
+    once per process, so the tiled variant is exercised through problems the panel kernel rejects)."""
+    from msr3d_amd import _lib
+    torch.manual_seed(14)
+    M, D, W = 960, 256, 816
+    dq, wv, xin = torch.randn(M, W, device="cuda"), torch.randn(W, D, device="cuda") / 16, torch.randn(M, D, device="cuda")
+    d_x = torch.randn(M, D, device="cuda")
+    d_x0 = d_x.clone()
+    gw, gb = torch.zeros(W, D, device="cuda"), torch.zeros(W, device="cuda")
+    ff = torch.randn(M, 63, device="cuda")
+    d_la = torch.randn(M, D, device="cuda")
+    gl, gbl = torch.zeros(D, 63, device="cuda"), torch.zeros(D, device="cuda")
+    arr = (_lib.GemmProblem * 3)()
+    def fill(q, **kw):
+        for k, v in kw.items():
+            setattr(q, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    fill(arr[0], a_kc=1, b_kc=0, M=M, N=D, K=W, A=dq, lda=W, B=wv, ldb=D, C=d_x, ldc=D, beta=1.0)
+    fill(arr[1], a_kc=0, b_kc=0, M=W, N=D, K=M, A=dq, lda=W, B=xin, ldb=D, C=gw, ldc=D, beta=1.0, colsum=gb)
+    fill(arr[2], a_kc=0, b_kc=0, M=D, N=63, K=M, A=d_la, lda=D, B=ff, ldb=63, C=gl, ldc=63, beta=1.0, colsum=gbl)
+    rc = _lib.load().msr3d_gemm_multi_f32(3, arr, _lib.current_stream_ptr(torch.device("cuda")))
+    _lib.check(rc, "msr3d_gemm_multi_f32")
+    torch.cuda.synchronize()
+    assert rel(d_x, d_x0.double() + dq.double() @ wv.double()) < 2e-5
+    assert rel(gw, dq.double().T @ xin.double()) < 2e-5 and rel(gb, dq.double().sum(0)) < 2e-5
+    assert rel(gl, d_la.double().T @ ff.double()) < 2e-5 and rel(gbl, d_la.double().sum(0)) < 2e-5
+    # beta = 0 with K-splits (the planner clears C itself) and a forward product with bias, K = 768
+    emb, Wp, bp = torch.randn(M, 768, device="cuda"), torch.randn(D, 768, device="cuda") / 28, torch.randn(D, device="cuda")
+    y = torch.full((M, D), float("nan"), device="cuda")
+    one = (_lib.GemmProblem * 1)()
+    fill(one[0], a_kc=1, b_kc=1, M=M, N=D, K=768, A=emb, lda=768, B=Wp, ldb=768, C=y, ldc=D, bias=bp, beta=0.0)
+    rc = _lib.load().msr3d_gemm_multi_f32(1, one, _lib.current_stream_ptr(torch.device("cuda")))
+    _lib.check(rc, "msr3d_gemm_multi_f32")
+    assert rel(y, emb.double() @ Wp.double().T + bp.double()) < 2e-5
