@@ -55,30 +55,33 @@ __global__ __launch_bounds__(256) void scene_prologue_kernel(
     }
   }
   __syncthreads();
-  // Fourier features of the (agent-frame) centres: threads < L, one token each
-  if (part == 0 && tid < L) {
-    float v[3] = {cx[tid], cy[tid], cz[tid]};
-    if (transform) {
-      const float *a = anchor_loc + (size_t)b * 3;
-      const float *q = anchor_ori + (size_t)b * 4;
-      const float r0 = v[0] - a[0], r1 = v[1] - a[1], r2 = v[2] - a[2];
-      const float x = -q[0], y = -q[1], z = -q[2], w = q[3];
-      const float xx = x * x, yy = y * y, zz = z * z;
-      const float xy = x * y, xz = x * z, xw = x * w, yz = y * z, yw = y * w, zw = z * w;
-      const float R00 = 1.f - 2.f * (yy + zz), R01 = 2.f * (xy + zw), R02 = 2.f * (xz - yw);
-      const float R10 = 2.f * (xy - zw), R11 = 1.f - 2.f * (xx + zz), R12 = 2.f * (yz + xw);
-      const float R20 = 2.f * (xz + yw), R21 = 2.f * (yz - xw), R22 = 1.f - 2.f * (xx + yy);
-      v[0] = (r0 * R00 + r1 * R10) + r2 * R20;
-      v[1] = (r0 * R01 + r1 * R11) + r2 * R21;
-      v[2] = (r0 * R02 + r1 * R12) + r2 * R22;
-    }
+  // Fourier features of the (agent-frame) centres: the four blocks of a sample share the tokens,
+  // one (token, coordinate) pair per thread and pass
+  {
     const int W = 3 + 6 * nb;
-    float *o = ff + ((size_t)b * L + tid) * W;
     const float pi = 3.14159265358979323846f;
-    for (int c = 0; c < 3; ++c) {
-      o[c] = v[c];
+    for (int e = part * 256 + tid; e < L * 3; e += 4 * 256) {
+      const int tok = e / 3, c = e - tok * 3;
+      float v[3] = {cx[tok], cy[tok], cz[tok]};
+      if (transform) {
+        const float *a = anchor_loc + (size_t)b * 3;
+        const float *q = anchor_ori + (size_t)b * 4;
+        const float r0 = v[0] - a[0], r1 = v[1] - a[1], r2 = v[2] - a[2];
+        const float x = -q[0], y = -q[1], z = -q[2], w = q[3];
+        const float xx = x * x, yy = y * y, zz = z * z;
+        const float xy = x * y, xz = x * z, xw = x * w, yz = y * z, yw = y * w, zw = z * w;
+        const float R00 = 1.f - 2.f * (yy + zz), R01 = 2.f * (xy + zw), R02 = 2.f * (xz - yw);
+        const float R10 = 2.f * (xy - zw), R11 = 1.f - 2.f * (xx + zz), R12 = 2.f * (yz + xw);
+        const float R20 = 2.f * (xz + yw), R21 = 2.f * (yz - xw), R22 = 1.f - 2.f * (xx + yy);
+        v[0] = (r0 * R00 + r1 * R10) + r2 * R20;
+        v[1] = (r0 * R01 + r1 * R11) + r2 * R21;
+        v[2] = (r0 * R02 + r1 * R12) + r2 * R22;
+      }
+      const float vc = c == 0 ? v[0] : c == 1 ? v[1] : v[2];
+      float *o = ff + ((size_t)b * L + tok) * W;
+      o[c] = vc;
       for (int k = 0; k < nb; ++k) {
-        const float s = pi * (v[c] * freqs[k]);
+        const float s = pi * (vc * freqs[k]);
         o[3 + c * nb + k] = sinf(s);
         o[3 + 3 * nb + c * nb + k] = cosf(s);
       }
@@ -134,9 +137,21 @@ __global__ __launch_bounds__(256) void pos_embed_fwd_kernel(
   float *T = F + PR * 64;            // [2][16][256] pre-norm results, both encoders
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = blockIdx.x * PR;
-  for (int e = tid; e < 256 * KF; e += 256) {          // coalesced read of Wa (256, KF)
-    const int cc = e / KF, k = e - cc * KF;
-    WT[k * 257 + cc] = Wa[e];
+  for (int e0 = 0; e0 < 256 * KF; e0 += 256 * 8) {     // coalesced read of Wa (256, KF), 8 loads in flight
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * 256 + tid;
+      v[u] = e < 256 * KF ? Wa[e] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * 256 + tid;
+      if (e < 256 * KF) {
+        const int cc = e / KF, k = e - cc * KF;
+        WT[k * 257 + cc] = v[u];
+      }
+    }
   }
   for (int k = KF; k < 64; ++k) WT[k * 257 + tid] = 0.f;
   for (int e = tid; e < PR * 64; e += 256) {

@@ -155,3 +155,42 @@ def test_registry_and_build_module_surface():
         modules.build_module("audio", cfg.model.vision)
     # the in-place `mlp_spec[0] += 3` quirk is visible to the caller (pointnet2_modules.py:120-122)
     assert cfg.model.vision.args.sa_mlps[0][0] == 3
+
+
+def test_fullsize_golden_through_the_cpu_mirror():
+    """Bs = 2, O = 60 (7 padded), P = 1024: the module mirror on CPU (oracle as `_ext`) reproduces the
+    reference's full-size outputs and gradients (tests/golden/fullsize_seed0.npz)."""
+    import os
+    import msr3d_amd.model  # noqa: F401
+    import msr3d_amd.modules  # noqa: F401
+    from msr3d_amd.config import default_prompter_cfg
+    from msr3d_amd.model import build_model
+    from msr3d_amd.pointnet2 import pointnet2_utils
+    from msr3d_amd.synth import synth_batch
+    from oracle import pn2
+    from tests.helpers import GOLDEN, rel_l2
+    g = dict(np.load(os.path.join(GOLDEN, "fullsize_seed0.npz"), allow_pickle=False))
+    B, O, P, n_pad, E = (int(v) for v in g["shape"])
+    saved = pointnet2_utils._ext
+    pointnet2_utils._ext = pn2.ext_module()
+    try:
+        torch.set_num_threads(8)
+        model = build_model(default_prompter_cfg(situation_type="as_transform_for_objects", freeze=True)).eval()
+        model.load_state_dict(fill_state_dict(model.state_dict(), int(g["weight_seed"])), strict=True)
+        with torch.no_grad():
+            model.object_orientation_feat.copy_(torch.from_numpy(g["orientation_feat"]))
+        proj = torch.nn.Linear(256, E)
+        proj.load_state_dict(fill_state_dict(proj.state_dict(), int(g["weight_seed"]) + 100))
+        batch = synth_batch(int(g["data_seed"]), B, O=O, P=P, n_valid=[O - n_pad, O - n_pad])
+        out = model(dict(batch))
+        scene = proj(out["obj_tokens"])
+        gy = torch.from_numpy(np.random.default_rng(int(g["loss_grad_seed"])).standard_normal(tuple(scene.shape)).astype(np.float32))
+        (scene * gy).sum().backward()
+    finally:
+        pointnet2_utils._ext = saved
+    assert rel_l2(out["obj_tokens"].detach().numpy(), g["obj_tokens"]) < 2e-5
+    assert rel_l2(scene.detach().numpy(), g["scene_embeds"]) < 2e-5
+    for n in ("obj_linear_projection.weight", "spatial_encoder.1.self_attn.w_qs.weight",
+              "loc_embedding_encoder.0.weight", "object_orientation_feat"):
+        assert rel_l2(dict(model.named_parameters())[n].grad.numpy(), g["grad/" + n]) < 1e-4, n
+    assert rel_l2(proj.weight.grad.numpy(), g["grad/llm_proj.weight"]) < 1e-4

@@ -1,0 +1,103 @@
+"""The BENCHMARKED schedule pinned directly to the reference at full size:
+HotPathTrainStep -- train mode, dropout 0, frozen encoder on the fused kernels, the whole trainable
+part as the fused schedule (msr3d_amd/fused_model.py), HIP-graph replay, gradients in the flat buffer,
+FlatAdamW with lr = 0 -- against tests/golden/fullsize_seed{0,1,2}.npz, which the reference's own
+Python produced for Bs = 2, O = 60 (7 padded), P = 1024 (tests/golden/make_golden_fullsize.py).
+Forward values <= 2e-5 rel-L2 (fp32, different summation orders); gradients <= 1e-4 (full tensors for
+obj_linear_projection, llm_proj, the LayerNorms, the positional encoders, the constant embeddings and
+all of spatial_encoder.1's attention block; every 8th row of its FFN matrices; norm and sum of the rest)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def _build(g, dropout=0.0):
+    import msr3d_amd.model  # noqa: F401
+    import msr3d_amd.modules  # noqa: F401
+    from msr3d_amd import hipops
+    from msr3d_amd.config import AttrDict, default_prompter_cfg
+    from msr3d_amd.dp import FlatGradAllReduce
+    from msr3d_amd.model import build_model
+    from msr3d_amd.optim import FlatAdamW
+    from tests.helpers import fill_state_dict
+    seed = int(g["weight_seed"])
+    B, O, P, n_pad, E = (int(v) for v in g["shape"])
+    cfg = AttrDict({"prompter": default_prompter_cfg(dropout=dropout), "llm_hidden_size": E,
+                    "model": {"name": "MSR3DHotPath"}})
+    model = build_model(cfg)
+    vp = model.visual_prompter
+    vp.load_state_dict(fill_state_dict(vp.state_dict(), seed), strict=True)
+    model.llm_proj.load_state_dict(fill_state_dict(model.llm_proj.state_dict(), seed + 100))
+    with torch.no_grad():
+        vp.object_orientation_feat.copy_(torch.from_numpy(g["orientation_feat"]))
+    model = model.cuda().train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    dp = FlatGradAllReduce(params, pack_groups=hipops.collect_pack_groups(model))
+    opt = FlatAdamW(dp, lr=0.0, weight_decay=0.0)
+    assert hipops.attach_packed_views(model, dp, opt) == 3
+    return model, dp, opt
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_benchmarked_schedule_matches_the_reference_at_full_size(seed, use_graph):
+    from msr3d_amd.synth import synth_batch
+    from msr3d_amd.train_step import HotPathTrainStep
+    g = dict(np.load(os.path.join(GOLD, f"fullsize_seed{seed}.npz"), allow_pickle=False))
+    B, O, P, n_pad, E = (int(v) for v in g["shape"])
+    model, dp, opt = _build(g)
+    batch = synth_batch(int(g["data_seed"]), B, O=O, P=P, n_valid=[O - n_pad, O - n_pad], device="cuda")
+    gy = torch.from_numpy(np.random.default_rng(int(g["loss_grad_seed"])).standard_normal((B, O, E)).astype(np.float32)).cuda()
+    seen = {}
+
+    def loss_fn(out):
+        y = out["scene_embeds"]
+        seen["tok"], seen["scene"] = out["obj_tokens"], y
+        with torch.no_grad():
+            loss = torch.dot(y.reshape(-1), gy.reshape(-1))
+        return loss, y, gy
+
+    step = HotPathTrainStep(model, opt, dp, loss_fn, batch, use_graph=use_graph)
+    assert model._schedule.eligible(dict(batch, obj_embeds=step.static["obj_embeds"]), ignore_grad_mode=True)
+    step.capture(batch)
+    loss = step(batch)
+    torch.cuda.synchronize()
+    assert (step.graph is not None) == use_graph and step._sched_direct
+    # frozen encoder (fused kernels) vs the reference's PcdObjEncoder driven by the oracle
+    assert rel(step.static["obj_embeds"].cpu().numpy(), g["enc_out"]) < 2e-5
+    assert rel(seen["tok"].detach().cpu().numpy(), g["obj_tokens"]) < 2e-5
+    assert rel(seen["scene"].detach().cpu().numpy(), g["scene_embeds"]) < 2e-5
+    assert abs(float(loss) - float(g["loss"])) <= 2e-4 * max(abs(float(g["loss"])), 10.0)
+    # lr = 0: the weights did not move; the flat buffer still holds this step's gradients
+    grads = {("llm_proj." + n[len("llm_proj."):] if n.startswith("llm_proj.") else n[len("visual_prompter."):]): p.grad
+             for n, p in model.named_parameters() if p.requires_grad}
+    names = [str(n) for n in g["grad_names"]]
+    checked_full = 0
+    for i, n in enumerate(names):
+        got = grads[n].detach().cpu().numpy().astype(np.float64)
+        if n.endswith("w_ks.bias"):                # mathematically zero; the reference holds rounding noise too
+            assert np.abs(got).max() < 1e-3
+            continue
+        if "grad/" + n in g:
+            assert rel(got, g["grad/" + n]) < 1e-4, n
+            checked_full += 1
+        elif "grad8/" + n in g:
+            assert rel(got[::8], g["grad8/" + n]) < 1e-4, n
+            checked_full += 1
+        assert abs(np.linalg.norm(got) - g["grad_norms"][i]) <= 1e-4 * g["grad_norms"][i] + 1e-7, n
+        assert abs(got.sum() - g["grad_sums"][i]) <= 1e-3 * max(abs(g["grad_sums"][i]), g["grad_norms"][i]), n
+    assert checked_full >= 30
+    # parameters the configuration does not use keep zero gradients (the reference leaves them None)
+    for n, gr in grads.items():
+        if n not in names:
+            assert float(gr.abs().max()) == 0.0, n
