@@ -29,12 +29,29 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# HBM traffic of one sa2_kernel launch at the bench's shape (960 objects), from the PMC passes
-# committed under profiles/ (tools/pmc_sa.sh: FETCH_SIZE and WRITE_SIZE in separate passes, KiB
-# units, FETCH_SIZE doubled per the gfx950 calibration in MI355X_MICROARCH.md §HBM):
-#   (28797 * 2 + 15360) KiB = 74.7 MB  vs  algorithmic 15.7 MB in (feat1) + 15.7 MB out (feat2);
-#   WRITE_SIZE is exactly the output, the read side carries the per-block weight stream's L2 misses
-SA2_TRAFFIC_BYTES_PER_OBJECT = (28797.3 * 2 + 15360) * 1024 / 960.0
+# HBM traffic of one sa2_kernel launch at the bench's shape (960 objects): read at run time from the
+# NEWEST committed PMC summary profiles/*pmc_sa*.txt (tools/pmc_sa.sh: FETCH_SIZE and WRITE_SIZE in
+# separate --pmc passes, KiB units, FETCH_SIZE doubled per the gfx950 calibration in
+# MI355X_MICROARCH.md §HBM).  None if no summary travels with the tree.
+
+
+def sa2_traffic_from_profiles():
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_sa*.txt")), key=os.path.getmtime)
+    for f in reversed(files):
+        block, vals = None, {}
+        for line in open(f):
+            if not line.startswith((" ", "#")) and line.strip():
+                block = line.strip()
+            m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.eE+]+)", line)
+            if m and block and block.startswith("sa2_kernel"):
+                vals[m.group(1)] = float(m.group(2))
+        if len(vals) == 2:
+            return (vals["FETCH_SIZE"] * 2 + vals["WRITE_SIZE"]) * 1024 / 960.0, os.path.relpath(f, ROOT)
+    return None, None
+
+
 MFMA_F32_PEAK_TF = 157.3       # f32-input MFMA dense peak
 O, P = 60, 1024                # objects per scene, points per object (configs/msr3d.yaml:60,153)
 
@@ -50,6 +67,9 @@ def parse():
     ap.add_argument("--objects", type=int, default=60, help="objects per scene (120: BASELINE stress config)")
     ap.add_argument("--points", type=int, default=1024, help="points per object (2048: stress config)")
     ap.add_argument("--situation-type", default="as_transform_for_objects")
+    ap.add_argument("--accum", type=int, default=1, help="gradient accumulation: micro-batches of --batch "
+                    "scenes per optimiser step (the reference launches 4 scenes/GPU x 5: configs/msr3d.yaml:33,164); "
+                    "a bench step is then one OPTIMISER step = accum micro-batches")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", action="store_true", help="overlap the frozen encoder of batch "
@@ -94,7 +114,7 @@ class Trainer:
     """The hot-path step.  Optimiser settings: optim/build.py + configs/msr3d.yaml:43-47
     (AdamW lr 3e-5, betas (0.9, 0.999), wd 0.05), grad clip 5.0 (leo_trainer.py:192-193)."""
 
-    def __init__(self, model, device, example_batch, E, use_graph):
+    def __init__(self, model, device, example_batch, E, use_graph, accum=1):
         from msr3d_amd.dp import FlatGradAllReduce
         from msr3d_amd.train_step import HotPathTrainStep
         self.model = model
@@ -127,7 +147,7 @@ class Trainer:
             return loss, y, state["g"]
 
         self.stepper = HotPathTrainStep(model, self.opt, self.dp, loss_fn, example_batch,
-                                        use_graph=use_graph, zero_in_optimizer=True)
+                                        use_graph=use_graph, zero_in_optimizer=True, accum_steps=accum)
         if on_gpu and use_graph:
             self.stepper.capture(example_batch)
 
@@ -151,17 +171,44 @@ def cpu_baseline(args, seconds):
         model = build(args, torch.device("cpu"))
         batches = [synth_batch(10_000 + i, 1, O=O, P=P) for i in range(2)]
         tr = Trainer(model, torch.device("cpu"), batches[0], args.llm_hidden, use_graph=False)
-        tr.step(batches[0])                       # warm-up
-        n, t0 = 0, time.perf_counter()
+        for _ in range(3):                        # warm-ups
+            tr.step(batches[0])
+        times = []
+        t0 = time.perf_counter()
         while True:
-            tr.step(batches[n % 2])
-            n += 1
+            ts = time.perf_counter()
+            tr.step(batches[len(times) % 2])
+            times.append(time.perf_counter() - ts)
             el = time.perf_counter() - t0
-            if el >= seconds or n >= 400:
+            if (el >= seconds and len(times) >= 5) or len(times) >= 400:
                 break
-        return {"value": n / el, "unit": "samples/s", "cores": cores, "kind": "port",
-                "sample": f"{n} steps of batch 1 ({O} obj x {P} pts) in {el:.1f}s: C oracle "
-                          "(OpenMP) for the 9 ops + torch-CPU mirror, fwd+bwd+AdamW"}
+        n = len(times)
+        st = sorted(times)
+        q = lambda f: st[min(n - 1, int(f * n))]   # noqa: E731
+        # one-thread figure on a short sample (a scalar port's number; bounded to a few seconds)
+        torch.set_num_threads(1)
+        pn2.set_threads(1)
+        one = []
+        t1 = time.perf_counter()
+        while len(one) < 2 or (time.perf_counter() - t1 < min(4.0, seconds / 3) and len(one) < 20):
+            ts = time.perf_counter()
+            tr.step(batches[len(one) % 2])
+            one.append(time.perf_counter() - ts)
+        one.sort()
+        host = "unknown"
+        try:
+            for ln in open("/proc/cpuinfo"):
+                if ln.startswith("model name"):
+                    host = ln.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
+        return {"value": 1.0 / q(0.5), "unit": "samples/s", "cores": cores, "kind": "port",
+                "median_s_per_sample": q(0.5), "p10_s": q(0.10), "p90_s": q(0.90), "mean_value": n / el,
+                "one_thread_value": 1.0 / one[len(one) // 2], "one_thread_steps": len(one),
+                "host": {"cpu": host, "hw_threads": os.cpu_count(), "threads_available": avail},
+                "sample": f"{n} steps of batch 1 ({O} obj x {P} pts) in {el:.1f}s after 3 warm-ups: C oracle "
+                          "(OpenMP) for the 9 ops + torch-CPU mirror, fwd+bwd+AdamW; value = 1 / median step"}
     finally:
         pointnet2_utils._ext = saved
 
@@ -207,7 +254,7 @@ def main():
     # distinct resident batches per rank, cycled (weak scaling: per-GPU work fixed)
     n_resident = 4
     batches = [synth_batch(1000 * rank + i, B, O=O, P=P, device=device) for i in range(n_resident)]
-    tr = Trainer(model, device, batches[0], args.llm_hidden, use_graph=not args.no_graph)
+    tr = Trainer(model, device, batches[0], args.llm_hidden, use_graph=not args.no_graph, accum=args.accum)
 
     # Software pipelining (msr3d_amd/train_step.py): the frozen encoder of batch k+1 runs on a
     # side stream while batch k trains.  Every timed step still encodes exactly one batch and
@@ -277,8 +324,19 @@ def main():
             return staged_step(bufs[i % 2], None)
         tr.step = step_from_host
 
-    for i in range(args.warmup):
+    for i in range(args.warmup * args.accum):
         tr.step(batches[i % n_resident], nxt(i))
+
+    # N > 1 self-checks (nobody can watch an 8-GPU run: the line has to prove it was one).
+    #   ranks_seen: an all-reduce of ones over the communicator the gradients travel on
+    ranks_seen = 1
+    if dist_on:
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        tr.dp.timing = True
+        tr.dp.comm_events.clear()
+        tr.dp.wait_events.clear()
 
     # the roofline leg needs the dominant kernel's duration, measured inside the timed region
     timed = (["msr3d_sa_fps2", "msr3d_sa_level1", "msr3d_sa_level2", "msr3d_sa_level3"]
@@ -289,9 +347,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     _lib.set_timing_sink(sink)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step spread
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
-        tr.step(batches[(args.warmup + i) % n_resident], nxt(args.warmup + i))
+        for m in range(args.accum):
+            j = (args.warmup + i) * args.accum + m
+            tr.step(batches[j % n_resident], nxt(j))
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
@@ -303,10 +366,28 @@ def main():
     if dist_on:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    comm = None
+    if dist_on:
+        tr.dp.timing = False
+        ar = [a.elapsed_time(b) for a, b in tr.dp.comm_events]          # on the communication stream
+        wt = [a.elapsed_time(b) for a, b in tr.dp.wait_events]          # compute stream waiting for it
+        # replicas must hold the same weights after the same number of steps
+        _, spread = tr.dp.replica_checksum(getattr(tr.opt, "flat_p", None))
+        stats = torch.tensor([sum(ar) / max(len(ar), 1), sum(wt) / max(len(wt), 1)], device=device,
+                             dtype=torch.float64)
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        comm = {"ranks_seen": ranks_seen, "exchange": tr.dp.exchange_mode,
+                "grad_bytes": int(tr.dp.numel * 4), "exchanges": len(ar),
+                "allreduce_ms": float(stats[0]), "allreduce_exposed_ms": float(stats[1]),
+                "replica_checksum_spread": spread}
+        assert ranks_seen == world, f"RCCL saw {ranks_seen} ranks, expected {world}"
+        assert spread == 0.0, f"replicas diverged: checksum spread {spread}"
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        value = B * world * args.steps / elapsed
+        value = B * args.accum * world * args.steps / elapsed
+        per_step = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
+        pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]   # noqa: E731
         # Per-launch durations from HIP events on the launching stream (msr3d_amd/_lib.py).
         kern_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / len(v) if v else None)
                    for k, v in sink.items()}
@@ -320,16 +401,21 @@ def main():
             first = args.warmup + (1 if pipe else 0)    # (pipelined: step i encodes batch i + 1)
             counts = [int(batches[(first + i) % n_resident]["obj_masks"].sum()) for i in range(args.steps)]
             objs_per_launch = sum(counts) / max(len(counts), 1)
+        traffic_per_obj, traffic_src = sa2_traffic_from_profiles()
         alg_flop = objs_per_launch * flop_per_obj
         achieved = alg_flop / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         line = {
             "metric": f"MSQA train samples/sec (whole node), {O} obj x {P} pts",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "ms_per_step_percentiles": {"p10": pct(0.10), "p50": pct(0.50), "p90": pct(0.90),
+                                        "note": "HIP events on the compute stream between steps, this rank"},
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs/msr3d.yaml hot path (OSE3DSituation + llm_proj, "
                                    "frozen PointNet++), synthetic ScanNet-like scenes",
-                       "objects": O, "points": P, "per_gpu_batch": B, "global_batch": B * world,
+                       "objects": O, "points": P, "per_gpu_batch": B, "global_batch": B * world * args.accum,
+                       "grad_accumulation": args.accum,
                        "llm_hidden": args.llm_hidden, "situation_type": args.situation_type,
                        "step": "fwd+bwd+allreduce+clip+AdamW, LLM excluded",
                        "hip_graph": not args.no_graph, "encoder_prefetch": args.pipeline,
@@ -344,12 +430,14 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "sa2_kernel (msr3d_sa_level level 2)",
                          "achieved": achieved, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F32_PEAK_TF,
-                         "traffic": SA2_TRAFFIC_BYTES_PER_OBJECT * objs_per_launch,
-                         "traffic_unit": "bytes/launch (PMC passes of tools/pmc_sa.sh, profiles/r01_v14_pmc_sa.txt)",
+                         "traffic": traffic_per_obj * objs_per_launch if traffic_per_obj else None,
+                         "traffic_unit": f"bytes/launch (PMC passes of tools/pmc_sa.sh, {traffic_src})",
                          "kernel_ms": k_ms, "launches": len(sink["msr3d_sa_level2"]),
                          "dtype": "f32-input MFMA (v_mfma_f32_16x16x4_f32)"},
             "kernels_ms": kern_ms,
         }
+        if comm is not None:
+            line["comm"] = comm
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
     else:

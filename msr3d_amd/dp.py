@@ -74,7 +74,9 @@ class FlatGradAllReduce:
         self.order = order
         self.offset = {}
         total = sum(p.numel() for p in order)
-        total_padded = (total + 3) // 4 * 4       # float4 kernels (fused optimiser) see whole vectors
+        # float4 kernels (fused optimiser) see whole vectors; a multiple of 32 also splits evenly over up
+        # to 8 ranks for the reduce-scatter / all-gather exchange
+        total_padded = (total + 31) // 32 * 32
         self.flat = torch.zeros(total_padded, dtype=torch.float32, device=dev)
         self.numel = total
         self.buckets = []                                   # (start, end) element ranges
@@ -106,6 +108,16 @@ class FlatGradAllReduce:
         # hold: gradient accumulation -- micro-batches before the last one must not exchange
         # (begin_micro); the buckets then launch from the LAST micro-batch's hooks, or from start()
         self.hold = False
+        # MSR3D_DP_EXCHANGE: "allreduce" (default: one all-reduce per flush) or "rs_ag" (reduce-scatter
+        # + all-gather of the same buffer: the two halves of a ring all-reduce as separate collectives,
+        # so that the 8-GPU run can A/B what RCCL does with each over the 7 xGMI links)
+        self.exchange_mode = os.environ.get("MSR3D_DP_EXCHANGE", "allreduce")
+        if self.exchange_mode not in ("allreduce", "rs_ag"):
+            raise ValueError("MSR3D_DP_EXCHANGE must be 'allreduce' or 'rs_ag'")
+        # timing (bench.py): HIP events on the communication stream around every exchange, and on the
+        # compute stream around the wait for it (= the part of the exchange that was NOT hidden)
+        self.timing = False
+        self.comm_events, self.wait_events = [], []
         self.comm_stream = torch.cuda.Stream(device=dev) if self.on_gpu else None
         # defer_comm (default): collectives are issued by finish(), after backward has been
         # enqueued -- required when backward is replayed from a HIP graph, and the safe choice
@@ -179,6 +191,19 @@ class FlatGradAllReduce:
 
     def _reduce(self, view):
         # SUM then scale: works on every backend (gloo has no AVG), one tiny launch
+        n = view.numel()
+        if self.exchange_mode == "rs_ag" and n % self.world == 0:
+            shard = n // self.world
+            rank = dist.get_rank(self.group)
+            mine = view[rank * shard:(rank + 1) * shard]
+            try:
+                dist.reduce_scatter_tensor(mine, view, op=dist.ReduceOp.SUM, group=self.group)
+            except RuntimeError:                      # a backend without reduce-scatter (gloo)
+                self.exchange_mode = "allreduce"
+                return self._reduce(view)
+            mine.mul_(1.0 / self.world)
+            dist.all_gather_into_tensor(view, mine.clone(), group=self.group)
+            return
         dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
         view.mul_(1.0 / self.world)
 
@@ -186,7 +211,14 @@ class FlatGradAllReduce:
         if self.on_gpu:
             self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm_stream):
-                self._reduce(view)
+                if self.timing:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.comm_stream)
+                    self._reduce(view)
+                    e1.record(self.comm_stream)
+                    self.comm_events.append((e0, e1))
+                else:
+                    self._reduce(view)
         else:
             self._reduce(view)
 
@@ -213,7 +245,15 @@ class FlatGradAllReduce:
     def wait(self):
         """The compute stream waits for the exchange started by start()."""
         if self.distributed and self.on_gpu:
-            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+            cur = torch.cuda.current_stream(self.device)
+            if self.timing:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_stream(self.comm_stream)
+                e1.record(cur)
+                self.wait_events.append((e0, e1))
+            else:
+                cur.wait_stream(self.comm_stream)
 
     def start(self):
         """Launch the exchange on the communication stream and return: work that does not touch
@@ -224,7 +264,8 @@ class FlatGradAllReduce:
                 # nothing is in flight and nothing is left to overlap with: ONE collective over the
                 # whole buffer (21 MB) instead of one per bucket -- fewer launches, and a ring over
                 # point-to-point xGMI links is latency-bound per call at this size
-                self._exchange(self.flat[:self.numel])
+                whole = self.exchange_mode == "rs_ag" and self.flat.numel() % max(self.world, 1) == 0
+                self._exchange(self.flat if whole else self.flat[:self.numel])
                 self._launched = [True] * len(self.buckets)
             else:
                 for b in range(len(self.buckets)):

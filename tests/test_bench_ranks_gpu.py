@@ -28,6 +28,12 @@ def test_bench_two_ranks_json_contract():
     assert j["config"]["global_batch"] == 8 and j["config"]["parallelism"] == "dp2"
     assert j["value"] > 0 and j["roofline"]["frac"] > 0
     assert "cpu_baseline" not in j                      # N=1 only
+    # the line proves it was a 2-rank run: communicator size seen through a collective, the gradient
+    # exchange timed on the communication stream, identical replicas afterwards
+    c = j["comm"]
+    assert c["ranks_seen"] == 2 and c["exchanges"] == 4 and c["allreduce_ms"] > 0
+    assert c["allreduce_exposed_ms"] >= 0 and c["replica_checksum_spread"] == 0.0
+    assert c["grad_bytes"] > 20e6 and c["exchange"] == "allreduce"
 
 
 def test_bench_multi_rank_schedule_over_rccl_with_one_rank():
@@ -44,6 +50,25 @@ def test_bench_multi_rank_schedule_over_rccl_with_one_rank():
     assert j["n_gpus"] == 1 and j["config"]["parallelism"] == "dp1"
     assert j["config"]["allreduce_hidden_behind_next_encoder"] is True and j["config"]["hip_graph"] is True
     assert j["value"] > 0 and j["roofline"]["launches"] == 6
+    assert j["comm"]["ranks_seen"] == 1 and j["comm"]["exchanges"] == 6 and j["comm"]["allreduce_ms"] > 0
+    assert {"p10", "p50", "p90"} <= set(j["ms_per_step_percentiles"])
+
+
+def test_bench_reduce_scatter_all_gather_exchange_and_accumulation():
+    """MSR3D_DP_EXCHANGE=rs_ag (the A/B switch for the 8-GPU run) on the one-rank RCCL communicator,
+    with the reference's launch shape: 4 scenes x 5 accumulated micro-batches per optimiser step."""
+    env = dict(os.environ, MSR3D_BENCH_FORCE_DIST="1", MASTER_PORT="29673", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               MSR3D_DP_EXCHANGE="rs_ag")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+                          "--batch", "4", "--accum", "5", "--no-cpu-baseline"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert j["comm"]["exchange"] == "rs_ag" and j["comm"]["exchanges"] == 3      # one per OPTIMISER step
+    assert j["config"]["grad_accumulation"] == 5 and j["config"]["global_batch"] == 20
+    assert j["roofline"]["launches"] == 15 and j["value"] > 0
 
 
 def test_bench_single_rank_json_contract():
@@ -56,5 +81,6 @@ def test_bench_single_rank_json_contract():
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in j, k
     assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
-    assert set(j["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert set(j["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample", "median_s_per_sample", "p10_s",
+                                      "p90_s", "one_thread_value", "host"}
     assert j["vs_baseline"] is None and j["data"] == "synthetic"
