@@ -493,6 +493,27 @@ int msr3d_pos_embed_bwd(int M, const float *d0, const float *d1, const float *d2
                         float *colsum1, float *colsum2, msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * The language-model side of the training step, first two pieces:
+ * the per-sequence mean cross-entropy of /root/reference/model/msr3d/msr3d.py:426-441 and the
+ * LoRA-augmented linear layer of the frozen-bf16 LLM (msr3d.py:103-112, peft LoraConfig r = 16).
+ * dtype codes: 0 = f32, 1 = f16, 2 = bf16.
+ * ------------------------------------------------------------------------- */
+
+/* loss[b] = sum_{t < T-1, targets[b][t+1] >= 0} (logsumexp(logits[b][t]) - logits[b][t][targets[b][t+1]])
+ *           / count[b],   count[b] = #{t: targets[b][t+1] >= 0}          (0 / 0 = NaN, as the reference).
+ * logits (B,T,V) in `dtype`, read in place (the shift is an index, no fp32 copy); targets (B,T) int64.
+ * Outputs: lse, tok_loss (B,T-1) f32 (saved for the backward), loss (B) f32, count (B) i32.  The
+ * sequence sums run in index order: bit-reproducible.  V * sizeof(dtype) % 16 == 0. */
+int msr3d_seq_ce_fwd(int B, int T, int V, const void *logits, int dtype, const long long *targets,
+                     float *lse, float *tok_loss, float *loss, int *count, msr3d_stream_t stream);
+
+/* dlogits (B,T,V) in `dtype`, fully written: (softmax - onehot) * grad_loss[b] / count[b] on the
+ * supervised rows, zeros elsewhere (ignored labels and the last position of every sequence). */
+int msr3d_seq_ce_bwd(int B, int T, int V, const void *logits, int dtype, const long long *targets,
+                     const float *lse, const int *count, const float *grad_loss, void *dlogits,
+                     msr3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Optimiser step of the hot path: global-norm clip + AdamW over flat buffers
  * (/root/reference/optim/build.py:7-17, trainer/leo_trainer.py:189-195,
  * optim/scheduler.py:17-25).  All buffers hold n floats (n % 4 == 0, 16-byte aligned).

@@ -34,6 +34,7 @@ SOURCES = [
     ("bn_train.hip", []),
     ("strip_gemm.hip", []),
     ("panel_gemm.hip", []),
+    ("seq_ce.hip", []),
     ("prompter_rows.hip", ["-ffp-contract=off"]),
 ]
 
