@@ -513,6 +513,22 @@ int msr3d_seq_ce_bwd(int B, int T, int V, const void *logits, int dtype, const l
                      const float *lse, const int *count, const float *grad_loss, void *dlogits,
                      msr3d_stream_t stream);
 
+/* C (M,N) = scale * (P Q^T + P2 Q2^T): bf16 operands, all k-contiguous (P (M,K), Q (N,K), P2 (M,R),
+ * Q2 (N,R); R = 0: no second pair), fp32 accumulate on v_mfma_f32_16x16x32_bf16, C bf16 (c_f32 = 0)
+ * or f32.  The LoRA forward y = x W^T + (s x A^T) B^T and its dx = dy W + (s dy B) A are this call with
+ * Q = W resp. W^T (the frozen weight is stored in both orientations).  K % 64 == 0, R % 8 == 0,
+ * leading dimensions % 8 == 0, 16-byte aligned operands. */
+int msr3d_bf16_gemm_lowrank(int M, int N, int K, int R, const void *P, int ldp, const void *Q, int ldq,
+                            const void *P2, int ldp2, const void *Q2, int ldq2, void *C, int ldc,
+                            int c_f32, float scale, msr3d_stream_t stream);
+
+/* LoRA weight gradients' token reduction: out (R, C) f32 (+)= scale * sum_m P[m][r] Q[m][c]
+ * (transpose_out: out is (C, R)); P (M, R) and Q (M, C) bf16; R in {16, 32}; `out` holds the value to
+ * add to (row splits meet by atomicAdd).  dA = s (dy B)^T x: P = dy B, Q = x;  dB = s dy^T (x A^T):
+ * P = x A^T, Q = dy, transpose_out = 1. */
+int msr3d_lora_grad(int M, int R, int C, const void *P, int ldp, const void *Q, int ldq, float *out,
+                    int transpose_out, float scale, msr3d_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Optimiser step of the hot path: global-norm clip + AdamW over flat buffers
  * (/root/reference/optim/build.py:7-17, trainer/leo_trainer.py:189-195,

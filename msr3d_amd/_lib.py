@@ -47,6 +47,9 @@ EPI = {"bias": 0, "gelu": 1, "gelubwd": 2}
 # name -> argtypes; every entry point returns int status and ends with the stream.
 _SIGNATURES = {
     "msr3d_strip_gemm_f32": [ctypes.POINTER(StripGemm), _ptr],
+    "msr3d_bf16_gemm_lowrank": [_c_int, _c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int,
+                                _ptr, _c_int, _c_int, _c_float, _ptr],
+    "msr3d_lora_grad": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_float, _ptr],
     "msr3d_seq_ce_fwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_seq_ce_bwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_gemm_multi_f32": [_c_int, ctypes.POINTER(GemmProblem), _ptr],

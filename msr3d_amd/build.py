@@ -35,6 +35,7 @@ SOURCES = [
     ("strip_gemm.hip", []),
     ("panel_gemm.hip", []),
     ("seq_ce.hip", []),
+    ("lora_linear.hip", []),
     ("prompter_rows.hip", ["-ffp-contract=off"]),
 ]
 

@@ -1,0 +1,119 @@
+"""LoRA-augmented linear layer of the frozen bf16 language model
+(/root/reference/model/msr3d/msr3d.py:103-112: peft LoraConfig(r=16, lora_alpha=16, dropout 0) on
+q/k/v/o/gate/up/down_proj; the LLM runs under bf16 autocast, msr3d.py:409-415).
+
+    y = x W^T + s (x A^T) B^T,   s = alpha / r;   W frozen, A (r, K) and B (N, r) trainable
+
+`LoRALinear` keeps the frozen weight in bf16 in BOTH orientations (W for the forward, W^T for dx:
+HBM capacity buys a transposing load path away) and fp32 masters of A / B like peft; forward and
+backward are msr3d_bf16_gemm_lowrank (bf16 MFMA, fp32 accumulate) with the low-rank term as one
+extra K step, the weight gradients msr3d_lora_grad.  GPU only (raises on CPU tensors)."""
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+PAD_R = 32          # the low-rank pair rides as one 32-wide K step
+PAD_ROWS = 128      # A / B^T padded to one output tile when they are the GEMM's Q operand
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def _gemm(M, N, K, R, P, ldp, Q, ldq, P2, ldp2, Q2, ldq2, C, ldc, c_f32, scale, dev):
+    with torch.cuda.device(dev):
+        rc = _lib.load().msr3d_bf16_gemm_lowrank(M, N, K, R, _p(P), ldp, _p(Q), ldq, _p(P2), ldp2, _p(Q2), ldq2,
+                                                 _p(C), ldc, int(c_f32), ctypes.c_float(scale),
+                                                 _lib.current_stream_ptr(dev))
+    _lib.check(rc, "msr3d_bf16_gemm_lowrank")
+
+
+class _LoRAFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lora_A, lora_B, mod):
+        K, N, r, s = mod.in_features, mod.out_features, mod.r, mod.scaling
+        x2 = x.reshape(-1, K)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        M, dev = x2.shape[0], x.device
+        # bf16 shadows of the trainable pair in the orientations the products read (tiny)
+        a_pad = torch.zeros((PAD_ROWS, K), dtype=torch.bfloat16, device=dev)
+        a_pad[:r] = lora_A.detach()
+        b2 = torch.zeros((N, PAD_R), dtype=torch.bfloat16, device=dev)
+        b2[:, :r] = lora_B.detach()
+        # u = s x A^T  (M, 128) bf16: the same kernel against the zero-padded A
+        u = torch.empty((M, PAD_ROWS), dtype=torch.bfloat16, device=dev)
+        _gemm(M, PAD_ROWS, K, 0, x2, K, a_pad, K, None, 0, None, 0, u, PAD_ROWS, False, s, dev)
+        y = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        _gemm(M, N, K, PAD_R, x2, K, mod.weight, K, u, PAD_ROWS, b2, PAD_R, y, N, False, 1.0, dev)
+        ctx.save_for_backward(x2, u, lora_A, lora_B)
+        ctx.mod = mod
+        ctx.shape = x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, u, lora_A, lora_B = ctx.saved_tensors
+        mod = ctx.mod
+        K, N, r, s = mod.in_features, mod.out_features, mod.r, mod.scaling
+        dev = dy.device
+        dy2 = dy.reshape(-1, N).to(torch.bfloat16)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        M = dy2.shape[0]
+        bt_pad = torch.zeros((PAD_ROWS, N), dtype=torch.bfloat16, device=dev)
+        bt_pad[:r] = lora_B.detach().t()
+        at2 = torch.zeros((K, PAD_R), dtype=torch.bfloat16, device=dev)
+        at2[:, :r] = lora_A.detach().t()
+        # v = s dy B  (M, 128) bf16
+        v = torch.empty((M, PAD_ROWS), dtype=torch.bfloat16, device=dev)
+        _gemm(M, PAD_ROWS, N, 0, dy2, N, bt_pad, N, None, 0, None, 0, v, PAD_ROWS, False, s, dev)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.bfloat16, device=dev)
+            _gemm(M, K, N, PAD_R, dy2, N, mod.weight_t, N, v, PAD_ROWS, at2, PAD_R, dx, K, False, 1.0, dev)
+            dx = dx.view(ctx.shape)
+        lib = _lib.load()
+        dA = torch.zeros((r, K), dtype=torch.float32, device=dev)
+        dB = torch.zeros((N, r), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _lib.current_stream_ptr(dev)
+            # dA = (s dy B)^T x = v^T x ; dB = dy^T (s x A^T) = dy^T u   (s already inside u and v)
+            rc = lib.msr3d_lora_grad(M, r, K, _p(v), PAD_ROWS, _p(x2), K, _p(dA), 0, ctypes.c_float(1.0), st)
+            _lib.check(rc, "msr3d_lora_grad")
+            rc = lib.msr3d_lora_grad(M, r, N, _p(u), PAD_ROWS, _p(dy2), N, _p(dB), 1, ctypes.c_float(1.0), st)
+            _lib.check(rc, "msr3d_lora_grad")
+        return dx, dA, dB, None
+
+
+class LoRALinear(nn.Module):
+    """nn.Linear(in_features, out_features, bias=False) with a frozen bf16 weight plus a rank-r
+    update, peft's parameter names (`lora_A.weight (r, K)`, `lora_B.weight (N, r)`) and init
+    (A: kaiming-uniform(a = sqrt 5), B: zeros)."""
+
+    def __init__(self, in_features, out_features, r=16, lora_alpha=16, device=None):
+        super().__init__()
+        if r not in (16, 32) or in_features % 64 or out_features % 64:
+            raise ValueError("r in {16, 32}; feature sizes must be multiples of 64")
+        self.in_features, self.out_features, self.r = in_features, out_features, r
+        self.scaling = lora_alpha / r
+        self.register_buffer("weight", torch.empty((out_features, in_features), dtype=torch.bfloat16, device=device))
+        self.register_buffer("weight_t", torch.empty((in_features, out_features), dtype=torch.bfloat16, device=device),
+                             persistent=False)
+        self.lora_A = nn.Linear(in_features, r, bias=False, device=device)
+        self.lora_B = nn.Linear(r, out_features, bias=False, device=device)
+        nn.init.kaiming_uniform_(self.lora_A.weight, a=math.sqrt(5))
+        nn.init.zeros_(self.lora_B.weight)
+
+    @torch.no_grad()
+    def load_base_weight(self, w):
+        """w (N, K): the frozen projection; stored in both orientations."""
+        self.weight.copy_(w.to(torch.bfloat16))
+        self.weight_t.copy_(self.weight.t())
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("LoRALinear runs on the GPU only (no CPU fallback)")
+        return _LoRAFn.apply(x.to(torch.bfloat16), self.lora_A.weight, self.lora_B.weight, self)
