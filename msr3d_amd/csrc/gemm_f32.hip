@@ -189,13 +189,7 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int bx, const in
   const bool do_colsum = (!A_KC) && a_colsum != nullptr && bx == 0;
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-#ifdef MSR3D_GEMM_ABLATE   // tools/ablate_gemm.py: flags >> 8 switches phases of the main loop off
-  const int abl = flags >> 8;
-#else
-  constexpr int abl = 0;
-#endif
   auto fetch = [&](int kt, float4 (&ra)[BM / 32], float4 (&rb)[BN / 32]) {
-    if ((abl & 1) && kt > 0) return;
     load_tile<A_KC, BM>(A, lda, m0, (kbeg + kt) * BK, M, K, a_vec, ra);
     load_tile<B_KC, BN>(B, ldb, n0, (kbeg + kt) * BK, N, K, b_vec, rb);
   };
@@ -204,12 +198,10 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int bx, const in
 #pragma unroll
       for (int p2 = 0; p2 < BM / 32; ++p2) { csum.x += ra[p2].x; csum.y += ra[p2].y; csum.z += ra[p2].z; csum.w += ra[p2].w; }
     }
-    if ((abl & 4) && buf + csum.x != 0.f) return;    // (keeps the first staging: buf 0, csum 0)
     store_tile<A_KC, BM>(As + buf * TA, ra);
     store_tile<B_KC, BN>(Bs + buf * TB, rb);
   };
   auto compute = [&](int cur) {
-    if (abl & 2) return;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       float fa[RM][4], fb[RN][4];

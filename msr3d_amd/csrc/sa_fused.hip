@@ -33,24 +33,14 @@ namespace {
 using namespace msr3d;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-#ifndef MSR3D_SA1_CPB
-#define MSR3D_SA1_CPB 2
-#endif
-#ifndef MSR3D_SA2_CPB
-#define MSR3D_SA2_CPB 2
-#endif
-#ifndef MSR3D_SA_PIPE
-#define MSR3D_SA_PIPE 0
-#endif
-#ifndef MSR3D_SA2_PADLDS
-#define MSR3D_SA2_PADLDS 0     // experiment: extra dynamic LDS bytes (forces one block per CU)
-#endif
-#ifndef MSR3D_SA2_SKEW
-#define MSR3D_SA2_SKEW 0       // experiment: delay (x s_sleep 127) of the second block a CU receives
-#endif
-#ifndef MSR3D_SA2_NG
-#define MSR3D_SA2_NG 1   // 2 = two phase-offset tile groups per block: measured 9 % SLOWER (see sa2_kernel)
-#endif
+// Tile choices, each the winner of a measured sweep (the losing variants -- register
+// pipeline pinned with sched_barrier, phase-skewed co-resident blocks, two tile groups per block,
+// forced single residency -- lived here as build switches in round 1 and are now only in the table).
+constexpr int kSa1Cpb = 2;      // centres per block, level 1: 64-row tile, 37 KB LDS, 4 blocks per CU
+constexpr int kSa2Cpb = 2;      // centres per block, level 2: 64-row tile, 75 KB LDS, 2 blocks per CU
+constexpr int kSa1Wm = 2;       // level 1 waves 2 x 2
+constexpr int kSa2Wm = 1;       // level 2 waves 1 x 4: every wave owns all 64 rows and a quarter of the
+                                // columns, so each weight fragment is fetched once per block (621 -> 537 us)
 
 // Weights arrive in MFMA-fragment order (include/msr3d_hip.h, msr3d_sa_level): the 16 columns x 16 k
 // of (slab, column tile) are ONE contiguous 1 KB block whose lane-th 16 bytes are what lane `lane`
@@ -111,40 +101,6 @@ __device__ __forceinline__ void gemm_lds_global(const float *xs, int ldx,
   const int i = lane & 15, g = lane >> 4;
   const float *xp = xs + i * ldx + 4 * g;
   const float *wp = wg + lane * 4;
-#if MSR3D_SA_PIPE
-  // explicit two-stage register pipeline, pinned: slab s+1's A (LDS) and B (L2) fragments are
-  // issued before slab s's first MFMA, so ONE wave can keep the matrix pipe busy on its own
-  constexpr int NS = KP / 16;
-  float4 a[2][RM], b[2][RN];
-#pragma unroll
-  for (int rn = 0; rn < RN; ++rn) b[0][rn] = bfirst[rn];
-#pragma unroll
-  for (int rm = 0; rm < RM; ++rm) a[0][rm] = *reinterpret_cast<const float4 *>(xp + rm * 16 * ldx);
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const int cur = s & 1, nxt = cur ^ 1;
-    if (s + 1 < NS) {
-#pragma unroll
-      for (int rn = 0; rn < RN; ++rn)
-        b[nxt][rn] = *reinterpret_cast<const float4 *>(wp + (size_t)(s + 1) * (NT * kFrag) + rn * kFrag);
-#pragma unroll
-      for (int rm = 0; rm < RM; ++rm)
-        a[nxt][rm] = *reinterpret_cast<const float4 *>(xp + rm * 16 * ldx + (s + 1) * 16);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#define MSR3D_PSTEP(c)                                                                          \
-    _Pragma("unroll") for (int rm = 0; rm < RM; ++rm)                                           \
-    _Pragma("unroll") for (int rn = 0; rn < RN; ++rn)                                           \
-        acc[rm][rn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][rm].c, b[cur][rn].c, acc[rm][rn], 0, 0, 0);
-    MSR3D_PSTEP(x)
-    MSR3D_PSTEP(y)
-    MSR3D_PSTEP(z)
-    MSR3D_PSTEP(w)
-#undef MSR3D_PSTEP
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  return;
-#endif
   float4 bcur[RN];
 #pragma unroll
   for (int rn = 0; rn < RN; ++rn) bcur[rn] = bfirst[rn];
@@ -260,10 +216,7 @@ struct Chain {
   }
 
   // out: first pooled row of this block; `groups_valid_block`: pooled rows of this block that exist
-  // `tid`: thread index inside the 256-thread tile group.  SPLIT: put a block barrier between
-  // each layer's MFMA phase and its epilogue, so that two tile groups running one barrier
-  // interval apart alternate "MFMA" and "epilogue / loader" intervals (see sa2_kernel).
-  template <bool SPLIT = false>
+  // `tid`: thread index inside the 256-thread block.
   __device__ static void run(float *bufA, float *bufB, const Pre1 &p1, const Layer &l1,
                              const Layer &l2, const Layer &l3, float *__restrict__ out,
                              int groups_valid_block, int tid, long long *tstamp = nullptr) {
@@ -281,7 +234,6 @@ struct Chain {
       load_b_first<RN2>(l2.w + (wn * RN2) * kFrag, lane, b2);
       load_affine<RN2>(l2.scale + wn * RN2 * 16, l2.shift + wn * RN2 * 16, lane, sc2, sh2);
       if (tstamp) tstamp[0] = clock64();
-      if (SPLIT) __syncthreads();
       store_bn_relu_lds<RM, RN1>(acc, p1.sc, p1.sh, bufB + row0 * LDB + col0, LDB, lane);
     }
     __syncthreads();
@@ -294,7 +246,6 @@ struct Chain {
       load_b_first<RN3>(l3.w + (wn * RN3) * kFrag, lane, b3);
       load_affine<RN3>(l3.scale + wn * RN3 * 16, l3.shift + wn * RN3 * 16, lane, sc3, sh3);
       if (tstamp) tstamp[2] = clock64();
-      if (SPLIT) __syncthreads();
       store_bn_relu_lds<RM, RN2>(acc, sc2, sh2, bufA + row0 * LDA + col0, LDA, lane);
     }
     __syncthreads();
@@ -305,7 +256,6 @@ struct Chain {
       zero_acc(acc);
       gemm_lds_global<RM, RN3, N2, N3 / 16>(bufA + row0 * LDA, LDA, l3.w + (col0 / 16) * kFrag, acc, lane, b3);
       if (tstamp) tstamp[4] = clock64();
-      if (SPLIT) __syncthreads();
       const int g0 = wm * (RM / GT);            // first pooled row owned by this wave
       int gv = groups_valid_block - g0;
       store_bn_relu_groupmax<RM, RN3, GT>(acc, sc3, sh3, out + (size_t)g0 * N3 + col0, N3, gv, lane);
@@ -351,21 +301,13 @@ constexpr int kNS = 32;   // neighbours per centre in both query levels (configs
 // CPB centres per block: 2 -> 64-row tile, 37 KB of LDS and (capped) <= 128 registers: four blocks per
 // CU, so one block's gather phase hides under the others' MFMA phases (128- / 256-row tiles: 297 / 358 us
 // against 279; waves 1 x 4: 300 us).
-#ifndef MSR3D_SA1_WM
-#define MSR3D_SA1_WM 2
-#endif
 template <int CPB> struct Sa1 {
-  using C = Chain<CPB * kNS, 16, 64, 64, 128, kNS, MSR3D_SA1_WM, 4 / MSR3D_SA1_WM>;
+  using C = Chain<CPB * kNS, 16, 64, 64, 128, kNS, kSa1Wm, 4 / kSa1Wm>;
 };
 
-#ifndef MSR3D_SA1_WAVES
-#define MSR3D_SA1_WAVES 4     // 128-register cap: the 37 KB of LDS allow four blocks per CU, 136 registers did not
-#endif
+// 128-register cap: the 37 KB of LDS allow four blocks per CU, 136 registers did not
 template <int CPB>
-__global__ __launch_bounds__(256)
-#if MSR3D_SA1_WAVES
-__attribute__((amdgpu_waves_per_eu(MSR3D_SA1_WAVES, MSR3D_SA1_WAVES)))
-#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void sa1_kernel(int n, int m, const float *__restrict__ pts,
                                                   const float *__restrict__ new_xyz,
                                                   const int *__restrict__ ball_idx, Layer l1,
@@ -425,30 +367,12 @@ void sa1_kernel(int n, int m, const float *__restrict__ pts,
 // (b, m, 3).  Block = 4 centres x 32 neighbours.  MLP 131 -> 128 -> 128 -> 256 with the
 // K order [feat(128), dxyz(3), 0 x13].  out: (b, m, 256).
 // =================================================================================
-#ifndef MSR3D_SA2_WM
-#define MSR3D_SA2_WM 1     // waves as 1 x 4: every wave owns all 64 rows (RM = 4) and a quarter of the columns,
-#endif                     // so each weight fragment is fetched once per block: 621 -> 537 us (tools/ab_sa2.py)
 template <int CPB> struct Sa2 {
-  using C = Chain<CPB * kNS, 144, 128, 128, 256, kNS, MSR3D_SA2_WM, 4 / MSR3D_SA2_WM>;
+  using C = Chain<CPB * kNS, 144, 128, 128, 256, kNS, kSa2Wm, 4 / kSa2Wm>;
 };
-#if MSR3D_SA2_SKEW
-__device__ unsigned g_cu_tickets[4096];
-#endif
 
-// NG = 2: the block holds TWO independent 64-row tiles (8 waves, two per SIMD).  Both tile groups
-// run the same program -- [stage] [ball query] [gather] [MFMA 1] [epi 1] [MFMA 2] [epi 2] [MFMA 3]
-// [epi 3], a block barrier after each -- but group 1 starts one barrier interval late (one extra
-// leading barrier for group 1, one extra trailing barrier for group 0).  From then on the groups
-// alternate: while one issues a layer's MFMAs, the other runs its epilogue / loader interval on
-// the same SIMDs' VALU, LDS and memory pipes, instead of both hitting the matrix pipe together
-// and both leaving it idle together (identical blocks sharing a CU march in lockstep; measured:
-// 64-row tiles at 2 blocks/CU timed exactly like 128-row tiles at 1 block/CU).
-// RESULT (MI355X, 960 objects): NG = 2 runs 693 us vs 637 us for NG = 1 at 2 blocks/CU -- with only
-// one group in its MFMA interval at a time each SIMD has a single wave to cover the B-fragment
-// load latency (RM = 2: one 16-byte load per 8 MFMAs), which costs more than the hidden
-// epilogues give back.  Kept selectable (MSR3D_SA2_NG) as a measured dead end; default NG = 1.
-template <int CPB, int NG>
-__global__ __launch_bounds__(256 * NG) void sa2_kernel(int n, int m, float radius2,
+template <int CPB>
+__global__ __launch_bounds__(256) void sa2_kernel(int n, int m, float radius2,
                                                        const float *__restrict__ xyz,
                                                        const float *__restrict__ feat,
                                                        const float *__restrict__ new_xyz, Layer l1,
@@ -456,36 +380,23 @@ __global__ __launch_bounds__(256 * NG) void sa2_kernel(int n, int m, float radiu
                                                        int *__restrict__ dbg_idx,
                                                        const unsigned char *__restrict__ valid) {
   if (valid && !valid[blockIdx.y]) return;
-#if MSR3D_SA2_SKEW
-  if (threadIdx.x == 0) {
-    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);      // HW_REG_XCC_ID[3:0]
-    const unsigned key = (xcc << 8) | ((hw >> 8) & 0xffu);                // (xcc, se, sh, cu)
-    if (atomicAdd(&g_cu_tickets[key], 1u) == 1u)
-      for (int t = 0; t < MSR3D_SA2_SKEW; ++t) __builtin_amdgcn_s_sleep(127);
-  }
-  __syncthreads();
-#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using Chain2 = typename Sa2<CPB>::C;
   constexpr int TM = CPB * kNS;
-  constexpr int GROUP_FLOATS = Chain2::LDS_FLOATS + 4 * kNS + 16 + 64 * 3;
-  const int gid = NG > 1 ? (int)(threadIdx.x >> 8) : 0;
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-  float *bufA = reinterpret_cast<float *>(smem) + (size_t)gid * GROUP_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float *bufA = reinterpret_cast<float *>(smem);
   float *bufB = bufA + TM * Chain2::LDA;
   int *nbr = reinterpret_cast<int *>(bufB + TM * Chain2::LDB);   // [CPB][32]
   float *ctr = reinterpret_cast<float *>(nbr + 4 * kNS);          // [4][4]
   float *sx = ctr + 16;                                            // [n][3], n <= 64
 
-  const int obj = blockIdx.y, c0 = (blockIdx.x * NG + gid) * CPB;   // may be >= m: barriers still run
-#ifdef MSR3D_PROF      // phase stamps for tools/prof_sa2.py (build with -DMSR3D_PROF, NG = 1)
+  const int obj = blockIdx.y, c0 = blockIdx.x * CPB;
+#ifdef MSR3D_PROF      // phase stamps for tools/prof_sa2.py (build with -DMSR3D_PROF)
   long long ts[4];
   ts[0] = clock64();
 #endif
   typename Chain2::Pre1 pre;
   Chain2::preload(l1, pre, tid);     // layer-1 weights/affine in flight during the loader phase
-  if (NG > 1 && gid == 1) __syncthreads();          // the one-interval phase offset
   if (tid < n * 3) sx[tid] = xyz[(size_t)obj * n * 3 + tid];
   if (tid >= 192 && tid < 192 + 3 * CPB) {
     const int t = tid - 192, w = t / 3, c = t - w * 3;
@@ -537,8 +448,7 @@ __global__ __launch_bounds__(256 * NG) void sa2_kernel(int n, int m, float radiu
 #ifdef MSR3D_PROF
   ts[2] = clock64();
   long long tl[5];
-  Chain2::template run<(NG > 1)>(bufA, bufB, pre, l1, l2, l3, out + ((size_t)obj * m + c0) * 256,
-                                 groups, tid, tl);
+  Chain2::run(bufA, bufB, pre, l1, l2, l3, out + ((size_t)obj * m + c0) * 256, groups, tid, tl);
   ts[3] = clock64();
   if (dbg_idx && tid == 0) {   // PROF build: the debug buffer carries phase durations instead
     int *o = dbg_idx + ((size_t)obj * gridDim.x + blockIdx.x) * 8;
@@ -552,10 +462,8 @@ __global__ __launch_bounds__(256 * NG) void sa2_kernel(int n, int m, float radiu
     o[7] = (int)(ts[3] - tl[4]);   // layer 3 epilogue
   }
 #else
-  Chain2::template run<(NG > 1)>(bufA, bufB, pre, l1, l2, l3, out + ((size_t)obj * m + c0) * 256,
-                                 groups, tid);
+  Chain2::run(bufA, bufB, pre, l1, l2, l3, out + ((size_t)obj * m + c0) * 256, groups, tid);
 #endif
-  if (NG > 1 && gid == 0) __syncthreads();          // matches group 1's leading barrier
 }
 
 // =================================================================================
@@ -697,7 +605,7 @@ int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pt
     if (!dbg_ball_idx) return MSR3D_EINVAL;
     if ((e = launch_ball_query(b, n, 6, m, r2, kNS, new_xyz, pts, dbg_ball_idx, st, valid)) != hipSuccess)
       return (int)e;
-    constexpr int CPB = MSR3D_SA1_CPB;
+    constexpr int CPB = kSa1Cpb;
     const size_t lds = sizeof(float) * Sa1<CPB>::C::LDS_FLOATS;
     if ((e = allow_lds(sa1_kernel<CPB>, lds)) != hipSuccess) return (int)e;
     dim3 grid((m + CPB - 1) / CPB, b);
@@ -708,18 +616,11 @@ int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pt
     // pts = xyz (b,n,3), feat (b,n,128); dims = {131, 128, 128, 256}
     if (!(dims[0] == 131 && dims[1] == 128 && dims[2] == 128 && dims[3] == 256)) return MSR3D_EINVAL;
     if (!pts || !feat || !new_xyz || n <= 0 || n > 64 || m <= 0) return MSR3D_EINVAL;
-    constexpr int CPB = MSR3D_SA2_CPB, NG = MSR3D_SA2_NG;
-    const size_t lds = sizeof(float) * NG * (Sa2<CPB>::C::LDS_FLOATS + 4 * kNS + 16 + 64 * 3) + MSR3D_SA2_PADLDS;
-    if ((e = allow_lds(sa2_kernel<CPB, NG>, lds)) != hipSuccess) return (int)e;
-#if MSR3D_SA2_SKEW
-    {
-      void *sym = nullptr;
-      if ((e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g_cu_tickets))) != hipSuccess) return (int)e;
-      if ((e = hipMemsetAsync(sym, 0, sizeof(unsigned) * 4096, st)) != hipSuccess) return (int)e;
-    }
-#endif
-    dim3 grid((m + CPB * NG - 1) / (CPB * NG), b);
-    sa2_kernel<CPB, NG><<<grid, 256 * NG, lds, st>>>(n, m, r2, pts, feat, new_xyz,
+    constexpr int CPB = kSa2Cpb;
+    const size_t lds = sizeof(float) * (Sa2<CPB>::C::LDS_FLOATS + 4 * kNS + 16 + 64 * 3);
+    if ((e = allow_lds(sa2_kernel<CPB>, lds)) != hipSuccess) return (int)e;
+    dim3 grid((m + CPB - 1) / CPB, b);
+    sa2_kernel<CPB><<<grid, 256, lds, st>>>(n, m, r2, pts, feat, new_xyz,
                                                      make_layer(params1, 128, 144),
                                                      make_layer(params2, 128, 128),
                                                      make_layer(params3, 256, 128), out, dbg_ball_idx,

@@ -132,7 +132,13 @@ def test_train_step_through_the_schedule_in_a_graph():
         step = HotPathTrainStep(model, opt, dp, loss_fn, batches[0], use_graph=use_graph)
         step.capture(batches[0])
         losses = [float(step(b)) for b in batches]
-        results.append((losses, opt.flat_p.clone()))
+        results.append((losses, {k: v.detach().clone() for k, v in model.named_parameters() if v.requires_grad}))
     (l0, p0), (l1, p1) = results
     assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
-    assert rel(p1, p0) < 1e-5
+    # split-K sums meet by atomicAdd (arrival order differs run to run) and AdamW's normalisation turns
+    # a noise-only gradient (w_ks.bias: mathematically zero) into O(lr) steps of random sign: exclude it,
+    # compare the rest at 3 lr (as tests/test_train_step_gpu.py does)
+    for k in p0:
+        if k.endswith("w_ks.bias"):
+            continue
+        assert torch.allclose(p0[k], p1[k], rtol=1e-3, atol=3e-3), k

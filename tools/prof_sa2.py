@@ -1,7 +1,7 @@
 """Phase timing of sa2_kernel from an MSR3D_PROF build (clock64 stamps written to the debug
 buffer).  Build, from msr3d_amd/csrc:
-    for c in 2 4; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I ../../include -ffp-contract=off \\
-        -DMSR3D_PROF -DMSR3D_SA2_CPB=$c -shared -o ../../tools/_prof/libprof_cpb$c.so sa_fused.hip; done
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I ../../include -ffp-contract=off \\
+        -DMSR3D_PROF -shared -o ../../tools/_prof/libprof_cpb2.so sa_fused.hip
 """
 import ctypes
 import os
