@@ -393,6 +393,20 @@ int msr3d_project_scatter_bf16(int B, int T, int n_scene, int E, int K, const lo
                                void *inputs_embeds, long long *attention_mask, int *map_ws,
                                int *count_out, msr3d_stream_t stream);
 
+/* msr3d_sa_level on the bf16 matrix pipe at fp32 accuracy (csrc/sa_split.hip): every fp32 operand is
+ * split exactly into three bf16 terms and a product is the six bf16 MFMA products above 2^-24 of it,
+ * summed in the fp32 accumulator -- error per product below one fp32 rounding.  Same semantics and
+ * outputs as msr3d_sa_level (same index ops); the parameters arrive pre-split:
+ *   wK      [K/32][N/16][3][64][8] bf16: plane p, lane 16 g + i, element j = W_p[16 t + i][32 s + 8 g + j]
+ *           (K padded with zeros to a multiple of 32; level 2: 160, K order [features, xyz]),
+ *           W = W_0 + W_1 + W_2 with W_0 = bf16(W), W_1 = bf16(W - W_0), W_2 = bf16(W - W_0 - W_1);
+ *   affineK [2][N] f32: scale, shift (BN(eval) folded).
+ * level: 2 (the dominant kernel; 1 and 3 stay on msr3d_sa_level). */
+int msr3d_sa_level_split(int level, int b, int n, int m, float radius, const float *pts, const float *feat,
+                         const float *new_xyz, const void *w1, const float *affine1, const void *w2,
+                         const float *affine2, const void *w3, const float *affine3, float *out,
+                         int *dbg_ball_idx, const unsigned char *valid, msr3d_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * The trainable part as a fixed schedule of fused launches (msr3d_amd/fused_model.py):
  * strip GEMMs with the row-local work of /root/reference/modules/layers/transformers.py:250-251,
@@ -453,6 +467,8 @@ typedef struct msr3d_gemm_problem {
   float beta;                   /* 0 or 1; K-splits meet by atomicAdd, so with beta = 1 C holds the value
                                    to add to (e.g. zeros from msr3d_step_begin, or a residual gradient) */
   float *colsum;                /* a_kc = 0, beta = 1 only: colsum[m] += sum_k a(m,k)  (bias gradient) */
+  int single_run;               /* 1: never split K (no atomics: bit-reproducible, every output row
+                                   independent of the others in the launch) */
 } msr3d_gemm_problem_t;
 
 /* Up to MSR3D_GEMM_MULTI_MAX independent products in one launch (dx, dW + db of a linear layer and

@@ -37,7 +37,7 @@ class GemmProblem(ctypes.Structure):
     """msr3d_gemm_problem_t (include/msr3d_hip.h)."""
     _fields_ = [("a_kc", _c_int), ("b_kc", _c_int), ("M", _c_int), ("N", _c_int), ("K", _c_int),
                 ("A", _ptr), ("lda", _c_int), ("B", _ptr), ("ldb", _c_int), ("C", _ptr), ("ldc", _c_int),
-                ("bias", _ptr), ("beta", _c_float), ("colsum", _ptr)]
+                ("bias", _ptr), ("beta", _c_float), ("colsum", _ptr), ("single_run", _c_int)]
 
 
 GEMM_MULTI_MAX = 4
@@ -50,6 +50,7 @@ _SIGNATURES = {
     "msr3d_bf16_gemm_lowrank": [_c_int, _c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int,
                                 _ptr, _c_int, _c_int, _c_float, _ptr],
     "msr3d_lora_grad": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_float, _ptr],
+    "msr3d_sa_level_split": [_c_int, _c_int, _c_int, _c_int, _c_float] + [_ptr] * 13,
     "msr3d_seq_ce_fwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_seq_ce_bwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_gemm_multi_f32": [_c_int, ctypes.POINTER(GemmProblem), _ptr],

@@ -24,6 +24,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-a
 SOURCES = [
     ("pn2_ops.hip", ["-ffp-contract=off"]),
     ("sa_fused.hip", ["-ffp-contract=off"]),
+    ("sa_split.hip", ["-ffp-contract=off"]),
     ("gemm_f32.hip", []),
     ("attn_spatial.hip", []),
     ("optim_flat.hip", ["-ffp-contract=off"]),

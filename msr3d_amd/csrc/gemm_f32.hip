@@ -825,7 +825,7 @@ int msr3d_gemm_multi_f32(int n, const msr3d_gemm_problem_t *pr, msr3d_stream_t s
   const bool use_panel = !no_panel && (live == 1 || panel_all);
   for (int j = 0; j < n; ++j) {
     if (pr[j].M <= 0 || pr[j].N <= 0) continue;
-    if (use_panel && msr3d::panel_eligible(pr[j])) {
+    if ((use_panel || pr[j].single_run) && msr3d::panel_eligible(pr[j])) {
       int tiles, stages;
       msr3d::panel_shape(pr[j], &tiles, &stages);
       units += (long long)tiles * stages;
@@ -849,7 +849,7 @@ int msr3d_gemm_multi_f32(int n, const msr3d_gemm_problem_t *pr, msr3d_stream_t s
     if (q.M < 0 || q.N < 0 || q.K < 0 || q.lda <= 0 || q.ldb <= 0 || q.ldc <= 0) return MSR3D_EINVAL;
     if (q.M == 0 || q.N == 0) continue;
     if (!q.A || !q.B || !q.C) return MSR3D_EINVAL;
-    if (use_panel && msr3d::panel_eligible(q)) {
+    if ((use_panel || q.single_run) && msr3d::panel_eligible(q)) {
       // long reductions and weight gradients: one K chunk per workgroup, operands staged once
       // (panel_gemm.hip)
       msr3d::PanelP pp;

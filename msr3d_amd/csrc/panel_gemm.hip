@@ -298,7 +298,7 @@ int panel_plan(const msr3d_gemm_problem_t &q, int stages_per_run, PanelP *out, h
   // K runs of ~stages_per_run stages (the caller balances the problems of a launch): every extra run
   // costs the tile's size again in atomics, so never shorter than two stages
   int spw = stages_per_run < 2 ? 2 : stages_per_run;
-  if (spw > stages) spw = stages;
+  if (spw > stages || q.single_run) spw = stages;
   int gz = (stages + spw - 1) / spw;
   spw = (stages + gz - 1) / gz;                      // even the runs out
   p.spw = spw;

@@ -60,7 +60,8 @@ def can_fuse(net, pts):
     return True
 
 
-def _pack_layer(conv, bn, kp, feat_first):
+def _pack_rows(conv, bn, kp, feat_first):
+    """(weight rows (N, kp) in the kernels' K order, zero-padded; scale (N); shift (N))."""
     w = conv.weight.detach().reshape(conv.out_channels, conv.in_channels).float()
     n, k = w.shape
     wp = w.new_zeros((n, kp))
@@ -77,10 +78,34 @@ def _pack_layer(conv, bn, kp, feat_first):
     else:
         scale = torch.ones(n, device=w.device)
         shift = conv.bias.detach().float() if conv.bias is not None else torch.zeros(n, device=w.device)
+    return wp, scale, shift
+
+
+def _pack_layer(conv, bn, kp, feat_first):
+    wp, scale, shift = _pack_rows(conv, bn, kp, feat_first)
+    n = wp.shape[0]
     # MFMA-fragment order (include/msr3d_hip.h): [slab s][column tile t][lane = 16 g + i][j] =
     # W[16 t + i][16 s + 4 g + j] -- one contiguous 1 KB block per (slab, tile)
     frag = wp.view(n // 16, 16, kp // 16, 4, 4).permute(2, 0, 3, 1, 4)      # (s, t, g, i, j)
     return torch.cat([frag.reshape(-1), scale, shift]).contiguous()
+
+
+_KP0_SPLIT = (32, 160, 288)
+
+
+def _pack_layer_split(conv, bn, kp, feat_first):
+    """Parameters for msr3d_sa_level_split: the weight split exactly into three bf16 terms, packed in
+    16x16x32 MFMA-fragment order, and the folded BN affine (fp32)."""
+    flat = _pack_rows(conv, bn, kp, feat_first)
+    wp, scale, shift = flat
+    n = wp.shape[0]
+    w0 = wp.to(torch.bfloat16)
+    r1 = wp - w0.float()
+    w1 = r1.to(torch.bfloat16)
+    w2 = (r1 - w1.float()).to(torch.bfloat16)
+    planes = torch.stack([w0, w1, w2])                                   # (3, n, kp)
+    frag = planes.view(3, n // 16, 16, kp // 32, 4, 8).permute(3, 1, 0, 4, 2, 5)   # (s, t, p, g, i, j)
+    return frag.contiguous().reshape(-1), torch.cat([scale, shift]).contiguous()
 
 
 def _state_key(net):
@@ -101,7 +126,11 @@ def get_plan(net):
             packed.append(_pack_layer(conv, bn, kp, feat_first=(j == 0 and li > 0)))
         levels.append(packed)
     dims = [(ctypes.c_int * 4)(*d) for d in _LEVEL_DIMS]
-    plan = {"key": key, "levels": levels, "dims": dims}
+    # level 2 (the dominant kernel) also in split form: three bf16 planes for the bf16 matrix pipe
+    _, pairs2 = _level_spec(net.encoder[1])
+    split2 = [_pack_layer_split(conv, bn, _KP0_SPLIT[1] if j == 0 else conv.in_channels, feat_first=(j == 0))
+              for j, (conv, bn) in enumerate(pairs2)]
+    plan = {"key": key, "levels": levels, "dims": dims, "split2": split2}
     net._fused_plan = plan
     return plan
 
@@ -111,6 +140,23 @@ def _p(t):
 
 
 PAD_VALUE = 1.0       # the dataset wrapper's padding cloud (dataset_wrapper.py:156-158)
+
+# Matrix-pipe arithmetic of the level-2 SharedMLP (the dominant kernel):
+#   "split"  every fp32 operand split exactly into three bf16 terms, six bf16 MFMA products per product,
+#            fp32 accumulate (csrc/sa_split.hip): error per product below one fp32 rounding
+#   "f32"    f32-input MFMA (csrc/sa_fused.hip): exact fp32 fma chains
+# MSR3D_SA_MMA=f32|split or set_sa_mma(); see DESIGN.md §4.1 for the measured accuracy of both.
+import os as _os
+_sa_mma = [_os.environ.get("MSR3D_SA_MMA", "split")]
+if _sa_mma[0] not in ("f32", "split"):
+    raise ValueError("MSR3D_SA_MMA must be 'f32' or 'split'")
+
+
+def set_sa_mma(name):
+    if name not in ("f32", "split"):
+        raise ValueError("sa mma must be 'f32' or 'split'")
+    prev, _sa_mma[0] = _sa_mma[0], name
+    return prev
 
 
 def padding_feature(net, n_points, device):
@@ -167,9 +213,16 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
                                     _p(L[0][2]), _p(feat1), _p(ball1), _p(vmask), st)
         _lib.check(rc, "msr3d_sa_level(1)")
         with _lib.kernel_timer("msr3d_sa_level2"):
-            rc = lib.msr3d_sa_level(2, b, m1, m2, ctypes.c_float(sa2.groupers[0].radius), _p(new1),
-                                    _p(feat1), _p(new2), plan["dims"][1], _p(L[1][0]), _p(L[1][1]),
-                                    _p(L[1][2]), _p(feat2), _p(dbg.get("ball2")), _p(vmask), st)
+            if _sa_mma[0] == "split":
+                S = plan["split2"]
+                rc = lib.msr3d_sa_level_split(2, b, m1, m2, ctypes.c_float(sa2.groupers[0].radius), _p(new1),
+                                              _p(feat1), _p(new2), _p(S[0][0]), _p(S[0][1]), _p(S[1][0]),
+                                              _p(S[1][1]), _p(S[2][0]), _p(S[2][1]), _p(feat2),
+                                              _p(dbg.get("ball2")), _p(vmask), st)
+            else:
+                rc = lib.msr3d_sa_level(2, b, m1, m2, ctypes.c_float(sa2.groupers[0].radius), _p(new1),
+                                        _p(feat1), _p(new2), plan["dims"][1], _p(L[1][0]), _p(L[1][1]),
+                                        _p(L[1][2]), _p(feat2), _p(dbg.get("ball2")), _p(vmask), st)
         _lib.check(rc, "msr3d_sa_level(2)")
         with _lib.kernel_timer("msr3d_sa_level3"):
             rc = lib.msr3d_sa_level(3, b, m2, 1, ctypes.c_float(0.0), _p(new2), _p(feat2),
@@ -182,14 +235,21 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
         pooled = torch.where(valid.reshape(b, 1), pooled, torch.zeros((), device=dev))
     # `fc` (/root/reference/modules/layers/pointnet.py:52-63) on the f32-MFMA token GEMM: the vendor
     # library's heuristic kernel was the last foreign launch of the encoder
-    from .. import hipops
     fc = net.fc
     n_out, k_in = fc.weight.shape
     res = out if (out is not None and vmask is None) else torch.empty((b, n_out), dtype=torch.float32, device=dev)
     if res.shape != (b, n_out) or not res.is_contiguous() or res.dtype != torch.float32:
         raise ValueError("out must be a contiguous (b, %d) float32 tensor" % n_out)
-    # (ordered K-splits: an object's feature must not depend on which other objects share the launch)
-    hipops._gemm(True, True, b, n_out, k_in, pooled, k_in, fc.weight, k_in, res, n_out, bias=fc.bias, ordered=True)
+    # one K run per tile on the panel kernel: no K-split, so an object's feature does not depend on
+    # which other objects share the launch (and no atomics: bit-reproducible)
+    arr = (_lib.GemmProblem * 1)()
+    q = arr[0]
+    q.a_kc, q.b_kc, q.M, q.N, q.K = 1, 1, b, n_out, k_in
+    q.A, q.lda, q.B, q.ldb = pooled.data_ptr(), k_in, fc.weight.data_ptr(), k_in
+    q.C, q.ldc, q.bias, q.beta, q.single_run = res.data_ptr(), n_out, fc.bias.data_ptr(), 0.0, 1
+    with torch.cuda.device(dev):
+        rc = lib.msr3d_gemm_multi_f32(1, arr, _lib.current_stream_ptr(dev))
+    _lib.check(rc, "msr3d_gemm_multi_f32")
     if vmask is not None:
         res = torch.where(valid.reshape(b, 1), res, pad_feat)
         if out is not None:
