@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # MI355X_MICROARCH.md §HBM).  None if no summary travels with the tree.
 
 
-def sa2_traffic_from_profiles():
+def sa2_traffic_from_profiles(kernel="sa2_kernel"):
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_sa*.txt")), key=os.path.getmtime)
@@ -45,7 +45,7 @@ def sa2_traffic_from_profiles():
             if not line.startswith((" ", "#")) and line.strip():
                 block = line.strip()
             m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.eE+]+)", line)
-            if m and block and block.startswith("sa2_kernel"):
+            if m and block and block.startswith(kernel):
                 vals[m.group(1)] = float(m.group(2))
         if len(vals) == 2:
             return (vals["FETCH_SIZE"] * 2 + vals["WRITE_SIZE"]) * 1024 / 960.0, os.path.relpath(f, ROOT)
@@ -53,6 +53,8 @@ def sa2_traffic_from_profiles():
 
 
 MFMA_F32_PEAK_TF = 157.3       # f32-input MFMA dense peak
+MFMA_BF16_PEAK_TF = 2500.0     # bf16 MFMA dense peak (MI355X_MICROARCH.md)
+SPLIT_PRODUCTS = 6             # bf16 MFMA products per fp32-accurate product (csrc/sa_split.hip)
 O, P = 60, 1024                # objects per scene, points per object (configs/msr3d.yaml:60,153)
 
 
@@ -401,9 +403,34 @@ def main():
             first = args.warmup + (1 if pipe else 0)    # (pipelined: step i encodes batch i + 1)
             counts = [int(batches[(first + i) % n_resident]["obj_masks"].sum()) for i in range(args.steps)]
             objs_per_launch = sum(counts) / max(len(counts), 1)
-        traffic_per_obj, traffic_src = sa2_traffic_from_profiles()
+        from msr3d_amd.pointnet2 import fused as _fused
+        split = _fused._sa_mma[0] == "split"
+        traffic_per_obj, traffic_src = sa2_traffic_from_profiles("sa2_split_kernel" if split else "sa2_kernel")
         alg_flop = objs_per_launch * flop_per_obj
         achieved = alg_flop / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        if split:
+            # Each fp32 operand is three bf16 terms and each product six bf16 MFMA products
+            # (sa_split.hip), so the bf16 pipe delivers at most 2500 / 6 = 416.7 TFLOP/s of fp32-
+            # accurate work: that is the roof the ALGORITHMIC rate is priced against.  Executed
+            # matrix-pipe work (six products, K padded 131 -> 160) is reported beside it.
+            peak = MFMA_BF16_PEAK_TF / SPLIT_PRODUCTS
+            executed = objs_per_launch * 512 * (160 * 128 + 128 * 128 + 128 * 256) * 2 * SPLIT_PRODUCTS
+            roof = {"bound": "mfma", "kernel": "sa2_split_kernel (msr3d_sa_level_split level 2)",
+                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                    "peak_note": "bf16 dense MFMA peak 2500 TFLOP/s / 6 products per fp32-accurate product",
+                    "mfma_executed_tflops": executed / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
+                    "mfma_pipe_frac": (executed / (k_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF) if k_ms > 0 else 0.0,
+                    "vs_f32_mfma_peak": achieved / MFMA_F32_PEAK_TF,
+                    "dtype": "f32 operands as 3 bf16 terms, 6 x v_mfma_f32_16x16x32_bf16 per product, "
+                             "fp32 accumulate (fp32 accuracy; MSR3D_SA_MMA=f32 selects the f32-input MFMA kernel)"}
+        else:
+            roof = {"bound": "mfma", "kernel": "sa2_kernel (msr3d_sa_level level 2)",
+                    "achieved": achieved, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": achieved / MFMA_F32_PEAK_TF,
+                    "dtype": "f32-input MFMA (v_mfma_f32_16x16x4_f32)"}
+        roof.update({"traffic": traffic_per_obj * objs_per_launch if traffic_per_obj else None,
+                     "traffic_unit": f"bytes/launch (PMC passes of tools/pmc_sa.sh, {traffic_src})",
+                     "kernel_ms": k_ms, "launches": len(sink["msr3d_sa_level2"])})
         line = {
             "metric": f"MSQA train samples/sec (whole node), {O} obj x {P} pts",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -411,7 +438,9 @@ def main():
             "ms_per_step_percentiles": {"p10": pct(0.10), "p50": pct(0.50), "p90": pct(0.90),
                                         "note": "HIP events on the compute stream between steps, this rank"},
             "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (level-2 SharedMLP: bf16x3 split on the bf16 MFMA, fp32 accuracy)" if split else "f32",
+            "data": "synthetic",
             "config": {"workload": "configs/msr3d.yaml hot path (OSE3DSituation + llm_proj, "
                                    "frozen PointNet++), synthetic ScanNet-like scenes",
                        "objects": O, "points": P, "per_gpu_batch": B, "global_batch": B * world * args.accum,
@@ -427,13 +456,7 @@ def main():
                                   "pinned host memory, copied over PCIe every step" if args.host_inputs
                                   else "resident in HBM"),
                        "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "sa2_kernel (msr3d_sa_level level 2)",
-                         "achieved": achieved, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F32_PEAK_TF,
-                         "traffic": traffic_per_obj * objs_per_launch if traffic_per_obj else None,
-                         "traffic_unit": f"bytes/launch (PMC passes of tools/pmc_sa.sh, {traffic_src})",
-                         "kernel_ms": k_ms, "launches": len(sink["msr3d_sa_level2"]),
-                         "dtype": "f32-input MFMA (v_mfma_f32_16x16x4_f32)"},
+            "roofline": roof,
             "kernels_ms": kern_ms,
         }
         if comm is not None:

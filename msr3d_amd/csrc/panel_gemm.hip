@@ -278,8 +278,9 @@ bool panel_eligible(const msr3d_gemm_problem_t &q) {
   if (!q.a_kc && q.lda < q.M) return false;
   if (q.beta != 0.f && q.beta != 1.f) return false;
   if (q.colsum && (q.a_kc || q.beta != 1.f)) return false;
-  // worth it only where the reduction is long enough to stage
-  return (long long)q.M * q.N * q.K >= (1ll << 24);
+  // worth it only where the reduction is long enough to stage -- unless the caller asked for the one-run
+  // schedule (results must not depend on how many rows share the launch)
+  return q.single_run || (long long)q.M * q.N * q.K >= (1ll << 24);
 }
 
 void panel_shape(const msr3d_gemm_problem_t &q, int *tiles, int *stages) {

@@ -17,15 +17,23 @@
 // path (2e-5 rel-L2 on features) is unchanged.  6 MFMAs x 16 cycles replace 8 x 32 per 16x16x32
 // block of products: 2.67x less matrix-pipe time.
 //
-// What moves instead is data: three bf16 planes are 6 bytes per operand element instead of 4, and
-// the matrix pipe now consumes them 2.67x faster, so the weight stream out of L2 (every block reads
-// all of a level's weights) becomes the co-limiter: ~32 B/clk/CU at the full MFMA rate, which takes
-// >= 8 KB of loads in flight per wave (tools/probe/l2_stream.hip: 10 B/clk/CU at one load in flight
-// per wave, 31-40 at eight).  Hence: weights pre-split on the host and packed in 16x16x32 fragment
-// order (one coalesced 1 KB read per (slab, tile, plane)), a whole slab of fragments prefetched ahead,
-// activations split ONCE where they are produced (epilogue / gather) and kept in LDS as three bf16
-// planes, operand roles swapped (D = W X^T) so that a lane ends up with four consecutive CHANNELS of
-// one row -- one 8-byte LDS store per plane -- instead of four rows of one channel.
+// What moves instead is data: three bf16 planes are 6 bytes per operand element instead of 4, and the
+// matrix pipe consumes them 2.67x faster, so the weight stream out of L2 (every tile reads all of a
+// level's weights: 418 KB per 64 rows at level 2) and every global round trip of a tile's query + gather
+// show.  Hence:
+//   * weights pre-split on the host, packed in 16x16x32 fragment order (one coalesced 1 KB read per
+//     (slab, tile, plane)), streamed through a buffer descriptor and a register ring four pieces
+//     (12 KB per wave) deep -- tools/probe/l2_stream.hip: 10 B/clk/CU at one load in flight per wave,
+//     31-40 at eight;
+//   * activations split ONCE where they are produced (epilogue / gather) and kept in LDS as three bf16
+//     planes; operand roles swapped (D = W X^T) so that a lane ends up with four consecutive CHANNELS
+//     of one row -- one 8-byte LDS store per plane -- instead of four rows of one channel;
+//   * one operand buffer rewritten in place by each epilogue (66 KB, two blocks per CU) and blocks
+//     persistent over runs of tiles with the next tile's geometry, ball query and neighbour rows
+//     fetched under the current tile's layers (see the kernel).
+// Measured (16 x 60 objects): 0.531 ms for the f32-MFMA kernel (122 TFLOP/s of the pipe's ~128 at the
+// clock it sustains) -> 0.300 ms; the bf16 pipe is 65-70 % busy, the rest is each block's serial chain
+// of epilogues and barriers (phase stamps: tools/ab_split.py, -DSPLIT_STAMP=1).
 //
 // Same contract as sa_fused.hip (msr3d_sa_level): same index ops (shared code), same folded BN affine
 // and ReLU on the accumulators, same max over the neighbourhood; /root/reference/modules/third_party/
@@ -35,6 +43,14 @@
 #include "../../include/msr3d_hip.h"
 #include "pn2_device.h"
 
+#ifndef SPLIT_STAMP
+#define SPLIT_STAMP 0
+#endif
+#if SPLIT_STAMP
+#define STAMP(i) if (tile_no == 2 && (tid & 63) == 0) stamps[i] = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(i)
+#endif
 namespace {
 
 using namespace msr3d;
@@ -72,43 +88,78 @@ __device__ __forceinline__ void split4(const float (&v)[4], uint2 (&p)[3]) {
   }
 }
 
-// one slab's weight fragments of RN column tiles, all three planes: RN x 3 coalesced 1 KB reads
-template <int RN>
-struct WFrag { bf16x8 v[RN][3]; };
+// One PIECE of weights = one (slab, column tile): three planes, 3 x 1 KB coalesced reads per wave.
+// Pieces are consumed in (slab, tile) order and fetched D pieces ahead through a register ring, so a
+// wave keeps D x 3 KB in flight whatever the layer width (tools/probe/l2_stream.hip: the L2 -> CU
+// stream needs >= 8 loads in flight per wave to pass 30 B/clk/CU).
+struct WPiece { bf16x8 v[3]; };
 
-template <int RN, int NT>
-__device__ __forceinline__ void load_w(WFrag<RN> &f, const unsigned short *__restrict__ wg, int s, int lane) {
+// The stream goes through a buffer descriptor: wave-uniform base (SGPRs) + one per-lane byte offset +
+// an SGPR piece offset.  With flat loads hipcc materialises every piece's 64-bit address in its own
+// VGPR pair and hoists them all out of the persistent loop (~180 VGPRs, all spilled).
+struct WStream {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int voff;                        // lane * 16
+  int soff;                        // the wave's first column tile, bytes
+};
+template <int RN>
+__device__ __forceinline__ WStream make_stream(const unsigned short *w, int bytes, int wave_uniform, int lane) {
+  WStream st;
+  st.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(w), 0, bytes, 0x00020000);
+  st.voff = lane * 16;
+  st.soff = wave_uniform * RN * 3 * kFragS * 2;
+  return st;
+}
+
+template <int NT>
+__device__ __forceinline__ void load_piece(WPiece &f, const WStream &st, int s, int rn, int /*lane*/) {
+  const int piece = st.soff + (s * NT + rn) * 3 * kFragS * 2;
 #pragma unroll
-  for (int rn = 0; rn < RN; ++rn)
+  for (int p = 0; p < 3; ++p) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4 r = __builtin_amdgcn_raw_buffer_load_b128(st.rsrc, st.voff, piece + p * kFragS * 2, 0);
+    f.v[p] = *reinterpret_cast<const bf16x8 *>(&r);
+  }
+}
+
+template <int RN, int NT, int D>
+__device__ __forceinline__ void preload_ring(WPiece (&ring)[D], const WStream &st, int lane) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
-      f.v[rn][p] = *reinterpret_cast<const bf16x8 *>(wg + ((size_t)(s * NT + rn) * 3 + p) * kFragS + lane * 8);
+  for (int q = 0; q < D; ++q) load_piece<NT>(ring[q], st, q / RN, q % RN, lane);
 }
 
 // acc[rn][mt] (+)= W[n-tile rn] X[m-tile mt]^T over KS slabs of 32.  X: LDS planes [3][TM][ldh] bf16.
 // D layout: lane (j = lane & 15, g = lane >> 4) holds rows n = 4 g + r (r = 0..3), column m = j.
-template <int RN, int MT, int KS, int NT>
-__device__ __forceinline__ void gemm_split(const unsigned short *xs, int ldh, int plane, const unsigned short *__restrict__ wg,
-                                           f32x4 (&acc)[RN][MT], int lane, const WFrag<RN> &first) {
+// `ring` holds pieces 0..D-1 on entry (fetched under the previous phase).
+template <int RN, int MT, int KS, int NT, int D>
+__device__ __forceinline__ void gemm_split(const unsigned short *xs, int ldh, int plane, const WStream &wg,
+                                           f32x4 (&acc)[RN][MT], int lane, const WPiece (&ring)[D]) {
+  constexpr int NP = KS * RN;
+  static_assert(D <= NP, "ring deeper than the layer");
   const int j = lane & 15, g = lane >> 4;
   const unsigned short *xp = xs + j * ldh + 8 * g;
-  WFrag<RN> wc = first;
+  WPiece w[NP];                    // fully unrolled: only a window of D + 1 pieces is ever live
 #pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    WFrag<RN> wn;
-    load_w<RN, NT>(wn, wg, s + 1 < KS ? s + 1 : s, lane);        // last slab: harmless re-read
-    bf16x8 x[MT][3];
+  for (int q = 0; q < D; ++q) w[q] = ring[q];
+  bf16x8 x[MT][3];                 // one slab of the operand (prefetching the next one a piece early: no gain)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+  for (int q = 0; q < NP; ++q) {
+    const int s = q / RN, rn = q % RN;
+    __builtin_amdgcn_sched_barrier(0);          // this piece's fetches stay below the previous piece's MFMAs ..
+    if (q + D < NP) load_piece<NT>(w[q + D], wg, (q + D) / RN, (q + D) % RN, lane);
+    if (rn == 0) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
-        x[mt][p] = *reinterpret_cast<const bf16x8 *>(xp + p * plane + mt * 16 * ldh + 32 * s);
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          x[mt][p] = *reinterpret_cast<const bf16x8 *>(xp + p * plane + mt * 16 * ldh + 32 * s);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // .. and above its own
     // the six significant products, SMALLEST first (the accumulator meets the big terms last);
     // consecutive MFMAs hit different accumulators
 #define MSR3D_TERM(PW, PX)                                                                             \
-    _Pragma("unroll") for (int rn = 0; rn < RN; ++rn)                                                  \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                  \
-        acc[rn][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc.v[rn][PW], x[mt][PX], acc[rn][mt], 0, 0, 0);
+        acc[rn][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[q].v[PW], x[mt][PX], acc[rn][mt], 0, 0, 0);
     MSR3D_TERM(2, 0)
     MSR3D_TERM(0, 2)
     MSR3D_TERM(1, 1)
@@ -116,7 +167,6 @@ __device__ __forceinline__ void gemm_split(const unsigned short *xs, int ldh, in
     MSR3D_TERM(0, 1)
     MSR3D_TERM(0, 0)
 #undef MSR3D_TERM
-    wc = wn;
   }
 }
 
@@ -151,36 +201,67 @@ __device__ __forceinline__ void store_split(const f32x4 (&acc)[RN][MT], const fl
   }
 }
 
-__device__ __forceinline__ float row16_max(float v) {     // all-reduce max over the lane's 16-lane row
-  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false)));
-  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false)));
-  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false)));
-  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false)));
-  return v;
+// max over each lane's 16-lane row (rotations by 8, 4, 2, 1), four values at a time so that every DPP
+// read sits three instructions behind the write it depends on (a DPP read needs two wait states after a
+// VALU write of the same register and inline asm gets no hazard padding); v_max_f32 with a DPP source is
+// one instruction per step -- hipcc does not fold update_dpp + fmaxf into it.
+__device__ __forceinline__ void row16_max4(float (&m)[4]) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]));
 }
 
-// max over groups of GT m-tiles of relu(acc * scale + shift) -> global out[group][n] (n0 + 16 rn + 4 g ..)
+// relu(acc * scale + shift) maxed over each group's GT m-tiles, per lane: the accumulators die here
 template <int RN, int MT, int GT>
-__device__ __forceinline__ void store_groupmax(const f32x4 (&acc)[RN][MT], const float4 (&sc)[RN], const float4 (&sh)[RN],
-                                               float *__restrict__ out, int ldo, int n0, int groups_valid, int lane) {
-  const int j = lane & 15, g = lane >> 4;
+__device__ __forceinline__ void group_reduce(const f32x4 (&acc)[RN][MT], const float4 (&sc)[RN], const float4 (&sh)[RN],
+                                             float (&m)[RN][MT / GT][4]) {
 #pragma unroll
   for (int rn = 0; rn < RN; ++rn) {
     const float s4[4] = {sc[rn].x, sc[rn].y, sc[rn].z, sc[rn].w};
     const float h4[4] = {sh[rn].x, sh[rn].y, sh[rn].z, sh[rn].w};
 #pragma unroll
     for (int gq = 0; gq < MT / GT; ++gq) {
-      float m[4] = {0.f, 0.f, 0.f, 0.f};              // starting the max at 0 IS the ReLU
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m[rn][gq][r] = 0.f;              // starting the max at 0 IS the ReLU
 #pragma unroll
       for (int t = 0; t < GT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) m[r] = fmaxf(m[r], __builtin_fmaf(acc[rn][gq * GT + t][r], s4[r], h4[r]));
-#pragma unroll
-      for (int r = 0; r < 4; ++r) m[r] = row16_max(m[r]);
-      if (j == 0 && gq < groups_valid)
-        *reinterpret_cast<float4 *>(out + (size_t)gq * ldo + n0 + rn * 16 + 4 * g) = make_float4(m[0], m[1], m[2], m[3]);
+        for (int r = 0; r < 4; ++r)
+          m[rn][gq][r] = fmaxf(m[rn][gq][r], __builtin_fmaf(acc[rn][gq * GT + t][r], s4[r], h4[r]));
     }
   }
+}
+// ... over the 16 rows a tile holds across lanes, -> global out[group][n] (n0 + 16 rn + 4 g ..)
+template <int RN, int NG>
+__device__ __forceinline__ void group_finish(float (&m)[RN][NG][4], float *__restrict__ out, int ldo, int n0,
+                                             int groups_valid, int lane) {
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) {
+      row16_max4(m[rn][gq]);
+      if (j == 0 && gq < groups_valid)
+        *reinterpret_cast<float4 *>(out + (size_t)gq * ldo + n0 + rn * 16 + 4 * g) =
+            make_float4(m[rn][gq][0], m[rn][gq][1], m[rn][gq][2], m[rn][gq][3]);
+    }
 }
 
 template <int RN>
@@ -193,62 +274,6 @@ __device__ __forceinline__ void load_affine4(const float *__restrict__ scale, co
     sh[rn] = *reinterpret_cast<const float4 *>(shift + n0 + rn * 16 + 4 * g);
   }
 }
-
-// ---------------------------------------------------------------------------------------------------
-// Three chained layers on a TM-row tile.  bufA: input planes [3][TM][K0P + 16], re-used for layer 2's
-// output [3][TM][N2 + 16]; bufB: layer 1's output [3][TM][N1 + 16].  4 waves as 1 x 4: every wave owns
-// all TM rows and a quarter of the channels, so each weight fragment is fetched once per block.
-// ---------------------------------------------------------------------------------------------------
-template <int TM, int K0P, int N1, int N2, int N3, int G>
-struct ChainS {
-  static constexpr int MT = TM / 16, GT = G / 16;
-  static constexpr int LDA = (K0P > N2 ? K0P : N2) + kPadH, LDB = N1 + kPadH;
-  static constexpr int PA = TM * LDA, PB = TM * LDB;          // plane strides (bf16 units)
-  static constexpr int LDS_HALVES = 3 * PA + 3 * PB;
-  static constexpr int RN1 = N1 / 64, RN2 = N2 / 64, RN3 = N3 / 64;
-  static_assert(K0P % 32 == 0 && N1 % 64 == 0 && N2 % 64 == 0 && N3 % 64 == 0 && MT % GT == 0, "shape");
-
-  struct Pre1 { WFrag<RN1> w; float4 sc[RN1], sh[RN1]; };
-  __device__ static void preload(const LayerS &l1, Pre1 &p, int tid) {
-    const int lane = tid & 63, wave = tid >> 6;
-    load_w<RN1, N1 / 16>(p.w, l1.w + (size_t)(wave * RN1) * 3 * kFragS, 0, lane);
-    load_affine4<RN1>(l1.scale, l1.shift, wave * RN1 * 16, lane, p.sc, p.sh);
-  }
-
-  __device__ static void run(unsigned short *bufA, unsigned short *bufB, const Pre1 &p1, const LayerS &l1,
-                             const LayerS &l2, const LayerS &l3, float *__restrict__ out, int groups_valid, int tid) {
-    const int lane = tid & 63, wave = tid >> 6;
-    WFrag<RN2> w2;
-    WFrag<RN3> w3;
-    float4 sc2[RN2], sh2[RN2], sc3[RN3], sh3[RN3];
-    {
-      f32x4 acc[RN1][MT];
-      zero_acc(acc);
-      gemm_split<RN1, MT, K0P / 32, N1 / 16>(bufA, LDA, PA, l1.w + (size_t)(wave * RN1) * 3 * kFragS, acc, lane, p1.w);
-      // the next layer's first operands fly while this layer's epilogue and barrier run
-      load_w<RN2, N2 / 16>(w2, l2.w + (size_t)(wave * RN2) * 3 * kFragS, 0, lane);
-      load_affine4<RN2>(l2.scale, l2.shift, wave * RN2 * 16, lane, sc2, sh2);
-      store_split<RN1, MT>(acc, p1.sc, p1.sh, bufB, LDB, PB, wave * RN1 * 16, lane);
-    }
-    __syncthreads();
-    {
-      f32x4 acc[RN2][MT];
-      zero_acc(acc);
-      gemm_split<RN2, MT, N1 / 32, N2 / 16>(bufB, LDB, PB, l2.w + (size_t)(wave * RN2) * 3 * kFragS, acc, lane, w2);
-      load_w<RN3, N3 / 16>(w3, l3.w + (size_t)(wave * RN3) * 3 * kFragS, 0, lane);
-      load_affine4<RN3>(l3.scale, l3.shift, wave * RN3 * 16, lane, sc3, sh3);
-      store_split<RN2, MT>(acc, sc2, sh2, bufA, N2 + kPadH, TM * (N2 + kPadH), wave * RN2 * 16, lane);
-    }
-    __syncthreads();
-    {
-      f32x4 acc[RN3][MT];
-      zero_acc(acc);
-      gemm_split<RN3, MT, N2 / 32, N3 / 16>(bufA, N2 + kPadH, TM * (N2 + kPadH), l3.w + (size_t)(wave * RN3) * 3 * kFragS,
-                                            acc, lane, w3);
-      store_groupmax<RN3, MT, GT>(acc, sc3, sh3, out, N3, wave * RN3 * 16, groups_valid, lane);
-    }
-  }
-};
 
 // ball query of ONE centre by ONE wave over a cloud staged in LDS (sa_fused.hip's, verbatim semantics:
 // ball_query_gpu.cu:9-44 -- index order, strict '<', first-hit fill, zeros when empty)
@@ -274,79 +299,223 @@ __device__ __forceinline__ void wave_ball_query(const float *sx, int n, float cx
 }
 
 // =====================================================================================================
-// Level 2: xyz (b, n <= 64, 3), feat (b, n, 128) point-major fp32; centres (b, m, 3).  Block = 2 centres
-// x 32 neighbours.  MLP 131 -> 128 -> 128 -> 256, K order [feat(128), dxyz(3), 0 x 29].  out (b, m, 256).
+// Level 2: xyz (b, n <= 64, 3), feat (b, n, 128) point-major fp32; centres (b, m, 3).  A TILE is 2 centres
+// x 32 neighbours = 64 rows; MLP 131 -> 128 -> 128 -> 256, K order [feat(128), dxyz(3), 0 x 29];
+// out (b, m, 256).
+//
+// The block is PERSISTENT over a contiguous run of tiles and software-pipelined across them: one tile
+// costs ~14k cycles of matrix pipe per wave but its query + gather is a chain of three dependent global
+// round trips (~10k cycles when exposed, measured with s_memtime stamps), so the next tile's geometry is
+// fetched under layer 1, its ball query runs under layer 1's epilogue, its 32 KB of neighbour features
+// fly under layer 3 and are split into the operand planes while layer 3's maxima are stored.  ONE LDS
+// operand buffer, rewritten in place by each epilogue (66 KB): two blocks per CU, so one block's
+// epilogues and barriers sit under the other's MFMAs.  4 waves as 1 x 4: every wave owns all 64 rows and
+// a quarter of the channels -- each weight fragment is fetched once per tile.
 // =====================================================================================================
-using Chain2S = ChainS<2 * kNS, 160, 128, 128, 256, kNS>;
+constexpr int kTM = 2 * kNS;                 // rows per tile
+constexpr int kK0 = 160, kN1 = 128, kN2 = 128, kN3 = 256;
+constexpr int kLd = kK0 + kPadH;             // one row pitch for every layer's operand (176: conflict-free b128 reads)
+constexpr int kPlane = kTM * kLd;            // plane stride, bf16 units
+constexpr int kRing = 4;                     // weight pieces in flight per wave (12 KB)
+constexpr int kSa2Lds = 3 * kPlane * 2 + (2 * (kN1 + kN2 + kN3) + 64 * 3 + 16) * 4 + 2 * kNS * 4;
 
-__global__ __launch_bounds__(256) void sa2_split_kernel(int n, int m, float radius2, const float *__restrict__ xyz,
-                                                        const float *__restrict__ feat, const float *__restrict__ new_xyz,
-                                                        LayerS l1, LayerS l2, LayerS l3, float *__restrict__ out,
-                                                        int *__restrict__ dbg_idx, const unsigned char *__restrict__ valid) {
-  if (valid && !valid[blockIdx.y]) return;
+__global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int tiles, int tiles_per_block, float radius2,
+                                                           const float *__restrict__ xyz, const float *__restrict__ feat,
+                                                           const float *__restrict__ new_xyz, LayerS l1, LayerS l2, LayerS l3,
+                                                           float *__restrict__ out, int *__restrict__ dbg_idx,
+                                                           const unsigned char *__restrict__ valid
+#if SPLIT_STAMP
+                                                           , unsigned long long *stamp_base
+#endif
+                                                           ) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-  constexpr int CPB = 2, TM = CPB * kNS;
-  unsigned short *bufA = smem, *bufB = smem + 3 * Chain2S::PA;
-  int *nbr = reinterpret_cast<int *>(smem + Chain2S::LDS_HALVES);       // [CPB][32]
-  float *ctr = reinterpret_cast<float *>(nbr + 4 * kNS);                // [4][4]
-  float *sx = ctr + 16;                                                  // [n][3], n <= 64
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int obj = blockIdx.y, c0 = blockIdx.x * CPB;
+  unsigned short *buf = smem;                                             // [3][64][176] bf16
+  float *aff = reinterpret_cast<float *>(smem + 3 * kPlane);               // sc1 sh1 sc2 sh2 sc3 sh3
+  float *sx = aff + 2 * (kN1 + kN2 + kN3);                                 // [n][3], n <= 64
+  float *ctr = sx + 64 * 3;                                                // [2][4]
+  int *nbr = reinterpret_cast<int *>(ctr + 16);                            // [2][32]
+  int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tpo = (m + 1) >> 1;                                            // tiles per object
+  const int t_end = min(tiles, (int)(blockIdx.x + 1) * tiles_per_block);
+#if SPLIT_STAMP
+  unsigned long long *stamps = stamp_base + ((size_t)blockIdx.x * 4 + wave) * 16;
+  int tile_no = 0;
+#endif
 
-  Chain2S::Pre1 pre;
-  Chain2S::preload(l1, pre, tid);           // layer-1 weights / affine in flight during the loader phase
-  if (tid < n * 3) sx[tid] = xyz[(size_t)obj * n * 3 + tid];
-  if (tid >= 192 && tid < 192 + 3 * CPB) {
-    const int t = tid - 192, w = t / 3, c = t - w * 3;
-    ctr[w * 4 + c] = (c0 + w < m) ? new_xyz[((size_t)obj * m + c0 + w) * 3 + c] : 0.f;
-  }
-  __syncthreads();
-  if (wave < CPB) {
-    if (c0 + wave < m)
-      wave_ball_query(sx, n, ctr[wave * 4 + 0], ctr[wave * 4 + 1], ctr[wave * 4 + 2], radius2, kNS, nbr + wave * kNS, lane);
-    else if (lane < kNS)
-      nbr[wave * kNS + lane] = 0;
-  }
-  __syncthreads();
-  if (dbg_idx && tid < CPB * kNS && c0 + tid / kNS < m) dbg_idx[((size_t)obj * m + c0) * kNS + tid] = nbr[tid];
-  const float *F = feat + (size_t)obj * n * 128;
-  {   // 32 float4 per row; indices first, then ALL loads, then split + LDS stores: one L2 round trip
-    constexpr int IT = TM * 32 / 256;
+  auto next_valid = [&](int t) {             // first tile >= t whose object is encoded (uniform)
+    if (valid)
+      while (t < t_end && !valid[t / tpo]) t = (t / tpo + 1) * tpo;
+    return t < t_end ? t : t_end;
+  };
+  int T = next_valid(blockIdx.x * tiles_per_block);
+  if (T >= t_end) return;
+
+  // folded BN affines: once per block
+  for (int i = tid; i < kN1; i += 256) { aff[i] = l1.scale[i]; aff[kN1 + i] = l1.shift[i]; }
+  for (int i = tid; i < kN2; i += 256) { aff[2 * kN1 + i] = l2.scale[i]; aff[2 * kN1 + kN2 + i] = l2.shift[i]; }
+  for (int i = tid; i < kN3; i += 256) { aff[2 * (kN1 + kN2) + i] = l3.scale[i]; aff[2 * (kN1 + kN2) + kN3 + i] = l3.shift[i]; }
+  const float *sc1 = aff, *sh1 = aff + kN1, *sc2 = aff + 2 * kN1, *sh2 = sc2 + kN2, *sc3 = aff + 2 * (kN1 + kN2), *sh3 = sc3 + kN3;
+
+  constexpr int RN1 = kN1 / 64, RN2 = kN2 / 64, RN3 = kN3 / 64, MT = kTM / 16, GT = kNS / 16;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);                 // uniform to the compiler as well
+  const WStream w1 = make_stream<RN1>(l1.w, kK0 * kN1 * 6, wave_u, lane);
+  const WStream w2 = make_stream<RN2>(l2.w, kN1 * kN2 * 6, wave_u, lane);
+  const WStream w3 = make_stream<RN3>(l3.w, kN2 * kN3 * 6, wave_u, lane);
+
+  // ---- the pieces of a tile's query + gather ----
+  float geo = 0.f;                           // one xyz / centre coordinate of the NEXT tile per thread
+  auto geo_fetch = [&](int t) {              // global -> register
+    const int obj = t / tpo, c0 = (t - obj * tpo) * 2;
+    if (tid < n * 3) geo = xyz[(size_t)obj * n * 3 + tid];
+    else if (tid >= 192 && tid < 198) {
+      const int q = tid - 192, w = q / 3, c = q - w * 3;
+      geo = (c0 + w < m) ? new_xyz[((size_t)obj * m + c0 + w) * 3 + c] : 0.f;
+    }
+  };
+  auto geo_store = [&]() {                   // register -> LDS
+    if (tid < n * 3) sx[tid] = geo;
+    else if (tid >= 192 && tid < 198) { const int q = tid - 192, w = q / 3; ctr[w * 4 + (q - w * 3)] = geo; }
+  };
+  auto query = [&](int t) {                  // waves 0, 1: one centre each
+    const int obj = t / tpo, c0 = (t - obj * tpo) * 2;
+    if (wave < 2) {
+      if (c0 + wave < m)
+        wave_ball_query(sx, n, ctr[wave * 4 + 0], ctr[wave * 4 + 1], ctr[wave * 4 + 2], radius2, kNS, nbr + wave * kNS, lane);
+      else if (lane < kNS)
+        nbr[wave * kNS + lane] = 0;
+    }
+  };
+  constexpr int IT = kTM * 32 / 256;         // float4 per thread per tile: 32 float4 per row
+  float4 val[IT];
+  auto feat_fetch = [&](int t) {             // indices first, then ALL loads: one L2 round trip
+    const int obj = t / tpo, c0 = (t - obj * tpo) * 2;
+    if (dbg_idx && tid < kTM && c0 + tid / kNS < m) dbg_idx[((size_t)obj * m + c0) * kNS + tid] = nbr[tid];
+    const float *F = feat + (size_t)obj * n * 128;
     int pidx[IT];
-    float4 val[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) pidx[it] = nbr[(tid + it * 256) >> 5];
 #pragma unroll
     for (int it = 0; it < IT; ++it)
       val[it] = *reinterpret_cast<const float4 *>(F + (size_t)pidx[it] * 128 + ((tid + it * 256) & 31) * 4);
+  };
+  auto feat_store = [&]() {                  // split + LDS planes; columns 128..159: [dx, dy, dz, 0 ...]
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int e = tid + it * 256;
       const float v[4] = {val[it].x, val[it].y, val[it].z, val[it].w};
       uint2 p[3];
       split4(v, p);
-      unsigned short *d = bufA + (e >> 5) * Chain2S::LDA + (e & 31) * 4;
+      unsigned short *d = buf + (e >> 5) * kLd + (e & 31) * 4;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2 *>(d + k * Chain2S::PA) = p[k];
+      for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2 *>(d + k * kPlane) = p[k];
     }
-  }
-  if (tid < TM) {                  // columns 128..159: [dx, dy, dz, 0 ...]
-    const int row = tid, pi = nbr[row], w = row >> 5;
-    const float v[4] = {sx[pi * 3 + 0] - ctr[w * 4 + 0], sx[pi * 3 + 1] - ctr[w * 4 + 1], sx[pi * 3 + 2] - ctr[w * 4 + 2], 0.f};
-    uint2 p[3];
-    split4(v, p);
+    if (tid < kTM) {
+      const int row = tid, pi = nbr[row], w = row >> 5;
+      const float v[4] = {sx[pi * 3 + 0] - ctr[w * 4 + 0], sx[pi * 3 + 1] - ctr[w * 4 + 1], sx[pi * 3 + 2] - ctr[w * 4 + 2], 0.f};
+      uint2 p[3];
+      split4(v, p);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      unsigned short *d = bufA + k * Chain2S::PA + row * Chain2S::LDA + 128;
-      *reinterpret_cast<uint2 *>(d) = p[k];
+      for (int k = 0; k < 3; ++k) {
+        unsigned short *d = buf + k * kPlane + row * kLd + 128;
+        *reinterpret_cast<uint2 *>(d) = p[k];
 #pragma unroll
-      for (int c = 4; c < 32; c += 4) *reinterpret_cast<uint2 *>(d + c) = make_uint2(0u, 0u);
+        for (int c = 4; c < 32; c += 4) *reinterpret_cast<uint2 *>(d + c) = make_uint2(0u, 0u);
+      }
     }
-  }
+  };
+
+  // ---- prologue: the first tile's operand, unpipelined ----
+  WPiece ring1[kRing];
+  preload_ring<RN1, kN1 / 16, kRing>(ring1, w1, lane);
+  geo_fetch(T);
+  geo_store();
   __syncthreads();
-  int groups = m - c0;
-  groups = groups < 0 ? 0 : (groups < CPB ? groups : CPB);
-  Chain2S::run(bufA, bufB, pre, l1, l2, l3, out + ((size_t)obj * m + c0) * 256, groups, tid);
+  query(T);
+  __syncthreads();
+  feat_fetch(T);
+  feat_store();
+  __syncthreads();
+
+  while (true) {
+    const int obj = T / tpo, c0 = (T - obj * tpo) * 2;
+    const int Tn = next_valid(T + 1);
+    const bool more = Tn < t_end;
+    // per-lane addresses are re-derived every tile: hoisted out of the loop they would sit in ~40 VGPRs
+    // across the layer-3 phase and spill (and a scratch reload's vmcnt(0) drains the weight ring)
+    asm volatile("" : "+v"(tid));
+    lane = tid & 63;
+    wave = tid >> 6;
+#if SPLIT_STAMP
+    if (tile_no == 3 && (tid & 63) == 0) stamps[10] = __builtin_amdgcn_s_memtime();
+#endif
+    STAMP(0);
+    if (more) geo_fetch(Tn);
+    WPiece ring2[kRing], ring3[kRing];
+    {
+      f32x4 acc[RN1][MT];
+      zero_acc(acc);
+      gemm_split<RN1, MT, kK0 / 32, kN1 / 16, kRing>(buf, kLd, kPlane, w1, acc, lane, ring1);
+      preload_ring<RN2, kN2 / 16, kRing>(ring2, w2, lane);        // the next layer's operands fly under the epilogue
+      float4 sc[RN1], sh[RN1];
+      load_affine4<RN1>(sc1, sh1, wave * RN1 * 16, lane, sc, sh);
+      STAMP(1);
+      __syncthreads();                                            // (A) every wave is done READING the operand; sx/ctr free
+      if (more) geo_store();
+      store_split<RN1, MT>(acc, sc, sh, buf, kLd, kPlane, wave * RN1 * 16, lane);
+    }
+    __syncthreads();                                              // (B) layer-1 planes + next geometry visible
+    STAMP(2);
+    if (more) query(Tn);
+    {
+      f32x4 acc[RN2][MT];
+      zero_acc(acc);
+      gemm_split<RN2, MT, kN1 / 32, kN2 / 16, kRing>(buf, kLd, kPlane, w2, acc, lane, ring2);
+      preload_ring<RN3, kN3 / 16, kRing>(ring3, w3, lane);
+      float4 sc[RN2], sh[RN2];
+      load_affine4<RN2>(sc2, sh2, wave * RN2 * 16, lane, sc, sh);
+      STAMP(3);
+      __syncthreads();                                            // (C)
+      store_split<RN2, MT>(acc, sc, sh, buf, kLd, kPlane, wave * RN2 * 16, lane);
+    }
+    __syncthreads();                                              // (D) layer-2 planes + next neighbour lists visible
+    STAMP(4);
+    float touch = 0.f;                                            // the neighbour rows' 256 cache lines start moving
+    float gm[RN3][MT / GT][4];
+    if (more) touch = feat[((size_t)(Tn / tpo) * n + nbr[tid >> 2]) * 128 + (tid & 3) * 32];   // towards this XCD's L2
+    {
+      f32x4 acc[RN3][MT];
+      zero_acc(acc);
+      gemm_split<RN3, MT, kN2 / 32, kN3 / 16, kRing>(buf, kLd, kPlane, w3, acc, lane, ring3);
+      STAMP(5);
+      float4 sc[RN3], sh[RN3];
+      load_affine4<RN3>(sc3, sh3, wave * RN3 * 16, lane, sc, sh);
+      group_reduce<RN3, MT, GT>(acc, sc, sh, gm);
+    }
+    // (touched lines: L2 hits) fly under the row maxima.  UNCONDITIONAL -- after the last tile it re-reads
+    // that tile: a conditional assignment would make val / ring1 loop-carried and live across the GEMMs
+    feat_fetch(more ? Tn : T);
+    preload_ring<RN1, kN1 / 16, kRing>(ring1, w1, lane);
+    {
+      int groups = m - c0;
+      groups = groups < 2 ? groups : 2;
+      group_finish<RN3, MT / GT>(gm, out + ((size_t)obj * m + c0) * kN3, kN3, wave * RN3 * 16, groups, lane);
+    }
+    if (!more) break;
+    STAMP(6);
+    __syncthreads();                                              // (E) every wave is done reading layer-2 planes
+    asm volatile("" ::"v"(touch));
+    STAMP(7);
+    feat_store();
+    STAMP(8);
+    __syncthreads();                                              // (F) the next tile's operand is in place
+    STAMP(9);
+#if SPLIT_STAMP
+    ++tile_no;
+#endif
+#if SPLIT_STAMP
+#endif
+    T = Tn;
+  }
 }
 
 template <typename K>
@@ -382,12 +551,26 @@ extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius
   hipError_t e;
   if (level == 2) {
     if (!pts || !feat || !new_xyz || n <= 0 || n > 64 || m <= 0) return MSR3D_EINVAL;
-    const size_t lds = sizeof(unsigned short) * Chain2S::LDS_HALVES + sizeof(int) * (4 * kNS + 16 + 64 * 3);
-    if ((e = allow_lds(sa2_split_kernel, lds)) != hipSuccess) return (int)e;
-    dim3 grid((m + 1) / 2, b);
-    sa2_split_kernel<<<grid, 256, lds, st>>>(n, m, r2, pts, feat, new_xyz, make_layer(w1, affine1, 128),
-                                             make_layer(w2, affine2, 128), make_layer(w3, affine3, 256), out,
-                                             dbg_ball_idx, valid);
+    if ((e = allow_lds(sa2_split_kernel, kSa2Lds)) != hipSuccess) return (int)e;
+    static int slots = 0;              // resident blocks: two per CU
+    if (!slots) {
+      int dev = 0, cus = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+      slots = 2 * cus;
+    }
+    const long long tiles = (long long)b * ((m + 1) / 2);
+    if (tiles > 0x7fffffffLL) return MSR3D_EINVAL;
+    const int per = (int)((tiles + slots - 1) / slots);
+    const int blocks = (int)((tiles + per - 1) / per);
+#if SPLIT_STAMP
+    unsigned long long *stamp_base = reinterpret_cast<unsigned long long *>(dbg_ball_idx);
+    sa2_split_kernel<<<blocks, 256, kSa2Lds, st>>>(n, m, (int)tiles, per, r2, pts, feat, new_xyz, make_layer(w1, affine1, 128),
+                                                   make_layer(w2, affine2, 128), make_layer(w3, affine3, 256), out, nullptr, valid, stamp_base);
+#else
+    sa2_split_kernel<<<blocks, 256, kSa2Lds, st>>>(n, m, (int)tiles, per, r2, pts, feat, new_xyz, make_layer(w1, affine1, 128),
+                                                   make_layer(w2, affine2, 128), make_layer(w3, affine3, 256), out, dbg_ball_idx, valid);
+#endif
   } else {
     return MSR3D_EINVAL;
   }

@@ -111,3 +111,36 @@ def test_split_weights_reassemble_exactly():
     w = conv.weight.double().view(n, kp)
     err = (planes.sum(0) - w).abs() / w.abs().clamp_min(1e-300)
     assert float(err.max()) < 2.0 ** -25
+
+
+@pytest.mark.parametrize("objects,keep", [(70, 0.6), (200, 0.35), (200, 1.0), (7, 0.5)])
+def test_split_persistent_tiles_and_the_valid_mask(objects, keep):
+    """The split kernel is persistent over runs of tiles and pipelines the next tile's query + gather under
+    the current one's layers; objects switched off by the valid mask are skipped inside that pipeline.
+    Many objects (several tiles per block, runs crossing object boundaries, skipped objects at the start,
+    middle and end of a run) must give what the one-tile-per-block f32 kernel gives."""
+    from msr3d_amd.pointnet2 import fused
+    from msr3d_amd.synth import synth_batch
+    net = _net(11)
+    scenes = (objects + 59) // 60
+    pts = synth_batch(5, scenes, O=60, P=1024, device="cuda")["obj_fts"].reshape(-1, 1024, 6)[:objects].contiguous()
+    g = torch.Generator().manual_seed(objects)
+    valid = (torch.rand(objects, generator=g) < keep).cuda() if keep < 1.0 else None
+    if valid is not None:
+        valid[0] = False
+        valid[-1] = False
+        valid[objects // 2] = True
+    out = {}
+    for mode in ("f32", "split"):
+        prev = fused.set_sa_mma(mode)
+        try:
+            with torch.no_grad():
+                out[mode] = fused.forward(net, pts, return_internals=True, valid=valid)
+        finally:
+            fused.set_sa_mma(prev)
+    (y32, d32), (ysp, dsp) = out["f32"], out["split"]
+    sel = valid if valid is not None else torch.ones(objects, dtype=torch.bool, device="cuda")
+    assert torch.equal(d32["ball2"][sel], dsp["ball2"][sel])
+    assert rel(dsp["feat2"][sel], d32["feat2"][sel]) < 2e-6
+    assert torch.equal(ysp[~sel], y32[~sel])                      # padding rows: the same constant feature
+    assert rel(ysp[sel], y32[sel]) < 2e-6

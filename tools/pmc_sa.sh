@@ -14,6 +14,7 @@ run() {  # name, counters...
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 run sq2 SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
+run sq3 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES
 run fetch FETCH_SIZE GRBM_GUI_ACTIVE
 run write WRITE_SIZE
 run tcc TCC_HIT TCC_MISS TCC_REQ
@@ -23,7 +24,7 @@ out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        for key in ("sa1_kernel", "sa2_kernel", "sa3_kernel", "fps_kernel", "ball_query_kernel"):
+        for key in ("sa1_kernel", "sa2_kernel", "sa2_split_kernel", "sa3_kernel", "fps_kernel", "ball_query_kernel"):
             if key in r["Kernel_Name"]:
                 agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as fo:
