@@ -91,6 +91,7 @@ class PrompterSchedule:
         # the step's first launch can also advance the dropout seed word (HotPathTrainStep sets this
         # and drops its own msr3d_bump_seed launch); off: the caller owns the seed
         self.bump_seed = False
+        self.need_d_embeds = False   # set per backward: the object features come from an unfrozen encoder
 
     # ------------------------------------------------------------------ eligibility
     def eligible(self, d, ignore_grad_mode=False):
@@ -174,6 +175,7 @@ class PrompterSchedule:
         # backward temporaries (one layer's worth, reused)
         a.want("d_ffn", M, D); a.want("d_t", M, D); a.want("d_pre", M, FF); a.want("d_fc", M, D)
         a.want("d_ctx", M, D); a.want("d_qkvc", M, W); a.want("d_la", M, D); a.want("d_lb", M, D)
+        a.want("d_emb", M, KE)        # gradient of the object features: only written for an unfrozen encoder
         a.build()
         self.arena = a
         self.pad = torch.zeros(M, dtype=torch.uint8, device=device)
@@ -373,10 +375,14 @@ class PrompterSchedule:
                 _ptr(pr.object_orientation_feat.grad) if pr.use_orientation else None, st)
             _lib.check(rc, "msr3d_pos_embed_bwd")
             lp = pr.obj_linear_projection
-            self._multi([self._dw(a["d_la"], D, a["ff"], KF, M, le[0].weight.grad, le[0].bias.grad),
-                         dict(a_kc=0, b_kc=0, M=D, N=3, K=M, A=a["d_lb"], lda=D, B=_ptr(a["loc6"], 3), ldb=6,
-                              C=se[0].weight.grad, ldc=3, beta=1.0, colsum=se[0].bias.grad),
-                         self._dw(a["d_xin0"], D, self.saved_embeds, KE, M, lp.weight.grad, lp.bias.grad)])
+            last = [self._dw(a["d_la"], D, a["ff"], KF, M, le[0].weight.grad, le[0].bias.grad),
+                    dict(a_kc=0, b_kc=0, M=D, N=3, K=M, A=a["d_lb"], lda=D, B=_ptr(a["loc6"], 3), ldb=6,
+                         C=se[0].weight.grad, ldc=3, beta=1.0, colsum=se[0].bias.grad),
+                    self._dw(a["d_xin0"], D, self.saved_embeds, KE, M, lp.weight.grad, lp.bias.grad)]
+            if self.need_d_embeds:     # unfrozen object encoder: d obj_embeds = d_xin0 W_proj, same launch
+                last.append(dict(a_kc=1, b_kc=0, M=M, N=KE, K=D, A=a["d_xin0"], lda=D, B=lp.weight, ldb=KE,
+                                 C=a["d_emb"], ldc=KE, beta=0.0))
+            self._multi(last)
         for p in self._params():
             self.dp.mark_ready(p)
 
@@ -387,14 +393,21 @@ class _PrompterFn(torch.autograd.Function):
         tok, scene = sched.forward(embeds)
         ctx.sched = sched
         ctx.n = len(params)
+        ctx.d_embeds = embeds.requires_grad
         ctx.set_materialize_grads(False)
         return tok, scene
 
     @staticmethod
     def backward(ctx, g_tok, g_scene):
+        sched = ctx.sched
+        d_emb = None
         if g_tok is not None or g_scene is not None:
-            ctx.sched.backward(g_scene, g_tok)
-        return (None, None) + (None,) * ctx.n
+            sched.need_d_embeds = ctx.d_embeds
+            sched.backward(g_scene, g_tok)
+            if ctx.d_embeds:
+                B, L, KE = (sched.dims[k] for k in ("B", "L", "KE"))
+                d_emb = sched.arena["d_emb"].view(B, L, KE)
+        return (None, d_emb) + (None,) * ctx.n
 
 
 def attach(model, dp):
