@@ -92,6 +92,9 @@ def parse():
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event brackets around all four "
                     "encoder launches instead of the dominant one only (each pair of event records costs "
                     "the step ~10 us: 2.15 ms without any, 2.16 with one pair, 2.19 with four)")
+    ap.add_argument("--unfrozen", action="store_true", help="variant line: `freeze: False` -- the PointNet++ "
+                    "backbone trains too (BatchNorm in training mode, encoder forward + backward inside the "
+                    "captured step); use a smaller --batch (4 scenes: 3.9 GiB of saved activations)")
     ap.add_argument("--no-graph", action="store_true", help="issue the trainable part eagerly "
                     "instead of replaying the captured HIP graph")
     ap.add_argument("--cpu-threads", type=int, default=32, help="threads of the CPU baseline leg "
@@ -105,10 +108,12 @@ def build(args, device):
     from msr3d_amd.config import AttrDict, default_prompter_cfg
     from msr3d_amd.model import build_model
     torch.manual_seed(1234)     # identical initial weights on every rank
-    cfg = AttrDict({"prompter": default_prompter_cfg(situation_type=args.situation_type),
+    cfg = AttrDict({"prompter": default_prompter_cfg(situation_type=args.situation_type, freeze=not args.unfrozen),
                     "llm_hidden_size": args.llm_hidden, "model": {"name": "MSR3DHotPath"}})
     model = build_model(cfg).to(device)
     model.train()               # dropout active, as in training; frozen backbone stays eval
+    if args.unfrozen and not any(p.requires_grad for p in model.visual_prompter.obj_encoder.parameters()):
+        raise RuntimeError("--unfrozen: the encoder came out frozen")
     return model
 
 
@@ -428,6 +433,12 @@ def main():
                     "achieved": achieved, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                     "frac": achieved / MFMA_F32_PEAK_TF,
                     "dtype": "f32-input MFMA (v_mfma_f32_16x16x4_f32)"}
+        if args.unfrozen:
+            # variant line: the fused frozen-encoder launches are not on this path (the SharedMLPs run as
+            # group_rows -> token GEMM -> BatchNorm(train) kernels under autograd); no roofline leg
+            roof = {"bound": "mfma", "kernel": None, "achieved": None, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": None, "note": "unfrozen-backbone variant: see DESIGN.md 4.1a"}
+            traffic_per_obj = None
         roof.update({"traffic": traffic_per_obj * objs_per_launch if traffic_per_obj else None,
                      "traffic_unit": f"bytes/launch (PMC passes of tools/pmc_sa.sh, {traffic_src})",
                      "kernel_ms": k_ms, "launches": len(sink["msr3d_sa_level2"])})
@@ -439,7 +450,7 @@ def main():
                                         "note": "HIP events on the compute stream between steps, this rank"},
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (level-2 SharedMLP: bf16x3 split on the bf16 MFMA, fp32 accuracy)" if split else "f32",
+            "dtype": "f32 (level-2 SharedMLP: bf16x3 split on the bf16 MFMA, fp32 accuracy)" if (split and not args.unfrozen) else "f32",
             "data": "synthetic",
             "config": {"workload": "configs/msr3d.yaml hot path (OSE3DSituation + llm_proj, "
                                    "frozen PointNet++), synthetic ScanNet-like scenes",
@@ -447,6 +458,8 @@ def main():
                        "grad_accumulation": args.accum,
                        "llm_hidden": args.llm_hidden, "situation_type": args.situation_type,
                        "step": "fwd+bwd+allreduce+clip+AdamW, LLM excluded",
+                       "backbone": "unfrozen (freeze: False, BatchNorm in training mode)" if args.unfrozen
+                       else "frozen (every shipped config)",
                        "hip_graph": not args.no_graph, "encoder_prefetch": args.pipeline,
                        "padded_slots_skipped": args.skip_padded,
                        "objects_encoded_per_step": objs_per_launch,

@@ -73,7 +73,19 @@ class FlatGradAllReduce:
                     order.append(q)
         self.order = order
         self.offset = {}
-        total = sum(p.numel() for p in order)
+        # Every parameter (every pack group) starts on a 16-byte boundary: the fused kernels read
+        # LayerNorm / bias vectors of the flat buffers as float4.  The gaps (a 607-way head, 3-wide
+        # biases of an unfrozen backbone ...) hold zeros in the parameter, gradient and moment buffers.
+        starts, off = {}, 0
+        i = 0
+        while i < len(order):
+            g = group_of.get(id(order[i]), [order[i]])
+            off = (off + 3) // 4 * 4
+            for q in g:
+                starts[id(q)] = off
+                off += q.numel()
+            i += len(g)
+        total = off
         # float4 kernels (fused optimiser) see whole vectors; a multiple of 32 also splits evenly over up
         # to 8 ranks for the reduce-scatter / all-gather exchange
         total_padded = (total + 31) // 32 * 32
@@ -85,6 +97,7 @@ class FlatGradAllReduce:
         per_bucket = max(1, bucket_bytes // 4)
         for p in order:
             n = p.numel()
+            off = starts[id(p)]
             p.grad = self.flat[off:off + n].view_as(p)
             self.offset[id(p)] = off
             # lets the HIP linear backward accumulate dW/db straight into these views (no

@@ -195,7 +195,9 @@ class PrompterSchedule:
                 v = v.value
             setattr(s, k, v if v is not None else 0)
         rc = self.lib.msr3d_strip_gemm_f32(ctypes.byref(s), self.stream)
-        _lib.check(rc, "msr3d_strip_gemm_f32")
+        if rc:
+            fields = ", ".join(f"{n}={getattr(s, n)!r}" for n, _ in s._fields_ if getattr(s, n))
+            _lib.check(rc, f"msr3d_strip_gemm_f32({fields})")
 
     def _multi(self, probs):
         arr = (GemmProblem * len(probs))()

@@ -193,10 +193,9 @@ class MSR3DHotPath(nn.Module):
         if sched is not None and "obj_tokens" not in scene_dict:
             # training on the flat-buffer engine: the whole trainable part as one fixed schedule of
             # fused launches (msr3d_amd/fused_model.py); anything it does not cover falls through
-            enc = self.visual_prompter.obj_encoder
             if "obj_embeds" not in scene_dict and scene_dict.get("obj_fts") is not None \
-                    and scene_dict["obj_fts"].is_cuda and "single_obj" not in scene_dict \
-                    and not any(p.requires_grad for p in enc.parameters()):
+                    and scene_dict["obj_fts"].is_cuda and "single_obj" not in scene_dict:
+                # (an unfrozen encoder runs under autograd here; the schedule hands back d obj_embeds)
                 scene_dict["obj_embeds"] = self.visual_prompter.encode_objects(
                     scene_dict["obj_fts"], scene_dict.get("obj_masks"))
             if sched.eligible(scene_dict):

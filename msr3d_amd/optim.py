@@ -44,14 +44,13 @@ class FlatAdamW:
             raise RuntimeError("flat buffer length must be a multiple of 4")
         self.flat_p = torch.empty_like(flat_g)
         # same element order as the gradient buffer: reversed(params)
-        off = 0
+        self.flat_p.zero_()      # (alignment gaps between parameters stay zero)
         with torch.no_grad():
             for p in dp.order:
-                k = p.numel()
+                k, off = p.numel(), dp.offset[id(p)]
                 view = self.flat_p[off:off + k].view_as(p)
                 view.copy_(p.data)
                 p.data = view
-                off += k
         self.exp_avg = torch.zeros_like(flat_g)
         self.exp_avg_sq = torch.zeros_like(flat_g)
         self.sumsq = torch.zeros(1024, dtype=torch.float32, device=flat_g.device)   # block partials
@@ -89,23 +88,20 @@ class FlatAdamW:
         keys = list(names) if names is not None else [str(i) for i in range(len(self.dp.order))]
         if len(keys) != len(self.dp.order):
             raise ValueError("names must have one entry per parameter of dp.order")
-        state, off = {}, 0
+        state = {}
         for k, p in zip(keys, self.dp.order):
-            n = p.numel()
+            n, off = p.numel(), self.dp.offset[id(p)]
             state[k] = {"exp_avg": self.exp_avg[off:off + n].view_as(p).clone(),
                         "exp_avg_sq": self.exp_avg_sq[off:off + n].view_as(p).clone()}
-            off += n
         return {"state": state, "step": int(self.step_ctr.item())}
 
     def load_state_dict(self, sd, names=None):
         keys = list(names) if names is not None else [str(i) for i in range(len(self.dp.order))]
-        off = 0
         for k, p in zip(keys, self.dp.order):
-            n = p.numel()
+            n, off = p.numel(), self.dp.offset[id(p)]
             if k in sd["state"]:
                 if tuple(sd["state"][k]["exp_avg"].shape) != tuple(p.shape):
                     raise ValueError(f"optimizer state of {k}: shape mismatch")
                 self.exp_avg[off:off + n].copy_(sd["state"][k]["exp_avg"].reshape(-1))
                 self.exp_avg_sq[off:off + n].copy_(sd["state"][k]["exp_avg_sq"].reshape(-1))
-            off += n
         self.step_ctr.fill_(int(sd["step"]))

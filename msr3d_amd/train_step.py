@@ -40,12 +40,15 @@ class HotPathTrainStep:
         accum_steps-th call."""
         self.model, self.opt, self.dp, self.loss_fn = model, optimizer, dp, loss_fn
         self.prompter = model.visual_prompter
-        if any(p.requires_grad for p in self.prompter.obj_encoder.parameters()):
-            # the encoder pass is hoisted out of autograd here (frozen in every shipped config); an
-            # unfrozen backbone trains through the modules' own forward/backward in a plain loop
-            raise NotImplementedError("HotPathTrainStep expects a frozen object encoder (freeze: True)")
+        # freeze: False -- the encoder is part of the differentiated (and captured) step: its pass cannot
+        # be hoisted out of autograd, prefetched or run ahead, and the point clouds become a static input
+        enc_params = [p for p in self.prompter.obj_encoder.parameters() if p.requires_grad]
+        self.unfrozen = bool(enc_params)
+        if self.unfrozen and not all(any(p is q for q in dp.order) for p in enc_params):
+            raise ValueError("unfrozen object encoder: its parameters must be owned by the gradient engine (dp)")
         self.use_graph = use_graph and example_batch["obj_fts"].is_cuda
-        self.static = {k: torch.empty_like(v) for k, v in example_batch.items() if k != "obj_fts"}
+        self.static = {k: torch.empty_like(v) for k, v in example_batch.items()
+                       if k != "obj_fts" or self.unfrozen}
         B, O = example_batch["obj_fts"].shape[:2]
         self.static["obj_embeds"] = torch.empty(
             (B, O, self.prompter.obj_linear_projection.in_features),
@@ -80,7 +83,10 @@ class HotPathTrainStep:
             hipops.bump_seed(self.static["obj_embeds"].device)   # fresh dropout masks per replay
         if zero:
             self.dp.zero_grad()
-        out = self.model(dict(self.static))
+        inp = dict(self.static)
+        if self.unfrozen:
+            inp.pop("obj_embeds")        # computed under autograd from the static point clouds
+        out = self.model(inp)
         res = self.loss_fn(out)
         scale = 1.0 / self.accum_steps
         if isinstance(res, tuple):
@@ -136,6 +142,8 @@ class HotPathTrainStep:
     def encode_ahead(self, batch):
         """Run the frozen encoder for `batch` NOW on the compute stream; the step that later
         receives this batch finds its features ready (same hand-over as prefetch())."""
+        if self.unfrozen:
+            return
         with torch.no_grad():
             self.prompter.encode_objects(batch["obj_fts"], batch.get("obj_masks"), out=self._pref["feats"])
         ev = torch.cuda.Event()
@@ -144,7 +152,7 @@ class HotPathTrainStep:
 
     def prefetch(self, batch):
         """Start the frozen encoder for `batch` on the side stream (returns immediately)."""
-        if self._enc_stream is None:
+        if self._enc_stream is None or self.unfrozen:
             return
         main = torch.cuda.current_stream()
         self._enc_stream.wait_stream(main)          # inputs exist; previous prefetch consumed
@@ -158,7 +166,9 @@ class HotPathTrainStep:
     def _load(self, batch):
         sched = getattr(self.model, "_schedule", None)
         with torch.no_grad():
-            if self._pref["key"] == id(batch["obj_fts"]):     # features were prefetched
+            if self.unfrozen:
+                self.static["obj_fts"].copy_(batch["obj_fts"])
+            elif self._pref["key"] == id(batch["obj_fts"]):     # features were prefetched
                 torch.cuda.current_stream().wait_event(self._pref["event"])
                 self.static["obj_embeds"].copy_(self._pref["feats"])
                 self._pref["key"] = None
@@ -178,7 +188,7 @@ class HotPathTrainStep:
                 self.static["_staged"] = True
             else:
                 self.static.pop("_staged", None)
-                keys = [k for k in self.static if k not in ("obj_embeds", "_staged")]
+                keys = [k for k in self.static if k not in ("obj_embeds", "_staged", "obj_fts")]
                 dst = [self.static[k] for k in keys]
                 src = [batch[k] for k in keys]
                 if all(d.is_cuda and s.is_cuda and d.dtype == s.dtype and d.shape == s.shape for d, s in zip(dst, src)):
@@ -195,6 +205,8 @@ class HotPathTrainStep:
         schedule / bias-correction phase), the device dropout seed, the accumulation phase."""
         opt = self.opt
         snap = {"micro": self._micro}
+        if self.unfrozen:      # BatchNorm running statistics and batch counters move in training mode
+            snap["buffers"] = [b.clone() for b in self.prompter.obj_encoder.buffers()]
         if hasattr(opt, "flat_p"):
             snap["flat"] = [t.clone() for t in (opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.step_ctr)]
         else:
@@ -227,6 +239,9 @@ class HotPathTrainStep:
                             st[k] = before[k]
             if "seed" in snap:
                 hipops.seed_word(self.static["obj_embeds"].device).copy_(snap["seed"])
+            if "buffers" in snap:
+                for b, v in zip(self.prompter.obj_encoder.buffers(), snap["buffers"]):
+                    b.copy_(v)
         self._micro = snap["micro"]
         self.dp.zero_grad()
 
@@ -273,6 +288,8 @@ class HotPathTrainStep:
         (world > 1) on the compute stream right after backward, where it hides the gradient
         all-reduce."""
         self._load(batch)
+        if self.unfrozen:
+            next_batch = None           # nothing of the next batch can run before this step's update
         hide_comm = next_batch is not None and self.dp.distributed and self.static["obj_embeds"].is_cuda
         if next_batch is not None and not hide_comm:
             self.prefetch(next_batch)

@@ -296,7 +296,8 @@ def test_bn_relu_maxpool_train_matches_max_pool2d_float64(G, ns, C):
 def test_hot_path_model_trains_an_unfrozen_backbone_in_a_plain_loop():
     """`freeze: False` end to end: MSR3DHotPath forward / backward / AdamW in an ordinary torch loop --
     backbone, situated encoder and projector all receive gradients, the loss goes down, BN running
-    statistics move; the hoisted train step says it does not take this configuration."""
+    statistics move; the train step takes this configuration only with the encoder's parameters in its
+    gradient engine (tests/test_unfrozen_step_gpu.py covers the step itself)."""
     import msr3d_amd.model  # noqa: F401
     import msr3d_amd.modules  # noqa: F401
     from msr3d_amd.config import AttrDict, default_prompter_cfg
@@ -327,6 +328,6 @@ def test_hot_path_model_trains_an_unfrozen_backbone_in_a_plain_loop():
     assert model.llm_proj.weight.grad is not None
     assert losses[-1] < losses[0]
     assert not torch.equal(rm0, enc.pcd_net.encoder[0].mlps[0].layer0.bn.bn.running_mean)
-    dp = FlatGradAllReduce([p for p in model.parameters() if p.requires_grad])
-    with pytest.raises(NotImplementedError, match="frozen object encoder"):
+    dp = FlatGradAllReduce([p for n, p in model.named_parameters() if p.requires_grad and "obj_encoder" not in n])
+    with pytest.raises(ValueError, match="owned by the gradient engine"):
         HotPathTrainStep(model, opt, dp, lambda o: o["scene_embeds"].sum(), batch)

@@ -1,0 +1,128 @@
+"""freeze: False through HotPathTrainStep: the encoder's forward + backward ride in the (captured) step,
+the schedule hands back the gradient of the object features, BatchNorm statistics move."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(freeze, seed=1234, E=512):
+    import msr3d_amd.model  # noqa: F401
+    import msr3d_amd.modules  # noqa: F401
+    from msr3d_amd.config import AttrDict, default_prompter_cfg
+    from msr3d_amd.model import build_model
+    torch.manual_seed(seed)
+    cfg = AttrDict({"prompter": default_prompter_cfg(freeze=freeze), "llm_hidden_size": E,
+                    "model": {"name": "MSR3DHotPath"}})
+    m = build_model(cfg).cuda()
+    m.train()
+    for mod in m.modules():                      # dropout off: the two routes draw masks differently
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    return m
+
+
+def _engine(model, batch, use_graph):
+    from msr3d_amd import hipops
+    from msr3d_amd.dp import FlatGradAllReduce
+    from msr3d_amd.optim import FlatAdamW
+    from msr3d_amd.train_step import HotPathTrainStep
+    params = [p for p in model.parameters() if p.requires_grad]
+    dp = FlatGradAllReduce(params, pack_groups=hipops.collect_pack_groups(model))
+    opt = FlatAdamW(dp, lr=1e-3, weight_decay=0.05, max_grad_norm=5.0)
+    hipops.attach_packed_views(model, dp, opt)
+    g = torch.Generator().manual_seed(5)
+    state = {}
+
+    def loss_fn(out):
+        y = out["scene_embeds"]
+        if "w" not in state:
+            state["w"] = torch.randn(tuple(y.shape), generator=g).cuda()
+        return (y * state["w"]).sum() / y.numel()
+
+    step = HotPathTrainStep(model, opt, dp, loss_fn, batch, use_graph=use_graph)
+    if use_graph:
+        step.capture(batch)
+    return step, dp, opt
+
+
+def _set_p0(model):
+    for layer in model.visual_prompter.spatial_encoder:
+        for name in ("dropout", "dropout1", "dropout2"):
+            if hasattr(layer, name):
+                getattr(layer, name).p = 0.0
+
+
+def test_unfrozen_step_trains_the_backbone_like_a_plain_autograd_loop():
+    from msr3d_amd.synth import synth_batch
+    batch = synth_batch(3, 2, O=12, P=1024, device="cuda")
+    # reference: plain autograd through the modules (no schedule, no graph), torch AdamW on the same weights
+    ref = _build(False)
+    _set_p0(ref)
+    test = _build(False)
+    _set_p0(test)
+    test.load_state_dict(ref.state_dict())
+    rp = [p for p in ref.parameters() if p.requires_grad]
+    g = torch.Generator().manual_seed(5)
+    w = None
+    opt = torch.optim.AdamW(rp, lr=1e-3, weight_decay=0.05)
+    losses_ref = []
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        out = ref(dict(batch))
+        y = out["scene_embeds"]
+        if w is None:
+            w = torch.randn(tuple(y.shape), generator=g).cuda()
+        loss = (y * w).sum() / y.numel()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([p for p in rp if p.grad is not None], 5.0)
+        opt.step()
+        losses_ref.append(float(loss.detach()))
+    step, dp, _ = _engine(test, batch, use_graph=True)
+    assert step.unfrozen
+    bn = [m for m in test.visual_prompter.obj_encoder.modules() if isinstance(m, torch.nn.BatchNorm2d)][0]
+    tracked0 = int(bn.num_batches_tracked)
+    losses = [float(step(batch)) for _ in range(2)]
+    assert int(bn.num_batches_tracked) == tracked0 + 2          # the capture warm-up was rolled back
+    assert losses == pytest.approx(losses_ref, rel=2e-4)
+    sd_ref, sd = ref.state_dict(), test.state_dict()
+    moved = 0
+    for k, v in sd_ref.items():
+        if not v.dtype.is_floating_point or k.endswith("w_ks.bias"):   # (key bias: mathematically zero gradient, Adam
+            continue                                                   # normalises rounding noise into +-lr steps)
+        a, b = sd[k].double(), v.double()
+        err = float((a - b).norm() / b.norm().clamp_min(1e-12))
+        # unused parameters (anchor_feat, loc_layers: no gradient) decay here and stay put under torch AdamW
+        tol = 5e-3 if ("anchor" in k or "loc_layers" in k or "clf" in k) else 2e-3
+        assert err < tol, (k, err)
+        moved += 1
+    assert moved > 50
+    # the backbone's first convolution really moved
+    k0 = [k for k in sd if "obj_encoder" in k and k.endswith("conv.weight")][0]
+    fresh = _build(False).state_dict()[k0]
+    assert float((sd[k0] - fresh).abs().max()) > 0
+
+
+def test_schedule_hands_back_the_gradient_of_the_object_features():
+    """d obj_embeds of the fused schedule vs autograd through the per-layer path."""
+    from msr3d_amd.synth import synth_batch
+    batch = synth_batch(4, 2, O=12, P=1024, device="cuda")
+    model = _build(True)
+    _set_p0(model)
+    step, dp, _ = _engine(model, batch, use_graph=False)
+    sched = model._schedule
+    e = torch.randn(2, 12, 768, device="cuda", requires_grad=True)
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(2, 12, 512, generator=g).cuda()
+    grads = {}
+    for on in (True, False):
+        sched.enabled = on
+        dp.zero_grad()
+        d = {k: v for k, v in batch.items() if k != "obj_fts"}
+        d["obj_embeds"] = e
+        out = model(d)
+        (ge,) = torch.autograd.grad((out["scene_embeds"] * w).sum(), e)
+        grads[on] = ge.clone()
+    sched.enabled = True
+    err = float((grads[True] - grads[False]).norm() / grads[False].norm())
+    assert err < 1e-5, err
