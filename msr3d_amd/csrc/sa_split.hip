@@ -31,8 +31,8 @@
 //   * one operand buffer rewritten in place by each epilogue (66 KB, two blocks per CU) and blocks
 //     persistent over runs of tiles with the next tile's geometry, ball query and neighbour rows
 //     fetched under the current tile's layers (see the kernel).
-// Measured (16 x 60 objects): 0.531 ms for the f32-MFMA kernel (122 TFLOP/s of the pipe's ~128 at the
-// clock it sustains) -> 0.300 ms; the bf16 pipe is 65-70 % busy, the rest is each block's serial chain
+// Measured (16 x 60 objects): 0.531 ms for the f32-MFMA kernel (122 of the 155.6 TFLOP/s a pure
+// issue loop sustains, tools/probe/mfma_peak.hip) -> 0.300 ms; the bf16 pipe is 56 % busy (PMC), the rest is each block's serial chain
 // of epilogues and barriers (phase stamps: tools/ab_split.py, -DSPLIT_STAMP=1).
 //
 // Same contract as sa_fused.hip (msr3d_sa_level): same index ops (shared code), same folded BN affine
@@ -518,6 +518,159 @@ __global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int til
   }
 }
 
+// =====================================================================================================
+// Level 3 (group-all): xyz (b, 16, 3), feat (b, 16, 256) -> MLP 259 -> 256 -> 512 -> 768, max over the 16
+// points; out (b, 768).  K order [feat(256), xyz(3), 0 x 29].  A tile is TWO objects (32 rows): layer 3's
+// operand (512 wide, three planes) is 101 KB of LDS, so one block per CU, and the level's 3.6 MB of split
+// weights stream past every tile -- the kernel is bound by that stream (~40 B/clk/CU out of L2), not by
+// the matrix pipe.  Hence wide register panels: each wave owns RN = 4 / 8 / 6+6 column tiles and keeps TWO
+// slabs of them (up to 36 KB per wave) in flight, rolled over slab pairs (ping-pong, no register copies).
+// =====================================================================================================
+constexpr int k3TM = 32, k3K0 = 288, k3N1 = 256, k3N2 = 512, k3N3 = 768;
+constexpr int k3Ld = k3N2 + kPadH;           // 528: same bank residue as 144 -- conflict-free b128 reads
+constexpr int k3Plane = k3TM * k3Ld;
+constexpr int kSa3Lds = 3 * k3Plane * 2 + 2 * (k3N1 + k3N2 + k3N3) * 4;
+
+template <int RN, int MT, int NT>
+__device__ __forceinline__ void gemm_split_rolled(const unsigned short *xs, int ldh, int plane, const WStream &wg, int t0,
+                                                  int KS, f32x4 (&acc)[RN][MT], int lane) {
+  const int j = lane & 15, g = lane >> 4;
+  const unsigned short *xp = xs + j * ldh + 8 * g;
+  WPiece wa[RN], wb[RN];
+  auto fetch = [&](WPiece (&w)[RN], int s) {
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn) load_piece<NT>(w[rn], wg, s, t0 + rn, lane);
+  };
+  auto mma = [&](const WPiece (&w)[RN], int s) {
+    bf16x8 x[MT][3];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        x[mt][p] = *reinterpret_cast<const bf16x8 *>(xp + p * plane + mt * 16 * ldh + 32 * s);
+#define MSR3D_TERM(PW, PX)                                                                             \
+    _Pragma("unroll") for (int rn = 0; rn < RN; ++rn)                                                  \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                  \
+        acc[rn][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[rn].v[PW], x[mt][PX], acc[rn][mt], 0, 0, 0);
+    MSR3D_TERM(2, 0)
+    MSR3D_TERM(0, 2)
+    MSR3D_TERM(1, 1)
+    MSR3D_TERM(1, 0)
+    MSR3D_TERM(0, 1)
+    MSR3D_TERM(0, 0)
+#undef MSR3D_TERM
+  };
+  fetch(wa, 0);
+  for (int s = 0; s < KS; s += 2) {
+    fetch(wb, s + 1 < KS ? s + 1 : s);          // (odd slab counts: a harmless re-read)
+    __builtin_amdgcn_sched_barrier(0);
+    mma(wa, s);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(wa, s + 2 < KS ? s + 2 : s);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 1 < KS) mma(wb, s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__global__ __launch_bounds__(256) void sa3_split_kernel(int b, const float *__restrict__ xyz, const float *__restrict__ feat,
+                                                        LayerS l1, LayerS l2, LayerS l3, float *__restrict__ out,
+                                                        const unsigned char *__restrict__ valid) {
+  const int obj0 = blockIdx.x * 2;
+  if (valid && !valid[obj0] && !(obj0 + 1 < b && valid[obj0 + 1])) return;   // (one valid: the other rides along)
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  unsigned short *buf = smem;                                              // [3][32][528] bf16
+  float *aff = reinterpret_cast<float *>(smem + 3 * k3Plane);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  for (int i = tid; i < k3N1; i += 256) { aff[i] = l1.scale[i]; aff[k3N1 + i] = l1.shift[i]; }
+  for (int i = tid; i < k3N2; i += 256) { aff[2 * k3N1 + i] = l2.scale[i]; aff[2 * k3N1 + k3N2 + i] = l2.shift[i]; }
+  for (int i = tid; i < k3N3; i += 256) { aff[2 * (k3N1 + k3N2) + i] = l3.scale[i]; aff[2 * (k3N1 + k3N2) + k3N3 + i] = l3.shift[i]; }
+  const float *sc1 = aff, *sh1 = aff + k3N1, *sc2 = aff + 2 * k3N1, *sh2 = sc2 + k3N2, *sc3 = aff + 2 * (k3N1 + k3N2), *sh3 = sc3 + k3N3;
+  const WStream w1 = make_stream<0>(l1.w, k3K0 * k3N1 * 6, 0, lane);
+  const WStream w2 = make_stream<0>(l2.w, k3N1 * k3N2 * 6, 0, lane);
+  const WStream w3 = make_stream<0>(l3.w, k3N2 * k3N3 * 6, 0, lane);
+  {   // operand: 32 rows x [feat(256), x, y, z, 0 ...]; all loads first, then split + LDS stores
+    constexpr int IT = k3TM * 64 / 256;
+    float4 val[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = tid + it * 256, row = e >> 6, obj = obj0 + (row >> 4);
+      val[it] = obj < b ? *reinterpret_cast<const float4 *>(feat + ((size_t)obj * 16 + (row & 15)) * 256 + (e & 63) * 4)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (tid < k3TM) {
+      const int obj = obj0 + (tid >> 4);
+      if (obj < b) {
+        const float *q = xyz + ((size_t)obj * 16 + (tid & 15)) * 3;
+        px = q[0]; py = q[1]; pz = q[2];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = tid + it * 256;
+      const float v[4] = {val[it].x, val[it].y, val[it].z, val[it].w};
+      uint2 p[3];
+      split4(v, p);
+      unsigned short *d = buf + (e >> 6) * k3Ld + (e & 63) * 4;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2 *>(d + k * k3Plane) = p[k];
+    }
+    if (tid < k3TM) {
+      const float v[4] = {px, py, pz, 0.f};
+      uint2 p[3];
+      split4(v, p);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        unsigned short *d = buf + k * k3Plane + tid * k3Ld + 256;
+        *reinterpret_cast<uint2 *>(d) = p[k];
+#pragma unroll
+        for (int c = 4; c < 32; c += 4) *reinterpret_cast<uint2 *>(d + c) = make_uint2(0u, 0u);
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int MT = k3TM / 16;
+  {
+    constexpr int RN = k3N1 / 64;
+    f32x4 acc[RN][MT];
+    zero_acc(acc);
+    gemm_split_rolled<RN, MT, k3N1 / 16>(buf, k3Ld, k3Plane, w1, wave_u * RN, k3K0 / 32, acc, lane);
+    float4 sc[RN], sh[RN];
+    load_affine4<RN>(sc1, sh1, wave * RN * 16, lane, sc, sh);
+    __syncthreads();                                            // every wave is done reading the operand
+    store_split<RN, MT>(acc, sc, sh, buf, k3Ld, k3Plane, wave * RN * 16, lane);
+  }
+  __syncthreads();
+  {
+    constexpr int RN = k3N2 / 64;
+    f32x4 acc[RN][MT];
+    zero_acc(acc);
+    gemm_split_rolled<RN, MT, k3N2 / 16>(buf, k3Ld, k3Plane, w2, wave_u * RN, k3N1 / 32, acc, lane);
+    float4 sc[RN], sh[RN];
+    load_affine4<RN>(sc2, sh2, wave * RN * 16, lane, sc, sh);
+    __syncthreads();
+    store_split<RN, MT>(acc, sc, sh, buf, k3Ld, k3Plane, wave * RN * 16, lane);
+  }
+  __syncthreads();
+  int groups = b - obj0;
+  groups = groups < 2 ? groups : 2;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {                        // the wave's 12 column tiles, six at a time
+    constexpr int RN = k3N3 / 128;
+    f32x4 acc[RN][MT];
+    zero_acc(acc);
+    const int t0 = wave_u * 2 * RN + pass * RN;
+    gemm_split_rolled<RN, MT, k3N3 / 16>(buf, k3Ld, k3Plane, w3, t0, k3N2 / 32, acc, lane);
+    float4 sc[RN], sh[RN];
+    load_affine4<RN>(sc3, sh3, t0 * 16, lane, sc, sh);
+    float gm[RN][MT][4];
+    group_reduce<RN, MT, 1>(acc, sc, sh, gm);
+    group_finish<RN, MT>(gm, out + (size_t)obj0 * k3N3, k3N3, t0 * 16, groups, lane);
+  }
+}
+
 template <typename K>
 inline hipError_t allow_lds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
@@ -571,6 +724,11 @@ extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius
     sa2_split_kernel<<<blocks, 256, kSa2Lds, st>>>(n, m, (int)tiles, per, r2, pts, feat, new_xyz, make_layer(w1, affine1, 128),
                                                    make_layer(w2, affine2, 128), make_layer(w3, affine3, 256), out, dbg_ball_idx, valid);
 #endif
+  } else if (level == 3) {
+    if (!pts || !feat || n != 16 || m != 1) return MSR3D_EINVAL;
+    if ((e = allow_lds(sa3_split_kernel, kSa3Lds)) != hipSuccess) return (int)e;
+    sa3_split_kernel<<<(b + 1) / 2, 256, kSa3Lds, st>>>(b, pts, feat, make_layer(w1, affine1, 256), make_layer(w2, affine2, 512),
+                                                       make_layer(w3, affine3, 768), out, valid);
   } else {
     return MSR3D_EINVAL;
   }

@@ -130,7 +130,10 @@ def get_plan(net):
     _, pairs2 = _level_spec(net.encoder[1])
     split2 = [_pack_layer_split(conv, bn, _KP0_SPLIT[1] if j == 0 else conv.in_channels, feat_first=(j == 0))
               for j, (conv, bn) in enumerate(pairs2)]
-    plan = {"key": key, "levels": levels, "dims": dims, "split2": split2}
+    _, pairs3 = _level_spec(net.encoder[2])
+    split3 = [_pack_layer_split(conv, bn, _KP0_SPLIT[2] if j == 0 else conv.in_channels, feat_first=(j == 0))
+              for j, (conv, bn) in enumerate(pairs3)]
+    plan = {"key": key, "levels": levels, "dims": dims, "split2": split2, "split3": split3}
     net._fused_plan = plan
     return plan
 
@@ -225,9 +228,15 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
                                         _p(L[1][2]), _p(feat2), _p(dbg.get("ball2")), _p(vmask), st)
         _lib.check(rc, "msr3d_sa_level(2)")
         with _lib.kernel_timer("msr3d_sa_level3"):
-            rc = lib.msr3d_sa_level(3, b, m2, 1, ctypes.c_float(0.0), _p(new2), _p(feat2),
-                                    _p(None), plan["dims"][2], _p(L[2][0]), _p(L[2][1]),
-                                    _p(L[2][2]), _p(pooled), _p(None), _p(vmask), st)
+            if _sa_mma[0] == "split" and m2 == 16:
+                S = plan["split3"]
+                rc = lib.msr3d_sa_level_split(3, b, m2, 1, ctypes.c_float(0.0), _p(new2), _p(feat2), _p(None),
+                                              _p(S[0][0]), _p(S[0][1]), _p(S[1][0]), _p(S[1][1]), _p(S[2][0]),
+                                              _p(S[2][1]), _p(pooled), _p(None), _p(vmask), st)
+            else:
+                rc = lib.msr3d_sa_level(3, b, m2, 1, ctypes.c_float(0.0), _p(new2), _p(feat2),
+                                        _p(None), plan["dims"][2], _p(L[2][0]), _p(L[2][1]),
+                                        _p(L[2][2]), _p(pooled), _p(None), _p(vmask), st)
         _lib.check(rc, "msr3d_sa_level(3)")
     if vmask is not None:
         # skipped rows of `pooled` are uninitialised memory: neutralise them before the GEMM (a NaN

@@ -1,4 +1,4 @@
-"""csrc/sa_split.hip: the level-2 SharedMLP on bf16 MFMA with every fp32 operand split exactly into
+"""csrc/sa_split.hip: the level-2 (and level-3) SharedMLPs on bf16 MFMA with every fp32 operand split exactly into
 three bf16 terms (six products per product, fp32 accumulate) against
 
   * a float64 evaluation of the reference's formulation (QueryAndGroup -> 3 x [conv1x1, BN(eval), ReLU]
@@ -29,7 +29,7 @@ def _net(seed, scale_spread=False):
     if scale_spread:          # weights spanning ~12 binades inside one layer
         g = torch.Generator().manual_seed(seed)
         for k in sd:
-            if k.startswith("encoder.1") and k.endswith("conv.weight"):
+            if k.startswith(("encoder.1", "encoder.2")) and k.endswith("conv.weight"):
                 sd[k] = sd[k] * torch.exp2(torch.randint(-8, 5, sd[k].shape, generator=g).float())
     net.load_state_dict(sd)
     return net.cuda().eval()
@@ -144,3 +144,42 @@ def test_split_persistent_tiles_and_the_valid_mask(objects, keep):
     assert rel(dsp["feat2"][sel], d32["feat2"][sel]) < 2e-6
     assert torch.equal(ysp[~sel], y32[~sel])                      # padding rows: the same constant feature
     assert rel(ysp[sel], y32[sel]) < 2e-6
+
+
+def _level3_float64(net, dbg):
+    """Group-all level from the level-2 internals, float64: [xyz, features] rows of the 16 points ->
+    SharedMLP (BN eval) -> max over the points."""
+    xyz2, feat2 = dbg["new_xyz2"].double(), dbg["feat2"].double()
+    x = torch.cat([xyz2, feat2], dim=-1)                                  # (b, 16, 259), reference K order
+    for conv, bn in net.encoder[2].mlps[0].conv_bn_pairs():
+        x = torch.einsum("bnk,ck->bnc", x, conv.weight.double().view(conv.out_channels, -1))
+        x = (x - bn.running_mean.double()) * torch.rsqrt(bn.running_var.double() + bn.eps) * bn.weight.double() + bn.bias.double()
+        x = torch.relu(x)
+    return x.max(1).values
+
+
+@pytest.mark.parametrize("seed,objects", [(21, 120), (22, 7)])
+def test_split_level3_is_fp32_accurate(seed, objects):
+    """Level 3 on the split path (two objects per tile, odd object counts, rolled slab pairs with an odd
+    slab count in layer 1) against float64 and against the f32-MFMA kernel."""
+    from msr3d_amd.pointnet2 import fused
+    from msr3d_amd.synth import synth_batch
+    net = _net(seed, True)
+    pts = synth_batch(seed, (objects + 59) // 60, O=60, P=1024, device="cuda")["obj_fts"].reshape(-1, 1024, 6)[:objects].contiguous()
+    out = {}
+    for mode in ("f32", "split"):
+        prev = fused.set_sa_mma(mode)
+        try:
+            with torch.no_grad():
+                out[mode] = fused.forward(net, pts, return_internals=True)
+        finally:
+            fused.set_sa_mma(prev)
+    (y32, d32), (ysp, dsp) = out["f32"], out["split"]
+    want = _level3_float64(net, dsp)                   # from the split run's own level-2 output
+    e_sp = rel(dsp["pooled"], want)
+    e_32 = rel(d32["pooled"], _level3_float64(net, d32))
+    assert e_sp < 2e-6 and e_32 < 2e-6, (e_sp, e_32)
+    assert e_sp < 4 * e_32 + 1e-7, (e_sp, e_32)
+    tol = 1e-5 * want.abs().amax(-1, keepdim=True).clamp_min(1e-30)
+    assert ((dsp["pooled"].double() - want).abs() <= tol).all()
+    assert rel(ysp, y32) < 2e-6
