@@ -150,7 +150,7 @@ class Trainer:
             if not y.is_cuda:
                 return (y * state["w"]).sum() / y.numel()
             with torch.no_grad():
-                loss = torch.dot(y.reshape(-1), state["g"].reshape(-1))
+                loss = hipops.dot(y, state["g"])
             return loss, y, state["g"]
 
         self.stepper = HotPathTrainStep(model, self.opt, self.dp, loss_fn, example_batch,

@@ -393,6 +393,13 @@ int msr3d_project_scatter_bf16(int B, int T, int n_scene, int E, int K, const lo
                                void *inputs_embeds, long long *attention_mask, int *map_ws,
                                int *count_out, msr3d_stream_t stream);
 
+/* out[0] = sum_i a[i] b[i] (fp32, n % 4 == 0, 16-byte aligned), one launch, bit-reproducible (per-block
+ * partials added in block order by the last block).  scratch: MSR3D_ADAMW_SCRATCH_FLOATS + 1 floats that
+ * were ZERO at first use (the trailing word is a counter the kernel leaves at zero).  Stands for a scalar
+ * loss head `(y * g).sum()` on the projector output -- what a trainer's reduction of the language-model
+ * loss would be (trainer/leo_trainer.py:180-186); bench.py's synthetic loss uses it. */
+int msr3d_dot_f32(long long n, const float *a, const float *b, float *scratch, float *out, msr3d_stream_t stream);
+
 /* msr3d_sa_level on the bf16 matrix pipe at fp32 accuracy (csrc/sa_split.hip): every fp32 operand is
  * split exactly into three bf16 terms and a product is the six bf16 MFMA products above 2^-24 of it,
  * summed in the fp32 accumulator -- error per product below one fp32 rounding.  Same semantics and

@@ -42,6 +42,43 @@ __global__ __launch_bounds__(256) void sumsq_kernel(long long n4, const float4 *
   if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
+// out[0] = sum a[i] b[i] in ONE launch, bit-reproducible: per-block partials travel through device-
+// coherent stores, the last block to arrive (ticket) adds them in block order.  scratch: kMaxBlocks
+// floats + one int counter (left at zero for the next call).
+__global__ __launch_bounds__(256) void dot_kernel(long long n4, const float4 *__restrict__ a, const float4 *__restrict__ b,
+                                                  float *__restrict__ partial, int *__restrict__ counter,
+                                                  float *__restrict__ out) {
+  float s = 0.f;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n4; t += (long long)gridDim.x * blockDim.x) {
+    const float4 x = a[t], y = b[t];
+    s = fmaf(x.x, y.x, s); s = fmaf(x.y, y.y, s); s = fmaf(x.z, y.z, s); s = fmaf(x.w, y.w, s);
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __shared__ float part[4];
+  __shared__ int ticket;
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(partial + blockIdx.x, (part[0] + part[1]) + (part[2] + part[3]), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (ticket != (int)gridDim.x - 1) return;
+  float t = 0.f;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)
+    t += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = (part[0] + part[1]) + (part[2] + part[3]);
+    __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // `sched` = schedule id | (scheduler steps per optimiser update << 8): accelerate's
 // AcceleratedScheduler steps the LambdaLR num_processes times per update, so with N ranks the
 // reference's lambda sees step * N (0 in the high bits = 1).
@@ -143,6 +180,19 @@ int msr3d_adamw_flat(long long n, float *params, float *grads, float *exp_avg, f
       (int)gsz, step_counter, base_lr, beta1, beta2, eps, weight_decay, max_grad_norm, schedule, warmup_steps,
       total_steps, zero_grad);
   adamw_tick_kernel<<<1, 1, 0, st>>>(step_counter);
+  return (int)hipGetLastError();
+}
+
+int msr3d_dot_f32(long long n, const float *a, const float *b, float *scratch, float *out, msr3d_stream_t stream) {
+  if (n < 0 || (n % 4) != 0) return MSR3D_EINVAL;
+  if (!a || !b || !scratch || !out) return MSR3D_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return MSR3D_EINVAL;
+  const long long n4 = n / 4;
+  long long gsz = (n4 + 255) / 256;
+  if (gsz > kMaxBlocks) gsz = kMaxBlocks;
+  if (gsz < 1) gsz = 1;
+  dot_kernel<<<(int)gsz, 256, 0, (hipStream_t)stream>>>(n4, reinterpret_cast<const float4 *>(a), reinterpret_cast<const float4 *>(b),
+                                                        scratch, reinterpret_cast<int *>(scratch + kMaxBlocks), out);
   return (int)hipGetLastError();
 }
 

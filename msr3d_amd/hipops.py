@@ -656,6 +656,29 @@ def bump_seed(device):
     _lib.check(rc, "msr3d_bump_seed")
 
 
+_dot_scratch = {}
+
+
+def dot(a, b):
+    """sum(a * b) of two fp32 GPU tensors in one bit-reproducible launch (msr3d_dot_f32) -> 0-d tensor."""
+    if not (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.numel() == b.numel()):
+        raise ValueError("dot: two fp32 GPU tensors of the same size")
+    a, b = a.contiguous(), b.contiguous()
+    dev = a.device
+    ws = _dot_scratch.get(dev)
+    if ws is None:
+        ws = _dot_scratch[dev] = torch.zeros(1024 + 1, dtype=torch.float32, device=dev)
+    out = torch.empty((), dtype=torch.float32, device=dev)
+    n = a.numel()
+    if n % 4 or a.data_ptr() % 16 or b.data_ptr() % 16:
+        return torch.dot(a.reshape(-1), b.reshape(-1))
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        rc = lib.msr3d_dot_f32(n, _p(a), _p(b), _p(ws), _p(out), _lib.current_stream_ptr(dev))
+    _lib.check(rc, "msr3d_dot_f32")
+    return out
+
+
 def _next_salt():
     _salt_counter[0] = (_salt_counter[0] + 1) & 0x7FFFFFFF
     return _salt_counter[0]

@@ -48,3 +48,15 @@ def test_flat_adamw_matches_torch(sched):
     # parameters are views of the flat buffer and the module still works / saves
     assert all(p.data_ptr() >= opt_a.flat_p.data_ptr() for p in a.parameters())
     assert set(a.state_dict().keys()) == set(b.state_dict().keys())
+
+
+def test_dot_is_exact_enough_and_bit_reproducible():
+    from msr3d_amd import hipops
+    g = torch.Generator().manual_seed(3)
+    for n in (4, 1024, 960 * 4096, 1000 * 1000):
+        a = torch.randn(n, generator=g).cuda()
+        b = torch.randn(n, generator=g).cuda()
+        want = float((a.double() * b.double()).sum())
+        got = [float(hipops.dot(a, b)) for _ in range(3)]
+        assert got[0] == got[1] == got[2]
+        assert abs(got[0] - want) <= 1e-5 * float((a.double() * b.double()).abs().sum()) + 1e-6
