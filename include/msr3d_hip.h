@@ -405,12 +405,13 @@ int msr3d_dot_f32(long long n, const float *a, const float *b, float *scratch, f
  * summed in the fp32 accumulator -- error per product below one fp32 rounding.  Same semantics and
  * outputs as msr3d_sa_level (same index ops); the parameters arrive pre-split:
  *   wK      [K/32][N/16][3][64][8] bf16: plane p, lane 16 g + i, element j = W_p[16 t + i][32 s + 8 g + j]
- *           (K padded with zeros to a multiple of 32; level 2: 160, level 3: 288, K order [features, xyz]),
+ *           (K padded with zeros to a multiple of 32; level 1: 32, level 2: 160, level 3: 288; K order [features, xyz] for levels 2 and 3),
  *           W = W_0 + W_1 + W_2 with W_0 = bf16(W), W_1 = bf16(W - W_0), W_2 = bf16(W - W_0 - W_1);
  *   affineK [2][N] f32: scale, shift (BN(eval) folded).
- * level: 2 (the dominant kernel) or 3 (group-all: n = 16 points per object, m = 1, pts = the level's
- * xyz (b, 16, 3), feat (b, 16, 256), new_xyz / radius unused, out (b, 768)); level 1 stays on
- * msr3d_sa_level. */
+ * level: 1 (pts (b, n, 6) rows [xyz, rgb], feat unused, K padded 6 -> 32 in the order [xyz, rgb];
+ * dbg_ball_idx is REQUIRED: the (b, m, 32) workspace the ball-query launch fills; m % 4 == 0),
+ * 2 (the dominant kernel) or 3 (group-all: n = 16 points per object, m = 1, pts = the level's
+ * xyz (b, 16, 3), feat (b, 16, 256), new_xyz / radius unused, out (b, 768)). */
 int msr3d_sa_level_split(int level, int b, int n, int m, float radius, const float *pts, const float *feat,
                          const float *new_xyz, const void *w1, const float *affine1, const void *w2,
                          const float *affine2, const void *w3, const float *affine3, float *out,

@@ -671,6 +671,199 @@ __global__ __launch_bounds__(256) void sa3_split_kernel(int b, const float *__re
   }
 }
 
+// =====================================================================================================
+// Level 1: pts (b, n, 6) rows [xyz, rgb]; centres (b, m, 3); ball_idx (b, m, 32) from the ball-query
+// launch.  MLP 6 -> 64 -> 64 -> 128, max over the 32 neighbours; out (b, m, 128).
+//
+// The layers are NARROW (13 k MAC per row against level 2's 70 k): with level 2's layout -- waves split
+// the channels, block barriers around every in-place epilogue -- a tile would be six barriers around
+// 170 MFMAs per wave.  Here the roles are turned: all of the level's split weights (86 KB) sit in LDS for
+// the life of a persistent block, and every WAVE owns one whole neighbourhood (32 rows) and ALL channels,
+// so the layer chain is wave-local.  And it never leaves the registers: with D = W X^T a lane (j, g) ends a
+// layer holding, for row j, channels 16 t + 4 g + r -- eight values per 32-channel slab (tiles 2s, 2s+1) --
+// which is exactly a lane's share of the next layer's X fragment if that layer's K axis is numbered
+// accordingly.  The host packs layers 2 and 3 with that K permutation inside each slab (position (g, e) <->
+// channel 32 s + 16 (e >> 2) + 4 g + (e & 3)), so an epilogue is affine + ReLU + split + two register
+// packs: no LDS writes, no operand reads, no barrier anywhere in the loop.  LDS carries only the weight
+// fragments (1 KB contiguous reads, conflict-free, a group ahead of the MFMAs that use them).
+// The gather is two dependent global round trips (neighbour index -> point row); both are issued a round
+// ahead (the index at the top of the previous round, the point row after its layer 1).
+// =====================================================================================================
+constexpr int k1K0 = 32, k1N1 = 64, k1N2 = 64, k1N3 = 128;
+constexpr int k1W1 = (k1K0 / 32) * (k1N1 / 16) * 3 * kFragS, k1W2 = (k1N1 / 32) * (k1N2 / 16) * 3 * kFragS,
+              k1W3 = (k1N2 / 32) * (k1N3 / 16) * 3 * kFragS;             // bf16 counts: 6144, 12288, 24576
+constexpr int k1Waves = 8;
+constexpr int kSa1Lds = (k1W1 + k1W2 + k1W3) * 2 + 2 * (k1N1 + k1N2 + k1N3) * 4;
+
+// one layer of a wave's 32-row neighbourhood: acc[t][mt] = W tile t (LDS, fragment order [s][t][3][64][8])
+// x X^T (registers).  Pieces are taken TWO at a time (x 2 row tiles = four independent accumulators per
+// product term) and the next two fly under these 24 MFMAs.
+template <int NT, int KS>
+__device__ __forceinline__ void wave_layer(const unsigned short *wl, const bf16x8 (&x)[KS][2][3], f32x4 (&acc)[NT][2], int lane) {
+  static_assert(NT % 2 == 0, "column tiles in pairs");
+  constexpr int NG = KS * NT / 2;
+  const unsigned short *wp = wl + lane * 8;
+  WPiece w[NG][2];                 // fully unrolled; two groups live
+  auto fetch = [&](int grp) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        w[grp][i].v[p] = *reinterpret_cast<const bf16x8 *>(wp + ((grp * 2 + i) * 3 + p) * kFragS);
+  };
+  fetch(0);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int grp = 0; grp < NG; ++grp) {
+    const int q0 = grp * 2, s = q0 / NT, t0 = q0 % NT;
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp + 1 < NG) fetch(grp + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#define MSR3D_TERM(PW, PX)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                      \
+    _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                   \
+        acc[t0 + i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[grp][i].v[PW], x[s][mt][PX], acc[t0 + i][mt], 0, 0, 0);
+    MSR3D_TERM(2, 0)
+    MSR3D_TERM(0, 2)
+    MSR3D_TERM(1, 1)
+    MSR3D_TERM(1, 0)
+    MSR3D_TERM(0, 1)
+    MSR3D_TERM(0, 0)
+#undef MSR3D_TERM
+  }
+}
+
+// relu(acc * scale + shift), split: the lane's accumulators of tiles 2s, 2s+1 ARE its share of slab s of
+// the next layer's operand (K numbered by the host accordingly)
+template <int NT>
+__device__ __forceinline__ void wave_next(const f32x4 (&acc)[NT][2], const float *sc, const float *sh,
+                                          bf16x8 (&x)[NT / 2][2][3], int lane) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const float4 s4 = *reinterpret_cast<const float4 *>(sc + t * 16 + 4 * g);
+    const float4 h4 = *reinterpret_cast<const float4 *>(sh + t * 16 + 4 * g);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const float v[4] = {fmaxf(__builtin_fmaf(acc[t][mt][0], s4.x, h4.x), 0.f), fmaxf(__builtin_fmaf(acc[t][mt][1], s4.y, h4.y), 0.f),
+                          fmaxf(__builtin_fmaf(acc[t][mt][2], s4.z, h4.z), 0.f), fmaxf(__builtin_fmaf(acc[t][mt][3], s4.w, h4.w), 0.f)};
+      uint2 p[3];
+      split4(v, p);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        unsigned *d = reinterpret_cast<unsigned *>(&x[t >> 1][mt][k]) + (t & 1) * 2;
+        d[0] = p[k].x;
+        d[1] = p[k].y;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64 * k1Waves, 1) void sa1_split_kernel(int n, int m, int centres, int rounds, int rounds_per_block,
+                                                                   const float *__restrict__ pts,
+                                                                   const float *__restrict__ new_xyz,
+                                                                   const int *__restrict__ ball_idx, LayerS l1, LayerS l2,
+                                                                   LayerS l3, float *__restrict__ out,
+                                                                   const unsigned char *__restrict__ valid) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  unsigned short *wl1 = smem, *wl2 = wl1 + k1W1, *wl3 = wl2 + k1W2;
+  float *aff = reinterpret_cast<float *>(wl3 + k1W3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int r_end = min(rounds, (int)(blockIdx.x + 1) * rounds_per_block);
+  int r = blockIdx.x * rounds_per_block;
+  if (r >= r_end) return;
+  {   // the level's weights and affines: once per block
+    const uint4 *s1 = reinterpret_cast<const uint4 *>(l1.w), *s2 = reinterpret_cast<const uint4 *>(l2.w),
+                *s3 = reinterpret_cast<const uint4 *>(l3.w);
+    uint4 *d = reinterpret_cast<uint4 *>(smem);
+    for (int i = tid; i < k1W1 / 8; i += 64 * k1Waves) d[i] = s1[i];
+    for (int i = tid; i < k1W2 / 8; i += 64 * k1Waves) d[k1W1 / 8 + i] = s2[i];
+    for (int i = tid; i < k1W3 / 8; i += 64 * k1Waves) d[(k1W1 + k1W2) / 8 + i] = s3[i];
+    for (int i = tid; i < k1N1; i += 64 * k1Waves) { aff[i] = l1.scale[i]; aff[k1N1 + i] = l1.shift[i]; }
+    for (int i = tid; i < k1N2; i += 64 * k1Waves) { aff[2 * k1N1 + i] = l2.scale[i]; aff[2 * k1N1 + k1N2 + i] = l2.shift[i]; }
+    for (int i = tid; i < k1N3; i += 64 * k1Waves) { aff[2 * (k1N1 + k1N2) + i] = l3.scale[i]; aff[2 * (k1N1 + k1N2) + k1N3 + i] = l3.shift[i]; }
+  }
+  const float *sc1 = aff, *sh1 = aff + k1N1, *sc2 = aff + 2 * k1N1, *sh2 = sc2 + k1N2, *sc3 = aff + 2 * (k1N1 + k1N2), *sh3 = sc3 + k1N3;
+  __syncthreads();
+
+  // lane (j, g = 0) carries rows j and 16 + j of the wave's neighbourhood through the gather
+  auto centre_of = [&](int rr) { return min(rr * k1Waves + wave, centres - 1); };   // (a ragged last round repeats the last centre)
+  int pi[2];
+  float2 pa[2], pb[2], pc[2];
+  float cx, cy, cz;
+  auto fetch_idx = [&](int cg) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) pi[mt] = min(max(ball_idx[(size_t)cg * kNS + mt * 16 + j], 0), n - 1);
+  };   // (clamped: an object the valid mask skips has no indices -- any row will do)
+  auto fetch_pts = [&](int cg) {
+    const int obj = cg / m;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const float2 *q = reinterpret_cast<const float2 *>(pts + ((size_t)obj * n + pi[mt]) * 6);
+      pa[mt] = q[0]; pb[mt] = q[1]; pc[mt] = q[2];
+    }
+    const float *ct = new_xyz + (size_t)cg * 3;
+    cx = ct[0]; cy = ct[1]; cz = ct[2];
+  };
+  fetch_idx(centre_of(r));
+  fetch_pts(centre_of(r));
+  for (; r < r_end; ++r) {
+    const int cg = centre_of(r);
+    const bool live = !(valid && !valid[cg / m]);        // wave-uniform
+    const int cgn = centre_of(r + 1 < r_end ? r + 1 : r);
+    // ---- layer-1 operand straight into registers: slab 0, k = 8 g + e; only g = 0 is non-zero ----
+    bf16x8 x1[1][2][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const float v0[4] = {pa[mt].x - cx, pa[mt].y - cy, pb[mt].x - cz, pb[mt].y};
+      const float v1[4] = {pc[mt].x, pc[mt].y, 0.f, 0.f};
+      uint2 p0[3], p1[3];
+      split4(v0, p0);
+      split4(v1, p1);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const uint4 q = g == 0 ? make_uint4(p0[k].x, p0[k].y, p1[k].x, p1[k].y) : make_uint4(0u, 0u, 0u, 0u);
+        x1[0][mt][k] = *reinterpret_cast<const bf16x8 *>(&q);
+      }
+    }
+    fetch_idx(cgn);                                      // next round's neighbours fly under layer 1
+    bf16x8 x2[k1N1 / 32][2][3], x3[k1N2 / 32][2][3];
+    if (live) {
+      f32x4 acc[k1N1 / 16][2];
+      wave_layer<k1N1 / 16, k1K0 / 32>(wl1, x1, acc, lane);
+      wave_next<k1N1 / 16>(acc, sc1, sh1, x2, lane);
+    }
+    fetch_pts(cgn);                                      // next round's point rows fly under layers 2 and 3
+    if (live) {
+      {
+        f32x4 acc[k1N2 / 16][2];
+        wave_layer<k1N2 / 16, k1N1 / 32>(wl2, x2, acc, lane);
+        wave_next<k1N2 / 16>(acc, sc2, sh2, x3, lane);
+      }
+      f32x4 acc[k1N3 / 16][2];
+      wave_layer<k1N3 / 16, k1N2 / 32>(wl3, x3, acc, lane);
+      // relu(affine), max over the 32 rows: the two row tiles per lane, then the 16 lanes of a row
+#pragma unroll
+      for (int t = 0; t < k1N3 / 16; ++t) {
+        const float4 s4 = *reinterpret_cast<const float4 *>(sc3 + t * 16 + 4 * g);
+        const float4 h4 = *reinterpret_cast<const float4 *>(sh3 + t * 16 + 4 * g);
+        float mx[4] = {0.f, 0.f, 0.f, 0.f};              // starting the max at 0 IS the ReLU
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          mx[0] = fmaxf(mx[0], __builtin_fmaf(acc[t][mt][0], s4.x, h4.x));
+          mx[1] = fmaxf(mx[1], __builtin_fmaf(acc[t][mt][1], s4.y, h4.y));
+          mx[2] = fmaxf(mx[2], __builtin_fmaf(acc[t][mt][2], s4.z, h4.z));
+          mx[3] = fmaxf(mx[3], __builtin_fmaf(acc[t][mt][3], s4.w, h4.w));
+        }
+        row16_max4(mx);
+        if (j == 0) *reinterpret_cast<float4 *>(out + (size_t)cg * k1N3 + t * 16 + 4 * g) = make_float4(mx[0], mx[1], mx[2], mx[3]);
+      }
+    }
+  }
+}
+
 template <typename K>
 inline hipError_t allow_lds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
@@ -724,6 +917,24 @@ extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius
     sa2_split_kernel<<<blocks, 256, kSa2Lds, st>>>(n, m, (int)tiles, per, r2, pts, feat, new_xyz, make_layer(w1, affine1, 128),
                                                    make_layer(w2, affine2, 128), make_layer(w3, affine3, 256), out, dbg_ball_idx, valid);
 #endif
+  } else if (level == 1) {
+    // pts (b, n, 6); `feat` unused; dbg_ball_idx is this level's WORKSPACE (b, m, 32), filled by the query launch
+    if (!pts || !new_xyz || !dbg_ball_idx || n <= 0 || m <= 0) return MSR3D_EINVAL;
+    if ((e = launch_ball_query(b, n, 6, m, r2, kNS, new_xyz, pts, dbg_ball_idx, st, valid)) != hipSuccess) return (int)e;
+    if ((e = allow_lds(sa1_split_kernel, kSa1Lds)) != hipSuccess) return (int)e;
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    }
+    const long long rounds = ((long long)b * m + k1Waves - 1) / k1Waves;
+    if (rounds > 0x7fffffffLL) return MSR3D_EINVAL;
+    const int per = (int)((rounds + cus - 1) / cus);
+    const int blocks = (int)((rounds + per - 1) / per);
+    sa1_split_kernel<<<blocks, 64 * k1Waves, kSa1Lds, st>>>(n, m, b * m, (int)rounds, per, pts, new_xyz, dbg_ball_idx,
+                                                           make_layer(w1, affine1, 64), make_layer(w2, affine2, 64),
+                                                           make_layer(w3, affine3, 128), out, valid);
   } else if (level == 3) {
     if (!pts || !feat || n != 16 || m != 1) return MSR3D_EINVAL;
     if ((e = allow_lds(sa3_split_kernel, kSa3Lds)) != hipSuccess) return (int)e;

@@ -93,12 +93,19 @@ def _pack_layer(conv, bn, kp, feat_first):
 _KP0_SPLIT = (32, 160, 288)
 
 
-def _pack_layer_split(conv, bn, kp, feat_first):
+def _pack_layer_split(conv, bn, kp, feat_first, kperm=False):
     """Parameters for msr3d_sa_level_split: the weight split exactly into three bf16 terms, packed in
-    16x16x32 MFMA-fragment order, and the folded BN affine (fp32)."""
+    16x16x32 MFMA-fragment order, and the folded BN affine (fp32).
+    kperm: the K axis of each 32-wide slab numbered the way the previous layer's accumulators lie in the
+    lanes (level 1 keeps its activations in registers: csrc/sa_split.hip) -- fragment position (g, e) of
+    slab s holds channel 32 s + 16 (e >> 2) + 4 g + (e & 3)."""
     flat = _pack_rows(conv, bn, kp, feat_first)
     wp, scale, shift = flat
     n = wp.shape[0]
+    if kperm:
+        k = torch.arange(kp, device=wp.device)
+        s_, g_, e_ = k // 32, (k % 32) // 8, k % 8
+        wp = wp[:, 32 * s_ + 16 * (e_ >> 2) + 4 * g_ + (e_ & 3)]
     w0 = wp.to(torch.bfloat16)
     r1 = wp - w0.float()
     w1 = r1.to(torch.bfloat16)
@@ -130,10 +137,13 @@ def get_plan(net):
     _, pairs2 = _level_spec(net.encoder[1])
     split2 = [_pack_layer_split(conv, bn, _KP0_SPLIT[1] if j == 0 else conv.in_channels, feat_first=(j == 0))
               for j, (conv, bn) in enumerate(pairs2)]
+    _, pairs1 = _level_spec(net.encoder[0])
+    split1 = [_pack_layer_split(conv, bn, _KP0_SPLIT[0] if j == 0 else conv.in_channels, feat_first=False,
+                                kperm=(j > 0)) for j, (conv, bn) in enumerate(pairs1)]
     _, pairs3 = _level_spec(net.encoder[2])
     split3 = [_pack_layer_split(conv, bn, _KP0_SPLIT[2] if j == 0 else conv.in_channels, feat_first=(j == 0))
               for j, (conv, bn) in enumerate(pairs3)]
-    plan = {"key": key, "levels": levels, "dims": dims, "split2": split2, "split3": split3}
+    plan = {"key": key, "levels": levels, "dims": dims, "split1": split1, "split2": split2, "split3": split3}
     net._fused_plan = plan
     return plan
 
@@ -211,9 +221,15 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
         _lib.check(rc, "msr3d_sa_fps2")
         L = plan["levels"]
         with _lib.kernel_timer("msr3d_sa_level1"):
-            rc = lib.msr3d_sa_level(1, b, n, m1, ctypes.c_float(sa1.groupers[0].radius), _p(pts),
-                                    _p(None), _p(new1), plan["dims"][0], _p(L[0][0]), _p(L[0][1]),
-                                    _p(L[0][2]), _p(feat1), _p(ball1), _p(vmask), st)
+            if _sa_mma[0] == "split":
+                S = plan["split1"]
+                rc = lib.msr3d_sa_level_split(1, b, n, m1, ctypes.c_float(sa1.groupers[0].radius), _p(pts), _p(None),
+                                              _p(new1), _p(S[0][0]), _p(S[0][1]), _p(S[1][0]), _p(S[1][1]), _p(S[2][0]),
+                                              _p(S[2][1]), _p(feat1), _p(ball1), _p(vmask), st)
+            else:
+                rc = lib.msr3d_sa_level(1, b, n, m1, ctypes.c_float(sa1.groupers[0].radius), _p(pts),
+                                        _p(None), _p(new1), plan["dims"][0], _p(L[0][0]), _p(L[0][1]),
+                                        _p(L[0][2]), _p(feat1), _p(ball1), _p(vmask), st)
         _lib.check(rc, "msr3d_sa_level(1)")
         with _lib.kernel_timer("msr3d_sa_level2"):
             if _sa_mma[0] == "split":

@@ -68,9 +68,9 @@ def test_split_path_is_fp32_accurate(seed, spread):
             fused.set_sa_mma(prev)
         out[mode] = (y, dbg)
     (y32, d32), (ysp, dsp) = out["f32"], out["split"]
-    assert torch.equal(d32["ball2"], dsp["ball2"]) and torch.equal(d32["feat1"], dsp["feat1"])   # same index path
-    want = _level2_float64(net, d32)
-    e32, esp = rel(d32["feat2"], want), rel(dsp["feat2"], want)
+    assert torch.equal(d32["ball2"], dsp["ball2"]) and torch.equal(d32["ball1"], dsp["ball1"])   # same index path
+    want32, want = _level2_float64(net, d32), _level2_float64(net, dsp)      # each from its own level-1 output
+    e32, esp = rel(d32["feat2"], want32), rel(dsp["feat2"], want)
     assert e32 < 2e-6 and esp < 2e-6, (e32, esp)
     assert esp < 4 * e32 + 1e-7, (e32, esp)                     # same class of error as exact-f32 chains
     # element-wise: no outlier beyond a few fp32 ulps of the row scale
@@ -182,4 +182,53 @@ def test_split_level3_is_fp32_accurate(seed, objects):
     assert e_sp < 4 * e_32 + 1e-7, (e_sp, e_32)
     tol = 1e-5 * want.abs().amax(-1, keepdim=True).clamp_min(1e-30)
     assert ((dsp["pooled"].double() - want).abs() <= tol).all()
+    assert rel(ysp, y32) < 2e-6
+
+
+def _level1_float64(net, pts, dbg):
+    """feat1 (b, 32, 128) in float64 from the points and the kernel's own centres / ball-query indices:
+    QueryAndGroup ([xyz - centre, rgb]) -> SharedMLP (BN eval) -> max over the 32 neighbours."""
+    new1, ball1 = dbg["new_xyz1"].double(), dbg["ball1"].long()
+    b, m, ns = ball1.shape
+    p = pts.double()
+    rows = torch.gather(p, 1, ball1.reshape(b, m * ns, 1).expand(-1, -1, 6)).view(b, m, ns, 6)
+    x = torch.cat([rows[..., :3] - new1.unsqueeze(2), rows[..., 3:]], dim=-1)
+    for conv, bn in net.encoder[0].mlps[0].conv_bn_pairs():
+        x = torch.einsum("bmnk,ck->bmnc", x, conv.weight.double().view(conv.out_channels, -1))
+        x = (x - bn.running_mean.double()) * torch.rsqrt(bn.running_var.double() + bn.eps) * bn.weight.double() + bn.bias.double()
+        x = torch.relu(x)
+    return x.max(2).values
+
+
+@pytest.mark.parametrize("seed,objects,spread", [(31, 64, False), (32, 130, True), (33, 3, True)])
+def test_split_level1_is_fp32_accurate(seed, objects, spread):
+    """Level 1 on the split path (weights resident in LDS, a wave per 16 rows, persistent rounds of four
+    centres, object counts that leave blocks with uneven runs) against float64 and the f32-MFMA kernel."""
+    from msr3d_amd.pointnet2 import fused
+    from msr3d_amd.synth import synth_batch
+    net = _net(seed, spread)
+    if spread:
+        sd = net.state_dict()
+        g = torch.Generator().manual_seed(seed)
+        for k in sd:
+            if k.startswith("encoder.0") and k.endswith("conv.weight"):
+                sd[k] = sd[k] * torch.exp2(torch.randint(-6, 4, sd[k].shape, generator=g).float()).cuda()
+        net.load_state_dict(sd)
+    pts = synth_batch(seed, (objects + 59) // 60, O=60, P=1024, device="cuda")["obj_fts"].reshape(-1, 1024, 6)[:objects].contiguous()
+    out = {}
+    for mode in ("f32", "split"):
+        prev = fused.set_sa_mma(mode)
+        try:
+            with torch.no_grad():
+                out[mode] = fused.forward(net, pts, return_internals=True)
+        finally:
+            fused.set_sa_mma(prev)
+    (y32, d32), (ysp, dsp) = out["f32"], out["split"]
+    assert torch.equal(d32["ball1"], dsp["ball1"])
+    want = _level1_float64(net, pts, dsp)
+    e_sp, e_32 = rel(dsp["feat1"], want), rel(d32["feat1"], want)
+    assert e_sp < 2e-6 and e_32 < 2e-6, (e_sp, e_32)
+    assert e_sp < 4 * e_32 + 1e-7, (e_sp, e_32)
+    tol = 1e-5 * want.abs().amax(-1, keepdim=True).clamp_min(1e-30)
+    assert ((dsp["feat1"].double() - want).abs() <= tol).all()
     assert rel(ysp, y32) < 2e-6
