@@ -405,7 +405,10 @@ int msr3d_dot_f32(long long n, const float *a, const float *b, float *scratch, f
  * summed in the fp32 accumulator -- error per product below one fp32 rounding.  Same semantics and
  * outputs as msr3d_sa_level (same index ops); the parameters arrive pre-split:
  *   wK      [K/32][N/16][3][64][8] bf16: plane p, lane 16 g + i, element j = W_p[16 t + i][32 s + 8 g + j]
- *           (K padded with zeros to a multiple of 32; level 1: 32, level 2: 160, level 3: 288; K order [features, xyz] for levels 2 and 3),
+ *           (K padded with zeros to a multiple of 32; level 1: 32, level 2: 160, level 3: 288; K order [features, xyz] for
+ *           levels 2 and 3; level 1 keeps its activations in registers, so the K axis of ITS layers 2 and 3 is numbered
+ *           the way the previous layer's accumulators lie in the lanes: fragment position (g, e) of slab s holds channel
+ *           32 s + 16 (e >> 2) + 4 g + (e & 3) -- pointnet2/fused.py::_pack_layer_split(kperm=True)),
  *           W = W_0 + W_1 + W_2 with W_0 = bf16(W), W_1 = bf16(W - W_0), W_2 = bf16(W - W_0 - W_1);
  *   affineK [2][N] f32: scale, shift (BN(eval) folded).
  * level: 1 (pts (b, n, 6) rows [xyz, rgb], feat unused, K padded 6 -> 32 in the order [xyz, rgb];
