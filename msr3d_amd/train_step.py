@@ -21,6 +21,10 @@ update of step k.  `step(batch, next_batch)` uses that in two ways:
   * data-parallel: it is issued on the compute stream between the start of the all-reduce and the
     optimiser, so the exchange over xGMI is hidden behind 1.2 ms of independent work.
 Results are identical to the sequential order: every step still encodes and trains one batch.
+
+`freeze: False` (unfrozen backbone): the encoder is part of the differentiated step -- the point
+clouds are a static input, its forward + backward ride in the same graph, and none of the above
+overlap applies (nothing of the next batch can run before this step's update).
 """
 import torch
 
