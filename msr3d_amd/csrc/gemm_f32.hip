@@ -607,21 +607,13 @@ static int plan_gemm(int a_kc, int M, int N, int K, const float *A, int lda, con
   // in steady state; 128-wide tiles halve the traffic but these problems (M = 960 tokens, 0.1-2
   // GFLOP) then have too few workgroups to cover the load latency and time WORSE (ffn1 forward
   // 27 -> 51 us).  So: 64x64 everywhere, split-K only when there are at most 256 tiles.  The
-  // larger tiles stay selectable (MSR3D_GEMM_BIG_TILES=1) for bigger batches.
+  // larger tiles are not selected at these sizes.
   auto ntiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
   int rm = 2, rn = 2;
   // ~2 workgroups per CU; the 2-GFLOP problems (llm_proj's dx and dW) time better with 4 per CU
   // (54.6 -> 47.8 us, 52.8 -> 46.6 us), the 1-GFLOP ones do not care, more than that is worse for all
-  static const int target_env = getenv("MSR3D_GEMM_TARGET_WGS") ? atoi(getenv("MSR3D_GEMM_TARGET_WGS")) : 0;
-  const int target_wgs = target_override > 0 ? target_override
-                         : target_env > 0 ? target_env : ((double)M * N * K >= 0.75e9 ? 1024 : 512);
-  static const int big_tiles = getenv("MSR3D_GEMM_BIG_TILES") ? atoi(getenv("MSR3D_GEMM_BIG_TILES")) : 0;
-  if (big_tiles && allow_big_tiles) {
-    if (ntiles(128, 128) >= 192) { rm = 4; rn = 4; }
-    else if (N >= M && ntiles(64, 128) >= 192) { rm = 2; rn = 4; }
-    else if (ntiles(128, 64) >= 192) { rm = 4; rn = 2; }
-    else if (ntiles(64, 128) >= 192) { rm = 2; rn = 4; }
-  }
+  const int target_wgs = target_override > 0 ? target_override : ((double)M * N * K >= 0.75e9 ? 1024 : 512);
+  (void)allow_big_tiles;           // (the 128-wide tile instantiations remain for callers that ask for them by shape)
   const int BM = 32 * rm, BN = 32 * rn;
   const int tiles = ntiles(BM, BN);
   const int slabs = (K + BK - 1) / BK;
@@ -703,7 +695,7 @@ static int gemm_f32_impl(int a_kc, int b_kc, int M, int N, int K, const float *A
   int rm, rn;
   bool empty;
   // short-reduction forward linears: A-resident kernel (no split-K, no meeting point, no zero-fill)
-  static const int ares_min_n = getenv("MSR3D_GEMM_ARES_MIN_N") ? atoi(getenv("MSR3D_GEMM_ARES_MIN_N")) : 512;
+  constexpr int ares_min_n = 512;
   // (wide outputs, or tall problems -- the unfrozen backbone's SharedMLP layers, up to 983 k rows -- whose
   // row strips alone fill the chip)
   if (a_kc && b_kc && !a_colsum && M > 0 && (N >= ares_min_n || (M >= 8192 && N >= 64)) && K >= 16 && K <= 256 &&
@@ -805,8 +797,6 @@ int msr3d_linear_bwd_f32(int M_tokens, int N_out, int K_in, const float *dy, con
 int msr3d_gemm_multi_f32(int n, const msr3d_gemm_problem_t *pr, msr3d_stream_t stream) {
   if (n < 0 || n > MSR3D_GEMM_MULTI_MAX || (n > 0 && !pr)) return MSR3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  static const bool no_panel = getenv("MSR3D_GEMM_NO_PANEL") != nullptr;     // A/B switch (tools/)
-  static const int run_env = getenv("MSR3D_PANEL_RUN_STAGES") ? atoi(getenv("MSR3D_PANEL_RUN_STAGES")) : 0;
   // The problems of one launch share the chip.  Panel problems (panel_gemm.hip) are cut into K runs
   // of equal LENGTH across the launch -- total (tiles x stages) over ~1.5 workgroups per CU, at least
   // 4 stages -- so that a problem with few tiles and a long reduction is split and one with many tiles
@@ -820,9 +810,8 @@ int msr3d_gemm_multi_f32(int n, const msr3d_gemm_problem_t *pr, msr3d_stream_t s
   // faster on the panel kernel (ffn2 27.9 -> 17.3 us, proj 15.3 -> 12.3 us); launches that mix a dx
   // with weight gradients are not (B4 55.5 vs 60.8 us, B2 24.3 vs 28.1 us) -- co-resident panel
   // workgroups gain nothing from each other -- and stay on the tiled kernel with a per-problem share
-  // of the workgroup budget.  MSR3D_GEMM_PANEL=all / MSR3D_GEMM_NO_PANEL=1 override for A/B runs.
-  static const bool panel_all = getenv("MSR3D_GEMM_PANEL") && getenv("MSR3D_GEMM_PANEL")[0] == 'a';
-  const bool use_panel = !no_panel && (live == 1 || panel_all);
+  // of the workgroup budget.
+  const bool use_panel = live == 1;
   for (int j = 0; j < n; ++j) {
     if (pr[j].M <= 0 || pr[j].N <= 0) continue;
     if ((use_panel || pr[j].single_run) && msr3d::panel_eligible(pr[j])) {
@@ -834,7 +823,6 @@ int msr3d_gemm_multi_f32(int n, const msr3d_gemm_problem_t *pr, msr3d_stream_t s
   const int target = live > 1 ? (768 / live < 192 ? 192 : 768 / live) : 0;
   int run_stages = (int)((units + 383) / 384);
   if (run_stages < 4) run_stages = 4;
-  if (run_env > 0) run_stages = run_env;
   GemmBatch gb;
   msr3d::PanelBatch pb;
   gb.n = pb.n = 0;

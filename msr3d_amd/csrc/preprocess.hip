@@ -380,7 +380,6 @@ int msr3d_preprocess_pcd(int B, int O, int P, const float *points, const unsigne
   if (!points || !colors || !obj_begin || !obj_count || !obj_fts || !obj_locs || !obj_masks)
     return MSR3D_EINVAL;
   const size_t lds = sizeof(double) * (160 + (size_t)P * 3) + sizeof(float) * ((size_t)P * 3 + 256);
-  static const int nt = getenv("MSR3D_PRE_NT") ? atoi(getenv("MSR3D_PRE_NT")) : 256;
 #define LAUNCH_PRE(NT)                                                                              \
   {                                                                                                 \
     static const hipError_t attr = hipFuncSetAttribute(                                             \
@@ -391,7 +390,7 @@ int msr3d_preprocess_pcd(int B, int O, int P, const float *points, const unsigne
         O, P, points, colors, obj_begin, obj_count, rot, pcd_idxs, seed, obj_fts, obj_locs,         \
         obj_masks, idx_out);                                                                        \
   }
-  if (nt == 1024) LAUNCH_PRE(1024) else if (nt == 512) LAUNCH_PRE(512) else LAUNCH_PRE(256)
+  LAUNCH_PRE(256)
   return (int)hipGetLastError();
 }
 

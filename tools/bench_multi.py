@@ -1,5 +1,6 @@
 """Microbenchmark of msr3d_gemm_multi_f32 on the schedule's launch groups (M = 960 tokens);
-MSR3D_GEMM_NO_PANEL=1 routes everything to gemm_f32.hip's kernel for an A/B."""
+(The A/B switches this tool was written with are gone from the library: single-problem launches take the
+panel kernel, mixed launches the tiled one.)"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
