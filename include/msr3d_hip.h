@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 6
+#define MSR3D_ABI_VERSION 7
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -573,6 +573,15 @@ int msr3d_adamw_flat(long long n, float *params, float *grads, float *exp_avg, f
                      float *sumsq_scratch, int *step_counter, float base_lr, float beta1,
                      float beta2, float eps, float weight_decay, float max_grad_norm, int schedule,
                      int warmup_steps, int total_steps, int zero_grad, msr3d_stream_t stream);
+/* The same with a mask: active4[i] == 0 leaves floats 4 i .. 4 i + 3 of params / exp_avg / exp_avg_sq
+ * untouched (no weight decay either) -- a parameter that receives no gradient, which torch.optim.AdamW
+ * skips (`p.grad is None`; the reference trains with find_unused_parameters=True,
+ * trainer/leo_trainer.py:50-52).  NULL = every element active.  n / 4 bytes of device memory. */
+int msr3d_adamw_flat_masked(long long n, float *params, float *grads, float *exp_avg, float *exp_avg_sq,
+                            float *sumsq_scratch, int *step_counter, float base_lr, float beta1,
+                            float beta2, float eps, float weight_decay, float max_grad_norm, int schedule,
+                            int warmup_steps, int total_steps, int zero_grad, const unsigned char *active4,
+                            msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Scene-sample construction on the device: replaces the host-side

@@ -111,6 +111,8 @@ _SIGNATURES = {
     "msr3d_dot_f32": [ctypes.c_longlong, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_adamw_flat": [ctypes.c_longlong, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_float,
                          _c_float, _c_float, _c_float, _c_float, _c_int, _c_int, _c_int, _c_int, _ptr],
+    "msr3d_adamw_flat_masked": [ctypes.c_longlong, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_float,
+                                _c_float, _c_float, _c_float, _c_float, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr],
     "msr3d_sa_fps2": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_sa_level": [_c_int, _c_int, _c_int, _c_int, _c_float, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                        _ptr, _ptr, _ptr, _ptr, _ptr],
@@ -127,7 +129,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 6        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 7        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(long long n4, float4 *__rest
                                                     int *__restrict__ step_ctr, float base_lr,
                                                     float beta1, float beta2, float eps, float wd,
                                                     float max_norm, int sched, int warmup, int total,
-                                                    int zero_grad) {
+                                                    int zero_grad, const unsigned char *__restrict__ active) {
   __shared__ float sh[4];
   __shared__ float red[256];
   if (max_norm > 0.f) {        // fixed-order sum of the block partials (same in every block)
@@ -135,6 +135,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(long long n4, float4 *__rest
   const float decay = 1.0f - lr * wd, w1 = 1.0f - beta1, w2 = 1.0f - beta2;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n4;
        t += (long long)gridDim.x * blockDim.x) {
+    if (active && !active[t]) {      // a parameter that receives no gradient: untouched, as torch.optim.AdamW
+      if (zero_grad) g[t] = make_float4(0.f, 0.f, 0.f, 0.f);      // leaves one whose .grad is None
+      continue;
+    }
     float4 pp = p[t], gg = g[t], mm = m[t], vv = v[t];
 #define UPD(c)                                                  \
     {                                                           \
@@ -163,6 +167,16 @@ int msr3d_adamw_flat(long long n, float *params, float *grads, float *exp_avg, f
                      float *sumsq_scratch, int *step_counter, float base_lr, float beta1,
                      float beta2, float eps, float weight_decay, float max_grad_norm, int schedule,
                      int warmup_steps, int total_steps, int zero_grad, msr3d_stream_t stream) {
+  return msr3d_adamw_flat_masked(n, params, grads, exp_avg, exp_avg_sq, sumsq_scratch, step_counter, base_lr, beta1, beta2,
+                                 eps, weight_decay, max_grad_norm, schedule, warmup_steps, total_steps, zero_grad, nullptr,
+                                 stream);
+}
+
+int msr3d_adamw_flat_masked(long long n, float *params, float *grads, float *exp_avg, float *exp_avg_sq,
+                            float *sumsq_scratch, int *step_counter, float base_lr, float beta1,
+                            float beta2, float eps, float weight_decay, float max_grad_norm, int schedule,
+                            int warmup_steps, int total_steps, int zero_grad, const unsigned char *active4,
+                            msr3d_stream_t stream) {
   if (n < 0 || (n % 4) != 0) return MSR3D_EINVAL;
   if (n == 0) return 0;
   if (!params || !grads || !exp_avg || !exp_avg_sq || !sumsq_scratch || !step_counter)
@@ -178,7 +192,7 @@ int msr3d_adamw_flat(long long n, float *params, float *grads, float *exp_avg, f
       n4, reinterpret_cast<float4 *>(params), reinterpret_cast<float4 *>(grads),
       reinterpret_cast<float4 *>(exp_avg), reinterpret_cast<float4 *>(exp_avg_sq), sumsq_scratch,
       (int)gsz, step_counter, base_lr, beta1, beta2, eps, weight_decay, max_grad_norm, schedule, warmup_steps,
-      total_steps, zero_grad);
+      total_steps, zero_grad, active4);
   adamw_tick_kernel<<<1, 1, 0, st>>>(step_counter);
   return (int)hipGetLastError();
 }

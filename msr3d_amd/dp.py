@@ -121,6 +121,7 @@ class FlatGradAllReduce:
         # hold: gradient accumulation -- micro-batches before the last one must not exchange
         # (begin_micro); the buckets then launch from the LAST micro-batch's hooks, or from start()
         self.hold = False
+        self._probe = None
         # MSR3D_DP_EXCHANGE: "allreduce" (default: one all-reduce per flush) or "rs_ag" (reduce-scatter
         # + all-gather of the same buffer: the two halves of a ring all-reduce as separate collectives,
         # so that the 8-GPU run can A/B what RCCL does with each over the 7 xGMI links)
@@ -157,8 +158,26 @@ class FlatGradAllReduce:
     def mark_ready(self, p):
         """A producer wrote p's gradient into the flat buffer directly (bypassing autograd's
         AccumulateGrad, hence its hook): same bookkeeping as the hook."""
+        if self._probe is not None:
+            self._probe.add(id(p))
         if self.distributed:
             self._on_grad(p)
+
+    def probe_unused(self, run):
+        """Run `run()` (one forward + backward) and return the parameters that received NO gradient --
+        neither through autograd (post-accumulate hooks) nor from a producer that writes the flat buffer
+        directly (mark_ready).  What DDP's find_unused_parameters establishes per step in the reference;
+        here once per configuration, for FlatAdamW.set_unused."""
+        seen = set()
+        self._probe = seen
+        handles = [p.register_post_accumulate_grad_hook(lambda q: seen.add(id(q))) for p in self.order]
+        try:
+            run()
+        finally:
+            for h in handles:
+                h.remove()
+            self._probe = None
+        return [p for p in self.order if id(p) not in seen]
 
     def _on_grad(self, p):
         b = self._bucket_of[id(p)]

@@ -56,6 +56,9 @@ class FlatAdamW:
         self.sumsq = torch.zeros(1024, dtype=torch.float32, device=flat_g.device)   # block partials
         self.step_ctr = torch.zeros(1, dtype=torch.int32, device=flat_g.device)
         self.fused_clip = True
+        # one byte per float4 of the flat buffers: 0 = the parameter it belongs to receives no gradient and
+        # is left alone (set_unused); None until then = everything is updated
+        self.active = None
         self.sync_replicas()
 
     def sync_replicas(self, src=0):
@@ -67,19 +70,33 @@ class FlatAdamW:
         for t in (self.flat_p, self.exp_avg, self.exp_avg_sq, self.step_ctr):
             dist.broadcast(t, src=src, group=self.dp.group)
 
+    def set_unused(self, params):
+        """Parameters that receive no gradient in this configuration (`anchor_feat`, `loc_layers` with
+        situation_type 'as_transform_for_objects', a classification head nobody reads): torch.optim.AdamW
+        skips a parameter whose .grad is None -- no moment update, NO weight decay -- and the reference
+        trains exactly so (DDP with find_unused_parameters=True, trainer/leo_trainer.py:50-52).  Here
+        every parameter has a (zero) gradient view, so the set is stated: these are left untouched."""
+        n4 = self.flat_p.numel() // 4
+        act = torch.ones(n4, dtype=torch.uint8, device=self.flat_p.device)
+        for p in params:
+            off, k = self.dp.offset[id(p)], p.numel()         # (offsets are multiples of 4 elements)
+            act[off // 4:(off + k + 3) // 4] = 0
+        self.active = act if int((act == 0).sum()) else None
+        self.unused = [id(p) for p in params]
+
     def step(self, zero_grad=False):
         lib = _lib.load()
         dev = self.flat_p.device
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         f = ctypes.c_float
         with torch.cuda.device(dev):
-            rc = lib.msr3d_adamw_flat(self.flat_p.numel(), p(self.flat_p), p(self.dp.flat),
-                                      p(self.exp_avg), p(self.exp_avg_sq), p(self.sumsq),
-                                      p(self.step_ctr), f(self.lr), f(self.betas[0]), f(self.betas[1]),
-                                      f(self.eps), f(self.wd), f(self.max_grad_norm or 0.0),
-                                      self.schedule | (self.sched_mult << 8), self.warmup_steps,
-                                      self.total_steps, int(zero_grad), _lib.current_stream_ptr(dev))
-        _lib.check(rc, "msr3d_adamw_flat")
+            rc = lib.msr3d_adamw_flat_masked(
+                self.flat_p.numel(), p(self.flat_p), p(self.dp.flat), p(self.exp_avg), p(self.exp_avg_sq),
+                p(self.sumsq), p(self.step_ctr), f(self.lr), f(self.betas[0]), f(self.betas[1]), f(self.eps),
+                f(self.wd), f(self.max_grad_norm or 0.0), self.schedule | (self.sched_mult << 8),
+                self.warmup_steps, self.total_steps, int(zero_grad),
+                p(self.active) if self.active is not None else None, _lib.current_stream_ptr(dev))
+        _lib.check(rc, "msr3d_adamw_flat_masked")
 
     def state_dict(self, names=None):
         """Per-parameter moments keyed by position in `dp.order` (or by `names[i]`, the parameter

@@ -72,6 +72,8 @@ class HotPathTrainStep:
         self._opt_zeroes = bool(zero_in_optimizer) and self.accum_steps == 1 and not dp.distributed \
             and getattr(optimizer, "fused_clip", False)
         self._sched_direct = False
+        self._probed = False
+        self.unused_parameters = []
         # encoder prefetch (software pipelining over steps)
         self._enc_stream = torch.cuda.Stream() if self.static["obj_embeds"].is_cuda else None
         self._pref = {"key": None, "feats": torch.empty_like(self.static["obj_embeds"]), "event": None}
@@ -249,6 +251,24 @@ class HotPathTrainStep:
         self._micro = snap["micro"]
         self.dp.zero_grad()
 
+    def _probe_unused(self, batch):
+        """Once per step object: which parameters receive no gradient in this configuration (one eager
+        forward + backward under the gradient engine's probe) -> FlatAdamW leaves them untouched, as
+        torch.optim.AdamW leaves a parameter whose .grad is None.  Training state the probe moves (dropout
+        seed, BatchNorm buffers of an unfrozen backbone) is put back."""
+        self._probed = True
+        if not hasattr(self.opt, "set_unused") or not hasattr(self.dp, "probe_unused"):
+            return
+        snap = self._snapshot()
+
+        def run():
+            self._load(batch)
+            self._fwd_bwd(zero=True)
+        unused = self.dp.probe_unused(run)
+        self._restore(snap)              # (also clears the gradients the probe left)
+        self.opt.set_unused(unused)
+        self.unused_parameters = unused
+
     def capture(self, batch, warmup=3):
         """Warm up on a side stream (allocator, autotune, lazy inits), then capture.  The warm-up
         runs REAL steps (with world > 1: real all-reduces, the same on every rank); their effect on
@@ -256,9 +276,12 @@ class HotPathTrainStep:
         before the capture, so training starts from exactly the state the caller prepared."""
         if not self.use_graph:
             return
-        snap = self._snapshot()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            if not self._probed:
+                self._probe_unused(batch)
+        snap = self._snapshot()
         with torch.cuda.stream(s):
             for _ in range(warmup * self.accum_steps):
                 self._load(batch)
@@ -291,6 +314,8 @@ class HotPathTrainStep:
         early: on one GPU on a side stream, overlapping this step's trainable part; data-parallel
         (world > 1) on the compute stream right after backward, where it hides the gradient
         all-reduce."""
+        if not self._probed and self.static["obj_embeds"].is_cuda:
+            self._probe_unused(batch)
         self._load(batch)
         if self.unfrozen:
             next_batch = None           # nothing of the next batch can run before this step's update
