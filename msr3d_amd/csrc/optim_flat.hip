@@ -28,7 +28,10 @@ constexpr int kMaxBlocks = 1024;   // == MSR3D_ADAMW_SCRATCH_FLOATS
 // ranks hold identical gradients after the all-reduce and must derive the identical clip
 // coefficient, or their weights drift apart.
 __global__ __launch_bounds__(256) void sumsq_kernel(long long n4, const float4 *__restrict__ g,
-                                                    float *__restrict__ partial) {
+                                                    float *__restrict__ partial, int *__restrict__ step_ctr) {
+  // (also advances the step counter: it runs before adamw_kernel, which then reads the NEW value --
+  // one launch fewer than a separate tick)
+  if (step_ctr && blockIdx.x == 0 && threadIdx.x == 0) *step_ctr += 1;
   float s = 0.f;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n4;
        t += (long long)gridDim.x * blockDim.x) {
@@ -102,7 +105,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(long long n4, float4 *__rest
                                                     int *__restrict__ step_ctr, float base_lr,
                                                     float beta1, float beta2, float eps, float wd,
                                                     float max_norm, int sched, int warmup, int total,
-                                                    int zero_grad, const unsigned char *__restrict__ active) {
+                                                    int zero_grad, const unsigned char *__restrict__ active,
+                                                    int ticked) {
   __shared__ float sh[4];
   __shared__ float red[256];
   if (max_norm > 0.f) {        // fixed-order sum of the block partials (same in every block)
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(long long n4, float4 *__rest
     }
   }
   if (threadIdx.x == 0) {
-    const int t = *step_ctr + 1;                         // this update's 1-based index
+    const int t = *step_ctr + (ticked ? 0 : 1);          // this update's 1-based index
     const float lr = base_lr * lr_lambda(sched, t - 1, warmup, total);   // LambdaLR: lambda(t-1)
     const double bc1 = 1.0 - pow((double)beta1, (double)t);
     const double bc2 = 1.0 - pow((double)beta2, (double)t);
@@ -186,14 +190,15 @@ int msr3d_adamw_flat_masked(long long n, float *params, float *grads, float *exp
   const long long n4 = n / 4;
   long long gsz = (n4 + 255) / 256;
   if (gsz > kMaxBlocks) gsz = kMaxBlocks;
-  if (max_grad_norm > 0.f)
-    sumsq_kernel<<<(int)gsz, 256, 0, st>>>(n4, reinterpret_cast<const float4 *>(grads), sumsq_scratch);
+  const int ticked = max_grad_norm > 0.f ? 1 : 0;
+  if (ticked)
+    sumsq_kernel<<<(int)gsz, 256, 0, st>>>(n4, reinterpret_cast<const float4 *>(grads), sumsq_scratch, step_counter);
   adamw_kernel<<<(int)gsz, 256, 0, st>>>(
       n4, reinterpret_cast<float4 *>(params), reinterpret_cast<float4 *>(grads),
       reinterpret_cast<float4 *>(exp_avg), reinterpret_cast<float4 *>(exp_avg_sq), sumsq_scratch,
       (int)gsz, step_counter, base_lr, beta1, beta2, eps, weight_decay, max_grad_norm, schedule, warmup_steps,
-      total_steps, zero_grad, active4);
-  adamw_tick_kernel<<<1, 1, 0, st>>>(step_counter);
+      total_steps, zero_grad, active4, ticked);
+  if (!ticked) adamw_tick_kernel<<<1, 1, 0, st>>>(step_counter);
   return (int)hipGetLastError();
 }
 

@@ -122,7 +122,9 @@ __global__ void step_begin_kernel(float4 *__restrict__ z, long long n4, unsigned
 // 16 rows per workgroup: thread c accumulates column c of all 16 rows (weights transposed in LDS,
 // features broadcast from LDS), then the rows are normalised wave-per-row.
 // ------------------------------------------------------------------------------------------------
-constexpr int PR = 16;
+// PR rows per workgroup, chosen so that ~240 workgroups exist (a workgroup's fixed cost is staging Wa,
+// 64 KB out of L2; at 16 rows there were 60 of them doing 4 rows of LayerNorm per wave in sequence).
+template <int PR>
 __global__ __launch_bounds__(256) void pos_embed_fwd_kernel(
     int M, int KF, const float *__restrict__ ff, const float *__restrict__ loc,
     const float *__restrict__ Wa, const float *__restrict__ ba, const float *__restrict__ ga,
@@ -133,27 +135,19 @@ __global__ __launch_bounds__(256) void pos_embed_fwd_kernel(
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float *WT = sm;                    // [64][257]  k-major copy of Wa (row stride 257: the transposing
                                      //            stores of consecutive k land in consecutive banks)
-  float *F = sm + 64 * 257;          // [16][64]   the rows' features, zero-padded (64 * 257 % 4 == 0)
-  float *T = F + PR * 64;            // [2][16][256] pre-norm results, both encoders
+  float *F = sm + 64 * 257;          // [PR][64]   the rows' features, zero-padded (64 * 257 % 4 == 0)
+  float *T = F + PR * 64;            // [2][PR][256] pre-norm results, both encoders
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = blockIdx.x * PR;
-  for (int e0 = 0; e0 < 256 * KF; e0 += 256 * 8) {     // coalesced read of Wa (256, KF), 8 loads in flight
+  // Wa (256, KF) row by row: a wave takes rows wave, wave + 4, ...; lane = k.  Eight row loads in flight,
+  // no index arithmetic beyond an add (the flat e -> (row, k) form cost a division per element).
+  for (int c0 = wave; c0 < 256; c0 += 32) {
     float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int e = e0 + u * 256 + tid;
-      v[u] = e < 256 * KF ? Wa[e] : 0.f;
-    }
+    for (int u = 0; u < 8; ++u) v[u] = lane < KF ? Wa[(size_t)(c0 + 4 * u) * KF + lane] : 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int e = e0 + u * 256 + tid;
-      if (e < 256 * KF) {
-        const int cc = e / KF, k = e - cc * KF;
-        WT[k * 257 + cc] = v[u];
-      }
-    }
+    for (int u = 0; u < 8; ++u) WT[lane * 257 + c0 + 4 * u] = v[u];
   }
-  for (int k = KF; k < 64; ++k) WT[k * 257 + tid] = 0.f;
   for (int e = tid; e < PR * 64; e += 256) {
     const int r = e >> 6, k = e & 63;
     F[e] = (r0 + r < M && k < KF) ? ff[(size_t)(r0 + r) * KF + k] : 0.f;
@@ -308,17 +302,22 @@ int msr3d_pos_embed_fwd(int M, int KF, const float *fourier, const float *locs, 
     return MSR3D_EINVAL;
   if (!al16(gamma_a) || !al16(beta_a) || !al16(gamma_b) || !al16(beta_b) || !al16(pos) || !al16(s_a) || !al16(s_b))
     return MSR3D_EINVAL;
-  const size_t lds = sizeof(float) * (64 * 257 + PR * 64 + 2 * PR * 256);
-  static bool done = false;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pos_embed_fwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    done = true;
-  }
-  pos_embed_fwd_kernel<<<(M + PR - 1) / PR, 256, lds, (hipStream_t)stream>>>(
-      M, KF, fourier, locs, Wa, ba, gamma_a, beta_a, eps_a, Wb, bb, gamma_b, beta_b, eps_b, pos, s_a, stats_a,
-      s_b, stats_b);
+#define LAUNCH_POS(PR)                                                                                   \
+  do {                                                                                                   \
+    const size_t lds = sizeof(float) * (64 * 257 + PR * 64 + 2 * PR * 256);                              \
+    static bool done = false;                                                                            \
+    if (!done) {                                                                                         \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pos_embed_fwd_kernel<PR>),      \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+      if (e != hipSuccess) return (int)e;                                                                \
+      done = true;                                                                                       \
+    }                                                                                                    \
+    pos_embed_fwd_kernel<PR><<<(M + PR - 1) / PR, 256, lds, (hipStream_t)stream>>>(                      \
+        M, KF, fourier, locs, Wa, ba, gamma_a, beta_a, eps_a, Wb, bb, gamma_b, beta_b, eps_b, pos, s_a,  \
+        stats_a, s_b, stats_b);                                                                          \
+  } while (0)
+  if (M > 16 * 192) LAUNCH_POS(16); else if (M > 8 * 192) LAUNCH_POS(8); else LAUNCH_POS(4);
+#undef LAUNCH_POS
   return (int)hipGetLastError();
 }
 
