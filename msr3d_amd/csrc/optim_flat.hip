@@ -52,7 +52,18 @@ __global__ __launch_bounds__(256) void dot_kernel(long long n4, const float4 *__
                                                   float *__restrict__ partial, int *__restrict__ counter,
                                                   float *__restrict__ out) {
   float s = 0.f;
-  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n4; t += (long long)gridDim.x * blockDim.x) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  for (; t + 3 * stride < n4; t += 4 * stride) {          // eight 16-byte loads in flight per thread
+    float4 x[4], y[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { x[u] = a[t + u * stride]; y[u] = b[t + u * stride]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s = fmaf(x[u].x, y[u].x, s); s = fmaf(x[u].y, y[u].y, s); s = fmaf(x[u].z, y[u].z, s); s = fmaf(x[u].w, y[u].w, s);
+    }
+  }
+  for (; t < n4; t += stride) {
     const float4 x = a[t], y = b[t];
     s = fmaf(x.x, y.x, s); s = fmaf(x.y, y.y, s); s = fmaf(x.z, y.z, s); s = fmaf(x.w, y.w, s);
   }
@@ -69,12 +80,12 @@ __global__ __launch_bounds__(256) void dot_kernel(long long n4, const float4 *__
   }
   __syncthreads();
   if (ticket != (int)gridDim.x - 1) return;
-  float t = 0.f;
+  float tot = 0.f;
   for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)
-    t += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    tot += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = tot;
   __syncthreads();
   if (threadIdx.x == 0) {
     out[0] = (part[0] + part[1]) + (part[2] + part[3]);
@@ -208,7 +219,7 @@ int msr3d_dot_f32(long long n, const float *a, const float *b, float *scratch, f
   if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return MSR3D_EINVAL;
   const long long n4 = n / 4;
   long long gsz = (n4 + 255) / 256;
-  if (gsz > kMaxBlocks) gsz = kMaxBlocks;
+  if (gsz > 256) gsz = 256;          // one block per CU: the last block adds 256 partials, one load per thread
   if (gsz < 1) gsz = 1;
   dot_kernel<<<(int)gsz, 256, 0, (hipStream_t)stream>>>(n4, reinterpret_cast<const float4 *>(a), reinterpret_cast<const float4 *>(b),
                                                         scratch, reinterpret_cast<int *>(scratch + kMaxBlocks), out);
