@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def sa2_traffic_from_profiles(kernel="sa2_kernel"):
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_sa*.txt")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_sa*.txt")))     # rNN_vM_...: by name = by age
     for f in reversed(files):
         block, vals = None, {}
         for line in open(f):
