@@ -167,3 +167,28 @@ def test_overlap_with_accumulation_exchanges_once_and_params_are_broadcast(accum
         assert np.allclose(res[r][0], want, rtol=1e-5, atol=1e-7), r
         for a, b in zip(res[r][1], [p.detach().numpy() for p in eng.order]):
             assert np.array_equal(a, b)          # every rank holds rank 0's initial weights
+
+
+def test_probe_unused_finds_parameters_without_a_gradient_and_offsets_are_aligned():
+    """`probe_unused`: one forward/backward under hooks (+ the direct producers' mark_ready) names the
+    parameters that receive no gradient -- what FlatAdamW then leaves untouched, as torch's AdamW leaves
+    `.grad is None`; every parameter starts on a 16-byte boundary of the flat buffer."""
+    from msr3d_amd.dp import FlatGradAllReduce
+    torch.manual_seed(0)
+    model = Toy()
+    eng = FlatGradAllReduce(model.parameters())
+    x = torch.randn(4, 8)
+
+    def run():
+        eng.zero_grad()
+        model(x).sum().backward()
+    unused = eng.probe_unused(run)
+    assert len(unused) == 1 and unused[0] is model.unused
+    # a producer that writes the flat buffer itself reports through mark_ready
+    unused = eng.probe_unused(lambda: eng.mark_ready(model.unused))
+    assert {id(p) for p in unused} == {id(p) for p in (model.a.weight, model.a.bias, model.b.weight, model.b.bias)}
+    assert all(eng.offset[id(p)] % 4 == 0 for p in eng.order)
+    assert eng.flat.numel() % 32 == 0
+    # the hooks are gone afterwards
+    run()
+    assert eng._probe is None
