@@ -228,6 +228,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    if world > 1:
+        # The 21 MB gradient all-reduce runs beside the next batch's encoder and has ~0.6 ms to finish:
+        # eight channels (~20 GB/s each over xGMI) are plenty, and the encoder's persistent kernels then
+        # leave exactly that many CUs free (msr3d_amd/dp.py -> msr3d_set_reserved_cus).  Overridable.
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
     # test hooks (tests/test_bench_ranks_gpu.py): run several ranks on ONE GPU over gloo to
     # exercise the multi-rank code path where only a single device exists
     if os.environ.get("MSR3D_BENCH_SINGLE_DEVICE") == "1":
@@ -384,6 +389,8 @@ def main():
                              dtype=torch.float64)
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
         comm = {"ranks_seen": ranks_seen, "exchange": tr.dp.exchange_mode,
+                "rccl_max_channels": os.environ.get("NCCL_MAX_NCHANNELS"),
+                "cus_left_to_rccl": getattr(tr.dp, "reserved_cus", 0),
                 "grad_bytes": int(tr.dp.numel * 4), "exchanges": len(ar),
                 "allreduce_ms": float(stats[0]), "allreduce_exposed_ms": float(stats[1]),
                 "replica_checksum_spread": spread}

@@ -393,6 +393,13 @@ int msr3d_project_scatter_bf16(int B, int T, int n_scene, int E, int K, const lo
                                void *inputs_embeds, long long *attention_mask, int *map_ws,
                                int *count_out, msr3d_stream_t stream);
 
+/* CUs the persistent set-abstraction kernels (msr3d_sa_level_split levels 1 and 2) leave to OTHER kernels:
+ * their grids are sized to the chip, so a kernel that holds CUs beside them -- RCCL's gradient all-reduce,
+ * issued beside the next batch's frozen encoder in the data-parallel step -- would push the last blocks of
+ * a launch into a second round.  0 (default) on a GPU the step has to itself; msr3d_amd/dp.py sets it to
+ * the number of RCCL channels when world > 1.  0 <= n <= 128; process-wide, takes effect at the next launch. */
+int msr3d_set_reserved_cus(int n);
+
 /* out[0] = sum_i a[i] b[i] (fp32, n % 4 == 0, 16-byte aligned), one launch, bit-reproducible (per-block
  * partials added in block order by the last block).  scratch: MSR3D_ADAMW_SCRATCH_FLOATS + 1 floats that
  * were ZERO at first use (the trailing word is a counter the kernel leaves at zero).  Stands for a scalar

@@ -108,6 +108,7 @@ _SIGNATURES = {
                             _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_project_scatter_bf16": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, ctypes.c_longlong, _ptr, _ptr,
                                    _ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_set_reserved_cus": [_c_int],
     "msr3d_dot_f32": [ctypes.c_longlong, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_adamw_flat": [ctypes.c_longlong, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_float,
                          _c_float, _c_float, _c_float, _c_float, _c_int, _c_int, _c_int, _c_int, _ptr],

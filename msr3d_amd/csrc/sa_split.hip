@@ -40,6 +40,11 @@
 // pointnet2/pointnet2_modules.py:34-75, pytorch_utils.py:11-36.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "../../include/msr3d_hip.h"
 #include "pn2_device.h"
 
@@ -317,9 +322,10 @@ constexpr int kK0 = 160, kN1 = 128, kN2 = 128, kN3 = 256;
 constexpr int kLd = kK0 + kPadH;             // one row pitch for every layer's operand (176: conflict-free b128 reads)
 constexpr int kPlane = kTM * kLd;            // plane stride, bf16 units
 constexpr int kRing = 4;                     // weight pieces in flight per wave (12 KB)
-constexpr int kSa2Lds = 3 * kPlane * 2 + (2 * (kN1 + kN2 + kN3) + 64 * 3 + 16) * 4 + 2 * kNS * 4;
+constexpr int kSa2Lds = 3 * kPlane * 2 + (2 * (kN1 + kN2 + kN3) + 64 * 3 + 16) * 4 + 2 * kNS * 4 + 16;
+constexpr int kChunk = 3;                   // tiles per queue fetch (15 per block at the bench shape: five fetches)
 
-__global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int tiles, int tiles_per_block, float radius2,
+__global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int tiles, int *__restrict__ queue, float radius2,
                                                            const float *__restrict__ xyz, const float *__restrict__ feat,
                                                            const float *__restrict__ new_xyz, LayerS l1, LayerS l2, LayerS l3,
                                                            float *__restrict__ out, int *__restrict__ dbg_idx,
@@ -334,21 +340,54 @@ __global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int til
   float *sx = aff + 2 * (kN1 + kN2 + kN3);                                 // [n][3], n <= 64
   float *ctr = sx + 64 * 3;                                                // [2][4]
   int *nbr = reinterpret_cast<int *>(ctr + 16);                            // [2][32]
+  int *s_next = nbr + 2 * kNS;                                             // [2]: tile hand-over from thread 0
   int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tpo = (m + 1) >> 1;                                            // tiles per object
-  const int t_end = min(tiles, (int)(blockIdx.x + 1) * tiles_per_block);
+  const int t_end = tiles;                                                 // (also the "no tile" value)
 #if SPLIT_STAMP
   unsigned long long *stamps = stamp_base + ((size_t)blockIdx.x * 4 + wave) * 16;
   int tile_no = 0;
 #endif
 
-  auto next_valid = [&](int t) {             // first tile >= t whose object is encoded (uniform)
-    if (valid)
-      while (t < t_end && !valid[t / tpo]) t = (t / tpo + 1) * tpo;
-    return t < t_end ? t : t_end;
+  // Tiles are handed out in CHUNKS of kChunk consecutive tiles from a device-wide queue (queue[0]: next
+  // chunk, queue[1]: blocks finished; the last block to leave resets both for the next launch).  A static
+  // split would be just as good on an idle chip -- but when other kernels hold CUs (the gradient
+  // all-reduce runs beside the next batch's encoder in the data-parallel step) the blocks that start late
+  // would carry a whole share each and double the kernel's time; from a queue they simply take less.
+  // Thread 0 walks the queue; the tile AFTER the next one is published through LDS between two of the
+  // loop's barriers, so the atomic's round trip sits under a layer.
+  int chunk_end = 0;                         // (thread 0's view of the chunk it is consuming)
+  auto advance = [&](int t) {                // thread 0 only: the next encoded tile after t, or t_end
+    ++t;
+    while (true) {
+      if (t >= chunk_end) {
+        const int c = __hip_atomic_fetch_add(queue, kChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c >= tiles) return t_end;
+        t = c;
+        chunk_end = min(c + kChunk, tiles);
+      }
+      if (!valid || valid[t / tpo]) return t;
+      ++t;
+    }
   };
-  int T = next_valid(blockIdx.x * tiles_per_block);
-  if (T >= t_end) return;
+  auto leave = [&]() {                       // thread 0 only
+    const int done = __hip_atomic_fetch_add(queue + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (int)gridDim.x - 1) {
+      __hip_atomic_store(queue, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(queue + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  if (tid == 0) {
+    const int t0 = advance(-1);              // (chunk_end = 0: fetches the first chunk)
+    s_next[0] = t0;
+    s_next[1] = t0 < t_end ? advance(t0) : t_end;
+  }
+  __syncthreads();
+  int T = s_next[0], Tn = s_next[1];
+  if (T >= t_end) {
+    if (tid == 0) leave();
+    return;
+  }
 
   // folded BN affines: once per block
   for (int i = tid; i < kN1; i += 256) { aff[i] = l1.scale[i]; aff[kN1 + i] = l1.shift[i]; }
@@ -438,7 +477,6 @@ __global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int til
 
   while (true) {
     const int obj = T / tpo, c0 = (T - obj * tpo) * 2;
-    const int Tn = next_valid(T + 1);
     const bool more = Tn < t_end;
     // per-lane addresses are re-derived every tile: hoisted out of the loop they would sit in ~40 VGPRs
     // across the layer-3 phase and spill (and a scratch reload's vmcnt(0) drains the weight ring)
@@ -460,10 +498,12 @@ __global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int til
       load_affine4<RN1>(sc1, sh1, wave * RN1 * 16, lane, sc, sh);
       STAMP(1);
       __syncthreads();                                            // (A) every wave is done READING the operand; sx/ctr free
+      if (tid == 0) s_next[0] = more ? advance(Tn) : t_end;       // the tile after the next one
       if (more) geo_store();
       store_split<RN1, MT>(acc, sc, sh, buf, kLd, kPlane, wave * RN1 * 16, lane);
     }
     __syncthreads();                                              // (B) layer-1 planes + next geometry visible
+    const int Tnn = s_next[0];
     STAMP(2);
     if (more) query(Tn);
     {
@@ -515,7 +555,9 @@ __global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int til
 #if SPLIT_STAMP
 #endif
     T = Tn;
+    Tn = Tnn;
   }
+  if (tid == 0) leave();
 }
 
 // =====================================================================================================
@@ -883,6 +925,38 @@ inline LayerS make_layer(const void *w, const float *affine, int n) {
   return l;
 }
 
+// CUs the persistent kernels leave to others (msr3d_set_reserved_cus): their grids are sized to the chip, so
+// a kernel that holds CUs beside them -- RCCL's all-reduce in the data-parallel step -- would push the last
+// blocks of a launch into a second round.
+std::atomic<int> g_reserved_cus{0};
+inline int usable_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, c = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0)
+      c = 256;
+    cus = c;
+  }
+  const int r = g_reserved_cus.load(std::memory_order_relaxed);
+  return cus - r > 8 ? cus - r : 8;
+}
+
+// Work queues of the persistent kernels: two ints per (stream, level), zero between launches (the last
+// block of a launch resets them).  Allocated on first use -- never inside a stream capture: the frozen
+// encoder runs eagerly, and a captured caller has run it eagerly before (warm-up).
+inline int *work_queue(hipStream_t st, int level, hipError_t *err) {
+  static std::mutex mu;
+  static std::map<std::pair<hipStream_t, int>, int *> queues;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = queues.find({st, level});
+  if (it != queues.end()) { *err = hipSuccess; return it->second; }
+  int *q = nullptr;
+  if ((*err = hipMalloc(&q, 2 * sizeof(int))) != hipSuccess) return nullptr;
+  if ((*err = hipMemset(q, 0, 2 * sizeof(int))) != hipSuccess) return nullptr;
+  queues[{st, level}] = q;
+  return q;
+}
+
 }  // namespace
 
 extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius, const float *pts, const float *feat,
@@ -898,23 +972,19 @@ extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius
   if (level == 2) {
     if (!pts || !feat || !new_xyz || n <= 0 || n > 64 || m <= 0) return MSR3D_EINVAL;
     if ((e = allow_lds(sa2_split_kernel, kSa2Lds)) != hipSuccess) return (int)e;
-    static int slots = 0;              // resident blocks: two per CU
-    if (!slots) {
-      int dev = 0, cus = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-        cus = 256;
-      slots = 2 * cus;
-    }
+    const int slots = 2 * usable_cus();        // resident blocks: two per CU
     const long long tiles = (long long)b * ((m + 1) / 2);
-    if (tiles > 0x7fffffffLL) return MSR3D_EINVAL;
-    const int per = (int)((tiles + slots - 1) / slots);
-    const int blocks = (int)((tiles + per - 1) / per);
+    if (tiles > 0x7fffffffLL - kChunk) return MSR3D_EINVAL;
+    const long long chunks = (tiles + kChunk - 1) / kChunk;
+    const int blocks = (int)(chunks < slots ? chunks : slots);
+    int *queue = work_queue(st, 2, &e);
+    if (!queue) return (int)e;
 #if SPLIT_STAMP
     unsigned long long *stamp_base = reinterpret_cast<unsigned long long *>(dbg_ball_idx);
-    sa2_split_kernel<<<blocks, 256, kSa2Lds, st>>>(n, m, (int)tiles, per, r2, pts, feat, new_xyz, make_layer(w1, affine1, 128),
+    sa2_split_kernel<<<blocks, 256, kSa2Lds, st>>>(n, m, (int)tiles, queue, r2, pts, feat, new_xyz, make_layer(w1, affine1, 128),
                                                    make_layer(w2, affine2, 128), make_layer(w3, affine3, 256), out, nullptr, valid, stamp_base);
 #else
-    sa2_split_kernel<<<blocks, 256, kSa2Lds, st>>>(n, m, (int)tiles, per, r2, pts, feat, new_xyz, make_layer(w1, affine1, 128),
+    sa2_split_kernel<<<blocks, 256, kSa2Lds, st>>>(n, m, (int)tiles, queue, r2, pts, feat, new_xyz, make_layer(w1, affine1, 128),
                                                    make_layer(w2, affine2, 128), make_layer(w3, affine3, 256), out, dbg_ball_idx, valid);
 #endif
   } else if (level == 1) {
@@ -922,12 +992,7 @@ extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius
     if (!pts || !new_xyz || !dbg_ball_idx || n <= 0 || m <= 0) return MSR3D_EINVAL;
     if ((e = launch_ball_query(b, n, 6, m, r2, kNS, new_xyz, pts, dbg_ball_idx, st, valid)) != hipSuccess) return (int)e;
     if ((e = allow_lds(sa1_split_kernel, kSa1Lds)) != hipSuccess) return (int)e;
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-        cus = 256;
-    }
+    const int cus = usable_cus();
     const long long rounds = ((long long)b * m + k1Waves - 1) / k1Waves;
     if (rounds > 0x7fffffffLL) return MSR3D_EINVAL;
     const int per = (int)((rounds + cus - 1) / cus);
@@ -944,4 +1009,10 @@ extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius
     return MSR3D_EINVAL;
   }
   return (int)hipGetLastError();
+}
+
+extern "C" int msr3d_set_reserved_cus(int n) {
+  if (n < 0 || n > 128) return MSR3D_EINVAL;
+  g_reserved_cus.store(n, std::memory_order_relaxed);
+  return 0;
 }

@@ -57,6 +57,18 @@ class FlatGradAllReduce:
         self.distributed = self.world > 1 or (
             dist.is_initialized() and os.environ.get("MSR3D_DP_FORCE_EXCHANGE") == "1")
         self.on_gpu = dev.type == "cuda"
+        if self.distributed and self.on_gpu and self.world > 1:
+            # The all-reduce runs BESIDE the next batch's frozen encoder (train_step.py), whose persistent
+            # kernels size their grids to the chip: leave RCCL's workgroups their CUs, or the blocks that find
+            # no CU free start a second round and double the kernel's time.  One CU per channel; the channel
+            # count is RCCL's (NCCL_MAX_NCHANNELS, which bench.py caps) or MSR3D_RESERVE_CUS.
+            n = int(os.environ.get("MSR3D_RESERVE_CUS", os.environ.get("NCCL_MAX_NCHANNELS", "16")))
+            try:
+                from . import _lib
+                _lib.check(_lib.load().msr3d_set_reserved_cus(max(0, min(n, 128))), "msr3d_set_reserved_cus")
+                self.reserved_cus = max(0, min(n, 128))
+            except (OSError, RuntimeError):
+                self.reserved_cus = 0
 
         group_of = {}
         for g in (pack_groups or []):
