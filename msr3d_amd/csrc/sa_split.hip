@@ -942,8 +942,7 @@ inline int usable_cus() {
 }
 
 // Work queues of the persistent kernels: two ints per (stream, level), zero between launches (the last
-// block of a launch resets them).  Allocated on first use -- never inside a stream capture: the frozen
-// encoder runs eagerly, and a captured caller has run it eagerly before (warm-up).
+// block of a launch resets them).  Allocated and cleared on first use of a stream.
 inline int *work_queue(hipStream_t st, int level, hipError_t *err) {
   static std::mutex mu;
   static std::map<std::pair<hipStream_t, int>, int *> queues;
@@ -952,7 +951,9 @@ inline int *work_queue(hipStream_t st, int level, hipError_t *err) {
   if (it != queues.end()) { *err = hipSuccess; return it->second; }
   int *q = nullptr;
   if ((*err = hipMalloc(&q, 2 * sizeof(int))) != hipSuccess) return nullptr;
-  if ((*err = hipMemset(q, 0, 2 * sizeof(int))) != hipSuccess) return nullptr;
+  // zeroed IN STREAM ORDER: the caller's streams do not synchronise with the null stream, where a plain
+  // hipMemset would run (the first launch could then read the counter before it is cleared)
+  if ((*err = hipMemsetAsync(q, 0, 2 * sizeof(int), st)) != hipSuccess) return nullptr;
   queues[{st, level}] = q;
   return q;
 }
