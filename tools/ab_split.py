@@ -1,5 +1,9 @@
-"""A/B timing of msr3d_sa_level_split builds: every tools/_prof/abl/*.so (compiled from sa_split.hip with
-different -D switches) is loaded beside the shipping library and level 2 is timed on the bench's shapes.
+"""A/B timing and phase stamps of msr3d_sa_level_split (level 2): every tools/_prof/abl/*.so -- builds of
+csrc/sa_split.hip with experimental edits -- is loaded beside the shipping library and timed on the bench's
+shapes; tools/_prof/abl/stamp/stamp.so, built with -DSPLIT_STAMP=1, writes s_memtime stamps of one steady-state
+tile per block (the phase table of DESIGN.md 4.1b).
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC -I include -DSPLIT_STAMP=1 \
+          msr3d_amd/csrc/sa_split.hip -o tools/_prof/abl/stamp/stamp.so
     python tools/ab_split.py [--batch 16]"""
 import argparse
 import ctypes
