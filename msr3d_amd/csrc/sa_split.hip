@@ -735,6 +735,7 @@ constexpr int k1K0 = 32, k1N1 = 64, k1N2 = 64, k1N3 = 128;
 constexpr int k1W1 = (k1K0 / 32) * (k1N1 / 16) * 3 * kFragS, k1W2 = (k1N1 / 32) * (k1N2 / 16) * 3 * kFragS,
               k1W3 = (k1N2 / 32) * (k1N3 / 16) * 3 * kFragS;             // bf16 counts: 6144, 12288, 24576
 constexpr int k1Waves = 8;
+constexpr int k1Chunk = 3;                   // rounds per queue fetch (15 per block at the bench shape)
 constexpr int kSa1Lds = (k1W1 + k1W2 + k1W3) * 2 + 2 * (k1N1 + k1N2 + k1N3) * 4;
 
 // one layer of a wave's 32-row neighbourhood: acc[t][mt] = W tile t (LDS, fragment order [s][t][3][64][8])
@@ -802,7 +803,7 @@ __device__ __forceinline__ void wave_next(const f32x4 (&acc)[NT][2], const float
   }
 }
 
-__global__ __launch_bounds__(64 * k1Waves, 1) void sa1_split_kernel(int n, int m, int centres, int rounds, int rounds_per_block,
+__global__ __launch_bounds__(64 * k1Waves, 1) void sa1_split_kernel(int n, int m, int centres, int rounds, int *__restrict__ queue,
                                                                    const float *__restrict__ pts,
                                                                    const float *__restrict__ new_xyz,
                                                                    const int *__restrict__ ball_idx, LayerS l1, LayerS l2,
@@ -813,9 +814,26 @@ __global__ __launch_bounds__(64 * k1Waves, 1) void sa1_split_kernel(int n, int m
   float *aff = reinterpret_cast<float *>(wl3 + k1W3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int r_end = min(rounds, (int)(blockIdx.x + 1) * rounds_per_block);
-  int r = blockIdx.x * rounds_per_block;
-  if (r >= r_end) return;
+  // Rounds (eight neighbourhoods, one per wave) are handed out per BLOCK in chunks of k1Chunk from a device-
+  // wide queue (queue[0]: next round, queue[1]: blocks finished; the last block to leave resets both) -- see
+  // the level-2 kernel for why not a static split.  Thread 0 walks the queue one chunk AHEAD (the chunk after
+  // the one being processed is always known, so the gather prefetch can cross a chunk boundary) and the
+  // waves, otherwise independent, meet at one barrier per chunk to take the next pair over from LDS.
+  // (The same queue per WAVE -- 2,048 waves x 5 returning device-scope atomics on one address -- cost +60 us.)
+  __shared__ int s_chunk[4];                 // [0..1]: the first two chunks; [2..3]: hand-over slots, alternating
+  auto fetch_chunk = [&]() { return __hip_atomic_fetch_add(queue, k1Chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto leave = [&]() {
+    const int done = __hip_atomic_fetch_add(queue + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (int)gridDim.x - 1) {
+      __hip_atomic_store(queue, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(queue + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  if (tid == 0) {
+    const int c0 = fetch_chunk();
+    s_chunk[0] = c0;
+    s_chunk[1] = c0 < rounds ? fetch_chunk() : rounds;
+  }
   {   // the level's weights and affines: once per block
     const uint4 *s1 = reinterpret_cast<const uint4 *>(l1.w), *s2 = reinterpret_cast<const uint4 *>(l2.w),
                 *s3 = reinterpret_cast<const uint4 *>(l3.w);
@@ -849,12 +867,22 @@ __global__ __launch_bounds__(64 * k1Waves, 1) void sa1_split_kernel(int n, int m
     const float *ct = new_xyz + (size_t)cg * 3;
     cx = ct[0]; cy = ct[1]; cz = ct[2];
   };
+  int cur = s_chunk[0], nxt = s_chunk[1];               // (published before the barrier above)
+  if (cur >= rounds) {
+    if (tid == 0) leave();
+    return;
+  }
+  int r = cur, r_end = min(cur + k1Chunk, rounds), par = 0;
+  int pending = rounds;                                   // thread 0: the chunk after `nxt`, fetched a chunk early
+  if (tid == 0 && nxt < rounds) pending = fetch_chunk();
   fetch_idx(centre_of(r));
   fetch_pts(centre_of(r));
-  for (; r < r_end; ++r) {
+  while (true) {
     const int cg = centre_of(r);
     const bool live = !(valid && !valid[cg / m]);        // wave-uniform
-    const int cgn = centre_of(r + 1 < r_end ? r + 1 : r);
+    const bool last_of_chunk = r + 1 >= r_end;
+    const bool more = !last_of_chunk || nxt < rounds;
+    const int cgn = centre_of(!more ? r : (last_of_chunk ? nxt : r + 1));
     // ---- layer-1 operand straight into registers: slab 0, k = 8 g + e; only g = 0 is non-zero ----
     bf16x8 x1[1][2][3];
 #pragma unroll
@@ -903,7 +931,19 @@ __global__ __launch_bounds__(64 * k1Waves, 1) void sa1_split_kernel(int n, int m
         if (j == 0) *reinterpret_cast<float4 *>(out + (size_t)cg * k1N3 + t * 16 + 4 * g) = make_float4(mx[0], mx[1], mx[2], mx[3]);
       }
     }
+    if (!more) break;
+    if (!last_of_chunk) { ++r; continue; }
+    // chunk boundary: everyone moves on to `nxt`; thread 0 hands over the chunk after it
+    if (tid == 0) s_chunk[2 + par] = pending;
+    __syncthreads();
+    cur = nxt;
+    nxt = s_chunk[2 + par];
+    par ^= 1;                                              // (the other slot is rewritten a whole chunk later)
+    r = cur;
+    r_end = min(cur + k1Chunk, rounds);
+    if (tid == 0) pending = nxt < rounds ? fetch_chunk() : rounds;
   }
+  if (tid == 0) leave();
 }
 
 template <typename K>
@@ -996,9 +1036,11 @@ extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius
     const int cus = usable_cus();
     const long long rounds = ((long long)b * m + k1Waves - 1) / k1Waves;
     if (rounds > 0x7fffffffLL) return MSR3D_EINVAL;
-    const int per = (int)((rounds + cus - 1) / cus);
-    const int blocks = (int)((rounds + per - 1) / per);
-    sa1_split_kernel<<<blocks, 64 * k1Waves, kSa1Lds, st>>>(n, m, b * m, (int)rounds, per, pts, new_xyz, dbg_ball_idx,
+    const long long chunks = (rounds + k1Chunk - 1) / k1Chunk;
+    const int blocks = (int)(chunks < cus ? chunks : cus);
+    int *queue = work_queue(st, 1, &e);
+    if (!queue) return (int)e;
+    sa1_split_kernel<<<blocks, 64 * k1Waves, kSa1Lds, st>>>(n, m, b * m, (int)rounds, queue, pts, new_xyz, dbg_ball_idx,
                                                            make_layer(w1, affine1, 64), make_layer(w2, affine2, 64),
                                                            make_layer(w3, affine3, 128), out, valid);
   } else if (level == 3) {
