@@ -232,3 +232,33 @@ def test_split_level1_is_fp32_accurate(seed, objects, spread):
     tol = 1e-5 * want.abs().amax(-1, keepdim=True).clamp_min(1e-30)
     assert ((dsp["feat1"].double() - want).abs() <= tol).all()
     assert rel(ysp, y32) < 2e-6
+
+
+def test_split_path_with_a_ragged_level1():
+    """24 level-1 centres per object and 5 objects: 120 neighbourhoods = 15 rounds of the level-1 kernel (no
+    object boundary on a round boundary), 12-tile objects in level 2 (runs of the tile queue crossing objects),
+    an odd object count in level 3 -- against the f32-MFMA kernels."""
+    from msr3d_amd.modules.layers.pointnet import PointNetPP
+    from msr3d_amd.pointnet2 import fused
+    from msr3d_amd.synth import synth_batch
+    from tests.helpers import fill_state_dict
+    net = PointNetPP(sa_n_points=[24, 16, None], sa_n_samples=[32, 32, None], sa_radii=[0.2, 0.4, None],
+                     sa_mlps=[[3, 64, 64, 128], [128, 128, 128, 256], [256, 256, 512, 768]])
+    net.load_state_dict(fill_state_dict(net.state_dict(), 41))
+    net = net.cuda().eval()
+    pts = synth_batch(41, 1, O=60, P=1024, device="cuda")["obj_fts"].reshape(-1, 1024, 6)[:5].contiguous()
+    with torch.no_grad():
+        assert fused.can_fuse(net, pts)
+    out = {}
+    for mode in ("f32", "split"):
+        prev = fused.set_sa_mma(mode)
+        try:
+            with torch.no_grad():
+                out[mode] = fused.forward(net, pts, return_internals=True)
+        finally:
+            fused.set_sa_mma(prev)
+    (y32, d32), (ysp, dsp) = out["f32"], out["split"]
+    assert torch.equal(d32["ball1"], dsp["ball1"]) and torch.equal(d32["ball2"], dsp["ball2"])
+    for k in ("feat1", "feat2", "pooled"):
+        assert rel(dsp[k], d32[k]) < 2e-6, k
+    assert rel(ysp, y32) < 2e-6
