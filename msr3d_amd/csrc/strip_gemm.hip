@@ -37,8 +37,10 @@ using msr3d::row_ln_bwd;
 
 constexpr int KD = 256;            // reduction length = row width
 constexpr int LDA = KD + 8;        // LDS row stride: conflict-free ds_read_b128 fragments (gemm_f32.hip)
-constexpr int ROWS = 64;           // strip height
-constexpr int RPW = ROWS / 8;      // rows per wave in the prologue
+// Strip height: 64 rows (eight waves: 8 rows each in the prologue, 2 x 4 over a 64 x 64 tile in the product)
+// or, where a launch would otherwise have fewer workgroups than half the chip's CUs (the 256-wide
+// products at 960 tokens: 60), 32 rows -- the same eight waves with half the prologue rows and half the
+// MFMAs each, twice the workgroups.
 
 using P = msr3d_strip_gemm_t;
 
@@ -133,8 +135,9 @@ __device__ __forceinline__ Row4 r4_ln_bwd(const Row4 &d, const Row4 &s, float me
   return o;
 }
 
-template <int PRO>
+template <int PRO, int ROWS>
 __device__ __forceinline__ void stage_strip(const P &p, float *As, float *red, int m0, bool side) {
+  constexpr int RPW = ROWS / 8;      // rows per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cseg = lane & 15, sub = lane >> 4;
   constexpr bool USE1 = PRO != MSR3D_PRO_PLAIN;
@@ -277,8 +280,9 @@ __device__ __forceinline__ void stage_strip(const P &p, float *As, float *red, i
   }
 }
 
-template <int PRO>
+template <int PRO, int ROWS>
 __global__ __launch_bounds__(512) void strip_gemm_kc_kernel(const P p) {
+  constexpr int MTW = ROWS / 32;                        // 16-row tiles per wave
   extern __shared__ __attribute__((aligned(16))) float As[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
@@ -301,10 +305,10 @@ __global__ __launch_bounds__(512) void strip_gemm_kc_kernel(const P p) {
 #pragma unroll
     for (int s = 0; s < 16; ++s) b[s] = ld4(wp + 16 * s);
   }
-  stage_strip<PRO>(p, As, As + ROWS * LDA, m0, blockIdx.x == 0);
+  stage_strip<PRO, ROWS>(p, As, As + ROWS * LDA, m0, blockIdx.x == 0);
   __syncthreads();
 
-  const float *a_base = As + (wm * 32 + i) * LDA + 4 * g;
+  const float *a_base = As + (wm * 16 * MTW + i) * LDA + 4 * g;
   const int epi = p.epi;
   const bool drop = p.p_drop > 0.f;
   const unsigned thresh = msr3d::drop_thresh(p.p_drop);
@@ -314,23 +318,23 @@ __global__ __launch_bounds__(512) void strip_gemm_kc_kernel(const P p) {
   // epilogue of one column group: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg.  No load in
   // here (the bias arrives with the weight panel): a load next to the stores makes the compiler wait
   // vmcnt(0) -- i.e. for the previous store's completion -- before every store.
-  const int rowb = m0 + wm * 32 + g * 4;
-  auto finish = [&](int grp, const f32x4 &acc0, const f32x4 &acc1, float bv) {
+  const int rowb = m0 + wm * 16 * MTW + g * 4;
+  auto finish = [&](int grp, const f32x4 (&acc)[MTW], float bv) {
     const int col = grp * 64 + wn * 16 + i;
     const bool cok = col < N;
-    float v[8];
+    float v[4 * MTW];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = ((e & 4) ? acc1[e & 3] : acc0[e & 3]) + bv;
+    for (int e = 0; e < 4 * MTW; ++e) v[e] = acc[e >> 2][e & 3] + bv;
     if (epi == MSR3D_EPI_GELU) {
       if (p.Cpre) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < 4 * MTW; ++e) {
           const int row = rowb + (e >> 2) * 16 + (e & 3);
           if (cok && row < p.M) p.Cpre[(size_t)row * p.ldc + col] = v[e];
         }
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      for (int e = 0; e < 4 * MTW; ++e) {
         const int row = rowb + (e >> 2) * 16 + (e & 3);
         v[e] = msr3d::gelu_exact(v[e]);
         if (drop)
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(512) void strip_gemm_kc_kernel(const P p) {
       }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < 4 * MTW; ++e) {
       const int row = rowb + (e >> 2) * 16 + (e & 3);
       if (cok && row < p.M) p.C[(size_t)row * p.ldc + col] = v[e];
     }
@@ -351,7 +355,9 @@ __global__ __launch_bounds__(512) void strip_gemm_kc_kernel(const P p) {
   // Software pipeline over the column groups: [issue the NEXT group's weight panel] [this group's
   // MFMAs] [the PREVIOUS group's epilogue and stores].  The panel loads have a whole MFMA phase to
   // land, and no wait ever sits behind a freshly issued store.
-  f32x4 pacc0 = {0.f, 0.f, 0.f, 0.f}, pacc1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 pacc[MTW];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) pacc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bv_cur = bias_of(grp0), bv_prev = 0.f;
   // one pipeline stage; the two panel buffers alternate roles (no register copy, hence no wait for
   // the freshly loaded panel -- nor for the stores issued after it -- at the end of a stage)
@@ -362,23 +368,27 @@ __global__ __launch_bounds__(512) void strip_gemm_kc_kernel(const P p) {
     for (int s = 0; s < 16; ++s) bnx[s] = ld4(wnext + 16 * s);   // (last group: a re-read, unused)
     const float bv_next = bias_of(more ? grp + 1 : grp);
     __builtin_amdgcn_sched_barrier(0);                  // keep the loads in front of the MFMA phase
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const float4 a0 = ld4(a_base + 16 * s);
-      const float4 a1 = ld4(a_base + 16 * LDA + 16 * s);
+      float4 a[MTW];
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) a[mt] = ld4(a_base + mt * 16 * LDA + 16 * s);
       const float4 bb = bc[s];
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bb.x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bb.x, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bb.y, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bb.y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bb.z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bb.z, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bb.w, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bb.w, acc1, 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, bb.x, acc[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, bb.y, acc[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, bb.z, acc[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, bb.w, acc[mt], 0, 0, 0);
     }
-    if (grp > grp0) finish(grp - 1, pacc0, pacc1, bv_prev);
-    pacc0 = acc0; pacc1 = acc1;
+    if (grp > grp0) finish(grp - 1, pacc, bv_prev);
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) pacc[mt] = acc[mt];
     bv_prev = bv_cur; bv_cur = bv_next;
   };
   float4 b2[16];
@@ -386,7 +396,7 @@ __global__ __launch_bounds__(512) void strip_gemm_kc_kernel(const P p) {
     stage(b, b2, grp);
     if (grp + 1 < grp1) stage(b2, b, grp + 1);
   }
-  finish(grp1 - 1, pacc0, pacc1, bv_prev);
+  finish(grp1 - 1, pacc, bv_prev);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -396,35 +406,41 @@ __global__ __launch_bounds__(512) void strip_gemm_kc_kernel(const P p) {
 // 4 i + t; wave (wr, wc) owns the 16-row tile wr and tiles {2 wc, 2 wc + 1}, i.e. one 8-byte load
 // per k fetches both of its B values and one 8-byte store per row writes both results.
 // ------------------------------------------------------------------------------------------------
-template <int PRO>
+template <int PRO, int ROWS>
 __global__ __launch_bounds__(512) void strip_gemm_kr_kernel(const P p) {
+  // 64-row strips: wave (wr, wc) owns the 16-row tile wr (of four) and column tiles {2 wc, 2 wc + 1} -- CT = 2
+  // values per 8-byte load / store; 32-row strips: row tile wr (of two) and the single column tile wc -- CT = 1.
+  constexpr int CT = ROWS / 32;
   extern __shared__ __attribute__((aligned(16))) float As[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
-  const int wr = wave & 3, wc = wave >> 2;
+  const int wr = CT == 2 ? (wave & 3) : (wave & 1), wc = CT == 2 ? (wave >> 2) : (wave >> 1);
   const int m0 = blockIdx.y * ROWS;
   const int N = p.N, NG = p.groups_per_wg;
   const int grp0 = blockIdx.x * NG;
   const int grp1 = min(N >> 6, grp0 + NG);              // N % 64 == 0 (checked by the host entry)
   const float *__restrict__ W = p.W;
   const int ldw = p.ldw;
+  auto ldc = [&](const float *q, float (&v)[CT]) {      // CT consecutive floats
+    if (CT == 2) { const float2 t = *reinterpret_cast<const float2 *>(q); v[0] = t.x; v[CT - 1] = t.y; }
+    else v[0] = *q;
+  };
 
-  // element (s, q) = W[(16 s + 4 g + q)][n0 + 4 i + 2 wc + {0, 1}].  Eight slabs (half a panel) live in
+  // element (s, q) = W[(16 s + 4 g + q)][n0 + 4 i + CT wc + {0 .. CT-1}].  Eight slabs (half a panel) live in
   // registers: slab s sits in slot s % 8 and is replaced by slab s + 8 right after its use, i.e. the
   // weight stream runs half a column group (~1 us of MFMA) ahead of the product.
-  const float *wbase = W + (size_t)(4 * g) * ldw + 4 * i + 2 * wc;
-  float2 b[8][4];
+  const float *wbase = W + (size_t)(4 * g) * ldw + 4 * i + CT * wc;
+  float b[8][4][CT];
   auto load_ring = [&]() {
 #pragma unroll
     for (int s = 0; s < 8; ++s)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        b[s][q] = *reinterpret_cast<const float2 *>(wbase + (size_t)(16 * s + q) * ldw + grp0 * 64);
+      for (int q = 0; q < 4; ++q) ldc(wbase + (size_t)(16 * s + q) * ldw + grp0 * 64, b[s][q]);
   };
   // (the two-LayerNorm backward prologue needs the registers: its weight ring is fetched afterwards)
   constexpr bool LATE_B = PRO == MSR3D_PRO_LN2BWD;
   if (!LATE_B) load_ring();
-  stage_strip<PRO>(p, As, As + ROWS * LDA, m0, blockIdx.x == 0);
+  stage_strip<PRO, ROWS>(p, As, As + ROWS * LDA, m0, blockIdx.x == 0);
   if (LATE_B) load_ring();
   __syncthreads();
 
@@ -436,70 +452,79 @@ __global__ __launch_bounds__(512) void strip_gemm_kr_kernel(const P p) {
   const unsigned long long sd = drop ? *p.seed : 0ull;
 
   // epilogue of one column group (its saved pre-activations were fetched a whole group earlier)
-  auto finish = [&](int grp, const f32x4 &acc0, const f32x4 &acc1, const float2 (&pre)[4]) {
-    const int colb = grp * 64 + 4 * i + 2 * wc;
+  auto finish = [&](int grp, const f32x4 (&acc)[CT], const float (&pre)[4][CT]) {
+    const int colb = grp * 64 + 4 * i + CT * wc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + wr * 16 + g * 4 + r;
       if (row >= p.M) continue;
-      float v0 = acc0[r], v1 = acc1[r];
+      float v[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) v[c] = acc[c][r];
       const size_t o = (size_t)row * p.ldc + colb;
       if (epi == MSR3D_EPI_GELUBWD) {
         // d pre = dropout-bwd(d h) * gelu'(pre); the forward's mask index is row * N + col
-        if (drop) {
-          const unsigned mi = (unsigned)((size_t)row * N + colb);
-          v0 = msr3d::keep_elem(sd, p.salt, mi, thresh) ? v0 * dscale : 0.f;
-          v1 = msr3d::keep_elem(sd, p.salt, mi + 1, thresh) ? v1 * dscale : 0.f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          if (drop) {
+            const unsigned mi = (unsigned)((size_t)row * N + colb) + c;
+            v[c] = msr3d::keep_elem(sd, p.salt, mi, thresh) ? v[c] * dscale : 0.f;
+          }
+          v[c] *= msr3d::gelu_exact_grad(pre[r][c]);
         }
-        v0 *= msr3d::gelu_exact_grad(pre[r].x);
-        v1 *= msr3d::gelu_exact_grad(pre[r].y);
       }
-      *reinterpret_cast<float2 *>(p.C + o) = make_float2(v0, v1);
+      if (CT == 2) *reinterpret_cast<float2 *>(p.C + o) = make_float2(v[0], v[CT - 1]);
+      else p.C[o] = v[0];
     }
   };
   // same software pipeline as the forward kernel: [refills + this group's pre-activations]
   // [MFMAs] [the previous group's epilogue]
-  f32x4 pacc0 = {0.f, 0.f, 0.f, 0.f}, pacc1 = {0.f, 0.f, 0.f, 0.f};
-  float2 ppre[4] = {};
+  f32x4 pacc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) pacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float ppre[4][CT] = {};
   for (int grp = grp0; grp < grp1; ++grp) {
     const bool more = grp + 1 < grp1;
     const int n0 = grp * 64, nn = (more ? grp + 1 : grp) * 64;
-    float2 pre[4] = {};
+    float pre[4][CT] = {};
     if (epi == MSR3D_EPI_GELUBWD) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = min(m0 + wr * 16 + g * 4 + r, p.M - 1);
-        pre[r] = *reinterpret_cast<const float2 *>(p.pre_in + (size_t)row * N + n0 + 4 * i + 2 * wc);
+        ldc(p.pre_in + (size_t)row * N + n0 + 4 * i + CT * wc, pre[r]);
       }
     }
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const float4 a = ld4(a_base + 16 * s);
-      float2 bb[4];
+      const float av[4] = {a.x, a.y, a.z, a.w};
+      float bb[4][CT];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        bb[q] = b[s & 7][q];
-        if (s < 8)
-          b[s][q] = *reinterpret_cast<const float2 *>(wbase + (size_t)(16 * (s + 8) + q) * ldw + n0);
-        else      // (last group: nn == n0, a harmless re-read)
-          b[s - 8][q] = *reinterpret_cast<const float2 *>(wbase + (size_t)(16 * (s - 8) + q) * ldw + nn);
-      }
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bb[0].x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bb[0].y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bb[1].x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bb[1].y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bb[2].x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bb[2].y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bb[3].x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bb[3].y, acc1, 0, 0, 0);
-    }
-    if (grp > grp0) finish(grp - 1, pacc0, pacc1, ppre);
-    pacc0 = acc0; pacc1 = acc1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ppre[r] = pre[r];
+        for (int c = 0; c < CT; ++c) bb[q][c] = b[s & 7][q][c];
+        if (s < 8)
+          ldc(wbase + (size_t)(16 * (s + 8) + q) * ldw + n0, b[s][q]);
+        else      // (last group: nn == n0, a harmless re-read)
+          ldc(wbase + (size_t)(16 * (s - 8) + q) * ldw + nn, b[s - 8][q]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bb[q][c], acc[c], 0, 0, 0);
+    }
+    if (grp > grp0) finish(grp - 1, pacc, ppre);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) pacc[c] = acc[c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) ppre[r][c] = pre[r][c];
   }
-  finish(grp1 - 1, pacc0, pacc1, ppre);
+  finish(grp1 - 1, pacc, ppre);
 }
 
 inline bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
@@ -534,8 +559,11 @@ extern "C" int msr3d_strip_gemm_f32(const msr3d_strip_gemm_t *pp, msr3d_stream_t
   }
   if (p.epi != MSR3D_EPI_BIAS && p.epi != MSR3D_EPI_GELU && p.epi != MSR3D_EPI_GELUBWD) return MSR3D_EINVAL;
   if (p.epi == MSR3D_EPI_GELU && p.p_drop > 0.f && p.ldc != p.N) return MSR3D_EINVAL;   // mask index = row * N + col
-  const int strips = (p.M + ROWS - 1) / ROWS;
   const int ngroups = (p.N + 63) / 64;
+  // 32-row strips where 64-row ones would leave more than half of the chip without a workgroup
+  const bool half = (long long)ngroups * ((p.M + 63) / 64) <= 128 && p.M > 32;
+  const int ROWS = half ? 32 : 64;
+  const int strips = (p.M + ROWS - 1) / ROWS;
   int ng = p.groups_per_wg;
   if (ng <= 0) {                     // about one workgroup per CU
     ng = (ngroups * strips + 128) / 256;
@@ -554,28 +582,33 @@ extern "C" int msr3d_strip_gemm_f32(const msr3d_strip_gemm_t *pp, msr3d_stream_t
     if (p.epi == MSR3D_EPI_GELUBWD && !p.pre_in) return MSR3D_EINVAL;
     if (p.pro != MSR3D_PRO_PLAIN && !bwd) return MSR3D_EINVAL;      // the backward products' prologues
   }
-#define LAUNCH(KERN)                                                                                  \
+#define LAUNCH1(KERN, PROC, R)                                                                              \
   do {                                                                                                \
     static bool attr_done = false;                                                                    \
     if (!attr_done) {                                                                                 \
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&KERN),                 \
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&KERN<PROC, R>),        \
                                                hipFuncAttributeMaxDynamicSharedMemorySize,            \
-                                               (int)(sizeof(float) * (ROWS * LDA + 4 * 8 * KD)));     \
+                                               (int)(sizeof(float) * (R * LDA + 4 * 8 * KD)));        \
       if (e != hipSuccess) return (int)e;                                                             \
       attr_done = true;                                                                               \
     }                                                                                                 \
-    KERN<<<grid, 512, lds, st>>>(p);                                                                  \
+    KERN<PROC, R><<<grid, 512, lds, st>>>(p);                                                         \
+  } while (0)
+#define LAUNCH(KERN, PROC)                                                                                  \
+  do {                                                                                                \
+    if (half) LAUNCH1(KERN, PROC, 32); else LAUNCH1(KERN, PROC, 64);                                  \
   } while (0)
   switch (p.pro) {
     case MSR3D_PRO_PLAIN:
-      if (p.b_kc) LAUNCH(strip_gemm_kc_kernel<MSR3D_PRO_PLAIN>); else LAUNCH(strip_gemm_kr_kernel<MSR3D_PRO_PLAIN>);
+      if (p.b_kc) LAUNCH(strip_gemm_kc_kernel, MSR3D_PRO_PLAIN); else LAUNCH(strip_gemm_kr_kernel, MSR3D_PRO_PLAIN);
       break;
-    case MSR3D_PRO_ADD: LAUNCH(strip_gemm_kc_kernel<MSR3D_PRO_ADD>); break;
-    case MSR3D_PRO_LN: LAUNCH(strip_gemm_kc_kernel<MSR3D_PRO_LN>); break;
-    case MSR3D_PRO_LN2: LAUNCH(strip_gemm_kc_kernel<MSR3D_PRO_LN2>); break;
-    case MSR3D_PRO_LNBWD: LAUNCH(strip_gemm_kr_kernel<MSR3D_PRO_LNBWD>); break;
-    default: LAUNCH(strip_gemm_kr_kernel<MSR3D_PRO_LN2BWD>); break;
+    case MSR3D_PRO_ADD: LAUNCH(strip_gemm_kc_kernel, MSR3D_PRO_ADD); break;
+    case MSR3D_PRO_LN: LAUNCH(strip_gemm_kc_kernel, MSR3D_PRO_LN); break;
+    case MSR3D_PRO_LN2: LAUNCH(strip_gemm_kc_kernel, MSR3D_PRO_LN2); break;
+    case MSR3D_PRO_LNBWD: LAUNCH(strip_gemm_kr_kernel, MSR3D_PRO_LNBWD); break;
+    default: LAUNCH(strip_gemm_kr_kernel, MSR3D_PRO_LN2BWD); break;
   }
 #undef LAUNCH
+#undef LAUNCH1
   return (int)hipGetLastError();
 }
