@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 7
+#define MSR3D_ABI_VERSION 8
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -527,6 +527,109 @@ int msr3d_pos_embed_bwd(int M, const float *d0, const float *d1, const float *d2
                         const float *stats_b, const float *gamma_b, float *d_lin_a, float *d_lin_b,
                         float *dgamma_a, float *dbeta_a, float *dgamma_b, float *dbeta_b,
                         float *colsum1, float *colsum2, msr3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * The trainable part as SCENE-LOCAL fused blocks on the bf16 matrix pipe at fp32 accuracy
+ * (round 3; /root/reference/modules/layers/transformers.py:200-252,314-329 and their autograd).
+ *
+ * Every fp32 operand is split exactly into three bf16 terms and a product is six bf16 MFMA products
+ * accumulated in fp32 (csrc/split_mma.h; the arithmetic of msr3d_sa_level_split).  Weights are split
+ * and packed in MFMA fragment order once per optimiser step (msr3d_split_pack); activations are split
+ * where they are produced and never leave the chip between the two products of a block.
+ *
+ * A block's unit of work is one scene (L <= 64 token rows = one 64-row tile) x one slice:
+ *
+ *   ATTN_FWD   (scene, head)      rows = prologue(..)            -> xin        (dropout+add+LayerNorm chain of
+ *                                 [q|k|v|cond]_h = rows W_h^T + b                msr3d_strip_gemm_f32's PRO codes)
+ *                                 ctx_h = spatial attention (attn_core.h)
+ *                                 acc  += ctx_h Wfc[:, 32h:32h+32]^T (+ bfc)    8 partial products meet by atomicAdd
+ *   FFN_FWD    (scene, 128 hidden) rows = LN2 prologue; pre = rows W1_s^T + b1; h = dropout(gelu(pre))
+ *                                 acc  += h W2[:, s]^T (+ b2)                   the (M, 2048) activation feeds the
+ *                                                                               second product from LDS
+ *   FFN_BWD    (scene, 128 hidden) rows = LN-bwd prologue (d_ffn); d_h = rows W2[:, s]; d_pre = gelu-bwd
+ *                                 acc  += d_pre W1[s, :]
+ *   ATTN_BWD   (scene, head)      rows = LN-LN-bwd prologue (d_fc); d_ctx_h = rows Wfc[:, 32h:..]
+ *                                 d[q|k|v|cond]_h = attention backward
+ *                                 acc  += d[q|k|v|cond]_h W_h
+ *   LINEAR     (scene, 256 cols)  C = prologue(..) W^T + b                      (llm_proj)
+ *   LINEAR_KSPLIT (scene, 256 k)  acc += a0[:, 256 s : 256 s + 256] W[.., s]^T  (d tokens = d scene . W_llm)
+ *
+ * Side outputs (pre-norm sums, statistics, layer inputs, q|k|v|cond, ctx, probabilities, pre, h, and in
+ * backward d_ffn, d_pre, d_fc, d[q|k|v|cond]) are written by the slice that owns them, dense f32, for the
+ * backward blocks and the weight-gradient launch (msr3d_wgrad_split).  `acc` (M, 256) must be zero on
+ * entry (msr3d_step_begin); in the backward kinds the residual gradient of the prologue is ADDED to o1
+ * atomically (o1 usually == acc).
+ * ------------------------------------------------------------------------- */
+typedef struct msr3d_pack_job {
+  const float *src; int ld;     /* source matrix (row-major f32), row stride */
+  int transposed;               /* 0: Op(n, k) = src[map(n) * ld + k];  1: Op(n, k) = src[map(k) * ld + n] */
+  int rows, k;                  /* operand shape: rows % 16 == 0, k % 32 == 0; unmapped positions are zero */
+  int nseg;                     /* the map over the mapped axis: up to 4 runs dst -> src */
+  int seg_dst[4], seg_len[4], seg_src[4];
+  unsigned short *dst;          /* [k/32][rows/16][3 planes][64 lanes][8] bf16 */
+} msr3d_pack_job_t;
+
+/* jobs, piece_prefix (njobs + 1 ints: first (slab, tile) piece of each job; [njobs] = total): DEVICE memory. */
+int msr3d_split_pack(int njobs, const msr3d_pack_job_t *jobs, const int *piece_prefix, int total_pieces,
+                     msr3d_stream_t stream);
+
+#define MSR3D_BLK_ATTN_FWD 0
+#define MSR3D_BLK_FFN_FWD 1
+#define MSR3D_BLK_FFN_BWD 2
+#define MSR3D_BLK_ATTN_BWD 3
+#define MSR3D_BLK_LINEAR 4
+#define MSR3D_BLK_LINEAR_KSPLIT 5
+
+typedef struct msr3d_scene_block {
+  int kind, B, L;               /* scenes, token rows per scene (L <= 64) */
+  int pro;                      /* MSR3D_PRO_*: the row-local prologue (operands as msr3d_strip_gemm_t) */
+  const float *a0, *a1, *a2;    /* (M, 256); LINEAR_KSPLIT: a0 (M, lda0), slice s reads columns 256 s .. */
+  int lda0;
+  const float *st1, *st2;
+  const float *g1, *b1, *g2, *b2;
+  float eps1, eps2, p1, p2;
+  unsigned salt1, salt2;
+  const unsigned long long *seed;
+  float *o0, *o1, *o2, *ost1, *ost2;
+  float *dg1, *db1, *dg2, *db2;
+  const unsigned short *w1; unsigned w1_bytes;   /* packed operand of product 1 (see the table above) */
+  const float *bias1;           /* in the packed operand's row order */
+  const unsigned short *w2; unsigned w2_bytes;   /* packed operand of product 2 */
+  const float *bias2;           /* (256) added once, by slice 0 */
+  float *acc;                   /* (M, 256) zero-initialised meeting point of product 2 */
+  /* FFN */
+  float *pre;                   /* (M, ff): FFN_FWD writes, FFN_BWD reads */
+  float *h;                     /* (M, ff): FFN_FWD writes dropout(gelu(pre)); FFN_BWD writes d_pre */
+  int ff;
+  float p_drop; unsigned salt;
+  /* ATTN */
+  float *qkvc; int ldq;         /* (M, ldq) [q 256 | k 256 | v 256 | cond 6 H]: ATTN_FWD writes, ATTN_BWD reads */
+  float *dqkvc;                 /* ATTN_BWD writes, same layout */
+  const float *ploc;            /* (B, L, L, 5) */
+  const unsigned char *pad;     /* (B, L) key padding mask */
+  float *probs;                 /* (B, H, L, L): ATTN_FWD writes, ATTN_BWD reads */
+  float *ctx;                   /* (M, 256): ATTN_FWD writes */
+  int H;                        /* 8 */
+  /* LINEAR */
+  float *C; int ldc; int N;     /* N % 256 == 0 */
+} msr3d_scene_block_t;
+
+int msr3d_scene_block(const msr3d_scene_block_t *p, msr3d_stream_t stream);
+
+/* All weight gradients of a step in ONE launch: for every problem dW (n_out, k_in) += dy^T x over the
+ * M token rows (dy (M, n_out), x (M, k_in), dense f32) and, optionally, db (n_out) += colsum(dy).
+ * fp32-accurate on the bf16 pipe (operands split on the way into LDS); one workgroup owns a 128 x 64
+ * tile of dW over the WHOLE reduction: no split-K, no atomics, bit-reproducible; `dW` holds the value to
+ * add to (the flat gradient buffer).  problems, tile_prefix (n + 1 ints): DEVICE memory. */
+typedef struct msr3d_wgrad_problem {
+  const float *dy; int ldy; int n_out;
+  const float *x; int ldx; int k_in;
+  int M;
+  float *dW; int ldw;
+  float *db;
+} msr3d_wgrad_problem_t;
+int msr3d_wgrad_split(int n, const msr3d_wgrad_problem_t *problems, const int *tile_prefix, int total_tiles,
+                      msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * The language-model side of the training step, first two pieces:

@@ -40,6 +40,36 @@ class GemmProblem(ctypes.Structure):
                 ("bias", _ptr), ("beta", _c_float), ("colsum", _ptr), ("single_run", _c_int)]
 
 
+class PackJob(ctypes.Structure):
+    """msr3d_pack_job_t (include/msr3d_hip.h)."""
+    _fields_ = [("src", _ptr), ("ld", _c_int), ("transposed", _c_int), ("rows", _c_int), ("k", _c_int),
+                ("nseg", _c_int), ("seg_dst", _c_int * 4), ("seg_len", _c_int * 4), ("seg_src", _c_int * 4),
+                ("dst", _ptr)]
+
+
+class SceneBlock(ctypes.Structure):
+    """msr3d_scene_block_t (include/msr3d_hip.h)."""
+    _fields_ = ([("kind", _c_int), ("B", _c_int), ("L", _c_int), ("pro", _c_int)]
+                + [(k, _ptr) for k in ("a0", "a1", "a2")] + [("lda0", _c_int)]
+                + [(k, _ptr) for k in ("st1", "st2", "g1", "b1", "g2", "b2")]
+                + [("eps1", _c_float), ("eps2", _c_float), ("p1", _c_float), ("p2", _c_float),
+                   ("salt1", ctypes.c_uint), ("salt2", ctypes.c_uint), ("seed", _ptr)]
+                + [(k, _ptr) for k in ("o0", "o1", "o2", "ost1", "ost2", "dg1", "db1", "dg2", "db2")]
+                + [("w1", _ptr), ("w1_bytes", ctypes.c_uint), ("bias1", _ptr),
+                   ("w2", _ptr), ("w2_bytes", ctypes.c_uint), ("bias2", _ptr), ("acc", _ptr),
+                   ("pre", _ptr), ("h", _ptr), ("ff", _c_int), ("p_drop", _c_float), ("salt", ctypes.c_uint),
+                   ("qkvc", _ptr), ("ldq", _c_int), ("dqkvc", _ptr), ("ploc", _ptr), ("pad", _ptr),
+                   ("probs", _ptr), ("ctx", _ptr), ("H", _c_int),
+                   ("C", _ptr), ("ldc", _c_int), ("N", _c_int)])
+
+
+class WgradProblem(ctypes.Structure):
+    """msr3d_wgrad_problem_t (include/msr3d_hip.h)."""
+    _fields_ = [("dy", _ptr), ("ldy", _c_int), ("n_out", _c_int), ("x", _ptr), ("ldx", _c_int), ("k_in", _c_int),
+                ("M", _c_int), ("dW", _ptr), ("ldw", _c_int), ("db", _ptr)]
+
+
+BLK = {"attn_fwd": 0, "ffn_fwd": 1, "ffn_bwd": 2, "attn_bwd": 3, "linear": 4, "linear_ksplit": 5}
 GEMM_MULTI_MAX = 4
 PRO = {"plain": 0, "add": 1, "ln": 2, "ln2": 3, "lnbwd": 4, "ln2bwd": 5}
 EPI = {"bias": 0, "gelu": 1, "gelubwd": 2}
@@ -47,6 +77,9 @@ EPI = {"bias": 0, "gelu": 1, "gelubwd": 2}
 # name -> argtypes; every entry point returns int status and ends with the stream.
 _SIGNATURES = {
     "msr3d_strip_gemm_f32": [ctypes.POINTER(StripGemm), _ptr],
+    "msr3d_split_pack": [_c_int, _ptr, _ptr, _c_int, _ptr],
+    "msr3d_scene_block": [ctypes.POINTER(SceneBlock), _ptr],
+    "msr3d_wgrad_split": [_c_int, _ptr, _ptr, _c_int, _ptr],
     "msr3d_bf16_gemm_lowrank": [_c_int, _c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int,
                                 _ptr, _c_int, _c_int, _c_float, _ptr],
     "msr3d_lora_grad": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_float, _ptr],
@@ -130,7 +163,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 7        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 8        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():

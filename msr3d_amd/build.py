@@ -38,6 +38,8 @@ SOURCES = [
     ("seq_ce.hip", []),
     ("lora_linear.hip", []),
     ("prompter_rows.hip", ["-ffp-contract=off"]),
+    ("scene_block.hip", []),
+    ("wgrad_split.hip", []),
 ]
 
 

@@ -25,12 +25,25 @@ products are f32-input MFMA chains), dropout masks keyed by the same (seed, salt
 with equal salts the two paths draw identical masks.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
 
-from . import _lib, hipops
-from ._lib import EPI, PRO, GemmProblem, StripGemm
+from . import _lib, hipops, scene_blocks
+from ._lib import BLK, EPI, PRO, GemmProblem, StripGemm
+
+# "blocks": scene-local fused blocks on the bf16x3 matrix pipe (csrc/scene_block.hip, round 3);
+# "strips": round 2's schedule of strip / panel / multi GEMM launches on the f32-input MFMA
+_MODE = [os.environ.get("MSR3D_TRAINABLE", "blocks")]
+if _MODE[0] not in ("blocks", "strips"):
+    raise ValueError("MSR3D_TRAINABLE must be 'blocks' or 'strips'")
+
+
+def set_mode(name):
+    if name not in ("blocks", "strips"):
+        raise ValueError("trainable-part mode must be 'blocks' or 'strips'")
+    _MODE[0] = name
 
 _vp = ctypes.c_void_p
 
@@ -159,6 +172,13 @@ class PrompterSchedule:
         for i in range(nl):
             a.want(f"ffn{i}", M, D, zero=True)
         a.want("d_tok", M, D, zero=True)
+        blocks = self._blocks_capable(L, FF, H)
+        if blocks:      # meeting points of the scene blocks' second products; per-layer dy for the deferred dW launch
+            for i in range(nl):
+                a.want(f"fcacc{i}", M, D, zero=True); a.want(f"d_t{i}", M, D, zero=True)
+                a.want(f"d_xacc{i}", M, D, zero=True)
+                a.want(f"d_ffn{i}", M, D); a.want(f"d_pre{i}", M, FF); a.want(f"d_fc{i}", M, D)
+                a.want(f"d_qkvc{i}", M, W)
         a.want("loc6", M, 6)
         a.want("ff", M, KF)
         a.want("pw", B, L, L, 5)
@@ -184,6 +204,215 @@ class PrompterSchedule:
         self.dims = dict(B=B, L=L, M=M, D=D, W=W, H=H, FF=FF, E=E, KF=KF, KE=KE, nl=nl)
         self.shape = key
         self.staged_for = None
+        self.packs = self.wgrad = None
+        if blocks:
+            self._build_block_tables()
+
+
+    # ------------------------------------------------------------------ scene-local fused blocks (round 3)
+    def _blocks_capable(self, L, FF, H):
+        return L <= 64 and FF % 128 == 0 and H == 8
+
+    def use_blocks(self):
+        return _MODE[0] == "blocks" and self.packs is not None
+
+    def _build_block_tables(self):
+        """Pack jobs for every weight operand of the blocks and the weight-gradient problem table; all
+        sources / destinations are views of the flat parameter and gradient buffers or of the arena."""
+        pr, m, a, dm = self.pr, self.model, self.arena, self.dims
+        M, D, W, H, FF, E, KF, KE, nl = (dm[k] for k in ("M", "D", "W", "H", "FF", "E", "KF", "KE", "nl"))
+        dev = a.buf.device
+        pk = scene_blocks.WeightPacks(dev)
+        wg = scene_blocks.WgradTable(dev)
+        PIECE = scene_blocks.PIECE
+        lp = m.llm_proj
+        self.llm_blocks = E % 256 == 0
+        if self.llm_blocks:
+            pk.add("llm", lp.weight, E, D, False)                   # scene = tok W^T
+            pk.add("llm_t", lp.weight, D, E, True)                  # d tok = d scene W
+        self.wg_llm = wg.add(0, E, E, a["tok"].data_ptr(), D, D, M, lp.weight.grad.data_ptr(), D, lp.bias.grad.data_ptr())
+        for i, layer in enumerate(pr.spatial_encoder):
+            sa = layer.self_attn
+            wv, bv, gwv, gbv, _dp = sa._packed
+            l1, l2 = layer.linear1, layer.linear2
+            head_rows = 8 * 8 * PIECE // 2              # int16 elements of one head's [8 slabs][8 tiles]
+            buf = torch.empty(H * head_rows, dtype=torch.int16, device=dev)
+            pk.bufs[f"qkvc{i}"] = buf
+            buf_t = torch.empty(H * (4 * 16 * PIECE // 2), dtype=torch.int16, device=dev)
+            pk.bufs[f"qkvc_t{i}"] = buf_t
+            for h in range(H):
+                segs = scene_blocks.head_segments(h)
+                pk.add(None, wv, 128, D, False, segs, out=buf, out_offset=h * head_rows * 2)
+                pk.add(None, wv, D, 128, True, segs, out=buf_t, out_offset=h * 4 * 16 * PIECE)
+            pk.add(f"fc{i}", sa.fc.weight, D, D, False)             # acc += ctx_h Wfc[:, h]^T
+            pk.add(f"fc_t{i}", sa.fc.weight, D, D, True)            # d ctx = d_fc Wfc
+            pk.add(f"w1_{i}", l1.weight, FF, D, False)              # pre = t W1^T
+            pk.add(f"w1_t{i}", l1.weight, D, FF, True)              # d t += d_pre W1
+            pk.add(f"w2_{i}", l2.weight, D, FF, False)              # ffn += h W2^T
+            pk.add(f"w2_t{i}", l2.weight, FF, D, True)              # d h = d_ffn W2
+            wg.add(a[f"d_ffn{i}"].data_ptr(), D, D, a[f"h{i}"].data_ptr(), FF, FF, M,
+                   l2.weight.grad.data_ptr(), FF, l2.bias.grad.data_ptr())
+            wg.add(a[f"d_pre{i}"].data_ptr(), FF, FF, a[f"t{i}"].data_ptr(), D, D, M,
+                   l1.weight.grad.data_ptr(), D, l1.bias.grad.data_ptr())
+            wg.add(a[f"d_qkvc{i}"].data_ptr(), W, W, a[f"xin{i}"].data_ptr(), D, D, M, gwv.data_ptr(), D, gbv.data_ptr())
+            wg.add(a[f"d_fc{i}"].data_ptr(), D, D, a[f"ctx{i}"].data_ptr(), D, D, M,
+                   sa.fc.weight.grad.data_ptr(), D, sa.fc.bias.grad.data_ptr())
+        le, se = pr.loc_embedding_encoder, pr.size_embedding_encoder
+        wg.add(a["d_la"].data_ptr(), D, D, a["ff"].data_ptr(), KF, KF, M, le[0].weight.grad.data_ptr(), KF,
+               le[0].bias.grad.data_ptr())
+        wg.add(a["d_lb"].data_ptr(), D, D, a["loc6"].data_ptr() + 12, 6, 3, M, se[0].weight.grad.data_ptr(), 3,
+               se[0].bias.grad.data_ptr())
+        lpj = pr.obj_linear_projection
+        self.wg_proj = wg.add(a["d_xacc0"].data_ptr(), D, D, 0, KE, KE, M, lpj.weight.grad.data_ptr(), KE,
+                              lpj.bias.grad.data_ptr())
+        self.packs, self.wgrad = pk, wg
+
+    def forward_blocks(self, embeds):
+        """forward   step_begin | pack | proj | pos | 3 x [attention block | feed-forward block] | LN -> llm_proj"""
+        pr, m, a, dm = self.pr, self.model, self.arena, self.dims
+        B, L, M, D, W, H, FF, E, KF, KE, nl = (dm[k] for k in ("B", "L", "M", "D", "W", "H", "FF", "E", "KF", "KE", "nl"))
+        dev = embeds.device
+        self.lib = lib = _lib.load()
+        self.stream = st = _lib.current_stream_ptr(dev)
+        train = m.training
+        seed = hipops.seed_word(dev)
+        e2 = embeds.reshape(M, KE)
+        e2 = e2 if e2.is_contiguous() else e2.contiguous()
+        self.saved_embeds = e2
+        layers = list(pr.spatial_encoder)
+        self.salts = [[hipops._next_salt() for _ in range(4)] for _ in layers]
+        self.ps = []
+        for layer in layers:
+            sa = layer.self_attn
+            self.ps.append((float(sa.dropout.p) if train else 0.0, float(layer.dropout1.p) if train else 0.0,
+                            float(layer.dropout2.p) if train else 0.0, float(layer.dropout.p) if train else 0.0))
+        same_all = pr.cfg.spatial_encoder.obj_loc_encoding == "same_all"
+        pk = self.packs
+        blk = scene_blocks.launch_block
+        with torch.cuda.device(dev):
+            rc = lib.msr3d_step_begin(_ptr(a.buf), a.zero_floats, _ptr(seed) if self.bump_seed else None, st)
+            _lib.check(rc, "msr3d_step_begin")
+            pk.launch(st)                                   # this step's weights, split and fragment-packed
+            lp = pr.obj_linear_projection
+            self._multi([dict(a_kc=1, b_kc=1, M=M, N=D, K=KE, A=e2, lda=KE, B=lp.weight, ldb=KE, C=a["x0"], ldc=D,
+                              bias=lp.bias, beta=1.0)])
+            le, se = pr.loc_embedding_encoder, pr.size_embedding_encoder
+            rc = lib.msr3d_pos_embed_fwd(M, KF, _ptr(a["ff"]), _ptr(a["loc6"]), _ptr(le[0].weight), _ptr(le[0].bias),
+                                         _ptr(le[1].weight), _ptr(le[1].bias), ctypes.c_float(le[1].eps),
+                                         _ptr(se[0].weight), _ptr(se[0].bias), _ptr(se[1].weight), _ptr(se[1].bias),
+                                         ctypes.c_float(se[1].eps), _ptr(a["pos"]), _ptr(a["sa"]), _ptr(a["sta"]),
+                                         _ptr(a["sb"]), _ptr(a["stb"]), st)
+            _lib.check(rc, "msr3d_pos_embed_fwd")
+            for i, layer in enumerate(layers):
+                sa = layer.self_attn
+                wv, bv = sa._packed[0], sa._packed[1]
+                p_attn, p1, p2, p_ffn = self.ps[i]
+                s_attn, s_1, s_2, s_ffn = self.salts[i]
+                common = dict(kind=BLK["attn_fwd"], B=B, L=L, w1=pk.bufs[f"qkvc{i}"], w1_bytes=pk.nbytes(f"qkvc{i}"),
+                              bias1=bv, w2=pk.bufs[f"fc{i}"], w2_bytes=pk.nbytes(f"fc{i}"), bias2=sa.fc.bias,
+                              acc=a[f"fcacc{i}"], qkvc=a[f"qkvc{i}"], ldq=W, ploc=a["pw"], pad=self.pad,
+                              probs=a[f"probs{i}"], ctx=a[f"ctx{i}"], H=H, seed=seed)
+                if i == 0:
+                    blk(st, pro=PRO["add"], a0=a["x0"], a1=a["pos"], g1=_ptr(pr.object_type_embedding.weight),
+                        b1=_ptr(pr.object_orientation_feat) if pr.use_orientation else None, o1=a["xin0"], **common)
+                else:
+                    prev = layers[i - 1]
+                    blk(st, pro=PRO["ln"], a0=a[f"ffn{i-1}"], a1=a[f"t{i-1}"], a2=a["pos"] if same_all else None,
+                        g1=prev.norm2.weight, b1=prev.norm2.bias, eps1=prev.norm2.eps, p1=self.ps[i - 1][2],
+                        salt1=self.salts[i - 1][2], o0=a[f"s3_{i-1}"], ost1=a[f"st3_{i-1}"], o1=a[f"xin{i}"], **common)
+                blk(st, kind=BLK["ffn_fwd"], B=B, L=L, pro=PRO["ln2"], a0=a[f"fcacc{i}"], a1=a[f"xin{i}"],
+                    g1=sa.layer_norm.weight, b1=sa.layer_norm.bias, eps1=sa.layer_norm.eps, p1=p_attn, salt1=s_attn,
+                    g2=layer.norm1.weight, b2=layer.norm1.bias, eps2=layer.norm1.eps, p2=p1, salt2=s_1, seed=seed,
+                    o0=a[f"s1_{i}"], ost1=a[f"st1_{i}"], o2=a[f"s2_{i}"], ost2=a[f"st2_{i}"], o1=a[f"t{i}"],
+                    w1=pk.bufs[f"w1_{i}"], w1_bytes=pk.nbytes(f"w1_{i}"), bias1=layer.linear1.bias,
+                    w2=pk.bufs[f"w2_{i}"], w2_bytes=pk.nbytes(f"w2_{i}"), bias2=layer.linear2.bias, acc=a[f"ffn{i}"],
+                    pre=a[f"pre{i}"], h=a[f"h{i}"], ff=FF, p_drop=p_ffn, salt=s_ffn)
+            last = layers[-1]
+            if self.llm_blocks:
+                blk(st, kind=BLK["linear"], B=B, L=L, pro=PRO["ln"], a0=a[f"ffn{nl-1}"], a1=a[f"t{nl-1}"],
+                    g1=last.norm2.weight, b1=last.norm2.bias, eps1=last.norm2.eps, p1=self.ps[-1][2],
+                    salt1=self.salts[-1][2], seed=seed, o0=a[f"s3_{nl-1}"], ost1=a[f"st3_{nl-1}"], o1=a["tok"],
+                    w1=pk.bufs["llm"], w1_bytes=pk.nbytes("llm"), bias1=m.llm_proj.bias, C=a["scene"], ldc=E, N=E)
+            else:
+                self._strip(M=M, N=E, pro=PRO["ln"], epi=EPI["bias"], b_kc=1, a0=a[f"ffn{nl-1}"], a1=a[f"t{nl-1}"],
+                            g1=last.norm2.weight, b1=last.norm2.bias, eps1=last.norm2.eps, p1=self.ps[-1][2],
+                            salt1=self.salts[-1][2], seed=seed, o0=a[f"s3_{nl-1}"], ost1=a[f"st3_{nl-1}"], o1=a["tok"],
+                            W=m.llm_proj.weight, ldw=D, bias=m.llm_proj.bias, C=a["scene"], ldc=E)
+        return a["tok"].view(B, L, D), a["scene"].view(B, L, E)
+
+    def backward_blocks(self, g_scene, g_tok):
+        """backward  d tok = d scene W_llm | 3 x [feed-forward block bwd | attention block bwd] | pos-bwd
+                     | ALL weight gradients in one launch"""
+        pr, m, a, dm = self.pr, self.model, self.arena, self.dims
+        B, L, M, D, W, H, FF, E, KF, KE, nl = (dm[k] for k in ("B", "L", "M", "D", "W", "H", "FF", "E", "KF", "KE", "nl"))
+        dev = a.buf.device
+        lib = self.lib
+        self.stream = st = _lib.current_stream_ptr(dev)
+        seed = hipops.seed_word(dev)
+        layers = list(pr.spatial_encoder)
+        same_all = pr.cfg.spatial_encoder.obj_loc_encoding == "same_all"
+        pk, wg = self.packs, self.wgrad
+        blk = scene_blocks.launch_block
+        with torch.cuda.device(dev):
+            if g_tok is not None:            # a consumer of obj_tokens besides llm_proj
+                a["d_tok"].add_(g_tok.reshape(M, D))
+            lp = m.llm_proj
+            if g_scene is not None:
+                g = g_scene.reshape(M, E)
+                g = g if g.is_contiguous() else g.contiguous()
+                self._g_keep = g
+                if self.llm_blocks:
+                    blk(st, kind=BLK["linear_ksplit"], B=B, L=L, pro=PRO["plain"], a0=g, lda0=E, w1=pk.bufs["llm_t"],
+                        w1_bytes=pk.nbytes("llm_t"), acc=a["d_tok"])
+                else:
+                    self._multi([dict(a_kc=1, b_kc=0, M=M, N=D, K=E, A=g, lda=E, B=lp.weight, ldb=D, C=a["d_tok"],
+                                      ldc=D, beta=1.0)])
+                wg.set_ptr(self.wg_llm, "dy", g.data_ptr())
+                wg.set_ptr(self.wg_llm, "M", M)
+            else:
+                wg.set_ptr(self.wg_llm, "M", 0)             # no upstream gradient for llm_proj in this step
+            d_out = a["d_tok"]
+            for i in range(nl - 1, -1, -1):
+                layer = layers[i]
+                sa = layer.self_attn
+                p_attn, p1, p2, p_ffn = self.ps[i]
+                s_attn, s_1, s_2, s_ffn = self.salts[i]
+                # LN(norm2)-bwd -> d_ffn; d_h = d_ffn W2 -> GELU-bwd -> d_pre; d_t = LN residual + d_pre W1
+                blk(st, kind=BLK["ffn_bwd"], B=B, L=L, pro=PRO["lnbwd"], a0=d_out, a1=a[f"s3_{i}"], st1=a[f"st3_{i}"],
+                    g1=layer.norm2.weight, p1=p2, salt1=s_2, seed=seed, o0=a[f"d_ffn{i}"], o1=a[f"d_t{i}"],
+                    dg1=layer.norm2.weight.grad, db1=layer.norm2.bias.grad,
+                    w1=pk.bufs[f"w2_t{i}"], w1_bytes=pk.nbytes(f"w2_t{i}"), w2=pk.bufs[f"w1_t{i}"],
+                    w2_bytes=pk.nbytes(f"w1_t{i}"), acc=a[f"d_t{i}"], pre=a[f"pre{i}"], h=a[f"d_pre{i}"], ff=FF,
+                    p_drop=p_ffn, salt=s_ffn)
+                # LN(norm1), LN(attention tail) bwd -> d_fc, residual gradient; d_ctx = d_fc Wfc; attention bwd;
+                # d_xin = residual + d[q|k|v|cond] W
+                blk(st, kind=BLK["attn_bwd"], B=B, L=L, pro=PRO["ln2bwd"], a0=a[f"d_t{i}"], a1=a[f"s1_{i}"],
+                    a2=a[f"s2_{i}"], st1=a[f"st1_{i}"], st2=a[f"st2_{i}"], g1=sa.layer_norm.weight,
+                    g2=layer.norm1.weight, p1=p_attn, salt1=s_attn, p2=p1, salt2=s_1, seed=seed,
+                    o0=a[f"d_fc{i}"], o1=a[f"d_xacc{i}"], dg1=sa.layer_norm.weight.grad, db1=sa.layer_norm.bias.grad,
+                    dg2=layer.norm1.weight.grad, db2=layer.norm1.bias.grad,
+                    w1=pk.bufs[f"fc_t{i}"], w1_bytes=pk.nbytes(f"fc_t{i}"), w2=pk.bufs[f"qkvc_t{i}"],
+                    w2_bytes=pk.nbytes(f"qkvc_t{i}"), acc=a[f"d_xacc{i}"], qkvc=a[f"qkvc{i}"], ldq=W,
+                    dqkvc=a[f"d_qkvc{i}"], ploc=a["pw"], pad=self.pad, probs=a[f"probs{i}"], H=H)
+                d_out = a[f"d_xacc{i}"]
+            le, se = pr.loc_embedding_encoder, pr.size_embedding_encoder
+            more = same_all and nl > 1
+            rc = lib.msr3d_pos_embed_bwd(
+                M, _ptr(a["d_xacc0"]), _ptr(a["d_xacc1"]) if more else None,
+                _ptr(a["d_xacc2"]) if (more and nl > 2) else None, _ptr(a["sa"]), _ptr(a["sta"]), _ptr(le[1].weight),
+                _ptr(a["sb"]), _ptr(a["stb"]), _ptr(se[1].weight), _ptr(a["d_la"]), _ptr(a["d_lb"]),
+                _ptr(le[1].weight.grad), _ptr(le[1].bias.grad), _ptr(se[1].weight.grad), _ptr(se[1].bias.grad),
+                _ptr(pr.object_type_embedding.weight.grad),
+                _ptr(pr.object_orientation_feat.grad) if pr.use_orientation else None, st)
+            _lib.check(rc, "msr3d_pos_embed_bwd")
+            wg.set_ptr(self.wg_proj, "x", self.saved_embeds.data_ptr())
+            wg.launch(st)
+            if self.need_d_embeds:     # unfrozen object encoder: d obj_embeds = d_xin0 W_proj
+                lpj = pr.obj_linear_projection
+                self._multi([dict(a_kc=1, b_kc=0, M=M, N=KE, K=D, A=a["d_xacc0"], lda=D, B=lpj.weight, ldb=KE,
+                                  C=a["d_emb"], ldc=KE, beta=0.0)])
+        for p in self._params():
+            self.dp.mark_ready(p)
 
     # ------------------------------------------------------------------ launch helpers
     def _strip(self, **kw):
@@ -239,6 +468,8 @@ class PrompterSchedule:
 
     # ------------------------------------------------------------------ forward / backward
     def forward(self, embeds):
+        if self.use_blocks():
+            return self.forward_blocks(embeds)
         pr, m, a, dm = self.pr, self.model, self.arena, self.dims
         B, L, M, D, W, H, FF, E, KF, KE, nl = (dm[k] for k in ("B", "L", "M", "D", "W", "H", "FF", "E", "KF", "KE", "nl"))
         dev = embeds.device
@@ -311,6 +542,8 @@ class PrompterSchedule:
         return a["tok"].view(B, L, D), a["scene"].view(B, L, E)
 
     def backward(self, g_scene, g_tok):
+        if self.use_blocks():
+            return self.backward_blocks(g_scene, g_tok)
         pr, m, a, dm = self.pr, self.model, self.arena, self.dims
         B, L, M, D, W, H, FF, E, KF, KE, nl = (dm[k] for k in ("B", "L", "M", "D", "W", "H", "FF", "E", "KF", "KE", "nl"))
         dev = a.buf.device

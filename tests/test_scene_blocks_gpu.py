@@ -1,0 +1,131 @@
+"""Scene-local fused blocks (csrc/scene_block.hip, csrc/wgrad_split.hip; round 3): the split/pack kernel
+bit for bit against a numpy restatement of the exact three-way bf16 split, the weight-gradient launch
+against float64, and the blocks schedule against round 2's strips schedule on every intermediate."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16_rne(x):
+    """fp32 array -> (bf16 bit patterns uint16, value as fp32)"""
+    u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32)
+    return r.astype(np.uint16), (r << 16).astype(np.uint32).view(np.float32)
+
+
+def _split3(x):
+    planes, rem = [], x.astype(np.float32)
+    for k in range(3):
+        bits, val = _bf16_rne(rem)
+        planes.append(bits)
+        rem = (rem - val).astype(np.float32)
+    return planes
+
+
+def _pack_ref(op):
+    """op (rows, k) fp32 -> [k/32][rows/16][3][64][8] uint16 in MFMA fragment order."""
+    rows, k = op.shape
+    out = np.zeros((k // 32, rows // 16, 3, 64, 8), np.uint16)
+    planes = _split3(op)
+    for p in range(3):
+        pl = planes[p].reshape(rows // 16, 16, k // 32, 4, 8)      # tile, j, slab, g, e
+        out[:, :, p] = pl.transpose(2, 0, 3, 1, 4).reshape(k // 32, rows // 16, 64, 8)   # lane = j + 16 g
+    return out
+
+
+def test_split_pack_matches_the_exact_split_bit_for_bit():
+    from msr3d_amd import _lib
+    from msr3d_amd.scene_blocks import WeightPacks, head_segments
+    rng = np.random.default_rng(0)
+    w = (rng.standard_normal((816, 256)) * np.exp(rng.uniform(-6, 6, (816, 256)))).astype(np.float32)
+    wt = torch.from_numpy(w).cuda()
+    pk = WeightPacks(wt.device)
+    pk.add("plain", wt[:256], 256, 256, False)
+    pk.add("trans", wt[:512], 256, 512, True)
+    segs = head_segments(3)
+    pk.add("head", wt, 128, 256, False, segs)
+    pk.add("head_t", wt, 256, 128, True, segs)
+    pk.launch(_lib.current_stream_ptr(wt.device))
+    torch.cuda.synchronize()
+    got = {k: v.cpu().numpy().view(np.uint16) for k, v in pk.bufs.items()}
+    head = np.zeros((128, 256), np.float32)
+    for d, n, s in segs:
+        head[d:d + n] = w[s:s + n]
+    want = {"plain": _pack_ref(w[:256]), "trans": _pack_ref(np.ascontiguousarray(w[:512].T)),
+            "head": _pack_ref(head), "head_t": _pack_ref(np.ascontiguousarray(head.T))}
+    for k in want:
+        assert np.array_equal(got[k], want[k].reshape(-1)), k
+    # and the three terms reproduce the value to 2^-24 relative
+    pl = _split3(w)
+    back = sum((p.astype(np.uint32) << 16).view(np.float32).astype(np.float64) for p in pl)
+    assert np.max(np.abs(back - w) / np.abs(w)) < 2.0 ** -23
+
+
+@pytest.mark.parametrize("M,n_out,k_in", [(960, 256, 2048), (976, 816, 256), (150, 256, 63), (37, 256, 3), (960, 4096, 256)])
+def test_wgrad_split_vs_float64(M, n_out, k_in):
+    from msr3d_amd import _lib
+    from msr3d_amd.scene_blocks import WgradTable
+    torch.manual_seed(M + n_out)
+    dy = torch.randn(M, n_out, device="cuda")
+    xw = torch.randn(M, k_in + 5, device="cuda")
+    x = xw[:, 2:2 + k_in]                                # unaligned, strided rows
+    dW0 = torch.randn(n_out, k_in, device="cuda")
+    db0 = torch.randn(n_out, device="cuda")
+    dW, db = dW0.clone(), db0.clone()
+    t = WgradTable(dy.device)
+    t.add(dy.data_ptr(), n_out, n_out, x.data_ptr(), xw.stride(0), k_in, M, dW.data_ptr(), k_in, db.data_ptr())
+    t.launch(_lib.current_stream_ptr(dy.device))
+    torch.cuda.synchronize()
+    want = dW0.double() + dy.double().t() @ x.double()
+    wantb = db0.double() + dy.double().sum(0)
+    assert float((dW.double() - want).norm() / want.norm()) < 2e-6
+    assert float((db.double() - wantb).norm() / wantb.norm()) < 2e-6
+    dW2, db2 = dW0.clone(), db0.clone()                  # bit-reproducible: no atomics, no split-K
+    t.set_ptr(0, "dW", dW2.data_ptr())
+    t.set_ptr(0, "db", db2.data_ptr())
+    t.launch(_lib.current_stream_ptr(dy.device))
+    torch.cuda.synchronize()
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("dropout,B,O,E", [(0.0, 3, 20, 256), (0.1, 2, 60, 512), (0.1, 4, 13, 128)])
+def test_blocks_schedule_matches_strips_schedule_on_every_intermediate(dropout, B, O, E):
+    """Same inputs, same dropout keys: every buffer both schedules produce agrees to fp32 rounding
+    (<= 2e-5 rel-L2; bf16x3 products vs f32-MFMA products, different summation orders)."""
+    import sys
+    sys.path.insert(0, "tools")
+    from dbg_blocks import run
+    from tests.test_fused_model_gpu import _setup
+    from msr3d_amd import fused_model
+    model, dp, batch = _setup(dropout, B=B, O=O, E=E)
+    try:
+        sb, sg = run(model, dp, batch, "strips")
+        bb, bg = run(model, dp, batch, "blocks")
+    finally:
+        fused_model.set_mode("blocks")
+    assert model._schedule.use_blocks()
+    names = ["x0", "pos", "tok", "scene", "d_tok", "d_la", "d_lb"]
+    for i in range(3):
+        names += [f"xin{i}", f"qkvc{i}", f"probs{i}", f"ctx{i}", f"s1_{i}", f"s2_{i}", f"t{i}", f"pre{i}", f"h{i}", f"ffn{i}"]
+    for k in names:
+        assert _rel(bb[k], sb[k]) < 2e-5, (k, _rel(bb[k], sb[k]))
+    for i in range(3):
+        assert _rel(bb[f"fcacc{i}"], sb[f"fc{i}"]) < 2e-5
+        assert _rel(bb[f"d_xacc{i}"], sb[f"d_xin{i}"]) < 5e-5, i
+    for k, kb in (("d_ffn", "d_ffn0"), ("d_pre", "d_pre0"), ("d_t", "d_t0"), ("d_fc", "d_fc0"), ("d_qkvc", "d_qkvc0")):
+        assert _rel(bb[kb], sb[k]) < 5e-5, k
+    for k in sg:
+        if k.endswith("w_ks.bias"):
+            continue
+        if float(sg[k].abs().max()) == 0:
+            assert float(bg[k].abs().max()) == 0, k
+        else:
+            assert _rel(bg[k], sg[k]) < 5e-5, (k, _rel(bg[k], sg[k]))
