@@ -537,28 +537,27 @@ int msr3d_pos_embed_bwd(int M, const float *d0, const float *d1, const float *d2
  * and packed in MFMA fragment order once per optimiser step (msr3d_split_pack); activations are split
  * where they are produced and never leave the chip between the two products of a block.
  *
- * A block's unit of work is one scene (L <= 64 token rows = one 64-row tile) x one slice:
+ * A block's unit of work is one scene (L <= 64 token rows = one 64-row tile) x one slice; its input rows
+ * arrive as three bf16 planes `xp` (B, 3, 64, 256) written by msr3d_scene_rows (rows past L zero):
  *
- *   ATTN_FWD   (scene, head)      rows = prologue(..)            -> xin        (dropout+add+LayerNorm chain of
- *                                 [q|k|v|cond]_h = rows W_h^T + b                msr3d_strip_gemm_f32's PRO codes)
- *                                 ctx_h = spatial attention (attn_core.h)
- *                                 acc  += ctx_h Wfc[:, 32h:32h+32]^T (+ bfc)    8 partial products meet by atomicAdd
- *   FFN_FWD    (scene, 128 hidden) rows = LN2 prologue; pre = rows W1_s^T + b1; h = dropout(gelu(pre))
- *                                 acc  += h W2[:, s]^T (+ b2)                   the (M, 2048) activation feeds the
- *                                                                               second product from LDS
- *   FFN_BWD    (scene, 128 hidden) rows = LN-bwd prologue (d_ffn); d_h = rows W2[:, s]; d_pre = gelu-bwd
- *                                 acc  += d_pre W1[s, :]
- *   ATTN_BWD   (scene, head)      rows = LN-LN-bwd prologue (d_fc); d_ctx_h = rows Wfc[:, 32h:..]
- *                                 d[q|k|v|cond]_h = attention backward
- *                                 acc  += d[q|k|v|cond]_h W_h
- *   LINEAR     (scene, 256 cols)  C = prologue(..) W^T + b                      (llm_proj)
- *   LINEAR_KSPLIT (scene, 256 k)  acc += a0[:, 256 s : 256 s + 256] W[.., s]^T  (d tokens = d scene . W_llm)
+ *   ATTN_FWD   (scene, head)      [q|k|v|cond]_h = rows W_h^T + b;  ctx_h = spatial attention (attn_core.h)
+ *                                 part[h]  = ctx_h Wfc[:, 32h:32h+32]^T
+ *   FFN_FWD    (scene, 128 hidden) pre = rows W1_s^T + b1; h = dropout(gelu(pre));   part[s] = h W2[:, s]^T
+ *                                 (the (M, 2048) activation feeds the second product from LDS)
+ *   FFN_BWD    (scene, 128 hidden) d_h = rows W2[:, s]; d_pre = gelu-bwd;               part[s] = d_pre W1[s, :]
+ *   ATTN_BWD   (scene, head)      d_ctx_h = rows Wfc[:, 32h:..]; d[q|k|v|cond]_h = attention backward
+ *                                 part[h]  = d[q|k|v|cond]_h W_h
+ *   LINEAR     (scene, 256 cols)  C = rows W^T + b                                     (llm_proj)
+ *   LINEAR_KSPLIT (scene, 256 k)  part[s] = a0[:, 256 s : 256 s + 256] W[.., s]^T      (d tokens = d scene . W_llm;
+ *                                 a0 (M, lda0) f32 is split on the way in)
  *
- * Side outputs (pre-norm sums, statistics, layer inputs, q|k|v|cond, ctx, probabilities, pre, h, and in
- * backward d_ffn, d_pre, d_fc, d[q|k|v|cond]) are written by the slice that owns them, dense f32, for the
- * backward blocks and the weight-gradient launch (msr3d_wgrad_split).  `acc` (M, 256) must be zero on
- * entry (msr3d_step_begin); in the backward kinds the residual gradient of the prologue is ADDED to o1
- * atomically (o1 usually == acc).
+ * The slices' partial products land in slabs part[slice] (M, 256), `part_stride` floats apart; the next
+ * msr3d_scene_rows launch sums them in slab order (no atomics: the step is bit-reproducible), adds the
+ * bias / residual, applies the row-local chain that follows (dropout + residual + LayerNorm once or
+ * twice, or their backward: the MSR3D_PRO_* codes of msr3d_strip_gemm_f32) ONCE per row, and writes the
+ * result as the next block's planes.  Side outputs (q|k|v|cond, ctx, probabilities, pre, h, and in
+ * backward d_pre, d[q|k|v|cond]) are written by the slice that owns them, dense f32, for the backward
+ * blocks and the weight-gradient launch (msr3d_wgrad_split).
  * ------------------------------------------------------------------------- */
 typedef struct msr3d_pack_job {
   const float *src; int ld;     /* source matrix (row-major f32), row stride */
@@ -582,26 +581,18 @@ int msr3d_split_pack(int njobs, const msr3d_pack_job_t *jobs, const int *piece_p
 
 typedef struct msr3d_scene_block {
   int kind, B, L;               /* scenes, token rows per scene (L <= 64) */
-  int pro;                      /* MSR3D_PRO_*: the row-local prologue (operands as msr3d_strip_gemm_t) */
-  const float *a0, *a1, *a2;    /* (M, 256); LINEAR_KSPLIT: a0 (M, lda0), slice s reads columns 256 s .. */
-  int lda0;
-  const float *st1, *st2;
-  const float *g1, *b1, *g2, *b2;
-  float eps1, eps2, p1, p2;
-  unsigned salt1, salt2;
-  const unsigned long long *seed;
-  float *o0, *o1, *o2, *ost1, *ost2;
-  float *dg1, *db1, *dg2, *db2;
+  const unsigned short *xp;     /* (B, 3, 64, 256) bf16 planes of the input rows */
+  const float *a0; int lda0;    /* LINEAR_KSPLIT only: (M, lda0) f32, lda0 % 256 == 0, lda0 <= 4096 */
   const unsigned short *w1; unsigned w1_bytes;   /* packed operand of product 1 (see the table above) */
-  const float *bias1;           /* in the packed operand's row order */
+  const float *bias1;           /* product 1's bias: ATTN_FWD the packed [q|k|v|cond] bias, FFN_FWD b1, LINEAR b */
   const unsigned short *w2; unsigned w2_bytes;   /* packed operand of product 2 */
-  const float *bias2;           /* (256) added once, by slice 0 */
-  float *acc;                   /* (M, 256) zero-initialised meeting point of product 2 */
+  float *part; long long part_stride;            /* (slices, M, 256) partial products, slabs part_stride floats apart */
   /* FFN */
   float *pre;                   /* (M, ff): FFN_FWD writes, FFN_BWD reads */
   float *h;                     /* (M, ff): FFN_FWD writes dropout(gelu(pre)); FFN_BWD writes d_pre */
-  int ff;
+  int ff;                       /* ff % 128 == 0, ff <= 2048 */
   float p_drop; unsigned salt;
+  const unsigned long long *seed;
   /* ATTN */
   float *qkvc; int ldq;         /* (M, ldq) [q 256 | k 256 | v 256 | cond 6 H]: ATTN_FWD writes, ATTN_BWD reads */
   float *dqkvc;                 /* ATTN_BWD writes, same layout */
@@ -616,11 +607,37 @@ typedef struct msr3d_scene_block {
 
 int msr3d_scene_block(const msr3d_scene_block_t *p, msr3d_stream_t stream);
 
+/* One wave per token row: a0 = sum_s part[s] (+ extra) (+ a0_bias) in slab order (nslab == 0: a0 itself),
+ * optionally stored whole (sum_out); then the MSR3D_PRO_* chain with the operands / outputs of
+ * the msr3d_strip_gemm_t struct -- in the backward codes o1 = the residual gradient, STORED, to be passed
+ * as the next sum's `extra`; the chain's result goes to `xp` (B, 3, 64, 256) bf16 as three exactly-split planes
+ * (optional).  MSR3D_PRO_PLAIN: sum only.  LayerNorm parameter gradients are accumulated (atomicAdd,
+ * one per column and four rows).  nslab <= 16. */
+typedef struct msr3d_scene_rows {
+  int M, L, pro;
+  const float *a0;
+  const float *part; int nslab; long long part_stride;
+  const float *extra;           /* (M, 256) or NULL */
+  const float *a0_bias;         /* (256) or NULL */
+  float *sum_out;               /* (M, 256) or NULL */
+  const float *a1, *a2;
+  const float *st1, *st2;
+  const float *g1, *b1, *g2, *b2;
+  float eps1, eps2, p1, p2;
+  unsigned salt1, salt2;
+  const unsigned long long *seed;
+  float *o0, *o1, *o2, *ost1, *ost2;
+  float *dg1, *db1, *dg2, *db2;
+  unsigned short *xp;
+} msr3d_scene_rows_t;
+int msr3d_scene_rows(const msr3d_scene_rows_t *p, msr3d_stream_t stream);
+
 /* All weight gradients of a step in ONE launch: for every problem dW (n_out, k_in) += dy^T x over the
  * M token rows (dy (M, n_out), x (M, k_in), dense f32) and, optionally, db (n_out) += colsum(dy).
  * fp32-accurate on the bf16 pipe (operands split on the way into LDS); one workgroup owns a 128 x 64
  * tile of dW over the WHOLE reduction: no split-K, no atomics, bit-reproducible; `dW` holds the value to
- * add to (the flat gradient buffer).  problems, tile_prefix (n + 1 ints): DEVICE memory. */
+ * add to (the flat gradient buffer).  problems, tile_prefix (n + 1 ints; problem i owns workgroups
+ * [tile_prefix[i], tile_prefix[i+1]), a multiple of 8 >= its ceil(n_out/128) * ceil(k_in/64) tiles): DEVICE memory. */
 typedef struct msr3d_wgrad_problem {
   const float *dy; int ldy; int n_out;
   const float *x; int ldx; int k_in;

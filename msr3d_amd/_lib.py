@@ -49,18 +49,24 @@ class PackJob(ctypes.Structure):
 
 class SceneBlock(ctypes.Structure):
     """msr3d_scene_block_t (include/msr3d_hip.h)."""
-    _fields_ = ([("kind", _c_int), ("B", _c_int), ("L", _c_int), ("pro", _c_int)]
-                + [(k, _ptr) for k in ("a0", "a1", "a2")] + [("lda0", _c_int)]
-                + [(k, _ptr) for k in ("st1", "st2", "g1", "b1", "g2", "b2")]
+    _fields_ = [("kind", _c_int), ("B", _c_int), ("L", _c_int), ("xp", _ptr), ("a0", _ptr), ("lda0", _c_int),
+                ("w1", _ptr), ("w1_bytes", ctypes.c_uint), ("bias1", _ptr), ("w2", _ptr), ("w2_bytes", ctypes.c_uint),
+                ("part", _ptr), ("part_stride", ctypes.c_longlong),
+                ("pre", _ptr), ("h", _ptr), ("ff", _c_int), ("p_drop", _c_float), ("salt", ctypes.c_uint),
+                ("seed", _ptr),
+                ("qkvc", _ptr), ("ldq", _c_int), ("dqkvc", _ptr), ("ploc", _ptr), ("pad", _ptr),
+                ("probs", _ptr), ("ctx", _ptr), ("H", _c_int),
+                ("C", _ptr), ("ldc", _c_int), ("N", _c_int)]
+
+
+class SceneRows(ctypes.Structure):
+    """msr3d_scene_rows_t (include/msr3d_hip.h)."""
+    _fields_ = ([("M", _c_int), ("L", _c_int), ("pro", _c_int), ("a0", _ptr), ("part", _ptr), ("nslab", _c_int),
+                 ("part_stride", ctypes.c_longlong), ("extra", _ptr), ("a0_bias", _ptr), ("sum_out", _ptr)]
+                + [(k, _ptr) for k in ("a1", "a2", "st1", "st2", "g1", "b1", "g2", "b2")]
                 + [("eps1", _c_float), ("eps2", _c_float), ("p1", _c_float), ("p2", _c_float),
                    ("salt1", ctypes.c_uint), ("salt2", ctypes.c_uint), ("seed", _ptr)]
-                + [(k, _ptr) for k in ("o0", "o1", "o2", "ost1", "ost2", "dg1", "db1", "dg2", "db2")]
-                + [("w1", _ptr), ("w1_bytes", ctypes.c_uint), ("bias1", _ptr),
-                   ("w2", _ptr), ("w2_bytes", ctypes.c_uint), ("bias2", _ptr), ("acc", _ptr),
-                   ("pre", _ptr), ("h", _ptr), ("ff", _c_int), ("p_drop", _c_float), ("salt", ctypes.c_uint),
-                   ("qkvc", _ptr), ("ldq", _c_int), ("dqkvc", _ptr), ("ploc", _ptr), ("pad", _ptr),
-                   ("probs", _ptr), ("ctx", _ptr), ("H", _c_int),
-                   ("C", _ptr), ("ldc", _c_int), ("N", _c_int)])
+                + [(k, _ptr) for k in ("o0", "o1", "o2", "ost1", "ost2", "dg1", "db1", "dg2", "db2", "xp")])
 
 
 class WgradProblem(ctypes.Structure):
@@ -79,6 +85,7 @@ _SIGNATURES = {
     "msr3d_strip_gemm_f32": [ctypes.POINTER(StripGemm), _ptr],
     "msr3d_split_pack": [_c_int, _ptr, _ptr, _c_int, _ptr],
     "msr3d_scene_block": [ctypes.POINTER(SceneBlock), _ptr],
+    "msr3d_scene_rows": [ctypes.POINTER(SceneRows), _ptr],
     "msr3d_wgrad_split": [_c_int, _ptr, _ptr, _c_int, _ptr],
     "msr3d_bf16_gemm_lowrank": [_c_int, _c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int,
                                 _ptr, _c_int, _c_int, _c_float, _ptr],

@@ -39,6 +39,7 @@ SOURCES = [
     ("lora_linear.hip", []),
     ("prompter_rows.hip", ["-ffp-contract=off"]),
     ("scene_block.hip", []),
+    ("scene_rows.hip", []),
     ("wgrad_split.hip", []),
 ]
 

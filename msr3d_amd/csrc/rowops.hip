@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void dal_fwd_kernel(int M, const float *__rest
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const bool drop = p_drop > 0.f;
-  const unsigned thresh = drop ? (unsigned)(p_drop * 4294967296.0) : 0u;
+  const unsigned thresh = msr3d::drop_thresh(drop ? p_drop : 0.f);
   const float scale = drop ? 1.0f / (1.0f - p_drop) : 1.0f;
   const unsigned long long sd = drop ? *seed : 0ull;
   float4 v[VPL];
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void dal_bwd_kernel(int M, int rows_per_block,
   __shared__ float red[2][4][D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool drop = p_drop > 0.f;
-  const unsigned thresh = drop ? (unsigned)(p_drop * 4294967296.0) : 0u;
+  const unsigned thresh = msr3d::drop_thresh(drop ? p_drop : 0.f);
   const float scale = drop ? 1.0f / (1.0f - p_drop) : 1.0f;
   const unsigned long long sd = drop ? *seed : 0ull;
   float4 gg[VPL], accg[VPL], accb[VPL];

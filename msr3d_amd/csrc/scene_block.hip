@@ -6,9 +6,10 @@
 // scene is a 64-row tile, and each half of the layer -- attention block, feed-forward block, forward
 // and backward -- is the same sandwich
 //
-//     rows  = row-local prologue (dropout / residual / LayerNorm chains or their backward)   64 x 256
+//     rows  = three bf16 planes of the block's 64 x 256 input (written by msr3d_scene_rows)
 //     mid   = middle( rows . Op1_slice^T )       K = 256 -> slice width (a head, 128 hidden units)
-//     acc  += mid . Op2_slice^T                  K = slice -> 256; slices meet by fp32 atomicAdd
+//     part[slice] = mid . Op2_slice^T            K = slice -> 256; the slices' partial products are summed,
+//                                                in slab order, by the next msr3d_scene_rows launch
 //
 // with the middle = spatial attention of one head (attn_core.h), GELU + dropout, or their backward.
 // One workgroup (4 waves) per (scene, slice): 128 workgroups for the attention blocks, 256 for the
@@ -16,21 +17,27 @@
 // through HBM between the two products (they are written once, as side outputs for the backward).
 //
 // Matrix products: six v_mfma_f32_16x16x32_bf16 per block of products on exactly-split operands
-// (split_mma.h).  `rows` is split by the prologue into three row-major bf16 planes in LDS, `mid` by
-// product 1's epilogue into fragment-order planes; the weights arrive pre-split and fragment-packed
-// (msr3d_split_pack, once per optimiser step) through a buffer descriptor and a register ring four
-// pieces deep, so there is no LDS staging of weights and no barrier inside a product.  Waves are laid
-// out 1 x 4: each owns all 64 rows and a quarter of the columns, so a weight fragment is fetched once
-// per workgroup.
+// (split_mma.h).  `mid` is split by product 1's epilogue into fragment-order planes in LDS; the weights
+// arrive pre-split and fragment-packed (msr3d_split_pack, once per optimiser step) through a buffer
+// descriptor and a register ring four pieces deep, so there is no LDS staging of weights and no barrier
+// inside a product.  Waves are laid out 1 x 4: each owns all 64 rows and a quarter of the columns, so a
+// weight fragment is fetched once per workgroup.
+//
+// Why partial slabs and not atomics: scene_rows.hip.
 //
 // Workgroup -> XCD: blockIdx.x = slice and gridDim.x in {8, 16}, so all scenes' workgroups of a slice
-// land on the XCD (slice mod 8): a slice's weights are fetched into ONE L2.
+// land on the XCD (slice mod 8): a slice's weights are fetched into ONE L2 (speed only).
 #include <hip/hip_runtime.h>
 
 #include "../../include/msr3d_hip.h"
 #include "attn_core.h"
 #include "rowmath.h"
 #include "split_mma.h"
+
+// phase marks: empty here; tools/prof/scene_block_stamped.hip defines SB_STAMP and includes this file
+#ifndef SB_STAMP
+#define SB_STAMP(i)
+#endif
 
 namespace {
 
@@ -53,268 +60,72 @@ constexpr int MID_BYTES = 4 * 4 * 3 * 1024;   // FRAG planes of a 64 x 128 middl
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 
-// =====================================================================================================
-// Prologue (strip_gemm.hip's stage_strip for a scene tile and four waves).  Wave w stages rows
-// 16 w .. 16 w + 15 in four passes of four rows; a row is held by SIXTEEN lanes (lane l: row
-// 4 pass + l / 16, columns 64 q + 4 (l % 16) .. + 3, q = 0..3): row reductions are in-lane adds + four DPP
-// rotate-adds.  Same operation order per element as rowmath.h / rowops.hip / strip_gemm.hip, same
-// dropout keys (global token row * 256 + column).  The result goes to the three ROWS planes.
-// =====================================================================================================
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
-  return v;
+// Input staging.  Every kind but LINEAR_KSPLIT: the scene's three planes (B, 3, 64, 256) bf16, one
+// contiguous 96 KB block, copied into the ROWS layout (pitch 272) -- 24 16-byte loads per thread, all in
+// flight together; rows past L are zero in the source.  LINEAR_KSPLIT: fp32 rows a0[row][col0 .. col0 + 256)
+// split on the way in (the upstream gradient of llm_proj comes from outside the schedule).
+__device__ __forceinline__ void stage_planes(const unsigned short *__restrict__ xp, unsigned short *xs, int b) {
+  const uint4 *src = reinterpret_cast<const uint4 *>(xp + (size_t)b * 3 * TM * KD);
+  uint4 v[24];
+#pragma unroll
+  for (int k = 0; k < 24; ++k) v[k] = src[threadIdx.x + 256 * k];
+#pragma unroll
+  for (int k = 0; k < 24; ++k) {
+    const int q = threadIdx.x + 256 * k;
+    const int plane = q >> 11, row = (q >> 5) & 63, c8 = q & 31;
+    *reinterpret_cast<uint4 *>(xs + plane * PLANE + row * PITCH + c8 * 8) = v[k];
+  }
 }
 
-struct Row4 { float4 q[4]; };
-
-__device__ __forceinline__ Row4 r4_add(const Row4 &a, const Row4 &b) {
-  Row4 o;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) o.q[q] = f4_add(a.q[q], b.q[q]);
-  return o;
-}
-__device__ __forceinline__ Row4 r4_drop(const Row4 &v, bool drop, unsigned long long sd, unsigned salt,
-                                        unsigned thresh, float scale, int row, int cseg) {
-  if (!drop) return v;
-  Row4 o;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const unsigned base = (unsigned)row * KD + 64 * q + 4 * cseg;
-    o.q[q].x = keep_elem(sd, salt, base + 0, thresh) ? v.q[q].x * scale : 0.f;
-    o.q[q].y = keep_elem(sd, salt, base + 1, thresh) ? v.q[q].y * scale : 0.f;
-    o.q[q].z = keep_elem(sd, salt, base + 2, thresh) ? v.q[q].z * scale : 0.f;
-    o.q[q].w = keep_elem(sd, salt, base + 3, thresh) ? v.q[q].w * scale : 0.f;
-  }
-  return o;
-}
-__device__ __forceinline__ Row4 r4_ln(const Row4 &v, const Row4 &g, const Row4 &b, float eps, float &mean,
-                                      float &rstd) {
-  float sum = 0.f;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) sum += (v.q[q].x + v.q[q].y) + (v.q[q].z + v.q[q].w);
-  mean = row16_sum(sum) * (1.0f / KD);
-  float var = 0.f;
-  Row4 d;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    d.q[q] = make_float4(v.q[q].x - mean, v.q[q].y - mean, v.q[q].z - mean, v.q[q].w - mean);
-    var += (d.q[q].x * d.q[q].x + d.q[q].y * d.q[q].y) + (d.q[q].z * d.q[q].z + d.q[q].w * d.q[q].w);
-  }
-  rstd = rsqrtf(row16_sum(var) * (1.0f / KD) + eps);
-  Row4 o;
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    o.q[q] = make_float4(d.q[q].x * rstd * g.q[q].x + b.q[q].x, d.q[q].y * rstd * g.q[q].y + b.q[q].y,
-                         d.q[q].z * rstd * g.q[q].z + b.q[q].z, d.q[q].w * rstd * g.q[q].w + b.q[q].w);
-  return o;
-}
-__device__ __forceinline__ Row4 r4_ln_bwd(const Row4 &d, const Row4 &s, float mean, float rstd, const Row4 &gg,
-                                          Row4 &tg, Row4 &tb) {
-  Row4 xh, g;
-  float c1 = 0.f, c2 = 0.f;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    xh.q[q] = make_float4((s.q[q].x - mean) * rstd, (s.q[q].y - mean) * rstd, (s.q[q].z - mean) * rstd,
-                          (s.q[q].w - mean) * rstd);
-    g.q[q] = make_float4(d.q[q].x * gg.q[q].x, d.q[q].y * gg.q[q].y, d.q[q].z * gg.q[q].z, d.q[q].w * gg.q[q].w);
-    c1 += (g.q[q].x + g.q[q].y) + (g.q[q].z + g.q[q].w);
-    c2 += (g.q[q].x * xh.q[q].x + g.q[q].y * xh.q[q].y) + (g.q[q].z * xh.q[q].z + g.q[q].w * xh.q[q].w);
-    tg.q[q] = make_float4(d.q[q].x * xh.q[q].x, d.q[q].y * xh.q[q].y, d.q[q].z * xh.q[q].z, d.q[q].w * xh.q[q].w);
-    tb.q[q] = d.q[q];
-  }
-  c1 = row16_sum(c1) * (1.0f / KD);
-  c2 = row16_sum(c2) * (1.0f / KD);
-  Row4 o;
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    o.q[q] = make_float4(rstd * (g.q[q].x - c1 - xh.q[q].x * c2), rstd * (g.q[q].y - c1 - xh.q[q].y * c2),
-                         rstd * (g.q[q].z - c1 - xh.q[q].z * c2), rstd * (g.q[q].w - c1 - xh.q[q].w * c2));
-  return o;
-}
-
-// `red`: LDS, [4 arrays][4 waves][256] floats (backward prologues only).  `side`: this workgroup owns the
-// prologue's row outputs.  `gx`, `bx`: slices per scene and this slice -- the LayerNorm parameter-gradient
-// column sums are shared out over the slices of a scene (item (array k, column quarter q) belongs to
-// slice (4 k + q) % gx), since every slice holds the same row values.
-template <int PRO>
-__device__ __forceinline__ void stage_rows(const SB &p, unsigned short *xs, float *red, int row_base, int L,
-                                           bool side, int gx, int bx, int col0, int lda) {
+__device__ __forceinline__ void stage_f32(const float *__restrict__ a0, int lda, int col0, unsigned short *xs,
+                                          int row_base, int L) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cseg = lane & 15, sub = lane >> 4;
-  constexpr bool USE1 = PRO != MSR3D_PRO_PLAIN;
-  constexpr bool BWD = PRO == MSR3D_PRO_LNBWD || PRO == MSR3D_PRO_LN2BWD;
-  const bool has2 = PRO == MSR3D_PRO_LN2BWD || (PRO == MSR3D_PRO_LN && p.a2 != nullptr);
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (BWD) {
-    for (int e = threadIdx.x; e < 4 * 4 * KD; e += 256) red[e] = 0.f;
-  }
-  const bool d1 = p.p1 > 0.f, d2 = p.p2 > 0.f;
-  const unsigned long long sd = (d1 || d2) ? *p.seed : 0ull;
-  const unsigned th1 = drop_thresh(p.p1), th2 = drop_thresh(p.p2);
-  const float sc1 = d1 ? 1.0f / (1.0f - p.p1) : 1.0f, sc2 = d2 ? 1.0f / (1.0f - p.p2) : 1.0f;
-  Row4 g1, b1, g2, b2;
+  float4 in[4][4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int c = 64 * q + 4 * cseg;
-    g1.q[q] = (PRO != MSR3D_PRO_PLAIN && p.g1) ? ld4(p.g1 + c) : z;
-    b1.q[q] = (PRO != MSR3D_PRO_PLAIN && p.b1) ? ld4(p.b1 + c) : z;
-    g2.q[q] = (PRO == MSR3D_PRO_LN2 || PRO == MSR3D_PRO_LN2BWD) ? ld4(p.g2 + c) : z;
-    b2.q[q] = (PRO == MSR3D_PRO_LN2 && p.b2) ? ld4(p.b2 + c) : z;
+  for (int j = 0; j < 4; ++j) {
+    const int r = wave * 16 + 4 * j + sub;
+    const float *src = a0 + (size_t)(row_base + min(r, L - 1)) * lda + col0 + 4 * cseg;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) in[j][q] = ld4(src + 64 * q);
   }
-  if (BWD) __syncthreads();
-  auto accum = [&](int k, const Row4 &v) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = wave * 16 + 4 * j + sub;
+    const bool ok = r < L;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if ((4 * k + q) % gx != bx) continue;
-      float4 t = v.q[q];
-      t.x += __shfl_xor(t.x, 16); t.y += __shfl_xor(t.y, 16); t.z += __shfl_xor(t.z, 16); t.w += __shfl_xor(t.w, 16);
-      t.x += __shfl_xor(t.x, 32); t.y += __shfl_xor(t.y, 32); t.z += __shfl_xor(t.z, 32); t.w += __shfl_xor(t.w, 32);
-      if (sub == 0) {
-        float *d = red + (k * 4 + wave) * KD + 64 * q + 4 * cseg;
-        st4(d, f4_add(ld4(d), t));
-      }
-    }
-  };
-  auto put = [&](float *dst, int row, const Row4 &v) {
+      const float v[4] = {ok ? in[j][q].x : 0.f, ok ? in[j][q].y : 0.f, ok ? in[j][q].z : 0.f, ok ? in[j][q].w : 0.f};
+      uint2 pl[3];
+      sm_split4(v, pl);
+      unsigned short *d = xs + r * PITCH + 64 * q + 4 * cseg;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) st4(dst + (size_t)row * KD + 64 * q + 4 * cseg, v.q[q]);
-  };
-  auto put_add = [&](float *dst, int row, const Row4 &v) {       // meets other slices' partial sums
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float *d = dst + (size_t)row * KD + 64 * q + 4 * cseg;
-      atomicAdd(d + 0, v.q[q].x); atomicAdd(d + 1, v.q[q].y); atomicAdd(d + 2, v.q[q].z); atomicAdd(d + 3, v.q[q].w);
-    }
-  };
-#pragma unroll 1
-  for (int jb = 0; jb < 4; jb += 2) {
-    Row4 in0[2], in1[2], in2[2];
-    float2 sv1[2], sv2[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int r = wave * 16 + 4 * (jb + j) + sub;
-      const int row = row_base + min(r, L - 1);
-      const size_t o = (size_t)row * KD + 4 * cseg;
-      const float *a0p = PRO == MSR3D_PRO_PLAIN ? p.a0 + (size_t)row * lda + col0 + 4 * cseg : p.a0 + o;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        in0[j].q[q] = ld4(a0p + 64 * q);
-        in1[j].q[q] = USE1 ? ld4(p.a1 + o + 64 * q) : z;
-        in2[j].q[q] = has2 ? ld4(p.a2 + o + 64 * q) : z;
-      }
-      if (BWD) sv1[j] = *reinterpret_cast<const float2 *>(p.st1 + (size_t)row * 2);
-      if (PRO == MSR3D_PRO_LN2BWD) sv2[j] = *reinterpret_cast<const float2 *>(p.st2 + (size_t)row * 2);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int r = wave * 16 + 4 * (jb + j) + sub, row = row_base + r;
-      const bool ok = r < L;
-      const bool wr = side && ok;
-      Row4 a = in0[j];
-      if (PRO == MSR3D_PRO_ADD) {
-        a = r4_add(r4_add(r4_add(a, in1[j]), g1), b1);
-        if (wr && p.o1) put(p.o1, row, a);
-      } else if (PRO == MSR3D_PRO_LN) {
-        const Row4 v = r4_add(r4_drop(a, d1, sd, p.salt1, th1, sc1, row, cseg), in1[j]);
-        float mean, rstd;
-        a = r4_add(r4_ln(v, g1, b1, p.eps1, mean, rstd), in2[j]);
-        if (wr) {
-          if (p.o0) put(p.o0, row, v);
-          if (p.ost1 && cseg == 0) *reinterpret_cast<float2 *>(p.ost1 + (size_t)row * 2) = make_float2(mean, rstd);
-          if (p.o1) put(p.o1, row, a);
-        }
-      } else if (PRO == MSR3D_PRO_LN2) {
-        const Row4 v1 = r4_add(r4_drop(a, d1, sd, p.salt1, th1, sc1, row, cseg), in1[j]);
-        float m1, r1, m2, r2;
-        const Row4 y1 = r4_ln(v1, g1, b1, p.eps1, m1, r1);
-        const Row4 v2 = r4_add(r4_drop(y1, d2, sd, p.salt2, th2, sc2, row, cseg), in1[j]);
-        a = r4_ln(v2, g2, b2, p.eps2, m2, r2);
-        if (wr) {
-          put(p.o0, row, v1);
-          put(p.o2, row, v2);
-          if (cseg == 0) {
-            *reinterpret_cast<float2 *>(p.ost1 + (size_t)row * 2) = make_float2(m1, r1);
-            *reinterpret_cast<float2 *>(p.ost2 + (size_t)row * 2) = make_float2(m2, r2);
-          }
-          put(p.o1, row, a);
-        }
-      } else if (PRO == MSR3D_PRO_LNBWD) {
-        Row4 tg, tb;
-        const Row4 dx = r4_ln_bwd(a, in1[j], sv1[j].x, sv1[j].y, g1, tg, tb);
-        { const Row4 zr = {{z, z, z, z}}; accum(0, ok ? tg : zr); accum(1, ok ? tb : zr); }
-        a = r4_drop(dx, d1, sd, p.salt1, th1, sc1, row, cseg);
-        if (wr) {
-          if (p.o1) put_add(p.o1, row, dx);
-          if (p.o0) put(p.o0, row, a);
-        }
-      } else if (PRO == MSR3D_PRO_LN2BWD) {
-        Row4 tg1, tb1, tg2, tb2;
-        const Row4 dx2 = r4_ln_bwd(a, in2[j], sv2[j].x, sv2[j].y, g2, tg2, tb2);
-        const Row4 d = r4_drop(dx2, d2, sd, p.salt2, th2, sc2, row, cseg);
-        const Row4 dx1 = r4_ln_bwd(d, in1[j], sv1[j].x, sv1[j].y, g1, tg1, tb1);
-        { const Row4 zr = {{z, z, z, z}};
-          accum(0, ok ? tg1 : zr); accum(1, ok ? tb1 : zr); accum(2, ok ? tg2 : zr); accum(3, ok ? tb2 : zr); }
-        a = r4_drop(dx1, d1, sd, p.salt1, th1, sc1, row, cseg);
-        if (wr) {
-          put_add(p.o1, row, r4_add(dx2, dx1));
-          put(p.o0, row, a);
-        }
-      }
-      // -> three bf16 planes (rows past L: zeros)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float v[4] = {ok ? a.q[q].x : 0.f, ok ? a.q[q].y : 0.f, ok ? a.q[q].z : 0.f, ok ? a.q[q].w : 0.f};
-        uint2 pl[3];
-        sm_split4(v, pl);
-        unsigned short *d = xs + r * PITCH + 64 * q + 4 * cseg;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2 *>(d + k * PLANE) = pl[k];
-      }
-    }
-  }
-  if (BWD) {
-    __syncthreads();
-    constexpr int NA = PRO == MSR3D_PRO_LN2BWD ? 4 : 2;
-    float *const dst[4] = {p.dg1, p.db1, p.dg2, p.db2};
-    for (int e = threadIdx.x; e < NA * KD; e += 256) {
-      const int k = e >> 8, col = e & 255;
-      if ((4 * k + (col >> 6)) % gx != bx || !dst[k]) continue;
-      float sum = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) sum += red[(k * 4 + w) * KD + col];
-      atomicAdd(dst[k] + col, sum);
+      for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2 *>(d + k * PLANE) = pl[k];
     }
   }
 }
 
-// product-2 epilogue: D = X W^T -- lane (j, g) holds tokens 16 mt + 4 g + r of channel n0 + 16 rn + j; the 16
-// lanes of a DPP row add 64 contiguous bytes
+// product-2 epilogue: this slice's partial product -> its slab.  D = W X^T: lane (j, g) holds channels
+// n0 + 16 rn + 4 g .. + 3 of token 16 mt + j -- one 16-byte store per tile, 64 contiguous bytes per row
 template <int RN>
-__device__ __forceinline__ void add_partials(const f32x4 (&acc)[RN][4], float *__restrict__ out, const float *bias,
-                                             int row_base, int L, int n0, int lane) {
+__device__ __forceinline__ void store_partials(const f32x4 (&acc)[RN][4], float *__restrict__ slab, int row_base,
+                                               int L, int n0, int lane) {
   const int j = lane & 15, g = lane >> 4;
 #pragma unroll
-  for (int rn = 0; rn < RN; ++rn) {
-    const int ch = n0 + 16 * rn + j;
-    const float bv = bias ? bias[ch] : 0.f;
+  for (int rn = 0; rn < RN; ++rn)
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * mt + 4 * g + r;
-        if (row < L) atomicAdd(out + (size_t)(row_base + row) * KD + ch, acc[rn][mt][r] + bv);
-      }
-  }
+    for (int mt = 0; mt < 4; ++mt) {
+      const int row = 16 * mt + j;
+      if (row < L)
+        st4(slab + (size_t)(row_base + row) * KD + n0 + 16 * rn + 4 * g,
+            make_float4(acc[rn][mt][0], acc[rn][mt][1], acc[rn][mt][2], acc[rn][mt][3]));
+    }
 }
 
 // LDS carve-up behind the ROWS planes, by kind
 constexpr int kTile = TM * LD32 * 4;                       // one [64][36] fp32 head tile: 9,216 B
 constexpr int kAttnFwdAux = 3 * kTile + 2048 + 4 * 3 * 1024;          // q k v | cond [64][8] | ctx FRAG (1 slab)
-constexpr int kAttnBwdAux = 4 * kTile + 2048 + 2048;                   // q k v do | cond | dcond   (red overlays q..)
-static_assert(4 * 4 * KD * 4 <= kAttnBwdAux && 4 * 4 * KD * 4 <= MID_BYTES, "the prologue's column sums overlay the aux region");
+constexpr int kAttnBwdAux = 4 * kTile + 2048 + 2048;                   // q k v do | cond | dcond
 
 template <int KIND>
 constexpr int lds_bytes() {
@@ -324,7 +135,7 @@ constexpr int lds_bytes() {
        : XS_BYTES;
 }
 
-template <int KIND, int PRO>
+template <int KIND>
 __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned short *xs = reinterpret_cast<unsigned short *>(smem);
@@ -334,7 +145,7 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
-  const int gx = gridDim.x;
+  float *const slab = p.part + (size_t)slice * p.part_stride;
 
   // ---- product 1's stream: the first pieces fly under the prologue ----
   constexpr int RN1 = (KIND == MSR3D_BLK_LINEAR || KIND == MSR3D_BLK_LINEAR_KSPLIT) ? 4
@@ -351,14 +162,16 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
     w1 = make_wstream(p.w1, p.w1_bytes, 16, KS1 * slice, 4 * wave, lane);
   else                                     // FFN: [8 slabs][ff / 16 tiles], this slice's 8 tiles
     w1 = make_wstream(p.w1, p.w1_bytes, p.ff / 16, 0, 8 * slice + 2 * wave, lane);
+  SB_STAMP(0);
   WPiece ring1[RING];
   preload_wring<RN1, RING>(ring1, w1);
 
-  // ---- prologue -> ROWS planes ----
-  float *red = reinterpret_cast<float *>(aux);
-  stage_rows<PRO>(p, xs, red, row_base, L, slice == 0, gx, slice,
-                  KIND == MSR3D_BLK_LINEAR_KSPLIT ? KD * slice : 0, KIND == MSR3D_BLK_LINEAR_KSPLIT ? p.lda0 : KD);
+  // ---- the block's input -> ROWS planes ----
+  if (KIND == MSR3D_BLK_LINEAR_KSPLIT) stage_f32(p.a0, p.lda0, KD * slice, xs, row_base, L);
+  else stage_planes(p.xp, xs, b);
+  SB_STAMP(1);
   __syncthreads();
+  SB_STAMP(2);
   const XRows xr = make_xrows(xs, PITCH, TM, lane);
 
   if constexpr (KIND == MSR3D_BLK_LINEAR) {
@@ -366,6 +179,7 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
     f32x4 acc[4][4];
     zero_acc3(acc);
     gemm_split3<true, 4, 4, KS1, RING>(xr, 0, w1, acc, ring1);
+    SB_STAMP(3);
     const int n0 = 256 * slice + 64 * wave + 4 * g;
 #pragma unroll
     for (int rn = 0; rn < 4; ++rn) {
@@ -379,11 +193,12 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
       }
     }
   } else if constexpr (KIND == MSR3D_BLK_LINEAR_KSPLIT) {
-    // ------------------------------------------------------------------ acc += a0[:, slice] W[.., slice]^T
+    // ------------------------------------------------------------------ part[slice] = a0[:, slice] W[.., slice]^T
     f32x4 acc[4][4];
     zero_acc3(acc);
-    gemm_split3<false, 4, 4, KS1, RING>(xr, 0, w1, acc, ring1);
-    add_partials<4>(acc, p.acc, slice == 0 ? p.bias2 : nullptr, row_base, L, 64 * wave, lane);
+    gemm_split3<true, 4, 4, KS1, RING>(xr, 0, w1, acc, ring1);
+    SB_STAMP(3);
+    store_partials<4>(acc, slab, row_base, L, 64 * wave, lane);
   } else if constexpr (KIND == MSR3D_BLK_FFN_FWD || KIND == MSR3D_BLK_FFN_BWD) {
     // ------------------------------------------------------------------ feed-forward block
     constexpr bool FWD = KIND == MSR3D_BLK_FFN_FWD;
@@ -403,6 +218,7 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
     f32x4 acc[2][4];
     zero_acc3(acc);
     gemm_split3<true, 2, 4, KS1, RING>(xr, 0, w1, acc, ring1);
+    SB_STAMP(3);
     WPiece ring2[RING];
     preload_wring<4, RING>(ring2, w2);
     const bool drop = p.p_drop > 0.f;
@@ -448,12 +264,15 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
           *reinterpret_cast<uint2 *>(mid + frag_off4<4>(mt, j, lc0 + 16 * rn, k)) = pl[k];
       }
     }
+    SB_STAMP(4);
     __syncthreads();
+    SB_STAMP(5);
     f32x4 acc2[4][4];
     zero_acc3(acc2);
     const XFrag<4> xm{reinterpret_cast<const unsigned short *>(mid) + lane * 8};
-    gemm_split3<false, 4, 4, 4, RING>(xm, 0, w2, acc2, ring2);
-    add_partials<4>(acc2, p.acc, slice == 0 ? p.bias2 : nullptr, row_base, L, 64 * wave, lane);
+    gemm_split3<true, 4, 4, 4, RING>(xm, 0, w2, acc2, ring2);
+    SB_STAMP(6);
+    store_partials<4>(acc2, slab, row_base, L, 64 * wave, lane);
   } else if constexpr (KIND == MSR3D_BLK_ATTN_FWD) {
     // ------------------------------------------------------------------ attention block, forward
     const int h = slice, H = p.H, ldq = p.ldq;
@@ -465,6 +284,7 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
     f32x4 acc[2][4];
     zero_acc3(acc);
     gemm_split3<true, 2, 4, KS1, RING>(xr, 0, w1, acc, ring1);
+    SB_STAMP(3);
     WPiece ring2[RING];
     preload_wring<4, RING>(ring2, w2);
     // wave 0 / 1 / 2: the head's q / k / v (32 columns each); wave 3: cond (6 of its first 16 columns)
@@ -501,10 +321,12 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
         }
       }
     }
+    SB_STAMP(4);
     __syncthreads();                       // every wave is done with the ROWS planes; q / k / v / cond visible
     float *sp = reinterpret_cast<float *>(xs);                      // P [64][68], then the pairwise slab
     const float *plb = msr3d_attn::stage_ploc<TM>(p.ploc, b, L, sp + TM * (TM + 4));
     __syncthreads();
+    SB_STAMP(5);
     f32x4 o[2];
     msr3d_attn::attn_fwd_core<TM, MSR3D_MMA_F32>(L, sq, sk, sv, sp, plb, scond, 8, p.pad + (size_t)b * L,
                                                  p.probs ? p.probs + ((size_t)b * H + h) * L * L : nullptr, o);
@@ -522,12 +344,14 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
         for (int k = 0; k < 3; ++k)
           *reinterpret_cast<unsigned short *>(ctxp + (((wave * 3 + k) * 64 + rr + 16 * (kk >> 3)) * 16 + (kk & 7) * 2)) = pl[k];
       }
+    SB_STAMP(6);
     __syncthreads();
     f32x4 acc2[4][4];
     zero_acc3(acc2);
     const XFrag<4> xm{reinterpret_cast<const unsigned short *>(ctxp) + lane * 8};
-    gemm_split3<false, 4, 4, 1, RING>(xm, 0, w2, acc2, ring2);
-    add_partials<4>(acc2, p.acc, h == 0 ? p.bias2 : nullptr, row_base, L, 64 * wave, lane);
+    gemm_split3<true, 4, 4, 1, RING>(xm, 0, w2, acc2, ring2);
+    SB_STAMP(7);
+    store_partials<4>(acc2, slab, row_base, L, 64 * wave, lane);
   } else {
     // ------------------------------------------------------------------ attention block, backward
     const int h = slice, H = p.H, ldq = p.ldq;
@@ -535,8 +359,7 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
     float *scond = sdo + TM * LD32, *sdc = scond + TM * 8;
     // product 2's stream: the head's gathered rows of W_qkvc as [k = 128 head columns][n = 256]: [4 slabs][16 tiles]
     const WStream w2 = make_wstream(p.w2 + (size_t)h * (4 * 16 * kPieceBytes / 2), 4 * 16 * kPieceBytes, 16, 0, 4 * wave, lane);
-    // the head's saved q, k, v, cond (the LDS behind the planes held the prologue's column sums until its
-    // last barrier)
+    // the head's saved q, k, v, cond
     msr3d_attn::load_head_tile<TM>(p.qkvc, ldq, b, h, L, sq);
     msr3d_attn::load_head_tile<TM>(p.qkvc + KD, ldq, b, h, L, sk);
     msr3d_attn::load_head_tile<TM>(p.qkvc + 2 * KD, ldq, b, h, L, sv);
@@ -548,6 +371,7 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
     f32x4 acc[1][2];
     zero_acc3(acc);
     gemm_split3<true, 1, 2, KS1, RING>(xr, 2 * (wave >> 1), w1, acc, ring1);
+    SB_STAMP(3);
     WPiece ring2[RING];
     preload_wring<4, RING>(ring2, w2);
 #pragma unroll
@@ -562,9 +386,11 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
     msr3d_attn::load_probs_tile<TM>(p.probs + ((size_t)b * H + h) * L * L, L, sp);
     const float *plb = msr3d_attn::stage_ploc<TM>(p.ploc, b, L, sp + TM * (TM + 4));
     __syncthreads();
+    SB_STAMP(5);
     f32x4 oq[2], ok[2], ov[2];
     msr3d_attn::attn_bwd_core<TM, MSR3D_MMA_F32>(L, sq, sk, sv, sdo, sp, plb, scond, 8, p.pad + (size_t)b * L, sdc, 8,
                                                  oq, ok, ov);
+    SB_STAMP(6);
     // every wave is past the core's last barrier: the pairwise slab is dead, product 2's operand
     // (FRAG planes, 4 slabs: [dq | dk | dv | dcond, 0]) goes on top of it
     unsigned char *mid = reinterpret_cast<unsigned char *>(sp + TM * (TM + 4));
@@ -608,18 +434,20 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
     f32x4 acc2[4][4];
     zero_acc3(acc2);
     const XFrag<4> xm{reinterpret_cast<const unsigned short *>(mid) + lane * 8};
-    gemm_split3<false, 4, 4, 4, RING>(xm, 0, w2, acc2, ring2);
-    add_partials<4>(acc2, p.acc, nullptr, row_base, L, 64 * wave, lane);
+    gemm_split3<true, 4, 4, 4, RING>(xm, 0, w2, acc2, ring2);
+    SB_STAMP(7);
+    store_partials<4>(acc2, slab, row_base, L, 64 * wave, lane);
   }
+  SB_STAMP(8);
 }
 
-template <int KIND, int PRO>
+template <int KIND>
 int launch_block(const SB &p, int slices, hipStream_t s) {
   constexpr int lds = lds_bytes<KIND>();
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&scene_block_kernel<KIND, PRO>),
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&scene_block_kernel<KIND>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (attr != hipSuccess) return (int)attr;
-  scene_block_kernel<KIND, PRO><<<dim3(slices, p.B), 256, lds, s>>>(p);
+  scene_block_kernel<KIND><<<dim3(slices, p.B), 256, lds, s>>>(p);
   return (int)hipGetLastError();
 }
 
@@ -692,51 +520,34 @@ int msr3d_scene_block(const msr3d_scene_block_t *pp, msr3d_stream_t stream) {
   const SB &p = *pp;
   if (p.B < 0 || p.L <= 0 || p.L > TM) return MSR3D_EINVAL;
   if (p.B == 0) return 0;
-  if (!p.a0 || !p.w1) return MSR3D_EINVAL;
-  if ((p.p1 > 0.f || p.p2 > 0.f || p.p_drop > 0.f) && !p.seed) return MSR3D_EINVAL;
+  if (!p.w1) return MSR3D_EINVAL;
+  if (p.kind == MSR3D_BLK_LINEAR_KSPLIT ? !p.a0 : !p.xp) return MSR3D_EINVAL;
+  if (p.kind != MSR3D_BLK_LINEAR && (!p.part || p.part_stride < (long long)p.B * p.L * KD)) return MSR3D_EINVAL;
+  if (p.p_drop > 0.f && !p.seed) return MSR3D_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   switch (p.kind) {
     case MSR3D_BLK_ATTN_FWD:
-      if (p.H != 8 || !p.w2 || !p.acc || !p.qkvc || !p.ploc || !p.pad || !p.ctx || !p.bias1 || p.ldq % 4) return MSR3D_EINVAL;
-      if (p.w2_bytes < 8u * 16u * kPieceBytes) return MSR3D_EINVAL;
-      if (p.pro == MSR3D_PRO_ADD) {
-        if (!p.a1) return MSR3D_EINVAL;
-        return launch_block<MSR3D_BLK_ATTN_FWD, MSR3D_PRO_ADD>(p, 8, s);
-      }
-      if (p.pro == MSR3D_PRO_LN) {
-        if (!p.a1 || !p.g1) return MSR3D_EINVAL;
-        return launch_block<MSR3D_BLK_ATTN_FWD, MSR3D_PRO_LN>(p, 8, s);
-      }
-      return MSR3D_EINVAL;
+      if (p.H != 8 || !p.w2 || !p.qkvc || !p.ploc || !p.pad || !p.ctx || !p.bias1 || p.ldq % 4) return MSR3D_EINVAL;
+      if (p.w1_bytes < 8u * 8u * 8u * kPieceBytes || p.w2_bytes < 8u * 16u * kPieceBytes) return MSR3D_EINVAL;
+      return launch_block<MSR3D_BLK_ATTN_FWD>(p, 8, s);
     case MSR3D_BLK_FFN_FWD:
-      if (p.pro != MSR3D_PRO_LN2 || !p.a1 || !p.g1 || !p.g2 || !p.o0 || !p.o1 || !p.o2 || !p.ost1 || !p.ost2) return MSR3D_EINVAL;
-      if (p.ff <= 0 || p.ff % 128 || !p.w2 || !p.acc || !p.pre || !p.h) return MSR3D_EINVAL;
-      if (p.w1_bytes < (unsigned)(8 * (p.ff / 16)) * kPieceBytes || p.w2_bytes < (unsigned)((p.ff / 32) * 16) * kPieceBytes)
-        return MSR3D_EINVAL;
-      return launch_block<MSR3D_BLK_FFN_FWD, MSR3D_PRO_LN2>(p, p.ff / 128, s);
     case MSR3D_BLK_FFN_BWD:
-      if (p.pro != MSR3D_PRO_LNBWD || !p.a1 || !p.st1 || !p.g1) return MSR3D_EINVAL;
-      if (p.ff <= 0 || p.ff % 128 || !p.w2 || !p.acc || !p.pre || !p.h) return MSR3D_EINVAL;
+      if (p.ff <= 0 || p.ff % 128 || p.ff / 128 > 16 || !p.w2 || !p.pre || !p.h) return MSR3D_EINVAL;
       if (p.w1_bytes < (unsigned)(8 * (p.ff / 16)) * kPieceBytes || p.w2_bytes < (unsigned)((p.ff / 32) * 16) * kPieceBytes)
         return MSR3D_EINVAL;
-      return launch_block<MSR3D_BLK_FFN_BWD, MSR3D_PRO_LNBWD>(p, p.ff / 128, s);
+      return p.kind == MSR3D_BLK_FFN_FWD ? launch_block<MSR3D_BLK_FFN_FWD>(p, p.ff / 128, s)
+                                         : launch_block<MSR3D_BLK_FFN_BWD>(p, p.ff / 128, s);
     case MSR3D_BLK_ATTN_BWD:
-      if (p.pro != MSR3D_PRO_LN2BWD || !p.a1 || !p.a2 || !p.st1 || !p.st2 || !p.g1 || !p.g2 || !p.o0 || !p.o1) return MSR3D_EINVAL;
-      if (p.H != 8 || !p.w2 || !p.acc || !p.qkvc || !p.dqkvc || !p.ploc || !p.pad || !p.probs || p.ldq % 4) return MSR3D_EINVAL;
-      if (p.w1_bytes < 8u * 16u * kPieceBytes) return MSR3D_EINVAL;
-      return launch_block<MSR3D_BLK_ATTN_BWD, MSR3D_PRO_LN2BWD>(p, 8, s);
+      if (p.H != 8 || !p.w2 || !p.qkvc || !p.dqkvc || !p.ploc || !p.pad || !p.probs || p.ldq % 4) return MSR3D_EINVAL;
+      if (p.w1_bytes < 8u * 16u * kPieceBytes || p.w2_bytes < 8u * 4u * 16u * kPieceBytes) return MSR3D_EINVAL;
+      return launch_block<MSR3D_BLK_ATTN_BWD>(p, 8, s);
     case MSR3D_BLK_LINEAR:
       if (p.N <= 0 || p.N % 256 || !p.C || p.ldc % 4 || p.w1_bytes < (unsigned)(8 * (p.N / 16)) * kPieceBytes) return MSR3D_EINVAL;
-      if (p.pro == MSR3D_PRO_PLAIN) return launch_block<MSR3D_BLK_LINEAR, MSR3D_PRO_PLAIN>(p, p.N / 256, s);
-      if (p.pro == MSR3D_PRO_LN) {
-        if (!p.a1 || !p.g1) return MSR3D_EINVAL;
-        return launch_block<MSR3D_BLK_LINEAR, MSR3D_PRO_LN>(p, p.N / 256, s);
-      }
-      return MSR3D_EINVAL;
+      return launch_block<MSR3D_BLK_LINEAR>(p, p.N / 256, s);
     case MSR3D_BLK_LINEAR_KSPLIT:
-      if (p.pro != MSR3D_PRO_PLAIN || p.lda0 <= 0 || p.lda0 % 256 || !p.acc) return MSR3D_EINVAL;
+      if (p.lda0 <= 0 || p.lda0 % 256 || p.lda0 / 256 > 16) return MSR3D_EINVAL;
       if (p.w1_bytes < (unsigned)((p.lda0 / 32) * 16) * kPieceBytes) return MSR3D_EINVAL;
-      return launch_block<MSR3D_BLK_LINEAR_KSPLIT, MSR3D_PRO_PLAIN>(p, p.lda0 / 256, s);
+      return launch_block<MSR3D_BLK_LINEAR_KSPLIT>(p, p.lda0 / 256, s);
     default:
       return MSR3D_EINVAL;
   }

@@ -41,8 +41,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(int nprob, const WP
     if (prefix[mid] <= t) lo = mid; else hi = mid - 1;
   }
   const WP pr = probs[lo];
-  const int local = t - prefix[lo];
+  // A problem owns a multiple of 8 workgroups; workgroup b runs on XCD b % 8 (observed dispatch order:
+  // speed only), so XCD x takes the CONTIGUOUS run of tiles [x nb/8, (x+1) nb/8): tiles that share a dy
+  // block (same output tile, consecutive input tiles) read it through one L2.
+  const int lb = t - prefix[lo], nb = prefix[lo + 1] - prefix[lo];
+  const int local = (lb & 7) * (nb >> 3) + (lb >> 3);
   const int nkt = (pr.k_in + TK - 1) / TK;
+  if (local >= ((pr.n_out + TN - 1) / TN) * nkt) return;
   const int ntile = local / nkt, ktile = local - ntile * nkt;
   const int n0 = ntile * TN, k0 = ktile * TK;
   const int M = pr.M;

@@ -173,12 +173,13 @@ class PrompterSchedule:
             a.want(f"ffn{i}", M, D, zero=True)
         a.want("d_tok", M, D, zero=True)
         blocks = self._blocks_capable(L, FF, H)
-        if blocks:      # meeting points of the scene blocks' second products; per-layer dy for the deferred dW launch
+        if blocks:      # scene blocks: per-layer sums and dy's (kept for the deferred dW launch), partial slabs
             for i in range(nl):
-                a.want(f"fcacc{i}", M, D, zero=True); a.want(f"d_t{i}", M, D, zero=True)
-                a.want(f"d_xacc{i}", M, D, zero=True)
+                a.want(f"fcacc{i}", M, D); a.want(f"d_t{i}", M, D); a.want(f"d_xacc{i}", M, D)
                 a.want(f"d_ffn{i}", M, D); a.want(f"d_pre{i}", M, FF); a.want(f"d_fc{i}", M, D)
                 a.want(f"d_qkvc{i}", M, W)
+            a.want("part", 16, M, D)       # a block's partial products, one slab per slice
+            a.want("res", M, D)            # the residual gradient that joins the next sum
         a.want("loc6", M, 6)
         a.want("ff", M, KF)
         a.want("pw", B, L, L, 5)
@@ -206,6 +207,8 @@ class PrompterSchedule:
         self.staged_for = None
         self.packs = self.wgrad = None
         if blocks:
+            # the blocks' input rows as three bf16 planes per scene; rows past L are never written (stay zero)
+            self.xp = torch.zeros(B * 3 * 64 * 256, dtype=torch.int16, device=device)
             self._build_block_tables()
 
 
@@ -268,7 +271,9 @@ class PrompterSchedule:
         self.packs, self.wgrad = pk, wg
 
     def forward_blocks(self, embeds):
-        """forward   step_begin | pack | proj | pos | 3 x [attention block | feed-forward block] | LN -> llm_proj"""
+        """forward   step_begin | pack | proj | pos | 3 x [rows | attention block | rows | feed-forward block]
+                     | rows | llm_proj        (rows = msr3d_scene_rows: sum of the partial slabs + the row-local
+                     dropout / residual / LayerNorm chain, once per row, -> bf16 planes)"""
         pr, m, a, dm = self.pr, self.model, self.arena, self.dims
         B, L, M, D, W, H, FF, E, KF, KE, nl = (dm[k] for k in ("B", "L", "M", "D", "W", "H", "FF", "E", "KF", "KE", "nl"))
         dev = embeds.device
@@ -287,8 +292,9 @@ class PrompterSchedule:
             self.ps.append((float(sa.dropout.p) if train else 0.0, float(layer.dropout1.p) if train else 0.0,
                             float(layer.dropout2.p) if train else 0.0, float(layer.dropout.p) if train else 0.0))
         same_all = pr.cfg.spatial_encoder.obj_loc_encoding == "same_all"
-        pk = self.packs
-        blk = scene_blocks.launch_block
+        pk, xp, part, MD = self.packs, self.xp, a["part"], M * D
+        blk, rows = scene_blocks.launch_block, scene_blocks.launch_rows
+        nff = FF // 128
         with torch.cuda.device(dev):
             rc = lib.msr3d_step_begin(_ptr(a.buf), a.zero_floats, _ptr(seed) if self.bump_seed else None, st)
             _lib.check(rc, "msr3d_step_begin")
@@ -305,44 +311,49 @@ class PrompterSchedule:
             _lib.check(rc, "msr3d_pos_embed_fwd")
             for i, layer in enumerate(layers):
                 sa = layer.self_attn
-                wv, bv = sa._packed[0], sa._packed[1]
+                bv = sa._packed[1]
                 p_attn, p1, p2, p_ffn = self.ps[i]
                 s_attn, s_1, s_2, s_ffn = self.salts[i]
-                common = dict(kind=BLK["attn_fwd"], B=B, L=L, w1=pk.bufs[f"qkvc{i}"], w1_bytes=pk.nbytes(f"qkvc{i}"),
-                              bias1=bv, w2=pk.bufs[f"fc{i}"], w2_bytes=pk.nbytes(f"fc{i}"), bias2=sa.fc.bias,
-                              acc=a[f"fcacc{i}"], qkvc=a[f"qkvc{i}"], ldq=W, ploc=a["pw"], pad=self.pad,
-                              probs=a[f"probs{i}"], ctx=a[f"ctx{i}"], H=H, seed=seed)
-                if i == 0:
-                    blk(st, pro=PRO["add"], a0=a["x0"], a1=a["pos"], g1=_ptr(pr.object_type_embedding.weight),
-                        b1=_ptr(pr.object_orientation_feat) if pr.use_orientation else None, o1=a["xin0"], **common)
-                else:
+                if i == 0:      # layer input = tokens + positional term + the two constant embedding rows
+                    rows(st, M=M, L=L, pro=PRO["add"], a0=a["x0"], a1=a["pos"], g1=_ptr(pr.object_type_embedding.weight),
+                         b1=_ptr(pr.object_orientation_feat) if pr.use_orientation else None, o1=a["xin0"], xp=xp)
+                else:           # previous layer's closing norm (+ the positional term)
                     prev = layers[i - 1]
-                    blk(st, pro=PRO["ln"], a0=a[f"ffn{i-1}"], a1=a[f"t{i-1}"], a2=a["pos"] if same_all else None,
-                        g1=prev.norm2.weight, b1=prev.norm2.bias, eps1=prev.norm2.eps, p1=self.ps[i - 1][2],
-                        salt1=self.salts[i - 1][2], o0=a[f"s3_{i-1}"], ost1=a[f"st3_{i-1}"], o1=a[f"xin{i}"], **common)
-                blk(st, kind=BLK["ffn_fwd"], B=B, L=L, pro=PRO["ln2"], a0=a[f"fcacc{i}"], a1=a[f"xin{i}"],
-                    g1=sa.layer_norm.weight, b1=sa.layer_norm.bias, eps1=sa.layer_norm.eps, p1=p_attn, salt1=s_attn,
-                    g2=layer.norm1.weight, b2=layer.norm1.bias, eps2=layer.norm1.eps, p2=p1, salt2=s_1, seed=seed,
-                    o0=a[f"s1_{i}"], ost1=a[f"st1_{i}"], o2=a[f"s2_{i}"], ost2=a[f"st2_{i}"], o1=a[f"t{i}"],
-                    w1=pk.bufs[f"w1_{i}"], w1_bytes=pk.nbytes(f"w1_{i}"), bias1=layer.linear1.bias,
-                    w2=pk.bufs[f"w2_{i}"], w2_bytes=pk.nbytes(f"w2_{i}"), bias2=layer.linear2.bias, acc=a[f"ffn{i}"],
-                    pre=a[f"pre{i}"], h=a[f"h{i}"], ff=FF, p_drop=p_ffn, salt=s_ffn)
+                    rows(st, M=M, L=L, pro=PRO["ln"], part=part, nslab=nff, part_stride=MD, a0_bias=prev.linear2.bias,
+                         sum_out=a[f"ffn{i-1}"], a1=a[f"t{i-1}"], a2=a["pos"] if same_all else None,
+                         g1=prev.norm2.weight, b1=prev.norm2.bias, eps1=prev.norm2.eps, p1=self.ps[i - 1][2],
+                         salt1=self.salts[i - 1][2], seed=seed, o0=a[f"s3_{i-1}"], ost1=a[f"st3_{i-1}"],
+                         o1=a[f"xin{i}"], xp=xp)
+                blk(st, kind=BLK["attn_fwd"], B=B, L=L, xp=xp, w1=pk.bufs[f"qkvc{i}"], w1_bytes=pk.nbytes(f"qkvc{i}"),
+                    bias1=bv, w2=pk.bufs[f"fc{i}"], w2_bytes=pk.nbytes(f"fc{i}"), part=part, part_stride=MD,
+                    qkvc=a[f"qkvc{i}"], ldq=W, ploc=a["pw"], pad=self.pad, probs=a[f"probs{i}"], ctx=a[f"ctx{i}"], H=H)
+                # attention tail's LayerNorm, then norm1 over the same residual -> the feed-forward block's input
+                rows(st, M=M, L=L, pro=PRO["ln2"], part=part, nslab=H, part_stride=MD, a0_bias=sa.fc.bias,
+                     sum_out=a[f"fcacc{i}"], a1=a[f"xin{i}"], g1=sa.layer_norm.weight, b1=sa.layer_norm.bias,
+                     eps1=sa.layer_norm.eps, p1=p_attn, salt1=s_attn, g2=layer.norm1.weight, b2=layer.norm1.bias,
+                     eps2=layer.norm1.eps, p2=p1, salt2=s_1, seed=seed, o0=a[f"s1_{i}"], ost1=a[f"st1_{i}"],
+                     o2=a[f"s2_{i}"], ost2=a[f"st2_{i}"], o1=a[f"t{i}"], xp=xp)
+                blk(st, kind=BLK["ffn_fwd"], B=B, L=L, xp=xp, w1=pk.bufs[f"w1_{i}"], w1_bytes=pk.nbytes(f"w1_{i}"),
+                    bias1=layer.linear1.bias, w2=pk.bufs[f"w2_{i}"], w2_bytes=pk.nbytes(f"w2_{i}"), part=part,
+                    part_stride=MD, pre=a[f"pre{i}"], h=a[f"h{i}"], ff=FF, p_drop=p_ffn, salt=s_ffn, seed=seed)
             last = layers[-1]
+            tail = dict(M=M, L=L, pro=PRO["ln"], part=part, nslab=nff, part_stride=MD, a0_bias=last.linear2.bias,
+                        sum_out=a[f"ffn{nl-1}"], a1=a[f"t{nl-1}"], g1=last.norm2.weight, b1=last.norm2.bias,
+                        eps1=last.norm2.eps, p1=self.ps[-1][2], salt1=self.salts[-1][2], seed=seed,
+                        o0=a[f"s3_{nl-1}"], ost1=a[f"st3_{nl-1}"], o1=a["tok"])
             if self.llm_blocks:
-                blk(st, kind=BLK["linear"], B=B, L=L, pro=PRO["ln"], a0=a[f"ffn{nl-1}"], a1=a[f"t{nl-1}"],
-                    g1=last.norm2.weight, b1=last.norm2.bias, eps1=last.norm2.eps, p1=self.ps[-1][2],
-                    salt1=self.salts[-1][2], seed=seed, o0=a[f"s3_{nl-1}"], ost1=a[f"st3_{nl-1}"], o1=a["tok"],
-                    w1=pk.bufs["llm"], w1_bytes=pk.nbytes("llm"), bias1=m.llm_proj.bias, C=a["scene"], ldc=E, N=E)
+                rows(st, xp=xp, **tail)
+                blk(st, kind=BLK["linear"], B=B, L=L, xp=xp, w1=pk.bufs["llm"], w1_bytes=pk.nbytes("llm"),
+                    bias1=m.llm_proj.bias, C=a["scene"], ldc=E, N=E)
             else:
-                self._strip(M=M, N=E, pro=PRO["ln"], epi=EPI["bias"], b_kc=1, a0=a[f"ffn{nl-1}"], a1=a[f"t{nl-1}"],
-                            g1=last.norm2.weight, b1=last.norm2.bias, eps1=last.norm2.eps, p1=self.ps[-1][2],
-                            salt1=self.salts[-1][2], seed=seed, o0=a[f"s3_{nl-1}"], ost1=a[f"st3_{nl-1}"], o1=a["tok"],
-                            W=m.llm_proj.weight, ldw=D, bias=m.llm_proj.bias, C=a["scene"], ldc=E)
+                rows(st, **tail)
+                self._strip(M=M, N=E, pro=PRO["plain"], epi=EPI["bias"], b_kc=1, a0=a["tok"], W=m.llm_proj.weight,
+                            ldw=D, bias=m.llm_proj.bias, C=a["scene"], ldc=E)
         return a["tok"].view(B, L, D), a["scene"].view(B, L, E)
 
     def backward_blocks(self, g_scene, g_tok):
-        """backward  d tok = d scene W_llm | 3 x [feed-forward block bwd | attention block bwd] | pos-bwd
-                     | ALL weight gradients in one launch"""
+        """backward  d tok partials = d scene W_llm | 3 x [rows | feed-forward block bwd | rows | attention block
+                     bwd] | rows (sum) | pos-bwd | ALL weight gradients in one launch"""
         pr, m, a, dm = self.pr, self.model, self.arena, self.dims
         B, L, M, D, W, H, FF, E, KF, KE, nl = (dm[k] for k in ("B", "L", "M", "D", "W", "H", "FF", "E", "KF", "KE", "nl"))
         dev = a.buf.device
@@ -351,19 +362,23 @@ class PrompterSchedule:
         seed = hipops.seed_word(dev)
         layers = list(pr.spatial_encoder)
         same_all = pr.cfg.spatial_encoder.obj_loc_encoding == "same_all"
-        pk, wg = self.packs, self.wgrad
-        blk = scene_blocks.launch_block
+        pk, wg, xp, part, MD = self.packs, self.wgrad, self.xp, a["part"], M * D
+        blk, rows = scene_blocks.launch_block, scene_blocks.launch_rows
+        nff = FF // 128
         with torch.cuda.device(dev):
-            if g_tok is not None:            # a consumer of obj_tokens besides llm_proj
-                a["d_tok"].add_(g_tok.reshape(M, D))
             lp = m.llm_proj
+            # the top layer's upstream gradient: d tok = d scene W_llm (+ a direct consumer of obj_tokens)
+            src = dict(a0=a["d_tok"])                       # zeros (step_begin) unless something arrives
+            if g_tok is not None:
+                a["d_tok"].add_(g_tok.reshape(M, D))
             if g_scene is not None:
                 g = g_scene.reshape(M, E)
                 g = g if g.is_contiguous() else g.contiguous()
                 self._g_keep = g
                 if self.llm_blocks:
-                    blk(st, kind=BLK["linear_ksplit"], B=B, L=L, pro=PRO["plain"], a0=g, lda0=E, w1=pk.bufs["llm_t"],
-                        w1_bytes=pk.nbytes("llm_t"), acc=a["d_tok"])
+                    blk(st, kind=BLK["linear_ksplit"], B=B, L=L, a0=g, lda0=E, w1=pk.bufs["llm_t"],
+                        w1_bytes=pk.nbytes("llm_t"), part=part, part_stride=MD)
+                    src = dict(part=part, nslab=E // 256, part_stride=MD, extra=a["d_tok"] if g_tok is not None else None)
                 else:
                     self._multi([dict(a_kc=1, b_kc=0, M=M, N=D, K=E, A=g, lda=E, B=lp.weight, ldb=D, C=a["d_tok"],
                                       ldc=D, beta=1.0)])
@@ -371,30 +386,32 @@ class PrompterSchedule:
                 wg.set_ptr(self.wg_llm, "M", M)
             else:
                 wg.set_ptr(self.wg_llm, "M", 0)             # no upstream gradient for llm_proj in this step
-            d_out = a["d_tok"]
             for i in range(nl - 1, -1, -1):
                 layer = layers[i]
                 sa = layer.self_attn
                 p_attn, p1, p2, p_ffn = self.ps[i]
                 s_attn, s_1, s_2, s_ffn = self.salts[i]
-                # LN(norm2)-bwd -> d_ffn; d_h = d_ffn W2 -> GELU-bwd -> d_pre; d_t = LN residual + d_pre W1
-                blk(st, kind=BLK["ffn_bwd"], B=B, L=L, pro=PRO["lnbwd"], a0=d_out, a1=a[f"s3_{i}"], st1=a[f"st3_{i}"],
-                    g1=layer.norm2.weight, p1=p2, salt1=s_2, seed=seed, o0=a[f"d_ffn{i}"], o1=a[f"d_t{i}"],
-                    dg1=layer.norm2.weight.grad, db1=layer.norm2.bias.grad,
-                    w1=pk.bufs[f"w2_t{i}"], w1_bytes=pk.nbytes(f"w2_t{i}"), w2=pk.bufs[f"w1_t{i}"],
-                    w2_bytes=pk.nbytes(f"w1_t{i}"), acc=a[f"d_t{i}"], pre=a[f"pre{i}"], h=a[f"d_pre{i}"], ff=FF,
-                    p_drop=p_ffn, salt=s_ffn)
-                # LN(norm1), LN(attention tail) bwd -> d_fc, residual gradient; d_ctx = d_fc Wfc; attention bwd;
-                # d_xin = residual + d[q|k|v|cond] W
-                blk(st, kind=BLK["attn_bwd"], B=B, L=L, pro=PRO["ln2bwd"], a0=a[f"d_t{i}"], a1=a[f"s1_{i}"],
-                    a2=a[f"s2_{i}"], st1=a[f"st1_{i}"], st2=a[f"st2_{i}"], g1=sa.layer_norm.weight,
-                    g2=layer.norm1.weight, p1=p_attn, salt1=s_attn, p2=p1, salt2=s_1, seed=seed,
-                    o0=a[f"d_fc{i}"], o1=a[f"d_xacc{i}"], dg1=sa.layer_norm.weight.grad, db1=sa.layer_norm.bias.grad,
-                    dg2=layer.norm1.weight.grad, db2=layer.norm1.bias.grad,
-                    w1=pk.bufs[f"fc_t{i}"], w1_bytes=pk.nbytes(f"fc_t{i}"), w2=pk.bufs[f"qkvc_t{i}"],
-                    w2_bytes=pk.nbytes(f"qkvc_t{i}"), acc=a[f"d_xacc{i}"], qkvc=a[f"qkvc{i}"], ldq=W,
-                    dqkvc=a[f"d_qkvc{i}"], ploc=a["pw"], pad=self.pad, probs=a[f"probs{i}"], H=H)
-                d_out = a[f"d_xacc{i}"]
+                # d_out (sum) -> LN(norm2)-bwd: residual gradient -> res, dropout-bwd -> d_ffn (+ planes)
+                rows(st, M=M, L=L, pro=PRO["lnbwd"], a1=a[f"s3_{i}"], st1=a[f"st3_{i}"], g1=layer.norm2.weight,
+                     p1=p2, salt1=s_2, seed=seed, o0=a[f"d_ffn{i}"], o1=a["res"], dg1=layer.norm2.weight.grad,
+                     db1=layer.norm2.bias.grad, sum_out=a[f"d_xacc{i+1}"] if i + 1 < nl else None, xp=xp, **src)
+                # d_h = d_ffn W2 -> GELU-bwd -> d_pre; partials of d_pre W1
+                blk(st, kind=BLK["ffn_bwd"], B=B, L=L, xp=xp, w1=pk.bufs[f"w2_t{i}"], w1_bytes=pk.nbytes(f"w2_t{i}"),
+                    w2=pk.bufs[f"w1_t{i}"], w2_bytes=pk.nbytes(f"w1_t{i}"), part=part, part_stride=MD,
+                    pre=a[f"pre{i}"], h=a[f"d_pre{i}"], ff=FF, p_drop=p_ffn, salt=s_ffn, seed=seed)
+                # d_t = residual + sum -> LN(norm1), LN(attention tail) bwd: residual -> res, d_fc (+ planes)
+                rows(st, M=M, L=L, pro=PRO["ln2bwd"], part=part, nslab=nff, part_stride=MD, extra=a["res"],
+                     sum_out=a[f"d_t{i}"], a1=a[f"s1_{i}"], a2=a[f"s2_{i}"], st1=a[f"st1_{i}"], st2=a[f"st2_{i}"],
+                     g1=sa.layer_norm.weight, g2=layer.norm1.weight, p1=p_attn, salt1=s_attn, p2=p1, salt2=s_1,
+                     seed=seed, o0=a[f"d_fc{i}"], o1=a["res"], dg1=sa.layer_norm.weight.grad,
+                     db1=sa.layer_norm.bias.grad, dg2=layer.norm1.weight.grad, db2=layer.norm1.bias.grad, xp=xp)
+                # d_ctx = d_fc Wfc; attention bwd; partials of d[q|k|v|cond] W
+                blk(st, kind=BLK["attn_bwd"], B=B, L=L, xp=xp, w1=pk.bufs[f"fc_t{i}"], w1_bytes=pk.nbytes(f"fc_t{i}"),
+                    w2=pk.bufs[f"qkvc_t{i}"], w2_bytes=pk.nbytes(f"qkvc_t{i}"), part=part, part_stride=MD,
+                    qkvc=a[f"qkvc{i}"], ldq=W, dqkvc=a[f"d_qkvc{i}"], ploc=a["pw"], pad=self.pad,
+                    probs=a[f"probs{i}"], H=H)
+                src = dict(part=part, nslab=H, part_stride=MD, extra=a["res"])
+            rows(st, M=M, L=L, pro=PRO["plain"], sum_out=a["d_xacc0"], **src)      # d_xin0, whole
             le, se = pr.loc_embedding_encoder, pr.size_embedding_encoder
             more = same_all and nl > 1
             rc = lib.msr3d_pos_embed_bwd(

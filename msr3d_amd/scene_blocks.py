@@ -12,7 +12,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import BLK, PRO, PackJob, SceneBlock, WgradProblem
+from ._lib import BLK, PRO, PackJob, SceneBlock, SceneRows, WgradProblem
 
 _vp = ctypes.c_void_p
 PIECE = 3 * 1024          # bytes of one (slab, tile): three planes of 64 lanes x 16 B
@@ -100,6 +100,7 @@ class WgradTable:
         p.dW, p.ldw, p.db = dW, ldw, db if db else None
         self.probs.append(p)
         tiles = -(-n_out // self.TN) * -(-k_in // self.TK)
+        tiles = (tiles + 7) // 8 * 8          # a multiple of 8 workgroups per problem (XCD-aware tile order)
         self.prefix.append(self.prefix[-1] + tiles)
         self._dirty = True
         return len(self.probs) - 1
@@ -144,4 +145,18 @@ def launch_block(stream, **kw):
         _lib.check(rc, f"msr3d_scene_block({fields})")
 
 
-__all__ = ["BLK", "PRO", "WeightPacks", "WgradTable", "launch_block", "head_segments", "PIECE"]
+def launch_rows(stream, **kw):
+    s = SceneRows()
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            v = v.data_ptr()
+        elif isinstance(v, _vp):
+            v = v.value
+        setattr(s, k, v if v is not None else 0)
+    rc = _lib.load().msr3d_scene_rows(ctypes.byref(s), stream)
+    if rc:
+        fields = ", ".join(f"{n}={getattr(s, n)!r}" for n, _ in s._fields_ if getattr(s, n))
+        _lib.check(rc, f"msr3d_scene_rows({fields})")
+
+
+__all__ = ["BLK", "PRO", "WeightPacks", "WgradTable", "launch_block", "launch_rows", "head_segments", "PIECE"]

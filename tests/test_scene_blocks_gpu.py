@@ -112,7 +112,7 @@ def test_blocks_schedule_matches_strips_schedule_on_every_intermediate(dropout, 
     finally:
         fused_model.set_mode("blocks")
     assert model._schedule.use_blocks()
-    names = ["x0", "pos", "tok", "scene", "d_tok", "d_la", "d_lb"]
+    names = ["x0", "pos", "tok", "scene", "d_la", "d_lb"]
     for i in range(3):
         names += [f"xin{i}", f"qkvc{i}", f"probs{i}", f"ctx{i}", f"s1_{i}", f"s2_{i}", f"t{i}", f"pre{i}", f"h{i}", f"ffn{i}"]
     for k in names:

@@ -45,7 +45,7 @@ def main():
     for i in range(nl):
         order += [f"xin{i}", f"qkvc{i}", f"probs{i}", f"ctx{i}", f"fc{i}", f"s1_{i}", f"s2_{i}", f"t{i}", f"pre{i}",
                   f"h{i}", f"ffn{i}"]
-    order += ["tok", "scene", "d_tok"]
+    order += ["tok", "scene"]
     print("--- forward / last-layer backward buffers (strips vs blocks)")
     for k in order:
         kb = k
