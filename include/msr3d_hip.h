@@ -634,10 +634,10 @@ int msr3d_scene_rows(const msr3d_scene_rows_t *p, msr3d_stream_t stream);
 
 /* All weight gradients of a step in ONE launch: for every problem dW (n_out, k_in) += dy^T x over the
  * M token rows (dy (M, n_out), x (M, k_in), dense f32) and, optionally, db (n_out) += colsum(dy).
- * fp32-accurate on the bf16 pipe (operands split on the way into LDS); one workgroup owns a 128 x 64
+ * fp32-accurate on the bf16 pipe (operands split on the way into LDS); one workgroup owns a 128 x 128
  * tile of dW over the WHOLE reduction: no split-K, no atomics, bit-reproducible; `dW` holds the value to
  * add to (the flat gradient buffer).  problems, tile_prefix (n + 1 ints; problem i owns workgroups
- * [tile_prefix[i], tile_prefix[i+1]), a multiple of 8 >= its ceil(n_out/128) * ceil(k_in/64) tiles): DEVICE memory. */
+ * [tile_prefix[i], tile_prefix[i+1]), a multiple of 8 >= its ceil(n_out/128) * ceil(k_in/128) tiles): DEVICE memory. */
 typedef struct msr3d_wgrad_problem {
   const float *dy; int ldy; int n_out;
   const float *x; int ldx; int k_in;

@@ -166,6 +166,51 @@ __device__ __forceinline__ void load_probs_tile(const float *__restrict__ probs_
   }
 }
 
+// The same two tiles fetched into REGISTERS first (the fused blocks issue these loads ahead of a matrix
+// product whose operand still occupies the LDS they are headed for) and stored later.  64-token tile,
+// 256 threads; `vec` (16-byte aligned source, element count % 4 == 0) is the caller's to check.
+constexpr int kPlocRegs = 64 * 64 * SD / 4 / 256;       // 20 float4 per thread
+__device__ __forceinline__ void ploc_fetch(const float *__restrict__ src, int n4, float4 (&v)[kPlocRegs]) {
+#pragma unroll
+  for (int k = 0; k < kPlocRegs; ++k) {
+    const int e = threadIdx.x + 256 * k;
+    v[k] = e < n4 ? reinterpret_cast<const float4 *>(src)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+__device__ __forceinline__ void ploc_store(float *spl, int n4, const float4 (&v)[kPlocRegs]) {
+#pragma unroll
+  for (int k = 0; k < kPlocRegs; ++k) {
+    const int e = threadIdx.x + 256 * k;
+    if (e < n4) reinterpret_cast<float4 *>(spl)[e] = v[k];
+  }
+}
+constexpr int kProbRegs = 64 * 64 / 4 / 256;            // 4 float4 per thread
+__device__ __forceinline__ void probs_fetch(const float *__restrict__ probs_bh, int L, float4 (&v)[kProbRegs]) {
+  const int n4 = (L * L) >> 2;
+#pragma unroll
+  for (int k = 0; k < kProbRegs; ++k) {
+    const int e = threadIdx.x + 256 * k;
+    v[k] = e < n4 ? reinterpret_cast<const float4 *>(probs_bh)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+// L % 4 == 0: a float4 never straddles a row; [64][68] tile, zero outside (L, L)
+__device__ __forceinline__ void probs_store(float *sp, int L, const float4 (&v)[kProbRegs]) {
+  constexpr int LDP = 64 + 4;
+  const int n4 = (L * L) >> 2;
+#pragma unroll
+  for (int k = 0; k < kProbRegs; ++k) {
+    const int e = threadIdx.x + 256 * k;
+    if (e < n4) {
+      const int idx = 4 * e, row = idx / L, col = idx - row * L;
+      *reinterpret_cast<float4 *>(sp + row * LDP + col) = v[k];
+    }
+  }
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int row = e >> 6, col = e & 63;
+    if (row >= L || col >= L) sp[row * LDP + col] = 0.f;
+  }
+}
+
 struct RowCond { float bias, w[SD]; };
 
 // `cond0`: the (bias, w[5]) sextet of row 0 of this (scene, head); rows are `ldc` floats apart
@@ -206,6 +251,9 @@ __device__ __forceinline__ void attn_fwd_core(int L, const float *sq, const floa
   strip_mma<MMA, NT, DH, true, true>(sq, LD32, sk, LD32, row0, acc, lane);
 
   // logits on the accumulators: element (row = row0 + 4g + r, col = 16 rn + i)
+  bool keyok[NT];                        // the lane's NT key columns: inside the scene and not padding
+#pragma unroll
+  for (int rn = 0; rn < NT; ++rn) keyok[rn] = rn * 16 + i < L && !pad_b[min(rn * 16 + i, L - 1)];
   float mx[4], sm[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -216,7 +264,7 @@ __device__ __forceinline__ void attn_fwd_core(int L, const float *sq, const floa
     for (int rn = 0; rn < NT; ++rn) {
       const int col = rn * 16 + i;
       float lg = -INFINITY;
-      if (row < L && col < L && !pad_b[col]) {
+      if (row < L && keyok[rn]) {
         const float *pl = plb + ((size_t)row * L + col) * SD;
         float z = c.bias;
 #pragma unroll
@@ -283,6 +331,9 @@ __device__ __forceinline__ void attn_bwd_core(int L, const float *sq, const floa
   strip_mma<MMA, 2, LT, false, false>(sp, LDP, sdo, LD32, row0, ov, lane);
   __syncthreads();                       // every wave is done reading P as a matrix operand
 
+  bool keyok[NT];
+#pragma unroll
+  for (int rn = 0; rn < NT; ++rn) keyok[rn] = rn * 16 + i < L && !pad_b[min(rn * 16 + i, L - 1)];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = row0 + 4 * g + r;
@@ -303,7 +354,7 @@ __device__ __forceinline__ void attn_bwd_core(int L, const float *sq, const floa
       const int col = rn * 16 + i;
       const float dlogit = p[rn] * (acc[rn][r] - dot);     // softmax backward
       sp[row * LDP + col] = dlogit;         // in place: this lane owns the element
-      if (row < L && col < L && !pad_b[col]) {
+      if (row < L && keyok[rn]) {
         const float *pl = plb + ((size_t)row * L + col) * SD;
         float z = c.bias;
 #pragma unroll

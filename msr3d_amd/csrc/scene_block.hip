@@ -60,6 +60,32 @@ constexpr int MID_BYTES = 4 * 4 * 3 * 1024;   // FRAG planes of a 64 x 128 middl
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 
+// erf-form GELU (F.gelu default, transformers.py:323) with erf by Abramowitz-Stegun 7.1.26:
+// |error| <= 1.5e-7 on erf, i.e. below the fp32 resolution of (1 + erf).  Branch-free, ~15 instructions:
+// the library erff (two polynomial branches, both executed by a diverged wave) made the feed-forward
+// block's epilogue -- 32 activations per lane with one wave per SIMD -- as long as its two products.
+__device__ __forceinline__ float erfc_pos(float z, float e) {      // erfc(z), z >= 0, e = exp(-z z)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float q = fmaf(1.061405429f, t, -1.453152027f);
+  q = fmaf(q, t, 1.421413741f);
+  q = fmaf(q, t, -0.284496736f);
+  q = fmaf(q, t, 0.254829592f);
+  return q * t * e;
+}
+__device__ __forceinline__ float gelu_as(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float ec = erfc_pos(z, __expf(-z * z));                     // erfc(|x| / sqrt 2)
+  const float phi = x >= 0.f ? 1.0f - 0.5f * ec : 0.5f * ec;        // Phi(x)
+  return x * phi;
+}
+__device__ __forceinline__ float gelu_as_grad(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float e = __expf(-z * z);                                   // exp(-x x / 2)
+  const float ec = erfc_pos(z, e);
+  const float phi = x >= 0.f ? 1.0f - 0.5f * ec : 0.5f * ec;
+  return fmaf(x * 0.39894228040143267794f, e, phi);
+}
+
 // Input staging.  Every kind but LINEAR_KSPLIT: the scene's three planes (B, 3, 64, 256) bf16, one
 // contiguous 96 KB block, copied into the ROWS layout (pitch 272) -- 24 16-byte loads per thread, all in
 // flight together; rows past L are zero in the source.  LINEAR_KSPLIT: fp32 rows a0[row][col0 .. col0 + 256)
@@ -176,14 +202,17 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
 
   if constexpr (KIND == MSR3D_BLK_LINEAR) {
     // ------------------------------------------------------------------ C = rows W^T + b
+    const int n0 = 256 * slice + 64 * wave + 4 * g;
+    float4 bias[4];                        // ahead of the product: a load next to the stores would make every store wait
+#pragma unroll
+    for (int rn = 0; rn < 4; ++rn) bias[rn] = p.bias1 ? ld4(p.bias1 + n0 + 16 * rn) : make_float4(0.f, 0.f, 0.f, 0.f);
     f32x4 acc[4][4];
     zero_acc3(acc);
     gemm_split3<true, 4, 4, KS1, RING>(xr, 0, w1, acc, ring1);
     SB_STAMP(3);
-    const int n0 = 256 * slice + 64 * wave + 4 * g;
 #pragma unroll
     for (int rn = 0; rn < 4; ++rn) {
-      const float4 bv = p.bias1 ? ld4(p.bias1 + n0 + 16 * rn) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 bv = bias[rn];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const int row = 16 * mt + j;
@@ -215,6 +244,10 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
         for (int mt = 0; mt < 4; ++mt)
           pre_in[rn][mt] = ld4(p.pre + (size_t)(row_base + min(16 * mt + j, L - 1)) * ff + hc0 + 16 * rn);
     }
+    float4 bias[2];
+#pragma unroll
+    for (int rn = 0; rn < 2; ++rn)
+      bias[rn] = (FWD && p.bias1) ? ld4(p.bias1 + hc0 + 16 * rn) : make_float4(0.f, 0.f, 0.f, 0.f);
     f32x4 acc[2][4];
     zero_acc3(acc);
     gemm_split3<true, 2, 4, KS1, RING>(xr, 0, w1, acc, ring1);
@@ -228,9 +261,7 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
     unsigned char *mid = aux;
 #pragma unroll
     for (int rn = 0; rn < 2; ++rn) {
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (FWD && p.bias1) bv = ld4(p.bias1 + hc0 + 16 * rn);
-      const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
+      const float b4[4] = {bias[rn].x, bias[rn].y, bias[rn].z, bias[rn].w};
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const int row = 16 * mt + j;
@@ -243,7 +274,7 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
           if (ok) st4(p.pre + o, make_float4(v[0], v[1], v[2], v[3]));
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            v[r] = gelu_exact(v[r]);
+            v[r] = gelu_as(v[r]);
             if (drop) v[r] = keep_elem(sd, p.salt, (unsigned)(o + r), thresh) ? v[r] * dscale : 0.f;
             if (!ok) v[r] = 0.f;
           }
@@ -253,7 +284,7 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
           for (int r = 0; r < 4; ++r) {
             float d = acc[rn][mt][r];
             if (drop) d = keep_elem(sd, p.salt, (unsigned)(o + r), thresh) ? d * dscale : 0.f;
-            v[r] = ok ? d * gelu_exact_grad(pi[r]) : 0.f;
+            v[r] = ok ? d * gelu_as_grad(pi[r]) : 0.f;
           }
         }
         if (ok) st4(p.h + o, make_float4(v[0], v[1], v[2], v[3]));
@@ -281,6 +312,12 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
     unsigned char *ctxp = reinterpret_cast<unsigned char *>(scond + TM * 8);   // FRAG, 1 slab x 4 row tiles
     // product 2's stream: Wfc [8 slabs][16 tiles], slab h
     const WStream w2 = make_wstream(p.w2, p.w2_bytes, 16, h, 4 * wave, lane);
+    // the scene's pairwise slab is headed for the LDS the planes occupy: fetched into registers now
+    const float *plsrc = p.ploc + (size_t)b * L * L * SD;
+    const int pn = L * L * SD;
+    const bool pvec = (reinterpret_cast<uintptr_t>(plsrc) & 15u) == 0 && (pn & 3) == 0;
+    float4 plv[msr3d_attn::kPlocRegs];
+    if (pvec) msr3d_attn::ploc_fetch(plsrc, pn >> 2, plv);
     f32x4 acc[2][4];
     zero_acc3(acc);
     gemm_split3<true, 2, 4, KS1, RING>(xr, 0, w1, acc, ring1);
@@ -324,7 +361,9 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
     SB_STAMP(4);
     __syncthreads();                       // every wave is done with the ROWS planes; q / k / v / cond visible
     float *sp = reinterpret_cast<float *>(xs);                      // P [64][68], then the pairwise slab
-    const float *plb = msr3d_attn::stage_ploc<TM>(p.ploc, b, L, sp + TM * (TM + 4));
+    const float *plb = sp + TM * (TM + 4);
+    if (pvec) msr3d_attn::ploc_store(sp + TM * (TM + 4), pn >> 2, plv);
+    else plb = msr3d_attn::stage_ploc<TM>(p.ploc, b, L, sp + TM * (TM + 4));
     __syncthreads();
     SB_STAMP(5);
     f32x4 o[2];
@@ -367,6 +406,13 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
       const int row = e >> 3, c = e & 7;
       scond[e] = (row < L && c < SD + 1) ? p.qkvc[(size_t)(row_base + row) * ldq + 3 * KD + h * (SD + 1) + c] : 0.f;
     }
+    const float *plsrc = p.ploc + (size_t)b * L * L * SD, *prsrc = p.probs + ((size_t)b * H + h) * L * L;
+    const int pn = L * L * SD;
+    const bool pvec = (reinterpret_cast<uintptr_t>(plsrc) & 15u) == 0 && (pn & 3) == 0;
+    const bool qvec = (reinterpret_cast<uintptr_t>(prsrc) & 15u) == 0 && (L & 3) == 0;
+    float4 plv[msr3d_attn::kPlocRegs], prv[msr3d_attn::kProbRegs];
+    if (pvec) msr3d_attn::ploc_fetch(plsrc, pn >> 2, plv);
+    if (qvec) msr3d_attn::probs_fetch(prsrc, L, prv);
     // d ctx_h = d_fc Wfc[:, 32 h : 32 h + 32]: wave (wr, wc) owns row tiles 2 wr, 2 wr + 1 and column tile wc
     f32x4 acc[1][2];
     zero_acc3(acc);
@@ -383,8 +429,11 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
     }
     __syncthreads();                       // planes free; q / k / v / cond / d ctx visible
     float *sp = reinterpret_cast<float *>(xs);
-    msr3d_attn::load_probs_tile<TM>(p.probs + ((size_t)b * H + h) * L * L, L, sp);
-    const float *plb = msr3d_attn::stage_ploc<TM>(p.ploc, b, L, sp + TM * (TM + 4));
+    if (qvec) msr3d_attn::probs_store(sp, L, prv);
+    else msr3d_attn::load_probs_tile<TM>(prsrc, L, sp);
+    const float *plb = sp + TM * (TM + 4);
+    if (pvec) msr3d_attn::ploc_store(sp + TM * (TM + 4), pn >> 2, plv);
+    else plb = msr3d_attn::stage_ploc<TM>(p.ploc, b, L, sp + TM * (TM + 4));
     __syncthreads();
     SB_STAMP(5);
     f32x4 oq[2], ok[2], ov[2];

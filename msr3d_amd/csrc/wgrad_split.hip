@@ -5,33 +5,59 @@
 //
 // The reduction runs over the TOKENS, i.e. across all scenes -- the one part of the backward that is not
 // scene-local -- so the weight gradients are deferred to the end of the backward (the scene blocks leave
-// dy and x of every linear layer behind as dense fp32 side outputs) and computed together: ~650 tiles of
-// 128 x 64 in one grid instead of ten launches of 2-3 products whose K-splits met by atomics.  A
+// dy and x of every linear layer behind as dense fp32 side outputs) and computed together: ~330 tiles of
+// 128 x 128 in one grid instead of ten launches of 2-3 products whose K-splits met by atomics.  A
 // workgroup owns a tile over the WHOLE reduction: no split-K, no atomics, bit-reproducible.
 //
 // Both operands are contracted over their ROW index, so a fragment (8 consecutive tokens of one column)
 // is a strided read: each thread loads 8 tokens x 1 column (a wave: 64 consecutive columns = 256
 // contiguous bytes per token), splits the eight values exactly into three bf16 terms (split_mma.h) and
 // writes its 16 bytes of each plane straight into fragment order in LDS -- the transpose costs nothing.
-// Register-prefetched, double-buffered over slabs of 32 tokens: one barrier per slab.
+// Register-prefetched three slabs ahead, LDS double-buffered over slabs of 32 tokens: one barrier per slab.
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "../../include/msr3d_hip.h"
 #include "split_mma.h"
+
+// phase marks: empty here; tools/prof/wgrad_stamped.hip defines WG_STAMP and includes this file
+#ifndef WG_STAMP
+#define WG_STAMP(i)
+#define WG_CLOCK() 0ull
+#define WG_PUT(i, v)
+#endif
 
 namespace {
 
 using namespace msr3d;
 using WP = msr3d_wgrad_problem_t;
 
-constexpr int TN = 128, TK = 64;                   // tile: 128 outputs x 64 inputs
-constexpr int A_BYTES = (TN / 16) * 3 * 1024;      // 24,576 per slab
-constexpr int B_BYTES = (TK / 16) * 3 * 1024;      // 12,288
-constexpr int BUF = A_BYTES + B_BYTES;
+constexpr int TN = 128, TK = 128;                  // tile: 128 outputs x 128 inputs
+// LDS fragment tiles: [3 planes][64 slots][16 B] + 64 B so that consecutive tiles start half a bank row apart,
+// and slot(j, g) = perm(j) + 16 g with perm(j) = 4 (j % 4) + j / 4.  A loader thread holds 4 CONSECUTIVE
+// columns (one 16-byte load per token): with the identity layout its 8-lane store groups would hit two
+// 16-byte positions per bank row (4-way conflicts); transposing the 4 x 4 slot grid and offsetting
+// alternate tiles makes the 8 stores of a group tile one whole bank row, and the multipliers'
+// ds_read_b128 lane groups still cover 16 distinct positions.
+constexpr int TILE_BYTES = 3 * 1024 + 64;
+constexpr int OP_BYTES = (TN / 16) * TILE_BYTES;   // one operand of one slab: 25,088
+constexpr int STAGE = 2 * OP_BYTES;                // dy^T tile + x tile
+constexpr int LDS_BYTES = 2 * STAGE;               // 100,352: one workgroup per CU
+__device__ __forceinline__ int frag_slot(int j, int g) { return (4 * (j & 3) + (j >> 2) + 16 * g) * 16; }
 
-__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(int nprob, const WP *__restrict__ probs,
-                                                            const int *__restrict__ prefix) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 x BUF
+// 8 waves, two roles.  Splitting an operand element costs ~7 VALU instructions and 4-byte loads run at a
+// quarter of the 16-byte rate per instruction: a 128 x 64 tile whose four waves did everything spent 3/4
+// of its time there (phase stamps: 2.9k cycles per slab against 768 of MFMA issue; 148 us for the step's
+// 10 GFLOP).  Now waves 4-7 LOAD -- waves 4, 5 the dy tile, waves 6, 7 the x tile; a thread takes 8 tokens
+// x 4 consecutive columns with eight 16-byte loads through a buffer descriptor (token offset in an SGPR,
+// out-of-range tokens read as zero), splits each column's eight values exactly into three bf16 terms and
+// writes 16 bytes per plane straight into fragment order, two slabs ahead -- and waves 0-3 MULTIPLY: a
+// 64 x 64 quarter each, 96 MFMAs per slab from 24 ds_read_b128.  One barrier per slab; the matrix pipe and
+// the VALU work of the split overlap.
+__global__ __launch_bounds__(512, 2) void wgrad_split_kernel(int nprob, const WP *__restrict__ probs,
+                                                          const int *__restrict__ prefix) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int lo = 0, hi = nprob - 1;
@@ -51,106 +77,175 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(int nprob, const WP
   const int ntile = local / nkt, ktile = local - ntile * nkt;
   const int n0 = ntile * TN, k0 = ktile * TK;
   const int M = pr.M;
-  const int nslab = (M + 31) >> 5;
+  // slabs of 32 tokens, padded to an even count: a slab past M reads zeros (out-of-range buffer loads) and
+  // adds nothing, and the loader's loop body stays straight-line (see there)
+  const int nslab = ((M + 63) >> 6) << 1;
+  WG_STAMP(0);
 
-  // loader role: column c (and c + 64 of the dy tile), tokens 8 wave .. 8 wave + 7 of the slab
-  const int c = lane;
-  const bool a0_ok = n0 + c < pr.n_out, a1_ok = n0 + 64 + c < pr.n_out, b_ok = k0 + c < pr.k_in;
-  const float *pa0 = pr.dy + n0 + c, *pa1 = pa0 + 64, *pb = pr.x + k0 + c;
-  float va0[8], va1[8], vb[8];
-  float cs0 = 0.f, cs1 = 0.f;                      // running column sums of dy (bias gradient)
-  auto fetch = [&](int s) {
-    const int m0 = 32 * s + 8 * wave;
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ loader
+    const bool isx = wave >= 6;                    // which operand this wave feeds (wave-uniform)
+    const float *src = isx ? pr.x : pr.dy;
+    const int ld = isx ? pr.ldx : pr.ldy, ncol = isx ? pr.k_in : pr.n_out, c0 = isx ? k0 : n0;
+    const int u = (wave & 1) * 64 + lane;          // unit: column quad Q (of 32), token octet o (of 4)
+    const int Q = u & 31, o = u >> 5;
+    const int col = c0 + 4 * Q;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(src), 0, (int)((size_t)M * ld * 4), 0x00020000);
+    const bool vec = (reinterpret_cast<uintptr_t>(src) & 15u) == 0 && (ld & 3) == 0;   // wave-uniform
+    float cm[4];
+    int cb[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int m = m0 + e;
-      const bool ok = m < M;
-      va0[e] = (ok && a0_ok) ? pa0[(size_t)m * pr.ldy] : 0.f;
-      va1[e] = (ok && a1_ok) ? pa1[(size_t)m * pr.ldy] : 0.f;
-      vb[e] = (ok && b_ok) ? pb[(size_t)m * pr.ldx] : 0.f;
+    for (int i = 0; i < 4; ++i) { cm[i] = col + i < ncol ? 1.f : 0.f; cb[i] = 4 * min(col + i, ncol - 1); }
+    const bool edge = cm[3] == 0.f;
+    struct Slab { float v[8][4]; };
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    // VEC is a compile-time property of the whole loop: a per-load `if (vec)` makes every load its own
+    // basic block, and the compiler then waits vmcnt(0) at each join -- the fetch serialises (measured:
+    // the loader waves at 3.7k cycles per slab, the multipliers waiting for them a third of their life)
+    unsigned long long tw = 0;                     // (profiling build: cycles spent waiting at the barriers)
+    (void)tw;
+    auto run = [&](auto vec_tag) {
+      constexpr bool VEC = decltype(vec_tag)::value;
+      auto fetch = [&](Slab &s_, int s) {
+        // the whole byte offset goes through the lane offset (the range check is defined on it): a token
+        // past M starts exactly at the buffer's size, so every out-of-range load returns 0
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int row = ((32 * s + e) + 8 * o) * ld * 4;
+          if constexpr (VEC) {
+#ifdef WG_ABLATE_LOAD
+            const f32x4 r = f32x4{(float)row, 1.f, 2.f, 3.f};
+#else
+            const f32x4 r = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, cb[0] + row, 0, 0));
+#endif
+            s_.v[e][0] = r.x; s_.v[e][1] = r.y; s_.v[e][2] = r.z; s_.v[e][3] = r.w;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              s_.v[e][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cb[i] + row, 0, 0));
+          }
+        }
+      };
+      auto stash = [&](Slab &s_, int buf) {
+        unsigned char *T = smem + buf * STAGE + (isx ? OP_BYTES : 0) + (Q >> 2) * TILE_BYTES;
+        if (edge) {                                // columns past the matrix (a 16-byte load reads on into the row)
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_.v[e][i] *= cm[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float c8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { c8[e] = s_.v[e][i]; cs[i] += c8[e]; }
+          uint4 pl[3];
+#ifdef WG_ABLATE_SPLIT
+          pl[0] = make_uint4(__float_as_uint(c8[0]), __float_as_uint(c8[1]), __float_as_uint(c8[2]), __float_as_uint(c8[3]));
+          pl[1] = make_uint4(__float_as_uint(c8[4]), __float_as_uint(c8[5]), __float_as_uint(c8[6]), __float_as_uint(c8[7]));
+          pl[2] = pl[0];
+#else
+          sm_split8(c8, pl);
+#endif
+          const int slot = frag_slot(4 * (Q & 3) + i, o);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) *reinterpret_cast<uint4 *>(T + k * 1024 + slot) = pl[k];
+        }
+      };
+      // Two slabs in flight per thread, fetched unconditionally (past the end: zeros).  Measured on the
+      // step's problem set (tools/prof_wgrad.py, ablation builds): without the loads the launch takes 104 us,
+      // without the MFMAs 178, whole 135-150 -- the loads are what bounds it: a tile reads 960 rows x 512
+      // bytes of each operand once, ~320 MB per launch of which at most half can hit an L2, and this access
+      // pattern gets ~1.5 TB/s out of the fabric whatever the row pitch and however deep the prefetch
+      // (unrolling by 8 slabs so that hipcc's wait counts become exact made it slower: 206 us).
+      Slab v0, v1;
+      fetch(v0, 0);
+      fetch(v1, 1);
+      for (int s = 0; s < nslab; s += 2) {
+        stash(v0, 0);
+        fetch(v0, s + 2);
+        { const unsigned long long c0_ = WG_CLOCK(); __syncthreads(); tw += WG_CLOCK() - c0_; }   // slab s is in stage 0
+        stash(v1, 1);
+        fetch(v1, s + 3);
+        { const unsigned long long c0_ = WG_CLOCK(); __syncthreads(); tw += WG_CLOCK() - c0_; }
+      }
+    };
+    if (vec) run(std::true_type{});
+    else run(std::false_type{});
+    WG_PUT(1, tw);
+    __syncthreads();                               // the last slab has been multiplied: LDS is free
+    float *red = reinterpret_cast<float *>(smem);  // [4 octets][128]: bias gradient = column sums of dy
+    if (!isx) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[o * TN + 4 * Q + i] = cs[i];
     }
-  };
-  auto stash = [&](int buf) {
-    unsigned char *A = smem + buf * BUF, *Bs = A + A_BYTES;
-    uint4 pl[3];
-    const int slot = ((c & 15) + 16 * wave) * 16;   // lane' = column-in-tile + 16 x token group
-    sm_split8(va0, pl);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) *reinterpret_cast<uint4 *>(A + ((c >> 4) * 3 + k) * 1024 + slot) = pl[k];
-    sm_split8(va1, pl);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) *reinterpret_cast<uint4 *>(A + ((4 + (c >> 4)) * 3 + k) * 1024 + slot) = pl[k];
-    sm_split8(vb, pl);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) *reinterpret_cast<uint4 *>(Bs + ((c >> 4) * 3 + k) * 1024 + slot) = pl[k];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { cs0 += va0[e]; cs1 += va1[e]; }
-  };
-
-  // MMA role: wave (wr, wc): output rows 64 wr .. (4 tiles), input columns 32 wc .. (2 tiles)
-  const int wr = wave >> 1, wc = wave & 1;
-  f32x4 acc[4][2];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  fetch(0);
-  for (int s = 0; s < nslab; ++s) {
-    stash(s & 1);
     __syncthreads();
-    if (s + 1 < nslab) fetch(s + 1);
-    const unsigned char *A = smem + (s & 1) * BUF, *Bs = A + A_BYTES;
-    bf16x8 fa[4][3], fb[2][3];
+    if (pr.db && ktile == 0 && wave < 6) {
+      const int c = u;
+      if (n0 + c < pr.n_out) pr.db[n0 + c] += (red[c] + red[TN + c]) + (red[2 * TN + c] + red[3 * TN + c]);
+    }
+  } else {
+    // ------------------------------------------------------------------ multiplier: wave (wr, wc) owns
+    // output rows 64 wr .. (4 tiles) x input columns 64 wc .. (4 tiles)
+    const int wr = wave >> 1, wc = wave & 1;
+    const int slot = frag_slot(lane & 15, lane >> 4);
+    f32x4 acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
-        fa[a][k] = *reinterpret_cast<const bf16x8 *>(A + ((4 * wr + a) * 3 + k) * 1024 + lane * 16);
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned long long tw = 0;
+    (void)tw;
+    for (int s = 0; s < nslab; ++s) {
+      { const unsigned long long c0_ = WG_CLOCK(); __syncthreads(); tw += WG_CLOCK() - c0_; }
+#ifdef WG_ABLATE_MMA
+      continue;
+#endif
+      const unsigned char *A = smem + (s & 1) * STAGE + slot, *Bs = A + OP_BYTES;
+      bf16x8 fa[4][3], fb[4][3];
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+      for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
-        fb[b][k] = *reinterpret_cast<const bf16x8 *>(Bs + ((2 * wc + b) * 3 + k) * 1024 + lane * 16);
+        for (int k = 0; k < 3; ++k) {
+          fa[a][k] = *reinterpret_cast<const bf16x8 *>(A + (4 * wr + a) * TILE_BYTES + k * 1024);
+          fb[a][k] = *reinterpret_cast<const bf16x8 *>(Bs + (4 * wc + a) * TILE_BYTES + k * 1024);
+        }
 #define MSR3D_TERM(PA, PB)                                                                       \
-    _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                \
-    _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                \
-        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][PA], fb[b][PB], acc[a][b], 0, 0, 0);
-    MSR3D_TERM(2, 0)
-    MSR3D_TERM(0, 2)
-    MSR3D_TERM(1, 1)
-    MSR3D_TERM(1, 0)
-    MSR3D_TERM(0, 1)
-    MSR3D_TERM(0, 0)
+      _Pragma("unroll") for (int a = 0; a < 4; ++a)                                              \
+      _Pragma("unroll") for (int b = 0; b < 4; ++b)                                              \
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][PA], fb[b][PB], acc[a][b], 0, 0, 0);
+      MSR3D_TERM(2, 0)
+      MSR3D_TERM(0, 2)
+      MSR3D_TERM(1, 1)
+      MSR3D_TERM(1, 0)
+      MSR3D_TERM(0, 1)
+      MSR3D_TERM(0, 0)
 #undef MSR3D_TERM
-  }
-
-  // D[n][k]: lane (j = k column, g): rows n = 4 g + r.  dW holds the value to add to; this workgroup is
-  // the tile's only writer.
-  const int j = lane & 15, g = lane >> 4;
+    }
+    WG_STAMP(5);
+    WG_PUT(1, tw);
+    __syncthreads();
+    __syncthreads();
+    // D[n][k]: lane (j = k column, g): rows n = 4 g + r.  dW holds the value to add to; this workgroup is
+    // the tile's only writer.
+    const int j = lane & 15, g = lane >> 4;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int kk = k0 + 32 * wc + 16 * b + j;
+      for (int b = 0; b < 4; ++b) {
+        const int kk = k0 + 64 * wc + 16 * b + j;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + 64 * wr + 16 * a + 4 * g + r;
-        if (n < pr.n_out && kk < pr.k_in) {
-          float *d = pr.dW + (size_t)n * pr.ldw + kk;
-          *d += acc[a][b][r];
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + 64 * wr + 16 * a + 4 * g + r;
+          if (n < pr.n_out && kk < pr.k_in) {
+            float *d = pr.dW + (size_t)n * pr.ldw + kk;
+            *d += acc[a][b][r];
+          }
         }
       }
-    }
-  if (pr.db && ktile == 0) {                        // bias gradient: the four token groups meet in LDS
-    __syncthreads();
-    float *red = reinterpret_cast<float *>(smem);   // [4 waves][128]
-    red[wave * TN + c] = cs0;
-    red[wave * TN + 64 + c] = cs1;
-    __syncthreads();
-    if (tid < TN && n0 + tid < pr.n_out)
-      pr.db[n0 + tid] += (red[tid] + red[TN + tid]) + (red[2 * TN + tid] + red[3 * TN + tid]);
   }
+  WG_STAMP(6);
 }
 
 }  // namespace
@@ -161,8 +256,8 @@ extern "C" int msr3d_wgrad_split(int n, const msr3d_wgrad_problem_t *problems, c
   if (n == 0 || total_tiles == 0) return 0;
   if (!problems || !tile_prefix) return MSR3D_EINVAL;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_split_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (attr != hipSuccess) return (int)attr;
-  wgrad_split_kernel<<<total_tiles, 256, 2 * BUF, (hipStream_t)stream>>>(n, problems, tile_prefix);
+  wgrad_split_kernel<<<total_tiles, 512, LDS_BYTES, (hipStream_t)stream>>>(n, problems, tile_prefix);
   return (int)hipGetLastError();
 }

@@ -83,7 +83,7 @@ def head_segments(h, dh=32, d=256, sd1=6):
 class WgradTable:
     """The problems of one msr3d_wgrad_split launch, in device memory; pointers that may move between
     calls (the upstream gradient, the object features) are patched through set_ptr()."""
-    TN, TK = 128, 64
+    TN, TK = 128, 128
 
     def __init__(self, device):
         self.device = device
