@@ -75,8 +75,13 @@ __global__ __launch_bounds__(256) void dot_kernel(long long n4, const float4 *__
   if (threadIdx.x == 0) {
     __hip_atomic_store(partial + blockIdx.x, (part[0] + part[1]) + (part[2] + part[3]), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // the partial must be visible to the LAST block, possibly on another XCD, before the ticket is: an
+    // agent-scope release (a workgroup-scope fence orders nothing another CU can observe) ...
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ... and an agent-scope acquire on the reader before it loads the others' partials
+    if (ticket == (int)gridDim.x - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
   if (ticket != (int)gridDim.x - 1) return;

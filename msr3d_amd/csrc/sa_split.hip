@@ -43,6 +43,7 @@
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <tuple>
 #include <utility>
 
 #include "../../include/msr3d_hip.h"
@@ -981,21 +982,27 @@ inline int usable_cus() {
   return cus - r > 8 ? cus - r : 8;
 }
 
-// Work queues of the persistent kernels: two ints per (stream, level), zero between launches (the last
-// block of a launch resets them).  Allocated and cleared on first use of a stream.
-inline int *work_queue(hipStream_t st, int level, hipError_t *err) {
+// Work queues of the persistent kernels: two ints per (device, stream, level), zero between launches: the
+// last block of a launch resets them.  (The default stream's handle is the same on every device, hence the
+// device in the key.)  Cleared in stream order on first use and again whenever the previous launch through
+// the queue did not report success -- a launch that never ran to its last block would otherwise leave the
+// counters non-zero and every later launch would silently skip tiles.
+struct WorkQueue { int *q = nullptr; bool suspect = true; };
+inline WorkQueue *work_queue(hipStream_t st, int level, hipError_t *err) {
   static std::mutex mu;
-  static std::map<std::pair<hipStream_t, int>, int *> queues;
+  static std::map<std::tuple<int, hipStream_t, int>, WorkQueue> queues;
+  int dev = 0;
+  if ((*err = hipGetDevice(&dev)) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
-  auto it = queues.find({st, level});
-  if (it != queues.end()) { *err = hipSuccess; return it->second; }
-  int *q = nullptr;
-  if ((*err = hipMalloc(&q, 2 * sizeof(int))) != hipSuccess) return nullptr;
-  // zeroed IN STREAM ORDER: the caller's streams do not synchronise with the null stream, where a plain
-  // hipMemset would run (the first launch could then read the counter before it is cleared)
-  if ((*err = hipMemsetAsync(q, 0, 2 * sizeof(int), st)) != hipSuccess) return nullptr;
-  queues[{st, level}] = q;
-  return q;
+  WorkQueue &w = queues[{dev, st, level}];
+  if (!w.q && (*err = hipMalloc(&w.q, 2 * sizeof(int))) != hipSuccess) return nullptr;
+  if (w.suspect) {
+    // (the caller's streams do not synchronise with the null stream, where a plain hipMemset would run)
+    if ((*err = hipMemsetAsync(w.q, 0, 2 * sizeof(int), st)) != hipSuccess) return nullptr;
+  }
+  w.suspect = true;                 // until the launch it is handed to reports success
+  *err = hipSuccess;
+  return &w;
 }
 
 }  // namespace
@@ -1008,6 +1015,7 @@ extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius
   if (b == 0) return 0;
   if (!w1 || !w2 || !w3 || !affine1 || !affine2 || !affine3 || !out) return MSR3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  WorkQueue *wq = nullptr;
   const float r2 = radius * radius;   // f32 product, as ball_query_gpu.cu:22
   hipError_t e;
   if (level == 2) {
@@ -1018,8 +1026,9 @@ extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius
     if (tiles > 0x7fffffffLL - kChunk) return MSR3D_EINVAL;
     const long long chunks = (tiles + kChunk - 1) / kChunk;
     const int blocks = (int)(chunks < slots ? chunks : slots);
-    int *queue = work_queue(st, 2, &e);
-    if (!queue) return (int)e;
+    wq = work_queue(st, 2, &e);
+    if (!wq) return (int)e;
+    int *queue = wq->q;
 #if SPLIT_STAMP
     unsigned long long *stamp_base = reinterpret_cast<unsigned long long *>(dbg_ball_idx);
     sa2_split_kernel<<<blocks, 256, kSa2Lds, st>>>(n, m, (int)tiles, queue, r2, pts, feat, new_xyz, make_layer(w1, affine1, 128),
@@ -1038,8 +1047,9 @@ extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius
     if (rounds > 0x7fffffffLL) return MSR3D_EINVAL;
     const long long chunks = (rounds + k1Chunk - 1) / k1Chunk;
     const int blocks = (int)(chunks < cus ? chunks : cus);
-    int *queue = work_queue(st, 1, &e);
-    if (!queue) return (int)e;
+    wq = work_queue(st, 1, &e);
+    if (!wq) return (int)e;
+    int *queue = wq->q;
     sa1_split_kernel<<<blocks, 64 * k1Waves, kSa1Lds, st>>>(n, m, b * m, (int)rounds, queue, pts, new_xyz, dbg_ball_idx,
                                                            make_layer(w1, affine1, 64), make_layer(w2, affine2, 64),
                                                            make_layer(w3, affine3, 128), out, valid);
@@ -1051,7 +1061,9 @@ extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius
   } else {
     return MSR3D_EINVAL;
   }
-  return (int)hipGetLastError();
+  e = hipGetLastError();
+  if (wq && e == hipSuccess) wq->suspect = false;
+  return (int)e;
 }
 
 extern "C" int msr3d_set_reserved_cus(int n) {

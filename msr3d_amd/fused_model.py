@@ -127,6 +127,12 @@ class PrompterSchedule:
         B, L = e.shape[:2]
         if L > 128 or e.shape[-1] % 4 or cfg.loc_fourier_dim > 64:
             return False
+        # msr3d_pos_embed_bwd sums the positional gradient of at most three layers; the mask is read as bytes
+        if not 1 <= len(pr.spatial_encoder) <= 3:
+            return False
+        msk = d.get("obj_masks")
+        if msk is not None and msk.dtype != torch.bool:
+            return False
         for layer in pr.spatial_encoder:
             sa = layer.self_attn
             if getattr(sa, "_packed", None) is None or sa.n_head * 32 != 256 or not sa.spatial_multihead:

@@ -665,9 +665,10 @@ def dot(a, b):
         raise ValueError("dot: two fp32 GPU tensors of the same size")
     a, b = a.contiguous(), b.contiguous()
     dev = a.device
-    ws = _dot_scratch.get(dev)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)     # concurrent dots on two streams must not share
+    ws = _dot_scratch.get(key)
     if ws is None:
-        ws = _dot_scratch[dev] = torch.zeros(1024 + 1, dtype=torch.float32, device=dev)
+        ws = _dot_scratch[key] = torch.zeros(1024 + 1, dtype=torch.float32, device=dev)
     out = torch.empty((), dtype=torch.float32, device=dev)
     n = a.numel()
     if n % 4 or a.data_ptr() % 16 or b.data_ptr() % 16:

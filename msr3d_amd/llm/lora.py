@@ -106,14 +106,27 @@ class LoRALinear(nn.Module):
         self.lora_B = nn.Linear(r, out_features, bias=False, device=device)
         nn.init.kaiming_uniform_(self.lora_A.weight, a=math.sqrt(5))
         nn.init.zeros_(self.lora_B.weight)
+        self._wt_version = None       # `weight._version` the transposed copy was made from
+
+    def _sync_weight_t(self):
+        """weight_t is a cache of weight^T (non-persistent): rebuilt whenever `weight` has been written --
+        load_state_dict, .copy_(), a dtype / device move -- so dx = dy W never reads a stale transpose."""
+        w = self.weight
+        if self._wt_version != (w._version, w.data_ptr()) or self.weight_t.device != w.device:
+            with torch.no_grad():
+                if self.weight_t.shape != (w.shape[1], w.shape[0]) or self.weight_t.device != w.device:
+                    self.weight_t = torch.empty((w.shape[1], w.shape[0]), dtype=w.dtype, device=w.device)
+                self.weight_t.copy_(w.t())
+            self._wt_version = (w._version, w.data_ptr())
 
     @torch.no_grad()
     def load_base_weight(self, w):
         """w (N, K): the frozen projection; stored in both orientations."""
         self.weight.copy_(w.to(torch.bfloat16))
-        self.weight_t.copy_(self.weight.t())
+        self._sync_weight_t()
 
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("LoRALinear runs on the GPU only (no CPU fallback)")
+        self._sync_weight_t()
         return _LoRAFn.apply(x.to(torch.bfloat16), self.lora_A.weight, self.lora_B.weight, self)

@@ -192,6 +192,14 @@ class HotPathTrainStep:
                 self.static["obj_masks"] = sched.valid
                 self.static["obj_locs"] = sched.arena["loc6"].view(sched.valid.shape[0], sched.valid.shape[1], 6)
                 self.static["_staged"] = True
+                # everything else the batch carries (anchor pose, and whatever a loss_fn reads from the scene
+                # dict: ids, targets, labels) still goes into the static buffers the captured step sees
+                rest = [k for k in self.static if k not in ("obj_embeds", "obj_fts", "obj_masks", "obj_locs", "_staged")]
+                missing = [k for k in rest if k not in batch]
+                if missing:
+                    raise KeyError(f"batch lacks {missing}, which the example batch of this step had")
+                if rest:
+                    torch._foreach_copy_([self.static[k] for k in rest], [batch[k] for k in rest])
             else:
                 self.static.pop("_staged", None)
                 keys = [k for k in self.static if k not in ("obj_embeds", "_staged", "obj_fts")]

@@ -85,3 +85,29 @@ def test_roofline_line_for_the_projection(capsys):
     with capsys.disabled():
         print(f"\n[lora] fwd {fw*1e3:.0f} us = {flop/fw/1e9:.0f} TFLOP/s ({flop/fw/1e9/2500:.2f} of 2.5 PF bf16); "
               f"fwd+bwd {fb*1e3:.0f} us = {2*flop/fb/1e9:.0f} TFLOP/s on the two big products")
+
+
+def test_transposed_weight_follows_load_state_dict():
+    """weight_t (W^T for dx = dy W) is a cache of `weight`; after load_state_dict or any other
+    write to `weight` the backward must use the NEW transpose."""
+    from msr3d_amd.llm import LoRALinear
+    torch.manual_seed(0)
+    K, N = 256, 192
+    a = LoRALinear(K, N, r=16, device="cuda")
+    a.load_base_weight(torch.randn(N, K, device="cuda") / K ** 0.5)
+    b = LoRALinear(K, N, r=16, device="cuda")
+    b.load_state_dict(a.state_dict())                         # `weight` arrives here, weight_t does not
+    x = torch.randn(64, K, device="cuda").to(torch.bfloat16)
+    dy = torch.randn(64, N, device="cuda").to(torch.bfloat16)
+    outs = []
+    for m in (a, b):
+        xi = x.clone().requires_grad_(True)
+        m(xi).backward(dy)
+        outs.append(xi.grad.float())
+    assert rel(outs[1], outs[0]) < 1e-6
+    with torch.no_grad():
+        b.weight.mul_(2.0)                                    # an in-place write bumps the version
+    xi = x.clone().requires_grad_(True)
+    b(xi).backward(dy)
+    want = (dy.double() @ b.weight.double()).float()
+    assert rel(xi.grad.float(), want) < 2 ** -7

@@ -254,3 +254,45 @@ def test_deterministic_mode_gives_bit_identical_weights(monkeypatch, use_graph):
     assert torch.equal(g1, g2), int((g1 != g2).sum())
     assert torch.equal(p1, p2), int((p1 != p2).sum())
     assert torch.isfinite(p1).all()
+
+
+def test_direct_staging_still_copies_the_batch_tensors_the_loss_reads():
+    """in the schedule's direct-staging mode (`_load` lets the one-launch prologue read the
+    batch's geometry where it is) every OTHER tensor of the batch must still reach the static buffers the
+    captured step sees -- here a per-batch weighting tensor consumed by loss_fn from the scene dict."""
+    import msr3d_amd.model  # noqa: F401
+    import msr3d_amd.modules  # noqa: F401
+    from msr3d_amd import hipops
+    from msr3d_amd.config import AttrDict, default_prompter_cfg
+    from msr3d_amd.dp import FlatGradAllReduce
+    from msr3d_amd.model import build_model
+    from msr3d_amd.optim import FlatAdamW
+    from msr3d_amd.synth import synth_batch
+    from msr3d_amd.train_step import HotPathTrainStep
+    losses = []
+    for use_graph in (True, False):
+        torch.manual_seed(0)
+        cfg = AttrDict({"prompter": default_prompter_cfg(dropout=0.0), "llm_hidden_size": 128,
+                        "model": {"name": "MSR3DHotPath"}})
+        model = build_model(cfg).cuda().train()
+        params = [p for p in model.parameters() if p.requires_grad]
+        dp = FlatGradAllReduce(params, pack_groups=hipops.collect_pack_groups(model))
+        opt = FlatAdamW(dp, lr=0.0, weight_decay=0.0)            # lr 0: the steps are independent
+        hipops.attach_packed_views(model, dp, opt)
+        batches = []
+        for i in range(3):
+            b = synth_batch(90 + i, 2, O=10, P=1024, device="cuda")
+            b["target_w"] = torch.full((2, 10, 128), float(i + 1), device="cuda")
+            batches.append(b)
+
+        def loss_fn(out):
+            return (out["scene_embeds"] * out["target_w"]).mean()
+        step = HotPathTrainStep(model, opt, dp, loss_fn, batches[0], use_graph=use_graph)
+        step.capture(batches[0])
+        ls = [float(step(b)) for b in batches]
+        assert step._sched_direct
+        losses.append(ls)
+        # same scene, different weighting tensor: the loss must scale with it
+        b0 = dict(batches[0]); b0["target_w"] = batches[0]["target_w"] * 4.0
+        assert float(step(b0)) == pytest.approx(4.0 * ls[0], rel=1e-5)
+    assert losses[0] == pytest.approx(losses[1], rel=1e-5)
