@@ -46,10 +46,8 @@ constexpr int ABUF = TM * LDA_K > KS * LDA_M ? TM * LDA_K : KS * LDA_M;     // f
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
-#ifdef MSR3D_PROF      // tools/prof_panel.py builds this variant: per-workgroup phase stamps (shader clock)
-__device__ unsigned long long g_panel_stamps[8192 * 8];
-#define STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_panel_stamps[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
-#else
+// phase marks: empty here; tools/prof/panel_gemm_stamped.hip defines STAMP and includes this file
+#ifndef STAMP
 #define STAMP(k) do {} while (0)
 #endif
 
@@ -315,12 +313,6 @@ int panel_plan(const msr3d_gemm_problem_t &q, int stages_per_run, PanelP *out, h
   *out = p;
   return 0;
 }
-
-#ifdef MSR3D_PROF
-extern "C" int msr3d_prof_panel_stamps(unsigned long long *host_out, int n_blocks) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_panel_stamps), sizeof(unsigned long long) * 8 * n_blocks);
-}
-#endif
 
 int panel_launch(const PanelBatch &pb, int blocks, hipStream_t st) {
   constexpr size_t lds = sizeof(float) * 2 * ABUF;

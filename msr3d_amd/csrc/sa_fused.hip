@@ -219,7 +219,7 @@ struct Chain {
   // `tid`: thread index inside the 256-thread block.
   __device__ static void run(float *bufA, float *bufB, const Pre1 &p1, const Layer &l1,
                              const Layer &l2, const Layer &l3, float *__restrict__ out,
-                             int groups_valid_block, int tid, long long *tstamp = nullptr) {
+                             int groups_valid_block, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int row0 = wm * RM * 16;
@@ -233,11 +233,9 @@ struct Chain {
       // next layer's first operands fly while this layer's epilogue and barrier run
       load_b_first<RN2>(l2.w + (wn * RN2) * kFrag, lane, b2);
       load_affine<RN2>(l2.scale + wn * RN2 * 16, l2.shift + wn * RN2 * 16, lane, sc2, sh2);
-      if (tstamp) tstamp[0] = clock64();
       store_bn_relu_lds<RM, RN1>(acc, p1.sc, p1.sh, bufB + row0 * LDB + col0, LDB, lane);
     }
     __syncthreads();
-    if (tstamp) tstamp[1] = clock64();
     {
       const int col0 = wn * RN2 * 16;
       f32x4 acc[RM][RN2];
@@ -245,17 +243,14 @@ struct Chain {
       gemm_lds_global<RM, RN2, N1, N2 / 16>(bufB + row0 * LDB, LDB, l2.w + (col0 / 16) * kFrag, acc, lane, b2);
       load_b_first<RN3>(l3.w + (wn * RN3) * kFrag, lane, b3);
       load_affine<RN3>(l3.scale + wn * RN3 * 16, l3.shift + wn * RN3 * 16, lane, sc3, sh3);
-      if (tstamp) tstamp[2] = clock64();
       store_bn_relu_lds<RM, RN2>(acc, sc2, sh2, bufA + row0 * LDA + col0, LDA, lane);
     }
     __syncthreads();
-    if (tstamp) tstamp[3] = clock64();
     {
       const int col0 = wn * RN3 * 16;
       f32x4 acc[RM][RN3];
       zero_acc(acc);
       gemm_lds_global<RM, RN3, N2, N3 / 16>(bufA + row0 * LDA, LDA, l3.w + (col0 / 16) * kFrag, acc, lane, b3);
-      if (tstamp) tstamp[4] = clock64();
       const int g0 = wm * (RM / GT);            // first pooled row owned by this wave
       int gv = groups_valid_block - g0;
       store_bn_relu_groupmax<RM, RN3, GT>(acc, sc3, sh3, out + (size_t)g0 * N3 + col0, N3, gv, lane);
@@ -391,10 +386,6 @@ __global__ __launch_bounds__(256) void sa2_kernel(int n, int m, float radius2,
   float *sx = ctr + 16;                                            // [n][3], n <= 64
 
   const int obj = blockIdx.y, c0 = blockIdx.x * CPB;
-#ifdef MSR3D_PROF      // phase stamps for tools/prof_sa2.py (build with -DMSR3D_PROF)
-  long long ts[4];
-  ts[0] = clock64();
-#endif
   typename Chain2::Pre1 pre;
   Chain2::preload(l1, pre, tid);     // layer-1 weights/affine in flight during the loader phase
   if (tid < n * 3) sx[tid] = xyz[(size_t)obj * n * 3 + tid];
@@ -411,12 +402,8 @@ __global__ __launch_bounds__(256) void sa2_kernel(int n, int m, float radius2,
       nbr[wave * kNS + lane] = 0;
   }
   __syncthreads();
-#ifndef MSR3D_PROF
   if (dbg_idx && tid < CPB * kNS && c0 + tid / kNS < m)
     dbg_idx[((size_t)obj * m + c0) * kNS + tid] = nbr[tid];
-#else
-  ts[1] = clock64();
-#endif
   const float *F = feat + (size_t)obj * n * 128;
   {   // 32 float4 per row; indices first, then ALL loads, then the LDS stores: one L2 round trip
     constexpr int IT = TM * 32 / 256;
@@ -445,25 +432,7 @@ __global__ __launch_bounds__(256) void sa2_kernel(int n, int m, float radius2,
   __syncthreads();
   int groups = m - c0;
   groups = groups < 0 ? 0 : (groups < CPB ? groups : CPB);
-#ifdef MSR3D_PROF
-  ts[2] = clock64();
-  long long tl[5];
-  Chain2::run(bufA, bufB, pre, l1, l2, l3, out + ((size_t)obj * m + c0) * 256, groups, tid, tl);
-  ts[3] = clock64();
-  if (dbg_idx && tid == 0) {   // PROF build: the debug buffer carries phase durations instead
-    int *o = dbg_idx + ((size_t)obj * gridDim.x + blockIdx.x) * 8;
-    o[0] = (int)(ts[1] - ts[0]);   // stage + ball query
-    o[1] = (int)(ts[2] - ts[1]);   // gather
-    o[2] = (int)(tl[0] - ts[2]);   // layer 1 mfma
-    o[3] = (int)(tl[1] - tl[0]);   // layer 1 epilogue + barrier
-    o[4] = (int)(tl[2] - tl[1]);   // layer 2 mfma
-    o[5] = (int)(tl[3] - tl[2]);   // layer 2 epilogue + barrier
-    o[6] = (int)(tl[4] - tl[3]);   // layer 3 mfma
-    o[7] = (int)(ts[3] - tl[4]);   // layer 3 epilogue
-  }
-#else
   Chain2::run(bufA, bufB, pre, l1, l2, l3, out + ((size_t)obj * m + c0) * 256, groups, tid);
-#endif
 }
 
 // =================================================================================

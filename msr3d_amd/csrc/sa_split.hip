@@ -33,7 +33,7 @@
 //     fetched under the current tile's layers (see the kernel).
 // Measured (16 x 60 objects): 0.531 ms for the f32-MFMA kernel (122 of the 155.6 TFLOP/s a pure
 // issue loop sustains, tools/probe/mfma_peak.hip) -> 0.300 ms; the bf16 pipe is 56 % busy (PMC), the rest is each block's serial chain
-// of epilogues and barriers (phase stamps: tools/ab_split.py, -DSPLIT_STAMP=1).
+// of epilogues and barriers (phase stamps: tools/ab_split.py with tools/prof/sa_split_stamped.hip).
 //
 // Same contract as sa_fused.hip (msr3d_sa_level): same index ops (shared code), same folded BN affine
 // and ReLU on the accumulators, same max over the neighbourhood; /root/reference/modules/third_party/
@@ -49,13 +49,13 @@
 #include "../../include/msr3d_hip.h"
 #include "pn2_device.h"
 
-#ifndef SPLIT_STAMP
-#define SPLIT_STAMP 0
-#endif
-#if SPLIT_STAMP
-#define STAMP(i) if (tile_no == 2 && (tid & 63) == 0) stamps[i] = __builtin_amdgcn_s_memtime()
-#else
+// phase marks of the level-2 kernel: empty here; tools/prof/sa_split_stamped.hip defines them and includes
+// this file (tools/ab_split.py reads the stamps)
+#ifndef STAMP
 #define STAMP(i)
+#define STAMP_DECL
+#define STAMP_TILE_TOP
+#define STAMP_TILE_END
 #endif
 namespace {
 
@@ -330,11 +330,7 @@ __global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int til
                                                            const float *__restrict__ xyz, const float *__restrict__ feat,
                                                            const float *__restrict__ new_xyz, LayerS l1, LayerS l2, LayerS l3,
                                                            float *__restrict__ out, int *__restrict__ dbg_idx,
-                                                           const unsigned char *__restrict__ valid
-#if SPLIT_STAMP
-                                                           , unsigned long long *stamp_base
-#endif
-                                                           ) {
+                                                           const unsigned char *__restrict__ valid) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   unsigned short *buf = smem;                                             // [3][64][176] bf16
   float *aff = reinterpret_cast<float *>(smem + 3 * kPlane);               // sc1 sh1 sc2 sh2 sc3 sh3
@@ -345,10 +341,7 @@ __global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int til
   int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tpo = (m + 1) >> 1;                                            // tiles per object
   const int t_end = tiles;                                                 // (also the "no tile" value)
-#if SPLIT_STAMP
-  unsigned long long *stamps = stamp_base + ((size_t)blockIdx.x * 4 + wave) * 16;
-  int tile_no = 0;
-#endif
+  STAMP_DECL;
 
   // Tiles are handed out in CHUNKS of kChunk consecutive tiles from a device-wide queue (queue[0]: next
   // chunk, queue[1]: blocks finished; the last block to leave resets both for the next launch).  A static
@@ -484,9 +477,7 @@ __global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int til
     asm volatile("" : "+v"(tid));
     lane = tid & 63;
     wave = tid >> 6;
-#if SPLIT_STAMP
-    if (tile_no == 3 && (tid & 63) == 0) stamps[10] = __builtin_amdgcn_s_memtime();
-#endif
+    STAMP_TILE_TOP;
     STAMP(0);
     if (more) geo_fetch(Tn);
     WPiece ring2[kRing], ring3[kRing];
@@ -550,11 +541,7 @@ __global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int til
     STAMP(8);
     __syncthreads();                                              // (F) the next tile's operand is in place
     STAMP(9);
-#if SPLIT_STAMP
-    ++tile_no;
-#endif
-#if SPLIT_STAMP
-#endif
+    STAMP_TILE_END;
     T = Tn;
     Tn = Tnn;
   }
@@ -1029,14 +1016,8 @@ extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius
     wq = work_queue(st, 2, &e);
     if (!wq) return (int)e;
     int *queue = wq->q;
-#if SPLIT_STAMP
-    unsigned long long *stamp_base = reinterpret_cast<unsigned long long *>(dbg_ball_idx);
-    sa2_split_kernel<<<blocks, 256, kSa2Lds, st>>>(n, m, (int)tiles, queue, r2, pts, feat, new_xyz, make_layer(w1, affine1, 128),
-                                                   make_layer(w2, affine2, 128), make_layer(w3, affine3, 256), out, nullptr, valid, stamp_base);
-#else
     sa2_split_kernel<<<blocks, 256, kSa2Lds, st>>>(n, m, (int)tiles, queue, r2, pts, feat, new_xyz, make_layer(w1, affine1, 128),
                                                    make_layer(w2, affine2, 128), make_layer(w3, affine3, 256), out, dbg_ball_idx, valid);
-#endif
   } else if (level == 1) {
     // pts (b, n, 6); `feat` unused; dbg_ball_idx is this level's WORKSPACE (b, m, 32), filled by the query launch
     if (!pts || !new_xyz || !dbg_ball_idx || n <= 0 || m <= 0) return MSR3D_EINVAL;

@@ -1,8 +1,8 @@
 """A/B timing and phase stamps of msr3d_sa_level_split (level 2): every tools/_prof/abl/*.so -- builds of
 csrc/sa_split.hip with experimental edits -- is loaded beside the shipping library and timed on the bench's
-shapes; tools/_prof/abl/stamp/stamp.so, built with -DSPLIT_STAMP=1, writes s_memtime stamps of one steady-state
+shapes; tools/_prof/abl/stamp/stamp.so, built from tools/prof/sa_split_stamped.hip, records s_memtime stamps of one steady-state
 tile per block (the phase table of DESIGN.md 4.1b).
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC -I include -DSPLIT_STAMP=1 \
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC -I include tools/prof/sa_split_stamped.hip \
           msr3d_amd/csrc/sa_split.hip -o tools/_prof/abl/stamp/stamp.so
     python tools/ab_split.py [--batch 16]"""
 import argparse
@@ -61,19 +61,22 @@ for name, path in libs:
     ts.sort()
     print(f"{name:24s} median {ts[len(ts)//2]:8.1f} us  min {ts[0]:8.1f} us")
 
-# phase stamps (s_memtime, 100 MHz constant clock): build with -DSPLIT_STAMP=1 into tools/_prof/abl/stamp.so
+# phase stamps (s_memtime): tools/prof/sa_split_stamped.hip built into tools/_prof/abl/stamp/stamp.so
 sp = os.path.join(here, "_prof/abl/stamp/stamp.so")
 if os.path.exists(sp):
     lib = ctypes.CDLL(sp)
     fn = lib.msr3d_sa_level_split
     fn.argtypes = [ctypes.c_int] * 4 + [ctypes.c_float] + [ctypes.c_void_p] * 13
     fn.restype = ctypes.c_int
-    stamps = torch.zeros(512 * 4 * 16, dtype=torch.int64, device="cuda")
+    import numpy as np
+    lib.msr3d_prof_sa2_stamps.argtypes = [ctypes.c_void_p]
     for _ in range(3):
         fn(2, b, 32, 16, ctypes.c_float(0.4), p(new1), p(feat1), p(new2), p(S[0][0]), p(S[0][1]), p(S[1][0]),
-           p(S[1][1]), p(S[2][0]), p(S[2][1]), p(out), p(stamps), p(None), st)
+           p(S[1][1]), p(S[2][0]), p(S[2][1]), p(out), p(None), p(None), st)
     torch.cuda.synchronize()
-    t = stamps.view(-1, 4, 16)[:, :, :11].double().cpu()
+    hbuf = np.zeros(512 * 4 * 16, np.uint64)
+    assert lib.msr3d_prof_sa2_stamps(hbuf.ctypes.data) == 0
+    t = torch.from_numpy(hbuf.astype(np.int64)).view(-1, 4, 16)[:, :, :11].double()
     d = (t[:, :, 1:] - t[:, :, :-1])           # ticks of 10 ns
     names = ["L1 gemm", "L1 epi+geo", "L2 gemm+query", "L2 epi", "L3 gemm", "L3 epi", "barrier E", "gather", "barrier F", "loop top"]
     med = d.reshape(-1, 10).median(dim=0).values

@@ -1,4 +1,5 @@
-"""Phase stamps of panel_gemm.hip's workgroups (MSR3D_PROF build of the library into tools/_prof/):
+"""Phase stamps of panel_gemm.hip's workgroups (the library rebuilt into tools/_prof/ with
+tools/prof/panel_gemm_stamped.hip in place of csrc/panel_gemm.hip):
 where a workgroup's life goes -- B-panel issue, A staging + barrier, MFMA phase, epilogue."""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +15,8 @@ if not os.path.exists(lib_path) or "--rebuild" in sys.argv:
     objs = []
     for src, extra in hb.SOURCES:
         o = os.path.join(out, src.replace(".hip", ".o"))
-        subprocess.check_call([hb.hipcc()] + hb.COMMON + extra + ["-DMSR3D_PROF", "-c", os.path.join(hb.CSRC, src), "-o", o])
+        path = os.path.join(ROOT, "tools", "prof", "panel_gemm_stamped.hip") if src == "panel_gemm.hip" else os.path.join(hb.CSRC, src)
+        subprocess.check_call([hb.hipcc()] + hb.COMMON + extra + ["-c", path, "-o", o])
         objs.append(o)
     subprocess.check_call([hb.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs)
 if "--build-only" in sys.argv:
