@@ -34,6 +34,10 @@ extern "C" {
 typedef void *msr3d_stream_t; /* hipStream_t */
 
 int msr3d_abi_version(void);
+/* Floating-point contract of the squared distance a*a + b*b + c*c in the index ops this library was built
+ * with (csrc/pn2_device.h): 0 = fma(c,c,fma(a,a,b*b)), the default; 1 = no fma; 2 = fma(c,c,fma(b,b,a*a));
+ * 3 = fma(a,a,fma(b,b,c*c)).  Reference: sampling_gpu.cu:99-104, ball_query_gpu.cu:32-35. */
+int msr3d_sqdist_contract(void);
 /* Static string for a status returned by any entry point. */
 const char *msr3d_status_string(int status);
 

@@ -167,7 +167,7 @@ _lib = None
 
 def exported_symbols():
     """Every symbol include/msr3d_hip.h declares (checked by the CPU test-suite)."""
-    return ["msr3d_abi_version", "msr3d_status_string"] + list(_SIGNATURES)
+    return ["msr3d_abi_version", "msr3d_status_string", "msr3d_sqdist_contract"] + list(_SIGNATURES)
 
 
 ABI_VERSION = 8        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
@@ -192,6 +192,7 @@ def load():
         raise ImportError(
             f"msr3d_amd: {LIB_PATH} has ABI version {lib.msr3d_abi_version()}, this package binds "
             f"version {ABI_VERSION} (include/msr3d_hip.h). Rebuild it with `python -m msr3d_amd.build`.")
+    lib.msr3d_sqdist_contract.restype = _c_int
     lib.msr3d_status_string.restype = ctypes.c_char_p
     lib.msr3d_status_string.argtypes = [_c_int]
     for name, argtypes in _SIGNATURES.items():

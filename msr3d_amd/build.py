@@ -60,9 +60,21 @@ def _newest_header():
     return max(t, os.path.getmtime(os.path.abspath(__file__)))
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, sqdist_contract=None):
+    """sqdist_contract: rebuild the index kernels under another floating-point contract of the squared
+    distance (csrc/pn2_device.h; 0 = default).  The choice is recorded in csrc/build/.sqdist_contract so a
+    later plain build() keeps it until it is changed back."""
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
+    mark = os.path.join(OBJ, ".sqdist_contract")
+    current = int(open(mark).read().strip()) if os.path.exists(mark) else 0
+    if sqdist_contract is None:
+        sqdist_contract = current
+    if sqdist_contract != current:
+        force = True
+    with open(mark, "w") as f:
+        f.write(str(int(sqdist_contract)))
+    contract_flag = ["-DMSR3D_SQDIST_CONTRACT=%d" % int(sqdist_contract)]
     hdr_t = _newest_header()
     objs, rebuilt = [], False
     for src, extra in SOURCES:
@@ -70,7 +82,7 @@ def build(force=False, verbose=False):
         o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_t):
-            cmd = [cc] + COMMON + extra + ["-c", s, "-o", o]
+            cmd = [cc] + COMMON + extra + contract_flag + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
@@ -84,4 +96,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    contract = None
+    if "--sqdist-contract" in sys.argv:
+        contract = int(sys.argv[sys.argv.index("--sqdist-contract") + 1])
+    print(build(force="--force" in sys.argv, verbose=True, sqdist_contract=contract))

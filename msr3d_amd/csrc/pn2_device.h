@@ -10,9 +10,26 @@ namespace msr3d {
 
 constexpr int kWave = 64;
 
-// (a*a + b*b) + c*c as an LLVM-based device compiler contracts it (see oracle/pn2_oracle.c)
+// (a*a + b*b) + c*c under the floating-point contract the library is built with (oracle/pn2_oracle.c: sq3 has
+// the same table and a run-time switch).  0, the default, is how an LLVM-based device compiler contracts the
+// reference's expression; `python -m msr3d_amd.build --sqdist-contract N` rebuilds the index kernels under
+// another one (msr3d_sqdist_contract() reports the value compiled in).  The files that include this header
+// are built with -ffp-contract=off, so nothing is fused beyond what is written here.
+#ifndef MSR3D_SQDIST_CONTRACT
+#define MSR3D_SQDIST_CONTRACT 0
+#endif
 __device__ __forceinline__ float sq3(float a, float b, float c) {
+#if MSR3D_SQDIST_CONTRACT == 1
+  const float aa = a * a, bb = b * b, cc = c * c;
+  const float s = aa + bb;
+  return s + cc;
+#elif MSR3D_SQDIST_CONTRACT == 2
+  return __builtin_fmaf(c, c, __builtin_fmaf(b, b, a * a));
+#elif MSR3D_SQDIST_CONTRACT == 3
+  return __builtin_fmaf(a, a, __builtin_fmaf(b, b, c * c));
+#else
   return __builtin_fmaf(c, c, __builtin_fmaf(a, a, b * b));
+#endif
 }
 
 // ---- wave64 integer max, all lanes -> uniform ---------------------------------

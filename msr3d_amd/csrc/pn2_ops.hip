@@ -354,6 +354,7 @@ __global__ __launch_bounds__(256) void group_rows_grad_kernel(int n, int E, int 
 extern "C" {
 
 int msr3d_abi_version(void) { return MSR3D_ABI_VERSION; }
+int msr3d_sqdist_contract(void) { return MSR3D_SQDIST_CONTRACT; }
 
 const char *msr3d_status_string(int status) {
   if (status == 0) return "ok";

@@ -53,6 +53,22 @@ def _i(a):
     return a, a.ctypes.data_as(_i32p)
 
 
+CONTRACTS = {0: "fma(c,c,fma(a,a,b*b))  [LLVM, default]", 1: "(a*a+b*b)+c*c  [no fma]",
+             2: "fma(c,c,fma(b,b,a*a))", 3: "fma(a,a,fma(b,b,c*c))",
+             4: "contract 0 + 1 ulp  [envelope, not a contract]", 5: "contract 0 - 1 ulp  [envelope, not a contract]"}
+
+
+def set_contract(c):
+    """Floating-point contract of the squared distance a*a + b*b + c*c in FPS / ball query / three_nn
+    (see pn2_oracle.c: sq3).  0 = default = what the HIP kernels are built with."""
+    lib().pn2o_set_contract(int(c))
+
+
+def get_contract():
+    lib().pn2o_get_contract.restype = ctypes.c_int
+    return lib().pn2o_get_contract()
+
+
 def set_threads(t):
     lib().pn2o_set_threads(int(t))
 

@@ -40,10 +40,35 @@
 #include <omp.h>
 #endif
 
-/* (a*a + b*b) + c*c as contracted by an LLVM-based device compiler. */
+/* (a*a + b*b) + c*c under the floating-point contract in force.  The reference's source spells the sum
+ * without parentheses (sampling_gpu.cu:99-104, ball_query_gpu.cu:32-35); which products its compiler fused
+ * into fma is not recoverable from the source.  Contract 0 is what an LLVM-based device compiler emits
+ * and what the HIP kernels are built with by default; the others are the remaining plausible choices, kept
+ * so that (a) tools/fma_contract_risk.py can measure how much the choice matters and (b) a vector from an
+ * NVIDIA build, should one appear, can be matched by flipping a switch (and MSR3D_SQDIST_CONTRACT in
+ * msr3d_amd/csrc/pn2_device.h):
+ *   0  fma(c,c, fma(a,a, b*b))      LLVM contraction of ((a*a + b*b) + c*c)          [default]
+ *   1  (a*a + b*b) + c*c            no contraction (-fmad=false)
+ *   2  fma(c,c, fma(b,b, a*a))      left product kept, the other two fused
+ *   3  fma(a,a, fma(b,b, c*c))      right-to-left chain
+ *   4, 5  contract 0 pushed one ulp up / down: NOT a contract -- the envelope of every possible rounding
+ *         difference, for the exposure figure of tools/fma_contract_risk.py */
+static int g_contract = 0;
+void pn2o_set_contract(int c) { g_contract = (c >= 0 && c <= 5) ? c : 0; }
+int pn2o_get_contract(void) { return g_contract; }
 static inline float sq3(float a, float b, float c) {
-  return fmaf(c, c, fmaf(a, a, b * b));
+  switch (g_contract) {
+    case 1: { const float aa = a * a, bb = b * b, cc = c * c; const float s = aa + bb; return s + cc; }
+    case 2: return fmaf(c, c, fmaf(b, b, a * a));
+    case 3: return fmaf(a, a, fmaf(b, b, c * c));
+    case 4: return nextafterf(fmaf(c, c, fmaf(a, a, b * b)), INFINITY);
+    case 5: return nextafterf(fmaf(c, c, fmaf(a, a, b * b)), -INFINITY);
+    default: return fmaf(c, c, fmaf(a, a, b * b));
+  }
 }
+
+/* the squared distance under the contract in force (tests, tools/fma_contract_risk.py) */
+float pn2o_sq3(float a, float b, float c) { return sq3(a, b, c); }
 
 /* include/cuda_utils.h:13-19 -- 2^floor(log2 work) clamped to [1, 512]; the
  * double log/log and the int truncation are kept as written. */
