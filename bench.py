@@ -95,6 +95,8 @@ def parse():
     ap.add_argument("--unfrozen", action="store_true", help="variant line: `freeze: False` -- the PointNet++ "
                     "backbone trains too (BatchNorm in training mode, encoder forward + backward inside the "
                     "captured step); use a smaller --batch (4 scenes: 3.9 GiB of saved activations)")
+    ap.add_argument("--cpu-ops", action="store_true", help="per-op CPU micro-benchmarks at the GPU kernels' shapes "
+                    "(BASELINE.md §3.4) beside the GPU kernels' times -> profiles/r03_cpu_ops.json; no training step")
     ap.add_argument("--no-graph", action="store_true", help="issue the trainable part eagerly "
                     "instead of replaying the captured HIP graph")
     ap.add_argument("--cpu-threads", type=int, default=32, help="threads of the CPU baseline leg "
@@ -224,6 +226,16 @@ def main():
     global O, P
     args = parse()
     O, P = args.objects, args.points
+    if args.cpu_ops:
+        from msr3d_amd import cpu_ops_bench
+        res = cpu_ops_bench.run(threads=args.cpu_threads)
+        out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_cpu_ops.json")
+        with open(out, "w") as f:
+            json.dump(res, f, indent=1)
+        for k, v in res["rows"].items():
+            print(f"{k:56s} " + "  ".join(f"{n} {x:9.3f}" for n, x in v.items()))
+        print(json.dumps({"cpu_ops": out, "threads": res["threads"], "host": res["host"]}))
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
