@@ -95,6 +95,8 @@ def parse():
     ap.add_argument("--unfrozen", action="store_true", help="variant line: `freeze: False` -- the PointNet++ "
                     "backbone trains too (BatchNorm in training mode, encoder forward + backward inside the "
                     "captured step); use a smaller --batch (4 scenes: 3.9 GiB of saved activations)")
+    ap.add_argument("--no-window", action="store_true", help="with --accum: encode every micro-batch on its own "
+                    "instead of the whole accumulation window in one encoder pass")
     ap.add_argument("--cpu-ops", action="store_true", help="per-op CPU micro-benchmarks at the GPU kernels' shapes "
                     "(BASELINE.md §3.4) beside the GPU kernels' times -> profiles/r03_cpu_ops.json; no training step")
     ap.add_argument("--no-graph", action="store_true", help="issue the trainable part eagerly "
@@ -276,7 +278,7 @@ def main():
         model.visual_prompter.obj_encoder.skip_padded = True
     B = args.batch
     # distinct resident batches per rank, cycled (weak scaling: per-GPU work fixed)
-    n_resident = 4
+    n_resident = 4 if args.accum == 1 else max(4, 2 * args.accum)     # (a window's micro-batches are distinct)
     batches = [synth_batch(1000 * rank + i, B, O=O, P=P, device=device) for i in range(n_resident)]
     tr = Trainer(model, device, batches[0], args.llm_hidden, use_graph=not args.no_graph, accum=args.accum)
 
@@ -349,6 +351,8 @@ def main():
         tr.step = step_from_host
 
     for i in range(args.warmup * args.accum):
+        if args.accum > 1 and not args.unfrozen and not args.no_window and not args.host_inputs and i % args.accum == 0:
+            tr.stepper.encode_window([batches[(i + m) % n_resident] for m in range(args.accum)])
         tr.step(batches[i % n_resident], nxt(i))
 
     # N > 1 self-checks (nobody can watch an 8-GPU run: the line has to prove it was one).
@@ -374,9 +378,13 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step spread
     t0 = time.perf_counter()
     marks[0].record()
+    window = args.accum > 1 and not args.unfrozen and not args.no_window and not args.host_inputs
     for i in range(args.steps):
+        j0 = (args.warmup + i) * args.accum
+        if window:       # frozen encoder: the whole accumulation window's objects in one encoder pass
+            tr.stepper.encode_window([batches[(j0 + m) % n_resident] for m in range(args.accum)])
         for m in range(args.accum):
-            j = (args.warmup + i) * args.accum + m
+            j = j0 + m
             tr.step(batches[j % n_resident], nxt(j))
         marks[i + 1].record()
     torch.cuda.synchronize()
@@ -422,7 +430,7 @@ def main():
         # positions x (131*128 + 128*128 + 128*256) MACs x 2 = 67.50 MFLOP; one launch = B*O objects.
         k_ms = kern_ms["msr3d_sa_level2"] or 0.0
         flop_per_obj = 512 * (131 * 128 + 128 * 128 + 128 * 256) * 2
-        objs_per_launch = float(B * O)
+        objs_per_launch = float(B * O) * (args.accum if window else 1)    # (a whole window per encoder launch)
         if args.skip_padded:      # only real objects are encoded: count them over the timed steps
             first = args.warmup + (1 if pipe else 0)    # (pipelined: step i encodes batch i + 1)
             counts = [int(batches[(first + i) % n_resident]["obj_masks"].sum()) for i in range(args.steps)]

@@ -77,6 +77,7 @@ class HotPathTrainStep:
         # encoder prefetch (software pipelining over steps)
         self._enc_stream = torch.cuda.Stream() if self.static["obj_embeds"].is_cuda else None
         self._pref = {"key": None, "feats": torch.empty_like(self.static["obj_embeds"]), "event": None}
+        self._win = {"feats": None, "index": {}, "B": 0}        # encode_window(): features of a whole accumulation window
 
     # ---- the trainable part, on static buffers -------------------------------------
     def _fwd_bwd(self, zero=True):
@@ -156,6 +157,40 @@ class HotPathTrainStep:
         ev.record(torch.cuda.current_stream())
         self._pref["key"], self._pref["event"] = id(batch["obj_fts"]), ev
 
+    def encode_window(self, batches):
+        """Gradient accumulation with a frozen encoder: the features of ALL micro-batches of an optimiser
+        step depend on nothing the step updates, so they are encoded in ONE pass (accum x B x O objects per
+        launch: the persistent set-abstraction kernels are sized for a full chip and a 4-scene micro-batch
+        fills a quarter of it) and each micro-step picks up its slice.  Same values as encoding each
+        micro-batch on its own (every object's feature is independent of what else is in the launch: tested
+        bit for bit).  Call it before the window's first micro-step; batches whose features are not in the
+        window are encoded on demand as before."""
+        if self.unfrozen or not batches:
+            return
+        fts = [b["obj_fts"] for b in batches]
+        B = fts[0].shape[0]
+        n = len(fts)
+        # micro-batches that already lie back to back in memory (a window-major loader) are encoded in place
+        step = fts[0].numel() * fts[0].element_size()
+        if all(f.is_contiguous() and f.shape == fts[0].shape and f.data_ptr() == fts[0].data_ptr() + i * step
+               for i, f in enumerate(fts)):
+            allf = torch.as_strided(fts[0], (n * B,) + tuple(fts[0].shape[1:]), fts[0].stride())
+        else:
+            allf = torch.cat(fts, 0)
+        masks = None
+        if all("obj_masks" in b for b in batches):
+            masks = torch.cat([b["obj_masks"] for b in batches], 0)
+        w = self._win
+        shape = (n * B,) + tuple(self.static["obj_embeds"].shape[1:])
+        if w.get("feats") is None or tuple(w["feats"].shape) != shape:
+            w["feats"] = torch.empty(shape, dtype=torch.float32, device=allf.device)
+        with torch.no_grad():
+            self.prompter.encode_objects(allf, masks, out=w["feats"])
+        w["index"] = {}
+        for i, f in enumerate(fts):           # (the same batch object may sit in a window twice)
+            w["index"].setdefault(id(f), []).append(i)
+        w["B"] = B
+
     def prefetch(self, batch):
         """Start the frozen encoder for `batch` on the side stream (returns immediately)."""
         if self._enc_stream is None or self.unfrozen:
@@ -174,6 +209,9 @@ class HotPathTrainStep:
         with torch.no_grad():
             if self.unfrozen:
                 self.static["obj_fts"].copy_(batch["obj_fts"])
+            elif self._win["index"].get(id(batch["obj_fts"])):  # encoded with its accumulation window
+                i, Bm = self._win["index"][id(batch["obj_fts"])].pop(0), self._win["B"]
+                self.static["obj_embeds"].copy_(self._win["feats"][i * Bm:(i + 1) * Bm])
             elif self._pref["key"] == id(batch["obj_fts"]):     # features were prefetched
                 torch.cuda.current_stream().wait_event(self._pref["event"])
                 self.static["obj_embeds"].copy_(self._pref["feats"])

@@ -296,3 +296,50 @@ def test_direct_staging_still_copies_the_batch_tensors_the_loss_reads():
         b0 = dict(batches[0]); b0["target_w"] = batches[0]["target_w"] * 4.0
         assert float(step(b0)) == pytest.approx(4.0 * ls[0], rel=1e-5)
     assert losses[0] == pytest.approx(losses[1], rel=1e-5)
+
+
+def test_accumulation_window_encoded_in_one_pass_gives_the_same_step():
+    """with the frozen encoder, encode_window() runs ONE encoder pass over all
+    micro-batches of an optimiser step.  The features are bit-identical to per-micro-batch encoding (every
+    object's feature is independent of the launch it is in), so the accumulated gradients and the updated
+    weights are the same (bit-identical up to the arrival order of the schedule's few float atomics)."""
+    import msr3d_amd.model  # noqa: F401
+    import msr3d_amd.modules  # noqa: F401
+    from msr3d_amd import hipops
+    from msr3d_amd.config import AttrDict, default_prompter_cfg
+    from msr3d_amd.dp import FlatGradAllReduce
+    from msr3d_amd.model import build_model
+    from msr3d_amd.optim import FlatAdamW
+    from msr3d_amd.synth import synth_batch
+    from msr3d_amd.train_step import HotPathTrainStep
+    accum, outs = 3, []
+    for window in (False, True):
+        torch.manual_seed(0)
+        cfg = AttrDict({"prompter": default_prompter_cfg(dropout=0.0), "llm_hidden_size": 256,
+                        "model": {"name": "MSR3DHotPath"}})
+        model = build_model(cfg).cuda().train()
+        params = [p for p in model.parameters() if p.requires_grad]
+        dp = FlatGradAllReduce(params, pack_groups=hipops.collect_pack_groups(model))
+        opt = FlatAdamW(dp, lr=1e-3, weight_decay=0.0)
+        hipops.attach_packed_views(model, dp, opt)
+        batches = [synth_batch(300 + i, 2, O=24, P=1024, device="cuda") for i in range(accum)]
+        w = torch.linspace(-1, 1, 2 * 24 * 256, device="cuda").view(2, 24, 256)
+        step = HotPathTrainStep(model, opt, dp, lambda o: (o["scene_embeds"] * w).mean(), batches[0],
+                                use_graph=True, accum_steps=accum)
+        step.capture(batches[0])
+        feats = []
+        for rep in range(2):                       # two optimiser steps
+            if window:
+                step.encode_window(batches)
+            for b in batches:
+                step(b)
+                feats.append(step.static["obj_embeds"].clone())
+        torch.cuda.synchronize()
+        outs.append((feats, {k: v.detach().clone() for k, v in model.named_parameters() if v.requires_grad}))
+    (f0, p0), (f1, p1) = outs
+    for a, b in zip(f0, f1):
+        assert torch.equal(a, b)                   # encoder features: bit-identical
+    for k in p0:
+        if k.endswith("w_ks.bias"):
+            continue
+        assert torch.allclose(p0[k], p1[k], rtol=1e-4, atol=1e-6), k
