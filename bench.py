@@ -229,7 +229,8 @@ def main():
     args = parse()
     O, P = args.objects, args.points
     if args.cpu_ops:
-        from msr3d_amd import cpu_ops_bench
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        import cpu_ops_bench          # (times the oracle as the CPU baseline: lives outside the product package)
         res = cpu_ops_bench.run(threads=args.cpu_threads)
         out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_cpu_ops.json")
         with open(out, "w") as f:

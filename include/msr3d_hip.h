@@ -686,6 +686,44 @@ int msr3d_bf16_gemm_lowrank(int M, int N, int K, int R, const void *P, int ldp, 
  * (transpose_out: out is (C, R)); P (M, R) and Q (M, C) bf16; R in {16, 32}; `out` holds the value to
  * add to (row splits meet by atomicAdd).  dA = s (dy B)^T x: P = dy B, Q = x;  dB = s dy^T (x A^T):
  * P = x A^T, Q = dy, transpose_out = 1. */
+/* Batched C[o][i] (M, N) = scale * P[o][i] (M, K) Q[o][i] (N, K)^T over outer x inner problems (e.g.
+ * sequences x heads; strides in elements: *_outer, *_inner, % 8 == 0 for P / Q, % 4 for C), bf16 operands with
+ * k-contiguous rows (ld % 8 == 0), fp32 accumulate, C bf16 or fp32 (ldc % 4 == 0): the per-(sequence, head)
+ * products of the decoder layer's attention (Q K^T, P V, and the four of its backward) on the same kernel as the
+ * projections.  K % 64 == 0, outer * inner <= 65535. */
+int msr3d_bf16_gemm_batched(int outer, int inner, int M, int N, int K, const void *P, int ldp, long long p_outer,
+                            long long p_inner, const void *Q, int ldq, long long q_outer, long long q_inner, void *C,
+                            int ldc, long long c_outer, long long c_inner, int c_f32, float scale,
+                            msr3d_stream_t stream);
+
+/* The row-local / element-wise kernels of one Llama decoder layer (csrc/llm_layer.hip; bf16 storage, fp32
+ * arithmetic; transformers.models.llama.modeling_llama: LlamaRMSNorm, apply_rotary_pos_emb, eager attention,
+ * LlamaMLP; /root/reference/model/msr3d/msr3d.py:409-415 runs them under bf16 autocast):
+ *   rmsnorm_fwd   s = x (+ delta) [-> sum_out]; y = w * bf16(s * rsqrt(mean(s^2) + eps)); rstd (M) f32.
+ *                 D in {512, 1024, 2048, 4096, 5120, 8192}.
+ *   rmsnorm_bwd   dx = rstd * (dy w - xh mean(dy w xh)) (+ dres), xh = s rstd   (w is frozen: no dw)
+ *   rope_inplace  x (B, T, H, D) bf16 *= rotation by (cos, sin) (T, D) f32; transpose != 0: the backward
+ *   causal_softmax_fwd   probs (B H, T, T) bf16 = softmax over keys t' <= t with key_keep[b][t'] != 0 of fp32 scores
+ *   causal_softmax_bwd   dscores bf16 = probs * (dprobs - rowsum(dprobs probs)), dprobs fp32
+ *   swiglu_fwd / bwd     h = silu(gate) * up and its two gradients; n % 8 == 0
+ *   transpose_bf16       dst[o][i] (cols, rows) = src[o][i] (rows, cols)^T, two-level batch strides (elements) */
+int msr3d_rmsnorm_fwd(int M, int D, const void *x, const void *delta, const void *w, float eps, void *sum_out,
+                      void *y, float *rstd, msr3d_stream_t stream);
+int msr3d_rmsnorm_bwd(int M, int D, const void *dy, const void *s, const void *w, const float *rstd,
+                      const void *dres, void *dx, msr3d_stream_t stream);
+int msr3d_rope_inplace(int B, int T, int H, int D, void *x, const float *cos_td, const float *sin_td, int transpose,
+                       msr3d_stream_t stream);
+int msr3d_causal_softmax_fwd(int B, int H, int T, const float *scores, const unsigned char *key_keep, void *probs,
+                             msr3d_stream_t stream);
+int msr3d_causal_softmax_bwd(int B, int H, int T, const float *dprobs, const void *probs, void *dscores,
+                             msr3d_stream_t stream);
+int msr3d_swiglu_fwd(long long n, const void *gate, const void *up, void *out, msr3d_stream_t stream);
+int msr3d_swiglu_bwd(long long n, const void *gate, const void *up, const void *dh, void *dgate, void *dup,
+                     msr3d_stream_t stream);
+int msr3d_transpose_bf16(int outer, int inner, int rows, int cols, const void *src, int ld_src, long long src_outer,
+                         long long src_inner, void *dst, int ld_dst, long long dst_outer, long long dst_inner,
+                         msr3d_stream_t stream);
+
 int msr3d_lora_grad(int M, int R, int C, const void *P, int ldp, const void *Q, int ldq, float *out,
                     int transpose_out, float scale, msr3d_stream_t stream);
 

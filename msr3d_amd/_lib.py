@@ -89,6 +89,18 @@ _SIGNATURES = {
     "msr3d_wgrad_split": [_c_int, _ptr, _ptr, _c_int, _ptr],
     "msr3d_bf16_gemm_lowrank": [_c_int, _c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int,
                                 _ptr, _c_int, _c_int, _c_float, _ptr],
+    "msr3d_bf16_gemm_batched": [_c_int] * 5 + [_ptr, _c_int, ctypes.c_longlong, ctypes.c_longlong, _ptr, _c_int,
+                                ctypes.c_longlong, ctypes.c_longlong, _ptr, _c_int, ctypes.c_longlong,
+                                ctypes.c_longlong, _c_int, _c_float, _ptr],
+    "msr3d_rmsnorm_fwd": [_c_int, _c_int, _ptr, _ptr, _ptr, _c_float, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_rmsnorm_bwd": [_c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_rope_inplace": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _c_int, _ptr],
+    "msr3d_causal_softmax_fwd": [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_causal_softmax_bwd": [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_swiglu_fwd": [ctypes.c_longlong, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_swiglu_bwd": [ctypes.c_longlong, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_transpose_bf16": [_c_int, _c_int, _c_int, _c_int, _ptr, _c_int, ctypes.c_longlong, ctypes.c_longlong,
+                             _ptr, _c_int, ctypes.c_longlong, ctypes.c_longlong, _ptr],
     "msr3d_lora_grad": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_float, _ptr],
     "msr3d_sa_level_split": [_c_int, _c_int, _c_int, _c_int, _c_float] + [_ptr] * 13,
     "msr3d_seq_ce_fwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],

@@ -1,0 +1,350 @@
+// llm_layer.hip -- the row-local and element-wise kernels of one LoRA-Llama decoder layer (SURVEY.md §8(f)
+// rank 4; /root/reference/model/msr3d/msr3d.py:103-112, 409-415: Vicuna-7B under bf16 autocast with peft
+// LoRA on q/k/v/o/gate/up/down_proj).  The layer, as transformers' LlamaDecoderLayer computes it:
+//
+//     h = RMSNorm(x) ; q, k, v = LoRALinear(h) ; RoPE(q, k) ; P = softmax(q k^T / sqrt(d) + causal + padding)
+//     x = x + LoRALinear_o(P v) ; h = RMSNorm(x) ; x = x + LoRALinear_down( silu(LoRALinear_gate(h)) * LoRALinear_up(h) )
+//
+// The seven projections and the attention's per-head products are msr3d_bf16_gemm_lowrank / _batched
+// (lora_linear.hip).  Here: RMSNorm (+ the residual add in front of it) forward / backward, rotary embedding
+// (forward and its transpose), the causal + key-padding softmax forward / backward on fp32 scores, SwiGLU
+// forward / backward, and a batched bf16 transpose (the backward products and P V need operands with the
+// contraction index contiguous).  bf16 storage, fp32 arithmetic, one rounding per stored value.
+// All HBM-bound: algorithmic bytes = the tensors read + written once.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "../../include/msr3d_hip.h"
+
+namespace {
+
+using u16 = unsigned short;
+
+__device__ __forceinline__ float bf2f(u16 v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ u16 f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (u16)(u >> 16);
+}
+__device__ __forceinline__ void unpack8(uint4 v, float (&f)[8]) {
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  unsigned w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(f[2 * i]) | ((unsigned)f2bf(f[2 * i + 1]) << 16);
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---- RMSNorm: one wave per row, D <= 8192, D % 512 == 0 (a lane holds D / 64 values as D / 512 x 8) ------
+// forward:  s = x (+ delta);  y = w * bf16( s * rsqrt(mean(s^2) + eps) )       (modeling_llama.LlamaRMSNorm)
+template <int V>     // V = D / 512 16-byte vectors per lane
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(int M, const u16 *__restrict__ x, const u16 *__restrict__ delta,
+                                                          const u16 *__restrict__ w, float eps, u16 *__restrict__ sum_out,
+                                                          u16 *__restrict__ y, float *__restrict__ rstd_out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  constexpr int D = V * 512;
+  float s[V][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const size_t o = (size_t)row * D + (v * 64 + lane) * 8;
+    unpack8(*reinterpret_cast<const uint4 *>(x + o), s[v]);
+    if (delta) {
+      float d[8];
+      unpack8(*reinterpret_cast<const uint4 *>(delta + o), d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[v][e] = bf2f(f2bf(s[v][e] + d[e]));      // the residual stream is stored in bf16
+      if (sum_out) *reinterpret_cast<uint4 *>(sum_out + o) = pack8(s[v]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss = fmaf(s[v][e], s[v][e], ss);
+  }
+  const float rstd = rsqrtf(wave_sum(ss) * (1.0f / D) + eps);
+  if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    float g[8], o8[8];
+    unpack8(*reinterpret_cast<const uint4 *>(w + (v * 64 + lane) * 8), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = g[e] * bf2f(f2bf(s[v][e] * rstd));
+    *reinterpret_cast<uint4 *>(y + (size_t)row * D + (v * 64 + lane) * 8) = pack8(o8);
+  }
+}
+// backward (w frozen): g = dy * w;  dx = rstd * (g - xh * mean(g * xh)) (+ dres),  xh = s * rstd
+template <int V>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(int M, const u16 *__restrict__ dy, const u16 *__restrict__ s_in,
+                                                          const u16 *__restrict__ w, const float *__restrict__ rstd_in,
+                                                          const u16 *__restrict__ dres, u16 *__restrict__ dx) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  constexpr int D = V * 512;
+  const float rstd = rstd_in[row];
+  float g[V][8], xh[V][8];
+  float c = 0.f;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const size_t o = (size_t)row * D + (v * 64 + lane) * 8;
+    float d[8], ww[8], s[8];
+    unpack8(*reinterpret_cast<const uint4 *>(dy + o), d);
+    unpack8(*reinterpret_cast<const uint4 *>(w + (v * 64 + lane) * 8), ww);
+    unpack8(*reinterpret_cast<const uint4 *>(s_in + o), s);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      g[v][e] = d[e] * ww[e];
+      xh[v][e] = s[e] * rstd;
+      c = fmaf(g[v][e], xh[v][e], c);
+    }
+  }
+  c = wave_sum(c) * (1.0f / D);
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const size_t o = (size_t)row * D + (v * 64 + lane) * 8;
+    float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, o8[8];
+    if (dres) unpack8(*reinterpret_cast<const uint4 *>(dres + o), r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = rstd * (g[v][e] - xh[v][e] * c) + r[e];
+    *reinterpret_cast<uint4 *>(dx + o) = pack8(o8);
+  }
+}
+
+// ---- rotary embedding, in place on (B, T, H, D) bf16; cos / sin (T, D) fp32 (position = t) ----------------
+// x' = x cos + rotate_half(x) sin, rotate_half(x) = [-x2, x1] (modeling_llama.apply_rotary_pos_emb);
+// sign = -1 applies the transpose (the backward): dx = dx' cos - rotate_half(dx' ... ) i.e. sin -> -sin.
+__global__ __launch_bounds__(256) void rope_kernel(long long n_pairs, int T, int H, int D, u16 *__restrict__ x,
+                                                   const float *__restrict__ cs, const float *__restrict__ sn, float sign) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;     // one (b, t, h, i < D/2) pair per thread
+  if (p >= n_pairs) return;
+  const int half = D >> 1;
+  const int i = (int)(p % half);
+  const long long bth = p / half;
+  const int t = (int)((bth / H) % T);
+  u16 *q = x + bth * D;
+  const float a = bf2f(q[i]), b = bf2f(q[i + half]);
+  const float c1 = cs[(size_t)t * D + i], c2 = cs[(size_t)t * D + i + half];
+  const float s1 = sign * sn[(size_t)t * D + i], s2 = sign * sn[(size_t)t * D + i + half];
+  q[i] = f2bf(a * c1 - b * s1);
+  q[i + half] = f2bf(b * c2 + a * s2);
+}
+
+// ---- causal + key-padding softmax over fp32 scores (B H, T, T) -> bf16 probabilities; one wave per row ------
+// key t' of row t is visible iff t' <= t and keep[b][t'] != 0; a row with no visible key gives zeros.
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(int BH, int H, int T, const float *__restrict__ S,
+                                                          const unsigned char *__restrict__ keep, u16 *__restrict__ P) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= (long long)BH * T) return;
+  const int t = (int)(row % T), b = (int)(row / T / H);
+  const float *s = S + row * T;
+  const unsigned char *kp = keep ? keep + (size_t)b * T : nullptr;
+  float m = -INFINITY;
+  for (int c = lane; c <= t; c += 64)
+    if (!kp || kp[c]) m = fmaxf(m, s[c]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float z = 0.f;
+  for (int c = lane; c <= t; c += 64)
+    if (!kp || kp[c]) z += expf(s[c] - m);
+  z = wave_sum(z);
+  const float inv = z > 0.f ? 1.0f / z : 0.f;
+  u16 *p = P + row * T;
+  for (int c = lane; c < T; c += 64) {
+    const bool vis = c <= t && (!kp || kp[c]);
+    p[c] = vis ? f2bf(expf(s[c] - m) * inv) : (u16)0;
+  }
+}
+// dS = P * (dP - sum_c dP P): dP fp32 (B H, T, T), P bf16 -> dS bf16
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(long long rows, int T, const float *__restrict__ dP,
+                                                          const u16 *__restrict__ P, u16 *__restrict__ dS) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float *d = dP + row * T;
+  const u16 *p = P + row * T;
+  float dot = 0.f;
+  for (int c = lane; c < T; c += 64) dot = fmaf(d[c], bf2f(p[c]), dot);
+  dot = wave_sum(dot);
+  u16 *o = dS + row * T;
+  for (int c = lane; c < T; c += 64) {
+    const float pv = bf2f(p[c]);
+    o[c] = f2bf(pv * (d[c] - dot));
+  }
+}
+
+// ---- SwiGLU: h = silu(gate) * up ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(long long n8, const uint4 *__restrict__ gate, const uint4 *__restrict__ up,
+                                                         uint4 *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  float g[8], u[8], o[8];
+  unpack8(gate[i], g);
+  unpack8(up[i], u);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float sg = bf2f(f2bf(g[e] / (1.0f + expf(-g[e]))));      // silu is its own (bf16) op in the reference graph
+    o[e] = sg * u[e];
+  }
+  out[i] = pack8(o);
+}
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(long long n8, const uint4 *__restrict__ gate, const uint4 *__restrict__ up,
+                                                         const uint4 *__restrict__ dh, uint4 *__restrict__ dgate,
+                                                         uint4 *__restrict__ dup) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  float g[8], u[8], d[8], og[8], ou[8];
+  unpack8(gate[i], g);
+  unpack8(up[i], u);
+  unpack8(dh[i], d);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float sig = 1.0f / (1.0f + expf(-g[e]));
+    const float sl = g[e] * sig;
+    ou[e] = d[e] * sl;
+    og[e] = d[e] * u[e] * (sig * (1.0f + g[e] * (1.0f - sig)));
+  }
+  dgate[i] = pack8(og);
+  dup[i] = pack8(ou);
+}
+
+// ---- batched bf16 transpose: dst[b][c][r] = src[b][r][c]; 64 x 64 tiles through LDS; two-level batch -----------
+__global__ __launch_bounds__(256) void transpose_kernel(int rows, int cols, int inner, const u16 *__restrict__ src, int lds_,
+                                                        long long so, long long si, u16 *__restrict__ dst, int ldd,
+                                                        long long dout, long long din) {
+  __shared__ u16 tile[64][66];
+  const int bz = blockIdx.z, bo = bz / inner, bi = bz - bo * inner;
+  const u16 *s = src + bo * so + bi * si;
+  u16 *d = dst + bo * dout + bi * din;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4)
+    tile[r][tx] = (r0 + r < rows && c0 + tx < cols) ? s[(size_t)(r0 + r) * lds_ + c0 + tx] : (u16)0;
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4)
+    if (c0 + c < cols && r0 + tx < rows) d[(size_t)(c0 + c) * ldd + r0 + tx] = tile[tx][c];
+}
+
+inline bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int msr3d_rmsnorm_fwd(int M, int D, const void *x, const void *delta, const void *w, float eps, void *sum_out,
+                      void *y, float *rstd, msr3d_stream_t stream) {
+  if (M < 0 || (D != 512 && D != 1024 && D != 2048 && D != 4096 && D != 5120 && D != 8192)) return MSR3D_EINVAL;
+  if (M == 0) return 0;
+  if (!x || !w || !y || !al16(x) || !al16(w) || !al16(y) || (delta && !al16(delta)) || (sum_out && !al16(sum_out)))
+    return MSR3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int g = (M + 3) / 4;
+#define MSR3D_RMS(V)                                                                                              \
+  rmsnorm_fwd_kernel<V><<<g, 256, 0, st>>>(M, (const u16 *)x, (const u16 *)delta, (const u16 *)w, eps, (u16 *)sum_out, \
+                                           (u16 *)y, rstd)
+  switch (D / 512) {
+    case 1: MSR3D_RMS(1); break;
+    case 2: MSR3D_RMS(2); break;
+    case 4: MSR3D_RMS(4); break;
+    case 8: MSR3D_RMS(8); break;
+    case 10: MSR3D_RMS(10); break;
+    default: MSR3D_RMS(16); break;
+  }
+#undef MSR3D_RMS
+  return (int)hipGetLastError();
+}
+
+int msr3d_rmsnorm_bwd(int M, int D, const void *dy, const void *s, const void *w, const float *rstd,
+                      const void *dres, void *dx, msr3d_stream_t stream) {
+  if (M < 0 || (D != 512 && D != 1024 && D != 2048 && D != 4096 && D != 5120 && D != 8192)) return MSR3D_EINVAL;
+  if (M == 0) return 0;
+  if (!dy || !s || !w || !rstd || !dx || !al16(dy) || !al16(s) || !al16(w) || !al16(dx) || (dres && !al16(dres)))
+    return MSR3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int g = (M + 3) / 4;
+#define MSR3D_RMSB(V)                                                                                          \
+  rmsnorm_bwd_kernel<V><<<g, 256, 0, st>>>(M, (const u16 *)dy, (const u16 *)s, (const u16 *)w, rstd, (const u16 *)dres, \
+                                           (u16 *)dx)
+  switch (D / 512) {
+    case 1: MSR3D_RMSB(1); break;
+    case 2: MSR3D_RMSB(2); break;
+    case 4: MSR3D_RMSB(4); break;
+    case 8: MSR3D_RMSB(8); break;
+    case 10: MSR3D_RMSB(10); break;
+    default: MSR3D_RMSB(16); break;
+  }
+#undef MSR3D_RMSB
+  return (int)hipGetLastError();
+}
+
+int msr3d_rope_inplace(int B, int T, int H, int D, void *x, const float *cos_td, const float *sin_td, int transpose,
+                       msr3d_stream_t stream) {
+  if (B < 0 || T <= 0 || H <= 0 || D <= 0 || (D & 1)) return MSR3D_EINVAL;
+  if (B == 0) return 0;
+  if (!x || !cos_td || !sin_td) return MSR3D_EINVAL;
+  const long long n = (long long)B * T * H * (D / 2);
+  rope_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(n, T, H, D, (u16 *)x, cos_td, sin_td,
+                                                                           transpose ? -1.0f : 1.0f);
+  return (int)hipGetLastError();
+}
+
+int msr3d_causal_softmax_fwd(int B, int H, int T, const float *scores, const unsigned char *key_keep, void *probs,
+                             msr3d_stream_t stream) {
+  if (B < 0 || H <= 0 || T <= 0) return MSR3D_EINVAL;
+  if (B == 0) return 0;
+  if (!scores || !probs) return MSR3D_EINVAL;
+  const long long rows = (long long)B * H * T;
+  softmax_fwd_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(B * H, H, T, scores, key_keep, (u16 *)probs);
+  return (int)hipGetLastError();
+}
+
+int msr3d_causal_softmax_bwd(int B, int H, int T, const float *dprobs, const void *probs, void *dscores,
+                             msr3d_stream_t stream) {
+  if (B < 0 || H <= 0 || T <= 0) return MSR3D_EINVAL;
+  if (B == 0) return 0;
+  if (!dprobs || !probs || !dscores) return MSR3D_EINVAL;
+  const long long rows = (long long)B * H * T;
+  softmax_bwd_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(rows, T, dprobs, (const u16 *)probs,
+                                                                                 (u16 *)dscores);
+  return (int)hipGetLastError();
+}
+
+int msr3d_swiglu_fwd(long long n, const void *gate, const void *up, void *out, msr3d_stream_t stream) {
+  if (n < 0 || (n % 8)) return MSR3D_EINVAL;
+  if (n == 0) return 0;
+  if (!gate || !up || !out || !al16(gate) || !al16(up) || !al16(out)) return MSR3D_EINVAL;
+  swiglu_fwd_kernel<<<(unsigned)((n / 8 + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      n / 8, (const uint4 *)gate, (const uint4 *)up, (uint4 *)out);
+  return (int)hipGetLastError();
+}
+
+int msr3d_swiglu_bwd(long long n, const void *gate, const void *up, const void *dh, void *dgate, void *dup,
+                     msr3d_stream_t stream) {
+  if (n < 0 || (n % 8)) return MSR3D_EINVAL;
+  if (n == 0) return 0;
+  if (!gate || !up || !dh || !dgate || !dup || !al16(gate) || !al16(up) || !al16(dh) || !al16(dgate) || !al16(dup))
+    return MSR3D_EINVAL;
+  swiglu_bwd_kernel<<<(unsigned)((n / 8 + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      n / 8, (const uint4 *)gate, (const uint4 *)up, (const uint4 *)dh, (uint4 *)dgate, (uint4 *)dup);
+  return (int)hipGetLastError();
+}
+
+int msr3d_transpose_bf16(int outer, int inner, int rows, int cols, const void *src, int ld_src, long long src_outer,
+                         long long src_inner, void *dst, int ld_dst, long long dst_outer, long long dst_inner,
+                         msr3d_stream_t stream) {
+  if (outer < 0 || inner <= 0 || rows <= 0 || cols <= 0 || (long long)outer * inner > 65535) return MSR3D_EINVAL;
+  if (outer == 0) return 0;
+  if (!src || !dst || ld_src < cols || ld_dst < rows) return MSR3D_EINVAL;
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64, outer * inner);
+  transpose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(rows, cols, inner, (const u16 *)src, ld_src, src_outer, src_inner,
+                                                         (u16 *)dst, ld_dst, dst_outer, dst_inner);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -13,8 +13,8 @@
 // first call of the same kernel against the zero-padded A; R = 32).  The frozen weight is kept in
 // BOTH orientations (W for the forward, W^T for dx): 13 GB extra for a 7B model, which is what a
 // 288 GB part is for -- no transposing load path, both products read k-contiguous rows.
-// 128 x 128 tile, BK = 64, LDS double-buffered through registers, 4 waves of 64 x 64 (4 x 4 MFMA
-// tiles).  The weight gradients' token reduction (M = a few thousand, output r x K / N x r) is a
+// 192 x 128 (or 128 x 128) tile, BK = 64, one LDS stage + register prefetch, 4 waves of 96 x 64 (6 x 4 MFMA
+// tiles); msr3d_bf16_gemm_batched: the same kernel over a batch (attention's per-head products).  The weight gradients' token reduction (M = a few thousand, output r x K / N x r) is a
 // column-per-thread VALU kernel: it is bound by reading x / dy once.
 #include <hip/hip_runtime.h>
 
@@ -27,8 +27,8 @@ namespace {
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int LD = BK + 8;                 // bf16 units: row stride 144 B
+constexpr int BN = 128, BK = 64;
+constexpr int LD = BK + 8;                 // bf16 units: row stride 144 B (conflict-free 16-byte fragment reads)
 
 __device__ __forceinline__ unsigned short f2bf(float f) {        // round to nearest even
   unsigned u = __float_as_uint(f);
@@ -44,96 +44,114 @@ struct GemmArgs {
   const unsigned short *Q2; int ldq2;
   void *C; int ldc; int c_f32;
   float scale;                             // applied to the whole result (the forward's u = s x A^T)
+  int inner;                               // blockIdx.z = outer * inner + inner index (e.g. sequence, head)
+  long long spo, spi, sqo, sqi, sco, sci;   // batch strides (elements) of P, Q, C, outer and inner
 };
 
-// rows x 64 k of a row-major bf16 matrix -> registers: 4 x 16 B per thread (row = t/8 + 32 j, k8 = t%8)
-__device__ __forceinline__ void tile_load(uint4 (&r)[4], const unsigned short *__restrict__ S, int ld, int row0,
+// ROWS x 64 k of a row-major bf16 matrix -> registers: 16 B per thread and pass (row = t/8 + 32 j, k8 = t%8)
+template <int ROWS>
+__device__ __forceinline__ void tile_load(uint4 (&r)[ROWS / 32], const unsigned short *__restrict__ S, int ld, int row0,
                                           int rows, int k0, int kmax) {
   const int t = threadIdx.x;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < ROWS / 32; ++j) {
     const int row = min(row0 + (t >> 3) + 32 * j, rows - 1), k = k0 + (t & 7) * 8;
     r[j] = k < kmax ? *reinterpret_cast<const uint4 *>(S + (size_t)row * ld + k) : make_uint4(0, 0, 0, 0);
   }
 }
-__device__ __forceinline__ void tile_store(unsigned short *L, const uint4 (&r)[4]) {
+template <int ROWS>
+__device__ __forceinline__ void tile_store(unsigned short *L, const uint4 (&r)[ROWS / 32]) {
   const int t = threadIdx.x;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < ROWS / 32; ++j)
     *reinterpret_cast<uint4 *>(L + ((t >> 3) + 32 * j) * LD + (t & 7) * 8) = r[j];
 }
 
+// BM x 128 tile, 4 waves as 2 x 2, each (BM / 2) x 64 = MT x 4 MFMA tiles.  BM = 192 is the shape for the
+// language model's token counts (4 x 576 = 2304 = 12 x 192): 6 x 4 tiles per wave read 10 fragments per 24
+// MFMAs -- the 64 x 64 sub-tile of the 128 x 128 variant reads 8 per 16, which with two workgroups per CU is
+// exactly the LDS's 128 B/clk (round 2: 275 TFLOP/s, the 576 tiles of 2304 x 4096 also being 1.125 rounds of
+// the chip's 512 slots).  The accumulators are transposed (D = Q P^T: a lane holds FOUR CONSECUTIVE output
+// columns of one row), so the epilogue is one 8-byte (bf16) or 16-byte (fp32) store per tile instead of four
+// scattered 2-byte ones.  Single LDS stage + register prefetch: next tile's loads fly under this tile's MFMAs.
+template <int BM>
 __global__ __launch_bounds__(256, 2) void bf16_gemm_kernel(const GemmArgs a) {
+  constexpr int MT = BM / 32;                    // 16-row tiles per wave
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
-  constexpr int STAGE = 2 * BM * LD;             // one stage = A tile then B tile
+  unsigned short *As = lds, *Bs = lds + BM * LD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int bo = blockIdx.z / a.inner, bi = blockIdx.z - bo * a.inner;
+  const unsigned short *P = a.P + bo * a.spo + bi * a.spi, *Q = a.Q + bo * a.sqo + bi * a.sqi;
 
-  f32x4 acc[4][4];
+  f32x4 acc[MT][4];
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+  for (int x = 0; x < MT; ++x)
 #pragma unroll
     for (int y = 0; y < 4; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // the K walk: main operands, then (if R > 0) the low-rank pair as extra stages
   const int nk_main = a.K / BK, nk = nk_main + (a.R + BK - 1) / BK;
-  auto fetch = [&](int kt, uint4 (&ra)[4], uint4 (&rb)[4]) {
+  uint4 ra[BM / 32], rb[BN / 32];
+  auto fetch = [&](int kt) {
     if (kt < nk_main) {
-      tile_load(ra, a.P, a.ldp, m0, a.M, kt * BK, a.K);
-      tile_load(rb, a.Q, a.ldq, n0, a.N, kt * BK, a.K);
+      tile_load<BM>(ra, P, a.ldp, m0, a.M, kt * BK, a.K);
+      tile_load<BN>(rb, Q, a.ldq, n0, a.N, kt * BK, a.K);
     } else {
       const int k0 = (kt - nk_main) * BK;
-      tile_load(ra, a.P2, a.ldp2, m0, a.M, k0, a.R);
-      tile_load(rb, a.Q2, a.ldq2, n0, a.N, k0, a.R);
+      tile_load<BM>(ra, a.P2, a.ldp2, m0, a.M, k0, a.R);
+      tile_load<BN>(rb, a.Q2, a.ldq2, n0, a.N, k0, a.R);
     }
   };
-  uint4 ra[4], rb[4];
-  fetch(0, ra, rb);
-  tile_store(lds, ra);
-  tile_store(lds + BM * LD, rb);
-  __syncthreads();
+  fetch(0);
   for (int kt = 0; kt < nk; ++kt) {
-    const unsigned short *Acur = lds + (kt & 1) * STAGE, *Bcur = Acur + BM * LD;
-    unsigned short *Anxt = lds + ((kt + 1) & 1) * STAGE;
-    if (kt + 1 < nk) fetch(kt + 1, ra, rb);
+    tile_store<BM>(As, ra);
+    tile_store<BN>(Bs, rb);
+    __syncthreads();
+    if (kt + 1 < nk) fetch(kt + 1);
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 fa[4], fb[4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-        fa[x] = *reinterpret_cast<const bf16x8 *>(Acur + (wm * 64 + x * 16 + i) * LD + ks * 32 + g * 8);
+      bf16x8 fa[MT], fb[4];
 #pragma unroll
       for (int y = 0; y < 4; ++y)
-        fb[y] = *reinterpret_cast<const bf16x8 *>(Bcur + (wn * 64 + y * 16 + i) * LD + ks * 32 + g * 8);
+        fb[y] = *reinterpret_cast<const bf16x8 *>(Bs + (wn * 64 + y * 16 + i) * LD + ks * 32 + g * 8);
 #pragma unroll
-      for (int x = 0; x < 4; ++x)
+      for (int x = 0; x < MT; ++x)
+        fa[x] = *reinterpret_cast<const bf16x8 *>(As + (wm * (BM / 2) + x * 16 + i) * LD + ks * 32 + g * 8);
+#pragma unroll
+      for (int x = 0; x < MT; ++x)
 #pragma unroll
         for (int y = 0; y < 4; ++y)
-          acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[x], fb[y], acc[x][y], 0, 0, 0);
-    }
-    if (kt + 1 < nk) {
-      tile_store(Anxt, ra);
-      tile_store(Anxt + BM * LD, rb);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[y], fa[x], acc[x][y], 0, 0, 0);
     }
     __syncthreads();
   }
-  // epilogue: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
+  // epilogue: D = Q P^T -- lane (i, g) holds columns n = 4 g + r of row m = i
 #pragma unroll
-  for (int y = 0; y < 4; ++y) {
-    const int col = n0 + wn * 64 + y * 16 + i;
-    if (col >= a.N) continue;
+  for (int x = 0; x < MT; ++x) {
+    const int row = m0 + wm * (BM / 2) + x * 16 + i;
+    if (row >= a.M) continue;
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 64 + x * 16 + g * 4 + r;
-        if (row >= a.M) continue;
-        const float v = acc[x][y][r] * a.scale;
-        if (a.c_f32) reinterpret_cast<float *>(a.C)[(size_t)row * a.ldc + col] = v;
-        else reinterpret_cast<unsigned short *>(a.C)[(size_t)row * a.ldc + col] = f2bf(v);
+    for (int y = 0; y < 4; ++y) {
+      const int col = n0 + wn * 64 + y * 16 + 4 * g;
+      if (col >= a.N) continue;
+      const float v0 = acc[x][y][0] * a.scale, v1 = acc[x][y][1] * a.scale, v2 = acc[x][y][2] * a.scale,
+                  v3 = acc[x][y][3] * a.scale;
+      const size_t o = (size_t)(bo * a.sco + bi * a.sci) + (size_t)row * a.ldc + col;
+      if (col + 3 < a.N) {
+        if (a.c_f32) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(a.C) + o) = make_float4(v0, v1, v2, v3);
+        else *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(a.C) + o) =
+            make_uint2(f2bf(v0) | ((unsigned)f2bf(v1) << 16), f2bf(v2) | ((unsigned)f2bf(v3) << 16));
+      } else {
+        const float vv[4] = {v0, v1, v2, v3};
+        for (int r = 0; r < 4 && col + r < a.N; ++r) {
+          if (a.c_f32) reinterpret_cast<float *>(a.C)[o + r] = vv[r];
+          else reinterpret_cast<unsigned short *>(a.C)[o + r] = f2bf(vv[r]);
+        }
       }
+    }
   }
 }
 
@@ -175,6 +193,23 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(int M, int C, const unsi
 
 inline bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
 
+template <int BM>
+int launch_gemm(const GemmArgs &a, int batch, hipStream_t st) {
+  constexpr size_t lds = sizeof(unsigned short) * (BM + BN) * LD;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&bf16_gemm_kernel<BM>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr != hipSuccess) return (int)attr;
+  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, batch);
+  bf16_gemm_kernel<BM><<<grid, 256, lds, st>>>(a);
+  return (int)hipGetLastError();
+}
+
+int gemm_dispatch(GemmArgs &a, int batch, hipStream_t st) {
+  // tile height: the one that wastes fewer padded rows; 192 on a tie at >= 192 rows (fewer LDS reads per MFMA)
+  const long long w128 = (long long)((a.M + 127) / 128) * 128, w192 = (long long)((a.M + 191) / 192) * 192;
+  return (a.M >= 192 && w192 <= w128) ? launch_gemm<192>(a, batch, st) : launch_gemm<128>(a, batch, st);
+}
+
 }  // namespace
 
 extern "C" {
@@ -186,6 +221,7 @@ int msr3d_bf16_gemm_lowrank(int M, int N, int K, int R, const void *P, int ldp, 
   if (M == 0 || N == 0) return 0;
   if (!P || !Q || !C || ldp < K || ldq < K || ldc < N || (ldp % 8) || (ldq % 8) || !al16(P) || !al16(Q))
     return MSR3D_EINVAL;
+  if ((ldc % 4) || (reinterpret_cast<uintptr_t>(C) & 15u)) return MSR3D_EINVAL;
   if (R > 0 && (!P2 || !Q2 || ldp2 < R || ldq2 < R || (ldp2 % 8) || (ldq2 % 8) || !al16(P2) || !al16(Q2)))
     return MSR3D_EINVAL;
   GemmArgs a;
@@ -193,17 +229,31 @@ int msr3d_bf16_gemm_lowrank(int M, int N, int K, int R, const void *P, int ldp, 
   a.P = (const unsigned short *)P; a.ldp = ldp; a.Q = (const unsigned short *)Q; a.ldq = ldq;
   a.P2 = (const unsigned short *)P2; a.ldp2 = ldp2; a.Q2 = (const unsigned short *)Q2; a.ldq2 = ldq2;
   a.C = C; a.ldc = ldc; a.c_f32 = c_f32; a.scale = scale;
-  constexpr size_t lds = sizeof(unsigned short) * 4 * BM * LD;         // 73.7 KB: two stages of A and B
-  static bool done = false;
-  if (!done) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bf16_gemm_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    done = true;
-  }
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
-  bf16_gemm_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(a);
-  return (int)hipGetLastError();
+  a.inner = 1;
+  a.spo = a.spi = a.sqo = a.sqi = a.sco = a.sci = 0;
+  return gemm_dispatch(a, 1, (hipStream_t)stream);
+}
+
+int msr3d_bf16_gemm_batched(int outer, int inner, int M, int N, int K, const void *P, int ldp, long long p_outer,
+                            long long p_inner, const void *Q, int ldq, long long q_outer, long long q_inner, void *C,
+                            int ldc, long long c_outer, long long c_inner, int c_f32, float scale,
+                            msr3d_stream_t stream) {
+  if (outer < 0 || inner <= 0 || M < 0 || N < 0 || K < 0 || (K % BK) != 0) return MSR3D_EINVAL;
+  if (outer == 0 || M == 0 || N == 0) return 0;
+  if ((long long)outer * inner > 65535 || !P || !Q || !C || ldp < K || ldq < K || ldc < N || (ldp % 8) || (ldq % 8) ||
+      !al16(P) || !al16(Q))
+    return MSR3D_EINVAL;
+  if ((p_outer % 8) || (p_inner % 8) || (q_outer % 8) || (q_inner % 8) || (c_outer % 4) || (c_inner % 4) || (ldc % 4) ||
+      (reinterpret_cast<uintptr_t>(C) & 15u))
+    return MSR3D_EINVAL;
+  GemmArgs a;
+  a.M = M; a.N = N; a.K = K; a.R = 0;
+  a.P = (const unsigned short *)P; a.ldp = ldp; a.Q = (const unsigned short *)Q; a.ldq = ldq;
+  a.P2 = nullptr; a.ldp2 = 0; a.Q2 = nullptr; a.ldq2 = 0;
+  a.C = C; a.ldc = ldc; a.c_f32 = c_f32; a.scale = scale;
+  a.inner = inner;
+  a.spo = p_outer; a.spi = p_inner; a.sqo = q_outer; a.sqi = q_inner; a.sco = c_outer; a.sci = c_inner;
+  return gemm_dispatch(a, outer * inner, (hipStream_t)stream);
 }
 
 int msr3d_lora_grad(int M, int R, int C, const void *P, int ldp, const void *Q, int ldq, float *out,

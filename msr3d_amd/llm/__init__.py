@@ -1,4 +1,5 @@
-"""Language-model side of MSR3D's training step: the self-contained pieces
-built so far -- the fused per-sequence cross-entropy and the LoRA-augmented linear layer."""
+"""Language-model side of MSR3D's training step: the fused per-sequence
+cross-entropy, the LoRA-augmented linear layer, and one LoRA-Llama decoder layer assembled from them."""
+from .decoder import LoRALlamaDecoderLayer  # noqa: F401
 from .lora import LoRALinear  # noqa: F401
 from .losses import seq_mean_cross_entropy  # noqa: F401

@@ -39,11 +39,9 @@ class _LoRAFn(torch.autograd.Function):
         x2 = x.reshape(-1, K)
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
         M, dev = x2.shape[0], x.device
-        # bf16 shadows of the trainable pair in the orientations the products read (tiny)
-        a_pad = torch.zeros((PAD_ROWS, K), dtype=torch.bfloat16, device=dev)
-        a_pad[:r] = lora_A.detach()
-        b2 = torch.zeros((N, PAD_R), dtype=torch.bfloat16, device=dev)
-        b2[:, :r] = lora_B.detach()
+        # bf16 shadows of the trainable pair in the orientations the products read: built once per weight
+        # version (i.e. once per optimiser step), not per call
+        a_pad, b2, _, _ = mod._shadows()
         # u = s x A^T  (M, 128) bf16: the same kernel against the zero-padded A
         u = torch.empty((M, PAD_ROWS), dtype=torch.bfloat16, device=dev)
         _gemm(M, PAD_ROWS, K, 0, x2, K, a_pad, K, None, 0, None, 0, u, PAD_ROWS, False, s, dev)
@@ -63,10 +61,7 @@ class _LoRAFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, N).to(torch.bfloat16)
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
         M = dy2.shape[0]
-        bt_pad = torch.zeros((PAD_ROWS, N), dtype=torch.bfloat16, device=dev)
-        bt_pad[:r] = lora_B.detach().t()
-        at2 = torch.zeros((K, PAD_R), dtype=torch.bfloat16, device=dev)
-        at2[:, :r] = lora_A.detach().t()
+        _, _, bt_pad, at2 = mod._shadows()
         # v = s dy B  (M, 128) bf16
         v = torch.empty((M, PAD_ROWS), dtype=torch.bfloat16, device=dev)
         _gemm(M, PAD_ROWS, N, 0, dy2, N, bt_pad, N, None, 0, None, 0, v, PAD_ROWS, False, s, dev)
@@ -107,6 +102,26 @@ class LoRALinear(nn.Module):
         nn.init.kaiming_uniform_(self.lora_A.weight, a=math.sqrt(5))
         nn.init.zeros_(self.lora_B.weight)
         self._wt_version = None       # `weight._version` the transposed copy was made from
+
+    def _shadows(self):
+        """Zero-padded bf16 copies of A / B in the four orientations forward and backward read
+        (a_pad (128, K), b2 (N, 32), bt_pad (128, N), at2 (K, 32)); rebuilt when A or B has been written."""
+        A, Bw = self.lora_A.weight, self.lora_B.weight
+        key = (A._version, Bw._version, A.data_ptr(), Bw.data_ptr())
+        if getattr(self, "_shadow_key", None) != key:
+            r, K, N, dev = self.r, self.in_features, self.out_features, A.device
+            with torch.no_grad():
+                a_pad = torch.zeros((PAD_ROWS, K), dtype=torch.bfloat16, device=dev)
+                a_pad[:r] = A
+                b2 = torch.zeros((N, PAD_R), dtype=torch.bfloat16, device=dev)
+                b2[:, :r] = Bw
+                bt_pad = torch.zeros((PAD_ROWS, N), dtype=torch.bfloat16, device=dev)
+                bt_pad[:r] = Bw.t()
+                at2 = torch.zeros((K, PAD_R), dtype=torch.bfloat16, device=dev)
+                at2[:, :r] = A.t()
+            self._shadow = (a_pad, b2, bt_pad, at2)
+            self._shadow_key = key
+        return self._shadow
 
     def _sync_weight_t(self):
         """weight_t is a cache of weight^T (non-persistent): rebuilt whenever `weight` has been written --

@@ -40,3 +40,27 @@ def rel_l2(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def _bf16_round(a):
+    """fp32 numpy array rounded to bf16 (nearest even), returned as fp32."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32) << 16
+    return r.view(np.float32).reshape(a.shape)
+
+
+def llama_layer_weights(seed, hidden, inter, r):
+    """Deterministic bf16-representable weights of one LoRA-Llama decoder layer (numpy generator: stable across
+    torch versions), shared by tests/golden/make_golden_llama_layer.py and tests/test_llama_layer_gpu.py."""
+    rng = np.random.default_rng(seed)
+    shapes = {"q_proj": (hidden, hidden), "k_proj": (hidden, hidden), "v_proj": (hidden, hidden),
+              "o_proj": (hidden, hidden), "gate_proj": (inter, hidden), "up_proj": (inter, hidden),
+              "down_proj": (hidden, inter)}
+    w = {}
+    for n, (o, i) in shapes.items():
+        w[n] = _bf16_round(rng.standard_normal((o, i)).astype(np.float32) / np.sqrt(i))
+        w[n + ".A"] = _bf16_round(rng.standard_normal((r, i)).astype(np.float32) / np.sqrt(i))
+        w[n + ".B"] = _bf16_round(rng.standard_normal((o, r)).astype(np.float32) * 0.05)
+    w["ln1"] = _bf16_round(1.0 + 0.1 * rng.standard_normal(hidden).astype(np.float32))
+    w["ln2"] = _bf16_round(1.0 + 0.1 * rng.standard_normal(hidden).astype(np.float32))
+    return w

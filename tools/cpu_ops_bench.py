@@ -14,10 +14,13 @@ thread.  GPU (when present): the shipped kernels on the same tensors, HIP events
 AND per 16 scenes (the bench's launch shape; the kernels are sized for that).  The oracle is used here as
 the timed CPU baseline only (cpu_baseline leg), never by the product."""
 import os
+import sys
 import time
 
 import numpy as np
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def _median(f, reps, warm=2):
