@@ -97,6 +97,9 @@ def parse():
                     "captured step); use a smaller --batch (4 scenes: 3.9 GiB of saved activations)")
     ap.add_argument("--no-window", action="store_true", help="with --accum: encode every micro-batch on its own "
                     "instead of the whole accumulation window in one encoder pass")
+    ap.add_argument("--llm-layer", action="store_true", help="SECONDARY, labelled line: one LoRA-Llama decoder layer "
+                    "(Vicuna-7B shape: hidden 4096, 32 heads, MLP 11008, LoRA r 16 on the seven projections), forward + "
+                    "backward at 4 sequences x 576 tokens, bf16 -- SURVEY.md §8(f) rank 4; not the headline metric")
     ap.add_argument("--cpu-ops", action="store_true", help="per-op CPU micro-benchmarks at the GPU kernels' shapes "
                     "(BASELINE.md §3.4) beside the GPU kernels' times -> profiles/r03_cpu_ops.json; no training step")
     ap.add_argument("--no-graph", action="store_true", help="issue the trainable part eagerly "
@@ -224,10 +227,63 @@ def cpu_baseline(args, seconds):
         pointnet2_utils._ext = saved
 
 
+def llm_layer_line(args):
+    """One decoder layer of the language model the scene tokens are fed to (msr3d_amd/llm/decoder.py)."""
+    from msr3d_amd.llm import LoRALlamaDecoderLayer
+    assert torch.cuda.is_available(), "bench.py --llm-layer needs a GPU"
+    dev = torch.device("cuda", 0)
+    Bq, T, Hd, NH, FF = 4, 576, 4096, 32, 11008        # configs/msr3d.yaml:164 batch 4; 576 = scene tokens + prompt + answer
+    torch.manual_seed(0)
+    layer = LoRALlamaDecoderLayer(Hd, NH, FF, r=16, lora_alpha=16, device=dev)
+    with torch.no_grad():
+        for grp in (layer.self_attn, layer.mlp):
+            for m in grp.values():
+                m.load_base_weight(torch.randn(m.out_features, m.in_features, device=dev) / m.in_features ** 0.5)
+                m.lora_B.weight.normal_(std=0.02)
+    x = torch.randn(Bq, T, Hd, device=dev).bfloat16().requires_grad_(True)
+    keep = torch.ones(Bq, T, dtype=torch.uint8, device=dev)
+    keep[1, :40] = 0
+    gy = (torch.randn(Bq, T, Hd, device=dev) * 0.01).bfloat16()
+
+    def step():
+        for p in layer.parameters():
+            p.grad = None
+        x.grad = None
+        layer(x, attention_mask=keep).backward(gy)
+    for _ in range(max(args.warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms = e0.elapsed_time(e1) / args.steps
+    M = Bq * T
+    lin = 2.0 * M * (4 * Hd * Hd + 3 * Hd * FF)                       # the seven projections, forward
+    att = 2.0 * 2.0 * Bq * NH * T * T * (Hd // NH)                    # Q K^T and P V, forward
+    flop = 2.0 * lin + 3.0 * att                                      # backward: dx only (frozen weights) + 4 attention products
+    print(json.dumps({
+        "metric": "SECONDARY: LoRA-Llama decoder layer fwd+bwd (Vicuna-7B shape), tokens/s per layer",
+        "value": M / (ms * 1e-3), "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 2),
+        "ms_per_step": ms, "wall_ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "dtype": "bf16",
+        "data": "synthetic (random bf16 weights; no checkpoint on the box)",
+        "config": {"workload": "one decoder layer: hidden 4096, 32 heads, MLP 11008, LoRA r=16 alpha=16 on q/k/v/o/gate/up/down, "
+                               "4 sequences x 576 tokens, left-padded mask, eager (host-issued) launches"},
+        "tflops": flop / (ms * 1e-3) / 1e12, "frac_of_bf16_peak": flop / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
+        "note": "not the headline metric; the frozen LLM is out of §8(a)-(e) scope (SURVEY §0.5) -- this line prices "
+                "the §8(f) rank-4 building block"}))
+
+
 def main():
     global O, P
     args = parse()
     O, P = args.objects, args.points
+    if args.llm_layer:
+        return llm_layer_line(args)
     if args.cpu_ops:
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
         import cpu_ops_bench          # (times the oracle as the CPU baseline: lives outside the product package)

@@ -18,7 +18,9 @@
 // column-per-thread VALU kernel: it is bound by reading x / dy once.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
+#include <cstdlib>
 
 #include "../../include/msr3d_hip.h"
 
@@ -155,6 +157,114 @@ __global__ __launch_bounds__(256, 2) void bf16_gemm_kernel(const GemmArgs a) {
   }
 }
 
+// The same product with the operands staged by LDS-DMA (global_load_lds, 16 bytes per lane) into THREE LDS
+// stages, two K steps in flight: the register-staged kernel above has one K step (768 cycles of MFMA) to
+// cover a ~2k-cycle load, and its prefetch registers (40 per stage) leave no room for a second one.  The DMA
+// writes wave-uniform base + lane x 16, so the LDS image is unpadded ([rows][64] bf16 = 8 chunks of 16 B per
+// row) and the bank-conflict fix is on the SOURCE side: chunk c of row r is stored at position c ^ (r & 7), and
+// the fragment read of lane (i, g) takes position (4 ks + g) ^ (i & 7) -- every ds_read_b128 lane group then
+// covers sixteen distinct 16-byte slots of the 256-byte bank row.  One raw s_barrier per K step; the loads are
+// retired by a counted vmcnt (this stage's 10 done, the next stage's 10 still flying), never by a full drain.
+template <int BM>
+__global__ __launch_bounds__(256, 1) void bf16_gemm_glds_kernel(const GemmArgs a) {
+  constexpr int MT = BM / 32;
+  constexpr int STAGE = (BM + BN) * BK;          // bf16 elements per stage
+  constexpr int NA = BM * 8 / 256, NB = BN * 8 / 256;     // 16-byte chunks per thread and stage: 6 + 4
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int bo = blockIdx.z / a.inner, bi = blockIdx.z - bo * a.inner;
+  const unsigned short *P = a.P + bo * a.spo + bi * a.spi, *Q = a.Q + bo * a.sqo + bi * a.sqi;
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int x = 0; x < MT; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk_main = a.K / BK, nk = nk_main + (a.R + BK - 1) / BK;
+  // per-thread source rows / chunks of the stage image (fixed over the K walk)
+  const unsigned short *srcA[NA], *srcA2[NA], *srcB[NB], *srcB2[NB];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int q = tid + 256 * j, row = q >> 3, c = (q & 7) ^ (row & 7);
+    const size_t r = (size_t)min(m0 + row, a.M - 1);
+    srcA[j] = P + r * a.ldp + c * 8;
+    srcA2[j] = a.R ? a.P2 + r * a.ldp2 + c * 8 : nullptr;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int q = tid + 256 * j, row = q >> 3, c = (q & 7) ^ (row & 7);
+    const size_t r = (size_t)min(n0 + row, a.N - 1);
+    srcB[j] = Q + r * a.ldq + c * 8;
+    srcB2[j] = a.R ? a.Q2 + r * a.ldq2 + c * 8 : nullptr;
+  }
+  auto issue = [&](int kt) {                     // stage kt -> LDS buffer kt % 3
+    unsigned short *buf = lds + (kt % 3) * STAGE;
+    const bool main = kt < nk_main;
+    const int k0 = main ? kt * BK : (kt - nk_main) * BK;
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((main ? srcA[j] : srcA2[j]) + k0),
+                                       (__attribute__((address_space(3))) void *)(buf + (256 * j + 64 * wave) * 8), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((main ? srcB[j] : srcB2[j]) + k0),
+                                       (__attribute__((address_space(3))) void *)(buf + BM * BK + (256 * j + 64 * wave) * 8), 16, 0, 0);
+  };
+  issue(0);
+  if (nk > 1) issue(1);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // stage kt landed; kt + 1 may still fly
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();               // ... for every wave; and every wave is done reading stage kt - 1
+    if (kt + 2 < nk) issue(kt + 2);             // (into the buffer stage kt - 1 occupied)
+    const unsigned short *As = lds + (kt % 3) * STAGE, *Bs = As + BM * BK;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      const int pos = ((4 * ks + g) ^ (i & 7)) * 8;
+      bf16x8 fa[MT], fb[4];
+#pragma unroll
+      for (int y = 0; y < 4; ++y) fb[y] = *reinterpret_cast<const bf16x8 *>(Bs + (wn * 64 + y * 16 + i) * BK + pos);
+#pragma unroll
+      for (int x = 0; x < MT; ++x) fa[x] = *reinterpret_cast<const bf16x8 *>(As + (wm * (BM / 2) + x * 16 + i) * BK + pos);
+#pragma unroll
+      for (int x = 0; x < MT; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+          acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[y], fa[x], acc[x][y], 0, 0, 0);
+    }
+  }
+  // epilogue: D = Q P^T -- lane (i, g) holds columns n = 4 g + r of row m = i
+#pragma unroll
+  for (int x = 0; x < MT; ++x) {
+    const int row = m0 + wm * (BM / 2) + x * 16 + i;
+    if (row >= a.M) continue;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      const int col = n0 + wn * 64 + y * 16 + 4 * g;
+      if (col >= a.N) continue;
+      const float v0 = acc[x][y][0] * a.scale, v1 = acc[x][y][1] * a.scale, v2 = acc[x][y][2] * a.scale,
+                  v3 = acc[x][y][3] * a.scale;
+      const size_t o = (size_t)(bo * a.sco + bi * a.sci) + (size_t)row * a.ldc + col;
+      if (col + 3 < a.N) {
+        if (a.c_f32) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(a.C) + o) = make_float4(v0, v1, v2, v3);
+        else *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(a.C) + o) =
+            make_uint2(f2bf(v0) | ((unsigned)f2bf(v1) << 16), f2bf(v2) | ((unsigned)f2bf(v3) << 16));
+      } else {
+        const float vv[4] = {v0, v1, v2, v3};
+        for (int r = 0; r < 4 && col + r < a.N; ++r) {
+          if (a.c_f32) reinterpret_cast<float *>(a.C)[o + r] = vv[r];
+          else reinterpret_cast<unsigned short *>(a.C)[o + r] = f2bf(vv[r]);
+        }
+      }
+    }
+  }
+}
+
 // out (R, C) (or its transpose) += sum_m P[m][r] * Q[m][c]: thread = column c, R accumulators;
 // rows split over blockIdx.y, meeting by atomicAdd.  P (M, R) bf16 is broadcast from LDS.
 template <int R>
@@ -204,7 +314,29 @@ int launch_gemm(const GemmArgs &a, int batch, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+template <int BM>
+int launch_gemm_glds(const GemmArgs &a, int batch, hipStream_t st) {
+  constexpr size_t lds = sizeof(unsigned short) * 3 * (BM + BN) * BK;         // 192: 122,880 B
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&bf16_gemm_glds_kernel<BM>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr != hipSuccess) return (int)attr;
+  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, batch);
+  bf16_gemm_glds_kernel<BM><<<grid, 256, lds, st>>>(a);
+  return (int)hipGetLastError();
+}
+
+std::atomic<int> g_gemm_path{-1};                // -1: read MSR3D_BF16_GEMM (glds | reg) on first use
+
 int gemm_dispatch(GemmArgs &a, int batch, hipStream_t st) {
+  int path = g_gemm_path.load(std::memory_order_relaxed);
+  if (path < 0) {
+    const char *e = getenv("MSR3D_BF16_GEMM");
+    path = (e && e[0] == 'r') ? 0 : 1;
+    g_gemm_path.store(path, std::memory_order_relaxed);
+  }
+  // LDS-DMA path: rows >= 16 bytes-aligned sources (checked by the callers) and R a multiple of 64 (a stage
+  // reads 64 columns of the low-rank pair)
+  if (path == 1 && a.M >= 192 && (a.R % BK) == 0) return launch_gemm_glds<192>(a, batch, st);
   // tile height: the one that wastes fewer padded rows; 192 on a tie at >= 192 rows (fewer LDS reads per MFMA)
   const long long w128 = (long long)((a.M + 127) / 128) * 128, w192 = (long long)((a.M + 191) / 192) * 192;
   return (a.M >= 192 && w192 <= w128) ? launch_gemm<192>(a, batch, st) : launch_gemm<128>(a, batch, st);

@@ -105,13 +105,15 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(int T_len, int V, const T *
   float m = -INFINITY, s = 0.f;
   const int nvec = V / VEC;
   for (int e0 = tid; e0 < nvec; e0 += 256 * 4) {     // 4 x 16-byte loads in flight per thread
+    // unconditional loads from a clamped index, masked afterwards: a load inside `if (e < nvec)` is its own basic
+    // block and the compiler waits vmcnt(0) behind each one -- the four loads then run one after the other
+    // (round 2: 1.6 TB/s with four round trips per row per pass)
     float v[4][VEC];
 #pragma unroll
+    for (int u = 0; u < 4; ++u) Ld<T>::load(x + (size_t)min(e0 + u * 256, nvec - 1) * VEC, v[u]);
+#pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u * 256;
-      if (e < nvec) {
-        Ld<T>::load(x + (size_t)e * VEC, v[u]);
-      } else {
+      if (e0 + u * 256 >= nvec) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) v[u][j] = -INFINITY;
       }
@@ -197,15 +199,24 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(int T_len, int V, const T *
   const T *x = logits + ((size_t)b * T_len + t) * V;
   const float l = lse[(size_t)b * (T_len - 1) + t];
   const float scale = g[b] / (float)count[b];
-  for (int e = tid; e < nvec; e += 256) {
-    float v[VEC];
-    Ld<T>::load(x + (size_t)e * VEC, v);
+  for (int e0 = tid; e0 < nvec; e0 += 256 * 4) {     // 4 x 16-byte loads in flight per thread, then 4 stores
+    float v[4][VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      const float p = __expf(v[j] - l);
-      v[j] = (p - ((long long)e * VEC + j == label ? 1.f : 0.f)) * scale;
+    for (int u = 0; u < 4; ++u) Ld<T>::load(x + (size_t)min(e0 + u * 256, nvec - 1) * VEC, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * 256;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float p = __expf(v[u][j] - l);
+        v[u][j] = (p - ((long long)e * VEC + j == label ? 1.f : 0.f)) * scale;
+      }
     }
-    Ld<T>::store(dx + (size_t)e * VEC, v);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * 256;
+      if (e < nvec) Ld<T>::store(dx + (size_t)e * VEC, v[u]);
+    }
   }
   for (int e = nvec * VEC + tid; e < V; e += 256)
     Ld<T>::store1(dx + e, (__expf(Ld<T>::one(x + e) - l) - (e == label ? 1.f : 0.f)) * scale);

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from .. import _lib
 
-PAD_R = 32          # the low-rank pair rides as one 32-wide K step
+PAD_R = 64          # the low-rank pair rides as one extra 64-wide K step (zero-padded)
 PAD_ROWS = 128      # A / B^T padded to one output tile when they are the GEMM's Q operand
 
 
