@@ -501,9 +501,10 @@ def main():
             # Each fp32 operand is three bf16 terms and each product six bf16 MFMA products
             # (sa_split.hip), so the bf16 pipe delivers at most 2500 / 6 = 416.7 TFLOP/s of fp32-
             # accurate work: that is the roof the ALGORITHMIC rate is priced against.  Executed
-            # matrix-pipe work (six products, K padded 131 -> 160) is reported beside it.
+            # matrix-pipe work (six products; layer 1's K is the 128 feature channels, the 3 coordinate columns
+            # are fp32 FMAs on the accumulators) is reported beside it.
             peak = MFMA_BF16_PEAK_TF / SPLIT_PRODUCTS
-            executed = objs_per_launch * 512 * (160 * 128 + 128 * 128 + 128 * 256) * 2 * SPLIT_PRODUCTS
+            executed = objs_per_launch * 512 * (128 * 128 + 128 * 128 + 128 * 256) * 2 * SPLIT_PRODUCTS
             roof = {"bound": "mfma", "kernel": "sa2_split_kernel (msr3d_sa_level_split level 2)",
                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                     "peak_note": "bf16 dense MFMA peak 2500 TFLOP/s / 6 products per fp32-accurate product",

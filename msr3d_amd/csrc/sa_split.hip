@@ -207,6 +207,86 @@ __device__ __forceinline__ void store_split(const f32x4 (&acc)[RN][MT], const fl
   }
 }
 
+// ---- level 2 (round 3): operand planes in two layouts ------------------------------------------------------
+// ROWS  [3][rows][pitch] row-major: what the gather writes (16 lanes per row, 8 contiguous bytes each: one
+//       bank row per store group); pitch = K + 16 bf16 keeps the 16-byte fragment reads conflict-free.
+// FRAG  [slab][4 row tiles][3 planes][64 lanes][16 B] MFMA-fragment order: what an epilogue writes.  A lane
+//       of D = W X^T holds four consecutive channels of ONE row, so its 8-byte store goes to slot
+//       (row, channel / 8); the 16 lanes of a store group are 16 rows = 16 consecutive 16-byte slots: two
+//       lanes per bank row instead of the four the row-major image gave (38 % of this kernel's LDS cycles
+//       were those conflicts, profiles/r02_v6_pmc_sa.txt), and every fragment READ is a contiguous 1 KB.
+struct XRowsS {
+  const unsigned short *base;      // + j * pitch + 8 g
+  int pitch, plane;
+  __device__ __forceinline__ bf16x8 operator()(int mt, int s, int p) const {
+    return *reinterpret_cast<const bf16x8 *>(base + p * plane + mt * 16 * pitch + 32 * s);
+  }
+};
+struct XFragS {
+  const unsigned short *base;      // + lane * 8
+  __device__ __forceinline__ bf16x8 operator()(int mt, int s, int p) const {
+    return *reinterpret_cast<const bf16x8 *>(base + ((s * 4 + mt) * 3 + p) * 512);
+  }
+};
+
+template <int RN, int MT, int KS, int NT, int D, typename XF>
+__device__ __forceinline__ void gemm_split_x(const XF &xf, const WStream &wg, f32x4 (&acc)[RN][MT], int lane,
+                                             const WPiece (&ring)[D]) {
+  constexpr int NP = KS * RN;
+  static_assert(D <= NP, "ring deeper than the layer");
+  WPiece w[NP];
+#pragma unroll
+  for (int q = 0; q < D; ++q) w[q] = ring[q];
+  bf16x8 x[MT][3];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const int s = q / RN, rn = q % RN;
+    __builtin_amdgcn_sched_barrier(0);
+    if (q + D < NP) load_piece<NT>(w[q + D], wg, (q + D) / RN, (q + D) % RN, lane);
+    if (rn == 0) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) x[mt][p] = xf(mt, s, p);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#define MSR3D_TERM(PW, PX)                                                                             \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                  \
+        acc[rn][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[q].v[PW], x[mt][PX], acc[rn][mt], 0, 0, 0);
+    MSR3D_TERM(2, 0)
+    MSR3D_TERM(0, 2)
+    MSR3D_TERM(1, 1)
+    MSR3D_TERM(1, 0)
+    MSR3D_TERM(0, 1)
+    MSR3D_TERM(0, 0)
+#undef MSR3D_TERM
+  }
+}
+
+// y = relu(acc * scale[n] + shift[n]), split -> FRAG planes (4 row tiles) at channels n0 + 16 rn + 4 g ..
+template <int RN, int MT>
+__device__ __forceinline__ void store_split_frag(const f32x4 (&acc)[RN][MT], const float4 (&sc)[RN], const float4 (&sh)[RN],
+                                                 unsigned char *ys, int n0, int lane) {
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int rn = 0; rn < RN; ++rn) {
+    const float s4[4] = {sc[rn].x, sc[rn].y, sc[rn].z, sc[rn].w};
+    const float h4[4] = {sh[rn].x, sh[rn].y, sh[rn].z, sh[rn].w};
+    const int c = n0 + rn * 16 + 4 * g, slab = c >> 5, kk = c & 31;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fmaxf(__builtin_fmaf(acc[rn][mt][r], s4[r], h4[r]), 0.0f);
+      uint2 p[3];
+      split4(v, p);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        *reinterpret_cast<uint2 *>(ys + ((((slab * 4 + mt) * 3 + k) * 64 + j + 16 * (kk >> 3)) * 16 + (kk & 7) * 2)) = p[k];
+    }
+  }
+}
+
 // max over each lane's 16-lane row (rotations by 8, 4, 2, 1), four values at a time so that every DPP
 // read sits three instructions behind the write it depends on (a DPP read needs two wait states after a
 // VALU write of the same register and inline asm gets no hazard padding); v_max_f32 with a DPP source is
@@ -319,11 +399,15 @@ __device__ __forceinline__ void wave_ball_query(const float *sx, int n, float cx
 // a quarter of the channels -- each weight fragment is fetched once per tile.
 // =====================================================================================================
 constexpr int kTM = 2 * kNS;                 // rows per tile
-constexpr int kK0 = 160, kN1 = 128, kN2 = 128, kN3 = 256;
-constexpr int kLd = kK0 + kPadH;             // one row pitch for every layer's operand (176: conflict-free b128 reads)
+// Layer 1's K is the 128 feature channels: the three recentred coordinates enter as fp32 FMAs on the
+// accumulators (a fifth, 29/32-empty slab of MFMAs in round 2: 9 % of the layer's matrix work).
+constexpr int kK0 = 128, kN1 = 128, kN2 = 128, kN3 = 256;
+constexpr int kLd = kK0 + kPadH;             // ROWS pitch of layer 1's operand (144: conflict-free b128 reads)
 constexpr int kPlane = kTM * kLd;            // plane stride, bf16 units
+constexpr int kFragBytes = 4 * 4 * 3 * 1024; // FRAG image of a 64 x 128 operand (layers 2, 3): 49,152 B
+static_assert(3 * kPlane * 2 >= kFragBytes, "the two images share one buffer");
 constexpr int kRing = 4;                     // weight pieces in flight per wave (12 KB)
-constexpr int kSa2Lds = 3 * kPlane * 2 + (2 * (kN1 + kN2 + kN3) + 64 * 3 + 16) * 4 + 2 * kNS * 4 + 16;
+constexpr int kSa2Lds = 3 * kPlane * 2 + (2 * (kN1 + kN2 + kN3) + 64 * 3 + 16 + kTM * 4) * 4 + 2 * kNS * 4 + 16;
 constexpr int kChunk = 3;                   // tiles per queue fetch (15 per block at the bench shape: five fetches)
 
 __global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int tiles, int *__restrict__ queue, float radius2,
@@ -338,6 +422,8 @@ __global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int til
   float *ctr = sx + 64 * 3;                                                // [2][4]
   int *nbr = reinterpret_cast<int *>(ctr + 16);                            // [2][32]
   int *s_next = nbr + 2 * kNS;                                             // [2]: tile hand-over from thread 0
+  float *dxs = reinterpret_cast<float *>(s_next + 4);                      // [64][4]: the rows' recentred coordinates
+  unsigned char *fbuf = reinterpret_cast<unsigned char *>(buf);            // the FRAG image of layers 2 / 3 (same buffer)
   int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tpo = (m + 1) >> 1;                                            // tiles per object
   const int t_end = tiles;                                                 // (also the "no tile" value)
@@ -392,6 +478,7 @@ __global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int til
   constexpr int RN1 = kN1 / 64, RN2 = kN2 / 64, RN3 = kN3 / 64, MT = kTM / 16, GT = kNS / 16;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);                 // uniform to the compiler as well
   const WStream w1 = make_stream<RN1>(l1.w, kK0 * kN1 * 6, wave_u, lane);
+  const float *__restrict__ wxyz = l1.shift + kN1;                         // [128][4] fp32: layer 1's weights on (dx, dy, dz)
   const WStream w2 = make_stream<RN2>(l2.w, kN1 * kN2 * 6, wave_u, lane);
   const WStream w3 = make_stream<RN3>(l3.w, kN2 * kN3 * 6, wave_u, lane);
 
@@ -444,16 +531,8 @@ __global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int til
     }
     if (tid < kTM) {
       const int row = tid, pi = nbr[row], w = row >> 5;
-      const float v[4] = {sx[pi * 3 + 0] - ctr[w * 4 + 0], sx[pi * 3 + 1] - ctr[w * 4 + 1], sx[pi * 3 + 2] - ctr[w * 4 + 2], 0.f};
-      uint2 p[3];
-      split4(v, p);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        unsigned short *d = buf + k * kPlane + row * kLd + 128;
-        *reinterpret_cast<uint2 *>(d) = p[k];
-#pragma unroll
-        for (int c = 4; c < 32; c += 4) *reinterpret_cast<uint2 *>(d + c) = make_uint2(0u, 0u);
-      }
+      *reinterpret_cast<float4 *>(dxs + row * 4) =
+          make_float4(sx[pi * 3 + 0] - ctr[w * 4 + 0], sx[pi * 3 + 1] - ctr[w * 4 + 1], sx[pi * 3 + 2] - ctr[w * 4 + 2], 0.f);
     }
   };
 
@@ -484,15 +563,30 @@ __global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int til
     {
       f32x4 acc[RN1][MT];
       zero_acc(acc);
-      gemm_split<RN1, MT, kK0 / 32, kN1 / 16, kRing>(buf, kLd, kPlane, w1, acc, lane, ring1);
+      const XRowsS x1{buf + (lane & 15) * kLd + 8 * (lane >> 4), kLd, kPlane};
+      gemm_split_x<RN1, MT, kK0 / 32, kN1 / 16, kRing>(x1, w1, acc, lane, ring1);
       preload_ring<RN2, kN2 / 16, kRing>(ring2, w2, lane);        // the next layer's operands fly under the epilogue
       float4 sc[RN1], sh[RN1];
       load_affine4<RN1>(sc1, sh1, wave * RN1 * 16, lane, sc, sh);
+      {   // + W_xyz (dx, dy, dz): lane (j, g) holds row 16 mt + j, channels n0 + 16 rn + 4 g + r
+        float4 d[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) d[mt] = *reinterpret_cast<const float4 *>(dxs + (16 * mt + (lane & 15)) * 4);
+#pragma unroll
+        for (int rn = 0; rn < RN1; ++rn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float4 wv = *reinterpret_cast<const float4 *>(wxyz + (wave * RN1 * 16 + rn * 16 + 4 * (lane >> 4) + r) * 4);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+              acc[rn][mt][r] = __builtin_fmaf(wv.z, d[mt].z, __builtin_fmaf(wv.y, d[mt].y, __builtin_fmaf(wv.x, d[mt].x, acc[rn][mt][r])));
+          }
+      }
       STAMP(1);
       __syncthreads();                                            // (A) every wave is done READING the operand; sx/ctr free
       if (tid == 0) s_next[0] = more ? advance(Tn) : t_end;       // the tile after the next one
       if (more) geo_store();
-      store_split<RN1, MT>(acc, sc, sh, buf, kLd, kPlane, wave * RN1 * 16, lane);
+      store_split_frag<RN1, MT>(acc, sc, sh, fbuf, wave * RN1 * 16, lane);
     }
     __syncthreads();                                              // (B) layer-1 planes + next geometry visible
     const int Tnn = s_next[0];
@@ -501,13 +595,14 @@ __global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int til
     {
       f32x4 acc[RN2][MT];
       zero_acc(acc);
-      gemm_split<RN2, MT, kN1 / 32, kN2 / 16, kRing>(buf, kLd, kPlane, w2, acc, lane, ring2);
+      const XFragS x2{buf + lane * 8};
+      gemm_split_x<RN2, MT, kN1 / 32, kN2 / 16, kRing>(x2, w2, acc, lane, ring2);
       preload_ring<RN3, kN3 / 16, kRing>(ring3, w3, lane);
       float4 sc[RN2], sh[RN2];
       load_affine4<RN2>(sc2, sh2, wave * RN2 * 16, lane, sc, sh);
       STAMP(3);
       __syncthreads();                                            // (C)
-      store_split<RN2, MT>(acc, sc, sh, buf, kLd, kPlane, wave * RN2 * 16, lane);
+      store_split_frag<RN2, MT>(acc, sc, sh, fbuf, wave * RN2 * 16, lane);
     }
     __syncthreads();                                              // (D) layer-2 planes + next neighbour lists visible
     STAMP(4);
@@ -517,7 +612,8 @@ __global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int til
     {
       f32x4 acc[RN3][MT];
       zero_acc(acc);
-      gemm_split<RN3, MT, kN2 / 32, kN3 / 16, kRing>(buf, kLd, kPlane, w3, acc, lane, ring3);
+      const XFragS x3{buf + lane * 8};
+      gemm_split_x<RN3, MT, kN2 / 32, kN3 / 16, kRing>(x3, w3, acc, lane, ring3);
       STAMP(5);
       float4 sc[RN3], sh[RN3];
       load_affine4<RN3>(sc3, sh3, wave * RN3 * 16, lane, sc, sh);

@@ -115,6 +115,26 @@ def _pack_layer_split(conv, bn, kp, feat_first, kperm=False):
     return frag.contiguous().reshape(-1), torch.cat([scale, shift]).contiguous()
 
 
+def _pack_level2_first(conv, bn):
+    """Level 2's first layer for sa2_split_kernel (round 3): the 128 feature columns as split planes (K = 128),
+    the three coordinate columns as fp32 rows (128, 4) appended to the affine -- the kernel adds their
+    contribution to the accumulators with fp32 FMAs instead of a fifth, 29/32-empty slab of MFMAs."""
+    w = conv.weight.detach().reshape(conv.out_channels, conv.in_channels).float()      # K order [xyz, features]
+    n = w.shape[0]
+    feat = w[:, 3:].contiguous()
+    w0 = feat.to(torch.bfloat16)
+    r1 = feat - w0.float()
+    w1 = r1.to(torch.bfloat16)
+    w2 = (r1 - w1.float()).to(torch.bfloat16)
+    planes = torch.stack([w0, w1, w2])
+    kp = feat.shape[1]
+    frag = planes.view(3, n // 16, 16, kp // 32, 4, 8).permute(3, 1, 0, 4, 2, 5)       # (s, t, p, g, i, j)
+    _, scale, shift = _pack_rows(conv, bn, conv.in_channels, False)
+    wxyz = torch.zeros((n, 4), device=w.device)
+    wxyz[:, :3] = w[:, :3]
+    return frag.contiguous().reshape(-1), torch.cat([scale, shift, wxyz.reshape(-1)]).contiguous()
+
+
 def _state_key(net):
     return tuple((t.data_ptr(), t._version) for t in list(net.parameters()) + list(net.buffers()))
 
@@ -137,6 +157,7 @@ def get_plan(net):
     _, pairs2 = _level_spec(net.encoder[1])
     split2 = [_pack_layer_split(conv, bn, _KP0_SPLIT[1] if j == 0 else conv.in_channels, feat_first=(j == 0))
               for j, (conv, bn) in enumerate(pairs2)]
+    split2[0] = _pack_level2_first(*pairs2[0])
     _, pairs1 = _level_spec(net.encoder[0])
     split1 = [_pack_layer_split(conv, bn, _KP0_SPLIT[0] if j == 0 else conv.in_channels, feat_first=False,
                                 kperm=(j > 0)) for j, (conv, bn) in enumerate(pairs1)]

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Everything profiles/ holds for a round, in one go on the GPU box:  bash tools/collect_profiles.sh gpurun_out/r03 r03_v1
+# (bench line with CPU baseline, rocprofv3 kernel stats + one-step timeline of the same command, PMC passes,
+#  the variant lines, the secondary LLM-layer line, the per-op CPU table)
+set -u
+OUT=${1:-gpurun_out/prof}
+TAG=${2:-rXX}
+export TMPDIR=/tmp
+ROOT=$(pwd)
+mkdir -p "$OUT"
+python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
+tail -c 400 "$OUT/${TAG}_bench.err"
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/kt" -- python "$ROOT/bench.py" --no-cpu-baseline > "$ROOT/$OUT/kt.log" 2>&1)
+F=$(ls "$OUT"/kt/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$F" ] && cp "$F" "$OUT/${TAG}_bench_kernel_stats.csv"
+F=$(ls "$OUT"/kt/*/*kernel_trace.csv 2>/dev/null | head -1); [ -n "$F" ] && python tools/trace_step.py "$F" > "$OUT/${TAG}_step_timeline.txt"
+rm -rf "$OUT/kt"
+bash tools/pmc_step.sh "$OUT/pmc_step" > /dev/null 2>&1; cp "$OUT/pmc_step/summary.txt" "$OUT/${TAG}_pmc_step.txt"; rm -rf "$OUT/pmc_step"
+bash tools/pmc_sa.sh "$OUT/pmc_sa" > /dev/null 2>&1; cp "$OUT/pmc_sa/summary.txt" "$OUT/${TAG}_pmc_sa.txt"; rm -rf "$OUT/pmc_sa"
+bash tools/pmc_blocks.sh "$OUT/pmc_blocks" > /dev/null 2>&1; cp "$OUT/pmc_blocks/summary.txt" "$OUT/${TAG}_pmc_blocks.txt"; rm -rf "$OUT/pmc_blocks"
+V="$OUT/${TAG}_variants.jsonl"; : > "$V"
+v() { echo "# $*" >> "$V.cmds"; "$@" 2>/dev/null | tail -1 >> "$V"; }
+v python bench.py --no-cpu-baseline --batch 4 --accum 5
+v python bench.py --no-cpu-baseline --batch 4 --accum 5 --no-window
+v python bench.py --no-cpu-baseline --skip-padded
+v python bench.py --no-cpu-baseline --pipeline
+v python bench.py --no-cpu-baseline --from-store
+v python bench.py --no-cpu-baseline --host-inputs
+v python bench.py --no-cpu-baseline --objects 120 --points 2048 --llm-hidden 5120 --batch 8 --situation-type as_object
+v env MSR3D_TRAINABLE=strips python bench.py --no-cpu-baseline
+v env MSR3D_SA_MMA=f32 python bench.py --no-cpu-baseline
+v env MSR3D_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline
+v python bench.py --no-cpu-baseline --unfrozen --batch 16 --steps 10 --warmup 2
+python bench.py --llm-layer --steps 10 --warmup 3 2>/dev/null | tail -1 > "$OUT/${TAG}_llm_layer.json"
+python bench.py --cpu-ops > "$OUT/${TAG}_cpu_ops.log" 2>&1; cp profiles/r03_cpu_ops.json "$OUT/${TAG}_cpu_ops.json"
+timeout 300 python tools/prof_blocks.py > "$OUT/${TAG}_block_stamps.txt" 2>&1
+ls -la "$OUT"
