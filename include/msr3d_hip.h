@@ -502,12 +502,14 @@ int msr3d_gemm_multi_f32(int n, const msr3d_gemm_problem_t *problems, msr3d_stre
 /* Data-only front of the prompter for one batch, ONE launch: pad_out = !obj_valid, valid_out =
  * obj_valid (optional copy into a step's static buffer), locs_out = obj_locs (B,L,6), pairwise_out
  * (B,L,L,5) = msr3d_pairwise_locs, fourier_out (B,L,3+6*num_bands) = msr3d_agent_fourier(transform).
- * L <= 128. */
+ * anchor_loc_out (B,3) / anchor_ori_out (B,4): optional copies of the anchor pose (a training step's static
+ * buffers).  L <= 128. */
 int msr3d_scene_prologue(int B, int L, const float *obj_locs, const unsigned char *obj_valid,
                          const float *anchor_loc, const float *anchor_ori, const float *freqs,
                          int num_bands, int transform, float eps, float *pairwise_out,
                          float *fourier_out, float *locs_out, unsigned char *pad_out,
-                         unsigned char *valid_out, msr3d_stream_t stream);
+                         unsigned char *valid_out, float *anchor_loc_out, float *anchor_ori_out,
+                         msr3d_stream_t stream);
 
 /* zero_region[0..n_floats) = 0 (n_floats % 4 == 0) and, if seed != NULL, the dropout seed bump of
  * msr3d_bump_seed -- the step's one fill for all split-K meeting points. */

@@ -36,12 +36,16 @@ __global__ __launch_bounds__(256) void scene_prologue_kernel(
     const float *__restrict__ anchor_loc, const float *__restrict__ anchor_ori,
     const float *__restrict__ freqs, int nb, int transform, float eps, float *__restrict__ pw,
     float *__restrict__ ff, float *__restrict__ loc_out, unsigned char *__restrict__ pad,
-    unsigned char *__restrict__ valid_out) {
+    unsigned char *__restrict__ valid_out, float *__restrict__ anchor_loc_out, float *__restrict__ anchor_ori_out) {
   __shared__ float cx[128], cy[128], cz[128];
   __shared__ float wmax[4];
   // grid (B, 4): the four blocks of a sample each find the sample's largest distance (cheap, all
   // pairs) and write a quarter of the pair features; block 0 also writes the per-token outputs
   const int b = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+  if (part == 0 && tid < 7) {          // the anchor pose, copied into the step's static buffers in the same launch
+    if (tid < 3) { if (anchor_loc_out && anchor_loc) anchor_loc_out[b * 3 + tid] = anchor_loc[b * 3 + tid]; }
+    else if (anchor_ori_out && anchor_ori) anchor_ori_out[b * 4 + tid - 3] = anchor_ori[b * 4 + tid - 3];
+  }
   for (int i = tid; i < L; i += 256) {
     const float *p = loc + ((size_t)b * L + i) * 6;
     const float x = p[0], y = p[1], z = p[2];
@@ -265,7 +269,8 @@ int msr3d_scene_prologue(int B, int L, const float *obj_locs, const unsigned cha
                          const float *anchor_loc, const float *anchor_ori, const float *freqs,
                          int num_bands, int transform, float eps, float *pairwise_out,
                          float *fourier_out, float *locs_out, unsigned char *pad_out,
-                         unsigned char *valid_out, msr3d_stream_t stream) {
+                         unsigned char *valid_out, float *anchor_loc_out, float *anchor_ori_out,
+                         msr3d_stream_t stream) {
   if (B < 0 || L <= 0 || L > 128 || num_bands <= 0) return MSR3D_EINVAL;
   if (B == 0) return 0;
   if (!obj_locs || !obj_valid || !freqs || !pairwise_out || !fourier_out || !locs_out || !pad_out ||
@@ -273,7 +278,8 @@ int msr3d_scene_prologue(int B, int L, const float *obj_locs, const unsigned cha
     return MSR3D_EINVAL;
   scene_prologue_kernel<<<dim3(B, 4), 256, 0, (hipStream_t)stream>>>(L, obj_locs, obj_valid, anchor_loc, anchor_ori,
                                                            freqs, num_bands, transform, eps, pairwise_out,
-                                                           fourier_out, locs_out, pad_out, valid_out);
+                                                           fourier_out, locs_out, pad_out, valid_out, anchor_loc_out,
+                                                           anchor_ori_out);
   return (int)hipGetLastError();
 }
 

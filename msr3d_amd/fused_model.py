@@ -470,10 +470,11 @@ class PrompterSchedule:
                     beta=1.0, colsum=db)
 
     # ------------------------------------------------------------------ data-only front
-    def stage(self, d):
+    def stage(self, d, anchor_out=None):
         """pad mask, pairwise features, Fourier features, obj_locs copy: one launch, reading the
         batch tensors where they are.  HotPathTrainStep calls it eagerly per batch (outside the
-        graph); forward() calls it itself otherwise."""
+        graph); forward() calls it itself otherwise.  anchor_out = (anchor_locs, anchor_orientation)
+        static buffers that receive a copy of the batch's anchor pose in the same launch."""
         e = d["obj_embeds"]
         B, L = e.shape[:2]
         self._ensure(B, L, e.shape[-1], e.device)
@@ -486,7 +487,9 @@ class PrompterSchedule:
         with torch.cuda.device(dev):
             rc = lib.msr3d_scene_prologue(B, L, _ptr(loc), _ptr(valid), _ptr(al), _ptr(ao), _ptr(self.freqs), 10, 1,
                                           ctypes.c_float(1e-10), _ptr(a["pw"]), _ptr(a["ff"]), _ptr(a["loc6"]),
-                                          _ptr(self.pad), _ptr(self.valid), _lib.current_stream_ptr(dev))
+                                          _ptr(self.pad), _ptr(self.valid),
+                                          _ptr(anchor_out[0]) if anchor_out else None,
+                                          _ptr(anchor_out[1]) if anchor_out else None, _lib.current_stream_ptr(dev))
         _lib.check(rc, "msr3d_scene_prologue")
 
     # ------------------------------------------------------------------ forward / backward

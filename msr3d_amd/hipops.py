@@ -657,6 +657,7 @@ def bump_seed(device):
 
 
 _dot_scratch = {}
+_dot_pool = {}
 
 
 def dot(a, b):
@@ -668,7 +669,14 @@ def dot(a, b):
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)     # concurrent dots on two streams must not share
     ws = _dot_scratch.get(key)
     if ws is None:
-        ws = _dot_scratch[key] = torch.zeros(1024 + 1, dtype=torch.float32, device=dev)
+        # a row of a pool zeroed ahead of time: a torch.zeros here would put a fill kernel into a graph that
+        # is being captured on a fresh stream (the kernel itself leaves its counter at zero)
+        pool = _dot_pool.setdefault(dev, [])
+        if not pool:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("hipops.dot: first use on this device inside a graph capture; call it once eagerly")
+            pool.extend(torch.zeros(8, 1024 + 1, dtype=torch.float32, device=dev).unbind(0))
+        ws = _dot_scratch[key] = pool.pop()
     out = torch.empty((), dtype=torch.float32, device=dev)
     n = a.numel()
     if n % 4 or a.data_ptr() % 16 or b.data_ptr() % 16:

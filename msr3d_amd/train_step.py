@@ -226,13 +226,18 @@ class HotPathTrainStep:
                 # the schedule's one-launch prologue reads the batch's small tensors where they are
                 # and writes every derived static buffer (key mask, pairwise / Fourier features,
                 # obj_locs and obj_masks copies): no input copies at all
-                sched.stage(dict(batch, obj_embeds=self.static["obj_embeds"]))
+                anchors = None
+                if all(k in self.static and k in batch and self.static[k].dtype == torch.float32 and batch[k].dtype == torch.float32 and batch[k].is_contiguous()
+                       for k in ("anchor_locs", "anchor_orientation")):
+                    anchors = (self.static["anchor_locs"], self.static["anchor_orientation"])
+                sched.stage(dict(batch, obj_embeds=self.static["obj_embeds"]), anchor_out=anchors)
                 self.static["obj_masks"] = sched.valid
                 self.static["obj_locs"] = sched.arena["loc6"].view(sched.valid.shape[0], sched.valid.shape[1], 6)
                 self.static["_staged"] = True
                 # everything else the batch carries (anchor pose, and whatever a loss_fn reads from the scene
                 # dict: ids, targets, labels) still goes into the static buffers the captured step sees
-                rest = [k for k in self.static if k not in ("obj_embeds", "obj_fts", "obj_masks", "obj_locs", "_staged")]
+                rest = [k for k in self.static if k not in ("obj_embeds", "obj_fts", "obj_masks", "obj_locs", "_staged")
+                        and not (anchors and k in ("anchor_locs", "anchor_orientation"))]     # (the prologue copied those)
                 missing = [k for k in rest if k not in batch]
                 if missing:
                     raise KeyError(f"batch lacks {missing}, which the example batch of this step had")

@@ -240,11 +240,14 @@ def test_pos_embed_and_scene_prologue_match_the_module_formulation():
     pw, ff = torch.empty(B, L, L, 5, device="cuda"), torch.empty(B, L, KF, device="cuda")
     loc6, pad = torch.empty(B, L, 6, device="cuda"), torch.empty(B, L, dtype=torch.uint8, device="cuda")
     vout = torch.empty(B, L, dtype=torch.uint8, device="cuda")
+    al2, ao2 = torch.empty_like(al), torch.empty_like(ao)
     vp = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else 0)   # noqa: E731
     lib, st = _lib.load(), _lib.current_stream_ptr(torch.device("cuda"))
     rc = lib.msr3d_scene_prologue(B, L, vp(loc), vp(valid.view(torch.uint8)), vp(al), vp(ao), vp(freqs), 10, 1,
-                                  ctypes.c_float(1e-10), vp(pw), vp(ff), vp(loc6), vp(pad), vp(vout), st)
+                                  ctypes.c_float(1e-10), vp(pw), vp(ff), vp(loc6), vp(pad), vp(vout), vp(al2), vp(ao2),
+                                  st)
     _lib.check(rc, "msr3d_scene_prologue")
+    assert torch.equal(al2, al) and torch.equal(ao2, ao)
     assert torch.equal(pw, hipops.pairwise_locs_center5(loc))
     assert torch.equal(ff, hipops.agent_fourier(loc, al, ao))
     assert torch.equal(loc6, loc) and torch.equal(pad.bool(), ~valid) and torch.equal(vout.bool(), valid)
