@@ -407,10 +407,25 @@ def main():
             return staged_step(bufs[i % 2], None)
         tr.step = step_from_host
 
-    for i in range(args.warmup * args.accum):
-        if args.accum > 1 and not args.unfrozen and not args.no_window and not args.host_inputs and i % args.accum == 0:
-            tr.stepper.encode_window([batches[(i + m) % n_resident] for m in range(args.accum)])
-        tr.step(batches[i % n_resident], nxt(i))
+    # gradient accumulation over a frozen encoder: the whole window's objects go through ONE encoder pass
+    window = args.accum > 1 and not args.unfrozen and not args.no_window and not args.host_inputs
+
+    def window_of(k):
+        return [batches[(k * args.accum + m) % n_resident] for m in range(args.accum)]
+
+    def run_window(k):
+        """optimiser step k = args.accum micro-steps"""
+        if window and not tr.stepper.window_ready(window_of(k)):
+            tr.stepper.encode_window(window_of(k))
+        for m in range(args.accum):
+            j = k * args.accum + m
+            nb = nxt(j)
+            if window:       # N > 1: the NEXT window's encoder pass is what runs beside the last micro-step's exchange
+                nb = window_of(k + 1) if (dist_on and pipe and m == args.accum - 1) else None
+            tr.step(batches[j % n_resident], nb)
+
+    for i in range(args.warmup):
+        run_window(i)
 
     # N > 1 self-checks (nobody can watch an 8-GPU run: the line has to prove it was one).
     #   ranks_seen: an all-reduce of ones over the communicator the gradients travel on
@@ -435,14 +450,8 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step spread
     t0 = time.perf_counter()
     marks[0].record()
-    window = args.accum > 1 and not args.unfrozen and not args.no_window and not args.host_inputs
     for i in range(args.steps):
-        j0 = (args.warmup + i) * args.accum
-        if window:       # frozen encoder: the whole accumulation window's objects in one encoder pass
-            tr.stepper.encode_window([batches[(j0 + m) % n_resident] for m in range(args.accum)])
-        for m in range(args.accum):
-            j = j0 + m
-            tr.step(batches[j % n_resident], nxt(j))
+        run_window(args.warmup + i)
         marks[i + 1].record()
     torch.cuda.synchronize()
     if dist_on:
@@ -451,6 +460,8 @@ def main():
     elapsed = time.perf_counter() - t0
     _lib.set_timing_sink(None)
 
+    # MSR3D_DP_GRAPH_COMM=1: the RCCL call was captured with the rest, the step is one graph at N > 1 as well
+    whole_graph = tr.stepper.graph is not None and not tr.stepper.split
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if dist_on:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -545,10 +556,11 @@ def main():
                        "step": "fwd+bwd+allreduce+clip+AdamW, LLM excluded",
                        "backbone": "unfrozen (freeze: False, BatchNorm in training mode)" if args.unfrozen
                        else "frozen (every shipped config)",
-                       "hip_graph": not args.no_graph, "encoder_prefetch": args.pipeline,
+                       "hip_graph": not args.no_graph, "encoder_prefetch": args.pipeline or (dist_on and whole_graph),
                        "padded_slots_skipped": args.skip_padded,
                        "objects_encoded_per_step": objs_per_launch,
-                       "allreduce_hidden_behind_next_encoder": dist_on,
+                       "allreduce_hidden_behind_next_encoder": dist_on and not whole_graph and not args.unfrozen,
+                       "exchange_inside_graph": dist_on and whole_graph,
                        "inputs": ("built per step on the device from HBM-resident scans "
                                   "(msr3d_preprocess_pcd)" if args.from_store else
                                   "pinned host memory, copied over PCIe every step" if args.host_inputs

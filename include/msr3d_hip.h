@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 8
+#define MSR3D_ABI_VERSION 9
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -753,6 +753,15 @@ int msr3d_adamw_flat_masked(long long n, float *params, float *grads, float *exp
                             float beta2, float eps, float weight_decay, float max_grad_norm, int schedule,
                             int warmup_steps, int total_steps, int zero_grad, const unsigned char *active4,
                             msr3d_stream_t stream);
+/* The same reading every gradient as grads[i] * grad_scale (the rounded fp32 product, in the norm and in
+ * the update -- bit-identical to a separate `grads *= grad_scale` pass before the call).  The data-parallel
+ * engine leaves the all-reduced SUM in the buffer and passes 1 / world here: the averaging
+ * (/root/reference/trainer/leo_trainer.py:50-52, DDP's gradient mean) costs no extra pass over 21 MB. */
+int msr3d_adamw_flat_scaled(long long n, float *params, float *grads, float *exp_avg, float *exp_avg_sq,
+                            float *sumsq_scratch, int *step_counter, float base_lr, float beta1,
+                            float beta2, float eps, float weight_decay, float max_grad_norm, int schedule,
+                            int warmup_steps, int total_steps, int zero_grad, const unsigned char *active4,
+                            float grad_scale, msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Scene-sample construction on the device: replaces the host-side

@@ -28,14 +28,16 @@ constexpr int kMaxBlocks = 1024;   // == MSR3D_ADAMW_SCRATCH_FLOATS
 // ranks hold identical gradients after the all-reduce and must derive the identical clip
 // coefficient, or their weights drift apart.
 __global__ __launch_bounds__(256) void sumsq_kernel(long long n4, const float4 *__restrict__ g,
-                                                    float *__restrict__ partial, int *__restrict__ step_ctr) {
+                                                    float *__restrict__ partial, int *__restrict__ step_ctr,
+                                                    float gscale) {
   // (also advances the step counter: it runs before adamw_kernel, which then reads the NEW value --
   // one launch fewer than a separate tick)
   if (step_ctr && blockIdx.x == 0 && threadIdx.x == 0) *step_ctr += 1;
   float s = 0.f;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n4;
        t += (long long)gridDim.x * blockDim.x) {
-    const float4 v = g[t];
+    float4 v = g[t];
+    v.x *= gscale; v.y *= gscale; v.z *= gscale; v.w *= gscale;      // (the rounded product, as a separate g *= s leaves it)
     s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
   }
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(long long n4, float4 *__rest
                                                     float beta1, float beta2, float eps, float wd,
                                                     float max_norm, int sched, int warmup, int total,
                                                     int zero_grad, const unsigned char *__restrict__ active,
-                                                    int ticked) {
+                                                    int ticked, float gscale) {
   __shared__ float sh[4];
   __shared__ float red[256];
   if (max_norm > 0.f) {        // fixed-order sum of the block partials (same in every block)
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(long long n4, float4 *__rest
     float4 pp = p[t], gg = g[t], mm = m[t], vv = v[t];
 #define UPD(c)                                                  \
     {                                                           \
-      const float gr = gg.c * coef;                             \
+      const float gr = (gg.c * gscale) * coef;                  \
       float pv = pp.c * decay;                                  \
       mm.c = mm.c + w1 * (gr - mm.c);                           \
       vv.c = vv.c * beta2 + w2 * gr * gr;                       \
@@ -197,6 +199,16 @@ int msr3d_adamw_flat_masked(long long n, float *params, float *grads, float *exp
                             float beta2, float eps, float weight_decay, float max_grad_norm, int schedule,
                             int warmup_steps, int total_steps, int zero_grad, const unsigned char *active4,
                             msr3d_stream_t stream) {
+  return msr3d_adamw_flat_scaled(n, params, grads, exp_avg, exp_avg_sq, sumsq_scratch, step_counter, base_lr, beta1, beta2,
+                                 eps, weight_decay, max_grad_norm, schedule, warmup_steps, total_steps, zero_grad, active4,
+                                 1.0f, stream);
+}
+
+int msr3d_adamw_flat_scaled(long long n, float *params, float *grads, float *exp_avg, float *exp_avg_sq,
+                            float *sumsq_scratch, int *step_counter, float base_lr, float beta1,
+                            float beta2, float eps, float weight_decay, float max_grad_norm, int schedule,
+                            int warmup_steps, int total_steps, int zero_grad, const unsigned char *active4,
+                            float grad_scale, msr3d_stream_t stream) {
   if (n < 0 || (n % 4) != 0) return MSR3D_EINVAL;
   if (n == 0) return 0;
   if (!params || !grads || !exp_avg || !exp_avg_sq || !sumsq_scratch || !step_counter)
@@ -208,12 +220,13 @@ int msr3d_adamw_flat_masked(long long n, float *params, float *grads, float *exp
   if (gsz > kMaxBlocks) gsz = kMaxBlocks;
   const int ticked = max_grad_norm > 0.f ? 1 : 0;
   if (ticked)
-    sumsq_kernel<<<(int)gsz, 256, 0, st>>>(n4, reinterpret_cast<const float4 *>(grads), sumsq_scratch, step_counter);
+    sumsq_kernel<<<(int)gsz, 256, 0, st>>>(n4, reinterpret_cast<const float4 *>(grads), sumsq_scratch, step_counter,
+                                              grad_scale);
   adamw_kernel<<<(int)gsz, 256, 0, st>>>(
       n4, reinterpret_cast<float4 *>(params), reinterpret_cast<float4 *>(grads),
       reinterpret_cast<float4 *>(exp_avg), reinterpret_cast<float4 *>(exp_avg_sq), sumsq_scratch,
       (int)gsz, step_counter, base_lr, beta1, beta2, eps, weight_decay, max_grad_norm, schedule, warmup_steps,
-      total_steps, zero_grad, active4, ticked);
+      total_steps, zero_grad, active4, ticked, grad_scale);
   if (!ticked) adamw_tick_kernel<<<1, 1, 0, st>>>(step_counter);
   return (int)hipGetLastError();
 }

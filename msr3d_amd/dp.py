@@ -142,6 +142,11 @@ class FlatGradAllReduce:
             raise ValueError("MSR3D_DP_EXCHANGE must be 'allreduce' or 'rs_ag'")
         # timing (bench.py): HIP events on the communication stream around every exchange, and on the
         # compute stream around the wait for it (= the part of the exchange that was NOT hidden)
+        # scale_in_optimizer: leave the SUM in the buffer; the consumer (FlatAdamW, msr3d_adamw_flat_scaled)
+        # reads every gradient times 1 / world -- same bits as the separate pass, one 21 MB round trip less.
+        # Set by HotPathTrainStep when the optimiser is the fused one; the gradients in the buffer are then
+        # sums, not means, after an exchange.
+        self.scale_in_optimizer = False
         self.timing = False
         self.comm_events, self.wait_events = [], []
         self.comm_stream = torch.cuda.Stream(device=dev) if self.on_gpu else None
@@ -245,17 +250,19 @@ class FlatGradAllReduce:
             except RuntimeError:                      # a backend without reduce-scatter (gloo)
                 self.exchange_mode = "allreduce"
                 return self._reduce(view)
-            mine.mul_(1.0 / self.world)
+            if not self.scale_in_optimizer:
+                mine.mul_(1.0 / self.world)
             dist.all_gather_into_tensor(view, mine.clone(), group=self.group)
             return
         dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-        view.mul_(1.0 / self.world)
+        if not self.scale_in_optimizer:
+            view.mul_(1.0 / self.world)
 
     def _exchange(self, view):
         if self.on_gpu:
             self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm_stream):
-                if self.timing:
+                if self.timing and not torch.cuda.is_current_stream_capturing():
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(self.comm_stream)
                     self._reduce(view)
@@ -274,6 +281,12 @@ class FlatGradAllReduce:
         self._exchange(self.flat[s:e])
 
     # ------------------------------------------------------------------ step API
+    def reset_marks(self):
+        """The bookkeeping half of zero_grad(), for a consumer that cleared the buffer itself (the fused
+        optimiser's zero_grad flag)."""
+        self._ready = [set() for _ in self.buckets]
+        self._launched = [False] * len(self.buckets)
+
     def zero_grad(self):
         """One memset for every gradient; `.grad` views stay attached."""
         self.flat.zero_()
@@ -290,7 +303,7 @@ class FlatGradAllReduce:
         """The compute stream waits for the exchange started by start()."""
         if self.distributed and self.on_gpu:
             cur = torch.cuda.current_stream(self.device)
-            if self.timing:
+            if self.timing and not torch.cuda.is_current_stream_capturing():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(cur)
                 cur.wait_stream(self.comm_stream)

@@ -90,13 +90,15 @@ class FlatAdamW:
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         f = ctypes.c_float
         with torch.cuda.device(dev):
-            rc = lib.msr3d_adamw_flat_masked(
+            # scale_in_optimizer: the gradient engine left the all-reduced SUM in the buffer (dp.py)
+            gscale = 1.0 / self.dp.world if getattr(self.dp, "scale_in_optimizer", False) else 1.0
+            rc = lib.msr3d_adamw_flat_scaled(
                 self.flat_p.numel(), p(self.flat_p), p(self.dp.flat), p(self.exp_avg), p(self.exp_avg_sq),
                 p(self.sumsq), p(self.step_ctr), f(self.lr), f(self.betas[0]), f(self.betas[1]), f(self.eps),
                 f(self.wd), f(self.max_grad_norm or 0.0), self.schedule | (self.sched_mult << 8),
                 self.warmup_steps, self.total_steps, int(zero_grad),
-                p(self.active) if self.active is not None else None, _lib.current_stream_ptr(dev))
-        _lib.check(rc, "msr3d_adamw_flat_masked")
+                p(self.active) if self.active is not None else None, f(gscale), _lib.current_stream_ptr(dev))
+        _lib.check(rc, "msr3d_adamw_flat_scaled")
 
     def state_dict(self, names=None):
         """Per-parameter moments keyed by position in `dp.order` (or by `names[i]`, the parameter

@@ -66,11 +66,19 @@ class HotPathTrainStep:
         self._micro = 0
         self._zero_in_graph = False
         # zero_in_optimizer: the fused AdamW kernel clears each gradient as it consumes it (its
-        # zero_grad flag) instead of a separate 21 MB fill at the start of the next step; only in the
-        # single-graph schedule (one rank, no accumulation), and the gradients are then NOT readable
-        # after a step
-        self._opt_zeroes = bool(zero_in_optimizer) and self.accum_steps == 1 and not dp.distributed \
-            and getattr(optimizer, "fused_clip", False)
+        # zero_grad flag) instead of a separate 21 MB fill at the start of the next step; without
+        # accumulation only, and the gradients are then NOT readable after a step
+        fused = bool(getattr(optimizer, "fused_clip", False))
+        self._opt_zeroes = bool(zero_in_optimizer) and self.accum_steps == 1 and fused
+        # world > 1 with the fused optimiser: the exchange leaves the SUM, the optimiser reads it times
+        # 1 / world (no separate averaging pass over the buffer)
+        if fused and dp.distributed and hasattr(dp, "scale_in_optimizer"):
+            dp.scale_in_optimizer = True
+        # MSR3D_DP_GRAPH_COMM=1: capture the RCCL call with the rest -- the whole data-parallel step is ONE
+        # graph (zero -> forward -> backward -> all-reduce on the side stream -> clip + AdamW), no next_batch
+        # needed.  Opt-in: the eager exchange is the schedule every test on this box can run with >1 rank.
+        import os
+        self._graph_comm = os.environ.get("MSR3D_DP_GRAPH_COMM") == "1" and self.accum_steps == 1
         self._sched_direct = False
         self._probed = False
         self.unused_parameters = []
@@ -114,7 +122,10 @@ class HotPathTrainStep:
         if between is not None:
             between()
         self.dp.wait()
-        if getattr(self.opt, "fused_clip", False):
+        if self._opt_zeroes:
+            self.opt.step(zero_grad=True)         # ... and the gradients are cleared as they are consumed
+            self.dp.reset_marks()
+        elif getattr(self.opt, "fused_clip", False):
             self.opt.step()                       # clip + AdamW in the flat-buffer kernels
         else:
             self.dp.clip_grad_norm_(5.0)
@@ -126,6 +137,7 @@ class HotPathTrainStep:
             self.dp.start()
             self.dp.wait()
             self.opt.step(zero_grad=True)
+            self.dp.reset_marks()
         else:
             self._update()
         return loss
@@ -133,7 +145,7 @@ class HotPathTrainStep:
     def _micro_step(self, run, between=None):
         """Split schedule: zero the gradients before the first micro-batch, `run` forward/backward
         (eagerly or by graph replay), exchange + optimiser after the last one."""
-        if self._micro == 0 and not self._zero_in_graph:
+        if self._micro == 0 and not self._zero_in_graph and not self._opt_zeroes:
             self.dp.zero_grad()
         # only the last micro-batch may exchange (overlap mode launches buckets from the hooks)
         self.dp.begin_micro(last=self._micro + 1 == self.accum_steps)
@@ -149,7 +161,7 @@ class HotPathTrainStep:
     def encode_ahead(self, batch):
         """Run the frozen encoder for `batch` NOW on the compute stream; the step that later
         receives this batch finds its features ready (same hand-over as prefetch())."""
-        if self.unfrozen:
+        if self.unfrozen or self._win["index"].get(id(batch["obj_fts"])):   # (already encoded with its window)
             return
         with torch.no_grad():
             self.prompter.encode_objects(batch["obj_fts"], batch.get("obj_masks"), out=self._pref["feats"])
@@ -191,9 +203,16 @@ class HotPathTrainStep:
             w["index"].setdefault(id(f), []).append(i)
         w["B"] = B
 
+    def window_ready(self, batches):
+        """True when encode_window() has been run for exactly these micro-batches and none was consumed."""
+        need = {}
+        for b in batches:
+            need[id(b["obj_fts"])] = need.get(id(b["obj_fts"]), 0) + 1
+        return bool(need) and all(len(self._win["index"].get(k, ())) == n for k, n in need.items())
+
     def prefetch(self, batch):
         """Start the frozen encoder for `batch` on the side stream (returns immediately)."""
-        if self._enc_stream is None or self.unfrozen:
+        if self._enc_stream is None or self.unfrozen or self._win["index"].get(id(batch["obj_fts"])):
             return
         main = torch.cuda.current_stream()
         self._enc_stream.wait_stream(main)          # inputs exist; previous prefetch consumed
@@ -350,13 +369,18 @@ class HotPathTrainStep:
         # between the captured forward/backward and the 3-launch optimiser) -- a handful of host
         # launches per step, and no dependence on collective capture support.
         # Gradient accumulation likewise: the graph holds one micro-batch's forward/backward.
-        self.split = self.dp.distributed or self.accum_steps > 1
+        self.split = (self.dp.distributed and not self._graph_comm) or self.accum_steps > 1
         if self.split:
             self.dp.defer_comm = True
+        elif self.dp.distributed and self.unfrozen:
+            # one graph, exchange inside: a bucket is sent (on the communication stream, a fork of the
+            # capture) as soon as backward has produced it -- the trainable part's gradients, complete
+            # first, travel while the backbone's backward still runs.  No next batch needed.
+            self.dp.defer_comm = False
         # thread_local: other threads (RCCL's watchdog polling its events, loader threads) may keep
         # calling the HIP runtime while this thread captures
         # one micro-batch per optimiser step: the gradient zero-fill rides in the graph as well
-        self._zero_in_graph = self.split and self.accum_steps == 1
+        self._zero_in_graph = self.split and self.accum_steps == 1 and not self._opt_zeroes
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss = self._fwd_bwd(zero=self._zero_in_graph) if self.split else self._train_part()
 
@@ -364,16 +388,30 @@ class HotPathTrainStep:
         """One training step on `batch`.  If `next_batch` is given its frozen-encoder pass is run
         early: on one GPU on a side stream, overlapping this step's trainable part; data-parallel
         (world > 1) on the compute stream right after backward, where it hides the gradient
-        all-reduce."""
+        all-reduce.  With gradient accumulation `next_batch` may be the LIST of the next window's
+        micro-batches, passed with the window's last micro-batch: data-parallel, encode_window() of that
+        list is what runs beside the exchange (one GPU: ignored, the caller's encode_window() does it)."""
+        next_window = None
+        if isinstance(next_batch, (list, tuple)):
+            next_window, next_batch = list(next_batch), None
         if not self._probed and self.static["obj_embeds"].is_cuda:
             self._probe_unused(batch)
         self._load(batch)
         if self.unfrozen:
             next_batch = None           # nothing of the next batch can run before this step's update
-        hide_comm = next_batch is not None and self.dp.distributed and self.static["obj_embeds"].is_cuda
+        # (a step whose graph holds the exchange as well is scheduled like the one-GPU step)
+        whole = self.graph is not None and not self.split
+        hide_comm = (next_batch is not None or next_window is not None) and self.dp.distributed and \
+            self.static["obj_embeds"].is_cuda and not whole and not self.unfrozen
         if next_batch is not None and not hide_comm:
             self.prefetch(next_batch)
-        between = (lambda: self.encode_ahead(next_batch)) if hide_comm else None
+        between = None
+        if hide_comm and next_window is not None:
+            def between():
+                if not any(self._win["index"].values()):      # (never over features still to be consumed)
+                    self.encode_window(next_window)
+        elif hide_comm:
+            between = lambda: self.encode_ahead(next_batch)   # noqa: E731
         if self.graph is not None:
             if self.split:
                 return self._micro_step(lambda: (self.graph.replay(), self.loss)[1], between)

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, hide_comm=False):
+def _worker(rank, world, port, q, hide_comm=False, zero_opt=False, separate_scale=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     try:
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -45,9 +45,13 @@ def _worker(rank, world, port, q, hide_comm=False):
         opt = FlatAdamW(dp, lr=1e-3)
         batches = [synth_batch(100 * rank + i, 2, O=8, P=1024, device="cuda") for i in range(2)]
         w = torch.randn(2, 8, 64, generator=torch.Generator().manual_seed(1)).cuda()
-        step = HotPathTrainStep(model, opt, dp, lambda o: (o["scene_embeds"] * w).mean(), batches[0])
+        step = HotPathTrainStep(model, opt, dp, lambda o: (o["scene_embeds"] * w).mean(), batches[0],
+                                zero_in_optimizer=zero_opt)
+        assert dp.scale_in_optimizer              # the fused optimiser reads the all-reduced SUM times 1 / world
+        if separate_scale:
+            dp.scale_in_optimizer = False         # ... or the engine averages in its own pass over the buffer
         step.capture(batches[0], warmup=1)
-        assert step.split and step.graph is not None
+        assert step.split and step.graph is not None and step._opt_zeroes == zero_opt
         for i in range(3):
             # hide_comm: the next batch's frozen encoder is issued between the start of the
             # all-reduce and the optimiser (train_step.encode_ahead) -- same numbers either way
@@ -62,11 +66,11 @@ def _worker(rank, world, port, q, hide_comm=False):
         q.put((rank, "err", traceback.format_exc()))
 
 
-def _run_pair(hide_comm):
+def _run_pair(hide_comm, zero_opt=False, separate_scale=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, hide_comm)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, hide_comm, zero_opt, separate_scale)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}
@@ -94,3 +98,74 @@ def test_two_ranks_one_gpu_split_graph_step():
     # encoding the next batch early changes the schedule, not the arithmetic (up to the atomic
     # split-K summation order of two separate runs)
     assert np.allclose(plain, hidden, rtol=1e-4, atol=3e-3)
+
+
+def test_two_ranks_average_in_the_optimiser_and_zero_there_too():
+    """1 / world folded into msr3d_adamw_flat_scaled is the same arithmetic as the separate averaging pass;
+    clearing the gradients in the optimiser (no fill at the head of the next step) does not change a step."""
+    import numpy as np
+    separate = _run_pair(False, separate_scale=True)
+    folded = _run_pair(False)
+    zeroed = _run_pair(False, zero_opt=True)
+    assert np.allclose(separate, folded, rtol=1e-4, atol=3e-3)      # (two runs: LayerNorm-gradient atomics order)
+    assert np.allclose(folded, zeroed, rtol=1e-4, atol=3e-3)
+
+
+def _worker_rccl(rank, port, q, graph_comm):
+    """one rank over the REAL backend (RCCL), exchange path forced"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MSR3D_DP_FORCE_EXCHANGE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", MSR3D_DP_GRAPH_COMM="1" if graph_comm else "0")
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        import msr3d_amd.model  # noqa: F401
+        import msr3d_amd.modules  # noqa: F401
+        from msr3d_amd.config import AttrDict, default_prompter_cfg
+        from msr3d_amd.dp import FlatGradAllReduce
+        from msr3d_amd.model import build_model
+        from msr3d_amd.optim import FlatAdamW
+        from msr3d_amd.synth import synth_batch
+        from msr3d_amd.train_step import HotPathTrainStep
+        torch.manual_seed(0)
+        cfg = AttrDict({"prompter": default_prompter_cfg(dropout=0.1), "llm_hidden_size": 64,
+                        "model": {"name": "MSR3DHotPath"}})
+        model = build_model(cfg).cuda().train()
+        dp = FlatGradAllReduce([p for p in model.parameters() if p.requires_grad], bucket_bytes=1 << 20)
+        assert dp.distributed and dp.world == 1
+        opt = FlatAdamW(dp, lr=1e-3)
+        batches = [synth_batch(i, 2, O=8, P=1024, device="cuda") for i in range(2)]
+        w = torch.randn(2, 8, 64, generator=torch.Generator().manual_seed(1)).cuda()
+        step = HotPathTrainStep(model, opt, dp, lambda o: (o["scene_embeds"] * w).mean(), batches[0],
+                                zero_in_optimizer=True)
+        step.capture(batches[0], warmup=1)
+        assert step.graph is not None and step.split == (not graph_comm)
+        losses = []
+        for i in range(4):
+            losses.append(step(batches[i % 2], batches[(i + 1) % 2]).clone())
+        torch.cuda.synchronize()
+        q.put(("ok", opt.flat_p.detach().cpu().numpy().copy(), [float(l) for l in losses]))
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put(("err", traceback.format_exc(), None))
+
+
+def _run_rccl(graph_comm):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_rccl, args=(0, _free_port(), q, graph_comm))
+    p.start()
+    status, flat, losses = q.get(timeout=300)
+    p.join(timeout=60)
+    assert status == "ok", flat
+    return flat, losses
+
+
+def test_exchange_captured_in_the_graph_trains_the_same_weights():
+    """split schedule (graph | eager RCCL + encoder of the next batch | eager optimiser) against
+    MSR3D_DP_GRAPH_COMM=1 (everything, the collective included, in one graph): same losses, same weights."""
+    import numpy as np
+    a, la = _run_rccl(False)
+    b, lb = _run_rccl(True)
+    assert np.isfinite(a).all() and np.allclose(la, lb, rtol=1e-5, atol=1e-7)
+    assert np.allclose(a, b, rtol=1e-4, atol=3e-3)

@@ -60,3 +60,27 @@ def test_dot_is_exact_enough_and_bit_reproducible():
         got = [float(hipops.dot(a, b)) for _ in range(3)]
         assert got[0] == got[1] == got[2]
         assert abs(got[0] - want) <= 1e-5 * float((a.double() * b.double()).abs().sum()) + 1e-6
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_grad_scale_in_the_optimiser_is_the_separate_averaging_pass_bit_for_bit(world):
+    """msr3d_adamw_flat_scaled(grad_scale = 1 / world) on the all-reduced SUM == `grads *= 1 / world` followed
+    by the unscaled call: same clip coefficient, same moments, same weights, for a world that is not a power
+    of two as well (/root/reference/trainer/leo_trainer.py:50-52: DDP averages, then accelerate clips)."""
+    from msr3d_amd.dp import FlatGradAllReduce
+    from msr3d_amd.optim import FlatAdamW
+    a, b = make(1), make(1)
+    dpa, dpb = FlatGradAllReduce(a.parameters()), FlatGradAllReduce(b.parameters())
+    oa = FlatAdamW(dpa, lr=1e-2, weight_decay=0.05, max_grad_norm=0.5)
+    ob = FlatAdamW(dpb, lr=1e-2, weight_decay=0.05, max_grad_norm=0.5)
+    dpa.world, dpa.scale_in_optimizer = world, True
+    for it in range(4):
+        x = torch.randn(16, 37, device="cuda", generator=torch.Generator("cuda").manual_seed(it))
+        for m, dp in ((a, dpa), (b, dpb)):
+            dp.zero_grad()
+            (m(x).pow(2).sum() * 10 * world).backward()       # "the sum over ranks"
+        dpb.flat.mul_(1.0 / world)
+        oa.step(zero_grad=True)
+        ob.step()
+        assert torch.equal(oa.flat_p, ob.flat_p) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq), it
+        assert float(dpa.flat.abs().max()) == 0.0
