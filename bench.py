@@ -95,6 +95,9 @@ def parse():
     ap.add_argument("--unfrozen", action="store_true", help="variant line: `freeze: False` -- the PointNet++ "
                     "backbone trains too (BatchNorm in training mode, encoder forward + backward inside the "
                     "captured step); use a smaller --batch (4 scenes: 3.9 GiB of saved activations)")
+    ap.add_argument("--window-step", action="store_true", help="with --accum A: the accumulation window as ONE pass "
+                    "(HotPathTrainStep micro_batches=A): encoder and trainable part run once over the A x batch scenes, "
+                    "the loss is taken per micro-batch slice, one optimiser step per pass")
     ap.add_argument("--no-window", action="store_true", help="with --accum: encode every micro-batch on its own "
                     "instead of the whole accumulation window in one encoder pass")
     ap.add_argument("--llm-layer", action="store_true", help="SECONDARY, labelled line: one LoRA-Llama decoder layer "
@@ -128,7 +131,7 @@ class Trainer:
     """The hot-path step.  Optimiser settings: optim/build.py + configs/msr3d.yaml:43-47
     (AdamW lr 3e-5, betas (0.9, 0.999), wd 0.05), grad clip 5.0 (leo_trainer.py:192-193)."""
 
-    def __init__(self, model, device, example_batch, E, use_graph, accum=1):
+    def __init__(self, model, device, example_batch, E, use_graph, accum=1, micro=1):
         from msr3d_amd.dp import FlatGradAllReduce
         from msr3d_amd.train_step import HotPathTrainStep
         self.model = model
@@ -161,7 +164,8 @@ class Trainer:
             return loss, y, state["g"]
 
         self.stepper = HotPathTrainStep(model, self.opt, self.dp, loss_fn, example_batch,
-                                        use_graph=use_graph, zero_in_optimizer=True, accum_steps=accum)
+                                        use_graph=use_graph, zero_in_optimizer=True, accum_steps=accum,
+                                        micro_batches=micro)
         if on_gpu and use_graph:
             self.stepper.capture(example_batch)
 
@@ -335,9 +339,14 @@ def main():
         model.visual_prompter.obj_encoder.skip_padded = True
     B = args.batch
     # distinct resident batches per rank, cycled (weak scaling: per-GPU work fixed)
-    n_resident = 4 if args.accum == 1 else max(4, 2 * args.accum)     # (a window's micro-batches are distinct)
-    batches = [synth_batch(1000 * rank + i, B, O=O, P=P, device=device) for i in range(n_resident)]
-    tr = Trainer(model, device, batches[0], args.llm_hidden, use_graph=not args.no_graph, accum=args.accum)
+    # --window-step: a call is a whole accumulation window (accum x B scenes back to back), one call per optimiser step
+    wstep = args.window_step and args.accum > 1 and not args.unfrozen
+    calls = 1 if wstep else args.accum                    # step calls per optimiser step
+    Bcall = B * args.accum if wstep else B                # scenes per call
+    n_resident = 4 if calls == 1 else max(4, 2 * calls)     # (a window's micro-batches are distinct)
+    batches = [synth_batch(1000 * rank + i, Bcall, O=O, P=P, device=device) for i in range(n_resident)]
+    tr = Trainer(model, device, batches[0], args.llm_hidden, use_graph=not args.no_graph, accum=calls,
+                 micro=args.accum if wstep else 1)
 
     # Software pipelining (msr3d_amd/train_step.py): the frozen encoder of batch k+1 runs on a
     # side stream while batch k trains.  Every timed step still encodes exactly one batch and
@@ -408,20 +417,20 @@ def main():
         tr.step = step_from_host
 
     # gradient accumulation over a frozen encoder: the whole window's objects go through ONE encoder pass
-    window = args.accum > 1 and not args.unfrozen and not args.no_window and not args.host_inputs
+    window = calls > 1 and not args.unfrozen and not args.no_window and not args.host_inputs
 
     def window_of(k):
-        return [batches[(k * args.accum + m) % n_resident] for m in range(args.accum)]
+        return [batches[(k * calls + m) % n_resident] for m in range(calls)]
 
     def run_window(k):
-        """optimiser step k = args.accum micro-steps"""
+        """optimiser step k = calls micro-steps"""
         if window and not tr.stepper.window_ready(window_of(k)):
             tr.stepper.encode_window(window_of(k))
-        for m in range(args.accum):
-            j = k * args.accum + m
+        for m in range(calls):
+            j = k * calls + m
             nb = nxt(j)
             if window:       # N > 1: the NEXT window's encoder pass is what runs beside the last micro-step's exchange
-                nb = window_of(k + 1) if (dist_on and pipe and m == args.accum - 1) else None
+                nb = window_of(k + 1) if (dist_on and pipe and m == calls - 1) else None
             tr.step(batches[j % n_resident], nb)
 
     for i in range(args.warmup):
@@ -498,7 +507,7 @@ def main():
         # positions x (131*128 + 128*128 + 128*256) MACs x 2 = 67.50 MFLOP; one launch = B*O objects.
         k_ms = kern_ms["msr3d_sa_level2"] or 0.0
         flop_per_obj = 512 * (131 * 128 + 128 * 128 + 128 * 256) * 2
-        objs_per_launch = float(B * O) * (args.accum if window else 1)    # (a whole window per encoder launch)
+        objs_per_launch = float(Bcall * O) * (calls if window else 1)    # (a whole window per encoder launch)
         if args.skip_padded:      # only real objects are encoded: count them over the timed steps
             first = args.warmup + (1 if pipe else 0)    # (pipelined: step i encodes batch i + 1)
             counts = [int(batches[(first + i) % n_resident]["obj_masks"].sum()) for i in range(args.steps)]
@@ -551,7 +560,7 @@ def main():
             "config": {"workload": "configs/msr3d.yaml hot path (OSE3DSituation + llm_proj, "
                                    "frozen PointNet++), synthetic ScanNet-like scenes",
                        "objects": O, "points": P, "per_gpu_batch": B, "global_batch": B * world * args.accum,
-                       "grad_accumulation": args.accum,
+                       "grad_accumulation": args.accum, "window_step": wstep,
                        "llm_hidden": args.llm_hidden, "situation_type": args.situation_type,
                        "step": "fwd+bwd+allreduce+clip+AdamW, LLM excluded",
                        "backbone": "unfrozen (freeze: False, BatchNorm in training mode)" if args.unfrozen

@@ -33,7 +33,7 @@ from . import hipops
 
 class HotPathTrainStep:
     def __init__(self, model, optimizer, dp, loss_fn, example_batch, use_graph=True, accum_steps=1,
-                 zero_in_optimizer=False):
+                 zero_in_optimizer=False, micro_batches=1):
         """model: MSR3DHotPath; dp: FlatGradAllReduce over its trainable params;
         loss_fn(scene_dict) -> scalar, or (scalar, tensor, d scalar / d tensor) when the caller
         already holds the upstream gradient; example_batch fixes the (static) shapes.
@@ -41,7 +41,19 @@ class HotPathTrainStep:
         configs/msr3d.yaml:33; accelerate scales each micro-batch loss by 1/accum_steps and
         synchronises / steps on the last one, trainer/leo_trainer.py:180-195): every call is one
         micro-batch; gradients add up in the flat buffer, the exchange, clip and AdamW run on every
-        accum_steps-th call."""
+        accum_steps-th call.
+        micro_batches = m > 1: the accumulation window as ONE pass -- `example_batch` (and every batch
+        given to a call) holds the m micro-batches of a window back to back along dim 0; encoder and
+        trainable part run once over all of them, loss_fn is called per micro-batch on its slice of the
+        outputs, each loss scaled by 1/m as accelerate scales it.  Same gradients as m accumulated calls
+        (no operation of the path couples scenes; dropout masks are drawn per window instead of per
+        micro-batch), one optimiser step per call; what stays per-micro-batch is whatever consumes
+        `scene_embeds` downstream (the language model, whose memory is why the reference accumulates)."""
+        self.micro_batches = int(micro_batches)
+        if self.micro_batches < 1 or example_batch["obj_fts"].shape[0] % self.micro_batches:
+            raise ValueError("micro_batches must divide the window's scene count")
+        if self.micro_batches > 1 and int(accum_steps) != 1:
+            raise ValueError("micro_batches (a window per call) and accum_steps (a micro-batch per call) exclude each other")
         self.model, self.opt, self.dp, self.loss_fn = model, optimizer, dp, loss_fn
         self.prompter = model.visual_prompter
         # freeze: False -- the encoder is part of the differentiated (and captured) step: its pass cannot
@@ -102,6 +114,8 @@ class HotPathTrainStep:
         if self.unfrozen:
             inp.pop("obj_embeds")        # computed under autograd from the static point clouds
         out = self.model(inp)
+        if self.micro_batches > 1:
+            return self._window_loss(out)
         res = self.loss_fn(out)
         scale = 1.0 / self.accum_steps
         if isinstance(res, tuple):
@@ -113,6 +127,33 @@ class HotPathTrainStep:
             loss = res
             (loss if self.accum_steps == 1 else loss * scale).backward()
         return loss.detach()
+
+    def _window_loss(self, out):
+        """loss_fn per micro-batch on its slice of the window's outputs, 1/m each; ONE backward."""
+        m = self.micro_batches
+        n = out["scene_embeds"].shape[0]
+        per = n // m
+        parts = []
+        for i in range(m):
+            parts.append(self.loss_fn({k: (v[i * per:(i + 1) * per] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n
+                                           else v) for k, v in out.items()}))
+        if isinstance(parts[0], tuple):
+            # (loss, slice of an output, its upstream gradient): the slices are views of one tensor
+            y0 = parts[0][1]
+            base = [v for v in out.values() if torch.is_tensor(v) and v.requires_grad and v.shape[0] == n
+                    and v.data_ptr() == y0.data_ptr() and v.shape[1:] == y0.shape[1:]]
+            if not base:
+                raise ValueError("window step: loss_fn must return (a slice of) one of the model's outputs")
+            base = base[0]
+            gy = torch.cat([g for _, _, g in parts], 0)
+            torch.autograd.backward([base], [gy * (1.0 / m)])
+            return torch.stack([l.detach() for l, _, _ in parts]).mean()
+        total = parts[0]
+        for l in parts[1:]:
+            total = total + l
+        total = total * (1.0 / m)
+        total.backward()
+        return total.detach()
 
     def _update(self, between=None):
         """Exchange + optimiser.  `between` (world > 1) is enqueued on the compute stream while the

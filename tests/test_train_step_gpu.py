@@ -343,3 +343,73 @@ def test_accumulation_window_encoded_in_one_pass_gives_the_same_step():
         if k.endswith("w_ks.bias"):
             continue
         assert torch.allclose(p0[k], p1[k], rtol=1e-4, atol=1e-6), k
+
+
+@pytest.mark.parametrize("explicit_grad", [False, True])
+def test_window_step_equals_the_accumulated_micro_steps(explicit_grad):
+    """micro_batches = m: the whole accumulation window in ONE pass (encoder, trainable part and backward once over
+    m x B scenes, loss per micro-batch slice scaled 1/m) == m accumulated micro-steps: same gradient buffer
+    (fp32 rounding of a different summation order), same weights after the optimiser step, captured graph."""
+    import msr3d_amd.model  # noqa: F401
+    import msr3d_amd.modules  # noqa: F401
+    from msr3d_amd import hipops
+    from msr3d_amd.config import AttrDict, default_prompter_cfg
+    from msr3d_amd.dp import FlatGradAllReduce
+    from msr3d_amd.model import build_model
+    from msr3d_amd.optim import FlatAdamW
+    from msr3d_amd.synth import synth_batch
+    from msr3d_amd.train_step import HotPathTrainStep
+    m, B, O, E = 3, 2, 24, 256
+    w = torch.linspace(-1, 1, B * O * E, device="cuda").view(B, O, E)
+    g = w / w.numel()
+
+    def loss_fn(o):
+        y = o["scene_embeds"]
+        assert y.shape[0] == B                      # always ONE micro-batch's scenes
+        if explicit_grad:
+            return (y.detach() * w).mean(), y, g
+        return (y * w).mean()
+
+    outs = []
+    for window in (False, True):
+        torch.manual_seed(0)
+        cfg = AttrDict({"prompter": default_prompter_cfg(dropout=0.0), "llm_hidden_size": E,
+                        "model": {"name": "MSR3DHotPath"}})
+        model = build_model(cfg).cuda().train()
+        dp = FlatGradAllReduce([p for p in model.parameters() if p.requires_grad],
+                               pack_groups=hipops.collect_pack_groups(model))
+        opt = FlatAdamW(dp, lr=1e-3, weight_decay=0.0)
+        hipops.attach_packed_views(model, dp, opt)
+        micro = [synth_batch(300 + i, B, O=O, P=1024, device="cuda") for i in range(m)]
+        if window:
+            whole = {k: torch.cat([b[k] for b in micro], 0) for k in micro[0]}
+            step = HotPathTrainStep(model, opt, dp, loss_fn, whole, use_graph=True, micro_batches=m)
+            step.capture(whole)
+            losses = [float(step(whole))]
+        else:
+            step = HotPathTrainStep(model, opt, dp, loss_fn, micro[0], use_graph=True, accum_steps=m)
+            step.capture(micro[0])
+            losses = [float(step(b)) for b in micro]
+        torch.cuda.synchronize()
+        outs.append((sum(losses) / len(losses), dp.flat.detach().clone(),
+                     {k: v.detach().clone() for k, v in model.named_parameters() if v.requires_grad}))
+    (l0, g0, p0), (l1, g1, p1) = outs
+    assert l0 == pytest.approx(l1, rel=1e-5)
+    assert float(g0.abs().max()) > 0
+    assert float((g0 - g1).norm() / g0.norm()) < 2e-5
+    # (the first Adam step moves every weight by ~lr * sign(g): where g is rounding noise around zero the two
+    # summation orders may disagree on the sign -- bounded by 2 lr, and rare)
+    for k in p0:
+        assert torch.allclose(p0[k], p1[k], rtol=0, atol=2.1e-3), k
+        assert float(((p0[k] - p1[k]).abs() > 1e-5).float().mean()) < 0.02 or k.endswith("w_ks.bias"), k
+
+
+def test_window_step_rejects_what_it_cannot_slice():
+    import msr3d_amd.model  # noqa: F401
+    from msr3d_amd.train_step import HotPathTrainStep
+    from msr3d_amd.synth import synth_batch
+    b = synth_batch(1, 3, O=4, P=64, device="cuda")
+    with pytest.raises(ValueError):
+        HotPathTrainStep(None, None, None, None, b, micro_batches=2)           # 3 scenes, 2 micro-batches
+    with pytest.raises(ValueError):
+        HotPathTrainStep(None, None, None, None, b, micro_batches=3, accum_steps=2)
