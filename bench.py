@@ -95,9 +95,11 @@ def parse():
     ap.add_argument("--unfrozen", action="store_true", help="variant line: `freeze: False` -- the PointNet++ "
                     "backbone trains too (BatchNorm in training mode, encoder forward + backward inside the "
                     "captured step); use a smaller --batch (4 scenes: 3.9 GiB of saved activations)")
-    ap.add_argument("--window-step", action="store_true", help="with --accum A: the accumulation window as ONE pass "
-                    "(HotPathTrainStep micro_batches=A): encoder and trainable part run once over the A x batch scenes, "
-                    "the loss is taken per micro-batch slice, one optimiser step per pass")
+    ap.add_argument("--window-step", action="store_true", help="(default with --accum A) the accumulation window as ONE "
+                    "pass (HotPathTrainStep micro_batches=A): encoder and trainable part run once over the A x batch "
+                    "scenes, the loss is taken per micro-batch slice, one optimiser step per pass")
+    ap.add_argument("--micro-steps", action="store_true", help="with --accum A: A accumulated calls of --batch scenes "
+                    "each (graph replay per micro-batch) instead of the window step")
     ap.add_argument("--no-window", action="store_true", help="with --accum: encode every micro-batch on its own "
                     "instead of the whole accumulation window in one encoder pass")
     ap.add_argument("--llm-layer", action="store_true", help="SECONDARY, labelled line: one LoRA-Llama decoder layer "
@@ -340,7 +342,7 @@ def main():
     B = args.batch
     # distinct resident batches per rank, cycled (weak scaling: per-GPU work fixed)
     # --window-step: a call is a whole accumulation window (accum x B scenes back to back), one call per optimiser step
-    wstep = args.window_step and args.accum > 1 and not args.unfrozen
+    wstep = not args.micro_steps and args.accum > 1 and not args.unfrozen and not args.host_inputs and not args.from_store
     calls = 1 if wstep else args.accum                    # step calls per optimiser step
     Bcall = B * args.accum if wstep else B                # scenes per call
     n_resident = 4 if calls == 1 else max(4, 2 * calls)     # (a window's micro-batches are distinct)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 9
+#define MSR3D_ABI_VERSION 10
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -726,8 +726,20 @@ int msr3d_transpose_bf16(int outer, int inner, int rows, int cols, const void *s
                          long long src_inner, void *dst, int ld_dst, long long dst_outer, long long dst_inner,
                          msr3d_stream_t stream);
 
+/* C (M, N) = scale * P Q^T for a Q of N <= 64 rows (N % 16 == 0; the LoRA down-projections x A^T and dy B), and
+ * C[:, N:zero_to] = 0 (the padding the low-rank K step of msr3d_bf16_gemm_lowrank reads).  P (M, K), Q (N, K)
+ * k-contiguous bf16, K % 32 == 0; C bf16.  (peft's lora_A / lora_B applications, model/msr3d/msr3d.py:103-112.) */
+int msr3d_bf16_gemm_skinny(int M, int N, int K, const void *P, int ldp, const void *Q, int ldq, void *C, int ldc,
+                           int zero_to, float scale, msr3d_stream_t stream);
+
+/* out (R, C) fp32 -- or its transpose (C, R) -- += scale * sum_m P[m][r] Q[m][c]: the LoRA weight gradients
+ * dA = (s dy B)^T x and dB = dy^T (s x A^T) (peft's lora_A / lora_B, model/msr3d/msr3d.py:103-112; R = 16 or 32).
+ * P (M, R), Q (M, C) bf16.  workspace (64 * R * C floats, 16-byte aligned; may be NULL): the row chunks' partial sums
+ * are added up in a fixed order by a second launch -- bit-reproducible; without it 16 chunks meet by atomicAdd. */
+#define MSR3D_LORA_GRAD_CHUNKS 64
 int msr3d_lora_grad(int M, int R, int C, const void *P, int ldp, const void *Q, int ldq, float *out,
-                    int transpose_out, float scale, msr3d_stream_t stream);
+                    int transpose_out, float scale, float *workspace, long long workspace_floats,
+                    msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Optimiser step of the hot path: global-norm clip + AdamW over flat buffers

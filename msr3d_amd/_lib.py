@@ -101,7 +101,9 @@ _SIGNATURES = {
     "msr3d_swiglu_bwd": [ctypes.c_longlong, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_transpose_bf16": [_c_int, _c_int, _c_int, _c_int, _ptr, _c_int, ctypes.c_longlong, ctypes.c_longlong,
                              _ptr, _c_int, ctypes.c_longlong, ctypes.c_longlong, _ptr],
-    "msr3d_lora_grad": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_float, _ptr],
+    "msr3d_bf16_gemm_skinny": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _c_float, _ptr],
+    "msr3d_lora_grad": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_float, _ptr,
+                        ctypes.c_longlong, _ptr],
     "msr3d_sa_level_split": [_c_int, _c_int, _c_int, _c_int, _c_float] + [_ptr] * 13,
     "msr3d_seq_ce_fwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_seq_ce_bwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
@@ -185,7 +187,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string", "msr3d_sqdist_contract"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 9        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 10        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():

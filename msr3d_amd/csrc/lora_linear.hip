@@ -21,6 +21,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 #include "../../include/msr3d_hip.h"
 
@@ -265,39 +266,319 @@ __global__ __launch_bounds__(256, 1) void bf16_gemm_glds_kernel(const GemmArgs a
   }
 }
 
-// out (R, C) (or its transpose) += sum_m P[m][r] * Q[m][c]: thread = column c, R accumulators;
-// rows split over blockIdx.y, meeting by atomicAdd.  P (M, R) bf16 is broadcast from LDS.
-template <int R>
-__global__ __launch_bounds__(256) void lora_grad_kernel(int M, int C, const unsigned short *__restrict__ P, int ldp,
-                                                        const unsigned short *__restrict__ Q, int ldq,
-                                                        float *__restrict__ out, int transpose_out, float scale) {
-  __shared__ float ps[64][R];
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  const int per = (M + gridDim.y - 1) / gridDim.y;
-  const int mb = blockIdx.y * per, me = min(M, mb + per);
-  float acc[R];
+// ---- the wide-tile kernel: (16 MTB) x 256 tile, 8 waves side by side along N ----------------------------------
+// The 4-wave kernels above keep one wave per SIMD in lockstep: every LDS-DMA piece a wave issues (~60-180 cycles
+// of issue each, 10 per K step) and every wait at the K step's barrier is time its SIMD's matrix pipe idles.  Here
+// a workgroup is 8 waves = two per SIMD, each owning ALL the tile's rows (MTB MFMA tiles) x 32 columns, so one
+// wave's staging runs under the other's MFMAs, and the tile height is chosen per problem from {128, 144, 160} so
+// that the tile count lands on whole rounds of the 256 CUs: the language model's M = 2304 tokens x N = 4096 is
+// 16 x 16 = 256 tiles of 144 x 256 -- one per CU, one round (192 x 128: 384 tiles, 1.5).
+// Three LDS stages of (BM + 256) x 64 bf16 filled by LDS-DMA (source-side XOR swizzle as above), two K steps in
+// flight, one raw s_barrier per K step, counted vmcnt; the pieces of the next-but-one stage are issued between
+// the MFMAs.  Tiles are numbered so that each XCD (blockIdx % 8) owns a compact 8 (M) x 4 (N) patch of them.
+//
+// Measured on 2304 x 4096 x 4096 (tools/bench_bf16_gemm.py, ablation builds of this file): 85 us = 900 TFLOP/s;
+// alone, the fragment reads take 30 us (the LDS delivers ~156 B/clk to 8 waves reading 22 KB each per K step),
+// the MFMAs 27 us (= the matrix pipe's rate), the staging 25 us, over a 20 us floor (launch, 64 barriers, 19 MB
+// of C) -- and the three overlap little: all waves read, then all multiply.  A finer pipeline (ring of six
+// 32-deep units, next unit's fragments read under this unit's MFMAs) was built and measured SLOWER (104 us):
+// 64-byte rows double the DMA's cache-line requests (staging alone 61 -> 85 us) and twice the barriers eat what
+// the read/MFMA overlap gives.
+constexpr int WBN = 256;
+
+template <int MTB>
+__global__ __launch_bounds__(512, 1) void bf16_gemm_wide_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
+  constexpr int BM = 16 * MTB;
+  constexpr int STAGE = (BM + WBN) * BK;                 // bf16 elements per stage
+  constexpr int PIECES = (BM + WBN) / 8;                 // 1 KB wave-pieces per stage (8 rows x 128 B)
+  constexpr int NP = (PIECES + 7) / 8;                   // per wave, at most
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, g = lane >> 4;
+
+  // tile of this workgroup: XCD x = id % 8 takes a contiguous run of the patch order (4-tile-wide panels, M-major)
+  int tm, tn;
+  {
+    const int T = tiles_m * tiles_n, id = blockIdx.x;
+    const int q = T / 8, r = T % 8, x = id % 8;
+    const int t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + id / 8;
+    const int per_panel = tiles_m * 4, p = t / per_panel, rem = t - p * per_panel;
+    const int w = min(4, tiles_n - 4 * p);
+    tm = rem / w;
+    tn = 4 * p + rem - tm * w;
+  }
+  const int m0 = tm * BM, n0 = tn * WBN;
+  const int bo = blockIdx.z / a.inner, bi = blockIdx.z - bo * a.inner;
+  const unsigned short *P = a.P + bo * a.spo + bi * a.spi, *Q = a.Q + bo * a.sqo + bi * a.sqi;
+
+  f32x4 acc[MTB][2];
 #pragma unroll
-  for (int r = 0; r < R; ++r) acc[r] = 0.f;
-  for (int m0 = mb; m0 < me; m0 += 64) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < 64 * R; e += 256) {
-      const int mm = e / R, r = e - mm * R;
-      ps[mm][r] = (m0 + mm < me) ? __uint_as_float((unsigned)P[(size_t)(m0 + mm) * ldp + r] << 16) : 0.f;
+  for (int x = 0; x < MTB; ++x) acc[x][0] = acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk_main = a.K / BK, nk = nk_main + (a.R + BK - 1) / BK;
+  // this wave's pieces: piece = wave + 8 j; rows 8 piece .. + 7 of the stage image (first BM rows: P, then Q)
+  const int np = (PIECES - wave + 7) / 8;                // wave-uniform
+  unsigned off1[NP], off2[NP];                           // element offsets of this lane's 16 bytes, main / low-rank pass
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int piece = min(wave + 8 * j, PIECES - 1), row = 8 * piece + (lane >> 3), c = (lane & 7) ^ (row & 7);
+    const bool isA = row < BM;
+    const int r = isA ? min(m0 + row, a.M - 1) : min(n0 + row - BM, a.N - 1);
+    off1[j] = (unsigned)r * (unsigned)(isA ? a.ldp : a.ldq) + c * 8;
+    off2[j] = (unsigned)r * (unsigned)(isA ? a.ldp2 : a.ldq2) + c * 8;
+  }
+  auto issue_piece = [&](int kt, int j) {                // piece j of stage kt -> LDS buffer kt % 3
+    const bool main = kt < nk_main;
+    const int k0 = main ? kt * BK : (kt - nk_main) * BK;
+    const bool isA = wave + 8 * j < BM / 8;              // (wave-uniform)
+    const unsigned short *base = isA ? (main ? P : a.P2) : (main ? Q : a.Q2);
+    const unsigned short *src = base + (main ? off1[j] : off2[j]) + k0;
+    unsigned short *dst = lds + (kt % 3) * STAGE + (wave + 8 * j) * 512;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+  };
+  auto issue = [&](int kt) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+      if (j < np) issue_piece(kt, j);
+  };
+  issue(0);
+  if (nk > 1) issue(1);
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt landed (this wave's pieces; the barrier extends it to everyone's); stage kt + 1 may still fly
+    if (kt + 1 < nk) {
+      if (np == NP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP - 1) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __syncthreads();
-    if (c < C) {
-      const int lim = min(64, me - m0);
-      for (int mm = 0; mm < lim; ++mm) {
-        const float q = __uint_as_float((unsigned)Q[(size_t)(m0 + mm) * ldq + c] << 16);
+    __builtin_amdgcn_s_barrier();               // ... and every wave is done reading stage kt - 1
+    const unsigned short *As = lds + (kt % 3) * STAGE, *Bs = As + BM * BK;
+    const bool more = kt + 2 < nk;
+    bf16x8 fa[2][MTB], fb[2][2];
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = fmaf(ps[mm][r], q, acc[r]);
+    for (int ks = 0; ks < 2; ++ks) {
+      const int pos = ((4 * ks + g) ^ (i & 7)) * 8;
+#pragma unroll
+      for (int y = 0; y < 2; ++y) fb[ks][y] = *reinterpret_cast<const bf16x8 *>(Bs + (wave * 32 + y * 16 + i) * BK + pos);
+#pragma unroll
+      for (int x = 0; x < MTB; ++x) fa[ks][x] = *reinterpret_cast<const bf16x8 *>(As + (x * 16 + i) * BK + pos);
+    }
+    // 2 MTB x 2 MFMAs; the next-but-one stage's pieces are issued among them (into the buffer stage kt - 1 held)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int x = 0; x < MTB; ++x) {
+        acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][0], fa[ks][x], acc[x][0], 0, 0, 0);
+        acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][1], fa[ks][x], acc[x][1], 0, 0, 0);
+        const int slot = ks * MTB + x;                   // 0 .. 2 MTB - 1: one piece every other slot
+        if (more && (slot & 1) == 0 && slot / 2 < NP && slot / 2 < np) issue_piece(kt + 2, slot / 2);
       }
     }
   }
-  if (c < C) {
+  // epilogue: D = Q P^T -- lane (i, g) holds columns n = 4 g + r of row m = i
+#pragma unroll
+  for (int x = 0; x < MTB; ++x) {
+    const int row = m0 + x * 16 + i;
+    if (row >= a.M) continue;
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int col = n0 + wave * 32 + y * 16 + 4 * g;
+      if (col >= a.N) continue;
+      const float v0 = acc[x][y][0] * a.scale, v1 = acc[x][y][1] * a.scale, v2 = acc[x][y][2] * a.scale,
+                  v3 = acc[x][y][3] * a.scale;
+      const size_t o = (size_t)(bo * a.sco + bi * a.sci) + (size_t)row * a.ldc + col;
+      if (col + 3 < a.N) {
+        if (a.c_f32) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(a.C) + o) = make_float4(v0, v1, v2, v3);
+        else *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(a.C) + o) =
+            make_uint2(f2bf(v0) | ((unsigned)f2bf(v1) << 16), f2bf(v2) | ((unsigned)f2bf(v3) << 16));
+      } else {
+        const float vv[4] = {v0, v1, v2, v3};
+        for (int r = 0; r < 4 && col + r < a.N; ++r) {
+          if (a.c_f32) reinterpret_cast<float *>(a.C)[o + r] = vv[r];
+          else reinterpret_cast<unsigned short *>(a.C)[o + r] = f2bf(vv[r]);
+        }
+      }
+    }
+  }
+}
+
+// out (R, C) (or its transpose) += scale * sum_m P[m][r] * Q[m][c]      (the LoRA weight gradients: the token
+// reduction of a (M, 16) against a (M, 4096..11008) bf16 matrix).  Bound by reading Q once (19-51 MB), so the rows
+// are cut into enough chunks to put a workgroup on every CU (up to kGradChunks): a lane owns 128 / R adjacent
+// columns (one 16-byte load per row at R = 16) and walks its chunk with R x 8 fp32 accumulators in registers, eight
+// rows' loads in flight; the chunk's P values are broadcast from LDS as float4.  The chunks' partial results go to
+// a workspace as plain stores and a second launch adds them up in chunk order (deterministic; 64 atomicAdds per
+// output element were 4 M memory-side atomics) -- without a workspace: 16 chunks and atomicAdd.
+// (Round 2's column-per-thread kernel, one 2-byte load and 16 LDS reads per row and thread: 112 us at 2304 x 4096.)
+constexpr int kGradChunks = 64, kGradChunksAtomic = 16;
+
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+template <int R>
+__global__ __launch_bounds__(256) void lora_grad_kernel(int M, int C, const unsigned short *__restrict__ P, int ldp,
+                                                        const unsigned short *__restrict__ Q, int ldq,
+                                                        float *__restrict__ out, int transpose_out, float scale,
+                                                        float *__restrict__ ws) {
+  constexpr int CPL = 128 / R;                         // columns per lane: 8 (R = 16) or 4 (R = 32)
+  constexpr int ROWS = 64;                             // rows of P staged per pass
+  constexpr int PF = 8;                                // rows in flight
+  __shared__ __attribute__((aligned(16))) float ps[ROWS][R];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = (blockIdx.x * 4 + wave) * 64 * CPL + lane * CPL;
+  const int per = (M + gridDim.y - 1) / gridDim.y;
+  const int mb = blockIdx.y * per, me = min(M, mb + per);
+  const bool live = c0 < C;                            // (C is a multiple of CPL: checked by the caller)
+  using qvec = typename std::conditional<CPL == 8, uint4, uint2>::type;
+  float acc[R][CPL];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) acc[r][j] = 0.f;
+  for (int m0 = mb; m0 < me; m0 += ROWS) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < ROWS * R; e += 256) {
+      const int mm = e / R, r = e - mm * R;
+      ps[mm][r] = (m0 + mm < me) ? bf_lo(P[(size_t)(m0 + mm) * ldp + r]) : 0.f;
+    }
+    __syncthreads();
+    if (!live) continue;
+    const int lim = min(ROWS, me - m0);
+    const unsigned short *q = Q + (size_t)m0 * ldq + c0;
+    for (int mb8 = 0; mb8 < lim; mb8 += PF) {
+      qvec v[PF];
+#pragma unroll
+      for (int u = 0; u < PF; ++u)                     // (rows past the chunk re-read its last row: their P is zero)
+        v[u] = *reinterpret_cast<const qvec *>(q + (size_t)min(mb8 + u, lim - 1) * ldq);
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int mm = mb8 + u;                        // (< ROWS: ROWS is a multiple of PF)
+        float qv[CPL];
+        if constexpr (CPL == 8) {
+          qv[0] = bf_lo(v[u].x); qv[1] = bf_hi(v[u].x); qv[2] = bf_lo(v[u].y); qv[3] = bf_hi(v[u].y);
+          qv[4] = bf_lo(v[u].z); qv[5] = bf_hi(v[u].z); qv[6] = bf_lo(v[u].w); qv[7] = bf_hi(v[u].w);
+        } else {
+          qv[0] = bf_lo(v[u].x); qv[1] = bf_hi(v[u].x); qv[2] = bf_lo(v[u].y); qv[3] = bf_hi(v[u].y);
+        }
+        const float live_row = mm < lim ? 1.f : 0.f;
+#pragma unroll
+        for (int r4 = 0; r4 < R; r4 += 4) {
+          const float4 pv = *reinterpret_cast<const float4 *>(&ps[mm][r4]);
+          const float pp[4] = {pv.x * live_row, pv.y * live_row, pv.z * live_row, pv.w * live_row};
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) acc[r4 + k][j] = fmaf(pp[k], qv[j], acc[r4 + k][j]);
+        }
+      }
+    }
+  }
+  if (!live) return;
+  if (ws) {                                            // partial (chunk, R, C), plain 16-byte stores
+    float *w = ws + (size_t)blockIdx.y * R * C + c0;
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      atomicAdd(out + (transpose_out ? (size_t)c * R + r : (size_t)r * C + c), acc[r] * scale);
+#pragma unroll
+      for (int j = 0; j < CPL; j += 4)
+        *reinterpret_cast<float4 *>(w + (size_t)r * C + j) = make_float4(acc[r][j], acc[r][j + 1], acc[r][j + 2], acc[r][j + 3]);
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int j = 0; j < CPL; ++j)
+      atomicAdd(out + (transpose_out ? (size_t)(c0 + j) * R + r : (size_t)r * C + c0 + j), acc[r][j] * scale);
+}
+
+// out (+)= scale * sum over the chunks' partials, in chunk order; thread = 4 adjacent columns of one r
+__global__ __launch_bounds__(256) void lora_grad_reduce_kernel(int R, int C, int chunks, const float *__restrict__ ws,
+                                                               float *__restrict__ out, int transpose_out, float scale) {
+  const int e = blockIdx.x * 256 + threadIdx.x;       // over R * C / 4
+  if (e >= R * (C / 4)) return;
+  const int r = e / (C / 4), c = 4 * (e - r * (C / 4));
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float *w = ws + (size_t)r * C + c;
+  for (int k = 0; k < chunks; ++k) {
+    const float4 v = *reinterpret_cast<const float4 *>(w + (size_t)k * R * C);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  if (transpose_out) {
+    float *o = out + (size_t)c * R + r;
+    o[0] += s.x * scale; o[R] += s.y * scale; o[2 * R] += s.z * scale; o[3 * R] += s.w * scale;
+  } else {
+    float4 *o = reinterpret_cast<float4 *>(out + (size_t)r * C + c);
+    float4 t = *o;
+    t.x += s.x * scale; t.y += s.y * scale; t.z += s.z * scale; t.w += s.w * scale;
+    *o = t;
+  }
+}
+
+// C (M, N <= 64) = scale * P Q^T for a Q of a few rows (the LoRA down-projections x A^T and dy B: N = 16 of
+// 64 padded columns), and C[:, N:zero_to] = 0.  A tile of the big kernels would put this on 18 CUs; here a
+// workgroup owns 16 rows of P, its four waves each a quarter of K, fragments loaded straight from global memory
+// (P is read once; the 16 x K operand Q stays in L2), and the four partial tiles meet in LDS.
+template <int NT>
+__global__ __launch_bounds__(256) void bf16_gemm_skinny_kernel(int M, int N, int K, const unsigned short *__restrict__ P,
+                                                               int ldp, const unsigned short *__restrict__ Q, int ldq,
+                                                               unsigned short *__restrict__ C, int ldc, int zero_to,
+                                                               float scale) {
+  __shared__ __attribute__((aligned(16))) float red[4][NT][64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * 16;
+  const int nks = K / 32, ks0 = wave * nks / 4, ks1 = (wave + 1) * nks / 4;
+  const unsigned short *p = P + (size_t)min(m0 + i, M - 1) * ldp + 8 * g;
+  const unsigned short *q[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) q[t] = Q + (size_t)min(16 * t + i, N - 1) * ldq + 8 * g;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 4;                                 // K steps in flight
+  int ks = ks0;
+  for (; ks + U <= ks1; ks += U) {
+    bf16x8 fp[U], fq[U][NT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      fp[u] = *reinterpret_cast<const bf16x8 *>(p + (ks + u) * 32);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) fq[u][t] = *reinterpret_cast<const bf16x8 *>(q[t] + (ks + u) * 32);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[u][t], fp[u], acc[t], 0, 0, 0);
+  }
+  for (; ks < ks1; ++ks) {
+    const bf16x8 fp = *reinterpret_cast<const bf16x8 *>(p + ks * 32);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q[t] + ks * 32), fp, acc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4 *>(&red[wave][t][lane][0]) = acc[t];
+  __syncthreads();
+  // D = Q P^T: lane (i, g) of tile t holds columns n = 16 t + 4 g + r of row m = i; wave w finishes tiles w, w + 4 ..
+  const int row = m0 + i;
+  for (int t = wave; t < NT; t += 4) {
+    f32x4 v = *reinterpret_cast<const f32x4 *>(&red[0][t][lane][0]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const f32x4 o = *reinterpret_cast<const f32x4 *>(&red[w][t][lane][0]);
+      v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+    }
+    const int col = 16 * t + 4 * g;
+    if (row < M && col < N)              // (N is a multiple of 4)
+      *reinterpret_cast<uint2 *>(C + (size_t)row * ldc + col) =
+          make_uint2(f2bf(v[0] * scale) | ((unsigned)f2bf(v[1] * scale) << 16),
+                     f2bf(v[2] * scale) | ((unsigned)f2bf(v[3] * scale) << 16));
+  }
+  // the padding columns the next product reads as part of its K step
+  for (int e = threadIdx.x; e < 16 * ((zero_to - N) / 4); e += 256) {
+    const int r = e / ((zero_to - N) / 4), c = N + 4 * (e - r * ((zero_to - N) / 4));
+    if (m0 + r < M) *reinterpret_cast<uint2 *>(C + (size_t)(m0 + r) * ldc + c) = make_uint2(0u, 0u);
   }
 }
 
@@ -325,18 +606,47 @@ int launch_gemm_glds(const GemmArgs &a, int batch, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-std::atomic<int> g_gemm_path{-1};                // -1: read MSR3D_BF16_GEMM (glds | reg) on first use
+template <int MTB>
+int launch_gemm_wide(const GemmArgs &a, int batch, hipStream_t st) {
+  constexpr int BM = 16 * MTB;
+  constexpr size_t lds = sizeof(unsigned short) * 3 * (BM + WBN) * BK;        // 144: 153,600 B
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&bf16_gemm_wide_kernel<MTB>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr != hipSuccess) return (int)attr;
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + WBN - 1) / WBN;
+  bf16_gemm_wide_kernel<MTB><<<dim3(tiles_m * tiles_n, 1, batch), 512, lds, st>>>(a, tiles_m, tiles_n);
+  return (int)hipGetLastError();
+}
+
+std::atomic<int> g_gemm_path{-1};                // -1: read MSR3D_BF16_GEMM (wide | glds | reg) on first use
 
 int gemm_dispatch(GemmArgs &a, int batch, hipStream_t st) {
   int path = g_gemm_path.load(std::memory_order_relaxed);
   if (path < 0) {
     const char *e = getenv("MSR3D_BF16_GEMM");
-    path = (e && e[0] == 'r') ? 0 : 1;
+    path = (e && e[0] == 'r') ? 0 : (e && e[0] == 'g') ? 1 : 2;
     g_gemm_path.store(path, std::memory_order_relaxed);
+  }
+  // wide tiles: big products whose offsets fit the kernel's 32-bit element offsets; tile height = the one with the
+  // least (rounds of 256 CUs) x height
+  if (path == 2 && a.M >= 128 && a.N >= 256 && (a.R % BK) == 0 &&
+      (long long)a.M * a.ldp < (1ll << 31) && (long long)a.N * a.ldq < (1ll << 31) &&
+      (a.R == 0 || ((long long)a.M * a.ldp2 < (1ll << 31) && (long long)a.N * a.ldq2 < (1ll << 31)))) {
+    const int tn = (a.N + WBN - 1) / WBN;
+    long long best = -1;
+    int bm = 0;
+    for (int h : {160, 144, 128}) {
+      const long long tiles = (long long)((a.M + h - 1) / h) * tn * batch, cost = (tiles + 255) / 256 * h;
+      if (best < 0 || cost < best) best = cost, bm = h;
+    }
+    // (fewer tiles than half the chip: the 128-wide tiles of the 4-wave kernels spread the product further)
+    if ((long long)((a.M + bm - 1) / bm) * tn * batch >= 128)
+      return bm == 160 ? launch_gemm_wide<10>(a, batch, st) : bm == 144 ? launch_gemm_wide<9>(a, batch, st)
+                                                                        : launch_gemm_wide<8>(a, batch, st);
   }
   // LDS-DMA path: rows >= 16 bytes-aligned sources (checked by the callers) and R a multiple of 64 (a stage
   // reads 64 columns of the low-rank pair)
-  if (path == 1 && a.M >= 192 && (a.R % BK) == 0) return launch_gemm_glds<192>(a, batch, st);
+  if (path >= 1 && a.M >= 192 && (a.R % BK) == 0) return launch_gemm_glds<192>(a, batch, st);
   // tile height: the one that wastes fewer padded rows; 192 on a tie at >= 192 rows (fewer LDS reads per MFMA)
   const long long w128 = (long long)((a.M + 127) / 128) * 128, w192 = (long long)((a.M + 191) / 192) * 192;
   return (a.M >= 192 && w192 <= w128) ? launch_gemm<192>(a, batch, st) : launch_gemm<128>(a, batch, st);
@@ -389,20 +699,50 @@ int msr3d_bf16_gemm_batched(int outer, int inner, int M, int N, int K, const voi
 }
 
 int msr3d_lora_grad(int M, int R, int C, const void *P, int ldp, const void *Q, int ldq, float *out,
-                    int transpose_out, float scale, msr3d_stream_t stream) {
+                    int transpose_out, float scale, float *workspace, long long workspace_floats,
+                    msr3d_stream_t stream) {
   if (M < 0 || C < 0 || (R != 16 && R != 32)) return MSR3D_EINVAL;
   if (M == 0 || C == 0) return 0;
   if (!P || !Q || !out || ldp < R || ldq < C) return MSR3D_EINVAL;
-  int splits = (M + 255) / 256;
-  if (splits > 32) splits = 32;
-  dim3 grid((C + 255) / 256, splits);
+  const int cpl = 128 / R;                      // a lane's columns: one 16- / 8-byte load per row
+  if ((C % cpl) || (C % 4) || (ldq % cpl) || (reinterpret_cast<uintptr_t>(Q) & (2 * cpl - 1))) return MSR3D_EINVAL;
+  if (workspace && ((reinterpret_cast<uintptr_t>(workspace) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u)))
+    return MSR3D_EINVAL;
+  int chunks = (M + 31) / 32;
+  const int cap = workspace ? kGradChunks : kGradChunksAtomic;
+  if (chunks > cap) chunks = cap;
+  if (workspace && workspace_floats < (long long)chunks * R * C) return MSR3D_EINVAL;
+  dim3 grid((C + 256 * cpl - 1) / (256 * cpl), chunks);
   hipStream_t st = (hipStream_t)stream;
   if (R == 16)
     lora_grad_kernel<16><<<grid, 256, 0, st>>>(M, C, (const unsigned short *)P, ldp, (const unsigned short *)Q, ldq,
-                                               out, transpose_out, scale);
+                                               out, transpose_out, scale, workspace);
   else
     lora_grad_kernel<32><<<grid, 256, 0, st>>>(M, C, (const unsigned short *)P, ldp, (const unsigned short *)Q, ldq,
-                                               out, transpose_out, scale);
+                                               out, transpose_out, scale, workspace);
+  if (workspace)
+    lora_grad_reduce_kernel<<<(R * (C / 4) + 255) / 256, 256, 0, st>>>(R, C, chunks, workspace, out, transpose_out, scale);
+  return (int)hipGetLastError();
+}
+
+int msr3d_bf16_gemm_skinny(int M, int N, int K, const void *P, int ldp, const void *Q, int ldq, void *C, int ldc,
+                           int zero_to, float scale, msr3d_stream_t stream) {
+  if (M < 0 || N <= 0 || N > 64 || (N % 16) || K <= 0 || (K % 32) || zero_to < N || (zero_to % 4) || zero_to > ldc)
+    return MSR3D_EINVAL;
+  if (M == 0) return 0;
+  if (!P || !Q || !C || ldp < K || ldq < K || ldc < N || (ldp % 8) || (ldq % 8) || (ldc % 4) || !al16(P) || !al16(Q) ||
+      (reinterpret_cast<uintptr_t>(C) & 7u))
+    return MSR3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = (M + 15) / 16;
+  const unsigned short *p = (const unsigned short *)P, *q = (const unsigned short *)Q;
+  unsigned short *c = (unsigned short *)C;
+  switch (N / 16) {
+    case 1: bf16_gemm_skinny_kernel<1><<<grid, 256, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
+    case 2: bf16_gemm_skinny_kernel<2><<<grid, 256, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
+    case 3: bf16_gemm_skinny_kernel<3><<<grid, 256, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
+    default: bf16_gemm_skinny_kernel<4><<<grid, 256, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
+  }
   return (int)hipGetLastError();
 }
 

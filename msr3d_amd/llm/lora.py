@@ -17,7 +17,6 @@ import torch.nn as nn
 from .. import _lib
 
 PAD_R = 64          # the low-rank pair rides as one extra 64-wide K step (zero-padded)
-PAD_ROWS = 128      # A / B^T padded to one output tile when they are the GEMM's Q operand
 
 
 def _p(t):
@@ -32,6 +31,27 @@ def _gemm(M, N, K, R, P, ldp, Q, ldq, P2, ldp2, Q2, ldq2, C, ldc, c_f32, scale, 
     _lib.check(rc, "msr3d_bf16_gemm_lowrank")
 
 
+def _skinny(M, N, K, P, Q, C, ldc, scale, dev):
+    """C[:, :N] = scale P Q^T, C[:, N:ldc] = 0 (N = r rows of Q)."""
+    with torch.cuda.device(dev):
+        rc = _lib.load().msr3d_bf16_gemm_skinny(M, N, K, _p(P), K, _p(Q), K, _p(C), ldc, ldc, ctypes.c_float(scale),
+                                                _lib.current_stream_ptr(dev))
+    _lib.check(rc, "msr3d_bf16_gemm_skinny")
+
+
+_ws = {}
+
+
+def _grad_workspace(dev, floats):
+    """Partial sums of the weight-gradient row chunks (msr3d_lora_grad): one buffer per device and stream, grown
+    to the largest layer seen (64 chunks x r x 11008 floats = 45 MB at r = 16)."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    w = _ws.get(key)
+    if w is None or w.numel() < floats:
+        w = _ws[key] = torch.empty(floats, dtype=torch.float32, device=dev)
+    return w
+
+
 class _LoRAFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, lora_A, lora_B, mod):
@@ -42,11 +62,11 @@ class _LoRAFn(torch.autograd.Function):
         # bf16 shadows of the trainable pair in the orientations the products read: built once per weight
         # version (i.e. once per optimiser step), not per call
         a_pad, b2, _, _ = mod._shadows()
-        # u = s x A^T  (M, 128) bf16: the same kernel against the zero-padded A
-        u = torch.empty((M, PAD_ROWS), dtype=torch.bfloat16, device=dev)
-        _gemm(M, PAD_ROWS, K, 0, x2, K, a_pad, K, None, 0, None, 0, u, PAD_ROWS, False, s, dev)
+        # u = s x A^T  (M, r) bf16 in a zero-padded (M, 64): the r-row product has its own kernel
+        u = torch.empty((M, PAD_R), dtype=torch.bfloat16, device=dev)
+        _skinny(M, r, K, x2, a_pad, u, PAD_R, s, dev)
         y = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-        _gemm(M, N, K, PAD_R, x2, K, mod.weight, K, u, PAD_ROWS, b2, PAD_R, y, N, False, 1.0, dev)
+        _gemm(M, N, K, PAD_R, x2, K, mod.weight, K, u, PAD_R, b2, PAD_R, y, N, False, 1.0, dev)
         ctx.save_for_backward(x2, u, lora_A, lora_B)
         ctx.mod = mod
         ctx.shape = x.shape
@@ -62,13 +82,13 @@ class _LoRAFn(torch.autograd.Function):
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
         M = dy2.shape[0]
         _, _, bt_pad, at2 = mod._shadows()
-        # v = s dy B  (M, 128) bf16
-        v = torch.empty((M, PAD_ROWS), dtype=torch.bfloat16, device=dev)
-        _gemm(M, PAD_ROWS, N, 0, dy2, N, bt_pad, N, None, 0, None, 0, v, PAD_ROWS, False, s, dev)
+        # v = s dy B  (M, r) bf16 in a zero-padded (M, 64)
+        v = torch.empty((M, PAD_R), dtype=torch.bfloat16, device=dev)
+        _skinny(M, r, N, dy2, bt_pad, v, PAD_R, s, dev)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.bfloat16, device=dev)
-            _gemm(M, K, N, PAD_R, dy2, N, mod.weight_t, N, v, PAD_ROWS, at2, PAD_R, dx, K, False, 1.0, dev)
+            _gemm(M, K, N, PAD_R, dy2, N, mod.weight_t, N, v, PAD_R, at2, PAD_R, dx, K, False, 1.0, dev)
             dx = dx.view(ctx.shape)
         lib = _lib.load()
         dA = torch.zeros((r, K), dtype=torch.float32, device=dev)
@@ -76,9 +96,10 @@ class _LoRAFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             st = _lib.current_stream_ptr(dev)
             # dA = (s dy B)^T x = v^T x ; dB = dy^T (s x A^T) = dy^T u   (s already inside u and v)
-            rc = lib.msr3d_lora_grad(M, r, K, _p(v), PAD_ROWS, _p(x2), K, _p(dA), 0, ctypes.c_float(1.0), st)
+            ws = _grad_workspace(dev, 64 * r * max(K, N))
+            rc = lib.msr3d_lora_grad(M, r, K, _p(v), PAD_R, _p(x2), K, _p(dA), 0, ctypes.c_float(1.0), _p(ws), ws.numel(), st)
             _lib.check(rc, "msr3d_lora_grad")
-            rc = lib.msr3d_lora_grad(M, r, N, _p(u), PAD_ROWS, _p(dy2), N, _p(dB), 1, ctypes.c_float(1.0), st)
+            rc = lib.msr3d_lora_grad(M, r, N, _p(u), PAD_R, _p(dy2), N, _p(dB), 1, ctypes.c_float(1.0), _p(ws), ws.numel(), st)
             _lib.check(rc, "msr3d_lora_grad")
         return dx, dA, dB, None
 
@@ -105,18 +126,16 @@ class LoRALinear(nn.Module):
 
     def _shadows(self):
         """Zero-padded bf16 copies of A / B in the four orientations forward and backward read
-        (a_pad (128, K), b2 (N, 32), bt_pad (128, N), at2 (K, 32)); rebuilt when A or B has been written."""
+        (a_pad (r, K), b2 (N, 64), bt_pad (r, N), at2 (K, 64)); rebuilt when A or B has been written."""
         A, Bw = self.lora_A.weight, self.lora_B.weight
         key = (A._version, Bw._version, A.data_ptr(), Bw.data_ptr())
         if getattr(self, "_shadow_key", None) != key:
             r, K, N, dev = self.r, self.in_features, self.out_features, A.device
             with torch.no_grad():
-                a_pad = torch.zeros((PAD_ROWS, K), dtype=torch.bfloat16, device=dev)
-                a_pad[:r] = A
+                a_pad = A.detach().to(torch.bfloat16).contiguous()
                 b2 = torch.zeros((N, PAD_R), dtype=torch.bfloat16, device=dev)
                 b2[:, :r] = Bw
-                bt_pad = torch.zeros((PAD_ROWS, N), dtype=torch.bfloat16, device=dev)
-                bt_pad[:r] = Bw.t()
+                bt_pad = Bw.detach().t().to(torch.bfloat16).contiguous()
                 at2 = torch.zeros((K, PAD_R), dtype=torch.bfloat16, device=dev)
                 at2[:, :r] = A.t()
             self._shadow = (a_pad, b2, bt_pad, at2)

@@ -54,7 +54,8 @@ def test_bench_multi_rank_schedule_over_rccl_with_one_rank():
     assert {"p10", "p50", "p90"} <= set(j["ms_per_step_percentiles"])
 
 
-def test_bench_reduce_scatter_all_gather_exchange_and_accumulation():
+@pytest.mark.parametrize("micro_steps", [True, False])
+def test_bench_reduce_scatter_all_gather_exchange_and_accumulation(micro_steps):
     """MSR3D_DP_EXCHANGE=rs_ag (the A/B switch for the 8-GPU run) on the one-rank RCCL communicator,
     with the reference's launch shape: 4 scenes x 5 accumulated micro-batches per optimiser step."""
     env = dict(os.environ, MSR3D_BENCH_FORCE_DIST="1", MASTER_PORT="29673", HSA_ENABLE_IPC_MODE_LEGACY="0",
@@ -62,12 +63,14 @@ def test_bench_reduce_scatter_all_gather_exchange_and_accumulation():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
-                          "--batch", "4", "--accum", "5", "--no-cpu-baseline"], env=env, cwd=ROOT,
+                          "--batch", "4", "--accum", "5", "--no-cpu-baseline"] +
+                         (["--micro-steps"] if micro_steps else []), env=env, cwd=ROOT,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert j["comm"]["exchange"] == "rs_ag" and j["comm"]["exchanges"] == 3      # one per OPTIMISER step
     assert j["config"]["grad_accumulation"] == 5 and j["config"]["global_batch"] == 20
+    assert j["config"]["window_step"] is (not micro_steps)
     assert j["roofline"]["launches"] == 3 and j["value"] > 0          # one encoder pass per accumulation WINDOW
 
 
