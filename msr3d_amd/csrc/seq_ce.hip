@@ -104,15 +104,16 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(int T_len, int V, const T *
   const T *x = logits + ((size_t)b * T_len + t) * V;
   float m = -INFINITY, s = 0.f;
   const int nvec = V / VEC;
-  for (int e0 = tid; e0 < nvec; e0 += 256 * 4) {     // 4 x 16-byte loads in flight per thread
+  constexpr int U = 8;                               // 16-byte loads in flight per thread: half a 32000-wide bf16 row per pass
+  for (int e0 = tid; e0 < nvec; e0 += 256 * U) {
     // unconditional loads from a clamped index, masked afterwards: a load inside `if (e < nvec)` is its own basic
-    // block and the compiler waits vmcnt(0) behind each one -- the four loads then run one after the other
+    // block and the compiler waits vmcnt(0) behind each one -- the loads then run one after the other
     // (round 2: 1.6 TB/s with four round trips per row per pass)
-    float v[4][VEC];
+    float v[U][VEC];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) Ld<T>::load(x + (size_t)min(e0 + u * 256, nvec - 1) * VEC, v[u]);
+    for (int u = 0; u < U; ++u) Ld<T>::load(x + (size_t)min(e0 + u * 256, nvec - 1) * VEC, v[u]);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       if (e0 + u * 256 >= nvec) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) v[u][j] = -INFINITY;
@@ -120,13 +121,13 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(int T_len, int V, const T *
     }
     float mx = m;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int j = 0; j < VEC; ++j) mx = fmaxf(mx, v[u][j]);
     if (mx > -INFINITY) {
       float acc = (m == -INFINITY) ? 0.f : s * __expf(m - mx);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc += __expf(v[u][j] - mx);       // exp(-inf) = 0
       m = mx; s = acc;
