@@ -20,7 +20,8 @@ bash tools/pmc_blocks.sh "$OUT/pmc_blocks" > /dev/null 2>&1; cp "$OUT/pmc_blocks
 V="$OUT/${TAG}_variants.jsonl"; : > "$V"
 v() { echo "# $*" >> "$V.cmds"; "$@" 2>/dev/null | tail -1 >> "$V"; }
 v python bench.py --no-cpu-baseline --batch 4 --accum 5
-v python bench.py --no-cpu-baseline --batch 4 --accum 5 --no-window
+v python bench.py --no-cpu-baseline --batch 4 --accum 5 --micro-steps
+v python bench.py --no-cpu-baseline --batch 4 --accum 5 --micro-steps --no-window
 v python bench.py --no-cpu-baseline --skip-padded
 v python bench.py --no-cpu-baseline --pipeline
 v python bench.py --no-cpu-baseline --from-store
@@ -29,8 +30,16 @@ v python bench.py --no-cpu-baseline --objects 120 --points 2048 --llm-hidden 512
 v env MSR3D_TRAINABLE=strips python bench.py --no-cpu-baseline
 v env MSR3D_SA_MMA=f32 python bench.py --no-cpu-baseline
 v env MSR3D_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline
+v env MSR3D_BENCH_FORCE_DIST=1 MSR3D_DP_GRAPH_COMM=1 python bench.py --no-cpu-baseline
+v env MSR3D_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --batch 4 --accum 5
+v env MSR3D_BENCH_FORCE_DIST=1 MSR3D_DP_GRAPH_COMM=1 python bench.py --no-cpu-baseline --unfrozen --batch 16 --steps 10 --warmup 2
 v python bench.py --no-cpu-baseline --unfrozen --batch 16 --steps 10 --warmup 2
 python bench.py --llm-layer --steps 10 --warmup 3 2>/dev/null | tail -1 > "$OUT/${TAG}_llm_layer.json"
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/ktl" -- python "$ROOT/bench.py" --llm-layer --steps 10 --warmup 3 > /dev/null 2>&1)
+F=$(ls "$OUT"/ktl/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$F" ] && cp "$F" "$OUT/${TAG}_llm_layer_kernel_stats.csv"
+rm -rf "$OUT/ktl"
+python tools/bench_bf16_gemm.py 2>/dev/null | grep -v amdgpu > "$OUT/${TAG}_bf16_gemm.txt"
+python -m pytest tests/test_seq_ce_gpu.py -q -s -k roofline 2>/dev/null | grep seq_ce > "$OUT/${TAG}_seq_ce.txt"
 python bench.py --cpu-ops > "$OUT/${TAG}_cpu_ops.log" 2>&1; cp profiles/r03_cpu_ops.json "$OUT/${TAG}_cpu_ops.json"
 timeout 300 python tools/prof_blocks.py > "$OUT/${TAG}_block_stamps.txt" 2>&1
 ls -la "$OUT"
