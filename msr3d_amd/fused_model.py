@@ -223,7 +223,9 @@ class PrompterSchedule:
         return L <= 64 and FF % 128 == 0 and H == 8
 
     def use_blocks(self):
-        return _MODE[0] == "blocks" and self.packs is not None
+        # (the blocks' attention core multiplies on the bf16x3 split = fp32 accuracy; a reduced-precision attention
+        # mode, hipops.set_attention_mma("bf16"), is honoured by the strip schedule's attention kernels)
+        return _MODE[0] == "blocks" and self.packs is not None and hipops._attn_mma[0] == "f32"
 
     def _build_block_tables(self):
         """Pack jobs for every weight operand of the blocks and the weight-gradient problem table; all
@@ -494,7 +496,8 @@ class PrompterSchedule:
 
     # ------------------------------------------------------------------ forward / backward
     def forward(self, embeds):
-        if self.use_blocks():
+        self._ran_blocks = self.use_blocks()             # (backward takes the schedule forward took)
+        if self._ran_blocks:
             return self.forward_blocks(embeds)
         pr, m, a, dm = self.pr, self.model, self.arena, self.dims
         B, L, M, D, W, H, FF, E, KF, KE, nl = (dm[k] for k in ("B", "L", "M", "D", "W", "H", "FF", "E", "KF", "KE", "nl"))
@@ -568,7 +571,7 @@ class PrompterSchedule:
         return a["tok"].view(B, L, D), a["scene"].view(B, L, E)
 
     def backward(self, g_scene, g_tok):
-        if self.use_blocks():
+        if self._ran_blocks:
             return self.backward_blocks(g_scene, g_tok)
         pr, m, a, dm = self.pr, self.model, self.arena, self.dims
         B, L, M, D, W, H, FF, E, KF, KE, nl = (dm[k] for k in ("B", "L", "M", "D", "W", "H", "FF", "E", "KF", "KE", "nl"))

@@ -58,8 +58,8 @@ def test_bench_multi_rank_schedule_over_rccl_with_one_rank():
 def test_bench_reduce_scatter_all_gather_exchange_and_accumulation(micro_steps):
     """MSR3D_DP_EXCHANGE=rs_ag (the A/B switch for the 8-GPU run) on the one-rank RCCL communicator,
     with the reference's launch shape: 4 scenes x 5 accumulated micro-batches per optimiser step."""
-    env = dict(os.environ, MSR3D_BENCH_FORCE_DIST="1", MASTER_PORT="29673", HSA_ENABLE_IPC_MODE_LEGACY="0",
-               MSR3D_DP_EXCHANGE="rs_ag")
+    env = dict(os.environ, MSR3D_BENCH_FORCE_DIST="1", MASTER_PORT="29683" if micro_steps else "29673",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", MSR3D_DP_EXCHANGE="rs_ag")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
@@ -94,7 +94,8 @@ def test_bench_exchange_captured_inside_the_step_graph(extra):
     """MSR3D_DP_GRAPH_COMM=1: the RCCL call is captured with forward, backward and the optimiser -- one graph
     per step at N > 1, no next batch needed; unfrozen backbone: buckets leave from the backward hooks (forks of
     the capture onto the communication stream)."""
-    env = dict(os.environ, MSR3D_BENCH_FORCE_DIST="1", MSR3D_DP_GRAPH_COMM="1", MASTER_PORT="29674",
+    # (a port of its own per case: the previous case's listener may still be in TIME_WAIT)
+    env = dict(os.environ, MSR3D_BENCH_FORCE_DIST="1", MSR3D_DP_GRAPH_COMM="1", MASTER_PORT=str(29674 + 2 * len(extra)),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
