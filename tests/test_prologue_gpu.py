@@ -41,3 +41,34 @@ def test_agent_fourier_kernel(B, L):
     got2 = hipops.agent_fourier(loc)
     want2 = generate_fourier_features(loc[:, :, :3].contiguous())
     assert torch.allclose(got2, want2, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_pairwise_kernels_against_the_references_own_output(seed):
+    """Not through the torch mirror: the pairwise-location slab of the stand-alone kernel AND of the one-launch scene
+    prologue against `calc_pairwise_locs` as the REFERENCE evaluated it (tests/golden/prompter_transform_seed*.npz,
+    captured by tests/golden/make_golden.py from /root/reference/modules/utils.py:88-137)."""
+    import ctypes
+    import numpy as np
+    from msr3d_amd import _lib, hipops
+    from tests.helpers import load_golden, rel_l2
+    g = load_golden("transform", seed)
+    loc = torch.from_numpy(g["obj_locs"]).cuda().float().contiguous()
+    want = g["pairwise_locs"]
+    got = hipops.pairwise_locs_center5(loc)
+    assert got.shape == want.shape and rel_l2(got.cpu().numpy(), want) < 1e-6
+    B, L = loc.shape[:2]
+    valid = torch.from_numpy(g["obj_masks"]).cuda().bool().contiguous()
+    al = torch.from_numpy(g["anchor_locs"]).cuda().float().contiguous()
+    ao = torch.from_numpy(g["anchor_orientation"]).cuda().float().contiguous()
+    freqs = torch.linspace(1.0, 15, steps=10, device="cuda")
+    pw, ff = torch.empty(B, L, L, 5, device="cuda"), torch.empty(B, L, 63, device="cuda")
+    loc6, pad = torch.empty(B, L, 6, device="cuda"), torch.empty(B, L, dtype=torch.uint8, device="cuda")
+    vout = torch.empty(B, L, dtype=torch.uint8, device="cuda")
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    rc = _lib.load().msr3d_scene_prologue(B, L, vp(loc), vp(valid.view(torch.uint8)), vp(al), vp(ao), vp(freqs), 10, 1,
+                                          ctypes.c_float(1e-10), vp(pw), vp(ff), vp(loc6), vp(pad), vp(vout), None, None,
+                                          _lib.current_stream_ptr(torch.device("cuda")))
+    _lib.check(rc, "msr3d_scene_prologue")
+    assert rel_l2(pw.cpu().numpy(), want) < 1e-6
+    assert np.array_equal(pad.cpu().numpy().astype(bool), ~g["obj_masks"].astype(bool))

@@ -136,3 +136,33 @@ def test_padding_slots_skipped_gives_identical_features():
     assert torch.equal(enc.embed(f2, m2), want)
     # without masks the flag changes nothing
     assert torch.equal(enc.embed(fts), full)
+
+
+@pytest.mark.parametrize("mma", ["split", "f32"])
+@pytest.mark.parametrize("variant,seed", [("transform", 0), ("transform", 1), ("anchor", 0), ("anchor", 1)])
+def test_every_level_against_the_references_own_level_outputs(variant, seed, mma):
+    """Level by level against what the REFERENCE's PointnetSAModule chain produced (tests/golden/make_golden.py::
+    capture_encoder_internals: FPS picks and ball-query rows of both sampled levels for every object, the level
+    outputs of the first two objects, the encoder output): the indices inside the fused launches bit for bit, the
+    features of every level -- split (bf16 x 3) and f32-input kernels alike -- within the fp32 tolerance."""
+    from msr3d_amd.pointnet2 import fused
+    g = load_golden(variant, seed)
+    model = build_prompter(variant, seed, device="cuda")
+    net = model.obj_encoder.pcd_net
+    fts = torch.from_numpy(g["obj_fts"]).cuda()
+    pts = fts.reshape(-1, fts.shape[2], fts.shape[3]).contiguous()
+    prev = fused.set_sa_mma(mma)
+    try:
+        with torch.no_grad():
+            _, dbg = fused.forward(net, pts, return_internals=True)
+    finally:
+        fused.set_sa_mma(prev)
+    b = pts.shape[0]
+    assert np.array_equal(dbg["idx1"].cpu().numpy(), g["sa0_fps_idx"].reshape(b, -1))
+    assert np.array_equal(dbg["ball1"].cpu().numpy().reshape(b, -1), g["sa0_ball_idx"].reshape(b, -1))
+    assert np.array_equal(dbg["idx2"].cpu().numpy(), g["sa1_fps_idx"].reshape(b, -1))
+    assert np.array_equal(dbg["ball2"].cpu().numpy().reshape(b, -1), g["sa1_ball_idx"].reshape(b, -1))
+    # level outputs: the reference's are channel-major (2, C, npoint), the kernels' token-major (b, npoint, C)
+    assert rel_l2(dbg["feat1"][:2].permute(0, 2, 1).cpu().numpy(), g["sa0_out_first2"]) < TOL
+    assert rel_l2(dbg["feat2"][:2].permute(0, 2, 1).cpu().numpy(), g["sa1_out_first2"]) < TOL
+    assert rel_l2(dbg["pooled"][:2].cpu().numpy(), g["sa2_out_first2"].reshape(2, -1)) < TOL
