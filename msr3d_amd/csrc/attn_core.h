@@ -20,7 +20,8 @@ constexpr int DH = 32;        // head dim
 constexpr int SD = 5;         // spatial dims
 constexpr int LD32 = DH + 4;  // [LT][36] tiles
 constexpr int kMaxL = 128;
-constexpr float kSqrtDh = 5.656854249492381f;   // sqrt(32): s = dot / this (a division, as :205)
+constexpr float kSqrtDh = 5.656854249492381f;   // sqrt(32): s = dot / this (:205)
+constexpr float kInvSqrtDh = 0.17677669529663687f;   // (multiplied: 1 ulp from the division, a tenth of its instructions)
 
 // acc[rn] += sum_{k<KD} a(row0+i.., k) * b(rn*16+.., k) for this wave's 16-row strip.
 // a(r,k) = A_KC ? As[r*lda + k] : As[k*lda + r];  b(c,k) likewise.
@@ -269,8 +270,11 @@ __device__ __forceinline__ void attn_fwd_core(int L, const float *sq, const floa
         float z = c.bias;
 #pragma unroll
         for (int d = 0; d < SD; ++d) z = fmaf(c.w[d], pl[d], z);
-        const float loc = 1.0f / (1.0f + expf(-z));
-        lg = logf(fmaxf(loc, 1e-6f)) + acc[rn][r] / kSqrtDh;
+        // sigmoid -> clamp -> log as the reference states it, on the hardware's exp2 / rcp / log2 (1 ulp each):
+        // expf / logf / a true division are ~45 VALU instructions per pair, these are 8 -- and this loop is
+        // where the block's time goes (16 pairs per lane, 18 k of its 50 k cycles)
+        const float loc = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+        lg = __logf(fmaxf(loc, 1e-6f)) + acc[rn][r] * kInvSqrtDh;
       }
       acc[rn][r] = lg;
       m = fmaxf(m, lg);
@@ -282,7 +286,7 @@ __device__ __forceinline__ void attn_fwd_core(int L, const float *sq, const floa
     float s = 0.f;
 #pragma unroll
     for (int rn = 0; rn < NT; ++rn) {
-      const float e = (acc[rn][r] == -INFINITY) ? 0.f : expf(acc[rn][r] - mx[r]);
+      const float e = (acc[rn][r] == -INFINITY) ? 0.f : __expf(acc[rn][r] - mx[r]);
       acc[rn][r] = e;
       s += e;
     }
@@ -359,7 +363,7 @@ __device__ __forceinline__ void attn_bwd_core(int L, const float *sq, const floa
         float z = c.bias;
 #pragma unroll
         for (int d = 0; d < SD; ++d) z = fmaf(c.w[d], pl[d], z);
-        const float loc = 1.0f / (1.0f + expf(-z));
+        const float loc = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
         // d log(max(loc,1e-6)) / dz = (1 - loc) where the clamp is inactive, else 0
         const float dz = (loc >= 1e-6f) ? dlogit * (1.0f - loc) : 0.f;
         gb += dz;

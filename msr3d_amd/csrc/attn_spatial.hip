@@ -121,8 +121,8 @@ __global__ __launch_bounds__(LT * 4) void attn_bwd_kernel(int B, int L, int H,
       const int row = row0 + 4 * g + r;
       if (row < L) {
         const size_t o = ((size_t)b * L + row) * ldg + h * DH + rn * 16 + i;
-        dq[o] = oq[rn][r] / kSqrtDh;
-        dk[o] = ok[rn][r] / kSqrtDh;
+        dq[o] = oq[rn][r] * kInvSqrtDh;
+        dk[o] = ok[rn][r] * kInvSqrtDh;
         dv[o] = ov[rn][r];
       }
     }

@@ -45,7 +45,7 @@ using namespace msr3d;
 using msr3d_attn::DH;
 using msr3d_attn::LD32;
 using msr3d_attn::SD;
-using msr3d_attn::kSqrtDh;
+using msr3d_attn::kInvSqrtDh;
 
 using SB = msr3d_scene_block_t;
 
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
       for (int r = 0; r < 4; ++r) {
         const int rr = 4 * g + r, row = 16 * wave + rr, kk = 16 * rn + j;
         const bool okr = row < L;
-        const float v3[3] = {okr ? oq[rn][r] / kSqrtDh : 0.f, okr ? ok[rn][r] / kSqrtDh : 0.f, okr ? ov[rn][r] : 0.f};
+        const float v3[3] = {okr ? oq[rn][r] * kInvSqrtDh : 0.f, okr ? ok[rn][r] * kInvSqrtDh : 0.f, okr ? ov[rn][r] : 0.f};
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           if (okr) p.dqkvc[(size_t)(row_base + row) * ldq + a * KD + h * DH + kk] = v3[a];
