@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 10
+#define MSR3D_ABI_VERSION 11
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -618,7 +618,7 @@ int msr3d_scene_block(const msr3d_scene_block_t *p, msr3d_stream_t stream);
  * the msr3d_strip_gemm_t struct -- in the backward codes o1 = the residual gradient, STORED, to be passed
  * as the next sum's `extra`; the chain's result goes to `xp` (B, 3, 64, 256) bf16 as three exactly-split planes
  * (optional).  MSR3D_PRO_PLAIN: sum only.  LayerNorm parameter gradients are accumulated (atomicAdd,
- * one per column and four rows).  nslab <= 16. */
+ * one per column and four rows) or stored as per-workgroup partials (grad_partials).  nslab <= 16. */
 typedef struct msr3d_scene_rows {
   int M, L, pro;
   const float *a0;
@@ -635,8 +635,22 @@ typedef struct msr3d_scene_rows {
   float *o0, *o1, *o2, *ost1, *ost2;
   float *dg1, *db1, *dg2, *db2;
   unsigned short *xp;
+  int grad_partials;            /* != 0: dg1 .. db2 are PARTIAL buffers ((M + 3) / 4, 256) each -- every workgroup stores
+                                   its four rows' column sums to row blockIdx.x (no atomics); msr3d_colsum_partials adds
+                                   them up in row order */
 } msr3d_scene_rows_t;
 int msr3d_scene_rows(const msr3d_scene_rows_t *p, msr3d_stream_t stream);
+
+/* dst[c] += sum_{i < n} part[i * 256 + c], c < 256, for every job, in row order (bit-reproducible): the second half
+ * of the LayerNorm parameter gradients (norm1 / norm2 / the attention tail's LayerNorm of every layer,
+ * /root/reference/modules/layers/transformers.py:250-251,324-328) when msr3d_scene_rows wrote partials.
+ * jobs: device memory. */
+typedef struct {
+  const float *part;
+  float *dst;
+  int n, reserved;
+} msr3d_colsum_job_t;
+int msr3d_colsum_partials(int n_jobs, const msr3d_colsum_job_t *jobs, msr3d_stream_t stream);
 
 /* All weight gradients of a step in ONE launch: for every problem dW (n_out, k_in) += dy^T x over the
  * M token rows (dy (M, n_out), x (M, k_in), dense f32) and, optionally, db (n_out) += colsum(dy).

@@ -66,7 +66,13 @@ class SceneRows(ctypes.Structure):
                 + [(k, _ptr) for k in ("a1", "a2", "st1", "st2", "g1", "b1", "g2", "b2")]
                 + [("eps1", _c_float), ("eps2", _c_float), ("p1", _c_float), ("p2", _c_float),
                    ("salt1", ctypes.c_uint), ("salt2", ctypes.c_uint), ("seed", _ptr)]
-                + [(k, _ptr) for k in ("o0", "o1", "o2", "ost1", "ost2", "dg1", "db1", "dg2", "db2", "xp")])
+                + [(k, _ptr) for k in ("o0", "o1", "o2", "ost1", "ost2", "dg1", "db1", "dg2", "db2", "xp")]
+                + [("grad_partials", _c_int)])
+
+
+class ColsumJob(ctypes.Structure):
+    """msr3d_colsum_job_t (include/msr3d_hip.h)."""
+    _fields_ = [("part", _ptr), ("dst", _ptr), ("n", _c_int), ("reserved", _c_int)]
 
 
 class WgradProblem(ctypes.Structure):
@@ -102,6 +108,7 @@ _SIGNATURES = {
     "msr3d_transpose_bf16": [_c_int, _c_int, _c_int, _c_int, _ptr, _c_int, ctypes.c_longlong, ctypes.c_longlong,
                              _ptr, _c_int, ctypes.c_longlong, ctypes.c_longlong, _ptr],
     "msr3d_bf16_gemm_skinny": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _c_float, _ptr],
+    "msr3d_colsum_partials": [_c_int, _ptr, _ptr],
     "msr3d_lora_grad": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_float, _ptr,
                         ctypes.c_longlong, _ptr],
     "msr3d_sa_level_split": [_c_int, _c_int, _c_int, _c_int, _c_float] + [_ptr] * 13,
@@ -187,7 +194,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string", "msr3d_sqdist_contract"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 10        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 11        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():

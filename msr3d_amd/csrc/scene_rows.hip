@@ -153,7 +153,11 @@ __global__ __launch_bounds__(256) void scene_rows_kernel(const SR p) {
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
       if (!dst[k]) continue;
-      atomicAdd(dst[k] + col, (red[k][0][col] + red[k][1][col]) + (red[k][2][col] + red[k][3][col]));
+      const float s4 = (red[k][0][col] + red[k][1][col]) + (red[k][2][col] + red[k][3][col]);
+      // 240 workgroups x 256 columns x 2-4 vectors of memory-side atomics cost ~4 us of a 12 us launch: as plain
+      // stores to the workgroup's row of a partial buffer they are free, and the sum becomes ordered
+      if (p.grad_partials) dst[k][(size_t)blockIdx.x * ROW_D + col] = s4;
+      else atomicAdd(dst[k] + col, s4);
     }
   }
 }
@@ -164,7 +168,30 @@ int launch_rows(const SR &p, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const msr3d_colsum_job_t *__restrict__ jobs) {
+  const msr3d_colsum_job_t j = jobs[blockIdx.x];
+  const int c = threadIdx.x;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  int i = 0;
+  for (; i + 4 <= j.n; i += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] += j.part[(size_t)(i + u) * ROW_D + c];
+  }
+  // (four interleaved chains, then the tail: a fixed order for a given n)
+  float t = (s[0] + s[1]) + (s[2] + s[3]);
+  for (; i < j.n; ++i) t += j.part[(size_t)i * ROW_D + c];
+  j.dst[c] += t;
+}
+
 }  // namespace
+
+extern "C" int msr3d_colsum_partials(int n_jobs, const msr3d_colsum_job_t *jobs, msr3d_stream_t stream) {
+  if (n_jobs < 0) return MSR3D_EINVAL;
+  if (n_jobs == 0) return 0;
+  if (!jobs) return MSR3D_EINVAL;
+  colsum_partials_kernel<<<n_jobs, 256, 0, (hipStream_t)stream>>>(jobs);
+  return (int)hipGetLastError();
+}
 
 extern "C" int msr3d_scene_rows(const msr3d_scene_rows_t *pp, msr3d_stream_t stream) {
   if (!pp) return MSR3D_EINVAL;

@@ -105,6 +105,7 @@ class PrompterSchedule:
         # and drops its own msr3d_bump_seed launch); off: the caller owns the seed
         self.bump_seed = False
         self.need_d_embeds = False   # set per backward: the object features come from an unfrozen encoder
+        self._ln_job_buf = None
 
     # ------------------------------------------------------------------ eligibility
     def eligible(self, d, ignore_grad_mode=False):
@@ -185,6 +186,9 @@ class PrompterSchedule:
                 a.want(f"d_ffn{i}", M, D); a.want(f"d_pre{i}", M, FF); a.want(f"d_fc{i}", M, D)
                 a.want(f"d_qkvc{i}", M, W)
             a.want("part", 16, M, D)       # a block's partial products, one slab per slice
+            # LayerNorm parameter gradients: per-workgroup column sums of the backward row kernels (4 rows each),
+            # added up in order by ONE launch at the end of backward (instead of 240 x 256 x 18 float atomics)
+            a.want("lnpart", nl * 6, (M + 3) // 4, D)
             a.want("res", M, D)            # the residual gradient that joins the next sum
         a.want("loc6", M, 6)
         a.want("ff", M, KF)
@@ -205,6 +209,7 @@ class PrompterSchedule:
         a.want("d_emb", M, KE)        # gradient of the object features: only written for an unfrozen encoder
         a.build()
         self.arena = a
+        self._ln_job_buf = None
         self.pad = torch.zeros(M, dtype=torch.uint8, device=device)
         self.valid = torch.zeros((B, L), dtype=torch.bool, device=device)      # static copy of obj_masks
         self.freqs = torch.linspace(1.0, 15, steps=10, device=device)
@@ -400,9 +405,10 @@ class PrompterSchedule:
                 p_attn, p1, p2, p_ffn = self.ps[i]
                 s_attn, s_1, s_2, s_ffn = self.salts[i]
                 # d_out (sum) -> LN(norm2)-bwd: residual gradient -> res, dropout-bwd -> d_ffn (+ planes)
+                lnp = a["lnpart"]
                 rows(st, M=M, L=L, pro=PRO["lnbwd"], a1=a[f"s3_{i}"], st1=a[f"st3_{i}"], g1=layer.norm2.weight,
-                     p1=p2, salt1=s_2, seed=seed, o0=a[f"d_ffn{i}"], o1=a["res"], dg1=layer.norm2.weight.grad,
-                     db1=layer.norm2.bias.grad, sum_out=a[f"d_xacc{i+1}"] if i + 1 < nl else None, xp=xp, **src)
+                     p1=p2, salt1=s_2, seed=seed, o0=a[f"d_ffn{i}"], o1=a["res"], dg1=lnp[6 * i], db1=lnp[6 * i + 1],
+                     grad_partials=1, sum_out=a[f"d_xacc{i+1}"] if i + 1 < nl else None, xp=xp, **src)
                 # d_h = d_ffn W2 -> GELU-bwd -> d_pre; partials of d_pre W1
                 blk(st, kind=BLK["ffn_bwd"], B=B, L=L, xp=xp, w1=pk.bufs[f"w2_t{i}"], w1_bytes=pk.nbytes(f"w2_t{i}"),
                     w2=pk.bufs[f"w1_t{i}"], w2_bytes=pk.nbytes(f"w1_t{i}"), part=part, part_stride=MD,
@@ -411,8 +417,8 @@ class PrompterSchedule:
                 rows(st, M=M, L=L, pro=PRO["ln2bwd"], part=part, nslab=nff, part_stride=MD, extra=a["res"],
                      sum_out=a[f"d_t{i}"], a1=a[f"s1_{i}"], a2=a[f"s2_{i}"], st1=a[f"st1_{i}"], st2=a[f"st2_{i}"],
                      g1=sa.layer_norm.weight, g2=layer.norm1.weight, p1=p_attn, salt1=s_attn, p2=p1, salt2=s_1,
-                     seed=seed, o0=a[f"d_fc{i}"], o1=a["res"], dg1=sa.layer_norm.weight.grad,
-                     db1=sa.layer_norm.bias.grad, dg2=layer.norm1.weight.grad, db2=layer.norm1.bias.grad, xp=xp)
+                     seed=seed, o0=a[f"d_fc{i}"], o1=a["res"], dg1=lnp[6 * i + 2], db1=lnp[6 * i + 3],
+                     dg2=lnp[6 * i + 4], db2=lnp[6 * i + 5], grad_partials=1, xp=xp)
                 # d_ctx = d_fc Wfc; attention bwd; partials of d[q|k|v|cond] W
                 blk(st, kind=BLK["attn_bwd"], B=B, L=L, xp=xp, w1=pk.bufs[f"fc_t{i}"], w1_bytes=pk.nbytes(f"fc_t{i}"),
                     w2=pk.bufs[f"qkvc_t{i}"], w2_bytes=pk.nbytes(f"qkvc_t{i}"), part=part, part_stride=MD,
@@ -420,6 +426,7 @@ class PrompterSchedule:
                     probs=a[f"probs{i}"], H=H)
                 src = dict(part=part, nslab=H, part_stride=MD, extra=a["res"])
             rows(st, M=M, L=L, pro=PRO["plain"], sum_out=a["d_xacc0"], **src)      # d_xin0, whole
+            _lib.check(lib.msr3d_colsum_partials(len(layers) * 6, _ptr(self._ln_jobs(layers)), st), "msr3d_colsum_partials")
             le, se = pr.loc_embedding_encoder, pr.size_embedding_encoder
             more = same_all and nl > 1
             rc = lib.msr3d_pos_embed_bwd(
@@ -438,6 +445,21 @@ class PrompterSchedule:
                                   C=a["d_emb"], ldc=KE, beta=0.0)])
         for p in self._params():
             self.dp.mark_ready(p)
+
+    def _ln_jobs(self, layers):
+        """Job table of msr3d_colsum_partials: (partial buffer, rows, gradient vector) per LayerNorm parameter."""
+        if self._ln_job_buf is None:
+            from ._lib import ColsumJob
+            lnp, n = self.arena["lnpart"], (self.dims["M"] + 3) // 4
+            jobs = []
+            for i, layer in enumerate(layers):
+                sa = layer.self_attn
+                for k, g in enumerate((layer.norm2.weight.grad, layer.norm2.bias.grad, sa.layer_norm.weight.grad,
+                                       sa.layer_norm.bias.grad, layer.norm1.weight.grad, layer.norm1.bias.grad)):
+                    jobs.append(ColsumJob(part=lnp[6 * i + k].data_ptr(), dst=g.data_ptr(), n=n))
+            arr = (ColsumJob * len(jobs))(*jobs)
+            self._ln_job_buf = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(lnp.device)
+        return self._ln_job_buf
 
     # ------------------------------------------------------------------ launch helpers
     def _strip(self, **kw):

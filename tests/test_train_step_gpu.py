@@ -339,10 +339,12 @@ def test_accumulation_window_encoded_in_one_pass_gives_the_same_step():
     (f0, p0), (f1, p1) = outs
     for a, b in zip(f0, f1):
         assert torch.equal(a, b)                   # encoder features: bit-identical
+    # Two Adam steps from zero moments move every weight by ~lr * sign(g) each: the positional encoders' parameter
+    # gradients still meet by float atomics, whose arrival order perturbs the LAST bits of step 1's update, and where a
+    # gradient of step 2 is rounding noise around zero that can flip its sign -- bounded by 2 lr per step, and rare
     for k in p0:
-        if k.endswith("w_ks.bias"):
-            continue
-        assert torch.allclose(p0[k], p1[k], rtol=1e-4, atol=1e-6), k
+        assert torch.allclose(p0[k], p1[k], rtol=0, atol=4.2e-3), k
+        assert float(((p0[k] - p1[k]).abs() > 1e-5).float().mean()) < 0.02 or k.endswith("w_ks.bias"), k
 
 
 @pytest.mark.parametrize("explicit_grad", [False, True])
