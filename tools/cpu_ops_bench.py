@@ -128,6 +128,24 @@ def run(threads=32, reps=7, gpu=None):
             with torch.no_grad():
                 rows.setdefault("whole frozen encoder (fused: fps, ball, sa1-3, fc)", {})[key] = _gpu_ms(
                     lambda: g_enc(b["obj_fts"]))
+                # ... and per level: HIP events around each launch of the fused path (msr3d_amd/_lib.py: kernel_timer).
+                # The two FPS levels are ONE launch (msr3d_sa_fps2) and go with level 1; level 1's figure includes its
+                # ball-query launch, level 2's query runs inside its kernel; level 3 = the group-all kernel (the fc
+                # GEMM is the difference to the whole-encoder row)
+                from msr3d_amd import _lib
+                sink = {k: [] for k in ("msr3d_sa_fps2", "msr3d_sa_level1", "msr3d_sa_level2", "msr3d_sa_level3")}
+                for _ in range(3):
+                    g_enc(b["obj_fts"])
+                torch.cuda.synchronize()
+                _lib.set_timing_sink(sink)
+                for _ in range(20):
+                    g_enc(b["obj_fts"])
+                torch.cuda.synchronize()
+                _lib.set_timing_sink(None)
+                ms = {k: sum(a.elapsed_time(e) for a, e in v) / max(len(v), 1) for k, v in sink.items()}
+                rows["sa1: FPS + ball + group + MLP 6-64-64-128 + max"][key] = ms["msr3d_sa_fps2"] + ms["msr3d_sa_level1"]
+                rows["sa2: FPS + ball + group + MLP 131-128-128-256 + max"][key] = ms["msr3d_sa_level2"]
+                rows["sa3 (group-all) + fc: MLP 259-256-512-768, 768-768"][key] = ms["msr3d_sa_level3"]
             model.visual_prompter.obj_encoder.to("cpu")
     host = "unknown"
     try:
