@@ -343,19 +343,40 @@ __global__ __launch_bounds__(512, 1) void bf16_gemm_wide_kernel(const GemmArgs a
     for (int j = 0; j < NP; ++j)
       if (j < np) issue_piece(kt, j);
   };
-  issue(0);
-  if (nk > 1) issue(1);
-  for (int kt = 0; kt < nk; ++kt) {
-    // stage kt landed (this wave's pieces; the barrier extends it to everyone's); stage kt + 1 may still fly
-    if (kt + 1 < nk) {
+  // Two wave groups half a K step apart (waves 0-3 = group A, 4-7 = group B: one of each per SIMD).  Every wave
+  // runs the same stream  read(kt) -> multiply(kt);  group A meets the step's barrier BEFORE its reads, group B
+  // BETWEEN its reads and its multiplies (its barrier kt + 1: it reads stage kt while A multiplies it, and multiplies
+  // it while A reads stage kt + 1).  So A's reads share the CU with B's MFMAs and the other way round -- with all
+  // eight waves in step, read time and multiply time simply added up (85 us for 27 us of MFMA).  Both groups pass
+  // the barrier nk times; a wave issues its pieces of stage kt + 2 (A) / kt + 3 (B) among its multiplies of stage
+  // kt, i.e. after the barrier that certifies everyone is done with the buffer they go into.
+  const int grp_b = wave >= 4 ? 1 : 0;           // (wave-uniform)
+  auto wait_stage = [&](bool last) {              // this wave's pieces of the stage about to be certified have landed
+    if (!last) {                                  // (the stage after it may still fly)
       if (np == NP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP - 1) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();               // ... and every wave is done reading stage kt - 1
+  };
+  issue(0);
+  if (nk > 1) issue(1);
+  if (grp_b) {                                    // barrier 0 (stage 0 landed); B runs one stage further ahead
+    if (nk > 2) issue(2);
+    if (nk > 2) {
+      if (np == NP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NP - 1)) : "memory");
+    } else {
+      wait_stage(nk == 1);
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    if (!grp_b) {                                 // A: barrier kt
+      wait_stage(kt + 1 >= nk);
+      __builtin_amdgcn_s_barrier();
+    }
     const unsigned short *As = lds + (kt % 3) * STAGE, *Bs = As + BM * BK;
-    const bool more = kt + 2 < nk;
     bf16x8 fa[2][MTB], fb[2][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -365,15 +386,21 @@ __global__ __launch_bounds__(512, 1) void bf16_gemm_wide_kernel(const GemmArgs a
 #pragma unroll
       for (int x = 0; x < MTB; ++x) fa[ks][x] = *reinterpret_cast<const bf16x8 *>(As + (x * 16 + i) * BK + pos);
     }
-    // 2 MTB x 2 MFMAs; the next-but-one stage's pieces are issued among them (into the buffer stage kt - 1 held)
+    if (grp_b && kt + 1 < nk) {                   // B: barrier kt + 1 -- its reads of stage kt are in registers
+      wait_stage(kt + 2 >= nk);
+      __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0), as a builtin: the compiler's scoreboard must see it
+      __builtin_amdgcn_s_barrier();
+    }
+    const int st = kt + 2 + grp_b;                // the stage whose buffer the last barrier has freed
+    const bool more = st < nk;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int x = 0; x < MTB; ++x) {
         acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][0], fa[ks][x], acc[x][0], 0, 0, 0);
         acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][1], fa[ks][x], acc[x][1], 0, 0, 0);
-        const int slot = ks * MTB + x;                   // 0 .. 2 MTB - 1: one piece every other slot
-        if (more && (slot & 1) == 0 && slot / 2 < NP && slot / 2 < np) issue_piece(kt + 2, slot / 2);
+        const int slot = ks * MTB + x;            // 0 .. 2 MTB - 1: one piece every other slot
+        if (more && (slot & 1) == 0 && slot / 2 < NP && slot / 2 < np) issue_piece(st, slot / 2);
       }
     }
   }

@@ -111,3 +111,26 @@ def test_transposed_weight_follows_load_state_dict():
     b(xi).backward(dy)
     want = (dy.double() @ b.weight.double()).float()
     assert rel(xi.grad.float(), want) < 2 ** -7
+
+
+@pytest.mark.parametrize("M,N,K,R", [(2304, 4096, 4096, 64), (2304, 1024, 512, 0), (1000, 4096, 2048, 0), (4600, 512, 1024, 64),
+                                     (144, 256, 64, 0)])
+def test_wide_gemm_exact_on_integer_operands_run_after_run(M, N, K, R):
+    """Race screen of the wide-tile kernel's hand-off (LDS-DMA stages, counted vmcnt, two wave groups half a K step
+    apart): small-integer bf16 operands make every product and every fp32 partial sum exact, so ONE stale or
+    early-read fragment anywhere shows as a wrong integer.  Ten runs per shape, fp32 output."""
+    import ctypes
+    from msr3d_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    ri = lambda *s: torch.randint(-3, 4, s, device="cuda", generator=g).to(torch.bfloat16)   # noqa: E731
+    P, Q = ri(M, K), ri(N, K)
+    P2, Q2 = ri(M, max(R, 8)), ri(N, max(R, 8))
+    want = P.float() @ Q.float().T + (P2[:, :R].float() @ Q2[:, :R].float().T if R else 0)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    lib, st = _lib.load(), _lib.current_stream_ptr(torch.device("cuda"))
+    for _ in range(10):
+        C = torch.full((M, N), float("nan"), device="cuda")
+        rc = lib.msr3d_bf16_gemm_lowrank(M, N, K, R, vp(P), K, vp(Q), K, vp(P2) if R else None, P2.shape[1],
+                                         vp(Q2) if R else None, Q2.shape[1], vp(C), N, 1, ctypes.c_float(1.0), st)
+        _lib.check(rc, "msr3d_bf16_gemm_lowrank")
+        assert torch.equal(C, want)
