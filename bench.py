@@ -102,6 +102,10 @@ def parse():
                     "each (graph replay per micro-batch) instead of the window step")
     ap.add_argument("--no-window", action="store_true", help="with --accum: encode every micro-batch on its own "
                     "instead of the whole accumulation window in one encoder pass")
+    ap.add_argument("--llm-stack", type=int, default=0, metavar="L", help="SECONDARY, labelled line: a training step of "
+                    "the language-model side -- L LoRA-Llama decoder layers (Vicuna-7B shape) + final norm + 32000-way head + "
+                    "per-sequence cross-entropy, forward + backward + LoRA gradient exchange (bucketed, from the backward "
+                    "hooks) + clip + AdamW")
     ap.add_argument("--llm-layer", action="store_true", help="SECONDARY, labelled line: one LoRA-Llama decoder layer "
                     "(Vicuna-7B shape: hidden 4096, 32 heads, MLP 11008, LoRA r 16 on the seven projections), forward + "
                     "backward at 4 sequences x 576 tokens, bf16 -- SURVEY.md §8(f) rank 4; not the headline metric")
@@ -284,10 +288,91 @@ def llm_layer_line(args):
                 "the §8(f) rank-4 building block"}))
 
 
+def llm_stack_line(args):
+    """The language-model side of a step: msr3d_amd/llm/stack.py on the flat-gradient engine (dp.py, optim.py)."""
+    import torch.distributed as dist
+    from msr3d_amd.dp import FlatGradAllReduce
+    from msr3d_amd.llm import LoRALlamaStack
+    from msr3d_amd.optim import FlatAdamW
+    assert torch.cuda.is_available(), "bench.py --llm-stack needs a GPU"
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=dev)
+    L, Bq, T, Hd, NH, FF, V = args.llm_stack, 4, 576, 4096, 32, 11008, 32000
+    torch.manual_seed(0)
+    net = LoRALlamaStack(L, Hd, NH, FF, V, r=16, lora_alpha=16, device=dev)
+    with torch.no_grad():
+        for layer in net.layers:
+            for grp in (layer.self_attn, layer.mlp):
+                for m in grp.values():
+                    m.load_base_weight(torch.randn(m.out_features, m.in_features, device=dev) / m.in_features ** 0.5)
+                    m.lora_B.weight.normal_(std=0.02)
+        net.lm_head.load_weight(torch.randn(V, Hd, device=dev) / Hd ** 0.5)
+    dp = FlatGradAllReduce(net.lora_parameters(), bucket_bytes=1 << 20, overlap=True)   # a bucket ~ one layer's LoRA pair set
+    opt = FlatAdamW(dp, lr=3e-5, betas=(0.9, 0.999), weight_decay=0.05, max_grad_norm=5.0)
+    g = torch.Generator(device="cpu").manual_seed(1 + rank)
+    x = (torch.randn(Bq, T, Hd, generator=g) * 0.5).to(dev).bfloat16()
+    keep = torch.ones(Bq, T, dtype=torch.uint8, device=dev)
+    keep[1, :40] = 0
+    targets = torch.randint(0, V, (Bq, T), generator=g).to(dev)
+    targets[:, :200] = -100                                     # scene tokens + prompt are not supervised
+
+    def step():
+        dp.zero_grad()
+        net(x, attention_mask=keep, targets=targets).mean().backward()     # buckets leave from the hooks (world > 1)
+        dp.finish()
+        opt.step()
+    for _ in range(max(args.warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    ms = e0.elapsed_time(e1) / args.steps
+    M = Bq * T
+    lin = 2.0 * M * (4 * Hd * Hd + 3 * Hd * FF)
+    att = 2.0 * 2.0 * Bq * NH * T * T * (Hd // NH)
+    flop = L * (2.0 * lin + 3.0 * att) + 2.0 * 2.0 * M * Hd * V          # + the head, forward and dx
+    if rank == 0:
+        print(json.dumps({
+            "metric": "SECONDARY: LoRA-Llama training step, language-model side (Vicuna-7B shapes), tokens/s",
+            "value": world * M * args.steps / wall, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": max(args.warmup, 2), "ms_per_step": 1e3 * wall / args.steps, "gpu_ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "dtype": "bf16",
+            "data": "synthetic (random bf16 weights; no checkpoint on the box)",
+            "config": {"workload": f"{L} decoder layers (hidden 4096, 32 heads, MLP 11008, LoRA r=16 on q/k/v/o/gate/up/down) + "
+                                   "RMSNorm + 32000-way frozen head + per-sequence mean cross-entropy; 4 sequences x 576 "
+                                   "tokens per GPU, left-padded mask; forward + backward + bucketed LoRA-gradient exchange "
+                                   "from the backward hooks + clip + AdamW; eager launches",
+                       "layers": L, "lora_parameters": dp.numel, "grad_bytes": dp.numel * 4},
+            "tflops_per_gpu": flop / (ms * 1e-3) / 1e12, "frac_of_bf16_peak": flop / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
+            "note": "not the headline metric; the frozen LLM is out of §8(a)-(e) scope (SURVEY §0.5) -- this line prices "
+                    "the §8(f) rank-4 step assembled from the C-ABI pieces"}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     global O, P
     args = parse()
     O, P = args.objects, args.points
+    if args.llm_stack:
+        return llm_stack_line(args)
     if args.llm_layer:
         return llm_layer_line(args)
     if args.cpu_ops:

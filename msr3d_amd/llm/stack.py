@@ -1,0 +1,116 @@
+"""The language-model side of one MSR3D training step, assembled from the C-ABI pieces
+(/root/reference/model/msr3d/msr3d.py:95-112 peft LoRA on q/k/v/o/gate/up/down, :409-415 the LLM forward from
+`inputs_embeds` under bf16 autocast, :426-441 the per-sequence mean cross-entropy):
+
+    inputs_embeds (B, T, H) -> n x LoRALlamaDecoderLayer -> RMSNorm -> lm_head (frozen, bf16) -> logits (B, T, V) bf16
+                            -> seq_mean_cross_entropy(logits, targets)  (B,)
+
+Everything frozen is bf16 and stays frozen (embeddings are not part of the step: the caller scatters the scene
+tokens into `inputs_embeds`, msr3d.py:277-287); the only trainable tensors are the layers' lora_A / lora_B (fp32),
+which is what a data-parallel step has to exchange: 14 small tensors per layer.  GPU only."""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .decoder import LoRALlamaDecoderLayer, _RMSNormFn
+from .losses import seq_mean_cross_entropy
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def _gemm(M, N, K, P, Q, C, dev):
+    """C (M, N) bf16 = P (M, K) Q (N, K)^T, bf16 operands."""
+    with torch.cuda.device(dev):
+        rc = _lib.load().msr3d_bf16_gemm_lowrank(M, N, K, 0, _p(P), K, _p(Q), K, None, 0, None, 0, _p(C), N, 0,
+                                                 ctypes.c_float(1.0), _lib.current_stream_ptr(dev))
+    _lib.check(rc, "msr3d_bf16_gemm_lowrank")
+
+
+class _FrozenLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod):
+        K, N = mod.in_features, mod.out_features
+        x2 = x.reshape(-1, K)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        y = torch.empty((x2.shape[0], N), dtype=torch.bfloat16, device=x.device)
+        _gemm(x2.shape[0], N, K, x2, mod.weight, y, x.device)
+        ctx.mod, ctx.shape = mod, x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        mod = ctx.mod
+        K, N = mod.in_features, mod.out_features
+        dy2 = dy.reshape(-1, N).to(torch.bfloat16)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        dx = torch.empty((dy2.shape[0], K), dtype=torch.bfloat16, device=dy.device)
+        _gemm(dy2.shape[0], K, N, dy2, mod.weight_t, dx, dy.device)
+        return dx.view(ctx.shape), None
+
+
+class FrozenLinear(nn.Module):
+    """nn.Linear(in_features, out_features, bias=False) with a frozen bf16 weight, kept in both orientations
+    (forward and dx read k-contiguous rows): the language-model head."""
+
+    def __init__(self, in_features, out_features, device=None):
+        super().__init__()
+        if in_features % 64 or out_features % 64:
+            raise ValueError("feature sizes must be multiples of 64")
+        self.in_features, self.out_features = in_features, out_features
+        self.register_buffer("weight", torch.empty((out_features, in_features), dtype=torch.bfloat16, device=device))
+        self.register_buffer("weight_t", torch.empty((in_features, out_features), dtype=torch.bfloat16, device=device),
+                             persistent=False)
+        self._wt_version = None
+
+    def _sync(self):
+        key = (self.weight._version, self.weight.data_ptr())
+        if self._wt_version != key:
+            with torch.no_grad():
+                self.weight_t.copy_(self.weight.t())
+            self._wt_version = (self.weight._version, self.weight.data_ptr())
+
+    def load_weight(self, w):
+        self.weight.copy_(w.to(torch.bfloat16))
+        self._sync()
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("FrozenLinear runs on the GPU only (no CPU fallback)")
+        self._sync()
+        return _FrozenLinearFn.apply(x.to(torch.bfloat16), self)
+
+
+class LoRALlamaStack(nn.Module):
+    """`layers` decoder layers + final RMSNorm + head.  Parameter / buffer names follow LlamaForCausalLM
+    (`layers.i.*`, `norm_weight`, `lm_head.weight`) with peft's lora_A / lora_B inside each projection."""
+
+    def __init__(self, num_layers, hidden_size=4096, num_heads=32, intermediate_size=11008, vocab_size=32000, r=16,
+                 lora_alpha=16, rms_eps=1e-6, rope_theta=10000.0, device=None):
+        super().__init__()
+        self.layers = nn.ModuleList([LoRALlamaDecoderLayer(hidden_size, num_heads, intermediate_size, r, lora_alpha,
+                                                           rms_eps, rope_theta, device=device) for _ in range(num_layers)])
+        self.register_buffer("norm_weight", torch.ones(hidden_size, dtype=torch.bfloat16, device=device))
+        self.lm_head = FrozenLinear(hidden_size, vocab_size, device=device)
+        self.eps = rms_eps
+
+    def lora_parameters(self):
+        return [p for p in self.parameters() if p.requires_grad]
+
+    def logits(self, inputs_embeds, attention_mask=None):
+        x = inputs_embeds.to(torch.bfloat16)
+        for layer in self.layers:
+            x = layer(x, attention_mask=attention_mask)
+        _, h = _RMSNormFn.apply(x, None, self.norm_weight, self.eps)
+        return self.lm_head(h)
+
+    def forward(self, inputs_embeds, attention_mask=None, targets=None):
+        """-> logits (B, T, V) bf16, or with `targets` (B, T) int64 (negative = not supervised) the per-sequence mean
+        cross-entropy (B,) of msr3d.py:426-441."""
+        lg = self.logits(inputs_embeds, attention_mask)
+        if targets is None:
+            return lg
+        return seq_mean_cross_entropy(lg, targets)

@@ -99,6 +99,12 @@ class FlatAdamW:
                 self.warmup_steps, self.total_steps, int(zero_grad),
                 p(self.active) if self.active is not None else None, f(gscale), _lib.current_stream_ptr(dev))
         _lib.check(rc, "msr3d_adamw_flat_scaled")
+        # the kernel wrote the parameters behind autograd's back: bump their version counters, so that anything keyed
+        # on `param._version` (LoRALinear's bf16 shadows of A / B) sees the update -- no launch, host side only
+        inc = getattr(torch.autograd.graph, "increment_version", None)
+        if inc is not None:
+            for q in self.dp.order:
+                inc(q)
 
     def state_dict(self, names=None):
         """Per-parameter moments keyed by position in `dp.order` (or by `names[i]`, the parameter

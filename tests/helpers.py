@@ -64,3 +64,12 @@ def llama_layer_weights(seed, hidden, inter, r):
     w["ln1"] = _bf16_round(1.0 + 0.1 * rng.standard_normal(hidden).astype(np.float32))
     w["ln2"] = _bf16_round(1.0 + 0.1 * rng.standard_normal(hidden).astype(np.float32))
     return w
+
+
+def llama_stack_weights(seed, layers, hidden, inter, r, vocab):
+    """Weights of a LoRA-Llama stack: per-layer sets (llama_layer_weights, seeds seed + 10 i), the final norm and the
+    head; shared by tests/golden/make_golden_llama_stack.py and tests/test_llama_stack_gpu.py."""
+    rng = np.random.default_rng(seed + 7777)
+    return {"layers": [llama_layer_weights(seed + 10 * i, hidden, inter, r) for i in range(layers)],
+            "norm": _bf16_round(1.0 + 0.1 * rng.standard_normal(hidden).astype(np.float32)),
+            "head": _bf16_round(rng.standard_normal((vocab, hidden)).astype(np.float32) / np.sqrt(hidden))}

@@ -107,3 +107,13 @@ def test_bench_exchange_captured_inside_the_step_graph(extra):
     assert j["config"]["exchange_inside_graph"] is True and j["config"]["hip_graph"] is True
     assert j["config"]["allreduce_hidden_behind_next_encoder"] is False
     assert j["comm"]["ranks_seen"] == 1 and j["comm"]["replica_checksum_spread"] == 0.0 and j["value"] > 0
+
+
+def test_bench_llm_stack_line():
+    """The language-model side of a step as a labelled secondary line: layers + head + loss + exchange + optimiser."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--llm-stack", "1", "--steps", "2", "--warmup", "1"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert j["metric"].startswith("SECONDARY") and j["unit"] == "tokens/s" and j["value"] > 0
+    assert j["config"]["layers"] == 1 and j["config"]["lora_parameters"] == 4 * 131072 + 3 * 241664

@@ -1,0 +1,107 @@
+"""The LoRA-Llama stack (msr3d_amd/llm/stack.py: decoder layers + final RMSNorm + frozen head + the per-sequence mean
+cross-entropy) against the reference stack's own numbers: tests/golden/llama_stack_seed0.npz was produced by
+transformers' LlamaForCausalLM called as /root/reference/model/msr3d/msr3d.py:409-415 calls it (inputs_embeds +
+left-padding attention_mask), peft's LoRA formula on all seven projections of both layers, and the loss statement of
+msr3d.py:426-441 (tests/golden/make_golden_llama_stack.py).  The HIP stack keeps every activation in bf16 (the
+reference runs under bf16 autocast): loss within 1e-2 relative, gradients within 3e-2 rel-L2.  Plus: a training step
+of the stack on the flat-buffer data-parallel engine (the LoRA matrices are what a rank exchanges)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = ["q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"]
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _stack(g):
+    from msr3d_amd.llm import LoRALlamaStack
+    from tests.helpers import llama_stack_weights
+    layers, hidden, heads, inter, vocab, r, alpha, B, T = (int(v) for v in g["cfg"])
+    w = llama_stack_weights(int(g["seed"]), layers, hidden, inter, r, vocab)
+    net = LoRALlamaStack(layers, hidden, heads, inter, vocab, r=r, lora_alpha=alpha, rms_eps=float(g["eps"]),
+                         rope_theta=float(g["theta"]), device="cuda")
+    with torch.no_grad():
+        for i, layer in enumerate(net.layers):
+            lw = w["layers"][i]
+            for n in NAMES:
+                m = (layer.self_attn if n in layer.self_attn else layer.mlp)[n]
+                m.load_base_weight(torch.from_numpy(lw[n]).cuda())
+                m.lora_A.weight.copy_(torch.from_numpy(lw[n + ".A"]))
+                m.lora_B.weight.copy_(torch.from_numpy(lw[n + ".B"]))
+            layer.input_layernorm_weight.copy_(torch.from_numpy(lw["ln1"]))
+            layer.post_attention_layernorm_weight.copy_(torch.from_numpy(lw["ln2"]))
+        net.norm_weight.copy_(torch.from_numpy(w["norm"]))
+        net.lm_head.load_weight(torch.from_numpy(w["head"]).cuda())
+    return net
+
+
+def test_stack_loss_and_gradients_match_the_transformers_fixture():
+    g = dict(np.load(os.path.join(GOLD, "llama_stack_seed0.npz")))
+    net = _stack(g)
+    assert all(p.dtype == torch.float32 for p in net.lora_parameters()) and len(net.lora_parameters()) == 2 * 7 * 2
+    x = torch.from_numpy(g["x"]).cuda().to(torch.bfloat16).requires_grad_(True)
+    keep = torch.from_numpy(g["keep"]).cuda()
+    targets = torch.from_numpy(g["targets"]).cuda()
+    lg = net(x, attention_mask=keep)
+    assert lg.dtype == torch.bfloat16 and lg.shape == (x.shape[0], x.shape[1], int(g["cfg"][4]))
+    assert rel(lg[0, 60:64].float(), g["logits_first"]) < 2e-2
+    loss = net(x, attention_mask=keep, targets=targets)
+    assert loss.shape == (x.shape[0],)
+    assert np.allclose(loss.detach().cpu().numpy(), g["loss"], rtol=1e-2)
+    loss.backward(torch.from_numpy(g["grad_loss"]).cuda())
+    rows = keep.bool()
+    assert rel(x.grad.float()[rows], torch.from_numpy(g["dx"]).cuda()[rows]) < 3e-2
+    for i, layer in enumerate(net.layers):
+        for n in NAMES:
+            m = (layer.self_attn if n in layer.self_attn else layer.mlp)[n]
+            assert rel(m.lora_A.weight.grad, g[f"dA/{i}/{n}"]) < 3e-2, (i, n)
+            assert rel(m.lora_B.weight.grad, g[f"dB/{i}/{n}"]) < 3e-2, (i, n)
+
+
+def test_stack_trains_on_the_flat_gradient_engine():
+    """The LoRA matrices as ONE flat gradient buffer (what a data-parallel rank all-reduces: msr3d_amd/dp.py) and the
+    fused clip + AdamW over it: the loss of a fixed batch goes down, the frozen weights do not move."""
+    from msr3d_amd.dp import FlatGradAllReduce
+    from msr3d_amd.optim import FlatAdamW
+    g = dict(np.load(os.path.join(GOLD, "llama_stack_seed0.npz")))
+    net = _stack(g)
+    dp = FlatGradAllReduce(net.lora_parameters())
+    opt = FlatAdamW(dp, lr=2e-3, weight_decay=0.0, max_grad_norm=1.0)
+    x = torch.from_numpy(g["x"]).cuda().to(torch.bfloat16)
+    keep = torch.from_numpy(g["keep"]).cuda()
+    targets = torch.from_numpy(g["targets"]).cuda()
+    head0 = net.lm_head.weight.clone()
+    w0 = net.layers[0].mlp["up_proj"].weight.clone()
+    losses = []
+    for _ in range(6):
+        dp.zero_grad()
+        loss = net(x, attention_mask=keep, targets=targets).mean()
+        loss.backward()
+        dp.finish()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0] - 0.05, losses
+    assert torch.equal(net.lm_head.weight, head0) and torch.equal(net.layers[0].mlp["up_proj"].weight, w0)
+    assert dp.numel == sum(p.numel() for p in net.lora_parameters())
+
+
+def test_frozen_linear_refuses_cpu_and_follows_weight_writes():
+    from msr3d_amd.llm import FrozenLinear
+    lin = FrozenLinear(128, 256, device="cuda")
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(256, 128, device="cuda"))
+    x = torch.randn(64, 128, device="cuda").bfloat16().requires_grad_(True)
+    y = lin(x)
+    y.backward(torch.ones_like(y))
+    assert rel(y.float(), x.float() @ lin.weight.float().T) < 1e-2
+    assert rel(x.grad.float(), torch.ones(64, 256, device="cuda") @ lin.weight.float()) < 1e-2
+    with pytest.raises(RuntimeError):
+        lin(torch.randn(4, 128))
