@@ -38,6 +38,7 @@ python bench.py --llm-layer --steps 10 --warmup 3 2>/dev/null | tail -1 > "$OUT/
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/ktl" -- python "$ROOT/bench.py" --llm-layer --steps 10 --warmup 3 > /dev/null 2>&1)
 F=$(ls "$OUT"/ktl/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$F" ] && cp "$F" "$OUT/${TAG}_llm_layer_kernel_stats.csv"
 rm -rf "$OUT/ktl"
+python bench.py --llm-stack 4 --steps 10 --warmup 3 2>/dev/null | tail -1 > "$OUT/${TAG}_llm_stack.json"
 python tools/bench_bf16_gemm.py 2>/dev/null | grep -v amdgpu > "$OUT/${TAG}_bf16_gemm.txt"
 python -m pytest tests/test_seq_ce_gpu.py -q -s -k roofline 2>/dev/null | grep seq_ce > "$OUT/${TAG}_seq_ce.txt"
 python bench.py --cpu-ops > "$OUT/${TAG}_cpu_ops.log" 2>&1; cp profiles/r03_cpu_ops.json "$OUT/${TAG}_cpu_ops.json"
