@@ -192,3 +192,44 @@ def test_probe_unused_finds_parameters_without_a_gradient_and_offsets_are_aligne
     # the hooks are gone afterwards
     run()
     assert eng._probe is None
+
+
+def _worker_sum(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from msr3d_amd.dp import FlatGradAllReduce
+    torch.manual_seed(0)
+    outs = []
+    for in_opt in (False, True):
+        torch.manual_seed(0)
+        model = Twice()
+        eng = FlatGradAllReduce(model.parameters(), bucket_bytes=64)
+        eng.scale_in_optimizer = in_opt        # the consumer (FlatAdamW) reads g * (1 / world): the engine leaves the SUM
+        eng.zero_grad()
+        model(_data(rank, 0)).pow(2).mean().backward()
+        eng.finish()
+        outs.append(eng.flat.numpy().copy())
+    q.put((rank, outs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_leaves_the_sum_when_the_optimiser_does_the_averaging():
+    """dp.scale_in_optimizer (HotPathTrainStep sets it with the fused optimiser): after the exchange the buffer holds
+    the all-reduced SUM -- world x the mean the default leaves -- on every rank."""
+    import numpy as np
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sum, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        mean, total = res[r]
+        assert np.abs(mean).max() > 0
+        assert np.allclose(total, world * mean, rtol=1e-6, atol=1e-7)
+    assert np.array_equal(res[0][1], res[1][1])
