@@ -721,6 +721,7 @@ int msr3d_bf16_gemm_batched(int outer, int inner, int M, int N, int K, const voi
  *   rope_inplace  x (B, T, H, D) bf16 *= rotation by (cos, sin) (T, D) f32; transpose != 0: the backward
  *   causal_softmax_fwd   probs (B H, T, T) bf16 = softmax over keys t' <= t with key_keep[b][t'] != 0 of fp32 scores
  *   causal_softmax_bwd   dscores bf16 = probs * (dprobs - rowsum(dprobs probs)), dprobs fp32
+ *                        (both: T % 4 == 0, T <= 2048, 16-byte aligned fp32 rows)
  *   swiglu_fwd / bwd     h = silu(gate) * up and its two gradients; n % 8 == 0
  *   transpose_bf16       dst[o][i] (cols, rows) = src[o][i] (rows, cols)^T, two-level batch strides (elements) */
 int msr3d_rmsnorm_fwd(int M, int D, const void *x, const void *delta, const void *w, float eps, void *sum_out,

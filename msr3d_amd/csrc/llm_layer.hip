@@ -138,45 +138,93 @@ __global__ __launch_bounds__(256) void rope_kernel(long long n_pairs, int T, int
 
 // ---- causal + key-padding softmax over fp32 scores (B H, T, T) -> bf16 probabilities; one wave per row ------
 // key t' of row t is visible iff t' <= t and keep[b][t'] != 0; a row with no visible key gives zeros.
+// The row lives in registers: NV float4 per lane (T <= 256 NV), loaded unconditionally in one go, one pass for the
+// maximum, one for the exponentials, 8-byte stores of four bf16 (the first version walked the row three times with
+// 4-byte loads behind a branch per element: 109 us = 2.3 TB/s at 4 x 32 x 576 x 576).
+template <int NV>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(int BH, int H, int T, const float *__restrict__ S,
                                                           const unsigned char *__restrict__ keep, u16 *__restrict__ P) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= (long long)BH * T) return;
-  const int t = (int)(row % T), b = (int)(row / T / H);
-  const float *s = S + row * T;
-  const unsigned char *kp = keep ? keep + (size_t)b * T : nullptr;
+  const int t = (int)(row % T), b = (int)(row / T / H), n4 = T >> 2;
+  const float4 *s = reinterpret_cast<const float4 *>(S + row * T);
+  const unsigned *kp = keep ? reinterpret_cast<const unsigned *>(keep + (size_t)b * T) : nullptr;
+  float4 v[NV];
+  unsigned kk[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int q = min(lane + 64 * i, n4 - 1);
+    v[i] = s[q];
+    kk[i] = kp ? kp[q] : 0x01010101u;
+  }
+  float x[NV][4];
   float m = -INFINITY;
-  for (int c = lane; c <= t; c += 64)
-    if (!kp || kp[c]) m = fmaxf(m, s[c]);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c0 = 4 * (lane + 64 * i);
+    const float f[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool vis = lane + 64 * i < n4 && c0 + e <= t && ((kk[i] >> (8 * e)) & 0xffu);
+      x[i][e] = vis ? f[e] : -INFINITY;
+      m = fmaxf(m, x[i][e]);
+    }
+  }
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   float z = 0.f;
-  for (int c = lane; c <= t; c += 64)
-    if (!kp || kp[c]) z += expf(s[c] - m);
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      x[i][e] = x[i][e] == -INFINITY ? 0.f : __expf(x[i][e] - m);
+      z += x[i][e];
+    }
   z = wave_sum(z);
   const float inv = z > 0.f ? 1.0f / z : 0.f;
-  u16 *p = P + row * T;
-  for (int c = lane; c < T; c += 64) {
-    const bool vis = c <= t && (!kp || kp[c]);
-    p[c] = vis ? f2bf(expf(s[c] - m) * inv) : (u16)0;
-  }
+  uint2 *p = reinterpret_cast<uint2 *>(P + row * T);
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (lane + 64 * i < n4)
+      p[lane + 64 * i] = make_uint2(f2bf(x[i][0] * inv) | ((unsigned)f2bf(x[i][1] * inv) << 16),
+                                    f2bf(x[i][2] * inv) | ((unsigned)f2bf(x[i][3] * inv) << 16));
 }
-// dS = P * (dP - sum_c dP P): dP fp32 (B H, T, T), P bf16 -> dS bf16
+// dS = P * (dP - sum_c dP P): dP fp32 (B H, T, T), P bf16 -> dS bf16; the row in registers as above
+template <int NV>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(long long rows, int T, const float *__restrict__ dP,
                                                           const u16 *__restrict__ P, u16 *__restrict__ dS) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
-  const float *d = dP + row * T;
-  const u16 *p = P + row * T;
-  float dot = 0.f;
-  for (int c = lane; c < T; c += 64) dot = fmaf(d[c], bf2f(p[c]), dot);
-  dot = wave_sum(dot);
-  u16 *o = dS + row * T;
-  for (int c = lane; c < T; c += 64) {
-    const float pv = bf2f(p[c]);
-    o[c] = f2bf(pv * (d[c] - dot));
+  const int n4 = T >> 2;
+  const float4 *d = reinterpret_cast<const float4 *>(dP + row * T);
+  const uint2 *p = reinterpret_cast<const uint2 *>(P + row * T);
+  float4 dv[NV];
+  uint2 pv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int q = min(lane + 64 * i, n4 - 1);
+    dv[i] = d[q];
+    pv[i] = p[q];
   }
+  float pr[NV][4], dd[NV][4];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const bool in = lane + 64 * i < n4;
+    pr[i][0] = in ? bf2f((u16)(pv[i].x & 0xffffu)) : 0.f; pr[i][1] = in ? bf2f((u16)(pv[i].x >> 16)) : 0.f;
+    pr[i][2] = in ? bf2f((u16)(pv[i].y & 0xffffu)) : 0.f; pr[i][3] = in ? bf2f((u16)(pv[i].y >> 16)) : 0.f;
+    dd[i][0] = dv[i].x; dd[i][1] = dv[i].y; dd[i][2] = dv[i].z; dd[i][3] = dv[i].w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dot = fmaf(dd[i][e], pr[i][e], dot);
+  }
+  dot = wave_sum(dot);
+  uint2 *o = reinterpret_cast<uint2 *>(dS + row * T);
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (lane + 64 * i < n4)
+      o[lane + 64 * i] = make_uint2(f2bf(pr[i][0] * (dd[i][0] - dot)) | ((unsigned)f2bf(pr[i][1] * (dd[i][1] - dot)) << 16),
+                                    f2bf(pr[i][2] * (dd[i][2] - dot)) | ((unsigned)f2bf(pr[i][3] * (dd[i][3] - dot)) << 16));
 }
 
 // ---- SwiGLU: h = silu(gate) * up ------------------------------------------------------------------------------
@@ -215,20 +263,40 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(long long n8, const uin
 }
 
 // ---- batched bf16 transpose: dst[b][c][r] = src[b][r][c]; 64 x 64 tiles through LDS; two-level batch -----------
+// VEC: rows / cols multiples of 64 and both leading dimensions and bases 8-byte aligned: 8-byte loads and stores
+// (four bf16), the transposition itself as 2-byte LDS reads (2-byte global accesses: 1.1 TB/s, a third of this).
+template <bool VEC>
 __global__ __launch_bounds__(256) void transpose_kernel(int rows, int cols, int inner, const u16 *__restrict__ src, int lds_,
                                                         long long so, long long si, u16 *__restrict__ dst, int ldd,
                                                         long long dout, long long din) {
-  __shared__ u16 tile[64][66];
+  __shared__ u16 tile[64][68];                         // (pitch 136 B: 8-byte row writes stay aligned)
   const int bz = blockIdx.z, bo = bz / inner, bi = bz - bo * inner;
   const u16 *s = src + bo * so + bi * si;
   u16 *d = dst + bo * dout + bi * din;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int r = ty; r < 64; r += 4)
-    tile[r][tx] = (r0 + r < rows && c0 + tx < cols) ? s[(size_t)(r0 + r) * lds_ + c0 + tx] : (u16)0;
-  __syncthreads();
-  for (int c = ty; c < 64; c += 4)
-    if (c0 + c < cols && r0 + tx < rows) d[(size_t)(c0 + c) * ldd + r0 + tx] = tile[tx][c];
+  if constexpr (VEC) {
+    const int q = threadIdx.x & 15, rr = threadIdx.x >> 4;           // 16 column quads x 16 rows per pass
+    uint2 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const uint2 *>(s + (size_t)(r0 + rr + 16 * k) * lds_ + c0 + 4 * q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<uint2 *>(&tile[rr + 16 * k][4 * q]) = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = rr + 16 * k;                                      // output row = source column
+      const unsigned lo = tile[4 * q][c] | ((unsigned)tile[4 * q + 1][c] << 16);
+      const unsigned hi = tile[4 * q + 2][c] | ((unsigned)tile[4 * q + 3][c] << 16);
+      *reinterpret_cast<uint2 *>(d + (size_t)(c0 + c) * ldd + r0 + 4 * q) = make_uint2(lo, hi);
+    }
+  } else {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4)
+      tile[r][tx] = (r0 + r < rows && c0 + tx < cols) ? s[(size_t)(r0 + r) * lds_ + c0 + tx] : (u16)0;
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4)
+      if (c0 + c < cols && r0 + tx < rows) d[(size_t)(c0 + c) * ldd + r0 + tx] = tile[tx][c];
+  }
 }
 
 inline bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
@@ -300,7 +368,16 @@ int msr3d_causal_softmax_fwd(int B, int H, int T, const float *scores, const uns
   if (B == 0) return 0;
   if (!scores || !probs) return MSR3D_EINVAL;
   const long long rows = (long long)B * H * T;
-  softmax_fwd_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(B * H, H, T, scores, key_keep, (u16 *)probs);
+  if ((T & 3) || T > 2048 || (reinterpret_cast<uintptr_t>(scores) & 15u) || (reinterpret_cast<uintptr_t>(probs) & 7u) ||
+      (key_keep && (reinterpret_cast<uintptr_t>(key_keep) & 3u)))
+    return MSR3D_EINVAL;
+  const unsigned g = (unsigned)((rows + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  const int nv = (T / 4 + 63) / 64;
+#define MSR3D_SM(NV) softmax_fwd_kernel<NV><<<g, 256, 0, st>>>(B * H, H, T, scores, key_keep, (u16 *)probs)
+  if (nv <= 1) MSR3D_SM(1); else if (nv <= 2) MSR3D_SM(2); else if (nv <= 3) MSR3D_SM(3); else if (nv <= 4) MSR3D_SM(4);
+  else MSR3D_SM(8);
+#undef MSR3D_SM
   return (int)hipGetLastError();
 }
 
@@ -310,8 +387,16 @@ int msr3d_causal_softmax_bwd(int B, int H, int T, const float *dprobs, const voi
   if (B == 0) return 0;
   if (!dprobs || !probs || !dscores) return MSR3D_EINVAL;
   const long long rows = (long long)B * H * T;
-  softmax_bwd_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(rows, T, dprobs, (const u16 *)probs,
-                                                                                 (u16 *)dscores);
+  if ((T & 3) || T > 2048 || (reinterpret_cast<uintptr_t>(dprobs) & 15u) || (reinterpret_cast<uintptr_t>(probs) & 7u) ||
+      (reinterpret_cast<uintptr_t>(dscores) & 7u))
+    return MSR3D_EINVAL;
+  const unsigned g = (unsigned)((rows + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  const int nv = (T / 4 + 63) / 64;
+#define MSR3D_SM(NV) softmax_bwd_kernel<NV><<<g, 256, 0, st>>>(rows, T, dprobs, (const u16 *)probs, (u16 *)dscores)
+  if (nv <= 1) MSR3D_SM(1); else if (nv <= 2) MSR3D_SM(2); else if (nv <= 3) MSR3D_SM(3); else if (nv <= 4) MSR3D_SM(4);
+  else MSR3D_SM(8);
+#undef MSR3D_SM
   return (int)hipGetLastError();
 }
 
@@ -342,8 +427,15 @@ int msr3d_transpose_bf16(int outer, int inner, int rows, int cols, const void *s
   if (outer == 0) return 0;
   if (!src || !dst || ld_src < cols || ld_dst < rows) return MSR3D_EINVAL;
   dim3 grid((cols + 63) / 64, (rows + 63) / 64, outer * inner);
-  transpose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(rows, cols, inner, (const u16 *)src, ld_src, src_outer, src_inner,
-                                                         (u16 *)dst, ld_dst, dst_outer, dst_inner);
+  const bool vec = !(rows % 64) && !(cols % 64) && !(ld_src % 4) && !(ld_dst % 4) && !(src_outer % 4) && !(src_inner % 4) &&
+                   !(dst_outer % 4) && !(dst_inner % 4) && !(reinterpret_cast<uintptr_t>(src) & 7u) &&
+                   !(reinterpret_cast<uintptr_t>(dst) & 7u);
+  if (vec)
+    transpose_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(rows, cols, inner, (const u16 *)src, ld_src, src_outer,
+                                                                  src_inner, (u16 *)dst, ld_dst, dst_outer, dst_inner);
+  else
+    transpose_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(rows, cols, inner, (const u16 *)src, ld_src, src_outer,
+                                                                   src_inner, (u16 *)dst, ld_dst, dst_outer, dst_inner);
   return (int)hipGetLastError();
 }
 
