@@ -750,10 +750,11 @@ int msr3d_bf16_gemm_skinny(int M, int N, int K, const void *P, int ldp, const vo
 /* out (R, C) fp32 -- or its transpose (C, R) -- += scale * sum_m P[m][r] Q[m][c]: the LoRA weight gradients
  * dA = (s dy B)^T x and dB = dy^T (s x A^T) (peft's lora_A / lora_B, model/msr3d/msr3d.py:103-112; R = 16 or 32).
  * P (M, R), Q (M, C) bf16.  workspace (64 * R * C floats, 16-byte aligned; may be NULL): the row chunks' partial sums
- * are added up in a fixed order by a second launch -- bit-reproducible; without it 16 chunks meet by atomicAdd. */
+ * are added up in a fixed order by a second launch -- bit-reproducible; without it 16 chunks meet by atomicAdd.
+ * accumulate == 0 (workspace only): `out` is overwritten instead of added to -- no zero-fill by the caller. */
 #define MSR3D_LORA_GRAD_CHUNKS 64
 int msr3d_lora_grad(int M, int R, int C, const void *P, int ldp, const void *Q, int ldq, float *out,
-                    int transpose_out, float scale, float *workspace, long long workspace_floats,
+                    int transpose_out, float scale, int accumulate, float *workspace, long long workspace_floats,
                     msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------

@@ -109,7 +109,7 @@ _SIGNATURES = {
                              _ptr, _c_int, ctypes.c_longlong, ctypes.c_longlong, _ptr],
     "msr3d_bf16_gemm_skinny": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _c_float, _ptr],
     "msr3d_colsum_partials": [_c_int, _ptr, _ptr],
-    "msr3d_lora_grad": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_float, _ptr,
+    "msr3d_lora_grad": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_float, _c_int, _ptr,
                         ctypes.c_longlong, _ptr],
     "msr3d_sa_level_split": [_c_int, _c_int, _c_int, _c_int, _c_float] + [_ptr] * 13,
     "msr3d_seq_ce_fwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],

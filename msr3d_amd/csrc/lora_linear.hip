@@ -521,7 +521,8 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(int M, int C, const unsi
 
 // out (+)= scale * sum over the chunks' partials, in chunk order; thread = 4 adjacent columns of one r
 __global__ __launch_bounds__(256) void lora_grad_reduce_kernel(int R, int C, int chunks, const float *__restrict__ ws,
-                                                               float *__restrict__ out, int transpose_out, float scale) {
+                                                               float *__restrict__ out, int transpose_out, float scale,
+                                                               int accumulate) {
   const int e = blockIdx.x * 256 + threadIdx.x;       // over R * C / 4
   if (e >= R * (C / 4)) return;
   const int r = e / (C / 4), c = 4 * (e - r * (C / 4));
@@ -536,12 +537,16 @@ __global__ __launch_bounds__(256) void lora_grad_reduce_kernel(int R, int C, int
     for (int u = 0; u < U; ++u)
       if (k0 + u < chunks) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
   }
+  const float keep = accumulate ? 1.f : 0.f;           // (accumulate == 0: `out` is written, whatever it held)
   if (transpose_out) {
     float *o = out + (size_t)c * R + r;
-    o[0] += s.x * scale; o[R] += s.y * scale; o[2 * R] += s.z * scale; o[3 * R] += s.w * scale;
+    const float o0 = accumulate ? o[0] : 0.f, o1 = accumulate ? o[R] : 0.f, o2 = accumulate ? o[2 * R] : 0.f,
+                o3 = accumulate ? o[3 * R] : 0.f;
+    o[0] = o0 * keep + s.x * scale; o[R] = o1 * keep + s.y * scale; o[2 * R] = o2 * keep + s.z * scale;
+    o[3 * R] = o3 * keep + s.w * scale;
   } else {
     float4 *o = reinterpret_cast<float4 *>(out + (size_t)r * C + c);
-    float4 t = *o;
+    float4 t = accumulate ? *o : make_float4(0.f, 0.f, 0.f, 0.f);
     t.x += s.x * scale; t.y += s.y * scale; t.z += s.z * scale; t.w += s.w * scale;
     *o = t;
   }
@@ -731,11 +736,12 @@ int msr3d_bf16_gemm_batched(int outer, int inner, int M, int N, int K, const voi
 }
 
 int msr3d_lora_grad(int M, int R, int C, const void *P, int ldp, const void *Q, int ldq, float *out,
-                    int transpose_out, float scale, float *workspace, long long workspace_floats,
+                    int transpose_out, float scale, int accumulate, float *workspace, long long workspace_floats,
                     msr3d_stream_t stream) {
   if (M < 0 || C < 0 || (R != 16 && R != 32)) return MSR3D_EINVAL;
   if (M == 0 || C == 0) return 0;
   if (!P || !Q || !out || ldp < R || ldq < C) return MSR3D_EINVAL;
+  if (!accumulate && !workspace) return MSR3D_EINVAL;     // (the atomic path can only add)
   const int cpl = 128 / R;                      // a lane's columns: one 16- / 8-byte load per row
   if ((C % cpl) || (C % 4) || (ldq % cpl) || (reinterpret_cast<uintptr_t>(Q) & (2 * cpl - 1))) return MSR3D_EINVAL;
   if (workspace && ((reinterpret_cast<uintptr_t>(workspace) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u)))
@@ -753,7 +759,8 @@ int msr3d_lora_grad(int M, int R, int C, const void *P, int ldp, const void *Q, 
     lora_grad_kernel<32><<<grid, 256, 0, st>>>(M, C, (const unsigned short *)P, ldp, (const unsigned short *)Q, ldq,
                                                out, transpose_out, scale, workspace);
   if (workspace)
-    lora_grad_reduce_kernel<<<(R * (C / 4) + 255) / 256, 256, 0, st>>>(R, C, chunks, workspace, out, transpose_out, scale);
+    lora_grad_reduce_kernel<<<(R * (C / 4) + 255) / 256, 256, 0, st>>>(R, C, chunks, workspace, out, transpose_out, scale,
+                                                                       accumulate);
   return (int)hipGetLastError();
 }
 

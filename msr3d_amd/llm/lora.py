@@ -91,15 +91,15 @@ class _LoRAFn(torch.autograd.Function):
             _gemm(M, K, N, PAD_R, dy2, N, mod.weight_t, N, v, PAD_R, at2, PAD_R, dx, K, False, 1.0, dev)
             dx = dx.view(ctx.shape)
         lib = _lib.load()
-        dA = torch.zeros((r, K), dtype=torch.float32, device=dev)
-        dB = torch.zeros((N, r), dtype=torch.float32, device=dev)
+        dA = torch.empty((r, K), dtype=torch.float32, device=dev)      # (written, not added to: accumulate = 0)
+        dB = torch.empty((N, r), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             st = _lib.current_stream_ptr(dev)
             # dA = (s dy B)^T x = v^T x ; dB = dy^T (s x A^T) = dy^T u   (s already inside u and v)
             ws = _grad_workspace(dev, 64 * r * max(K, N))
-            rc = lib.msr3d_lora_grad(M, r, K, _p(v), PAD_R, _p(x2), K, _p(dA), 0, ctypes.c_float(1.0), _p(ws), ws.numel(), st)
+            rc = lib.msr3d_lora_grad(M, r, K, _p(v), PAD_R, _p(x2), K, _p(dA), 0, ctypes.c_float(1.0), 0, _p(ws), ws.numel(), st)
             _lib.check(rc, "msr3d_lora_grad")
-            rc = lib.msr3d_lora_grad(M, r, N, _p(u), PAD_R, _p(dy2), N, _p(dB), 1, ctypes.c_float(1.0), _p(ws), ws.numel(), st)
+            rc = lib.msr3d_lora_grad(M, r, N, _p(u), PAD_R, _p(dy2), N, _p(dB), 1, ctypes.c_float(1.0), 0, _p(ws), ws.numel(), st)
             _lib.check(rc, "msr3d_lora_grad")
         return dx, dA, dB, None
 
