@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 11
+#define MSR3D_ABI_VERSION 12
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -667,6 +667,19 @@ typedef struct msr3d_wgrad_problem {
 } msr3d_wgrad_problem_t;
 int msr3d_wgrad_split(int n, const msr3d_wgrad_problem_t *problems, const int *tile_prefix, int total_tiles,
                       msr3d_stream_t stream);
+
+/* C (M, N) = A (M, K) op(B)^T for TALL fp32 operands on the bf16 matrix pipe at fp32 accuracy (three exact bf16
+ * terms per operand, six MFMA products per product: csrc/split_mma.h): the SharedMLP layers of an UNFROZEN
+ * PointNet++ backbone as token GEMMs over the grouped rows (/root/reference/model/pointnet2/pytorch_utils.py:9-60;
+ * hipops.py::_mlp_rows) -- forward z = t W^T (b_trans = 0, B = W (N, K)) and d t = d z W (b_trans = 1, B = W
+ * (K, N): op(B)[n][k] = B[k * ldb + n]).  HBM-bound: the weight is split into LDS by each workgroup, the rows are
+ * read once in MFMA fragment shape and split in registers.  K % 4 == 0, K <= MSR3D_ROWS_GEMM_MAX_K,
+ * N <= MSR3D_ROWS_GEMM_MAX_N, lda % 4 == 0, ldc % 4 == 0, A and C 16-byte aligned; no split-K, no atomics:
+ * bit-reproducible, every output row independent of the others. */
+#define MSR3D_ROWS_GEMM_MAX_K 160
+#define MSR3D_ROWS_GEMM_MAX_N 256
+int msr3d_rows_gemm_split(int M, int N, int K, const float *A, int lda, const float *B, int ldb, int b_trans,
+                          float *C, int ldc, msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * The language-model side of the training step, first two pieces:

@@ -42,6 +42,7 @@ SOURCES = [
     ("scene_block.hip", []),
     ("scene_rows.hip", []),
     ("wgrad_split.hip", []),
+    ("rows_gemm_split.hip", []),
 ]
 
 

@@ -1,0 +1,171 @@
+// rows_gemm_split.hip -- C (M, N) = A (M, K) op(B)^T for TALL operands (hundreds of thousands of rows, K and N
+// at most a few hundred), fp32-accurate on the bf16 matrix pipe (include/msr3d_hip.h: msr3d_rows_gemm_split).
+//
+// The SharedMLP layers of an UNFROZEN PointNet++ backbone in training mode
+// (/root/reference/model/pointnet2/pytorch_utils.py:9-60 as token GEMMs, hipops.py::_mlp_rows): 983 k / 491 k
+// rows x (3..131 -> 64..256) channels at 16 scenes x 60 objects.  On the fp32 matrix instructions
+// (gemm_nt_ares_kernel) they ran at ~58 TFLOP/s, 250 us a layer; the rows themselves are only 2 x 250 MB of
+// traffic (~100 us).  Here every operand is split exactly into three bf16 terms and a product is the six bf16
+// MFMA products above 2^-24 of it (split_mma.h, the arithmetic of the frozen encoder's sa_split.hip), which
+// makes the product HBM-bound:
+//
+//   * op(B) -- the layer's weight, at most 144 x 160 -- is split by the workgroup itself on its way into LDS,
+//     in MFMA fragment order ([k/32][n/16][3 planes][64 lanes][8]), once per workgroup: no pack launch;
+//   * a wave owns 32 rows per pass: its lanes load the rows' fp32 values straight in fragment shape (row i,
+//     k = 32 s + 8 g .. + 7: two 16-byte loads; the four g-lanes of a row cover 128 contiguous bytes), split them
+//     in registers, and multiply against every column tile of B from LDS (three ds_read_b128 per 12 MFMAs);
+//   * 8 waves = 256 rows per pass and workgroup, one workgroup per CU walking the row blocks grid-stride; the
+//     other wave of a SIMD multiplies while this one's loads fly.
+// A lane of D holds four consecutive columns of one row: 16-byte stores.
+#include <hip/hip_runtime.h>
+
+#include "../../include/msr3d_hip.h"
+#include "split_mma.h"
+
+namespace {
+
+using namespace msr3d;
+
+struct RowsGemm {
+  int M, N, K;
+  const float *A; int lda;
+  const float *B; int ldb; int b_trans;
+  float *C; int ldc;
+  int nblk;                       // row blocks of 256
+};
+
+template <int NT, int KS>
+__global__ __launch_bounds__(512, 1) void rows_gemm_split_kernel(const RowsGemm p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [KS][NT][3][64][16 B]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.y * (NT * 16);
+
+  // op(B) -> LDS planes: unit = (slab s, tile t, lane l): row n0 + 16 t + (l & 15), k = 32 s + 8 (l >> 4) .. + 7
+  for (int u = tid; u < KS * NT * 64; u += 512) {
+    const int l = u & 63, t = (u >> 6) % NT, s = (u >> 6) / NT;
+    const int n = n0 + 16 * t + (l & 15), k = 32 * s + 8 * (l >> 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool ok = n < p.N && k + e < p.K;
+      v[e] = ok ? (p.b_trans ? p.B[(size_t)(k + e) * p.ldb + n] : p.B[(size_t)n * p.ldb + k + e]) : 0.f;
+    }
+    uint4 pl[3];
+    sm_split8(v, pl);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<uint4 *>(smem + (((s * NT + t) * 3 + q) * 64 + l) * 16) = pl[q];
+  }
+  __syncthreads();
+
+  const unsigned char *bl = smem + lane * 16;
+  for (int blk = blockIdx.x; blk < p.nblk; blk += gridDim.x) {
+    const int r0 = blk * 256 + wave * 32;
+    if (r0 >= p.M) continue;
+    // this lane's fragment-shaped fp32 values: rows r0 + 16 rt + i (clamped: rows past M are computed and dropped)
+    f32x4 raw[2][KS][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const float *row = p.A + (size_t)min(r0 + 16 * rt + i, p.M - 1) * p.lda + 8 * g;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int k = 32 * s + 8 * g;
+        raw[rt][s][0] = k < p.K ? *reinterpret_cast<const f32x4 *>(row + 32 * s) : f32x4{0.f, 0.f, 0.f, 0.f};
+        raw[rt][s][1] = k + 4 < p.K ? *reinterpret_cast<const f32x4 *>(row + 32 * s + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      bf16x8 fa[2][3];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const float v[8] = {raw[rt][s][0][0], raw[rt][s][0][1], raw[rt][s][0][2], raw[rt][s][0][3],
+                            raw[rt][s][1][0], raw[rt][s][1][1], raw[rt][s][1][2], raw[rt][s][1][3]};
+        uint4 pl[3];
+        sm_split8(v, pl);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fa[rt][q] = __builtin_bit_cast(bf16x8, pl[q]);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        bf16x8 fb[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fb[q] = *reinterpret_cast<const bf16x8 *>(bl + ((s * NT + t) * 3 + q) * 1024);
+#define MSR3D_TERM(PB, PA)                                                                            \
+        _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                              \
+            acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[PB], fa[rt][PA], acc[rt][t], 0, 0, 0);
+        MSR3D_TERM(2, 0)
+        MSR3D_TERM(0, 2)
+        MSR3D_TERM(1, 1)
+        MSR3D_TERM(1, 0)
+        MSR3D_TERM(0, 1)
+        MSR3D_TERM(0, 0)
+#undef MSR3D_TERM
+      }
+    }
+    // lane (i, g) holds columns 16 t + 4 g .. + 3 of row i
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int r = r0 + 16 * rt + i;
+      if (r >= p.M) continue;
+      float *crow = p.C + (size_t)r * p.ldc;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int c = n0 + 16 * t + 4 * g;
+        if (c + 3 < p.N) {
+          *reinterpret_cast<f32x4 *>(crow + c) = acc[rt][t];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c + e < p.N) crow[c + e] = acc[rt][t][e];
+        }
+      }
+    }
+  }
+}
+
+template <int NT, int KS>
+int launch(const RowsGemm &p, int ny, hipStream_t st) {
+  constexpr int lds = KS * NT * 3 * 1024;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&rows_gemm_split_kernel<NT, KS>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (attr != hipSuccess) return (int)attr;
+  const int gx = min(p.nblk, max(1, 256 / ny));
+  rows_gemm_split_kernel<NT, KS><<<dim3(gx, ny), 512, lds, st>>>(p);
+  return (int)hipGetLastError();
+}
+
+template <int NT>
+int pick_ks(const RowsGemm &p, int ny, int ks, hipStream_t st) {
+  switch (ks) {
+    case 1: return launch<NT, 1>(p, ny, st);
+    case 2: return launch<NT, 2>(p, ny, st);
+    case 3: return launch<NT, 3>(p, ny, st);
+    case 4: return launch<NT, 4>(p, ny, st);
+    default: return launch<NT, 5>(p, ny, st);
+  }
+}
+
+}  // namespace
+
+extern "C" int msr3d_rows_gemm_split(int M, int N, int K, const float *A, int lda, const float *B, int ldb, int b_trans,
+                                     float *C, int ldc, msr3d_stream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || K > MSR3D_ROWS_GEMM_MAX_K || N > MSR3D_ROWS_GEMM_MAX_N) return MSR3D_EINVAL;
+  if (!A || !B || !C || (K & 3) || (lda & 3) || (ldc & 3) || lda < K || ldc < N) return MSR3D_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(A) & 15u) || (reinterpret_cast<uintptr_t>(C) & 15u)) return MSR3D_EINVAL;
+  RowsGemm p{M, N, K, A, lda, B, ldb, b_trans, C, ldc, (M + 255) / 256};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int ks = (K + 31) / 32;
+  // column tiles per workgroup: all of them up to 144 columns (9 tiles), else halves of <= 128
+  const int tiles = (N + 15) / 16;
+  if (tiles <= 4) return pick_ks<4>(p, 1, ks, st);
+  if (tiles <= 8) return pick_ks<8>(p, 1, ks, st);
+  if (tiles == 9) return pick_ks<9>(p, 1, ks, st);
+  return pick_ks<8>(p, (tiles + 7) / 8, ks, st);
+}

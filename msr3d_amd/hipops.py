@@ -103,6 +103,24 @@ def _gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, bias=None, c_pre=None, fl
     _lib.check(rc, "msr3d_gemm_f32")
 
 
+# Tall token GEMMs (an unfrozen backbone's SharedMLP rows: >= 8192 rows, <= 160 reduction, <= 256 outputs) go to
+# msr3d_rows_gemm_split: bf16 pipe at fp32 accuracy, HBM-bound.  MSR3D_ROWS_GEMM=f32 keeps them on the fp32 pipe.
+_ROWS_SPLIT = _os.environ.get("MSR3D_ROWS_GEMM", "split") != "f32"
+
+
+def _rows_split_ok(M, N, K, A, C):
+    return (_ROWS_SPLIT and M >= 8192 and K % 4 == 0 and N % 4 == 0 and K <= 160 and N <= 256
+            and A.data_ptr() % 16 == 0 and C.data_ptr() % 16 == 0)
+
+
+def _rows_gemm(M, N, K, A, lda, B, ldb, b_trans, C, ldc):
+    """C (M, N) = A (M, K) op(B)^T, op(B) = B (N, K) or, b_trans, B (K, N)^T."""
+    with torch.cuda.device(C.device):
+        rc = _lib.load().msr3d_rows_gemm_split(M, N, K, _p(A), lda, _p(B), ldb, int(b_trans), _p(C), ldc,
+                                               _lib.current_stream_ptr(C.device))
+    _lib.check(rc, "msr3d_rows_gemm_split")
+
+
 def _linear_bwd(M, N, K, dy, x, w, dx, dx_beta, dw, db):
     """dx (M,K) = dx_beta*dx + dy (M,N) @ w (N,K);  dw += dy^T x;  db += colsum(dy): one launch."""
     lib = _lib.load()
@@ -143,7 +161,10 @@ class _HipLinear(torch.autograd.Function):
         N = w.shape[0]
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
         pre = torch.empty_like(y) if gelu else None
-        _gemm(True, True, M, N, K, x2, K, w, K, y, N, bias=bias, c_pre=pre, flags=1 if gelu else 0)
+        if bias is None and not gelu and _rows_split_ok(M, N, K, x2, y):
+            _rows_gemm(M, N, K, x2, K, w, K, False, y, N)
+        else:
+            _gemm(True, True, M, N, K, x2, K, w, K, y, N, bias=bias, c_pre=pre, flags=1 if gelu else 0)
         ctx.save_for_backward(x2, w, pre)
         ctx.has_bias = bias is not None
         ctx.x_shape = x.shape
@@ -179,7 +200,9 @@ class _HipLinear(torch.autograd.Function):
             return dx.reshape(ctx.x_shape), None, None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-            if M >= 8192 and K >= 64 and 16 <= N <= 256 and N % 16 == 0:
+            if _rows_split_ok(M, K, N, dy2, dx):
+                _rows_gemm(M, K, N, dy2, N, w, K, True, dx, K)            # dx = dy @ W: op(B)[k][n] = W[n][k]
+            elif M >= 8192 and K >= 64 and 16 <= N <= 256 and N % 16 == 0:
                 # tall and skinny (the unfrozen backbone's SharedMLP layers, up to 983 k rows): against a
                 # transposed copy of the small weight this is a forward-shaped product with a short
                 # reduction, which the A-resident kernel takes (one strip of dy in LDS, no per-slab barrier)

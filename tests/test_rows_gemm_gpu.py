@@ -1,0 +1,95 @@
+"""msr3d_rows_gemm_split (csrc/rows_gemm_split.hip): the tall token GEMMs of an unfrozen backbone's SharedMLP
+layers (/root/reference/model/pointnet2/pytorch_utils.py:9-60) on the bf16 pipe at fp32 accuracy, against
+float64 -- tolerance 2e-6 of the product's scale (an fp32 GEMM's own rounding), both operand orientations,
+ragged row counts, widths that are not a multiple of 16, zero-padded reduction widths."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(M, N, K, b_trans, lda=None, ldc=None, seed=0):
+    from msr3d_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(seed + M + 7 * N + 13 * K)
+    lda = lda or K
+    ldc = ldc or ((N + 3) // 4 * 4)
+    A = torch.randn(M, lda, device="cuda", generator=g)
+    B = torch.randn((K, N) if b_trans else (N, K), device="cuda", generator=g) * 0.3
+    C = torch.full((M, ldc), float("nan"), device="cuda")
+    st = _lib.current_stream_ptr(torch.device("cuda"))
+    rc = _lib.load().msr3d_rows_gemm_split(M, N, K, ctypes.c_void_p(A.data_ptr()), lda, ctypes.c_void_p(B.data_ptr()),
+                                           B.shape[1], int(b_trans), ctypes.c_void_p(C.data_ptr()), ldc, st)
+    assert rc == 0
+    want = A[:, :K].double() @ (B.double() if b_trans else B.double().t())
+    scale = (A[:, :K].double().abs() @ (B.double().abs() if b_trans else B.double().abs().t()))
+    err = float(((C[:, :N].double() - want).abs() / scale).max())
+    assert err < 2e-6, err
+    if ldc > N:
+        assert bool(torch.isnan(C[:, N:]).all())          # columns past N are not touched
+    return err
+
+
+@pytest.mark.parametrize("M,N,K,b_trans", [
+    (40000, 64, 4, 0), (40000, 64, 64, 0), (40000, 128, 64, 0),          # sa1 forward
+    (30000, 128, 132, 0), (30000, 128, 128, 0), (30000, 256, 128, 0),    # sa2 forward
+    (40000, 64, 128, 1), (40000, 64, 64, 1),                             # sa1 d t = d z W
+    (30000, 128, 128, 1), (30000, 132, 128, 1),                          # sa2
+    (257, 144, 160, 0), (31, 20, 36, 1), (1, 4, 4, 0), (513, 200, 96, 0)])
+def test_rows_gemm_split_vs_float64(M, N, K, b_trans):
+    _run(M, N, K, b_trans)
+
+
+def test_rows_gemm_split_padded_pitches_and_reproducible():
+    from msr3d_amd import _lib
+    _run(9000, 64, 64, 0, lda=72, ldc=80)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    A = torch.randn(70000, 128, device="cuda", generator=g)
+    B = torch.randn(128, 128, device="cuda", generator=g)
+    st = _lib.current_stream_ptr(torch.device("cuda"))
+    outs = []
+    for _ in range(3):
+        C = torch.empty(70000, 128, device="cuda")
+        assert _lib.load().msr3d_rows_gemm_split(70000, 128, 128, ctypes.c_void_p(A.data_ptr()), 128,
+                                                 ctypes.c_void_p(B.data_ptr()), 128, 0,
+                                                 ctypes.c_void_p(C.data_ptr()), 128, st) == 0
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_rows_gemm_split_rejects_what_it_does_not_take():
+    from msr3d_amd import _lib
+    A = torch.zeros(64, 256, device="cuda")
+    C = torch.zeros(64, 512, device="cuda")
+    st = _lib.current_stream_ptr(torch.device("cuda"))
+    f = _lib.load().msr3d_rows_gemm_split
+    p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    assert f(64, 64, 192, p(A), 256, p(A), 256, 0, p(C), 512, st) == -22      # K > 160
+    assert f(64, 272, 64, p(A), 256, p(A), 256, 0, p(C), 512, st) == -22      # N > 256
+    assert f(64, 64, 62, p(A), 256, p(A), 256, 0, p(C), 512, st) == -22       # K % 4
+
+
+def test_rows_gemm_split_throughput():
+    """The sa2 middle layer at 16 scenes x 60 objects: 491,520 rows x 128 -> 128; report time and HBM rate."""
+    from msr3d_amd import _lib
+    M, N, K = 491520, 128, 128
+    A = torch.randn(M, K, device="cuda")
+    B = torch.randn(N, K, device="cuda")
+    C = torch.empty(M, N, device="cuda")
+    st = _lib.current_stream_ptr(torch.device("cuda"))
+    f = _lib.load().msr3d_rows_gemm_split
+    p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    for _ in range(5):
+        f(M, N, K, p(A), K, p(B), K, 0, p(C), N, st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        f(M, N, K, p(A), K, p(B), K, 0, p(C), N, st)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 100
+    print(f"\nrows_gemm_split {M} x {K} -> {N}: {us:.0f} us = {(M * (K + N) * 4) / us / 1e6:.2f} TB/s of rows, "
+          f"{2 * M * N * K / us / 1e6:.0f} TFLOP/s fp32-equivalent")
+    assert us < 400

@@ -92,7 +92,10 @@ def test_unfrozen_step_trains_the_backbone_like_a_plain_autograd_loop():
             continue                                                   # normalises rounding noise into +-lr steps)
         a, b = sd[k].double(), v.double()
         err = float((a - b).norm() / b.norm().clamp_min(1e-12))
-        assert err < 2e-3, (k, err)
+        # (BatchNorm biases start at zero: after two steps they ARE two Adam steps, +-2e-3, and their gradients are
+        #  cancelling sums over ~10^5 rows -- a difference below 10 % of one step is rounding, whatever its ratio to
+        #  the norm)
+        assert err < 2e-3 or float((a - b).abs().max()) < 1e-4, (k, err)
         moved += 1
     assert moved > 50
     # parameters that receive no gradient (anchor_feat, loc_layers, the unread classification head) are left
