@@ -285,17 +285,19 @@ int msr3d_bn_relu_train_bwd(long long rows, int C, const float *x, const float *
  * pooled (G, C) = max over a group's rows of relu(bn(x)), argmax (G, C) = the FIRST row (0..nsample-1)
  * holding it, as max_pool2d chooses.  The (rows, C) activation is never materialised, and neither is
  * its gradient: _bwd takes dpooled (G, C) and routes it to the arg-max rows itself (rows whose pooled
- * value is 0 receive none: ReLU).  Other arguments as above. */
+ * value is 0 receive none: ReLU).  xsel (G, C) = x at the arg-max row: _fwd writes it and _bwd forms dgamma / dbeta
+ * from the (G, C) arrays alone (only that row of a (group, channel) carries a gradient) instead of a pass over
+ * the (rows, C) activation.  Other arguments as above. */
 int msr3d_bn_relu_maxpool_train_fwd(long long rows, int C, int nsample, const float *x,
                                     const float *gamma, const float *beta, float eps, float momentum,
                                     float *running_mean, float *running_var, float *pooled, int *argmax,
-                                    float *save_mean, float *save_rstd, float *partial_ws,
+                                    float *xsel, float *save_mean, float *save_rstd, float *partial_ws,
                                     msr3d_stream_t stream);
 int msr3d_bn_relu_maxpool_train_bwd(long long rows, int C, int nsample, const float *x,
                                     const float *dpooled, const float *pooled, const int *argmax,
-                                    const float *gamma, const float *save_mean, const float *save_rstd,
-                                    float *dx, float *dgamma, float *dbeta, float *partial_ws,
-                                    msr3d_stream_t stream);
+                                    const float *xsel, const float *gamma, const float *save_mean,
+                                    const float *save_rstd, float *dx, float *dgamma, float *dbeta,
+                                    float *partial_ws, msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Data-only front of the situated encoder (inputs are dataset tensors, no gradients).

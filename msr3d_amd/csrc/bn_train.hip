@@ -235,13 +235,15 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(long long G, int n
                                                               const float4 *__restrict__ mean,
                                                               const float4 *__restrict__ rstd,
                                                               float4 *__restrict__ pooled,
-                                                              int4 *__restrict__ argmax) {
+                                                              int4 *__restrict__ argmax,
+                                                              float4 *__restrict__ xsel) {
   const int GL = 256 / C4;
   const int gl = threadIdx.x / C4, c4 = threadIdx.x - gl * C4;
   const long long grp = (long long)blockIdx.x * GL + gl;
   if (gl >= GL || grp >= G) return;
   const float4 ga = gamma[c4], be = beta[c4], mu = mean[c4], rs = rstd[c4];
   float4 best = make_float4(-1.f, -1.f, -1.f, -1.f);       // relu(...) >= 0 > -1: row 0 always enters
+  float4 sel = best;                                       // x at the arg-max row (the backward's statistics)
   int4 arg = make_int4(0, 0, 0, 0);
   const float4 *X = x + grp * ns * C4 + c4;
 #pragma unroll 4
@@ -250,13 +252,63 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(long long G, int n
 #define BNM(k)                                                                     \
     {                                                                              \
       const float y = fmaxf(__builtin_fmaf(ga.k, (v.k - mu.k) * rs.k, be.k), 0.f); \
-      if (y > best.k) { best.k = y; arg.k = r; }                                   \
+      if (y > best.k) { best.k = y; arg.k = r; sel.k = v.k; }                      \
     }
     BNM(x) BNM(y) BNM(z) BNM(w)
 #undef BNM
   }
   pooled[grp * C4 + c4] = best;
   argmax[grp * C4 + c4] = arg;
+  xsel[grp * C4 + c4] = sel;
+}
+
+// Backward statistics of the pooled layer.  Only the arg-max row of a (group, channel) carries a gradient, so
+//   dbeta = sum_groups [pooled > 0] dpooled        dgamma = sum_groups [pooled > 0] dpooled * xhat(arg-max row)
+// need the (G, C) arrays only -- xsel is x at that row, kept by the forward -- not a pass over the (R, C)
+// activation with three group lookups per element (bn_partial_kernel<true, true>: 205 us a layer at 983 k rows).
+// Same two-stage ordered scheme: a workgroup reduces gpc groups (the groups of kChunk rows: as many partials as
+// the row pass had), the finalize adds the partials in double.
+__global__ __launch_bounds__(256) void bn_pooled_partial_kernel(long long G, int C, int gpc,
+                                                                const float4 *__restrict__ dpooled,
+                                                                const float4 *__restrict__ pooled,
+                                                                const float4 *__restrict__ xsel,
+                                                                const float *__restrict__ mean,
+                                                                const float *__restrict__ rstd,
+                                                                float *__restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float red[];      // [2][RL][C]
+  const int C4 = C >> 2, RL = 256 / C4;
+  const int rl = threadIdx.x / C4, c4 = threadIdx.x - rl * C4;
+  const long long g0 = (long long)blockIdx.x * gpc;
+  const long long g1 = g0 + gpc < G ? g0 + gpc : G;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (rl < RL) {
+    const float4 mu = reinterpret_cast<const float4 *>(mean)[c4], rs = reinterpret_cast<const float4 *>(rstd)[c4];
+#pragma unroll 4
+    for (long long r = g0 + rl; r < g1; r += RL) {
+      const float4 d = dpooled[r * C4 + c4], v = pooled[r * C4 + c4], xs = xsel[r * C4 + c4];
+#define BNS(k)                                              \
+      {                                                     \
+        const float g = v.k > 0.f ? d.k : 0.f;              \
+        s1.k += g;                                          \
+        s2.k = __builtin_fmaf(g, (xs.k - mu.k) * rs.k, s2.k); \
+      }
+      BNS(x) BNS(y) BNS(z) BNS(w)
+#undef BNS
+    }
+    reinterpret_cast<float4 *>(red)[rl * C4 + c4] = s1;
+    reinterpret_cast<float4 *>(red)[(RL + rl) * C4 + c4] = s2;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, q = 0.f;
+    for (int l = 0; l < RL; ++l) {            // fixed order
+      a += red[l * C + c];
+      q += red[(RL + l) * C + c];
+    }
+    float *p = partial + ((size_t)blockIdx.x * 2) * C + c;
+    p[0] = a;
+    p[C] = q;
+  }
 }
 
 inline int chunks_of(long long R) { return (int)((R + kChunk - 1) / kChunk); }
@@ -317,11 +369,12 @@ int msr3d_bn_relu_train_bwd(long long rows, int C, const float *x, const float *
 int msr3d_bn_relu_maxpool_train_fwd(long long rows, int C, int nsample, const float *x,
                                     const float *gamma, const float *beta, float eps, float momentum,
                                     float *running_mean, float *running_var, float *pooled, int *argmax,
-                                    float *save_mean, float *save_rstd, float *partial_ws,
+                                    float *xsel, float *save_mean, float *save_rstd, float *partial_ws,
                                     msr3d_stream_t stream) {
   if (rows < 0 || C <= 0 || (C % 4) != 0 || C > 1024 || nsample <= 0 || rows % nsample) return MSR3D_EINVAL;
   if (rows == 0) return 0;
-  if (!x || !gamma || !beta || !pooled || !argmax || !save_mean || !save_rstd || !partial_ws) return MSR3D_EINVAL;
+  if (!x || !gamma || !beta || !pooled || !argmax || !xsel || !save_mean || !save_rstd || !partial_ws)
+    return MSR3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int chunks = chunks_of(rows);
   bn_partial_kernel<false><<<chunks, 256, partial_lds(C), st>>>(rows, C, x, nullptr, nullptr, nullptr, nullptr,
@@ -334,29 +387,33 @@ int msr3d_bn_relu_maxpool_train_fwd(long long rows, int C, int nsample, const fl
       G, nsample, C / 4, reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(gamma),
       reinterpret_cast<const float4 *>(beta), reinterpret_cast<const float4 *>(save_mean),
       reinterpret_cast<const float4 *>(save_rstd), reinterpret_cast<float4 *>(pooled),
-      reinterpret_cast<int4 *>(argmax));
+      reinterpret_cast<int4 *>(argmax), reinterpret_cast<float4 *>(xsel));
   return (int)hipGetLastError();
 }
 
 int msr3d_bn_relu_maxpool_train_bwd(long long rows, int C, int nsample, const float *x,
                                     const float *dpooled, const float *pooled, const int *argmax,
-                                    const float *gamma, const float *save_mean, const float *save_rstd,
+                                    const float *xsel, const float *gamma, const float *save_mean,
+                                    const float *save_rstd,
                                     float *dx, float *dgamma, float *dbeta, float *partial_ws,
                                     msr3d_stream_t stream) {
   if (rows < 0 || C <= 0 || (C % 4) != 0 || C > 1024 || nsample <= 0 || rows % nsample) return MSR3D_EINVAL;
   if (rows == 0) return 0;
-  if (!x || !dpooled || !pooled || !argmax || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !dbeta ||
-      !partial_ws)
+  if (!x || !dpooled || !pooled || !argmax || !xsel || !gamma || !save_mean || !save_rstd || !dx || !dgamma ||
+      !dbeta || !partial_ws)
     return MSR3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int chunks = chunks_of(rows);
+  const long long G = rows / nsample;
+  const int gpc = (kChunk + nsample - 1) / nsample;          // groups per partial: >= kChunk rows' worth
+  const int chunks = (int)((G + gpc - 1) / gpc);             // (<= ceil(rows / kChunk): partial_ws holds them)
   Pooled pg;
   pg.ns = nsample;
   pg.dpooled = reinterpret_cast<const float4 *>(dpooled);
   pg.pooled = reinterpret_cast<const float4 *>(pooled);
   pg.argmax = reinterpret_cast<const int4 *>(argmax);
-  bn_partial_kernel<true, true><<<chunks, 256, partial_lds(C), st>>>(rows, C, x, nullptr, gamma, gamma, save_mean,
-                                                                     save_rstd, partial_ws, pg);
+  bn_pooled_partial_kernel<<<chunks, 256, partial_lds(C), st>>>(
+      G, C, gpc, reinterpret_cast<const float4 *>(dpooled), reinterpret_cast<const float4 *>(pooled),
+      reinterpret_cast<const float4 *>(xsel), save_mean, save_rstd, partial_ws);
   bn_bwd_finalize_kernel<<<(C + 63) / 64, 256, 0, st>>>(C, chunks, partial_ws, dgamma, dbeta);
   const long long n4 = rows * (C / 4);
   bn_relu_bwd_apply_kernel<true><<<ew_grid(n4), 256, 0, st>>>(

@@ -421,21 +421,22 @@ class _BNReLUMaxPoolTrain(torch.autograd.Function):
         g, b = gamma.contiguous(), beta.contiguous()
         pooled = torch.empty((R // ns, C), dtype=torch.float32, device=x.device)
         arg = torch.empty((R // ns, C), dtype=torch.int32, device=x.device)
+        xsel = torch.empty_like(pooled)
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         ws = torch.empty(2 * C * max(1, -(-R // BN_CHUNK_ROWS)), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             rc = _lib.load().msr3d_bn_relu_maxpool_train_fwd(
                 R, C, ns, _p(x), _p(g), _p(b), float(bn.eps), momentum, _p(rm), _p(rv), _p(pooled), _p(arg),
-                _p(mean), _p(rstd), _p(ws), _lib.current_stream_ptr(x.device))
+                _p(xsel), _p(mean), _p(rstd), _p(ws), _lib.current_stream_ptr(x.device))
         _lib.check(rc, "msr3d_bn_relu_maxpool_train_fwd")
-        ctx.save_for_backward(x, g, mean, rstd, pooled, arg)
+        ctx.save_for_backward(x, g, mean, rstd, pooled, arg, xsel)
         ctx.ns = ns
         return pooled
 
     @staticmethod
     def backward(ctx, dpooled):
-        x, g, mean, rstd, pooled, arg = ctx.saved_tensors
+        x, g, mean, rstd, pooled, arg, xsel = ctx.saved_tensors
         R, C = x.shape
         dpooled = dpooled if dpooled.is_contiguous() else dpooled.contiguous()
         dx = torch.empty_like(x)
@@ -444,7 +445,7 @@ class _BNReLUMaxPoolTrain(torch.autograd.Function):
         ws = torch.empty(2 * C * max(1, -(-R // BN_CHUNK_ROWS)), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             rc = _lib.load().msr3d_bn_relu_maxpool_train_bwd(
-                R, C, ctx.ns, _p(x), _p(dpooled), _p(pooled), _p(arg), _p(g), _p(mean), _p(rstd), _p(dx),
+                R, C, ctx.ns, _p(x), _p(dpooled), _p(pooled), _p(arg), _p(xsel), _p(g), _p(mean), _p(rstd), _p(dx),
                 _p(dg), _p(db), _p(ws), _lib.current_stream_ptr(x.device))
         _lib.check(rc, "msr3d_bn_relu_maxpool_train_bwd")
         return dx, dg, db, None, None
