@@ -670,6 +670,17 @@ typedef struct msr3d_wgrad_problem {
 int msr3d_wgrad_split(int n, const msr3d_wgrad_problem_t *problems, const int *tile_prefix, int total_tiles,
                       msr3d_stream_t stream);
 
+/* dW (n_out, k_in) (+)= dy^T x over M rows for TALL operands (the SharedMLP weight gradients of an unfrozen
+ * backbone: up to ~10^6 rows), the arithmetic and tile kernel of msr3d_wgrad_split: the rows are cut into up to
+ * MSR3D_WGRAD_ROWS_CHUNKS / tiles chunks, one workgroup per (chunk, 128 x 128 tile) stores its partial product to
+ * workspace[chunk] (n_out * k_in floats each), and a second launch adds the partials in chunk order -- no atomics,
+ * bit-reproducible.  accumulate != 0: dW holds the value to add to.  workspace_floats >= n_out * k_in (more
+ * chunks, up to the cap, when there is room). */
+#define MSR3D_WGRAD_ROWS_CHUNKS 256
+int msr3d_wgrad_rows_split(int M, int n_out, int k_in, const float *dy, int ldy, const float *x, int ldx,
+                           float *dW, int ldw, int accumulate, float *workspace, long long workspace_floats,
+                           msr3d_stream_t stream);
+
 /* C (M, N) = A (M, K) op(B)^T for TALL fp32 operands on the bf16 matrix pipe at fp32 accuracy (three exact bf16
  * terms per operand, six MFMA products per product: csrc/split_mma.h): the SharedMLP layers of an UNFROZEN
  * PointNet++ backbone as token GEMMs over the grouped rows (/root/reference/model/pointnet2/pytorch_utils.py:9-60;

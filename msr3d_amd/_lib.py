@@ -93,6 +93,8 @@ _SIGNATURES = {
     "msr3d_scene_block": [ctypes.POINTER(SceneBlock), _ptr],
     "msr3d_scene_rows": [ctypes.POINTER(SceneRows), _ptr],
     "msr3d_wgrad_split": [_c_int, _ptr, _ptr, _c_int, _ptr],
+    "msr3d_wgrad_rows_split": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _ptr,
+                               ctypes.c_longlong, _ptr],
     "msr3d_rows_gemm_split": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _ptr, _c_int, _ptr],
     "msr3d_bf16_gemm_lowrank": [_c_int, _c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int,
                                 _ptr, _c_int, _c_int, _c_float, _ptr],

@@ -55,26 +55,11 @@ __device__ __forceinline__ int frag_slot(int j, int g) { return (4 * (j & 3) + (
 // writes 16 bytes per plane straight into fragment order, two slabs ahead -- and waves 0-3 MULTIPLY: a
 // 64 x 64 quarter each, 96 MFMAs per slab from 24 ds_read_b128.  One barrier per slab; the matrix pipe and
 // the VALU work of the split overlap.
-__global__ __launch_bounds__(512, 2) void wgrad_split_kernel(int nprob, const WP *__restrict__ probs,
-                                                          const int *__restrict__ prefix) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// One 128 x 128 tile of one problem, whole reduction.  OVERWRITE: dW is set, not added to.
+template <bool OVERWRITE>
+__device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, unsigned char *smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int lo = 0, hi = nprob - 1;
-  const int t = blockIdx.x;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (prefix[mid] <= t) lo = mid; else hi = mid - 1;
-  }
-  const WP pr = probs[lo];
-  // A problem owns a multiple of 8 workgroups; workgroup b runs on XCD b % 8 (observed dispatch order:
-  // speed only), so XCD x takes the CONTIGUOUS run of tiles [x nb/8, (x+1) nb/8): tiles that share a dy
-  // block (same output tile, consecutive input tiles) read it through one L2.
-  const int lb = t - prefix[lo], nb = prefix[lo + 1] - prefix[lo];
-  const int local = (lb & 7) * (nb >> 3) + (lb >> 3);
-  const int nkt = (pr.k_in + TK - 1) / TK;
-  if (local >= ((pr.n_out + TN - 1) / TN) * nkt) return;
-  const int ntile = local / nkt, ktile = local - ntile * nkt;
   const int n0 = ntile * TN, k0 = ktile * TK;
   const int M = pr.M;
   // slabs of 32 tokens, padded to an even count: a slab past M reads zeros (out-of-range buffer loads) and
@@ -240,12 +225,67 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_kernel(int nprob, const WP
           const int n = n0 + 64 * wr + 16 * a + 4 * g + r;
           if (n < pr.n_out && kk < pr.k_in) {
             float *d = pr.dW + (size_t)n * pr.ldw + kk;
-            *d += acc[a][b][r];
+            *d = OVERWRITE ? acc[a][b][r] : *d + acc[a][b][r];
           }
         }
       }
   }
   WG_STAMP(6);
+}
+
+__global__ __launch_bounds__(512, 2) void wgrad_split_kernel(int nprob, const WP *__restrict__ probs,
+                                                          const int *__restrict__ prefix) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int lo = 0, hi = nprob - 1;
+  const int t = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (prefix[mid] <= t) lo = mid; else hi = mid - 1;
+  }
+  const WP pr = probs[lo];
+  // A problem owns a multiple of 8 workgroups; workgroup b runs on XCD b % 8 (observed dispatch order:
+  // speed only), so XCD x takes the CONTIGUOUS run of tiles [x nb/8, (x+1) nb/8): tiles that share a dy
+  // block (same output tile, consecutive input tiles) read it through one L2.
+  const int lb = t - prefix[lo], nb = prefix[lo + 1] - prefix[lo];
+  const int local = (lb & 7) * (nb >> 3) + (lb >> 3);
+  const int nkt = (pr.k_in + TK - 1) / TK;
+  if (local >= ((pr.n_out + TN - 1) / TN) * nkt) return;
+  wgrad_tile<false>(pr, local / nkt, local % nkt, smem);
+}
+
+// TALL problems (an unfrozen backbone's SharedMLP layers: dW (<= 256 x <= 256) over 10^5 .. 10^6 rows): the rows are
+// cut into chunks, workgroup (chunk, tile) reduces its chunk into ws[chunk] (n_out, k_in) -- plain stores, every
+// workgroup the only writer of its slab -- and wgrad_rows_reduce_kernel adds the slabs in chunk order.
+__global__ __launch_bounds__(512, 2) void wgrad_rows_kernel(WP base, int chunk_rows, int tiles, float *ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int chunk = blockIdx.x / tiles, tile = blockIdx.x - chunk * tiles;
+  const int nkt = (base.k_in + TK - 1) / TK;
+  WP pr = base;
+  const long long r0 = (long long)chunk * chunk_rows;
+  pr.dy = base.dy + r0 * base.ldy;
+  pr.x = base.x + r0 * base.ldx;
+  pr.M = (int)min((long long)chunk_rows, (long long)base.M - r0);
+  pr.dW = ws + (size_t)chunk * base.n_out * base.k_in;
+  pr.ldw = base.k_in;
+  pr.db = nullptr;
+  wgrad_tile<true>(pr, tile / nkt, tile % nkt, smem);
+}
+
+__global__ __launch_bounds__(256) void wgrad_rows_reduce_kernel(int n_out, int k_in, int chunks, const float *__restrict__ ws,
+                                                                float *__restrict__ dW, int ldw, int accumulate) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_out * k_in) return;
+  const size_t slab = (size_t)n_out * k_in;
+  float t = 0.f;
+  for (int c0 = 0; c0 < chunks; c0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = c0 + u < chunks ? ws[(size_t)(c0 + u) * slab + e] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t += v[u];
+  }
+  float *d = dW + (size_t)(e / k_in) * ldw + e % k_in;
+  *d = accumulate ? *d + t : t;
 }
 
 }  // namespace
@@ -259,5 +299,36 @@ extern "C" int msr3d_wgrad_split(int n, const msr3d_wgrad_problem_t *problems, c
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (attr != hipSuccess) return (int)attr;
   wgrad_split_kernel<<<total_tiles, 512, LDS_BYTES, (hipStream_t)stream>>>(n, problems, tile_prefix);
+  return (int)hipGetLastError();
+}
+
+extern "C" int msr3d_wgrad_rows_split(int M, int n_out, int k_in, const float *dy, int ldy, const float *x, int ldx,
+                                      float *dW, int ldw, int accumulate, float *workspace, long long workspace_floats,
+                                      msr3d_stream_t stream) {
+  if (M <= 0 || n_out <= 0 || k_in <= 0 || !dy || !x || !dW || !workspace || ldy < n_out || ldx < k_in || ldw < k_in)
+    return MSR3D_EINVAL;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_rows_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (attr != hipSuccess) return (int)attr;
+  const int tiles = ((n_out + TN - 1) / TN) * ((k_in + TK - 1) / TK);
+  const long long slab = (long long)n_out * k_in;
+  // chunks: one round of the 256 CUs, at least 512 rows each, as many as the workspace holds
+  long long chunks = MSR3D_WGRAD_ROWS_CHUNKS / tiles;
+  chunks = chunks < 1 ? 1 : chunks;
+  chunks = chunks < (M + 511) / 512 ? chunks : (M + 511) / 512;
+  chunks = chunks < workspace_floats / slab ? chunks : workspace_floats / slab;
+  if (chunks < 1) return MSR3D_EINVAL;
+  int chunk_rows = (int)((M + chunks - 1) / chunks);
+  chunk_rows = (chunk_rows + 63) / 64 * 64;                  // whole slab pairs
+  chunks = (M + chunk_rows - 1) / chunk_rows;
+  WP base;
+  base.dy = dy; base.ldy = ldy; base.n_out = n_out;
+  base.x = x; base.ldx = ldx; base.k_in = k_in;
+  base.M = M;
+  base.dW = nullptr; base.ldw = k_in; base.db = nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  wgrad_rows_kernel<<<(unsigned)(chunks * tiles), 512, LDS_BYTES, st>>>(base, chunk_rows, tiles, workspace);
+  wgrad_rows_reduce_kernel<<<(unsigned)((slab + 255) / 256), 256, 0, st>>>(n_out, k_in, (int)chunks, workspace, dW, ldw,
+                                                                          accumulate);
   return (int)hipGetLastError();
 }

@@ -121,6 +121,30 @@ def _rows_gemm(M, N, K, A, lda, B, ldb, b_trans, C, ldc):
     _lib.check(rc, "msr3d_rows_gemm_split")
 
 
+_wgrad_ws = {}
+
+
+def _wgrad_rows_ok(M, N, K):
+    return _ROWS_SPLIT and M >= 8192 and N <= 256 and K <= 256
+
+
+def _wgrad_rows(M, N, K, dy, x, dw, accumulate=False):
+    """dw (N, K) (+)= dy (M, N)^T x (M, K) over tall row counts (msr3d_wgrad_rows_split); the chunk workspace is one
+    buffer per device, grown to the largest layer seen (allocated outside any capture: see HotPathTrainStep's
+    eager warm-up)."""
+    dev = dy.device
+    need = 256 * N * K
+    ws = _wgrad_ws.get(dev.index)
+    if ws is None or ws.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the tall weight-gradient workspace must exist before graph capture (run one eager step)")
+        ws = _wgrad_ws[dev.index] = torch.empty(max(need, 256 * 256 * 128), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().msr3d_wgrad_rows_split(M, N, K, _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw.stride(0),
+                                                int(accumulate), _p(ws), ws.numel(), _lib.current_stream_ptr(dev))
+    _lib.check(rc, "msr3d_wgrad_rows_split")
+
+
 def _linear_bwd(M, N, K, dy, x, w, dx, dx_beta, dw, db):
     """dx (M,K) = dx_beta*dx + dy (M,N) @ w (N,K);  dw += dy^T x;  db += colsum(dy): one launch."""
     lib = _lib.load()
@@ -239,7 +263,10 @@ class _HipLinear(torch.autograd.Function):
         else:
             if ctx.needs_input_grad[1]:
                 dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-                _gemm(False, False, N, K, M, dy2, N, x2, K, dw, K)        # dW = dy^T @ x
+                if _wgrad_rows_ok(M, N, K):
+                    _wgrad_rows(M, N, K, dy2, x2, dw)
+                else:
+                    _gemm(False, False, N, K, M, dy2, N, x2, K, dw, K)    # dW = dy^T @ x
             if want_db:
                 db = torch.empty((N,), dtype=torch.float32, device=dy.device)
                 _colsum(dy2, M, N, db)

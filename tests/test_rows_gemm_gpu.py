@@ -93,3 +93,61 @@ def test_rows_gemm_split_throughput():
     print(f"\nrows_gemm_split {M} x {K} -> {N}: {us:.0f} us = {(M * (K + N) * 4) / us / 1e6:.2f} TB/s of rows, "
           f"{2 * M * N * K / us / 1e6:.0f} TFLOP/s fp32-equivalent")
     assert us < 400
+
+
+def _wgrad(M, N, K, accumulate=False, ldy=None, ldx=None, seed=0):
+    from msr3d_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(seed + M + 3 * N + 11 * K)
+    ldy, ldx = ldy or N, ldx or K
+    dy = torch.randn(M, ldy, device="cuda", generator=g)
+    x = torch.randn(M, ldx, device="cuda", generator=g)
+    dW0 = torch.randn(N, K, device="cuda", generator=g)
+    dW = dW0.clone()
+    ws = torch.empty(256 * N * K, device="cuda")
+    st = _lib.current_stream_ptr(torch.device("cuda"))
+    rc = _lib.load().msr3d_wgrad_rows_split(M, N, K, ctypes.c_void_p(dy.data_ptr()), ldy, ctypes.c_void_p(x.data_ptr()), ldx,
+                                            ctypes.c_void_p(dW.data_ptr()), K, int(accumulate),
+                                            ctypes.c_void_p(ws.data_ptr()), ws.numel(), st)
+    assert rc == 0
+    want = dy[:, :N].double().t() @ x[:, :K].double() + (dW0.double() if accumulate else 0)
+    scale = dy[:, :N].double().abs().t() @ x[:, :K].double().abs() + 1.0
+    err = float(((dW.double() - want).abs() / scale).max())
+    assert err < 5e-6, err
+    return dW
+
+
+@pytest.mark.parametrize("M,N,K", [(983040, 64, 64), (200000, 64, 4), (200000, 128, 64), (150000, 128, 132),
+                                   (150000, 256, 128), (70001, 128, 128), (700, 64, 64), (40, 20, 12)])
+def test_wgrad_rows_split_vs_float64(M, N, K):
+    _wgrad(M, N, K)
+
+
+def test_wgrad_rows_split_accumulates_pitches_and_is_reproducible():
+    _wgrad(50000, 64, 64, accumulate=True, ldy=72, ldx=68)
+    a = _wgrad(300000, 128, 128, seed=3)
+    b = _wgrad(300000, 128, 128, seed=3)
+    assert torch.equal(a, b)
+
+
+def test_wgrad_rows_split_throughput():
+    from msr3d_amd import _lib
+    M, N, K = 491520, 128, 128
+    dy = torch.randn(M, N, device="cuda")
+    x = torch.randn(M, K, device="cuda")
+    dW = torch.empty(N, K, device="cuda")
+    ws = torch.empty(256 * N * K, device="cuda")
+    st = _lib.current_stream_ptr(torch.device("cuda"))
+    p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    f = lambda: _lib.load().msr3d_wgrad_rows_split(M, N, K, p(dy), N, p(x), K, p(dW), K, 0, p(ws), ws.numel(), st)   # noqa: E731
+    for _ in range(5):
+        f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 100
+    print(f"\nwgrad_rows_split {M} rows, {N} x {K}: {us:.0f} us = {(M * (K + N) * 4) / us / 1e6:.2f} TB/s of rows")
+    assert us < 600
