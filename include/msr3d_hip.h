@@ -269,12 +269,15 @@ int msr3d_group_rows_grad(int b, int n, int m, int nsample, int C, int KP, const
  *   bwd: dx, and dgamma / dbeta (C, WRITTEN).
  * C % 4 == 0, C <= 1024.  partial_ws: 2 * C * ceil(rows / MSR3D_BN_CHUNK_ROWS) floats of scratch; the reductions
  * are two-stage and ordered (no float atomics: results are run-to-run bit-identical).
+ * partial_chunks (the _fwd entries): 0 = compute the first stage here; n > 0 = partial_ws already holds n partials
+ * [n][2][C] (column sums, sums of squares) covering all rows -- written by the producer of x
+ * (msr3d_rows_gemm_split's col_stats) -- and the pass over x that would form them is skipped.
  * ------------------------------------------------------------------------- */
 #define MSR3D_BN_CHUNK_ROWS 512
 int msr3d_bn_relu_train_fwd(long long rows, int C, const float *x, const float *gamma,
                             const float *beta, float eps, float momentum, float *running_mean,
                             float *running_var, float *y, float *save_mean, float *save_rstd,
-                            float *partial_ws, msr3d_stream_t stream);
+                            float *partial_ws, int partial_chunks, msr3d_stream_t stream);
 int msr3d_bn_relu_train_bwd(long long rows, int C, const float *x, const float *dy, const float *gamma,
                             const float *beta, const float *save_mean, const float *save_rstd,
                             float *dx, float *dgamma, float *dbeta, float *partial_ws,
@@ -292,7 +295,7 @@ int msr3d_bn_relu_maxpool_train_fwd(long long rows, int C, int nsample, const fl
                                     const float *gamma, const float *beta, float eps, float momentum,
                                     float *running_mean, float *running_var, float *pooled, int *argmax,
                                     float *xsel, float *save_mean, float *save_rstd, float *partial_ws,
-                                    msr3d_stream_t stream);
+                                    int partial_chunks, msr3d_stream_t stream);
 int msr3d_bn_relu_maxpool_train_bwd(long long rows, int C, int nsample, const float *x,
                                     const float *dpooled, const float *pooled, const int *argmax,
                                     const float *xsel, const float *gamma, const float *save_mean,
@@ -688,11 +691,15 @@ int msr3d_wgrad_rows_split(int M, int n_out, int k_in, const float *dy, int ldy,
  * (K, N): op(B)[n][k] = B[k * ldb + n]).  HBM-bound: the weight is split into LDS by each workgroup, the rows are
  * read once in MFMA fragment shape and split in registers.  K % 4 == 0, K <= MSR3D_ROWS_GEMM_MAX_K,
  * N <= MSR3D_ROWS_GEMM_MAX_N, lda % 4 == 0, ldc % 4 == 0, A and C 16-byte aligned; no split-K, no atomics:
- * bit-reproducible, every output row independent of the others. */
+ * bit-reproducible, every output row independent of the others.
+ * col_stats (optional): [ceil(M / MSR3D_ROWS_GEMM_BLOCK)][2][N] floats -- the column sums and sums of squares of C
+ * over each block of MSR3D_ROWS_GEMM_BLOCK rows, summed in a fixed order: the first stage of the BatchNorm
+ * statistics that follow the product (msr3d_bn_relu_train_fwd with have_partials). */
+#define MSR3D_ROWS_GEMM_BLOCK 256
 #define MSR3D_ROWS_GEMM_MAX_K 160
 #define MSR3D_ROWS_GEMM_MAX_N 256
 int msr3d_rows_gemm_split(int M, int N, int K, const float *A, int lda, const float *B, int ldb, int b_trans,
-                          float *C, int ldc, msr3d_stream_t stream);
+                          float *C, int ldc, float *col_stats, msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * The language-model side of the training step, first two pieces:

@@ -95,7 +95,7 @@ _SIGNATURES = {
     "msr3d_wgrad_split": [_c_int, _ptr, _ptr, _c_int, _ptr],
     "msr3d_wgrad_rows_split": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _ptr,
                                ctypes.c_longlong, _ptr],
-    "msr3d_rows_gemm_split": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _ptr, _c_int, _ptr],
+    "msr3d_rows_gemm_split": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr],
     "msr3d_bf16_gemm_lowrank": [_c_int, _c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int,
                                 _ptr, _c_int, _c_int, _c_float, _ptr],
     "msr3d_bf16_gemm_batched": [_c_int] * 5 + [_ptr, _c_int, ctypes.c_longlong, ctypes.c_longlong, _ptr, _c_int,
@@ -147,11 +147,11 @@ _SIGNATURES = {
     "msr3d_group_rows": [_c_int] * 6 + [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_group_rows_grad": [_c_int] * 6 + [_ptr, _ptr, _ptr, _ptr],
     "msr3d_bn_relu_train_fwd": [ctypes.c_longlong, _c_int, _ptr, _ptr, _ptr, _c_float, _c_float, _ptr, _ptr, _ptr,
-                                _ptr, _ptr, _ptr, _ptr],
+                                _ptr, _ptr, _ptr, _c_int, _ptr],
     "msr3d_bn_relu_train_bwd": [ctypes.c_longlong, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                                 _ptr, _ptr],
     "msr3d_bn_relu_maxpool_train_fwd": [ctypes.c_longlong, _c_int, _c_int, _ptr, _ptr, _ptr, _c_float, _c_float,
-                                        _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+                                        _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _ptr],
     "msr3d_bn_relu_maxpool_train_bwd": [ctypes.c_longlong, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                                         _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_pairwise_locs": [_c_int, _c_int, _ptr, _c_int, _c_float, _ptr, _ptr],

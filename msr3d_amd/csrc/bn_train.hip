@@ -116,32 +116,46 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(long long R, int C, con
   }
 }
 
-// Second stage: 64 channels per workgroup, 4 chunk-lanes per channel (lane l adds chunks l, l+4, ...
-// in order, in double; the four lane sums are then added in lane order): a fixed summation tree.
+// Second stage: 16 channels per workgroup, 16 chunk-lanes per channel (lane l adds chunks l, l + 16, ... in order,
+// in double; the sixteen lane sums are then added pairwise in a fixed tree).  (Four lanes per channel and 64
+// channels per workgroup left the pass at 17 us for 1,920 partials -- eighteen such launches per step.)
+constexpr int kFinCh = 16, kFinLanes = 16;
 __device__ __forceinline__ void bn_sum_partials(int C, int chunks, const float *__restrict__ partial, int c,
-                                                int l, double (*red)[4][64], double &s, double &q) {
+                                                int l, double (*red)[kFinLanes][kFinCh], double &s, double &q) {
   double a = 0.0, b = 0.0;
   if (c < C) {
 #pragma unroll 8
-    for (int k = l; k < chunks; k += 4) {
+    for (int k = l; k < chunks; k += kFinLanes) {
       a += (double)partial[((size_t)k * 2) * C + c];
       b += (double)partial[((size_t)k * 2 + 1) * C + c];
     }
   }
-  red[0][l][threadIdx.x & 63] = a;
-  red[1][l][threadIdx.x & 63] = b;
+  const int j = threadIdx.x % kFinCh;
+  red[0][l][j] = a;
+  red[1][l][j] = b;
   __syncthreads();
-  const int j = threadIdx.x & 63;
-  s = (red[0][0][j] + red[0][1][j]) + (red[0][2][j] + red[0][3][j]);
-  q = (red[1][0][j] + red[1][1][j]) + (red[1][2][j] + red[1][3][j]);
+  double t[2];
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    double v[kFinLanes];
+#pragma unroll
+    for (int u = 0; u < kFinLanes; ++u) v[u] = red[w][u][j];
+#pragma unroll
+    for (int step = 1; step < kFinLanes; step *= 2)
+#pragma unroll
+      for (int u = 0; u < kFinLanes; u += 2 * step) v[u] += v[u + step];
+    t[w] = v[0];
+  }
+  s = t[0];
+  q = t[1];
 }
 
 __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
     long long R, int C, int chunks, const float *__restrict__ partial, float eps, float momentum,
     float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ save_mean,
     float *__restrict__ save_rstd) {
-  __shared__ double red[2][4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), l = threadIdx.x >> 6;
+  __shared__ double red[2][kFinLanes][kFinCh];
+  const int c = blockIdx.x * kFinCh + threadIdx.x % kFinCh, l = threadIdx.x / kFinCh;
   double s, q;
   bn_sum_partials(C, chunks, partial, c, l, red, s, q);
   if (l != 0 || c >= C) return;
@@ -161,8 +175,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, int chunks,
                                                               const float *__restrict__ partial,
                                                               float *__restrict__ dgamma,
                                                               float *__restrict__ dbeta) {
-  __shared__ double red[2][4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), l = threadIdx.x >> 6;
+  __shared__ double red[2][kFinLanes][kFinCh];
+  const int c = blockIdx.x * kFinCh + threadIdx.x % kFinCh, l = threadIdx.x / kFinCh;
   double s, q;
   bn_sum_partials(C, chunks, partial, c, l, red, s, q);
   if (l != 0 || c >= C) return;
@@ -325,15 +339,16 @@ extern "C" {
 int msr3d_bn_relu_train_fwd(long long rows, int C, const float *x, const float *gamma,
                             const float *beta, float eps, float momentum, float *running_mean,
                             float *running_var, float *y, float *save_mean, float *save_rstd,
-                            float *partial_ws, msr3d_stream_t stream) {
-  if (rows < 0 || C <= 0 || (C % 4) != 0 || C > 1024) return MSR3D_EINVAL;
+                            float *partial_ws, int partial_chunks, msr3d_stream_t stream) {
+  if (rows < 0 || C <= 0 || (C % 4) != 0 || C > 1024 || partial_chunks < 0) return MSR3D_EINVAL;
   if (rows == 0) return 0;
   if (!x || !gamma || !beta || !y || !save_mean || !save_rstd || !partial_ws) return MSR3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int chunks = chunks_of(rows);
-  bn_partial_kernel<false><<<chunks, 256, partial_lds(C), st>>>(rows, C, x, nullptr, nullptr, nullptr, nullptr,
-                                                                nullptr, partial_ws);
-  bn_fwd_finalize_kernel<<<(C + 63) / 64, 256, 0, st>>>(rows, C, chunks, partial_ws, eps, momentum,
+  const int chunks = partial_chunks ? partial_chunks : chunks_of(rows);
+  if (!partial_chunks)
+    bn_partial_kernel<false><<<chunks, 256, partial_lds(C), st>>>(rows, C, x, nullptr, nullptr, nullptr, nullptr,
+                                                                  nullptr, partial_ws);
+  bn_fwd_finalize_kernel<<<(C + kFinCh - 1) / kFinCh, 256, 0, st>>>(rows, C, chunks, partial_ws, eps, momentum,
                                                        running_mean, running_var, save_mean, save_rstd);
   const long long n4 = rows * (C / 4);
   bn_relu_apply_kernel<<<ew_grid(n4), 256, 0, st>>>(
@@ -355,7 +370,7 @@ int msr3d_bn_relu_train_bwd(long long rows, int C, const float *x, const float *
   const int chunks = chunks_of(rows);
   bn_partial_kernel<true><<<chunks, 256, partial_lds(C), st>>>(rows, C, x, dy, gamma, beta, save_mean, save_rstd,
                                                                partial_ws);
-  bn_bwd_finalize_kernel<<<(C + 63) / 64, 256, 0, st>>>(C, chunks, partial_ws, dgamma, dbeta);
+  bn_bwd_finalize_kernel<<<(C + kFinCh - 1) / kFinCh, 256, 0, st>>>(C, chunks, partial_ws, dgamma, dbeta);
   const long long n4 = rows * (C / 4);
   bn_relu_bwd_apply_kernel<false><<<ew_grid(n4), 256, 0, st>>>(
       n4, C / 4, 1.0f / (float)rows, reinterpret_cast<const float4 *>(x),
@@ -370,16 +385,18 @@ int msr3d_bn_relu_maxpool_train_fwd(long long rows, int C, int nsample, const fl
                                     const float *gamma, const float *beta, float eps, float momentum,
                                     float *running_mean, float *running_var, float *pooled, int *argmax,
                                     float *xsel, float *save_mean, float *save_rstd, float *partial_ws,
-                                    msr3d_stream_t stream) {
-  if (rows < 0 || C <= 0 || (C % 4) != 0 || C > 1024 || nsample <= 0 || rows % nsample) return MSR3D_EINVAL;
+                                    int partial_chunks, msr3d_stream_t stream) {
+  if (rows < 0 || C <= 0 || (C % 4) != 0 || C > 1024 || nsample <= 0 || rows % nsample || partial_chunks < 0)
+    return MSR3D_EINVAL;
   if (rows == 0) return 0;
   if (!x || !gamma || !beta || !pooled || !argmax || !xsel || !save_mean || !save_rstd || !partial_ws)
     return MSR3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int chunks = chunks_of(rows);
-  bn_partial_kernel<false><<<chunks, 256, partial_lds(C), st>>>(rows, C, x, nullptr, nullptr, nullptr, nullptr,
-                                                                nullptr, partial_ws);
-  bn_fwd_finalize_kernel<<<(C + 63) / 64, 256, 0, st>>>(rows, C, chunks, partial_ws, eps, momentum,
+  const int chunks = partial_chunks ? partial_chunks : chunks_of(rows);
+  if (!partial_chunks)
+    bn_partial_kernel<false><<<chunks, 256, partial_lds(C), st>>>(rows, C, x, nullptr, nullptr, nullptr, nullptr,
+                                                                  nullptr, partial_ws);
+  bn_fwd_finalize_kernel<<<(C + kFinCh - 1) / kFinCh, 256, 0, st>>>(rows, C, chunks, partial_ws, eps, momentum,
                                                         running_mean, running_var, save_mean, save_rstd);
   const long long G = rows / nsample;
   const int GL = 256 / (C / 4);
@@ -414,7 +431,7 @@ int msr3d_bn_relu_maxpool_train_bwd(long long rows, int C, int nsample, const fl
   bn_pooled_partial_kernel<<<chunks, 256, partial_lds(C), st>>>(
       G, C, gpc, reinterpret_cast<const float4 *>(dpooled), reinterpret_cast<const float4 *>(pooled),
       reinterpret_cast<const float4 *>(xsel), save_mean, save_rstd, partial_ws);
-  bn_bwd_finalize_kernel<<<(C + 63) / 64, 256, 0, st>>>(C, chunks, partial_ws, dgamma, dbeta);
+  bn_bwd_finalize_kernel<<<(C + kFinCh - 1) / kFinCh, 256, 0, st>>>(C, chunks, partial_ws, dgamma, dbeta);
   const long long n4 = rows * (C / 4);
   bn_relu_bwd_apply_kernel<true><<<ew_grid(n4), 256, 0, st>>>(
       n4, C / 4, 1.0f / (float)rows, reinterpret_cast<const float4 *>(x), nullptr,

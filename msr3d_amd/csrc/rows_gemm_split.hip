@@ -32,11 +32,27 @@ struct RowsGemm {
   const float *B; int ldb; int b_trans;
   float *C; int ldc;
   int nblk;                       // row blocks of 256
+  float *stats;                   // optional: [nblk][2][N] column sums / sums of squares of each block's rows of C
 };
+
+// sum over the 16 lanes of a DPP row (the 16 rows of an MFMA tile a lane group holds), result in every lane;
+// a fixed tree: quad, half row, row
+__device__ __forceinline__ float row16_sum(float v) {
+  int x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true));   // row_half_mirror
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, true));   // row_mirror
+  return v;
+}
 
 template <int NT, int KS>
 __global__ __launch_bounds__(512, 1) void rows_gemm_split_kernel(const RowsGemm p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [KS][NT][3][64][16 B]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [KS][NT][3][64][16 B], then the statistics'
+  float *sred = reinterpret_cast<float *>(smem + KS * NT * 3 * 1024);    // [2 parities][8 waves][2][NT * 16]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
@@ -60,9 +76,24 @@ __global__ __launch_bounds__(512, 1) void rows_gemm_split_kernel(const RowsGemm 
   __syncthreads();
 
   const unsigned char *bl = smem + lane * 16;
-  for (int blk = blockIdx.x; blk < p.nblk; blk += gridDim.x) {
+  int parity = 0;
+  for (int blk = blockIdx.x; blk < p.nblk; blk += gridDim.x, parity ^= 1) {
     const int r0 = blk * 256 + wave * 32;
-    if (r0 >= p.M) continue;
+    if (r0 >= p.M) {                // (only in the last block; with statistics the wave still meets the barrier)
+      if (p.stats) {
+        float *mine = sred + ((parity * 8 + wave) * 2) * (NT * 16);
+        for (int c = lane; c < 2 * NT * 16; c += 64) mine[c] = 0.f;
+        __syncthreads();
+        for (int c = tid; c < 2 * NT * 16; c += 512) {
+          const int which = c / (NT * 16), col = c - which * (NT * 16);
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < 8; ++w) t += sred[((parity * 8 + w) * 2 + which) * (NT * 16) + col];
+          if (n0 + col < p.N) p.stats[((size_t)blk * 2 + which) * p.N + n0 + col] = t;
+        }
+      }
+      continue;
+    }
     // this lane's fragment-shaped fp32 values: rows r0 + 16 rt + i (clamped: rows past M are computed and dropped)
     f32x4 raw[2][KS][2];
 #pragma unroll
@@ -109,6 +140,32 @@ __global__ __launch_bounds__(512, 1) void rows_gemm_split_kernel(const RowsGemm 
 #undef MSR3D_TERM
       }
     }
+    if (p.stats) {
+      // column sums / sums of squares of this block's rows (rows past M: nothing), wave by wave, then the eight
+      // waves in order: the first stage of the BatchNorm statistics that follow the product (bn_train.hip)
+      const float m0 = r0 + i < p.M ? 1.f : 0.f, m1 = r0 + 16 + i < p.M ? 1.f : 0.f;
+      float *mine = sred + ((parity * 8 + wave) * 2) * (NT * 16);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = acc[0][t][e] * m0, b = acc[1][t][e] * m1;
+          const float s1 = row16_sum(a + b), s2 = row16_sum(__builtin_fmaf(a, a, b * b));
+          if (i == 0) {
+            mine[16 * t + 4 * g + e] = s1;
+            mine[NT * 16 + 16 * t + 4 * g + e] = s2;
+          }
+        }
+      }
+      __syncthreads();
+      for (int c = tid; c < 2 * NT * 16; c += 512) {
+        const int which = c / (NT * 16), col = c - which * (NT * 16);
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += sred[((parity * 8 + w) * 2 + which) * (NT * 16) + col];
+        if (n0 + col < p.N) p.stats[((size_t)blk * 2 + which) * p.N + n0 + col] = t;
+      }
+    }
     // lane (i, g) holds columns 16 t + 4 g .. + 3 of row i
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -132,7 +189,7 @@ __global__ __launch_bounds__(512, 1) void rows_gemm_split_kernel(const RowsGemm 
 
 template <int NT, int KS>
 int launch(const RowsGemm &p, int ny, hipStream_t st) {
-  constexpr int lds = KS * NT * 3 * 1024;
+  constexpr int lds = KS * NT * 3 * 1024 + 2 * 8 * 2 * NT * 16 * 4;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&rows_gemm_split_kernel<NT, KS>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (attr != hipSuccess) return (int)attr;
@@ -155,11 +212,11 @@ int pick_ks(const RowsGemm &p, int ny, int ks, hipStream_t st) {
 }  // namespace
 
 extern "C" int msr3d_rows_gemm_split(int M, int N, int K, const float *A, int lda, const float *B, int ldb, int b_trans,
-                                     float *C, int ldc, msr3d_stream_t stream) {
+                                     float *C, int ldc, float *col_stats, msr3d_stream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || K > MSR3D_ROWS_GEMM_MAX_K || N > MSR3D_ROWS_GEMM_MAX_N) return MSR3D_EINVAL;
   if (!A || !B || !C || (K & 3) || (lda & 3) || (ldc & 3) || lda < K || ldc < N) return MSR3D_EINVAL;
   if ((reinterpret_cast<uintptr_t>(A) & 15u) || (reinterpret_cast<uintptr_t>(C) & 15u)) return MSR3D_EINVAL;
-  RowsGemm p{M, N, K, A, lda, B, ldb, b_trans, C, ldc, (M + 255) / 256};
+  RowsGemm p{M, N, K, A, lda, B, ldb, b_trans, C, ldc, (M + 255) / 256, col_stats};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int ks = (K + 31) / 32;
   // column tiles per workgroup: all of them up to 144 columns (9 tiles), else halves of <= 128

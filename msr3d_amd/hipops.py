@@ -113,10 +113,14 @@ def _rows_split_ok(M, N, K, A, C):
             and A.data_ptr() % 16 == 0 and C.data_ptr() % 16 == 0)
 
 
-def _rows_gemm(M, N, K, A, lda, B, ldb, b_trans, C, ldc):
-    """C (M, N) = A (M, K) op(B)^T, op(B) = B (N, K) or, b_trans, B (K, N)^T."""
+ROWS_GEMM_BLOCK = 256      # MSR3D_ROWS_GEMM_BLOCK
+
+
+def _rows_gemm(M, N, K, A, lda, B, ldb, b_trans, C, ldc, stats=None):
+    """C (M, N) = A (M, K) op(B)^T, op(B) = B (N, K) or, b_trans, B (K, N)^T.  stats: (ceil(M / 256), 2, N) floats that
+    receive C's per-block column sums and sums of squares."""
     with torch.cuda.device(C.device):
-        rc = _lib.load().msr3d_rows_gemm_split(M, N, K, _p(A), lda, _p(B), ldb, int(b_trans), _p(C), ldc,
+        rc = _lib.load().msr3d_rows_gemm_split(M, N, K, _p(A), lda, _p(B), ldb, int(b_trans), _p(C), ldc, _p(stats),
                                                _lib.current_stream_ptr(C.device))
     _lib.check(rc, "msr3d_rows_gemm_split")
 
@@ -176,7 +180,7 @@ def _colsum(X, M, N, out, accumulate=False):
 
 class _HipLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, gelu):
+    def forward(ctx, x, weight, bias, gelu, stats_out=None):
         x2 = x.reshape(-1, x.shape[-1])
         if not x2.is_contiguous():
             x2 = x2.contiguous()
@@ -186,7 +190,11 @@ class _HipLinear(torch.autograd.Function):
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
         pre = torch.empty_like(y) if gelu else None
         if bias is None and not gelu and _rows_split_ok(M, N, K, x2, y):
-            _rows_gemm(M, N, K, x2, K, w, K, False, y, N)
+            stats = None
+            if stats_out is not None:      # the BatchNorm that follows takes its first-stage statistics from here
+                stats = torch.empty((-(-M // ROWS_GEMM_BLOCK), 2, N), dtype=torch.float32, device=x.device)
+                stats_out.append(stats)
+            _rows_gemm(M, N, K, x2, K, w, K, False, y, N, stats)
         else:
             _gemm(True, True, M, N, K, x2, K, w, K, y, N, bias=bias, c_pre=pre, flags=1 if gelu else 0)
         ctx.save_for_backward(x2, w, pre)
@@ -221,7 +229,7 @@ class _HipLinear(torch.autograd.Function):
             dpw.mark_ready(wparam)
             if bparam is not None:
                 dpw.mark_ready(bparam)
-            return dx.reshape(ctx.x_shape), None, None, None
+            return dx.reshape(ctx.x_shape), None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
             if _rows_split_ok(M, K, N, dy2, dx):
@@ -249,7 +257,7 @@ class _HipLinear(torch.autograd.Function):
             dpw.mark_ready(wparam)
             if bparam is not None:
                 dpw.mark_ready(bparam)
-            return dx, None, None, None
+            return dx, None, None, None, None
         if ctx.needs_input_grad[1] and want_db:
             # dW = dy^T @ x and db = colsum(dy) from ONE launch into one buffer
             buf = torch.empty((N * K + N,), dtype=torch.float32, device=dy.device)
@@ -270,17 +278,18 @@ class _HipLinear(torch.autograd.Function):
             if want_db:
                 db = torch.empty((N,), dtype=torch.float32, device=dy.device)
                 _colsum(dy2, M, N, db)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def linear(x, weight, bias=None, gelu=False):
-    """F.linear (optionally followed by exact GELU) on the HIP GEMM for GPU fp32 tensors."""
+def linear(x, weight, bias=None, gelu=False, stats_out=None):
+    """F.linear (optionally followed by exact GELU) on the HIP GEMM for GPU fp32 tensors.  stats_out: a list; when
+    the product runs on the tall-rows kernel, the per-block column statistics of y are appended to it."""
     if x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32:
         # (the path is fp32; other dtypes -- e.g. the float64 references of the tests -- are not
         # part of it and use torch's own GEMM)
         if gelu and weight.shape[0] % 4 != 0:
             raise RuntimeError("fused GELU needs an output width that is a multiple of 4")
-        return _HipLinear.apply(x, weight, bias, gelu)
+        return _HipLinear.apply(x, weight, bias, gelu, stats_out)
     y = F.linear(x, weight, bias)
     return F.gelu(y) if gelu else y
 
@@ -385,7 +394,7 @@ class _BNReLUTrain(torch.autograd.Function):
     running statistics like nn.BatchNorm2d.forward does."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, bn):
+    def forward(ctx, x, gamma, beta, bn, partials=None):
         R, C = x.shape
         momentum, rm, rv = _bn_train_args(bn, x)
         x = x if x.is_contiguous() else x.contiguous()
@@ -393,11 +402,11 @@ class _BNReLUTrain(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        ws = torch.empty(2 * C * max(1, -(-R // BN_CHUNK_ROWS)), dtype=torch.float32, device=x.device)
+        ws, chunks = _bn_partials(partials, R, C, x.device)
         with torch.cuda.device(x.device):
             rc = _lib.load().msr3d_bn_relu_train_fwd(
                 R, C, _p(x), _p(g), _p(b), float(bn.eps), momentum, _p(rm), _p(rv), _p(y), _p(mean),
-                _p(rstd), _p(ws), _lib.current_stream_ptr(x.device))
+                _p(rstd), _p(ws), chunks, _lib.current_stream_ptr(x.device))
         _lib.check(rc, "msr3d_bn_relu_train_fwd")
         ctx.save_for_backward(x, g, b, mean, rstd)
         return y
@@ -416,7 +425,16 @@ class _BNReLUTrain(torch.autograd.Function):
                 R, C, _p(x), _p(dy), _p(g), _p(b), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), _p(ws),
                 _lib.current_stream_ptr(x.device))
         _lib.check(rc, "msr3d_bn_relu_train_bwd")
-        return dx, dg, db, None
+        return dx, dg, db, None, None
+
+
+def _bn_partials(partials, R, C, device):
+    """(workspace, partial_chunks) for the forward statistics: the producer's per-block partials (the tall-rows GEMM's
+    col_stats) if it left any, else scratch for the kernel's own first stage."""
+    if partials is not None:
+        assert partials.shape == (-(-R // ROWS_GEMM_BLOCK), 2, C) and partials.is_contiguous()
+        return partials, partials.shape[0]
+    return torch.empty(2 * C * max(1, -(-R // BN_CHUNK_ROWS)), dtype=torch.float32, device=device), 0
 
 
 def _bn_train_args(bn, x):
@@ -441,7 +459,7 @@ class _BNReLUMaxPoolTrain(torch.autograd.Function):
     neither the (R, C) activation nor its gradient is materialised."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, bn, ns):
+    def forward(ctx, x, gamma, beta, bn, ns, partials=None):
         R, C = x.shape
         momentum, rm, rv = _bn_train_args(bn, x)
         x = x if x.is_contiguous() else x.contiguous()
@@ -451,11 +469,11 @@ class _BNReLUMaxPoolTrain(torch.autograd.Function):
         xsel = torch.empty_like(pooled)
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        ws = torch.empty(2 * C * max(1, -(-R // BN_CHUNK_ROWS)), dtype=torch.float32, device=x.device)
+        ws, chunks = _bn_partials(partials, R, C, x.device)
         with torch.cuda.device(x.device):
             rc = _lib.load().msr3d_bn_relu_maxpool_train_fwd(
                 R, C, ns, _p(x), _p(g), _p(b), float(bn.eps), momentum, _p(rm), _p(rv), _p(pooled), _p(arg),
-                _p(xsel), _p(mean), _p(rstd), _p(ws), _lib.current_stream_ptr(x.device))
+                _p(xsel), _p(mean), _p(rstd), _p(ws), chunks, _lib.current_stream_ptr(x.device))
         _lib.check(rc, "msr3d_bn_relu_maxpool_train_fwd")
         ctx.save_for_backward(x, g, mean, rstd, pooled, arg, xsel)
         ctx.ns = ns
@@ -475,7 +493,7 @@ class _BNReLUMaxPoolTrain(torch.autograd.Function):
                 R, C, ctx.ns, _p(x), _p(dpooled), _p(pooled), _p(arg), _p(xsel), _p(g), _p(mean), _p(rstd), _p(dx),
                 _p(dg), _p(db), _p(ws), _lib.current_stream_ptr(x.device))
         _lib.check(rc, "msr3d_bn_relu_maxpool_train_bwd")
-        return dx, dg, db, None, None
+        return dx, dg, db, None, None, None
 
 
 def _mlp_train_ok(mlp):
@@ -511,11 +529,13 @@ def _mlp_rows(mlp, t, pool_ns):
         w = conv.weight.view(conv.out_channels, conv.in_channels)
         if t.shape[1] != w.shape[1]:
             w = F.pad(w, (0, t.shape[1] - w.shape[1]))      # zero columns against the operand's padding
-        z = linear(t, w)
+        got = []
+        z = linear(t, w, stats_out=got)
+        part = got[0] if got else None
         if j + 1 < len(pairs):
-            t = _BNReLUTrain.apply(z, bn.weight, bn.bias, bn)
+            t = _BNReLUTrain.apply(z, bn.weight, bn.bias, bn, part)
         else:
-            t = _BNReLUMaxPoolTrain.apply(z, bn.weight, bn.bias, bn, pool_ns)
+            t = _BNReLUMaxPoolTrain.apply(z, bn.weight, bn.bias, bn, pool_ns, part)
     return t
 
 

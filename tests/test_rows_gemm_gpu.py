@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(M, N, K, b_trans, lda=None, ldc=None, seed=0):
+def _run(M, N, K, b_trans, lda=None, ldc=None, seed=0, with_stats=False):
     from msr3d_amd import _lib
     g = torch.Generator(device="cuda").manual_seed(seed + M + 7 * N + 13 * K)
     lda = lda or K
@@ -19,9 +19,19 @@ def _run(M, N, K, b_trans, lda=None, ldc=None, seed=0):
     B = torch.randn((K, N) if b_trans else (N, K), device="cuda", generator=g) * 0.3
     C = torch.full((M, ldc), float("nan"), device="cuda")
     st = _lib.current_stream_ptr(torch.device("cuda"))
+    stats = torch.full(((M + 255) // 256, 2, N), float("nan"), device="cuda") if with_stats else None
     rc = _lib.load().msr3d_rows_gemm_split(M, N, K, ctypes.c_void_p(A.data_ptr()), lda, ctypes.c_void_p(B.data_ptr()),
-                                           B.shape[1], int(b_trans), ctypes.c_void_p(C.data_ptr()), ldc, st)
+                                           B.shape[1], int(b_trans), ctypes.c_void_p(C.data_ptr()), ldc,
+                                           ctypes.c_void_p(stats.data_ptr() if with_stats else 0), st)
     assert rc == 0
+    if with_stats:
+        # per 256-row block: column sums and sums of squares of the STORED values (fp32 summation noise only)
+        Cd = C[:, :N].double()
+        pad = (-M) % 256
+        Cp = torch.cat([Cd, torch.zeros(pad, N, device="cuda", dtype=torch.float64)]).view(-1, 256, N)
+        s1, s2 = Cp.sum(1), (Cp * Cp).sum(1)
+        assert float((stats[:, 0].double() - s1).abs().max() / Cp.abs().sum(1).max()) < 1e-6
+        assert float((stats[:, 1].double() - s2).abs().max() / s2.max()) < 1e-6
     want = A[:, :K].double() @ (B.double() if b_trans else B.double().t())
     scale = (A[:, :K].double().abs() @ (B.double().abs() if b_trans else B.double().abs().t()))
     err = float(((C[:, :N].double() - want).abs() / scale).max())
@@ -41,6 +51,11 @@ def test_rows_gemm_split_vs_float64(M, N, K, b_trans):
     _run(M, N, K, b_trans)
 
 
+@pytest.mark.parametrize("M,N,K", [(40000, 64, 64), (30000, 128, 132), (30001, 256, 128), (257, 144, 160), (100, 20, 36)])
+def test_rows_gemm_split_column_statistics(M, N, K):
+    _run(M, N, K, 0, with_stats=True)
+
+
 def test_rows_gemm_split_padded_pitches_and_reproducible():
     from msr3d_amd import _lib
     _run(9000, 64, 64, 0, lda=72, ldc=80)
@@ -53,7 +68,7 @@ def test_rows_gemm_split_padded_pitches_and_reproducible():
         C = torch.empty(70000, 128, device="cuda")
         assert _lib.load().msr3d_rows_gemm_split(70000, 128, 128, ctypes.c_void_p(A.data_ptr()), 128,
                                                  ctypes.c_void_p(B.data_ptr()), 128, 0,
-                                                 ctypes.c_void_p(C.data_ptr()), 128, st) == 0
+                                                 ctypes.c_void_p(C.data_ptr()), 128, None, st) == 0
         outs.append(C)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
@@ -65,9 +80,9 @@ def test_rows_gemm_split_rejects_what_it_does_not_take():
     st = _lib.current_stream_ptr(torch.device("cuda"))
     f = _lib.load().msr3d_rows_gemm_split
     p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
-    assert f(64, 64, 192, p(A), 256, p(A), 256, 0, p(C), 512, st) == -22      # K > 160
-    assert f(64, 272, 64, p(A), 256, p(A), 256, 0, p(C), 512, st) == -22      # N > 256
-    assert f(64, 64, 62, p(A), 256, p(A), 256, 0, p(C), 512, st) == -22       # K % 4
+    assert f(64, 64, 192, p(A), 256, p(A), 256, 0, p(C), 512, None, st) == -22      # K > 160
+    assert f(64, 272, 64, p(A), 256, p(A), 256, 0, p(C), 512, None, st) == -22      # N > 256
+    assert f(64, 64, 62, p(A), 256, p(A), 256, 0, p(C), 512, None, st) == -22       # K % 4
 
 
 def test_rows_gemm_split_throughput():
@@ -77,16 +92,17 @@ def test_rows_gemm_split_throughput():
     A = torch.randn(M, K, device="cuda")
     B = torch.randn(N, K, device="cuda")
     C = torch.empty(M, N, device="cuda")
+    S = torch.empty((M + 255) // 256, 2, N, device="cuda")        # (with the statistics epilogue, as the layer runs it)
     st = _lib.current_stream_ptr(torch.device("cuda"))
     f = _lib.load().msr3d_rows_gemm_split
     p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
     for _ in range(5):
-        f(M, N, K, p(A), K, p(B), K, 0, p(C), N, st)
+        f(M, N, K, p(A), K, p(B), K, 0, p(C), N, p(S), st)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10):
-        f(M, N, K, p(A), K, p(B), K, 0, p(C), N, st)
+        f(M, N, K, p(A), K, p(B), K, 0, p(C), N, p(S), st)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 100
