@@ -696,8 +696,8 @@ int msr3d_wgrad_rows_split(int M, int n_out, int k_in, const float *dy, int ldy,
  * over each block of MSR3D_ROWS_GEMM_BLOCK rows, summed in a fixed order: the first stage of the BatchNorm
  * statistics that follow the product (msr3d_bn_relu_train_fwd with have_partials). */
 #define MSR3D_ROWS_GEMM_BLOCK 256
-#define MSR3D_ROWS_GEMM_MAX_K 160
-#define MSR3D_ROWS_GEMM_MAX_N 256
+#define MSR3D_ROWS_GEMM_MAX_K 1024
+#define MSR3D_ROWS_GEMM_MAX_N 1024
 int msr3d_rows_gemm_split(int M, int N, int K, const float *A, int lda, const float *B, int ldb, int b_trans,
                           float *C, int ldc, float *col_stats, msr3d_stream_t stream);
 

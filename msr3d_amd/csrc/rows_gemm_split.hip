@@ -58,86 +58,89 @@ __global__ __launch_bounds__(512, 1) void rows_gemm_split_kernel(const RowsGemm 
   const int i = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.y * (NT * 16);
 
-  // op(B) -> LDS planes: unit = (slab s, tile t, lane l): row n0 + 16 t + (l & 15), k = 32 s + 8 (l >> 4) .. + 7
-  for (int u = tid; u < KS * NT * 64; u += 512) {
-    const int l = u & 63, t = (u >> 6) % NT, s = (u >> 6) / NT;
-    const int n = n0 + 16 * t + (l & 15), k = 32 * s + 8 * (l >> 4);
-    float v[8];
+  // op(B) -> LDS planes: unit = (slab s, tile t, lane l): row n0 + 16 t + (l & 15), k = kb + 32 s + 8 (l >> 4) .. + 7
+  auto load_b = [&](int kb) {
+    for (int u = tid; u < KS * NT * 64; u += 512) {
+      const int l = u & 63, t = (u >> 6) % NT, s = (u >> 6) / NT;
+      const int n = n0 + 16 * t + (l & 15), k = kb + 32 * s + 8 * (l >> 4);
+      float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const bool ok = n < p.N && k + e < p.K;
-      v[e] = ok ? (p.b_trans ? p.B[(size_t)(k + e) * p.ldb + n] : p.B[(size_t)n * p.ldb + k + e]) : 0.f;
+      for (int e = 0; e < 8; ++e) {
+        const bool ok = n < p.N && k + e < p.K;
+        v[e] = ok ? (p.b_trans ? p.B[(size_t)(k + e) * p.ldb + n] : p.B[(size_t)n * p.ldb + k + e]) : 0.f;
+      }
+      uint4 pl[3];
+      sm_split8(v, pl);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<uint4 *>(smem + (((s * NT + t) * 3 + q) * 64 + l) * 16) = pl[q];
     }
-    uint4 pl[3];
-    sm_split8(v, pl);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) *reinterpret_cast<uint4 *>(smem + (((s * NT + t) * 3 + q) * 64 + l) * 16) = pl[q];
+  };
+  // K wider than one LDS image of op(B) (KS slabs): the image is re-filled per super-slab inside the row-block loop
+  // (the short, wide products of the last set-abstraction level: a workgroup has one or two row blocks)
+  const int nsup = (p.K + KS * 32 - 1) / (KS * 32);
+  if (nsup == 1) {
+    load_b(0);
+    __syncthreads();
   }
-  __syncthreads();
 
   const unsigned char *bl = smem + lane * 16;
   int parity = 0;
   for (int blk = blockIdx.x; blk < p.nblk; blk += gridDim.x, parity ^= 1) {
     const int r0 = blk * 256 + wave * 32;
-    if (r0 >= p.M) {                // (only in the last block; with statistics the wave still meets the barrier)
-      if (p.stats) {
-        float *mine = sred + ((parity * 8 + wave) * 2) * (NT * 16);
-        for (int c = lane; c < 2 * NT * 16; c += 64) mine[c] = 0.f;
-        __syncthreads();
-        for (int c = tid; c < 2 * NT * 16; c += 512) {
-          const int which = c / (NT * 16), col = c - which * (NT * 16);
-          float t = 0.f;
-#pragma unroll
-          for (int w = 0; w < 8; ++w) t += sred[((parity * 8 + w) * 2 + which) * (NT * 16) + col];
-          if (n0 + col < p.N) p.stats[((size_t)blk * 2 + which) * p.N + n0 + col] = t;
-        }
-      }
-      continue;
-    }
-    // this lane's fragment-shaped fp32 values: rows r0 + 16 rt + i (clamped: rows past M are computed and dropped)
-    f32x4 raw[2][KS][2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      const float *row = p.A + (size_t)min(r0 + 16 * rt + i, p.M - 1) * p.lda + 8 * g;
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int k = 32 * s + 8 * g;
-        raw[rt][s][0] = k < p.K ? *reinterpret_cast<const f32x4 *>(row + 32 * s) : f32x4{0.f, 0.f, 0.f, 0.f};
-        raw[rt][s][1] = k + 4 < p.K ? *reinterpret_cast<const f32x4 *>(row + 32 * s + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
+    const bool live = r0 < p.M;     // (a wave past M -- last block only -- still meets the barriers)
     f32x4 acc[2][NT];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      bf16x8 fa[2][3];
+    for (int sup = 0; sup < nsup; ++sup) {
+      const int kb = sup * KS * 32;
+      if (nsup > 1) {
+        __syncthreads();            // everyone is done with the previous image
+        load_b(kb);
+        __syncthreads();
+      }
+      if (!live) continue;
+      // this lane's fragment-shaped fp32 values: rows r0 + 16 rt + i (clamped: rows past M are computed and dropped)
+      f32x4 raw[2][KS][2];
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        const float v[8] = {raw[rt][s][0][0], raw[rt][s][0][1], raw[rt][s][0][2], raw[rt][s][0][3],
-                            raw[rt][s][1][0], raw[rt][s][1][1], raw[rt][s][1][2], raw[rt][s][1][3]};
-        uint4 pl[3];
-        sm_split8(v, pl);
+        const float *row = p.A + (size_t)min(r0 + 16 * rt + i, p.M - 1) * p.lda + kb + 8 * g;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) fa[rt][q] = __builtin_bit_cast(bf16x8, pl[q]);
+        for (int s = 0; s < KS; ++s) {
+          const int k = kb + 32 * s + 8 * g;
+          raw[rt][s][0] = k < p.K ? *reinterpret_cast<const f32x4 *>(row + 32 * s) : f32x4{0.f, 0.f, 0.f, 0.f};
+          raw[rt][s][1] = k + 4 < p.K ? *reinterpret_cast<const f32x4 *>(row + 32 * s + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        bf16x8 fb[3];
+      for (int s = 0; s < KS; ++s) {
+        bf16x8 fa[2][3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) fb[q] = *reinterpret_cast<const bf16x8 *>(bl + ((s * NT + t) * 3 + q) * 1024);
+        for (int rt = 0; rt < 2; ++rt) {
+          const float v[8] = {raw[rt][s][0][0], raw[rt][s][0][1], raw[rt][s][0][2], raw[rt][s][0][3],
+                              raw[rt][s][1][0], raw[rt][s][1][1], raw[rt][s][1][2], raw[rt][s][1][3]};
+          uint4 pl[3];
+          sm_split8(v, pl);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) fa[rt][q] = __builtin_bit_cast(bf16x8, pl[q]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          bf16x8 fb[3];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) fb[q] = *reinterpret_cast<const bf16x8 *>(bl + ((s * NT + t) * 3 + q) * 1024);
 #define MSR3D_TERM(PB, PA)                                                                            \
-        _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                              \
-            acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[PB], fa[rt][PA], acc[rt][t], 0, 0, 0);
-        MSR3D_TERM(2, 0)
-        MSR3D_TERM(0, 2)
-        MSR3D_TERM(1, 1)
-        MSR3D_TERM(1, 0)
-        MSR3D_TERM(0, 1)
-        MSR3D_TERM(0, 0)
+          _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                            \
+              acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[PB], fa[rt][PA], acc[rt][t], 0, 0, 0);
+          MSR3D_TERM(2, 0)
+          MSR3D_TERM(0, 2)
+          MSR3D_TERM(1, 1)
+          MSR3D_TERM(1, 0)
+          MSR3D_TERM(0, 1)
+          MSR3D_TERM(0, 0)
 #undef MSR3D_TERM
+        }
       }
     }
     if (p.stats) {
@@ -166,6 +169,7 @@ __global__ __launch_bounds__(512, 1) void rows_gemm_split_kernel(const RowsGemm 
         if (n0 + col < p.N) p.stats[((size_t)blk * 2 + which) * p.N + n0 + col] = t;
       }
     }
+    if (!live) continue;
     // lane (i, g) holds columns 16 t + 4 g .. + 3 of row i
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -205,7 +209,8 @@ int pick_ks(const RowsGemm &p, int ny, int ks, hipStream_t st) {
     case 2: return launch<NT, 2>(p, ny, st);
     case 3: return launch<NT, 3>(p, ny, st);
     case 4: return launch<NT, 4>(p, ny, st);
-    default: return launch<NT, 5>(p, ny, st);
+    case 5: return launch<NT, 5>(p, ny, st);
+    default: return launch<NT, 4>(p, ny, st);      // wider: super-slabs of 128
   }
 }
 
@@ -223,6 +228,6 @@ extern "C" int msr3d_rows_gemm_split(int M, int N, int K, const float *A, int ld
   const int tiles = (N + 15) / 16;
   if (tiles <= 4) return pick_ks<4>(p, 1, ks, st);
   if (tiles <= 8) return pick_ks<8>(p, 1, ks, st);
-  if (tiles == 9) return pick_ks<9>(p, 1, ks, st);
+  if (tiles == 9 && ks <= 5) return pick_ks<9>(p, 1, ks, st);
   return pick_ks<8>(p, (tiles + 7) / 8, ks, st);
 }

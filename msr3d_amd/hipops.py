@@ -103,13 +103,16 @@ def _gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, bias=None, c_pre=None, fl
     _lib.check(rc, "msr3d_gemm_f32")
 
 
-# Tall token GEMMs (an unfrozen backbone's SharedMLP rows: >= 8192 rows, <= 160 reduction, <= 256 outputs) go to
+# Tall token GEMMs (an unfrozen backbone's SharedMLP rows: >= 8192 rows) go to
 # msr3d_rows_gemm_split: bf16 pipe at fp32 accuracy, HBM-bound.  MSR3D_ROWS_GEMM=f32 keeps them on the fp32 pipe.
 _ROWS_SPLIT = _os.environ.get("MSR3D_ROWS_GEMM", "split") != "f32"
 
 
 def _rows_split_ok(M, N, K, A, C):
-    return (_ROWS_SPLIT and M >= 8192 and K % 4 == 0 and N % 4 == 0 and K <= 160 and N <= 256
+    # K <= 160: the weight stays in LDS for the whole launch.  Wider reductions re-fill LDS per 128-wide super-slab
+    # and row block: right for the last level's short, wide layers (15 k rows), not for half a million rows.
+    return (_ROWS_SPLIT and M >= 8192 and K % 4 == 0 and N % 4 == 0 and N <= 1024
+            and (K <= 160 or (K <= 1024 and M <= 65536))
             and A.data_ptr() % 16 == 0 and C.data_ptr() % 16 == 0)
 
 
@@ -129,20 +132,20 @@ _wgrad_ws = {}
 
 
 def _wgrad_rows_ok(M, N, K):
-    return _ROWS_SPLIT and M >= 8192 and N <= 256 and K <= 256
+    # (any width: the chunk count adapts -- 256 / tiles chunks of n_out x k_in floats never exceed 256 x 128 x 128)
+    return _ROWS_SPLIT and M >= 8192
 
 
 def _wgrad_rows(M, N, K, dy, x, dw, accumulate=False):
     """dw (N, K) (+)= dy (M, N)^T x (M, K) over tall row counts (msr3d_wgrad_rows_split); the chunk workspace is one
-    buffer per device, grown to the largest layer seen (allocated outside any capture: see HotPathTrainStep's
-    eager warm-up)."""
+    buffer per device (33 MB: 256 / tiles chunks of n_out x k_in floats never exceed it), allocated outside any
+    capture -- HotPathTrainStep's eager warm-up step does that."""
     dev = dy.device
-    need = 256 * N * K
     ws = _wgrad_ws.get(dev.index)
-    if ws is None or ws.numel() < need:
+    if ws is None:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("the tall weight-gradient workspace must exist before graph capture (run one eager step)")
-        ws = _wgrad_ws[dev.index] = torch.empty(max(need, 256 * 256 * 128), dtype=torch.float32, device=dev)
+        ws = _wgrad_ws[dev.index] = torch.empty(256 * 256 * 128, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = _lib.load().msr3d_wgrad_rows_split(M, N, K, _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw.stride(0),
                                                 int(accumulate), _p(ws), ws.numel(), _lib.current_stream_ptr(dev))

@@ -46,12 +46,15 @@ def _run(M, N, K, b_trans, lda=None, ldc=None, seed=0, with_stats=False):
     (30000, 128, 132, 0), (30000, 128, 128, 0), (30000, 256, 128, 0),    # sa2 forward
     (40000, 64, 128, 1), (40000, 64, 64, 1),                             # sa1 d t = d z W
     (30000, 128, 128, 1), (30000, 132, 128, 1),                          # sa2
-    (257, 144, 160, 0), (31, 20, 36, 1), (1, 4, 4, 0), (513, 200, 96, 0)])
+    (257, 144, 160, 0), (31, 20, 36, 1), (1, 4, 4, 0), (513, 200, 96, 0),
+    (15360, 256, 264, 0), (15360, 512, 256, 0), (15360, 768, 512, 0),   # sa3 forward: super-slabs of 128
+    (15360, 512, 768, 1), (15360, 256, 512, 1), (9000, 260, 256, 1), (300, 1000, 1000, 0)])
 def test_rows_gemm_split_vs_float64(M, N, K, b_trans):
     _run(M, N, K, b_trans)
 
 
-@pytest.mark.parametrize("M,N,K", [(40000, 64, 64), (30000, 128, 132), (30001, 256, 128), (257, 144, 160), (100, 20, 36)])
+@pytest.mark.parametrize("M,N,K", [(40000, 64, 64), (30000, 128, 132), (30001, 256, 128), (257, 144, 160), (100, 20, 36),
+                                   (15360, 512, 256), (1000, 768, 512)])
 def test_rows_gemm_split_column_statistics(M, N, K):
     _run(M, N, K, 0, with_stats=True)
 
@@ -80,8 +83,8 @@ def test_rows_gemm_split_rejects_what_it_does_not_take():
     st = _lib.current_stream_ptr(torch.device("cuda"))
     f = _lib.load().msr3d_rows_gemm_split
     p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
-    assert f(64, 64, 192, p(A), 256, p(A), 256, 0, p(C), 512, None, st) == -22      # K > 160
-    assert f(64, 272, 64, p(A), 256, p(A), 256, 0, p(C), 512, None, st) == -22      # N > 256
+    assert f(64, 64, 1028, p(A), 1028, p(A), 1028, 0, p(C), 512, None, st) == -22   # K > 1024
+    assert f(64, 1028, 64, p(A), 256, p(A), 256, 0, p(C), 1028, None, st) == -22    # N > 1024
     assert f(64, 64, 62, p(A), 256, p(A), 256, 0, p(C), 512, None, st) == -22       # K % 4
 
 
