@@ -84,6 +84,32 @@ __global__ __launch_bounds__(512, 1) void rows_gemm_split_kernel(const RowsGemm 
   }
 
   const unsigned char *bl = smem + lane * 16;
+  // Units of work = (row block, super-slab), walked in order.  The fp32 values of unit u + 1 are loaded INTO the
+  // registers of unit u slab by slab, each right after its slab has been split (the raw values are dead then): the
+  // next unit's loads fly under this unit's MFMAs and epilogue at no register cost.
+  // (buffer loads: one descriptor in SGPRs, one 32-bit lane offset per row tile, the slab's offset as an immediate --
+  //  64-bit pointers per load cost 2 x 2 x KS address registers, which is what spilled)
+  const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.A), 0, (int)((size_t)p.M * p.lda * 4), 0x00020000);
+  auto row_off = [&](int r0, int rt, int kb) {
+    return (unsigned)(min(r0 + 16 * rt + i, p.M - 1) * p.lda + kb + 8 * g) * 4u;
+  };
+  // (a row's tail past K is zeroed where the values are CONSUMED: a select here would wait for the load)
+  auto load_slab = [&](f32x4 (&raw)[2][KS][2], int s, unsigned off0, unsigned off1) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const unsigned off = rt ? off1 : off0;
+      raw[rt][s][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, off, 128 * s, 0));
+      raw[rt][s][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, off, 128 * s + 16, 0));
+    }
+  };
+  f32x4 raw[2][KS][2];
+  if (blockIdx.x < p.nblk && blockIdx.x * 256 + wave * 32 < p.M) {
+    const int r0 = blockIdx.x * 256 + wave * 32;
+    const unsigned o0 = row_off(r0, 0, 0), o1 = row_off(r0, 1, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) load_slab(raw, s, o0, o1);
+  }
   int parity = 0;
   for (int blk = blockIdx.x; blk < p.nblk; blk += gridDim.x, parity ^= 1) {
     const int r0 = blk * 256 + wave * 32;
@@ -100,31 +126,34 @@ __global__ __launch_bounds__(512, 1) void rows_gemm_split_kernel(const RowsGemm 
         load_b(kb);
         __syncthreads();
       }
-      if (!live) continue;
-      // this lane's fragment-shaped fp32 values: rows r0 + 16 rt + i (clamped: rows past M are computed and dropped)
-      f32x4 raw[2][KS][2];
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const float *row = p.A + (size_t)min(r0 + 16 * rt + i, p.M - 1) * p.lda + kb + 8 * g;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const int k = kb + 32 * s + 8 * g;
-          raw[rt][s][0] = k < p.K ? *reinterpret_cast<const f32x4 *>(row + 32 * s) : f32x4{0.f, 0.f, 0.f, 0.f};
-          raw[rt][s][1] = k + 4 < p.K ? *reinterpret_cast<const f32x4 *>(row + 32 * s + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
+      // the unit after this one
+      const bool last_sup = sup + 1 == nsup;
+      const int nblk2 = last_sup ? blk + (int)gridDim.x : blk, nkb = last_sup ? 0 : kb + KS * 32;
+      const int nr0 = nblk2 * 256 + wave * 32;
+      const bool next_live = nblk2 < p.nblk && nr0 < p.M;
+      if (!live) continue;          // (then no later unit of this wave is live either: blocks ascend)
+      const unsigned no0 = row_off(nr0, 0, nkb), no1 = row_off(nr0, 1, nkb);
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         bf16x8 fa[2][3];
+        const float in0 = kb + 32 * s + 8 * g < p.K ? 1.f : 0.f, in1 = kb + 32 * s + 8 * g + 4 < p.K ? 1.f : 0.f;
+        const bool tail = kb + 32 * s + 32 > p.K;     // (wave-uniform: only the slab that straddles K pays the select)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-          const float v[8] = {raw[rt][s][0][0], raw[rt][s][0][1], raw[rt][s][0][2], raw[rt][s][0][3],
-                              raw[rt][s][1][0], raw[rt][s][1][1], raw[rt][s][1][2], raw[rt][s][1][3]};
+          float v[8] = {raw[rt][s][0][0], raw[rt][s][0][1], raw[rt][s][0][2], raw[rt][s][0][3],
+                        raw[rt][s][1][0], raw[rt][s][1][1], raw[rt][s][1][2], raw[rt][s][1][3]};
+          if (tail) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? in0 : in1) != 0.f ? v[e] : 0.f;
+          }
           uint4 pl[3];
           sm_split8(v, pl);
 #pragma unroll
           for (int q = 0; q < 3; ++q) fa[rt][q] = __builtin_bit_cast(bf16x8, pl[q]);
         }
+        __builtin_amdgcn_sched_barrier(0);          // (the re-load of raw[s] stays below its last use ...
+        if (next_live) load_slab(raw, s, no0, no1);
+        __builtin_amdgcn_sched_barrier(0);          //  ... and later slabs' splits stay below this slab's MFMAs)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           bf16x8 fb[3];
@@ -221,13 +250,17 @@ extern "C" int msr3d_rows_gemm_split(int M, int N, int K, const float *A, int ld
   if (M <= 0 || N <= 0 || K <= 0 || K > MSR3D_ROWS_GEMM_MAX_K || N > MSR3D_ROWS_GEMM_MAX_N) return MSR3D_EINVAL;
   if (!A || !B || !C || (K & 3) || (lda & 3) || (ldc & 3) || lda < K || ldc < N) return MSR3D_EINVAL;
   if ((reinterpret_cast<uintptr_t>(A) & 15u) || (reinterpret_cast<uintptr_t>(C) & 15u)) return MSR3D_EINVAL;
+  if ((long long)M * lda * 4 >= (1ll << 31)) return MSR3D_EINVAL;       // (32-bit byte offsets into A)
   RowsGemm p{M, N, K, A, lda, B, ldb, b_trans, C, ldc, (M + 255) / 256, col_stats};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int ks = (K + 31) / 32;
   // column tiles per workgroup: all of them up to 144 columns (9 tiles), else halves of <= 128
   const int tiles = (N + 15) / 16;
+  // tall with a 161..256-wide reduction (d t of a 256-channel layer): the whole of op(B) for 64 columns stays in LDS
+  // and the rows are read once per 64-column group -- cheaper than re-filling LDS twice per row block
+  if (ks > 5 && ks <= 8 && M > 65536) return launch<4, 8>(p, (tiles + 3) / 4, st);
   if (tiles <= 4) return pick_ks<4>(p, 1, ks, st);
   if (tiles <= 8) return pick_ks<8>(p, 1, ks, st);
-  if (tiles == 9 && ks <= 5) return pick_ks<9>(p, 1, ks, st);
+  if (tiles == 9 && ks <= 4) return pick_ks<9>(p, 1, ks, st);
   return pick_ks<8>(p, (tiles + 7) / 8, ks, st);
 }

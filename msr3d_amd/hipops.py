@@ -109,10 +109,10 @@ _ROWS_SPLIT = _os.environ.get("MSR3D_ROWS_GEMM", "split") != "f32"
 
 
 def _rows_split_ok(M, N, K, A, C):
-    # K <= 160: the weight stays in LDS for the whole launch.  Wider reductions re-fill LDS per 128-wide super-slab
+    # K <= 256: the weight stays in LDS for the whole launch.  Wider reductions re-fill LDS per 128-wide super-slab
     # and row block: right for the last level's short, wide layers (15 k rows), not for half a million rows.
     return (_ROWS_SPLIT and M >= 8192 and K % 4 == 0 and N % 4 == 0 and N <= 1024
-            and (K <= 160 or (K <= 1024 and M <= 65536))
+            and (K <= 256 or (K <= 1024 and M <= 65536))
             and A.data_ptr() % 16 == 0 and C.data_ptr() % 16 == 0)
 
 

@@ -48,7 +48,8 @@ def _run(M, N, K, b_trans, lda=None, ldc=None, seed=0, with_stats=False):
     (30000, 128, 128, 1), (30000, 132, 128, 1),                          # sa2
     (257, 144, 160, 0), (31, 20, 36, 1), (1, 4, 4, 0), (513, 200, 96, 0),
     (15360, 256, 264, 0), (15360, 512, 256, 0), (15360, 768, 512, 0),   # sa3 forward: super-slabs of 128
-    (15360, 512, 768, 1), (15360, 256, 512, 1), (9000, 260, 256, 1), (300, 1000, 1000, 0)])
+    (15360, 512, 768, 1), (15360, 256, 512, 1), (9000, 260, 256, 1), (300, 1000, 1000, 0),
+    (70000, 128, 256, 1), (66000, 132, 192, 0)])                         # tall, 161..256-wide reduction
 def test_rows_gemm_split_vs_float64(M, N, K, b_trans):
     _run(M, N, K, b_trans)
 
