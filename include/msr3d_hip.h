@@ -677,7 +677,8 @@ int msr3d_wgrad_split(int n, const msr3d_wgrad_problem_t *problems, const int *t
  * backbone: up to ~10^6 rows), the arithmetic and tile kernel of msr3d_wgrad_split: the rows are cut into up to
  * MSR3D_WGRAD_ROWS_CHUNKS / tiles chunks, one workgroup per (chunk, 128 x 128 tile) stores its partial product to
  * workspace[chunk] (n_out * k_in floats each), and a second launch adds the partials in chunk order -- no atomics,
- * bit-reproducible.  accumulate != 0: dW holds the value to add to.  workspace_floats >= n_out * k_in (more
+ * bit-reproducible.  Layers with n_out, k_in <= 64 take two chunks per workgroup, side by side in one tile (twice
+ * the chunks, the same launch size).  accumulate != 0: dW holds the value to add to.  workspace_floats >= n_out * k_in (more
  * chunks, up to the cap, when there is room). */
 #define MSR3D_WGRAD_ROWS_CHUNKS 256
 int msr3d_wgrad_rows_split(int M, int n_out, int k_in, const float *dy, int ldy, const float *x, int ldx,

@@ -56,8 +56,14 @@ __device__ __forceinline__ int frag_slot(int j, int g) { return (4 * (j & 3) + (
 // 64 x 64 quarter each, 96 MFMAs per slab from 24 ds_read_b128.  One barrier per slab; the matrix pipe and
 // the VALU work of the split overlap.
 // One 128 x 128 tile of one problem, whole reduction.  OVERWRITE: dW is set, not added to.
-template <bool OVERWRITE>
-__device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, unsigned char *smem) {
+// FOLD (n_out, k_in <= 64: half the tile's columns would be padding, and so would half of every loader
+// instruction's bytes -- the loaders' issue rate is what bounds this kernel): the tile carries TWO row chunks
+// side by side -- columns 0..63 of both operands from the rows of chunk A, columns 64..127 from those of chunk B
+// (fold_rows further down, fold_mb of them) -- so D's diagonal 64 x 64 blocks are the two chunks' products
+// (written to pr.dW and pr.dW + n_out * k_in) and the off-diagonal ones are never multiplied.
+template <bool OVERWRITE, bool FOLD = false>
+__device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, unsigned char *smem, int fold_rows = 0,
+                                           int fold_mb = 0) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n0 = ntile * TN, k0 = ktile * TK;
@@ -74,9 +80,10 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
     const int ld = isx ? pr.ldx : pr.ldy, ncol = isx ? pr.k_in : pr.n_out, c0 = isx ? k0 : n0;
     const int u = (wave & 1) * 64 + lane;          // unit: column quad Q (of 32), token octet o (of 4)
     const int Q = u & 31, o = u >> 5;
-    const int col = c0 + 4 * Q;
+    const int col = FOLD ? 4 * (Q & 15) : c0 + 4 * Q;
+    const int fold_off = FOLD ? (Q >> 4) * fold_rows * ld * 4 : 0;     // (chunk B's rows)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(src), 0, (int)((size_t)M * ld * 4), 0x00020000);
+        const_cast<float *>(src), 0, (int)((size_t)(FOLD && fold_mb ? fold_rows + fold_mb : M) * ld * 4), 0x00020000);
     const bool vec = (reinterpret_cast<uintptr_t>(src) & 15u) == 0 && (ld & 3) == 0;   // wave-uniform
     float cm[4];
     int cb[4];
@@ -97,7 +104,7 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
         // past M starts exactly at the buffer's size, so every out-of-range load returns 0
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int row = ((32 * s + e) + 8 * o) * ld * 4;
+          const int row = ((32 * s + e) + 8 * o) * ld * 4 + fold_off;
           if constexpr (VEC) {
 #ifdef WG_ABLATE_LOAD
             const f32x4 r = f32x4{(float)row, 1.f, 2.f, 3.f};
@@ -187,6 +194,7 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
 #ifdef WG_ABLATE_MMA
       continue;
 #endif
+      if (FOLD && wr != wc) continue;               // (an off-diagonal block: chunk A's dy against chunk B's x)
       const unsigned char *A = smem + (s & 1) * STAGE + slot, *Bs = A + OP_BYTES;
       bf16x8 fa[4][3], fb[4][3];
 #pragma unroll
@@ -219,12 +227,12 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const int kk = k0 + 64 * wc + 16 * b + j;
+        const int kk = FOLD ? 16 * b + j : k0 + 64 * wc + 16 * b + j;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int n = n0 + 64 * wr + 16 * a + 4 * g + r;
-          if (n < pr.n_out && kk < pr.k_in) {
-            float *d = pr.dW + (size_t)n * pr.ldw + kk;
+          const int n = FOLD ? 16 * a + 4 * g + r : n0 + 64 * wr + 16 * a + 4 * g + r;
+          if (n < pr.n_out && kk < pr.k_in && (!FOLD || (wr == wc && (wr == 0 || fold_mb > 0)))) {
+            float *d = pr.dW + (FOLD ? (size_t)wr * pr.n_out * pr.k_in : 0) + (size_t)n * pr.ldw + kk;
             *d = OVERWRITE ? acc[a][b][r] : *d + acc[a][b][r];
           }
         }
@@ -256,6 +264,22 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_kernel(int nprob, const WP
 // TALL problems (an unfrozen backbone's SharedMLP layers: dW (<= 256 x <= 256) over 10^5 .. 10^6 rows): the rows are
 // cut into chunks, workgroup (chunk, tile) reduces its chunk into ws[chunk] (n_out, k_in) -- plain stores, every
 // workgroup the only writer of its slab -- and wgrad_rows_reduce_kernel adds the slabs in chunk order.
+// n_out, k_in <= 64: workgroup b takes the chunk PAIR (2 b, 2 b + 1) in one folded tile (wgrad_tile<.., FOLD>)
+__global__ __launch_bounds__(512, 2) void wgrad_rows_fold_kernel(WP base, int chunk_rows, float *ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  WP pr = base;
+  const long long r0 = (long long)(2 * blockIdx.x) * chunk_rows;
+  pr.dy = base.dy + r0 * base.ldy;
+  pr.x = base.x + r0 * base.ldx;
+  const long long left = (long long)base.M - r0;
+  pr.M = (int)min((long long)chunk_rows, left);
+  const int mb = (int)max(0ll, min((long long)chunk_rows, left - chunk_rows));
+  pr.dW = ws + (size_t)(2 * blockIdx.x) * base.n_out * base.k_in;
+  pr.ldw = base.k_in;
+  pr.db = nullptr;
+  wgrad_tile<true, true>(pr, 0, 0, smem, chunk_rows, mb);
+}
+
 __global__ __launch_bounds__(512, 2) void wgrad_rows_kernel(WP base, int chunk_rows, int tiles, float *ws) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int chunk = blockIdx.x / tiles, tile = blockIdx.x - chunk * tiles;
@@ -312,8 +336,9 @@ extern "C" int msr3d_wgrad_rows_split(int M, int n_out, int k_in, const float *d
   if (attr != hipSuccess) return (int)attr;
   const int tiles = ((n_out + TN - 1) / TN) * ((k_in + TK - 1) / TK);
   const long long slab = (long long)n_out * k_in;
+  const bool fold = n_out <= 64 && k_in <= 64;               // two chunks per workgroup (see wgrad_tile)
   // chunks: one round of the 256 CUs, at least 512 rows each, as many as the workspace holds
-  long long chunks = MSR3D_WGRAD_ROWS_CHUNKS / tiles;
+  long long chunks = (fold ? 2 : 1) * MSR3D_WGRAD_ROWS_CHUNKS / tiles;
   chunks = chunks < 1 ? 1 : chunks;
   chunks = chunks < (M + 511) / 512 ? chunks : (M + 511) / 512;
   chunks = chunks < workspace_floats / slab ? chunks : workspace_floats / slab;
@@ -327,7 +352,14 @@ extern "C" int msr3d_wgrad_rows_split(int M, int n_out, int k_in, const float *d
   base.M = M;
   base.dW = nullptr; base.ldw = k_in; base.db = nullptr;
   hipStream_t st = (hipStream_t)stream;
-  wgrad_rows_kernel<<<(unsigned)(chunks * tiles), 512, LDS_BYTES, st>>>(base, chunk_rows, tiles, workspace);
+  if (fold) {
+    static const hipError_t fattr = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_rows_fold_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (fattr != hipSuccess) return (int)fattr;
+    wgrad_rows_fold_kernel<<<(unsigned)((chunks + 1) / 2), 512, LDS_BYTES, st>>>(base, chunk_rows, workspace);
+  } else {
+    wgrad_rows_kernel<<<(unsigned)(chunks * tiles), 512, LDS_BYTES, st>>>(base, chunk_rows, tiles, workspace);
+  }
   wgrad_rows_reduce_kernel<<<(unsigned)((slab + 255) / 256), 256, 0, st>>>(n_out, k_in, (int)chunks, workspace, dW, ldw,
                                                                           accumulate);
   return (int)hipGetLastError();

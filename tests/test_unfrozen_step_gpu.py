@@ -53,7 +53,20 @@ def _set_p0(model):
                 getattr(layer, name).p = 0.0
 
 
-def test_unfrozen_step_trains_the_backbone_like_a_plain_autograd_loop():
+@pytest.fixture
+def ordered_reductions():
+    """Bit-reproducible reductions for the test's duration.  With float atomics the forward carries ~1e-7 of
+    run-to-run noise, and a pre-activation that sits within that distance of zero flips its ReLU mask bit in the
+    BatchNorm backward: every gradient below it then moves by ~2e-3 in one run out of ten (traced to the last
+    level's second layer: same dy, different d beta) -- chaos of the network, not of the kernels, but fatal to a
+    comparison of two routes at 2e-3."""
+    from msr3d_amd import hipops
+    was = hipops.set_deterministic(True)
+    yield
+    hipops.set_deterministic(was)
+
+
+def test_unfrozen_step_trains_the_backbone_like_a_plain_autograd_loop(ordered_reductions):
     from msr3d_amd.synth import synth_batch
     batch = synth_batch(3, 2, O=12, P=1024, device="cuda")
     # reference: plain autograd through the modules (no schedule, no graph), torch AdamW on the same weights
@@ -92,10 +105,12 @@ def test_unfrozen_step_trains_the_backbone_like_a_plain_autograd_loop():
             continue                                                   # normalises rounding noise into +-lr steps)
         a, b = sd[k].double(), v.double()
         err = float((a - b).norm() / b.norm().clamp_min(1e-12))
-        # (BatchNorm biases start at zero: after two steps they ARE two Adam steps, +-2e-3, and their gradients are
-        #  cancelling sums over ~10^5 rows -- a difference below 10 % of one step is rounding, whatever its ratio to
-        #  the norm)
-        assert err < 2e-3 or float((a - b).abs().max()) < 1e-4, (k, err)
+        # (Adam normalises: where a gradient element is rounding noise around zero -- BatchNorm biases start at zero
+        #  and their gradients are cancelling sums over 10^4..10^5 rows -- its SIGN decides a whole +-lr step, and the
+        #  plain loop's split-K atomics already vary it from run to run.  So: the norm-relative bound, or at most 5 % of
+        #  the elements off by more than a tenth of a step and none by more than the two steps taken)
+        d = (a - b).abs()
+        assert err < 2e-3 or (float((d > 1e-4).double().mean()) <= 0.05 and float(d.max()) <= 2.1 * 2e-3), (k, err)
         moved += 1
     assert moved > 50
     # parameters that receive no gradient (anchor_feat, loc_layers, the unread classification head) are left
