@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void group_rows_lds_kernel(int n, int m, int n
 __global__ __launch_bounds__(256) void group_rows_grad_kernel(int n, int E, int C, int KP,
                                                               const float *__restrict__ d_rows,
                                                               const int *__restrict__ idx,
-                                                              float *__restrict__ d_feats) {
+                                                              float *__restrict__ d_feats, int stage) {
   extern __shared__ int det_lds[];
   int *start = det_lds;
   int *cursor = start + n + 1;
@@ -379,11 +379,29 @@ __global__ __launch_bounds__(256) void group_rows_grad_kernel(int n, int E, int 
   float *O = d_feats + (size_t)b * C * n;
   const int c0 = blockIdx.y * 64;                 // 64 channels per workgroup
   const int cw = min(64, C - c0);
+  // (four gathers in flight per thread -- the entries are added in list order all the same --, and the (64, n) result
+  //  goes out through LDS so that the global writes run along the points: a wave's direct stores were 64 four-byte
+  //  writes n floats apart)
+  float *ot = reinterpret_cast<float *>(list + E);           // [64][n + 1]
   for (int item = threadIdx.x; item < n * cw; item += 256) {
-    const int p = item / cw, c = c0 + item - p * cw;
+    const int p = item / cw, cl = item - p * cw, c = c0 + cl;
     float acc = 0.f;
-    for (int q = start[p]; q < start[p + 1]; ++q) acc += G[(size_t)list[q] * KP + c];
-    O[(size_t)c * n + p] = acc;
+    int q = start[p];
+    const int qe = start[p + 1];
+    for (; q + 4 <= qe; q += 4) {
+      const float g0 = G[(size_t)list[q] * KP + c], g1 = G[(size_t)list[q + 1] * KP + c],
+                  g2 = G[(size_t)list[q + 2] * KP + c], g3 = G[(size_t)list[q + 3] * KP + c];
+      acc += g0; acc += g1; acc += g2; acc += g3;
+    }
+    for (; q < qe; ++q) acc += G[(size_t)list[q] * KP + c];
+    if (stage) ot[cl * (n + 1) + p] = acc;
+    else O[(size_t)c * n + p] = acc;
+  }
+  if (!stage) return;
+  __syncthreads();
+  for (int e = threadIdx.x; e < n * cw; e += 256) {
+    const int cl = e / n, p = e - cl * n;
+    O[(size_t)(c0 + cl) * n + p] = ot[cl * (n + 1) + p];
   }
 }
 
@@ -560,13 +578,16 @@ int msr3d_group_rows_grad(int b, int n, int m, int nsample, int C, int KP, const
   if (E == 0) return (int)hipMemsetAsync(d_feats, 0, sizeof(float) * (size_t)b * C * n, (hipStream_t)stream);
   if (!d_rows || !idx) return MSR3D_EINVAL;
   if (!det_fits(n, E)) return MSR3D_EINVAL;          // the caller keeps the composite path
-  const size_t lds = sizeof(int) * (size_t)(2 * n + 1 + E);
+  size_t lds = sizeof(int) * (size_t)(2 * n + 1 + E);
+  const size_t staged = lds + sizeof(float) * 64 * (size_t)(n + 1);
+  const int stage = staged <= 160 * 1024 - 4096;             // (the output tile beside the inverted index)
+  if (stage) lds = staged;
   static const hipError_t attr = hipFuncSetAttribute(
       reinterpret_cast<const void *>(&group_rows_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-      (int)(sizeof(int) * kDetMaxInts));
+      160 * 1024 - 4096);
   if (attr != hipSuccess) return (int)attr;
   group_rows_grad_kernel<<<dim3(b, (C + 63) / 64), 256, lds, (hipStream_t)stream>>>(n, E, C, KP, d_rows, idx,
-                                                                                   d_feats);
+                                                                                   d_feats, stage);
   return (int)hipGetLastError();
 }
 
