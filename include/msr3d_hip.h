@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 12
+#define MSR3D_ABI_VERSION 13
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -282,6 +282,12 @@ int msr3d_bn_relu_train_bwd(long long rows, int C, const float *x, const float *
                             const float *beta, const float *save_mean, const float *save_rstd,
                             float *dx, float *dgamma, float *dbeta, float *partial_ws,
                             msr3d_stream_t stream);
+/* The statistics alone (second stage over partial_chunks > 0 partials left by the producer of x; running statistics
+ * updated as in _fwd): for a layer whose normalised activation is never written -- the next product applies
+ * relu(batch_norm(.)) to its operand on load (msr3d_rows_gemm_split's a_bn, msr3d_wgrad_rows_split's x_bn). */
+int msr3d_bn_train_stats(long long rows, int C, const float *partial_ws, int partial_chunks, float eps, float momentum,
+                         float *running_mean, float *running_var, float *save_mean, float *save_rstd,
+                         msr3d_stream_t stream);
 
 /* The LAST layer of a SharedMLP fused with the neighbourhood max-pool that follows it
  * (pointnet2_modules.py:66-68, F.max_pool2d over nsample): rows = G * nsample consecutive rows per group;
@@ -683,7 +689,7 @@ int msr3d_wgrad_split(int n, const msr3d_wgrad_problem_t *problems, const int *t
 #define MSR3D_WGRAD_ROWS_CHUNKS 256
 int msr3d_wgrad_rows_split(int M, int n_out, int k_in, const float *dy, int ldy, const float *x, int ldx,
                            float *dW, int ldw, int accumulate, float *workspace, long long workspace_floats,
-                           msr3d_stream_t stream);
+                           const float *x_bn, msr3d_stream_t stream);
 
 /* C (M, N) = A (M, K) op(B)^T for TALL fp32 operands on the bf16 matrix pipe at fp32 accuracy (three exact bf16
  * terms per operand, six MFMA products per product: csrc/split_mma.h): the SharedMLP layers of an UNFROZEN
@@ -695,12 +701,15 @@ int msr3d_wgrad_rows_split(int M, int n_out, int k_in, const float *dy, int ldy,
  * bit-reproducible, every output row independent of the others.
  * col_stats (optional): [ceil(M / MSR3D_ROWS_GEMM_BLOCK)][2][N] floats -- the column sums and sums of squares of C
  * over each block of MSR3D_ROWS_GEMM_BLOCK rows, summed in a fixed order: the first stage of the BatchNorm
- * statistics that follow the product (msr3d_bn_relu_train_fwd with have_partials). */
+ * statistics that follow the product (msr3d_bn_relu_train_fwd with partial_chunks).
+ * a_bn (optional): [gamma | beta | mean | rstd], K floats each -- A holds the PRE-normalisation output of a
+ * BatchNorm + ReLU layer and the product is taken of max(gamma (A - mean) rstd + beta, 0), formed on the way into the
+ * matrix pipe: the normalised activation is never written or re-read (msr3d_wgrad_rows_split takes the same for x). */
 #define MSR3D_ROWS_GEMM_BLOCK 256
 #define MSR3D_ROWS_GEMM_MAX_K 1024
 #define MSR3D_ROWS_GEMM_MAX_N 1024
 int msr3d_rows_gemm_split(int M, int N, int K, const float *A, int lda, const float *B, int ldb, int b_trans,
-                          float *C, int ldc, float *col_stats, msr3d_stream_t stream);
+                          float *C, int ldc, float *col_stats, const float *a_bn, msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * The language-model side of the training step, first two pieces:

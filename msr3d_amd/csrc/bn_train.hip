@@ -358,6 +358,16 @@ int msr3d_bn_relu_train_fwd(long long rows, int C, const float *x, const float *
   return (int)hipGetLastError();
 }
 
+int msr3d_bn_train_stats(long long rows, int C, const float *partial_ws, int partial_chunks, float eps, float momentum,
+                         float *running_mean, float *running_var, float *save_mean, float *save_rstd,
+                         msr3d_stream_t stream) {
+  if (rows <= 0 || C <= 0 || (C % 4) != 0 || C > 1024 || partial_chunks <= 0) return MSR3D_EINVAL;
+  if (!partial_ws || !save_mean || !save_rstd) return MSR3D_EINVAL;
+  bn_fwd_finalize_kernel<<<(C + kFinCh - 1) / kFinCh, 256, 0, (hipStream_t)stream>>>(
+      rows, C, partial_chunks, partial_ws, eps, momentum, running_mean, running_var, save_mean, save_rstd);
+  return (int)hipGetLastError();
+}
+
 int msr3d_bn_relu_train_bwd(long long rows, int C, const float *x, const float *dy, const float *gamma,
                             const float *beta, const float *save_mean, const float *save_rstd,
                             float *dx, float *dgamma, float *dbeta, float *partial_ws,

@@ -33,6 +33,7 @@ struct RowsGemm {
   float *C; int ldc;
   int nblk;                       // row blocks of 256
   float *stats;                   // optional: [nblk][2][N] column sums / sums of squares of each block's rows of C
+  const float *apro;              // optional: [gamma | beta | mean | rstd], K floats each: A <- relu(batch_norm(A)) on load
 };
 
 // sum over the 16 lanes of a DPP row (the 16 rows of an MFMA tile a lane group holds), result in every lane;
@@ -53,6 +54,7 @@ template <int NT, int KS>
 __global__ __launch_bounds__(512, 1) void rows_gemm_split_kernel(const RowsGemm p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [KS][NT][3][64][16 B], then the statistics'
   float *sred = reinterpret_cast<float *>(smem + KS * NT * 3 * 1024);    // [2 parities][8 waves][2][NT * 16]
+  float *ppro = sred + 2 * 8 * 2 * NT * 16;                             // [4][kpad]: the operand's BatchNorm parameters
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
@@ -78,10 +80,15 @@ __global__ __launch_bounds__(512, 1) void rows_gemm_split_kernel(const RowsGemm 
   // K wider than one LDS image of op(B) (KS slabs): the image is re-filled per super-slab inside the row-block loop
   // (the short, wide products of the last set-abstraction level: a workgroup has one or two row blocks)
   const int nsup = (p.K + KS * 32 - 1) / (KS * 32);
-  if (nsup == 1) {
-    load_b(0);
-    __syncthreads();
+  const int kpad = nsup * KS * 32;
+  if (p.apro) {                   // (columns past K: all four zero -> relu(0) = 0, like the zero padding they replace)
+    for (int e = tid; e < 4 * kpad; e += 512) {
+      const int a = e / kpad, k = e - a * kpad;
+      ppro[e] = k < p.K ? p.apro[a * p.K + k] : 0.f;
+    }
   }
+  if (nsup == 1) load_b(0);
+  if (nsup == 1 || p.apro) __syncthreads();
 
   const unsigned char *bl = smem + lane * 16;
   // Units of work = (row block, super-slab), walked in order.  The fp32 values of unit u + 1 are loaded INTO the
@@ -142,6 +149,18 @@ __global__ __launch_bounds__(512, 1) void rows_gemm_split_kernel(const RowsGemm 
         for (int rt = 0; rt < 2; ++rt) {
           float v[8] = {raw[rt][s][0][0], raw[rt][s][0][1], raw[rt][s][0][2], raw[rt][s][0][3],
                         raw[rt][s][1][0], raw[rt][s][1][1], raw[rt][s][1][2], raw[rt][s][1][3]};
+          if (p.apro) {            // A <- max(gamma (A - mean) rstd + beta, 0): the layer's normalisation, never stored
+            const float *pp = ppro + kb + 32 * s + 8 * g;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const f32x4 ga = *reinterpret_cast<const f32x4 *>(pp + 4 * h), be = *reinterpret_cast<const f32x4 *>(pp + kpad + 4 * h),
+                          mu = *reinterpret_cast<const f32x4 *>(pp + 2 * kpad + 4 * h),
+                          rs = *reinterpret_cast<const f32x4 *>(pp + 3 * kpad + 4 * h);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                v[4 * h + e] = fmaxf(__builtin_fmaf(ga[e], (v[4 * h + e] - mu[e]) * rs[e], be[e]), 0.f);
+            }
+          }
           if (tail) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? in0 : in1) != 0.f ? v[e] : 0.f;
@@ -222,10 +241,13 @@ __global__ __launch_bounds__(512, 1) void rows_gemm_split_kernel(const RowsGemm 
 
 template <int NT, int KS>
 int launch(const RowsGemm &p, int ny, hipStream_t st) {
-  constexpr int lds = KS * NT * 3 * 1024 + 2 * 8 * 2 * NT * 16 * 4;
+  constexpr int lds0 = KS * NT * 3 * 1024 + 2 * 8 * 2 * NT * 16 * 4;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&rows_gemm_split_kernel<NT, KS>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     lds0 + 16 * 1024 < 160 * 1024 ? lds0 + 16 * 1024 : 160 * 1024);
   if (attr != hipSuccess) return (int)attr;
+  const int lds = lds0 + (p.apro ? 16 * ((p.K + KS * 32 - 1) / (KS * 32)) * KS * 32 : 0);
+  if (lds > 160 * 1024) return MSR3D_EINVAL;
   const int gx = min(p.nblk, max(1, 256 / ny));
   rows_gemm_split_kernel<NT, KS><<<dim3(gx, ny), 512, lds, st>>>(p);
   return (int)hipGetLastError();
@@ -246,12 +268,12 @@ int pick_ks(const RowsGemm &p, int ny, int ks, hipStream_t st) {
 }  // namespace
 
 extern "C" int msr3d_rows_gemm_split(int M, int N, int K, const float *A, int lda, const float *B, int ldb, int b_trans,
-                                     float *C, int ldc, float *col_stats, msr3d_stream_t stream) {
+                                     float *C, int ldc, float *col_stats, const float *a_bn, msr3d_stream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || K > MSR3D_ROWS_GEMM_MAX_K || N > MSR3D_ROWS_GEMM_MAX_N) return MSR3D_EINVAL;
   if (!A || !B || !C || (K & 3) || (lda & 3) || (ldc & 3) || lda < K || ldc < N) return MSR3D_EINVAL;
   if ((reinterpret_cast<uintptr_t>(A) & 15u) || (reinterpret_cast<uintptr_t>(C) & 15u)) return MSR3D_EINVAL;
   if ((long long)M * lda * 4 >= (1ll << 31)) return MSR3D_EINVAL;       // (32-bit byte offsets into A)
-  RowsGemm p{M, N, K, A, lda, B, ldb, b_trans, C, ldc, (M + 255) / 256, col_stats};
+  RowsGemm p{M, N, K, A, lda, B, ldb, b_trans, C, ldc, (M + 255) / 256, col_stats, a_bn};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int ks = (K + 31) / 32;
   // column tiles per workgroup: all of them up to 144 columns (9 tiles), else halves of <= 128

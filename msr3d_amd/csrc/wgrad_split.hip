@@ -61,9 +61,12 @@ __device__ __forceinline__ int frag_slot(int j, int g) { return (4 * (j & 3) + (
 // side by side -- columns 0..63 of both operands from the rows of chunk A, columns 64..127 from those of chunk B
 // (fold_rows further down, fold_mb of them) -- so D's diagonal 64 x 64 blocks are the two chunks' products
 // (written to pr.dW and pr.dW + n_out * k_in) and the off-diagonal ones are never multiplied.
-template <bool OVERWRITE, bool FOLD = false>
+// XPRO: the x operand is the PRE-normalisation activation of a BatchNorm + ReLU layer and the product wants its output:
+// x <- max(gamma (x - mean) rstd + beta, 0) per column, applied by the loaders before the split (xpro = [gamma | beta |
+// mean | rstd], k_in floats each) -- the normalised activation is never written (hipops._BNReLULinear).
+template <bool OVERWRITE, bool FOLD = false, bool XPRO = false>
 __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, unsigned char *smem, int fold_rows = 0,
-                                           int fold_mb = 0) {
+                                           int fold_mb = 0, const float *xpro = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n0 = ntile * TN, k0 = ktile * TK;
@@ -90,6 +93,14 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
 #pragma unroll
     for (int i = 0; i < 4; ++i) { cm[i] = col + i < ncol ? 1.f : 0.f; cb[i] = 4 * min(col + i, ncol - 1); }
     const bool edge = cm[3] == 0.f;
+    float xg[4] = {0.f, 0.f, 0.f, 0.f}, xb[4] = {0.f, 0.f, 0.f, 0.f}, xm[4] = {0.f, 0.f, 0.f, 0.f}, xr[4] = {0.f, 0.f, 0.f, 0.f};
+    if (XPRO && isx) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int cc = min(col + i, ncol - 1);
+        xg[i] = xpro[cc]; xb[i] = xpro[ncol + cc]; xm[i] = xpro[2 * ncol + cc]; xr[i] = xpro[3 * ncol + cc];
+      }
+    }
     struct Slab { float v[8][4]; };
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
     // VEC is a compile-time property of the whole loop: a per-load `if (vec)` makes every load its own
@@ -121,6 +132,13 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
       };
       auto stash = [&](Slab &s_, int buf) {
         unsigned char *T = smem + buf * STAGE + (isx ? OP_BYTES : 0) + (Q >> 2) * TILE_BYTES;
+        if (XPRO && isx) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              s_.v[e][i] = fmaxf(__builtin_fmaf(xg[i], (s_.v[e][i] - xm[i]) * xr[i], xb[i]), 0.f);
+        }
         if (edge) {                                // columns past the matrix (a 16-byte load reads on into the row)
 #pragma unroll
           for (int e = 0; e < 8; ++e)
@@ -265,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_kernel(int nprob, const WP
 // cut into chunks, workgroup (chunk, tile) reduces its chunk into ws[chunk] (n_out, k_in) -- plain stores, every
 // workgroup the only writer of its slab -- and wgrad_rows_reduce_kernel adds the slabs in chunk order.
 // n_out, k_in <= 64: workgroup b takes the chunk PAIR (2 b, 2 b + 1) in one folded tile (wgrad_tile<.., FOLD>)
-__global__ __launch_bounds__(512, 2) void wgrad_rows_fold_kernel(WP base, int chunk_rows, float *ws) {
+__global__ __launch_bounds__(512, 2) void wgrad_rows_fold_kernel(WP base, int chunk_rows, float *ws, const float *xpro) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   WP pr = base;
   const long long r0 = (long long)(2 * blockIdx.x) * chunk_rows;
@@ -277,10 +295,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_rows_fold_kernel(WP base, int ch
   pr.dW = ws + (size_t)(2 * blockIdx.x) * base.n_out * base.k_in;
   pr.ldw = base.k_in;
   pr.db = nullptr;
-  wgrad_tile<true, true>(pr, 0, 0, smem, chunk_rows, mb);
+  if (xpro) wgrad_tile<true, true, true>(pr, 0, 0, smem, chunk_rows, mb, xpro);
+  else wgrad_tile<true, true>(pr, 0, 0, smem, chunk_rows, mb);
 }
 
-__global__ __launch_bounds__(512, 2) void wgrad_rows_kernel(WP base, int chunk_rows, int tiles, float *ws) {
+__global__ __launch_bounds__(512, 2) void wgrad_rows_kernel(WP base, int chunk_rows, int tiles, float *ws,
+                                                            const float *xpro) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int chunk = blockIdx.x / tiles, tile = blockIdx.x - chunk * tiles;
   const int nkt = (base.k_in + TK - 1) / TK;
@@ -292,7 +312,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_rows_kernel(WP base, int chunk_r
   pr.dW = ws + (size_t)chunk * base.n_out * base.k_in;
   pr.ldw = base.k_in;
   pr.db = nullptr;
-  wgrad_tile<true>(pr, tile / nkt, tile % nkt, smem);
+  if (xpro) wgrad_tile<true, false, true>(pr, tile / nkt, tile % nkt, smem, 0, 0, xpro);
+  else wgrad_tile<true>(pr, tile / nkt, tile % nkt, smem);
 }
 
 __global__ __launch_bounds__(256) void wgrad_rows_reduce_kernel(int n_out, int k_in, int chunks, const float *__restrict__ ws,
@@ -328,7 +349,7 @@ extern "C" int msr3d_wgrad_split(int n, const msr3d_wgrad_problem_t *problems, c
 
 extern "C" int msr3d_wgrad_rows_split(int M, int n_out, int k_in, const float *dy, int ldy, const float *x, int ldx,
                                       float *dW, int ldw, int accumulate, float *workspace, long long workspace_floats,
-                                      msr3d_stream_t stream) {
+                                      const float *x_bn, msr3d_stream_t stream) {
   if (M <= 0 || n_out <= 0 || k_in <= 0 || !dy || !x || !dW || !workspace || ldy < n_out || ldx < k_in || ldw < k_in)
     return MSR3D_EINVAL;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_rows_kernel),
@@ -356,9 +377,9 @@ extern "C" int msr3d_wgrad_rows_split(int M, int n_out, int k_in, const float *d
     static const hipError_t fattr = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_rows_fold_kernel),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (fattr != hipSuccess) return (int)fattr;
-    wgrad_rows_fold_kernel<<<(unsigned)((chunks + 1) / 2), 512, LDS_BYTES, st>>>(base, chunk_rows, workspace);
+    wgrad_rows_fold_kernel<<<(unsigned)((chunks + 1) / 2), 512, LDS_BYTES, st>>>(base, chunk_rows, workspace, x_bn);
   } else {
-    wgrad_rows_kernel<<<(unsigned)(chunks * tiles), 512, LDS_BYTES, st>>>(base, chunk_rows, tiles, workspace);
+    wgrad_rows_kernel<<<(unsigned)(chunks * tiles), 512, LDS_BYTES, st>>>(base, chunk_rows, tiles, workspace, x_bn);
   }
   wgrad_rows_reduce_kernel<<<(unsigned)((slab + 255) / 256), 256, 0, st>>>(n_out, k_in, (int)chunks, workspace, dW, ldw,
                                                                           accumulate);

@@ -119,12 +119,13 @@ def _rows_split_ok(M, N, K, A, C):
 ROWS_GEMM_BLOCK = 256      # MSR3D_ROWS_GEMM_BLOCK
 
 
-def _rows_gemm(M, N, K, A, lda, B, ldb, b_trans, C, ldc, stats=None):
+def _rows_gemm(M, N, K, A, lda, B, ldb, b_trans, C, ldc, stats=None, a_bn=None):
     """C (M, N) = A (M, K) op(B)^T, op(B) = B (N, K) or, b_trans, B (K, N)^T.  stats: (ceil(M / 256), 2, N) floats that
-    receive C's per-block column sums and sums of squares."""
+    receive C's per-block column sums and sums of squares.  a_bn (4, K) = [gamma | beta | mean | rstd]: the product
+    is taken of relu(batch_norm(A)), formed on load."""
     with torch.cuda.device(C.device):
         rc = _lib.load().msr3d_rows_gemm_split(M, N, K, _p(A), lda, _p(B), ldb, int(b_trans), _p(C), ldc, _p(stats),
-                                               _lib.current_stream_ptr(C.device))
+                                               _p(a_bn), _lib.current_stream_ptr(C.device))
     _lib.check(rc, "msr3d_rows_gemm_split")
 
 
@@ -136,7 +137,7 @@ def _wgrad_rows_ok(M, N, K):
     return _ROWS_SPLIT and M >= 8192
 
 
-def _wgrad_rows(M, N, K, dy, x, dw, accumulate=False):
+def _wgrad_rows(M, N, K, dy, x, dw, accumulate=False, x_bn=None):
     """dw (N, K) (+)= dy (M, N)^T x (M, K) over tall row counts (msr3d_wgrad_rows_split); the chunk workspace is one
     buffer per device (33 MB: 256 / tiles chunks of n_out x k_in floats never exceed it), allocated outside any
     capture -- HotPathTrainStep's eager warm-up step does that."""
@@ -148,7 +149,8 @@ def _wgrad_rows(M, N, K, dy, x, dw, accumulate=False):
         ws = _wgrad_ws[dev.index] = torch.empty(256 * 256 * 128, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = _lib.load().msr3d_wgrad_rows_split(M, N, K, _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw.stride(0),
-                                                int(accumulate), _p(ws), ws.numel(), _lib.current_stream_ptr(dev))
+                                                int(accumulate), _p(ws), ws.numel(), _p(x_bn),
+                                                _lib.current_stream_ptr(dev))
     _lib.check(rc, "msr3d_wgrad_rows_split")
 
 
@@ -499,6 +501,68 @@ class _BNReLUMaxPoolTrain(torch.autograd.Function):
         return dx, dg, db, None, None, None
 
 
+class _BNReLULinear(torch.autograd.Function):
+    """z_next (R, N) = relu(batch_norm(z)) W^T for a tall z whose first-stage statistics the producing GEMM left in
+    `partials`: the statistics are finalised (running statistics updated), and the normalisation + ReLU is applied to
+    the operand on its way into the matrix pipe -- forward here, and again in the backward's weight gradient -- so the
+    (R, C) activation is neither written nor re-read.  Backward: dy = dz_next W, dW = dz_next^T relu(bn(z)), then the
+    BatchNorm + ReLU backward of msr3d_bn_relu_train_bwd on (z, dy)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, bn, partials, weight, stats_out):
+        R, C = z.shape
+        N = weight.shape[0]
+        momentum, rm, rv = _bn_train_args(bn, z)
+        w = weight if weight.is_contiguous() else weight.contiguous()
+        pro = torch.empty((4, C), dtype=torch.float32, device=z.device)     # [gamma | beta | mean | rstd]
+        pro[0].copy_(gamma)
+        pro[1].copy_(beta)
+        with torch.cuda.device(z.device):
+            rc = _lib.load().msr3d_bn_train_stats(R, C, _p(partials), partials.shape[0], float(bn.eps), momentum, _p(rm),
+                                                  _p(rv), _p(pro[2]), _p(pro[3]), _lib.current_stream_ptr(z.device))
+        _lib.check(rc, "msr3d_bn_train_stats")
+        y = torch.empty((R, N), dtype=torch.float32, device=z.device)
+        stats = torch.empty((-(-R // ROWS_GEMM_BLOCK), 2, N), dtype=torch.float32, device=z.device)
+        stats_out.append(stats)
+        _rows_gemm(R, N, C, z, C, w, C, False, y, N, stats, pro)
+        ctx.save_for_backward(z, pro, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dzn):
+        z, pro, w = ctx.saved_tensors
+        R, C = z.shape
+        N = w.shape[0]
+        dzn = dzn if dzn.is_contiguous() else dzn.contiguous()
+        dw = None
+        if ctx.needs_input_grad[5]:
+            dw = torch.empty((N, C), dtype=torch.float32, device=z.device)
+            _wgrad_rows(R, N, C, dzn, z, dw, x_bn=pro)
+        dy = torch.empty((R, C), dtype=torch.float32, device=z.device)
+        _rows_gemm(R, C, N, dzn, N, w, C, True, dy, C)
+        dz = torch.empty_like(z)
+        dg = torch.empty(C, dtype=torch.float32, device=z.device)
+        db = torch.empty_like(dg)
+        ws = torch.empty(2 * C * max(1, -(-R // BN_CHUNK_ROWS)), dtype=torch.float32, device=z.device)
+        with torch.cuda.device(z.device):
+            rc = _lib.load().msr3d_bn_relu_train_bwd(R, C, _p(z), _p(dy), _p(pro[0]), _p(pro[1]), _p(pro[2]), _p(pro[3]),
+                                                     _p(dz), _p(dg), _p(db), _p(ws), _lib.current_stream_ptr(z.device))
+        _lib.check(rc, "msr3d_bn_relu_train_bwd")
+        return dz, dg, db, None, None, dw, None
+
+
+def _bn_linear_fused_ok(z, part, w):
+    """The normalisation of z can ride on the next product's operand load: statistics already there, both products of
+    the pair on the tall-rows kernels (whole weight in LDS), no padding between the layers."""
+    R, C = z.shape
+    N, K = w.shape
+    return (part is not None and K == C and _ROWS_SPLIT and _FUSE_BN and R >= 8192 and C % 4 == 0 and N % 4 == 0
+            and C <= 256 and N <= 256 and z.data_ptr() % 16 == 0)
+
+
+_FUSE_BN = _os.environ.get("MSR3D_BN_FUSE", "1") != "0"
+
+
 def _mlp_train_ok(mlp):
     """Module in training mode, every layer a bias-free 1x1 convolution followed by an affine,
     statistics-tracking BatchNorm2d and a ReLU, channel counts the kernels take."""
@@ -528,18 +592,21 @@ def _mlp_rows(mlp, t, pool_ns):
     pool_ns consecutive rows -> (R / pool_ns, C_out); the last layer's normalisation and the pooling
     are one kernel."""
     pairs = mlp.conv_bn_pairs()
+    z = part = pending = None        # pending: the BatchNorm whose normalisation the NEXT product applies on load
     for j, (conv, bn) in enumerate(pairs):
         w = conv.weight.view(conv.out_channels, conv.in_channels)
-        if t.shape[1] != w.shape[1]:
-            w = F.pad(w, (0, t.shape[1] - w.shape[1]))      # zero columns against the operand's padding
         got = []
-        z = linear(t, w, stats_out=got)
-        part = got[0] if got else None
-        if j + 1 < len(pairs):
-            t = _BNReLUTrain.apply(z, bn.weight, bn.bias, bn, part)
+        if pending is not None and _bn_linear_fused_ok(z, part, w):
+            z = _BNReLULinear.apply(z, pending.weight, pending.bias, pending, part, w, got)
         else:
-            t = _BNReLUMaxPoolTrain.apply(z, bn.weight, bn.bias, bn, pool_ns, part)
-    return t
+            if pending is not None:
+                t = _BNReLUTrain.apply(z, pending.weight, pending.bias, pending, part)
+            if t.shape[1] != w.shape[1]:
+                w = F.pad(w, (0, t.shape[1] - w.shape[1]))      # zero columns against the operand's padding
+            z = linear(t, w, stats_out=got)
+        part = got[0] if got else None
+        pending = bn
+    return _BNReLUMaxPoolTrain.apply(z, pending.weight, pending.bias, pending, pool_ns, part)
 
 
 def shared_mlp_train(mlp, x):

@@ -22,7 +22,7 @@ def _run(M, N, K, b_trans, lda=None, ldc=None, seed=0, with_stats=False):
     stats = torch.full(((M + 255) // 256, 2, N), float("nan"), device="cuda") if with_stats else None
     rc = _lib.load().msr3d_rows_gemm_split(M, N, K, ctypes.c_void_p(A.data_ptr()), lda, ctypes.c_void_p(B.data_ptr()),
                                            B.shape[1], int(b_trans), ctypes.c_void_p(C.data_ptr()), ldc,
-                                           ctypes.c_void_p(stats.data_ptr() if with_stats else 0), st)
+                                           ctypes.c_void_p(stats.data_ptr() if with_stats else 0), None, st)
     assert rc == 0
     if with_stats:
         # per 256-row block: column sums and sums of squares of the STORED values (fp32 summation noise only)
@@ -72,7 +72,7 @@ def test_rows_gemm_split_padded_pitches_and_reproducible():
         C = torch.empty(70000, 128, device="cuda")
         assert _lib.load().msr3d_rows_gemm_split(70000, 128, 128, ctypes.c_void_p(A.data_ptr()), 128,
                                                  ctypes.c_void_p(B.data_ptr()), 128, 0,
-                                                 ctypes.c_void_p(C.data_ptr()), 128, None, st) == 0
+                                                 ctypes.c_void_p(C.data_ptr()), 128, None, None, st) == 0
         outs.append(C)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
@@ -84,9 +84,9 @@ def test_rows_gemm_split_rejects_what_it_does_not_take():
     st = _lib.current_stream_ptr(torch.device("cuda"))
     f = _lib.load().msr3d_rows_gemm_split
     p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
-    assert f(64, 64, 1028, p(A), 1028, p(A), 1028, 0, p(C), 512, None, st) == -22   # K > 1024
-    assert f(64, 1028, 64, p(A), 256, p(A), 256, 0, p(C), 1028, None, st) == -22    # N > 1024
-    assert f(64, 64, 62, p(A), 256, p(A), 256, 0, p(C), 512, None, st) == -22       # K % 4
+    assert f(64, 64, 1028, p(A), 1028, p(A), 1028, 0, p(C), 512, None, None, st) == -22   # K > 1024
+    assert f(64, 1028, 64, p(A), 256, p(A), 256, 0, p(C), 1028, None, None, st) == -22    # N > 1024
+    assert f(64, 64, 62, p(A), 256, p(A), 256, 0, p(C), 512, None, None, st) == -22       # K % 4
 
 
 def test_rows_gemm_split_throughput():
@@ -101,12 +101,12 @@ def test_rows_gemm_split_throughput():
     f = _lib.load().msr3d_rows_gemm_split
     p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
     for _ in range(5):
-        f(M, N, K, p(A), K, p(B), K, 0, p(C), N, p(S), st)
+        f(M, N, K, p(A), K, p(B), K, 0, p(C), N, p(S), None, st)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10):
-        f(M, N, K, p(A), K, p(B), K, 0, p(C), N, p(S), st)
+        f(M, N, K, p(A), K, p(B), K, 0, p(C), N, p(S), None, st)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 100
@@ -127,7 +127,7 @@ def _wgrad(M, N, K, accumulate=False, ldy=None, ldx=None, seed=0):
     st = _lib.current_stream_ptr(torch.device("cuda"))
     rc = _lib.load().msr3d_wgrad_rows_split(M, N, K, ctypes.c_void_p(dy.data_ptr()), ldy, ctypes.c_void_p(x.data_ptr()), ldx,
                                             ctypes.c_void_p(dW.data_ptr()), K, int(accumulate),
-                                            ctypes.c_void_p(ws.data_ptr()), ws.numel(), st)
+                                            ctypes.c_void_p(ws.data_ptr()), ws.numel(), None, st)
     assert rc == 0
     want = dy[:, :N].double().t() @ x[:, :K].double() + (dW0.double() if accumulate else 0)
     scale = dy[:, :N].double().abs().t() @ x[:, :K].double().abs() + 1.0
@@ -158,7 +158,7 @@ def test_wgrad_rows_split_throughput():
     ws = torch.empty(256 * N * K, device="cuda")
     st = _lib.current_stream_ptr(torch.device("cuda"))
     p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
-    f = lambda: _lib.load().msr3d_wgrad_rows_split(M, N, K, p(dy), N, p(x), K, p(dW), K, 0, p(ws), ws.numel(), st)   # noqa: E731
+    f = lambda: _lib.load().msr3d_wgrad_rows_split(M, N, K, p(dy), N, p(x), K, p(dW), K, 0, p(ws), ws.numel(), None, st)   # noqa: E731
     for _ in range(5):
         f()
     torch.cuda.synchronize()
@@ -171,3 +171,31 @@ def test_wgrad_rows_split_throughput():
     us = e0.elapsed_time(e1) * 100
     print(f"\nwgrad_rows_split {M} rows, {N} x {K}: {us:.0f} us = {(M * (K + N) * 4) / us / 1e6:.2f} TB/s of rows")
     assert us < 600
+
+
+@pytest.mark.parametrize("M,N,K", [(40000, 64, 64), (30000, 128, 128), (30001, 256, 128), (9000, 128, 64), (300, 64, 132)])
+def test_operand_normalisation_on_load(M, N, K):
+    """a_bn / x_bn: the products of relu(batch_norm(A)) without the normalised activation in memory -- against the
+    same products of the explicitly normalised operand (fp32 formula of bn_train.hip) in float64."""
+    from msr3d_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda", generator=g) * 2 + 0.3
+    B = torch.randn(N, K, device="cuda", generator=g) * 0.3
+    pro = torch.stack([1 + 0.2 * torch.randn(K, device="cuda", generator=g), 0.3 * torch.randn(K, device="cuda", generator=g),
+                       0.3 + 0.1 * torch.randn(K, device="cuda", generator=g),
+                       0.5 + 0.1 * torch.rand(K, device="cuda", generator=g)]).contiguous()
+    Y = torch.relu(torch.addcmul(pro[1], pro[0], (A - pro[2]) * pro[3]))          # the kernels' fp32 statement
+    C = torch.empty(M, N, device="cuda")
+    st = _lib.current_stream_ptr(torch.device("cuda"))
+    p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    assert _lib.load().msr3d_rows_gemm_split(M, N, K, p(A), K, p(B), K, 0, p(C), N, None, p(pro), st) == 0
+    want = Y.double() @ B.double().t()
+    scale = Y.double().abs() @ B.double().abs().t() + 1e-3
+    assert float(((C.double() - want).abs() / scale).max()) < 4e-6
+    dy = torch.randn(M, N, device="cuda", generator=g)
+    dW = torch.empty(N, K, device="cuda")
+    ws = torch.empty(256 * N * K, device="cuda")
+    assert _lib.load().msr3d_wgrad_rows_split(M, N, K, p(dy), N, p(A), K, p(dW), K, 0, p(ws), ws.numel(), p(pro), st) == 0
+    want = dy.double().t() @ Y.double()
+    scale = dy.double().abs().t() @ Y.double().abs() + 1.0
+    assert float(((dW.double() - want).abs() / scale).max()) < 5e-6
