@@ -284,9 +284,10 @@ int msr3d_bn_relu_train_bwd(long long rows, int C, const float *x, const float *
                             msr3d_stream_t stream);
 /* The statistics alone (second stage over partial_chunks > 0 partials left by the producer of x; running statistics
  * updated as in _fwd): for a layer whose normalised activation is never written -- the next product applies
- * relu(batch_norm(.)) to its operand on load (msr3d_rows_gemm_split's a_bn, msr3d_wgrad_rows_split's x_bn). */
+ * relu(batch_norm(.)) to its operand on load (msr3d_rows_gemm_split's a_bn, msr3d_wgrad_rows_split's x_bn).
+ * bn_block (4, C) receives [gamma | beta | mean | rstd], the block those arguments take. */
 int msr3d_bn_train_stats(long long rows, int C, const float *partial_ws, int partial_chunks, float eps, float momentum,
-                         float *running_mean, float *running_var, float *save_mean, float *save_rstd,
+                         float *running_mean, float *running_var, const float *gamma, const float *beta, float *bn_block,
                          msr3d_stream_t stream);
 
 /* The LAST layer of a SharedMLP fused with the neighbourhood max-pool that follows it

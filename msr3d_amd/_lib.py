@@ -97,7 +97,8 @@ _SIGNATURES = {
                                ctypes.c_longlong, _ptr, _ptr],
     "msr3d_rows_gemm_split": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr,
                               _ptr],
-    "msr3d_bn_train_stats": [ctypes.c_longlong, _c_int, _ptr, _c_int, _c_float, _c_float, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_bn_train_stats": [ctypes.c_longlong, _c_int, _ptr, _c_int, _c_float, _c_float, _ptr, _ptr, _ptr, _ptr, _ptr,
+                             _ptr],
     "msr3d_bf16_gemm_lowrank": [_c_int, _c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int,
                                 _ptr, _c_int, _c_int, _c_float, _ptr],
     "msr3d_bf16_gemm_batched": [_c_int] * 5 + [_ptr, _c_int, ctypes.c_longlong, ctypes.c_longlong, _ptr, _c_int,

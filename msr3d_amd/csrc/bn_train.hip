@@ -153,7 +153,8 @@ __device__ __forceinline__ void bn_sum_partials(int C, int chunks, const float *
 __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
     long long R, int C, int chunks, const float *__restrict__ partial, float eps, float momentum,
     float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ save_mean,
-    float *__restrict__ save_rstd) {
+    float *__restrict__ save_rstd, const float *__restrict__ gamma = nullptr, const float *__restrict__ beta = nullptr,
+    float *__restrict__ gamma_out = nullptr, float *__restrict__ beta_out = nullptr) {
   __shared__ double red[2][kFinLanes][kFinCh];
   const int c = blockIdx.x * kFinCh + threadIdx.x % kFinCh, l = threadIdx.x / kFinCh;
   double s, q;
@@ -164,6 +165,10 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
   var = var > 0.0 ? var : 0.0;
   save_mean[c] = (float)mu;
   save_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (gamma_out) {                 // (the operand-prologue block [gamma | beta | mean | rstd] in one launch)
+    gamma_out[c] = gamma[c];
+    beta_out[c] = beta[c];
+  }
   if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
   if (running_var) {
     const double unbiased = R > 1 ? var * ((double)R / (double)(R - 1)) : var;
@@ -359,12 +364,13 @@ int msr3d_bn_relu_train_fwd(long long rows, int C, const float *x, const float *
 }
 
 int msr3d_bn_train_stats(long long rows, int C, const float *partial_ws, int partial_chunks, float eps, float momentum,
-                         float *running_mean, float *running_var, float *save_mean, float *save_rstd,
+                         float *running_mean, float *running_var, const float *gamma, const float *beta, float *bn_block,
                          msr3d_stream_t stream) {
   if (rows <= 0 || C <= 0 || (C % 4) != 0 || C > 1024 || partial_chunks <= 0) return MSR3D_EINVAL;
-  if (!partial_ws || !save_mean || !save_rstd) return MSR3D_EINVAL;
+  if (!partial_ws || !gamma || !beta || !bn_block) return MSR3D_EINVAL;
   bn_fwd_finalize_kernel<<<(C + kFinCh - 1) / kFinCh, 256, 0, (hipStream_t)stream>>>(
-      rows, C, partial_chunks, partial_ws, eps, momentum, running_mean, running_var, save_mean, save_rstd);
+      rows, C, partial_chunks, partial_ws, eps, momentum, running_mean, running_var, bn_block + 2 * C, bn_block + 3 * C,
+      gamma, beta, bn_block, bn_block + C);
   return (int)hipGetLastError();
 }
 

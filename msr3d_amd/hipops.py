@@ -515,11 +515,10 @@ class _BNReLULinear(torch.autograd.Function):
         momentum, rm, rv = _bn_train_args(bn, z)
         w = weight if weight.is_contiguous() else weight.contiguous()
         pro = torch.empty((4, C), dtype=torch.float32, device=z.device)     # [gamma | beta | mean | rstd]
-        pro[0].copy_(gamma)
-        pro[1].copy_(beta)
+        g, b = gamma.contiguous(), beta.contiguous()
         with torch.cuda.device(z.device):
             rc = _lib.load().msr3d_bn_train_stats(R, C, _p(partials), partials.shape[0], float(bn.eps), momentum, _p(rm),
-                                                  _p(rv), _p(pro[2]), _p(pro[3]), _lib.current_stream_ptr(z.device))
+                                                  _p(rv), _p(g), _p(b), _p(pro), _lib.current_stream_ptr(z.device))
         _lib.check(rc, "msr3d_bn_train_stats")
         y = torch.empty((R, N), dtype=torch.float32, device=z.device)
         stats = torch.empty((-(-R // ROWS_GEMM_BLOCK), 2, N), dtype=torch.float32, device=z.device)
@@ -556,8 +555,9 @@ def _bn_linear_fused_ok(z, part, w):
     the pair on the tall-rows kernels (whole weight in LDS), no padding between the layers."""
     R, C = z.shape
     N, K = w.shape
+    wide_ok = R <= 65536 and C <= 1024 and N <= 1024          # (the last level: LDS re-filled per super-slab)
     return (part is not None and K == C and _ROWS_SPLIT and _FUSE_BN and R >= 8192 and C % 4 == 0 and N % 4 == 0
-            and C <= 256 and N <= 256 and z.data_ptr() % 16 == 0)
+            and ((C <= 256 and N <= 256) or wide_ok) and z.data_ptr() % 16 == 0)
 
 
 _FUSE_BN = _os.environ.get("MSR3D_BN_FUSE", "1") != "0"
