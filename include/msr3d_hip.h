@@ -269,6 +269,8 @@ int msr3d_group_rows_grad(int b, int n, int m, int nsample, int C, int KP, const
  *   bwd: dx, and dgamma / dbeta (C, WRITTEN).
  * C % 4 == 0, C <= 1024.  partial_ws: 2 * C * ceil(rows / MSR3D_BN_CHUNK_ROWS) floats of scratch; the reductions
  * are two-stage and ordered (no float atomics: results are run-to-run bit-identical).
+ * dgamma_acc / dbeta_acc (the _bwd entries; both or neither): buffers the parameter gradients are ADDED to as well
+ * (the parameters' views of the flat gradient buffer: no AccumulateGrad launch per parameter).
  * partial_chunks (the _fwd entries): 0 = compute the first stage here; n > 0 = partial_ws already holds n partials
  * [n][2][C] (column sums, sums of squares) covering all rows -- written by the producer of x
  * (msr3d_rows_gemm_split's col_stats) -- and the pass over x that would form them is skipped.
@@ -281,7 +283,7 @@ int msr3d_bn_relu_train_fwd(long long rows, int C, const float *x, const float *
 int msr3d_bn_relu_train_bwd(long long rows, int C, const float *x, const float *dy, const float *gamma,
                             const float *beta, const float *save_mean, const float *save_rstd,
                             float *dx, float *dgamma, float *dbeta, float *partial_ws,
-                            msr3d_stream_t stream);
+                            float *dgamma_acc, float *dbeta_acc, msr3d_stream_t stream);
 /* The statistics alone (second stage over partial_chunks > 0 partials left by the producer of x; running statistics
  * updated as in _fwd): for a layer whose normalised activation is never written -- the next product applies
  * relu(batch_norm(.)) to its operand on load (msr3d_rows_gemm_split's a_bn, msr3d_wgrad_rows_split's x_bn).
@@ -307,7 +309,7 @@ int msr3d_bn_relu_maxpool_train_bwd(long long rows, int C, int nsample, const fl
                                     const float *dpooled, const float *pooled, const int *argmax,
                                     const float *xsel, const float *gamma, const float *save_mean,
                                     const float *save_rstd, float *dx, float *dgamma, float *dbeta,
-                                    float *partial_ws, msr3d_stream_t stream);
+                                    float *partial_ws, float *dgamma_acc, float *dbeta_acc, msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Data-only front of the situated encoder (inputs are dataset tensors, no gradients).

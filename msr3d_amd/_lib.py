@@ -152,11 +152,11 @@ _SIGNATURES = {
     "msr3d_bn_relu_train_fwd": [ctypes.c_longlong, _c_int, _ptr, _ptr, _ptr, _c_float, _c_float, _ptr, _ptr, _ptr,
                                 _ptr, _ptr, _ptr, _c_int, _ptr],
     "msr3d_bn_relu_train_bwd": [ctypes.c_longlong, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
-                                _ptr, _ptr],
+                                _ptr, _ptr, _ptr, _ptr],
     "msr3d_bn_relu_maxpool_train_fwd": [ctypes.c_longlong, _c_int, _c_int, _ptr, _ptr, _ptr, _c_float, _c_float,
                                         _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _ptr],
     "msr3d_bn_relu_maxpool_train_bwd": [ctypes.c_longlong, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
-                                        _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+                                        _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_pairwise_locs": [_c_int, _c_int, _ptr, _c_int, _c_float, _ptr, _ptr],
     "msr3d_agent_fourier": [_c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr, _ptr],
     "msr3d_add_row_vectors": [_c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],

@@ -179,7 +179,9 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, int chunks,
                                                               const float *__restrict__ partial,
                                                               float *__restrict__ dgamma,
-                                                              float *__restrict__ dbeta) {
+                                                              float *__restrict__ dbeta,
+                                                              float *__restrict__ dgamma_acc,
+                                                              float *__restrict__ dbeta_acc) {
   __shared__ double red[2][kFinLanes][kFinCh];
   const int c = blockIdx.x * kFinCh + threadIdx.x % kFinCh, l = threadIdx.x / kFinCh;
   double s, q;
@@ -187,6 +189,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, int chunks,
   if (l != 0 || c >= C) return;
   dbeta[c] = (float)s;
   dgamma[c] = (float)q;
+  if (dgamma_acc) {                // (the parameters' gradient buffers: added to, no AccumulateGrad launch each)
+    dbeta_acc[c] += (float)s;
+    dgamma_acc[c] += (float)q;
+  }
 }
 
 // elementwise, float4 over channels (C % 4 == 0)
@@ -377,16 +383,18 @@ int msr3d_bn_train_stats(long long rows, int C, const float *partial_ws, int par
 int msr3d_bn_relu_train_bwd(long long rows, int C, const float *x, const float *dy, const float *gamma,
                             const float *beta, const float *save_mean, const float *save_rstd,
                             float *dx, float *dgamma, float *dbeta, float *partial_ws,
-                            msr3d_stream_t stream) {
+                            float *dgamma_acc, float *dbeta_acc, msr3d_stream_t stream) {
   if (rows < 0 || C <= 0 || (C % 4) != 0 || C > 1024) return MSR3D_EINVAL;
   if (rows == 0) return 0;
-  if (!x || !dy || !gamma || !beta || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !partial_ws)
+  if (!x || !dy || !gamma || !beta || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !partial_ws ||
+      (dgamma_acc == nullptr) != (dbeta_acc == nullptr))
     return MSR3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int chunks = chunks_of(rows);
   bn_partial_kernel<true><<<chunks, 256, partial_lds(C), st>>>(rows, C, x, dy, gamma, beta, save_mean, save_rstd,
                                                                partial_ws);
-  bn_bwd_finalize_kernel<<<(C + kFinCh - 1) / kFinCh, 256, 0, st>>>(C, chunks, partial_ws, dgamma, dbeta);
+  bn_bwd_finalize_kernel<<<(C + kFinCh - 1) / kFinCh, 256, 0, st>>>(C, chunks, partial_ws, dgamma, dbeta, dgamma_acc,
+                                                                    dbeta_acc);
   const long long n4 = rows * (C / 4);
   bn_relu_bwd_apply_kernel<false><<<ew_grid(n4), 256, 0, st>>>(
       n4, C / 4, 1.0f / (float)rows, reinterpret_cast<const float4 *>(x),
@@ -429,11 +437,11 @@ int msr3d_bn_relu_maxpool_train_bwd(long long rows, int C, int nsample, const fl
                                     const float *xsel, const float *gamma, const float *save_mean,
                                     const float *save_rstd,
                                     float *dx, float *dgamma, float *dbeta, float *partial_ws,
-                                    msr3d_stream_t stream) {
+                                    float *dgamma_acc, float *dbeta_acc, msr3d_stream_t stream) {
   if (rows < 0 || C <= 0 || (C % 4) != 0 || C > 1024 || nsample <= 0 || rows % nsample) return MSR3D_EINVAL;
   if (rows == 0) return 0;
   if (!x || !dpooled || !pooled || !argmax || !xsel || !gamma || !save_mean || !save_rstd || !dx || !dgamma ||
-      !dbeta || !partial_ws)
+      !dbeta || !partial_ws || (dgamma_acc == nullptr) != (dbeta_acc == nullptr))
     return MSR3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const long long G = rows / nsample;
@@ -447,7 +455,8 @@ int msr3d_bn_relu_maxpool_train_bwd(long long rows, int C, int nsample, const fl
   bn_pooled_partial_kernel<<<chunks, 256, partial_lds(C), st>>>(
       G, C, gpc, reinterpret_cast<const float4 *>(dpooled), reinterpret_cast<const float4 *>(pooled),
       reinterpret_cast<const float4 *>(xsel), save_mean, save_rstd, partial_ws);
-  bn_bwd_finalize_kernel<<<(C + kFinCh - 1) / kFinCh, 256, 0, st>>>(C, chunks, partial_ws, dgamma, dbeta);
+  bn_bwd_finalize_kernel<<<(C + kFinCh - 1) / kFinCh, 256, 0, st>>>(C, chunks, partial_ws, dgamma, dbeta, dgamma_acc,
+                                                                    dbeta_acc);
   const long long n4 = rows * (C / 4);
   bn_relu_bwd_apply_kernel<true><<<ew_grid(n4), 256, 0, st>>>(
       n4, C / 4, 1.0f / (float)rows, reinterpret_cast<const float4 *>(x), nullptr,

@@ -394,6 +394,34 @@ def module_linear(mod, x, gelu=False):
 BN_CHUNK_ROWS = 512        # MSR3D_BN_CHUNK_ROWS
 
 
+def _direct_targets(*params):
+    """(engine, params) when every one of `params` is a leaf owned by ONE data-parallel engine with its gradient view in
+    place: their producers then add into those views themselves and report through mark_ready -- no AccumulateGrad
+    launch per parameter."""
+    if _NO_DIRECT:
+        return None
+    dp = getattr(params[0], "_msr3d_dp", None)
+    if dp is None:
+        return None
+    for q in params:
+        if getattr(q, "_msr3d_dp", None) is not dp or not q.is_leaf or q.grad is None or not q.grad.is_contiguous():
+            return None
+    return dp, params
+
+
+def _direct_ptrs(direct):
+    """The two accumulate pointers of the BatchNorm backward entries (gamma.grad, beta.grad) or NULLs."""
+    if direct is None:
+        return ctypes.c_void_p(0), ctypes.c_void_p(0)
+    return _p(direct[1][0].grad), _p(direct[1][1].grad)
+
+
+def _direct_done(direct, n=None):
+    dp, params = direct
+    for q in params[:n]:
+        dp.mark_ready(q)
+
+
 class _BNReLUTrain(torch.autograd.Function):
     """y = relu(batch_norm(x)) over the rows of x (R, C), training mode; updates the module's
     running statistics like nn.BatchNorm2d.forward does."""
@@ -414,6 +442,7 @@ class _BNReLUTrain(torch.autograd.Function):
                 _p(rstd), _p(ws), chunks, _lib.current_stream_ptr(x.device))
         _lib.check(rc, "msr3d_bn_relu_train_fwd")
         ctx.save_for_backward(x, g, b, mean, rstd)
+        ctx.direct = _direct_targets(gamma, beta)
         return y
 
     @staticmethod
@@ -428,8 +457,11 @@ class _BNReLUTrain(torch.autograd.Function):
         with torch.cuda.device(x.device):
             rc = _lib.load().msr3d_bn_relu_train_bwd(
                 R, C, _p(x), _p(dy), _p(g), _p(b), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), _p(ws),
-                _lib.current_stream_ptr(x.device))
+                *_direct_ptrs(ctx.direct), _lib.current_stream_ptr(x.device))
         _lib.check(rc, "msr3d_bn_relu_train_bwd")
+        if ctx.direct is not None:
+            _direct_done(ctx.direct)
+            return dx, None, None, None, None
         return dx, dg, db, None, None
 
 
@@ -481,6 +513,7 @@ class _BNReLUMaxPoolTrain(torch.autograd.Function):
                 _p(xsel), _p(mean), _p(rstd), _p(ws), chunks, _lib.current_stream_ptr(x.device))
         _lib.check(rc, "msr3d_bn_relu_maxpool_train_fwd")
         ctx.save_for_backward(x, g, mean, rstd, pooled, arg, xsel)
+        ctx.direct = _direct_targets(gamma, beta)
         ctx.ns = ns
         return pooled
 
@@ -496,8 +529,11 @@ class _BNReLUMaxPoolTrain(torch.autograd.Function):
         with torch.cuda.device(x.device):
             rc = _lib.load().msr3d_bn_relu_maxpool_train_bwd(
                 R, C, ctx.ns, _p(x), _p(dpooled), _p(pooled), _p(arg), _p(xsel), _p(g), _p(mean), _p(rstd), _p(dx),
-                _p(dg), _p(db), _p(ws), _lib.current_stream_ptr(x.device))
+                _p(dg), _p(db), _p(ws), *_direct_ptrs(ctx.direct), _lib.current_stream_ptr(x.device))
         _lib.check(rc, "msr3d_bn_relu_maxpool_train_bwd")
+        if ctx.direct is not None:
+            _direct_done(ctx.direct)
+            return dx, None, None, None, None, None
         return dx, dg, db, None, None, None
 
 
@@ -513,7 +549,9 @@ class _BNReLULinear(torch.autograd.Function):
         R, C = z.shape
         N = weight.shape[0]
         momentum, rm, rv = _bn_train_args(bn, z)
-        w = weight if weight.is_contiguous() else weight.contiguous()
+        w = (weight if weight.is_contiguous() else weight.contiguous()).view(N, C)    # (the conv parameter: (N, C, 1, 1))
+        ctx.direct_bn = _direct_targets(gamma, beta)
+        ctx.direct_w = _direct_targets(weight)
         pro = torch.empty((4, C), dtype=torch.float32, device=z.device)     # [gamma | beta | mean | rstd]
         g, b = gamma.contiguous(), beta.contiguous()
         with torch.cuda.device(z.device):
@@ -525,6 +563,7 @@ class _BNReLULinear(torch.autograd.Function):
         stats_out.append(stats)
         _rows_gemm(R, N, C, z, C, w, C, False, y, N, stats, pro)
         ctx.save_for_backward(z, pro, w)
+        ctx.w_shape = tuple(weight.shape)
         return y
 
     @staticmethod
@@ -535,8 +574,12 @@ class _BNReLULinear(torch.autograd.Function):
         dzn = dzn if dzn.is_contiguous() else dzn.contiguous()
         dw = None
         if ctx.needs_input_grad[5]:
-            dw = torch.empty((N, C), dtype=torch.float32, device=z.device)
-            _wgrad_rows(R, N, C, dzn, z, dw, x_bn=pro)
+            if ctx.direct_w is not None:         # added straight into the parameter's view of the flat gradients
+                _wgrad_rows(R, N, C, dzn, z, ctx.direct_w[1][0].grad.view(N, C), accumulate=True, x_bn=pro)
+                _direct_done(ctx.direct_w)
+            else:
+                dw = torch.empty((N, C), dtype=torch.float32, device=z.device).view(ctx.w_shape)
+                _wgrad_rows(R, N, C, dzn, z, dw.view(N, C), x_bn=pro)
         dy = torch.empty((R, C), dtype=torch.float32, device=z.device)
         _rows_gemm(R, C, N, dzn, N, w, C, True, dy, C)
         dz = torch.empty_like(z)
@@ -545,8 +588,12 @@ class _BNReLULinear(torch.autograd.Function):
         ws = torch.empty(2 * C * max(1, -(-R // BN_CHUNK_ROWS)), dtype=torch.float32, device=z.device)
         with torch.cuda.device(z.device):
             rc = _lib.load().msr3d_bn_relu_train_bwd(R, C, _p(z), _p(dy), _p(pro[0]), _p(pro[1]), _p(pro[2]), _p(pro[3]),
-                                                     _p(dz), _p(dg), _p(db), _p(ws), _lib.current_stream_ptr(z.device))
+                                                     _p(dz), _p(dg), _p(db), _p(ws), *_direct_ptrs(ctx.direct_bn),
+                                                     _lib.current_stream_ptr(z.device))
         _lib.check(rc, "msr3d_bn_relu_train_bwd")
+        if ctx.direct_bn is not None:
+            _direct_done(ctx.direct_bn)
+            dg = db = None
         return dz, dg, db, None, None, dw, None
 
 
@@ -597,7 +644,7 @@ def _mlp_rows(mlp, t, pool_ns):
         w = conv.weight.view(conv.out_channels, conv.in_channels)
         got = []
         if pending is not None and _bn_linear_fused_ok(z, part, w):
-            z = _BNReLULinear.apply(z, pending.weight, pending.bias, pending, part, w, got)
+            z = _BNReLULinear.apply(z, pending.weight, pending.bias, pending, part, conv.weight, got)
         else:
             if pending is not None:
                 t = _BNReLUTrain.apply(z, pending.weight, pending.bias, pending, part)
