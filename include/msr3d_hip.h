@@ -699,7 +699,9 @@ int msr3d_wgrad_rows_split(int M, int n_out, int k_in, const float *dy, int ldy,
  * PointNet++ backbone as token GEMMs over the grouped rows (/root/reference/model/pointnet2/pytorch_utils.py:9-60;
  * hipops.py::_mlp_rows) -- forward z = t W^T (b_trans = 0, B = W (N, K)) and d t = d z W (b_trans = 1, B = W
  * (K, N): op(B)[n][k] = B[k * ldb + n]).  HBM-bound: the weight is split into LDS by each workgroup, the rows are
- * read once in MFMA fragment shape and split in registers.  K % 4 == 0, K <= MSR3D_ROWS_GEMM_MAX_K,
+ * read once in MFMA fragment shape and split in registers.  B may be NARROWER than the product reads it (ldb < K
+ * with b_trans = 0, ldb < N with b_trans = 1): it then ends at column ldb and counts as zero beyond -- the weight of
+ * a layer whose input rows are zero-padded to whole 16-wide slabs needs no padded copy.  K % 4 == 0, K <= MSR3D_ROWS_GEMM_MAX_K,
  * N <= MSR3D_ROWS_GEMM_MAX_N, lda % 4 == 0, ldc % 4 == 0, A and C 16-byte aligned; no split-K, no atomics:
  * bit-reproducible, every output row independent of the others.
  * col_stats (optional): [ceil(M / MSR3D_ROWS_GEMM_BLOCK)][2][N] floats -- the column sums and sums of squares of C

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(512, 1) void rows_gemm_split_kernel(const RowsGemm 
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const bool ok = n < p.N && k + e < p.K;
+        // (a B narrower than the product -- ldb below the width op(B) is read at -- ends there: the operand's zero
+        //  padding needs no padded copy of the weight)
+        const bool ok = n < p.N && k + e < p.K && (p.b_trans ? n : k + e) < p.ldb;
         v[e] = ok ? (p.b_trans ? p.B[(size_t)(k + e) * p.ldb + n] : p.B[(size_t)n * p.ldb + k + e]) : 0.f;
       }
       uint4 pl[3];

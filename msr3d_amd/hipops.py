@@ -597,6 +597,55 @@ class _BNReLULinear(torch.autograd.Function):
         return dz, dg, db, None, None, dw, None
 
 
+class _RowsLinear(torch.autograd.Function):
+    """z (R, N) = t (R, KP) W^T for the FIRST layer of a SharedMLP on tall grouped rows: t is zero-padded from the
+    weight's K to KP columns (whole 16-wide slabs) and the kernels read the (N, K) weight as it lies -- no padded copy,
+    its gradient added straight into the parameter's view of the flat gradients when there is one."""
+
+    @staticmethod
+    def forward(ctx, t, weight, stats_out):
+        R, KP = t.shape
+        N = weight.shape[0]
+        w = (weight if weight.is_contiguous() else weight.contiguous()).view(N, -1)
+        K = w.shape[1]
+        z = torch.empty((R, N), dtype=torch.float32, device=t.device)
+        stats = torch.empty((-(-R // ROWS_GEMM_BLOCK), 2, N), dtype=torch.float32, device=t.device)
+        stats_out.append(stats)
+        _rows_gemm(R, N, KP, t, KP, w, K, False, z, N, stats)
+        ctx.save_for_backward(t, w)
+        ctx.direct_w = _direct_targets(weight)
+        ctx.w_shape = tuple(weight.shape)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        t, w = ctx.saved_tensors
+        R, KP = t.shape
+        N, K = w.shape
+        dz = dz if dz.is_contiguous() else dz.contiguous()
+        dw = None
+        if ctx.needs_input_grad[1]:
+            if ctx.direct_w is not None:
+                _wgrad_rows(R, N, K, dz, t, ctx.direct_w[1][0].grad.view(N, K), accumulate=True)
+                _direct_done(ctx.direct_w)
+            else:
+                dw = torch.empty((N, K), dtype=torch.float32, device=t.device)
+                _wgrad_rows(R, N, K, dz, t, dw)
+                dw = dw.view(ctx.w_shape)
+        dt = None
+        if ctx.needs_input_grad[0]:
+            dt = torch.empty((R, KP), dtype=torch.float32, device=t.device)
+            _rows_gemm(R, KP, N, dz, N, w, K, True, dt, KP)           # (columns K .. KP: zero)
+        return dt, dw, None
+
+
+def _rows_linear_ok(t, w):
+    R, KP = t.shape
+    N, K = w.shape
+    return (_ROWS_SPLIT and _FUSE_BN and R >= 8192 and KP % 4 == 0 and N % 4 == 0 and K <= KP <= 256 and N <= 256
+            and t.is_contiguous() and t.data_ptr() % 16 == 0)
+
+
 def _bn_linear_fused_ok(z, part, w):
     """The normalisation of z can ride on the next product's operand load: statistics already there, both products of
     the pair on the tall-rows kernels (whole weight in LDS), no padding between the layers."""
@@ -648,9 +697,12 @@ def _mlp_rows(mlp, t, pool_ns):
         else:
             if pending is not None:
                 t = _BNReLUTrain.apply(z, pending.weight, pending.bias, pending, part)
-            if t.shape[1] != w.shape[1]:
-                w = F.pad(w, (0, t.shape[1] - w.shape[1]))      # zero columns against the operand's padding
-            z = linear(t, w, stats_out=got)
+            if _rows_linear_ok(t, w):
+                z = _RowsLinear.apply(t, conv.weight, got)
+            else:
+                if t.shape[1] != w.shape[1]:
+                    w = F.pad(w, (0, t.shape[1] - w.shape[1]))      # zero columns against the operand's padding
+                z = linear(t, w, stats_out=got)
         part = got[0] if got else None
         pending = bn
     return _BNReLUMaxPoolTrain.apply(z, pending.weight, pending.bias, pending, pool_ns, part)

@@ -199,3 +199,31 @@ def test_operand_normalisation_on_load(M, N, K):
     want = dy.double().t() @ Y.double()
     scale = dy.double().abs().t() @ Y.double().abs() + 1.0
     assert float(((dW.double() - want).abs() / scale).max()) < 5e-6
+
+
+@pytest.mark.parametrize("b_trans", [0, 1])
+def test_weight_narrower_than_the_padded_operand(b_trans):
+    """The first SharedMLP layer: rows zero-padded from 131 to 144 columns against the (128, 131) weight as it lies
+    (ldb = 131 < K = 144), and its transpose product d t = d z W with 144 output columns of which 131 exist."""
+    from msr3d_amd import _lib
+    M, N, Kr, KP = 20000, 128, 131, 144
+    g = torch.Generator(device="cuda").manual_seed(7 + b_trans)
+    W = torch.randn(N, Kr, device="cuda", generator=g) * 0.3
+    st = _lib.current_stream_ptr(torch.device("cuda"))
+    p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    if not b_trans:
+        A = torch.zeros(M, KP, device="cuda")
+        A[:, :Kr] = torch.randn(M, Kr, device="cuda", generator=g)
+        C = torch.empty(M, N, device="cuda")
+        assert _lib.load().msr3d_rows_gemm_split(M, N, KP, p(A), KP, p(W), Kr, 0, p(C), N, None, None, st) == 0
+        want = A[:, :Kr].double() @ W.double().t()
+        scale = A[:, :Kr].double().abs() @ W.double().abs().t()
+    else:
+        A = torch.randn(M, N, device="cuda", generator=g)
+        C = torch.full((M, KP), float("nan"), device="cuda")
+        assert _lib.load().msr3d_rows_gemm_split(M, KP, N, p(A), N, p(W), Kr, 1, p(C), KP, None, None, st) == 0
+        assert float(C[:, Kr:].abs().max()) == 0.0          # the padding columns of d t: exact zeros
+        C = C[:, :Kr]
+        want = A.double() @ W.double()
+        scale = A.double().abs() @ W.double().abs()
+    assert float(((C.double() - want).abs() / scale).max()) < 2e-6
