@@ -9,13 +9,21 @@
 // MFMA products above 2^-24 of it (split_mma.h, the arithmetic of the frozen encoder's sa_split.hip), which
 // makes the product HBM-bound:
 //
-//   * op(B) -- the layer's weight, at most 144 x 160 -- is split by the workgroup itself on its way into LDS,
-//     in MFMA fragment order ([k/32][n/16][3 planes][64 lanes][8]), once per workgroup: no pack launch;
+//   * op(B) -- the layer's weight, up to 144 x 160 or 64 x 256 -- is split by the workgroup itself on its way into
+//     LDS, in MFMA fragment order ([k/32][n/16][3 planes][64 lanes][8]), once per workgroup: no pack launch.  Wider
+//     outputs: column groups over blockIdx.y; wider reductions (the last level's 15 k x 256..768 layers): 128-wide
+//     super-slabs of op(B) re-filled per row block, the accumulators carried across them;
 //   * a wave owns 32 rows per pass: its lanes load the rows' fp32 values straight in fragment shape (row i,
-//     k = 32 s + 8 g .. + 7: two 16-byte loads; the four g-lanes of a row cover 128 contiguous bytes), split them
-//     in registers, and multiply against every column tile of B from LDS (three ds_read_b128 per 12 MFMAs);
-//   * 8 waves = 256 rows per pass and workgroup, one workgroup per CU walking the row blocks grid-stride; the
-//     other wave of a SIMD multiplies while this one's loads fly.
+//     k = 32 s + 8 g .. + 7: two 16-byte buffer loads; the four g-lanes of a row cover 128 contiguous bytes), split
+//     them in registers, and multiply against every column tile of B from LDS (three ds_read_b128 per 12 MFMAs).
+//     The NEXT unit's values are loaded into the registers of each slab right after it has been split, so the loads
+//     fly under this unit's MFMAs at no register cost;
+//   * 8 waves = 256 rows per pass and workgroup, one workgroup per CU walking the row blocks grid-stride.
+// Two things ride on it for the BatchNorm that surrounds every product of the backbone (bn_train.hip):
+//   * col_stats: the column sums and sums of squares of each 256-row block of C from the accumulators (DPP row
+//     reduction, the eight waves added in order) -- the normalisation's first-stage statistics without a pass over C;
+//   * a_bn: A <- max(gamma (A - mean) rstd + beta, 0) per column as the values are consumed -- the PREVIOUS layer's
+//     normalisation + ReLU, whose output is then never written (hipops._BNReLULinear).
 // A lane of D holds four consecutive columns of one row: 16-byte stores.
 #include <hip/hip_runtime.h>
 
