@@ -686,7 +686,9 @@ def shared_mlp_train_supported(mlp, x):
 def _mlp_rows(mlp, t, pool_ns):
     """The SharedMLP on token-major rows t (R, K >= C_in, zero-padded), then the max over every
     pool_ns consecutive rows -> (R / pool_ns, C_out); the last layer's normalisation and the pooling
-    are one kernel."""
+    are one kernel.  On tall rows (>= 8192) every product runs on the tall-rows kernels, leaves the next
+    BatchNorm's first-stage statistics behind, and applies the PREVIOUS layer's normalisation + ReLU to its operand
+    on load (_BNReLULinear): between two layers only the pre-normalisation z exists in memory."""
     pairs = mlp.conv_bn_pairs()
     z = part = pending = None        # pending: the BatchNorm whose normalisation the NEXT product applies on load
     for j, (conv, bn) in enumerate(pairs):
