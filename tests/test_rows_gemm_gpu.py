@@ -227,3 +227,40 @@ def test_weight_narrower_than_the_padded_operand(b_trans):
         want = A.double() @ W.double()
         scale = A.double().abs() @ W.double().abs()
     assert float(((C.double() - want).abs() / scale).max()) < 2e-6
+
+
+def test_full_size_checksums_of_the_first_level():
+    """At the bench's full row count (16 scenes x 60 objects x 32 centres x 32 neighbours = 983,040 rows), through
+    size-independent properties: the column sums of C -- the kernel's own col_stats -- equal (column sums of A) B^T
+    (a checksum of checksums), and the weight gradient over all rows equals the sum of the gradients over the two
+    halves of the rows (linearity)."""
+    from msr3d_amd import _lib
+    M, N, K = 983040, 128, 64
+    g = torch.Generator(device="cuda").manual_seed(11)
+    A = torch.randn(M, K, device="cuda", generator=g)
+    B = torch.randn(N, K, device="cuda", generator=g) * 0.3
+    C = torch.empty(M, N, device="cuda")
+    S = torch.empty((M + 255) // 256, 2, N, device="cuda")
+    st = _lib.current_stream_ptr(torch.device("cuda"))
+    p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    assert _lib.load().msr3d_rows_gemm_split(M, N, K, p(A), K, p(B), K, 0, p(C), N, p(S), None, st) == 0
+    got = S[:, 0].double().sum(0)
+    want = A.double().sum(0) @ B.double().t()
+    scale = A.double().abs().sum(0) @ B.double().abs().t()
+    assert float(((got - want).abs() / scale).max()) < 1e-6
+    assert float((C.double().sum(0) - got).abs().max() / scale.max()) < 1e-6
+    sq = (C.double() ** 2).sum(0)
+    assert float(((S[:, 1].double().sum(0) - sq).abs() / sq).max()) < 1e-6
+    dy = torch.randn(M, N, device="cuda", generator=g)
+    ws = torch.empty(256 * N * K, device="cuda")
+    f = _lib.load().msr3d_wgrad_rows_split
+    outs = []
+    for lo, hi in ((0, M), (0, M // 2), (M // 2, M)):
+        dW = torch.empty(N, K, device="cuda")
+        assert f(hi - lo, N, K, p(dy[lo:hi]), N, p(A[lo:hi]), K, p(dW), K, 0, p(ws), ws.numel(), None, st) == 0
+        outs.append(dW.double())
+    scale = float(outs[0].abs().max())
+    assert float((outs[0] - (outs[1] + outs[2])).abs().max()) / scale < 1e-5
+    # and a sample of its entries against float64 over all rows
+    want = dy[:, :4].double().t() @ A.double()
+    assert float((outs[0][:4] - want).abs().max()) / scale < 1e-5
