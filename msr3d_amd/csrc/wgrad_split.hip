@@ -302,7 +302,19 @@ __global__ __launch_bounds__(512, 2) void wgrad_rows_fold_kernel(WP base, int ch
 __global__ __launch_bounds__(512, 2) void wgrad_rows_kernel(WP base, int chunk_rows, int tiles, float *ws,
                                                             const float *xpro) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int chunk = blockIdx.x / tiles, tile = blockIdx.x - chunk * tiles;
+  // (chunk, tile) of this workgroup.  With several tiles per chunk the tiles of ONE chunk read the same rows of one
+  // operand: they are placed on the same XCD (workgroup b runs on XCD b % 8) and dispatched together -- b and b + 8 --
+  // so that the second read is served by that XCD's L2 instead of HBM (491 k rows, 256 x 128: 281 -> 254 us).
+  int chunk, tile;
+  const int nchunks = gridDim.x / tiles;
+  if (tiles > 1 && (nchunks & 7) == 0) {
+    const int grp = blockIdx.x / (8 * tiles), r = blockIdx.x - grp * 8 * tiles;
+    chunk = grp * 8 + (r & 7);
+    tile = r >> 3;
+  } else {
+    chunk = blockIdx.x / tiles;
+    tile = blockIdx.x - chunk * tiles;
+  }
   const int nkt = (base.k_in + TK - 1) / TK;
   WP pr = base;
   const long long r0 = (long long)chunk * chunk_rows;
