@@ -8,8 +8,10 @@ HBM before the timed region:
     -> (N>1) RCCL gradient all-reduce overlapped with backward -> global-norm clip -> AdamW
 (SURVEY.md §8(d) "primary metric").  The frozen LLM is NOT part of this path.
 
-Contract (driver):  python bench.py --gpus N --steps K --warmup W   [torchrun for N>1]
-prints ONE JSON line on rank 0.
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+prints ONE JSON line on rank 0.  For N > 1 either launch it under torchrun (one rank per GPU; RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* from the environment) or run it plainly: without WORLD_SIZE in the environment it re-executes
+itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`.
 """
 import argparse
 import json
@@ -63,7 +65,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="scenes per GPU per step "
+    ap.add_argument("--batch", type=int, default=None, help="scenes per GPU per step (default 16; --full-step: 4) "
                     "(global 128 on 8 GPUs = configs/msr3d_3_dataset.yaml DDP shape)")
     ap.add_argument("--llm-hidden", type=int, default=4096, help="Vicuna-7B hidden size")
     ap.add_argument("--objects", type=int, default=60, help="objects per scene (120: BASELINE stress config)")
@@ -106,16 +108,45 @@ def parse():
                     "the language-model side -- L LoRA-Llama decoder layers (Vicuna-7B shape) + final norm + 32000-way head + "
                     "per-sequence cross-entropy, forward + backward + LoRA gradient exchange (bucketed, from the backward "
                     "hooks) + clip + AdamW")
+    ap.add_argument("--full-step", action="store_true", help="SECONDARY, labelled line: the FULL MSR3D training step -- hot path "
+                    "(frozen encoder, prompter, llm_proj) -> scatter into inputs_embeds -> --llm-layers LoRA-Llama layers (Vicuna-7B "
+                    "shapes, random bf16 weights) -> head -> per-sequence CE -> backward through the language model into the "
+                    "prompter -> ONE flat gradient buffer (bucketed exchange from the backward hooks) -> clip + AdamW; "
+                    "--batch sequences (default 4 here) x --seq-len tokens per GPU")
+    ap.add_argument("--llm-layers", type=int, default=32, help="decoder layers of --full-step (32 = Vicuna-7B)")
+    ap.add_argument("--seq-len", type=int, default=576, help="tokens per sequence of --full-step (prompt incl. 60 scene "
+                    "tokens + answer; multiple of 64)")
+    ap.add_argument("--round-tag", default=os.environ.get("MSR3D_ROUND_TAG", "r04"), help="prefix of files this run writes "
+                    "under profiles/ (--cpu-ops)")
     ap.add_argument("--llm-layer", action="store_true", help="SECONDARY, labelled line: one LoRA-Llama decoder layer "
                     "(Vicuna-7B shape: hidden 4096, 32 heads, MLP 11008, LoRA r 16 on the seven projections), forward + "
                     "backward at 4 sequences x 576 tokens, bf16 -- SURVEY.md §8(f) rank 4; not the headline metric")
     ap.add_argument("--cpu-ops", action="store_true", help="per-op CPU micro-benchmarks at the GPU kernels' shapes "
-                    "(BASELINE.md §3.4) beside the GPU kernels' times -> profiles/r03_cpu_ops.json; no training step")
+                    "(BASELINE.md §3.4) beside the GPU kernels' times -> profiles/<round-tag>_cpu_ops.json; no training step")
     ap.add_argument("--no-graph", action="store_true", help="issue the trainable part eagerly "
                     "instead of replaying the captured HIP graph")
     ap.add_argument("--cpu-threads", type=int, default=32, help="threads of the CPU baseline leg "
                     "(small GEMMs stop scaling well before a 2-socket host's 256 HW threads)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 4 if args.full_step else 16
+    return args
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: become `torchrun --nproc-per-node N bench.py ...` (same argv;
+    rank 0's JSON line is the child's stdout = ours).  Returns the exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
 
 def build(args, device):
@@ -288,6 +319,138 @@ def llm_layer_line(args):
                 "the §8(f) rank-4 building block"}))
 
 
+def full_step_line(args):
+    """SECONDARY line: the FULL MSR3D training step (msr3d_amd/model/msr3d_full.py + msr3d_amd/full_step.py) at the
+    Vicuna-7B shapes of BASELINE configs[1] -- random bf16 weights (no checkpoint on the box), synthetic scenes and
+    token ids, everything resident in HBM."""
+    import msr3d_amd.model  # noqa: F401
+    import msr3d_amd.modules  # noqa: F401
+    from msr3d_amd.config import AttrDict, default_prompter_cfg
+    from msr3d_amd.full_step import FullTrainStep
+    from msr3d_amd.model import build_model
+    from msr3d_amd.synth import synth_batch, synth_text
+    assert torch.cuda.is_available(), "bench.py --full-step needs a GPU"
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = 0 if os.environ.get("MSR3D_BENCH_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    dist_on = world > 1 or os.environ.get("MSR3D_BENCH_FORCE_DIST") == "1"
+    if dist_on and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ["MSR3D_DP_FORCE_EXCHANGE"] = "1"
+    if dist_on and not dist.is_initialized():
+        backend = os.environ.get("MSR3D_BENCH_BACKEND", "nccl")
+        dist.init_process_group("nccl", device_id=dev) if backend == "nccl" else dist.init_process_group(backend)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    L, Bq, T, Hd, NH, FF, V = args.llm_layers, args.batch, args.seq_len, args.llm_hidden, 32, 11008, 32000
+    if Hd != 4096:
+        NH, FF = 40, 13824                                   # Vicuna-13B
+    T_out = 32
+    torch.manual_seed(1234)
+    cfg = AttrDict({"prompter": default_prompter_cfg(situation_type=args.situation_type), "llm_hidden_size": Hd,
+                    "llm": {"num_layers": L, "hidden_size": Hd, "num_heads": NH, "intermediate_size": FF, "vocab_size": V,
+                            "lora": {"rank": 16, "alpha": 16}},
+                    "device": str(dev), "model": {"name": "MSR3DFullStep"}})
+    model = build_model(cfg).to(dev).train()
+    net = model.llm_model
+    with torch.no_grad():
+        for layer in net.layers:
+            for grp in (layer.self_attn, layer.mlp):
+                for m in grp.values():
+                    m.load_base_weight(torch.randn(m.out_features, m.in_features, device=dev) / m.in_features ** 0.5)
+                    m.lora_B.weight.normal_(std=0.02)
+        net.lm_head.load_weight(torch.randn(V, Hd, device=dev) / Hd ** 0.5)
+        model.embed_tokens.copy_(torch.randn(V, Hd, device=dev) * 0.02)
+    ts = FullTrainStep(model, lr=3e-5, betas=(0.9, 0.999), weight_decay=0.05, max_grad_norm=5.0)
+    Ltok = O + (1 if args.situation_type == "as_object" else 0)
+    batches = []
+    for i in range(3):
+        b = synth_batch(1000 * rank + i, Bq, O=O, P=P, device=dev)
+        b.update(synth_text(5000 + 1000 * rank + i, Bq, L=Ltok, T_in=T - T_out, T_out=T_out, vocab=V, device=dev))
+        batches.append(b)
+    for i in range(max(args.warmup, 2)):
+        ts(batches[i % 3])
+    ranks_seen = 1
+    if dist_on:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        ts.dp.timing = True
+        ts.dp.comm_events.clear()
+        ts.dp.wait_events.clear()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(args.steps):
+        loss = ts(batches[i % 3])
+        marks[i + 1].record()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    comm = None
+    if dist_on:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ts.dp.timing = False
+        ar = [a.elapsed_time(b) for a, b in ts.dp.comm_events]
+        wt = [a.elapsed_time(b) for a, b in ts.dp.wait_events]
+        _, spread = ts.dp.replica_checksum(ts.opt.flat_p)
+        stats = torch.tensor([sum(ar) / args.steps, sum(wt) / args.steps], device=dev, dtype=torch.float64)
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        comm = {"ranks_seen": ranks_seen, "exchange": ts.dp.exchange_mode, "buckets": len(ts.dp.buckets),
+                "collectives_per_step": len(ar) / args.steps, "exchange_ms_per_step_on_comm_stream": float(stats[0]),
+                "exchange_exposed_ms_per_step": float(stats[1]), "replica_checksum_spread": spread}
+        assert ranks_seen == world and spread == 0.0
+    elapsed = float(tt.item())
+    if rank == 0:
+        per = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
+        M = Bq * T
+        lin = 2.0 * M * (4 * Hd * Hd + 3 * Hd * FF)
+        att = 2.0 * 2.0 * Bq * NH * T * T * (Hd // NH)
+        flop = L * (2.0 * lin + 3.0 * att) + 2.0 * 2.0 * M * Hd * V + Bq * 8.8e9
+        ms = 1e3 * elapsed / args.steps
+        line = {
+            "metric": "SECONDARY: full MSR3D training step (hot path + LoRA-Llama), samples/s",
+            "value": Bq * world * args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": max(args.warmup, 2), "ms_per_step": ms,
+            "ms_per_step_percentiles": {"p10": per[int(0.1 * len(per))], "p50": per[len(per) // 2], "p90": per[min(len(per) - 1, int(0.9 * len(per)))]},
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "hot path f32 (bf16x3 split MFMA); language model bf16 storage, fp32 accumulate; LoRA / optimiser fp32",
+            "data": "synthetic (random bf16 LLM weights: no checkpoint on the box; synthetic scenes and token ids)",
+            "config": {"workload": "configs/msr3d.yaml full step: frozen PointNet++ -> OSE3DSituation -> llm_proj -> scatter into "
+                                   f"inputs_embeds -> {L} LoRA-Llama layers (hidden {Hd}, {NH} heads, MLP {FF}, LoRA r=16 on "
+                                   "q/k/v/o/gate/up/down) -> RMSNorm -> 32000-way frozen head -> per-sequence CE -> backward through "
+                                   "the LLM and the scatter into the prompter -> ONE flat gradient buffer, buckets exchanged from the "
+                                   "backward hooks -> clip + AdamW; eager launches",
+                       "layers": L, "sequences_per_gpu": Bq, "tokens_per_sequence": T, "scene_tokens": Ltok,
+                       "objects": O, "points": P, "trainable_parameters": ts.dp.numel, "grad_bytes": ts.dp.numel * 4,
+                       "lora_parameters": sum(p.numel() for p in net.lora_parameters()),
+                       "unused_parameters_skipped": len(ts.unused_parameters),
+                       "prompter_schedule": "blocks" if getattr(model._schedule, "_ran_blocks", False) else "strips/modular",
+                       "parallelism": f"dp{world}"},
+            "loss": float(loss), "tokens_per_s": world * M * args.steps / elapsed,
+            "tflops_per_gpu": flop / (ms * 1e-3) / 1e12, "frac_of_bf16_peak": flop / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
+            "hbm_allocated_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
+            "note": "not the headline metric (SURVEY 0.5 / 8(d): the hot-path line is); this is the step BASELINE configs[1] names"}
+        if comm is not None:
+            line["comm"] = comm
+    if dist_on:
+        dist.destroy_process_group()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
 def llm_stack_line(args):
     """The language-model side of a step: msr3d_amd/llm/stack.py on the flat-gradient engine (dp.py, optim.py)."""
     import torch.distributed as dist
@@ -371,6 +534,10 @@ def main():
     global O, P
     args = parse()
     O, P = args.objects, args.points
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not (args.llm_layer or args.cpu_ops):
+        sys.exit(relaunch_under_torchrun(args))
+    if args.full_step:
+        return full_step_line(args)
     if args.llm_stack:
         return llm_stack_line(args)
     if args.llm_layer:
@@ -379,7 +546,7 @@ def main():
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
         import cpu_ops_bench          # (times the oracle as the CPU baseline: lives outside the product package)
         res = cpu_ops_bench.run(threads=args.cpu_threads)
-        out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_cpu_ops.json")
+        out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"{args.round_tag}_cpu_ops.json")
         with open(out, "w") as f:
             json.dump(res, f, indent=1)
         for k, v in res["rows"].items():
@@ -642,7 +809,7 @@ def main():
                                         "note": "HIP events on the compute stream between steps, this rank"},
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (level-2 SharedMLP: bf16x3 split on the bf16 MFMA, fp32 accuracy)" if (split and not args.unfrozen) else "f32",
+            "dtype": "f32 (every product as 6 bf16 MFMA products of exact 3-way bf16 splits, fp32 accumulate: fp32 accuracy)" if (split and not args.unfrozen) else "f32",
             "data": "synthetic",
             "config": {"workload": "configs/msr3d.yaml hot path (OSE3DSituation + llm_proj, "
                                    "frozen PointNet++), synthetic ScanNet-like scenes",

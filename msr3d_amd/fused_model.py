@@ -164,6 +164,13 @@ class PrompterSchedule:
     def _ensure(self, B, L, KE, device):
         key = (B, L, KE, str(device))
         if self.shape == key:
+            # The block tables hold RAW addresses of every parameter, every .grad view and the arena.  Anything
+            # that re-points parameter storage after the tables were built -- FlatAdamW constructed later, a new
+            # gradient engine, .to(), load_state_dict(assign=True) -- must rebuild them, or the blocks would pack
+            # stale weights and write dW into old memory.
+            if self.packs is not None and self._ptr_key != self._pointer_key():
+                self._ln_job_buf = None
+                self._build_block_tables()
             return
         pr, m = self.pr, self.model
         D, M = 256, B * L
@@ -217,6 +224,7 @@ class PrompterSchedule:
         self.shape = key
         self.staged_for = None
         self.packs = self.wgrad = None
+        self._ptr_key = None
         if blocks:
             # the blocks' input rows as three bf16 planes per scene; rows past L are never written (stay zero)
             self.xp = torch.zeros(B * 3 * 64 * 256, dtype=torch.int16, device=device)
@@ -225,16 +233,22 @@ class PrompterSchedule:
 
     # ------------------------------------------------------------------ scene-local fused blocks (round 3)
     def _blocks_capable(self, L, FF, H):
-        return L <= 64 and FF % 128 == 0 and H == 8
+        # (the arena's `part` has 16 partial slabs and msr3d_scene_block rejects more slices than that)
+        return L <= 64 and FF % 128 == 0 and FF // 128 <= 16 and H == 8
 
     def use_blocks(self):
         # (the blocks' attention core multiplies on the bf16x3 split = fp32 accuracy; a reduced-precision attention
         # mode, hipops.set_attention_mma("bf16"), is honoured by the strip schedule's attention kernels)
         return _MODE[0] == "blocks" and self.packs is not None and hipops._attn_mma[0] == "f32"
 
+    def _pointer_key(self):
+        """Addresses the block tables captured: every parameter and its gradient view."""
+        return tuple((p.data_ptr(), p.grad.data_ptr() if p.grad is not None else 0) for p in self._params())
+
     def _build_block_tables(self):
         """Pack jobs for every weight operand of the blocks and the weight-gradient problem table; all
         sources / destinations are views of the flat parameter and gradient buffers or of the arena."""
+        self._ptr_key = self._pointer_key()
         pr, m, a, dm = self.pr, self.model, self.arena, self.dims
         M, D, W, H, FF, E, KF, KE, nl = (dm[k] for k in ("M", "D", "W", "H", "FF", "E", "KF", "KE", "nl"))
         dev = a.buf.device
@@ -242,7 +256,7 @@ class PrompterSchedule:
         wg = scene_blocks.WgradTable(dev)
         PIECE = scene_blocks.PIECE
         lp = m.llm_proj
-        self.llm_blocks = E % 256 == 0
+        self.llm_blocks = E % 256 == 0 and E // 256 <= 16      # (16 partial slabs; wider projectors take the strip GEMM)
         if self.llm_blocks:
             pk.add("llm", lp.weight, E, D, False)                   # scene = tok W^T
             pk.add("llm_t", lp.weight, D, E, True)                  # d tok = d scene W

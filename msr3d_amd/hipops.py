@@ -138,15 +138,15 @@ def _wgrad_rows_ok(M, N, K):
 
 
 def _wgrad_rows(M, N, K, dy, x, dw, accumulate=False, x_bn=None):
-    """dw (N, K) (+)= dy (M, N)^T x (M, K) over tall row counts (msr3d_wgrad_rows_split); the chunk workspace is one
-    buffer per device (33 MB: 256 / tiles chunks of n_out x k_in floats never exceed it), allocated outside any
-    capture -- HotPathTrainStep's eager warm-up step does that."""
+    """dw (N, K) (+)= dy (M, N)^T x (M, K) over tall row counts (msr3d_wgrad_rows_split).  The chunk workspace (33 MB:
+    256 / tiles chunks of n_out x k_in floats never exceed it) is one buffer per (device, stream) -- two tall
+    weight-gradient launches on different streams must not share partial slabs (as lora._grad_workspace and `dot`'s
+    scratch).  A capture stream gets its own from the graph's pool, held here for the replays."""
     dev = dy.device
-    ws = _wgrad_ws.get(dev.index)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _wgrad_ws.get(key)
     if ws is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("the tall weight-gradient workspace must exist before graph capture (run one eager step)")
-        ws = _wgrad_ws[dev.index] = torch.empty(256 * 256 * 128, dtype=torch.float32, device=dev)
+        ws = _wgrad_ws[key] = torch.empty(256 * 256 * 128, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = _lib.load().msr3d_wgrad_rows_split(M, N, K, _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw.stride(0),
                                                 int(accumulate), _p(ws), ws.numel(), _p(x_bn),

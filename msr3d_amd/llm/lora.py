@@ -61,7 +61,7 @@ class _LoRAFn(torch.autograd.Function):
         M, dev = x2.shape[0], x.device
         # bf16 shadows of the trainable pair in the orientations the products read: built once per weight
         # version (i.e. once per optimiser step), not per call
-        a_pad, b2, _, _ = mod._shadows()
+        a_pad, b2, _, _ = mod._shadows(forward=True)
         # u = s x A^T  (M, r) bf16 in a zero-padded (M, 64): the r-row product has its own kernel
         u = torch.empty((M, PAD_R), dtype=torch.bfloat16, device=dev)
         _skinny(M, r, K, x2, a_pad, u, PAD_R, s, dev)
@@ -91,16 +91,29 @@ class _LoRAFn(torch.autograd.Function):
             _gemm(M, K, N, PAD_R, dy2, N, mod.weight_t, N, v, PAD_R, at2, PAD_R, dx, K, False, 1.0, dev)
             dx = dx.view(ctx.shape)
         lib = _lib.load()
-        dA = torch.empty((r, K), dtype=torch.float32, device=dev)      # (written, not added to: accumulate = 0)
-        dB = torch.empty((N, r), dtype=torch.float32, device=dev)
+        # On the flat-gradient engine (dp.py) the pair's .grad are views of the flat buffer: the kernels ADD into them
+        # (accumulate = 1) and report readiness themselves -- no AccumulateGrad add launch per parameter (448 a step for
+        # a 32-layer stack) and no temporaries.
+        from .. import hipops
+        pA, pB = mod.lora_A.weight, mod.lora_B.weight          # (the Parameter objects themselves: they carry the engine)
+        direct = hipops._direct_targets(pA, pB) if (ctx.needs_input_grad[1] and ctx.needs_input_grad[2]) else None
+        if direct is not None:
+            dA, dB, acc = pA.grad, pB.grad, 1
+        else:
+            dA = torch.empty((r, K), dtype=torch.float32, device=dev)      # (written, not added to: accumulate = 0)
+            dB = torch.empty((N, r), dtype=torch.float32, device=dev)
+            acc = 0
         with torch.cuda.device(dev):
             st = _lib.current_stream_ptr(dev)
             # dA = (s dy B)^T x = v^T x ; dB = dy^T (s x A^T) = dy^T u   (s already inside u and v)
             ws = _grad_workspace(dev, 64 * r * max(K, N))
-            rc = lib.msr3d_lora_grad(M, r, K, _p(v), PAD_R, _p(x2), K, _p(dA), 0, ctypes.c_float(1.0), 0, _p(ws), ws.numel(), st)
+            rc = lib.msr3d_lora_grad(M, r, K, _p(v), PAD_R, _p(x2), K, _p(dA), 0, ctypes.c_float(1.0), acc, _p(ws), ws.numel(), st)
             _lib.check(rc, "msr3d_lora_grad")
-            rc = lib.msr3d_lora_grad(M, r, N, _p(u), PAD_R, _p(dy2), N, _p(dB), 1, ctypes.c_float(1.0), 0, _p(ws), ws.numel(), st)
+            rc = lib.msr3d_lora_grad(M, r, N, _p(u), PAD_R, _p(dy2), N, _p(dB), 1, ctypes.c_float(1.0), acc, _p(ws), ws.numel(), st)
             _lib.check(rc, "msr3d_lora_grad")
+        if direct is not None:
+            hipops._direct_done(direct)
+            return dx, None, None, None
         return dx, dA, dB, None
 
 
@@ -124,11 +137,26 @@ class LoRALinear(nn.Module):
         nn.init.zeros_(self.lora_B.weight)
         self._wt_version = None       # `weight._version` the transposed copy was made from
 
-    def _shadows(self):
+    def _shadows(self, forward=False):
         """Zero-padded bf16 copies of A / B in the four orientations forward and backward read
         (a_pad (r, K), b2 (N, 64), bt_pad (r, N), at2 (K, 64)); rebuilt when A or B has been written."""
         A, Bw = self.lora_A.weight, self.lora_B.weight
         key = (A._version, Bw._version, A.data_ptr(), Bw.data_ptr())
+        # Inside a graph capture the copies are ALWAYS rebuilt (into the same storage): a replayed optimiser step
+        # changes A / B without running this host code again, so the rebuild has to be part of the graph.
+        capturing = forward and A.is_cuda and torch.cuda.is_current_stream_capturing()     # (backward reuses forward's)
+        if capturing and getattr(self, "_shadow", None) is not None:
+            a_pad, b2, bt_pad, at2 = self._shadow
+            r = self.r
+            with torch.no_grad():
+                a_pad.copy_(A)
+                b2[:, :r].copy_(Bw)
+                bt_pad.copy_(Bw.t())
+                at2[:, :r].copy_(A.t())
+            self._shadow_key = "captured"       # (whatever eager call follows rebuilds as well)
+            return self._shadow
+        if getattr(self, "_shadow_key", None) == "captured" and A.is_cuda and torch.cuda.is_current_stream_capturing():
+            return self._shadow                 # backward of the captured step: forward's copies
         if getattr(self, "_shadow_key", None) != key:
             r, K, N, dev = self.r, self.in_features, self.out_features, A.device
             with torch.no_grad():
@@ -141,6 +169,11 @@ class LoRALinear(nn.Module):
             self._shadow = (a_pad, b2, bt_pad, at2)
             self._shadow_key = key
         return self._shadow
+
+    def invalidate_shadows(self):
+        """Force the bf16 copies of A / B to be rebuilt at the next forward / backward (for writers that changed
+        the parameters without going through autograd or FlatAdamW.mark_written)."""
+        self._shadow_key = None
 
     def _sync_weight_t(self):
         """weight_t is a cache of weight^T (non-persistent): rebuilt whenever `weight` has been written --

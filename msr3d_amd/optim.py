@@ -69,6 +69,18 @@ class FlatAdamW:
             return
         for t in (self.flat_p, self.exp_avg, self.exp_avg_sq, self.step_ctr):
             dist.broadcast(t, src=src, group=self.dp.group)
+        self.mark_written()
+
+    def mark_written(self):
+        """The parameters were written through `flat_p` behind autograd's back (the fused kernel, a broadcast, a
+        roll-back copy): bump their version counters so that anything keyed on `param._version` -- LoRALinear's bf16
+        shadows of A / B -- rebuilds.  Host side only, no launch.  Call it after ANY direct write to `flat_p`."""
+        inc = getattr(torch.autograd.graph, "increment_version", None)
+        if inc is None:
+            raise RuntimeError("torch.autograd.graph.increment_version is missing: caches keyed on parameter versions "
+                               "(LoRALinear shadows) could go stale silently -- need torch >= 2.3")
+        for q in self.dp.order:
+            inc(q)
 
     def set_unused(self, params):
         """Parameters that receive no gradient in this configuration (`anchor_feat`, `loc_layers` with
@@ -99,12 +111,7 @@ class FlatAdamW:
                 self.warmup_steps, self.total_steps, int(zero_grad),
                 p(self.active) if self.active is not None else None, f(gscale), _lib.current_stream_ptr(dev))
         _lib.check(rc, "msr3d_adamw_flat_scaled")
-        # the kernel wrote the parameters behind autograd's back: bump their version counters, so that anything keyed
-        # on `param._version` (LoRALinear's bf16 shadows of A / B) sees the update -- no launch, host side only
-        inc = getattr(torch.autograd.graph, "increment_version", None)
-        if inc is not None:
-            for q in self.dp.order:
-                inc(q)
+        self.mark_written()       # (the kernel wrote the parameters behind autograd's back)
 
     def state_dict(self, names=None):
         """Per-parameter moments keyed by position in `dp.order` (or by `names[i]`, the parameter
@@ -130,3 +137,9 @@ class FlatAdamW:
                 self.exp_avg[off:off + n].copy_(sd["state"][k]["exp_avg"].reshape(-1))
                 self.exp_avg_sq[off:off + n].copy_(sd["state"][k]["exp_avg_sq"].reshape(-1))
         self.step_ctr.fill_(int(sd["step"]))
+
+    def load_params_flat(self, flat):
+        """Overwrite every parameter from a flat fp32 tensor laid out like `flat_p` (checkpoint restore, roll-back)."""
+        with torch.no_grad():
+            self.flat_p.copy_(flat)
+        self.mark_written()

@@ -74,3 +74,33 @@ def synth_scan(rng, n_inst, n_points):
     deg = labels == 3
     pts[deg] = centres[3]
     return pts.astype(np.float32), rng.integers(0, 256, (n_points, 3)).astype(np.uint8), labels
+
+
+def synth_text(seed, B, L=60, T_in=544, T_out=32, vocab=32000, scene_token=31495, pad_id=0, device="cpu"):
+    """Token side of a synthetic MSQA sample, in the shapes `MSR3D.forward` builds them
+    (/root/reference/model/msr3d/msr3d.py:203-206 left-padded prompt ids + mask, :368-376 right-padded answer + eos):
+    input_ids / attention_mask (B, T_in) with exactly L scene placeholders per row (contiguous, as
+    build_text_prompt writes them, msr3d.py:308-309), output_ids / output_mask (B, T_out).  Random ids stand in for
+    text (there is no tokenizer on the box); none of them equals the placeholder id."""
+    rng = np.random.default_rng(seed)
+    ids = np.full((B, T_in), pad_id, np.int64)
+    am = np.zeros((B, T_in), np.int64)
+    out = np.full((B, T_out), pad_id, np.int64)
+    om = np.zeros((B, T_out), np.int64)
+
+    def words(n):
+        w = rng.integers(3, vocab, n)
+        w[w == scene_token] = 3
+        return w
+    for b in range(B):
+        n_pad = int(rng.integers(0, max(1, min(40, T_in - L - 8))))
+        n = T_in - n_pad                                 # real prompt tokens, left-padded
+        before = int(rng.integers(4, n - L - 3))
+        row = np.concatenate([[1], words(before - 1), np.full(L, scene_token), words(n - before - L)])
+        ids[b, n_pad:] = row
+        am[b, n_pad:] = 1
+        n_ans = int(rng.integers(3, T_out + 1))
+        out[b, :n_ans] = np.concatenate([[1], words(n_ans - 2), [2]])        # bos ... eos
+        om[b, :n_ans] = 1
+    return {"input_ids": torch.from_numpy(ids).to(device), "attention_mask": torch.from_numpy(am).to(device),
+            "output_ids": torch.from_numpy(out).to(device), "output_mask": torch.from_numpy(om).to(device)}

@@ -341,6 +341,8 @@ class HotPathTrainStep:
             if "flat" in snap:
                 for t, v in zip((opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.step_ctr), snap["flat"]):
                     t.copy_(v)
+                if hasattr(opt, "mark_written"):
+                    opt.mark_written()         # (flat_p was written directly: version-keyed caches must rebuild)
             else:
                 for p, v in zip(self.dp.order, snap["params"]):
                     p.copy_(v)

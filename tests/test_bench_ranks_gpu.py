@@ -117,3 +117,38 @@ def test_bench_llm_stack_line():
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert j["metric"].startswith("SECONDARY") and j["unit"] == "tokens/s" and j["value"] > 0
     assert j["config"]["layers"] == 1 and j["config"]["lora_parameters"] == 4 * 131072 + 3 * 241664
+
+
+def test_bench_plain_python_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (how the driver's N = 1 record invokes it): the script re-executes
+    itself under torch.distributed.run and rank 0 still prints exactly one JSON line of a 2-rank run."""
+    env = dict(os.environ, MSR3D_BENCH_SINGLE_DEVICE="1", MSR3D_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--batch", "4"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["comm"]["ranks_seen"] == 2 and j["comm"]["replica_checksum_spread"] == 0.0
+    assert j["config"]["global_batch"] == 8 and j["value"] > 0
+
+
+def test_bench_full_step_line():
+    """The full MSR3D step (hot path joined to the LoRA-Llama stack) as a labelled secondary line; 2 layers here, the
+    one-rank RCCL communicator so that the bucketed exchange from the backward hooks really runs."""
+    env = dict(os.environ, MSR3D_BENCH_FORCE_DIST="1", MASTER_PORT="29691", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-step", "--llm-layers", "2", "--steps", "2",
+                          "--warmup", "1", "--batch", "2", "--seq-len", "256"], env=env, cwd=ROOT, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert j["metric"].startswith("SECONDARY") and j["unit"] == "samples/s" and j["value"] > 0
+    c = j["config"]
+    assert c["layers"] == 2 and c["sequences_per_gpu"] == 2 and c["prompter_schedule"] == "blocks"
+    assert c["lora_parameters"] == 2 * (4 * 131072 + 3 * 241664) and c["grad_bytes"] > 4 * c["lora_parameters"]
+    assert j["comm"]["ranks_seen"] == 1 and j["comm"]["collectives_per_step"] >= 2
+    assert j["comm"]["replica_checksum_spread"] == 0.0 and j["comm"]["exchange_exposed_ms_per_step"] >= 0

@@ -1,0 +1,235 @@
+"""The FULL MSR3D training step (msr3d_amd/model/msr3d_full.py, msr3d_amd/full_step.py) -- prompter -> llm_proj ->
+scatter into inputs_embeds -> LoRA-Llama layers -> per-sequence cross-entropy -> backward through the language model and
+the scatter into llm_proj and the prompter, every gradient in ONE flat buffer -- against
+tests/golden/full_step_seed0.npz: the REFERENCE's OSE3DSituation (imported), the statements of MSR3D.build_embeds /
+MSR3D.forward that join the halves, transformers' LlamaForCausalLM with peft's LoRA formula and leo_trainer's
+loss.mean().backward(), evaluated in float32 on the CPU (tests/golden/make_golden_full_step.py).
+
+Tolerances: the hot path is fp32 (scene_embeds <= 2e-5 rel-L2); everything downstream of the scatter runs with bf16
+storage as the reference's LLM does under autocast: loss 1e-2 relative, d scene_embeds and every gradient that comes back
+through the language model 4e-2 rel-L2 (norms 3e-2)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = ["q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"]
+KEYS = ("layers", "hidden", "heads", "inter", "vocab", "r", "alpha", "B", "O", "P", "n_pad", "T_in", "T_out", "scene_token")
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def build_model(g, dropout=0.0, device="cuda"):
+    import msr3d_amd.model  # noqa: F401
+    import msr3d_amd.modules  # noqa: F401
+    from msr3d_amd.config import AttrDict, default_prompter_cfg
+    from msr3d_amd.model import build_model as bm
+    from tests.golden.make_golden_full_step import embed_table
+    from tests.helpers import fill_state_dict, llama_stack_weights
+    c = dict(zip(KEYS, (int(v) for v in g["cfg"])))
+    seed = int(g["seed"])
+    cfg = AttrDict({"prompter": default_prompter_cfg(dropout=dropout), "llm_hidden_size": c["hidden"],
+                    "llm": {"num_layers": c["layers"], "hidden_size": c["hidden"], "num_heads": c["heads"],
+                            "intermediate_size": c["inter"], "vocab_size": c["vocab"],
+                            "lora": {"rank": c["r"], "alpha": c["alpha"]}, "rms_eps": float(g["eps"]),
+                            "rope_theta": float(g["theta"])},
+                    "scene_sp_token": c["scene_token"], "model": {"name": "MSR3DFullStep"}})
+    model = bm(cfg)
+    vp = model.visual_prompter
+    vp.load_state_dict(fill_state_dict(vp.state_dict(), seed), strict=True)
+    model.llm_proj.load_state_dict(fill_state_dict(model.llm_proj.state_dict(), seed + 100))
+    with torch.no_grad():
+        vp.object_orientation_feat.copy_(torch.from_numpy(g["orientation_feat"]))
+    model = model.to(device).train()
+    w = llama_stack_weights(seed, c["layers"], c["hidden"], c["inter"], c["r"], c["vocab"])
+    net = model.llm_model
+    with torch.no_grad():
+        for i, layer in enumerate(net.layers):
+            lw = w["layers"][i]
+            for n in NAMES:
+                m = (layer.self_attn if n in layer.self_attn else layer.mlp)[n]
+                m.load_base_weight(torch.from_numpy(lw[n]).to(device))
+                m.lora_A.weight.copy_(torch.from_numpy(lw[n + ".A"]))
+                m.lora_B.weight.copy_(torch.from_numpy(lw[n + ".B"]))
+            layer.input_layernorm_weight.copy_(torch.from_numpy(lw["ln1"]))
+            layer.post_attention_layernorm_weight.copy_(torch.from_numpy(lw["ln2"]))
+        net.norm_weight.copy_(torch.from_numpy(w["norm"]))
+        net.lm_head.load_weight(torch.from_numpy(w["head"]).to(device))
+        model.embed_tokens.copy_(torch.from_numpy(embed_table(seed)))
+    return model, c
+
+
+def make_batch(g, c, device="cuda"):
+    from msr3d_amd.synth import synth_batch, synth_text
+    batch = synth_batch(int(g["data_seed"]), c["B"], O=c["O"], P=c["P"], n_valid=[c["O"] - c["n_pad"]] * c["B"], device=device)
+    batch.update(synth_text(int(g["text_seed"]), c["B"], L=c["O"], T_in=c["T_in"], T_out=c["T_out"], vocab=c["vocab"],
+                            scene_token=c["scene_token"], device=device))
+    return batch
+
+
+def test_full_step_matches_the_reference_fixture_through_the_language_model():
+    from msr3d_amd.full_step import FullTrainStep
+    g = dict(np.load(os.path.join(GOLD, "full_step_seed0.npz"), allow_pickle=False))
+    model, c = build_model(g)
+    batch = make_batch(g, c)
+    ts = FullTrainStep(model, lr=0.0, weight_decay=0.0, zero_in_optimizer=False)
+    # ONE flat buffer holds prompter + llm_proj + every LoRA pair, in the order backward produces them
+    n_lora = sum(p.numel() for p in model.llm_model.lora_parameters())
+    assert ts.dp.numel >= n_lora + sum(p.numel() for p in model.llm_proj.parameters())
+    first, last = ts.dp.order[0], ts.dp.order[-1]
+    assert any(first is p for p in model.llm_model.layers[-1].parameters())          # last decoder layer leaves first
+    assert any(last is p for p in model.visual_prompter.parameters())
+    seen = {}
+    fwd = model.embed_inputs
+
+    def spy(d, scene, mask):
+        scene.retain_grad()
+        seen["scene"] = scene
+        emb, am, tg = fwd(d, scene, mask)
+        seen["am"], seen["targets"] = am, tg
+        return emb, am, tg
+    model.embed_inputs = spy
+    loss = ts(batch)
+    torch.cuda.synchronize()
+    sched = model._schedule
+    assert sched._ran_blocks and sched.use_blocks(), "the fused scene-block schedule did not run"
+    assert torch.equal(seen["am"].cpu(), torch.from_numpy(g["attention_mask"]))
+    assert torch.equal(seen["targets"].cpu(), torch.from_numpy(g["targets"]))
+    assert rel(seen["scene"].detach().cpu().numpy(), g["scene_embeds"]) < 2e-5
+    model.embed_inputs = fwd
+    with torch.no_grad():
+        model.eval()                                   # (dropout is 0; eval only keeps the schedule's arena untouched)
+        out_loss = model(dict(batch))["loss"].detach().cpu().numpy()
+        model.train()
+    assert np.allclose(out_loss, g["loss"], rtol=1e-2), (out_loss, g["loss"])
+    assert abs(float(loss) - float(g["loss"].mean())) < 1e-2 * float(g["loss"].mean())
+    # gradient of the scene tokens, as the language model's backward + the scatter's backward deliver it
+    d_scene = seen["scene"].grad.detach().cpu().numpy()
+    assert rel(d_scene, g["d_scene_embeds"]) < 4e-2
+    # lr = 0: nothing moved; the flat buffer holds this step's gradients
+    grads = {}
+    for n, p in model.named_parameters():
+        if not p.requires_grad or n.startswith("llm_model."):
+            continue
+        grads[n[len("visual_prompter."):] if n.startswith("visual_prompter.") else n] = p.grad
+    names = [str(n) for n in g["grad_names"]]
+    checked = 0
+    for i, n in enumerate(names):
+        got = grads[n].detach().cpu().numpy().astype(np.float64)
+        if n.endswith("w_ks.bias"):                # mathematically zero; both sides hold rounding noise
+            assert np.abs(got).max() < 1e-4
+            continue
+        if "grad/" + n in g:
+            assert rel(got, g["grad/" + n]) < 4e-2, n
+            checked += 1
+        elif "grad8/" + n in g:
+            assert rel(got[::8], g["grad8/" + n]) < 4e-2, n
+            checked += 1
+        assert abs(np.linalg.norm(got) - g["grad_norms"][i]) <= 3e-2 * g["grad_norms"][i] + 1e-9, n
+    assert checked >= 30
+    for n, gr in grads.items():                    # parameters the configuration does not use keep zero gradients
+        if n not in names:
+            assert float(gr.abs().max()) == 0.0, n
+    for i, layer in enumerate(model.llm_model.layers):
+        for n in NAMES:
+            m = (layer.self_attn if n in layer.self_attn else layer.mlp)[n]
+            assert rel(m.lora_A.weight.grad.cpu().numpy(), g[f"dA/{i}/{n}"]) < 4e-2, (i, n)
+            assert rel(m.lora_B.weight.grad.cpu().numpy(), g[f"dB/{i}/{n}"]) < 4e-2, (i, n)
+    # the unused set was found by the probe, as DDP's find_unused_parameters would
+    unused = {id(p) for p in ts.unused_parameters}
+    assert id(model.visual_prompter.anchor_feat) in unused
+
+
+def test_full_step_trains_prompter_projector_and_lora_together():
+    """Six optimiser steps on a fixed batch: the loss goes down, prompter / llm_proj / LoRA all move, nothing frozen moves,
+    and the gradients are cleared by the optimiser (no fill launch)."""
+    from msr3d_amd.full_step import FullTrainStep
+    g = dict(np.load(os.path.join(GOLD, "full_step_seed0.npz"), allow_pickle=False))
+    model, c = build_model(g, dropout=0.1)
+    batch = make_batch(g, c)
+    ts = FullTrainStep(model, lr=2e-3, weight_decay=0.0, max_grad_norm=1.0)
+    head0 = model.llm_model.lm_head.weight.clone()
+    emb0 = model.embed_tokens.clone()
+    enc0 = [p.detach().clone() for p in model.visual_prompter.obj_encoder.parameters()]
+    w0 = {"proj": model.llm_proj.weight.detach().clone(),
+          "ffn": model.visual_prompter.spatial_encoder[0].linear1.weight.detach().clone(),
+          "lora": model.llm_model.layers[0].self_attn["q_proj"].lora_B.weight.detach().clone()}
+    losses = [float(ts(batch)) for _ in range(6)]
+    torch.cuda.synchronize()
+    assert losses[-1] < losses[0] - 0.05, losses
+    assert float(ts.dp.flat.abs().max()) == 0.0                       # cleared as consumed
+    assert torch.equal(model.llm_model.lm_head.weight, head0) and torch.equal(model.embed_tokens, emb0)
+    assert all(torch.equal(a, b) for a, b in zip(enc0, model.visual_prompter.obj_encoder.parameters()))
+    assert not torch.equal(w0["proj"], model.llm_proj.weight)
+    assert not torch.equal(w0["ffn"], model.visual_prompter.spatial_encoder[0].linear1.weight)
+    assert not torch.equal(w0["lora"], model.llm_model.layers[0].self_attn["q_proj"].lora_B.weight)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        from msr3d_amd.full_step import FullTrainStep
+        from msr3d_amd.synth import synth_batch, synth_text
+        g = dict(np.load(os.path.join(GOLD, "full_step_seed0.npz"), allow_pickle=False))
+        model, c = build_model(g)
+        ts = FullTrainStep(model, lr=1e-3, weight_decay=0.0, bucket_bytes=256 << 10, zero_in_optimizer=False)
+        assert ts.dp.world == world and len(ts.dp.buckets) > 4
+        sent = []
+        launch = ts.dp._launch
+        ts.dp._launch = lambda b: (sent.append(b), launch(b))[1]
+        for i in range(2):
+            batch = synth_batch(7000 + 10 * rank + i, 2, O=c["O"], P=c["P"], device="cuda")
+            batch.update(synth_text(7100 + 10 * rank + i, 2, L=c["O"], T_in=c["T_in"], T_out=c["T_out"], vocab=c["vocab"],
+                                    scene_token=c["scene_token"], device="cuda"))
+            ts(batch)
+        torch.cuda.synchronize()
+        q.put((rank, "ok", ts.opt.flat_p.detach().cpu().numpy().copy(), ts.dp.flat.detach().cpu().numpy().copy(), sent[-len(ts.dp.buckets):]))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:            # noqa: BLE001
+        import traceback
+        q.put((rank, "error: " + repr(e) + "\n" + traceback.format_exc(), None, None, None))
+
+
+def test_two_ranks_share_the_joint_gradient_engine():
+    """world 2 over gloo on the one test GPU (RCCL refuses two ranks on a device): both ranks run the full step on their
+    own samples; buckets leave from the backward hooks in bucket order (LoRA of the upper layers first, the prompter's
+    last), and after two steps the replicas hold identical parameters and identical (summed) gradients."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, status, flat_p, flat_g, sent = q.get(timeout=600)
+        assert status == "ok", status
+        res[r] = (flat_p, flat_g, sent)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][0], res[1][0]), "replicas diverged"
+    assert np.array_equal(res[0][1], res[1][1]) and np.count_nonzero(res[0][1]) > 0
+    sent, nb = res[0][2], len(res[0][2])
+    assert sorted(sent) == list(range(nb))                           # every bucket exactly once per step
+    assert sent[0] < nb // 4 and sent[-1] == nb - 1, sent            # upper layers' LoRA first, the prompter's last
