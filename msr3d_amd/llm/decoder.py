@@ -195,7 +195,10 @@ def rope_tables(T, D, theta=10000.0, device=None):
 
 
 class LoRALlamaDecoderLayer(nn.Module):
-    """Parameter names follow LlamaDecoderLayer (+ peft's lora_A / lora_B inside each projection)."""
+    """State-dict keys: `self_attn.{q,k,v,o}_proj.{weight, lora_A.weight, lora_B.weight}`, `mlp.{gate,up,down}_proj.*`,
+    and the two norm weights as buffers of the layer (`input_layernorm_weight`, `post_attention_layernorm_weight`).
+    Hugging Face / peft spell these `input_layernorm.weight`, `q_proj.base_layer.weight`, `lora_A.default.weight`:
+    msr3d_amd/llm/checkpoint.py maps both ways (load_hf_state_dict, hf_state_dict, peft_adapter_state_dict)."""
 
     def __init__(self, hidden_size=4096, num_heads=32, intermediate_size=11008, r=16, lora_alpha=16, rms_eps=1e-6,
                  rope_theta=10000.0, device=None):

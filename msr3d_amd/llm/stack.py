@@ -85,8 +85,9 @@ class FrozenLinear(nn.Module):
 
 
 class LoRALlamaStack(nn.Module):
-    """`layers` decoder layers + final RMSNorm + head.  Parameter / buffer names follow LlamaForCausalLM
-    (`layers.i.*`, `norm_weight`, `lm_head.weight`) with peft's lora_A / lora_B inside each projection."""
+    """`layers` decoder layers + final RMSNorm + head.  Own state-dict keys: `layers.i.*` (see LoRALlamaDecoderLayer),
+    `norm_weight`, `lm_head.weight`; Hugging Face LlamaForCausalLM / peft checkpoints load through
+    msr3d_amd/llm/checkpoint.py::load_hf_state_dict (and save through hf_state_dict / peft_adapter_state_dict)."""
 
     def __init__(self, num_layers, hidden_size=4096, num_heads=32, intermediate_size=11008, vocab_size=32000, r=16,
                  lora_alpha=16, rms_eps=1e-6, rope_theta=10000.0, device=None):

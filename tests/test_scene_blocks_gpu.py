@@ -96,7 +96,10 @@ def _rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("dropout,B,O,E", [(0.0, 3, 20, 256), (0.1, 2, 60, 512), (0.1, 4, 13, 128)])
+# (0.1, 16, 60, 4096) IS the benchmarked shape -- 16 scenes x 60 objects, Vicuna-7B projector width: the 16-slab
+# LINEAR_KSPLIT, the 360-tile weight-gradient grid, the 5,056-workgroup pack; (0.1, 20, 60, 4096) the window step's
+@pytest.mark.parametrize("dropout,B,O,E", [(0.0, 3, 20, 256), (0.1, 2, 60, 512), (0.1, 4, 13, 128),
+                                           (0.1, 16, 60, 4096), (0.1, 20, 60, 4096)])
 def test_blocks_schedule_matches_strips_schedule_on_every_intermediate(dropout, B, O, E):
     """Same inputs, same dropout keys: every buffer both schedules produce agrees to fp32 rounding
     (<= 2e-5 rel-L2; bf16x3 products vs f32-MFMA products, different summation orders)."""
@@ -111,7 +114,7 @@ def test_blocks_schedule_matches_strips_schedule_on_every_intermediate(dropout, 
         bb, bg = run(model, dp, batch, "blocks")
     finally:
         fused_model.set_mode("blocks")
-    assert model._schedule.use_blocks()
+    assert model._schedule.use_blocks() and model._schedule._ran_blocks and model._schedule.llm_blocks == (E % 256 == 0)
     names = ["x0", "pos", "tok", "scene", "d_la", "d_lb"]
     for i in range(3):
         names += [f"xin{i}", f"qkvc{i}", f"probs{i}", f"ctx{i}", f"s1_{i}", f"s2_{i}", f"t{i}", f"pre{i}", f"h{i}", f"ffn{i}"]
@@ -122,10 +125,14 @@ def test_blocks_schedule_matches_strips_schedule_on_every_intermediate(dropout, 
         assert _rel(bb[f"d_xacc{i}"], sb[f"d_xin{i}"]) < 5e-5, i
     for k, kb in (("d_ffn", "d_ffn0"), ("d_pre", "d_pre0"), ("d_t", "d_t0"), ("d_fc", "d_fc0"), ("d_qkvc", "d_qkvc0")):
         assert _rel(bb[kb], sb[k]) < 5e-5, k
+    # parameter gradients: column sums over B x O token rows of quantities that came through the E-wide reduction
+    # d tok = d scene W_llm -- at E = 4096 both schedules carry ~2.5e-5 of fp32 summation-order noise there (the strips meet
+    # their K-splits by float atomics), measured 5.2e-5 / 5.6e-5 between them on the last layer's norm2.bias
+    gtol = 5e-5 if E <= 512 else 1.5e-4
     for k in sg:
         if k.endswith("w_ks.bias"):
             continue
         if float(sg[k].abs().max()) == 0:
             assert float(bg[k].abs().max()) == 0, k
         else:
-            assert _rel(bg[k], sg[k]) < 5e-5, (k, _rel(bg[k], sg[k]))
+            assert _rel(bg[k], sg[k]) < gtol, (k, _rel(bg[k], sg[k]))

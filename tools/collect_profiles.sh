@@ -39,8 +39,11 @@ python bench.py --llm-layer --steps 10 --warmup 3 2>/dev/null | tail -1 > "$OUT/
 F=$(ls "$OUT"/ktl/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$F" ] && cp "$F" "$OUT/${TAG}_llm_layer_kernel_stats.csv"
 rm -rf "$OUT/ktl"
 python bench.py --llm-stack 4 --steps 10 --warmup 3 2>/dev/null | tail -1 > "$OUT/${TAG}_llm_stack.json"
+python bench.py --full-step --steps 8 --warmup 2 2>/dev/null | tail -1 > "$OUT/${TAG}_full_step.json"
+python bench.py --full-step --batch 20 --steps 4 --warmup 2 2>/dev/null | tail -1 > "$OUT/${TAG}_full_step_window20.json"
+env MSR3D_BENCH_FORCE_DIST=1 python bench.py --full-step --steps 8 --warmup 2 2>/dev/null | tail -1 > "$OUT/${TAG}_full_step_rccl1.json"
 python tools/bench_bf16_gemm.py 2>/dev/null | grep -v amdgpu > "$OUT/${TAG}_bf16_gemm.txt"
 python -m pytest tests/test_seq_ce_gpu.py -q -s -k roofline 2>/dev/null | grep seq_ce > "$OUT/${TAG}_seq_ce.txt"
-python bench.py --cpu-ops > "$OUT/${TAG}_cpu_ops.log" 2>&1; cp profiles/r03_cpu_ops.json "$OUT/${TAG}_cpu_ops.json"
+python bench.py --cpu-ops --round-tag "$TAG" > "$OUT/${TAG}_cpu_ops.log" 2>&1; cp "profiles/${TAG}_cpu_ops.json" "$OUT/${TAG}_cpu_ops.json"
 timeout 300 python tools/prof_blocks.py > "$OUT/${TAG}_block_stamps.txt" 2>&1
 ls -la "$OUT"
