@@ -46,24 +46,24 @@ constexpr int STAGE = 2 * OP_BYTES;                // dy^T tile + x tile
 constexpr int LDS_BYTES = 2 * STAGE;               // 100,352: one workgroup per CU
 __device__ __forceinline__ int frag_slot(int j, int g) { return (4 * (j & 3) + (j >> 2) + 16 * g) * 16; }
 
-// 8 waves, two roles.  Splitting an operand element costs ~7 VALU instructions and 4-byte loads run at a
-// quarter of the 16-byte rate per instruction: a 128 x 64 tile whose four waves did everything spent 3/4
-// of its time there (phase stamps: 2.9k cycles per slab against 768 of MFMA issue; 148 us for the step's
-// 10 GFLOP).  Now waves 4-7 LOAD -- waves 4, 5 the dy tile, waves 6, 7 the x tile; a thread takes 8 tokens
-// x 4 consecutive columns with eight 16-byte loads through a buffer descriptor (token offset in an SGPR,
-// out-of-range tokens read as zero), splits each column's eight values exactly into three bf16 terms and
-// writes 16 bytes per plane straight into fragment order, two slabs ahead -- and waves 0-3 MULTIPLY: a
-// 64 x 64 quarter each, 96 MFMAs per slab from 24 ds_read_b128.  One barrier per slab; the matrix pipe and
-// the VALU work of the split overlap.
+// 16 waves, two roles (round 4; round 3 ran 4 + 4 waves).  Splitting an operand element costs ~6 VALU instructions,
+// so the work is divided: waves 8-15 LOAD -- waves 8-11 the dy tile, 12-15 the x tile; a thread takes 8 tokens x 2
+// consecutive columns with eight 8-byte loads through a buffer descriptor (out-of-range tokens read as zero), splits
+// each column's eight values exactly into three bf16 terms and writes 16 bytes per plane straight into fragment
+// order, two slabs ahead -- and waves 0-7 MULTIPLY: a 64 x 32 piece each, 48 MFMAs per slab from 18 ds_read_b128,
+// two multiplier waves per SIMD so that one's fragment reads fly under the other's MFMAs.  One barrier per slab.
+// Round 3's stamps (4 multipliers of 64 x 64, 4 loaders of 8 x 4 units) per slab and wave: multiplier 1.1 k cycles
+// of exposed fragment reads + 2.0 k of MFMAs, loader 3.2 k -- both twice the matrix pipe's 1.5 k.
 // One 128 x 128 tile of one problem, whole reduction.  OVERWRITE: dW is set, not added to.
 // FOLD (n_out, k_in <= 64: half the tile's columns would be padding, and so would half of every loader
-// instruction's bytes -- the loaders' issue rate is what bounds this kernel): the tile carries TWO row chunks
+// instruction's bytes): the tile carries TWO row chunks
 // side by side -- columns 0..63 of both operands from the rows of chunk A, columns 64..127 from those of chunk B
 // (fold_rows further down, fold_mb of them) -- so D's diagonal 64 x 64 blocks are the two chunks' products
 // (written to pr.dW and pr.dW + n_out * k_in) and the off-diagonal ones are never multiplied.
 // XPRO: the x operand is the PRE-normalisation activation of a BatchNorm + ReLU layer and the product wants its output:
 // x <- max(gamma (x - mean) rstd + beta, 0) per column, applied by the loaders before the split (xpro = [gamma | beta |
 // mean | rstd], k_in floats each) -- the normalised activation is never written (hipops._BNReLULinear).
+constexpr int NMULT = 8, NLOAD = 8, NTHREADS = (NMULT + NLOAD) * 64;
 template <bool OVERWRITE, bool FOLD = false, bool XPRO = false>
 __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, unsigned char *smem, int fold_rows = 0,
                                            int fold_mb = 0, const float *xpro = nullptr) {
@@ -76,33 +76,34 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
   const int nslab = ((M + 63) >> 6) << 1;
   WG_STAMP(0);
 
-  if (wave >= 4) {
+  if (wave >= NMULT) {
     // ------------------------------------------------------------------ loader
-    const bool isx = wave >= 6;                    // which operand this wave feeds (wave-uniform)
+    const int lw = wave - NMULT;
+    const bool isx = lw >= NLOAD / 2;              // which operand this wave feeds (wave-uniform)
     const float *src = isx ? pr.x : pr.dy;
     const int ld = isx ? pr.ldx : pr.ldy, ncol = isx ? pr.k_in : pr.n_out, c0 = isx ? k0 : n0;
-    const int u = (wave & 1) * 64 + lane;          // unit: column quad Q (of 32), token octet o (of 4)
-    const int Q = u & 31, o = u >> 5;
-    const int col = FOLD ? 4 * (Q & 15) : c0 + 4 * Q;
-    const int fold_off = FOLD ? (Q >> 4) * fold_rows * ld * 4 : 0;     // (chunk B's rows)
+    const int u = (lw & 3) * 64 + lane;            // unit: column pair P (of 64), token octet o (of 4)
+    const int P = u & 63, o = u >> 6;
+    const int col = FOLD ? 2 * (P & 31) : c0 + 2 * P;
+    const int fold_off = FOLD ? (P >> 5) * fold_rows * ld * 4 : 0;     // (chunk B's rows)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(src), 0, (int)((size_t)(FOLD && fold_mb ? fold_rows + fold_mb : M) * ld * 4), 0x00020000);
-    const bool vec = (reinterpret_cast<uintptr_t>(src) & 15u) == 0 && (ld & 3) == 0;   // wave-uniform
-    float cm[4];
-    int cb[4];
+    const bool vec = (reinterpret_cast<uintptr_t>(src) & 7u) == 0 && (ld & 1) == 0;   // wave-uniform
+    float cm[2];
+    int cb[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { cm[i] = col + i < ncol ? 1.f : 0.f; cb[i] = 4 * min(col + i, ncol - 1); }
-    const bool edge = cm[3] == 0.f;
-    float xg[4] = {0.f, 0.f, 0.f, 0.f}, xb[4] = {0.f, 0.f, 0.f, 0.f}, xm[4] = {0.f, 0.f, 0.f, 0.f}, xr[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 2; ++i) { cm[i] = col + i < ncol ? 1.f : 0.f; cb[i] = 4 * min(col + i, ncol - 1); }
+    const bool edge = cm[1] == 0.f;
+    float xg[2] = {0.f, 0.f}, xb[2] = {0.f, 0.f}, xm[2] = {0.f, 0.f}, xr[2] = {0.f, 0.f};
     if (XPRO && isx) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 2; ++i) {
         const int cc = min(col + i, ncol - 1);
         xg[i] = xpro[cc]; xb[i] = xpro[ncol + cc]; xm[i] = xpro[2 * ncol + cc]; xr[i] = xpro[3 * ncol + cc];
       }
     }
-    struct Slab { float v[8][4]; };
-    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    struct Slab { float v[8][2]; };
+    float cs[2] = {0.f, 0.f};
     // VEC is a compile-time property of the whole loop: a per-load `if (vec)` makes every load its own
     // basic block, and the compiler then waits vmcnt(0) at each join -- the fetch serialises (measured:
     // the loader waves at 3.7k cycles per slab, the multipliers waiting for them a third of their life)
@@ -118,35 +119,35 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
           const int row = ((32 * s + e) + 8 * o) * ld * 4 + fold_off;
           if constexpr (VEC) {
 #ifdef WG_ABLATE_LOAD
-            const f32x4 r = f32x4{(float)row, 1.f, 2.f, 3.f};
+            s_.v[e][0] = (float)row; s_.v[e][1] = 1.f;
 #else
-            const f32x4 r = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, cb[0] + row, 0, 0));
+            const sm_f32x2 r = __builtin_bit_cast(sm_f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, cb[0] + row, 0, 0));
+            s_.v[e][0] = r.x; s_.v[e][1] = r.y;
 #endif
-            s_.v[e][0] = r.x; s_.v[e][1] = r.y; s_.v[e][2] = r.z; s_.v[e][3] = r.w;
           } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
               s_.v[e][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cb[i] + row, 0, 0));
           }
         }
       };
       auto stash = [&](Slab &s_, int buf) {
-        unsigned char *T = smem + buf * STAGE + (isx ? OP_BYTES : 0) + (Q >> 2) * TILE_BYTES;
+        unsigned char *T = smem + buf * STAGE + (isx ? OP_BYTES : 0) + (P >> 3) * TILE_BYTES;
         if (XPRO && isx) {
 #pragma unroll
           for (int e = 0; e < 8; ++e)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
               s_.v[e][i] = fmaxf(__builtin_fmaf(xg[i], (s_.v[e][i] - xm[i]) * xr[i], xb[i]), 0.f);
         }
-        if (edge) {                                // columns past the matrix (a 16-byte load reads on into the row)
+        if (edge) {                                // columns past the matrix (an 8-byte load reads on into the row)
 #pragma unroll
           for (int e = 0; e < 8; ++e)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s_.v[e][i] *= cm[i];
+            for (int i = 0; i < 2; ++i) s_.v[e][i] *= cm[i];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
           float c8[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) { c8[e] = s_.v[e][i]; cs[i] += c8[e]; }
@@ -158,17 +159,14 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
 #else
           sm_split8(c8, pl);
 #endif
-          const int slot = frag_slot(4 * (Q & 3) + i, o);
+          // (lanes P = 0..7 of a store group hold the even columns of one 16-column tile: slots 0, 8, 1, 9, 2, 10, 3, 11
+          // -- eight distinct 16-byte positions of one bank row)
+          const int slot = frag_slot(2 * (P & 7) + i, o);
 #pragma unroll
           for (int k = 0; k < 3; ++k) *reinterpret_cast<uint4 *>(T + k * 1024 + slot) = pl[k];
         }
       };
-      // Two slabs in flight per thread, fetched unconditionally (past the end: zeros).  Measured on the
-      // step's problem set (tools/prof_wgrad.py, ablation builds): without the loads the launch takes 104 us,
-      // without the MFMAs 178, whole 135-150 -- the loads are what bounds it: a tile reads 960 rows x 512
-      // bytes of each operand once, ~320 MB per launch of which at most half can hit an L2, and this access
-      // pattern gets ~1.5 TB/s out of the fabric whatever the row pitch and however deep the prefetch
-      // (unrolling by 8 slabs so that hipcc's wait counts become exact made it slower: 206 us).
+      // Two slabs in flight per thread, fetched unconditionally (past the end: zeros).
       Slab v0, v1;
       fetch(v0, 0);
       fetch(v1, 1);
@@ -188,23 +186,23 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
     float *red = reinterpret_cast<float *>(smem);  // [4 octets][128]: bias gradient = column sums of dy
     if (!isx) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) red[o * TN + 4 * Q + i] = cs[i];
+      for (int i = 0; i < 2; ++i) red[o * TN + 2 * P + i] = cs[i];
     }
     __syncthreads();
-    if (pr.db && ktile == 0 && wave < 6) {
-      const int c = u;
+    if (pr.db && ktile == 0 && lw < 2) {
+      const int c = lw * 64 + lane;
       if (n0 + c < pr.n_out) pr.db[n0 + c] += (red[c] + red[TN + c]) + (red[2 * TN + c] + red[3 * TN + c]);
     }
   } else {
     // ------------------------------------------------------------------ multiplier: wave (wr, wc) owns
-    // output rows 64 wr .. (4 tiles) x input columns 64 wc .. (4 tiles)
-    const int wr = wave >> 1, wc = wave & 1;
+    // output rows 64 wr .. (4 tiles) x input columns 32 wc .. (2 tiles)
+    const int wr = wave >> 2, wc = wave & 3;
     const int slot = frag_slot(lane & 15, lane >> 4);
-    f32x4 acc[4][4];
+    f32x4 acc[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     unsigned long long tw = 0;
     (void)tw;
     for (int s = 0; s < nslab; ++s) {
@@ -212,19 +210,26 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
 #ifdef WG_ABLATE_MMA
       continue;
 #endif
-      if (FOLD && wr != wc) continue;               // (an off-diagonal block: chunk A's dy against chunk B's x)
+      if (FOLD && wr != (wc >> 1)) continue;        // (an off-diagonal block: chunk A's dy against chunk B's x)
       const unsigned char *A = smem + (s & 1) * STAGE + slot, *Bs = A + OP_BYTES;
-      bf16x8 fa[4][3], fb[4][3];
+      // all 18 fragment reads first, in the order the products consume them (planes A2 B0 | A0 B2 | A1 B1), then the
+      // MFMAs behind counted waits: left to itself hipcc re-used one fragment register serially -- read, wait
+      // lgkmcnt(0), two MFMAs, read ... -- and the first third of every slab ran at LDS latency
+      bf16x8 fa[4][3], fb[2][3];
+      constexpr int ORD_A[3] = {2, 0, 1}, ORD_B[3] = {0, 2, 1};
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int q = 0; q < 3; ++q) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          fa[a][k] = *reinterpret_cast<const bf16x8 *>(A + (4 * wr + a) * TILE_BYTES + k * 1024);
-          fb[a][k] = *reinterpret_cast<const bf16x8 *>(Bs + (4 * wc + a) * TILE_BYTES + k * 1024);
-        }
+        for (int a = 0; a < 4; ++a)
+          fa[a][ORD_A[q]] = *reinterpret_cast<const bf16x8 *>(A + (4 * wr + a) * TILE_BYTES + ORD_A[q] * 1024);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          fb[b][ORD_B[q]] = *reinterpret_cast<const bf16x8 *>(Bs + (2 * wc + b) * TILE_BYTES + ORD_B[q] * 1024);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #define MSR3D_TERM(PA, PB)                                                                       \
       _Pragma("unroll") for (int a = 0; a < 4; ++a)                                              \
-      _Pragma("unroll") for (int b = 0; b < 4; ++b)                                              \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b)                                              \
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][PA], fb[b][PB], acc[a][b], 0, 0, 0);
       MSR3D_TERM(2, 0)
       MSR3D_TERM(0, 2)
@@ -244,12 +249,12 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int kk = FOLD ? 16 * b + j : k0 + 64 * wc + 16 * b + j;
+      for (int b = 0; b < 2; ++b) {
+        const int kk = FOLD ? 32 * (wc & 1) + 16 * b + j : k0 + 32 * wc + 16 * b + j;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int n = FOLD ? 16 * a + 4 * g + r : n0 + 64 * wr + 16 * a + 4 * g + r;
-          if (n < pr.n_out && kk < pr.k_in && (!FOLD || (wr == wc && (wr == 0 || fold_mb > 0)))) {
+          if (n < pr.n_out && kk < pr.k_in && (!FOLD || (wr == (wc >> 1) && (wr == 0 || fold_mb > 0)))) {
             float *d = pr.dW + (FOLD ? (size_t)wr * pr.n_out * pr.k_in : 0) + (size_t)n * pr.ldw + kk;
             *d = OVERWRITE ? acc[a][b][r] : *d + acc[a][b][r];
           }
@@ -259,7 +264,7 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
   WG_STAMP(6);
 }
 
-__global__ __launch_bounds__(512, 2) void wgrad_split_kernel(int nprob, const WP *__restrict__ probs,
+__global__ __launch_bounds__(NTHREADS) void wgrad_split_kernel(int nprob, const WP *__restrict__ probs,
                                                           const int *__restrict__ prefix) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int lo = 0, hi = nprob - 1;
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_kernel(int nprob, const WP
 // cut into chunks, workgroup (chunk, tile) reduces its chunk into ws[chunk] (n_out, k_in) -- plain stores, every
 // workgroup the only writer of its slab -- and wgrad_rows_reduce_kernel adds the slabs in chunk order.
 // n_out, k_in <= 64: workgroup b takes the chunk PAIR (2 b, 2 b + 1) in one folded tile (wgrad_tile<.., FOLD>)
-__global__ __launch_bounds__(512, 2) void wgrad_rows_fold_kernel(WP base, int chunk_rows, float *ws, const float *xpro) {
+__global__ __launch_bounds__(NTHREADS) void wgrad_rows_fold_kernel(WP base, int chunk_rows, float *ws, const float *xpro) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   WP pr = base;
   const long long r0 = (long long)(2 * blockIdx.x) * chunk_rows;
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_rows_fold_kernel(WP base, int ch
   else wgrad_tile<true, true>(pr, 0, 0, smem, chunk_rows, mb);
 }
 
-__global__ __launch_bounds__(512, 2) void wgrad_rows_kernel(WP base, int chunk_rows, int tiles, float *ws,
+__global__ __launch_bounds__(NTHREADS) void wgrad_rows_kernel(WP base, int chunk_rows, int tiles, float *ws,
                                                             const float *xpro) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // (chunk, tile) of this workgroup.  With several tiles per chunk the tiles of ONE chunk read the same rows of one
@@ -355,7 +360,7 @@ extern "C" int msr3d_wgrad_split(int n, const msr3d_wgrad_problem_t *problems, c
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_split_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (attr != hipSuccess) return (int)attr;
-  wgrad_split_kernel<<<total_tiles, 512, LDS_BYTES, (hipStream_t)stream>>>(n, problems, tile_prefix);
+  wgrad_split_kernel<<<total_tiles, NTHREADS, LDS_BYTES, (hipStream_t)stream>>>(n, problems, tile_prefix);
   return (int)hipGetLastError();
 }
 
@@ -389,9 +394,9 @@ extern "C" int msr3d_wgrad_rows_split(int M, int n_out, int k_in, const float *d
     static const hipError_t fattr = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_rows_fold_kernel),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (fattr != hipSuccess) return (int)fattr;
-    wgrad_rows_fold_kernel<<<(unsigned)((chunks + 1) / 2), 512, LDS_BYTES, st>>>(base, chunk_rows, workspace, x_bn);
+    wgrad_rows_fold_kernel<<<(unsigned)((chunks + 1) / 2), NTHREADS, LDS_BYTES, st>>>(base, chunk_rows, workspace, x_bn);
   } else {
-    wgrad_rows_kernel<<<(unsigned)(chunks * tiles), 512, LDS_BYTES, st>>>(base, chunk_rows, tiles, workspace, x_bn);
+    wgrad_rows_kernel<<<(unsigned)(chunks * tiles), NTHREADS, LDS_BYTES, st>>>(base, chunk_rows, tiles, workspace, x_bn);
   }
   wgrad_rows_reduce_kernel<<<(unsigned)((slab + 255) / 256), 256, 0, st>>>(n_out, k_in, (int)chunks, workspace, dW, ldw,
                                                                           accumulate);

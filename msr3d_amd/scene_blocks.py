@@ -118,11 +118,19 @@ class WgradTable:
                 self._pin = torch.empty(n, dtype=torch.uint8).pin_memory()
                 self._table = torch.empty(n, dtype=torch.uint8, device=self.device)
                 self._pfx = torch.tensor(self.prefix, dtype=torch.int32).to(self.device)
-            if self._ev is not None:
-                self._ev.synchronize()        # the previous upload has left the pinned staging buffer
-            _device_bytes(arr, self.device, pinned=self._pin)
-            self._table.copy_(self._pin, non_blocking=True)
-            if not torch.cuda.is_current_stream_capturing():
+            if torch.cuda.is_current_stream_capturing():
+                # Inside a graph capture the upload becomes a memcpy NODE that re-reads its pinned source at every
+                # replay: it gets a staging buffer of its own that is never rewritten (kept alive with the table), and
+                # no event of an earlier eager upload is waited for (illegal while capturing).
+                pin = torch.empty(n, dtype=torch.uint8).pin_memory()
+                self._capture_pins = getattr(self, "_capture_pins", []) + [pin]
+                _device_bytes(arr, self.device, pinned=pin)
+                self._table.copy_(pin, non_blocking=True)
+            else:
+                if self._ev is not None:
+                    self._ev.synchronize()    # the previous upload has left the pinned staging buffer
+                _device_bytes(arr, self.device, pinned=self._pin)
+                self._table.copy_(self._pin, non_blocking=True)
                 self._ev = torch.cuda.Event()
                 self._ev.record()
             self._dirty = False

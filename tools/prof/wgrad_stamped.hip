@@ -4,12 +4,12 @@
 #include <hip/hip_runtime.h>
 
 #define WG_NSTAMP 8
-#define WG_MAXWAVES 4096
+#define WG_MAXWAVES 8192
 __device__ unsigned long long g_wg_stamps[WG_MAXWAVES * WG_NSTAMP];
 #define WG_STAMP(i)                                                                                        \
   do {                                                                                                     \
     if ((threadIdx.x & 63) == 0) {                                                                         \
-      const unsigned w_ = blockIdx.x * 8 + (threadIdx.x >> 6);                                             \
+      const unsigned w_ = blockIdx.x * 16 + (threadIdx.x >> 6);                                             \
       if (w_ < WG_MAXWAVES) g_wg_stamps[w_ * WG_NSTAMP + (i)] = __builtin_readcyclecounter();              \
     }                                                                                                      \
   } while (0)
@@ -18,7 +18,7 @@ __device__ unsigned long long g_wg_stamps[WG_MAXWAVES * WG_NSTAMP];
 #define WG_PUT(i, v)                                                                                       \
   do {                                                                                                     \
     if ((threadIdx.x & 63) == 0) {                                                                         \
-      const unsigned w_ = blockIdx.x * 8 + (threadIdx.x >> 6);                                             \
+      const unsigned w_ = blockIdx.x * 16 + (threadIdx.x >> 6);                                             \
       if (w_ < WG_MAXWAVES) g_wg_stamps[w_ * WG_NSTAMP + (i)] = (v);                                       \
     }                                                                                                      \
   } while (0)

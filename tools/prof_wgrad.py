@@ -50,10 +50,11 @@ for rep in range(3):
     torch.cuda.synchronize()
     assert rc == 0
 print("problems", len(t.probs), "workgroups", t.prefix[-1], "ms", e0.elapsed_time(e1))
-buf = np.zeros(4096 * 8, np.uint64)
+buf = np.zeros(8192 * 8, np.uint64)
 assert lib.msr3d_prof_wgrad_stamps(buf.ctypes.data) == 0
-s = buf.reshape(4096, 8).astype(np.int64)
-role = np.arange(4096) % 8 >= 4
+s = buf.reshape(8192, 8).astype(np.int64)
+NM = int(os.environ.get('WG_NMULT', '8'))
+role = np.arange(8192) % 16 >= NM
 ok = (s[:, 0] != 0) & (s[:, 6] != 0)
 for name, sel in (("multiplier", ok & ~role), ("loader", ok & role)):
     q = s[sel]
