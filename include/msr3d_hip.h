@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 13
+#define MSR3D_ABI_VERSION 14
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -681,6 +681,16 @@ typedef struct msr3d_wgrad_problem {
 } msr3d_wgrad_problem_t;
 int msr3d_wgrad_split(int n, const msr3d_wgrad_problem_t *problems, const int *tile_prefix, int total_tiles,
                       msr3d_stream_t stream);
+
+/* The same launch with every tile's token reduction cut in TWO units (2 x total_tiles workgroups) so that a step's
+ * ~1.4 tiles per CU spread evenly over the chip.  The unit that STARTS first parks its 128 x 128 partial in the
+ * tile's workspace slot, the one that starts second adds first half + second half -- in that order, whichever of
+ * them it is -- onto dW: still no float atomics, still bit-reproducible, identical sums for both launch forms only
+ * up to fp32 association.  workspace: total_tiles x MSR3D_WGRAD_HALF_SLOT_FLOATS floats; sync: 2 x total_tiles
+ * ints, ZERO before the first launch (every launch leaves them zero).  total_tiles % 8 == 0. */
+#define MSR3D_WGRAD_HALF_SLOT_FLOATS (128 * 128 + 128)
+int msr3d_wgrad_split_halves(int n, const msr3d_wgrad_problem_t *problems, const int *tile_prefix, int total_tiles,
+                             float *workspace, long long workspace_floats, int *sync, msr3d_stream_t stream);
 
 /* dW (n_out, k_in) (+)= dy^T x over M rows for TALL operands (the SharedMLP weight gradients of an unfrozen
  * backbone: up to ~10^6 rows), the arithmetic and tile kernel of msr3d_wgrad_split: the rows are cut into up to

@@ -64,16 +64,32 @@ __device__ __forceinline__ int frag_slot(int j, int g) { return (4 * (j & 3) + (
 // x <- max(gamma (x - mean) rstd + beta, 0) per column, applied by the loaders before the split (xpro = [gamma | beta |
 // mean | rstd], k_in floats each) -- the normalised activation is never written (hipops._BNReLULinear).
 constexpr int NMULT = 8, NLOAD = 8, NTHREADS = (NMULT + NLOAD) * 64;
-template <bool OVERWRITE, bool FOLD = false, bool XPRO = false>
+// HALVES (msr3d_wgrad_split_halves): a tile's reduction is cut in two units of whole slab pairs so that the ~1.4
+// tiles per CU of a step spread evenly (360 one-per-CU tiles = two rounds, the second 41 % full).  A unit takes a
+// ticket when it STARTS: the first starter (role 0) parks its accumulators in the tile's workspace slot and raises a
+// flag, the second (role 1) adds  first-half + second-half  in that fixed order -- whichever of them it is -- onto dW:
+// bit-reproducible, no float atomics; the flag's owner is resident when anyone waits for it.
+struct Half {
+  int s0, s1;               // slab range [s0, s1), both even
+  int role;                 // -1: whole reduction, 0: park the partial, 1: finish
+  int second;               // this unit holds the reduction's second half
+  float *ws;                // the tile's slot: 128 x 128 accumulator image + 128 column sums
+  int *flag;                // raised by role 0 after its image is visible; cleared by role 1
+};
+constexpr int kHalfSlot = MSR3D_WGRAD_HALF_SLOT_FLOATS;      // floats per tile slot: image + column sums
+static_assert(kHalfSlot == TN * TK + TN, "slot size");
+
+template <bool OVERWRITE, bool FOLD = false, bool XPRO = false, bool HALVES = false>
 __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, unsigned char *smem, int fold_rows = 0,
-                                           int fold_mb = 0, const float *xpro = nullptr) {
+                                           int fold_mb = 0, const float *xpro = nullptr, Half hf = Half{0, 0, -1, 0, nullptr, nullptr}) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n0 = ntile * TN, k0 = ktile * TK;
   const int M = pr.M;
   // slabs of 32 tokens, padded to an even count: a slab past M reads zeros (out-of-range buffer loads) and
   // adds nothing, and the loader's loop body stays straight-line (see there)
-  const int nslab = ((M + 63) >> 6) << 1;
+  const int s_lo = HALVES ? hf.s0 : 0;
+  const int nslab = HALVES ? hf.s1 : ((M + 63) >> 6) << 1;
   WG_STAMP(0);
 
   if (wave >= NMULT) {
@@ -168,9 +184,9 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
       };
       // Two slabs in flight per thread, fetched unconditionally (past the end: zeros).
       Slab v0, v1;
-      fetch(v0, 0);
-      fetch(v1, 1);
-      for (int s = 0; s < nslab; s += 2) {
+      fetch(v0, s_lo);
+      fetch(v1, s_lo + 1);
+      for (int s = s_lo; s < nslab; s += 2) {
         stash(v0, 0);
         fetch(v0, s + 2);
         { const unsigned long long c0_ = WG_CLOCK(); __syncthreads(); tw += WG_CLOCK() - c0_; }   // slab s is in stage 0
@@ -191,7 +207,21 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
     __syncthreads();
     if (pr.db && ktile == 0 && lw < 2) {
       const int c = lw * 64 + lane;
-      if (n0 + c < pr.n_out) pr.db[n0 + c] += (red[c] + red[TN + c]) + (red[2 * TN + c] + red[3 * TN + c]);
+      float t = (red[c] + red[TN + c]) + (red[2 * TN + c] + red[3 * TN + c]);
+      if (HALVES && hf.role == 0) {
+        hf.ws[TN * TK + c] = t;
+      } else {
+        if (HALVES && hf.role == 1) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          const float o = hf.ws[TN * TK + c];
+          t = hf.second ? o + t : t + o;           // first half + second half
+        }
+        if (n0 + c < pr.n_out) pr.db[n0 + c] += t;
+      }
+    }
+    if (HALVES) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                             // (the hand-over barrier: see the multipliers' tail)
     }
   } else {
     // ------------------------------------------------------------------ multiplier: wave (wr, wc) owns
@@ -205,7 +235,7 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
       for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     unsigned long long tw = 0;
     (void)tw;
-    for (int s = 0; s < nslab; ++s) {
+    for (int s = s_lo; s < nslab; ++s) {
       { const unsigned long long c0_ = WG_CLOCK(); __syncthreads(); tw += WG_CLOCK() - c0_; }
 #ifdef WG_ABLATE_MMA
       continue;
@@ -241,25 +271,61 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
     }
     WG_STAMP(5);
     WG_PUT(1, tw);
+    if (HALVES && hf.role == 1) {
+      // the other half's image must be there: its owner took its ticket before this unit did, so it is running (or
+      // done) -- one lane polls, everyone else waits at the barrier below
+      if (tid == 0)
+        while (__hip_atomic_load(hf.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+    }
     __syncthreads();
     __syncthreads();
+    if (HALVES && hf.role == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     // D[n][k]: lane (j = k column, g): rows n = 4 g + r.  dW holds the value to add to; this workgroup is
     // the tile's only writer.
     const int j = lane & 15, g = lane >> 4;
+    if (HALVES && hf.role == 0) {
+      // park the accumulators: image[(wave, a, b)][lane] float4 -- plain 16-byte stores (4-byte device-coherent ones
+      // are partial-line writes at the memory side: the first version of this hand-over cost 40 us a launch); the
+      // release fence below writes the L2 lines back before the flag goes up
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int kk = FOLD ? 32 * (wc & 1) + 16 * b + j : k0 + 32 * wc + 16 * b + j;
+        for (int b = 0; b < 2; ++b)
+          *reinterpret_cast<f32x4 *>(hf.ws + (((wave * 4 + a) * 2 + b) * 64 + lane) * 4) = acc[a][b];
+    } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int n = FOLD ? 16 * a + 4 * g + r : n0 + 64 * wr + 16 * a + 4 * g + r;
-          if (n < pr.n_out && kk < pr.k_in && (!FOLD || (wr == (wc >> 1) && (wr == 0 || fold_mb > 0)))) {
-            float *d = pr.dW + (FOLD ? (size_t)wr * pr.n_out * pr.k_in : 0) + (size_t)n * pr.ldw + kk;
-            *d = OVERWRITE ? acc[a][b][r] : *d + acc[a][b][r];
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          if (HALVES && hf.role == 1) {
+            const f32x4 o = *reinterpret_cast<const f32x4 *>(hf.ws + (((wave * 4 + a) * 2 + b) * 64 + lane) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              acc[a][b][r] = hf.second ? o[r] + acc[a][b][r] : acc[a][b][r] + o[r];     // first half + second half
+          }
+          const int kk = FOLD ? 32 * (wc & 1) + 16 * b + j : k0 + 32 * wc + 16 * b + j;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n = FOLD ? 16 * a + 4 * g + r : n0 + 64 * wr + 16 * a + 4 * g + r;
+            if (n < pr.n_out && kk < pr.k_in && (!FOLD || (wr == (wc >> 1) && (wr == 0 || fold_mb > 0)))) {
+              float *d = pr.dW + (FOLD ? (size_t)wr * pr.n_out * pr.k_in : 0) + (size_t)n * pr.ldw + kk;
+              *d = OVERWRITE ? acc[a][b][r] : *d + acc[a][b][r];
+            }
           }
         }
+    }
+    if (HALVES) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                             // every wave's image stores (loaders: column sums) have left the CU
+      if (tid == 0) {
+        if (hf.role == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          __hip_atomic_store(hf.flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (hf.role == 1) {
+          __hip_atomic_store(hf.flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // clean for the next launch
+        }
       }
+    }
   }
   WG_STAMP(6);
 }
@@ -282,6 +348,52 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_split_kernel(int nprob, const 
   const int nkt = (pr.k_in + TK - 1) / TK;
   if (local >= ((pr.n_out + TN - 1) / TN) * nkt) return;
   wgrad_tile<false>(pr, local / nkt, local % nkt, smem);
+}
+
+// The same tiles as wgrad_split_kernel, each as TWO units (gridDim.x = 2 x padded tiles): workgroups [0, T) hold the
+// first halves, [T, 2 T) the second halves -- T is a multiple of 8, so both halves of a tile run on one XCD
+// (workgroup b -> XCD b % 8: speed only) and the parked image travels through that XCD's L2.
+// sync: [T] tickets | [T] flags (all zero between launches); ws: T slots of kHalfSlot floats.
+__global__ __launch_bounds__(NTHREADS) void wgrad_halves_kernel(int nprob, const WP *__restrict__ probs,
+                                                                const int *__restrict__ prefix, float *__restrict__ ws,
+                                                                int *__restrict__ sync) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int role_s;
+  const int T = gridDim.x >> 1;
+  const int second = blockIdx.x >= T ? 1 : 0;
+  const int t = blockIdx.x - second * T;
+  int lo = 0, hi = nprob - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (prefix[mid] <= t) lo = mid; else hi = mid - 1;
+  }
+  const WP pr = probs[lo];
+  const int lb = t - prefix[lo], nb = prefix[lo + 1] - prefix[lo];
+  const int local = (lb & 7) * (nb >> 3) + (lb >> 3);
+  const int nkt = (pr.k_in + TK - 1) / TK;
+  if (local >= ((pr.n_out + TN - 1) / TN) * nkt) return;
+  const int nslab = ((pr.M + 63) >> 6) << 1;
+  const int cut = ((nslab >> 1) + 1) & ~1;            // whole slab pairs: 30 slabs -> 16 + 14
+  Half hf;
+  hf.second = second;
+  hf.s0 = second ? cut : 0;
+  hf.s1 = second ? nslab : cut;
+  hf.ws = ws + (size_t)t * kHalfSlot;
+  hf.flag = sync + T + t;
+  if (cut >= nslab) {                                  // a reduction of one slab pair is not cut
+    if (second) return;
+    hf.s1 = nslab;
+    hf.role = -1;
+  } else {
+    if (threadIdx.x == 0) {
+      const int k = __hip_atomic_fetch_add(sync + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (k == 1) __hip_atomic_store(sync + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (both tickets taken)
+      role_s = k;
+    }
+    __syncthreads();
+    hf.role = role_s;
+  }
+  wgrad_tile<false, false, false, true>(pr, local / nkt, local % nkt, smem, 0, 0, nullptr, hf);
 }
 
 // TALL problems (an unfrozen backbone's SharedMLP layers: dW (<= 256 x <= 256) over 10^5 .. 10^6 rows): the rows are
@@ -361,6 +473,21 @@ extern "C" int msr3d_wgrad_split(int n, const msr3d_wgrad_problem_t *problems, c
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (attr != hipSuccess) return (int)attr;
   wgrad_split_kernel<<<total_tiles, NTHREADS, LDS_BYTES, (hipStream_t)stream>>>(n, problems, tile_prefix);
+  return (int)hipGetLastError();
+}
+
+extern "C" int msr3d_wgrad_split_halves(int n, const msr3d_wgrad_problem_t *problems, const int *tile_prefix,
+                                        int total_tiles, float *workspace, long long workspace_floats, int *sync,
+                                        msr3d_stream_t stream) {
+  if (n < 0 || total_tiles < 0) return MSR3D_EINVAL;
+  if (n == 0 || total_tiles == 0) return 0;
+  if (!problems || !tile_prefix || !workspace || !sync || (total_tiles & 7)) return MSR3D_EINVAL;
+  if (workspace_floats < (long long)total_tiles * MSR3D_WGRAD_HALF_SLOT_FLOATS) return MSR3D_EINVAL;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_halves_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (attr != hipSuccess) return (int)attr;
+  wgrad_halves_kernel<<<2 * total_tiles, NTHREADS, LDS_BYTES, (hipStream_t)stream>>>(n, problems, tile_prefix, workspace,
+                                                                                    sync);
   return (int)hipGetLastError();
 }
 

@@ -8,6 +8,7 @@ every matrix is packed twice (plain and transposed), the packed [q|k|v|cond] pro
 launch from the flat parameter buffer; the packs are valid until the next optimiser step.
 """
 import ctypes
+import os
 
 import torch
 
@@ -80,6 +81,9 @@ def head_segments(h, dh=32, d=256, sd1=6):
     return [(0, dh, h * dh), (dh, dh, d + h * dh), (2 * dh, dh, 2 * d + h * dh), (3 * dh, sd1, 3 * d + h * sd1)]
 
 
+HALF_SLOT_FLOATS = 128 * 128 + 128      # MSR3D_WGRAD_HALF_SLOT_FLOATS
+
+
 class WgradTable:
     """The problems of one msr3d_wgrad_split launch, in device memory; pointers that may move between
     calls (the upstream gradient, the object features) are patched through set_ptr()."""
@@ -93,6 +97,12 @@ class WgradTable:
         self._dirty = True
         self._pin = None
         self._ev = None
+        # MSR3D_WGRAD_HALVES=1: every tile's reduction as two units with a ticket hand-over (msr3d_wgrad_split_halves).
+        # Built to remove the second, 41 %-full round of the 360 one-per-CU tiles; measured SLOWER in the step (1.306 vs
+        # 1.290 ms: two pipeline fills, the parked 64 KB image and the release / acquire fences per tile cost more than the
+        # tail they remove), so the default stays one workgroup per tile.  Kept, tested, opt-in.
+        self.halves = os.environ.get("MSR3D_WGRAD_HALVES", "0") == "1"
+        self._ws = self._sync = None
 
     def add(self, dy, ldy, n_out, x, ldx, k_in, M, dW, ldw, db):
         p = WgradProblem()
@@ -134,6 +144,17 @@ class WgradTable:
                 self._ev = torch.cuda.Event()
                 self._ev.record()
             self._dirty = False
+        if self.halves:
+            # every tile's token reduction as two units (2 x tiles workgroups): ~1.4 tiles per CU spread evenly
+            # instead of two rounds with a 41 %-full second one; partial hand-over through `_ws`, tickets in `_sync`
+            if self._ws is None:
+                self._ws = torch.empty(self.prefix[-1] * HALF_SLOT_FLOATS, dtype=torch.float32, device=self.device)
+                self._sync = torch.zeros(2 * self.prefix[-1], dtype=torch.int32, device=self.device)
+            rc = _lib.load().msr3d_wgrad_split_halves(len(self.probs), _vp(self._table.data_ptr()), _vp(self._pfx.data_ptr()),
+                                                      self.prefix[-1], _vp(self._ws.data_ptr()), self._ws.numel(),
+                                                      _vp(self._sync.data_ptr()), stream)
+            _lib.check(rc, "msr3d_wgrad_split_halves")
+            return
         rc = _lib.load().msr3d_wgrad_split(len(self.probs), _vp(self._table.data_ptr()), _vp(self._pfx.data_ptr()),
                                            self.prefix[-1], stream)
         _lib.check(rc, "msr3d_wgrad_split")

@@ -65,8 +65,10 @@ def test_split_pack_matches_the_exact_split_bit_for_bit():
     assert np.max(np.abs(back - w) / np.abs(w)) < 2.0 ** -23
 
 
+@pytest.mark.parametrize("halves", [False, True])
 @pytest.mark.parametrize("M,n_out,k_in", [(960, 256, 2048), (976, 816, 256), (150, 256, 63), (37, 256, 3), (960, 4096, 256)])
-def test_wgrad_split_vs_float64(M, n_out, k_in):
+def test_wgrad_split_vs_float64(M, n_out, k_in, halves):
+    """halves: msr3d_wgrad_split_halves -- two units per tile, ticket hand-over of the first starter's partial."""
     from msr3d_amd import _lib
     from msr3d_amd.scene_blocks import WgradTable
     torch.manual_seed(M + n_out)
@@ -77,6 +79,7 @@ def test_wgrad_split_vs_float64(M, n_out, k_in):
     db0 = torch.randn(n_out, device="cuda")
     dW, db = dW0.clone(), db0.clone()
     t = WgradTable(dy.device)
+    t.halves = halves
     t.add(dy.data_ptr(), n_out, n_out, x.data_ptr(), xw.stride(0), k_in, M, dW.data_ptr(), k_in, db.data_ptr())
     t.launch(_lib.current_stream_ptr(dy.device))
     torch.cuda.synchronize()
