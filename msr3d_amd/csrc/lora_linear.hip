@@ -519,6 +519,91 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(int M, int C, const unsi
       atomicAdd(out + (transpose_out ? (size_t)(c0 + j) * R + r : (size_t)r * C + c0 + j), acc[r][j] * scale);
 }
 
+// The same reduction on the matrix pipe (round 4; the workspace path).  D[c][r] = sum_m Q[m][c] P[m][r] contracts over
+// the ROW index of both operands, so an MFMA fragment (8 consecutive tokens of one column) is a strided gather: a
+// workgroup stages 64 tokens x 256 columns of Q (and the tokens' R values of P) row-major in LDS with coalesced 16-byte
+// loads -- all of a pass's loads in flight together -- and each wave gathers its fragments with eight 2-byte LDS reads
+// (32 contiguous bytes per 16-lane row group).  4 waves x 64 columns; one v_mfma_f32_16x16x32_bf16 per (column tile,
+// r tile, 32 tokens).  The arithmetic is ~20 k MFMAs per call: the kernel is bound by reading Q once.  Round 3's VALU
+// kernel (a lane = 8 columns x R accumulators, P broadcast from LDS) spent 28 us per 2304 x 4096 call on 128
+// workgroups; the 14 calls of a decoder layer were 14 % of its forward + backward.
+constexpr int kGQ = 256 + 8;       // LDS pitch of a staged Q row, bf16 units (528 B: 16-byte aligned)
+template <int R>
+__global__ __launch_bounds__(256) void lora_grad_mfma_kernel(int M, int C, const unsigned short *__restrict__ P, int ldp,
+                                                             const unsigned short *__restrict__ Q, int ldq,
+                                                             float *__restrict__ ws, int per) {
+  constexpr int RT = R / 16;
+  constexpr int GP = R + 2;                            // LDS pitch of a staged P row (36 / 68 B: 4-byte aligned)
+  __shared__ __attribute__((aligned(16))) unsigned short qs[64 * kGQ];
+  __shared__ __attribute__((aligned(16))) unsigned short ps[64 * GP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int cb = blockIdx.x * 256;
+  const int mb = blockIdx.y * per, me = min(M, mb + per);
+  f32x4 acc[4][RT];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int u = 0; u < RT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // staging roles: Q -- thread t covers 16 bytes (8 columns) of row t / 32 + 8 j; P -- R / 8 chunks of 16 bytes per row
+  const int qrow = tid >> 5, qc = (tid & 31) * 8;
+  const bool qlive = cb + qc < C;                      // (C % 8 == 0: a chunk is inside or outside)
+  constexpr int PCH = R / 8;                           // 16-byte chunks per P row
+  const int prow = tid / PCH, pc = (tid % PCH) * 8;
+  uint4 qv[8], pv;
+  auto fetch = [&](int m0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int m = m0 + qrow + 8 * j;
+      qv[j] = (qlive && m < me) ? *reinterpret_cast<const uint4 *>(Q + (size_t)m * ldq + cb + qc) : make_uint4(0, 0, 0, 0);
+    }
+    const int m = m0 + prow;
+    pv = (prow < 64 && m < me) ? *reinterpret_cast<const uint4 *>(P + (size_t)m * ldp + pc) : make_uint4(0, 0, 0, 0);
+  };
+  fetch(mb);
+  for (int m0 = mb; m0 < me; m0 += 64) {
+    __syncthreads();                                   // the previous pass's fragments have been read
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4 *>(qs + (qrow + 8 * j) * kGQ + qc) = qv[j];
+    if (prow < 64) {
+      unsigned *d = reinterpret_cast<unsigned *>(ps + prow * GP + pc);
+      d[0] = pv.x; d[1] = pv.y; d[2] = pv.z; d[3] = pv.w;
+    }
+    __syncthreads();
+    if (m0 + 64 < me) fetch(m0 + 64);                  // the next pass's loads fly under this pass's gathers
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      const int tk = 32 * sl + 8 * g;                  // this lane's eight tokens
+      bf16x8 fb[RT];
+#pragma unroll
+      for (int u = 0; u < RT; ++u) {
+        union { unsigned short h[8]; bf16x8 v; } w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w.h[e] = ps[(tk + e) * GP + 16 * u + i];
+        fb[u] = w.v;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        union { unsigned short h[8]; bf16x8 v; } w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w.h[e] = qs[(tk + e) * kGQ + wave * 64 + 16 * t + i];
+#pragma unroll
+        for (int u = 0; u < RT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, fb[u], acc[t][u], 0, 0, 0);
+      }
+    }
+  }
+  // D[c][r]: lane (i, g) of tile (t, u) holds columns c = 16 t + 4 g + q (q = 0..3) of r = 16 u + i
+  float *w = ws + (size_t)blockIdx.y * R * C;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int c = cb + wave * 64 + 16 * t + 4 * g;
+    if (c >= C) continue;                              // (C % 4 == 0)
+#pragma unroll
+    for (int u = 0; u < RT; ++u)
+      *reinterpret_cast<float4 *>(w + (size_t)(16 * u + i) * C + c) = make_float4(acc[t][u][0], acc[t][u][1], acc[t][u][2], acc[t][u][3]);
+  }
+}
+
 // out (+)= scale * sum over the chunks' partials, in chunk order; thread = 4 adjacent columns of one r
 __global__ __launch_bounds__(256) void lora_grad_reduce_kernel(int R, int C, int chunks, const float *__restrict__ ws,
                                                                float *__restrict__ out, int transpose_out, float scale,
@@ -746,18 +831,34 @@ int msr3d_lora_grad(int M, int R, int C, const void *P, int ldp, const void *Q, 
   if ((C % cpl) || (C % 4) || (ldq % cpl) || (reinterpret_cast<uintptr_t>(Q) & (2 * cpl - 1))) return MSR3D_EINVAL;
   if (workspace && ((reinterpret_cast<uintptr_t>(workspace) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u)))
     return MSR3D_EINVAL;
-  int chunks = (M + 31) / 32;
-  const int cap = workspace ? kGradChunks : kGradChunksAtomic;
-  if (chunks > cap) chunks = cap;
-  if (workspace && workspace_floats < (long long)chunks * R * C) return MSR3D_EINVAL;
-  dim3 grid((C + 256 * cpl - 1) / (256 * cpl), chunks);
   hipStream_t st = (hipStream_t)stream;
-  if (R == 16)
-    lora_grad_kernel<16><<<grid, 256, 0, st>>>(M, C, (const unsigned short *)P, ldp, (const unsigned short *)Q, ldq,
-                                               out, transpose_out, scale, workspace);
-  else
-    lora_grad_kernel<32><<<grid, 256, 0, st>>>(M, C, (const unsigned short *)P, ldp, (const unsigned short *)Q, ldq,
-                                               out, transpose_out, scale, workspace);
+  int chunks;
+  if (workspace && (C % 8) == 0 && (ldq % 8) == 0 && (ldp % 8) == 0 && al16(P) && al16(Q)) {
+    // matrix-pipe kernel: chunks of whole 64-token passes, at most kGradChunks of them
+    int per = (M + kGradChunks - 1) / kGradChunks;
+    per = (per + 63) / 64 * 64;
+    chunks = (M + per - 1) / per;
+    if (workspace_floats < (long long)chunks * R * C) return MSR3D_EINVAL;
+    dim3 grid((C + 255) / 256, chunks);
+    if (R == 16)
+      lora_grad_mfma_kernel<16><<<grid, 256, 0, st>>>(M, C, (const unsigned short *)P, ldp, (const unsigned short *)Q, ldq,
+                                                      workspace, per);
+    else
+      lora_grad_mfma_kernel<32><<<grid, 256, 0, st>>>(M, C, (const unsigned short *)P, ldp, (const unsigned short *)Q, ldq,
+                                                      workspace, per);
+  } else {
+    chunks = (M + 31) / 32;
+    const int cap = workspace ? kGradChunks : kGradChunksAtomic;
+    if (chunks > cap) chunks = cap;
+    if (workspace && workspace_floats < (long long)chunks * R * C) return MSR3D_EINVAL;
+    dim3 grid((C + 256 * cpl - 1) / (256 * cpl), chunks);
+    if (R == 16)
+      lora_grad_kernel<16><<<grid, 256, 0, st>>>(M, C, (const unsigned short *)P, ldp, (const unsigned short *)Q, ldq,
+                                                 out, transpose_out, scale, workspace);
+    else
+      lora_grad_kernel<32><<<grid, 256, 0, st>>>(M, C, (const unsigned short *)P, ldp, (const unsigned short *)Q, ldq,
+                                                 out, transpose_out, scale, workspace);
+  }
   if (workspace)
     lora_grad_reduce_kernel<<<(R * (C / 4) + 255) / 256, 256, 0, st>>>(R, C, chunks, workspace, out, transpose_out, scale,
                                                                        accumulate);

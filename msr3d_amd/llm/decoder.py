@@ -74,19 +74,24 @@ class _RMSNormFn(torch.autograd.Function):
 
 
 class _RopeFn(torch.autograd.Function):
+    """Rotary embedding IN PLACE on a projection's output (nothing else reads that tensor: _LoRAFn saves its inputs,
+    not its output), and in place on the incoming gradient in backward: no copies (round 3 cloned both)."""
+
     @staticmethod
-    def forward(ctx, x, cos, sin):          # x (B, T, H, D) bf16
-        x = x.contiguous().clone()
+    def forward(ctx, x, cos, sin):          # x (B, T, H, D) bf16, contiguous
+        if not x.is_contiguous():
+            raise RuntimeError("_RopeFn: contiguous (B, T, H, D) expected")
         B, T, H, D = x.shape
         with torch.cuda.device(x.device):
             _call("msr3d_rope_inplace", B, T, H, D, _p(x), _p(cos), _p(sin), 0, _st(x.device))
+        ctx.mark_dirty(x)
         ctx.save_for_backward(cos, sin)
         return x
 
     @staticmethod
     def backward(ctx, g):
         cos, sin = ctx.saved_tensors
-        g = g.contiguous().clone()
+        g = g.contiguous()                  # (the attention backward hands over fresh contiguous tensors: no copy)
         B, T, H, D = g.shape
         with torch.cuda.device(g.device):
             _call("msr3d_rope_inplace", B, T, H, D, _p(g), _p(cos), _p(sin), 1, _st(g.device))

@@ -70,7 +70,7 @@ class _LoRAFn(torch.autograd.Function):
         ctx.save_for_backward(x2, u, lora_A, lora_B)
         ctx.mod = mod
         ctx.shape = x.shape
-        return y.view(*x.shape[:-1], N)
+        return y            # (M, N): the caller reshapes -- a view made in here could not be updated in place (RoPE)
 
     @staticmethod
     def backward(ctx, dy):
@@ -145,29 +145,24 @@ class LoRALinear(nn.Module):
         # Inside a graph capture the copies are ALWAYS rebuilt (into the same storage): a replayed optimiser step
         # changes A / B without running this host code again, so the rebuild has to be part of the graph.
         capturing = forward and A.is_cuda and torch.cuda.is_current_stream_capturing()     # (backward reuses forward's)
-        if capturing and getattr(self, "_shadow", None) is not None:
-            a_pad, b2, bt_pad, at2 = self._shadow
-            r = self.r
-            with torch.no_grad():
+        if getattr(self, "_shadow_key", None) == "captured" and not forward and A.is_cuda and \
+                torch.cuda.is_current_stream_capturing():
+            return self._shadow                 # backward of the captured step: forward's copies
+        if capturing or getattr(self, "_shadow_key", None) != key:
+            r, K, N, dev = self.r, self.in_features, self.out_features, A.device
+            sh = getattr(self, "_shadow", None)
+            if sh is None or sh[0].device != dev:
+                # allocated once: the padding columns r..63 of b2 / at2 are zero and stay zero
+                sh = (torch.empty((r, K), dtype=torch.bfloat16, device=dev), torch.zeros((N, PAD_R), dtype=torch.bfloat16, device=dev),
+                      torch.empty((r, N), dtype=torch.bfloat16, device=dev), torch.zeros((K, PAD_R), dtype=torch.bfloat16, device=dev))
+                self._shadow = sh
+            a_pad, b2, bt_pad, at2 = sh
+            with torch.no_grad():               # four conversion launches per rebuild (it was nine ops with fresh buffers)
                 a_pad.copy_(A)
                 b2[:, :r].copy_(Bw)
                 bt_pad.copy_(Bw.t())
                 at2[:, :r].copy_(A.t())
-            self._shadow_key = "captured"       # (whatever eager call follows rebuilds as well)
-            return self._shadow
-        if getattr(self, "_shadow_key", None) == "captured" and A.is_cuda and torch.cuda.is_current_stream_capturing():
-            return self._shadow                 # backward of the captured step: forward's copies
-        if getattr(self, "_shadow_key", None) != key:
-            r, K, N, dev = self.r, self.in_features, self.out_features, A.device
-            with torch.no_grad():
-                a_pad = A.detach().to(torch.bfloat16).contiguous()
-                b2 = torch.zeros((N, PAD_R), dtype=torch.bfloat16, device=dev)
-                b2[:, :r] = Bw
-                bt_pad = Bw.detach().t().to(torch.bfloat16).contiguous()
-                at2 = torch.zeros((K, PAD_R), dtype=torch.bfloat16, device=dev)
-                at2[:, :r] = A.t()
-            self._shadow = (a_pad, b2, bt_pad, at2)
-            self._shadow_key = key
+            self._shadow_key = "captured" if capturing else key
         return self._shadow
 
     def invalidate_shadows(self):
@@ -196,4 +191,5 @@ class LoRALinear(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("LoRALinear runs on the GPU only (no CPU fallback)")
         self._sync_weight_t()
-        return _LoRAFn.apply(x.to(torch.bfloat16), self.lora_A.weight, self.lora_B.weight, self)
+        y = _LoRAFn.apply(x.to(torch.bfloat16), self.lora_A.weight, self.lora_B.weight, self)
+        return y.view(*x.shape[:-1], self.out_features)
