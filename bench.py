@@ -113,6 +113,9 @@ def parse():
                     "shapes, random bf16 weights) -> head -> per-sequence CE -> backward through the language model into the "
                     "prompter -> ONE flat gradient buffer (bucketed exchange from the backward hooks) -> clip + AdamW; "
                     "--batch sequences (default 4 here) x --seq-len tokens per GPU")
+    ap.add_argument("--llm-fp8", action="store_true", help="with --full-step / --llm-layer / --llm-stack: the decoder layers' frozen "
+                    "projections on OCP e4m3 operands (per-output-channel weight scales, per-token activation scales, MX matrix "
+                    "instruction; LoRA pair and accumulators bf16 / fp32) -- labelled in the line's dtype")
     ap.add_argument("--llm-layers", type=int, default=32, help="decoder layers of --full-step (32 = Vicuna-7B)")
     ap.add_argument("--seq-len", type=int, default=576, help="tokens per sequence of --full-step (prompt incl. 60 scene "
                     "tokens + answer; multiple of 64)")
@@ -275,7 +278,7 @@ def llm_layer_line(args):
     dev = torch.device("cuda", 0)
     Bq, T, Hd, NH, FF = 4, 576, 4096, 32, 11008        # configs/msr3d.yaml:164 batch 4; 576 = scene tokens + prompt + answer
     torch.manual_seed(0)
-    layer = LoRALlamaDecoderLayer(Hd, NH, FF, r=16, lora_alpha=16, device=dev)
+    layer = LoRALlamaDecoderLayer(Hd, NH, FF, r=16, lora_alpha=16, device=dev, base="fp8" if args.llm_fp8 else "bf16")
     with torch.no_grad():
         for grp in (layer.self_attn, layer.mlp):
             for m in grp.values():
@@ -310,7 +313,8 @@ def llm_layer_line(args):
     print(json.dumps({
         "metric": "SECONDARY: LoRA-Llama decoder layer fwd+bwd (Vicuna-7B shape), tokens/s per layer",
         "value": M / (ms * 1e-3), "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 2),
-        "ms_per_step": ms, "wall_ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "dtype": "bf16",
+        "ms_per_step": ms, "wall_ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True,
+        "dtype": "bf16; frozen projections on OCP e4m3 operands" if args.llm_fp8 else "bf16",
         "data": "synthetic (random bf16 weights; no checkpoint on the box)",
         "config": {"workload": "one decoder layer: hidden 4096, 32 heads, MLP 11008, LoRA r=16 alpha=16 on q/k/v/o/gate/up/down, "
                                "4 sequences x 576 tokens, left-padded mask, eager (host-issued) launches"},
@@ -352,7 +356,7 @@ def full_step_line(args):
     torch.manual_seed(1234)
     cfg = AttrDict({"prompter": default_prompter_cfg(situation_type=args.situation_type), "llm_hidden_size": Hd,
                     "llm": {"num_layers": L, "hidden_size": Hd, "num_heads": NH, "intermediate_size": FF, "vocab_size": V,
-                            "lora": {"rank": 16, "alpha": 16}},
+                            "lora": {"rank": 16, "alpha": 16}, "base": "fp8" if args.llm_fp8 else "bf16"},
                     "device": str(dev), "model": {"name": "MSR3DFullStep"}})
     model = build_model(cfg).to(dev).train()
     net = model.llm_model
@@ -424,7 +428,9 @@ def full_step_line(args):
             "warmup": max(args.warmup, 2), "ms_per_step": ms,
             "ms_per_step_percentiles": {"p10": per[int(0.1 * len(per))], "p50": per[len(per) // 2], "p90": per[min(len(per) - 1, int(0.9 * len(per)))]},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "hot path f32 (bf16x3 split MFMA); language model bf16 storage, fp32 accumulate; LoRA / optimiser fp32",
+            "dtype": "hot path f32 (bf16x3 split MFMA); language model bf16 storage, fp32 accumulate; LoRA / optimiser fp32" +
+                     ("; frozen projections of the decoder layers: OCP e4m3 operands (forward and dx), per-channel / per-token scales"
+                      if args.llm_fp8 else ""),
             "data": "synthetic (random bf16 LLM weights: no checkpoint on the box; synthetic scenes and token ids)",
             "config": {"workload": "configs/msr3d.yaml full step: frozen PointNet++ -> OSE3DSituation -> llm_proj -> scatter into "
                                    f"inputs_embeds -> {L} LoRA-Llama layers (hidden {Hd}, {NH} heads, MLP {FF}, LoRA r=16 on "
@@ -465,7 +471,7 @@ def llm_stack_line(args):
         dist.init_process_group("nccl", device_id=dev)
     L, Bq, T, Hd, NH, FF, V = args.llm_stack, 4, 576, 4096, 32, 11008, 32000
     torch.manual_seed(0)
-    net = LoRALlamaStack(L, Hd, NH, FF, V, r=16, lora_alpha=16, device=dev)
+    net = LoRALlamaStack(L, Hd, NH, FF, V, r=16, lora_alpha=16, device=dev, base="fp8" if args.llm_fp8 else "bf16")
     with torch.no_grad():
         for layer in net.layers:
             for grp in (layer.self_attn, layer.mlp):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 14
+#define MSR3D_ABI_VERSION 15
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -804,6 +804,20 @@ int msr3d_transpose_bf16(int outer, int inner, int rows, int cols, const void *s
  * k-contiguous bf16, K % 32 == 0; C bf16.  (peft's lora_A / lora_B applications, model/msr3d/msr3d.py:103-112.) */
 int msr3d_bf16_gemm_skinny(int M, int N, int K, const void *P, int ldp, const void *Q, int ldq, void *C, int ldc,
                            int zero_to, float scale, msr3d_stream_t stream);
+
+/* fp8 (OCP e4m3) operands for the frozen projections of the LoRA-Llama layers (model/msr3d/msr3d.py:103-112,409-415;
+ * csrc/lora_fp8.hip).
+ * msr3d_quant_rows_fp8: q[m][k] = rne_e4m3(x[m][k] / scale[m]), scale[m] = max_k |x[m][k]| / 448 (1 for a zero row);
+ *   x (M, K) bf16, q (M, K) bytes; K % 8 == 0, K <= 12288.  Used per call for activations / upstream gradients and
+ *   once per checkpoint for the frozen weight (a row = an output channel; both orientations).
+ * msr3d_fp8_gemm_lowrank: C (M, N) bf16 = diag(sp) (Pq Qq^T) diag(sq) + P2 Q2^T with Pq (M, K), Qq (N, K) e4m3
+ *   k-contiguous, their row scales sp (M), sq (N), and the LoRA pair P2 (M, 64), Q2 (N, 64) bf16 zero-padded (both
+ *   NULL: no low-rank term).  K % 128 == 0, N % 4 == 0, M >= 128, N >= 256.  v_mfma_scale_f32_16x16x128_f8f6f4 with
+ *   unit block scales, fp32 accumulate; the LoRA term on the bf16 instruction into the same accumulators. */
+int msr3d_quant_rows_fp8(int M, int K, const void *x, int ldx, void *q, int ldq, float *scale, msr3d_stream_t stream);
+int msr3d_fp8_gemm_lowrank(int M, int N, int K, const void *Pq, int ldp, const float *sp, const void *Qq, int ldq,
+                           const float *sq, const void *P2, int ldp2, const void *Q2, int ldq2, void *C, int ldc,
+                           msr3d_stream_t stream);
 
 /* out (R, C) fp32 -- or its transpose (C, R) -- += scale * sum_m P[m][r] Q[m][c]: the LoRA weight gradients
  * dA = (s dy B)^T x and dB = dy^T (s x A^T) (peft's lora_A / lora_B, model/msr3d/msr3d.py:103-112; R = 16 or 32).

@@ -93,6 +93,9 @@ _SIGNATURES = {
     "msr3d_scene_block": [ctypes.POINTER(SceneBlock), _ptr],
     "msr3d_scene_rows": [ctypes.POINTER(SceneRows), _ptr],
     "msr3d_wgrad_split": [_c_int, _ptr, _ptr, _c_int, _ptr],
+    "msr3d_quant_rows_fp8": [_c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _ptr],
+    "msr3d_fp8_gemm_lowrank": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _c_int, _ptr, _ptr, _c_int, _ptr, _c_int,
+                               _ptr, _c_int, _ptr],
     "msr3d_wgrad_split_halves": [_c_int, _ptr, _ptr, _c_int, _ptr, ctypes.c_longlong, _ptr, _ptr],
     "msr3d_wgrad_rows_split": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _ptr,
                                ctypes.c_longlong, _ptr, _ptr],
@@ -201,7 +204,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string", "msr3d_sqdist_contract"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 14        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 15        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():

@@ -37,6 +37,7 @@ SOURCES = [
     ("panel_gemm.hip", []),
     ("seq_ce.hip", []),
     ("lora_linear.hip", []),
+    ("lora_fp8.hip", []),
     ("llm_layer.hip", []),
     ("prompter_rows.hip", ["-ffp-contract=off"]),
     ("scene_block.hip", []),

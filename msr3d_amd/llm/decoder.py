@@ -206,13 +206,13 @@ class LoRALlamaDecoderLayer(nn.Module):
     msr3d_amd/llm/checkpoint.py maps both ways (load_hf_state_dict, hf_state_dict, peft_adapter_state_dict)."""
 
     def __init__(self, hidden_size=4096, num_heads=32, intermediate_size=11008, r=16, lora_alpha=16, rms_eps=1e-6,
-                 rope_theta=10000.0, device=None):
+                 rope_theta=10000.0, device=None, base="bf16"):
         super().__init__()
         if hidden_size % num_heads or (hidden_size // num_heads) % 64:
             raise ValueError("head size must be a multiple of 64")
         self.hidden_size, self.num_heads, self.head_dim = hidden_size, num_heads, hidden_size // num_heads
         self.eps, self.theta = rms_eps, rope_theta
-        mk = lambda i, o: LoRALinear(i, o, r=r, lora_alpha=lora_alpha, device=device)     # noqa: E731
+        mk = lambda i, o: LoRALinear(i, o, r=r, lora_alpha=lora_alpha, device=device, base=base)     # noqa: E731
         self.self_attn = nn.ModuleDict(dict(q_proj=mk(hidden_size, hidden_size), k_proj=mk(hidden_size, hidden_size),
                                             v_proj=mk(hidden_size, hidden_size), o_proj=mk(hidden_size, hidden_size)))
         self.mlp = nn.ModuleDict(dict(gate_proj=mk(hidden_size, intermediate_size), up_proj=mk(hidden_size, intermediate_size),

@@ -39,6 +39,39 @@ def _skinny(M, N, K, P, Q, C, ldc, scale, dev):
     _lib.check(rc, "msr3d_bf16_gemm_skinny")
 
 
+def quant_rows_fp8(x2):
+    """x2 (M, K) bf16 contiguous -> (q (M, K) uint8 = OCP e4m3 codes, scale (M,) f32): q = rne(x / scale),
+    scale = max |row| / 448 (msr3d_quant_rows_fp8)."""
+    M, K = x2.shape
+    q = torch.empty((M, K), dtype=torch.uint8, device=x2.device)
+    sc = torch.empty((M,), dtype=torch.float32, device=x2.device)
+    with torch.cuda.device(x2.device):
+        rc = _lib.load().msr3d_quant_rows_fp8(M, K, _p(x2), x2.stride(0), _p(q), K, _p(sc), _lib.current_stream_ptr(x2.device))
+    _lib.check(rc, "msr3d_quant_rows_fp8")
+    return q, sc
+
+
+def _gemm_fp8(M, N, K, Pq, sp, Qq, sq, P2, Q2, C, dev):
+    with torch.cuda.device(dev):
+        rc = _lib.load().msr3d_fp8_gemm_lowrank(M, N, K, _p(Pq), K, _p(sp), _p(Qq), K, _p(sq), _p(P2), PAD_R, _p(Q2), PAD_R,
+                                                _p(C), N, _lib.current_stream_ptr(dev))
+    _lib.check(rc, "msr3d_fp8_gemm_lowrank")
+
+
+def _quant_cached(x, x2):
+    """The e4m3 image of an activation, shared by the projections that read the same tensor (q / k / v, gate / up):
+    cached on the tensor OBJECT the layer handed in (dies with it)."""
+    c = getattr(x, "_msr3d_fp8", None)
+    if c is None or c[2] != x._version:
+        q, sc = quant_rows_fp8(x2)
+        c = (q, sc, x._version)
+        try:
+            x._msr3d_fp8 = c
+        except AttributeError:
+            pass
+    return c[0], c[1]
+
+
 _ws = {}
 
 
@@ -66,7 +99,13 @@ class _LoRAFn(torch.autograd.Function):
         u = torch.empty((M, PAD_R), dtype=torch.bfloat16, device=dev)
         _skinny(M, r, K, x2, a_pad, u, PAD_R, s, dev)
         y = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-        _gemm(M, N, K, PAD_R, x2, K, mod.weight, K, u, PAD_R, b2, PAD_R, y, N, False, 1.0, dev)
+        if mod.base == "fp8" and M >= 128:
+            # frozen W as e4m3 with per-output-channel scales (quantised once), x per token row (per call, shared by the
+            # projections reading the same tensor); the LoRA term rides in bf16 -- csrc/lora_fp8.hip
+            xq, sx = _quant_cached(x, x2)
+            _gemm_fp8(M, N, K, xq, sx, mod.weight_q, mod.weight_scale, u, b2, y, dev)
+        else:
+            _gemm(M, N, K, PAD_R, x2, K, mod.weight, K, u, PAD_R, b2, PAD_R, y, N, False, 1.0, dev)
         ctx.save_for_backward(x2, u, lora_A, lora_B)
         ctx.mod = mod
         ctx.shape = x.shape
@@ -88,7 +127,11 @@ class _LoRAFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.bfloat16, device=dev)
-            _gemm(M, K, N, PAD_R, dy2, N, mod.weight_t, N, v, PAD_R, at2, PAD_R, dx, K, False, 1.0, dev)
+            if mod.base == "fp8" and mod.fp8_backward and M >= 128:
+                dq, sdy = quant_rows_fp8(dy2)              # the upstream gradient, per token row
+                _gemm_fp8(M, K, N, dq, sdy, mod.weight_t_q, mod.weight_t_scale, v, at2, dx, dev)
+            else:
+                _gemm(M, K, N, PAD_R, dy2, N, mod.weight_t, N, v, PAD_R, at2, PAD_R, dx, K, False, 1.0, dev)
             dx = dx.view(ctx.shape)
         lib = _lib.load()
         # On the flat-gradient engine (dp.py) the pair's .grad are views of the flat buffer: the kernels ADD into them
@@ -122,10 +165,20 @@ class LoRALinear(nn.Module):
     update, peft's parameter names (`lora_A.weight (r, K)`, `lora_B.weight (N, r)`) and init
     (A: kaiming-uniform(a = sqrt 5), B: zeros)."""
 
-    def __init__(self, in_features, out_features, r=16, lora_alpha=16, device=None):
+    def __init__(self, in_features, out_features, r=16, lora_alpha=16, device=None, base="bf16", fp8_backward=True):
+        """base = "fp8": the frozen weight is ALSO kept as OCP e4m3 with one scale per output channel, in both
+        orientations (quantised whenever the bf16 weight is written), and forward / dx multiply on the MX fp8 matrix
+        instruction with activations quantised per token row (csrc/lora_fp8.hip); the LoRA pair stays bf16 / fp32.
+        fp8_backward = False keeps dx on the bf16 product."""
         super().__init__()
         if r not in (16, 32) or in_features % 64 or out_features % 64:
             raise ValueError("r in {16, 32}; feature sizes must be multiples of 64")
+        if base not in ("bf16", "fp8"):
+            raise ValueError("base must be 'bf16' or 'fp8'")
+        if base == "fp8" and (in_features % 128 or out_features % 128):
+            raise ValueError("fp8 base weights: feature sizes must be multiples of 128")
+        self.base, self.fp8_backward = base, bool(fp8_backward)
+        self.weight_q = self.weight_scale = self.weight_t_q = self.weight_t_scale = None
         self.in_features, self.out_features, self.r = in_features, out_features, r
         self.scaling = lora_alpha / r
         self.register_buffer("weight", torch.empty((out_features, in_features), dtype=torch.bfloat16, device=device))
@@ -179,6 +232,9 @@ class LoRALinear(nn.Module):
                 if self.weight_t.shape != (w.shape[1], w.shape[0]) or self.weight_t.device != w.device:
                     self.weight_t = torch.empty((w.shape[1], w.shape[0]), dtype=w.dtype, device=w.device)
                 self.weight_t.copy_(w.t())
+                if self.base == "fp8" and w.is_cuda:
+                    self.weight_q, self.weight_scale = quant_rows_fp8(w)
+                    self.weight_t_q, self.weight_t_scale = quant_rows_fp8(self.weight_t)
             self._wt_version = (w._version, w.data_ptr())
 
     @torch.no_grad()

@@ -90,10 +90,12 @@ class LoRALlamaStack(nn.Module):
     msr3d_amd/llm/checkpoint.py::load_hf_state_dict (and save through hf_state_dict / peft_adapter_state_dict)."""
 
     def __init__(self, num_layers, hidden_size=4096, num_heads=32, intermediate_size=11008, vocab_size=32000, r=16,
-                 lora_alpha=16, rms_eps=1e-6, rope_theta=10000.0, device=None):
+                 lora_alpha=16, rms_eps=1e-6, rope_theta=10000.0, device=None, base="bf16"):
+        """base = "fp8": the decoder layers' frozen projections on e4m3 operands (LoRALinear); the head stays bf16."""
         super().__init__()
         self.layers = nn.ModuleList([LoRALlamaDecoderLayer(hidden_size, num_heads, intermediate_size, r, lora_alpha,
-                                                           rms_eps, rope_theta, device=device) for _ in range(num_layers)])
+                                                           rms_eps, rope_theta, device=device, base=base)
+                                     for _ in range(num_layers)])
         self.register_buffer("norm_weight", torch.ones(hidden_size, dtype=torch.bfloat16, device=device))
         self.lm_head = FrozenLinear(hidden_size, vocab_size, device=device)
         self.eps = rms_eps

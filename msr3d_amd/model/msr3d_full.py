@@ -34,7 +34,7 @@ def build_targets(T_in, output_ids, output_mask):
 @MODEL_REGISTRY.register()
 class MSR3DFullStep(MSR3DHotPath):
     """cfg: `prompter`, `llm_hidden_size` as MSR3DHotPath, plus `llm`: {num_layers, hidden_size, num_heads,
-    intermediate_size, vocab_size, lora: {rank, alpha}, rms_eps, rope_theta}, optional `scene_sp_token` and `device`
+    intermediate_size, vocab_size, lora: {rank, alpha}, rms_eps, rope_theta, base: 'bf16' | 'fp8'}, optional `scene_sp_token` and `device`
     (the language model's weights -- 26 GB in both orientations for Vicuna-7B -- are created there directly)."""
 
     def __init__(self, cfg):
@@ -49,7 +49,8 @@ class MSR3DFullStep(MSR3DHotPath):
                                         int(llm.intermediate_size), int(llm.vocab_size),
                                         r=int(lora.get("rank", 16)), lora_alpha=int(lora.get("alpha", 16)),
                                         rms_eps=float(llm.get("rms_eps", 1e-6)),
-                                        rope_theta=float(llm.get("rope_theta", 10000.0)), device=dev)
+                                        rope_theta=float(llm.get("rope_theta", 10000.0)), device=dev,
+                                        base=str(llm.get("base", "bf16")))
         self.register_buffer("embed_tokens", torch.zeros((int(llm.vocab_size), int(llm.hidden_size)),
                                                          dtype=torch.bfloat16, device=dev))
         self.scene_sp_token = int(cfg.get("scene_sp_token", SCENE_SP_TOKEN)) if hasattr(cfg, "get") else SCENE_SP_TOKEN
