@@ -659,13 +659,13 @@ constexpr int kSa3Lds = 3 * k3Plane * 2 + 2 * (k3N1 + k3N2 + k3N3) * 4;
 
 template <int RN, int MT, int NT>
 __device__ __forceinline__ void gemm_split_rolled(const unsigned short *xs, int ldh, int plane, const WStream &wg, int t0,
-                                                  int KS, f32x4 (&acc)[RN][MT], int lane) {
+                                                  int KS, f32x4 (&acc)[RN][MT], int lane, int ws0 = 0) {
   const int j = lane & 15, g = lane >> 4;
   const unsigned short *xp = xs + j * ldh + 8 * g;
   WPiece wa[RN], wb[RN];
   auto fetch = [&](WPiece (&w)[RN], int s) {
 #pragma unroll
-    for (int rn = 0; rn < RN; ++rn) load_piece<NT>(w[rn], wg, s, t0 + rn, lane);
+    for (int rn = 0; rn < RN; ++rn) load_piece<NT>(w[rn], wg, ws0 + s, t0 + rn, lane);     // (ws0: the weights' first slab)
   };
   auto mma = [&](const WPiece (&w)[RN], int s) {
     bf16x8 x[MT][3];
@@ -794,6 +794,136 @@ __global__ __launch_bounds__(256) void sa3_split_kernel(int b, const float *__re
     float gm[RN][MT][4];
     group_reduce<RN, MT, 1>(acc, sc, sh, gm);
     group_finish<RN, MT>(gm, out + (size_t)obj0 * k3N3, k3N3, t0 * 16, groups, lane);
+  }
+}
+
+// ---- level 3, FOUR objects per tile (round 4) ----------------------------------------------------------------------
+// The two-object tile above streams the level's 3.6 MB of split weights past every 32 rows: 480 tiles = 1.7 GB per launch
+// out of L2 (73.8 MB of HBM traffic for 18.7 MB of unique data) in 1.9 rounds of the 256 CUs, matrix pipe 41 % busy.  A
+// 64-row tile halves the stream per object and is ONE round (240 tiles) -- but layer 3's operand (512 wide, three
+// planes, 64 rows) is 203 KB.  So the 512-wide activation never exists as a whole: layer 2 is accumulated entirely in
+// registers (each wave: 4 column tiles of either half), its first half goes to LDS (104 KB), layer 3 runs over that
+// K half into ALL of its accumulators (12 column tiles x 4 row tiles per wave = 192 registers), then the second half
+// takes the buffer's place and layer 3 finishes.  LDS: one 64 x 304 x 3 bf16 buffer (the 288-wide input; 272 pitch for
+// the 256-wide images -- both pitches leave every 16-byte fragment read on its own bank quad) + the affine tables.
+constexpr int k4TM = 64, k4LdIn = k3K0 + kPadH, k4Ld = 256 + kPadH;
+constexpr int k4PlaneIn = k4TM * k4LdIn, k4Plane = k4TM * k4Ld;
+constexpr int kSa3x4Lds = 3 * k4PlaneIn * 2 + 2 * (k3N1 + k3N2 + k3N3) * 4;
+
+__global__ __launch_bounds__(256, 1) void sa3_split4_kernel(int b, const float *__restrict__ xyz, const float *__restrict__ feat,
+                                                            LayerS l1, LayerS l2, LayerS l3, float *__restrict__ out,
+                                                            const unsigned char *__restrict__ valid) {
+  const int obj0 = blockIdx.x * 4;
+  if (valid) {                                               // (any valid object: the others ride along)
+    bool any = false;
+    for (int q = 0; q < 4; ++q) any = any || (obj0 + q < b && valid[obj0 + q]);
+    if (!any) return;
+  }
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  unsigned short *buf = smem;
+  float *aff = reinterpret_cast<float *>(smem + 3 * k4PlaneIn);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  for (int i = tid; i < k3N1; i += 256) { aff[i] = l1.scale[i]; aff[k3N1 + i] = l1.shift[i]; }
+  for (int i = tid; i < k3N2; i += 256) { aff[2 * k3N1 + i] = l2.scale[i]; aff[2 * k3N1 + k3N2 + i] = l2.shift[i]; }
+  for (int i = tid; i < k3N3; i += 256) { aff[2 * (k3N1 + k3N2) + i] = l3.scale[i]; aff[2 * (k3N1 + k3N2) + k3N3 + i] = l3.shift[i]; }
+  const float *sc1 = aff, *sh1 = aff + k3N1, *sc2 = aff + 2 * k3N1, *sh2 = sc2 + k3N2, *sc3 = aff + 2 * (k3N1 + k3N2), *sh3 = sc3 + k3N3;
+  const WStream w1 = make_stream<0>(l1.w, k3K0 * k3N1 * 6, 0, lane);
+  const WStream w2 = make_stream<0>(l2.w, k3N1 * k3N2 * 6, 0, lane);
+  const WStream w3 = make_stream<0>(l3.w, k3N2 * k3N3 * 6, 0, lane);
+  {   // operand: 64 rows x [feat(256), x, y, z, 0 ...]; all loads first, then split + LDS stores
+    constexpr int IT = k4TM * 64 / 256;
+    float4 val[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = tid + it * 256, row = e >> 6, obj = obj0 + (row >> 4);
+      val[it] = obj < b ? *reinterpret_cast<const float4 *>(feat + ((size_t)obj * 16 + (row & 15)) * 256 + (e & 63) * 4)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (tid < k4TM) {
+      const int obj = obj0 + (tid >> 4);
+      if (obj < b) {
+        const float *q = xyz + ((size_t)obj * 16 + (tid & 15)) * 3;
+        px = q[0]; py = q[1]; pz = q[2];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = tid + it * 256;
+      const float v[4] = {val[it].x, val[it].y, val[it].z, val[it].w};
+      uint2 p[3];
+      split4(v, p);
+      unsigned short *d = buf + (e >> 6) * k4LdIn + (e & 63) * 4;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2 *>(d + k * k4PlaneIn) = p[k];
+    }
+    if (tid < k4TM) {
+      const float v[4] = {px, py, pz, 0.f};
+      uint2 p[3];
+      split4(v, p);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        unsigned short *d = buf + k * k4PlaneIn + tid * k4LdIn + 256;
+        *reinterpret_cast<uint2 *>(d) = p[k];
+#pragma unroll
+        for (int c = 4; c < 32; c += 4) *reinterpret_cast<uint2 *>(d + c) = make_uint2(0u, 0u);
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int MT = k4TM / 16;
+  {   // layer 1: 288 -> 256, each wave 4 column tiles
+    f32x4 acc[4][MT];
+    zero_acc(acc);
+    gemm_split_rolled<4, MT, k3N1 / 16>(buf, k4LdIn, k4PlaneIn, w1, wave_u * 4, k3K0 / 32, acc, lane);
+    float4 sc[4], sh[4];
+    load_affine4<4>(sc1, sh1, wave * 64, lane, sc, sh);
+    __syncthreads();                                            // every wave is done reading the operand
+    store_split<4, MT>(acc, sc, sh, buf, k4Ld, k4Plane, wave * 64, lane);
+  }
+  __syncthreads();
+  // layer 2: 256 -> 512, all of it in registers: tiles 4 w .. 4 w + 3 of the first half, 16 + 4 w .. of the second
+  f32x4 acc2b[4][MT];
+  {
+    f32x4 acc2a[4][MT];
+    zero_acc(acc2a);
+    gemm_split_rolled<4, MT, k3N2 / 16>(buf, k4Ld, k4Plane, w2, wave_u * 4, k3N1 / 32, acc2a, lane);
+    zero_acc(acc2b);
+    gemm_split_rolled<4, MT, k3N2 / 16>(buf, k4Ld, k4Plane, w2, 16 + wave_u * 4, k3N1 / 32, acc2b, lane);
+    float4 sc[4], sh[4];
+    load_affine4<4>(sc2, sh2, wave * 64, lane, sc, sh);
+    __syncthreads();                                            // layer 1's image has been read by everyone
+    store_split<4, MT>(acc2a, sc, sh, buf, k4Ld, k4Plane, wave * 64, lane);
+  }
+  __syncthreads();
+  // layer 3 over the first K half (weight slabs 0..7), the wave's 12 column tiles as 6 + 6
+  f32x4 acc3a[6][MT], acc3b[6][MT];
+  zero_acc(acc3a);
+  zero_acc(acc3b);
+  const int t3 = wave_u * 12;
+  gemm_split_rolled<6, MT, k3N3 / 16>(buf, k4Ld, k4Plane, w3, t3, 8, acc3a, lane, 0);
+  gemm_split_rolled<6, MT, k3N3 / 16>(buf, k4Ld, k4Plane, w3, t3 + 6, 8, acc3b, lane, 0);
+  {
+    float4 sc[4], sh[4];
+    load_affine4<4>(sc2, sh2, 256 + wave * 64, lane, sc, sh);
+    __syncthreads();                                            // the first half has been read by everyone
+    store_split<4, MT>(acc2b, sc, sh, buf, k4Ld, k4Plane, wave * 64, lane);
+  }
+  __syncthreads();
+  gemm_split_rolled<6, MT, k3N3 / 16>(buf, k4Ld, k4Plane, w3, t3, 8, acc3a, lane, 8);
+  gemm_split_rolled<6, MT, k3N3 / 16>(buf, k4Ld, k4Plane, w3, t3 + 6, 8, acc3b, lane, 8);
+  int groups = b - obj0;
+  groups = groups < 4 ? groups : 4;
+  {
+    float4 sc[6], sh[6];
+    float gm[6][MT][4];
+    load_affine4<6>(sc3, sh3, t3 * 16, lane, sc, sh);
+    group_reduce<6, MT, 1>(acc3a, sc, sh, gm);
+    group_finish<6, MT>(gm, out + (size_t)obj0 * k3N3, k3N3, t3 * 16, groups, lane);
+    load_affine4<6>(sc3, sh3, (t3 + 6) * 16, lane, sc, sh);
+    group_reduce<6, MT, 1>(acc3b, sc, sh, gm);
+    group_finish<6, MT>(gm, out + (size_t)obj0 * k3N3, k3N3, (t3 + 6) * 16, groups, lane);
   }
 }
 
@@ -1132,9 +1262,16 @@ extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius
                                                            make_layer(w3, affine3, 128), out, valid);
   } else if (level == 3) {
     if (!pts || !feat || n != 16 || m != 1) return MSR3D_EINVAL;
-    if ((e = allow_lds(sa3_split_kernel, kSa3Lds)) != hipSuccess) return (int)e;
-    sa3_split_kernel<<<(b + 1) / 2, 256, kSa3Lds, st>>>(b, pts, feat, make_layer(w1, affine1, 256), make_layer(w2, affine2, 512),
-                                                       make_layer(w3, affine3, 768), out, valid);
+    static const bool two = [] { const char *v = getenv("MSR3D_SA3_TILE"); return v && v[0] == '2'; }();
+    if (two) {
+      if ((e = allow_lds(sa3_split_kernel, kSa3Lds)) != hipSuccess) return (int)e;
+      sa3_split_kernel<<<(b + 1) / 2, 256, kSa3Lds, st>>>(b, pts, feat, make_layer(w1, affine1, 256), make_layer(w2, affine2, 512),
+                                                         make_layer(w3, affine3, 768), out, valid);
+    } else {
+      if ((e = allow_lds(sa3_split4_kernel, kSa3x4Lds)) != hipSuccess) return (int)e;
+      sa3_split4_kernel<<<(b + 3) / 4, 256, kSa3x4Lds, st>>>(b, pts, feat, make_layer(w1, affine1, 256),
+                                                            make_layer(w2, affine2, 512), make_layer(w3, affine3, 768), out, valid);
+    }
   } else {
     return MSR3D_EINVAL;
   }
