@@ -246,6 +246,10 @@ __device__ __forceinline__ void attn_fwd_core(int L, const float *sq, const floa
   constexpr float kPScale = (MMA == MSR3D_MMA_FP8) ? 256.f : 1.f;   // P into e4m3's normal range
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4, row0 = wave * 16;
+  // a workgroup may hold more waves than query tiles (the fused block with two waves per SIMD): the extra waves only
+  // keep the barrier company
+  const bool act = wave < NT;
+  if (act) {
   f32x4 acc[NT];
 #pragma unroll
   for (int rn = 0; rn < NT; ++rn) acc[rn] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -304,10 +308,11 @@ __device__ __forceinline__ void attn_fwd_core(int L, const float *sq, const floa
       if (probs_bh && row < L && col < L) probs_bh[(size_t)row * L + col] = p;
     }
   }
+  }
   __syncthreads();
   o[0] = f32x4{0.f, 0.f, 0.f, 0.f};
   o[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  strip_mma<MMA, 2, LT, true, false>(sp, LDP, sv, LD32, row0, o, lane);   // ctx = P V
+  if (act) strip_mma<MMA, 2, LT, true, false>(sp, LDP, sv, LD32, row0, o, lane);   // ctx = P V
 }
 
 // =================================================================================

@@ -29,6 +29,8 @@
 // land on the XCD (slice mod 8): a slice's weights are fetched into ONE L2 (speed only).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/msr3d_hip.h"
 #include "attn_core.h"
 #include "rowmath.h"
@@ -90,14 +92,16 @@ __device__ __forceinline__ float gelu_as_grad(float x) {
 // contiguous 96 KB block, copied into the ROWS layout (pitch 272) -- 24 16-byte loads per thread, all in
 // flight together; rows past L are zero in the source.  LINEAR_KSPLIT: fp32 rows a0[row][col0 .. col0 + 256)
 // split on the way in (the upstream gradient of llm_proj comes from outside the schedule).
+template <int NTHR = 256>
 __device__ __forceinline__ void stage_planes(const unsigned short *__restrict__ xp, unsigned short *xs, int b) {
   const uint4 *src = reinterpret_cast<const uint4 *>(xp + (size_t)b * 3 * TM * KD);
-  uint4 v[24];
+  constexpr int NV = 24 * 256 / NTHR;
+  uint4 v[NV];
 #pragma unroll
-  for (int k = 0; k < 24; ++k) v[k] = src[threadIdx.x + 256 * k];
+  for (int k = 0; k < NV; ++k) v[k] = src[threadIdx.x + NTHR * k];
 #pragma unroll
-  for (int k = 0; k < 24; ++k) {
-    const int q = threadIdx.x + 256 * k;
+  for (int k = 0; k < NV; ++k) {
+    const int q = threadIdx.x + NTHR * k;
     const int plane = q >> 11, row = (q >> 5) & 63, c8 = q & 31;
     *reinterpret_cast<uint4 *>(xs + plane * PLANE + row * PITCH + c8 * 8) = v[k];
   }
@@ -161,8 +165,10 @@ constexpr int lds_bytes() {
        : XS_BYTES;
 }
 
-template <int KIND>
-__global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
+// NW: waves per workgroup.  4 everywhere; 8 (two per SIMD) is an option of the attention forward block, whose phases
+// are short dependent chains that one wave per SIMD cannot overlap (MSR3D_ATTN_FWD_WAVES=8).
+template <int KIND, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void scene_block_kernel(const SB p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned short *xs = reinterpret_cast<unsigned short *>(smem);
   unsigned char *aux = smem + XS_BYTES;
@@ -175,11 +181,12 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
 
   // ---- product 1's stream: the first pieces fly under the prologue ----
   constexpr int RN1 = (KIND == MSR3D_BLK_LINEAR || KIND == MSR3D_BLK_LINEAR_KSPLIT) ? 4
-                    : KIND == MSR3D_BLK_ATTN_BWD ? 1 : 2;
+                    : (KIND == MSR3D_BLK_ATTN_BWD || NW == 8) ? 1 : 2;
   constexpr int KS1 = KD / 32;
   WStream w1;
   if (KIND == MSR3D_BLK_ATTN_FWD)          // per head: [8 slabs][8 tiles]: q q k k v v cond -
-    w1 = make_wstream(p.w1 + (size_t)slice * (KS1 * 8 * kPieceBytes / 2), KS1 * 8 * kPieceBytes, 8, 0, 2 * wave, lane);
+    w1 = make_wstream(p.w1 + (size_t)slice * (KS1 * 8 * kPieceBytes / 2), KS1 * 8 * kPieceBytes, 8, 0,
+                      NW == 8 ? wave : 2 * wave, lane);
   else if (KIND == MSR3D_BLK_ATTN_BWD)     // Wfc as [k = fc row][n = ctx column]: [8 slabs][16 tiles], tiles 2 h, 2 h + 1
     w1 = make_wstream(p.w1, p.w1_bytes, 16, 0, 2 * slice + (wave & 1), lane);
   else if (KIND == MSR3D_BLK_LINEAR)       // [8 slabs][N / 16 tiles]
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
 
   // ---- the block's input -> ROWS planes ----
   if (KIND == MSR3D_BLK_LINEAR_KSPLIT) stage_f32(p.a0, p.lda0, KD * slice, xs, row_base, L);
-  else stage_planes(p.xp, xs, b);
+  else stage_planes<64 * NW>(p.xp, xs, b);
   SB_STAMP(1);
   __syncthreads();
   SB_STAMP(2);
@@ -311,26 +318,31 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
     float *scond = sv + TM * LD32;                                  // [64][8]
     unsigned char *ctxp = reinterpret_cast<unsigned char *>(scond + TM * 8);   // FRAG, 1 slab x 4 row tiles
     // product 2's stream: Wfc [8 slabs][16 tiles], slab h
-    const WStream w2 = make_wstream(p.w2, p.w2_bytes, 16, h, 4 * wave, lane);
-    // the scene's pairwise slab is headed for the LDS the planes occupy: fetched into registers now
+    constexpr int RN2 = 16 / NW, RING2 = RN2 < RING ? RN2 : RING;
+    const WStream w2 = make_wstream(p.w2, p.w2_bytes, 16, h, RN2 * wave, lane);
+    // the scene's pairwise slab is headed for the LDS the planes occupy: fetched into registers now (threads 0..255)
     const float *plsrc = p.ploc + (size_t)b * L * L * SD;
     const int pn = L * L * SD;
     const bool pvec = (reinterpret_cast<uintptr_t>(plsrc) & 15u) == 0 && (pn & 3) == 0;
+    const bool plt = NW == 4 || tid < 256;
     float4 plv[msr3d_attn::kPlocRegs];
-    if (pvec) msr3d_attn::ploc_fetch(plsrc, pn >> 2, plv);
-    f32x4 acc[2][4];
+    if (pvec && plt) msr3d_attn::ploc_fetch(plsrc, pn >> 2, plv);
+    f32x4 acc[RN1][4];
     zero_acc3(acc);
-    gemm_split3<true, 2, 4, KS1, RING>(xr, 0, w1, acc, ring1);
+    gemm_split3<true, RN1, 4, KS1, RING>(xr, 0, w1, acc, ring1);
     SB_STAMP(3);
-    WPiece ring2[RING];
-    preload_wring<4, RING>(ring2, w2);
-    // wave 0 / 1 / 2: the head's q / k / v (32 columns each); wave 3: cond (6 of its first 16 columns)
-    if (wave < 3) {
-      float *tile = sq + wave * TM * LD32;
+    WPiece ring2[RING2];
+    preload_wring<RN2, RING2>(ring2, w2);
+    // the head's column tiles: q q k k v v cond -.  NW = 4: wave 0 / 1 / 2 the head's q / k / v (32 columns each),
+    // wave 3 cond; NW = 8: one tile a wave
+    constexpr int TPW = 8 / NW;                                       // column tiles per wave
+    const int which = (TPW * wave) >> 1;                              // 0 q, 1 k, 2 v, 3 cond
+    if (which < 3) {
+      float *tile = sq + which * TM * LD32;
 #pragma unroll
-      for (int rn = 0; rn < 2; ++rn) {
-        const int c = 16 * rn + 4 * g;
-        const float4 bv = ld4(p.bias1 + wave * KD + h * DH + c);       // bias of the packed [q | k | v | cond] rows
+      for (int rn = 0; rn < RN1; ++rn) {
+        const int c = 16 * ((TPW * wave + rn) & 1) + 4 * g;
+        const float4 bv = ld4(p.bias1 + which * KD + h * DH + c);     // bias of the packed [q | k | v | cond] rows
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const int row = 16 * mt + j;
@@ -339,10 +351,10 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
                                             acc[rn][mt][3] + bv.w)
                               : make_float4(0.f, 0.f, 0.f, 0.f);
           st4(tile + row * LD32 + c, v);
-          if (ok) st4(p.qkvc + (size_t)(row_base + row) * ldq + wave * KD + h * DH + c, v);
+          if (ok) st4(p.qkvc + (size_t)(row_base + row) * ldq + which * KD + h * DH + c, v);
         }
       }
-    } else {
+    } else if (TPW * wave == 6) {
       float b4[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) b4[r] = 4 * g + r < SD + 1 ? p.bias1[3 * KD + h * (SD + 1) + 4 * g + r] : 0.f;
@@ -362,7 +374,7 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
     __syncthreads();                       // every wave is done with the ROWS planes; q / k / v / cond visible
     float *sp = reinterpret_cast<float *>(xs);                      // P [64][68], then the pairwise slab
     const float *plb = sp + TM * (TM + 4);
-    if (pvec) msr3d_attn::ploc_store(sp + TM * (TM + 4), pn >> 2, plv);
+    if (pvec) { if (plt) msr3d_attn::ploc_store(sp + TM * (TM + 4), pn >> 2, plv); }
     else plb = msr3d_attn::stage_ploc<TM>(p.ploc, b, L, sp + TM * (TM + 4));
     __syncthreads();
     SB_STAMP(5);
@@ -370,27 +382,29 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
     msr3d_attn::attn_fwd_core<TM, MSR3D_MMA_F32>(L, sq, sk, sv, sp, plb, scond, 8, p.pad + (size_t)b * L,
                                                  p.probs ? p.probs + ((size_t)b * H + h) * L * L : nullptr, o);
     // ctx_h: side output + product 2's operand (FRAG planes, one slab; row tile = wave)
+    if (wave < 4) {
 #pragma unroll
-    for (int rn = 0; rn < 2; ++rn)
+      for (int rn = 0; rn < 2; ++rn)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rr = 4 * g + r, row = 16 * wave + rr, kk = 16 * rn + j;
-        const float v = row < L ? o[rn][r] : 0.f;
-        if (row < L) p.ctx[(size_t)(row_base + row) * KD + h * DH + kk] = v;
-        unsigned short pl[3];
-        sm_split1(v, pl);
+        for (int r = 0; r < 4; ++r) {
+          const int rr = 4 * g + r, row = 16 * wave + rr, kk = 16 * rn + j;
+          const float v = row < L ? o[rn][r] : 0.f;
+          if (row < L) p.ctx[(size_t)(row_base + row) * KD + h * DH + kk] = v;
+          unsigned short pl[3];
+          sm_split1(v, pl);
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-          *reinterpret_cast<unsigned short *>(ctxp + (((wave * 3 + k) * 64 + rr + 16 * (kk >> 3)) * 16 + (kk & 7) * 2)) = pl[k];
-      }
+          for (int k = 0; k < 3; ++k)
+            *reinterpret_cast<unsigned short *>(ctxp + (((wave * 3 + k) * 64 + rr + 16 * (kk >> 3)) * 16 + (kk & 7) * 2)) = pl[k];
+        }
+    }
     SB_STAMP(6);
     __syncthreads();
-    f32x4 acc2[4][4];
+    f32x4 acc2[RN2][4];
     zero_acc3(acc2);
     const XFrag<4> xm{reinterpret_cast<const unsigned short *>(ctxp) + lane * 8};
-    gemm_split3<true, 4, 4, 1, RING>(xm, 0, w2, acc2, ring2);
+    gemm_split3<true, RN2, 4, 1, RING2>(xm, 0, w2, acc2, ring2);
     SB_STAMP(7);
-    store_partials<4>(acc2, slab, row_base, L, 64 * wave, lane);
+    store_partials<RN2>(acc2, slab, row_base, L, 16 * RN2 * wave, lane);
   } else {
     // ------------------------------------------------------------------ attention block, backward
     const int h = slice, H = p.H, ldq = p.ldq;
@@ -490,13 +504,13 @@ __global__ __launch_bounds__(256) void scene_block_kernel(const SB p) {
   SB_STAMP(8);
 }
 
-template <int KIND>
+template <int KIND, int NW = 4>
 int launch_block(const SB &p, int slices, hipStream_t s) {
   constexpr int lds = lds_bytes<KIND>();
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&scene_block_kernel<KIND>),
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&scene_block_kernel<KIND, NW>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (attr != hipSuccess) return (int)attr;
-  scene_block_kernel<KIND><<<dim3(slices, p.B), 256, lds, s>>>(p);
+  scene_block_kernel<KIND, NW><<<dim3(slices, p.B), 64 * NW, lds, s>>>(p);
   return (int)hipGetLastError();
 }
 
@@ -578,7 +592,10 @@ int msr3d_scene_block(const msr3d_scene_block_t *pp, msr3d_stream_t stream) {
     case MSR3D_BLK_ATTN_FWD:
       if (p.H != 8 || !p.w2 || !p.qkvc || !p.ploc || !p.pad || !p.ctx || !p.bias1 || p.ldq % 4) return MSR3D_EINVAL;
       if (p.w1_bytes < 8u * 8u * 8u * kPieceBytes || p.w2_bytes < 8u * 16u * kPieceBytes) return MSR3D_EINVAL;
-      return launch_block<MSR3D_BLK_ATTN_FWD>(p, 8, s);
+      {
+        static const bool eight = [] { const char *v = getenv("MSR3D_ATTN_FWD_WAVES"); return v && v[0] == '8'; }();
+        return eight ? launch_block<MSR3D_BLK_ATTN_FWD, 8>(p, 8, s) : launch_block<MSR3D_BLK_ATTN_FWD>(p, 8, s);
+      }
     case MSR3D_BLK_FFN_FWD:
     case MSR3D_BLK_FFN_BWD:
       if (p.ff <= 0 || p.ff % 128 || p.ff / 128 > 16 || !p.w2 || !p.pre || !p.h) return MSR3D_EINVAL;

@@ -10,7 +10,7 @@ from msr3d_amd.llm import LoRALlamaDecoderLayer  # noqa: E402
 dev = torch.device("cuda", 0)
 Bq, T, Hd, NH, FF = 4, 576, 4096, 32, 11008
 torch.manual_seed(0)
-layer = LoRALlamaDecoderLayer(Hd, NH, FF, r=16, lora_alpha=16, device=dev)
+layer = LoRALlamaDecoderLayer(Hd, NH, FF, r=16, lora_alpha=16, device=dev, base=("fp8" if "--fp8" in sys.argv else "bf16"))
 with torch.no_grad():
     for grp in (layer.self_attn, layer.mlp):
         for m in grp.values():
