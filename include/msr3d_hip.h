@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 15
+#define MSR3D_ABI_VERSION 16
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -591,6 +591,10 @@ typedef struct msr3d_pack_job {
 /* jobs, piece_prefix (njobs + 1 ints: first (slab, tile) piece of each job; [njobs] = total): DEVICE memory. */
 int msr3d_split_pack(int njobs, const msr3d_pack_job_t *jobs, const int *piece_prefix, int total_pieces,
                      msr3d_stream_t stream);
+/* msr3d_split_pack + msr3d_step_begin in ONE launch (extra workgroups zero-fill `zero_region` and bump the dropout seed
+ * word): the two are independent and open every step of the scene-block schedule. */
+int msr3d_split_pack_begin(int njobs, const msr3d_pack_job_t *jobs, const int *piece_prefix, int total_pieces,
+                           float *zero_region, long long n_floats, unsigned long long *seed, msr3d_stream_t stream);
 
 #define MSR3D_BLK_ATTN_FWD 0
 #define MSR3D_BLK_FFN_FWD 1
@@ -681,6 +685,11 @@ typedef struct msr3d_wgrad_problem {
 } msr3d_wgrad_problem_t;
 int msr3d_wgrad_split(int n, const msr3d_wgrad_problem_t *problems, const int *tile_prefix, int total_tiles,
                       msr3d_stream_t stream);
+/* msr3d_wgrad_split with the jobs of msr3d_colsum_partials as n_jobs EXTRA workgroups of the same launch (they start in
+ * the launch's second, partly empty round: the LayerNorm parameter gradients cost no launch of their own).  Same sums,
+ * same order, as the two separate calls. */
+int msr3d_wgrad_split_colsum(int n, const msr3d_wgrad_problem_t *problems, const int *tile_prefix, int total_tiles,
+                             int n_jobs, const msr3d_colsum_job_t *jobs, msr3d_stream_t stream);
 
 /* The same launch with every tile's token reduction cut in TWO units (2 x total_tiles workgroups) so that a step's
  * ~1.4 tiles per CU spread evenly over the chip.  The unit that STARTS first parks its 128 x 128 partial in the

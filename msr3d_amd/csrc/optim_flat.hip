@@ -237,7 +237,7 @@ int msr3d_dot_f32(long long n, const float *a, const float *b, float *scratch, f
   if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return MSR3D_EINVAL;
   const long long n4 = n / 4;
   long long gsz = (n4 + 255) / 256;
-  if (gsz > 256) gsz = 256;          // one block per CU: the last block adds 256 partials, one load per thread
+  if (gsz > kMaxBlocks) gsz = kMaxBlocks;   // four blocks per CU: 31 MB in 12.5 us with one (2.5 TB/s); the last block adds the partials
   if (gsz < 1) gsz = 1;
   dot_kernel<<<(int)gsz, 256, 0, (hipStream_t)stream>>>(n4, reinterpret_cast<const float4 *>(a), reinterpret_cast<const float4 *>(b),
                                                         scratch, reinterpret_cast<int *>(scratch + kMaxBlocks), out);

@@ -529,8 +529,16 @@ __device__ __forceinline__ int map_index(const msr3d_pack_job_t *jb, int nseg, i
   return r;
 }
 
+// workgroups past `pack_wgs` (msr3d_split_pack_begin): the step's zero fill + dropout seed bump (= msr3d_step_begin)
 __global__ __launch_bounds__(256) void split_pack_kernel(int njobs, const msr3d_pack_job_t *__restrict__ jobs,
-                                                         const int *__restrict__ prefix, int total) {
+                                                         const int *__restrict__ prefix, int total, int pack_wgs,
+                                                         float4 *__restrict__ z, long long n4, unsigned long long *seed) {
+  if ((int)blockIdx.x >= pack_wgs) {
+    const int zb = blockIdx.x - pack_wgs, nz = gridDim.x - pack_wgs;
+    if (seed && zb == 0 && threadIdx.x == 0) *seed = *seed * 6364136223846793005ull + 1442695040888963407ull;
+    for (long long t = zb * 256ll + threadIdx.x; t < n4; t += nz * 256ll) z[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   const int piece = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (piece >= total) return;
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
@@ -574,7 +582,24 @@ int msr3d_split_pack(int njobs, const msr3d_pack_job_t *jobs, const int *piece_p
   if (njobs < 0 || total_pieces < 0) return MSR3D_EINVAL;
   if (njobs == 0 || total_pieces == 0) return 0;
   if (!jobs || !piece_prefix) return MSR3D_EINVAL;
-  split_pack_kernel<<<(total_pieces + 3) / 4, 256, 0, (hipStream_t)stream>>>(njobs, jobs, piece_prefix, total_pieces);
+  const int wgs = (total_pieces + 3) / 4;
+  split_pack_kernel<<<wgs, 256, 0, (hipStream_t)stream>>>(njobs, jobs, piece_prefix, total_pieces, wgs, nullptr, 0, nullptr);
+  return (int)hipGetLastError();
+}
+
+int msr3d_split_pack_begin(int njobs, const msr3d_pack_job_t *jobs, const int *piece_prefix, int total_pieces,
+                           float *zero_region, long long n_floats, unsigned long long *seed, msr3d_stream_t stream) {
+  if (njobs < 0 || total_pieces < 0 || n_floats < 0 || (n_floats % 4)) return MSR3D_EINVAL;
+  if (njobs > 0 && total_pieces > 0 && (!jobs || !piece_prefix)) return MSR3D_EINVAL;
+  if (n_floats > 0 && (!zero_region || (reinterpret_cast<uintptr_t>(zero_region) & 15u))) return MSR3D_EINVAL;
+  const int wgs = (njobs > 0) ? (total_pieces + 3) / 4 : 0;
+  const long long n4 = n_floats / 4;
+  long long zw = (n4 + 255) / 256;
+  zw = zw > 512 ? 512 : zw;
+  if (zw < 1 && seed) zw = 1;
+  if (wgs + zw == 0) return 0;
+  split_pack_kernel<<<wgs + (int)zw, 256, 0, (hipStream_t)stream>>>(njobs, jobs, piece_prefix, total_pieces, wgs,
+                                                                    reinterpret_cast<float4 *>(zero_region), n4, seed);
   return (int)hipGetLastError();
 }
 

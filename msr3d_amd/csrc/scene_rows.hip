@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/msr3d_hip.h"
+#include "colsum.h"
 #include "rowmath.h"
 #include "split_mma.h"
 
@@ -169,30 +170,8 @@ int launch_rows(const SR &p, hipStream_t s) {
 }
 
 __global__ __launch_bounds__(256) void colsum_partials_kernel(const msr3d_colsum_job_t *__restrict__ jobs) {
-  // thread = (float4 column q, row group rg): rows rg, rg + 4, ... in batches of 16 loads in flight (240 rows of
-  // dependent loads by one thread per column took 17 us); the four row groups meet in LDS in a fixed order
-  __shared__ __attribute__((aligned(16))) float red[4][ROW_D];
-  const msr3d_colsum_job_t j = jobs[blockIdx.x];
-  const int q = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  constexpr int U = 16;
-  for (int i0 = rg; i0 < j.n; i0 += 4 * U) {
-    float4 v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = i0 + 4 * u;
-      v[u] = ld4(j.part + (size_t)min(i, j.n - 1) * ROW_D + 4 * q);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (i0 + 4 * u < j.n) s = f4_add(s, v[u]);
-  }
-  st4(&red[rg][4 * q], s);
-  __syncthreads();
-  if (rg == 0) {
-    float4 t = f4_add(f4_add(ld4(&red[0][4 * q]), ld4(&red[1][4 * q])), f4_add(ld4(&red[2][4 * q]), ld4(&red[3][4 * q])));
-    st4(j.dst + 4 * q, f4_add(ld4(j.dst + 4 * q), t));
-  }
+  __shared__ __attribute__((aligned(16))) float red[4 * ROW_D];
+  colsum_job(jobs[blockIdx.x], red);
 }
 
 }  // namespace

@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "../../include/msr3d_hip.h"
+#include "colsum.h"
 #include "split_mma.h"
 
 // phase marks: empty here; tools/prof/wgrad_stamped.hip defines WG_STAMP and includes this file
@@ -330,9 +331,16 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
   WG_STAMP(6);
 }
 
+// workgroups past `tiles` (msr3d_wgrad_split_colsum): one column-sum job each -- the LayerNorm parameter gradients'
+// second stage rides in the weight-gradient launch's second round instead of a launch of its own
 __global__ __launch_bounds__(NTHREADS) void wgrad_split_kernel(int nprob, const WP *__restrict__ probs,
-                                                          const int *__restrict__ prefix) {
+                                                          const int *__restrict__ prefix, int tiles,
+                                                          const msr3d_colsum_job_t *__restrict__ cjobs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if ((int)blockIdx.x >= tiles) {
+    colsum_job(cjobs[blockIdx.x - tiles], reinterpret_cast<float *>(smem));
+    return;
+  }
   int lo = 0, hi = nprob - 1;
   const int t = blockIdx.x;
   while (lo < hi) {
@@ -472,7 +480,21 @@ extern "C" int msr3d_wgrad_split(int n, const msr3d_wgrad_problem_t *problems, c
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_split_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (attr != hipSuccess) return (int)attr;
-  wgrad_split_kernel<<<total_tiles, NTHREADS, LDS_BYTES, (hipStream_t)stream>>>(n, problems, tile_prefix);
+  wgrad_split_kernel<<<total_tiles, NTHREADS, LDS_BYTES, (hipStream_t)stream>>>(n, problems, tile_prefix, total_tiles, nullptr);
+  return (int)hipGetLastError();
+}
+
+extern "C" int msr3d_wgrad_split_colsum(int n, const msr3d_wgrad_problem_t *problems, const int *tile_prefix,
+                                        int total_tiles, int n_jobs, const msr3d_colsum_job_t *jobs,
+                                        msr3d_stream_t stream) {
+  if (n < 0 || total_tiles < 0 || n_jobs < 0) return MSR3D_EINVAL;
+  if ((n == 0 || total_tiles == 0) && n_jobs == 0) return 0;
+  if ((total_tiles > 0 && (!problems || !tile_prefix)) || (n_jobs > 0 && !jobs)) return MSR3D_EINVAL;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_split_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (attr != hipSuccess) return (int)attr;
+  wgrad_split_kernel<<<total_tiles + n_jobs, NTHREADS, LDS_BYTES, (hipStream_t)stream>>>(n, problems, tile_prefix,
+                                                                                        total_tiles, jobs);
   return (int)hipGetLastError();
 }
 

@@ -45,6 +45,9 @@ def set_mode(name):
         raise ValueError("trainable-part mode must be 'blocks' or 'strips'")
     _MODE[0] = name
 
+# MSR3D_MERGE_LAUNCHES=0: the step's zero fill and the LayerNorm-gradient column sums as launches of their own (round 3)
+_MERGE = os.environ.get("MSR3D_MERGE_LAUNCHES", "1") != "0"
+
 _vp = ctypes.c_void_p
 
 
@@ -323,9 +326,13 @@ class PrompterSchedule:
         blk, rows = scene_blocks.launch_block, scene_blocks.launch_rows
         nff = FF // 128
         with torch.cuda.device(dev):
-            rc = lib.msr3d_step_begin(_ptr(a.buf), a.zero_floats, _ptr(seed) if self.bump_seed else None, st)
-            _lib.check(rc, "msr3d_step_begin")
-            pk.launch(st)                                   # this step's weights, split and fragment-packed
+            if _MERGE:
+                # ONE launch: this step's weights split and fragment-packed + the arena's zero fill + the seed bump
+                pk.launch(st, begin=(a.buf, a.zero_floats, seed if self.bump_seed else None))
+            else:
+                rc = lib.msr3d_step_begin(_ptr(a.buf), a.zero_floats, _ptr(seed) if self.bump_seed else None, st)
+                _lib.check(rc, "msr3d_step_begin")
+                pk.launch(st)
             lp = pr.obj_linear_projection
             self._multi([dict(a_kc=1, b_kc=1, M=M, N=D, K=KE, A=e2, lda=KE, B=lp.weight, ldb=KE, C=a["x0"], ldc=D,
                               bias=lp.bias, beta=1.0)])
@@ -440,7 +447,6 @@ class PrompterSchedule:
                     probs=a[f"probs{i}"], H=H)
                 src = dict(part=part, nslab=H, part_stride=MD, extra=a["res"])
             rows(st, M=M, L=L, pro=PRO["plain"], sum_out=a["d_xacc0"], **src)      # d_xin0, whole
-            _lib.check(lib.msr3d_colsum_partials(len(layers) * 6, _ptr(self._ln_jobs(layers)), st), "msr3d_colsum_partials")
             le, se = pr.loc_embedding_encoder, pr.size_embedding_encoder
             more = same_all and nl > 1
             rc = lib.msr3d_pos_embed_bwd(
@@ -452,7 +458,12 @@ class PrompterSchedule:
                 _ptr(pr.object_orientation_feat.grad) if pr.use_orientation else None, st)
             _lib.check(rc, "msr3d_pos_embed_bwd")
             wg.set_ptr(self.wg_proj, "x", self.saved_embeds.data_ptr())
-            wg.launch(st)
+            if _MERGE:
+                # every weight gradient + (as extra workgroups) the ordered LayerNorm-gradient column sums: one launch
+                wg.launch(st, colsum=(len(layers) * 6, self._ln_jobs(layers)))
+            else:
+                _lib.check(lib.msr3d_colsum_partials(len(layers) * 6, _ptr(self._ln_jobs(layers)), st), "msr3d_colsum_partials")
+                wg.launch(st)
             if self.need_d_embeds:     # unfrozen object encoder: d obj_embeds = d_xin0 W_proj
                 lpj = pr.obj_linear_projection
                 self._multi([dict(a_kc=1, b_kc=0, M=M, N=KE, K=D, A=a["d_xacc0"], lda=D, B=lpj.weight, ldb=KE,

@@ -65,11 +65,20 @@ class WeightPacks:
     def nbytes(self, name):
         return self.bufs[name].numel() * 2
 
-    def launch(self, stream):
+    def launch(self, stream, begin=None):
+        """begin = (zero_region tensor, n_floats, seed tensor or None): the step's zero fill + seed bump ride as extra
+        workgroups of the same launch (msr3d_split_pack_begin)."""
         if self._table is None:
             arr = (PackJob * len(self.jobs))(*self.jobs)
             self._table = _device_bytes(arr, self.device)
             self._pfx = torch.tensor(self._prefix, dtype=torch.int32).to(self.device)
+        if begin is not None:
+            z, n, seed = begin
+            rc = _lib.load().msr3d_split_pack_begin(len(self.jobs), _vp(self._table.data_ptr()), _vp(self._pfx.data_ptr()),
+                                                    self.total_pieces, _vp(z.data_ptr()), n,
+                                                    _vp(seed.data_ptr()) if seed is not None else None, stream)
+            _lib.check(rc, "msr3d_split_pack_begin")
+            return
         rc = _lib.load().msr3d_split_pack(len(self.jobs), _vp(self._table.data_ptr()), _vp(self._pfx.data_ptr()),
                                           self.total_pieces, stream)
         _lib.check(rc, "msr3d_split_pack")
@@ -120,7 +129,8 @@ class WgradTable:
             setattr(self.probs[idx], field, ptr)
             self._dirty = True
 
-    def launch(self, stream):
+    def launch(self, stream, colsum=None):
+        """colsum = (n_jobs, job-table tensor): msr3d_colsum_partials' jobs as extra workgroups of this launch."""
         if self._dirty:
             arr = (WgradProblem * len(self.probs))(*self.probs)
             n = ctypes.sizeof(arr)
@@ -154,6 +164,13 @@ class WgradTable:
                                                       self.prefix[-1], _vp(self._ws.data_ptr()), self._ws.numel(),
                                                       _vp(self._sync.data_ptr()), stream)
             _lib.check(rc, "msr3d_wgrad_split_halves")
+            if colsum is not None:
+                _lib.check(_lib.load().msr3d_colsum_partials(colsum[0], _vp(colsum[1].data_ptr()), stream), "msr3d_colsum_partials")
+            return
+        if colsum is not None:
+            rc = _lib.load().msr3d_wgrad_split_colsum(len(self.probs), _vp(self._table.data_ptr()), _vp(self._pfx.data_ptr()),
+                                                      self.prefix[-1], colsum[0], _vp(colsum[1].data_ptr()), stream)
+            _lib.check(rc, "msr3d_wgrad_split_colsum")
             return
         rc = _lib.load().msr3d_wgrad_split(len(self.probs), _vp(self._table.data_ptr()), _vp(self._pfx.data_ptr()),
                                            self.prefix[-1], stream)

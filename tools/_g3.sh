@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python tools/prof_llm_layer.py --fp8 2>&1 | grep -v amdgpu.ids | grep -E "Name|kernel|aten::|Memcpy|Self CUDA time" | cut -c1-60,120-200 | head -44
+for i in 1 2 3; do for m in 1 0; do MSR3D_MERGE_LAUNCHES=$m python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import json,sys;j=json.loads(sys.stdin.read());print('merge $m',round(j['value']),j['ms_per_step'],j['ms_per_step_percentiles']['p50'])"; done; done

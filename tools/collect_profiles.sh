@@ -29,6 +29,9 @@ v python bench.py --no-cpu-baseline --host-inputs
 v python bench.py --no-cpu-baseline --objects 120 --points 2048 --llm-hidden 5120 --batch 8 --situation-type as_object
 v env MSR3D_TRAINABLE=strips python bench.py --no-cpu-baseline
 v env MSR3D_SA_MMA=f32 python bench.py --no-cpu-baseline
+v env MSR3D_SA3_TILE=2 python bench.py --no-cpu-baseline
+v env MSR3D_WGRAD_HALVES=1 python bench.py --no-cpu-baseline
+v env MSR3D_ATTN_FWD_WAVES=8 python bench.py --no-cpu-baseline
 v env MSR3D_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline
 v env MSR3D_BENCH_FORCE_DIST=1 MSR3D_DP_GRAPH_COMM=1 python bench.py --no-cpu-baseline
 v env MSR3D_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --batch 4 --accum 5
@@ -42,6 +45,12 @@ python bench.py --llm-stack 4 --steps 10 --warmup 3 2>/dev/null | tail -1 > "$OU
 python bench.py --full-step --steps 8 --warmup 2 2>/dev/null | tail -1 > "$OUT/${TAG}_full_step.json"
 python bench.py --full-step --batch 20 --steps 4 --warmup 2 2>/dev/null | tail -1 > "$OUT/${TAG}_full_step_window20.json"
 env MSR3D_BENCH_FORCE_DIST=1 python bench.py --full-step --steps 8 --warmup 2 2>/dev/null | tail -1 > "$OUT/${TAG}_full_step_rccl1.json"
+python bench.py --full-step --llm-fp8 --steps 8 --warmup 2 2>/dev/null | tail -1 > "$OUT/${TAG}_full_step_fp8.json"
+python bench.py --full-step --llm-fp8 --batch 20 --steps 4 --warmup 2 2>/dev/null | tail -1 > "$OUT/${TAG}_full_step_fp8_window20.json"
+python bench.py --llm-layer --llm-fp8 --steps 10 --warmup 3 2>/dev/null | tail -1 > "$OUT/${TAG}_llm_layer_fp8.json"
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/ktf" -- python "$ROOT/bench.py" --full-step --llm-fp8 --steps 4 --warmup 2 > /dev/null 2>&1)
+F=$(ls "$OUT"/ktf/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$F" ] && cp "$F" "$OUT/${TAG}_full_step_fp8_kernel_stats.csv"
+rm -rf "$OUT/ktf"
 python tools/bench_bf16_gemm.py 2>/dev/null | grep -v amdgpu > "$OUT/${TAG}_bf16_gemm.txt"
 python -m pytest tests/test_seq_ce_gpu.py -q -s -k roofline 2>/dev/null | grep seq_ce > "$OUT/${TAG}_seq_ce.txt"
 python bench.py --cpu-ops --round-tag "$TAG" > "$OUT/${TAG}_cpu_ops.log" 2>&1; cp "profiles/${TAG}_cpu_ops.json" "$OUT/${TAG}_cpu_ops.json"
