@@ -641,16 +641,18 @@ __global__ __launch_bounds__(256) void lora_grad_reduce_kernel(int R, int C, int
 // 64 padded columns), and C[:, N:zero_to] = 0.  A tile of the big kernels would put this on 18 CUs; here a
 // workgroup owns 16 rows of P, its four waves each a quarter of K, fragments loaded straight from global memory
 // (P is read once; the 16 x K operand Q stays in L2), and the four partial tiles meet in LDS.
+constexpr int kSkinnyWaves = 8;      // two per SIMD, each an eighth of K (round 3: four)
 template <int NT>
-__global__ __launch_bounds__(256) void bf16_gemm_skinny_kernel(int M, int N, int K, const unsigned short *__restrict__ P,
+__global__ __launch_bounds__(64 * kSkinnyWaves) void bf16_gemm_skinny_kernel(int M, int N, int K, const unsigned short *__restrict__ P,
                                                                int ldp, const unsigned short *__restrict__ Q, int ldq,
                                                                unsigned short *__restrict__ C, int ldc, int zero_to,
                                                                float scale) {
-  __shared__ __attribute__((aligned(16))) float red[4][NT][64][4];
+  constexpr int NW = kSkinnyWaves;
+  __shared__ __attribute__((aligned(16))) float red[NW][NT][64][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.x * 16;
-  const int nks = K / 32, ks0 = wave * nks / 4, ks1 = (wave + 1) * nks / 4;
+  const int nks = K / 32, ks0 = wave * nks / NW, ks1 = (wave + 1) * nks / NW;
   const unsigned short *p = P + (size_t)min(m0 + i, M - 1) * ldp + 8 * g;
   const unsigned short *q[NT];
 #pragma unroll
@@ -658,20 +660,36 @@ __global__ __launch_bounds__(256) void bf16_gemm_skinny_kernel(int M, int N, int
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int U = 4;                                 // K steps in flight
-  int ks = ks0;
-  for (; ks + U <= ks1; ks += U) {
-    bf16x8 fp[U], fq[U][NT];
+  // batches of U K steps, the NEXT batch's loads issued before this batch's MFMAs (round 3 loaded a batch, waited a full
+  // memory latency, multiplied, and started over: 8 latencies per 16 rows x 4096 -- 15 us for 19 MB on 144 workgroups)
+  constexpr int U = 4;
+  struct Batch { bf16x8 fp[U], fq[U][NT]; };
+  auto fetch = [&](Batch &b_, int ks) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      fp[u] = *reinterpret_cast<const bf16x8 *>(p + (ks + u) * 32);
+      b_.fp[u] = *reinterpret_cast<const bf16x8 *>(p + (ks + u) * 32);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) fq[u][t] = *reinterpret_cast<const bf16x8 *>(q[t] + (ks + u) * 32);
+      for (int t = 0; t < NT; ++t) b_.fq[u][t] = *reinterpret_cast<const bf16x8 *>(q[t] + (ks + u) * 32);
     }
+  };
+  auto mma = [&](const Batch &b_) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[u][t], fp[u], acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_.fq[u][t], b_.fp[u], acc[t], 0, 0, 0);
+  };
+  const int nb = (ks1 - ks0) / U;
+  int ks = ks0;
+  if (nb > 0) {
+    Batch ba, bb;
+    fetch(ba, ks0);
+    for (int b2 = 0; b2 < nb; b2 += 2) {
+      if (b2 + 1 < nb) fetch(bb, ks0 + (b2 + 1) * U);
+      mma(ba);
+      if (b2 + 2 < nb) fetch(ba, ks0 + (b2 + 2) * U);
+      if (b2 + 1 < nb) mma(bb);
+    }
+    ks = ks0 + nb * U;
   }
   for (; ks < ks1; ++ks) {
     const bf16x8 fp = *reinterpret_cast<const bf16x8 *>(p + ks * 32);
@@ -684,10 +702,10 @@ __global__ __launch_bounds__(256) void bf16_gemm_skinny_kernel(int M, int N, int
   __syncthreads();
   // D = Q P^T: lane (i, g) of tile t holds columns n = 16 t + 4 g + r of row m = i; wave w finishes tiles w, w + 4 ..
   const int row = m0 + i;
-  for (int t = wave; t < NT; t += 4) {
+  for (int t = wave; t < NT; t += NW) {
     f32x4 v = *reinterpret_cast<const f32x4 *>(&red[0][t][lane][0]);
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < NW; ++w) {
       const f32x4 o = *reinterpret_cast<const f32x4 *>(&red[w][t][lane][0]);
       v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
     }
@@ -698,7 +716,7 @@ __global__ __launch_bounds__(256) void bf16_gemm_skinny_kernel(int M, int N, int
                      f2bf(v[2] * scale) | ((unsigned)f2bf(v[3] * scale) << 16));
   }
   // the padding columns the next product reads as part of its K step
-  for (int e = threadIdx.x; e < 16 * ((zero_to - N) / 4); e += 256) {
+  for (int e = threadIdx.x; e < 16 * ((zero_to - N) / 4); e += 64 * NW) {
     const int r = e / ((zero_to - N) / 4), c = N + 4 * (e - r * ((zero_to - N) / 4));
     if (m0 + r < M) *reinterpret_cast<uint2 *>(C + (size_t)(m0 + r) * ldc + c) = make_uint2(0u, 0u);
   }
@@ -878,10 +896,10 @@ int msr3d_bf16_gemm_skinny(int M, int N, int K, const void *P, int ldp, const vo
   const unsigned short *p = (const unsigned short *)P, *q = (const unsigned short *)Q;
   unsigned short *c = (unsigned short *)C;
   switch (N / 16) {
-    case 1: bf16_gemm_skinny_kernel<1><<<grid, 256, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
-    case 2: bf16_gemm_skinny_kernel<2><<<grid, 256, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
-    case 3: bf16_gemm_skinny_kernel<3><<<grid, 256, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
-    default: bf16_gemm_skinny_kernel<4><<<grid, 256, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
+    case 1: bf16_gemm_skinny_kernel<1><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
+    case 2: bf16_gemm_skinny_kernel<2><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
+    case 3: bf16_gemm_skinny_kernel<3><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
+    default: bf16_gemm_skinny_kernel<4><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
   }
   return (int)hipGetLastError();
 }
