@@ -50,32 +50,42 @@ __global__ __launch_bounds__(256) void sumsq_kernel(long long n4, const float4 *
 // out[0] = sum a[i] b[i] in ONE launch, bit-reproducible: per-block partials travel through device-
 // coherent stores, the last block to arrive (ticket) adds them in block order.  scratch: kMaxBlocks
 // floats + one int counter (left at zero for the next call).
-__global__ __launch_bounds__(256) void dot_kernel(long long n4, const float4 *__restrict__ a, const float4 *__restrict__ b,
+constexpr int kDotThreads = 1024;  // 16 waves a CU on ONE block per CU: the cost that grows with the block count is the
+                                   // agent-scope release (an L2 write-back per block) -- 1024 blocks of 256: 40 us, 256: 12 us
+__global__ __launch_bounds__(kDotThreads) void dot_kernel(long long n4, const float4 *__restrict__ a, const float4 *__restrict__ b,
                                                   float *__restrict__ partial, int *__restrict__ counter,
                                                   float *__restrict__ out) {
   float s = 0.f;
   const long long stride = (long long)gridDim.x * blockDim.x;
   long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  for (; t + 3 * stride < n4; t += 4 * stride) {          // eight 16-byte loads in flight per thread
-    float4 x[4], y[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { x[u] = a[t + u * stride]; y[u] = b[t + u * stride]; }
+  for (; t < n4; t += 4 * stride) {                        // eight 16-byte loads in flight per thread; an index past
+    float4 x[4], y[4];                                     // the end reads the last element and contributes zero
+    bool ok[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      s = fmaf(x[u].x, y[u].x, s); s = fmaf(x[u].y, y[u].y, s); s = fmaf(x[u].z, y[u].z, s); s = fmaf(x[u].w, y[u].w, s);
+      const long long i = t + u * stride;
+      ok[u] = i < n4;
+      const long long j = ok[u] ? i : n4 - 1;
+      x[u] = a[j]; y[u] = b[j];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float p = 0.f;
+      p = fmaf(x[u].x, y[u].x, p); p = fmaf(x[u].y, y[u].y, p); p = fmaf(x[u].z, y[u].z, p); p = fmaf(x[u].w, y[u].w, p);
+      s += ok[u] ? p : 0.f;
     }
   }
-  for (; t < n4; t += stride) {
-    const float4 x = a[t], y = b[t];
-    s = fmaf(x.x, y.x, s); s = fmaf(x.y, y.y, s); s = fmaf(x.z, y.z, s); s = fmaf(x.w, y.w, s);
-  }
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  __shared__ float part[4];
+  constexpr int NWAVE = kDotThreads / 64;
+  __shared__ float part[NWAVE];
   __shared__ int ticket;
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_store(partial + blockIdx.x, (part[0] + part[1]) + (part[2] + part[3]), __ATOMIC_RELAXED,
+    float blk = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) blk += part[w];          // fixed order
+    __hip_atomic_store(partial + blockIdx.x, blk, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
     // the partial must be visible to the LAST block, possibly on another XCD, before the ticket is: an
     // agent-scope release (a workgroup-scope fence orders nothing another CU can observe) ...
@@ -88,14 +98,17 @@ __global__ __launch_bounds__(256) void dot_kernel(long long n4, const float4 *__
   __syncthreads();
   if (ticket != (int)gridDim.x - 1) return;
   float tot = 0.f;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += kDotThreads)
     tot += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = tot;
   __syncthreads();
   if (threadIdx.x == 0) {
-    out[0] = (part[0] + part[1]) + (part[2] + part[3]);
+    float all = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) all += part[w];
+    out[0] = all;
     __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -236,10 +249,10 @@ int msr3d_dot_f32(long long n, const float *a, const float *b, float *scratch, f
   if (!a || !b || !scratch || !out) return MSR3D_EINVAL;
   if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return MSR3D_EINVAL;
   const long long n4 = n / 4;
-  long long gsz = (n4 + 255) / 256;
-  if (gsz > kMaxBlocks) gsz = kMaxBlocks;   // four blocks per CU: 31 MB in 12.5 us with one (2.5 TB/s); the last block adds the partials
+  long long gsz = (n4 + kDotThreads - 1) / kDotThreads;
+  if (gsz > 256) gsz = 256;                 // one block per CU (see kDotThreads); the last block adds the partials
   if (gsz < 1) gsz = 1;
-  dot_kernel<<<(int)gsz, 256, 0, (hipStream_t)stream>>>(n4, reinterpret_cast<const float4 *>(a), reinterpret_cast<const float4 *>(b),
+  dot_kernel<<<(int)gsz, kDotThreads, 0, (hipStream_t)stream>>>(n4, reinterpret_cast<const float4 *>(a), reinterpret_cast<const float4 *>(b),
                                                         scratch, reinterpret_cast<int *>(scratch + kMaxBlocks), out);
   return (int)hipGetLastError();
 }

@@ -223,10 +223,15 @@ class HotPathTrainStep:
         fts = [b["obj_fts"] for b in batches]
         B = fts[0].shape[0]
         n = len(fts)
-        # micro-batches that already lie back to back in memory (a window-major loader) are encoded in place
+        # micro-batches that already lie back to back IN ONE STORAGE (slices of a window-major loader's buffer) are
+        # encoded in place; separately allocated tensors that merely happen to be neighbours in the caching
+        # allocator's block are not one storage and are concatenated
         step = fts[0].numel() * fts[0].element_size()
-        if all(f.is_contiguous() and f.shape == fts[0].shape and f.data_ptr() == fts[0].data_ptr() + i * step
-               for i, f in enumerate(fts)):
+        st0 = fts[0].untyped_storage()
+        room = st0.nbytes() - (fts[0].data_ptr() - st0.data_ptr())
+        if room >= n * step and all(
+                f.is_contiguous() and f.shape == fts[0].shape and f.data_ptr() == fts[0].data_ptr() + i * step
+                and f.untyped_storage().data_ptr() == st0.data_ptr() for i, f in enumerate(fts)):
             allf = torch.as_strided(fts[0], (n * B,) + tuple(fts[0].shape[1:]), fts[0].stride())
         else:
             allf = torch.cat(fts, 0)

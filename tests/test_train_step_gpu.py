@@ -313,7 +313,7 @@ def test_accumulation_window_encoded_in_one_pass_gives_the_same_step():
     from msr3d_amd.synth import synth_batch
     from msr3d_amd.train_step import HotPathTrainStep
     accum, outs = 3, []
-    for window in (False, True):
+    for window in (False, True, "slices"):
         torch.manual_seed(0)
         cfg = AttrDict({"prompter": default_prompter_cfg(dropout=0.0), "llm_hidden_size": 256,
                         "model": {"name": "MSR3DHotPath"}})
@@ -336,7 +336,12 @@ def test_accumulation_window_encoded_in_one_pass_gives_the_same_step():
                 feats.append(step.static["obj_embeds"].clone())
         torch.cuda.synchronize()
         outs.append((feats, {k: v.detach().clone() for k, v in model.named_parameters() if v.requires_grad}))
-    (f0, p0), (f1, p1) = outs
+    (f0, p0) = outs[0]
+    for f1, p1 in outs[1:]:
+        _same_window(f0, p0, f1, p1)
+
+
+def _same_window(f0, p0, f1, p1):
     for a, b in zip(f0, f1):
         assert torch.equal(a, b)                   # encoder features: bit-identical
     # Two Adam steps from zero moments move every weight by ~lr * sign(g) each: the positional encoders' parameter
