@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 16
+#define MSR3D_ABI_VERSION 17
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -837,6 +837,32 @@ int msr3d_fp8_gemm_lowrank(int M, int N, int K, const void *Pq, int ldp, const f
 int msr3d_lora_grad(int M, int R, int C, const void *P, int ldp, const void *Q, int ldq, float *out,
                     int transpose_out, float scale, int accumulate, float *workspace, long long workspace_floats,
                     msr3d_stream_t stream);
+
+/* dA and dB of one LoRA pair (or one of them: njobs = 1) in ONE launch: job z computes out_z (R, C_z) -- or its
+ * transpose (C_z, R) -- (+)= scale * sum_m P_z[m][r] Q_z[m][c] as msr3d_lora_grad does, each workgroup owning 64 output
+ * columns over ALL rows (no partial sums, no workspace, bit-reproducible by construction; 236 workgroups for a
+ * 4096 / 11008 pair).  accumulate == 0: `out` is overwritten.  C % 8 == 0, ldp / ldq % 8 == 0, P / Q / out 16-byte
+ * aligned.  (peft's lora_A / lora_B gradients, model/msr3d/msr3d.py:103-112.) */
+typedef struct {
+  int C;
+  const void *P; int ldp;      /* (M, R) bf16 */
+  const void *Q; int ldq;      /* (M, C) bf16 */
+  float *out; int transpose_out;
+} msr3d_lora_grad_job_t;
+int msr3d_lora_grad_pair(int M, int R, int njobs, const msr3d_lora_grad_job_t *jobs, float scale, int accumulate,
+                         msr3d_stream_t stream);
+
+/* The bf16 images of the LoRA pairs of a whole stack, in the orientations the products read, in ONE launch (once per
+ * optimiser step): per job  a_pad (r, K) = A,  at2 (K, 64)[:, :r] = A^T,  b2 (N, 64)[:, :r] = B,  bt_pad (r, N) = B^T
+ * (A (r, K), B (N, r) fp32; r = 16 or 32; columns r..63 of at2 / b2 are not written: the caller zeroes them once).
+ * `jobs_device`: the table in DEVICE memory.  (peft LoraConfig targets, model/msr3d/msr3d.py:103-112.) */
+typedef struct {
+  const float *A, *B;
+  unsigned short *a_pad, *b2, *bt_pad, *at2;
+  int r, K, N, pad_;
+} msr3d_lora_shadow_job_t;
+int msr3d_lora_shadows(int njobs, const msr3d_lora_shadow_job_t *jobs_device, msr3d_stream_t stream);
+
 
 /* ---------------------------------------------------------------------------
  * Optimiser step of the hot path: global-norm clip + AdamW over flat buffers

@@ -47,6 +47,18 @@ class PackJob(ctypes.Structure):
                 ("dst", _ptr)]
 
 
+class LoraGradJob(ctypes.Structure):
+    """msr3d_lora_grad_job_t (include/msr3d_hip.h)."""
+    _fields_ = [("C", _c_int), ("P", _ptr), ("ldp", _c_int), ("Q", _ptr), ("ldq", _c_int), ("out", _ptr),
+                ("transpose_out", _c_int)]
+
+
+class LoraShadowJob(ctypes.Structure):
+    """msr3d_lora_shadow_job_t (include/msr3d_hip.h)."""
+    _fields_ = [("A", _ptr), ("B", _ptr), ("a_pad", _ptr), ("b2", _ptr), ("bt_pad", _ptr), ("at2", _ptr),
+                ("r", _c_int), ("K", _c_int), ("N", _c_int), ("pad_", _c_int)]
+
+
 class SceneBlock(ctypes.Structure):
     """msr3d_scene_block_t (include/msr3d_hip.h)."""
     _fields_ = [("kind", _c_int), ("B", _c_int), ("L", _c_int), ("xp", _ptr), ("a0", _ptr), ("lda0", _c_int),
@@ -123,6 +135,8 @@ _SIGNATURES = {
     "msr3d_colsum_partials": [_c_int, _ptr, _ptr],
     "msr3d_lora_grad": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_float, _c_int, _ptr,
                         ctypes.c_longlong, _ptr],
+    "msr3d_lora_grad_pair": [_c_int, _c_int, _c_int, ctypes.POINTER(LoraGradJob), _c_float, _c_int, _ptr],
+    "msr3d_lora_shadows": [_c_int, _ptr, _ptr],
     "msr3d_sa_level_split": [_c_int, _c_int, _c_int, _c_int, _c_float] + [_ptr] * 13,
     "msr3d_seq_ce_fwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_seq_ce_bwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
@@ -206,7 +220,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string", "msr3d_sqdist_contract"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 16        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 17        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():

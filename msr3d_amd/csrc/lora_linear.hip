@@ -637,6 +637,170 @@ __global__ __launch_bounds__(256) void lora_grad_reduce_kernel(int R, int C, int
   }
 }
 
+// dA and dB of ONE LoRA pair in ONE launch, no partial sums at all (round 4 cut the rows into 64 chunks for
+// parallelism, wrote the chunks' partials to a workspace and added them up in a second launch: four launches per pair,
+// 896 a step for a 32-layer stack, 8.5 ms of an 83 ms step; a first one-launch version -- tickets + agent-scope fences, the
+// last workgroup of a column block adding the partials -- measured 80-150 us per pair against 37-41: an L2 write-back per
+// wave).  Here a workgroup OWNS 64 output columns over ALL rows: 64 + 172 = 236 workgroups for a 4096 / 11008 pair, one
+// per CU; the sum over the tokens never leaves the accumulators, so the result is bit-reproducible by construction.  One
+// CU's share of the bandwidth needs ~64 KB in flight: a register ring of kGD passes (64 rows x 128 bytes each), refilled
+// as it drains; the pass's rows go row-major into LDS (double-buffered: one barrier per pass) and each wave gathers the
+// fragments of its 16 columns (eight 2-byte LDS reads per fragment: an MFMA fragment here is 8 consecutive TOKENS of one
+// column).
+struct GradJob {
+  int C;
+  const unsigned short *P; int ldp;          // (M, R)
+  const unsigned short *Q; int ldq;          // (M, C)
+  float *out; int transpose_out;
+  int blocks;                                // 64-column blocks of this job
+};
+struct GradPair { GradJob j[2]; };
+using v4s = __attribute__((ext_vector_type(4))) short;
+__device__ __forceinline__ v4s tr_read(const unsigned short *p) {          // ds_read_b64_tr_b16
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3))) *)p);
+}
+constexpr int kGD = 8;                       // passes in flight per workgroup
+constexpr int kGC = 64 + 8;                  // LDS pitch of a staged Q row, bf16 units (144 B)
+
+template <int R>
+__global__ __launch_bounds__(256) void lora_grad_cols_kernel(int M, const GradPair pr, float scale, int accumulate) {
+  constexpr int RT = R / 16;
+  constexpr int GP = R + 4;                  // LDS pitch of a staged P row (40 / 72 B: 8-byte aligned for the transpose reads)
+  constexpr int PCH = R / 8;                 // 16-byte chunks per P row
+  const int z = (int)blockIdx.x >= pr.j[0].blocks ? 1 : 0;
+  const GradJob &jb = pr.j[z];
+  const int C = jb.C;
+  const int cb = 64 * ((int)blockIdx.x - (z ? pr.j[0].blocks : 0));
+  __shared__ __attribute__((aligned(16))) unsigned short qs[2][64 * kGC];
+  __shared__ __attribute__((aligned(16))) unsigned short ps[2][64 * GP];
+  const unsigned short *__restrict__ P = jb.P;
+  const unsigned short *__restrict__ Q = jb.Q;
+  const int ldp = jb.ldp, ldq = jb.ldq;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  f32x4 acc[RT];
+#pragma unroll
+  for (int u = 0; u < RT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // staging roles: Q -- thread t covers 16 bytes (8 columns) of rows t / 8 and 32 + t / 8; P -- threads 0 .. 64 PCH - 1
+  const int qrow = tid >> 3, qc = (tid & 7) * 8;
+  const bool qlive = cb + qc < C;            // (C % 8 == 0: a 16-byte piece is inside or outside)
+  const int prow = tid / PCH, pc = (tid % PCH) * 8;
+  const int np = (M + 63) >> 6;
+  uint4 qv[kGD][2], pv[kGD];
+  auto fetch = [&](int d, int pass) {
+    const int m0 = pass * 64;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int m = m0 + qrow + 32 * h;
+      qv[d][h] = (qlive && m < M) ? *reinterpret_cast<const uint4 *>(Q + (size_t)m * ldq + cb + qc) : make_uint4(0, 0, 0, 0);
+    }
+    const int m = m0 + prow;
+    pv[d] = (prow < 64 && m < M) ? *reinterpret_cast<const uint4 *>(P + (size_t)m * ldp + pc) : make_uint4(0, 0, 0, 0);
+  };
+#pragma unroll
+  for (int d = 0; d < kGD; ++d) fetch(d, d);                // (passes beyond the last read nothing: zeros)
+  for (int base = 0; base < np; base += kGD) {
+#pragma unroll
+    for (int d = 0; d < kGD; ++d) {
+      const int pass = base + d;
+      if (pass < np) {                                      // (uniform)
+        unsigned short *q_ = qs[d & 1], *p_ = ps[d & 1];    // (kGD is even: pass parity == d parity)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) *reinterpret_cast<uint4 *>(q_ + (qrow + 32 * h) * kGC + qc) = qv[d][h];
+        if (prow < 64) {
+          uint2 *dst = reinterpret_cast<uint2 *>(p_ + prow * GP + pc);
+          dst[0] = make_uint2(pv[d].x, pv[d].y); dst[1] = make_uint2(pv[d].z, pv[d].w);
+        }
+        fetch(d, pass + kGD);                               // refill the ring slot just drained
+        __syncthreads();                                    // (the other buffer's readers finished before the last barrier)
+        // fragments by the LDS transpose read: a 16-lane group hands in the addresses of a [4 tokens][16 columns] block
+        // (lane i': token i' >> 2, columns 4 (i' & 3) ..) and lane i receives column i of it -- four consecutive tokens
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+          const int tr = 32 * sl + 8 * g + (i >> 2), tc = 4 * (i & 3);
+          union { v4s h[2]; bf16x8 v; } wq;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) wq.h[h] = tr_read(q_ + (tr + 4 * h) * kGC + wave * 16 + tc);
+#pragma unroll
+          for (int u = 0; u < RT; ++u) {
+            union { v4s h[2]; bf16x8 v; } wp;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) wp.h[h] = tr_read(p_ + (tr + 4 * h) * GP + 16 * u + tc);
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq.v, wp.v, acc[u], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // D[c][r]: lane (i, g) holds columns c = cb + 16 wave + 4 g + q (q = 0..3) of r = 16 u + i
+  const int c = cb + wave * 16 + 4 * g;
+  if (c >= C) return;                                       // (C % 4 == 0)
+  float *out = jb.out;
+#pragma unroll
+  for (int u = 0; u < RT; ++u) {
+    const int r = 16 * u + i;
+    if (jb.transpose_out) {
+      float *o = out + (size_t)c * R + r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q * R] = (accumulate ? o[q * R] : 0.f) + acc[u][q] * scale;
+    } else {
+      float4 *o = reinterpret_cast<float4 *>(out + (size_t)r * C + c);
+      float4 t = accumulate ? *o : make_float4(0.f, 0.f, 0.f, 0.f);
+      t.x += acc[u][0] * scale; t.y += acc[u][1] * scale; t.z += acc[u][2] * scale; t.w += acc[u][3] * scale;
+      *o = t;
+    }
+  }
+}
+
+// The bf16 images of EVERY LoRA pair of a stack in the four orientations its products read, in one launch (once per
+// optimiser step; round 4 issued four conversion launches per pair: 896 a step):
+//   a_pad (r, K) = bf16(A)         bt_pad (r, N) = bf16(B^T)
+//   at2   (K, 64)[:, :r] = bf16(A^T)    b2 (N, 64)[:, :r] = bf16(B)     (columns r..63 are zero and are not touched)
+// blockIdx.y = pair; a thread owns one column k of A (then one row n of B).
+template <int R>
+__device__ __forceinline__ void shadow_pair(const msr3d_lora_shadow_job_t &jb) {
+  const int K = jb.K, N = jb.N;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < K + N; t += gridDim.x * 256) {
+    if (t < K) {
+      const int k = t;
+      unsigned w[R / 2];
+#pragma unroll
+      for (int r = 0; r < R; r += 2) {
+        const unsigned lo = f2bf(jb.A[(size_t)r * K + k]), hi = f2bf(jb.A[(size_t)(r + 1) * K + k]);
+        jb.a_pad[(size_t)r * K + k] = (unsigned short)lo;
+        jb.a_pad[(size_t)(r + 1) * K + k] = (unsigned short)hi;
+        w[r / 2] = lo | (hi << 16);
+      }
+      uint4 *d = reinterpret_cast<uint4 *>(jb.at2 + (size_t)k * 64);
+#pragma unroll
+      for (int q = 0; q < R / 8; ++q) d[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    } else {
+      const int n = t - K;
+      const float4 *src = reinterpret_cast<const float4 *>(jb.B + (size_t)n * R);
+      unsigned w[R / 2];
+#pragma unroll
+      for (int q = 0; q < R / 4; ++q) {
+        const float4 v = src[q];
+        const unsigned b0 = f2bf(v.x), b1 = f2bf(v.y), b2 = f2bf(v.z), b3 = f2bf(v.w);
+        w[2 * q] = b0 | (b1 << 16);
+        w[2 * q + 1] = b2 | (b3 << 16);
+        jb.bt_pad[(size_t)(4 * q) * N + n] = (unsigned short)b0;
+        jb.bt_pad[(size_t)(4 * q + 1) * N + n] = (unsigned short)b1;
+        jb.bt_pad[(size_t)(4 * q + 2) * N + n] = (unsigned short)b2;
+        jb.bt_pad[(size_t)(4 * q + 3) * N + n] = (unsigned short)b3;
+      }
+      uint4 *d = reinterpret_cast<uint4 *>(jb.b2 + (size_t)n * 64);
+#pragma unroll
+      for (int q = 0; q < R / 8; ++q) d[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void lora_shadows_kernel(const msr3d_lora_shadow_job_t *__restrict__ jobs) {
+  const msr3d_lora_shadow_job_t jb = jobs[blockIdx.y];
+  if (jb.r == 16) shadow_pair<16>(jb);
+  else shadow_pair<32>(jb);
+}
+
 // C (M, N <= 64) = scale * P Q^T for a Q of a few rows (the LoRA down-projections x A^T and dy B: N = 16 of
 // 64 padded columns), and C[:, N:zero_to] = 0.  A tile of the big kernels would put this on 18 CUs; here a
 // workgroup owns 16 rows of P, its four waves each a quarter of K, fragments loaded straight from global memory
@@ -880,6 +1044,37 @@ int msr3d_lora_grad(int M, int R, int C, const void *P, int ldp, const void *Q, 
   if (workspace)
     lora_grad_reduce_kernel<<<(R * (C / 4) + 255) / 256, 256, 0, st>>>(R, C, chunks, workspace, out, transpose_out, scale,
                                                                        accumulate);
+  return (int)hipGetLastError();
+}
+
+int msr3d_lora_grad_pair(int M, int R, int njobs, const msr3d_lora_grad_job_t *jobs, float scale, int accumulate,
+                         msr3d_stream_t stream) {
+  if (M < 0 || (R != 16 && R != 32) || njobs < 1 || njobs > 2 || !jobs) return MSR3D_EINVAL;
+  if (M == 0) return 0;
+  GradPair pr{};
+  int total = 0;
+  for (int z = 0; z < njobs; ++z) {
+    const msr3d_lora_grad_job_t &j = jobs[z];
+    if (j.C <= 0 || (j.C % 8) || !j.P || !j.Q || !j.out || j.ldp < R || j.ldq < j.C || (j.ldp % 8) || (j.ldq % 8) ||
+        !al16(j.P) || !al16(j.Q) || (reinterpret_cast<uintptr_t>(j.out) & 15u))
+      return MSR3D_EINVAL;
+    GradJob &g = pr.j[z];
+    g.C = j.C; g.P = (const unsigned short *)j.P; g.ldp = j.ldp; g.Q = (const unsigned short *)j.Q; g.ldq = j.ldq;
+    g.out = j.out; g.transpose_out = j.transpose_out;
+    g.blocks = (j.C + 63) / 64;
+    total += g.blocks;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (R == 16) lora_grad_cols_kernel<16><<<total, 256, 0, st>>>(M, pr, scale, accumulate);
+  else lora_grad_cols_kernel<32><<<total, 256, 0, st>>>(M, pr, scale, accumulate);
+  return (int)hipGetLastError();
+}
+
+int msr3d_lora_shadows(int njobs, const msr3d_lora_shadow_job_t *jobs_device, msr3d_stream_t stream) {
+  if (njobs < 0) return MSR3D_EINVAL;
+  if (njobs == 0) return 0;
+  if (!jobs_device) return MSR3D_EINVAL;
+  lora_shadows_kernel<<<dim3(16, njobs), 256, 0, (hipStream_t)stream>>>(jobs_device);
   return (int)hipGetLastError();
 }
 

@@ -75,27 +75,29 @@ class _RMSNormFn(torch.autograd.Function):
 
 class _RopeFn(torch.autograd.Function):
     """Rotary embedding IN PLACE on a projection's output (nothing else reads that tensor: _LoRAFn saves its inputs,
-    not its output), and in place on the incoming gradient in backward: no copies (round 3 cloned both)."""
+    not its output), and in place on the incoming gradient in backward: no copies.  Takes the projection's OWN output
+    tensor (tokens, H D) -- not a view of it: an in-place op on a view of a custom function's output is rebased by
+    autograd (CopySlices), which costs two full copies per call in backward (round 4: 128 copies a step)."""
 
     @staticmethod
-    def forward(ctx, x, cos, sin):          # x (B, T, H, D) bf16, contiguous
-        if not x.is_contiguous():
-            raise RuntimeError("_RopeFn: contiguous (B, T, H, D) expected")
-        B, T, H, D = x.shape
+    def forward(ctx, x, cos, sin, B, T, H, D):          # x (B T, H D) or (B, T, H, D) bf16, contiguous
+        if not x.is_contiguous() or x.numel() != B * T * H * D:
+            raise RuntimeError("_RopeFn: a contiguous (B T, H D) tensor expected")
         with torch.cuda.device(x.device):
             _call("msr3d_rope_inplace", B, T, H, D, _p(x), _p(cos), _p(sin), 0, _st(x.device))
         ctx.mark_dirty(x)
         ctx.save_for_backward(cos, sin)
+        ctx.dims = (B, T, H, D)
         return x
 
     @staticmethod
     def backward(ctx, g):
         cos, sin = ctx.saved_tensors
+        B, T, H, D = ctx.dims
         g = g.contiguous()                  # (the attention backward hands over fresh contiguous tensors: no copy)
-        B, T, H, D = g.shape
         with torch.cuda.device(g.device):
             _call("msr3d_rope_inplace", B, T, H, D, _p(g), _p(cos), _p(sin), 1, _st(g.device))
-        return g, None, None
+        return g, None, None, None, None, None, None
 
 
 def _bgemm(dev, B, H, M, N, K, P, ldp, po, pi, Q, ldq, qo, qi, C, ldc, co, ci, c_f32, scale):
@@ -226,8 +228,11 @@ class LoRALlamaDecoderLayer(nn.Module):
             self._rope = ((T, str(dev)), rope_tables(T, self.head_dim, self.theta, dev))
         return self._rope[1]
 
-    def forward(self, x, attention_mask=None):
-        """x (B, T, hidden) bf16; attention_mask (B, T) (1 / True = real token) or None."""
+    def forward(self, x, attention_mask=None, delta=None, defer_residual=False):
+        """x (B, T, hidden) bf16; attention_mask (B, T) (1 / True = real token) or None.
+        delta: a residual term still to be added to x (the previous layer's MLP output): the input norm's launch
+        adds it.  defer_residual: return (x_after_attention, mlp_output) instead of their sum, for the next layer's
+        `delta` -- a stack of layers then has no stand-alone add kernels in forward or backward."""
         if not x.is_cuda:
             raise RuntimeError("LoRALlamaDecoderLayer runs on the GPU only (no CPU fallback)")
         B, T, Hd = x.shape
@@ -236,12 +241,17 @@ class LoRALlamaDecoderLayer(nn.Module):
         keep = None if attention_mask is None else attention_mask.to(torch.uint8).contiguous()
         cos, sin = self._tables(T, x.device)
         a = self.self_attn
-        _, h = _RMSNormFn.apply(x, None, self.input_layernorm_weight, self.eps)
-        q = _RopeFn.apply(a["q_proj"](h).view(B, T, H, D), cos, sin)
-        k = _RopeFn.apply(a["k_proj"](h).view(B, T, H, D), cos, sin)
+        # (x0 = x + delta; with delta None it is x itself -- and the ONLY use of the layer input from here on, so its
+        # gradient arrives in one piece through the norm's backward)
+        x0, h = _RMSNormFn.apply(x, delta, self.input_layernorm_weight, self.eps)
+        # RoPE in place on the projections' own (tokens, hidden) outputs, not on views of them
+        q = _RopeFn.apply(a["q_proj"].forward2d(h), cos, sin, B, T, H, D).view(B, T, H, D)
+        k = _RopeFn.apply(a["k_proj"].forward2d(h), cos, sin, B, T, H, D).view(B, T, H, D)
         v = a["v_proj"](h).view(B, T, H, D)
         ctx = _AttentionFn.apply(q, k, v, keep)
-        x1, h2 = _RMSNormFn.apply(x, a["o_proj"](ctx), self.post_attention_layernorm_weight, self.eps)
+        x1, h2 = _RMSNormFn.apply(x0, a["o_proj"](ctx), self.post_attention_layernorm_weight, self.eps)
         m = self.mlp
         y = m["down_proj"](_SwiGLUFn.apply(m["gate_proj"](h2), m["up_proj"](h2)))
+        if defer_residual:
+            return x1, y
         return x1 + y

@@ -72,17 +72,44 @@ def _quant_cached(x, x2):
     return c[0], c[1]
 
 
-_ws = {}
+_tables = {}
 
 
-def _grad_workspace(dev, floats):
-    """Partial sums of the weight-gradient row chunks (msr3d_lora_grad): one buffer per device and stream, grown
-    to the largest layer seen (64 chunks x r x 11008 floats = 45 MB at r = 16)."""
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
-    w = _ws.get(key)
-    if w is None or w.numel() < floats:
-        w = _ws[key] = torch.empty(floats, dtype=torch.float32, device=dev)
-    return w
+def refresh_shadows(mods, capturing=False):
+    """bf16 images of the LoRA pairs of `mods` (LoRALinear) in the four orientations the products read, ONE launch for
+    all of them (msr3d_lora_shadows) -- once per weight version, i.e. once per optimiser step; inside a graph capture
+    always (a replayed optimiser step changes A / B without running this host code again)."""
+    stale = [m for m in mods if capturing or m._shadow_key != m._pair_key()]
+    if not stale:
+        return
+    dev = stale[0].lora_A.weight.device
+    jobs = []
+    for m in stale:
+        A, Bw = m.lora_A.weight, m.lora_B.weight
+        r, K, N = m.r, m.in_features, m.out_features
+        sh = m._shadow
+        if sh is None or sh[0].device != A.device:
+            # allocated once: the padding columns r..63 of b2 / at2 are zero and stay zero
+            sh = m._shadow = (torch.empty((r, K), dtype=torch.bfloat16, device=dev),
+                              torch.zeros((N, PAD_R), dtype=torch.bfloat16, device=dev),
+                              torch.empty((r, N), dtype=torch.bfloat16, device=dev),
+                              torch.zeros((K, PAD_R), dtype=torch.bfloat16, device=dev))
+        jobs.append((A.data_ptr(), Bw.data_ptr(), sh[0].data_ptr(), sh[1].data_ptr(), sh[2].data_ptr(), sh[3].data_ptr(),
+                     r, K, N, 0))
+    key = tuple(jobs)
+    tab = _tables.get(key)
+    if tab is None:
+        if capturing:
+            raise RuntimeError("LoRA shadow table not built before the graph capture (run a warm-up step first)")
+        arr = (_lib.LoraShadowJob * len(jobs))(*[_lib.LoraShadowJob(*j) for j in jobs])
+        if len(_tables) > 64:
+            _tables.clear()
+        tab = _tables[key] = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().msr3d_lora_shadows(len(jobs), _p(tab), _lib.current_stream_ptr(dev))
+    _lib.check(rc, "msr3d_lora_shadows")
+    for m in stale:
+        m._shadow_key = "captured" if capturing else m._pair_key()
 
 
 class _LoRAFn(torch.autograd.Function):
@@ -148,12 +175,13 @@ class _LoRAFn(torch.autograd.Function):
             acc = 0
         with torch.cuda.device(dev):
             st = _lib.current_stream_ptr(dev)
-            # dA = (s dy B)^T x = v^T x ; dB = dy^T (s x A^T) = dy^T u   (s already inside u and v)
-            ws = _grad_workspace(dev, 64 * r * max(K, N))
-            rc = lib.msr3d_lora_grad(M, r, K, _p(v), PAD_R, _p(x2), K, _p(dA), 0, ctypes.c_float(1.0), acc, _p(ws), ws.numel(), st)
-            _lib.check(rc, "msr3d_lora_grad")
-            rc = lib.msr3d_lora_grad(M, r, N, _p(u), PAD_R, _p(dy2), N, _p(dB), 1, ctypes.c_float(1.0), acc, _p(ws), ws.numel(), st)
-            _lib.check(rc, "msr3d_lora_grad")
+            # dA = (s dy B)^T x = v^T x ; dB = dy^T (s x A^T) = dy^T u   (s already inside u and v): both in ONE launch,
+            # a workgroup per 64 output columns over all tokens -- no partial sums, no workspace
+            jobs = (_lib.LoraGradJob * 2)(
+                _lib.LoraGradJob(K, v.data_ptr(), PAD_R, x2.data_ptr(), K, dA.data_ptr(), 0),
+                _lib.LoraGradJob(N, u.data_ptr(), PAD_R, dy2.data_ptr(), N, dB.data_ptr(), 1))
+            rc = lib.msr3d_lora_grad_pair(M, r, 2, jobs, ctypes.c_float(1.0), acc, st)
+            _lib.check(rc, "msr3d_lora_grad_pair")
         if direct is not None:
             hipops._direct_done(direct)
             return dx, None, None, None
@@ -189,34 +217,29 @@ class LoRALinear(nn.Module):
         nn.init.kaiming_uniform_(self.lora_A.weight, a=math.sqrt(5))
         nn.init.zeros_(self.lora_B.weight)
         self._wt_version = None       # `weight._version` the transposed copy was made from
+        self._shadow, self._shadow_key = None, None
+        self._fresh_in_capture = False    # set by LoRALlamaStack around a captured forward (its one refresh launch)
 
     def _shadows(self, forward=False):
         """Zero-padded bf16 copies of A / B in the four orientations forward and backward read
         (a_pad (r, K), b2 (N, 64), bt_pad (r, N), at2 (K, 64)); rebuilt when A or B has been written."""
         A, Bw = self.lora_A.weight, self.lora_B.weight
-        key = (A._version, Bw._version, A.data_ptr(), Bw.data_ptr())
+        key = self._pair_key()
         # Inside a graph capture the copies are ALWAYS rebuilt (into the same storage): a replayed optimiser step
         # changes A / B without running this host code again, so the rebuild has to be part of the graph.
         capturing = forward and A.is_cuda and torch.cuda.is_current_stream_capturing()     # (backward reuses forward's)
         if getattr(self, "_shadow_key", None) == "captured" and not forward and A.is_cuda and \
                 torch.cuda.is_current_stream_capturing():
             return self._shadow                 # backward of the captured step: forward's copies
+        if capturing and self._fresh_in_capture:
+            return self._shadow                 # the enclosing stack rebuilt every pair at the top of this capture
         if capturing or getattr(self, "_shadow_key", None) != key:
-            r, K, N, dev = self.r, self.in_features, self.out_features, A.device
-            sh = getattr(self, "_shadow", None)
-            if sh is None or sh[0].device != dev:
-                # allocated once: the padding columns r..63 of b2 / at2 are zero and stay zero
-                sh = (torch.empty((r, K), dtype=torch.bfloat16, device=dev), torch.zeros((N, PAD_R), dtype=torch.bfloat16, device=dev),
-                      torch.empty((r, N), dtype=torch.bfloat16, device=dev), torch.zeros((K, PAD_R), dtype=torch.bfloat16, device=dev))
-                self._shadow = sh
-            a_pad, b2, bt_pad, at2 = sh
-            with torch.no_grad():               # four conversion launches per rebuild (it was nine ops with fresh buffers)
-                a_pad.copy_(A)
-                b2[:, :r].copy_(Bw)
-                bt_pad.copy_(Bw.t())
-                at2[:, :r].copy_(A.t())
-            self._shadow_key = "captured" if capturing else key
+            refresh_shadows([self], capturing)        # (a stack refreshes all of its pairs in one launch before this)
         return self._shadow
+
+    def _pair_key(self):
+        A, Bw = self.lora_A.weight, self.lora_B.weight
+        return (A._version, Bw._version, A.data_ptr(), Bw.data_ptr())
 
     def invalidate_shadows(self):
         """Force the bf16 copies of A / B to be rebuilt at the next forward / backward (for writers that changed
@@ -243,9 +266,14 @@ class LoRALinear(nn.Module):
         self.weight.copy_(w.to(torch.bfloat16))
         self._sync_weight_t()
 
-    def forward(self, x):
+    def forward2d(self, x):
+        """-> y (tokens, out_features): the autograd function's own output, NOT a view of it -- what a caller that goes
+        on IN PLACE (RoPE) must take: an in-place op on a view of a custom function's output makes autograd rebase the
+        view (CopySlices: two full copies per op in backward)."""
         if not x.is_cuda:
             raise RuntimeError("LoRALinear runs on the GPU only (no CPU fallback)")
         self._sync_weight_t()
-        y = _LoRAFn.apply(x.to(torch.bfloat16), self.lora_A.weight, self.lora_B.weight, self)
-        return y.view(*x.shape[:-1], self.out_features)
+        return _LoRAFn.apply(x.to(torch.bfloat16), self.lora_A.weight, self.lora_B.weight, self)
+
+    def forward(self, x):
+        return self.forward2d(x).view(*x.shape[:-1], self.out_features)

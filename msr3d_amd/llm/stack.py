@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from .. import _lib
 from .decoder import LoRALlamaDecoderLayer, _RMSNormFn
+from .lora import LoRALinear, refresh_shadows
 from .losses import seq_mean_cross_entropy
 
 
@@ -99,15 +100,34 @@ class LoRALlamaStack(nn.Module):
         self.register_buffer("norm_weight", torch.ones(hidden_size, dtype=torch.bfloat16, device=device))
         self.lm_head = FrozenLinear(hidden_size, vocab_size, device=device)
         self.eps = rms_eps
+        self._lora_mods = None
 
     def lora_parameters(self):
         return [p for p in self.parameters() if p.requires_grad]
 
+    def _pairs(self):
+        if self._lora_mods is None:
+            self._lora_mods = [m for m in self.modules() if isinstance(m, LoRALinear)]
+        return self._lora_mods
+
     def logits(self, inputs_embeds, attention_mask=None):
         x = inputs_embeds.to(torch.bfloat16)
-        for layer in self.layers:
-            x = layer(x, attention_mask=attention_mask)
-        _, h = _RMSNormFn.apply(x, None, self.norm_weight, self.eps)
+        # the bf16 images of all 7 x layers LoRA pairs: ONE launch per optimiser step (224 pairs x 4 copies before)
+        mods = self._pairs()
+        capturing = x.is_cuda and torch.cuda.is_current_stream_capturing()
+        refresh_shadows(mods, capturing)
+        keep = None if attention_mask is None else attention_mask.to(torch.uint8).contiguous()     # once, not per layer
+        for m in mods:
+            m._fresh_in_capture = capturing
+        try:
+            delta = None
+            for layer in self.layers:
+                # the residual sum x + mlp(x) is left to the NEXT layer's input norm (one fused launch, no add kernel)
+                x, delta = layer(x, attention_mask=keep, delta=delta, defer_residual=True)
+            _, h = _RMSNormFn.apply(x, delta, self.norm_weight, self.eps)
+        finally:
+            for m in mods:
+                m._fresh_in_capture = False
         return self.lm_head(h)
 
     def forward(self, inputs_embeds, attention_mask=None, targets=None):

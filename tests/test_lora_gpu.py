@@ -134,3 +134,74 @@ def test_wide_gemm_exact_on_integer_operands_run_after_run(M, N, K, R):
                                          vp(Q2) if R else None, Q2.shape[1], vp(C), N, 1, ctypes.c_float(1.0), st)
         _lib.check(rc, "msr3d_bf16_gemm_lowrank")
         assert torch.equal(C, want)
+
+
+@pytest.mark.parametrize("M,K,N,r,njobs", [(2304, 4096, 11008, 16, 2), (576, 512, 1024, 16, 2), (100, 256, 72, 32, 2),
+                                            (2304, 4096, 4096, 16, 1), (64, 128, 128, 16, 2), (1031, 136, 264, 16, 2)])
+def test_lora_grad_pair_one_launch_bit_reproducible(M, K, N, r, njobs):
+    """msr3d_lora_grad_pair: dA = v^T x and dB^T = u^T dy in ONE launch, a workgroup per 64 output columns over all
+    tokens: vs float64, accumulate on / off, ragged token counts, run-to-run identical."""
+    import ctypes
+
+    from msr3d_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    bf = lambda *s: torch.randn(*s, generator=g, device="cuda").to(torch.bfloat16)      # noqa: E731
+    v, u = torch.zeros(M, 64, dtype=torch.bfloat16, device="cuda"), torch.zeros(M, 64, dtype=torch.bfloat16, device="cuda")
+    v[:, :r], u[:, :r] = bf(M, r), bf(M, r)
+    x, dy = bf(M, K), bf(M, N)
+    st = _lib.current_stream_ptr(torch.device("cuda:0"))
+    refA = (v[:, :r].double().t() @ x.double())
+    refB = (dy.double().t() @ u[:, :r].double())
+    outs = []
+    for acc in (0, 1, 1):
+        dA = torch.full((r, K), 3.0, device="cuda")
+        dB = torch.full((N, r), -2.0, device="cuda")
+        jobs = (_lib.LoraGradJob * 2)(_lib.LoraGradJob(K, v.data_ptr(), 64, x.data_ptr(), K, dA.data_ptr(), 0),
+                                      _lib.LoraGradJob(N, u.data_ptr(), 64, dy.data_ptr(), N, dB.data_ptr(), 1))
+        assert lib.msr3d_lora_grad_pair(M, r, njobs, jobs, ctypes.c_float(0.5), acc, st) == 0
+        torch.cuda.synchronize()
+        base = 3.0 if acc else 0.0
+        err = (dA.double() - (base + 0.5 * refA)).abs().max() / refA.abs().max()
+        assert err < 2e-6, err
+        if njobs == 2:
+            base = -2.0 if acc else 0.0
+            err = (dB.double() - (base + 0.5 * refB)).abs().max() / refB.abs().max()
+            assert err < 2e-6, err
+        else:
+            assert torch.all(dB == -2.0)
+        outs.append((dA.clone(), dB.clone()))
+    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
+    # argument checks: C not a multiple of 8, a misaligned operand, three jobs
+    bad = (_lib.LoraGradJob * 2)(_lib.LoraGradJob(K - 4, v.data_ptr(), 64, x.data_ptr(), K, dA.data_ptr(), 0), jobs[1])
+    assert lib.msr3d_lora_grad_pair(M, r, 2, bad, ctypes.c_float(1.0), 1, st) == -22
+    bad = (_lib.LoraGradJob * 2)(_lib.LoraGradJob(K, v.data_ptr() + 2, 64, x.data_ptr(), K, dA.data_ptr(), 0), jobs[1])
+    assert lib.msr3d_lora_grad_pair(M, r, 2, bad, ctypes.c_float(1.0), 1, st) == -22
+    assert lib.msr3d_lora_grad_pair(M, r, 3, jobs, ctypes.c_float(1.0), 1, st) == -22
+
+
+def test_lora_shadows_one_launch_for_all_pairs():
+    """msr3d_lora_shadows via lora.refresh_shadows: the four bf16 images of several pairs at once == the per-tensor
+    conversions; rebuilt only when A / B were written; padding columns stay zero."""
+    from msr3d_amd.llm import lora
+    torch.manual_seed(0)
+    mods = [lora.LoRALinear(256, 512, r=16, device="cuda"), lora.LoRALinear(512, 128, r=32, device="cuda"),
+            lora.LoRALinear(4096, 11008, r=16, device="cuda")]
+    for m in mods:
+        with torch.no_grad():
+            m.lora_B.weight.normal_()
+    lora.refresh_shadows(mods)
+    for m in mods:
+        a_pad, b2, bt_pad, at2 = m._shadow
+        A, Bw, r = m.lora_A.weight.detach(), m.lora_B.weight.detach(), m.r
+        assert torch.equal(a_pad, A.to(torch.bfloat16)) and torch.equal(bt_pad, Bw.t().to(torch.bfloat16))
+        assert torch.equal(b2[:, :r], Bw.to(torch.bfloat16)) and torch.equal(at2[:, :r], A.t().to(torch.bfloat16))
+        assert not b2[:, r:].any() and not at2[:, r:].any()
+        assert m._shadow_key == m._pair_key()
+    keep = mods[0]._shadow[0].clone()
+    with torch.no_grad():
+        mods[1].lora_A.weight.mul_(2.0)                 # only this pair is stale now
+    lora.refresh_shadows(mods)
+    assert torch.equal(mods[0]._shadow[0], keep)
+    assert torch.equal(mods[1]._shadow[0], mods[1].lora_A.weight.detach().to(torch.bfloat16))
+    assert mods[1]._shadows()[0] is mods[1]._shadow[0]
