@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 17
+#define MSR3D_ABI_VERSION 18
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -807,6 +807,19 @@ int msr3d_swiglu_bwd(long long n, const void *gate, const void *up, const void *
 int msr3d_transpose_bf16(int outer, int inner, int rows, int cols, const void *src, int ld_src, long long src_outer,
                          long long src_inner, void *dst, int ld_dst, long long dst_outer, long long dst_inner,
                          msr3d_stream_t stream);
+
+/* Causal self-attention of a decoder layer, fused (csrc/llm_attn.hip; transformers' LlamaAttention as the LLM of
+ * model/msr3d/msr3d.py:409-415 runs it: softmax(scale q k^T + causal + key padding) v per sequence and head).
+ * q, k, v, out, dout, dq, dk, dv: (B, T, H, D) bf16 token-major, row stride ld >= H D (ld % 8 == 0), RoPE already
+ * applied; D = 64 or 128; T % 64 == 0.  key_keep (B, T) bytes, 0 = padded key, or NULL.  lse, delta: (B, H, T) fp32 --
+ * the rows' log2-sum-exp2 (forward output; +inf for a row with no visible key, whose output is 0) and rowsum(dout * out)
+ * (written by the backward).  The scores stay in registers (online softmax forward; the backward recomputes the
+ * probabilities from lse: one kernel for dq, one for dk / dv, every output row has one owner -- no atomics). */
+int msr3d_attn_fwd(int B, int T, int H, int D, const void *q, const void *k, const void *v, int ld,
+                   const unsigned char *key_keep, float scale, void *out, float *lse, msr3d_stream_t stream);
+int msr3d_attn_bwd(int B, int T, int H, int D, const void *q, const void *k, const void *v, const void *out,
+                   const void *dout, int ld, const unsigned char *key_keep, float scale, const float *lse, float *delta,
+                   void *dq, void *dk, void *dv, msr3d_stream_t stream);
 
 /* C (M, N) = scale * P Q^T for a Q of N <= 64 rows (N % 16 == 0; the LoRA down-projections x A^T and dy B), and
  * C[:, N:zero_to] = 0 (the padding the low-rank K step of msr3d_bf16_gemm_lowrank reads).  P (M, K), Q (N, K)

@@ -137,6 +137,9 @@ _SIGNATURES = {
                         ctypes.c_longlong, _ptr],
     "msr3d_lora_grad_pair": [_c_int, _c_int, _c_int, ctypes.POINTER(LoraGradJob), _c_float, _c_int, _ptr],
     "msr3d_lora_shadows": [_c_int, _ptr, _ptr],
+    "msr3d_attn_fwd": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _c_int, _ptr, _c_float, _ptr, _ptr, _ptr],
+    "msr3d_attn_bwd": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _c_float, _ptr, _ptr,
+                       _ptr, _ptr, _ptr, _ptr],
     "msr3d_sa_level_split": [_c_int, _c_int, _c_int, _c_int, _c_float] + [_ptr] * 13,
     "msr3d_seq_ce_fwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_seq_ce_bwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
@@ -220,7 +223,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string", "msr3d_sqdist_contract"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 17        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 18        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():

@@ -39,6 +39,7 @@ SOURCES = [
     ("lora_linear.hip", []),
     ("lora_fp8.hip", []),
     ("llm_layer.hip", []),
+    ("llm_attn.hip", []),
     ("prompter_rows.hip", ["-ffp-contract=off"]),
     ("scene_block.hip", []),
     ("scene_rows.hip", []),

@@ -7,9 +7,8 @@ transformers.models.llama.modeling_llama.LlamaDecoderLayer with eager attention:
     x = x + o_proj(P v); h = RMSNorm(x); x = x + down_proj(silu(gate_proj(h)) * up_proj(h))
 
 with every projection a LoRALinear (msr3d_bf16_gemm_lowrank: frozen bf16 weight + rank-r update riding as one
-extra K step), the per-(sequence, head) products of the attention on msr3d_bf16_gemm_batched (the scores of a
-576-token sequence are 85 MB per layer on a 288 GB part: no tiling of the softmax needed; the attention is 2 %
-of the layer's FLOPs), and the row-local pieces on csrc/llm_layer.hip.  bf16 storage, fp32 accumulation.
+extra K step), the attention fused (msr3d_attn_fwd / _bwd, csrc/llm_attn.hip: the scores never leave the registers),
+and the row-local pieces on csrc/llm_layer.hip.  bf16 storage, fp32 accumulation.
 Forward + backward: dx, and dA / dB of the seven LoRA pairs (the base weights and norm weights are frozen).
 GPU only."""
 import ctypes
@@ -100,76 +99,43 @@ class _RopeFn(torch.autograd.Function):
         return g, None, None, None, None, None, None
 
 
-def _bgemm(dev, B, H, M, N, K, P, ldp, po, pi, Q, ldq, qo, qi, C, ldc, co, ci, c_f32, scale):
-    with torch.cuda.device(dev):
-        _call("msr3d_bf16_gemm_batched", B, H, M, N, K, _p(P), ldp, po, pi, _p(Q), ldq, qo, qi, _p(C), ldc, co, ci,
-              int(c_f32), ctypes.c_float(scale), _st(dev))
-
-
-def _transpose(dev, B, H, rows, cols, src, lds, so, si, dst, ldd, do, di):
-    with torch.cuda.device(dev):
-        _call("msr3d_transpose_bf16", B, H, rows, cols, _p(src), lds, so, si, _p(dst), ldd, do, di, _st(dev))
-
-
 class _AttentionFn(torch.autograd.Function):
-    """q, k, v (B, T, H, D) bf16 (RoPE applied), keep (B, T) uint8 or None -> context (B, T, H D) bf16."""
+    """q, k, v (B, T, H, D) bf16 (RoPE applied), keep (B, T) uint8 or None -> context (B, T, H D) bf16.
+    Fused (csrc/llm_attn.hip): the scores stay in registers -- online softmax forward, the row's log-sum-exp kept; the
+    backward recomputes the probabilities from it (one kernel for dq, one for dk / dv).  Round 4 ran seven batched
+    GEMMs, two softmax launches and six transposes per layer through 85 MB of fp32 scores."""
 
     @staticmethod
     def forward(ctx, q, k, v, keep):
         B, T, H, D = q.shape
-        if T % 64 or D % 64:
-            raise ValueError("attention: sequence length and head size must be multiples of 64")
+        if T % 64 or D not in (64, 128):
+            raise ValueError("attention: sequence length a multiple of 64, head size 64 or 128")
+        for t in (q, k, v):
+            if not t.is_contiguous():
+                raise RuntimeError("attention: contiguous (B, T, H, D) tensors expected")
         dev, HD = q.device, H * D
         scale = 1.0 / math.sqrt(D)
-        S = torch.empty((B, H, T, T), dtype=torch.float32, device=dev)
-        # scores[b, h] = scale q_h k_h^T: rows of (B, T, H D), head h at column offset h D
-        _bgemm(dev, B, H, T, T, D, q, HD, T * HD, D, k, HD, T * HD, D, S, T, H * T * T, T * T, True, scale)
-        P = torch.empty((B, H, T, T), dtype=torch.bfloat16, device=dev)
-        with torch.cuda.device(dev):
-            _call("msr3d_causal_softmax_fwd", B, H, T, _p(S), _p(keep), _p(P), _st(dev))
-        del S
-        vt = torch.empty((B, H, D, T), dtype=torch.bfloat16, device=dev)       # v_h^T: the contraction index contiguous
-        _transpose(dev, B, H, T, D, v, HD, T * HD, D, vt, T, H * D * T, D * T)
         out = torch.empty((B, T, HD), dtype=torch.bfloat16, device=dev)
-        _bgemm(dev, B, H, T, D, T, P, T, H * T * T, T * T, vt, T, H * D * T, D * T, out, HD, T * HD, D, False, 1.0)
-        ctx.save_for_backward(q, k, v, P)
+        lse = torch.empty((B, H, T), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _call("msr3d_attn_fwd", B, T, H, D, _p(q), _p(k), _p(v), HD, _p(keep), ctypes.c_float(scale), _p(out), _p(lse),
+                  _st(dev))
+        ctx.save_for_backward(q, k, v, out, lse, keep)
         ctx.scale = scale
         return out
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, P = ctx.saved_tensors
+        q, k, v, out, lse, keep = ctx.saved_tensors
         B, T, H, D = q.shape
-        dev, HD, scale = q.device, H * D, ctx.scale
+        dev, HD = q.device, H * D
         do = do.reshape(B, T, HD)
         do = do if do.is_contiguous() else do.contiguous()
-        bf = dict(dtype=torch.bfloat16, device=dev)
-        # dP = dO V^T (no transposes: both operands have D contiguous); dS = softmax backward
-        dP = torch.empty((B, H, T, T), dtype=torch.float32, device=dev)
-        _bgemm(dev, B, H, T, T, D, do, HD, T * HD, D, v, HD, T * HD, D, dP, T, H * T * T, T * T, True, 1.0)
-        dS = torch.empty((B, H, T, T), **bf)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty_like(lse)
         with torch.cuda.device(dev):
-            _call("msr3d_causal_softmax_bwd", B, H, T, _p(dP), _p(P), _p(dS), _st(dev))
-        del dP
-        # dV = P^T dO
-        Pt = torch.empty((B, H, T, T), **bf)
-        _transpose(dev, B, H, T, T, P, T, H * T * T, T * T, Pt, T, H * T * T, T * T)
-        dot = torch.empty((B, H, D, T), **bf)
-        _transpose(dev, B, H, T, D, do, HD, T * HD, D, dot, T, H * D * T, D * T)
-        dv = torch.empty((B, T, H, D), **bf)
-        _bgemm(dev, B, H, T, D, T, Pt, T, H * T * T, T * T, dot, T, H * D * T, D * T, dv, HD, T * HD, D, False, 1.0)
-        del Pt, dot
-        # dQ = scale dS K ; dK = scale dS^T Q
-        kt = torch.empty((B, H, D, T), **bf)
-        _transpose(dev, B, H, T, D, k, HD, T * HD, D, kt, T, H * D * T, D * T)
-        dq = torch.empty((B, T, H, D), **bf)
-        _bgemm(dev, B, H, T, D, T, dS, T, H * T * T, T * T, kt, T, H * D * T, D * T, dq, HD, T * HD, D, False, scale)
-        dSt = torch.empty((B, H, T, T), **bf)
-        _transpose(dev, B, H, T, T, dS, T, H * T * T, T * T, dSt, T, H * T * T, T * T)
-        qt = kt
-        _transpose(dev, B, H, T, D, q, HD, T * HD, D, qt, T, H * D * T, D * T)
-        dk = torch.empty((B, T, H, D), **bf)
-        _bgemm(dev, B, H, T, D, T, dSt, T, H * T * T, T * T, qt, T, H * D * T, D * T, dk, HD, T * HD, D, False, scale)
+            _call("msr3d_attn_bwd", B, T, H, D, _p(q), _p(k), _p(v), _p(out), _p(do), HD, _p(keep), ctypes.c_float(ctx.scale),
+                  _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _st(dev))
         return dq, dk, dv, None
 
 

@@ -186,3 +186,60 @@ def test_projection_gemm_throughput(M):
     tf = 2.0 * M * N * (K + 32 + 128) / (ms * 1e-3) / 1e12
     print(f"\nLoRALinear forward M={M} K=N=4096: {ms * 1e3:.1f} us = {tf:.0f} TFLOP/s = {tf / 2500:.1%} of the bf16 dense peak")
     assert tf > 150
+
+
+@pytest.mark.parametrize("B,T,H,D,pad", [(2, 192, 3, 128, (0, 37)), (1, 576, 2, 128, (60,)), (2, 128, 4, 64, (0, 0)),
+                                          (3, 64, 1, 64, (5, 0, 63))])
+def test_fused_attention_forward_backward_vs_float64(B, T, H, D, pad):
+    """msr3d_attn_fwd / _bwd (csrc/llm_attn.hip) == softmax(q k^T / sqrt(D) + causal + key padding) v in float64 on the
+    same bf16 operands: output, log-sum-exp, dq / dk / dv; left-padded sequences (rows with no visible key give zeros and
+    take no gradient); bit-identical run to run (every output row has one owner)."""
+    import ctypes
+    import math
+
+    from msr3d_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + T + D)
+    mk = lambda: (torch.randn(B, T, H, D, generator=g, device="cuda") * 1.5).to(torch.bfloat16)      # noqa: E731
+    q, k, v, do = mk(), mk(), mk(), mk()
+    keep = torch.ones(B, T, dtype=torch.uint8, device="cuda")
+    for b, n in enumerate(pad):
+        keep[b, :n] = 0
+    scale = 1.0 / math.sqrt(D)
+    st = _lib.current_stream_ptr(torch.device("cuda"))
+    HD = H * D
+
+    def run():
+        out = torch.empty(B, T, HD, dtype=torch.bfloat16, device="cuda")
+        lse = torch.empty(B, H, T, device="cuda")
+        _call("msr3d_attn_fwd", B, T, H, D, _p(q), _p(k), _p(v), HD, _p(keep), ctypes.c_float(scale), _p(out), _p(lse), st)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty_like(lse)
+        _call("msr3d_attn_bwd", B, T, H, D, _p(q), _p(k), _p(v), _p(out), _p(do), HD, _p(keep), ctypes.c_float(scale),
+              _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), st)
+        torch.cuda.synchronize()
+        return out, lse, dq, dk, dv
+
+    out, lse, dq, dk, dv = run()
+    qd, kd, vd = (t.double().permute(0, 2, 1, 3).requires_grad_(True) for t in (q, k, v))      # (B, H, T, D)
+    S = (qd @ kd.transpose(-1, -2)) * scale
+    vis = torch.tril(torch.ones(T, T, dtype=torch.bool, device="cuda"))[None, None] & keep.bool()[:, None, None, :]
+    Pm = torch.softmax(S.masked_fill(~vis, float("-inf")), -1).nan_to_num(0.0)
+    ref = (Pm @ vd).permute(0, 2, 1, 3).reshape(B, T, HD)
+    assert rel(out, ref) < 4e-3
+    dead = ~vis.any(-1)                                                  # (B, 1, T) rows with no visible key
+    assert float(out.float().view(B, T, H, D)[dead[:, 0]].abs().max() if dead.any() else 0.0) == 0.0
+    want_lse = torch.logsumexp(S.masked_fill(~vis, float("-inf")), -1) / math.log(2.0)
+    live = ~dead.expand(B, H, T)
+    assert float((lse.double() - want_lse)[live].abs().max()) < 2e-3
+    assert bool(torch.isinf(lse[~live]).all())
+    ref.backward(do.double().reshape(B, T, HD))
+    for got, want in ((dq, qd.grad), (dk, kd.grad), (dv, vd.grad)):
+        assert rel(got, want.permute(0, 2, 1, 3)) < 8e-3
+    again = run()
+    for x, y in zip((out, lse, dq, dk, dv), again):
+        assert torch.equal(x, y)
+    # refused shapes: T not a multiple of 64, head size 96
+    assert _lib.load().msr3d_attn_fwd(B, T - 8, H, D, _p(q), _p(k), _p(v), HD, _p(keep), ctypes.c_float(scale), _p(out),
+                                      _p(lse), st) == -22
+    assert _lib.load().msr3d_attn_fwd(B, T, H, 96, _p(q), _p(k), _p(v), HD, _p(keep), ctypes.c_float(scale), _p(out),
+                                      _p(lse), st) == -22
