@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 18
+#define MSR3D_ABI_VERSION 19
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -797,6 +797,9 @@ int msr3d_rmsnorm_bwd(int M, int D, const void *dy, const void *s, const void *w
                       const void *dres, void *dx, msr3d_stream_t stream);
 int msr3d_rope_inplace(int B, int T, int H, int D, void *x, const float *cos_td, const float *sin_td, int transpose,
                        msr3d_stream_t stream);
+/* the same rotation on TWO tensors of one shape (q and k of a decoder layer) in one launch */
+int msr3d_rope_inplace2(int B, int T, int H, int D, void *x0, void *x1, const float *cos_td, const float *sin_td,
+                        int transpose, msr3d_stream_t stream);
 int msr3d_causal_softmax_fwd(int B, int H, int T, const float *scores, const unsigned char *key_keep, void *probs,
                              msr3d_stream_t stream);
 int msr3d_causal_softmax_bwd(int B, int H, int T, const float *dprobs, const void *probs, void *dscores,

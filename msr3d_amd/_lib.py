@@ -125,6 +125,7 @@ _SIGNATURES = {
     "msr3d_rmsnorm_fwd": [_c_int, _c_int, _ptr, _ptr, _ptr, _c_float, _ptr, _ptr, _ptr, _ptr],
     "msr3d_rmsnorm_bwd": [_c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_rope_inplace": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _c_int, _ptr],
+    "msr3d_rope_inplace2": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_int, _ptr],
     "msr3d_causal_softmax_fwd": [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
     "msr3d_causal_softmax_bwd": [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
     "msr3d_swiglu_fwd": [ctypes.c_longlong, _ptr, _ptr, _ptr, _ptr],
@@ -223,7 +224,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string", "msr3d_sqdist_contract"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 18        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 19        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():

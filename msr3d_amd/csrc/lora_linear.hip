@@ -806,6 +806,8 @@ __global__ __launch_bounds__(256) void lora_shadows_kernel(const msr3d_lora_shad
 // workgroup owns 16 rows of P, its four waves each a quarter of K, fragments loaded straight from global memory
 // (P is read once; the 16 x K operand Q stays in L2), and the four partial tiles meet in LDS.
 constexpr int kSkinnyWaves = 8;      // two per SIMD, each an eighth of K (round 3: four)
+// (Measured and dropped: 8 rows per workgroup, half of the MFMA tile empty, so that 2304 tokens are 288 workgroups
+// instead of 144 on 256 CUs -- 19 us against 13 per call.)
 template <int NT>
 __global__ __launch_bounds__(64 * kSkinnyWaves) void bf16_gemm_skinny_kernel(int M, int N, int K, const unsigned short *__restrict__ P,
                                                                int ldp, const unsigned short *__restrict__ Q, int ldq,
@@ -1087,9 +1089,9 @@ int msr3d_bf16_gemm_skinny(int M, int N, int K, const void *P, int ldp, const vo
       (reinterpret_cast<uintptr_t>(C) & 7u))
     return MSR3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int grid = (M + 15) / 16;
   const unsigned short *p = (const unsigned short *)P, *q = (const unsigned short *)Q;
   unsigned short *c = (unsigned short *)C;
+  const int grid = (M + 15) / 16;
   switch (N / 16) {
     case 1: bf16_gemm_skinny_kernel<1><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
     case 2: bf16_gemm_skinny_kernel<2><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;

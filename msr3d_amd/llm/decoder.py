@@ -99,6 +99,31 @@ class _RopeFn(torch.autograd.Function):
         return g, None, None, None, None, None, None
 
 
+class _Rope2Fn(torch.autograd.Function):
+    """_RopeFn on q AND k in one launch each way (msr3d_rope_inplace2)."""
+
+    @staticmethod
+    def forward(ctx, q, k, cos, sin, B, T, H, D):
+        for x in (q, k):
+            if not x.is_contiguous() or x.numel() != B * T * H * D:
+                raise RuntimeError("_Rope2Fn: contiguous (B T, H D) tensors expected")
+        with torch.cuda.device(q.device):
+            _call("msr3d_rope_inplace2", B, T, H, D, _p(q), _p(k), _p(cos), _p(sin), 0, _st(q.device))
+        ctx.mark_dirty(q, k)
+        ctx.save_for_backward(cos, sin)
+        ctx.dims = (B, T, H, D)
+        return q, k
+
+    @staticmethod
+    def backward(ctx, gq, gk):
+        cos, sin = ctx.saved_tensors
+        B, T, H, D = ctx.dims
+        gq, gk = gq.contiguous(), gk.contiguous()
+        with torch.cuda.device(gq.device):
+            _call("msr3d_rope_inplace2", B, T, H, D, _p(gq), _p(gk), _p(cos), _p(sin), 1, _st(gq.device))
+        return gq, gk, None, None, None, None, None, None
+
+
 class _AttentionFn(torch.autograd.Function):
     """q, k, v (B, T, H, D) bf16 (RoPE applied), keep (B, T) uint8 or None -> context (B, T, H D) bf16.
     Fused (csrc/llm_attn.hip): the scores stay in registers -- online softmax forward, the row's log-sum-exp kept; the
@@ -211,8 +236,8 @@ class LoRALlamaDecoderLayer(nn.Module):
         # gradient arrives in one piece through the norm's backward)
         x0, h = _RMSNormFn.apply(x, delta, self.input_layernorm_weight, self.eps)
         # RoPE in place on the projections' own (tokens, hidden) outputs, not on views of them
-        q = _RopeFn.apply(a["q_proj"].forward2d(h), cos, sin, B, T, H, D).view(B, T, H, D)
-        k = _RopeFn.apply(a["k_proj"].forward2d(h), cos, sin, B, T, H, D).view(B, T, H, D)
+        q, k = _Rope2Fn.apply(a["q_proj"].forward2d(h), a["k_proj"].forward2d(h), cos, sin, B, T, H, D)
+        q, k = q.view(B, T, H, D), k.view(B, T, H, D)
         v = a["v_proj"](h).view(B, T, H, D)
         ctx = _AttentionFn.apply(q, k, v, keep)
         x1, h2 = _RMSNormFn.apply(x0, a["o_proj"](ctx), self.post_attention_layernorm_weight, self.eps)

@@ -111,6 +111,22 @@ def test_rope_is_the_reference_rotation_and_its_transpose():
     gt = g.clone()
     _call("msr3d_rope_inplace", B, T, H, D, _p(gt), _p(cos), _p(sin), 1, st)
     assert abs(float((gt.double() * xd).sum() - (g.double() * want).sum())) < 2e-2 * float((g.double() * want).abs().sum()) ** 0.5 + 1.0
+    # every launch shape: heads in groups of four (above), single heads (H = 3), the pair-per-thread kernel (D = 24), and
+    # two tensors in one launch == one after the other
+    for Bx, Tx, Hx, Dx in ((1, 64, 3, 64), (2, 10, 2, 24), (1, 32, 8, 128)):
+        xa = torch.randn(Bx, Tx, Hx, Dx, device="cuda").bfloat16()
+        xb = torch.randn(Bx, Tx, Hx, Dx, device="cuda").bfloat16()
+        cs, sn = rope_tables(Tx, Dx, 10000.0, "cuda")
+        for tr in (0, 1):
+            one_a, one_b, two_a, two_b = xa.clone(), xb.clone(), xa.clone(), xb.clone()
+            _call("msr3d_rope_inplace", Bx, Tx, Hx, Dx, _p(one_a), _p(cs), _p(sn), tr, st)
+            _call("msr3d_rope_inplace", Bx, Tx, Hx, Dx, _p(one_b), _p(cs), _p(sn), tr, st)
+            _call("msr3d_rope_inplace2", Bx, Tx, Hx, Dx, _p(two_a), _p(two_b), _p(cs), _p(sn), tr, st)
+            assert torch.equal(one_a, two_a) and torch.equal(one_b, two_b)
+            xd2 = xa.double()
+            rot2 = torch.cat([-xd2[..., Dx // 2:], xd2[..., :Dx // 2]], -1)
+            sgn = -1.0 if tr else 1.0
+            assert rel(one_a, xd2 * cs.double()[None, :, None] + sgn * rot2 * sn.double()[None, :, None]) < 3e-3
 
 
 def test_causal_softmax_and_swiglu_vs_float64():

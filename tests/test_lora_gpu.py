@@ -18,7 +18,7 @@ def bf(t):
 
 
 @pytest.mark.parametrize("M,K,N,r", [(2304, 4096, 4096, 16), (300, 4096, 11008, 16), (129, 11008, 4096, 16),
-                                     (64, 256, 192, 32)])
+                                     (64, 256, 192, 32), (4000, 512, 256, 16)])      # (>= 3584 rows: 16-row skinny tiles)
 def test_lora_linear_matches_the_float64_formulation(M, K, N, r):
     from msr3d_amd.llm import LoRALinear
     torch.manual_seed(M + N)
