@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
-from .lora import LoRALinear
+from .lora import LoRALinear, group_inputs
 
 
 def _p(t):
@@ -210,6 +210,9 @@ class LoRALlamaDecoderLayer(nn.Module):
                                             v_proj=mk(hidden_size, hidden_size), o_proj=mk(hidden_size, hidden_size)))
         self.mlp = nn.ModuleDict(dict(gate_proj=mk(hidden_size, intermediate_size), up_proj=mk(hidden_size, intermediate_size),
                                       down_proj=mk(intermediate_size, hidden_size)))
+        if device is not None and torch.device(device).type == "cuda":
+            group_inputs([self.self_attn[n] for n in ("q_proj", "k_proj", "v_proj")])      # one x A^T product per input
+            group_inputs([self.mlp[n] for n in ("gate_proj", "up_proj")])
         self.register_buffer("input_layernorm_weight", torch.ones(hidden_size, dtype=torch.bfloat16, device=device))
         self.register_buffer("post_attention_layernorm_weight", torch.ones(hidden_size, dtype=torch.bfloat16, device=device))
         self._rope = None

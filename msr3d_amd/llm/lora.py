@@ -75,6 +75,26 @@ def _quant_cached(x, x2):
 _tables = {}
 
 
+def group_inputs(mods):
+    """Declare that `mods` (LoRALinear, same in_features / r / scaling / device) always read the SAME input tensor (q / k / v,
+    gate / up): their A matrices' bf16 images are stacked into one (n r, K) operand, so ONE r-row product s x [A_1; ..; A_n]^T
+    serves all of them (n r <= 64 columns of the shared (M, 64) low-rank activation; member i's B image sits in columns
+    i r .. of ITS zero-padded (N, 64) operand, so its GEMM picks out its own slice).  Reads the input once instead of n times."""
+    m0 = mods[0]
+    r, K, dev = m0.r, m0.in_features, m0.lora_A.weight.device
+    if len(mods) * r > PAD_R or any(m.r != r or m.in_features != K or m.scaling != m0.scaling or
+                                    m.lora_A.weight.device != dev for m in mods):
+        raise ValueError("group_inputs: members must share in_features, r, scaling and device, n r <= 64")
+    a_cat = torch.empty((len(mods) * r, K), dtype=torch.bfloat16, device=dev)
+    grp = {"a_cat": a_cat, "mods": list(mods)}
+    for i, m in enumerate(mods):
+        N = m.out_features
+        m._shadow = (a_cat[i * r:(i + 1) * r], torch.zeros((N, PAD_R), dtype=torch.bfloat16, device=dev),
+                     torch.empty((r, N), dtype=torch.bfloat16, device=dev), torch.zeros((K, PAD_R), dtype=torch.bfloat16, device=dev))
+        m._shadow_key = None
+        m._group, m._u_col = grp, i * r
+
+
 def refresh_shadows(mods, capturing=False):
     """bf16 images of the LoRA pairs of `mods` (LoRALinear) in the four orientations the products read, ONE launch for
     all of them (msr3d_lora_shadows) -- once per weight version, i.e. once per optimiser step; inside a graph capture
@@ -89,13 +109,14 @@ def refresh_shadows(mods, capturing=False):
         r, K, N = m.r, m.in_features, m.out_features
         sh = m._shadow
         if sh is None or sh[0].device != A.device:
+            m._group, m._u_col = None, 0          # (a module moved to another device leaves its input group)
             # allocated once: the padding columns r..63 of b2 / at2 are zero and stay zero
             sh = m._shadow = (torch.empty((r, K), dtype=torch.bfloat16, device=dev),
                               torch.zeros((N, PAD_R), dtype=torch.bfloat16, device=dev),
                               torch.empty((r, N), dtype=torch.bfloat16, device=dev),
                               torch.zeros((K, PAD_R), dtype=torch.bfloat16, device=dev))
-        jobs.append((A.data_ptr(), Bw.data_ptr(), sh[0].data_ptr(), sh[1].data_ptr(), sh[2].data_ptr(), sh[3].data_ptr(),
-                     r, K, N, 0))
+        jobs.append((A.data_ptr(), Bw.data_ptr(), sh[0].data_ptr(), sh[1].data_ptr() + 2 * m._u_col, sh[2].data_ptr(),
+                     sh[3].data_ptr(), r, K, N, 0))
     key = tuple(jobs)
     tab = _tables.get(key)
     if tab is None:
@@ -122,9 +143,23 @@ class _LoRAFn(torch.autograd.Function):
         # bf16 shadows of the trainable pair in the orientations the products read: built once per weight
         # version (i.e. once per optimiser step), not per call
         a_pad, b2, _, _ = mod._shadows(forward=True)
-        # u = s x A^T  (M, r) bf16 in a zero-padded (M, 64): the r-row product has its own kernel
-        u = torch.empty((M, PAD_R), dtype=torch.bfloat16, device=dev)
-        _skinny(M, r, K, x2, a_pad, u, PAD_R, s, dev)
+        # u = s x A^T  (M, r) bf16 in a zero-padded (M, 64): the r-row product has its own kernel; members of an input
+        # group (q / k / v, gate / up) share ONE product over their stacked A's, cached on the input tensor they share
+        grp, col = mod._group, mod._u_col
+        if grp is not None:
+            c = getattr(x, "_msr3d_u", None)
+            if c is None or c[1] != x._version or c[2] is not grp:
+                u = torch.empty((M, PAD_R), dtype=torch.bfloat16, device=dev)
+                _skinny(M, grp["a_cat"].shape[0], K, x2, grp["a_cat"], u, PAD_R, s, dev)
+                c = (u, x._version, grp)
+                try:
+                    x._msr3d_u = c
+                except AttributeError:
+                    pass
+            u = c[0]
+        else:
+            u = torch.empty((M, PAD_R), dtype=torch.bfloat16, device=dev)
+            _skinny(M, r, K, x2, a_pad, u, PAD_R, s, dev)
         y = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
         if mod.base == "fp8" and M >= 128:
             # frozen W as e4m3 with per-output-channel scales (quantised once), x per token row (per call, shared by the
@@ -135,6 +170,7 @@ class _LoRAFn(torch.autograd.Function):
             _gemm(M, N, K, PAD_R, x2, K, mod.weight, K, u, PAD_R, b2, PAD_R, y, N, False, 1.0, dev)
         ctx.save_for_backward(x2, u, lora_A, lora_B)
         ctx.mod = mod
+        ctx.u_col = col if grp is not None else 0
         ctx.shape = x.shape
         return y            # (M, N): the caller reshapes -- a view made in here could not be updated in place (RoPE)
 
@@ -179,7 +215,7 @@ class _LoRAFn(torch.autograd.Function):
             # a workgroup per 64 output columns over all tokens -- no partial sums, no workspace
             jobs = (_lib.LoraGradJob * 2)(
                 _lib.LoraGradJob(K, v.data_ptr(), PAD_R, x2.data_ptr(), K, dA.data_ptr(), 0),
-                _lib.LoraGradJob(N, u.data_ptr(), PAD_R, dy2.data_ptr(), N, dB.data_ptr(), 1))
+                _lib.LoraGradJob(N, u.data_ptr() + 2 * ctx.u_col, PAD_R, dy2.data_ptr(), N, dB.data_ptr(), 1))
             rc = lib.msr3d_lora_grad_pair(M, r, 2, jobs, ctypes.c_float(1.0), acc, st)
             _lib.check(rc, "msr3d_lora_grad_pair")
         if direct is not None:
@@ -219,6 +255,7 @@ class LoRALinear(nn.Module):
         self._wt_version = None       # `weight._version` the transposed copy was made from
         self._shadow, self._shadow_key = None, None
         self._fresh_in_capture = False    # set by LoRALlamaStack around a captured forward (its one refresh launch)
+        self._group, self._u_col = None, 0    # group_inputs(): modules reading the same tensor share one r-row product
 
     def _shadows(self, forward=False):
         """Zero-padded bf16 copies of A / B in the four orientations forward and backward read

@@ -50,6 +50,8 @@ python bench.py --full-step --llm-fp8 --batch 20 --steps 4 --warmup 2 2>/dev/nul
 python bench.py --llm-layer --llm-fp8 --steps 10 --warmup 3 2>/dev/null | tail -1 > "$OUT/${TAG}_llm_layer_fp8.json"
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/ktf" -- python "$ROOT/bench.py" --full-step --llm-fp8 --steps 4 --warmup 2 > /dev/null 2>&1)
 F=$(ls "$OUT"/ktf/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$F" ] && cp "$F" "$OUT/${TAG}_full_step_fp8_kernel_stats.csv"
+# (the stats above include the model's construction: init kernels, weight transposes; ONE step's kernels, aggregated:)
+F=$(ls "$OUT"/ktf/*/*kernel_trace.csv 2>/dev/null | head -1); [ -n "$F" ] && python tools/trace_step_agg.py "$F" > "$OUT/${TAG}_full_step_fp8_one_step.txt"
 rm -rf "$OUT/ktf"
 python tools/bench_bf16_gemm.py 2>/dev/null | grep -v amdgpu > "$OUT/${TAG}_bf16_gemm.txt"
 python -m pytest tests/test_seq_ce_gpu.py -q -s -k roofline 2>/dev/null | grep seq_ce > "$OUT/${TAG}_seq_ce.txt"
