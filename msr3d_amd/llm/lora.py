@@ -142,6 +142,9 @@ class _LoRAFn(torch.autograd.Function):
         M, dev = x2.shape[0], x.device
         # bf16 shadows of the trainable pair in the orientations the products read: built once per weight
         # version (i.e. once per optimiser step), not per call
+        if mod._group is not None and not mod._fresh_in_capture:
+            # the shared product reads EVERY member's A image: all of them current, not only this module's
+            refresh_shadows(mod._group["mods"], x.is_cuda and torch.cuda.is_current_stream_capturing())
         a_pad, b2, _, _ = mod._shadows(forward=True)
         # u = s x A^T  (M, r) bf16 in a zero-padded (M, 64): the r-row product has its own kernel; members of an input
         # group (q / k / v, gate / up) share ONE product over their stacked A's, cached on the input tensor they share
