@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 19
+#define MSR3D_ABI_VERSION 20
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -829,6 +829,11 @@ int msr3d_attn_bwd(int B, int T, int H, int D, const void *q, const void *k, con
  * k-contiguous bf16, K % 32 == 0; C bf16.  (peft's lora_A / lora_B applications, model/msr3d/msr3d.py:103-112.) */
 int msr3d_bf16_gemm_skinny(int M, int N, int K, const void *P, int ldp, const void *Q, int ldq, void *C, int ldc,
                            int zero_to, float scale, msr3d_stream_t stream);
+/* ... and, in the same pass over P, its OCP e4m3 image with one scale per row -- q8 (M, K) bytes, row_scale (M) -- bit
+ * for bit what msr3d_quant_rows_fp8 writes (the frozen-weight product msr3d_fp8_gemm_lowrank reads exactly this tensor
+ * next: one launch and one read of P instead of two).  ldq8 >= K, ldq8 % 8 == 0, q8 8-byte aligned. */
+int msr3d_bf16_gemm_skinny_quant(int M, int N, int K, const void *P, int ldp, const void *Q, int ldq, void *C, int ldc,
+                                 int zero_to, float scale, void *q8, int ldq8, float *row_scale, msr3d_stream_t stream);
 
 /* fp8 (OCP e4m3) operands for the frozen projections of the LoRA-Llama layers (model/msr3d/msr3d.py:103-112,409-415;
  * csrc/lora_fp8.hip).

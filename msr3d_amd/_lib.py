@@ -133,6 +133,8 @@ _SIGNATURES = {
     "msr3d_transpose_bf16": [_c_int, _c_int, _c_int, _c_int, _ptr, _c_int, ctypes.c_longlong, ctypes.c_longlong,
                              _ptr, _c_int, ctypes.c_longlong, ctypes.c_longlong, _ptr],
     "msr3d_bf16_gemm_skinny": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _c_float, _ptr],
+    "msr3d_bf16_gemm_skinny_quant": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _c_float, _ptr,
+                                     _c_int, _ptr, _ptr],
     "msr3d_colsum_partials": [_c_int, _ptr, _ptr],
     "msr3d_lora_grad": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_float, _c_int, _ptr,
                         ctypes.c_longlong, _ptr],
@@ -224,7 +226,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string", "msr3d_sqdist_contract"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 19        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 20        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():

@@ -808,13 +808,20 @@ __global__ __launch_bounds__(256) void lora_shadows_kernel(const msr3d_lora_shad
 constexpr int kSkinnyWaves = 8;      // two per SIMD, each an eighth of K (round 3: four)
 // (Measured and dropped: 8 rows per workgroup, half of the MFMA tile empty, so that 2304 tokens are 288 workgroups
 // instead of 144 on 256 CUs -- 19 us against 13 per call.)
-template <int NT>
+// QUANT: the same pass also leaves the e4m3 image of P with one scale per row (= msr3d_quant_rows_fp8, bit for bit) --
+// the frozen-weight product that follows reads exactly this tensor, and its own quantisation launch read it a second
+// time: the rows' absolute maxima are taken from the fragments as they go by (integer maxima of the bf16 bit patterns),
+// met across the waves in LDS, and a second walk over the wave's K slice (L2 hits) converts and stores 8 bytes per lane.
+template <int NT, bool QUANT = false>
 __global__ __launch_bounds__(64 * kSkinnyWaves) void bf16_gemm_skinny_kernel(int M, int N, int K, const unsigned short *__restrict__ P,
                                                                int ldp, const unsigned short *__restrict__ Q, int ldq,
                                                                unsigned short *__restrict__ C, int ldc, int zero_to,
-                                                               float scale) {
+                                                               float scale, unsigned char *__restrict__ q8 = nullptr,
+                                                               int ldq8 = 0, float *__restrict__ row_scale = nullptr) {
   constexpr int NW = kSkinnyWaves;
   __shared__ __attribute__((aligned(16))) float red[NW][NT][64][4];
+  __shared__ unsigned rmax[NW][16];
+  unsigned amax = 0;                                   // two 15-bit maxima of |bf16| bit patterns, packed
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.x * 16;
@@ -838,11 +845,24 @@ __global__ __launch_bounds__(64 * kSkinnyWaves) void bf16_gemm_skinny_kernel(int
       for (int t = 0; t < NT; ++t) b_.fq[u][t] = *reinterpret_cast<const bf16x8 *>(q[t] + (ks + u) * 32);
     }
   };
+  auto track = [&](const bf16x8 &f) {                  // |x| as integers: for non-negative floats the orders agree
+    if constexpr (QUANT) {
+      union { bf16x8 v; unsigned w[4]; } x;
+      x.v = f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned a = x.w[e] & 0x7fff7fffu;
+        amax = (max(amax >> 16, a >> 16) << 16) | max(amax & 0xffffu, a & 0xffffu);
+      }
+    }
+  };
   auto mma = [&](const Batch &b_) {
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int u = 0; u < U; ++u) {
+      track(b_.fp[u]);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_.fq[u][t], b_.fp[u], acc[t], 0, 0, 0);
+    }
   };
   const int nb = (ks1 - ks0) / U;
   int ks = ks0;
@@ -859,13 +879,62 @@ __global__ __launch_bounds__(64 * kSkinnyWaves) void bf16_gemm_skinny_kernel(int
   }
   for (; ks < ks1; ++ks) {
     const bf16x8 fp = *reinterpret_cast<const bf16x8 *>(p + ks * 32);
+    track(fp);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(q[t] + ks * 32), fp, acc[t], 0, 0, 0);
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4 *>(&red[wave][t][lane][0]) = acc[t];
+  constexpr int QU = 16;                               // 16-byte pieces per thread and round of the second walk
+  const int qr = threadIdx.x >> 5, qc = (threadIdx.x & 31) * 8;
+  const unsigned short *src = P + (size_t)min(m0 + qr, M - 1) * ldp + qc;
+  uint4 xv[QUANT ? QU : 1];
+  if constexpr (QUANT) {
+    unsigned m = max(amax >> 16, amax & 0xffffu);
+    m = max(m, (unsigned)__shfl_xor((int)m, 16));
+    m = max(m, (unsigned)__shfl_xor((int)m, 32));
+    if (g == 0) rmax[wave][i] = m;
+    // the second walk's first round of loads leaves BEFORE the barrier (it needs the scale only to convert)
+#pragma unroll
+    for (int u = 0; u < QU; ++u) xv[u] = 256 * u + qc < K ? *reinterpret_cast<const uint4 *>(src + 256 * u) : make_uint4(0, 0, 0, 0);
+  }
   __syncthreads();
+  if constexpr (QUANT) {
+    unsigned m = rmax[0][i];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = max(m, rmax[w][i]);
+    const float mx = __uint_as_float(m << 16);
+    const float sc = mx > 0.f ? mx * (1.0f / 448.0f) : 1.0f;
+    if (m0 + i < M && wave == 0 && g == 0) row_scale[m0 + i] = sc;
+    // second walk, ROW-major over the workgroup's 16 x K block (L2 hits): 32 threads per row, 16 bytes each -- 512
+    // contiguous bytes read and 256 written per row and step (the fragment order of pass 1 would store 32-byte pieces)
+    unsigned mr = rmax[0][qr];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mr = max(mr, rmax[w][qr]);
+    const float mxr = __uint_as_float(mr << 16);
+    const float inv = 1.0f / (mxr > 0.f ? mxr * (1.0f / 448.0f) : 1.0f);
+    const bool live = m0 + qr < M;
+    unsigned char *dst = q8 + (size_t)(m0 + qr) * ldq8 + qc;
+    for (int c0 = 0; c0 < K; c0 += 256 * QU) {
+      if (c0 > 0) {
+#pragma unroll
+        for (int u = 0; u < QU; ++u)
+          xv[u] = c0 + 256 * u + qc < K ? *reinterpret_cast<const uint4 *>(src + c0 + 256 * u) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < QU; ++u) {
+        const int c = c0 + 256 * u + qc;
+        const unsigned w4[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(w4[0] << 16) * inv, __uint_as_float(w4[0] & 0xffff0000u) * inv, lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(w4[1] << 16) * inv, __uint_as_float(w4[1] & 0xffff0000u) * inv, lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(w4[2] << 16) * inv, __uint_as_float(w4[2] & 0xffff0000u) * inv, hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(w4[3] << 16) * inv, __uint_as_float(w4[3] & 0xffff0000u) * inv, hi, true);
+        if (live && c < K) *reinterpret_cast<uint2 *>(dst + c0 + 256 * u) = make_uint2((unsigned)lo, (unsigned)hi);
+      }
+    }
+  }
   // D = Q P^T: lane (i, g) of tile t holds columns n = 16 t + 4 g + r of row m = i; wave w finishes tiles w, w + 4 ..
   const int row = m0 + i;
   for (int t = wave; t < NT; t += NW) {
@@ -1080,8 +1149,8 @@ int msr3d_lora_shadows(int njobs, const msr3d_lora_shadow_job_t *jobs_device, ms
   return (int)hipGetLastError();
 }
 
-int msr3d_bf16_gemm_skinny(int M, int N, int K, const void *P, int ldp, const void *Q, int ldq, void *C, int ldc,
-                           int zero_to, float scale, msr3d_stream_t stream) {
+static int skinny_launch(int M, int N, int K, const void *P, int ldp, const void *Q, int ldq, void *C, int ldc, int zero_to,
+                         float scale, void *q8, int ldq8, float *row_scale, msr3d_stream_t stream) {
   if (M < 0 || N <= 0 || N > 64 || (N % 16) || K <= 0 || (K % 32) || zero_to < N || (zero_to % 4) || zero_to > ldc)
     return MSR3D_EINVAL;
   if (M == 0) return 0;
@@ -1092,6 +1161,16 @@ int msr3d_bf16_gemm_skinny(int M, int N, int K, const void *P, int ldp, const vo
   const unsigned short *p = (const unsigned short *)P, *q = (const unsigned short *)Q;
   unsigned short *c = (unsigned short *)C;
   const int grid = (M + 15) / 16;
+  if (q8) {
+    unsigned char *q8p = (unsigned char *)q8;
+    switch (N / 16) {
+      case 1: bf16_gemm_skinny_kernel<1, true><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale, q8p, ldq8, row_scale); break;
+      case 2: bf16_gemm_skinny_kernel<2, true><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale, q8p, ldq8, row_scale); break;
+      case 3: bf16_gemm_skinny_kernel<3, true><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale, q8p, ldq8, row_scale); break;
+      default: bf16_gemm_skinny_kernel<4, true><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale, q8p, ldq8, row_scale); break;
+    }
+    return (int)hipGetLastError();
+  }
   switch (N / 16) {
     case 1: bf16_gemm_skinny_kernel<1><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
     case 2: bf16_gemm_skinny_kernel<2><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
@@ -1099,6 +1178,17 @@ int msr3d_bf16_gemm_skinny(int M, int N, int K, const void *P, int ldp, const vo
     default: bf16_gemm_skinny_kernel<4><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
   }
   return (int)hipGetLastError();
+}
+
+int msr3d_bf16_gemm_skinny(int M, int N, int K, const void *P, int ldp, const void *Q, int ldq, void *C, int ldc,
+                           int zero_to, float scale, msr3d_stream_t stream) {
+  return skinny_launch(M, N, K, P, ldp, Q, ldq, C, ldc, zero_to, scale, nullptr, 0, nullptr, stream);
+}
+
+int msr3d_bf16_gemm_skinny_quant(int M, int N, int K, const void *P, int ldp, const void *Q, int ldq, void *C, int ldc,
+                                 int zero_to, float scale, void *q8, int ldq8, float *row_scale, msr3d_stream_t stream) {
+  if (!q8 || !row_scale || ldq8 < K || (ldq8 % 8) || (reinterpret_cast<uintptr_t>(q8) & 7u)) return MSR3D_EINVAL;
+  return skinny_launch(M, N, K, P, ldp, Q, ldq, C, ldc, zero_to, scale, q8, ldq8, row_scale, stream);
 }
 
 }  // extern "C"

@@ -39,6 +39,17 @@ def _skinny(M, N, K, P, Q, C, ldc, scale, dev):
     _lib.check(rc, "msr3d_bf16_gemm_skinny")
 
 
+def _skinny_quant(M, N, K, P, Q, C, ldc, scale, dev):
+    """_skinny + the e4m3 image of P with its row scales in the same launch (msr3d_bf16_gemm_skinny_quant)."""
+    q = torch.empty((M, K), dtype=torch.uint8, device=dev)
+    sc = torch.empty((M,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().msr3d_bf16_gemm_skinny_quant(M, N, K, _p(P), K, _p(Q), K, _p(C), ldc, ldc, ctypes.c_float(scale),
+                                                      _p(q), K, _p(sc), _lib.current_stream_ptr(dev))
+    _lib.check(rc, "msr3d_bf16_gemm_skinny_quant")
+    return q, sc
+
+
 def quant_rows_fp8(x2):
     """x2 (M, K) bf16 contiguous -> (q (M, K) uint8 = OCP e4m3 codes, scale (M,) f32): q = rne(x / scale),
     scale = max |row| / 448 (msr3d_quant_rows_fp8)."""
@@ -149,25 +160,38 @@ class _LoRAFn(torch.autograd.Function):
         # u = s x A^T  (M, r) bf16 in a zero-padded (M, 64): the r-row product has its own kernel; members of an input
         # group (q / k / v, gate / up) share ONE product over their stacked A's, cached on the input tensor they share
         grp, col = mod._group, mod._u_col
-        if grp is not None:
-            c = getattr(x, "_msr3d_u", None)
-            if c is None or c[1] != x._version or c[2] is not grp:
-                u = torch.empty((M, PAD_R), dtype=torch.bfloat16, device=dev)
-                _skinny(M, grp["a_cat"].shape[0], K, x2, grp["a_cat"], u, PAD_R, s, dev)
-                c = (u, x._version, grp)
+        fp8 = mod.base == "fp8" and M >= 128
+        qc = getattr(x, "_msr3d_fp8", None) if fp8 else None
+        if qc is not None and qc[2] != x._version:
+            qc = None
+        uc = getattr(x, "_msr3d_u", None) if grp is not None else None
+        if uc is not None and (uc[1] != x._version or uc[2] is not grp):
+            uc = None
+        if uc is None:
+            u = torch.empty((M, PAD_R), dtype=torch.bfloat16, device=dev)
+            a_op = grp["a_cat"] if grp is not None else a_pad
+            if fp8 and qc is None:
+                # the e4m3 image of x (per token row; shared by the projections reading the same tensor) comes out of the
+                # same pass over x as the r-row product
+                xq, sx = _skinny_quant(M, a_op.shape[0], K, x2, a_op, u, PAD_R, s, dev)
+                qc = (xq, sx, x._version)
                 try:
-                    x._msr3d_u = c
+                    x._msr3d_fp8 = qc
                 except AttributeError:
                     pass
-            u = c[0]
+            else:
+                _skinny(M, a_op.shape[0], K, x2, a_op, u, PAD_R, s, dev)
+            if grp is not None:
+                try:
+                    x._msr3d_u = (u, x._version, grp)
+                except AttributeError:
+                    pass
         else:
-            u = torch.empty((M, PAD_R), dtype=torch.bfloat16, device=dev)
-            _skinny(M, r, K, x2, a_pad, u, PAD_R, s, dev)
+            u = uc[0]
         y = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-        if mod.base == "fp8" and M >= 128:
-            # frozen W as e4m3 with per-output-channel scales (quantised once), x per token row (per call, shared by the
-            # projections reading the same tensor); the LoRA term rides in bf16 -- csrc/lora_fp8.hip
-            xq, sx = _quant_cached(x, x2)
+        if fp8:
+            # frozen W as e4m3 with per-output-channel scales (quantised once); the LoRA term rides in bf16 -- csrc/lora_fp8.hip
+            xq, sx = (qc[0], qc[1]) if qc is not None else _quant_cached(x, x2)
             _gemm_fp8(M, N, K, xq, sx, mod.weight_q, mod.weight_scale, u, b2, y, dev)
         else:
             _gemm(M, N, K, PAD_R, x2, K, mod.weight, K, u, PAD_R, b2, PAD_R, y, N, False, 1.0, dev)
@@ -189,12 +213,15 @@ class _LoRAFn(torch.autograd.Function):
         _, _, bt_pad, at2 = mod._shadows()
         # v = s dy B  (M, r) bf16 in a zero-padded (M, 64)
         v = torch.empty((M, PAD_R), dtype=torch.bfloat16, device=dev)
-        _skinny(M, r, N, dy2, bt_pad, v, PAD_R, s, dev)
+        fp8_dx = ctx.needs_input_grad[0] and mod.base == "fp8" and mod.fp8_backward and M >= 128
+        if fp8_dx:
+            dq, sdy = _skinny_quant(M, r, N, dy2, bt_pad, v, PAD_R, s, dev)     # + the upstream gradient as e4m3, per token row
+        else:
+            _skinny(M, r, N, dy2, bt_pad, v, PAD_R, s, dev)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.bfloat16, device=dev)
-            if mod.base == "fp8" and mod.fp8_backward and M >= 128:
-                dq, sdy = quant_rows_fp8(dy2)              # the upstream gradient, per token row
+            if fp8_dx:
                 _gemm_fp8(M, K, N, dq, sdy, mod.weight_t_q, mod.weight_t_scale, v, at2, dx, dev)
             else:
                 _gemm(M, K, N, PAD_R, dy2, N, mod.weight_t, N, v, PAD_R, at2, PAD_R, dx, K, False, 1.0, dev)

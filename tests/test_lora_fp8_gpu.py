@@ -141,3 +141,33 @@ def test_decoder_layer_fp8_against_the_transformers_fixture():
         m = (layer.self_attn if n in layer.self_attn else layer.mlp)[n]
         assert rel(m.lora_A.weight.grad, g["dA/" + n]) < 1e-1, n
         assert rel(m.lora_B.weight.grad, g["dB/" + n]) < 1e-1, n
+
+
+@pytest.mark.parametrize("M,K,N", [(2304, 4096, 16), (300, 11008, 48), (129, 256, 32), (16, 4096, 64)])
+def test_skinny_product_with_fused_quantisation_is_both_kernels_bit_for_bit(M, K, N):
+    """msr3d_bf16_gemm_skinny_quant == msr3d_bf16_gemm_skinny + msr3d_quant_rows_fp8 on the same tensor, bit for bit
+    (codes, scales, the r-row product and its zero padding); rows of zeros keep scale 1."""
+    import ctypes
+
+    from msr3d_amd import _lib
+    from msr3d_amd.llm.lora import quant_rows_fp8
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(M + K + N)
+    x = (torch.randn(M, K, generator=g, device="cuda") * torch.rand(M, 1, generator=g, device="cuda") * 8).to(torch.bfloat16)
+    x[M // 2] = 0
+    a = torch.randn(N, K, generator=g, device="cuda").to(torch.bfloat16)
+    st = _lib.current_stream_ptr(torch.device("cuda:0"))
+    p = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
+    u0 = torch.full((M, 64), 7.0, dtype=torch.bfloat16, device="cuda")
+    u1 = u0.clone()
+    assert lib.msr3d_bf16_gemm_skinny(M, N, K, p(x), K, p(a), K, p(u0), 64, 64, ctypes.c_float(0.5), st) == 0
+    q0, s0 = quant_rows_fp8(x)
+    q1 = torch.empty_like(q0)
+    s1 = torch.empty_like(s0)
+    assert lib.msr3d_bf16_gemm_skinny_quant(M, N, K, p(x), K, p(a), K, p(u1), 64, 64, ctypes.c_float(0.5), p(q1), K, p(s1),
+                                            st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(u0, u1) and torch.equal(q0, q1) and torch.equal(s0, s1)
+    assert float(s1[M // 2]) == 1.0 and not q1[M // 2].any()
+    assert lib.msr3d_bf16_gemm_skinny_quant(M, N, K, p(x), K, p(a), K, p(u1), 64, 64, ctypes.c_float(0.5), None, K, p(s1),
+                                            st) == -22
