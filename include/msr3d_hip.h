@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 20
+#define MSR3D_ABI_VERSION 21
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -848,6 +848,11 @@ int msr3d_quant_rows_fp8(int M, int K, const void *x, int ldx, void *q, int ldq,
 int msr3d_fp8_gemm_lowrank(int M, int N, int K, const void *Pq, int ldp, const float *sp, const void *Qq, int ldq,
                            const float *sq, const void *P2, int ldp2, const void *Q2, int ldq2, void *C, int ldc,
                            msr3d_stream_t stream);
+/* C += the same product (C read as bf16, the sum rounded to bf16 again): the input gradients of projections that read
+ * ONE tensor (q / k / v, gate / up) meet in one buffer instead of three tensors and two add launches. */
+int msr3d_fp8_gemm_lowrank_acc(int M, int N, int K, const void *Pq, int ldp, const float *sp, const void *Qq, int ldq,
+                               const float *sq, const void *P2, int ldp2, const void *Q2, int ldq2, void *C, int ldc,
+                               msr3d_stream_t stream);
 
 /* out (R, C) fp32 -- or its transpose (C, R) -- += scale * sum_m P[m][r] Q[m][c]: the LoRA weight gradients
  * dA = (s dy B)^T x and dB = dy^T (s x A^T) (peft's lora_A / lora_B, model/msr3d/msr3d.py:103-112; R = 16 or 32).

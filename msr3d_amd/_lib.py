@@ -110,6 +110,8 @@ _SIGNATURES = {
     "msr3d_quant_rows_fp8": [_c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _ptr],
     "msr3d_fp8_gemm_lowrank": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _c_int, _ptr, _ptr, _c_int, _ptr, _c_int,
                                _ptr, _c_int, _ptr],
+    "msr3d_fp8_gemm_lowrank_acc": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _c_int, _ptr, _ptr, _c_int, _ptr, _c_int,
+                               _ptr, _c_int, _ptr],
     "msr3d_wgrad_split_halves": [_c_int, _ptr, _ptr, _c_int, _ptr, ctypes.c_longlong, _ptr, _ptr],
     "msr3d_wgrad_rows_split": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _ptr,
                                ctypes.c_longlong, _ptr, _ptr],
@@ -226,7 +228,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string", "msr3d_sqdist_contract"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 20        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 21        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():

@@ -94,6 +94,7 @@ struct Fp8Args {
   const unsigned short *P2; int ldp2;                      // (M, 64) bf16: s x A^T, zero-padded
   const unsigned short *Q2; int ldq2;                      // (N, 64) bf16: B, zero-padded
   unsigned short *C; int ldc;                              // (M, N) bf16
+  int accumulate;                                          // C += the product (one more bf16 rounding per call)
 };
 
 template <int MTB>
@@ -265,8 +266,12 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm_wide_kernel(const Fp8Args a, 
       const int col = n0 + wave * 32 + y * 16 + 4 * g;
       if (col >= a.N) continue;                          // (N % 4 == 0: checked by the caller)
       const float4 sn = *reinterpret_cast<const float4 *>(a.sq + col);
-      const float v0 = acc[x][y][0] * sm * sn.x, v1 = acc[x][y][1] * sm * sn.y, v2 = acc[x][y][2] * sm * sn.z,
-                  v3 = acc[x][y][3] * sm * sn.w;
+      float v0 = acc[x][y][0] * sm * sn.x, v1 = acc[x][y][1] * sm * sn.y, v2 = acc[x][y][2] * sm * sn.z,
+            v3 = acc[x][y][3] * sm * sn.w;
+      if (a.accumulate) {
+        const uint2 old = *reinterpret_cast<const uint2 *>(a.C + (size_t)row * a.ldc + col);
+        v0 += bf_lo(old.x); v1 += bf_hi(old.x); v2 += bf_lo(old.y); v3 += bf_hi(old.y);
+      }
       *reinterpret_cast<uint2 *>(a.C + (size_t)row * a.ldc + col) =
           make_uint2(f2bf(v0) | ((unsigned)f2bf(v1) << 16), f2bf(v2) | ((unsigned)f2bf(v3) << 16));
     }
@@ -300,9 +305,9 @@ int msr3d_quant_rows_fp8(int M, int K, const void *x, int ldx, void *q, int ldq,
   return (int)hipGetLastError();
 }
 
-int msr3d_fp8_gemm_lowrank(int M, int N, int K, const void *Pq, int ldp, const float *sp, const void *Qq, int ldq,
-                           const float *sq, const void *P2, int ldp2, const void *Q2, int ldq2, void *C, int ldc,
-                           msr3d_stream_t stream) {
+static int fp8_gemm(int M, int N, int K, const void *Pq, int ldp, const float *sp, const void *Qq, int ldq,
+                    const float *sq, const void *P2, int ldp2, const void *Q2, int ldq2, void *C, int ldc, int accumulate,
+                    msr3d_stream_t stream) {
   if (M < 0 || N < 0 || K <= 0 || (K % 128) || (N % 4)) return MSR3D_EINVAL;
   if (M == 0 || N == 0) return 0;
   if (M < 128 || N < 256) return MSR3D_EINVAL;             // (the wide tile's domain: the language model's products)
@@ -319,6 +324,7 @@ int msr3d_fp8_gemm_lowrank(int M, int N, int K, const void *Pq, int ldp, const f
   a.P2 = (const unsigned short *)P2; a.ldp2 = ldp2;
   a.Q2 = (const unsigned short *)Q2; a.ldq2 = ldq2;
   a.C = (unsigned short *)C; a.ldc = ldc;
+  a.accumulate = accumulate;
   // tile height = the one with the least (rounds of 256 CUs) x height, as the bf16 kernel picks it
   const int tn = (N + WBN - 1) / WBN;
   long long best = -1;
@@ -329,6 +335,18 @@ int msr3d_fp8_gemm_lowrank(int M, int N, int K, const void *Pq, int ldp, const f
   }
   hipStream_t st = (hipStream_t)stream;
   return bm == 160 ? launch<10>(a, st) : bm == 144 ? launch<9>(a, st) : launch<8>(a, st);
+}
+
+int msr3d_fp8_gemm_lowrank(int M, int N, int K, const void *Pq, int ldp, const float *sp, const void *Qq, int ldq,
+                           const float *sq, const void *P2, int ldp2, const void *Q2, int ldq2, void *C, int ldc,
+                           msr3d_stream_t stream) {
+  return fp8_gemm(M, N, K, Pq, ldp, sp, Qq, ldq, sq, P2, ldp2, Q2, ldq2, C, ldc, 0, stream);
+}
+
+int msr3d_fp8_gemm_lowrank_acc(int M, int N, int K, const void *Pq, int ldp, const float *sp, const void *Qq, int ldq,
+                               const float *sq, const void *P2, int ldp2, const void *Q2, int ldq2, void *C, int ldc,
+                               msr3d_stream_t stream) {
+  return fp8_gemm(M, N, K, Pq, ldp, sp, Qq, ldq, sq, P2, ldp2, Q2, ldq2, C, ldc, 1, stream);
 }
 
 }  // extern "C"

@@ -62,11 +62,12 @@ def quant_rows_fp8(x2):
     return q, sc
 
 
-def _gemm_fp8(M, N, K, Pq, sp, Qq, sq, P2, Q2, C, dev):
+def _gemm_fp8(M, N, K, Pq, sp, Qq, sq, P2, Q2, C, dev, accumulate=False):
+    fn = "msr3d_fp8_gemm_lowrank_acc" if accumulate else "msr3d_fp8_gemm_lowrank"
     with torch.cuda.device(dev):
-        rc = _lib.load().msr3d_fp8_gemm_lowrank(M, N, K, _p(Pq), K, _p(sp), _p(Qq), K, _p(sq), _p(P2), PAD_R, _p(Q2), PAD_R,
-                                                _p(C), N, _lib.current_stream_ptr(dev))
-    _lib.check(rc, "msr3d_fp8_gemm_lowrank")
+        rc = getattr(_lib.load(), fn)(M, N, K, _p(Pq), K, _p(sp), _p(Qq), K, _p(sq), _p(P2), PAD_R, _p(Q2), PAD_R,
+                                      _p(C), N, _lib.current_stream_ptr(dev))
+    _lib.check(rc, fn)
 
 
 def _quant_cached(x, x2):
@@ -182,10 +183,11 @@ class _LoRAFn(torch.autograd.Function):
             else:
                 _skinny(M, a_op.shape[0], K, x2, a_op, u, PAD_R, s, dev)
             if grp is not None:
+                uc = [u, x._version, grp, None]        # [3]: the members' shared input-gradient buffer (backward)
                 try:
-                    x._msr3d_u = (u, x._version, grp)
+                    x._msr3d_u = uc
                 except AttributeError:
-                    pass
+                    uc = None
         else:
             u = uc[0]
         y = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
@@ -198,6 +200,7 @@ class _LoRAFn(torch.autograd.Function):
         ctx.save_for_backward(x2, u, lora_A, lora_B)
         ctx.mod = mod
         ctx.u_col = col if grp is not None else 0
+        ctx.rec = uc if (grp is not None and fp8) else None
         ctx.shape = x.shape
         return y            # (M, N): the caller reshapes -- a view made in here could not be updated in place (RoPE)
 
@@ -220,12 +223,21 @@ class _LoRAFn(torch.autograd.Function):
             _skinny(M, r, N, dy2, bt_pad, v, PAD_R, s, dev)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((M, K), dtype=torch.bfloat16, device=dev)
-            if fp8_dx:
-                _gemm_fp8(M, K, N, dq, sdy, mod.weight_t_q, mod.weight_t_scale, v, at2, dx, dev)
+            rec = ctx.rec if fp8_dx else None
+            if rec is not None and rec[3] is not None:
+                # a member of this input group already produced its share of d input in THIS backward: the product is
+                # ADDED into that buffer -- autograd holds it as the input's gradient, and the input's producer runs only
+                # after every member -- and this member hands back nothing: no third tensor, no add launch
+                _gemm_fp8(M, K, N, dq, sdy, mod.weight_t_q, mod.weight_t_scale, v, at2, rec[3], dev, accumulate=True)
             else:
-                _gemm(M, K, N, PAD_R, dy2, N, mod.weight_t, N, v, PAD_R, at2, PAD_R, dx, K, False, 1.0, dev)
-            dx = dx.view(ctx.shape)
+                dx = torch.empty((M, K), dtype=torch.bfloat16, device=dev)
+                if fp8_dx:
+                    _gemm_fp8(M, K, N, dq, sdy, mod.weight_t_q, mod.weight_t_scale, v, at2, dx, dev)
+                else:
+                    _gemm(M, K, N, PAD_R, dy2, N, mod.weight_t, N, v, PAD_R, at2, PAD_R, dx, K, False, 1.0, dev)
+                if rec is not None:
+                    rec[3] = dx
+                dx = dx.view(ctx.shape)
         lib = _lib.load()
         # On the flat-gradient engine (dp.py) the pair's .grad are views of the flat buffer: the kernels ADD into them
         # (accumulate = 1) and report readiness themselves -- no AccumulateGrad add launch per parameter (448 a step for

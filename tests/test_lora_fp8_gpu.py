@@ -81,6 +81,13 @@ def test_fp8_product_is_exact_on_the_dequantised_operands(M, N, K, lora):
     # and against the unquantised product: the e4m3 rounding of both operands, ~2^-4 / sqrt(3) each
     full = x.double().cpu() @ w.double().cpu().T + (u.double().cpu() @ b2.double().cpu().T if lora else 0)
     assert rel(y, full) < 6e-2
+    # msr3d_fp8_gemm_lowrank_acc: C += the product (what the input gradients of q / k / v meet through)
+    c0 = torch.randn(M, N, device="cuda").bfloat16()
+    acc = c0.clone()
+    _gemm_fp8(M, N, K, xq, sx, wq, sw, u, b2, acc, x.device, accumulate=True)
+    torch.cuda.synchronize()
+    assert rel(acc, want + c0.double().cpu()) < 4e-3
+    assert float((acc.float() - (y.float() + c0.float())).abs().max()) <= 2.0 ** -6 * float((y.float().abs() + c0.float().abs()).max())
 
 
 def test_lora_linear_fp8_against_the_bf16_module():
