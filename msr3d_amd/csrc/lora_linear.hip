@@ -805,7 +805,9 @@ __global__ __launch_bounds__(256) void lora_shadows_kernel(const msr3d_lora_shad
 // 64 padded columns), and C[:, N:zero_to] = 0.  A tile of the big kernels would put this on 18 CUs; here a
 // workgroup owns 16 rows of P, its four waves each a quarter of K, fragments loaded straight from global memory
 // (P is read once; the 16 x K operand Q stays in L2), and the four partial tiles meet in LDS.
-constexpr int kSkinnyWaves = 8;      // two per SIMD, each an eighth of K (round 3: four)
+// waves per workgroup, each a share of K: sixteen (four per SIMD) while their partial tiles fit 32 KB of LDS (N <= 32), eight
+// otherwise (round 3: four).  2304 tokens are only 144 workgroups: what a CU has in flight is what its own waves issue.
+template <int NT> constexpr int kSkinnyWaves = NT <= 2 ? 16 : 8;
 // (Measured and dropped: 8 rows per workgroup, half of the MFMA tile empty, so that 2304 tokens are 288 workgroups
 // instead of 144 on 256 CUs -- 19 us against 13 per call.)
 // QUANT: the same pass also leaves the e4m3 image of P with one scale per row (= msr3d_quant_rows_fp8, bit for bit) --
@@ -813,12 +815,12 @@ constexpr int kSkinnyWaves = 8;      // two per SIMD, each an eighth of K (round
 // time: the rows' absolute maxima are taken from the fragments as they go by (integer maxima of the bf16 bit patterns),
 // met across the waves in LDS, and a second walk over the wave's K slice (L2 hits) converts and stores 8 bytes per lane.
 template <int NT, bool QUANT = false>
-__global__ __launch_bounds__(64 * kSkinnyWaves) void bf16_gemm_skinny_kernel(int M, int N, int K, const unsigned short *__restrict__ P,
+__global__ __launch_bounds__(64 * kSkinnyWaves<NT>) void bf16_gemm_skinny_kernel(int M, int N, int K, const unsigned short *__restrict__ P,
                                                                int ldp, const unsigned short *__restrict__ Q, int ldq,
                                                                unsigned short *__restrict__ C, int ldc, int zero_to,
                                                                float scale, unsigned char *__restrict__ q8 = nullptr,
                                                                int ldq8 = 0, float *__restrict__ row_scale = nullptr) {
-  constexpr int NW = kSkinnyWaves;
+  constexpr int NW = kSkinnyWaves<NT>;
   __shared__ __attribute__((aligned(16))) float red[NW][NT][64][4];
   __shared__ unsigned rmax[NW][16];
   unsigned amax = 0;                                   // two 15-bit maxima of |bf16| bit patterns, packed
@@ -886,8 +888,9 @@ __global__ __launch_bounds__(64 * kSkinnyWaves) void bf16_gemm_skinny_kernel(int
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4 *>(&red[wave][t][lane][0]) = acc[t];
-  constexpr int QU = 16;                               // 16-byte pieces per thread and round of the second walk
-  const int qr = threadIdx.x >> 5, qc = (threadIdx.x & 31) * 8;
+  constexpr int QU = 8;                                // 16-byte pieces per thread and round of the second walk
+  constexpr int TPR = 4 * NW, QS = 8 * TPR;            // threads per row of the second walk; elements per row and step
+  const int qr = threadIdx.x / TPR, qc = (threadIdx.x % TPR) * 8;
   const unsigned short *src = P + (size_t)min(m0 + qr, M - 1) * ldp + qc;
   uint4 xv[QUANT ? QU : 1];
   if constexpr (QUANT) {
@@ -897,7 +900,7 @@ __global__ __launch_bounds__(64 * kSkinnyWaves) void bf16_gemm_skinny_kernel(int
     if (g == 0) rmax[wave][i] = m;
     // the second walk's first round of loads leaves BEFORE the barrier (it needs the scale only to convert)
 #pragma unroll
-    for (int u = 0; u < QU; ++u) xv[u] = 256 * u + qc < K ? *reinterpret_cast<const uint4 *>(src + 256 * u) : make_uint4(0, 0, 0, 0);
+    for (int u = 0; u < QU; ++u) xv[u] = QS * u + qc < K ? *reinterpret_cast<const uint4 *>(src + QS * u) : make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
   if constexpr (QUANT) {
@@ -916,22 +919,22 @@ __global__ __launch_bounds__(64 * kSkinnyWaves) void bf16_gemm_skinny_kernel(int
     const float inv = 1.0f / (mxr > 0.f ? mxr * (1.0f / 448.0f) : 1.0f);
     const bool live = m0 + qr < M;
     unsigned char *dst = q8 + (size_t)(m0 + qr) * ldq8 + qc;
-    for (int c0 = 0; c0 < K; c0 += 256 * QU) {
+    for (int c0 = 0; c0 < K; c0 += QS * QU) {
       if (c0 > 0) {
 #pragma unroll
         for (int u = 0; u < QU; ++u)
-          xv[u] = c0 + 256 * u + qc < K ? *reinterpret_cast<const uint4 *>(src + c0 + 256 * u) : make_uint4(0, 0, 0, 0);
+          xv[u] = c0 + QS * u + qc < K ? *reinterpret_cast<const uint4 *>(src + c0 + QS * u) : make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
       for (int u = 0; u < QU; ++u) {
-        const int c = c0 + 256 * u + qc;
+        const int c = c0 + QS * u + qc;
         const unsigned w4[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
         int lo = 0, hi = 0;
         lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(w4[0] << 16) * inv, __uint_as_float(w4[0] & 0xffff0000u) * inv, lo, false);
         lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(w4[1] << 16) * inv, __uint_as_float(w4[1] & 0xffff0000u) * inv, lo, true);
         hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(w4[2] << 16) * inv, __uint_as_float(w4[2] & 0xffff0000u) * inv, hi, false);
         hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(w4[3] << 16) * inv, __uint_as_float(w4[3] & 0xffff0000u) * inv, hi, true);
-        if (live && c < K) *reinterpret_cast<uint2 *>(dst + c0 + 256 * u) = make_uint2((unsigned)lo, (unsigned)hi);
+        if (live && c < K) *reinterpret_cast<uint2 *>(dst + c0 + QS * u) = make_uint2((unsigned)lo, (unsigned)hi);
       }
     }
   }
@@ -1164,18 +1167,18 @@ static int skinny_launch(int M, int N, int K, const void *P, int ldp, const void
   if (q8) {
     unsigned char *q8p = (unsigned char *)q8;
     switch (N / 16) {
-      case 1: bf16_gemm_skinny_kernel<1, true><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale, q8p, ldq8, row_scale); break;
-      case 2: bf16_gemm_skinny_kernel<2, true><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale, q8p, ldq8, row_scale); break;
-      case 3: bf16_gemm_skinny_kernel<3, true><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale, q8p, ldq8, row_scale); break;
-      default: bf16_gemm_skinny_kernel<4, true><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale, q8p, ldq8, row_scale); break;
+      case 1: bf16_gemm_skinny_kernel<1, true><<<grid, 64 * kSkinnyWaves<1>, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale, q8p, ldq8, row_scale); break;
+      case 2: bf16_gemm_skinny_kernel<2, true><<<grid, 64 * kSkinnyWaves<2>, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale, q8p, ldq8, row_scale); break;
+      case 3: bf16_gemm_skinny_kernel<3, true><<<grid, 64 * kSkinnyWaves<3>, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale, q8p, ldq8, row_scale); break;
+      default: bf16_gemm_skinny_kernel<4, true><<<grid, 64 * kSkinnyWaves<4>, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale, q8p, ldq8, row_scale); break;
     }
     return (int)hipGetLastError();
   }
   switch (N / 16) {
-    case 1: bf16_gemm_skinny_kernel<1><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
-    case 2: bf16_gemm_skinny_kernel<2><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
-    case 3: bf16_gemm_skinny_kernel<3><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
-    default: bf16_gemm_skinny_kernel<4><<<grid, 64 * kSkinnyWaves, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
+    case 1: bf16_gemm_skinny_kernel<1><<<grid, 64 * kSkinnyWaves<1>, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
+    case 2: bf16_gemm_skinny_kernel<2><<<grid, 64 * kSkinnyWaves<2>, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
+    case 3: bf16_gemm_skinny_kernel<3><<<grid, 64 * kSkinnyWaves<3>, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
+    default: bf16_gemm_skinny_kernel<4><<<grid, 64 * kSkinnyWaves<4>, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale); break;
   }
   return (int)hipGetLastError();
 }
