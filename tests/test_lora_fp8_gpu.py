@@ -55,7 +55,10 @@ def test_row_quantiser_is_rne_e4m3_with_absmax_scales(M, K):
     assert np.array_equal(q.cpu().numpy(), e4m3_encode_rne(scaled))
 
 
-@pytest.mark.parametrize("M,N,K,lora", [(2304, 4096, 4096, True), (300, 512, 256, True), (144, 256, 128, False), (2304, 4096, 11008, True)])
+@pytest.mark.parametrize("M,N,K,lora", [(2304, 4096, 4096, True), (300, 512, 256, True), (144, 256, 128, False), (2304, 4096, 11008, True),
+                                        # more tiles than CUs (2.7 and 5 rounds), short K loops with / without the LoRA stage
+                                        (2304, 11008, 1024, True), (11520, 4096, 512, False), (6000, 4096, 256, True),
+                                        (6000, 4096, 256, False), (5000, 11008, 384, False)])
 def test_fp8_product_is_exact_on_the_dequantised_operands(M, N, K, lora):
     from msr3d_amd.llm.lora import PAD_R, _gemm_fp8, quant_rows_fp8
     torch.manual_seed(N + K)
