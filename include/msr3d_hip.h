@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 21
+#define MSR3D_ABI_VERSION 22
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -121,6 +121,14 @@ int msr3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_o
 int msr3d_sa_fps2(int b, int n, int point_stride, int m1, int m2, const float *pts, int *idx1,
                   float *new_xyz1, int *idx2, float *new_xyz2, const unsigned char *valid,
                   msr3d_stream_t stream);
+/* msr3d_sa_fps2 AND, beside it, the ball query of level 1 on the centres it picks (ball_query_gpu.cu:9-44 with
+ * radius1, nsample1; same index order, strict '<', first-hit fill): the FPS is one wave per cloud and a dependent chain
+ * per pick, so three more waves of the same workgroup query each winner as soon as it is published.  ball_idx1
+ * (b, m1, nsample1) is then what msr3d_sa_level / msr3d_sa_level_split take for level 1 with radius <= 0 (= "already
+ * queried").  Clouds of 257..1024 rank slots that fit 48 KB of LDS; MSR3D_EINVAL otherwise (run the two launches). */
+int msr3d_sa_fps2_query(int b, int n, int point_stride, int m1, int m2, const float *pts, int *idx1,
+                        float *new_xyz1, int *idx2, float *new_xyz2, const unsigned char *valid, float radius1,
+                        int nsample1, int *ball_idx1, msr3d_stream_t stream);
 
 /* One fused level.  `dims` = {C_in(+3), C1, C2, C3} must be one of the shipped
  * configurations (configs/msr3d.yaml:198-201) else MSR3D_EINVAL:

@@ -213,6 +213,8 @@ _SIGNATURES = {
                                 _c_float, _c_float, _c_float, _c_float, _c_int, _c_int, _c_int, _c_int, _ptr, _c_float,
                                 _ptr],
     "msr3d_sa_fps2": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_sa_fps2_query": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_int, _ptr,
+                            _ptr],
     "msr3d_sa_level": [_c_int, _c_int, _c_int, _c_int, _c_float, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                        _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_segment_scan": [_c_int, _ptr, _ptr, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
@@ -228,7 +230,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string", "msr3d_sqdist_contract"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 21        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 22        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():

@@ -105,7 +105,7 @@ template <int PPT, int NW>
 __device__ __forceinline__ void fps_level(const float *src, int ps, int n, int m, int bs,
                                           int log2bs, int q, int *red_bits, int *red_k,
                                           int *__restrict__ out_idx, float *__restrict__ out_xyz,
-                                          float *keep) {
+                                          float *keep, int *progress = nullptr) {
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = tid >> 6;
@@ -141,6 +141,8 @@ __device__ __forceinline__ void fps_level(const float *src, int ps, int n, int m
     if (out_idx) out_idx[0] = 0;
     if (out_xyz) { out_xyz[0] = ox; out_xyz[1] = oy; out_xyz[2] = oz; }
     if (keep) { keep[0] = ox; keep[1] = oy; keep[2] = oz; }
+    // (fps_query_kernel: the query waves of this workgroup start on a winner as soon as it is in `keep`)
+    if (progress) __hip_atomic_store(progress, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 
   int par = 0;
@@ -187,6 +189,7 @@ __device__ __forceinline__ void fps_level(const float *src, int ps, int n, int m
       if (out_idx) out_idx[jj] = old;
       if (out_xyz) { out_xyz[jj * 3 + 0] = ox; out_xyz[jj * 3 + 1] = oy; out_xyz[jj * 3 + 2] = oz; }
       if (keep) { keep[jj * 3 + 0] = ox; keep[jj * 3 + 1] = oy; keep[jj * 3 + 2] = oz; }
+      if (progress) __hip_atomic_store(progress, jj + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
 }
@@ -249,6 +252,86 @@ inline hipError_t launch_fps(int b, const FpsShape &s, int ps, int m, const floa
     fps_kernel<PPT, NW, false><<<b, kWave * NW, kFpsLdsFixed(NW), st>>>(
         s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, bs2, log2bs2, idx2, new_xyz2, valid);
   }
+  return hipGetLastError();
+}
+
+// One cloud per block, FPS by wave 0 as above (one wave, <= 1024 rank slots, cloud staged) -- and BESIDE it the ball query
+// of the level whose centres the FPS picks (ball_query_gpu.cu:9-44, the loop of ball_query_kernel below): QW more waves
+// take the winners as wave 0 publishes them (a counter in LDS, release / acquire at workgroup scope) and each scans the
+// staged cloud for its centre.  FPS is a dependent chain per pick (~1 us: 33 us for 32 picks of 1024 points) that leaves
+// the CU's other wave slots idle; the query (24 us as a launch of its own) fits under it -- mostly: the FPS chain
+// stretches to ~46 us with three query waves beside it (one: 91 us, the queries become the chain; seven: 51; a packed
+// xyz copy for the query waves: 54), against 33 + 24 for the two launches.
+template <int PPT, int QW>
+__global__ __launch_bounds__(kWave * (1 + QW)) void fps_query_kernel(
+    int n, int ps, int m, int bs, int log2bs, int q, const float *__restrict__ pts,
+    int *__restrict__ idxs, float *__restrict__ new_xyz,
+    int m2, int bs2, int log2bs2, int *__restrict__ idxs2, float *__restrict__ new_xyz2,
+    const unsigned char *__restrict__ valid, float radius2, int nsample, int *__restrict__ ball_idx) {
+  if (valid && !valid[blockIdx.x]) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int *red_bits = reinterpret_cast<int *>(smem);          // [2] (unused with one FPS wave)
+  int *red_k = red_bits + 2;                              // [2]
+  int *progress = red_k + 2;                              // winners published so far
+  float *keep = reinterpret_cast<float *>(progress + 4);  // [64 * 3] winners
+  float *sx = keep + 64 * 3;                              // [n * ps]
+  const int obj = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  const float *P = pts + (size_t)obj * n * ps;
+  if (tid == 0) *progress = 0;
+  for (int i = tid; i < n * ps; i += kWave * (1 + QW)) sx[i] = P[i];
+  __syncthreads();
+  if (wave == 0) {
+    __builtin_amdgcn_s_setprio(3);                        // the chain everything waits for
+    fps_level<PPT, 1>(sx, ps, n, m, bs, log2bs, q, red_bits, red_k, idxs ? idxs + (size_t)obj * m : nullptr,
+                      new_xyz ? new_xyz + (size_t)obj * m * 3 : nullptr, keep, progress);
+    __builtin_amdgcn_s_setprio(0);
+    if (m2 > 0)                                           // (one wave: its own LDS writes are in order, no barrier)
+      fps_level<1, 1>(keep, 3, m, m2, bs2, log2bs2, 1, red_bits, red_k, idxs2 ? idxs2 + (size_t)obj * m2 : nullptr,
+                      new_xyz2 ? new_xyz2 + (size_t)obj * m2 * 3 : nullptr, nullptr);
+    return;
+  }
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int j = wave - 1; j < m; j += QW) {
+    while (__hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= j) __builtin_amdgcn_s_sleep(2);
+    const float cx = keep[j * 3 + 0], cy = keep[j * 3 + 1], cz = keep[j * 3 + 2];
+    int *row = ball_idx + ((size_t)obj * m + j) * nsample;
+    int cnt = 0, first = 0;
+    for (int base = 0; base < n && cnt < nsample; base += kWave) {
+      const int k = base + lane;
+      bool hit = false;
+      if (k < n) hit = sq3(cx - sx[k * ps + 0], cy - sx[k * ps + 1], cz - sx[k * ps + 2]) < radius2;
+      const unsigned long long mask = __ballot(hit);
+      if (mask) {
+        if (cnt == 0) first = base + __ffsll((long long)mask) - 1;
+        const int slot = cnt + __popcll(mask & lt);
+        if (hit && slot < nsample) row[slot] = k;
+        cnt += __popcll(mask);
+      }
+    }
+    const int filled = cnt < nsample ? cnt : nsample;
+    const int fill = cnt > 0 ? first : 0;
+    for (int l = filled + lane; l < nsample; l += kWave) row[l] = fill;
+  }
+}
+
+// -> hipErrorInvalidValue for a shape the fused kernel does not take (the caller then runs the two launches)
+inline hipError_t launch_fps_query(int b, int n, int ps, int m, const float *pts, int *idx, float *new_xyz, int m2,
+                                   int *idx2, float *new_xyz2, float radius2, int nsample, int *ball_idx,
+                                   hipStream_t st, const unsigned char *valid) {
+  const FpsShape s = fps_shape(n);
+  const size_t cloud = (size_t)n * ps * sizeof(float);
+  if (s.slots > 1024 || s.slots <= 256 || cloud > 48 * 1024 || m > 64 || (m2 > 0 && m2 > m) || !ball_idx || nsample <= 0)
+    return hipErrorInvalidValue;
+  int bs2 = 1, log2bs2 = 0;
+  if (m2 > 0) {
+    const FpsShape s2 = fps_shape(m);
+    bs2 = s2.bs;
+    log2bs2 = s2.log2bs;
+  }
+  constexpr int QW = 3;
+  const size_t lds = sizeof(int) * 8 + sizeof(float) * 64 * 3 + cloud;
+  fps_query_kernel<16, QW><<<b, kWave * (1 + QW), lds, st>>>(s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, bs2,
+                                                            log2bs2, idx2, new_xyz2, valid, radius2, nsample, ball_idx);
   return hipGetLastError();
 }
 

@@ -554,6 +554,17 @@ int msr3d_sa_fps2(int b, int n, int point_stride, int m1, int m2, const float *p
   return e == hipErrorInvalidValue ? MSR3D_EINVAL : (int)e;
 }
 
+int msr3d_sa_fps2_query(int b, int n, int point_stride, int m1, int m2, const float *pts, int *idx1,
+                        float *new_xyz1, int *idx2, float *new_xyz2, const unsigned char *valid, float radius1,
+                        int nsample1, int *ball_idx1, msr3d_stream_t stream) {
+  if (b < 0 || n <= 0 || m1 <= 0 || m2 < 0 || point_stride < 3 || nsample1 <= 0 || !(radius1 > 0.f)) return MSR3D_EINVAL;
+  if (b == 0) return 0;
+  if (!pts || !ball_idx1) return MSR3D_EINVAL;
+  const hipError_t e = launch_fps_query(b, n, point_stride, m1, pts, idx1, new_xyz1, m2, idx2, new_xyz2,
+                                        radius1 * radius1, nsample1, ball_idx1, (hipStream_t)stream, valid);
+  return e == hipErrorInvalidValue ? MSR3D_EINVAL : (int)e;
+}
+
 int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pts,
                    const float *feat, const float *new_xyz, const int *dims,
                    const float *params1, const float *params2, const float *params3, float *out,
@@ -572,7 +583,8 @@ int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pt
     // ball_idx (required here: it is this level's workspace), then gather + MLP + max.  Keeping
     // the query out of the MLP kernel leaves it 37 KB of LDS -> 4 blocks per CU.
     if (!dbg_ball_idx) return MSR3D_EINVAL;
-    if ((e = launch_ball_query(b, n, 6, m, r2, kNS, new_xyz, pts, dbg_ball_idx, st, valid)) != hipSuccess)
+    // (radius <= 0: ball_idx already holds the neighbour lists -- msr3d_sa_fps2_query wrote them beside the FPS)
+    if (radius > 0.f && (e = launch_ball_query(b, n, 6, m, r2, kNS, new_xyz, pts, dbg_ball_idx, st, valid)) != hipSuccess)
       return (int)e;
     constexpr int CPB = kSa1Cpb;
     const size_t lds = sizeof(float) * Sa1<CPB>::C::LDS_FLOATS;

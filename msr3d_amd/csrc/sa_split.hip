@@ -1247,7 +1247,9 @@ extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius
   } else if (level == 1) {
     // pts (b, n, 6); `feat` unused; dbg_ball_idx is this level's WORKSPACE (b, m, 32), filled by the query launch
     if (!pts || !new_xyz || !dbg_ball_idx || n <= 0 || m <= 0) return MSR3D_EINVAL;
-    if ((e = launch_ball_query(b, n, 6, m, r2, kNS, new_xyz, pts, dbg_ball_idx, st, valid)) != hipSuccess) return (int)e;
+    // (radius <= 0: ball_idx already holds the neighbour lists -- msr3d_sa_fps2_query wrote them beside the FPS)
+    if (radius > 0.f && (e = launch_ball_query(b, n, 6, m, r2, kNS, new_xyz, pts, dbg_ball_idx, st, valid)) != hipSuccess)
+      return (int)e;
     if ((e = allow_lds(sa1_split_kernel, kSa1Lds)) != hipSuccess) return (int)e;
     const int cus = usable_cus();
     const long long rounds = ((long long)b * m + k1Waves - 1) / k1Waves;

@@ -182,6 +182,8 @@ PAD_VALUE = 1.0       # the dataset wrapper's padding cloud (dataset_wrapper.py:
 # MSR3D_SA_MMA=f32|split or set_sa_mma(); see DESIGN.md §4.1 for the measured accuracy of both.
 import os as _os
 _sa_mma = [_os.environ.get("MSR3D_SA_MMA", "split")]
+# MSR3D_FPS_QUERY=0: furthest-point sampling and level 1's ball query as the two launches of round 3
+_FPS_QUERY = _os.environ.get("MSR3D_FPS_QUERY", "1") != "0"
 if _sa_mma[0] not in ("f32", "split"):
     raise ValueError("MSR3D_SA_MMA must be 'f32' or 'split'")
 
@@ -236,19 +238,31 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
                "ball2": torch.empty((b, m2, _NSAMPLE), dtype=torch.int32, device=dev)}
     with torch.cuda.device(dev):
         st = _lib.current_stream_ptr(dev)
+        # FPS of both levels and, beside it in the same workgroups, level 1's ball query (one launch instead of two; the
+        # query's 24 us sit under the FPS chain's 33); clouds the fused kernel does not take: the two launches
+        r1 = float(sa1.groupers[0].radius)
+        queried = _FPS_QUERY and 256 < n <= 1024 and m1 <= 64
         with _lib.kernel_timer("msr3d_sa_fps2"):
-            rc = lib.msr3d_sa_fps2(b, n, 6, m1, m2, _p(pts), _p(dbg.get("idx1")), _p(new1),
-                                   _p(dbg.get("idx2")), _p(new2), _p(vmask), st)
+            if queried:
+                rc = lib.msr3d_sa_fps2_query(b, n, 6, m1, m2, _p(pts), _p(dbg.get("idx1")), _p(new1), _p(dbg.get("idx2")),
+                                             _p(new2), _p(vmask), ctypes.c_float(r1), _NSAMPLE, _p(ball1), st)
+                if rc == -22:                                   # MSR3D_EINVAL: not a shape of the fused kernel
+                    queried = False
+            if not queried:
+                rc = lib.msr3d_sa_fps2(b, n, 6, m1, m2, _p(pts), _p(dbg.get("idx1")), _p(new1),
+                                       _p(dbg.get("idx2")), _p(new2), _p(vmask), st)
         _lib.check(rc, "msr3d_sa_fps2")
+        if queried:
+            r1 = 0.0                                            # level 1: ball1 already holds the neighbour lists
         L = plan["levels"]
         with _lib.kernel_timer("msr3d_sa_level1"):
             if _sa_mma[0] == "split":
                 S = plan["split1"]
-                rc = lib.msr3d_sa_level_split(1, b, n, m1, ctypes.c_float(sa1.groupers[0].radius), _p(pts), _p(None),
+                rc = lib.msr3d_sa_level_split(1, b, n, m1, ctypes.c_float(r1), _p(pts), _p(None),
                                               _p(new1), _p(S[0][0]), _p(S[0][1]), _p(S[1][0]), _p(S[1][1]), _p(S[2][0]),
                                               _p(S[2][1]), _p(feat1), _p(ball1), _p(vmask), st)
             else:
-                rc = lib.msr3d_sa_level(1, b, n, m1, ctypes.c_float(sa1.groupers[0].radius), _p(pts),
+                rc = lib.msr3d_sa_level(1, b, n, m1, ctypes.c_float(r1), _p(pts),
                                         _p(None), _p(new1), plan["dims"][0], _p(L[0][0]), _p(L[0][1]),
                                         _p(L[0][2]), _p(feat1), _p(ball1), _p(vmask), st)
         _lib.check(rc, "msr3d_sa_level(1)")

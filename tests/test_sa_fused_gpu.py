@@ -37,8 +37,12 @@ def clouds(seed, b, P=1024):
 @pytest.mark.parametrize("b,seed,npts", [(5, 0, (32, 16, None)), (8, 1, (32, 16, None)),
                                          (1, 2, (32, 16, None)), (3, 3, (30, 16, None)),
                                          (4, 4, (17, 16, None))])
-def test_fused_indices_bit_exact_and_features_close(b, seed, npts):
+@pytest.mark.parametrize("fps_query", [True, False])
+def test_fused_indices_bit_exact_and_features_close(b, seed, npts, fps_query, monkeypatch):
+    """(fps_query: level 1's ball query beside the furthest-point sampling in ONE launch, msr3d_sa_fps2_query -- or the
+    two launches; both bit-exact against the oracle)"""
     from msr3d_amd.pointnet2 import fused
+    monkeypatch.setattr(fused, "_FPS_QUERY", fps_query)
     net = make_net(seed, npts)
     pts = clouds(seed, b).cuda()
     with torch.no_grad():

@@ -2,7 +2,7 @@
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'fps_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'fps_kernel' in r['Kernel_Name'] or 'fps_query_kernel' in r['Kernel_Name']]
 a, b = idx[-3], idx[-2]
 t0 = int(rows[a]['Start_Timestamp'])
 prev_end = None

@@ -3,7 +3,7 @@ name, calls, total us, share -- plus the step's span and the sum of the gaps bet
 import csv, re, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'fps_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'fps_kernel' in r['Kernel_Name'] or 'fps_query_kernel' in r['Kernel_Name']]
 a, b = idx[-2], idx[-1]
 agg = collections.OrderedDict()
 prev_end, gaps, busy = None, 0, 0
