@@ -48,8 +48,22 @@ class _FrozenLinearFn(torch.autograd.Function):
         K, N = mod.in_features, mod.out_features
         dy2 = dy.reshape(-1, N).to(torch.bfloat16)
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
-        dx = torch.empty((dy2.shape[0], K), dtype=torch.bfloat16, device=dy.device)
-        _gemm(dy2.shape[0], K, N, dy2, mod.weight_t, dx, dy.device)
+        M = dy2.shape[0]
+        S = next((c for c in (10, 8, 5, 4) if N % (64 * c) == 0), 0)
+        if M <= 1024 and N >= 8192 and S:
+            # few rows against a long reduction (the 32000-way head over the answer span: 260 x 4096 x 32000): one tile per
+            # 128 x 128 of the output is 96 workgroups walking 500 K steps each (507 us); the reduction cut into S chunks
+            # as a batch with fp32 partials puts 10 x as many workgroups on it, the partials are added in chunk order
+            part = torch.empty((S, M, K), dtype=torch.float32, device=dy.device)
+            with torch.cuda.device(dy.device):
+                rc = _lib.load().msr3d_bf16_gemm_batched(S, 1, M, K, N // S, _p(dy2), N, N // S, 0, _p(mod.weight_t), N, N // S, 0,
+                                                         _p(part), K, M * K, 0, 1, ctypes.c_float(1.0),
+                                                         _lib.current_stream_ptr(dy.device))
+            _lib.check(rc, "msr3d_bf16_gemm_batched")
+            dx = part.sum(0).to(torch.bfloat16)
+        else:
+            dx = torch.empty((M, K), dtype=torch.bfloat16, device=dy.device)
+            _gemm(M, K, N, dy2, mod.weight_t, dx, dy.device)
         return dx.view(ctx.shape), None
 
 
@@ -110,7 +124,9 @@ class LoRALlamaStack(nn.Module):
             self._lora_mods = [m for m in self.modules() if isinstance(m, LoRALinear)]
         return self._lora_mods
 
-    def logits(self, inputs_embeds, attention_mask=None):
+    def logits(self, inputs_embeds, attention_mask=None, from_position=0):
+        """from_position = p: only the logits of positions p .. T-1 (B, T - p, V) -- the decoder layers still run over all
+        T tokens; the final norm and the head only over that tail."""
         x = inputs_embeds.to(torch.bfloat16)
         # the bf16 images of all 7 x layers LoRA pairs: ONE launch per optimiser step (224 pairs x 4 copies before)
         mods = self._pairs()
@@ -124,16 +140,26 @@ class LoRALlamaStack(nn.Module):
             for layer in self.layers:
                 # the residual sum x + mlp(x) is left to the NEXT layer's input norm (one fused launch, no add kernel)
                 x, delta = layer(x, attention_mask=keep, delta=delta, defer_residual=True)
+            if from_position > 0:
+                # (the slice of x + delta: the last layer's residual sum has to exist as a tensor to be cut)
+                x = (x + delta)[:, from_position:].contiguous() if delta is not None else x[:, from_position:].contiguous()
+                delta = None
             _, h = _RMSNormFn.apply(x, delta, self.norm_weight, self.eps)
         finally:
             for m in mods:
                 m._fresh_in_capture = False
         return self.lm_head(h)
 
-    def forward(self, inputs_embeds, attention_mask=None, targets=None):
+    def forward(self, inputs_embeds, attention_mask=None, targets=None, supervised_from=None):
         """-> logits (B, T, V) bf16, or with `targets` (B, T) int64 (negative = not supervised) the per-sequence mean
-        cross-entropy (B,) of msr3d.py:426-441."""
-        lg = self.logits(inputs_embeds, attention_mask)
+        cross-entropy (B,) of msr3d.py:426-441.
+        supervised_from = p (with targets): the caller GUARANTEES targets[:, :p] < 0 (msr3d.py:384-392 builds them that
+        way: -100 over the whole prompt, p = its length).  The loss reads logits[t] against targets[t + 1], so only the
+        logits of positions p - 1 .. T - 2 can contribute: final norm, the 32000-way head and the cross-entropy then run
+        over T - p + 1 positions instead of T (65 of 576 in the benchmarked shape) -- same loss, same gradients (the
+        skipped rows' d logits are exactly zero), 0.9 ms of a step's head products not spent on rows nothing reads."""
         if targets is None:
-            return lg
-        return seq_mean_cross_entropy(lg, targets)
+            return self.logits(inputs_embeds, attention_mask)
+        p0 = 0 if supervised_from is None else max(int(supervised_from) - 1, 0)
+        lg = self.logits(inputs_embeds, attention_mask, from_position=p0)
+        return seq_mean_cross_entropy(lg, targets[:, p0:] if p0 else targets)

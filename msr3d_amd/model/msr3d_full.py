@@ -83,5 +83,6 @@ class MSR3DFullStep(MSR3DHotPath):
             raise RuntimeError("MSR3DFullStep runs on the GPU only (the language-model kernels have no CPU fallback)")
         d = MSR3DHotPath.forward(self, data_dict)
         emb, am, targets = self.embed_inputs(d, d["scene_embeds"], d["obj_masks"])
-        d["loss"] = self.llm_model(emb, attention_mask=am, targets=targets)
+        # (targets are -100 over the whole prompt by construction: the head and the loss run over the answer span only)
+        d["loss"] = self.llm_model(emb, attention_mask=am, targets=targets, supervised_from=data_dict["input_ids"].shape[1])
         return d

@@ -66,6 +66,31 @@ def test_stack_loss_and_gradients_match_the_transformers_fixture():
             assert rel(m.lora_B.weight.grad, g[f"dB/{i}/{n}"]) < 3e-2, (i, n)
 
 
+def test_head_and_loss_over_the_answer_span_only_are_the_same_loss_and_gradients():
+    """supervised_from = p: final norm + head + cross-entropy over positions p - 1 .. T - 1 only, given targets[:, :p] < 0.
+    The loss is the same number (the same logit rows enter it) and so is every gradient -- the rows left out had
+    d logits == 0 exactly."""
+    g = dict(np.load(os.path.join(GOLD, "llama_stack_seed0.npz")))
+    keep = torch.from_numpy(g["keep"]).cuda()
+    T = keep.shape[1]
+    p = T - 40
+    targets = torch.from_numpy(g["targets"]).cuda().clone()
+    targets[:, :p] = -100
+    targets[:, p + 3:p + 30] = torch.randint(0, int(g["cfg"][4]), (targets.shape[0], 27), device="cuda")
+    outs = []
+    for span in (None, p, 1):
+        net = _stack(g)
+        x = torch.from_numpy(g["x"]).cuda().to(torch.bfloat16).requires_grad_(True)
+        loss = net(x, attention_mask=keep, targets=targets, supervised_from=span)
+        loss.sum().backward()
+        outs.append((loss.detach(), x.grad.clone(), [q.grad.clone() for q in net.lora_parameters()]))
+    (l0, dx0, g0) = outs[0]
+    for l1, dx1, g1 in outs[1:]:
+        assert torch.equal(l0, l1)
+        assert torch.equal(dx0, dx1)
+        assert all(torch.equal(a, b) for a, b in zip(g0, g1))
+
+
 def test_stack_trains_on_the_flat_gradient_engine():
     """The LoRA matrices as ONE flat gradient buffer (what a data-parallel rank all-reduces: msr3d_amd/dp.py) and the
     fused clip + AdamW over it: the loss of a fixed batch goes down, the frozen weights do not move."""
@@ -105,3 +130,19 @@ def test_frozen_linear_refuses_cpu_and_follows_weight_writes():
     assert rel(x.grad.float(), torch.ones(64, 256, device="cuda") @ lin.weight.float()) < 1e-2
     with pytest.raises(RuntimeError):
         lin(torch.randn(4, 128))
+
+
+def test_frozen_head_backward_with_few_rows_cuts_the_long_reduction():
+    """FrozenLinear's d input at few rows against a long reduction (the head over the answer span) runs as a batch of
+    reduction chunks with fp32 partials: against float64 on the same bf16 operands, and against the one-launch product."""
+    from msr3d_amd.llm.stack import FrozenLinear
+    torch.manual_seed(3)
+    K, V = 512, 16000
+    head = FrozenLinear(K, V, device="cuda")
+    head.load_weight((torch.randn(V, K, device="cuda") / K ** 0.5))
+    for M in (260, 1500):                               # 260: the chunked path; 1500: one launch
+        x = torch.randn(M, K, device="cuda").bfloat16().requires_grad_(True)
+        gy = torch.randn(M, V, device="cuda").bfloat16()
+        head(x).backward(gy)
+        want = gy.double() @ head.weight.double()
+        assert rel(x.grad, want) < 4e-3, M
