@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_llama_stack_gpu.py tests/test_full_step_gpu.py -m gpu -q -x 2>&1 | tail -3
-timeout 300 python bench.py --full-step --llm-fp8 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-200
-timeout 300 python bench.py --full-step --llm-fp8 --no-cpu-baseline --batch 20 2>/dev/null | tail -1 | cut -c1-200
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests/ -m gpu -q 2>&1 > gpurun_out/full_suite.log; tail -3 gpurun_out/full_suite.log; grep -n "^FAILED" gpurun_out/full_suite.log | head
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+bash tools/collect_profiles.sh gpurun_out/r04v5 r04_v5 2>&1 | tail -3
