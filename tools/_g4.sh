@@ -1,5 +1,2 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/ -m gpu -q 2>&1 > gpurun_out/full_suite.log; tail -3 gpurun_out/full_suite.log; grep -n "^FAILED" gpurun_out/full_suite.log | head
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-bash tools/collect_profiles.sh gpurun_out/r04v5 r04_v5 2>&1 | tail -3
+for a in 0 1 2 3; do echo "abl $a"; MSR3D_FA_ABL=$a python tools/prof_attn.py 2>&1 | grep forward; done
