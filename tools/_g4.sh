@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-for a in 0 1 2 3; do echo "abl $a"; MSR3D_FA_ABL=$a python tools/prof_attn.py 2>&1 | grep forward; done
+timeout 600 python -m pytest tests/test_lora_gpu.py -m gpu -q -x 2>&1 | tail -3
+python tools/prof_lora_grad.py 2>&1 | grep pair
+timeout 300 python bench.py --full-step --llm-fp8 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-200
