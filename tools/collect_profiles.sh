@@ -54,6 +54,9 @@ F=$(ls "$OUT"/ktf/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$F" ] && cp 
 # (the stats above include the model's construction: init kernels, weight transposes; ONE step's kernels, aggregated:)
 F=$(ls "$OUT"/ktf/*/*kernel_trace.csv 2>/dev/null | head -1); [ -n "$F" ] && python tools/trace_step_agg.py "$F" > "$OUT/${TAG}_full_step_fp8_one_step.txt"
 rm -rf "$OUT/ktf"
+bash tools/pmc_llm.sh "$OUT/pmc_llm" > /dev/null 2>&1; cp "$OUT/pmc_llm/summary.txt" "$OUT/${TAG}_pmc_llm_layer.txt"; rm -rf "$OUT/pmc_llm"
+python tools/prof_fp8_gemm.py 2>/dev/null | grep "^M=" > "$OUT/${TAG}_fp8_gemm.txt"
+python tools/prof_attn.py 2>/dev/null | grep "^B=" > "$OUT/${TAG}_attn.txt"
 python tools/bench_bf16_gemm.py 2>/dev/null | grep -v amdgpu > "$OUT/${TAG}_bf16_gemm.txt"
 python -m pytest tests/test_seq_ce_gpu.py -q -s -k roofline 2>/dev/null | grep seq_ce > "$OUT/${TAG}_seq_ce.txt"
 python bench.py --cpu-ops --round-tag "$TAG" > "$OUT/${TAG}_cpu_ops.log" 2>&1; cp "profiles/${TAG}_cpu_ops.json" "$OUT/${TAG}_cpu_ops.json"
