@@ -222,11 +222,14 @@ class LoRALlamaDecoderLayer(nn.Module):
             self._rope = ((T, str(dev)), rope_tables(T, self.head_dim, self.theta, dev))
         return self._rope[1]
 
-    def forward(self, x, attention_mask=None, delta=None, defer_residual=False):
+    def forward(self, x, attention_mask=None, delta=None, defer_residual=False, tail_from=0):
         """x (B, T, hidden) bf16; attention_mask (B, T) (1 / True = real token) or None.
         delta: a residual term still to be added to x (the previous layer's MLP output): the input norm's launch
         adds it.  defer_residual: return (x_after_attention, mlp_output) instead of their sum, for the next layer's
-        `delta` -- a stack of layers then has no stand-alone add kernels in forward or backward."""
+        `delta` -- a stack of layers then has no stand-alone add kernels in forward or backward.
+        tail_from = p > 0 (the LAST layer of a stack whose head only reads positions >= p): the attention still runs over
+        all T tokens, but the second norm and the MLP -- token-local -- only over positions p .. T-1; the outputs are
+        (B, T - p, hidden)."""
         if not x.is_cuda:
             raise RuntimeError("LoRALlamaDecoderLayer runs on the GPU only (no CPU fallback)")
         B, T, Hd = x.shape
@@ -243,7 +246,10 @@ class LoRALlamaDecoderLayer(nn.Module):
         q, k = q.view(B, T, H, D), k.view(B, T, H, D)
         v = a["v_proj"](h).view(B, T, H, D)
         ctx = _AttentionFn.apply(q, k, v, keep)
-        x1, h2 = _RMSNormFn.apply(x0, a["o_proj"](ctx), self.post_attention_layernorm_weight, self.eps)
+        o = a["o_proj"](ctx)
+        if tail_from > 0:
+            x0, o = x0[:, tail_from:].contiguous(), o[:, tail_from:].contiguous()
+        x1, h2 = _RMSNormFn.apply(x0, o, self.post_attention_layernorm_weight, self.eps)
         m = self.mlp
         y = m["down_proj"](_SwiGLUFn.apply(m["gate_proj"](h2), m["up_proj"](h2)))
         if defer_residual:

@@ -125,8 +125,9 @@ class LoRALlamaStack(nn.Module):
         return self._lora_mods
 
     def logits(self, inputs_embeds, attention_mask=None, from_position=0):
-        """from_position = p: only the logits of positions p .. T-1 (B, T - p, V) -- the decoder layers still run over all
-        T tokens; the final norm and the head only over that tail."""
+        """from_position = p: only the logits of positions p .. T-1 (B, T - p, V) -- the attention of every layer still runs
+        over all T tokens; the LAST layer's token-local half (second norm + MLP), the final norm and the head only over that
+        tail (nothing else ever reads the other rows of those)."""
         x = inputs_embeds.to(torch.bfloat16)
         # the bf16 images of all 7 x layers LoRA pairs: ONE launch per optimiser step (224 pairs x 4 copies before)
         mods = self._pairs()
@@ -137,13 +138,14 @@ class LoRALlamaStack(nn.Module):
             m._fresh_in_capture = capturing
         try:
             delta = None
-            for layer in self.layers:
-                # the residual sum x + mlp(x) is left to the NEXT layer's input norm (one fused launch, no add kernel)
-                x, delta = layer(x, attention_mask=keep, delta=delta, defer_residual=True)
-            if from_position > 0:
-                # (the slice of x + delta: the last layer's residual sum has to exist as a tensor to be cut)
-                x = (x + delta)[:, from_position:].contiguous() if delta is not None else x[:, from_position:].contiguous()
-                delta = None
+            last = len(self.layers) - 1
+            for i, layer in enumerate(self.layers):
+                # the residual sum x + mlp(x) is left to the NEXT layer's input norm (one fused launch, no add kernel);
+                # the last layer's token-local half (second norm + MLP) only over the positions the head reads
+                x, delta = layer(x, attention_mask=keep, delta=delta, defer_residual=True,
+                                 tail_from=from_position if i == last else 0)
+            if from_position > 0 and not self.layers:
+                x = x[:, from_position:].contiguous()
             _, h = _RMSNormFn.apply(x, delta, self.norm_weight, self.eps)
         finally:
             for m in mods:
