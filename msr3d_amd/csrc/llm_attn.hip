@@ -164,7 +164,7 @@ __device__ __forceinline__ void decode(int B, int T, int H, bool heavy_last, int
 // forward: workgroup = 64 query rows; online softmax over the key blocks 0 .. own
 // =====================================================================================================
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const FA a) {
+__global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const FA a) {
   constexpr int P = D + 8, NDT = D / 16;
   __shared__ __attribute__((aligned(16))) u16 ks_[BLK * P];
   __shared__ __attribute__((aligned(16))) u16 vs_[BLK * P];
@@ -181,21 +181,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FA a) {
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
-  Tile<D> kt, vt;
-  tile_fetch<D>(kt, kbase, a.ld, tid);
-  tile_fetch<D>(vt, vbase, a.ld, tid);
   for (int kb = 0; kb <= qb; ++kb) {
     const int k0 = kb * BLK;
-    __syncthreads();                                           // the previous block's readers are done
-    tile_store<D>(kt, ks_, tid);
-    tile_store<D>(vt, vs_, tid);
-    __syncthreads();
-    {   // the next block's loads fly under this block's products (unconditional: after the last block it is re-read --
-        // a conditionally assigned register array is kept in scratch by hipcc)
-      const size_t nxt = (size_t)min(kb + 1, qb) * BLK * a.ld;
-      tile_fetch<D>(kt, kbase + nxt, a.ld, tid);
-      tile_fetch<D>(vt, vbase + nxt, a.ld, tid);
+    {   // no register prefetch: 128 registers a lane = four workgroups per CU, whose round trips hide one another's
+      Tile<D> kt, vt;
+      tile_fetch<D>(kt, kbase + (size_t)k0 * a.ld, a.ld, tid);
+      tile_fetch<D>(vt, vbase + (size_t)k0 * a.ld, a.ld, tid);
+      __syncthreads();                                         // the previous block's readers are done
+      tile_store<D>(kt, ks_, tid);
+      tile_store<D>(vt, vs_, tid);
     }
+    __syncthreads();
     f32x4 s[4];
     mma_rows<D>(s, ks_, qf, lane);                             // s[t][r] = <k[k0 + 16 t + 4 g + r], q[qrow]>
     float x[4][4], mloc = -INFINITY;
@@ -235,7 +231,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FA a) {
 // dQ: workgroup = 64 query rows, key blocks 0 .. own; also writes delta = rowsum(dO o) for the dK / dV kernel
 // =====================================================================================================
 template <int D>
-__global__ __launch_bounds__(256) void attn_dq_kernel(const FA a) {
+__global__ __launch_bounds__(256, 3) void attn_dq_kernel(const FA a) {
   constexpr int P = D + 8, NDT = D / 16;
   __shared__ __attribute__((aligned(16))) u16 ks_[BLK * P];
   __shared__ __attribute__((aligned(16))) u16 vs_[BLK * P];
@@ -270,20 +266,17 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(const FA a) {
   f32x4 acc[NDT];
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  Tile<D> kt, vt;
-  tile_fetch<D>(kt, kbase, a.ld, tid);
-  tile_fetch<D>(vt, vbase, a.ld, tid);
   for (int kb = 0; kb <= qb; ++kb) {
     const int k0 = kb * BLK;
-    __syncthreads();
-    tile_store<D>(kt, ks_, tid);
-    tile_store<D>(vt, vs_, tid);
-    __syncthreads();
-    {
-      const size_t nxt = (size_t)min(kb + 1, qb) * BLK * a.ld;
-      tile_fetch<D>(kt, kbase + nxt, a.ld, tid);
-      tile_fetch<D>(vt, vbase + nxt, a.ld, tid);
+    {   // (no register prefetch: see the forward kernel)
+      Tile<D> kt, vt;
+      tile_fetch<D>(kt, kbase + (size_t)k0 * a.ld, a.ld, tid);
+      tile_fetch<D>(vt, vbase + (size_t)k0 * a.ld, a.ld, tid);
+      __syncthreads();
+      tile_store<D>(kt, ks_, tid);
+      tile_store<D>(vt, vs_, tid);
     }
+    __syncthreads();
     f32x4 s[4], dp[4];
     mma_rows<D>(s, ks_, qf, lane);                             // <k[key], q[qrow]>
     mma_rows<D>(dp, vs_, dof, lane);                           // <v[key], dO[qrow]> = dP[qrow][key]
@@ -330,25 +323,22 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const FA a) {
   f32x4 dk[NDT], dv[NDT];
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  Tile<D> qt, ot;
-  float stv = 0.f;                                              // threads 0..127: one lse / delta value of the next block
-  auto fetch = [&](int qb) {
-    const int q0 = qb * BLK;
-    tile_fetch<D>(qt, qbase + (size_t)q0 * a.ld, a.ld, tid);
-    tile_fetch<D>(ot, dobase + (size_t)q0 * a.ld, a.ld, tid);
-    if (tid < BLK) stv = a.lse[stat0 + q0 + tid];
-    else if (tid < 2 * BLK) stv = a.delta[stat0 + q0 + tid - BLK];
-  };
-  fetch(kb);
   for (int qb = kb; qb < nb; ++qb) {
     const int q0 = qb * BLK;
     float *st = st_[(qb - kb) & 1];
+    {   // (no register prefetch: see the forward kernel)
+      Tile<D> qt, ot;
+      float stv = 0.f;                                          // threads 0..127: one lse / delta value of the block
+      tile_fetch<D>(qt, qbase + (size_t)q0 * a.ld, a.ld, tid);
+      tile_fetch<D>(ot, dobase + (size_t)q0 * a.ld, a.ld, tid);
+      if (tid < BLK) stv = a.lse[stat0 + q0 + tid];
+      else if (tid < 2 * BLK) stv = a.delta[stat0 + q0 + tid - BLK];
+      __syncthreads();
+      tile_store<D>(qt, qs_, tid);
+      tile_store<D>(ot, os_, tid);
+      if (tid < 2 * BLK) st[tid] = stv;
+    }
     __syncthreads();
-    tile_store<D>(qt, qs_, tid);
-    tile_store<D>(ot, os_, tid);
-    if (tid < 2 * BLK) st[tid] = stv;
-    __syncthreads();
-    fetch(min(qb + 1, nb - 1));                                 // (unconditional, as above)
     f32x4 s[4], dp[4];
     mma_rows<D>(s, qs_, kf, lane);                              // s[t][r] = <q[q0 + 16 t + 4 g + r], k[key]>
     mma_rows<D>(dp, os_, vf, lane);                             // <dO[query], v[key]> = dP[query][key]
