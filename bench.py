@@ -442,6 +442,10 @@ def full_step_line(args):
                        "lora_parameters": sum(p.numel() for p in net.lora_parameters()),
                        "unused_parameters_skipped": len(ts.unused_parameters),
                        "prompter_schedule": "blocks" if getattr(model._schedule, "_ran_blocks", False) else "strips/modular",
+                       "attention": "fused (msr3d_attn_fwd / _bwd): all tokens of every layer",
+                       "head_and_loss_rows": "answer span only: final norm, head, cross-entropy and the LAST layer's MLP over the "
+                                             f"{T_out + 1} positions whose logits the loss reads (targets are -100 over the "
+                                             "prompt by construction, msr3d.py:384-392); same loss, same gradients",
                        "parallelism": f"dp{world}"},
             "loss": float(loss), "tokens_per_s": world * M * args.steps / elapsed,
             "tflops_per_gpu": flop / (ms * 1e-3) / 1e12, "frac_of_bf16_peak": flop / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
