@@ -26,7 +26,7 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-def build_model(g, dropout=0.0, device="cuda"):
+def build_model(g, dropout=0.0, device="cuda", base="bf16"):
     import msr3d_amd.model  # noqa: F401
     import msr3d_amd.modules  # noqa: F401
     from msr3d_amd.config import AttrDict, default_prompter_cfg
@@ -39,7 +39,7 @@ def build_model(g, dropout=0.0, device="cuda"):
                     "llm": {"num_layers": c["layers"], "hidden_size": c["hidden"], "num_heads": c["heads"],
                             "intermediate_size": c["inter"], "vocab_size": c["vocab"],
                             "lora": {"rank": c["r"], "alpha": c["alpha"]}, "rms_eps": float(g["eps"]),
-                            "rope_theta": float(g["theta"])},
+                            "rope_theta": float(g["theta"]), "base": base},
                     "scene_sp_token": c["scene_token"], "model": {"name": "MSR3DFullStep"}})
     model = bm(cfg)
     vp = model.visual_prompter
@@ -74,10 +74,15 @@ def make_batch(g, c, device="cuda"):
     return batch
 
 
-def test_full_step_matches_the_reference_fixture_through_the_language_model():
+@pytest.mark.parametrize("base,k", [("bf16", 1.0), ("fp8", 4.0)])
+def test_full_step_matches_the_reference_fixture_through_the_language_model(base, k):
+    """base = "fp8": the frozen projections of the decoder layers on e4m3 operands (forward and d input, the members of an
+    input group adding into one d-input buffer, quantisation inside the r-row product): the same fixture at k = 4 times
+    the bf16 tolerances (the worst prompter gradient sits at 0.13 rel-L2 through two e4m3 layers) -- what a 3-bit mantissa
+    on both operands of every frozen product costs downstream."""
     from msr3d_amd.full_step import FullTrainStep
     g = dict(np.load(os.path.join(GOLD, "full_step_seed0.npz"), allow_pickle=False))
-    model, c = build_model(g)
+    model, c = build_model(g, base=base)
     batch = make_batch(g, c)
     ts = FullTrainStep(model, lr=0.0, weight_decay=0.0, zero_in_optimizer=False)
     # ONE flat buffer holds prompter + llm_proj + every LoRA pair, in the order backward produces them
@@ -108,11 +113,11 @@ def test_full_step_matches_the_reference_fixture_through_the_language_model():
         model.eval()                                   # (dropout is 0; eval only keeps the schedule's arena untouched)
         out_loss = model(dict(batch))["loss"].detach().cpu().numpy()
         model.train()
-    assert np.allclose(out_loss, g["loss"], rtol=1e-2), (out_loss, g["loss"])
-    assert abs(float(loss) - float(g["loss"].mean())) < 1e-2 * float(g["loss"].mean())
+    assert np.allclose(out_loss, g["loss"], rtol=1e-2 * k), (out_loss, g["loss"])
+    assert abs(float(loss) - float(g["loss"].mean())) < 1e-2 * k * float(g["loss"].mean())
     # gradient of the scene tokens, as the language model's backward + the scatter's backward deliver it
     d_scene = seen["scene"].grad.detach().cpu().numpy()
-    assert rel(d_scene, g["d_scene_embeds"]) < 4e-2
+    assert rel(d_scene, g["d_scene_embeds"]) < 4e-2 * k
     # lr = 0: nothing moved; the flat buffer holds this step's gradients
     grads = {}
     for n, p in model.named_parameters():
@@ -127,12 +132,12 @@ def test_full_step_matches_the_reference_fixture_through_the_language_model():
             assert np.abs(got).max() < 1e-4
             continue
         if "grad/" + n in g:
-            assert rel(got, g["grad/" + n]) < 4e-2, n
+            assert rel(got, g["grad/" + n]) < 4e-2 * k, n
             checked += 1
         elif "grad8/" + n in g:
-            assert rel(got[::8], g["grad8/" + n]) < 4e-2, n
+            assert rel(got[::8], g["grad8/" + n]) < 4e-2 * k, n
             checked += 1
-        assert abs(np.linalg.norm(got) - g["grad_norms"][i]) <= 3e-2 * g["grad_norms"][i] + 1e-9, n
+        assert abs(np.linalg.norm(got) - g["grad_norms"][i]) <= 3e-2 * k * g["grad_norms"][i] + 1e-9, n
     assert checked >= 30
     for n, gr in grads.items():                    # parameters the configuration does not use keep zero gradients
         if n not in names:
@@ -140,8 +145,8 @@ def test_full_step_matches_the_reference_fixture_through_the_language_model():
     for i, layer in enumerate(model.llm_model.layers):
         for n in NAMES:
             m = (layer.self_attn if n in layer.self_attn else layer.mlp)[n]
-            assert rel(m.lora_A.weight.grad.cpu().numpy(), g[f"dA/{i}/{n}"]) < 4e-2, (i, n)
-            assert rel(m.lora_B.weight.grad.cpu().numpy(), g[f"dB/{i}/{n}"]) < 4e-2, (i, n)
+            assert rel(m.lora_A.weight.grad.cpu().numpy(), g[f"dA/{i}/{n}"]) < 4e-2 * k, (i, n)
+            assert rel(m.lora_B.weight.grad.cpu().numpy(), g[f"dB/{i}/{n}"]) < 4e-2 * k, (i, n)
     # the unused set was found by the probe, as DDP's find_unused_parameters would
     unused = {id(p) for p in ts.unused_parameters}
     assert id(model.visual_prompter.anchor_feat) in unused
