@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 22
+#define MSR3D_ABI_VERSION 23
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -772,6 +772,11 @@ int msr3d_seq_ce_bwd(int B, int T, int V, const void *logits, int dtype, const l
 int msr3d_bf16_gemm_lowrank(int M, int N, int K, int R, const void *P, int ldp, const void *Q, int ldq,
                             const void *P2, int ldp2, const void *Q2, int ldq2, void *C, int ldc,
                             int c_f32, float scale, msr3d_stream_t stream);
+/* C += the same product, C bf16 (the sum rounded to bf16 again) -- the wide-tile kernel's domain only (M >= 128, N >= 256,
+ * R % 64 == 0, N % 4 == 0): the d-input of projections that read one tensor, as msr3d_fp8_gemm_lowrank_acc. */
+int msr3d_bf16_gemm_lowrank_acc(int M, int N, int K, int R, const void *P, int ldp, const void *Q, int ldq,
+                                const void *P2, int ldp2, const void *Q2, int ldq2, void *C, int ldc, float scale,
+                                msr3d_stream_t stream);
 
 /* LoRA weight gradients' token reduction: out (R, C) f32 (+)= scale * sum_m P[m][r] Q[m][c]
  * (transpose_out: out is (C, R)); P (M, R) and Q (M, C) bf16; R in {16, 32}; `out` holds the value to

@@ -121,6 +121,8 @@ _SIGNATURES = {
                              _ptr],
     "msr3d_bf16_gemm_lowrank": [_c_int, _c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int,
                                 _ptr, _c_int, _c_int, _c_float, _ptr],
+    "msr3d_bf16_gemm_lowrank_acc": [_c_int, _c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int,
+                                    _ptr, _c_int, _c_float, _ptr],
     "msr3d_bf16_gemm_batched": [_c_int] * 5 + [_ptr, _c_int, ctypes.c_longlong, ctypes.c_longlong, _ptr, _c_int,
                                 ctypes.c_longlong, ctypes.c_longlong, _ptr, _c_int, ctypes.c_longlong,
                                 ctypes.c_longlong, _c_int, _c_float, _ptr],
@@ -230,7 +232,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string", "msr3d_sqdist_contract"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 22        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 23        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():

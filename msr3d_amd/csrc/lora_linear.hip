@@ -39,6 +39,9 @@ __device__ __forceinline__ unsigned short f2bf(float f) {        // round to nea
   return (unsigned short)(u >> 16);
 }
 
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
 struct GemmArgs {
   int M, N, K, R;
   const unsigned short *P; int ldp;
@@ -46,6 +49,7 @@ struct GemmArgs {
   const unsigned short *P2; int ldp2;
   const unsigned short *Q2; int ldq2;
   void *C; int ldc; int c_f32;
+  int accumulate;                          // wide kernel, bf16 C only: C += the product
   float scale;                             // applied to the whole result (the forward's u = s x A^T)
   int inner;                               // blockIdx.z = outer * inner + inner index (e.g. sequence, head)
   long long spo, spi, sqo, sqi, sco, sci;   // batch strides (elements) of P, Q, C, outer and inner
@@ -413,9 +417,13 @@ __global__ __launch_bounds__(512, 1) void bf16_gemm_wide_kernel(const GemmArgs a
     for (int y = 0; y < 2; ++y) {
       const int col = n0 + wave * 32 + y * 16 + 4 * g;
       if (col >= a.N) continue;
-      const float v0 = acc[x][y][0] * a.scale, v1 = acc[x][y][1] * a.scale, v2 = acc[x][y][2] * a.scale,
-                  v3 = acc[x][y][3] * a.scale;
+      float v0 = acc[x][y][0] * a.scale, v1 = acc[x][y][1] * a.scale, v2 = acc[x][y][2] * a.scale,
+            v3 = acc[x][y][3] * a.scale;
       const size_t o = (size_t)(bo * a.sco + bi * a.sci) + (size_t)row * a.ldc + col;
+      if (a.accumulate) {                  // (bf16 C, N % 4 == 0: checked by the caller)
+        const uint2 old = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(a.C) + o);
+        v0 += bf_lo(old.x); v1 += bf_hi(old.x); v2 += bf_lo(old.y); v3 += bf_hi(old.y);
+      }
       if (col + 3 < a.N) {
         if (a.c_f32) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(a.C) + o) = make_float4(v0, v1, v2, v3);
         else *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(a.C) + o) =
@@ -441,8 +449,6 @@ __global__ __launch_bounds__(512, 1) void bf16_gemm_wide_kernel(const GemmArgs a
 // (Round 2's column-per-thread kernel, one 2-byte load and 16 LDS reads per row and thread: 112 us at 2304 x 4096.)
 constexpr int kGradChunks = 64, kGradChunksAtomic = 16;
 
-__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
 template <int R>
 __global__ __launch_bounds__(256) void lora_grad_kernel(int M, int C, const unsigned short *__restrict__ P, int ldp,
@@ -1051,9 +1057,43 @@ int msr3d_bf16_gemm_lowrank(int M, int N, int K, int R, const void *P, int ldp, 
   a.P = (const unsigned short *)P; a.ldp = ldp; a.Q = (const unsigned short *)Q; a.ldq = ldq;
   a.P2 = (const unsigned short *)P2; a.ldp2 = ldp2; a.Q2 = (const unsigned short *)Q2; a.ldq2 = ldq2;
   a.C = C; a.ldc = ldc; a.c_f32 = c_f32; a.scale = scale;
+  a.accumulate = 0;
   a.inner = 1;
   a.spo = a.spi = a.sqo = a.sqi = a.sco = a.sci = 0;
   return gemm_dispatch(a, 1, (hipStream_t)stream);
+}
+
+int msr3d_bf16_gemm_lowrank_acc(int M, int N, int K, int R, const void *P, int ldp, const void *Q, int ldq,
+                                const void *P2, int ldp2, const void *Q2, int ldq2, void *C, int ldc, float scale,
+                                msr3d_stream_t stream) {
+  if (M < 0 || N < 0 || K < 0 || R < 0 || (K % BK) != 0 || (R % BK) != 0 || (N % 4) != 0) return MSR3D_EINVAL;
+  if (M == 0 || N == 0) return 0;
+  if (!P || !Q || !C || ldp < K || ldq < K || ldc < N || (ldp % 8) || (ldq % 8) || !al16(P) || !al16(Q))
+    return MSR3D_EINVAL;
+  if ((ldc % 4) || (reinterpret_cast<uintptr_t>(C) & 15u)) return MSR3D_EINVAL;
+  if (R > 0 && (!P2 || !Q2 || ldp2 < R || ldq2 < R || (ldp2 % 8) || (ldq2 % 8) || !al16(P2) || !al16(Q2)))
+    return MSR3D_EINVAL;
+  // the wide-tile kernel only (the language model's products): its domain, as gemm_dispatch states it
+  if (M < 128 || N < 256 || (long long)M * ldp >= (1ll << 31) || (long long)N * ldq >= (1ll << 31) ||
+      (R > 0 && ((long long)M * ldp2 >= (1ll << 31) || (long long)N * ldq2 >= (1ll << 31))))
+    return MSR3D_EINVAL;
+  GemmArgs a;
+  a.M = M; a.N = N; a.K = K; a.R = R;
+  a.P = (const unsigned short *)P; a.ldp = ldp; a.Q = (const unsigned short *)Q; a.ldq = ldq;
+  a.P2 = (const unsigned short *)P2; a.ldp2 = ldp2; a.Q2 = (const unsigned short *)Q2; a.ldq2 = ldq2;
+  a.C = C; a.ldc = ldc; a.c_f32 = 0; a.scale = scale;
+  a.accumulate = 1;
+  a.inner = 1;
+  a.spo = a.spi = a.sqo = a.sqi = a.sco = a.sci = 0;
+  const int tn = (N + WBN - 1) / WBN;
+  long long best = -1;
+  int bm = 0;
+  for (int h : {160, 144, 128}) {
+    const long long tiles = (long long)((M + h - 1) / h) * tn, cost = (tiles + 255) / 256 * h;
+    if (best < 0 || cost < best) best = cost, bm = h;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  return bm == 160 ? launch_gemm_wide<10>(a, 1, st) : bm == 144 ? launch_gemm_wide<9>(a, 1, st) : launch_gemm_wide<8>(a, 1, st);
 }
 
 int msr3d_bf16_gemm_batched(int outer, int inner, int M, int N, int K, const void *P, int ldp, long long p_outer,
@@ -1073,6 +1113,7 @@ int msr3d_bf16_gemm_batched(int outer, int inner, int M, int N, int K, const voi
   a.P = (const unsigned short *)P; a.ldp = ldp; a.Q = (const unsigned short *)Q; a.ldq = ldq;
   a.P2 = nullptr; a.ldp2 = 0; a.Q2 = nullptr; a.ldq2 = 0;
   a.C = C; a.ldc = ldc; a.c_f32 = c_f32; a.scale = scale;
+  a.accumulate = 0;
   a.inner = inner;
   a.spo = p_outer; a.spi = p_inner; a.sqo = q_outer; a.sqi = q_inner; a.sco = c_outer; a.sci = c_inner;
   return gemm_dispatch(a, outer * inner, (hipStream_t)stream);

@@ -31,6 +31,17 @@ def _gemm(M, N, K, R, P, ldp, Q, ldq, P2, ldp2, Q2, ldq2, C, ldc, c_f32, scale, 
     _lib.check(rc, "msr3d_bf16_gemm_lowrank")
 
 
+def _gemm_acc(M, N, K, R, P, ldp, Q, ldq, P2, ldp2, Q2, ldq2, C, ldc, scale, dev):
+    """C (bf16) += the product (msr3d_bf16_gemm_lowrank_acc); -> False where the shape is outside that entry's domain."""
+    with torch.cuda.device(dev):
+        rc = _lib.load().msr3d_bf16_gemm_lowrank_acc(M, N, K, R, _p(P), ldp, _p(Q), ldq, _p(P2), ldp2, _p(Q2), ldq2,
+                                                     _p(C), ldc, ctypes.c_float(scale), _lib.current_stream_ptr(dev))
+    if rc == -22:
+        return False
+    _lib.check(rc, "msr3d_bf16_gemm_lowrank_acc")
+    return True
+
+
 def _skinny(M, N, K, P, Q, C, ldc, scale, dev):
     """C[:, :N] = scale P Q^T, C[:, N:ldc] = 0 (N = r rows of Q)."""
     with torch.cuda.device(dev):
@@ -200,7 +211,7 @@ class _LoRAFn(torch.autograd.Function):
         ctx.save_for_backward(x2, u, lora_A, lora_B)
         ctx.mod = mod
         ctx.u_col = col if grp is not None else 0
-        ctx.rec = uc if (grp is not None and fp8) else None
+        ctx.rec = uc if grp is not None else None
         ctx.shape = x.shape
         return y            # (M, N): the caller reshapes -- a view made in here could not be updated in place (RoPE)
 
@@ -223,19 +234,24 @@ class _LoRAFn(torch.autograd.Function):
             _skinny(M, r, N, dy2, bt_pad, v, PAD_R, s, dev)
         dx = None
         if ctx.needs_input_grad[0]:
-            rec = ctx.rec if fp8_dx else None
+            # A member of this input group may already have produced its share of d input in THIS backward: the product is
+            # then ADDED into that buffer -- autograd holds it as the input's gradient, and the input's producer runs only
+            # after every member -- and this member hands back nothing: no third tensor, no add launch.
+            rec = ctx.rec
+            added = False
             if rec is not None and rec[3] is not None:
-                # a member of this input group already produced its share of d input in THIS backward: the product is
-                # ADDED into that buffer -- autograd holds it as the input's gradient, and the input's producer runs only
-                # after every member -- and this member hands back nothing: no third tensor, no add launch
-                _gemm_fp8(M, K, N, dq, sdy, mod.weight_t_q, mod.weight_t_scale, v, at2, rec[3], dev, accumulate=True)
-            else:
+                if fp8_dx:
+                    _gemm_fp8(M, K, N, dq, sdy, mod.weight_t_q, mod.weight_t_scale, v, at2, rec[3], dev, accumulate=True)
+                    added = True
+                else:
+                    added = _gemm_acc(M, K, N, PAD_R, dy2, N, mod.weight_t, N, v, PAD_R, at2, PAD_R, rec[3], K, 1.0, dev)
+            if not added:
                 dx = torch.empty((M, K), dtype=torch.bfloat16, device=dev)
                 if fp8_dx:
                     _gemm_fp8(M, K, N, dq, sdy, mod.weight_t_q, mod.weight_t_scale, v, at2, dx, dev)
                 else:
                     _gemm(M, K, N, PAD_R, dy2, N, mod.weight_t, N, v, PAD_R, at2, PAD_R, dx, K, False, 1.0, dev)
-                if rec is not None:
+                if rec is not None and rec[3] is None:
                     rec[3] = dx
                 dx = dx.view(ctx.shape)
         lib = _lib.load()

@@ -90,9 +90,10 @@ def test_head_and_loss_over_the_answer_span_only_are_the_same_loss_and_gradients
         # token-local half over fewer rows (the left-out rows contributed exact zeros, but the 32-token groups of the
         # weight-gradient products fall differently): equal to fp32 rounding of a reordered sum
         assert torch.equal(l0, l1)
-        assert rel(dx1.float(), dx0.float()) < 2e-3
+        assert rel(dx1.float(), dx0.float()) < 1e-2          # (bf16 storage: the members of an input group add their d input
+        #                                                      in bf16, in place above 128 rows, through autograd below)
         for a, b in zip(g0, g1):
-            assert rel(b, a) < 1e-4 or float(a.abs().max()) == 0.0
+            assert rel(b, a) < 2e-2 or float(a.abs().max()) == 0.0      # (downstream of those bf16 sums)
 
 
 def test_stack_trains_on_the_flat_gradient_engine():

@@ -205,3 +205,23 @@ def test_lora_shadows_one_launch_for_all_pairs():
     assert torch.equal(mods[0]._shadow[0], keep)
     assert torch.equal(mods[1]._shadow[0], mods[1].lora_A.weight.detach().to(torch.bfloat16))
     assert mods[1]._shadows()[0] is mods[1]._shadow[0]
+
+
+@pytest.mark.parametrize("M,N,K,R", [(2304, 4096, 4096, 64), (300, 512, 256, 0)])
+def test_wide_gemm_accumulate_adds_into_a_bf16_output(M, N, K, R):
+    """msr3d_bf16_gemm_lowrank_acc: C += P Q^T + P2 Q2^T on the wide-tile kernel (the shared d-input buffer of projections
+    that read one tensor); outside that kernel's domain the entry refuses."""
+    from msr3d_amd.llm import lora
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    mk = lambda *s: (torch.randn(*s, generator=g, device="cuda") * 0.5).to(torch.bfloat16)      # noqa: E731
+    P, Q, C0 = mk(M, K), mk(N, K) / K ** 0.5, mk(M, N)
+    P2 = mk(M, 64) if R else None
+    Q2 = mk(N, 64) if R else None
+    C = C0.clone()
+    assert lora._gemm_acc(M, N, K, R, P, K, Q, K, P2, 64 if R else 0, Q2, 64 if R else 0, C, N, 1.0, P.device)
+    want = P.double() @ Q.double().t() + C0.double()
+    if R:
+        want = want + P2.double() @ Q2.double().t()
+    torch.cuda.synchronize()
+    assert rel(C, want) < 4e-3
+    assert not lora._gemm_acc(64, N, K, R, P, K, Q, K, P2, 64 if R else 0, Q2, 64 if R else 0, C, N, 1.0, P.device)
