@@ -968,111 +968,6 @@ __global__ __launch_bounds__(64 * kSkinnyWaves<NT>) void bf16_gemm_skinny_kernel
   }
 }
 
-// The same product + e4m3 image with the workgroup's 16 x K block RESIDENT IN REGISTERS between the two passes (K <= 512 KS
-// elements, used with KS = 8: sixteen waves, a wave's share of a row is at most KS fragments of 32 = KS x 4 registers a lane): every P
-// fragment is loaded once, all of a wave's loads in flight together; after the rows' maxima have met in LDS the fragments
-// are converted where they sit and stored as the 8 bytes per lane they are.  No second walk over P (the kernel above reads
-// the block again, from L2: 15 us at K = 4096, 33 at 11008).
-template <int NT, int KS>
-__global__ __launch_bounds__(1024) void skinny_quant_reg_kernel(int M, int N, int K, const unsigned short *__restrict__ P, int ldp,
-                                                                const unsigned short *__restrict__ Q, int ldq,
-                                                                unsigned short *__restrict__ C, int ldc, int zero_to, float scale,
-                                                                unsigned char *__restrict__ q8, int ldq8,
-                                                                float *__restrict__ row_scale) {
-  constexpr int NW = 16;
-  __shared__ __attribute__((aligned(16))) float red[NW][NT][64][4];
-  __shared__ unsigned rmax[NW][16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * 16;
-  const int nks = K / 32, ks0 = wave * nks / NW, ks1 = (wave + 1) * nks / NW;      // (ks1 - ks0 <= KS: checked by the caller)
-  const unsigned short *p = P + (size_t)min(m0 + i, M - 1) * ldp + 8 * g;
-  const unsigned short *q[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) q[t] = Q + (size_t)min(16 * t + i, N - 1) * ldq + 8 * g;
-  bf16x8 fp[KS];
-#pragma unroll
-  for (int u = 0; u < KS; ++u)
-    fp[u] = ks0 + u < ks1 ? *reinterpret_cast<const bf16x8 *>(p + (ks0 + u) * 32) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-  f32x4 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  unsigned amax = 0;
-  constexpr int U = 4;                                 // Q fragments (L2) fetched a group ahead of their MFMAs
-#pragma unroll
-  for (int u0 = 0; u0 < KS; u0 += U) {
-    bf16x8 fq[U][NT];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-        fq[u][t] = (u0 + u < KS && ks0 + u0 + u < ks1) ? *reinterpret_cast<const bf16x8 *>(q[t] + (ks0 + u0 + u) * 32)
-                                                        : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (u0 + u >= KS) continue;
-      union { bf16x8 v; unsigned w[4]; } x;
-      x.v = fp[u0 + u];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const unsigned a = x.w[e] & 0x7fff7fffu;
-        amax = (max(amax >> 16, a >> 16) << 16) | max(amax & 0xffffu, a & 0xffffu);
-      }
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[u][t], fp[u0 + u], acc[t], 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4 *>(&red[wave][t][lane][0]) = acc[t];
-  {
-    unsigned m = max(amax >> 16, amax & 0xffffu);
-    m = max(m, (unsigned)__shfl_xor((int)m, 16));
-    m = max(m, (unsigned)__shfl_xor((int)m, 32));
-    if (g == 0) rmax[wave][i] = m;
-  }
-  __syncthreads();
-  {
-    unsigned m = rmax[0][i];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) m = max(m, rmax[w][i]);
-    const float mx = __uint_as_float(m << 16);
-    const float sc = mx > 0.f ? mx * (1.0f / 448.0f) : 1.0f;
-    const float inv = 1.0f / sc;
-    const bool live = m0 + i < M;
-    if (live && wave == 0 && g == 0) row_scale[m0 + i] = sc;
-    unsigned char *dst = q8 + (size_t)(m0 + i) * ldq8 + 8 * g;
-#pragma unroll
-    for (int u = 0; u < KS; ++u) {
-      union { bf16x8 v; unsigned w[4]; } x;
-      x.v = fp[u];
-      int lo = 0, hi = 0;
-      lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(x.w[0] << 16) * inv, __uint_as_float(x.w[0] & 0xffff0000u) * inv, lo, false);
-      lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(x.w[1] << 16) * inv, __uint_as_float(x.w[1] & 0xffff0000u) * inv, lo, true);
-      hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(x.w[2] << 16) * inv, __uint_as_float(x.w[2] & 0xffff0000u) * inv, hi, false);
-      hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(x.w[3] << 16) * inv, __uint_as_float(x.w[3] & 0xffff0000u) * inv, hi, true);
-      if (live && ks0 + u < ks1) *reinterpret_cast<uint2 *>(dst + (ks0 + u) * 32) = make_uint2((unsigned)lo, (unsigned)hi);
-    }
-  }
-  const int row = m0 + i;
-  for (int t = wave; t < NT; t += NW) {
-    f32x4 v = *reinterpret_cast<const f32x4 *>(&red[0][t][lane][0]);
-#pragma unroll
-    for (int w = 1; w < NW; ++w) {
-      const f32x4 o = *reinterpret_cast<const f32x4 *>(&red[w][t][lane][0]);
-      v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-    }
-    const int col = 16 * t + 4 * g;
-    if (row < M && col < N)
-      *reinterpret_cast<uint2 *>(C + (size_t)row * ldc + col) =
-          make_uint2(f2bf(v[0] * scale) | ((unsigned)f2bf(v[1] * scale) << 16),
-                     f2bf(v[2] * scale) | ((unsigned)f2bf(v[3] * scale) << 16));
-  }
-  for (int e = threadIdx.x; e < 16 * ((zero_to - N) / 4); e += 64 * NW) {
-    const int r = e / ((zero_to - N) / 4), c = N + 4 * (e - r * ((zero_to - N) / 4));
-    if (m0 + r < M) *reinterpret_cast<uint2 *>(C + (size_t)(m0 + r) * ldc + c) = make_uint2(0u, 0u);
-  }
-}
-
 inline bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
 
 template <int BM>
@@ -1314,15 +1209,6 @@ static int skinny_launch(int M, int N, int K, const void *P, int ldp, const void
   const int grid = (M + 15) / 16;
   if (q8) {
     unsigned char *q8p = (unsigned char *)q8;
-    // the register-resident form where a wave's share of K fits (N <= 48: its sixteen waves' partial tiles fit 48 KB of LDS)
-    const int per_wave = (K / 32 + 15) / 16;
-    if (N <= 48 && per_wave <= 8) {            // (K <= 4096; 22 fragments a wave for K = 11008 spill at 128 registers)
-      const int nt = N / 16;
-      if (nt == 1) skinny_quant_reg_kernel<1, 8><<<grid, 1024, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale, q8p, ldq8, row_scale);
-      else if (nt == 2) skinny_quant_reg_kernel<2, 8><<<grid, 1024, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale, q8p, ldq8, row_scale);
-      else skinny_quant_reg_kernel<3, 8><<<grid, 1024, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale, q8p, ldq8, row_scale);
-      return (int)hipGetLastError();
-    }
     switch (N / 16) {
       case 1: bf16_gemm_skinny_kernel<1, true><<<grid, 64 * kSkinnyWaves<1>, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale, q8p, ldq8, row_scale); break;
       case 2: bf16_gemm_skinny_kernel<2, true><<<grid, 64 * kSkinnyWaves<2>, 0, st>>>(M, N, K, p, ldp, q, ldq, c, ldc, zero_to, scale, q8p, ldq8, row_scale); break;
