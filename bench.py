@@ -113,6 +113,8 @@ def parse():
                     "shapes, random bf16 weights) -> head -> per-sequence CE -> backward through the language model into the "
                     "prompter -> ONE flat gradient buffer (bucketed exchange from the backward hooks) -> clip + AdamW; "
                     "--batch sequences (default 4 here) x --seq-len tokens per GPU")
+    ap.add_argument("--full-step-graph", action="store_true", help="--full-step: the whole step captured into ONE HIP graph "
+                    "after an eager step and replayed (one rank only)")
     ap.add_argument("--llm-fp8", action="store_true", help="with --full-step / --llm-layer / --llm-stack: the decoder layers' frozen "
                     "projections on OCP e4m3 operands (per-output-channel weight scales, per-token activation scales, MX matrix "
                     "instruction; LoRA pair and accumulators bf16 / fp32) -- labelled in the line's dtype")
@@ -368,7 +370,8 @@ def full_step_line(args):
                     m.lora_B.weight.normal_(std=0.02)
         net.lm_head.load_weight(torch.randn(V, Hd, device=dev) / Hd ** 0.5)
         model.embed_tokens.copy_(torch.randn(V, Hd, device=dev) * 0.02)
-    ts = FullTrainStep(model, lr=3e-5, betas=(0.9, 0.999), weight_decay=0.05, max_grad_norm=5.0)
+    ts = FullTrainStep(model, lr=3e-5, betas=(0.9, 0.999), weight_decay=0.05, max_grad_norm=5.0,
+                       use_graph=args.full_step_graph and not dist_on)
     Ltok = O + (1 if args.situation_type == "as_object" else 0)
     batches = []
     for i in range(3):
@@ -436,7 +439,8 @@ def full_step_line(args):
                                    f"inputs_embeds -> {L} LoRA-Llama layers (hidden {Hd}, {NH} heads, MLP {FF}, LoRA r=16 on "
                                    "q/k/v/o/gate/up/down) -> RMSNorm -> 32000-way frozen head -> per-sequence CE -> backward through "
                                    "the LLM and the scatter into the prompter -> ONE flat gradient buffer, buckets exchanged from the "
-                                   "backward hooks -> clip + AdamW; eager launches",
+                                   "backward hooks -> clip + AdamW; " + ("ONE captured HIP graph per step" if ts.graph is not None
+                                                                         else "eager launches"),
                        "layers": L, "sequences_per_gpu": Bq, "tokens_per_sequence": T, "scene_tokens": Ltok,
                        "objects": O, "points": P, "trainable_parameters": ts.dp.numel, "grad_bytes": ts.dp.numel * 4,
                        "lora_parameters": sum(p.numel() for p in net.lora_parameters()),

@@ -26,7 +26,7 @@ from .optim import FlatAdamW
 
 class FullTrainStep:
     def __init__(self, model, lr=3e-5, betas=(0.9, 0.999), weight_decay=0.05, max_grad_norm=5.0,
-                 bucket_bytes=8 << 20, overlap=True, process_group=None, zero_in_optimizer=True, **opt_kw):
+                 bucket_bytes=8 << 20, overlap=True, process_group=None, zero_in_optimizer=True, use_graph=False, **opt_kw):
         """model: MSR3DFullStep on its GPU.  bucket_bytes: 8 MiB ~ one and a half decoder layers' LoRA pairs --
         large enough that a ring over point-to-point xGMI links is bandwidth- rather than latency-bound per call,
         small enough that ~20 of them leave during backward."""
@@ -45,6 +45,15 @@ class FullTrainStep:
         self._probed = False
         self.unused_parameters = []
         self.loss = None
+        # use_graph (one rank only): after ONE eager step on a batch of the same shapes, the whole step -- seed bump, forward,
+        # backward, clip + AdamW: ~1,500 launches -- is captured into a HIP graph and replayed from static copies of the
+        # batch's tensors; a kernel boundary inside a replayed graph costs the GPU a fraction of what a stream-ordered launch
+        # does.  With world > 1 the exchange is issued from the backward hooks as eager RCCL calls: no graph then.
+        self.use_graph = bool(use_graph) and not self.dp.distributed
+        self.graph = None
+        self.static = None
+        self._eager_steps = 0
+        self._cap_stream = None
 
     # ------------------------------------------------------------------
     def _forward_backward(self, batch):
@@ -76,11 +85,7 @@ class FullTrainStep:
         self.opt.set_unused(unused)
         self.unused_parameters = unused
 
-    def __call__(self, batch):
-        """batch: scene keys (obj_fts, obj_masks, obj_locs, anchor_locs, anchor_orientation) + input_ids,
-        attention_mask, output_ids, output_mask, all on the model's GPU.  -> mean loss (device scalar)."""
-        if not self._probed:
-            self._probe_unused(batch)
+    def _step(self, batch):
         hipops.bump_seed(self.opt.flat_p.device)      # fresh dropout masks per step
         sched = getattr(self.model, "_schedule", None)
         if sched is not None:
@@ -88,8 +93,45 @@ class FullTrainStep:
         if not self.zero_in_optimizer:
             self.dp.zero_grad()
         self.dp.begin_micro(last=True)
-        self.loss = self._forward_backward(batch)
+        loss = self._forward_backward(batch)
         self.dp.finish()                              # flush what the hooks did not send; wait for the exchange
         self.opt.step(zero_grad=self.zero_in_optimizer)      # clip + AdamW (+ gradients cleared as they are consumed)
         self.dp.reset_marks()
+        return loss
+
+    def _capture(self, batch):
+        self.static = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        # (on the stream the eager step ran on: work queues, workspaces and LDS attributes exist per stream / per kernel
+        # from that step -- creating them is not something a capture can hold)
+        with torch.cuda.graph(self.graph, stream=self._cap_stream, capture_error_mode="thread_local"):
+            self.loss = self._step(self.static)
+
+    def __call__(self, batch):
+        """batch: scene keys (obj_fts, obj_masks, obj_locs, anchor_locs, anchor_orientation) + input_ids,
+        attention_mask, output_ids, output_mask, all on the model's GPU.  -> mean loss (device scalar)."""
+        if not self._probed:
+            self._probe_unused(batch)
+        if self.use_graph:
+            if self.graph is None and self._eager_steps >= 1:
+                self._capture(batch)
+            if self.graph is not None:
+                keys = [k for k in self.static if k in batch]
+                if any(batch[k].shape != self.static[k].shape for k in keys):
+                    raise RuntimeError("the captured step was built for other batch shapes")
+                torch._foreach_copy_([self.static[k] for k in keys], [batch[k] for k in keys])
+                self.graph.replay()
+                return self.loss
+            # the eager step(s) before the capture run on the capture's own stream
+            if self._cap_stream is None:
+                self._cap_stream = torch.cuda.Stream(device=self.opt.flat_p.device)
+            cur = torch.cuda.current_stream(self.opt.flat_p.device)
+            self._cap_stream.wait_stream(cur)
+            with torch.cuda.stream(self._cap_stream):
+                self.loss = self._step(batch)
+            cur.wait_stream(self._cap_stream)
+            self._eager_steps += 1
+            return self.loss
+        self.loss = self._step(batch)
         return self.loss

@@ -177,6 +177,32 @@ def test_full_step_trains_prompter_projector_and_lora_together():
     assert not torch.equal(w0["lora"], model.llm_model.layers[0].self_attn["q_proj"].lora_B.weight)
 
 
+def test_full_step_captured_graph_replays_the_eager_steps():
+    """use_graph: the first step runs eagerly (on the capture's stream), the second call captures the whole step -- seed bump,
+    encoder, prompter schedule, language model, backward, clip + AdamW -- and every later call replays it from static copies
+    of the batch: the same loss sequence and the same weights as eager steps on the same batches (dropout 0; the schedule's
+    few float atomics leave last-bit differences)."""
+    from msr3d_amd.full_step import FullTrainStep
+    from msr3d_amd.synth import synth_batch, synth_text
+    g = dict(np.load(os.path.join(GOLD, "full_step_seed0.npz"), allow_pickle=False))
+    outs = []
+    for use_graph in (False, True):
+        model, c = build_model(g, dropout=0.0)
+        ts = FullTrainStep(model, lr=1e-3, weight_decay=0.0, max_grad_norm=1.0, use_graph=use_graph)
+        losses = []
+        for i in range(5):
+            batch = synth_batch(8000 + i, c["B"], O=c["O"], P=c["P"], n_valid=[c["O"] - c["n_pad"]] * c["B"], device="cuda")
+            batch.update(synth_text(8100 + i, c["B"], L=c["O"], T_in=c["T_in"], T_out=c["T_out"], vocab=c["vocab"],
+                                    scene_token=c["scene_token"], device="cuda"))
+            losses.append(float(ts(batch)))
+        torch.cuda.synchronize()
+        assert (ts.graph is not None) == use_graph
+        outs.append((losses, ts.opt.flat_p.detach().clone()))
+    (l0, p0), (l1, p1) = outs
+    assert np.allclose(l0, l1, rtol=2e-3), (l0, l1)
+    assert float((p0 - p1).abs().max()) < 5e-3 and float(((p0 - p1).abs() > 1e-4).float().mean()) < 0.02
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
