@@ -254,6 +254,17 @@ def test_fused_attention_forward_backward_vs_float64(B, T, H, D, pad):
     again = run()
     for x, y in zip((out, lse, dq, dk, dv), again):
         assert torch.equal(x, y)
+    # no key mask at all (NULL) == a mask of ones
+    if not any(pad):
+        out2 = torch.empty_like(out)
+        lse2 = torch.empty_like(lse)
+        _call("msr3d_attn_fwd", B, T, H, D, _p(q), _p(k), _p(v), HD, _p(None), ctypes.c_float(scale), _p(out2), _p(lse2), st)
+        dq2, dk2, dv2, dl2 = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), torch.empty_like(lse)
+        _call("msr3d_attn_bwd", B, T, H, D, _p(q), _p(k), _p(v), _p(out2), _p(do), HD, _p(None), ctypes.c_float(scale),
+              _p(lse2), _p(dl2), _p(dq2), _p(dk2), _p(dv2), st)
+        torch.cuda.synchronize()
+        for x, y in zip((out, lse, dq, dk, dv), (out2, lse2, dq2, dk2, dv2)):
+            assert torch.equal(x, y)
     # refused shapes: T not a multiple of 64, head size 96
     assert _lib.load().msr3d_attn_fwd(B, T - 8, H, D, _p(q), _p(k), _p(v), HD, _p(keep), ctypes.c_float(scale), _p(out),
                                       _p(lse), st) == -22
