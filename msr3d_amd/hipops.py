@@ -722,6 +722,71 @@ def shared_mlp_train(mlp, x):
     return pooled.permute(0, 2, 1).contiguous()
 
 
+# ---- SharedMLP on the GPU outside the two fast paths (frozen fused kernels; training-mode rows above) --------------
+# nn.Conv2d / nn.BatchNorm2d on a GPU tensor are MIOpen calls (convolution find + run-time kernel compilation through
+# comgr on a fresh box, BatchNorm forward AND backward kernels built the same way): the one piece of GPU code a
+# composite set-abstraction or feature-propagation module would run that is not this build's.  The 1x1 convolutions
+# are products over token-major rows, so they run on this build's own GEMM (`linear`), the normalisation is spelled
+# with elementwise / reduction operators (autograd differentiates them, batch statistics included), and the
+# activation module is applied as it is.  Same values as the module tree (pytorch_utils.py:11-66 of the reference).
+def _conv_is_pointwise(conv):
+    return (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.padding_mode == "zeros")
+
+
+def shared_mlp_rows_supported(mlp, x):
+    """GPU fp32 (B, C, H, W) input and a stack of [1x1 conv | BatchNorm2d | activation] layers."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        return False
+    for layer in mlp:
+        for m in layer.children():
+            if isinstance(m, torch.nn.Conv2d):
+                if not _conv_is_pointwise(m) or m.weight.dtype != torch.float32:
+                    return False
+            elif isinstance(m, torch.nn.Sequential):
+                if not (len(m) == 1 and isinstance(m[0], torch.nn.BatchNorm2d)):
+                    return False
+    return True
+
+
+def batch_norm_rows(bn, z):
+    """nn.BatchNorm2d.forward on rows z (R, C): batch statistics (biased variance for the normalisation, unbiased
+    into the running estimate, momentum or cumulative average) in training mode or without running buffers,
+    running statistics otherwise."""
+    use_batch = bn.training or bn.running_mean is None
+    if use_batch:
+        mean = z.mean(dim=0)
+        var = z.var(dim=0, unbiased=False)
+        if bn.training and bn.track_running_stats and bn.running_mean is not None:
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+                f = (1.0 / float(bn.num_batches_tracked)) if bn.momentum is None else bn.momentum
+                R = z.shape[0]
+                bn.running_mean.mul_(1 - f).add_(mean.detach(), alpha=f)
+                bn.running_var.mul_(1 - f).add_(var.detach() * (R / max(R - 1, 1)), alpha=f)
+    else:
+        mean, var = bn.running_mean, bn.running_var
+    y = (z - mean) * torch.rsqrt(var + bn.eps)
+    if bn.affine:
+        y = y * bn.weight + bn.bias
+    return y
+
+
+def shared_mlp_rows(mlp, x):
+    """`mlp(x)` for x (B, C, H, W) -> (B, C_out, H, W): the layers over token-major rows (b, h, w)."""
+    B, C, H, W = x.shape
+    t = x.permute(0, 2, 3, 1).reshape(B * H * W, C)
+    for layer in mlp:
+        for m in layer.children():
+            if isinstance(m, torch.nn.Conv2d):
+                t = linear(t, m.weight.view(m.out_channels, m.in_channels), m.bias)
+            elif isinstance(m, torch.nn.Sequential):
+                t = batch_norm_rows(m[0], t)
+            else:
+                t = m(t)
+    return t.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
 class _GroupRows(torch.autograd.Function):
     """QueryAndGroup's output as token-major rows (msr3d_group_rows), gradient to the features by
     the deterministic ordered scatter (msr3d_group_rows_grad)."""

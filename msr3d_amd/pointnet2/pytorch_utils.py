@@ -59,6 +59,15 @@ class SharedMLP(nn.Sequential):
                 Conv2d(args[i], args[i + 1], bn=bn and not plain,
                        activation=None if plain else activation, preact=preact))
 
+    def forward(self, x):
+        """GPU fp32 tensors: the 1x1 convolutions on this build's GEMM and the normalisation as elementwise
+        operators (hipops.shared_mlp_rows) -- no MIOpen convolution / BatchNorm call anywhere on the GPU side;
+        CPU tensors (the host-logic tests) take the module tree as torch runs it."""
+        from .. import hipops
+        if hipops.shared_mlp_rows_supported(self, x):
+            return hipops.shared_mlp_rows(self, x)
+        return super().forward(x)
+
     def conv_bn_pairs(self):
         """[(conv, bn-or-None)] per layer -- what the fused SA kernels consume."""
         out = []
