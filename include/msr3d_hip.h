@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 23
+#define MSR3D_ABI_VERSION 24
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -129,6 +129,18 @@ int msr3d_sa_fps2(int b, int n, int point_stride, int m1, int m2, const float *p
 int msr3d_sa_fps2_query(int b, int n, int point_stride, int m1, int m2, const float *pts, int *idx1,
                         float *new_xyz1, int *idx2, float *new_xyz2, const unsigned char *valid, float radius1,
                         int nsample1, int *ball_idx1, msr3d_stream_t stream);
+
+/* The two entries above with one more output, constant_out (b bytes, may be NULL): 1 for an object whose n points are
+ * all bit-identical to its first point (coordinates and the other point_stride - 3 channels), 0 otherwise -- the
+ * dataset's padding slots (dataset_wrapper.py:156-158).  Found while the cloud is staged in LDS for the sampling (no
+ * extra pass over memory); a cloud too large to stage (> 64 KB) is reported 0; objects skipped by `valid` are not
+ * written.  The distinct-row kernels (msr3d_sa_level*_rows) multiply ONE row per level for such an object. */
+int msr3d_sa_fps2_flags(int b, int n, int point_stride, int m1, int m2, const float *pts, int *idx1,
+                        float *new_xyz1, int *idx2, float *new_xyz2, const unsigned char *valid,
+                        unsigned char *constant_out, msr3d_stream_t stream);
+int msr3d_sa_fps2_query_flags(int b, int n, int point_stride, int m1, int m2, const float *pts, int *idx1,
+                              float *new_xyz1, int *idx2, float *new_xyz2, const unsigned char *valid, float radius1,
+                              int nsample1, int *ball_idx1, unsigned char *constant_out, msr3d_stream_t stream);
 
 /* One fused level.  `dims` = {C_in(+3), C1, C2, C3} must be one of the shipped
  * configurations (configs/msr3d.yaml:198-201) else MSR3D_EINVAL:
@@ -452,6 +464,28 @@ int msr3d_sa_level_split(int level, int b, int n, int m, float radius, const flo
                          const float *new_xyz, const void *w1, const float *affine1, const void *w2,
                          const float *affine2, const void *w3, const float *affine3, float *out,
                          int *dbg_ball_idx, const unsigned char *valid, msr3d_stream_t stream);
+
+/* Level 2 of msr3d_sa_level_split over the DISTINCT rows of each neighbourhood (round 5).  ball_query fills a
+ * neighbourhood with fewer than nsample hits by repeating its first hit (ball_query_gpu.cu:35-39), the SharedMLP
+ * acts on every row by itself and max is idempotent: multiplying only the min(hits, nsample) different (centre,
+ * point) rows of a centre (one row -- index 0 -- for a centre without hits) gives the SAME BITS as multiplying all
+ * nsample = 32.  Rows are packed densely across the centres of an object into 16-row MFMA tiles, up to 64 rows per
+ * pass; each row's arithmetic is msr3d_sa_level_split's to the letter; the maximum is taken per centre (segmented).
+ * Same arguments, layouts and outputs as msr3d_sa_level_split(level = 2, ...) (xyz = that call's `pts`), n <= 64
+ * points, m <= 16 centres per object (MSR3D_EINVAL otherwise: use msr3d_sa_level_split), plus plan_ws (below) and
+ *   constant (b bytes, may be NULL): objects whose cloud is ONE repeated point, as msr3d_sa_fps2* report them (the
+ *   dataset's padding slots, dataset_wrapper.py:156-158): every row of such an object is the same row; one is
+ *   multiplied and written to all m centres.  Flagging an object that is not constant is the caller's error. */
+int msr3d_sa_level2_rows(int b, int n, int m, float radius, const float *xyz, const float *feat,
+                         const float *new_xyz, const void *w1, const float *affine1, const void *w2,
+                         const float *affine2, const void *w3, const float *affine3, float *out,
+                         int *dbg_ball_idx, const unsigned char *valid, const unsigned char *constant,
+                         void *plan_ws, msr3d_stream_t stream);
+/* Bytes of plan_ws for b objects (device memory, 16-byte aligned, the caller's; contents need not survive the call's
+ * work on the stream).  Three launches: one wave per object runs its m ball queries and writes the list of its distinct
+ * rows there; one workgroup orders the objects by work (heaviest first) for a balanced static deal; the multiplying
+ * workgroups read each of their objects' lists one object ahead. */
+size_t msr3d_sa_level2_rows_ws_bytes(int b);
 
 /* ---------------------------------------------------------------------------
  * The trainable part as a fixed schedule of fused launches (msr3d_amd/fused_model.py):

@@ -148,6 +148,8 @@ _SIGNATURES = {
     "msr3d_attn_bwd": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _c_float, _ptr, _ptr,
                        _ptr, _ptr, _ptr, _ptr],
     "msr3d_sa_level_split": [_c_int, _c_int, _c_int, _c_int, _c_float] + [_ptr] * 13,
+    "msr3d_sa_level2_rows": [_c_int, _c_int, _c_int, _c_float] + [_ptr] * 15,
+    "msr3d_sa_level2_rows_ws_bytes": [_c_int],
     "msr3d_seq_ce_fwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_seq_ce_bwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_gemm_multi_f32": [_c_int, ctypes.POINTER(GemmProblem), _ptr],
@@ -217,6 +219,9 @@ _SIGNATURES = {
     "msr3d_sa_fps2": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_sa_fps2_query": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_int, _ptr,
                             _ptr],
+    "msr3d_sa_fps2_flags": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "msr3d_sa_fps2_query_flags": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_int,
+                                  _ptr, _ptr, _ptr],
     "msr3d_sa_level": [_c_int, _c_int, _c_int, _c_int, _c_float, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                        _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_segment_scan": [_c_int, _ptr, _ptr, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
@@ -232,7 +237,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string", "msr3d_sqdist_contract"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 23        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 24        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():
@@ -260,7 +265,7 @@ def load():
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = _c_int
+        fn.restype = ctypes.c_size_t if name.endswith("_ws_bytes") else _c_int
     _lib = lib
     return lib
 

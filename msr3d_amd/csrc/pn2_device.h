@@ -194,6 +194,20 @@ __device__ __forceinline__ void fps_level(const float *src, int ps, int n, int m
   }
 }
 
+// Cloud -> LDS by the whole workgroup (ends on a barrier); returns non-zero (to every thread) unless ALL points of the
+// cloud are bit-identical to its first point -- a CONSTANT cloud, the dataset's padding slot
+// (dataset_wrapper.py:156-158): the distinct-row kernels of sa_split.hip then multiply one row for it.  Compared as bit
+// patterns: +0 / -0 or two NaN payloads are different points.
+__device__ __forceinline__ int stage_cloud(const float *__restrict__ P, float *sx, int count, int ps, int tid, int threads) {
+  int differs = 0;
+  for (int i = tid; i < count; i += threads) {
+    const float v = P[i];
+    sx[i] = v;
+    differs |= __float_as_int(v) ^ __float_as_int(P[i % ps]);
+  }
+  return __syncthreads_or(differs);
+}
+
 // One cloud per block.  pts: (b, n, ps) f32.  Optional second level (m2 > 0): FPS over the
 // m winners of the first level (what the next set-abstraction level does), same launch,
 // wave 0 only; requires m <= 64.
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(kWave * NW) void fps_kernel(
     int n, int ps, int m, int bs, int log2bs, int q, const float *__restrict__ pts,
     int *__restrict__ idxs, float *__restrict__ new_xyz,
     int m2, int bs2, int log2bs2, int *__restrict__ idxs2, float *__restrict__ new_xyz2,
-    const unsigned char *__restrict__ valid) {
+    const unsigned char *__restrict__ valid, unsigned char *__restrict__ constant_out) {
   if (valid && !valid[blockIdx.x]) return;                // padding object: nothing downstream reads it
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int *red_bits = reinterpret_cast<int *>(smem);          // [2][NW]
@@ -214,8 +228,10 @@ __global__ __launch_bounds__(kWave * NW) void fps_kernel(
   const int tid = threadIdx.x;
   const float *P = pts + (size_t)obj * n * ps;
   if (STAGE) {
-    for (int i = tid; i < n * ps; i += kWave * NW) sx[i] = P[i];
-    __syncthreads();
+    const int differs = stage_cloud(P, sx, n * ps, ps, tid, kWave * NW);
+    if (tid == 0 && constant_out) constant_out[obj] = differs ? 0 : 1;
+  } else if (tid == 0 && constant_out) {
+    constant_out[obj] = 0;                                // (a cloud too large to stage is not examined: "not constant")
   }
   const float *src = STAGE ? sx : P;
   fps_level<PPT, NW>(src, ps, n, m, bs, log2bs, q, red_bits, red_k,
@@ -236,7 +252,7 @@ constexpr size_t kFpsLdsFixed(int NW) { return sizeof(int) * 4 * NW + sizeof(flo
 template <int PPT, int NW>
 inline hipError_t launch_fps(int b, const FpsShape &s, int ps, int m, const float *pts, int *idx,
                              float *new_xyz, int m2, int *idx2, float *new_xyz2,
-                             hipStream_t st, const unsigned char *valid) {
+                             hipStream_t st, const unsigned char *valid, unsigned char *constant_out) {
   const size_t cloud = (size_t)s.n * ps * sizeof(float);
   const bool stage = cloud <= 64 * 1024;
   int bs2 = 1, log2bs2 = 0;
@@ -247,10 +263,10 @@ inline hipError_t launch_fps(int b, const FpsShape &s, int ps, int m, const floa
   }
   if (stage) {
     fps_kernel<PPT, NW, true><<<b, kWave * NW, kFpsLdsFixed(NW) + cloud, st>>>(
-        s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, bs2, log2bs2, idx2, new_xyz2, valid);
+        s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, bs2, log2bs2, idx2, new_xyz2, valid, constant_out);
   } else {
     fps_kernel<PPT, NW, false><<<b, kWave * NW, kFpsLdsFixed(NW), st>>>(
-        s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, bs2, log2bs2, idx2, new_xyz2, valid);
+        s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, bs2, log2bs2, idx2, new_xyz2, valid, constant_out);
   }
   return hipGetLastError();
 }
@@ -267,7 +283,8 @@ __global__ __launch_bounds__(kWave * (1 + QW)) void fps_query_kernel(
     int n, int ps, int m, int bs, int log2bs, int q, const float *__restrict__ pts,
     int *__restrict__ idxs, float *__restrict__ new_xyz,
     int m2, int bs2, int log2bs2, int *__restrict__ idxs2, float *__restrict__ new_xyz2,
-    const unsigned char *__restrict__ valid, float radius2, int nsample, int *__restrict__ ball_idx) {
+    const unsigned char *__restrict__ valid, float radius2, int nsample, int *__restrict__ ball_idx,
+    unsigned char *__restrict__ constant_out) {
   if (valid && !valid[blockIdx.x]) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int *red_bits = reinterpret_cast<int *>(smem);          // [2] (unused with one FPS wave)
@@ -278,8 +295,8 @@ __global__ __launch_bounds__(kWave * (1 + QW)) void fps_query_kernel(
   const int obj = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const float *P = pts + (size_t)obj * n * ps;
   if (tid == 0) *progress = 0;
-  for (int i = tid; i < n * ps; i += kWave * (1 + QW)) sx[i] = P[i];
-  __syncthreads();
+  const int differs = stage_cloud(P, sx, n * ps, ps, tid, kWave * (1 + QW));
+  if (tid == 0 && constant_out) constant_out[obj] = differs ? 0 : 1;
   if (wave == 0) {
     __builtin_amdgcn_s_setprio(3);                        // the chain everything waits for
     fps_level<PPT, 1>(sx, ps, n, m, bs, log2bs, q, red_bits, red_k, idxs ? idxs + (size_t)obj * m : nullptr,
@@ -317,7 +334,7 @@ __global__ __launch_bounds__(kWave * (1 + QW)) void fps_query_kernel(
 // -> hipErrorInvalidValue for a shape the fused kernel does not take (the caller then runs the two launches)
 inline hipError_t launch_fps_query(int b, int n, int ps, int m, const float *pts, int *idx, float *new_xyz, int m2,
                                    int *idx2, float *new_xyz2, float radius2, int nsample, int *ball_idx,
-                                   hipStream_t st, const unsigned char *valid) {
+                                   hipStream_t st, const unsigned char *valid, unsigned char *constant_out = nullptr) {
   const FpsShape s = fps_shape(n);
   const size_t cloud = (size_t)n * ps * sizeof(float);
   if (s.slots > 1024 || s.slots <= 256 || cloud > 48 * 1024 || m > 64 || (m2 > 0 && m2 > m) || !ball_idx || nsample <= 0)
@@ -331,18 +348,20 @@ inline hipError_t launch_fps_query(int b, int n, int ps, int m, const float *pts
   constexpr int QW = 3;
   const size_t lds = sizeof(int) * 8 + sizeof(float) * 64 * 3 + cloud;
   fps_query_kernel<16, QW><<<b, kWave * (1 + QW), lds, st>>>(s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, bs2,
-                                                            log2bs2, idx2, new_xyz2, valid, radius2, nsample, ball_idx);
+                                                            log2bs2, idx2, new_xyz2, valid, radius2, nsample, ball_idx,
+                                                            constant_out);
   return hipGetLastError();
 }
 
 // Dispatch on the number of rank slots.  Returns hipErrorInvalidValue above 32768 slots.
 inline hipError_t dispatch_fps(int b, int n, int ps, int m, const float *pts, int *idx,
                                float *new_xyz, int m2, int *idx2, float *new_xyz2,
-                               hipStream_t st, const unsigned char *valid = nullptr) {
+                               hipStream_t st, const unsigned char *valid = nullptr,
+                               unsigned char *constant_out = nullptr) {
   const FpsShape s = fps_shape(n);
   if (m2 > 0 && (m > 64 || m2 > m)) return hipErrorInvalidValue;
 #define MSR3D_FPS(PPT, NW) \
-  return launch_fps<PPT, NW>(b, s, ps, m, pts, idx, new_xyz, m2, idx2, new_xyz2, st, valid)
+  return launch_fps<PPT, NW>(b, s, ps, m, pts, idx, new_xyz, m2, idx2, new_xyz2, st, valid, constant_out)
   // (measured: 4 waves x 4 points/lane per cloud times the same as 1 wave x 16 at 960 clouds --
   // the iteration is a dependent chain scan -> reduce -> readlane -> LDS read, not VALU-bound)
   if (s.slots <= 64) MSR3D_FPS(1, 1);

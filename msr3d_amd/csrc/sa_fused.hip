@@ -543,26 +543,39 @@ inline hipError_t allow_lds(K kernel, size_t bytes) {
 
 extern "C" {
 
-int msr3d_sa_fps2(int b, int n, int point_stride, int m1, int m2, const float *pts, int *idx1,
-                  float *new_xyz1, int *idx2, float *new_xyz2, const unsigned char *valid,
-                  msr3d_stream_t stream) {
+int msr3d_sa_fps2_flags(int b, int n, int point_stride, int m1, int m2, const float *pts, int *idx1,
+                        float *new_xyz1, int *idx2, float *new_xyz2, const unsigned char *valid,
+                        unsigned char *constant_out, msr3d_stream_t stream) {
   if (b < 0 || n <= 0 || m1 <= 0 || m2 < 0 || point_stride < 3) return MSR3D_EINVAL;
   if (b == 0) return 0;
   if (!pts) return MSR3D_EINVAL;
   const hipError_t e = dispatch_fps(b, n, point_stride, m1, pts, idx1, new_xyz1, m2, idx2,
-                                    new_xyz2, (hipStream_t)stream, valid);
+                                    new_xyz2, (hipStream_t)stream, valid, constant_out);
+  return e == hipErrorInvalidValue ? MSR3D_EINVAL : (int)e;
+}
+
+int msr3d_sa_fps2(int b, int n, int point_stride, int m1, int m2, const float *pts, int *idx1,
+                  float *new_xyz1, int *idx2, float *new_xyz2, const unsigned char *valid,
+                  msr3d_stream_t stream) {
+  return msr3d_sa_fps2_flags(b, n, point_stride, m1, m2, pts, idx1, new_xyz1, idx2, new_xyz2, valid, nullptr, stream);
+}
+
+int msr3d_sa_fps2_query_flags(int b, int n, int point_stride, int m1, int m2, const float *pts, int *idx1,
+                              float *new_xyz1, int *idx2, float *new_xyz2, const unsigned char *valid, float radius1,
+                              int nsample1, int *ball_idx1, unsigned char *constant_out, msr3d_stream_t stream) {
+  if (b < 0 || n <= 0 || m1 <= 0 || m2 < 0 || point_stride < 3 || nsample1 <= 0 || !(radius1 > 0.f)) return MSR3D_EINVAL;
+  if (b == 0) return 0;
+  if (!pts || !ball_idx1) return MSR3D_EINVAL;
+  const hipError_t e = launch_fps_query(b, n, point_stride, m1, pts, idx1, new_xyz1, m2, idx2, new_xyz2,
+                                        radius1 * radius1, nsample1, ball_idx1, (hipStream_t)stream, valid, constant_out);
   return e == hipErrorInvalidValue ? MSR3D_EINVAL : (int)e;
 }
 
 int msr3d_sa_fps2_query(int b, int n, int point_stride, int m1, int m2, const float *pts, int *idx1,
                         float *new_xyz1, int *idx2, float *new_xyz2, const unsigned char *valid, float radius1,
                         int nsample1, int *ball_idx1, msr3d_stream_t stream) {
-  if (b < 0 || n <= 0 || m1 <= 0 || m2 < 0 || point_stride < 3 || nsample1 <= 0 || !(radius1 > 0.f)) return MSR3D_EINVAL;
-  if (b == 0) return 0;
-  if (!pts || !ball_idx1) return MSR3D_EINVAL;
-  const hipError_t e = launch_fps_query(b, n, point_stride, m1, pts, idx1, new_xyz1, m2, idx2, new_xyz2,
-                                        radius1 * radius1, nsample1, ball_idx1, (hipStream_t)stream, valid);
-  return e == hipErrorInvalidValue ? MSR3D_EINVAL : (int)e;
+  return msr3d_sa_fps2_query_flags(b, n, point_stride, m1, m2, pts, idx1, new_xyz1, idx2, new_xyz2, valid, radius1,
+                                   nsample1, ball_idx1, nullptr, stream);
 }
 
 int msr3d_sa_level(int level, int b, int n, int m, float radius, const float *pts,

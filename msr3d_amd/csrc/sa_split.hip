@@ -51,6 +51,10 @@
 
 // phase marks of the level-2 kernel: empty here; tools/prof/sa_split_stamped.hip defines them and includes
 // this file (tools/ab_split.py reads the stamps)
+#ifndef RSTAMP                 // phase marks of the distinct-row kernels (tools/prof/sa_rows_stamped.hip)
+#define RSTAMP(i)
+#define RSTAMP_DECL
+#endif
 #ifndef STAMP
 #define STAMP(i)
 #define STAMP_DECL
@@ -642,6 +646,440 @@ __global__ __launch_bounds__(256, 2) void sa2_split_kernel(int n, int m, int til
     Tn = Tnn;
   }
   if (tid == 0) leave();
+}
+
+// =====================================================================================================
+// Level 2 over DISTINCT neighbourhood rows (round 5).
+//
+// ball_query pads a neighbourhood that has fewer than nsample hits by repeating its first hit
+// (ball_query_gpu.cu:35-39), so the rows a centre's SharedMLP sees are `filled = min(hits, nsample)`
+// different (centre, point) pairs followed by nsample - filled bit-identical copies of the first one.  A row's
+// way through the three layers depends on nothing but that row, and max is idempotent: the level's output is
+// THE SAME BITS when only the distinct rows are multiplied.  On the benchmark's scenes a level-2 centre
+// (32 points, r = 0.4) has 2.9 distinct neighbours on average -- 49 rows per object instead of 512.
+//
+// A tile is up to 64 distinct rows of ONE object (an object with more takes several chunks), packed densely
+// across its centres; every row keeps the arithmetic of sa2_split_kernel to the letter (same gather, same
+// split, same MFMA order per row, xyz as the same three FMAs, same affine + ReLU), only the 16-row tiles
+// that hold no row are not multiplied (MT = 1..4 row tiles per chunk).  The maximum is SEGMENTED: rows of
+// different centres share a 16-row tile, so the last epilogue is an LDS atomic max (values are >= 0 after
+// the ReLU: the order of their bit patterns as unsigned integers is their order as floats) into an
+// (m <= 16) x 256 table that starts at zero -- starting at zero IS the ReLU -- and is written out once per
+// object.  A centre without hits keeps the reference's row of index 0 (one row).
+// `constant` (b bytes, optional): objects whose cloud is one repeated point (the dataset's padding slots,
+// dataset_wrapper.py:156-158; msr3d_sa_fps2* reports them): every (centre, point) row of such an object is the
+// same row, so ONE row is multiplied and its result written to all m centres.
+// =====================================================================================================
+constexpr int kRowsMaxM = 16;                // centres per object the out table holds
+constexpr int kOutPitch = 257;               // floats per centre in the table: centre c, channel n -> bank (c + n) % 32
+// The PLAN of a launch (caller's workspace, kPlanBytes per object): header int = R | constant << 16 (R = the
+// object's distinct rows, 0 for an object the valid mask skips), then the row list, R x (centre << 8 | point),
+// sorted by centre.  Written by sa2_plan_kernel (one wave per object: the m ball queries + the list), read by
+// sa2_rows_kernel an object ahead -- the dependent chain centres -> queries -> list -> gather of an object is
+// off the multiplying blocks' critical path.
+constexpr int kPlanRows = kRowsMaxM * kNS;   // 512
+constexpr int kPlanBytes = 32 + kPlanRows * 2;
+
+// wave_ball_query with byte indices (n <= 64) and the number of hits returned
+__device__ __forceinline__ int wave_ball_query_u8(const float *sx, int n, float cx, float cy, float cz, float radius2,
+                                                  int nsample, unsigned char *row, int lane) {
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int cnt = 0, first = 0;
+  for (int base = 0; base < n && cnt < nsample; base += kWave) {
+    const int k = base + lane;
+    bool hit = false;
+    if (k < n) hit = sq3(cx - sx[k * 3 + 0], cy - sx[k * 3 + 1], cz - sx[k * 3 + 2]) < radius2;
+    const unsigned long long mask = __ballot(hit);
+    if (mask) {
+      if (cnt == 0) first = base + __ffsll((long long)mask) - 1;
+      const int slot = cnt + __popcll(mask & lt);
+      if (hit && slot < nsample) row[slot] = (unsigned char)k;
+      cnt += __popcll(mask);
+    }
+  }
+  const int filled = cnt < nsample ? cnt : nsample;
+  const int fill = cnt > 0 ? first : 0;
+  for (int l = filled + lane; l < nsample; l += kWave) row[l] = (unsigned char)fill;
+  return cnt;
+}
+
+__global__ __launch_bounds__(256) void sa2_plan_kernel(int b, int n, int m, float radius2, const float *__restrict__ xyz,
+                                                       const float *__restrict__ new_xyz, int *__restrict__ rows_of,
+                                                       unsigned char *__restrict__ plan,
+                                                       int *__restrict__ dbg_idx, const unsigned char *__restrict__ valid,
+                                                       const unsigned char *__restrict__ constant) {
+  __shared__ float s_x[4][64 * 3];
+  __shared__ float s_c[4][kRowsMaxM * 3];
+  __shared__ unsigned char s_nbr[4][kRowsMaxM * kNS];
+  __shared__ int s_f[4][kRowsMaxM];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int obj = blockIdx.x * 4 + wave;
+  if (obj >= b) return;                                  // (no block barrier below: every wave is on its own)
+  int *hdr = reinterpret_cast<int *>(plan + (size_t)obj * kPlanBytes);
+  unsigned short *list = reinterpret_cast<unsigned short *>(plan + (size_t)obj * kPlanBytes + 32);
+  if (valid && !valid[obj]) {
+    if (lane == 0) hdr[0] = rows_of[obj] = 0;
+    return;
+  }
+  float *sx = s_x[wave], *ctr = s_c[wave];
+  unsigned char *nbr = s_nbr[wave];
+  int *fcnt = s_f[wave];
+  for (int i = lane; i < n * 3; i += kWave) sx[i] = xyz[(size_t)obj * n * 3 + i];
+  if (lane < m * 3) ctr[lane] = new_xyz[(size_t)obj * m * 3 + lane];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int c = 0; c < m; ++c) {
+    const int cnt = wave_ball_query_u8(sx, n, ctr[c * 3 + 0], ctr[c * 3 + 1], ctr[c * 3 + 2], radius2, kNS, nbr + c * kNS, lane);
+    if (lane == 0) fcnt[c] = cnt > 0 ? (cnt < kNS ? cnt : kNS) : 1;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (dbg_idx)
+    for (int i = lane; i < m * kNS; i += kWave) dbg_idx[(size_t)obj * m * kNS + i] = nbr[i];
+  if (constant && constant[obj]) {                       // one repeated point: every row is the same row
+    if (lane == 0) {
+      hdr[0] = 1 | (1 << 16);
+      rows_of[obj] = 1;
+      list[0] = nbr[0];
+    }
+    return;
+  }
+  int R = 0;
+  for (int q = 0; q < m; ++q) R += fcnt[q];
+  for (int i = lane; i < m * kNS; i += kWave) {
+    const int c = i >> 5, sl = i & 31;
+    int off = 0;
+    for (int q = 0; q < c; ++q) off += fcnt[q];
+    if (sl < fcnt[c]) list[off + sl] = (unsigned short)((c << 8) | nbr[i]);
+  }
+  if (lane == 0) hdr[0] = rows_of[obj] = R;
+}
+
+template <int V> struct IntTag { static constexpr int value = V; };
+
+constexpr int kSa2RowsLds = 3 * kPlane * 2 + 2 * (kPlanRows * 2 + 64 * 3 * 4 + kRowsMaxM * 4 * 4) + kTM * 4 * 4 + kTM * 4 +
+                            kRowsMaxM * kOutPitch * 4;
+
+constexpr int kMineMax = 32;                 // objects one block can be dealt (b <= kMineMax x blocks)
+
+// Objects differ 30-fold in work (1 .. 32 row tiles; a padding slot: one), there are only a few per block (960 objects
+// on 512 resident blocks), and a block reads its objects' plans an object ahead -- a device-wide queue would be drained
+// by that look-ahead before any block knew how long its share takes.  So the deal is STATIC and balanced: one small
+// workgroup sorts all objects by row tiles, heaviest first (a stable counting sort on the 33 possible costs: thread t
+// counts its strip of objects per cost, the counts are scanned over the threads, every object's position follows), and
+// block k of B takes positions k, 2B-1-k, 2B+k, 4B-1-k, ... of that order: the heaviest objects go to different blocks
+// and each is paired with one from the light end.  order[0] = number of objects with rows, order[1 + p] = object at p.
+__global__ __launch_bounds__(256) void sa2_deal_kernel(int b, const int *__restrict__ rows_of, int *__restrict__ order) {
+  __shared__ unsigned short cnt[256][34];      // [thread][cost]: objects of that cost in the thread's strip
+  __shared__ int start[34];
+  const int tid = threadIdx.x, per = (b + 255) / 256, i0 = tid * per, i1 = min(b, i0 + per);
+  for (int c = 0; c < 34; ++c) cnt[tid][c] = 0;
+  for (int i = i0; i < i1; ++i) {
+    const int R = rows_of[i];
+    if (R > 0) ++cnt[tid][(R + 15) >> 4];
+  }
+  __syncthreads();
+  if (tid < 34) {                              // exclusive scan of column `tid` over the 256 threads
+    int run = 0;
+    for (int t = 0; t < 256; ++t) {
+      const int v = cnt[t][tid];
+      cnt[t][tid] = (unsigned short)run;
+      run += v;
+    }
+    start[tid] = run;                          // (the column total, for now)
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int c = 33; c >= 1; --c) { const int v = start[c]; start[c] = run; run += v; }
+    order[0] = run;
+  }
+  __syncthreads();
+  for (int i = i0; i < i1; ++i) {
+    const int R = rows_of[i];
+    if (R > 0) {
+      const int c = (R + 15) >> 4;
+      order[1 + start[c] + cnt[tid][c]++] = i;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void sa2_rows_kernel(int b, int n, int m, const int *__restrict__ order,
+                                                          const unsigned char *__restrict__ plan,
+                                                          const float *__restrict__ xyz, const float *__restrict__ feat,
+                                                          const float *__restrict__ new_xyz, LayerS l1, LayerS l2, LayerS l3,
+                                                          float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  unsigned short *buf = smem;                                             // ROWS [3][64][144] / FRAG image
+  unsigned short *rowmap2 = smem + 3 * kPlane;                             // [2][512]: this object's and the next one's list
+  float *sx2 = reinterpret_cast<float *>(rowmap2 + 2 * kPlanRows);         // [2][64 * 3]
+  float *ctr2 = sx2 + 2 * 64 * 3;                                          // [2][16 * 4]
+  float *dxs = ctr2 + 2 * kRowsMaxM * 4;                                   // [64][4]: the chunk rows' recentred coordinates
+  int *rowc = reinterpret_cast<int *>(dxs + kTM * 4);                      // [64]: centre of each row of the chunk
+  unsigned *outb = reinterpret_cast<unsigned *>(rowc + kTM);               // [16][257]: running maxima (bit patterns)
+  unsigned char *fbuf = reinterpret_cast<unsigned char *>(buf);
+  __shared__ int s_mine[kMineMax + 1];
+  int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  RSTAMP_DECL;
+  if (tid <= kMineMax) {                       // this block's objects (see sa2_deal_kernel)
+    const int B = gridDim.x, k = blockIdx.x, r = tid, nv = order[0];
+    const int pos = (r & 1) ? (r + 1) * B - 1 - k : r * B + k;
+    s_mine[tid] = (tid < kMineMax && pos < nv) ? order[1 + pos] : b;
+  }
+  __syncthreads();
+  // (the folded BN affines are read where they are used, from global memory -- 4 KB that every block shares in L2: the
+  // table's 4 KB of LDS are what lets TWO blocks share a CU)
+  const float *__restrict__ sc1 = l1.scale, *__restrict__ sh1 = l1.shift, *__restrict__ sc2 = l2.scale,
+                           *__restrict__ sh2 = l2.shift, *__restrict__ sc3 = l3.scale, *__restrict__ sh3 = l3.shift;
+  constexpr int RN1 = kN1 / 64, RN2 = kN2 / 64, RN3 = kN3 / 64;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const WStream w1 = make_stream<RN1>(l1.w, kK0 * kN1 * 6, wave_u, lane);
+  const float *__restrict__ wxyz = l1.shift + kN1;                         // [128][4] fp32: layer 1's weights on (dx, dy, dz)
+  const WStream w2 = make_stream<RN2>(l2.w, kN1 * kN2 * 6, wave_u, lane);
+  const WStream w3 = make_stream<RN3>(l3.w, kN2 * kN3 * 6, wave_u, lane);
+  for (int i = tid; i < m * kOutPitch; i += 256) outb[i] = 0u;
+  int oi = 0, obj = s_mine[0], objn = s_mine[1];
+  if (obj >= b) return;
+
+  // ---- an object's plan + geometry: global -> registers -> LDS (parity p) ----
+  unsigned plw = 0u;                           // two entries of the row list per thread
+  float geo = 0.f;                             // one coordinate of a point / of a centre per thread
+  int hdrn = 0;
+  auto plan_fetch = [&](int o) {
+    const unsigned char *P = plan + (size_t)o * kPlanBytes;
+    hdrn = *reinterpret_cast<const int *>(P);
+    plw = reinterpret_cast<const unsigned *>(P + 32)[tid];
+    if (tid < n * 3) geo = xyz[(size_t)o * n * 3 + tid];
+    else if (tid >= 192 && tid < 192 + m * 3) geo = new_xyz[(size_t)o * m * 3 + (tid - 192)];
+  };
+  auto plan_store = [&](int p) {
+    reinterpret_cast<unsigned *>(rowmap2 + p * kPlanRows)[tid] = plw;
+    if (tid < n * 3) sx2[p * 192 + tid] = geo;
+    else if (tid >= 192 && tid < 192 + m * 3) {
+      const int q = tid - 192, c = q / 3;
+      ctr2[p * kRowsMaxM * 4 + c * 4 + (q - c * 3)] = geo;
+    }
+  };
+  // ---- a chunk's rows: global -> registers (all loads first), then split -> operand planes, dx and centre per row ----
+  constexpr int IT = kTM * 32 / 256;
+  float4 val[IT];
+  auto rows_fetch = [&](int o, int p, int base, int R) {          // (slots past the last row repeat it: a duplicate
+    const float *F = feat + (size_t)o * n * 128;                   //  does not move a maximum)
+    const unsigned short *rm = rowmap2 + p * kPlanRows;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = tid + it * 256;
+      int rr = base + (e >> 5);
+      rr = rr < R ? rr : R - 1;
+      val[it] = *reinterpret_cast<const float4 *>(F + (size_t)(rm[rr] & 255) * 128 + (e & 31) * 4);
+    }
+  };
+  auto rows_store = [&](int p, int base, int R) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = tid + it * 256;
+      const float v[4] = {val[it].x, val[it].y, val[it].z, val[it].w};
+      uint2 q[3];
+      split4(v, q);
+      unsigned short *d = buf + (e >> 5) * kLd + (e & 31) * 4;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2 *>(d + k * kPlane) = q[k];
+    }
+    if (tid < kTM) {
+      int rr = base + tid;
+      rr = rr < R ? rr : R - 1;
+      const int rm = rowmap2[p * kPlanRows + rr], pi = rm & 255, c = rm >> 8;
+      const float *sx = sx2 + p * 192, *ct = ctr2 + p * kRowsMaxM * 4 + c * 4;
+      rowc[tid] = c;
+      *reinterpret_cast<float4 *>(dxs + tid * 4) = make_float4(sx[pi * 3 + 0] - ct[0], sx[pi * 3 + 1] - ct[1], sx[pi * 3 + 2] - ct[2], 0.f);
+    }
+  };
+
+  // ---- prologue: the first object's plan and its first chunk, unpipelined ----
+  plan_fetch(obj);
+  int hdr = hdrn, pb = 0, base = 0;
+  plan_store(0);
+  __syncthreads();
+  rows_fetch(obj, 0, 0, hdr & 0xffff);
+  rows_store(0, 0, hdr & 0xffff);
+  bool first = true;                           // first chunk of its object: the NEXT object's plan is fetched under it
+  __syncthreads();
+
+  while (true) {
+    const int R = hdr & 0xffff;
+    const int rows = R - base < kTM ? R - base : kTM;
+    const int nmt = (rows + 15) >> 4;
+    const bool last = base + kTM >= R;         // last chunk of its object
+    const bool more_obj = objn < b;
+    // per-lane addresses are re-derived every chunk (see sa2_split_kernel)
+    asm volatile("" : "+v"(tid));
+    lane = tid & 63;
+    wave = tid >> 6;
+    RSTAMP(4);
+    if (first) plan_fetch(more_obj ? objn : obj);   // (wave-uniform; no next object: a harmless re-read)
+    auto layers = [&](auto tag) {
+      constexpr int MT = decltype(tag)::value;
+      // (each variant derives its lane addresses from its own opaque copy of the thread id: expressions common to the
+      // four variants would otherwise be hoisted above the switch and stay live through a whole variant -- 71 spills)
+      int t_ = tid;
+      asm volatile("" : "+v"(t_));
+      const int lane = t_ & 63, wave = t_ >> 6;
+      WPiece ring1[kRing], ring2[kRing], ring3[kRing];
+      preload_ring<RN1, kN1 / 16, kRing>(ring1, w1, lane);
+      {
+        f32x4 acc[RN1][MT];
+        zero_acc(acc);
+        const XRowsS x1{buf + (lane & 15) * kLd + 8 * (lane >> 4), kLd, kPlane};
+        gemm_split_x<RN1, MT, kK0 / 32, kN1 / 16, kRing>(x1, w1, acc, lane, ring1);
+        preload_ring<RN2, kN2 / 16, kRing>(ring2, w2, lane);
+        float4 sc[RN1], sh[RN1];
+        load_affine4<RN1>(sc1, sh1, wave * RN1 * 16, lane, sc, sh);
+        {   // + W_xyz (dx, dy, dz), exactly as sa2_split_kernel
+          float4 d[MT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) d[mt] = *reinterpret_cast<const float4 *>(dxs + (16 * mt + (lane & 15)) * 4);
+#pragma unroll
+          for (int rn = 0; rn < RN1; ++rn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float4 wv = *reinterpret_cast<const float4 *>(wxyz + (wave * RN1 * 16 + rn * 16 + 4 * (lane >> 4) + r) * 4);
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt)
+                acc[rn][mt][r] = __builtin_fmaf(wv.z, d[mt].z, __builtin_fmaf(wv.y, d[mt].y, __builtin_fmaf(wv.x, d[mt].x, acc[rn][mt][r])));
+            }
+        }
+        RSTAMP(6);
+        __syncthreads();                                          // (A) every wave is done READING the operand
+        if (first) plan_store(pb ^ 1);                            // the next object's plan: registers -> LDS (other parity)
+        store_split_frag<RN1, MT>(acc, sc, sh, fbuf, wave * RN1 * 16, lane);
+      }
+      __syncthreads();                                            // (B)
+      RSTAMP(7);
+      {
+        f32x4 acc[RN2][MT];
+        zero_acc(acc);
+        const XFragS x2{buf + lane * 8};
+        gemm_split_x<RN2, MT, kN1 / 32, kN2 / 16, kRing>(x2, w2, acc, lane, ring2);
+        preload_ring<RN3, kN3 / 16, kRing>(ring3, w3, lane);
+        float4 sc[RN2], sh[RN2];
+        load_affine4<RN2>(sc2, sh2, wave * RN2 * 16, lane, sc, sh);
+        RSTAMP(8);
+        __syncthreads();                                          // (C)
+        store_split_frag<RN2, MT>(acc, sc, sh, fbuf, wave * RN2 * 16, lane);
+      }
+      __syncthreads();                                            // (D)
+      RSTAMP(9);
+      {
+        f32x4 acc[RN3][MT];
+        zero_acc(acc);
+        const XFragS x3{buf + lane * 8};
+        gemm_split_x<RN3, MT, kN2 / 32, kN3 / 16, kRing>(x3, w3, acc, lane, ring3);
+        RSTAMP(10);
+        float4 sc[RN3], sh[RN3];
+        load_affine4<RN3>(sc3, sh3, wave * RN3 * 16, lane, sc, sh);
+        // Segmented maximum.  The chunk's rows are sorted by centre, so inside a 16-row tile (the 16 lanes j of a lane
+        // group) every centre is a run of consecutive lanes: an inclusive max-scan over the runs (offsets 1, 2, 4, 8 by
+        // DPP row shifts; a lane takes its neighbour's value only when that neighbour belongs to the same centre) leaves
+        // each run's maximum in its LAST lane, and only those lanes touch the table -- different centres, different
+        // words: no two lanes of an instruction meet on an address.  (One atomic per row and channel instead: the 16 rows
+        // of a dense neighbourhood are 16 read-modify-writes of ONE word, served one after the other.)  Values are
+        // >= 0 after the ReLU: the unsigned order of their bit patterns is their order, and the bitwise AND with an
+        // all-ones / all-zeros word is the select.
+        const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int c = rowc[16 * mt + j];
+          unsigned same[4];
+          bool any[4];
+#define MSR3D_SHR(K, X, OLD) __builtin_amdgcn_update_dpp((OLD), (X), 0x110 + (K), 0xf, 0xf, false)
+          same[0] = MSR3D_SHR(1, c, -1) == c ? 0xffffffffu : 0u;
+          same[1] = MSR3D_SHR(2, c, -1) == c ? 0xffffffffu : 0u;
+          same[2] = MSR3D_SHR(4, c, -1) == c ? 0xffffffffu : 0u;
+          same[3] = MSR3D_SHR(8, c, -1) == c ? 0xffffffffu : 0u;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) any[q] = __ballot(same[q] != 0u) != 0ull;      // wave-uniform: runs longer than 2^q
+          const bool tail = __builtin_amdgcn_update_dpp(-1, c, 0x101, 0xf, 0xf, false) != c;   // row_shl:1 (lane 15: -1)
+          unsigned u[RN3][4];
+#pragma unroll
+          for (int rn = 0; rn < RN3; ++rn) {
+            const float s4[4] = {sc[rn].x, sc[rn].y, sc[rn].z, sc[rn].w};
+            const float h4[4] = {sh[rn].x, sh[rn].y, sh[rn].z, sh[rn].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[rn][r] = __float_as_uint(fmaxf(__builtin_fmaf(acc[rn][mt][r], s4[r], h4[r]), 0.0f));
+          }
+#define MSR3D_STEP(Q, K)                                                                               \
+          if (any[Q]) {                                                                                \
+            _Pragma("unroll") for (int rn = 0; rn < RN3; ++rn)                                         \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
+              const unsigned t = (unsigned)MSR3D_SHR(K, (int)u[rn][r], 0) & same[Q];                   \
+              u[rn][r] = t > u[rn][r] ? t : u[rn][r];                                                  \
+            }                                                                                          \
+          }
+          MSR3D_STEP(0, 1)
+          MSR3D_STEP(1, 2)
+          MSR3D_STEP(2, 4)
+          MSR3D_STEP(3, 8)
+#undef MSR3D_STEP
+#undef MSR3D_SHR
+          if (tail) {
+            unsigned *o = outb + c * kOutPitch + wave * RN3 * 16 + 4 * g;
+#pragma unroll
+            for (int rn = 0; rn < RN3; ++rn)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                __hip_atomic_fetch_max(o + rn * 16 + r, u[rn][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    };
+    switch (nmt) {
+      case 1: layers(IntTag<1>{}); break;
+      case 2: layers(IntTag<2>{}); break;
+      case 3: layers(IntTag<3>{}); break;
+      default: layers(IntTag<4>{}); break;
+    }
+    RSTAMP(11);
+    // the NEXT chunk's rows start moving (UNCONDITIONAL: after the very last chunk a harmless re-read of it -- a
+    // conditional assignment would make `val` loop-carried and live across the three products)
+    const bool next_is_obj = last && more_obj;
+    const int f_obj = next_is_obj ? objn : obj, f_p = next_is_obj ? pb ^ 1 : pb;
+    const int f_base = last ? (more_obj ? 0 : base) : base + kTM;
+    const int f_R = next_is_obj ? (hdrn & 0xffff) : R;
+    rows_fetch(f_obj, f_p, f_base, f_R);
+    __syncthreads();                                              // (E) the chunk's maxima are in; the operand buffer is free
+    RSTAMP(12);
+    if (last) {   // ---- the object's m x 256 maxima (a constant object: centre 0's row for every centre) ----
+      float *O = out + (size_t)obj * m * kN3;
+      const bool is_const = (hdr >> 16) != 0;
+      if (is_const) {
+        for (int i = tid; i < m * kN3; i += 256) O[i] = __uint_as_float(outb[i & 255]);
+        __syncthreads();
+        if (tid < kN3) outb[tid] = 0u;
+      } else {
+        for (int i = tid; i < m * kN3; i += 256) {
+          const int w = (i >> 8) * kOutPitch + (i & 255);
+          O[i] = __uint_as_float(outb[w]);
+          outb[w] = 0u;
+        }
+      }
+      RSTAMP(13);
+      if (!more_obj) break;
+    }
+    rows_store(f_p, f_base, f_R);
+    if (last) {
+      obj = objn;
+      objn = s_mine[++oi + 1];                                     // (s_mine[kMineMax] = b)
+      hdr = hdrn;
+      pb ^= 1;
+      base = 0;
+      first = true;
+    } else {
+      base += kTM;
+      first = false;
+    }
+    __syncthreads();                                              // (F) the next chunk's operand is in place
+    RSTAMP(5);
+  }
 }
 
 // =====================================================================================================
@@ -1280,6 +1718,42 @@ extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius
   e = hipGetLastError();
   if (wq && e == hipSuccess) wq->suspect = false;
   return (int)e;
+}
+
+inline size_t plan_costs_bytes(int b) { return ((size_t)b * sizeof(int) + 15) & ~(size_t)15; }
+inline size_t plan_order_bytes(int b) { return ((size_t)(b + 1) * sizeof(int) + 15) & ~(size_t)15; }
+extern "C" size_t msr3d_sa_level2_rows_ws_bytes(int b) {
+  return b > 0 ? plan_costs_bytes(b) + plan_order_bytes(b) + (size_t)b * kPlanBytes : 0;
+}
+
+extern "C" int msr3d_sa_level2_rows(int b, int n, int m, float radius, const float *xyz, const float *feat,
+                                    const float *new_xyz, const void *w1, const float *affine1, const void *w2,
+                                    const float *affine2, const void *w3, const float *affine3, float *out,
+                                    int *dbg_ball_idx, const unsigned char *valid, const unsigned char *constant,
+                                    void *plan_ws, msr3d_stream_t stream) {
+  if (b < 0) return MSR3D_EINVAL;
+  if (b == 0) return 0;
+  if (!w1 || !w2 || !w3 || !affine1 || !affine2 || !affine3 || !out || !xyz || !feat || !new_xyz || !plan_ws) return MSR3D_EINVAL;
+  if (n <= 0 || n > 64 || m <= 0 || m > kRowsMaxM || (reinterpret_cast<uintptr_t>(plan_ws) & 15u)) return MSR3D_EINVAL;
+  if (b > 65535 * 256 / 256) return MSR3D_EINVAL;                            // (the deal's 16-bit strip counts)
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e;
+  const float r2 = radius * radius;   // f32 product, as ball_query_gpu.cu:22
+  int *rows_of = reinterpret_cast<int *>(plan_ws);
+  int *order = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(plan_ws) + plan_costs_bytes(b));
+  unsigned char *plan = reinterpret_cast<unsigned char *>(order) + plan_order_bytes(b);
+  sa2_plan_kernel<<<(b + 3) / 4, 256, 0, st>>>(b, n, m, r2, xyz, new_xyz, rows_of, plan, dbg_ball_idx, valid, constant);
+  if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+  sa2_deal_kernel<<<1, 256, 0, st>>>(b, rows_of, order);
+  if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+  if ((e = allow_lds(sa2_rows_kernel, kSa2RowsLds)) != hipSuccess) return (int)e;
+  static const int per_cu = [] { const char *v = getenv("MSR3D_SA2_ROWS_BLOCKS"); return v ? atoi(v) : 2; }();
+  const int slots = per_cu * usable_cus();
+  int blocks = b < slots ? b : slots;
+  if ((long long)blocks * kMineMax < b) blocks = (b + kMineMax - 1) / kMineMax;   // (more rounds of blocks than resident slots)
+  sa2_rows_kernel<<<blocks, 256, kSa2RowsLds, st>>>(b, n, m, order, plan, xyz, feat, new_xyz, make_layer(w1, affine1, 128),
+                                                    make_layer(w2, affine2, 128), make_layer(w3, affine3, 256), out);
+  return (int)hipGetLastError();
 }
 
 extern "C" int msr3d_set_reserved_cus(int n) {

@@ -188,6 +188,17 @@ if _sa_mma[0] not in ("f32", "split"):
     raise ValueError("MSR3D_SA_MMA must be 'f32' or 'split'")
 
 
+# Distinct-row kernels (round 5): a neighbourhood's SharedMLP over the min(hits, nsample) DIFFERENT rows ball_query
+# found instead of all nsample (the rest are copies of the first hit; max is idempotent: same bits).
+# MSR3D_SA_ROWS=0 or set_sa_rows(False): the all-rows kernels of rounds 2-4.
+_sa_rows = [_os.environ.get("MSR3D_SA_ROWS", "1") != "0"]
+
+
+def set_sa_rows(on):
+    prev, _sa_rows[0] = _sa_rows[0], bool(on)
+    return prev
+
+
 def set_sa_mma(name):
     if name not in ("f32", "split"):
         raise ValueError("sa mma must be 'f32' or 'split'")
@@ -230,6 +241,8 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
     feat2 = torch.empty((b, m2, 256), dtype=torch.float32, device=dev)
     pooled = torch.empty((b, 768), dtype=torch.float32, device=dev)
     ball1 = torch.empty((b, m1, _NSAMPLE), dtype=torch.int32, device=dev)   # level-1 workspace
+    # objects whose cloud is one repeated point (padding slots), reported by the sampling launch: one row per level
+    constant = torch.empty((b,), dtype=torch.uint8, device=dev) if (_sa_rows[0] and _sa_mma[0] == "split") else None
     dbg = {}
     if return_internals:
         dbg = {"idx1": torch.empty((b, m1), dtype=torch.int32, device=dev),
@@ -244,13 +257,14 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
         queried = _FPS_QUERY and 256 < n <= 1024 and m1 <= 64
         with _lib.kernel_timer("msr3d_sa_fps2"):
             if queried:
-                rc = lib.msr3d_sa_fps2_query(b, n, 6, m1, m2, _p(pts), _p(dbg.get("idx1")), _p(new1), _p(dbg.get("idx2")),
-                                             _p(new2), _p(vmask), ctypes.c_float(r1), _NSAMPLE, _p(ball1), st)
+                rc = lib.msr3d_sa_fps2_query_flags(b, n, 6, m1, m2, _p(pts), _p(dbg.get("idx1")), _p(new1),
+                                                   _p(dbg.get("idx2")), _p(new2), _p(vmask), ctypes.c_float(r1), _NSAMPLE,
+                                                   _p(ball1), _p(constant), st)
                 if rc == -22:                                   # MSR3D_EINVAL: not a shape of the fused kernel
                     queried = False
             if not queried:
-                rc = lib.msr3d_sa_fps2(b, n, 6, m1, m2, _p(pts), _p(dbg.get("idx1")), _p(new1),
-                                       _p(dbg.get("idx2")), _p(new2), _p(vmask), st)
+                rc = lib.msr3d_sa_fps2_flags(b, n, 6, m1, m2, _p(pts), _p(dbg.get("idx1")), _p(new1),
+                                             _p(dbg.get("idx2")), _p(new2), _p(vmask), _p(constant), st)
         _lib.check(rc, "msr3d_sa_fps2")
         if queried:
             r1 = 0.0                                            # level 1: ball1 already holds the neighbour lists
@@ -267,7 +281,14 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
                                         _p(L[0][2]), _p(feat1), _p(ball1), _p(vmask), st)
         _lib.check(rc, "msr3d_sa_level(1)")
         with _lib.kernel_timer("msr3d_sa_level2"):
-            if _sa_mma[0] == "split":
+            if _sa_mma[0] == "split" and _sa_rows[0] and m1 <= 64 and m2 <= 16:
+                S = plan["split2"]
+                ws = torch.empty((int(lib.msr3d_sa_level2_rows_ws_bytes(b)),), dtype=torch.uint8, device=dev)
+                rc = lib.msr3d_sa_level2_rows(b, m1, m2, ctypes.c_float(sa2.groupers[0].radius), _p(new1),
+                                              _p(feat1), _p(new2), _p(S[0][0]), _p(S[0][1]), _p(S[1][0]),
+                                              _p(S[1][1]), _p(S[2][0]), _p(S[2][1]), _p(feat2),
+                                              _p(dbg.get("ball2")), _p(vmask), _p(constant), _p(ws), st)
+            elif _sa_mma[0] == "split":
                 S = plan["split2"]
                 rc = lib.msr3d_sa_level_split(2, b, m1, m2, ctypes.c_float(sa2.groupers[0].radius), _p(new1),
                                               _p(feat1), _p(new2), _p(S[0][0]), _p(S[0][1]), _p(S[1][0]),
@@ -317,6 +338,6 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
             res = out
     out = res
     if return_internals:
-        dbg.update(new_xyz1=new1, new_xyz2=new2, feat1=feat1, feat2=feat2, pooled=pooled)
+        dbg.update(new_xyz1=new1, new_xyz2=new2, feat1=feat1, feat2=feat2, pooled=pooled, constant=constant)
         return out, dbg
     return out

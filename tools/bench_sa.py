@@ -18,7 +18,7 @@ from msr3d_amd.synth import synth_batch  # noqa: E402
 torch.manual_seed(0)
 net = PointNetPP(sa_n_points=[32, 16, None], sa_n_samples=[32, 32, None], sa_radii=[0.2, 0.4, None],
                  sa_mlps=[[3, 64, 64, 128], [128, 128, 128, 256], [256, 256, 512, 768]]).cuda().eval()
-pts = synth_batch(0, args.batch, device="cuda")["obj_fts"].reshape(-1, 1024, 6).contiguous()
+pts = synth_batch(10000, args.batch, device="cuda")["obj_fts"].reshape(-1, 1024, 6).contiguous()
 with torch.no_grad():
     for _ in range(3):
         net(pts)
