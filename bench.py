@@ -716,15 +716,17 @@ def main():
         tr.dp.wait_events.clear()
 
     # the roofline leg needs the dominant kernel's duration, measured inside the timed region
+    # (the three SharedMLP levels are within ~30 % of one another since the distinct-row kernels of round 5: all three
+    #  are timed and the slowest is the line's roofline kernel)
     timed = (["msr3d_sa_fps2", "msr3d_sa_level1", "msr3d_sa_level2", "msr3d_sa_level3"]
-             if args.time_all_kernels else ["msr3d_sa_level2"])
+             if args.time_all_kernels else ["msr3d_sa_level1", "msr3d_sa_level2", "msr3d_sa_level3"])
     sink = {k: [] for k in timed}
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
-    # (the dominant kernel is event-timed on every 4th step: an event pair idles the GPU for ~12 us around the launch)
-    time_every = 1 if (args.time_all_kernels or args.steps < 16) else 4
+    # (event-timed on every 6th step: an event pair idles the GPU for ~12 us around the launch)
+    time_every = 1 if (args.time_all_kernels or args.steps < 16) else 6
     _lib.set_timing_sink(sink, every=time_every)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step spread
     t0 = time.perf_counter()
@@ -772,52 +774,69 @@ def main():
         # Per-launch durations from HIP events on the launching stream (msr3d_amd/_lib.py).
         kern_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / len(v) if v else None)
                    for k, v in sink.items()}
-        # Dominant kernel: sa2_kernel (level-2 set abstraction, 59 % of the path's FLOPs).
-        # Algorithmic work per object: 16 centres x 32 neighbours = 512
-        # positions x (131*128 + 128*128 + 128*256) MACs x 2 = 67.50 MFLOP; one launch = B*O objects.
-        k_ms = kern_ms["msr3d_sa_level2"] or 0.0
-        flop_per_obj = 512 * (131 * 128 + 128 * 128 + 128 * 256) * 2
+        # Roofline leg: the three SharedMLP levels of the frozen encoder (98 % of the path's FLOPs), each priced as
+        #   frac = FLOPs of the DISTINCT rows the result needs / launch time / peak
+        # with the nominal figure of SURVEY.md 8(d) (every one of the 32 neighbourhood slots multiplied: 512 x
+        # (131*128 + 128*128 + 128*256) MACs x 2 = 67.5 MFLOP per object at level 2) beside it as `nominal_tflops`:
+        # ball_query repeats a neighbourhood's first hit in its empty slots, the SharedMLP acts row by row and max is
+        # idempotent, so the kernels of round 5 multiply only the different rows -- same bits, and a rate priced on the
+        # nominal FLOPs would exceed the roof and read as "work skipped".  Row counts: one untimed pass per resident batch.
+        from msr3d_amd.pointnet2 import fused as _fused
+        split = _fused._sa_mma[0] == "split"
+        rows_on = split and _fused._sa_rows[0]
         objs_per_launch = float(Bcall * O) * (calls if window else 1)    # (a whole window per encoder launch)
         if args.skip_padded:      # only real objects are encoded: count them over the timed steps
             first = args.warmup + (1 if pipe else 0)    # (pipelined: step i encodes batch i + 1)
             counts = [int(batches[(first + i) % n_resident]["obj_masks"].sum()) for i in range(args.steps)]
             objs_per_launch = sum(counts) / max(len(counts), 1)
-        from msr3d_amd.pointnet2 import fused as _fused
-        split = _fused._sa_mma[0] == "split"
-        traffic_per_obj, traffic_src = sa2_traffic_from_profiles("sa2_split_kernel" if split else "sa2_kernel")
-        alg_flop = objs_per_launch * flop_per_obj
-        achieved = alg_flop / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        if split:
-            # Each fp32 operand is three bf16 terms and each product six bf16 MFMA products
-            # (sa_split.hip), so the bf16 pipe delivers at most 2500 / 6 = 416.7 TFLOP/s of fp32-
-            # accurate work: that is the roof the ALGORITHMIC rate is priced against.  Executed
-            # matrix-pipe work (six products; layer 1's K is the 128 feature channels, the 3 coordinate columns
-            # are fp32 FMAs on the accumulators) is reported beside it.
-            peak = MFMA_BF16_PEAK_TF / SPLIT_PRODUCTS
-            executed = objs_per_launch * 512 * (128 * 128 + 128 * 128 + 128 * 256) * 2 * SPLIT_PRODUCTS
-            roof = {"bound": "mfma", "kernel": "sa2_split_kernel (msr3d_sa_level_split level 2)",
-                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                    "peak_note": "bf16 dense MFMA peak 2500 TFLOP/s / 6 products per fp32-accurate product",
-                    "mfma_executed_tflops": executed / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
-                    "mfma_pipe_frac": (executed / (k_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF) if k_ms > 0 else 0.0,
-                    "vs_f32_mfma_peak": achieved / MFMA_F32_PEAK_TF,
-                    "dtype": "f32 operands as 3 bf16 terms, 6 x v_mfma_f32_16x16x32_bf16 per product, "
-                             "fp32 accumulate (fp32 accuracy; MSR3D_SA_MMA=f32 selects the f32-input MFMA kernel)"}
+        roof = None
+        if not args.unfrozen:
+            net = model.visual_prompter.obj_encoder.pcd_net
+            stats = [_fused.row_statistics(net, bt["obj_fts"].reshape(-1, P, 6)) for bt in batches]
+            scale = (calls if window else 1)
+            peak = MFMA_BF16_PEAK_TF / SPLIT_PRODUCTS if split else MFMA_F32_PEAK_TF
+            levels = {}
+            for lvl in (1, 2, 3):
+                ms = kern_ms.get(f"msr3d_sa_level{lvl}") or 0.0
+                mean = lambda k: scale * sum(st[lvl][k] for st in stats) / len(stats)   # noqa: E731
+                nom, dis, pip = mean("nominal_flop"), mean("distinct_flop"), mean("pipe_flop")
+                if not rows_on:
+                    dis = pip = nom
+                tf = lambda f: f / (ms * 1e-3) / 1e12 if ms > 0 else 0.0                  # noqa: E731
+                levels[f"level{lvl}"] = {
+                    "kernel_ms": ms, "distinct_rows": mean("distinct_rows") if rows_on else mean("nominal_rows"),
+                    "nominal_rows": mean("nominal_rows"), "achieved_tflops": tf(dis), "frac": tf(dis) / peak,
+                    "nominal_tflops": tf(nom), "mfma_executed_tflops": tf(pip) * (SPLIT_PRODUCTS if split else 1),
+                    "mfma_pipe_frac": (tf(pip) * SPLIT_PRODUCTS / MFMA_BF16_PEAK_TF) if split else tf(pip) / MFMA_F32_PEAK_TF}
+            dom = max(levels, key=lambda k: levels[k]["kernel_ms"])
+            names = {"level1": "sa1_rows_kernel (+ sa1_plan_kernel; msr3d_sa_level1_rows)" if rows_on else "sa1_split_kernel",
+                     "level2": "sa2_rows_kernel (+ sa2_plan_kernel; msr3d_sa_level2_rows)" if rows_on else "sa2_split_kernel",
+                     "level3": "sa3_split4_kernel (msr3d_sa_level_split level 3)"}
+            if not split:
+                names = {k: f"sa{k[-1]}_kernel (msr3d_sa_level, f32-input MFMA)" for k in names}
+            d = levels[dom]
+            traffic_per_obj, traffic_src = sa2_traffic_from_profiles(names[dom].split(" ")[0])
+            roof = {"bound": "mfma", "kernel": names[dom], "achieved": d["achieved_tflops"], "peak": peak, "unit": "TFLOP/s",
+                    "frac": d["frac"], "nominal_tflops": d["nominal_tflops"],
+                    "achieved_note": "FLOPs of the distinct neighbourhood rows (what the result needs; SURVEY.md 8(d)'s nominal "
+                                     "figure counts every padded slot: nominal_tflops) / the launch's duration",
+                    "peak_note": ("bf16 dense MFMA peak 2500 TFLOP/s / 6 products per fp32-accurate product" if split
+                                  else "f32-input MFMA peak"),
+                    "mfma_executed_tflops": d["mfma_executed_tflops"], "mfma_pipe_frac": d["mfma_pipe_frac"],
+                    "vs_f32_mfma_peak": d["achieved_tflops"] / MFMA_F32_PEAK_TF,
+                    "dtype": ("f32 operands as 3 bf16 terms, 6 x v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate "
+                              "(fp32 accuracy; MSR3D_SA_MMA=f32 selects the f32-input MFMA kernels)") if split
+                    else "f32-input MFMA (v_mfma_f32_16x16x4_f32)",
+                    "levels": levels, "constant_objects_per_launch": scale * sum(st["constant_objects"] for st in stats) / len(stats),
+                    "traffic": traffic_per_obj * objs_per_launch if traffic_per_obj else None,
+                    "traffic_unit": f"bytes/launch (PMC passes of tools/pmc_sa.sh, {traffic_src})",
+                    "kernel_ms": d["kernel_ms"], "launches": len(sink[f"msr3d_sa_{dom}"]),
+                    "timed": f"HIP events around every {time_every}{'st' if time_every == 1 else 'th'} launch inside the timed region"}
         else:
-            roof = {"bound": "mfma", "kernel": "sa2_kernel (msr3d_sa_level level 2)",
-                    "achieved": achieved, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": achieved / MFMA_F32_PEAK_TF,
-                    "dtype": "f32-input MFMA (v_mfma_f32_16x16x4_f32)"}
-        if args.unfrozen:
             # variant line: the fused frozen-encoder launches are not on this path (the SharedMLPs run as
             # group_rows -> token GEMM -> BatchNorm(train) kernels under autograd); no roofline leg
             roof = {"bound": "mfma", "kernel": None, "achieved": None, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": None, "note": "unfrozen-backbone variant: see DESIGN.md 4.1a"}
-            traffic_per_obj = None
-        roof.update({"traffic": traffic_per_obj * objs_per_launch if traffic_per_obj else None,
-                     "traffic_unit": f"bytes/launch (PMC passes of tools/pmc_sa.sh, {traffic_src})",
-                     "kernel_ms": k_ms, "launches": len(sink["msr3d_sa_level2"]),
-                     "timed": f"HIP events around every {time_every}{'st' if time_every == 1 else 'th'} launch inside the timed region"})
+                    "frac": None, "note": "unfrozen-backbone variant: see DESIGN.md 4.1a", "traffic": None}
         line = {
             "metric": f"MSQA train samples/sec (whole node), {O} obj x {P} pts",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,

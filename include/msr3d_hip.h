@@ -482,10 +482,22 @@ int msr3d_sa_level2_rows(int b, int n, int m, float radius, const float *xyz, co
                          int *dbg_ball_idx, const unsigned char *valid, const unsigned char *constant,
                          void *plan_ws, msr3d_stream_t stream);
 /* Bytes of plan_ws for b objects (device memory, 16-byte aligned, the caller's; contents need not survive the call's
- * work on the stream).  Three launches: one wave per object runs its m ball queries and writes the list of its distinct
- * rows there; one workgroup orders the objects by work (heaviest first) for a balanced static deal; the multiplying
- * workgroups read each of their objects' lists one object ahead. */
+ * work on the stream).  Two launches: one wave per object runs its m ball queries and writes the list of its distinct
+ * rows there; the multiplying workgroups deal the objects among themselves by work (a balanced static deal, the same
+ * in every workgroup) and read each of their objects' lists one object ahead. */
 size_t msr3d_sa_level2_rows_ws_bytes(int b);
+
+/* Level 1 of msr3d_sa_level_split over distinct rows: a centre with at most 16 different neighbours (slot 16 of its
+ * ball-query row repeats slot 0) needs one 16-row MFMA tile, so two such centres share a wave's 32 rows; a constant
+ * object (see msr3d_sa_fps2_flags) is one such task whose result is written to all m centres.  Same bits as
+ * msr3d_sa_level_split(level = 1, ..., radius <= 0) on the same ball_idx (b, m, 32) -- which must hold the level's
+ * neighbour lists already (msr3d_sa_fps2_query* or msr3d_ball_query).  m <= 64; task_ws: msr3d_sa_level1_rows_ws_bytes(b, m)
+ * bytes of device memory, 16-byte aligned (two launches: the task list, then the products). */
+int msr3d_sa_level1_rows(int b, int n, int m, const float *pts, const float *new_xyz, const int *ball_idx,
+                         const void *w1, const float *affine1, const void *w2, const float *affine2,
+                         const void *w3, const float *affine3, float *out, const unsigned char *valid,
+                         const unsigned char *constant, void *task_ws, msr3d_stream_t stream);
+size_t msr3d_sa_level1_rows_ws_bytes(int b, int m);
 
 /* ---------------------------------------------------------------------------
  * The trainable part as a fixed schedule of fused launches (msr3d_amd/fused_model.py):

@@ -150,6 +150,8 @@ _SIGNATURES = {
     "msr3d_sa_level_split": [_c_int, _c_int, _c_int, _c_int, _c_float] + [_ptr] * 13,
     "msr3d_sa_level2_rows": [_c_int, _c_int, _c_int, _c_float] + [_ptr] * 15,
     "msr3d_sa_level2_rows_ws_bytes": [_c_int],
+    "msr3d_sa_level1_rows": [_c_int, _c_int, _c_int] + [_ptr] * 14,
+    "msr3d_sa_level1_rows_ws_bytes": [_c_int, _c_int],
     "msr3d_seq_ce_fwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_seq_ce_bwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_gemm_multi_f32": [_c_int, ctypes.POINTER(GemmProblem), _ptr],

@@ -680,37 +680,15 @@ constexpr int kOutPitch = 257;               // floats per centre in the table: 
 constexpr int kPlanRows = kRowsMaxM * kNS;   // 512
 constexpr int kPlanBytes = 32 + kPlanRows * 2;
 
-// wave_ball_query with byte indices (n <= 64) and the number of hits returned
-__device__ __forceinline__ int wave_ball_query_u8(const float *sx, int n, float cx, float cy, float cz, float radius2,
-                                                  int nsample, unsigned char *row, int lane) {
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  int cnt = 0, first = 0;
-  for (int base = 0; base < n && cnt < nsample; base += kWave) {
-    const int k = base + lane;
-    bool hit = false;
-    if (k < n) hit = sq3(cx - sx[k * 3 + 0], cy - sx[k * 3 + 1], cz - sx[k * 3 + 2]) < radius2;
-    const unsigned long long mask = __ballot(hit);
-    if (mask) {
-      if (cnt == 0) first = base + __ffsll((long long)mask) - 1;
-      const int slot = cnt + __popcll(mask & lt);
-      if (hit && slot < nsample) row[slot] = (unsigned char)k;
-      cnt += __popcll(mask);
-    }
-  }
-  const int filled = cnt < nsample ? cnt : nsample;
-  const int fill = cnt > 0 ? first : 0;
-  for (int l = filled + lane; l < nsample; l += kWave) row[l] = (unsigned char)fill;
-  return cnt;
-}
-
+// One wave per object, ALL of its m <= 16 ball queries at once (ball_query_gpu.cu:9-44: index order, strict '<', first-hit
+// fill, zeros when empty): lane 4 c + q tests its quarter of the n <= 64 points against centre c, the quad ORs the four
+// partial hit masks, and slot s of the centre's row is the s-th set bit of the mask (or the first hit past the last one).
 __global__ __launch_bounds__(256) void sa2_plan_kernel(int b, int n, int m, float radius2, const float *__restrict__ xyz,
                                                        const float *__restrict__ new_xyz, int *__restrict__ rows_of,
                                                        unsigned char *__restrict__ plan,
                                                        int *__restrict__ dbg_idx, const unsigned char *__restrict__ valid,
                                                        const unsigned char *__restrict__ constant) {
   __shared__ float s_x[4][64 * 3];
-  __shared__ float s_c[4][kRowsMaxM * 3];
-  __shared__ unsigned char s_nbr[4][kRowsMaxM * kNS];
   __shared__ int s_f[4][kRowsMaxM];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int obj = blockIdx.x * 4 + wave;
@@ -721,36 +699,72 @@ __global__ __launch_bounds__(256) void sa2_plan_kernel(int b, int n, int m, floa
     if (lane == 0) hdr[0] = rows_of[obj] = 0;
     return;
   }
-  float *sx = s_x[wave], *ctr = s_c[wave];
-  unsigned char *nbr = s_nbr[wave];
+  float *sx = s_x[wave];
   int *fcnt = s_f[wave];
+  const int c = lane >> 2, q = lane & 3;
   for (int i = lane; i < n * 3; i += kWave) sx[i] = xyz[(size_t)obj * n * 3 + i];
-  if (lane < m * 3) ctr[lane] = new_xyz[(size_t)obj * m * 3 + lane];
+  float cx = 0.f, cy = 0.f, cz = 0.f;
+  if (c < m) {
+    const float *ct = new_xyz + ((size_t)obj * m + c) * 3;
+    cx = ct[0]; cy = ct[1]; cz = ct[2];
+  }
+  const bool is_const = constant && constant[obj];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  for (int c = 0; c < m; ++c) {
-    const int cnt = wave_ball_query_u8(sx, n, ctr[c * 3 + 0], ctr[c * 3 + 1], ctr[c * 3 + 2], radius2, kNS, nbr + c * kNS, lane);
-    if (lane == 0) fcnt[c] = cnt > 0 ? (cnt < kNS ? cnt : kNS) : 1;
+  const int ppl = (n + 3) >> 2;
+  unsigned long long mask = 0ull;
+  if (c < m)
+    for (int t = 0; t < ppl; ++t) {
+      const int k = q * ppl + t;
+      if (k < n && sq3(cx - sx[k * 3 + 0], cy - sx[k * 3 + 1], cz - sx[k * 3 + 2]) < radius2) mask |= 1ull << k;
+    }
+  {   // OR over the quad (xor 1, xor 2)
+    unsigned lo = (unsigned)mask, hi = (unsigned)(mask >> 32);
+    lo |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+    hi |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xf, 0xf, false);
+    lo |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+    hi |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x4E, 0xf, 0xf, false);
+    mask = ((unsigned long long)hi << 32) | lo;
+  }
+  const int cnt = __popcll(mask);
+  const int filled = cnt > 0 ? (cnt < kNS ? cnt : kNS) : 1;
+  const int fill = cnt > 0 ? __ffsll((long long)mask) - 1 : 0;
+  if (q == 0 && c < m) fcnt[c] = filled;
+  // this lane's eight slots 8 q .. 8 q + 7 of the centre's row
+  int slot[8];
+  {
+    unsigned long long w = mask;
+    for (int t = 0; t < 8 * q; ++t) w &= w - 1;          // drop the 8 q lowest hits
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      slot[t] = w ? __ffsll((long long)w) - 1 : fill;
+      w &= w - 1;
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  if (dbg_idx)
-    for (int i = lane; i < m * kNS; i += kWave) dbg_idx[(size_t)obj * m * kNS + i] = nbr[i];
-  if (constant && constant[obj]) {                       // one repeated point: every row is the same row
+  if (dbg_idx && c < m) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) dbg_idx[((size_t)obj * m + c) * kNS + 8 * q + t] = slot[t];
+  }
+  if (is_const) {                                        // one repeated point: every row is the same row
     if (lane == 0) {
       hdr[0] = 1 | (1 << 16);
       rows_of[obj] = 1;
-      list[0] = nbr[0];
+      list[0] = (unsigned short)slot[0];
     }
     return;
   }
-  int R = 0;
-  for (int q = 0; q < m; ++q) R += fcnt[q];
-  for (int i = lane; i < m * kNS; i += kWave) {
-    const int c = i >> 5, sl = i & 31;
-    int off = 0;
-    for (int q = 0; q < c; ++q) off += fcnt[q];
-    if (sl < fcnt[c]) list[off + sl] = (unsigned short)((c << 8) | nbr[i]);
+  int off = 0, R = 0;
+  for (int k = 0; k < m; ++k) {
+    const int f = fcnt[k];
+    off += k < c ? f : 0;
+    R += f;
+  }
+  if (c < m) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      if (8 * q + t < filled) list[off + 8 * q + t] = (unsigned short)((c << 8) | slot[t]);
   }
   if (lane == 0) hdr[0] = rows_of[obj] = R;
 }
@@ -762,49 +776,65 @@ constexpr int kSa2RowsLds = 3 * kPlane * 2 + 2 * (kPlanRows * 2 + 64 * 3 * 4 + k
 
 constexpr int kMineMax = 32;                 // objects one block can be dealt (b <= kMineMax x blocks)
 
-// Objects differ 30-fold in work (1 .. 32 row tiles; a padding slot: one), there are only a few per block (960 objects
-// on 512 resident blocks), and a block reads its objects' plans an object ahead -- a device-wide queue would be drained
-// by that look-ahead before any block knew how long its share takes.  So the deal is STATIC and balanced: one small
-// workgroup sorts all objects by row tiles, heaviest first (a stable counting sort on the 33 possible costs: thread t
-// counts its strip of objects per cost, the counts are scanned over the threads, every object's position follows), and
-// block k of B takes positions k, 2B-1-k, 2B+k, 4B-1-k, ... of that order: the heaviest objects go to different blocks
-// and each is paired with one from the light end.  order[0] = number of objects with rows, order[1 + p] = object at p.
-__global__ __launch_bounds__(256) void sa2_deal_kernel(int b, const int *__restrict__ rows_of, int *__restrict__ order) {
-  __shared__ unsigned short cnt[256][34];      // [thread][cost]: objects of that cost in the thread's strip
-  __shared__ int start[34];
-  const int tid = threadIdx.x, per = (b + 255) / 256, i0 = tid * per, i1 = min(b, i0 + per);
-  for (int c = 0; c < 34; ++c) cnt[tid][c] = 0;
-  for (int i = i0; i < i1; ++i) {
-    const int R = rows_of[i];
-    if (R > 0) ++cnt[tid][(R + 15) >> 4];
+// Objects differ 30-fold in work (1 .. 512 rows; a padding slot: one), there are only a few per block (960 objects on
+// 512 resident blocks), and a block reads its objects' plans an object ahead -- a device-wide queue would be drained by
+// that look-ahead before any block knew how long its share takes.  So the deal is STATIC and balanced: objects are
+// ordered by cost class, heaviest first (a STABLE counting sort on ceil(rows / 32), ranks by ballot / popcount -- every
+// block computes the same order for itself from the b row counts, ~1 us, and keeps only its own entries), and block k of
+// B takes positions k, 2B-1-k, 2B+k, 4B-1-k, ... of that order: the heaviest objects go to different blocks and each is
+// paired with one from the light end.  Returns with s_mine[r] = this block's r-th object (b: none), after a barrier.
+constexpr int kDealClasses = 17;               // cost class = ceil(rows / 32): 1 .. 16 (0: no rows)
+__device__ __forceinline__ void deal_objects(int b, const int *__restrict__ rows_of, int *s_cnt /* [4][17] */,
+                                             int *s_off /* [4][17] */, int *s_mine, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int per_wave = ((b + 255) / 256) * 64, i0 = wave * per_wave, i1 = min(b, i0 + per_wave);
+  if (tid <= kMineMax) s_mine[tid] = b;
+  int cnt[kDealClasses];
+#pragma unroll
+  for (int c = 0; c < kDealClasses; ++c) cnt[c] = 0;
+  for (int base = i0; base < i1; base += 64) {
+    const int i = base + lane, R = i < i1 ? rows_of[i] : 0, cls = (R + 31) >> 5;
+#pragma unroll
+    for (int c = 1; c < kDealClasses; ++c) cnt[c] += __popcll(__ballot(cls == c));
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 1; c < kDealClasses; ++c) s_cnt[wave * kDealClasses + c] = cnt[c];
   }
   __syncthreads();
-  if (tid < 34) {                              // exclusive scan of column `tid` over the 256 threads
+  if (tid < 4) {                                 // thread w: where wave w's objects of each class start
     int run = 0;
-    for (int t = 0; t < 256; ++t) {
-      const int v = cnt[t][tid];
-      cnt[t][tid] = (unsigned short)run;
-      run += v;
-    }
-    start[tid] = run;                          // (the column total, for now)
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int c = 33; c >= 1; --c) { const int v = start[c]; start[c] = run; run += v; }
-    order[0] = run;
-  }
-  __syncthreads();
-  for (int i = i0; i < i1; ++i) {
-    const int R = rows_of[i];
-    if (R > 0) {
-      const int c = (R + 15) >> 4;
-      order[1 + start[c] + cnt[tid][c]++] = i;
+    for (int c = kDealClasses - 1; c >= 1; --c) {
+      for (int w = 0; w < 4; ++w) {
+        if (w == tid) s_off[tid * kDealClasses + c] = run;
+        run += s_cnt[w * kDealClasses + c];
+      }
     }
   }
+  __syncthreads();
+  int run[kDealClasses];
+#pragma unroll
+  for (int c = 1; c < kDealClasses; ++c) run[c] = s_off[wave * kDealClasses + c];
+  const int B = gridDim.x, k = blockIdx.x;
+  for (int base = i0; base < i1; base += 64) {
+    const int i = base + lane, R = i < i1 ? rows_of[i] : 0, cls = (R + 31) >> 5;
+    int pos = -1;
+#pragma unroll
+    for (int c = 1; c < kDealClasses; ++c) {
+      const unsigned long long mk = __ballot(cls == c);
+      if (cls == c) pos = run[c] + __popcll(mk & lt);
+      run[c] += __popcll(mk);
+    }
+    if (pos >= 0) {
+      const int r = pos / B, rem = pos - r * B;
+      if (((r & 1) ? B - 1 - rem : rem) == k && r < kMineMax) s_mine[r] = i;
+    }
+  }
+  __syncthreads();
 }
 
-__global__ __launch_bounds__(256, 2) void sa2_rows_kernel(int b, int n, int m, const int *__restrict__ order,
+__global__ __launch_bounds__(256, 2) void sa2_rows_kernel(int b, int n, int m, const int *__restrict__ rows_of,
                                                           const unsigned char *__restrict__ plan,
                                                           const float *__restrict__ xyz, const float *__restrict__ feat,
                                                           const float *__restrict__ new_xyz, LayerS l1, LayerS l2, LayerS l3,
@@ -818,15 +848,10 @@ __global__ __launch_bounds__(256, 2) void sa2_rows_kernel(int b, int n, int m, c
   int *rowc = reinterpret_cast<int *>(dxs + kTM * 4);                      // [64]: centre of each row of the chunk
   unsigned *outb = reinterpret_cast<unsigned *>(rowc + kTM);               // [16][257]: running maxima (bit patterns)
   unsigned char *fbuf = reinterpret_cast<unsigned char *>(buf);
-  __shared__ int s_mine[kMineMax + 1];
+  __shared__ int s_mine[kMineMax + 1], s_cnt[4 * kDealClasses], s_off[4 * kDealClasses];
   int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   RSTAMP_DECL;
-  if (tid <= kMineMax) {                       // this block's objects (see sa2_deal_kernel)
-    const int B = gridDim.x, k = blockIdx.x, r = tid, nv = order[0];
-    const int pos = (r & 1) ? (r + 1) * B - 1 - k : r * B + k;
-    s_mine[tid] = (tid < kMineMax && pos < nv) ? order[1 + pos] : b;
-  }
-  __syncthreads();
+  deal_objects(b, rows_of, s_cnt, s_off, s_mine, tid);
   // (the folded BN affines are read where they are used, from global memory -- 4 KB that every block shares in L2: the
   // table's 4 KB of LDS are what lets TWO blocks share a CU)
   const float *__restrict__ sc1 = l1.scale, *__restrict__ sh1 = l1.shift, *__restrict__ sc2 = l2.scale,
@@ -1393,7 +1418,11 @@ constexpr int kSa1Lds = (k1W1 + k1W2 + k1W3) * 2 + 2 * (k1N1 + k1N2 + k1N3) * 4;
 // one layer of a wave's 32-row neighbourhood: acc[t][mt] = W tile t (LDS, fragment order [s][t][3][64][8])
 // x X^T (registers).  Pieces are taken TWO at a time (x 2 row tiles = four independent accumulators per
 // product term) and the next two fly under these 24 MFMAs.
-template <int NT, int KS>
+// SWAP: the operands change roles (D^T = X W^T): the same registers, the same products summed over k in the same order
+// -- the same bits (tests/test_sa_rows_gpu.py compares with the unswapped kernel) -- but a lane (j, g) then holds rows
+// 4 g + r of CHANNEL j instead of channels 4 g + r of row j: the maximum over a tile's 16 rows is three in-lane
+// maxima and two exchanges between the four lane groups instead of a 16-lane DPP reduction per value.
+template <int NT, int KS, bool SWAP = false>
 __device__ __forceinline__ void wave_layer(const unsigned short *wl, const bf16x8 (&x)[KS][2][3], f32x4 (&acc)[NT][2], int lane) {
   static_assert(NT % 2 == 0, "column tiles in pairs");
   constexpr int NG = KS * NT / 2;
@@ -1418,7 +1447,8 @@ __device__ __forceinline__ void wave_layer(const unsigned short *wl, const bf16x
 #define MSR3D_TERM(PW, PX)                                                                             \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                      \
     _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                   \
-        acc[t0 + i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[grp][i].v[PW], x[s][mt][PX], acc[t0 + i][mt], 0, 0, 0);
+        acc[t0 + i][mt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[s][mt][PX], w[grp][i].v[PW], acc[t0 + i][mt], 0, 0, 0) \
+                               : __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[grp][i].v[PW], x[s][mt][PX], acc[t0 + i][mt], 0, 0, 0);
     MSR3D_TERM(2, 0)
     MSR3D_TERM(0, 2)
     MSR3D_TERM(1, 1)
@@ -1598,6 +1628,219 @@ __global__ __launch_bounds__(64 * k1Waves, 1) void sa1_split_kernel(int n, int m
   if (tid == 0) leave();
 }
 
+// =====================================================================================================
+// Level 1 over DISTINCT neighbourhood rows (round 5).  Same kernel as sa1_split_kernel -- the level's weights in LDS, a
+// wave owns 32 rows and all channels, the layer chain never leaves the registers -- but the 32 rows of a wave are a TASK:
+//   BIG    a centre with more than 16 different neighbours: its 32 row slots, as before;
+//   PAIR   TWO centres with at most 16 different neighbours each (slots 16..31 of such a centre's ball-query row repeat
+//          its first hit, ball_query_gpu.cu:35-39): the first 16 slots of one in row tile 0, of the other in row tile 1,
+//          and the two maxima taken per row tile (a centre without a partner is paired with itself);
+//   CONST  an object whose cloud is one repeated point (msr3d_sa_fps2*_flags): every row of every centre is the same
+//          row; one PAIR task of its centre 0, the result written to all m centres.
+// Every row's arithmetic is unchanged and max is idempotent: the level's output is the same bits.  On the benchmark's
+// scenes 40 % of the real centres are small and a third of the objects are padding: 30,720 wave tasks become ~16,700.
+// sa1_plan_kernel (16 lanes ... one wave per object) classifies the centres (slot 16 == slot 0 <=> at most 16 different
+// neighbours), pairs the small ones in index order and writes, per task, a header word and its 32 point indices into the
+// caller's workspace; tasks of different objects are appended through ONE atomic per workgroup of 4 objects (the order of
+// the list is not reproducible; no result depends on it).
+// =====================================================================================================
+constexpr int kTaskBig = 0, kTaskPair = 1, kTaskConst = 2;      // header: kind | obj << 2 | cA << 20 | cB << 26
+
+__global__ __launch_bounds__(256) void sa1_plan_kernel(int b, int m, const int *__restrict__ ball_idx, int *__restrict__ total,
+                                                       int *__restrict__ thdr, int *__restrict__ trow,
+                                                       const unsigned char *__restrict__ valid,
+                                                       const unsigned char *__restrict__ constant) {
+  __shared__ int s_n[4], s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int obj = blockIdx.x * 4 + wave;
+  const bool live = obj < b && !(valid && !valid[obj]);
+  const bool is_const = live && constant && constant[obj];
+  const int *row = ball_idx + ((size_t)(live ? obj : 0) * m + (lane < m ? lane : 0)) * kNS;
+  bool small = false;
+  if (live && lane < m) small = row[16] == row[0];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const unsigned long long in = (live && lane < m && !is_const) ? ~0ull : 0ull;
+  const unsigned long long bigs = __ballot(in && !small), smalls = __ballot(in && small);
+  const int nbig = __popcll(bigs), nsmall = __popcll(smalls);
+  const int ntask = !live ? 0 : (is_const ? 1 : nbig + ((nsmall + 1) >> 1));
+  if (lane == 0) s_n[wave] = ntask;
+  __syncthreads();
+  if (threadIdx.x == 0) s_base = atomicAdd(total, s_n[0] + s_n[1] + s_n[2] + s_n[3]);
+  __syncthreads();
+  if (!live || lane >= m) return;
+  int base = s_base;
+  for (int w = 0; w < wave; ++w) base += s_n[w];
+  const int4 *src = reinterpret_cast<const int4 *>(row);
+  if (is_const) {
+    if (lane == 0) {
+      thdr[base] = kTaskConst | (obj << 2);
+      int4 *d = reinterpret_cast<int4 *>(trow + (size_t)base * kNS);
+      for (int q = 0; q < 4; ++q) d[q] = d[4 + q] = src[q];
+    }
+    return;
+  }
+  if (!small) {
+    const int t = base + __popcll(bigs & lt);
+    thdr[t] = kTaskBig | (obj << 2) | (lane << 20) | (lane << 26);
+    int4 *d = reinterpret_cast<int4 *>(trow + (size_t)t * kNS);
+    for (int q = 0; q < 8; ++q) d[q] = src[q];
+  } else {
+    const int r = __popcll(smalls & lt), t = base + nbig + (r >> 1);
+    int4 *d = reinterpret_cast<int4 *>(trow + (size_t)t * kNS) + 4 * (r & 1);
+    for (int q = 0; q < 4; ++q) d[q] = src[q];
+    if (!(r & 1)) {                                      // first of its pair: the header (and both halves when alone)
+      const unsigned long long above = smalls & ~lt & ~(1ull << lane);
+      const int partner = above ? __ffsll((long long)above) - 1 : lane;
+      thdr[t] = kTaskPair | (obj << 2) | (lane << 20) | (partner << 26);
+      if (!above)
+        for (int q = 0; q < 4; ++q) d[4 + q] = src[q];
+    }
+  }
+}
+
+__global__ __launch_bounds__(64 * k1Waves, 1) void sa1_rows_kernel(int n, int m, int *__restrict__ queue,
+                                                                  const float *__restrict__ pts,
+                                                                  const float *__restrict__ new_xyz,
+                                                                  const int *__restrict__ thdr, const int *__restrict__ trow,
+                                                                  LayerS l1, LayerS l2, LayerS l3, float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  unsigned short *wl1 = smem, *wl2 = wl1 + k1W1, *wl3 = wl2 + k1W2;
+  float *aff = reinterpret_cast<float *>(wl3 + k1W3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  // Tasks cost the same (32 rows each), so they are dealt STATICALLY: wave w of block k takes tasks 8 k + w, + 8 B, ...
+  // -- no queue, no atomics and no barrier in the loop: every wave runs on its own.  (sa1_split_kernel's queue of
+  // three-round chunks, fetched two chunks ahead, is drained by that look-ahead once a block's share is only ~8 rounds:
+  // the stamps showed blocks with 6 and with 9 rounds and 11k cycles per chunk spent at the chunk barrier.)
+  // queue[2] holds the number of tasks sa1_plan_kernel appended, queue[1] counts the blocks that are done: the last
+  // one resets both for the next launch.
+  const int tasks = __hip_atomic_load(queue + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  auto leave = [&]() {
+    const int done = __hip_atomic_fetch_add(queue + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (int)gridDim.x - 1) {
+      __hip_atomic_store(queue, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(queue + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(queue + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  {   // the level's weights and affines: once per block
+    const uint4 *s1 = reinterpret_cast<const uint4 *>(l1.w), *s2 = reinterpret_cast<const uint4 *>(l2.w),
+                *s3 = reinterpret_cast<const uint4 *>(l3.w);
+    uint4 *d = reinterpret_cast<uint4 *>(smem);
+    for (int i = tid; i < k1W1 / 8; i += 64 * k1Waves) d[i] = s1[i];
+    for (int i = tid; i < k1W2 / 8; i += 64 * k1Waves) d[k1W1 / 8 + i] = s2[i];
+    for (int i = tid; i < k1W3 / 8; i += 64 * k1Waves) d[(k1W1 + k1W2) / 8 + i] = s3[i];
+    for (int i = tid; i < k1N1; i += 64 * k1Waves) { aff[i] = l1.scale[i]; aff[k1N1 + i] = l1.shift[i]; }
+    for (int i = tid; i < k1N2; i += 64 * k1Waves) { aff[2 * k1N1 + i] = l2.scale[i]; aff[2 * k1N1 + k1N2 + i] = l2.shift[i]; }
+    for (int i = tid; i < k1N3; i += 64 * k1Waves) { aff[2 * (k1N1 + k1N2) + i] = l3.scale[i]; aff[2 * (k1N1 + k1N2) + k1N3 + i] = l3.shift[i]; }
+  }
+  const float *sc1 = aff, *sh1 = aff + k1N1, *sc2 = aff + 2 * k1N1, *sh2 = sc2 + k1N2, *sc3 = aff + 2 * (k1N1 + k1N2), *sh3 = sc3 + k1N3;
+  __syncthreads();
+
+  int pi[2], hw = 0, hwn = 0;                  // this lane's two point indices; header of the current / the fetched task
+  float2 pa[2], pb[2], pc[2];
+  float cx[2], cy[2], cz[2];
+  auto fetch_idx = [&](int t) {
+    hwn = thdr[t];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) pi[mt] = min(max(trow[(size_t)t * kNS + mt * 16 + j], 0), n - 1);
+  };
+  auto fetch_pts = [&](int h) {
+    const int obj = (h >> 2) & 0x3ffff, kind = h & 3, ca = (h >> 20) & 63, cb = kind == kTaskBig ? ca : (h >> 26) & 63;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const float2 *q = reinterpret_cast<const float2 *>(pts + ((size_t)obj * n + pi[mt]) * 6);
+      pa[mt] = q[0]; pb[mt] = q[1]; pc[mt] = q[2];
+      const float *ct = new_xyz + ((size_t)obj * m + (mt ? cb : ca)) * 3;
+      cx[mt] = ct[0]; cy[mt] = ct[1]; cz[mt] = ct[2];
+    }
+  };
+  const int stride = gridDim.x * k1Waves;
+  int t = blockIdx.x * k1Waves + wave;
+  RSTAMP_DECL;
+  if (t < tasks) {
+  fetch_idx(t);
+  fetch_pts(hwn);
+  while (true) {
+    RSTAMP(0);
+    hw = hwn;
+    const bool more = t + stride < tasks;
+    const int tn = more ? t + stride : t;                // (no next task: a harmless re-read)
+    bf16x8 x1[1][2][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const float v0[4] = {pa[mt].x - cx[mt], pa[mt].y - cy[mt], pb[mt].x - cz[mt], pb[mt].y};
+      const float v1[4] = {pc[mt].x, pc[mt].y, 0.f, 0.f};
+      uint2 p0[3], p1[3];
+      split4(v0, p0);
+      split4(v1, p1);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const uint4 q = g == 0 ? make_uint4(p0[k].x, p0[k].y, p1[k].x, p1[k].y) : make_uint4(0u, 0u, 0u, 0u);
+        x1[0][mt][k] = *reinterpret_cast<const bf16x8 *>(&q);
+      }
+    }
+    fetch_idx(tn);                                       // next round's header and neighbours fly under layer 1
+    bf16x8 x2[k1N1 / 32][2][3], x3[k1N2 / 32][2][3];
+    {
+      f32x4 acc[k1N1 / 16][2];
+      wave_layer<k1N1 / 16, k1K0 / 32>(wl1, x1, acc, lane);
+      wave_next<k1N1 / 16>(acc, sc1, sh1, x2, lane);
+    }
+    RSTAMP(1);
+    fetch_pts(hwn);                                      // next round's point rows fly under layers 2 and 3
+    RSTAMP(2);
+    {
+      {
+        f32x4 acc[k1N2 / 16][2];
+        wave_layer<k1N2 / 16, k1N1 / 32>(wl2, x2, acc, lane);
+        wave_next<k1N2 / 16>(acc, sc2, sh2, x3, lane);
+      }
+      f32x4 acc[k1N3 / 16][2];
+      wave_layer<k1N3 / 16, k1N2 / 32, true>(wl3, x3, acc, lane);        // lane (j, g): rows 4 g + r of channel 16 t + j
+      RSTAMP(3);
+      const int hu = __builtin_amdgcn_readfirstlane(hw);
+      const int obj = (hu >> 2) & 0x3ffff, kind = hu & 3, ca = (hu >> 20) & 63, cb = (hu >> 26) & 63;
+      float *oa = out + ((size_t)obj * m + ca) * k1N3 + j, *ob = out + ((size_t)obj * m + cb) * k1N3 + j;
+      const int x16 = (lane ^ 16) * 4, x32 = (lane ^ 32) * 4;
+      auto groups_max = [&](float v) {                     // over the four lane groups: every lane ends with the maximum
+        v = fmaxf(v, __int_as_float(__builtin_amdgcn_ds_bpermute(x16, __float_as_int(v))));
+        return fmaxf(v, __int_as_float(__builtin_amdgcn_ds_bpermute(x32, __float_as_int(v))));
+      };
+#pragma unroll
+      for (int t = 0; t < k1N3 / 16; ++t) {
+        const float sc = sc3[t * 16 + j], sh = sh3[t * 16 + j];
+        float m0 = 0.f, m1 = 0.f;                          // starting the max at 0 IS the ReLU
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          m0 = fmaxf(m0, __builtin_fmaf(acc[t][0][r], sc, sh));
+          m1 = fmaxf(m1, __builtin_fmaf(acc[t][1][r], sc, sh));
+        }
+        if (kind == kTaskBig) {                            // (wave-uniform) one centre: both row tiles
+          m0 = groups_max(fmaxf(m0, m1));
+          if (g == 0) oa[t * 16] = m0;
+        } else {
+          m0 = groups_max(m0);
+          m1 = groups_max(m1);
+          if (kind == kTaskPair) {
+            if (g == 0) oa[t * 16] = m0;
+            if (g == 1) ob[t * 16] = m1;
+          } else {                                         // constant cloud: every centre of the object
+            float *o0 = out + (size_t)obj * m * k1N3 + t * 16 + j;
+            for (int c = g; c < m; c += 4) o0[(size_t)c * k1N3] = m0;
+          }
+        }
+      }
+    }
+    RSTAMP(4);
+    if (!more) break;
+    t = tn;
+  }
+  }
+  __syncthreads();                                        // every wave of the block is done
+  if (tid == 0) leave();
+}
+
 template <typename K>
 inline hipError_t allow_lds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
@@ -1633,7 +1876,7 @@ inline int usable_cus() {
   return cus - r > 8 ? cus - r : 8;
 }
 
-// Work queues of the persistent kernels: two ints per (device, stream, level), zero between launches: the
+// Work queues of the persistent kernels: four ints per (device, stream, level), zero between launches: the
 // last block of a launch resets them.  (The default stream's handle is the same on every device, hence the
 // device in the key.)  Cleared in stream order on first use and again whenever the previous launch through
 // the queue did not report success -- a launch that never ran to its last block would otherwise leave the
@@ -1646,10 +1889,10 @@ inline WorkQueue *work_queue(hipStream_t st, int level, hipError_t *err) {
   if ((*err = hipGetDevice(&dev)) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
   WorkQueue &w = queues[{dev, st, level}];
-  if (!w.q && (*err = hipMalloc(&w.q, 2 * sizeof(int))) != hipSuccess) return nullptr;
+  if (!w.q && (*err = hipMalloc(&w.q, 4 * sizeof(int))) != hipSuccess) return nullptr;
   if (w.suspect) {
     // (the caller's streams do not synchronise with the null stream, where a plain hipMemset would run)
-    if ((*err = hipMemsetAsync(w.q, 0, 2 * sizeof(int), st)) != hipSuccess) return nullptr;
+    if ((*err = hipMemsetAsync(w.q, 0, 4 * sizeof(int), st)) != hipSuccess) return nullptr;
   }
   w.suspect = true;                 // until the launch it is handed to reports success
   *err = hipSuccess;
@@ -1721,10 +1964,7 @@ extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius
 }
 
 inline size_t plan_costs_bytes(int b) { return ((size_t)b * sizeof(int) + 15) & ~(size_t)15; }
-inline size_t plan_order_bytes(int b) { return ((size_t)(b + 1) * sizeof(int) + 15) & ~(size_t)15; }
-extern "C" size_t msr3d_sa_level2_rows_ws_bytes(int b) {
-  return b > 0 ? plan_costs_bytes(b) + plan_order_bytes(b) + (size_t)b * kPlanBytes : 0;
-}
+extern "C" size_t msr3d_sa_level2_rows_ws_bytes(int b) { return b > 0 ? plan_costs_bytes(b) + (size_t)b * kPlanBytes : 0; }
 
 extern "C" int msr3d_sa_level2_rows(int b, int n, int m, float radius, const float *xyz, const float *feat,
                                     const float *new_xyz, const void *w1, const float *affine1, const void *w2,
@@ -1735,25 +1975,52 @@ extern "C" int msr3d_sa_level2_rows(int b, int n, int m, float radius, const flo
   if (b == 0) return 0;
   if (!w1 || !w2 || !w3 || !affine1 || !affine2 || !affine3 || !out || !xyz || !feat || !new_xyz || !plan_ws) return MSR3D_EINVAL;
   if (n <= 0 || n > 64 || m <= 0 || m > kRowsMaxM || (reinterpret_cast<uintptr_t>(plan_ws) & 15u)) return MSR3D_EINVAL;
-  if (b > 65535 * 256 / 256) return MSR3D_EINVAL;                            // (the deal's 16-bit strip counts)
   hipStream_t st = (hipStream_t)stream;
   hipError_t e;
   const float r2 = radius * radius;   // f32 product, as ball_query_gpu.cu:22
   int *rows_of = reinterpret_cast<int *>(plan_ws);
-  int *order = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(plan_ws) + plan_costs_bytes(b));
-  unsigned char *plan = reinterpret_cast<unsigned char *>(order) + plan_order_bytes(b);
+  unsigned char *plan = reinterpret_cast<unsigned char *>(plan_ws) + plan_costs_bytes(b);
   sa2_plan_kernel<<<(b + 3) / 4, 256, 0, st>>>(b, n, m, r2, xyz, new_xyz, rows_of, plan, dbg_ball_idx, valid, constant);
-  if ((e = hipGetLastError()) != hipSuccess) return (int)e;
-  sa2_deal_kernel<<<1, 256, 0, st>>>(b, rows_of, order);
   if ((e = hipGetLastError()) != hipSuccess) return (int)e;
   if ((e = allow_lds(sa2_rows_kernel, kSa2RowsLds)) != hipSuccess) return (int)e;
   static const int per_cu = [] { const char *v = getenv("MSR3D_SA2_ROWS_BLOCKS"); return v ? atoi(v) : 2; }();
   const int slots = per_cu * usable_cus();
   int blocks = b < slots ? b : slots;
   if ((long long)blocks * kMineMax < b) blocks = (b + kMineMax - 1) / kMineMax;   // (more rounds of blocks than resident slots)
-  sa2_rows_kernel<<<blocks, 256, kSa2RowsLds, st>>>(b, n, m, order, plan, xyz, feat, new_xyz, make_layer(w1, affine1, 128),
+  sa2_rows_kernel<<<blocks, 256, kSa2RowsLds, st>>>(b, n, m, rows_of, plan, xyz, feat, new_xyz, make_layer(w1, affine1, 128),
                                                     make_layer(w2, affine2, 128), make_layer(w3, affine3, 256), out);
   return (int)hipGetLastError();
+}
+
+extern "C" size_t msr3d_sa_level1_rows_ws_bytes(int b, int m) {
+  return (b > 0 && m > 0) ? (size_t)b * m * (sizeof(int) + kNS * sizeof(int)) + 16 : 0;
+}
+
+extern "C" int msr3d_sa_level1_rows(int b, int n, int m, const float *pts, const float *new_xyz, const int *ball_idx,
+                                    const void *w1, const float *affine1, const void *w2, const float *affine2,
+                                    const void *w3, const float *affine3, float *out, const unsigned char *valid,
+                                    const unsigned char *constant, void *task_ws, msr3d_stream_t stream) {
+  if (b < 0) return MSR3D_EINVAL;
+  if (b == 0) return 0;
+  if (!w1 || !w2 || !w3 || !affine1 || !affine2 || !affine3 || !out || !pts || !new_xyz || !ball_idx || !task_ws) return MSR3D_EINVAL;
+  if (n <= 0 || m <= 0 || m > 64 || b >= (1 << 18) || (reinterpret_cast<uintptr_t>(task_ws) & 15u)) return MSR3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e;
+  WorkQueue *wq = work_queue(st, 5, &e);
+  if (!wq) return (int)e;
+  int *trow = reinterpret_cast<int *>(task_ws);                         // [b m][32], 16-byte aligned rows
+  int *thdr = trow + (size_t)b * m * kNS;
+  sa1_plan_kernel<<<(b + 3) / 4, 256, 0, st>>>(b, m, ball_idx, wq->q + 2, thdr, trow, valid, constant);
+  if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+  if ((e = allow_lds(sa1_rows_kernel, kSa1Lds)) != hipSuccess) return (int)e;
+  const int cus = usable_cus();
+  const long long max_rounds = ((long long)b * m + k1Waves - 1) / k1Waves;
+  const int blocks = (int)(max_rounds < cus ? max_rounds : cus);
+  sa1_rows_kernel<<<blocks, 64 * k1Waves, kSa1Lds, st>>>(n, m, wq->q, pts, new_xyz, thdr, trow, make_layer(w1, affine1, 64),
+                                                        make_layer(w2, affine2, 64), make_layer(w3, affine3, 128), out);
+  e = hipGetLastError();
+  if (e == hipSuccess) wq->suspect = false;
+  return (int)e;
 }
 
 extern "C" int msr3d_set_reserved_cus(int n) {

@@ -270,7 +270,16 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
             r1 = 0.0                                            # level 1: ball1 already holds the neighbour lists
         L = plan["levels"]
         with _lib.kernel_timer("msr3d_sa_level1"):
-            if _sa_mma[0] == "split":
+            if _sa_mma[0] == "split" and _sa_rows[0] and m1 <= 64 and b < (1 << 18):
+                S = plan["split1"]
+                if r1 > 0.0:                                    # (not queried beside the sampling: the query's own launch)
+                    _lib.check(lib.msr3d_ball_query(b, n, m1, ctypes.c_float(r1), _NSAMPLE, _p(new1), _p(pts[..., :3].contiguous()),
+                                                    _p(ball1), st), "msr3d_ball_query")
+                ws1 = torch.empty((int(lib.msr3d_sa_level1_rows_ws_bytes(b, m1)),), dtype=torch.uint8, device=dev)
+                rc = lib.msr3d_sa_level1_rows(b, n, m1, _p(pts), _p(new1), _p(ball1), _p(S[0][0]), _p(S[0][1]), _p(S[1][0]),
+                                              _p(S[1][1]), _p(S[2][0]), _p(S[2][1]), _p(feat1), _p(vmask), _p(constant),
+                                              _p(ws1), st)
+            elif _sa_mma[0] == "split":
                 S = plan["split1"]
                 rc = lib.msr3d_sa_level_split(1, b, n, m1, ctypes.c_float(r1), _p(pts), _p(None),
                                               _p(new1), _p(S[0][0]), _p(S[0][1]), _p(S[1][0]), _p(S[1][1]), _p(S[2][0]),
@@ -340,4 +349,43 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
     if return_internals:
         dbg.update(new_xyz1=new1, new_xyz2=new2, feat1=feat1, feat2=feat2, pooled=pooled, constant=constant)
         return out, dbg
+    return out
+
+
+# per-row multiply-accumulates of the three levels' SharedMLPs (configs/msr3d.yaml:198-201)
+_ROW_MACS = (6 * 64 + 64 * 64 + 64 * 128, 131 * 128 + 128 * 128 + 128 * 256, 259 * 256 + 256 * 512 + 512 * 768)
+
+
+def row_statistics(net, pts):
+    """What one encoder pass over pts (b, P, 6) multiplies, per level (bench.py's roofline leg; one untimed pass):
+    nominal rows (every neighbourhood slot), distinct rows (what the result needs: the min(hits, nsample)
+    different rows of a centre, one row per level for a constant cloud) and the rows the matrix pipe is handed by the
+    distinct-row kernels (whole 16-row tiles), each with its FLOPs (2 x MAC, fp32-accurate products)."""
+    with torch.no_grad():
+        _, dbg = forward(net, pts, return_internals=True)
+    b = pts.shape[0]
+    const = dbg["constant"].bool() if dbg.get("constant") is not None else torch.zeros(b, dtype=torch.bool, device=pts.device)
+    real = ~const
+    out = {}
+    for lvl, key in ((1, "ball1"), (2, "ball2")):
+        ball = dbg[key]
+        m, ns = ball.shape[1], ball.shape[2]
+        d = 1 + (ball[:, :, 1:] != ball[:, :, :1]).sum(-1)              # distinct rows per centre (first hit repeated)
+        dr = d[real]
+        distinct = int(dr.sum()) + int(const.sum())
+        if lvl == 1:      # a wave's 32 rows: one big centre, or two centres of <= 16 distinct rows; a constant object: one
+            small = (dr <= 16).sum(-1)
+            tasks = (m - small) + (small + 1) // 2
+            pipe_rows = 32 * (int(tasks.sum()) + int(const.sum()))
+        else:             # chunks of 64 rows, 16-row tiles
+            R = dr.sum(-1)
+            pipe_rows = int(((R // 64) * 64 + ((R % 64 + 15) // 16) * 16).sum()) + 16 * int(const.sum())
+        out[lvl] = {"nominal_rows": b * m * ns, "distinct_rows": distinct, "pipe_rows": pipe_rows}
+    n3 = dbg["feat2"].shape[1]
+    out[3] = {"nominal_rows": b * n3, "distinct_rows": n3 * int(real.sum()) + int(const.sum()), "pipe_rows": b * n3}
+    for lvl in (1, 2, 3):
+        for k in ("nominal", "distinct", "pipe"):
+            out[lvl][k + "_flop"] = 2.0 * _ROW_MACS[lvl - 1] * out[lvl][k + "_rows"]
+    out["constant_objects"] = int(const.sum())
+    out["objects"] = b
     return out

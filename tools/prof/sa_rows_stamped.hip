@@ -5,9 +5,9 @@
 #include <hip/hip_runtime.h>
 
 constexpr int kRLog = 240;
-__device__ unsigned long long g_rows_log[512 * 4 * kRLog];
+__device__ unsigned long long g_rows_log[512 * 8 * kRLog];
 #define RSTAMP_DECL                                                                                         \
-  unsigned long long *rlog = g_rows_log + ((size_t)(blockIdx.x & 511) * 4 + (threadIdx.x >> 6)) * kRLog;    \
+  unsigned long long *rlog = g_rows_log + ((size_t)(blockIdx.x & 511) * 8 + (threadIdx.x >> 6)) * kRLog;    \
   int rlog_n = 0
 #define RSTAMP(i)                                                                                            \
   if ((threadIdx.x & 63) == 0 && rlog_n < kRLog)                                                             \
@@ -16,9 +16,9 @@ __device__ unsigned long long g_rows_log[512 * 4 * kRLog];
 #include "../../msr3d_amd/csrc/sa_split.hip"
 
 extern "C" int msr3d_prof_rows_log(unsigned long long *host) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rows_log), sizeof(unsigned long long) * 512 * 4 * kRLog);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rows_log), sizeof(unsigned long long) * 512 * 8 * kRLog);
 }
 extern "C" int msr3d_prof_rows_clear() {
-  static unsigned long long zeros[512 * 4 * kRLog];
+  static unsigned long long zeros[512 * 8 * kRLog];
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_rows_log), zeros, sizeof(zeros));
 }

@@ -63,10 +63,10 @@ e0.record(); call(); e1.record()
 torch.cuda.synchronize()
 print(f"stamped launch: {e0.elapsed_time(e1) * 1e3:.1f} ticks")
 KL = 240
-buf = np.zeros(512 * 4 * KL, np.uint64)
+buf = np.zeros(512 * 8 * KL, np.uint64)
 lib.msr3d_prof_rows_log.argtypes = [ctypes.c_void_p]
 assert lib.msr3d_prof_rows_log(buf.ctypes.data) == 0
-log = buf.reshape(512, 4, KL)
+log = buf.reshape(512, 8, KL)
 names = {4: "(chunk top)", 5: "rows -> operand + barrier F", 6: "layer 1 product + xyz", 7: "layer 1 epilogue (A, B)",
          8: "layer 2 product", 9: "layer 2 epilogue (C, D)", 10: "layer 3 product", 11: "segmented max",
          12: "next rows issued + barrier E", 13: "flush"}
@@ -89,3 +89,49 @@ print(f"blocks with work: {len(spans)}, objects logged {objs}, chunks {chunks}; 
 for i in sorted(tot):
     v = np.array(tot[i])
     print(f"  {names.get(i, i):28s} n {len(v):6d}  median {np.median(v):7.2f} tk  mean {v.mean():7.2f}  sum/block {v.sum() / len(spans):7.1f} ticks")
+
+
+# ---- level 1 (sa1_rows_kernel): marks 0 round top, 1 after layer 1, 2 point rows issued, 3 after layer 3, 4 after the maxima, 5 chunk barrier
+fn1 = lib.msr3d_sa_level1_rows
+fn1.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 14
+fn1.restype = ctypes.c_int
+S1 = fused.get_plan(net)["split1"]
+ball1, feat1_ref = dbg["ball1"], dbg["feat1"]
+out1 = torch.empty(b, 32, 128, device="cuda")
+ws1 = torch.empty(b * 32 * 132 + 64, dtype=torch.uint8, device="cuda")
+
+
+def call1():
+    rc = fn1(b, 1024, 32, p(pts), p(new1), p(ball1), p(S1[0][0]), p(S1[0][1]), p(S1[1][0]), p(S1[1][1]), p(S1[2][0]), p(S1[2][1]),
+             p(out1), p(None), p(const), p(ws1), st)
+    assert rc == 0, rc
+
+
+for _ in range(3):
+    call1()
+torch.cuda.synchronize()
+assert torch.equal(out1, feat1_ref)
+lib.msr3d_prof_rows_clear()
+e0.record(); call1(); e1.record()
+torch.cuda.synchronize()
+print(f"level 1 stamped launch (plan + products): {e0.elapsed_time(e1) * 1e3:.1f} us")
+assert lib.msr3d_prof_rows_log(buf.ctypes.data) == 0
+log = buf.reshape(512, 8, KL)
+n1 = {0: "chunk hand-over", 1: "operand + layer 1", 2: "issue point rows", 3: "layers 2, 3", 4: "maxima + stores", 5: "chunk barrier"}
+tot, spans, rounds = {}, [], 0
+for blk in range(256):
+    for w in range(8):
+        e = log[blk, w]
+        e = e[e != 0]
+        if len(e) < 2:
+            continue
+        ids = (e >> np.uint64(56)).astype(int)
+        t = (e & np.uint64((1 << 56) - 1)).astype(np.int64)
+        spans.append(t[-1] - t[0])
+        rounds += int((ids == 0).sum())
+        for i in range(1, len(e)):
+            tot.setdefault((ids[i - 1], ids[i]), []).append(t[i] - t[i - 1])
+print(f"waves logged {len(spans)}, rounds {rounds}; per-wave span median {np.median(spans):.0f} max {np.max(spans):.0f} ticks")
+for kk in sorted(tot):
+    v = np.array(tot[kk])
+    print(f"  {kk[0]}->{kk[1]} {n1.get(kk[1], '')[:24]:24s} n {len(v):6d}  median {np.median(v):8.0f}  mean {v.mean():8.0f}  sum/wave {v.sum() / len(spans):9.0f}")
