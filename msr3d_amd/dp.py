@@ -28,6 +28,8 @@ mode the bucket size is chosen large (8 MiB -> 3 buckets) for the same reason.
 """
 import os
 
+import threading
+
 import torch
 import torch.distributed as dist
 
@@ -275,6 +277,15 @@ class FlatGradAllReduce:
 
     def _launch(self, b):
         if self._launched[b] or not self.distributed:
+            return
+        if (self.on_gpu and threading.current_thread() is not threading.main_thread()
+                and torch.cuda.is_current_stream_capturing()):
+            # A bucket completed inside a backward hook, on an autograd worker thread, while the step is being CAPTURED
+            # (MSR3D_DP_GRAPH_COMM=1 with an unfrozen backbone).  torch's ProcessGroupNCCL decides from the calling
+            # thread's current stream whether a collective belongs to a capture (and then keeps it away from its
+            # watchdog); issued from a worker thread, one run in four ended with the watchdog polling an event "last
+            # recorded in a capturing stream" (hipErrorCapturedEvent) and taking the process down.  Such buckets are
+            # left to start(), which runs on the thread that owns the capture, in bucket order.
             return
         self._launched[b] = True
         s, e = self.buckets[b]

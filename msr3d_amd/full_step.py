@@ -122,6 +122,10 @@ class FullTrainStep:
                     raise RuntimeError("the captured step was built for other batch shapes")
                 torch._foreach_copy_([self.static[k] for k in keys], [batch[k] for k in keys])
                 self.graph.replay()
+                # the replayed optimiser launch rewrote the parameters without running its host code: bump their versions
+                # so that version-keyed caches (the LoRA pairs' bf16 images, weight packs) are rebuilt by the next EAGER
+                # forward instead of serving the images of a step ago
+                self.opt.mark_written()
                 return self.loss
             # the eager step(s) before the capture run on the capture's own stream
             if self._cap_stream is None:

@@ -5,4 +5,4 @@ from .decoder import LoRALlamaDecoderLayer  # noqa: F401
 from .lora import LoRALinear  # noqa: F401
 from .losses import seq_mean_cross_entropy  # noqa: F401
 from .stack import FrozenLinear, LoRALlamaStack  # noqa: F401
-from .checkpoint import hf_state_dict, load_hf_state_dict, peft_adapter_state_dict  # noqa: F401
+from .checkpoint import hf_state_dict, load_hf_state_dict, peft_adapter_state_dict, reference_trainer_state_dict  # noqa: F401

@@ -24,6 +24,8 @@ _PEFT_PREFIX = "base_model.model."
 def _strip(key):
     """Any of the accepted spellings -> ('layer', i, rest) | ('norm',) | ('head',) | ('embed',) | None."""
     k = key
+    if k.startswith("llm_model."):            # the reference trainer's pytorch_model.bin (leo_trainer.py:445-454)
+        k = k[len("llm_model."):]
     if k.startswith(_PEFT_PREFIX):
         k = k[len(_PEFT_PREFIX):]
     if k.startswith("model."):
@@ -86,6 +88,9 @@ def load_hf_state_dict(stack, state_dict, embed_out=None, strict=True):
                     else:
                         mod.lora_B.weight.copy_(v)
                     mod.invalidate_shadows()
+    if state_dict and len(unused) == len(state_dict):
+        # nothing matched: a silent no-op load would leave the LoRA matrices at their initial values
+        raise KeyError(f"none of the {len(state_dict)} keys names a tensor of the stack (first key: {next(iter(state_dict))!r})")
     full = any(isinstance(s, tuple) for s in seen)
     if strict and full:
         missing = [(i, n) for i in range(len(stack.layers)) for n in PROJ if (i, n) not in seen]
@@ -121,4 +126,15 @@ def peft_adapter_state_dict(stack):
             base = f"{_PEFT_PREFIX}model.layers.{i}.{grp}.{n}"
             sd[f"{base}.lora_A.weight"] = mod.lora_A.weight.detach().clone()
             sd[f"{base}.lora_B.weight"] = mod.lora_B.weight.detach().clone()
+    return sd
+
+
+def reference_trainer_state_dict(stack):
+    """The trainable language-model tensors under the keys of the REFERENCE TRAINER's `pytorch_model.bin`
+    (/root/reference/trainer/leo_trainer.py:445-454 saves `named_parameters()` with requires_grad of the whole MSR3D module:
+    `llm_model.` + peft's in-memory spelling, adapter name `default` included)."""
+    sd = {}
+    for k, v in peft_adapter_state_dict(stack).items():
+        k = k.replace(".lora_A.weight", ".lora_A.default.weight").replace(".lora_B.weight", ".lora_B.default.weight")
+        sd["llm_model." + k] = v
     return sd

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
-from .lora import LoRALinear, group_inputs
+from .lora import PAD_R, LoRALinear, group_inputs
 
 
 def _p(t):
@@ -211,8 +211,15 @@ class LoRALlamaDecoderLayer(nn.Module):
         self.mlp = nn.ModuleDict(dict(gate_proj=mk(hidden_size, intermediate_size), up_proj=mk(hidden_size, intermediate_size),
                                       down_proj=mk(intermediate_size, hidden_size)))
         if device is not None and torch.device(device).type == "cuda":
-            group_inputs([self.self_attn[n] for n in ("q_proj", "k_proj", "v_proj")])      # one x A^T product per input
-            group_inputs([self.mlp[n] for n in ("gate_proj", "up_proj")])
+            # one x A^T product per input: as many members as fit the 64 columns of the shared low-rank activation
+            # (r = 16: q, k, v and gate, up; r = 32: q, k and gate, up -- v keeps its own product).  When ALL consumers of
+            # the norm's output are members, they also share one d-input buffer in backward; with v outside the group
+            # its gradient reaches autograd between two members, so every member then returns its own.
+            fit = max(1, PAD_R // r)
+            for names, table in ((("q_proj", "k_proj", "v_proj"), self.self_attn), (("gate_proj", "up_proj"), self.mlp)):
+                mods = [table[n] for n in names][:fit]
+                if len(mods) > 1:
+                    group_inputs(mods, shared_grad=len(mods) == len(names))
         self.register_buffer("input_layernorm_weight", torch.ones(hidden_size, dtype=torch.bfloat16, device=device))
         self.register_buffer("post_attention_layernorm_weight", torch.ones(hidden_size, dtype=torch.bfloat16, device=device))
         self._rope = None

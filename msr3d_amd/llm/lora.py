@@ -98,18 +98,22 @@ def _quant_cached(x, x2):
 _tables = {}
 
 
-def group_inputs(mods):
+def group_inputs(mods, shared_grad=False):
     """Declare that `mods` (LoRALinear, same in_features / r / scaling / device) always read the SAME input tensor (q / k / v,
     gate / up): their A matrices' bf16 images are stacked into one (n r, K) operand, so ONE r-row product s x [A_1; ..; A_n]^T
     serves all of them (n r <= 64 columns of the shared (M, 64) low-rank activation; member i's B image sits in columns
-    i r .. of ITS zero-padded (N, 64) operand, so its GEMM picks out its own slice).  Reads the input once instead of n times."""
+    i r .. of ITS zero-padded (N, 64) operand, so its GEMM picks out its own slice).  Reads the input once instead of n times.
+    shared_grad: the caller GUARANTEES that the members are the only consumers of that input tensor (the decoder layer's
+    norm outputs): in backward the first member to run hands autograd its d input and the others ADD theirs into that
+    buffer and return nothing.  Without the guarantee (default) every member returns its own d input -- a gradient from
+    another consumer arriving between two members would make autograd replace the buffer and the later adds would be lost."""
     m0 = mods[0]
     r, K, dev = m0.r, m0.in_features, m0.lora_A.weight.device
     if len(mods) * r > PAD_R or any(m.r != r or m.in_features != K or m.scaling != m0.scaling or
                                     m.lora_A.weight.device != dev for m in mods):
         raise ValueError("group_inputs: members must share in_features, r, scaling and device, n r <= 64")
     a_cat = torch.empty((len(mods) * r, K), dtype=torch.bfloat16, device=dev)
-    grp = {"a_cat": a_cat, "mods": list(mods)}
+    grp = {"a_cat": a_cat, "mods": list(mods), "shared_grad": bool(shared_grad)}
     for i, m in enumerate(mods):
         N = m.out_features
         m._shadow = (a_cat[i * r:(i + 1) * r], torch.zeros((N, PAD_R), dtype=torch.bfloat16, device=dev),
@@ -146,9 +150,13 @@ def refresh_shadows(mods, capturing=False):
         if capturing:
             raise RuntimeError("LoRA shadow table not built before the graph capture (run a warm-up step first)")
         arr = (_lib.LoraShadowJob * len(jobs))(*[_lib.LoraShadowJob(*j) for j in jobs])
-        if len(_tables) > 64:
-            _tables.clear()
         tab = _tables[key] = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        # NEVER evicted: a captured graph holds the table's ADDRESS as a kernel argument (a cleared cache would hand the
+        # block back to the allocator and a replay would read job pointers out of whatever lives there next).  A table is
+        # a few hundred bytes per distinct stale set; it is also pinned on every module it serves.
+        for m in stale:
+            m._shadow_tables = getattr(m, "_shadow_tables", [])
+            m._shadow_tables.append(tab)
     with torch.cuda.device(dev):
         rc = _lib.load().msr3d_lora_shadows(len(jobs), _p(tab), _lib.current_stream_ptr(dev))
     _lib.check(rc, "msr3d_lora_shadows")
@@ -194,7 +202,9 @@ class _LoRAFn(torch.autograd.Function):
             else:
                 _skinny(M, a_op.shape[0], K, x2, a_op, u, PAD_R, s, dev)
             if grp is not None:
-                uc = [u, x._version, grp, None]        # [3]: the members' shared input-gradient buffer (backward)
+                # [3]: the members' shared input-gradient buffer of the backward pass in progress, [4]: members that have
+                # run in it, [5]: members that took this record in forward
+                uc = [u, x._version, grp, None, 0, 0]
                 try:
                     x._msr3d_u = uc
                 except AttributeError:
@@ -211,7 +221,9 @@ class _LoRAFn(torch.autograd.Function):
         ctx.save_for_backward(x2, u, lora_A, lora_B)
         ctx.mod = mod
         ctx.u_col = col if grp is not None else 0
-        ctx.rec = uc if grp is not None else None
+        ctx.rec = uc if (grp is not None and grp.get("shared_grad")) else None
+        if ctx.rec is not None:
+            ctx.rec[5] += 1
         ctx.shape = x.shape
         return y            # (M, N): the caller reshapes -- a view made in here could not be updated in place (RoPE)
 
@@ -254,6 +266,10 @@ class _LoRAFn(torch.autograd.Function):
                 if rec is not None and rec[3] is None:
                     rec[3] = dx
                 dx = dx.view(ctx.shape)
+            if rec is not None:
+                rec[4] += 1
+                if rec[4] >= rec[5]:           # the last member of THIS backward pass: a second pass over the same graph
+                    rec[3], rec[4] = None, 0   # (retain_graph) starts with a buffer of its own
         lib = _lib.load()
         # On the flat-gradient engine (dp.py) the pair's .grad are views of the flat buffer: the kernels ADD into them
         # (accumulate = 1) and report readiness themselves -- no AccumulateGrad add launch per parameter (448 a step for

@@ -99,18 +99,11 @@ def test_bench_exchange_captured_inside_the_step_graph(extra):
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    # Known race of this OPT-IN mode with torch's ProcessGroupNCCL watchdog thread (not with anything in this repo): the
-    # watchdog polls the completion event of a collective while that event has last been recorded inside the capture and
-    # the process dies with hipErrorCapturedEvent ("operation not permitted on an event last recorded in a capturing
-    # stream") -- about one unfrozen-backbone run in four in the full suite, never in eight stand-alone runs.  The default
-    # schedule (exchange outside the graph) is not affected.  Retried, and only for exactly that error.
-    for attempt in range(3):
-        env["MASTER_PORT"] = str(29674 + 2 * len(extra) + 10 * attempt)
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2",
-                              "--no-cpu-baseline"] + extra, env=env, cwd=ROOT, capture_output=True, text=True,
-                             timeout=600)
-        if out.returncode == 0 or "last recorded in a capturing stream" not in out.stderr:
-            break
+    # (Round 4 retried this case on hipErrorCapturedEvent, "one unfrozen run in four": buckets that complete inside
+    # backward hooks -- autograd worker threads -- during the capture are now left to the capturing thread, dp.py::_launch.
+    # No retry.)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2",
+                          "--no-cpu-baseline"] + extra, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert j["config"]["exchange_inside_graph"] is True and j["config"]["hip_graph"] is True

@@ -203,6 +203,40 @@ def test_full_step_captured_graph_replays_the_eager_steps():
     assert float((p0 - p1).abs().max()) < 5e-3 and float(((p0 - p1).abs() > 1e-4).float().mean()) < 0.02
 
 
+def test_eager_forward_between_replays_sees_the_replayed_weights():
+    """A replayed step rewrites the LoRA pairs without running the optimiser's host code; an EAGER forward in between
+    (evaluation) must still multiply with the pairs' current bf16 images, not with those of the step before
+    (FullTrainStep marks the parameters written after every replay).  replay, eval, replay, eval against the same
+    sequence without a graph."""
+    from msr3d_amd.full_step import FullTrainStep
+    from msr3d_amd.synth import synth_batch, synth_text
+    g = dict(np.load(os.path.join(GOLD, "full_step_seed0.npz"), allow_pickle=False))
+    evals = []
+    for use_graph in (False, True):
+        model, c = build_model(g, dropout=0.0)
+        ts = FullTrainStep(model, lr=5e-3, weight_decay=0.0, max_grad_norm=1.0, use_graph=use_graph)
+
+        def mk(i):
+            batch = synth_batch(8000 + i, c["B"], O=c["O"], P=c["P"], n_valid=[c["O"] - c["n_pad"]] * c["B"], device="cuda")
+            batch.update(synth_text(8100 + i, c["B"], L=c["O"], T_in=c["T_in"], T_out=c["T_out"], vocab=c["vocab"],
+                                    scene_token=c["scene_token"], device="cuda"))
+            return batch
+        probe = mk(99)
+        seen = []
+        for i in range(5):
+            ts(mk(i))
+            if i >= 2:                                   # (steps 0, 1: eager + capture; from 2 on every step is a replay)
+                model.eval()
+                with torch.no_grad():
+                    seen.append(float(model(dict(probe))["loss"].float().mean()))
+                model.train()
+        torch.cuda.synchronize()
+        assert (ts.graph is not None) == use_graph
+        evals.append(seen)
+    assert len(set(evals[1])) == len(evals[1])            # the evaluation moved with every replayed step ...
+    assert np.allclose(evals[0], evals[1], rtol=3e-3), evals   # ... exactly as it does without a graph
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

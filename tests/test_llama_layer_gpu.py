@@ -57,6 +57,71 @@ def test_decoder_layer_matches_the_transformers_fixture():
         assert rel(m.lora_B.weight.grad, g["dB/" + n]) < 2.5e-2, n
 
 
+def test_decoder_layer_with_rank_32_pairs():
+    """r = 32: q / k / v do not fit one 64-column low-rank activation (3 x 32 = 96): q and k share a product, v keeps its
+    own (round 4 raised at construction).  Same values as the layer with no input groups at all."""
+    from msr3d_amd.llm import LoRALlamaDecoderLayer
+    torch.manual_seed(0)
+    a = LoRALlamaDecoderLayer(512, 4, 768, r=32, lora_alpha=32, device="cuda")
+    assert a.self_attn["q_proj"]._group is a.self_attn["k_proj"]._group is not None
+    assert a.self_attn["v_proj"]._group is None and a.mlp["gate_proj"]._group is a.mlp["up_proj"]._group is not None
+    b = LoRALlamaDecoderLayer(512, 4, 768, r=32, lora_alpha=32, device=None).cuda()       # built on the CPU: ungrouped
+    assert b.self_attn["q_proj"]._group is None
+    with torch.no_grad():
+        for (_, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+            pa.normal_(0, 0.05)
+            pb.copy_(pa)
+        for n in NAMES:
+            ma, mb = (a.self_attn if n in a.self_attn else a.mlp)[n], (b.self_attn if n in b.self_attn else b.mlp)[n]
+            w = torch.randn(ma.out_features, ma.in_features, device="cuda") * 0.05
+            ma.load_base_weight(w)
+            mb.load_base_weight(w)
+    x = (torch.randn(2, 64, 512, device="cuda") * 0.5).to(torch.bfloat16)
+    outs = []
+    for layer in (a, b):
+        xi = x.clone().requires_grad_(True)
+        y = layer(xi)
+        y.float().square().sum().backward()
+        outs.append((y.float(), xi.grad.float(), [p.grad.clone() for p in layer.parameters()]))
+    assert rel(outs[0][0], outs[1][0]) < 1e-2 and rel(outs[0][1], outs[1][1]) < 2e-2
+    for ga, gb in zip(outs[0][2], outs[1][2]):
+        assert rel(ga, gb) < 2.5e-2
+
+
+def test_shared_input_gradient_survives_a_second_backward_pass():
+    """The members of an input group share ONE d-input buffer per backward pass (the first hands it to autograd, the others
+    add into it).  A second pass over a retained graph must start with a buffer of its own: both passes give the same
+    d input, equal to the sum of the members' own gradients."""
+    from msr3d_amd.llm import LoRALinear
+    from msr3d_amd.llm.lora import group_inputs
+    torch.manual_seed(1)
+    mods = [LoRALinear(256, 256, r=16, device="cuda") for _ in range(3)]
+    with torch.no_grad():
+        for m in mods:
+            m.load_base_weight(torch.randn(256, 256, device="cuda") * 0.05)
+            m.lora_B.weight.normal_(0, 0.05)
+    group_inputs(mods, shared_grad=True)
+    x = (torch.randn(128, 256, device="cuda") * 0.5).to(torch.bfloat16).requires_grad_(True)
+    h = x * 1.0                                            # (a non-leaf input, as the norm's output is)
+    loss = sum(m(h).float().square().sum() for m in mods)
+    loss.backward(retain_graph=True)
+    g1 = x.grad.clone()
+    x.grad = None
+    loss.backward()
+    g2 = x.grad.clone()
+    assert torch.equal(g1, g2) and float(g1.float().abs().sum()) > 0
+    # against members that each return their own gradient (no sharing declared)
+    ref = [LoRALinear(256, 256, r=16, device="cuda") for _ in range(3)]
+    with torch.no_grad():
+        for m, q in zip(mods, ref):
+            q.load_base_weight(m.weight)
+            q.lora_A.weight.copy_(m.lora_A.weight)
+            q.lora_B.weight.copy_(m.lora_B.weight)
+    xr = x.detach().clone().requires_grad_(True)
+    sum(q(xr * 1.0).float().square().sum() for q in ref).backward()
+    assert rel(g1.float(), xr.grad.float()) < 2e-2
+
+
 def _call(name, *a):
     from msr3d_amd import _lib
     rc = getattr(_lib.load(), name)(*a)

@@ -63,3 +63,22 @@ def test_peft_spellings_round_trip():
     assert torch.equal(c.layers[0].self_attn["q_proj"].weight,
                        wrapped["base_model.model.model.layers.0.self_attn.q_proj.base_layer.weight"].to(torch.bfloat16))
     assert torch.equal(c.layers[1].mlp["gate_proj"].lora_A.weight, a.layers[1].mlp["gate_proj"].lora_A.weight)
+
+
+def test_reference_trainer_checkpoint_spelling_round_trips_and_nothing_loads_silently():
+    """leo_trainer.py:445-454 saves the trainable tensors of the whole MSR3D module: `llm_model.` + peft's in-memory
+    spelling.  Such a file loads; a state dict of which NO key names a tensor of the stack is refused (it would leave the
+    LoRA matrices at their initial values without a word)."""
+    from msr3d_amd.llm import load_hf_state_dict, reference_trainer_state_dict
+    torch.manual_seed(2)
+    a, b = _tiny(), _tiny()
+    with torch.no_grad():
+        for p in a.lora_parameters():
+            p.normal_()
+    sd = reference_trainer_state_dict(a)
+    assert "llm_model.base_model.model.model.layers.0.self_attn.q_proj.lora_A.default.weight" in sd and len(sd) == 2 * 7 * 2
+    assert load_hf_state_dict(b, sd) == []
+    for pa, pb in zip(a.lora_parameters(), b.lora_parameters()):
+        assert torch.equal(pa, pb)
+    with pytest.raises(KeyError, match="none of the"):
+        load_hf_state_dict(_tiny(), {"visual_prompter.anchor_feat": torch.zeros(3), "some.other.key": torch.zeros(1)})
