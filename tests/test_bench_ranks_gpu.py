@@ -89,6 +89,25 @@ def test_bench_single_rank_json_contract():
     assert j["vs_baseline"] is None and j["data"] == "synthetic"
 
 
+def test_bench_default_line_carries_the_full_step_and_the_levels():
+    """The driver's invocation (no workload flags): the headline line carries the roofline of the slowest SharedMLP level
+    with all three levels beside it (distinct-row FLOPs priced, nominal rate stated) and, measured in the same process, the
+    FULL MSR3D step at 4 x 576 tokens with e4m3 and with bf16 projections as extra.full_step."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "16", "--warmup", "2",
+                          "--cpu-baseline-seconds", "1"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    r = j["roofline"]
+    assert set(r["levels"]) == {"level1", "level2", "level3"} and 0 < r["frac"] < 1 and r["nominal_tflops"] >= r["achieved"]
+    for lv in r["levels"].values():
+        assert 0 < lv["frac"] < 1 and lv["distinct_rows"] <= lv["nominal_rows"] and lv["kernel_ms"] > 0
+    assert r["levels"]["level2"]["distinct_rows"] < 0.2 * r["levels"]["level2"]["nominal_rows"]      # ~9 % on these scenes
+    fs = j["extra"]["full_step"]
+    for k in ("fp8", "bf16"):
+        assert fs[k]["value"] > 0 and fs[k]["config"]["layers"] == 32 and fs[k]["config"]["tokens_per_sequence"] == 576, fs
+    assert fs["fp8"]["ms_per_step"] < fs["bf16"]["ms_per_step"]
+
+
 @pytest.mark.parametrize("extra", [[], ["--unfrozen", "--batch", "2"]])
 def test_bench_exchange_captured_inside_the_step_graph(extra):
     """MSR3D_DP_GRAPH_COMM=1: the RCCL call is captured with forward, backward and the optimiser -- one graph
