@@ -121,7 +121,7 @@ def parse():
     ap.add_argument("--llm-layers", type=int, default=32, help="decoder layers of --full-step (32 = Vicuna-7B)")
     ap.add_argument("--seq-len", type=int, default=576, help="tokens per sequence of --full-step (prompt incl. 60 scene "
                     "tokens + answer; multiple of 64)")
-    ap.add_argument("--round-tag", default=os.environ.get("MSR3D_ROUND_TAG", "r04"), help="prefix of files this run writes "
+    ap.add_argument("--round-tag", default=os.environ.get("MSR3D_ROUND_TAG", "r05"), help="prefix of files this run writes "
                     "under profiles/ (--cpu-ops)")
     ap.add_argument("--llm-layer", action="store_true", help="SECONDARY, labelled line: one LoRA-Llama decoder layer "
                     "(Vicuna-7B shape: hidden 4096, 32 heads, MLP 11008, LoRA r 16 on the seven projections), forward + "

@@ -734,6 +734,8 @@ typedef struct msr3d_wgrad_problem {
   const float *dy; int ldy; int n_out;
   const float *x; int ldx; int k_in;
   int M;
+  int xcd_rot;   /* 0..7: which XCD takes the problem's FIRST run of tiles (workgroup b of the launch runs on XCD b % 8;
+                    a problem's padding workgroups -- it owns a multiple of 8 -- then fall on other XCDs for every problem) */
   float *dW; int ldw;
   float *db;
 } msr3d_wgrad_problem_t;
@@ -754,6 +756,15 @@ int msr3d_wgrad_split_colsum(int n, const msr3d_wgrad_problem_t *problems, const
 #define MSR3D_WGRAD_HALF_SLOT_FLOATS (128 * 128 + 128)
 int msr3d_wgrad_split_halves(int n, const msr3d_wgrad_problem_t *problems, const int *tile_prefix, int total_tiles,
                              float *workspace, long long workspace_floats, int *sync, msr3d_stream_t stream);
+/* MIXED form (round 5): only the tiles of the launch's PARTIAL round are cut.  Workgroups [0, whole_tiles) take whole
+ * tiles, the other H = total_tiles - whole_tiles tiles run as two half-reductions each (the protocol above), n_jobs
+ * column-sum workgroups follow (msr3d_wgrad_split_colsum).  The caller picks whole_tiles so that the halves fill what the
+ * whole tiles leave of the chip's second round (msr3d_amd/scene_blocks.py: real tiles beyond one per CU, when they are at
+ * most half a round).  whole_tiles % 8 == 0 and H % 8 == 0; workspace: H x MSR3D_WGRAD_HALF_SLOT_FLOATS floats; sync:
+ * 2 H ints, zero before the first launch.  H == 0 is msr3d_wgrad_split_colsum. */
+int msr3d_wgrad_split_mixed(int n, const msr3d_wgrad_problem_t *problems, const int *tile_prefix, int total_tiles,
+                            int whole_tiles, int n_jobs, const msr3d_colsum_job_t *jobs, float *workspace,
+                            long long workspace_floats, int *sync, msr3d_stream_t stream);
 
 /* dW (n_out, k_in) (+)= dy^T x over M rows for TALL operands (the SharedMLP weight gradients of an unfrozen
  * backbone: up to ~10^6 rows), the arithmetic and tile kernel of msr3d_wgrad_split: the rows are cut into up to

@@ -90,7 +90,7 @@ class ColsumJob(ctypes.Structure):
 class WgradProblem(ctypes.Structure):
     """msr3d_wgrad_problem_t (include/msr3d_hip.h)."""
     _fields_ = [("dy", _ptr), ("ldy", _c_int), ("n_out", _c_int), ("x", _ptr), ("ldx", _c_int), ("k_in", _c_int),
-                ("M", _c_int), ("dW", _ptr), ("ldw", _c_int), ("db", _ptr)]
+                ("M", _c_int), ("xcd_rot", _c_int), ("dW", _ptr), ("ldw", _c_int), ("db", _ptr)]
 
 
 BLK = {"attn_fwd": 0, "ffn_fwd": 1, "ffn_bwd": 2, "attn_bwd": 3, "linear": 4, "linear_ksplit": 5}
@@ -113,6 +113,7 @@ _SIGNATURES = {
     "msr3d_fp8_gemm_lowrank_acc": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _c_int, _ptr, _ptr, _c_int, _ptr, _c_int,
                                _ptr, _c_int, _ptr],
     "msr3d_wgrad_split_halves": [_c_int, _ptr, _ptr, _c_int, _ptr, ctypes.c_longlong, _ptr, _ptr],
+    "msr3d_wgrad_split_mixed": [_c_int, _ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _ptr, ctypes.c_longlong, _ptr, _ptr],
     "msr3d_wgrad_rows_split": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _ptr,
                                ctypes.c_longlong, _ptr, _ptr],
     "msr3d_rows_gemm_split": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr,

@@ -349,10 +349,13 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_split_kernel(int nprob, const 
   }
   const WP pr = probs[lo];
   // A problem owns a multiple of 8 workgroups; workgroup b runs on XCD b % 8 (observed dispatch order:
-  // speed only), so XCD x takes the CONTIGUOUS run of tiles [x nb/8, (x+1) nb/8): tiles that share a dy
-  // block (same output tile, consecutive input tiles) read it through one L2.
+  // speed only), so XCD x takes the CONTIGUOUS run of tiles [x' nb/8, (x'+1) nb/8), x' = (x - xcd_rot) % 8: tiles that
+  // share a dy block (same output tile, consecutive input tiles) read it through one L2.  xcd_rot (the host's, per
+  // problem) spreads the problems' PADDING workgroups over the XCDs: unrotated, the step's 230 real tiles fell
+  // 33 / 33 / 31 / 31 / 28 / 28 / 26 / 20 on the eight XCDs of 32 CUs -- one tile too many on two of them, i.e. a
+  // second round of one tile: the launch lasted TWO tile times (118 us) for 0.9 rounds of work.
   const int lb = t - prefix[lo], nb = prefix[lo + 1] - prefix[lo];
-  const int local = (lb & 7) * (nb >> 3) + (lb >> 3);
+  const int local = ((lb - pr.xcd_rot) & 7) * (nb >> 3) + (lb >> 3);
   const int nkt = (pr.k_in + TK - 1) / TK;
   if (local >= ((pr.n_out + TN - 1) / TN) * nkt) return;
   wgrad_tile<false>(pr, local / nkt, local % nkt, smem);
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_halves_kernel(int nprob, const
   }
   const WP pr = probs[lo];
   const int lb = t - prefix[lo], nb = prefix[lo + 1] - prefix[lo];
-  const int local = (lb & 7) * (nb >> 3) + (lb >> 3);
+  const int local = ((lb - pr.xcd_rot) & 7) * (nb >> 3) + (lb >> 3);
   const int nkt = (pr.k_in + TK - 1) / TK;
   if (local >= ((pr.n_out + TN - 1) / TN) * nkt) return;
   const int nslab = ((pr.M + 63) >> 6) << 1;
@@ -396,6 +399,66 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_halves_kernel(int nprob, const
     if (threadIdx.x == 0) {
       const int k = __hip_atomic_fetch_add(sync + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (k == 1) __hip_atomic_store(sync + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (both tickets taken)
+      role_s = k;
+    }
+    __syncthreads();
+    hf.role = role_s;
+  }
+  wgrad_tile<false, false, false, true>(pr, local / nkt, local % nkt, smem, 0, 0, nullptr, hf);
+}
+
+// MIXED (round 5): the step's ~330 real tiles on 256 CUs are one full round and a second one that is 29 % full -- the
+// launch lasts two tile times.  Cutting EVERY tile in two (wgrad_halves_kernel) does not change that ratio and pays the
+// hand-over everywhere (measured slower).  Here only the tiles of the partial round are cut: workgroups [0, W) take whole
+// tiles, [W, W + H) and [W + H, W + 2 H) the first and second halves of tiles W .. W + H - 1 (H = tiles - W, a multiple
+// of 8: both halves on one XCD), so the second round lasts half a tile time.  Same ticket protocol as above (the unit
+// that STARTS first parks, the second adds first + second in that order: bit-reproducible); workgroups past W + 2 H
+// run the column-sum jobs.  sync: [H] tickets | [H] flags, zero between launches; ws: H slots.
+__global__ __launch_bounds__(NTHREADS) void wgrad_mixed_kernel(int nprob, const WP *__restrict__ probs,
+                                                               const int *__restrict__ prefix, int tiles, int W,
+                                                               float *__restrict__ ws, int *__restrict__ sync,
+                                                               const msr3d_colsum_job_t *__restrict__ cjobs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int role_s;
+  const int H = tiles - W, b = blockIdx.x;
+  if (b >= W + 2 * H) {
+    colsum_job(cjobs[b - (W + 2 * H)], reinterpret_cast<float *>(smem));
+    return;
+  }
+  const bool halved = b >= W;
+  const int second = b >= W + H ? 1 : 0;
+  const int t = halved ? b - second * H : b;
+  int lo = 0, hi = nprob - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (prefix[mid] <= t) lo = mid; else hi = mid - 1;
+  }
+  const WP pr = probs[lo];
+  const int lb = t - prefix[lo], nb = prefix[lo + 1] - prefix[lo];
+  const int local = ((lb - pr.xcd_rot) & 7) * (nb >> 3) + (lb >> 3);
+  const int nkt = (pr.k_in + TK - 1) / TK;
+  if (local >= ((pr.n_out + TN - 1) / TN) * nkt) return;
+  if (!halved) {
+    wgrad_tile<false>(pr, local / nkt, local % nkt, smem);
+    return;
+  }
+  const int nslab = ((pr.M + 63) >> 6) << 1;
+  const int cut = ((nslab >> 1) + 1) & ~1;            // whole slab pairs: 30 slabs -> 16 + 14
+  const int h = t - W;
+  Half hf;
+  hf.second = second;
+  hf.s0 = second ? cut : 0;
+  hf.s1 = second ? nslab : cut;
+  hf.ws = ws + (size_t)h * kHalfSlot;
+  hf.flag = sync + H + h;
+  if (cut >= nslab) {                                  // a reduction of one slab pair is not cut
+    if (second) return;
+    hf.s1 = nslab;
+    hf.role = -1;
+  } else {
+    if (threadIdx.x == 0) {
+      const int k = __hip_atomic_fetch_add(sync + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (k == 1) __hip_atomic_store(sync + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (both tickets taken)
       role_s = k;
     }
     __syncthreads();
@@ -510,6 +573,22 @@ extern "C" int msr3d_wgrad_split_halves(int n, const msr3d_wgrad_problem_t *prob
   if (attr != hipSuccess) return (int)attr;
   wgrad_halves_kernel<<<2 * total_tiles, NTHREADS, LDS_BYTES, (hipStream_t)stream>>>(n, problems, tile_prefix, workspace,
                                                                                     sync);
+  return (int)hipGetLastError();
+}
+
+extern "C" int msr3d_wgrad_split_mixed(int n, const msr3d_wgrad_problem_t *problems, const int *tile_prefix,
+                                       int total_tiles, int whole_tiles, int n_jobs, const msr3d_colsum_job_t *jobs,
+                                       float *workspace, long long workspace_floats, int *sync, msr3d_stream_t stream) {
+  if (n < 0 || total_tiles < 0 || n_jobs < 0 || whole_tiles < 0 || whole_tiles > total_tiles) return MSR3D_EINVAL;
+  if ((n == 0 || total_tiles == 0) && n_jobs == 0) return 0;
+  const int H = total_tiles - whole_tiles;
+  if ((total_tiles > 0 && (!problems || !tile_prefix)) || (n_jobs > 0 && !jobs) || (H & 7) || (whole_tiles & 7)) return MSR3D_EINVAL;
+  if (H > 0 && (!workspace || !sync || workspace_floats < (long long)H * MSR3D_WGRAD_HALF_SLOT_FLOATS)) return MSR3D_EINVAL;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_mixed_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (attr != hipSuccess) return (int)attr;
+  wgrad_mixed_kernel<<<whole_tiles + 2 * H + n_jobs, NTHREADS, LDS_BYTES, (hipStream_t)stream>>>(
+      n, problems, tile_prefix, total_tiles, whole_tiles, workspace, sync, jobs);
   return (int)hipGetLastError();
 }
 

@@ -111,7 +111,12 @@ class WgradTable:
         # 1.290 ms: two pipeline fills, the parked 64 KB image and the release / acquire fences per tile cost more than the
         # tail they remove), so the default stays one workgroup per tile.  Kept, tested, opt-in.
         self.halves = os.environ.get("MSR3D_WGRAD_HALVES", "0") == "1"
+        # Round 5 (default; MSR3D_WGRAD_MIXED=0 turns it off): only the tiles of the launch's PARTIAL round are cut in two
+        # (msr3d_wgrad_split_mixed) -- ~330 real tiles on 256 CUs are one full round and one that is 29 % full; with those
+        # 74 tiles as 148 half-reductions the second round lasts half a tile time.
+        self.mixed = os.environ.get("MSR3D_WGRAD_MIXED", "1") != "0" and not self.halves
         self._ws = self._sync = None
+        self._real = []                       # real (non-padding) tiles of each problem
 
     def add(self, dy, ldy, n_out, x, ldx, k_in, M, dW, ldw, db):
         p = WgradProblem()
@@ -119,10 +124,56 @@ class WgradTable:
         p.dW, p.ldw, p.db = dW, ldw, db if db else None
         self.probs.append(p)
         tiles = -(-n_out // self.TN) * -(-k_in // self.TK)
+        self._real.append(tiles)
         tiles = (tiles + 7) // 8 * 8          # a multiple of 8 workgroups per problem (XCD-aware tile order)
         self.prefix.append(self.prefix[-1] + tiles)
         self._dirty = True
         return len(self.probs) - 1
+
+    def _balance_xcds(self):
+        """xcd_rot of every problem: workgroup b runs on XCD b % 8 and a problem's real tiles occupy the first
+        ceil-runs of its 8 XCD slots, so without a rotation the padding always falls on the high XCDs.  Greedy: problems
+        in order, each takes the rotation that leaves the fullest XCD emptiest."""
+        load = [0] * 8
+        for p, r, a, b in zip(self.probs, self._real, self.prefix[:-1], self.prefix[1:]):
+            nb = b - a
+            per = [sum(1 for lb in range(x, nb, 8) if x * (nb >> 3) + (lb >> 3) < r) for x in range(8)]   # slot x' -> tiles
+            if p.M <= 0:
+                per = [0] * 8
+            best = min(range(8), key=lambda rot: (max(load[(x + rot) & 7] + per[x] for x in range(8)), rot))
+            p.xcd_rot = best
+            for x in range(8):
+                load[(x + best) & 7] += per[x]
+        self.xcd_load = load
+
+    def _whole_tiles(self):
+        """Workgroups [0, W) of the mixed launch take whole tiles, the rest run as two half-reductions each (see below).
+        Problems whose token count is zero this step still own their workgroups."""
+        key = tuple(p.M for p in self.probs)
+        if getattr(self, "_whole_key", None) == key:
+            return self._whole
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        real = []                                          # per workgroup slot: does it multiply?
+        for p, r, a, b in zip(self.probs, self._real, self.prefix[:-1], self.prefix[1:]):
+            nb = b - a
+            for lb in range(nb):
+                local = ((lb - p.xcd_rot) & 7) * (nb >> 3) + (lb >> 3)     # (the kernel's XCD-aware order)
+                real.append(local < r and p.M > 0)
+        # Measured (tools/bench_wgrad.py, the step's 326 real tiles of 360 workgroups on 256 CUs): whole tiles only 115 us,
+        # every tile halved 129 us, the last 96-136 workgroups halved 110 us -- a unit costs ~27 us besides its slabs
+        # (its life is set by the loader waves: 16 waves of splitting VALU + MFMA issue on one CU), so cutting helps only
+        # the tail.  W: the real tiles left whole number one per CU less a sixteenth (the halves then start on CUs that
+        # are already free); nothing is cut when the tiles fit one round or the rest would not fit a second.
+        total_real, whole = sum(real), self.prefix[-1]
+        target = cus - cus // 16
+        if total_real > cus and 2 * (total_real - target) <= cus:
+            seen, w = 0, 0
+            while w < self.prefix[-1] and seen + sum(real[w:w + 8]) <= target:
+                seen += sum(real[w:w + 8])
+                w += 8
+            whole = w
+        self._whole_key, self._whole = key, whole
+        return whole
 
     def set_ptr(self, idx, field, ptr):
         if getattr(self.probs[idx], field) != ptr:
@@ -132,6 +183,7 @@ class WgradTable:
     def launch(self, stream, colsum=None):
         """colsum = (n_jobs, job-table tensor): msr3d_colsum_partials' jobs as extra workgroups of this launch."""
         if self._dirty:
+            self._balance_xcds()
             arr = (WgradProblem * len(self.probs))(*self.probs)
             n = ctypes.sizeof(arr)
             if self._table is None:
@@ -166,6 +218,18 @@ class WgradTable:
             _lib.check(rc, "msr3d_wgrad_split_halves")
             if colsum is not None:
                 _lib.check(_lib.load().msr3d_colsum_partials(colsum[0], _vp(colsum[1].data_ptr()), stream), "msr3d_colsum_partials")
+            return
+        whole = self._whole_tiles() if self.mixed else self.prefix[-1]
+        if whole < self.prefix[-1]:
+            H = self.prefix[-1] - whole
+            if self._ws is None or self._ws.numel() < H * HALF_SLOT_FLOATS:
+                self._ws = torch.empty(H * HALF_SLOT_FLOATS, dtype=torch.float32, device=self.device)
+                self._sync = torch.zeros(2 * H, dtype=torch.int32, device=self.device)
+            nj, jt = (colsum[0], _vp(colsum[1].data_ptr())) if colsum is not None else (0, _vp(0))
+            rc = _lib.load().msr3d_wgrad_split_mixed(len(self.probs), _vp(self._table.data_ptr()), _vp(self._pfx.data_ptr()),
+                                                     self.prefix[-1], whole, nj, jt, _vp(self._ws.data_ptr()),
+                                                     self._ws.numel(), _vp(self._sync.data_ptr()), stream)
+            _lib.check(rc, "msr3d_wgrad_split_mixed")
             return
         if colsum is not None:
             rc = _lib.load().msr3d_wgrad_split_colsum(len(self.probs), _vp(self._table.data_ptr()), _vp(self._pfx.data_ptr()),

@@ -29,6 +29,8 @@ v python bench.py --no-cpu-baseline --host-inputs
 v python bench.py --no-cpu-baseline --objects 120 --points 2048 --llm-hidden 5120 --batch 8 --situation-type as_object
 v env MSR3D_TRAINABLE=strips python bench.py --no-cpu-baseline
 v env MSR3D_SA_MMA=f32 python bench.py --no-cpu-baseline
+v env MSR3D_SA_ROWS=0 python bench.py --no-cpu-baseline
+v env MSR3D_WGRAD_MIXED=0 python bench.py --no-cpu-baseline
 v env MSR3D_SA3_TILE=2 python bench.py --no-cpu-baseline
 v env MSR3D_WGRAD_HALVES=1 python bench.py --no-cpu-baseline
 v env MSR3D_ATTN_FWD_WAVES=4 python bench.py --no-cpu-baseline
@@ -61,4 +63,7 @@ python tools/bench_bf16_gemm.py 2>/dev/null | grep -v amdgpu > "$OUT/${TAG}_bf16
 python -m pytest tests/test_seq_ce_gpu.py -q -s -k roofline 2>/dev/null | grep seq_ce > "$OUT/${TAG}_seq_ce.txt"
 python bench.py --cpu-ops --round-tag "$TAG" > "$OUT/${TAG}_cpu_ops.log" 2>&1; cp "profiles/${TAG}_cpu_ops.json" "$OUT/${TAG}_cpu_ops.json"
 timeout 300 python tools/prof_blocks.py > "$OUT/${TAG}_block_stamps.txt" 2>&1
+timeout 300 python tools/prof_sa_rows.py > "$OUT/${TAG}_sa_rows_stamps.txt" 2>&1
+timeout 120 python tools/bench_wgrad.py > "$OUT/${TAG}_wgrad_forms.txt" 2>&1
+timeout 120 python tools/bench_sa.py > "$OUT/${TAG}_encoder_kernels.txt" 2>&1
 ls -la "$OUT"
