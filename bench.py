@@ -822,7 +822,9 @@ def main():
         # idempotent, so the kernels of round 5 multiply only the different rows -- same bits, and a rate priced on the
         # nominal FLOPs would exceed the roof and read as "work skipped".  Row counts: one untimed pass per resident batch.
         from msr3d_amd.pointnet2 import fused as _fused
-        split = _fused._sa_mma[0] == "split"
+        split = _fused._sa_mma[0] in ("split", "split2")
+        reduced = _fused._sa_mma[0] == "split2"          # LABELLED variant: 2 bf16 terms per operand, 3 products
+        SPLIT_PRODUCTS = 3 if reduced else 6
         rows_on = split and _fused._sa_rows[0]
         objs_per_launch = float(Bcall * O) * (calls if window else 1)    # (a whole window per encoder launch)
         if args.skip_padded:      # only real objects are encoded: count them over the timed steps
@@ -860,11 +862,14 @@ def main():
                     "frac": d["frac"], "nominal_tflops": d["nominal_tflops"],
                     "achieved_note": "FLOPs of the distinct neighbourhood rows (what the result needs; SURVEY.md 8(d)'s nominal "
                                      "figure counts every padded slot: nominal_tflops) / the launch's duration",
-                    "peak_note": ("bf16 dense MFMA peak 2500 TFLOP/s / 6 products per fp32-accurate product" if split
+                    "peak_note": (f"bf16 dense MFMA peak 2500 TFLOP/s / {SPLIT_PRODUCTS} products per product" if split
                                   else "f32-input MFMA peak"),
                     "mfma_executed_tflops": d["mfma_executed_tflops"], "mfma_pipe_frac": d["mfma_pipe_frac"],
                     "vs_f32_mfma_peak": d["achieved_tflops"] / MFMA_F32_PEAK_TF,
-                    "dtype": ("f32 operands as 3 bf16 terms, 6 x v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate "
+                    "dtype": ("VARIANT split2: f32 operands as 2 bf16 terms, 3 x v_mfma_f32_16x16x32_bf16 per product (~16 significant "
+                              "bits per product, fp32 accumulate): NOT fp32 accuracy -- encoder output rel-L2 vs the fp32 path "
+                              "in extra.split2_rel_l2") if reduced else
+                             ("f32 operands as 3 bf16 terms, 6 x v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate "
                               "(fp32 accuracy; MSR3D_SA_MMA=f32 selects the f32-input MFMA kernels)") if split
                     else "f32-input MFMA (v_mfma_f32_16x16x4_f32)",
                     "levels": levels, "constant_objects_per_launch": scale * sum(st["constant_objects"] for st in stats) / len(stats),
@@ -885,7 +890,9 @@ def main():
                                         "note": "HIP events on the compute stream between steps, this rank"},
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (every product as 6 bf16 MFMA products of exact 3-way bf16 splits, fp32 accumulate: fp32 accuracy)" if (split and not args.unfrozen) else "f32",
+            "dtype": ("VARIANT (MSR3D_SA_MMA=split2): frozen encoder on 2-term bf16 splits, 3 MFMA products per product (~16 bits); "
+                      "trainable part f32-accurate (6 products)") if (reduced and not args.unfrozen) else
+                     "f32 (every product as 6 bf16 MFMA products of exact 3-way bf16 splits, fp32 accumulate: fp32 accuracy)" if (split and not args.unfrozen) else "f32",
             "data": "synthetic",
             "config": {"workload": "configs/msr3d.yaml hot path (OSE3DSituation + llm_proj, "
                                    "frozen PointNet++), synthetic ScanNet-like scenes",
@@ -915,7 +922,17 @@ def main():
         plain = not (dist_on or args.unfrozen or args.skip_padded or args.pipeline or args.from_store or args.host_inputs
                      or args.accum > 1 or args.no_graph or args.time_all_kernels or (O, P) != (60, 1024)
                      or args.llm_hidden != 4096 or args.batch != 16 or args.no_cpu_baseline)
-        if plain and not args.no_extra:
+        if reduced and not args.unfrozen:
+            # how far the reduced variant's encoder output is from the fp32-accurate path, on the first resident batch
+            net = model.visual_prompter.obj_encoder.pcd_net
+            pts0 = batches[0]["obj_fts"].reshape(-1, P, 6)
+            with torch.no_grad():
+                y2 = _fused.forward(net, pts0).double()
+                prev = _fused.set_sa_mma("split")
+                y6 = _fused.forward(net, pts0).double()
+                _fused.set_sa_mma(prev)
+            line.setdefault("extra", {})["split2_rel_l2"] = float((y2 - y6).norm() / y6.norm())
+        if plain and not args.no_extra and not reduced:
             # SURVEY 8(f) rank 4, where > 99 % of a real step's time lives: the FULL step of BASELINE configs[1] (prompter ->
             # llm_proj -> scatter -> 32 LoRA-Llama layers at the Vicuna-7B shapes -> head -> CE -> backward into the
             # prompter -> clip + AdamW), in this process, after the headline: labelled secondary figures, never `value`

@@ -273,6 +273,30 @@ def load():
     return lib
 
 
+_lib_split2 = None
+_SPLIT2_ENTRIES = ("msr3d_sa_level_split", "msr3d_sa_level1_rows", "msr3d_sa_level2_rows", "msr3d_sa_level1_rows_ws_bytes",
+                   "msr3d_sa_level2_rows_ws_bytes")
+
+
+def load_split2():
+    """libmsr3d_hip_split2.so: csrc/sa_split.hip compiled with two bf16 terms per operand and three products per product
+    (msr3d_amd/build.py) -- the labelled variant MSR3D_SA_MMA=split2 / fused.set_sa_mma("split2").  Same entry names and
+    signatures as the main library's set-abstraction entries; loaded only on request."""
+    global _lib_split2
+    if _lib_split2 is None:
+        load()                                       # (builds both libraries if needed; the HIP runtime is torch's)
+        from . import build as _build
+        if not os.path.exists(_build.LIB_SPLIT2):
+            _build.build()
+        lib = ctypes.CDLL(_build.LIB_SPLIT2)
+        for name in _SPLIT2_ENTRIES:
+            fn = getattr(lib, name)
+            fn.argtypes = _SIGNATURES[name]
+            fn.restype = ctypes.c_size_t if name.endswith("_ws_bytes") else _c_int
+        _lib_split2 = lib
+    return _lib_split2
+
+
 def check(status, what):
     if status != 0:
         msg = load().msr3d_status_string(status).decode()

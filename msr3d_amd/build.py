@@ -13,6 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libmsr3d_hip.so")
+# the labelled reduced-split variant of the set-abstraction SharedMLPs (MSR3D_SA_MMA=split2): csrc/sa_split.hip alone,
+# compiled with MSR3D_SPLIT_TERMS=3, under the same entry names
+LIB_SPLIT2 = os.path.join(HERE, "libmsr3d_hip_split2.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 ARCH = "gfx950"
@@ -93,6 +96,12 @@ def build(force=False, verbose=False, sqdist_contract=None):
             rebuilt = True
     if rebuilt or not os.path.exists(LIB):
         cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    s2 = os.path.join(CSRC, "sa_split.hip")
+    if force or not os.path.exists(LIB_SPLIT2) or os.path.getmtime(LIB_SPLIT2) < max(os.path.getmtime(s2), hdr_t):
+        cmd = [cc] + COMMON + ["-ffp-contract=off", "-DMSR3D_SPLIT_TERMS=3"] + contract_flag + ["-shared", s2, "-o", LIB_SPLIT2]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -51,6 +51,20 @@
 
 // phase marks of the level-2 kernel: empty here; tools/prof/sa_split_stamped.hip defines them and includes
 // this file (tools/ab_split.py reads the stamps)
+// MSR3D_SPLIT_TERMS = 3 (python -m msr3d_amd.build builds libmsr3d_hip_split2.so from this file with it): the LABELLED
+// reduced variant MSR3D_SA_MMA=split2 -- two bf16 terms per operand, the three products x0 w0 + x0 w1 + x1 w0 (~16
+// significant bits per product; the reference's cuDNN convolutions run TF32, 10 bits, by default on any Ampere-or-later
+// GPU: README.md:81 pins torch 1.12.1 and nothing in the reference touches allow_tf32).  Never the headline.
+#ifndef MSR3D_SPLIT_TERMS
+#define MSR3D_SPLIT_TERMS 6
+#endif
+#if MSR3D_SPLIT_TERMS == 6     // smallest first: the accumulator meets the big terms last
+#define MSR3D_TERMS_ALL MSR3D_TERM(2, 0) MSR3D_TERM(0, 2) MSR3D_TERM(1, 1) MSR3D_TERM(1, 0) MSR3D_TERM(0, 1) MSR3D_TERM(0, 0)
+#elif MSR3D_SPLIT_TERMS == 3
+#define MSR3D_TERMS_ALL MSR3D_TERM(1, 0) MSR3D_TERM(0, 1) MSR3D_TERM(0, 0)
+#else
+#error "MSR3D_SPLIT_TERMS must be 6 or 3"
+#endif
 #ifndef RSTAMP                 // phase marks of the distinct-row kernels (tools/prof/sa_rows_stamped.hip)
 #define RSTAMP(i)
 #define RSTAMP_DECL
@@ -170,12 +184,7 @@ __device__ __forceinline__ void gemm_split(const unsigned short *xs, int ldh, in
 #define MSR3D_TERM(PW, PX)                                                                             \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                  \
         acc[rn][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[q].v[PW], x[mt][PX], acc[rn][mt], 0, 0, 0);
-    MSR3D_TERM(2, 0)
-    MSR3D_TERM(0, 2)
-    MSR3D_TERM(1, 1)
-    MSR3D_TERM(1, 0)
-    MSR3D_TERM(0, 1)
-    MSR3D_TERM(0, 0)
+    MSR3D_TERMS_ALL
 #undef MSR3D_TERM
   }
 }
@@ -257,12 +266,7 @@ __device__ __forceinline__ void gemm_split_x(const XF &xf, const WStream &wg, f3
 #define MSR3D_TERM(PW, PX)                                                                             \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                  \
         acc[rn][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[q].v[PW], x[mt][PX], acc[rn][mt], 0, 0, 0);
-    MSR3D_TERM(2, 0)
-    MSR3D_TERM(0, 2)
-    MSR3D_TERM(1, 1)
-    MSR3D_TERM(1, 0)
-    MSR3D_TERM(0, 1)
-    MSR3D_TERM(0, 0)
+    MSR3D_TERMS_ALL
 #undef MSR3D_TERM
   }
 }
@@ -687,7 +691,7 @@ __global__ __launch_bounds__(256) void sa2_plan_kernel(int b, int n, int m, floa
                                                        const float *__restrict__ new_xyz, int *__restrict__ rows_of,
                                                        unsigned char *__restrict__ plan,
                                                        int *__restrict__ dbg_idx, const unsigned char *__restrict__ valid,
-                                                       const unsigned char *__restrict__ constant) {
+                                                       const unsigned char *__restrict__ constant, float *__restrict__ out) {
   __shared__ float s_x[4][64 * 3];
   __shared__ int s_f[4][kRowsMaxM];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -767,72 +771,96 @@ __global__ __launch_bounds__(256) void sa2_plan_kernel(int b, int n, int m, floa
       if (8 * q + t < filled) list[off + 8 * q + t] = (unsigned short)((c << 8) | slot[t]);
   }
   if (lane == 0) hdr[0] = rows_of[obj] = R;
+  if (R > kTM) {     // more than one chunk: its units may run in different workgroups and meet in `out` by atomic max
+    float4 *o = reinterpret_cast<float4 *>(out + (size_t)obj * m * kN3);
+    for (int i = lane; i < m * kN3 / 4; i += kWave) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 }
 
 template <int V> struct IntTag { static constexpr int value = V; };
 
-constexpr int kSa2RowsLds = 3 * kPlane * 2 + 2 * (kPlanRows * 2 + 64 * 3 * 4 + kRowsMaxM * 4 * 4) + kTM * 4 * 4 + kTM * 4 +
-                            kRowsMaxM * kOutPitch * 4;
+constexpr int kMineMax = 32;                 // units one block can be dealt (units <= kMineMax x blocks)
 
-constexpr int kMineMax = 32;                 // objects one block can be dealt (b <= kMineMax x blocks)
-
-// Objects differ 30-fold in work (1 .. 512 rows; a padding slot: one), there are only a few per block (960 objects on
-// 512 resident blocks), and a block reads its objects' plans an object ahead -- a device-wide queue would be drained by
-// that look-ahead before any block knew how long its share takes.  So the deal is STATIC and balanced: objects are
-// ordered by cost class, heaviest first (a STABLE counting sort on ceil(rows / 32), ranks by ballot / popcount -- every
-// block computes the same order for itself from the b row counts, ~1 us, and keeps only its own entries), and block k of
-// B takes positions k, 2B-1-k, 2B+k, 4B-1-k, ... of that order: the heaviest objects go to different blocks and each is
-// paired with one from the light end.  Returns with s_mine[r] = this block's r-th object (b: none), after a barrier.
-constexpr int kDealClasses = 17;               // cost class = ceil(rows / 32): 1 .. 16 (0: no rows)
-__device__ __forceinline__ void deal_objects(int b, const int *__restrict__ rows_of, int *s_cnt /* [4][17] */,
-                                             int *s_off /* [4][17] */, int *s_mine, int tid) {
+// The unit of work is a CHUNK: up to 64 consecutive rows of one object's list (an object of R rows: ceil(R / 64) units).
+// Units differ 4-fold in work (1 .. 4 row tiles), there are only a few per block (~1,150 on 512 resident blocks at the
+// bench shape), and a block reads a unit's plan a unit ahead -- a device-wide queue would be drained by that look-ahead
+// before any block knew how long its share takes.  So the deal is STATIC and balanced: units are ordered by row tiles,
+// heaviest first (a STABLE counting sort on 4 .. 1 tiles; ranks by ballot / popcount over the b row counts -- every block
+// computes the same order for itself, ~1 us, and keeps only its own entries), and block k of B takes positions k,
+// 2B-1-k, 2B+k, 4B-1-k, ... of that order.  (Round 5's first form dealt whole OBJECTS: the heaviest, three chunks, set
+// the launch's length -- median block 68 k cycles, slowest 98 k.)  An object cut over several blocks meets in `out`
+// through an integer atomic max (sa2_plan_kernel zeroes its rows): values are >= 0, the order of arrival changes nothing.
+// Returns with s_mine[r] = this block's r-th unit, object | chunk << 20 (-1: none), after a barrier.
+__device__ __forceinline__ void deal_units(int b, const int *__restrict__ rows_of, int *s_cnt /* [4][5] */,
+                                           int *s_off /* [4][5] */, int *s_mine, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
   const int per_wave = ((b + 255) / 256) * 64, i0 = wave * per_wave, i1 = min(b, i0 + per_wave);
-  if (tid <= kMineMax) s_mine[tid] = b;
-  int cnt[kDealClasses];
-#pragma unroll
-  for (int c = 0; c < kDealClasses; ++c) cnt[c] = 0;
+  if (tid <= kMineMax) s_mine[tid] = -1;
+  // per object: `full` units of 4 tiles and one LAST unit of 1 .. 4 tiles (none when it has no rows)
+  auto units_of = [&](int i, int &full, int &last_tiles) {
+    const int R = i < i1 ? rows_of[i] : 0;
+    const int nch = (R + kTM - 1) / kTM;
+    full = nch > 0 ? nch - 1 : 0;                                   // (0 .. 7: three bits)
+    last_tiles = nch > 0 ? (R - full * kTM + 15) >> 4 : 0;
+  };
+  auto wave_sum = [&](int v) {                                      // sum of a 3-bit value over the wave
+    return __popcll(__ballot(v & 1)) + 2 * __popcll(__ballot(v & 2)) + 4 * __popcll(__ballot(v & 4));
+  };
+  auto wave_before = [&](int v) {                                   // ... over the lanes below this one
+    return __popcll(__ballot(v & 1) & lt) + 2 * __popcll(__ballot(v & 2) & lt) + 4 * __popcll(__ballot(v & 4) & lt);
+  };
+  int cnt[5] = {0, 0, 0, 0, 0};
   for (int base = i0; base < i1; base += 64) {
-    const int i = base + lane, R = i < i1 ? rows_of[i] : 0, cls = (R + 31) >> 5;
+    int full, lt_;
+    units_of(base + lane, full, lt_);
+    cnt[4] += wave_sum(full);
 #pragma unroll
-    for (int c = 1; c < kDealClasses; ++c) cnt[c] += __popcll(__ballot(cls == c));
+    for (int c = 1; c <= 4; ++c) cnt[c] += __popcll(__ballot(lt_ == c));
   }
   if (lane == 0) {
 #pragma unroll
-    for (int c = 1; c < kDealClasses; ++c) s_cnt[wave * kDealClasses + c] = cnt[c];
+    for (int c = 1; c <= 4; ++c) s_cnt[wave * 5 + c] = cnt[c];
   }
   __syncthreads();
-  if (tid < 4) {                                 // thread w: where wave w's objects of each class start
+  if (tid < 4) {                                 // thread w: where wave w's units of each class start
     int run = 0;
-    for (int c = kDealClasses - 1; c >= 1; --c) {
+    for (int c = 4; c >= 1; --c)
       for (int w = 0; w < 4; ++w) {
-        if (w == tid) s_off[tid * kDealClasses + c] = run;
-        run += s_cnt[w * kDealClasses + c];
+        if (w == tid) s_off[tid * 5 + c] = run;
+        run += s_cnt[w * 5 + c];
       }
-    }
   }
   __syncthreads();
-  int run[kDealClasses];
+  int run[5];
 #pragma unroll
-  for (int c = 1; c < kDealClasses; ++c) run[c] = s_off[wave * kDealClasses + c];
+  for (int c = 1; c <= 4; ++c) run[c] = s_off[wave * 5 + c];
   const int B = gridDim.x, k = blockIdx.x;
+  auto claim = [&](int pos, int unit) {
+    const int r = pos / B, rem = pos - r * B;
+    if (((r & 1) ? B - 1 - rem : rem) == k && r < kMineMax) s_mine[r] = unit;
+  };
   for (int base = i0; base < i1; base += 64) {
-    const int i = base + lane, R = i < i1 ? rows_of[i] : 0, cls = (R + 31) >> 5;
-    int pos = -1;
+    const int i = base + lane;
+    int full, lt_;
+    units_of(i, full, lt_);
+    // class 4: the object's full chunks first, then (if its last chunk also has 4 tiles) that one
+    const int p4 = run[4] + wave_before(full) + __popcll(__ballot(lt_ == 4) & lt);
+    for (int c = 0; c < full; ++c) claim(p4 + c, i | (c << 20));
+    if (lt_ == 4) claim(p4 + full, i | (full << 20));
+    run[4] += wave_sum(full) + __popcll(__ballot(lt_ == 4));
 #pragma unroll
-    for (int c = 1; c < kDealClasses; ++c) {
-      const unsigned long long mk = __ballot(cls == c);
-      if (cls == c) pos = run[c] + __popcll(mk & lt);
+    for (int c = 3; c >= 1; --c) {
+      const unsigned long long mk = __ballot(lt_ == c);
+      if (lt_ == c) claim(run[c] + __popcll(mk & lt), i | (full << 20));
       run[c] += __popcll(mk);
-    }
-    if (pos >= 0) {
-      const int r = pos / B, rem = pos - r * B;
-      if (((r & 1) ? B - 1 - rem : rem) == k && r < kMineMax) s_mine[r] = i;
     }
   }
   __syncthreads();
 }
+
+constexpr int kSa2RowsLds = 3 * kPlane * 2 + 2 * (kPlanRows * 2 + 64 * 3 * 4 + kRowsMaxM * 4 * 4) + kTM * 4 * 4 + kTM * 4 +
+                            kRowsMaxM * kOutPitch * 4;
 
 __global__ __launch_bounds__(256, 2) void sa2_rows_kernel(int b, int n, int m, const int *__restrict__ rows_of,
                                                           const unsigned char *__restrict__ plan,
@@ -841,17 +869,17 @@ __global__ __launch_bounds__(256, 2) void sa2_rows_kernel(int b, int n, int m, c
                                                           float *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   unsigned short *buf = smem;                                             // ROWS [3][64][144] / FRAG image
-  unsigned short *rowmap2 = smem + 3 * kPlane;                             // [2][512]: this object's and the next one's list
+  unsigned short *rowmap2 = smem + 3 * kPlane;                             // [2][512]: this unit's object's list and the next one's
   float *sx2 = reinterpret_cast<float *>(rowmap2 + 2 * kPlanRows);         // [2][64 * 3]
   float *ctr2 = sx2 + 2 * 64 * 3;                                          // [2][16 * 4]
   float *dxs = ctr2 + 2 * kRowsMaxM * 4;                                   // [64][4]: the chunk rows' recentred coordinates
   int *rowc = reinterpret_cast<int *>(dxs + kTM * 4);                      // [64]: centre of each row of the chunk
-  unsigned *outb = reinterpret_cast<unsigned *>(rowc + kTM);               // [16][257]: running maxima (bit patterns)
+  unsigned *outb = reinterpret_cast<unsigned *>(rowc + kTM);               // [16][257]: the chunk's maxima (bit patterns)
   unsigned char *fbuf = reinterpret_cast<unsigned char *>(buf);
-  __shared__ int s_mine[kMineMax + 1], s_cnt[4 * kDealClasses], s_off[4 * kDealClasses];
+  __shared__ int s_mine[kMineMax + 1], s_cnt[4 * 5], s_off[4 * 5];
   int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   RSTAMP_DECL;
-  deal_objects(b, rows_of, s_cnt, s_off, s_mine, tid);
+  deal_units(b, rows_of, s_cnt, s_off, s_mine, tid);
   // (the folded BN affines are read where they are used, from global memory -- 4 KB that every block shares in L2: the
   // table's 4 KB of LDS are what lets TWO blocks share a CU)
   const float *__restrict__ sc1 = l1.scale, *__restrict__ sh1 = l1.shift, *__restrict__ sc2 = l2.scale,
@@ -863,8 +891,9 @@ __global__ __launch_bounds__(256, 2) void sa2_rows_kernel(int b, int n, int m, c
   const WStream w2 = make_stream<RN2>(l2.w, kN1 * kN2 * 6, wave_u, lane);
   const WStream w3 = make_stream<RN3>(l3.w, kN2 * kN3 * 6, wave_u, lane);
   for (int i = tid; i < m * kOutPitch; i += 256) outb[i] = 0u;
-  int oi = 0, obj = s_mine[0], objn = s_mine[1];
-  if (obj >= b) return;
+  int ui = 0, un = s_mine[1];
+  if (s_mine[0] < 0) return;
+  int obj = s_mine[0] & 0xfffff, base = (s_mine[0] >> 20) * kTM;
 
   // ---- an object's plan + geometry: global -> registers -> LDS (parity p) ----
   unsigned plw = 0u;                           // two entries of the row list per thread
@@ -888,18 +917,18 @@ __global__ __launch_bounds__(256, 2) void sa2_rows_kernel(int b, int n, int m, c
   // ---- a chunk's rows: global -> registers (all loads first), then split -> operand planes, dx and centre per row ----
   constexpr int IT = kTM * 32 / 256;
   float4 val[IT];
-  auto rows_fetch = [&](int o, int p, int base, int R) {          // (slots past the last row repeat it: a duplicate
+  auto rows_fetch = [&](int o, int p, int bs, int R) {            // (slots past the last row repeat it: a duplicate
     const float *F = feat + (size_t)o * n * 128;                   //  does not move a maximum)
     const unsigned short *rm = rowmap2 + p * kPlanRows;
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int e = tid + it * 256;
-      int rr = base + (e >> 5);
+      int rr = bs + (e >> 5);
       rr = rr < R ? rr : R - 1;
       val[it] = *reinterpret_cast<const float4 *>(F + (size_t)(rm[rr] & 255) * 128 + (e & 31) * 4);
     }
   };
-  auto rows_store = [&](int p, int base, int R) {
+  auto rows_store = [&](int p, int bs, int R) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int e = tid + it * 256;
@@ -911,7 +940,7 @@ __global__ __launch_bounds__(256, 2) void sa2_rows_kernel(int b, int n, int m, c
       for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2 *>(d + k * kPlane) = q[k];
     }
     if (tid < kTM) {
-      int rr = base + tid;
+      int rr = bs + tid;
       rr = rr < R ? rr : R - 1;
       const int rm = rowmap2[p * kPlanRows + rr], pi = rm & 255, c = rm >> 8;
       const float *sx = sx2 + p * 192, *ct = ctr2 + p * kRowsMaxM * 4 + c * 4;
@@ -920,28 +949,27 @@ __global__ __launch_bounds__(256, 2) void sa2_rows_kernel(int b, int n, int m, c
     }
   };
 
-  // ---- prologue: the first object's plan and its first chunk, unpipelined ----
+  // ---- prologue: the first unit's plan and rows, unpipelined ----
   plan_fetch(obj);
-  int hdr = hdrn, pb = 0, base = 0;
+  int hdr = hdrn, pb = 0;
   plan_store(0);
   __syncthreads();
-  rows_fetch(obj, 0, 0, hdr & 0xffff);
-  rows_store(0, 0, hdr & 0xffff);
-  bool first = true;                           // first chunk of its object: the NEXT object's plan is fetched under it
+  rows_fetch(obj, 0, base, hdr & 0xffff);
+  rows_store(0, base, hdr & 0xffff);
   __syncthreads();
 
   while (true) {
     const int R = hdr & 0xffff;
     const int rows = R - base < kTM ? R - base : kTM;
     const int nmt = (rows + 15) >> 4;
-    const bool last = base + kTM >= R;         // last chunk of its object
-    const bool more_obj = objn < b;
-    // per-lane addresses are re-derived every chunk (see sa2_split_kernel)
+    const bool more = un >= 0;
+    const int objn = more ? un & 0xfffff : obj, basen = more ? (un >> 20) * kTM : base;
+    // per-lane addresses are re-derived every unit (see sa2_split_kernel)
     asm volatile("" : "+v"(tid));
     lane = tid & 63;
     wave = tid >> 6;
     RSTAMP(4);
-    if (first) plan_fetch(more_obj ? objn : obj);   // (wave-uniform; no next object: a harmless re-read)
+    plan_fetch(objn);                          // the NEXT unit's plan flies under layer 1 (no next unit: a harmless re-read)
     auto layers = [&](auto tag) {
       constexpr int MT = decltype(tag)::value;
       // (each variant derives its lane addresses from its own opaque copy of the thread id: expressions common to the
@@ -975,7 +1003,7 @@ __global__ __launch_bounds__(256, 2) void sa2_rows_kernel(int b, int n, int m, c
         }
         RSTAMP(6);
         __syncthreads();                                          // (A) every wave is done READING the operand
-        if (first) plan_store(pb ^ 1);                            // the next object's plan: registers -> LDS (other parity)
+        plan_store(pb ^ 1);                                       // the next unit's plan: registers -> LDS (other parity)
         store_split_frag<RN1, MT>(acc, sc, sh, fbuf, wave * RN1 * 16, lane);
       }
       __syncthreads();                                            // (B)
@@ -1064,45 +1092,45 @@ __global__ __launch_bounds__(256, 2) void sa2_rows_kernel(int b, int n, int m, c
       default: layers(IntTag<4>{}); break;
     }
     RSTAMP(11);
-    // the NEXT chunk's rows start moving (UNCONDITIONAL: after the very last chunk a harmless re-read of it -- a
-    // conditional assignment would make `val` loop-carried and live across the three products)
-    const bool next_is_obj = last && more_obj;
-    const int f_obj = next_is_obj ? objn : obj, f_p = next_is_obj ? pb ^ 1 : pb;
-    const int f_base = last ? (more_obj ? 0 : base) : base + kTM;
-    const int f_R = next_is_obj ? (hdrn & 0xffff) : R;
-    rows_fetch(f_obj, f_p, f_base, f_R);
+    // the NEXT unit's rows start moving (UNCONDITIONAL: after the last unit a harmless re-read of it -- a conditional
+    // assignment would make `val` loop-carried and live across the three products); its plan sits in the other parity
+    const int Rn = hdrn & 0xffff;
+    rows_fetch(objn, pb ^ 1, basen, Rn);
     __syncthreads();                                              // (E) the chunk's maxima are in; the operand buffer is free
     RSTAMP(12);
-    if (last) {   // ---- the object's m x 256 maxima (a constant object: centre 0's row for every centre) ----
+    {   // ---- the chunk's maxima -> out.  An object of ONE chunk: plain stores (a constant object: centre 0's row for every
+        // centre); an object cut into several units: integer atomic max onto rows sa2_plan_kernel zeroed ----
       float *O = out + (size_t)obj * m * kN3;
-      const bool is_const = (hdr >> 16) != 0;
-      if (is_const) {
+      if ((hdr >> 16) != 0) {
         for (int i = tid; i < m * kN3; i += 256) O[i] = __uint_as_float(outb[i & 255]);
         __syncthreads();
         if (tid < kN3) outb[tid] = 0u;
-      } else {
+      } else if (R <= kTM) {
         for (int i = tid; i < m * kN3; i += 256) {
           const int w = (i >> 8) * kOutPitch + (i & 255);
           O[i] = __uint_as_float(outb[w]);
           outb[w] = 0u;
         }
+      } else {
+        for (int i = tid; i < m * kN3; i += 256) {
+          const int w = (i >> 8) * kOutPitch + (i & 255);
+          const unsigned v = outb[w];
+          if (v) {
+            __hip_atomic_fetch_max(reinterpret_cast<unsigned *>(O) + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            outb[w] = 0u;
+          }
+        }
       }
-      RSTAMP(13);
-      if (!more_obj) break;
     }
-    rows_store(f_p, f_base, f_R);
-    if (last) {
-      obj = objn;
-      objn = s_mine[++oi + 1];                                     // (s_mine[kMineMax] = b)
-      hdr = hdrn;
-      pb ^= 1;
-      base = 0;
-      first = true;
-    } else {
-      base += kTM;
-      first = false;
-    }
-    __syncthreads();                                              // (F) the next chunk's operand is in place
+    RSTAMP(13);
+    if (!more) break;
+    rows_store(pb ^ 1, basen, Rn);
+    obj = objn;
+    base = basen;
+    hdr = hdrn;
+    pb ^= 1;
+    un = s_mine[++ui + 1];                                        // (s_mine[kMineMax] = -1)
+    __syncthreads();                                              // (F) the next unit's operand is in place
     RSTAMP(5);
   }
 }
@@ -1141,12 +1169,7 @@ __device__ __forceinline__ void gemm_split_rolled(const unsigned short *xs, int 
     _Pragma("unroll") for (int rn = 0; rn < RN; ++rn)                                                  \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                  \
         acc[rn][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[rn].v[PW], x[mt][PX], acc[rn][mt], 0, 0, 0);
-    MSR3D_TERM(2, 0)
-    MSR3D_TERM(0, 2)
-    MSR3D_TERM(1, 1)
-    MSR3D_TERM(1, 0)
-    MSR3D_TERM(0, 1)
-    MSR3D_TERM(0, 0)
+    MSR3D_TERMS_ALL
 #undef MSR3D_TERM
   };
   fetch(wa, 0);
@@ -1449,12 +1472,7 @@ __device__ __forceinline__ void wave_layer(const unsigned short *wl, const bf16x
     _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                   \
         acc[t0 + i][mt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[s][mt][PX], w[grp][i].v[PW], acc[t0 + i][mt], 0, 0, 0) \
                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[grp][i].v[PW], x[s][mt][PX], acc[t0 + i][mt], 0, 0, 0);
-    MSR3D_TERM(2, 0)
-    MSR3D_TERM(0, 2)
-    MSR3D_TERM(1, 1)
-    MSR3D_TERM(1, 0)
-    MSR3D_TERM(0, 1)
-    MSR3D_TERM(0, 0)
+    MSR3D_TERMS_ALL
 #undef MSR3D_TERM
   }
 }
@@ -1945,7 +1963,13 @@ extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius
                                                            make_layer(w3, affine3, 128), out, valid);
   } else if (level == 3) {
     if (!pts || !feat || n != 16 || m != 1) return MSR3D_EINVAL;
+#if MSR3D_SPLIT_TERMS == 3
+    // (the four-object tile's register allocation -- 256 VGPRs + 200 AGPRs with six products in flight per piece -- falls
+    //  into scratch with three: the reduced variant takes the two-object tile)
+    static const bool two = true;
+#else
     static const bool two = [] { const char *v = getenv("MSR3D_SA3_TILE"); return v && v[0] == '2'; }();
+#endif
     if (two) {
       if ((e = allow_lds(sa3_split_kernel, kSa3Lds)) != hipSuccess) return (int)e;
       sa3_split_kernel<<<(b + 1) / 2, 256, kSa3Lds, st>>>(b, pts, feat, make_layer(w1, affine1, 256), make_layer(w2, affine2, 512),
@@ -1980,13 +2004,14 @@ extern "C" int msr3d_sa_level2_rows(int b, int n, int m, float radius, const flo
   const float r2 = radius * radius;   // f32 product, as ball_query_gpu.cu:22
   int *rows_of = reinterpret_cast<int *>(plan_ws);
   unsigned char *plan = reinterpret_cast<unsigned char *>(plan_ws) + plan_costs_bytes(b);
-  sa2_plan_kernel<<<(b + 3) / 4, 256, 0, st>>>(b, n, m, r2, xyz, new_xyz, rows_of, plan, dbg_ball_idx, valid, constant);
+  sa2_plan_kernel<<<(b + 3) / 4, 256, 0, st>>>(b, n, m, r2, xyz, new_xyz, rows_of, plan, dbg_ball_idx, valid, constant, out);
   if ((e = hipGetLastError()) != hipSuccess) return (int)e;
   if ((e = allow_lds(sa2_rows_kernel, kSa2RowsLds)) != hipSuccess) return (int)e;
   static const int per_cu = [] { const char *v = getenv("MSR3D_SA2_ROWS_BLOCKS"); return v ? atoi(v) : 2; }();
   const int slots = per_cu * usable_cus();
   int blocks = b < slots ? b : slots;
-  if ((long long)blocks * kMineMax < b) blocks = (b + kMineMax - 1) / kMineMax;   // (more rounds of blocks than resident slots)
+  const long long max_units = (long long)b * (kPlanRows / kTM);                  // (an object: at most 8 chunks)
+  if ((long long)blocks * kMineMax < max_units) blocks = (int)((max_units + kMineMax - 1) / kMineMax);   // (more blocks than resident slots)
   sa2_rows_kernel<<<blocks, 256, kSa2RowsLds, st>>>(b, n, m, rows_of, plan, xyz, feat, new_xyz, make_layer(w1, affine1, 128),
                                                     make_layer(w2, affine2, 128), make_layer(w3, affine3, 256), out);
   return (int)hipGetLastError();

@@ -179,13 +179,16 @@ PAD_VALUE = 1.0       # the dataset wrapper's padding cloud (dataset_wrapper.py:
 #   "split"  every fp32 operand split exactly into three bf16 terms, six bf16 MFMA products per product,
 #            fp32 accumulate (csrc/sa_split.hip): error per product below one fp32 rounding
 #   "f32"    f32-input MFMA (csrc/sa_fused.hip): exact fp32 fma chains
-# MSR3D_SA_MMA=f32|split or set_sa_mma(); see DESIGN.md §4.1 for the measured accuracy of both.
+#   "split2" LABELLED reduced variant, never the default: two bf16 terms per operand, three products (x0 w0 + x0 w1 + x1 w0,
+#            ~16 significant bits per product), the same kernels from libmsr3d_hip_split2.so -- for comparison with what the
+#            reference's cuDNN convolutions compute on its own hardware (TF32, 10 bits, by default)
+# MSR3D_SA_MMA=f32|split|split2 or set_sa_mma(); see DESIGN.md §4.1 for the measured accuracy.
 import os as _os
 _sa_mma = [_os.environ.get("MSR3D_SA_MMA", "split")]
 # MSR3D_FPS_QUERY=0: furthest-point sampling and level 1's ball query as the two launches of round 3
 _FPS_QUERY = _os.environ.get("MSR3D_FPS_QUERY", "1") != "0"
-if _sa_mma[0] not in ("f32", "split"):
-    raise ValueError("MSR3D_SA_MMA must be 'f32' or 'split'")
+if _sa_mma[0] not in ("f32", "split", "split2"):
+    raise ValueError("MSR3D_SA_MMA must be 'f32', 'split' or 'split2'")
 
 
 # Distinct-row kernels (round 5): a neighbourhood's SharedMLP over the min(hits, nsample) DIFFERENT rows ball_query
@@ -200,8 +203,8 @@ def set_sa_rows(on):
 
 
 def set_sa_mma(name):
-    if name not in ("f32", "split"):
-        raise ValueError("sa mma must be 'f32' or 'split'")
+    if name not in ("f32", "split", "split2"):
+        raise ValueError("sa mma must be 'f32', 'split' or 'split2'")
     prev, _sa_mma[0] = _sa_mma[0], name
     return prev
 
@@ -233,6 +236,8 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
         pad_feat = padding_feature(net, n, dev)
         vmask = valid.reshape(b).contiguous().view(torch.uint8)
     lib = _lib.load()
+    split = _sa_mma[0] in ("split", "split2")
+    slib = _lib.load_split2() if _sa_mma[0] == "split2" else lib          # whose SharedMLP kernels run
     sa1, sa2, _ = net.encoder
     m1, m2 = sa1.npoint, sa2.npoint
     new1 = torch.empty((b, m1, 3), dtype=torch.float32, device=dev)
@@ -242,7 +247,7 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
     pooled = torch.empty((b, 768), dtype=torch.float32, device=dev)
     ball1 = torch.empty((b, m1, _NSAMPLE), dtype=torch.int32, device=dev)   # level-1 workspace
     # objects whose cloud is one repeated point (padding slots), reported by the sampling launch: one row per level
-    constant = torch.empty((b,), dtype=torch.uint8, device=dev) if (_sa_rows[0] and _sa_mma[0] == "split") else None
+    constant = torch.empty((b,), dtype=torch.uint8, device=dev) if (_sa_rows[0] and split) else None
     dbg = {}
     if return_internals:
         dbg = {"idx1": torch.empty((b, m1), dtype=torch.int32, device=dev),
@@ -270,18 +275,18 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
             r1 = 0.0                                            # level 1: ball1 already holds the neighbour lists
         L = plan["levels"]
         with _lib.kernel_timer("msr3d_sa_level1"):
-            if _sa_mma[0] == "split" and _sa_rows[0] and m1 <= 64 and b < (1 << 18):
+            if split and _sa_rows[0] and m1 <= 64 and b < (1 << 18):
                 S = plan["split1"]
                 if r1 > 0.0:                                    # (not queried beside the sampling: the query's own launch)
                     _lib.check(lib.msr3d_ball_query(b, n, m1, ctypes.c_float(r1), _NSAMPLE, _p(new1), _p(pts[..., :3].contiguous()),
                                                     _p(ball1), st), "msr3d_ball_query")
-                ws1 = torch.empty((int(lib.msr3d_sa_level1_rows_ws_bytes(b, m1)),), dtype=torch.uint8, device=dev)
-                rc = lib.msr3d_sa_level1_rows(b, n, m1, _p(pts), _p(new1), _p(ball1), _p(S[0][0]), _p(S[0][1]), _p(S[1][0]),
+                ws1 = torch.empty((int(slib.msr3d_sa_level1_rows_ws_bytes(b, m1)),), dtype=torch.uint8, device=dev)
+                rc = slib.msr3d_sa_level1_rows(b, n, m1, _p(pts), _p(new1), _p(ball1), _p(S[0][0]), _p(S[0][1]), _p(S[1][0]),
                                               _p(S[1][1]), _p(S[2][0]), _p(S[2][1]), _p(feat1), _p(vmask), _p(constant),
                                               _p(ws1), st)
-            elif _sa_mma[0] == "split":
+            elif split:
                 S = plan["split1"]
-                rc = lib.msr3d_sa_level_split(1, b, n, m1, ctypes.c_float(r1), _p(pts), _p(None),
+                rc = slib.msr3d_sa_level_split(1, b, n, m1, ctypes.c_float(r1), _p(pts), _p(None),
                                               _p(new1), _p(S[0][0]), _p(S[0][1]), _p(S[1][0]), _p(S[1][1]), _p(S[2][0]),
                                               _p(S[2][1]), _p(feat1), _p(ball1), _p(vmask), st)
             else:
@@ -290,16 +295,16 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
                                         _p(L[0][2]), _p(feat1), _p(ball1), _p(vmask), st)
         _lib.check(rc, "msr3d_sa_level(1)")
         with _lib.kernel_timer("msr3d_sa_level2"):
-            if _sa_mma[0] == "split" and _sa_rows[0] and m1 <= 64 and m2 <= 16:
+            if split and _sa_rows[0] and m1 <= 64 and m2 <= 16:
                 S = plan["split2"]
-                ws = torch.empty((int(lib.msr3d_sa_level2_rows_ws_bytes(b)),), dtype=torch.uint8, device=dev)
-                rc = lib.msr3d_sa_level2_rows(b, m1, m2, ctypes.c_float(sa2.groupers[0].radius), _p(new1),
+                ws = torch.empty((int(slib.msr3d_sa_level2_rows_ws_bytes(b)),), dtype=torch.uint8, device=dev)
+                rc = slib.msr3d_sa_level2_rows(b, m1, m2, ctypes.c_float(sa2.groupers[0].radius), _p(new1),
                                               _p(feat1), _p(new2), _p(S[0][0]), _p(S[0][1]), _p(S[1][0]),
                                               _p(S[1][1]), _p(S[2][0]), _p(S[2][1]), _p(feat2),
                                               _p(dbg.get("ball2")), _p(vmask), _p(constant), _p(ws), st)
-            elif _sa_mma[0] == "split":
+            elif split:
                 S = plan["split2"]
-                rc = lib.msr3d_sa_level_split(2, b, m1, m2, ctypes.c_float(sa2.groupers[0].radius), _p(new1),
+                rc = slib.msr3d_sa_level_split(2, b, m1, m2, ctypes.c_float(sa2.groupers[0].radius), _p(new1),
                                               _p(feat1), _p(new2), _p(S[0][0]), _p(S[0][1]), _p(S[1][0]),
                                               _p(S[1][1]), _p(S[2][0]), _p(S[2][1]), _p(feat2),
                                               _p(dbg.get("ball2")), _p(vmask), st)
@@ -309,9 +314,9 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
                                         _p(L[1][2]), _p(feat2), _p(dbg.get("ball2")), _p(vmask), st)
         _lib.check(rc, "msr3d_sa_level(2)")
         with _lib.kernel_timer("msr3d_sa_level3"):
-            if _sa_mma[0] == "split" and m2 == 16:
+            if split and m2 == 16:
                 S = plan["split3"]
-                rc = lib.msr3d_sa_level_split(3, b, m2, 1, ctypes.c_float(0.0), _p(new2), _p(feat2), _p(None),
+                rc = slib.msr3d_sa_level_split(3, b, m2, 1, ctypes.c_float(0.0), _p(new2), _p(feat2), _p(None),
                                               _p(S[0][0]), _p(S[0][1]), _p(S[1][0]), _p(S[1][1]), _p(S[2][0]),
                                               _p(S[2][1]), _p(pooled), _p(None), _p(vmask), st)
             else:

@@ -79,6 +79,32 @@ def test_split_path_is_fp32_accurate(seed, spread):
     assert rel(ysp, y32) < 2e-6                                   # encoder output, both modes
 
 
+def test_split2_variant_is_what_its_label_says():
+    """MSR3D_SA_MMA=split2 (labelled variant, never the default): two bf16 terms per operand, three MFMA products per
+    product -- ~16 significant bits per product.  Same indices (the index path is untouched); level-2 features within
+    1e-4 rel-L2 of float64 (measured ~1e-5: printed), clearly NOT the fp32-accurate path's 2e-6; the encoder output within
+    2e-4 of the six-product path.  For scale: TF32 -- what the reference's convolutions run on by default on its own
+    hardware -- keeps 10 bits."""
+    from msr3d_amd.pointnet2 import fused
+    from msr3d_amd.synth import synth_batch
+    net = _net(3)
+    pts = synth_batch(3, 2, O=60, P=1024, device="cuda")["obj_fts"].reshape(-1, 1024, 6).contiguous()
+    out = {}
+    for mode in ("split", "split2"):
+        prev = fused.set_sa_mma(mode)
+        try:
+            with torch.no_grad():
+                out[mode] = fused.forward(net, pts, return_internals=True)
+        finally:
+            fused.set_sa_mma(prev)
+    (y6, d6), (y3, d3) = out["split"], out["split2"]
+    assert torch.equal(d6["ball1"], d3["ball1"]) and torch.equal(d6["ball2"], d3["ball2"])
+    e6, e3 = rel(d6["feat2"], _level2_float64(net, d6)), rel(d3["feat2"], _level2_float64(net, d3))
+    ey = rel(y3, y6)
+    print(f"split2: level-2 rel-L2 vs float64 {e3:.2e} (six products: {e6:.2e}); encoder output vs six products {ey:.2e}")
+    assert e6 < 2e-6 and 2e-6 < e3 < 1e-4 and ey < 2e-4
+
+
 def test_split_handles_tiny_and_zero_activations():
     """ReLU zeros, a padding cloud (all coordinates 1.0: degenerate neighbourhoods) and features scaled
     down to the fp32 denormal boundary."""
