@@ -1821,32 +1821,44 @@ __global__ __launch_bounds__(64 * k1Waves, 1) void sa1_rows_kernel(int n, int m,
       const int obj = (hu >> 2) & 0x3ffff, kind = hu & 3, ca = (hu >> 20) & 63, cb = (hu >> 26) & 63;
       float *oa = out + ((size_t)obj * m + ca) * k1N3 + j, *ob = out + ((size_t)obj * m + cb) * k1N3 + j;
       const int x16 = (lane ^ 16) * 4, x32 = (lane ^ 32) * 4;
-      auto groups_max = [&](float v) {                     // over the four lane groups: every lane ends with the maximum
-        v = fmaxf(v, __int_as_float(__builtin_amdgcn_ds_bpermute(x16, __float_as_int(v))));
-        return fmaxf(v, __int_as_float(__builtin_amdgcn_ds_bpermute(x32, __float_as_int(v))));
-      };
+      constexpr int NT3 = k1N3 / 16;
+      // per lane: the maximum over its four rows (and, for a big centre, over both row tiles) of every channel tile ...
+      float m0[NT3], m1[NT3];
 #pragma unroll
-      for (int t = 0; t < k1N3 / 16; ++t) {
+      for (int t = 0; t < NT3; ++t) {
         const float sc = sc3[t * 16 + j], sh = sh3[t * 16 + j];
-        float m0 = 0.f, m1 = 0.f;                          // starting the max at 0 IS the ReLU
+        m0[t] = m1[t] = 0.f;                               // starting the max at 0 IS the ReLU
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          m0 = fmaxf(m0, __builtin_fmaf(acc[t][0][r], sc, sh));
-          m1 = fmaxf(m1, __builtin_fmaf(acc[t][1][r], sc, sh));
+          m0[t] = fmaxf(m0[t], __builtin_fmaf(acc[t][0][r], sc, sh));
+          m1[t] = fmaxf(m1[t], __builtin_fmaf(acc[t][1][r], sc, sh));
         }
-        if (kind == kTaskBig) {                            // (wave-uniform) one centre: both row tiles
-          m0 = groups_max(fmaxf(m0, m1));
-          if (g == 0) oa[t * 16] = m0;
-        } else {
-          m0 = groups_max(m0);
-          m1 = groups_max(m1);
-          if (kind == kTaskPair) {
-            if (g == 0) oa[t * 16] = m0;
-            if (g == 1) ob[t * 16] = m1;
-          } else {                                         // constant cloud: every centre of the object
-            float *o0 = out + (size_t)obj * m * k1N3 + t * 16 + j;
-            for (int c = g; c < m; c += 4) o0[(size_t)c * k1N3] = m0;
-          }
+        if (kind == kTaskBig) m0[t] = fmaxf(m0[t], m1[t]);
+      }
+      // ... then over the four lane groups: two exchanges per value, all of a stage in flight together (every lane ends
+      // with the maximum)
+      auto exchange = [&](float (&v)[NT3], int addr) {
+        int got[NT3];
+#pragma unroll
+        for (int t = 0; t < NT3; ++t) got[t] = __builtin_amdgcn_ds_bpermute(addr, __float_as_int(v[t]));
+#pragma unroll
+        for (int t = 0; t < NT3; ++t) v[t] = fmaxf(v[t], __int_as_float(got[t]));
+      };
+      exchange(m0, x16);
+      if (kind != kTaskBig) exchange(m1, x16);
+      exchange(m0, x32);
+      if (kind != kTaskBig) exchange(m1, x32);
+      if (kind == kTaskConst) {                            // constant cloud: every centre of the object
+#pragma unroll
+        for (int t = 0; t < NT3; ++t) {
+          float *o0 = out + (size_t)obj * m * k1N3 + t * 16 + j;
+          for (int c = g; c < m; c += 4) o0[(size_t)c * k1N3] = m0[t];
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < NT3; ++t) {
+          if (g == 0) oa[t * 16] = m0[t];
+          if (kind == kTaskPair && g == 1) ob[t * 16] = m1[t];
         }
       }
     }
