@@ -30,6 +30,7 @@ v python bench.py --no-cpu-baseline --objects 120 --points 2048 --llm-hidden 512
 v env MSR3D_TRAINABLE=strips python bench.py --no-cpu-baseline
 v env MSR3D_SA_MMA=f32 python bench.py --no-cpu-baseline
 v env MSR3D_SA_ROWS=0 python bench.py --no-cpu-baseline
+v env MSR3D_SA_MMA=split2 python bench.py --no-cpu-baseline
 v env MSR3D_WGRAD_MIXED=0 python bench.py --no-cpu-baseline
 v env MSR3D_SA3_TILE=2 python bench.py --no-cpu-baseline
 v env MSR3D_WGRAD_HALVES=1 python bench.py --no-cpu-baseline
