@@ -165,8 +165,9 @@ constexpr int lds_bytes() {
        : XS_BYTES;
 }
 
-// NW: waves per workgroup.  4 everywhere; 8 (two per SIMD) is an option of the attention forward block, whose phases
-// are short dependent chains that one wave per SIMD cannot overlap (MSR3D_ATTN_FWD_WAVES=8).
+// NW: waves per workgroup.  8 (two per SIMD: one wave alone issues at most 44 % of a SIMD's VALU rate,
+// profiles/r05_hw_probes.txt) for the attention forward and the feed-forward blocks -- each wave then owns half the
+// column tiles -- 4 for the rest; MSR3D_ATTN_FWD_WAVES=4 / MSR3D_FFN_WAVES=4 restore four.
 template <int KIND, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void scene_block_kernel(const SB p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(64 * NW) void scene_block_kernel(const SB p) {
   else if (KIND == MSR3D_BLK_LINEAR_KSPLIT)   // [K / 32 slabs][16 tiles]
     w1 = make_wstream(p.w1, p.w1_bytes, 16, KS1 * slice, 4 * wave, lane);
   else                                     // FFN: [8 slabs][ff / 16 tiles], this slice's 8 tiles
-    w1 = make_wstream(p.w1, p.w1_bytes, p.ff / 16, 0, 8 * slice + 2 * wave, lane);
+    w1 = make_wstream(p.w1, p.w1_bytes, p.ff / 16, 0, 8 * slice + (8 / NW) * wave, lane);
   SB_STAMP(0);
   WPiece ring1[RING];
   preload_wring<RN1, RING>(ring1, w1);
@@ -239,35 +240,37 @@ __global__ __launch_bounds__(64 * NW) void scene_block_kernel(const SB p) {
     // ------------------------------------------------------------------ feed-forward block
     constexpr bool FWD = KIND == MSR3D_BLK_FFN_FWD;
     const int ff = p.ff;
-    const int lc0 = 32 * wave + 4 * g;                 // + 16 rn: the lane's four middle columns inside the slice
+    // NW = 4: a wave owns 32 of the slice's 128 middle columns and 64 of product 2's 256; NW = 8: 16 and 32
+    constexpr int RN2 = 16 / NW, RING2 = RING;         // (product 2: 4 slabs x RN2 pieces >= RING)
+    const int lc0 = 16 * RN1 * wave + 4 * g;           // + 16 rn: the lane's four middle columns inside the slice
     const int hc0 = 128 * slice + lc0;
     // product 2's stream: [ff / 32 slabs][16 tiles], this slice's four slabs
-    const WStream w2 = make_wstream(p.w2, p.w2_bytes, 16, 4 * slice, 4 * wave, lane);
-    float4 pre_in[2][4];
+    const WStream w2 = make_wstream(p.w2, p.w2_bytes, 16, 4 * slice, RN2 * wave, lane);
+    float4 pre_in[RN1][4];
     if (!FWD) {                                        // gelu'(pre): fetched under product 1
 #pragma unroll
-      for (int rn = 0; rn < 2; ++rn)
+      for (int rn = 0; rn < RN1; ++rn)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
           pre_in[rn][mt] = ld4(p.pre + (size_t)(row_base + min(16 * mt + j, L - 1)) * ff + hc0 + 16 * rn);
     }
-    float4 bias[2];
+    float4 bias[RN1];
 #pragma unroll
-    for (int rn = 0; rn < 2; ++rn)
+    for (int rn = 0; rn < RN1; ++rn)
       bias[rn] = (FWD && p.bias1) ? ld4(p.bias1 + hc0 + 16 * rn) : make_float4(0.f, 0.f, 0.f, 0.f);
-    f32x4 acc[2][4];
+    f32x4 acc[RN1][4];
     zero_acc3(acc);
-    gemm_split3<true, 2, 4, KS1, RING>(xr, 0, w1, acc, ring1);
+    gemm_split3<true, RN1, 4, KS1, RING>(xr, 0, w1, acc, ring1);
     SB_STAMP(3);
-    WPiece ring2[RING];
-    preload_wring<4, RING>(ring2, w2);
+    WPiece ring2[RING2];
+    preload_wring<RN2, RING2>(ring2, w2);
     const bool drop = p.p_drop > 0.f;
     const unsigned thresh = drop_thresh(p.p_drop);
     const float dscale = drop ? 1.0f / (1.0f - p.p_drop) : 1.0f;
     const unsigned long long sd = drop ? *p.seed : 0ull;
     unsigned char *mid = aux;
 #pragma unroll
-    for (int rn = 0; rn < 2; ++rn) {
+    for (int rn = 0; rn < RN1; ++rn) {
       const float b4[4] = {bias[rn].x, bias[rn].y, bias[rn].z, bias[rn].w};
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
@@ -305,12 +308,12 @@ __global__ __launch_bounds__(64 * NW) void scene_block_kernel(const SB p) {
     SB_STAMP(4);
     __syncthreads();
     SB_STAMP(5);
-    f32x4 acc2[4][4];
+    f32x4 acc2[RN2][4];
     zero_acc3(acc2);
     const XFrag<4> xm{reinterpret_cast<const unsigned short *>(mid) + lane * 8};
-    gemm_split3<true, 4, 4, 4, RING>(xm, 0, w2, acc2, ring2);
+    gemm_split3<true, RN2, 4, 4, RING2>(xm, 0, w2, acc2, ring2);
     SB_STAMP(6);
-    store_partials<4>(acc2, slab, row_base, L, 64 * wave, lane);
+    store_partials<RN2>(acc2, slab, row_base, L, 16 * RN2 * wave, lane);
   } else if constexpr (KIND == MSR3D_BLK_ATTN_FWD) {
     // ------------------------------------------------------------------ attention block, forward
     const int h = slice, H = p.H, ldq = p.ldq;
@@ -628,6 +631,15 @@ int msr3d_scene_block(const msr3d_scene_block_t *pp, msr3d_stream_t stream) {
       if (p.ff <= 0 || p.ff % 128 || p.ff / 128 > 16 || !p.w2 || !p.pre || !p.h) return MSR3D_EINVAL;
       if (p.w1_bytes < (unsigned)(8 * (p.ff / 16)) * kPieceBytes || p.w2_bytes < (unsigned)((p.ff / 32) * 16) * kPieceBytes)
         return MSR3D_EINVAL;
+      {
+        // eight waves here too (round 5): -1.6 us a step over the six feed-forward blocks in three interleaved same-box
+        // pairs (0.9497 / 0.9502 / 0.9479 -> 0.9492 / 0.9484 / 0.9453 ms) -- the blocks wait on their weight pieces and
+        // planes, not on instruction issue; MSR3D_FFN_WAVES=4 restores four
+        static const bool eight = [] { const char *v = getenv("MSR3D_FFN_WAVES"); return !(v && v[0] == '4'); }();
+        if (eight)
+          return p.kind == MSR3D_BLK_FFN_FWD ? launch_block<MSR3D_BLK_FFN_FWD, 8>(p, p.ff / 128, s)
+                                             : launch_block<MSR3D_BLK_FFN_BWD, 8>(p, p.ff / 128, s);
+      }
       return p.kind == MSR3D_BLK_FFN_FWD ? launch_block<MSR3D_BLK_FFN_FWD>(p, p.ff / 128, s)
                                          : launch_block<MSR3D_BLK_FFN_BWD>(p, p.ff / 128, s);
     case MSR3D_BLK_ATTN_BWD:
