@@ -39,9 +39,11 @@ __global__ __launch_bounds__(256) void scene_prologue_kernel(
     unsigned char *__restrict__ valid_out, float *__restrict__ anchor_loc_out, float *__restrict__ anchor_ori_out) {
   __shared__ float cx[128], cy[128], cz[128];
   __shared__ float wmax[4];
-  // grid (B, 4): the four blocks of a sample each find the sample's largest distance (cheap, all
-  // pairs) and write a quarter of the pair features; block 0 also writes the per-token outputs
-  const int b = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+  // grid (B, parts): the blocks of a sample each find the sample's largest distance (cheap, all pairs; a maximum,
+  // so the same bits however it is split) and write their share of the pair features and of the Fourier features;
+  // block 0 also writes the per-token outputs.  parts = 16 (round 5; 4 before): the launch is 64 -> 256 workgroups and
+  // a thread's chain of accurate sinf / cosf calls -- the kernel's longest -- shrinks from four to one
+  const int b = blockIdx.x, part = blockIdx.y, parts = gridDim.y, tid = threadIdx.x;
   if (part == 0 && tid < 7) {          // the anchor pose, copied into the step's static buffers in the same launch
     if (tid < 3) { if (anchor_loc_out && anchor_loc) anchor_loc_out[b * 3 + tid] = anchor_loc[b * 3 + tid]; }
     else if (anchor_ori_out && anchor_ori) anchor_ori_out[b * 4 + tid - 3] = anchor_ori[b * 4 + tid - 3];
@@ -59,13 +61,14 @@ __global__ __launch_bounds__(256) void scene_prologue_kernel(
     }
   }
   __syncthreads();
-  // Fourier features of the (agent-frame) centres: the four blocks of a sample share the tokens,
-  // one (token, coordinate) pair per thread and pass
+  // Fourier features of the (agent-frame) centres: one (token, coordinate, frequency) per thread and pass over all the
+  // sample's blocks -- a thread's chain is one sinf + one cosf (accurate forms, ~100 instructions each), not the 20 it
+  // was with one (token, coordinate) per thread
   {
     const int W = 3 + 6 * nb;
     const float pi = 3.14159265358979323846f;
-    for (int e = part * 256 + tid; e < L * 3; e += 4 * 256) {
-      const int tok = e / 3, c = e - tok * 3;
+    for (int e = part * 256 + tid; e < L * 3 * nb; e += parts * 256) {
+      const int tok = e / (3 * nb), rem = e - tok * 3 * nb, c = rem / nb, k = rem - c * nb;
       float v[3] = {cx[tok], cy[tok], cz[tok]};
       if (transform) {
         const float *a = anchor_loc + (size_t)b * 3;
@@ -83,12 +86,10 @@ __global__ __launch_bounds__(256) void scene_prologue_kernel(
       }
       const float vc = c == 0 ? v[0] : c == 1 ? v[1] : v[2];
       float *o = ff + ((size_t)b * L + tok) * W;
-      o[c] = vc;
-      for (int k = 0; k < nb; ++k) {
-        const float s = pi * (vc * freqs[k]);
-        o[3 + c * nb + k] = sinf(s);
-        o[3 + 3 * nb + c * nb + k] = cosf(s);
-      }
+      if (k == 0) o[c] = vc;
+      const float s = pi * (vc * freqs[k]);
+      o[3 + c * nb + k] = sinf(s);
+      o[3 + 3 * nb + c * nb + k] = cosf(s);
     }
   }
   float m = 0.f;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void scene_prologue_kernel(
   __syncthreads();
   const float dmax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
   float *O = pw + (size_t)b * L * L * 5;
-  const int per = (L * L + 3) / 4, e1 = min(L * L, (part + 1) * per);
+  const int per = (L * L + parts - 1) / parts, e1 = min(L * L, (part + 1) * per);
   for (int e = part * per + tid; e < e1; e += 256) {
     const int l = e / L, t = e - l * L;
     const float dx = cx[l] - cx[t], dy = cy[l] - cy[t], dz = cz[l] - cz[t];
@@ -276,7 +277,7 @@ int msr3d_scene_prologue(int B, int L, const float *obj_locs, const unsigned cha
   if (!obj_locs || !obj_valid || !freqs || !pairwise_out || !fourier_out || !locs_out || !pad_out ||
       (transform && (!anchor_loc || !anchor_ori)))
     return MSR3D_EINVAL;
-  scene_prologue_kernel<<<dim3(B, 4), 256, 0, (hipStream_t)stream>>>(L, obj_locs, obj_valid, anchor_loc, anchor_ori,
+  scene_prologue_kernel<<<dim3(B, 16), 256, 0, (hipStream_t)stream>>>(L, obj_locs, obj_valid, anchor_loc, anchor_ori,
                                                            freqs, num_bands, transform, eps, pairwise_out,
                                                            fourier_out, locs_out, pad_out, valid_out, anchor_loc_out,
                                                            anchor_ori_out);

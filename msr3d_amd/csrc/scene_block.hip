@@ -532,6 +532,8 @@ __device__ __forceinline__ int map_index(const msr3d_pack_job_t *jb, int nseg, i
   return r;
 }
 
+constexpr int kPackPer = 1;        // pieces per wave (measured: 4, all 32 loads issued before the first split: 27.2 us against 24.3)
+
 // workgroups past `pack_wgs` (msr3d_split_pack_begin): the step's zero fill + dropout seed bump (= msr3d_step_begin)
 __global__ __launch_bounds__(256) void split_pack_kernel(int njobs, const msr3d_pack_job_t *__restrict__ jobs,
                                                          const int *__restrict__ prefix, int total, int pack_wgs,
@@ -542,38 +544,55 @@ __global__ __launch_bounds__(256) void split_pack_kernel(int njobs, const msr3d_
     for (long long t = zb * 256ll + threadIdx.x; t < n4; t += nz * 256ll) z[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
-  const int piece = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (piece >= total) return;
+  // A wave takes kPackPer consecutive pieces and issues all their loads before the first split.
+  const int piece0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kPackPer;
+  if (piece0 >= total) return;
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-  int lo = 0, hi = njobs - 1;                         // the job holding this piece
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (prefix[mid] <= piece) lo = mid; else hi = mid - 1;
-  }
-  const msr3d_pack_job_t *jb = jobs + lo;
-  const float *__restrict__ src = jb->src;
-  const int ld = jb->ld, nseg = jb->nseg;
-  const int local = piece - prefix[lo];
-  const int nt = jb->rows >> 4;
-  const int slab = local / nt, tile = local - slab * nt;
-  const int n = 16 * tile + j, k0 = 32 * slab + 8 * g;
-  float v[8];
-  if (!jb->transposed) {
-    const int r = map_index(jb, nseg, n);
+  float v[kPackPer][8];
+  unsigned short *dst[kPackPer];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = r >= 0 ? src[(size_t)r * ld + k0 + e] : 0.f;
-  } else {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int r = map_index(jb, nseg, k0 + e);
-      v[e] = r >= 0 ? src[(size_t)r * ld + n] : 0.f;
+  for (int u = 0; u < kPackPer; ++u) {
+    const int piece = piece0 + u;
+    dst[u] = nullptr;
+    if (piece >= total) continue;
+    // the job holding this piece = (number of prefix entries <= piece) - 1: one coalesced load of the table + a ballot
+    // per 64 jobs.  (Round 4's binary search was six DEPENDENT round trips to L2 in front of every wave's real loads:
+    // 27.9 -> 24.3 us a launch of ~22 k one-piece waves.)
+    int cnt = 0;
+    for (int base = 0; base < njobs; base += 64) {
+      const int q = base + lane;
+      const bool le = q < njobs && prefix[q] <= piece;
+      cnt += __popcll(__ballot(le));
     }
-  }
-  uint4 pl[3];
-  sm_split8(v, pl);
-  unsigned short *d = jb->dst + (size_t)local * (3 * 512) + lane * 8;
+    const int lo = __builtin_amdgcn_readfirstlane(cnt - 1);
+    const msr3d_pack_job_t *jb = jobs + lo;
+    const float *__restrict__ src = jb->src;
+    const int ld = jb->ld, nseg = jb->nseg;
+    const int local = piece - prefix[lo];
+    const int nt = jb->rows >> 4;
+    const int slab = local / nt, tile = local - slab * nt;
+    const int n = 16 * tile + j, k0 = 32 * slab + 8 * g;
+    if (!jb->transposed) {
+      const int r = map_index(jb, nseg, n);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) *reinterpret_cast<uint4 *>(d + k * 512) = pl[k];
+      for (int e = 0; e < 8; ++e) v[u][e] = r >= 0 ? src[(size_t)r * ld + k0 + e] : 0.f;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int r = map_index(jb, nseg, k0 + e);
+        v[u][e] = r >= 0 ? src[(size_t)r * ld + n] : 0.f;
+      }
+    }
+    dst[u] = jb->dst + (size_t)local * (3 * 512) + lane * 8;
+  }
+#pragma unroll
+  for (int u = 0; u < kPackPer; ++u) {
+    if (!dst[u]) continue;
+    uint4 pl[3];
+    sm_split8(v[u], pl);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<uint4 *>(dst[u] + k * 512) = pl[k];
+  }
 }
 
 }  // namespace
@@ -585,7 +604,7 @@ int msr3d_split_pack(int njobs, const msr3d_pack_job_t *jobs, const int *piece_p
   if (njobs < 0 || total_pieces < 0) return MSR3D_EINVAL;
   if (njobs == 0 || total_pieces == 0) return 0;
   if (!jobs || !piece_prefix) return MSR3D_EINVAL;
-  const int wgs = (total_pieces + 3) / 4;
+  const int wgs = (total_pieces + 4 * kPackPer - 1) / (4 * kPackPer);
   split_pack_kernel<<<wgs, 256, 0, (hipStream_t)stream>>>(njobs, jobs, piece_prefix, total_pieces, wgs, nullptr, 0, nullptr);
   return (int)hipGetLastError();
 }
@@ -595,7 +614,7 @@ int msr3d_split_pack_begin(int njobs, const msr3d_pack_job_t *jobs, const int *p
   if (njobs < 0 || total_pieces < 0 || n_floats < 0 || (n_floats % 4)) return MSR3D_EINVAL;
   if (njobs > 0 && total_pieces > 0 && (!jobs || !piece_prefix)) return MSR3D_EINVAL;
   if (n_floats > 0 && (!zero_region || (reinterpret_cast<uintptr_t>(zero_region) & 15u))) return MSR3D_EINVAL;
-  const int wgs = (njobs > 0) ? (total_pieces + 3) / 4 : 0;
+  const int wgs = (njobs > 0) ? (total_pieces + 4 * kPackPer - 1) / (4 * kPackPer) : 0;
   const long long n4 = n_floats / 4;
   long long zw = (n4 + 255) / 256;
   zw = zw > 512 ? 512 : zw;

@@ -10,7 +10,7 @@ __device__ unsigned long long g_sb_stamps[SB_MAXWAVES * SB_NSTAMP];
 #define SB_STAMP(i)                                                                                        \
   do {                                                                                                     \
     if ((threadIdx.x & 63) == 0) {                                                                         \
-      const unsigned w_ = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);                  \
+      const unsigned w_ = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);                 \
       if (w_ < SB_MAXWAVES) g_sb_stamps[w_ * SB_NSTAMP + (i)] = __builtin_readcyclecounter();              \
     }                                                                                                      \
   } while (0)

@@ -37,9 +37,17 @@ def launch_block(stream, **kw):
     assert lib.msr3d_prof_stamps(buf.ctypes.data, 1) == 0
     st = buf.reshape(MAXW, NST).astype(np.int64)
     st = st[st[:, 0] != 0]
-    t0 = st[:, 0].min()
     marks = [i for i in range(NST) if (st[:, i] != 0).all()]
-    line = f"{KIND[s.kind]:14s} waves {len(st):5d} span {st[:, marks].max() - t0:7d} | start spread {int(st[:, 0].max() - t0):6d} |"
+    # a workgroup's waves are consecutive rows; its span = last mark of its slowest wave - first mark of its earliest
+    # (one XCD, one counter: spans are comparable inside a workgroup only)
+    name = KIND[s.kind]
+    slices = 8 if name.startswith("attn") else int(s.ff) // 128 if name.startswith("ffn") else \
+        int(s.N) // 256 if name == "linear" else int(s.lda0) // 256
+    nblk = int(s.B) * slices
+    wpb = max(len(st) // max(nblk, 1), 1)
+    blk = st[:nblk * wpb].reshape(nblk, wpb, NST)
+    span = blk[:, :, marks[-1]].max(axis=1) - blk[:, :, 0].min(axis=1)
+    line = f"{KIND[s.kind]:14s} waves {len(st):5d} ({wpb}/wg) wg span {int(np.median(span)):6d}/{int(span.max()):6d} |"
     prev = 0
     for i in marks[1:]:
         d = st[:, i] - st[:, prev]
