@@ -858,6 +858,9 @@ def main():
                 names = {k: f"sa{k[-1]}_kernel (msr3d_sa_level, f32-input MFMA)" for k in names}
             d = levels[dom]
             traffic_per_obj, traffic_src = sa2_traffic_from_profiles(names[dom].split(" ")[0])
+            if traffic_per_obj and rows_on and dom in ("level1", "level2"):        # the level = its plan launch + its rows launch
+                plan_per_obj, _ = sa2_traffic_from_profiles(f"sa{dom[-1]}_plan_kernel")
+                traffic_per_obj += plan_per_obj or 0.0
             roof = {"bound": "mfma", "kernel": names[dom], "achieved": d["achieved_tflops"], "peak": peak, "unit": "TFLOP/s",
                     "frac": d["frac"], "nominal_tflops": d["nominal_tflops"],
                     "achieved_note": "FLOPs of the distinct neighbourhood rows (what the result needs; SURVEY.md 8(d)'s nominal "

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 24
+#define MSR3D_ABI_VERSION 25
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -480,8 +480,9 @@ int msr3d_sa_level2_rows(int b, int n, int m, float radius, const float *xyz, co
                          const float *new_xyz, const void *w1, const float *affine1, const void *w2,
                          const float *affine2, const void *w3, const float *affine3, float *out,
                          int *dbg_ball_idx, const unsigned char *valid, const unsigned char *constant,
-                         void *plan_ws, msr3d_stream_t stream);
-/* Bytes of plan_ws for b objects (device memory, 16-byte aligned, the caller's; contents need not survive the call's
+                         void *plan_ws, int planned, msr3d_stream_t stream);
+/* (planned != 0: plan_ws was filled by msr3d_sa_plan12 on this stream -- the call is then the products' launch alone.)
+ * Bytes of plan_ws for b objects (device memory, 16-byte aligned, the caller's; contents need not survive the call's
  * work on the stream).  Two launches: one wave per object runs its m ball queries and writes the list of its distinct
  * rows there; the multiplying workgroups deal the objects among themselves by work (a balanced static deal, the same
  * in every workgroup) and read each of their objects' lists one object ahead. */
@@ -496,8 +497,18 @@ size_t msr3d_sa_level2_rows_ws_bytes(int b);
 int msr3d_sa_level1_rows(int b, int n, int m, const float *pts, const float *new_xyz, const int *ball_idx,
                          const void *w1, const float *affine1, const void *w2, const float *affine2,
                          const void *w3, const float *affine3, float *out, const unsigned char *valid,
-                         const unsigned char *constant, void *task_ws, msr3d_stream_t stream);
+                         const unsigned char *constant, void *task_ws, int planned, msr3d_stream_t stream);
 size_t msr3d_sa_level1_rows_ws_bytes(int b, int m);
+
+/* The planning launches of msr3d_sa_level1_rows and msr3d_sa_level2_rows as ONE launch: both read only what the sampling
+ * launch wrote (level 1: ball_idx1 (b, m1, 32); level 2: its points xyz2 (b, n2, 3) = level 1's centres and its centres
+ * new_xyz2 (b, m2, 3)), and a dependent launch costs ~5 us on this part before it does anything.  Arguments as the two
+ * calls take them (radius2: level 2's radius; out2: level 2's output, whose rows of multi-chunk objects are zeroed here);
+ * afterwards call both with planned = 1 on the same stream, level 1 first.  MSR3D_EINVAL for a planned = 1 call without
+ * a plan; a plan that is never consumed is discarded by the next call. */
+int msr3d_sa_plan12(int b, int m1, const int *ball_idx1, void *task_ws1, int n2, int m2, float radius2,
+                    const float *xyz2, const float *new_xyz2, float *out2, int *dbg_ball_idx2, void *plan_ws2,
+                    const unsigned char *valid, const unsigned char *constant, msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * The trainable part as a fixed schedule of fused launches (msr3d_amd/fused_model.py):

@@ -149,9 +149,10 @@ _SIGNATURES = {
     "msr3d_attn_bwd": [_c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _c_float, _ptr, _ptr,
                        _ptr, _ptr, _ptr, _ptr],
     "msr3d_sa_level_split": [_c_int, _c_int, _c_int, _c_int, _c_float] + [_ptr] * 13,
-    "msr3d_sa_level2_rows": [_c_int, _c_int, _c_int, _c_float] + [_ptr] * 15,
+    "msr3d_sa_level2_rows": [_c_int, _c_int, _c_int, _c_float] + [_ptr] * 14 + [_c_int, _ptr],
     "msr3d_sa_level2_rows_ws_bytes": [_c_int],
-    "msr3d_sa_level1_rows": [_c_int, _c_int, _c_int] + [_ptr] * 14,
+    "msr3d_sa_level1_rows": [_c_int, _c_int, _c_int] + [_ptr] * 13 + [_c_int, _ptr],
+    "msr3d_sa_plan12": [_c_int, _c_int, _ptr, _ptr, _c_int, _c_int, _c_float] + [_ptr] * 8,
     "msr3d_sa_level1_rows_ws_bytes": [_c_int, _c_int],
     "msr3d_seq_ce_fwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "msr3d_seq_ce_bwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
@@ -240,7 +241,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string", "msr3d_sqdist_contract"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 24        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 25        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():
@@ -275,7 +276,7 @@ def load():
 
 _lib_split2 = None
 _SPLIT2_ENTRIES = ("msr3d_sa_level_split", "msr3d_sa_level1_rows", "msr3d_sa_level2_rows", "msr3d_sa_level1_rows_ws_bytes",
-                   "msr3d_sa_level2_rows_ws_bytes")
+                   "msr3d_sa_level2_rows_ws_bytes", "msr3d_sa_plan12")
 
 
 def load_split2():

@@ -687,15 +687,27 @@ constexpr int kPlanBytes = 32 + kPlanRows * 2;
 // One wave per object, ALL of its m <= 16 ball queries at once (ball_query_gpu.cu:9-44: index order, strict '<', first-hit
 // fill, zeros when empty): lane 4 c + q tests its quarter of the n <= 64 points against centre c, the quad ORs the four
 // partial hit masks, and slot s of the centre's row is the s-th set bit of the mask (or the first hit past the last one).
-__global__ __launch_bounds__(256) void sa2_plan_kernel(int b, int n, int m, float radius2, const float *__restrict__ xyz,
-                                                       const float *__restrict__ new_xyz, int *__restrict__ rows_of,
-                                                       unsigned char *__restrict__ plan,
-                                                       int *__restrict__ dbg_idx, const unsigned char *__restrict__ valid,
-                                                       const unsigned char *__restrict__ constant, float *__restrict__ out) {
+struct Sa2PlanArgs {
+  int b, n, m;
+  float radius2;
+  const float *xyz, *new_xyz;
+  int *rows_of;
+  unsigned char *plan;
+  int *dbg_idx;
+  const unsigned char *valid, *constant;
+  float *out;
+};
+
+// (`blk`: the workgroup's index among the level-2 planners -- blockIdx.x of sa2_plan_kernel, an offset one in sa12_plan_kernel)
+__device__ __forceinline__ void sa2_plan_body(const int blk, const int b, const int n, const int m, const float radius2,
+                                              const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                              int *__restrict__ rows_of, unsigned char *__restrict__ plan,
+                                              int *__restrict__ dbg_idx, const unsigned char *__restrict__ valid,
+                                              const unsigned char *__restrict__ constant, float *__restrict__ out) {
   __shared__ float s_x[4][64 * 3];
   __shared__ int s_f[4][kRowsMaxM];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int obj = blockIdx.x * 4 + wave;
+  const int obj = blk * 4 + wave;
   if (obj >= b) return;                                  // (no block barrier below: every wave is on its own)
   int *hdr = reinterpret_cast<int *>(plan + (size_t)obj * kPlanBytes);
   unsigned short *list = reinterpret_cast<unsigned short *>(plan + (size_t)obj * kPlanBytes + 32);
@@ -775,6 +787,10 @@ __global__ __launch_bounds__(256) void sa2_plan_kernel(int b, int n, int m, floa
     float4 *o = reinterpret_cast<float4 *>(out + (size_t)obj * m * kN3);
     for (int i = lane; i < m * kN3 / 4; i += kWave) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+}
+
+__global__ __launch_bounds__(256) void sa2_plan_kernel(const Sa2PlanArgs a) {
+  sa2_plan_body(blockIdx.x, a.b, a.n, a.m, a.radius2, a.xyz, a.new_xyz, a.rows_of, a.plan, a.dbg_idx, a.valid, a.constant, a.out);
 }
 
 template <int V> struct IntTag { static constexpr int value = V; };
@@ -1664,13 +1680,13 @@ __global__ __launch_bounds__(64 * k1Waves, 1) void sa1_split_kernel(int n, int m
 // =====================================================================================================
 constexpr int kTaskBig = 0, kTaskPair = 1, kTaskConst = 2;      // header: kind | obj << 2 | cA << 20 | cB << 26
 
-__global__ __launch_bounds__(256) void sa1_plan_kernel(int b, int m, const int *__restrict__ ball_idx, int *__restrict__ total,
-                                                       int *__restrict__ thdr, int *__restrict__ trow,
-                                                       const unsigned char *__restrict__ valid,
-                                                       const unsigned char *__restrict__ constant) {
+__device__ __forceinline__ void sa1_plan_body(const int blk, const int b, const int m, const int *__restrict__ ball_idx,
+                                              int *__restrict__ total, int *__restrict__ thdr, int *__restrict__ trow,
+                                              const unsigned char *__restrict__ valid,
+                                              const unsigned char *__restrict__ constant) {
   __shared__ int s_n[4], s_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int obj = blockIdx.x * 4 + wave;
+  const int obj = blk * 4 + wave;
   const bool live = obj < b && !(valid && !valid[obj]);
   const bool is_const = live && constant && constant[obj];
   const int *row = ball_idx + ((size_t)(live ? obj : 0) * m + (lane < m ? lane : 0)) * kNS;
@@ -1714,6 +1730,28 @@ __global__ __launch_bounds__(256) void sa1_plan_kernel(int b, int m, const int *
         for (int q = 0; q < 4; ++q) d[4 + q] = src[q];
     }
   }
+}
+
+struct Sa1PlanArgs {
+  int b, m;
+  const int *ball_idx;
+  int *total, *thdr, *trow;
+  const unsigned char *valid, *constant;
+};
+
+__global__ __launch_bounds__(256) void sa1_plan_kernel(const Sa1PlanArgs a) {
+  sa1_plan_body(blockIdx.x, a.b, a.m, a.ball_idx, a.total, a.thdr, a.trow, a.valid, a.constant);
+}
+
+// Both planners in ONE launch (msr3d_sa_plan12): each needs only what the sampling launch wrote -- level 1 the ball
+// rows, level 2 the two sets of centres -- and a launch on this part costs ~5 us before it does anything; workgroups
+// [0, nb1) plan level 1, the rest level 2.
+__global__ __launch_bounds__(256) void sa12_plan_kernel(const Sa1PlanArgs a1, const Sa2PlanArgs a2, const int nb1) {
+  if ((int)blockIdx.x < nb1)
+    sa1_plan_body(blockIdx.x, a1.b, a1.m, a1.ball_idx, a1.total, a1.thdr, a1.trow, a1.valid, a1.constant);
+  else
+    sa2_plan_body(blockIdx.x - nb1, a2.b, a2.n, a2.m, a2.radius2, a2.xyz, a2.new_xyz, a2.rows_of, a2.plan, a2.dbg_idx, a2.valid,
+                  a2.constant, a2.out);
 }
 
 __global__ __launch_bounds__(64 * k1Waves, 1) void sa1_rows_kernel(int n, int m, int *__restrict__ queue,
@@ -1911,7 +1949,11 @@ inline int usable_cus() {
 // device in the key.)  Cleared in stream order on first use and again whenever the previous launch through
 // the queue did not report success -- a launch that never ran to its last block would otherwise leave the
 // counters non-zero and every later launch would silently skip tiles.
-struct WorkQueue { int *q = nullptr; bool suspect = true; };
+struct WorkQueue {
+  int *q = nullptr;
+  bool suspect = true;
+  bool planned = false;             // msr3d_sa_plan12 appended a task list that no msr3d_sa_level1_rows has consumed yet
+};
 inline WorkQueue *work_queue(hipStream_t st, int level, hipError_t *err) {
   static std::mutex mu;
   static std::map<std::tuple<int, hipStream_t, int>, WorkQueue> queues;
@@ -2002,22 +2044,38 @@ extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius
 inline size_t plan_costs_bytes(int b) { return ((size_t)b * sizeof(int) + 15) & ~(size_t)15; }
 extern "C" size_t msr3d_sa_level2_rows_ws_bytes(int b) { return b > 0 ? plan_costs_bytes(b) + (size_t)b * kPlanBytes : 0; }
 
+static bool sa2_plan_args(int b, int n, int m, float radius, const float *xyz, const float *new_xyz, float *out,
+                          int *dbg_ball_idx, const unsigned char *valid, const unsigned char *constant, void *plan_ws,
+                          Sa2PlanArgs *a) {
+  if (!out || !xyz || !new_xyz || !plan_ws) return false;
+  if (n <= 0 || n > 64 || m <= 0 || m > kRowsMaxM || (reinterpret_cast<uintptr_t>(plan_ws) & 15u)) return false;
+  a->b = b; a->n = n; a->m = m;
+  a->radius2 = radius * radius;       // f32 product, as ball_query_gpu.cu:22
+  a->xyz = xyz; a->new_xyz = new_xyz;
+  a->rows_of = reinterpret_cast<int *>(plan_ws);
+  a->plan = reinterpret_cast<unsigned char *>(plan_ws) + plan_costs_bytes(b);
+  a->dbg_idx = dbg_ball_idx; a->valid = valid; a->constant = constant; a->out = out;
+  return true;
+}
+
 extern "C" int msr3d_sa_level2_rows(int b, int n, int m, float radius, const float *xyz, const float *feat,
                                     const float *new_xyz, const void *w1, const float *affine1, const void *w2,
                                     const float *affine2, const void *w3, const float *affine3, float *out,
                                     int *dbg_ball_idx, const unsigned char *valid, const unsigned char *constant,
-                                    void *plan_ws, msr3d_stream_t stream) {
+                                    void *plan_ws, int planned, msr3d_stream_t stream) {
   if (b < 0) return MSR3D_EINVAL;
   if (b == 0) return 0;
-  if (!w1 || !w2 || !w3 || !affine1 || !affine2 || !affine3 || !out || !xyz || !feat || !new_xyz || !plan_ws) return MSR3D_EINVAL;
-  if (n <= 0 || n > 64 || m <= 0 || m > kRowsMaxM || (reinterpret_cast<uintptr_t>(plan_ws) & 15u)) return MSR3D_EINVAL;
+  if (!w1 || !w2 || !w3 || !affine1 || !affine2 || !affine3 || !feat) return MSR3D_EINVAL;
+  Sa2PlanArgs pa;
+  if (!sa2_plan_args(b, n, m, radius, xyz, new_xyz, out, dbg_ball_idx, valid, constant, plan_ws, &pa)) return MSR3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   hipError_t e;
-  const float r2 = radius * radius;   // f32 product, as ball_query_gpu.cu:22
-  int *rows_of = reinterpret_cast<int *>(plan_ws);
-  unsigned char *plan = reinterpret_cast<unsigned char *>(plan_ws) + plan_costs_bytes(b);
-  sa2_plan_kernel<<<(b + 3) / 4, 256, 0, st>>>(b, n, m, r2, xyz, new_xyz, rows_of, plan, dbg_ball_idx, valid, constant, out);
-  if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+  int *rows_of = pa.rows_of;
+  unsigned char *plan = pa.plan;
+  if (!planned) {                     // (planned: msr3d_sa_plan12 wrote plan_ws on this stream)
+    sa2_plan_kernel<<<(b + 3) / 4, 256, 0, st>>>(pa);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+  }
   if ((e = allow_lds(sa2_rows_kernel, kSa2RowsLds)) != hipSuccess) return (int)e;
   static const int per_cu = [] { const char *v = getenv("MSR3D_SA2_ROWS_BLOCKS"); return v ? atoi(v) : 2; }();
   const int slots = per_cu * usable_cus();
@@ -2033,22 +2091,66 @@ extern "C" size_t msr3d_sa_level1_rows_ws_bytes(int b, int m) {
   return (b > 0 && m > 0) ? (size_t)b * m * (sizeof(int) + kNS * sizeof(int)) + 16 : 0;
 }
 
-extern "C" int msr3d_sa_level1_rows(int b, int n, int m, const float *pts, const float *new_xyz, const int *ball_idx,
-                                    const void *w1, const float *affine1, const void *w2, const float *affine2,
-                                    const void *w3, const float *affine3, float *out, const unsigned char *valid,
-                                    const unsigned char *constant, void *task_ws, msr3d_stream_t stream) {
+static bool sa1_plan_args(int b, int m, const int *ball_idx, const unsigned char *valid, const unsigned char *constant,
+                          void *task_ws, WorkQueue *wq, Sa1PlanArgs *a) {
+  if (!ball_idx || !task_ws || m <= 0 || m > 64 || b >= (1 << 18) || (reinterpret_cast<uintptr_t>(task_ws) & 15u)) return false;
+  a->b = b; a->m = m; a->ball_idx = ball_idx;
+  a->total = wq->q + 2;
+  a->trow = reinterpret_cast<int *>(task_ws);                            // [b m][32], 16-byte aligned rows
+  a->thdr = a->trow + (size_t)b * m * kNS;
+  a->valid = valid; a->constant = constant;
+  return true;
+}
+
+// The level-1 task list and the level-2 row lists of one batch in ONE launch, for a caller that then passes planned = 1
+// to msr3d_sa_level1_rows / msr3d_sa_level2_rows on the same stream (same arguments as those take).
+extern "C" int msr3d_sa_plan12(int b, int m1, const int *ball_idx1, void *task_ws1, int n2, int m2, float radius2,
+                               const float *xyz2, const float *new_xyz2, float *out2, int *dbg_ball_idx2, void *plan_ws2,
+                               const unsigned char *valid, const unsigned char *constant, msr3d_stream_t stream) {
   if (b < 0) return MSR3D_EINVAL;
   if (b == 0) return 0;
-  if (!w1 || !w2 || !w3 || !affine1 || !affine2 || !affine3 || !out || !pts || !new_xyz || !ball_idx || !task_ws) return MSR3D_EINVAL;
-  if (n <= 0 || m <= 0 || m > 64 || b >= (1 << 18) || (reinterpret_cast<uintptr_t>(task_ws) & 15u)) return MSR3D_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   hipError_t e;
   WorkQueue *wq = work_queue(st, 5, &e);
   if (!wq) return (int)e;
-  int *trow = reinterpret_cast<int *>(task_ws);                         // [b m][32], 16-byte aligned rows
-  int *thdr = trow + (size_t)b * m * kNS;
-  sa1_plan_kernel<<<(b + 3) / 4, 256, 0, st>>>(b, m, ball_idx, wq->q + 2, thdr, trow, valid, constant);
+  Sa1PlanArgs a1;
+  Sa2PlanArgs a2;
+  if (!sa1_plan_args(b, m1, ball_idx1, valid, constant, task_ws1, wq, &a1)) return MSR3D_EINVAL;
+  if (!sa2_plan_args(b, n2, m2, radius2, xyz2, new_xyz2, out2, dbg_ball_idx2, valid, constant, plan_ws2, &a2)) return MSR3D_EINVAL;
+  if (wq->planned) {                  // a plan nobody consumed: its task count is still in the queue
+    if ((e = hipMemsetAsync(wq->q, 0, 4 * sizeof(int), st)) != hipSuccess) return (int)e;
+    wq->planned = false;
+  }
+  const int nb = (b + 3) / 4;
+  sa12_plan_kernel<<<2 * nb, 256, 0, st>>>(a1, a2, nb);
   if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+  wq->suspect = false;
+  wq->planned = true;
+  return 0;
+}
+
+extern "C" int msr3d_sa_level1_rows(int b, int n, int m, const float *pts, const float *new_xyz, const int *ball_idx,
+                                    const void *w1, const float *affine1, const void *w2, const float *affine2,
+                                    const void *w3, const float *affine3, float *out, const unsigned char *valid,
+                                    const unsigned char *constant, void *task_ws, int planned, msr3d_stream_t stream) {
+  if (b < 0) return MSR3D_EINVAL;
+  if (b == 0) return 0;
+  if (!w1 || !w2 || !w3 || !affine1 || !affine2 || !affine3 || !out || !pts || !new_xyz || n <= 0) return MSR3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e;
+  WorkQueue *wq = work_queue(st, 5, &e);
+  if (!wq) return (int)e;
+  Sa1PlanArgs pa;
+  if (!sa1_plan_args(b, m, ball_idx, valid, constant, task_ws, wq, &pa)) return MSR3D_EINVAL;
+  int *trow = pa.trow, *thdr = pa.thdr;
+  if (planned) {                      // msr3d_sa_plan12 appended the tasks on this stream
+    if (!wq->planned) return MSR3D_EINVAL;
+  } else {
+    if (wq->planned && (e = hipMemsetAsync(wq->q, 0, 4 * sizeof(int), st)) != hipSuccess) return (int)e;   // (a stale plan)
+    sa1_plan_kernel<<<(b + 3) / 4, 256, 0, st>>>(pa);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+  }
+  wq->planned = false;
   if ((e = allow_lds(sa1_rows_kernel, kSa1Lds)) != hipSuccess) return (int)e;
   const int cus = usable_cus();
   const long long max_rounds = ((long long)b * m + k1Waves - 1) / k1Waves;

@@ -195,6 +195,8 @@ if _sa_mma[0] not in ("f32", "split", "split2"):
 # found instead of all nsample (the rest are copies of the first hit; max is idempotent: same bits).
 # MSR3D_SA_ROWS=0 or set_sa_rows(False): the all-rows kernels of rounds 2-4.
 _sa_rows = [_os.environ.get("MSR3D_SA_ROWS", "1") != "0"]
+# the planning launches of levels 1 and 2 as one (msr3d_sa_plan12); MSR3D_SA_PLAN12=0: each level plans in its own call
+_PLAN12 = _os.environ.get("MSR3D_SA_PLAN12", "1") != "0"
 
 
 def set_sa_rows(on):
@@ -274,16 +276,26 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
         if queried:
             r1 = 0.0                                            # level 1: ball1 already holds the neighbour lists
         L = plan["levels"]
+        rows1 = split and _sa_rows[0] and m1 <= 64 and b < (1 << 18)
+        rows2 = split and _sa_rows[0] and m1 <= 64 and m2 <= 16
+        planned = 1 if (rows1 and rows2 and _PLAN12) else 0
         with _lib.kernel_timer("msr3d_sa_level1"):
-            if split and _sa_rows[0] and m1 <= 64 and b < (1 << 18):
+            if rows1:
                 S = plan["split1"]
                 if r1 > 0.0:                                    # (not queried beside the sampling: the query's own launch)
                     _lib.check(lib.msr3d_ball_query(b, n, m1, ctypes.c_float(r1), _NSAMPLE, _p(new1), _p(pts[..., :3].contiguous()),
                                                     _p(ball1), st), "msr3d_ball_query")
                 ws1 = torch.empty((int(slib.msr3d_sa_level1_rows_ws_bytes(b, m1)),), dtype=torch.uint8, device=dev)
+                if planned:
+                    # both levels' planning launches as one (each reads only what the sampling launch wrote); timed with
+                    # level 1 -- level 2's timer then holds its products' launch alone
+                    ws2 = torch.empty((int(slib.msr3d_sa_level2_rows_ws_bytes(b)),), dtype=torch.uint8, device=dev)
+                    _lib.check(slib.msr3d_sa_plan12(b, m1, _p(ball1), _p(ws1), m1, m2, ctypes.c_float(sa2.groupers[0].radius),
+                                                    _p(new1), _p(new2), _p(feat2), _p(dbg.get("ball2")), _p(ws2), _p(vmask),
+                                                    _p(constant), st), "msr3d_sa_plan12")
                 rc = slib.msr3d_sa_level1_rows(b, n, m1, _p(pts), _p(new1), _p(ball1), _p(S[0][0]), _p(S[0][1]), _p(S[1][0]),
                                               _p(S[1][1]), _p(S[2][0]), _p(S[2][1]), _p(feat1), _p(vmask), _p(constant),
-                                              _p(ws1), st)
+                                              _p(ws1), planned, st)
             elif split:
                 S = plan["split1"]
                 rc = slib.msr3d_sa_level_split(1, b, n, m1, ctypes.c_float(r1), _p(pts), _p(None),
@@ -295,13 +307,13 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
                                         _p(L[0][2]), _p(feat1), _p(ball1), _p(vmask), st)
         _lib.check(rc, "msr3d_sa_level(1)")
         with _lib.kernel_timer("msr3d_sa_level2"):
-            if split and _sa_rows[0] and m1 <= 64 and m2 <= 16:
+            if rows2:
                 S = plan["split2"]
-                ws = torch.empty((int(slib.msr3d_sa_level2_rows_ws_bytes(b)),), dtype=torch.uint8, device=dev)
+                ws = ws2 if planned else torch.empty((int(slib.msr3d_sa_level2_rows_ws_bytes(b)),), dtype=torch.uint8, device=dev)
                 rc = slib.msr3d_sa_level2_rows(b, m1, m2, ctypes.c_float(sa2.groupers[0].radius), _p(new1),
                                               _p(feat1), _p(new2), _p(S[0][0]), _p(S[0][1]), _p(S[1][0]),
                                               _p(S[1][1]), _p(S[2][0]), _p(S[2][1]), _p(feat2),
-                                              _p(dbg.get("ball2")), _p(vmask), _p(constant), _p(ws), st)
+                                              _p(dbg.get("ball2")), _p(vmask), _p(constant), _p(ws), planned, st)
             elif split:
                 S = plan["split2"]
                 rc = slib.msr3d_sa_level_split(2, b, m1, m2, ctypes.c_float(sa2.groupers[0].radius), _p(new1),

@@ -106,7 +106,7 @@ def _level2_direct(net, xyz, feat, new_xyz, radius, rows, constant=None):
         ws = torch.empty((int(lib.msr3d_sa_level2_rows_ws_bytes(b)),), dtype=torch.uint8, device="cuda")
         rc = lib.msr3d_sa_level2_rows(b, n, m, ctypes.c_float(radius), p(xyz), p(feat), p(new_xyz), p(S[0][0]), p(S[0][1]),
                                       p(S[1][0]), p(S[1][1]), p(S[2][0]), p(S[2][1]), p(out), p(ball), p(None), p(constant),
-                                      p(ws), st)
+                                      p(ws), 0, st)
     else:
         rc = lib.msr3d_sa_level_split(2, b, n, m, ctypes.c_float(radius), p(xyz), p(feat), p(new_xyz), p(S[0][0]), p(S[0][1]),
                                       p(S[1][0]), p(S[1][1]), p(S[2][0]), p(S[2][1]), p(out), p(ball), p(None), st)
@@ -201,3 +201,47 @@ def test_level2_rows_refuses_shapes_it_does_not_take():
         _level2_direct(net, xyz, feat, torch.rand(1, 17, 3).cuda(), 0.4, rows=True)      # m > 16
     with pytest.raises(RuntimeError):
         _level2_direct(net, torch.rand(1, 65, 3).cuda(), torch.randn(1, 65, 128).cuda(), torch.rand(1, 4, 3).cuda(), 0.4, rows=True)
+
+
+def test_one_planning_launch_for_both_levels_is_the_two_planning_launches():
+    """msr3d_sa_plan12 (default) against each level planning in its own call: same bits, debug lists included."""
+    from msr3d_amd.pointnet2 import fused
+    from msr3d_amd.synth import synth_batch
+    net = _net(4)
+    pts = synth_batch(77, 3, device="cuda")["obj_fts"].reshape(-1, 1024, 6).contiguous()
+    outs = {}
+    for merged in (False, True):
+        prev, fused._PLAN12 = fused._PLAN12, merged
+        try:
+            with torch.no_grad():
+                outs[merged] = fused.forward(net, pts, return_internals=True)
+        finally:
+            fused._PLAN12 = prev
+    _same(outs[False], outs[True])
+
+
+def test_planned_call_without_a_plan_is_refused():
+    from msr3d_amd import _lib
+    from msr3d_amd.pointnet2 import fused
+    net = _net(6)
+    S = fused.get_plan(net)["split2"]
+    lib = _lib.load()
+    b, n, m = 2, 32, 16
+    xyz, feat, ctr = torch.rand(b, n, 3).cuda(), torch.randn(b, n, 128).cuda(), torch.rand(b, m, 3).cuda()
+    out = torch.empty(b, m, 256, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+    S1 = fused.get_plan(net)["split1"]
+    pts = torch.rand(b, 64, 6).cuda()
+    ball = torch.zeros(b, n, 32, dtype=torch.int32, device="cuda")
+    out1 = torch.empty(b, n, 128, device="cuda")
+    ws1 = torch.empty((int(lib.msr3d_sa_level1_rows_ws_bytes(b, n)),), dtype=torch.uint8, device="cuda")
+    st = _lib.current_stream_ptr(xyz.device)
+    # a fresh stream has no plan: planned = 1 must not run on whatever the workspace holds
+    s2 = torch.cuda.Stream()
+    with torch.cuda.stream(s2):
+        rc = lib.msr3d_sa_level1_rows(b, 64, n, p(pts), p(xyz), p(ball), p(S1[0][0]), p(S1[0][1]), p(S1[1][0]), p(S1[1][1]),
+                                      p(S1[2][0]), p(S1[2][1]), p(out1), p(None), p(None), p(ws1), 1,
+                                      _lib.current_stream_ptr(xyz.device))
+    assert rc == -22
+    torch.cuda.synchronize()
+    del st, S, feat, ctr, out

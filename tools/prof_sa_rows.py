@@ -43,13 +43,13 @@ p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 lib = ctypes.CDLL(so)
 fn = lib.msr3d_sa_level2_rows
-fn.argtypes = [ctypes.c_int] * 3 + [ctypes.c_float] + [ctypes.c_void_p] * 15
+fn.argtypes = [ctypes.c_int] * 3 + [ctypes.c_float] + [ctypes.c_void_p] * 14 + [ctypes.c_int, ctypes.c_void_p]
 fn.restype = ctypes.c_int
 
 
 def call():
     rc = fn(b, 32, 16, ctypes.c_float(0.4), p(new1), p(feat1), p(new2), p(S[0][0]), p(S[0][1]), p(S[1][0]), p(S[1][1]),
-            p(S[2][0]), p(S[2][1]), p(out), p(None), p(None), p(const), p(ws), st)
+            p(S[2][0]), p(S[2][1]), p(out), p(None), p(None), p(const), p(ws), 0, st)
     assert rc == 0, rc
 
 
@@ -93,7 +93,7 @@ for i in sorted(tot):
 
 # ---- level 1 (sa1_rows_kernel): marks 0 round top, 1 after layer 1, 2 point rows issued, 3 after layer 3, 4 after the maxima, 5 chunk barrier
 fn1 = lib.msr3d_sa_level1_rows
-fn1.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 14
+fn1.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 13 + [ctypes.c_int, ctypes.c_void_p]
 fn1.restype = ctypes.c_int
 S1 = fused.get_plan(net)["split1"]
 ball1, feat1_ref = dbg["ball1"], dbg["feat1"]
@@ -103,7 +103,7 @@ ws1 = torch.empty(b * 32 * 132 + 64, dtype=torch.uint8, device="cuda")
 
 def call1():
     rc = fn1(b, 1024, 32, p(pts), p(new1), p(ball1), p(S1[0][0]), p(S1[0][1]), p(S1[1][0]), p(S1[1][1]), p(S1[2][0]), p(S1[2][1]),
-             p(out1), p(None), p(const), p(ws1), st)
+             p(out1), p(None), p(const), p(ws1), 0, st)
     assert rc == 0, rc
 
 
