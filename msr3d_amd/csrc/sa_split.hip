@@ -1451,6 +1451,11 @@ constexpr int k1K0 = 32, k1N1 = 64, k1N2 = 64, k1N3 = 128;
 constexpr int k1W1 = (k1K0 / 32) * (k1N1 / 16) * 3 * kFragS, k1W2 = (k1N1 / 32) * (k1N2 / 16) * 3 * kFragS,
               k1W3 = (k1N2 / 32) * (k1N3 / 16) * 3 * kFragS;             // bf16 counts: 6144, 12288, 24576
 constexpr int k1Waves = 8;
+#ifndef MSR3D_SA1_ROWS_WAVES
+#define MSR3D_SA1_ROWS_WAVES 8
+#endif
+constexpr int k1RowsWaves = MSR3D_SA1_ROWS_WAVES;     // waves per workgroup of sa1_rows_kernel (226 registers a lane: 12 waves
+                                                      // = 3 per SIMD spill 59 of them, 103 us against 88; 16 spill 119)
 constexpr int k1Chunk = 3;                   // rounds per queue fetch (15 per block at the bench shape)
 constexpr int kSa1Lds = (k1W1 + k1W2 + k1W3) * 2 + 2 * (k1N1 + k1N2 + k1N3) * 4;
 
@@ -1754,7 +1759,7 @@ __global__ __launch_bounds__(256) void sa12_plan_kernel(const Sa1PlanArgs a1, co
                   a2.constant, a2.out);
 }
 
-__global__ __launch_bounds__(64 * k1Waves, 1) void sa1_rows_kernel(int n, int m, int *__restrict__ queue,
+__global__ __launch_bounds__(64 * k1RowsWaves, 1) void sa1_rows_kernel(int n, int m, int *__restrict__ queue,
                                                                   const float *__restrict__ pts,
                                                                   const float *__restrict__ new_xyz,
                                                                   const int *__restrict__ thdr, const int *__restrict__ trow,
@@ -1783,12 +1788,12 @@ __global__ __launch_bounds__(64 * k1Waves, 1) void sa1_rows_kernel(int n, int m,
     const uint4 *s1 = reinterpret_cast<const uint4 *>(l1.w), *s2 = reinterpret_cast<const uint4 *>(l2.w),
                 *s3 = reinterpret_cast<const uint4 *>(l3.w);
     uint4 *d = reinterpret_cast<uint4 *>(smem);
-    for (int i = tid; i < k1W1 / 8; i += 64 * k1Waves) d[i] = s1[i];
-    for (int i = tid; i < k1W2 / 8; i += 64 * k1Waves) d[k1W1 / 8 + i] = s2[i];
-    for (int i = tid; i < k1W3 / 8; i += 64 * k1Waves) d[(k1W1 + k1W2) / 8 + i] = s3[i];
-    for (int i = tid; i < k1N1; i += 64 * k1Waves) { aff[i] = l1.scale[i]; aff[k1N1 + i] = l1.shift[i]; }
-    for (int i = tid; i < k1N2; i += 64 * k1Waves) { aff[2 * k1N1 + i] = l2.scale[i]; aff[2 * k1N1 + k1N2 + i] = l2.shift[i]; }
-    for (int i = tid; i < k1N3; i += 64 * k1Waves) { aff[2 * (k1N1 + k1N2) + i] = l3.scale[i]; aff[2 * (k1N1 + k1N2) + k1N3 + i] = l3.shift[i]; }
+    for (int i = tid; i < k1W1 / 8; i += 64 * k1RowsWaves) d[i] = s1[i];
+    for (int i = tid; i < k1W2 / 8; i += 64 * k1RowsWaves) d[k1W1 / 8 + i] = s2[i];
+    for (int i = tid; i < k1W3 / 8; i += 64 * k1RowsWaves) d[(k1W1 + k1W2) / 8 + i] = s3[i];
+    for (int i = tid; i < k1N1; i += 64 * k1RowsWaves) { aff[i] = l1.scale[i]; aff[k1N1 + i] = l1.shift[i]; }
+    for (int i = tid; i < k1N2; i += 64 * k1RowsWaves) { aff[2 * k1N1 + i] = l2.scale[i]; aff[2 * k1N1 + k1N2 + i] = l2.shift[i]; }
+    for (int i = tid; i < k1N3; i += 64 * k1RowsWaves) { aff[2 * (k1N1 + k1N2) + i] = l3.scale[i]; aff[2 * (k1N1 + k1N2) + k1N3 + i] = l3.shift[i]; }
   }
   const float *sc1 = aff, *sh1 = aff + k1N1, *sc2 = aff + 2 * k1N1, *sh2 = sc2 + k1N2, *sc3 = aff + 2 * (k1N1 + k1N2), *sh3 = sc3 + k1N3;
   __syncthreads();
@@ -1811,8 +1816,8 @@ __global__ __launch_bounds__(64 * k1Waves, 1) void sa1_rows_kernel(int n, int m,
       cx[mt] = ct[0]; cy[mt] = ct[1]; cz[mt] = ct[2];
     }
   };
-  const int stride = gridDim.x * k1Waves;
-  int t = blockIdx.x * k1Waves + wave;
+  const int stride = gridDim.x * k1RowsWaves;
+  int t = blockIdx.x * k1RowsWaves + wave;
   RSTAMP_DECL;
   if (t < tasks) {
   fetch_idx(t);
@@ -2153,9 +2158,9 @@ extern "C" int msr3d_sa_level1_rows(int b, int n, int m, const float *pts, const
   wq->planned = false;
   if ((e = allow_lds(sa1_rows_kernel, kSa1Lds)) != hipSuccess) return (int)e;
   const int cus = usable_cus();
-  const long long max_rounds = ((long long)b * m + k1Waves - 1) / k1Waves;
+  const long long max_rounds = ((long long)b * m + k1RowsWaves - 1) / k1RowsWaves;
   const int blocks = (int)(max_rounds < cus ? max_rounds : cus);
-  sa1_rows_kernel<<<blocks, 64 * k1Waves, kSa1Lds, st>>>(n, m, wq->q, pts, new_xyz, thdr, trow, make_layer(w1, affine1, 64),
+  sa1_rows_kernel<<<blocks, 64 * k1RowsWaves, kSa1Lds, st>>>(n, m, wq->q, pts, new_xyz, thdr, trow, make_layer(w1, affine1, 64),
                                                         make_layer(w2, affine2, 64), make_layer(w3, affine3, 128), out);
   e = hipGetLastError();
   if (e == hipSuccess) wq->suspect = false;
