@@ -802,7 +802,9 @@ def main():
                 "cus_left_to_rccl": getattr(tr.dp, "reserved_cus", 0),
                 "grad_bytes": int(tr.dp.numel * 4), "exchanges": len(ar),
                 "allreduce_ms": float(stats[0]), "allreduce_exposed_ms": float(stats[1]),
-                "replica_checksum_spread": spread}
+                "replica_checksum_spread": spread,
+                # start-up self-check of the captured exchange (train_step._capture_checked); None: forced by env
+                "graph_comm_check": getattr(tr.stepper, "graph_comm_check", None)}
         assert ranks_seen == world, f"RCCL saw {ranks_seen} ranks, expected {world}"
         assert spread == 0.0, f"replicas diverged: checksum spread {spread}"
 

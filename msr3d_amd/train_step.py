@@ -86,11 +86,19 @@ class HotPathTrainStep:
         # 1 / world (no separate averaging pass over the buffer)
         if fused and dp.distributed and hasattr(dp, "scale_in_optimizer"):
             dp.scale_in_optimizer = True
-        # MSR3D_DP_GRAPH_COMM=1: capture the RCCL call with the rest -- the whole data-parallel step is ONE
-        # graph (zero -> forward -> backward -> all-reduce on the side stream -> clip + AdamW), no next_batch
-        # needed.  Opt-in: the eager exchange is the schedule every test on this box can run with >1 rank.
+        # The exchange captured with the rest -- the whole data-parallel step is ONE graph (zero -> forward ->
+        # backward -> all-reduce on the side stream -> clip + AdamW), no next_batch needed.
+        #   MSR3D_DP_GRAPH_COMM=1   always (no check)
+        #   MSR3D_DP_GRAPH_COMM=0   never: eager RCCL calls between the captured forward / backward and the optimiser
+        #   unset                   world > 1 on the GPU: captured, after capture()'s start-up self-check (two replays
+        #                           against two eager steps from the same state, every rank must agree); a failed
+        #                           check falls back to the eager exchange, loudly (graph_comm_check says why)
         import os
-        self._graph_comm = os.environ.get("MSR3D_DP_GRAPH_COMM") == "1" and self.accum_steps == 1
+        env = os.environ.get("MSR3D_DP_GRAPH_COMM")
+        self._graph_comm = env == "1" and self.accum_steps == 1
+        self._graph_comm_auto = (env is None or env == "auto") and bool(dp.distributed) and self.accum_steps == 1 \
+            and self.use_graph and self._backend_captures(dp)
+        self.graph_comm_check = None
         self._sched_direct = False
         self._probed = False
         self.unused_parameters = []
@@ -98,6 +106,15 @@ class HotPathTrainStep:
         self._enc_stream = torch.cuda.Stream() if self.static["obj_embeds"].is_cuda else None
         self._pref = {"key": None, "feats": torch.empty_like(self.static["obj_embeds"]), "event": None}
         self._win = {"feats": None, "index": {}, "B": 0}        # encode_window(): features of a whole accumulation window
+
+    @staticmethod
+    def _backend_captures(dp):
+        """RCCL calls can be stream-captured; gloo's (host-side) cannot."""
+        try:
+            import torch.distributed as dist
+            return dist.get_backend(getattr(dp, "group", None)) == "nccl"
+        except Exception:      # noqa: BLE001
+            return False
 
     # ---- the trainable part, on static buffers -------------------------------------
     def _fwd_bwd(self, zero=True):
@@ -411,6 +428,71 @@ class HotPathTrainStep:
         torch.cuda.synchronize()
         self._restore(snap)
         torch.cuda.synchronize()
+        if self._graph_comm_auto:
+            self._capture_checked(batch)
+        else:
+            self._capture_graph(batch)
+
+    def _state_vector(self):
+        flat = getattr(self.opt, "flat_p", None)
+        if flat is not None:
+            return flat.detach().clone()
+        return torch.cat([p.detach().reshape(-1).float() for p in self.dp.order])
+
+    def _all_ranks_agree(self, ok):
+        if not self.dp.distributed:
+            return ok
+        import torch.distributed as dist
+        t = torch.tensor([1 if ok else 0], device=self.static["obj_embeds"].device, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=getattr(self.dp, "group", None))
+        return bool(t.item())
+
+    def _capture_checked(self, batch):
+        """world > 1, MSR3D_DP_GRAPH_COMM unset: take the one-graph step (exchange captured) if it survives a
+        self-check, the eager exchange otherwise.  The check: from one saved state, two replays of the captured
+        step and two eager steps (real collectives both ways) must leave the same weights on every rank."""
+        import sys
+        why = None
+        snap = self._snapshot()
+        self._graph_comm = True
+        try:
+            self._capture_graph(batch)
+            for _ in range(2):
+                self.graph.replay()
+            torch.cuda.synchronize()
+            got = self._state_vector()
+            self._restore(snap)
+            saved_defer = self.dp.defer_comm
+            for _ in range(2):
+                self._load(batch)
+                self._train_part()
+            torch.cuda.synchronize()
+            want = self._state_vector()
+            self.dp.defer_comm = saved_defer
+            diff = float((got - want).abs().max())
+            scale = float(want.abs().max())
+            if not (diff <= 1e-5 * max(scale, 1e-30)) or not bool(torch.isfinite(got).all()):
+                why = f"two captured steps differ from two eager ones: max |d| = {diff:.3e} at scale {scale:.3e}"
+            self.graph_comm_check = {"captured": True, "max_abs_diff": diff, "scale": scale}
+        except Exception as e:      # noqa: BLE001 -- a capture that fails must not take the run with it
+            why = f"{type(e).__name__}: {e}"
+        if not self._all_ranks_agree(why is None):
+            why = why or "another rank's check failed"
+            print(f"[msr3d] captured gradient exchange NOT taken ({why}); falling back to the eager exchange",
+                  file=sys.stderr, flush=True)
+            self.graph_comm_check = {"captured": False, "why": why}
+            self._graph_comm = False
+            self.graph = None
+            torch.cuda.synchronize()
+            self._restore(snap)
+            torch.cuda.synchronize()
+            self._capture_graph(batch)
+            return
+        self._restore(snap)
+        torch.cuda.synchronize()
+        self._load(batch)
+
+    def _capture_graph(self, batch):
         self.graph = torch.cuda.CUDAGraph()
         self._load(batch)
         # world > 1: the gradient exchange stays OUTSIDE the graph (RCCL calls are issued eagerly

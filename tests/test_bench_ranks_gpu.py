@@ -40,7 +40,8 @@ def test_bench_multi_rank_schedule_over_rccl_with_one_rank():
     """The multi-rank schedule on the REAL backend: RCCL communicator (one rank -- the box has one
     GPU), all-reduce of the flat gradient buffer on the communication stream between the replayed
     forward/backward graph and the optimiser, the next batch's encoder issued in between."""
-    env = dict(os.environ, MSR3D_BENCH_FORCE_DIST="1", MASTER_PORT="29672", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MSR3D_BENCH_FORCE_DIST="1", MASTER_PORT="29672", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               MSR3D_DP_GRAPH_COMM="0")           # (this test is about the eager-exchange schedule)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "3",
@@ -59,7 +60,7 @@ def test_bench_reduce_scatter_all_gather_exchange_and_accumulation(micro_steps):
     """MSR3D_DP_EXCHANGE=rs_ag (the A/B switch for the 8-GPU run) on the one-rank RCCL communicator,
     with the reference's launch shape: 4 scenes x 5 accumulated micro-batches per optimiser step."""
     env = dict(os.environ, MSR3D_BENCH_FORCE_DIST="1", MASTER_PORT="29683" if micro_steps else "29673",
-               HSA_ENABLE_IPC_MODE_LEGACY="0", MSR3D_DP_EXCHANGE="rs_ag")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", MSR3D_DP_EXCHANGE="rs_ag", MSR3D_DP_GRAPH_COMM="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
@@ -127,6 +128,23 @@ def test_bench_exchange_captured_inside_the_step_graph(extra):
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert j["config"]["exchange_inside_graph"] is True and j["config"]["hip_graph"] is True
     assert j["config"]["allreduce_hidden_behind_next_encoder"] is False
+    assert j["comm"]["ranks_seen"] == 1 and j["comm"]["replica_checksum_spread"] == 0.0 and j["value"] > 0
+
+
+def test_bench_default_multi_rank_schedule_is_the_captured_exchange_after_its_self_check():
+    """World > 1 on RCCL with MSR3D_DP_GRAPH_COMM unset (what an 8-GPU driver run takes): the exchange is captured in the
+    step's graph after the start-up self-check -- two replays against two eager steps from the same state -- and the line
+    says so; no retry."""
+    env = dict(os.environ, MSR3D_BENCH_FORCE_DIST="1", MASTER_PORT="29679", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MSR3D_DP_GRAPH_COMM"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2",
+                          "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert j["config"]["exchange_inside_graph"] is True, out.stderr[-2000:]
+    chk = j["comm"]["graph_comm_check"]
+    assert chk["captured"] is True and chk["max_abs_diff"] <= 1e-5 * chk["scale"]
     assert j["comm"]["ranks_seen"] == 1 and j["comm"]["replica_checksum_spread"] == 0.0 and j["value"] > 0
 
 

@@ -38,6 +38,7 @@ v env MSR3D_ATTN_FWD_WAVES=4 python bench.py --no-cpu-baseline
 v env MSR3D_FFN_WAVES=4 python bench.py --no-cpu-baseline
 v env MSR3D_SA_PLAN12=0 python bench.py --no-cpu-baseline
 v env MSR3D_FPS_QUERY=0 python bench.py --no-cpu-baseline
+v env MSR3D_BENCH_FORCE_DIST=1 MSR3D_DP_GRAPH_COMM=0 python bench.py --no-cpu-baseline
 v env MSR3D_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline
 v env MSR3D_BENCH_FORCE_DIST=1 MSR3D_DP_GRAPH_COMM=1 python bench.py --no-cpu-baseline
 v env MSR3D_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --batch 4 --accum 5
