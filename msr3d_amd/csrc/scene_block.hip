@@ -507,6 +507,227 @@ __global__ __launch_bounds__(64 * NW) void scene_block_kernel(const SB p) {
   SB_STAMP(8);
 }
 
+// =====================================================================================================
+// Attention block, forward, as TWO workgroups per (scene, head) (round 5): workgroup
+// (h, qh) owns the query rows [32 qh, 32 qh + 32) -- q, cond, the probabilities, the context and the head's
+// partial out-projection of those rows -- and computes k and v of ALL rows for itself (each workgroup saves
+// the k / v rows of its own half for the backward).  256 workgroups at the bench shape instead of 128, and
+// inside the core the eight waves split the KEYS as well: wave (qt, kq) owns the 16 x 16 logits of query
+// tile qt and key quarter kq (4 (query, key) pairs per lane instead of 16); the quarters' row maxima and row
+// sums meet through LDS in quarter order (deterministic).
+//
+// Column tiles of product 1 by wave -- k0 k1 v0 v1 (all four row tiles) | q0 q1 cond (this half's two row
+// tiles) | idle -- so that the two waves of a SIMD (w, w + 4) issue 6, 6, 6 and 4 tile-units.
+// =====================================================================================================
+constexpr int kPloc2Regs = 32 * 64 * SD / 4 / 512;          // 5 float4 per thread: the half's (32, L, 5) slab
+constexpr int kAttnFwd2Aux = 3 * kTile + 2048 + 2 * 3 * 1024 + 2 * 4 * 32 * 4;   // q k v | cond | ctx FRAG (2 row tiles) | max, sum
+constexpr int kAttnFwd2Lds = XS_BYTES + kAttnFwd2Aux;
+
+__global__ __launch_bounds__(512) void scene_attn_fwd2_kernel(const SB p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned short *xs = reinterpret_cast<unsigned short *>(smem);
+  unsigned char *aux = smem + XS_BYTES;
+  const int h = blockIdx.x & 7, qh = blockIdx.x >> 3, b = blockIdx.y, L = p.L, H = p.H, ldq = p.ldq;
+  const int q0 = 32 * qh;
+  if (q0 >= L) return;                       // (a scene of <= 32 tokens: the first workgroup owns every row)
+  const int row_base = b * L;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  float *const slab = p.part + (size_t)h * p.part_stride;
+  float *sq = reinterpret_cast<float *>(aux), *sk = sq + TM * LD32, *sv = sk + TM * LD32;
+  float *scond = sv + TM * LD32;                                           // [64][8]
+  unsigned char *ctxp = reinterpret_cast<unsigned char *>(scond + TM * 8); // FRAG, 1 slab x 2 row tiles
+  float *xmax = reinterpret_cast<float *>(ctxp + 2 * 3 * 1024), *xsum = xmax + 4 * 32;   // [4 quarters][32 rows] each
+
+  constexpr int KS1 = KD / 32;
+  const int tile = wave < 4 ? 2 + wave : wave == 7 ? 7 : wave - 4 + (wave == 6 ? 4 : 0);   // k0 k1 v0 v1 q0 q1 cond -
+  const bool kv = wave < 4, busy = wave < 7;
+  WStream w1 = make_wstream(p.w1 + (size_t)h * (KS1 * 8 * kPieceBytes / 2), KS1 * 8 * kPieceBytes, 8, 0, tile, lane);
+  SB_STAMP(0);
+  WPiece ring1[RING];
+  if (busy) preload_wring<1, RING>(ring1, w1);
+  // this half's rows of the scene's pairwise slab: registers now, LDS when the planes are dead
+  const int nq = min(32, L - q0);
+  const float *plsrc = p.ploc + ((size_t)b * L + q0) * L * SD;
+  const int pn = nq * L * SD;
+  const bool pvec = (reinterpret_cast<uintptr_t>(plsrc) & 15u) == 0 && (pn & 3) == 0;
+  float4 plv[kPloc2Regs];
+  if (pvec) {
+#pragma unroll
+    for (int k = 0; k < kPloc2Regs; ++k) {
+      const int e = tid + 512 * k;
+      plv[k] = e < (pn >> 2) ? reinterpret_cast<const float4 *>(plsrc)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  stage_planes<512>(p.xp, xs, b);
+  SB_STAMP(1);
+  __syncthreads();
+  SB_STAMP(2);
+  const XRows xr = make_xrows(xs, PITCH, TM, lane);
+  // product 2's stream: Wfc [8 slabs][16 tiles], slab h, two column tiles a wave
+  const WStream w2 = make_wstream(p.w2, p.w2_bytes, 16, h, 2 * wave, lane);
+  WPiece ring2[2];
+
+  if (kv) {
+    f32x4 acc[1][4];
+    zero_acc3(acc);
+    gemm_split3<true, 1, 4, KS1, RING>(xr, 0, w1, acc, ring1);
+    SB_STAMP(3);
+    preload_wring<2, 2>(ring2, w2);
+    const int which = 1 + (wave >> 1);                                      // 1 k, 2 v
+    float *t = sq + which * TM * LD32;
+    const int c = 16 * (wave & 1) + 4 * g;
+    const float4 bv = ld4(p.bias1 + which * KD + h * DH + c);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int row = 16 * mt + j;
+      const bool ok = row < L;
+      const float4 v = ok ? make_float4(acc[0][mt][0] + bv.x, acc[0][mt][1] + bv.y, acc[0][mt][2] + bv.z, acc[0][mt][3] + bv.w)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      st4(t + row * LD32 + c, v);
+      if (ok && (mt >> 1) == qh) st4(p.qkvc + (size_t)(row_base + row) * ldq + which * KD + h * DH + c, v);
+    }
+  } else if (busy) {
+    f32x4 acc[1][2];
+    zero_acc3(acc);
+    gemm_split3<true, 1, 2, KS1, RING>(xr, 2 * qh, w1, acc, ring1);
+    SB_STAMP(3);
+    preload_wring<2, 2>(ring2, w2);
+    if (wave < 6) {                                                         // q
+      const int c = 16 * (wave & 1) + 4 * g;
+      const float4 bv = ld4(p.bias1 + h * DH + c);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = q0 + 16 * mt + j;
+        const bool ok = row < L;
+        const float4 v = ok ? make_float4(acc[0][mt][0] + bv.x, acc[0][mt][1] + bv.y, acc[0][mt][2] + bv.z, acc[0][mt][3] + bv.w)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        st4(sq + row * LD32 + c, v);
+        if (ok) st4(p.qkvc + (size_t)(row_base + row) * ldq + h * DH + c, v);
+      }
+    } else {                                                                // cond
+      float b4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b4[r] = 4 * g + r < SD + 1 ? p.bias1[3 * KD + h * (SD + 1) + 4 * g + r] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = q0 + 16 * mt + j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 4 * g + r;
+          const float v = row < L ? acc[0][mt][r] + b4[r] : 0.f;
+          if (c < 8) scond[row * 8 + c] = c < SD + 1 ? v : 0.f;
+          if (c < SD + 1 && row < L) p.qkvc[(size_t)(row_base + row) * ldq + 3 * KD + h * (SD + 1) + c] = v;
+        }
+      }
+    }
+  } else {
+    SB_STAMP(3);
+    preload_wring<2, 2>(ring2, w2);
+  }
+  SB_STAMP(4);
+  __syncthreads();                           // every wave is done with the ROWS planes; q / k / v / cond visible
+  constexpr int LDP = TM + 4;
+  float *sp = reinterpret_cast<float *>(xs);                                // P [32][68], then the half's pairwise slab
+  float *spl = sp + 32 * LDP;
+  if (pvec) {
+#pragma unroll
+    for (int k = 0; k < kPloc2Regs; ++k) {
+      const int e = tid + 512 * k;
+      if (e < (pn >> 2)) reinterpret_cast<float4 *>(spl)[e] = plv[k];
+    }
+  } else {
+    for (int e = tid; e < pn; e += 512) spl[e] = plsrc[e];
+  }
+  __syncthreads();
+  SB_STAMP(5);
+  // ---- the core: wave (qt, kq) ----
+  {
+    const int qt = wave & 1, kq = wave >> 1;
+    const int i = j;
+    f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    msr3d_attn::strip_mma<MSR3D_MMA_F32, 1, DH, true, true>(sq, LD32, sk + 16 * kq * LD32, LD32, q0 + 16 * qt, acc, lane);
+    const int col = 16 * kq + i;
+    const unsigned char *pad_b = p.pad + (size_t)b * L;
+    const bool keyok = col < L && !pad_b[min(col, L - 1)];
+    float lg[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lr = 16 * qt + 4 * g + r, row = q0 + lr;
+      const msr3d_attn::RowCond c = msr3d_attn::load_cond(scond, 8, L, row);
+      float v = -INFINITY;
+      if (row < L && keyok) {
+        const float *pl = spl + ((size_t)lr * L + col) * SD;
+        float z = c.bias;
+#pragma unroll
+        for (int d = 0; d < SD; ++d) z = fmaf(c.w[d], pl[d], z);
+        const float loc = __builtin_amdgcn_rcpf(1.0f + __expf(-z));      // (attn_core.h: the reference's sigmoid -> clamp -> log)
+        v = __logf(fmaxf(loc, 1e-6f)) + acc[0][r] * kInvSqrtDh;
+      }
+      lg[r] = v;
+      const float m = msr3d_attn::row16_max(v);
+      if (i == 0) xmax[kq * 32 + lr] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lr = 16 * qt + 4 * g + r;
+      const float m = fmaxf(fmaxf(xmax[lr], xmax[32 + lr]), fmaxf(xmax[64 + lr], xmax[96 + lr]));
+      const float e = (lg[r] == -INFINITY) ? 0.f : __expf(lg[r] - m);
+      lg[r] = e;
+      const float sm = msr3d_attn::row16_sum(e);
+      if (i == 0) xsum[kq * 32 + lr] = sm;
+    }
+    __syncthreads();
+    float *probs_bh = p.probs ? p.probs + ((size_t)b * H + h) * L * L : nullptr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lr = 16 * qt + 4 * g + r, row = q0 + lr;
+      const float tot = ((xsum[lr] + xsum[32 + lr]) + xsum[64 + lr]) + xsum[96 + lr];
+      const float inv = 1.0f / tot;          // a fully padded row gives NaN, as the reference would
+      const float pr = (row < L) ? lg[r] * inv : 0.f;
+      sp[lr * LDP + col] = pr;
+      if (probs_bh && row < L && col < L) probs_bh[(size_t)row * L + col] = pr;
+    }
+    __syncthreads();
+    // ctx = P V: waves 0 .. 3 as (query tile, half of the head's 32 columns); side output + product 2's operand
+    if (wave < 4) {
+      const int dt = wave >> 1;
+      f32x4 o[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+      msr3d_attn::strip_mma<MSR3D_MMA_F32, 1, TM, true, false>(sp, LDP, sv + 16 * dt, LD32, 16 * qt, o, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 4 * g + r, row = q0 + 16 * qt + rr, kk = 16 * dt + i;
+        const float v = row < L ? o[0][r] : 0.f;
+        if (row < L) p.ctx[(size_t)(row_base + row) * KD + h * DH + kk] = v;
+        unsigned short pl[3];
+        sm_split1(v, pl);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          *reinterpret_cast<unsigned short *>(ctxp + (((qt * 3 + k) * 64 + rr + 16 * (kk >> 3)) * 16 + (kk & 7) * 2)) = pl[k];
+      }
+    }
+  }
+  SB_STAMP(6);
+  __syncthreads();
+  f32x4 acc2[2][2];
+  zero_acc3(acc2);
+  const XFrag<2> xm{reinterpret_cast<const unsigned short *>(ctxp) + lane * 8};
+  gemm_split3<true, 2, 2, 1, 2>(xm, 0, w2, acc2, ring2);
+  SB_STAMP(7);
+#pragma unroll
+  for (int rn = 0; rn < 2; ++rn)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = q0 + 16 * mt + j;
+      if (row < L)
+        st4(slab + (size_t)(row_base + row) * KD + 32 * wave + 16 * rn + 4 * g,
+            make_float4(acc2[rn][mt][0], acc2[rn][mt][1], acc2[rn][mt][2], acc2[rn][mt][3]));
+    }
+  SB_STAMP(8);
+}
+
 template <int KIND, int NW = 4>
 int launch_block(const SB &p, int slices, hipStream_t s) {
   constexpr int lds = lds_bytes<KIND>();
@@ -639,6 +860,18 @@ int msr3d_scene_block(const msr3d_scene_block_t *pp, msr3d_stream_t stream) {
     case MSR3D_BLK_ATTN_FWD:
       if (p.H != 8 || !p.w2 || !p.qkvc || !p.ploc || !p.pad || !p.ctx || !p.bias1 || p.ldq % 4) return MSR3D_EINVAL;
       if (p.w1_bytes < 8u * 8u * 8u * kPieceBytes || p.w2_bytes < 8u * 16u * kPieceBytes) return MSR3D_EINVAL;
+      {
+        // two workgroups per (scene, head), keys split over the core's eight waves (round 5): default;
+        // MSR3D_ATTN_FWD_SPLIT=0 restores one workgroup per (scene, head)
+        static const bool split = [] { const char *v = getenv("MSR3D_ATTN_FWD_SPLIT"); return !(v && v[0] == '0'); }();
+        if (split) {
+          static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&scene_attn_fwd2_kernel),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, kAttnFwd2Lds);
+          if (attr != hipSuccess) return (int)attr;
+          scene_attn_fwd2_kernel<<<dim3(16, p.B), 512, kAttnFwd2Lds, s>>>(p);
+          return (int)hipGetLastError();
+        }
+      }
       {
         // eight waves per workgroup (two per SIMD) by default: -6 us a step in three interleaved same-box runs
         // (1.2421 -> 1.2362 ms); MSR3D_ATTN_FWD_WAVES=4 restores round 3's four
