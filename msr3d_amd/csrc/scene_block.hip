@@ -519,7 +519,7 @@ __global__ __launch_bounds__(64 * NW) void scene_block_kernel(const SB p) {
 // Column tiles of product 1 by wave -- k0 k1 v0 v1 (all four row tiles) | q0 q1 cond (this half's two row
 // tiles) | idle -- so that the two waves of a SIMD (w, w + 4) issue 6, 6, 6 and 4 tile-units.
 // =====================================================================================================
-constexpr int kPloc2Regs = 32 * 64 * SD / 4 / 512;          // 5 float4 per thread: the half's (32, L, 5) slab
+constexpr int kPloc2Regs = 32 * 64 * SD / 4 / 256;          // 10 float4 per thread of waves 4 .. 7: the half's (32, L, 5) slab
 constexpr int kAttnFwd2Aux = 3 * kTile + 2048 + 2 * 3 * 1024 + 2 * 4 * 32 * 4;   // q k v | cond | ctx FRAG (2 row tiles) | max, sum
 constexpr int kAttnFwd2Lds = XS_BYTES + kAttnFwd2Aux;
 
@@ -553,14 +553,43 @@ __global__ __launch_bounds__(512) void scene_attn_fwd2_kernel(const SB p) {
   const int pn = nq * L * SD;
   const bool pvec = (reinterpret_cast<uintptr_t>(plsrc) & 15u) == 0 && (pn & 3) == 0;
   float4 plv[kPloc2Regs];
-  if (pvec) {
+  // The scene's planes, THIS half's 32 rows first and the other half's only when those have arrived: the pair's two
+  // workgroups (same XCD) then miss on disjoint halves and hit, in L2, on what the partner has fetched -- all 64 rows
+  // requested at once by both doubled the traffic over the fabric and the staging time (5.3 k -> 11.6 k cycles).
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(p.xp + (size_t)b * 3 * TM * KD);
 #pragma unroll
-    for (int k = 0; k < kPloc2Regs; ++k) {
-      const int e = tid + 512 * k;
-      plv[k] = e < (pn >> 2) ? reinterpret_cast<const float4 *>(plsrc)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int part = 0; part < 2; ++part) {
+      const int r0 = 32 * (part == 0 ? qh : 1 - qh);
+      uint4 v[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int q = tid + 512 * k, plane = q >> 10, row = r0 + ((q >> 5) & 31), c8 = q & 31;
+        v[k] = src[plane * 2048 + row * 32 + c8];
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int q = tid + 512 * k, plane = q >> 10, row = r0 + ((q >> 5) & 31), c8 = q & 31;
+        *reinterpret_cast<uint4 *>(xs + plane * PLANE + row * PITCH + c8 * 8) = v[k];
+      }
+      if (part == 0) __builtin_amdgcn_sched_barrier(0);       // (the second half's loads stay behind the first half's stores)
+      if (part == 1) {
+        // the half's pairwise rows last: they return behind the planes (loads complete in order) and are not needed
+        // before product 1 is over -- their 1.15 MB per XCD cross the fabric under the product, not in front of it.
+        // By waves 4 .. 7 only (q, cond, idle: half the product of the k / v waves, whose weight pieces would queue
+        // behind these loads).
+        __builtin_amdgcn_sched_barrier(0);
+        if (pvec && !kv) {
+#pragma unroll
+          for (int k2 = 0; k2 < kPloc2Regs; ++k2) {
+            const int e = tid - 256 + 256 * k2;
+            plv[k2] = e < (pn >> 2) ? reinterpret_cast<const float4 *>(plsrc)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
-  stage_planes<512>(p.xp, xs, b);
   SB_STAMP(1);
   __syncthreads();
   SB_STAMP(2);
@@ -632,10 +661,12 @@ __global__ __launch_bounds__(512) void scene_attn_fwd2_kernel(const SB p) {
   float *sp = reinterpret_cast<float *>(xs);                                // P [32][68], then the half's pairwise slab
   float *spl = sp + 32 * LDP;
   if (pvec) {
+    if (!kv) {
 #pragma unroll
-    for (int k = 0; k < kPloc2Regs; ++k) {
-      const int e = tid + 512 * k;
-      if (e < (pn >> 2)) reinterpret_cast<float4 *>(spl)[e] = plv[k];
+      for (int k = 0; k < kPloc2Regs; ++k) {
+        const int e = tid - 256 + 256 * k;
+        if (e < (pn >> 2)) reinterpret_cast<float4 *>(spl)[e] = plv[k];
+      }
     }
   } else {
     for (int e = tid; e < pn; e += 512) spl[e] = plsrc[e];

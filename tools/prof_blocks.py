@@ -43,11 +43,18 @@ def launch_block(stream, **kw):
     name = KIND[s.kind]
     slices = 8 if name.startswith("attn") else int(s.ff) // 128 if name.startswith("ffn") else \
         int(s.N) // 256 if name == "linear" else int(s.lda0) // 256
+    if name == "attn_fwd" and os.environ.get("MSR3D_ATTN_FWD_SPLIT", "1") != "0":
+        slices = 16                      # two workgroups per (scene, head)
     nblk = int(s.B) * slices
     wpb = max(len(st) // max(nblk, 1), 1)
     blk = st[:nblk * wpb].reshape(nblk, wpb, NST)
     span = blk[:, :, marks[-1]].max(axis=1) - blk[:, :, 0].min(axis=1)
-    line = f"{KIND[s.kind]:14s} waves {len(st):5d} ({wpb}/wg) wg span {int(np.median(span)):6d}/{int(span.max()):6d} |"
+    # start skew inside an XCD (workgroups of one XCD = one counter): the spread of the workgroups' first marks
+    x = np.arange(nblk) % 8
+    first = blk[:, :, 0].min(axis=1)
+    skew = max(int(first[x == k].max() - first[x == k].min()) for k in range(8) if (x == k).any())
+    whole = max(int(blk[x == k][:, :, marks[-1]].max() - first[x == k].min()) for k in range(8) if (x == k).any())
+    line = f"{KIND[s.kind]:14s} waves {len(st):5d} ({wpb}/wg) wg span {int(np.median(span)):6d}/{int(span.max()):6d} xcd skew {skew:6d} xcd whole {whole:6d} |"
     prev = 0
     for i in marks[1:]:
         d = st[:, i] - st[:, prev]
