@@ -62,10 +62,14 @@ __device__ __forceinline__ long pack_fp8(const float (&f)[8]) {
   return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo);
 }
 
-template <int MMA, int RN, int KD, bool A_KC, bool B_KC>
+// SWAP (f32 only): the two operands trade roles, D^T instead of D -- acc[rn][r] is then element (row = row0 + i,
+// col = 16 rn + 4 g + r): a lane holds four CONSECUTIVE columns of one row (one 16-byte store, one sm_split4) instead of
+// four rows of one column.  The same products summed over k in the same order.
+template <int MMA, int RN, int KD, bool A_KC, bool B_KC, bool SWAP = false>
 __device__ __forceinline__ void strip_mma(const float *As, int lda, const float *Bs, int ldb,
                                           int row0, f32x4 (&acc)[RN], int lane) {
   const int i = lane & 15, g = lane >> 4;
+  static_assert(!SWAP || MMA == MSR3D_MMA_F32, "swapped roles: f32 operand map only");
   if (MMA == MSR3D_MMA_F32) {
 #pragma unroll
     for (int k0 = 0; k0 < KD; k0 += 4) {
@@ -74,7 +78,8 @@ __device__ __forceinline__ void strip_mma(const float *As, int lda, const float 
 #pragma unroll
       for (int rn = 0; rn < RN; ++rn) {
         const float b = B_KC ? Bs[(rn * 16 + i) * ldb + k] : Bs[k * ldb + rn * 16 + i];
-        acc[rn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[rn], 0, 0, 0);
+        acc[rn] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc[rn], 0, 0, 0)
+                       : __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[rn], 0, 0, 0);
       }
     }
   } else {
@@ -321,7 +326,8 @@ __device__ __forceinline__ void attn_fwd_core(int L, const float *sq, const floa
 // the accumulator layout (row = 16 wave + 4 g + r, col = 16 rn + i; dq / dk still to be divided by
 // sqrt(dh)) and writes the (bias, w[5]) gradients of each row to dcond0 + row * lddc (lane i == 0).
 // =================================================================================
-template <int LT, int MMA>
+// TR: dq / dk / dv returned TRANSPOSED per tile (strip_mma's SWAP): element (row = 16 wave + i, col = 16 rn + 4 g + r).
+template <int LT, int MMA, bool TR = false>
 __device__ __forceinline__ void attn_bwd_core(int L, const float *sq, const float *sk, const float *sv,
                                               const float *sdo, float *sp, const float *plb, const float *cond0,
                                               int ldc, const unsigned char *pad_b, float *dcond0, int lddc,
@@ -337,7 +343,7 @@ __device__ __forceinline__ void attn_bwd_core(int L, const float *sq, const floa
   // dv = P^T dctx (rows = keys) while P is still intact
   ov[0] = f32x4{0.f, 0.f, 0.f, 0.f};
   ov[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  strip_mma<MMA, 2, LT, false, false>(sp, LDP, sdo, LD32, row0, ov, lane);
+  strip_mma<MMA, 2, LT, false, false, TR>(sp, LDP, sdo, LD32, row0, ov, lane);
   __syncthreads();                       // every wave is done reading P as a matrix operand
 
   bool keyok[NT];
@@ -394,8 +400,8 @@ __device__ __forceinline__ void attn_bwd_core(int L, const float *sq, const floa
     oq[rn] = f32x4{0.f, 0.f, 0.f, 0.f};
     ok[rn] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  strip_mma<MMA, 2, LT, true, false>(sp, LDP, sk, LD32, row0, oq, lane);
-  strip_mma<MMA, 2, LT, false, false>(sp, LDP, sq, LD32, row0, ok, lane);
+  strip_mma<MMA, 2, LT, true, false, TR>(sp, LDP, sk, LD32, row0, oq, lane);
+  strip_mma<MMA, 2, LT, false, false, TR>(sp, LDP, sq, LD32, row0, ok, lane);
 }
 
 }  // namespace msr3d_attn

@@ -107,6 +107,22 @@ __device__ __forceinline__ void stage_planes(const unsigned short *__restrict__ 
   }
 }
 
+// stage_planes in two steps (256 threads): the loads, and -- after the caller has issued other loads behind them -- the
+// LDS stores
+__device__ __forceinline__ void planes_fetch(const unsigned short *__restrict__ xp, int b, uint4 (&v)[24]) {
+  const uint4 *src = reinterpret_cast<const uint4 *>(xp + (size_t)b * 3 * TM * KD);
+#pragma unroll
+  for (int k = 0; k < 24; ++k) v[k] = src[threadIdx.x + 256 * k];
+}
+__device__ __forceinline__ void planes_store(unsigned short *xs, const uint4 (&v)[24]) {
+#pragma unroll
+  for (int k = 0; k < 24; ++k) {
+    const int q = threadIdx.x + 256 * k;
+    const int plane = q >> 11, row = (q >> 5) & 63, c8 = q & 31;
+    *reinterpret_cast<uint4 *>(xs + plane * PLANE + row * PITCH + c8 * 8) = v[k];
+  }
+}
+
 __device__ __forceinline__ void stage_f32(const float *__restrict__ a0, int lda, int col0, unsigned short *xs,
                                           int row_base, int L) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -759,6 +775,175 @@ __global__ __launch_bounds__(512) void scene_attn_fwd2_kernel(const SB p) {
   SB_STAMP(8);
 }
 
+// =====================================================================================================
+// Attention block, backward (one workgroup of four waves per (scene, head), as scene_block_kernel<ATTN_BWD> was), with
+// ALL of the block's inputs crossing the fabric together: the head's saved q / k / v / cond and probabilities are asked
+// for with the planes (they used to be fetched, one dependent round trip after another, once the planes had arrived:
+// 13 k cycles in front of an 8-piece product), all eight weight pieces of product 1 sit in registers before the pairwise
+// slab's 72 KB are requested (loads complete in order), and the core returns dq / dk / dv transposed per tile
+// (attn_core.h: strip_mma's SWAP) so that the side outputs are 16-byte stores and product 2's operand 8-byte LDS stores.
+// MSR3D_ATTN_BWD_V2=0 restores scene_block_kernel<ATTN_BWD>.
+// =====================================================================================================
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void scene_attn_bwd2_kernel(const SB p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned short *xs = reinterpret_cast<unsigned short *>(smem);
+  unsigned char *aux = smem + XS_BYTES;
+  const int slice = blockIdx.x, b = blockIdx.y, L = p.L;
+  const int row_base = b * L;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  float *const slab = p.part + (size_t)slice * p.part_stride;
+  constexpr int KS1 = KD / 32;
+  {
+    const int h = slice, H = p.H, ldq = p.ldq;
+    float *sq = reinterpret_cast<float *>(aux), *sk = sq + TM * LD32, *sv = sk + TM * LD32, *sdo = sv + TM * LD32;
+    float *scond = sdo + TM * LD32, *sdc = scond + TM * 8;
+    // Wfc as [k = fc row][n = ctx column]: [8 slabs][16 tiles], tiles 2 h, 2 h + 1
+    const WStream w1 = make_wstream(p.w1, p.w1_bytes, 16, 0, 2 * slice + (wave & 1), lane);
+    SB_STAMP(0);
+#ifndef BW_R1
+#define BW_R1 8
+#endif
+    WPiece ring1[BW_R1];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_wpiece(ring1[q], w1, q, 0);
+    uint4 xv[24];
+    planes_fetch(p.xp, b, xv);
+    // saved q / k / v (two float4 a thread and tile), cond, probabilities
+    float4 tq[6];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int e = tid + 256 * k, row = e >> 3, c4 = (e & 7) * 4;
+        tq[2 * t + k] = row < L ? ld4(p.qkvc + (size_t)(row_base + row) * ldq + t * KD + h * DH + c4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    float tc[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = tid + 256 * k, row = e >> 3, c = e & 7;
+      tc[k] = (row < L && c < SD + 1) ? p.qkvc[(size_t)(row_base + row) * ldq + 3 * KD + h * (SD + 1) + c] : 0.f;
+    }
+    const float *plsrc = p.ploc + (size_t)b * L * L * SD, *prsrc = p.probs + ((size_t)b * H + h) * L * L;
+    const int pn = L * L * SD;
+    const bool pvec = (reinterpret_cast<uintptr_t>(plsrc) & 15u) == 0 && (pn & 3) == 0;
+    const bool qvec = (reinterpret_cast<uintptr_t>(prsrc) & 15u) == 0 && (L & 3) == 0;
+    float4 plv[msr3d_attn::kPlocRegs], prv[msr3d_attn::kProbRegs];
+    if (qvec) msr3d_attn::probs_fetch(prsrc, L, prv);
+    {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int e = tid + 256 * k, row = e >> 3, c4 = (e & 7) * 4;
+          st4(sq + t * TM * LD32 + row * LD32 + c4, tq[2 * t + k]);
+        }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) scond[tid + 256 * k] = tc[k];
+      planes_store(xs, xv);
+    }
+    // the planes' registers are free: the rest of product 1's pieces, then the pairwise slab (consumed after product 1).
+    // (Their addresses pass through an empty asm so that no pass hoists these loads above the planes' stores.  No
+    //  sched_barrier in this prologue: with them the planes went to scratch, one serialised load at a time.)
+    {
+      WStream w1b = w1;
+      const float *plsrc2 = plsrc;
+      asm volatile("" : "+s"(w1b.soff), "+s"(plsrc2) : : "memory");
+#pragma unroll
+      for (int q = 4; q < BW_R1; ++q) load_wpiece(ring1[q], w1b, q, 0);
+      if (pvec) msr3d_attn::ploc_fetch(plsrc2, pn >> 2, plv);
+    }
+    SB_STAMP(1);
+    __syncthreads();
+    SB_STAMP(2);
+    const XRows xr = make_xrows(xs, PITCH, TM, lane);
+    // ------------------------------------------------------------------ attention block, backward
+    // product 2's stream: the head's gathered rows of W_qkvc as [k = 128 head columns][n = 256]: [4 slabs][16 tiles]
+    const WStream w2 = make_wstream(p.w2 + (size_t)h * (4 * 16 * kPieceBytes / 2), 4 * 16 * kPieceBytes, 16, 0, 4 * wave, lane);
+    // d ctx_h = d_fc Wfc[:, 32 h : 32 h + 32]: wave (wr, wc) owns row tiles 2 wr, 2 wr + 1 and column tile wc
+    f32x4 acc[1][2];
+    zero_acc3(acc);
+    gemm_split3<true, 1, 2, KS1, BW_R1>(xr, 2 * (wave >> 1), w1, acc, ring1);
+    SB_STAMP(3);
+    WPiece ring2[RING];
+    preload_wring<4, RING>(ring2, w2);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = 16 * (2 * (wave >> 1) + mt) + j;
+      const float4 v = row < L ? make_float4(acc[0][mt][0], acc[0][mt][1], acc[0][mt][2], acc[0][mt][3])
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+      st4(sdo + row * LD32 + 16 * (wave & 1) + 4 * g, v);
+    }
+    __syncthreads();                       // planes free; q / k / v / cond / d ctx visible
+    float *sp = reinterpret_cast<float *>(xs);
+    if (qvec) msr3d_attn::probs_store(sp, L, prv);
+    else msr3d_attn::load_probs_tile<TM>(prsrc, L, sp);
+    const float *plb = sp + TM * (TM + 4);
+    if (pvec) msr3d_attn::ploc_store(sp + TM * (TM + 4), pn >> 2, plv);
+    else plb = msr3d_attn::stage_ploc<TM>(p.ploc, b, L, sp + TM * (TM + 4));
+    __syncthreads();
+    SB_STAMP(5);
+    f32x4 oq[2], ok[2], ov[2];
+    msr3d_attn::attn_bwd_core<TM, MSR3D_MMA_F32, true>(L, sq, sk, sv, sdo, sp, plb, scond, 8, p.pad + (size_t)b * L, sdc, 8,
+                                                       oq, ok, ov);
+    SB_STAMP(6);
+    // every wave is past the core's last barrier: the pairwise slab is dead, product 2's operand
+    // (FRAG planes, 4 slabs: [dq | dk | dv | dcond, 0]) goes on top of it.  The core hands dq / dk / dv over transposed:
+    // a lane holds columns 16 rn + 4 g .. + 3 of row 16 wave + j -- one 16-byte side-output store and one 8-byte LDS
+    // store per plane (they were four 4-byte and twelve 2-byte stores per tile and operand: 11 k cycles of the block)
+    unsigned char *mid = reinterpret_cast<unsigned char *>(sp + TM * (TM + 4));
+    {
+      const int row = 16 * wave + j;
+      const bool okr = row < L;
+#pragma unroll
+      for (int rn = 0; rn < 2; ++rn)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const f32x4 &src = a == 0 ? oq[rn] : a == 1 ? ok[rn] : ov[rn];
+          const float sc = a < 2 ? kInvSqrtDh : 1.0f;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = okr ? src[r] * sc : 0.f;
+          if (okr) st4(p.dqkvc + (size_t)(row_base + row) * ldq + a * KD + h * DH + 16 * rn + 4 * g, make_float4(v[0], v[1], v[2], v[3]));
+          uint2 pl[3];
+          sm_split4(v, pl);
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            *reinterpret_cast<uint2 *>(mid + frag_off4<4>(wave, j, 32 * a + 16 * rn + 4 * g, k)) = pl[k];
+        }
+    }
+    if (tid < TM) {                        // slab 3 of row `tid`: the six cond gradients, zeros behind them
+      const int row = tid;
+      float dc[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) dc[c] = (row < L && c < SD + 1) ? sdc[row * 8 + c] : 0.f;
+      if (row < L) {
+#pragma unroll
+        for (int c = 0; c < SD + 1; ++c) p.dqkvc[(size_t)(row_base + row) * ldq + 3 * KD + h * (SD + 1) + c] = dc[c];
+      }
+      uint4 pl[3];
+      sm_split8(dc, pl);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        unsigned char *d = mid + (((3 * 4 + (row >> 4)) * 3 + k) * 64 + (row & 15)) * 16;
+        *reinterpret_cast<uint4 *>(d) = pl[k];
+#pragma unroll
+        for (int gg = 1; gg < 4; ++gg) *reinterpret_cast<uint4 *>(d + gg * 256) = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+    __syncthreads();
+    f32x4 acc2[4][4];
+    zero_acc3(acc2);
+    const XFrag<4> xm{reinterpret_cast<const unsigned short *>(mid) + lane * 8};
+    gemm_split3<true, 4, 4, 4, RING>(xm, 0, w2, acc2, ring2);
+    SB_STAMP(7);
+    store_partials<4>(acc2, slab, row_base, L, 64 * wave, lane);
+  }
+  SB_STAMP(8);
+}
+
 template <int KIND, int NW = 4>
 int launch_block(const SB &p, int slices, hipStream_t s) {
   constexpr int lds = lds_bytes<KIND>();
@@ -928,6 +1113,17 @@ int msr3d_scene_block(const msr3d_scene_block_t *pp, msr3d_stream_t stream) {
     case MSR3D_BLK_ATTN_BWD:
       if (p.H != 8 || !p.w2 || !p.qkvc || !p.dqkvc || !p.ploc || !p.pad || !p.probs || p.ldq % 4) return MSR3D_EINVAL;
       if (p.w1_bytes < 8u * 16u * kPieceBytes || p.w2_bytes < 8u * 4u * 16u * kPieceBytes) return MSR3D_EINVAL;
+      {
+        static const bool v2 = [] { const char *v = getenv("MSR3D_ATTN_BWD_V2"); return !(v && v[0] == '0'); }();
+        if (v2) {
+          static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&scene_attn_bwd2_kernel),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                             lds_bytes<MSR3D_BLK_ATTN_BWD>());
+          if (attr != hipSuccess) return (int)attr;
+          scene_attn_bwd2_kernel<<<dim3(8, p.B), 256, lds_bytes<MSR3D_BLK_ATTN_BWD>(), s>>>(p);
+          return (int)hipGetLastError();
+        }
+      }
       return launch_block<MSR3D_BLK_ATTN_BWD>(p, 8, s);
     case MSR3D_BLK_LINEAR:
       if (p.N <= 0 || p.N % 256 || !p.C || p.ldc % 4 || p.w1_bytes < (unsigned)(8 * (p.N / 16)) * kPieceBytes) return MSR3D_EINVAL;
