@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 25
+#define MSR3D_ABI_VERSION 26
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -660,6 +660,13 @@ int msr3d_split_pack(int njobs, const msr3d_pack_job_t *jobs, const int *piece_p
  * word): the two are independent and open every step of the scene-block schedule. */
 int msr3d_split_pack_begin(int njobs, const msr3d_pack_job_t *jobs, const int *piece_prefix, int total_pieces,
                            float *zero_region, long long n_floats, unsigned long long *seed, msr3d_stream_t stream);
+
+/* C (M, ldc) = A (M, lda) . W^T + bias for a few hundred rows and a long reduction (K % 128 == 0, N % 32 == 0) on the
+ * bf16 matrix pipe at fp32 accuracy; W pre-split in msr3d_split_pack's layout ([K / 32][N / 16] pieces, transposed = 0).
+ * No K split: row-independent and bit-reproducible.  Replaces the f32-MFMA launch of the encoder's `fc`
+ * (/root/reference/modules/layers/pointnet.py:52-63).  a, C, w_pack, bias: 16-byte aligned. */
+int msr3d_rows_linear_split(int M, int N, int K, const float *a, int lda, const unsigned short *w_pack, unsigned w_bytes,
+                            const float *bias, float *C, int ldc, msr3d_stream_t stream);
 
 #define MSR3D_BLK_ATTN_FWD 0
 #define MSR3D_BLK_FFN_FWD 1

@@ -102,6 +102,7 @@ EPI = {"bias": 0, "gelu": 1, "gelubwd": 2}
 _SIGNATURES = {
     "msr3d_strip_gemm_f32": [ctypes.POINTER(StripGemm), _ptr],
     "msr3d_split_pack": [_c_int, _ptr, _ptr, _c_int, _ptr],
+    "msr3d_rows_linear_split": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, ctypes.c_uint, _ptr, _ptr, _c_int, _ptr],
     "msr3d_split_pack_begin": [_c_int, _ptr, _ptr, _c_int, _ptr, ctypes.c_longlong, _ptr, _ptr],
     "msr3d_wgrad_split_colsum": [_c_int, _ptr, _ptr, _c_int, _c_int, _ptr, _ptr],
     "msr3d_scene_block": [ctypes.POINTER(SceneBlock), _ptr],
@@ -241,7 +242,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string", "msr3d_sqdist_contract"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 25        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 26        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():

@@ -48,6 +48,7 @@ SOURCES = [
     ("scene_rows.hip", []),
     ("wgrad_split.hip", []),
     ("rows_gemm_split.hip", []),
+    ("rows_linear.hip", []),
 ]
 
 

@@ -299,6 +299,41 @@ def linear(x, weight, bias=None, gelu=False, stats_out=None):
     return F.gelu(y) if gelu else y
 
 
+def pack_split_weight(w):
+    """(N, K) fp32 weight -> the PACK operand of the split-MFMA kernels (include/msr3d_hip.h, msr3d_split_pack's layout,
+    transposed = 0): three exact bf16 terms, [K / 32 slabs][N / 16 tiles][3 planes][64 lanes][8] -- int16 tensor.
+    For weights that do not change between steps (a frozen `fc`); trainable ones go through msr3d_split_pack."""
+    n, k = w.shape
+    if n % 16 or k % 32:
+        raise ValueError("pack_split_weight: N % 16 == 0 and K % 32 == 0")
+    wf = w.detach().float()
+    w0 = wf.to(torch.bfloat16)
+    r1 = wf - w0.float()
+    w1 = r1.to(torch.bfloat16)
+    w2 = (r1 - w1.float()).to(torch.bfloat16)
+    planes = torch.stack([w0, w1, w2])                                              # (3, n, k)
+    frag = planes.view(3, n // 16, 16, k // 32, 4, 8).permute(3, 1, 0, 4, 2, 5)      # (s, t, p, g, i, j)
+    return frag.contiguous().reshape(-1).view(torch.int16)
+
+
+def rows_linear_split_ok(m, n, k):
+    return n % 32 == 0 and k % 128 == 0
+
+
+def rows_linear_split(x, pack, n_out, bias=None, out=None):
+    """y (M, n_out) = x (M, K) . W^T + bias with W as pack_split_weight / msr3d_split_pack left it (msr3d_rows_linear_split:
+    fp32 accuracy on the bf16 matrix pipe, no K split -- row-independent, bit-reproducible).  Forward only."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
+        raise ValueError("rows_linear_split: a 2-D fp32 GPU tensor with unit column stride")
+    M, K = x.shape
+    y = out if out is not None else torch.empty((M, n_out), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().msr3d_rows_linear_split(M, n_out, K, _p(x), x.stride(0), _p(pack), pack.numel() * 2, _p(bias),
+                                                 _p(y), y.stride(0), _lib.current_stream_ptr(x.device))
+    _lib.check(rc, "msr3d_rows_linear_split")
+    return y
+
+
 class _HipLinearPacked(torch.autograd.Function):
     """y = x Wp^T + bp where Wp / bp are VIEWS of the flat parameter buffer spanning several
     nn.Linear modules laid out back to back (q | k | v | cond projections), and their gradient

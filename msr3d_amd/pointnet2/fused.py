@@ -165,6 +165,11 @@ def get_plan(net):
     split3 = [_pack_layer_split(conv, bn, _KP0_SPLIT[2] if j == 0 else conv.in_channels, feat_first=(j == 0))
               for j, (conv, bn) in enumerate(pairs3)]
     plan = {"key": key, "levels": levels, "dims": dims, "split1": split1, "split2": split2, "split3": split3}
+    # `fc` on the split kernels too (msr3d_rows_linear_split): the frozen weight packed once per plan
+    from .. import hipops
+    n_out, k_in = net.fc.weight.shape
+    if hipops.rows_linear_split_ok(0, n_out, k_in) and net.fc.weight.is_cuda:
+        plan["fc_split"] = hipops.pack_split_weight(net.fc.weight)
     net._fused_plan = plan
     return plan
 
@@ -197,6 +202,8 @@ if _sa_mma[0] not in ("f32", "split", "split2"):
 _sa_rows = [_os.environ.get("MSR3D_SA_ROWS", "1") != "0"]
 # the planning launches of levels 1 and 2 as one (msr3d_sa_plan12); MSR3D_SA_PLAN12=0: each level plans in its own call
 _PLAN12 = _os.environ.get("MSR3D_SA_PLAN12", "1") != "0"
+# the encoder's `fc` on msr3d_rows_linear_split (bf16 x 3 split) instead of the f32-input MFMA panel kernel
+_FC_SPLIT = _os.environ.get("MSR3D_FC_SPLIT", "1") != "0"
 
 
 def set_sa_rows(on):
@@ -233,7 +240,7 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
     b, n, _ = pts.shape
     dev = pts.device
     plan = get_plan(net)
-    vmask = None
+    vmask = pad_feat = None
     if valid is not None:
         pad_feat = padding_feature(net, n, dev)
         vmask = valid.reshape(b).contiguous().view(torch.uint8)
@@ -347,6 +354,13 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
     res = out if (out is not None and vmask is None) else torch.empty((b, n_out), dtype=torch.float32, device=dev)
     if res.shape != (b, n_out) or not res.is_contiguous() or res.dtype != torch.float32:
         raise ValueError("out must be a contiguous (b, %d) float32 tensor" % n_out)
+    if _sa_mma[0] != "f32" and "fc_split" in plan and _FC_SPLIT:
+        # the bf16 matrix pipe at fp32 accuracy, as the levels (round 5; MSR3D_FC_SPLIT=0: the f32-input MFMA launch below)
+        from .. import hipops
+        hipops.rows_linear_split(pooled, plan["fc_split"], n_out, fc.bias, out=res)
+        return _fc_tail(res, out, vmask, valid, pad_feat, return_internals, dbg,
+                        dict(new_xyz1=new1, new_xyz2=new2, feat1=feat1, feat2=feat2, pooled=pooled, constant=constant)
+                        if return_internals else None)
     # one K run per tile on the panel kernel: no K-split, so an object's feature does not depend on
     # which other objects share the launch (and no atomics: bit-reproducible)
     arr = (_lib.GemmProblem * 1)()
@@ -367,6 +381,18 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
         dbg.update(new_xyz1=new1, new_xyz2=new2, feat1=feat1, feat2=feat2, pooled=pooled, constant=constant)
         return out, dbg
     return out
+
+
+def _fc_tail(res, out, vmask, valid, pad_feat, return_internals, dbg, internals):
+    if vmask is not None:
+        res = torch.where(valid.reshape(res.shape[0], 1), res, pad_feat)
+        if out is not None:
+            out.copy_(res)
+            res = out
+    if return_internals:
+        dbg.update(**internals)
+        return res, dbg
+    return res
 
 
 # per-row multiply-accumulates of the three levels' SharedMLPs (configs/msr3d.yaml:198-201)
