@@ -144,7 +144,8 @@ def test_bench_default_multi_rank_schedule_is_the_captured_exchange_after_its_se
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert j["config"]["exchange_inside_graph"] is True, out.stderr[-2000:]
     chk = j["comm"]["graph_comm_check"]
-    assert chk["captured"] is True and chk["max_abs_diff"] <= 1e-5 * chk["scale"]
+    assert chk["captured"] is True and chk["replica_checksum_spread"] == 0.0
+    assert chk["max_abs_diff"] <= 2.0 * chk["eager_moved"] + 1e-6 * chk["scale"] and chk["eager_moved"] > 0
     assert j["comm"]["ranks_seen"] == 1 and j["comm"]["replica_checksum_spread"] == 0.0 and j["value"] > 0
 
 
