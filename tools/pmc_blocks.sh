@@ -32,7 +32,7 @@ names = sorted({c for v in agg.values() for c in v})
 with open(out + "/summary.txt", "w") as fo:
     fo.write("# per-launch means; SQ_* summed over all waves / SEs; GRBM_GUI_ACTIVE summed over the 8 XCDs\n")
     for k, cs in sorted(agg.items()):
-        if "scene_block" not in k and "wgrad" not in k and "split_pack" not in k and "sa2" not in k:
+        if not any(t in k for t in ("scene_block", "scene_attn", "wgrad", "split_pack", "sa2", "rows_linear")):
             continue
         fo.write(k + "\n")
         for c in names:
