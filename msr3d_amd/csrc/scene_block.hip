@@ -802,10 +802,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // Wfc as [k = fc row][n = ctx column]: [8 slabs][16 tiles], tiles 2 h, 2 h + 1
     const WStream w1 = make_wstream(p.w1, p.w1_bytes, 16, 0, 2 * slice + (wave & 1), lane);
     SB_STAMP(0);
-#ifndef BW_R1
-#define BW_R1 8
-#endif
-    WPiece ring1[BW_R1];
+    WPiece ring1[8];
 #pragma unroll
     for (int q = 0; q < 4; ++q) load_wpiece(ring1[q], w1, q, 0);
     uint4 xv[24];
@@ -852,7 +849,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const float *plsrc2 = plsrc;
       asm volatile("" : "+s"(w1b.soff), "+s"(plsrc2) : : "memory");
 #pragma unroll
-      for (int q = 4; q < BW_R1; ++q) load_wpiece(ring1[q], w1b, q, 0);
+      for (int q = 4; q < 8; ++q) load_wpiece(ring1[q], w1b, q, 0);
       if (pvec) msr3d_attn::ploc_fetch(plsrc2, pn >> 2, plv);
     }
     SB_STAMP(1);
@@ -865,7 +862,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // d ctx_h = d_fc Wfc[:, 32 h : 32 h + 32]: wave (wr, wc) owns row tiles 2 wr, 2 wr + 1 and column tile wc
     f32x4 acc[1][2];
     zero_acc3(acc);
-    gemm_split3<true, 1, 2, KS1, BW_R1>(xr, 2 * (wave >> 1), w1, acc, ring1);
+    gemm_split3<true, 1, 2, KS1, 8>(xr, 2 * (wave >> 1), w1, acc, ring1);
     SB_STAMP(3);
     WPiece ring2[RING];
     preload_wring<4, RING>(ring2, w2);
