@@ -941,6 +941,267 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   SB_STAMP(8);
 }
 
+// =====================================================================================================
+// Attention block, backward, EIGHT waves (two per SIMD) with the core's work split over all of them
+// (scene_attn_bwd2_kernel's four waves each carried 16 (query, key) pairs per lane through the softmax /
+// sigmoid backward: 14-15 k of the block's 47 k cycles).  Wave (t, kh): query / key tile t, key half kh.
+//   d P     16 queries x the half's 32 keys                      (was: x 64)
+//   d v     tile t's 16 keys x column half kh, over all queries   (was: x 32 columns)
+//   softmax / sigmoid backward on 8 pairs per lane; the row's  sum_k p dP  and the six cond gradients are partial
+//           sums over a key half that meet through LDS in half order (deterministic)
+//   d q, d k  tile t's 16 rows x column half kh
+// Product 1 (d ctx) is one tile-unit per wave, product 2 two column tiles per wave.  Everything else as bwd2: inputs
+// requested up front, product 1's eight pieces in registers before the pairwise slab is asked for, transposed core
+// outputs.  MSR3D_ATTN_BWD=2 selects scene_attn_bwd2_kernel, =0 scene_block_kernel<ATTN_BWD>.
+// =====================================================================================================
+constexpr int kAttnBwd3Aux = kAttnBwdAux + 2 * 64 * 4 + 2 * 64 * 8 * 4;     // + row dots [2][64] + cond partials [2][64][8]
+constexpr int kAttnBwd3Lds = XS_BYTES + kAttnBwd3Aux;
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void scene_attn_bwd3_kernel(const SB p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned short *xs = reinterpret_cast<unsigned short *>(smem);
+  unsigned char *aux = smem + XS_BYTES;
+  const int h = blockIdx.x, b = blockIdx.y, L = p.L, H = p.H, ldq = p.ldq;
+  const int row_base = b * L;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  float *const slab = p.part + (size_t)h * p.part_stride;
+  constexpr int KS1 = KD / 32, LDP = TM + 4;
+  float *sq = reinterpret_cast<float *>(aux), *sk = sq + TM * LD32, *sv = sk + TM * LD32, *sdo = sv + TM * LD32;
+  float *scond = sdo + TM * LD32, *sdc = scond + TM * 8;
+  float *xdot = sdc + TM * 8, *xg = xdot + 2 * 64;
+  // Wfc as [k = fc row][n = ctx column]: [8 slabs][16 tiles], tiles 2 h, 2 h + 1
+  const WStream w1 = make_wstream(p.w1, p.w1_bytes, 16, 0, 2 * h + (wave & 1), lane);
+  SB_STAMP(0);
+  WPiece ring1[8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) load_wpiece(ring1[q], w1, q, 0);
+  // the scene's planes, the head's saved q / k / v (one float4 a thread and tile), cond, probabilities
+  uint4 xv[12];
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(p.xp + (size_t)b * 3 * TM * KD);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) xv[k] = src[tid + 512 * k];
+  }
+  float4 tq[3];
+  {
+    const int row = tid >> 3, c4 = (tid & 7) * 4;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      tq[t] = row < L ? ld4(p.qkvc + (size_t)(row_base + row) * ldq + t * KD + h * DH + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float tc;
+  {
+    const int row = tid >> 3, c = tid & 7;
+    tc = (row < L && c < SD + 1) ? p.qkvc[(size_t)(row_base + row) * ldq + 3 * KD + h * (SD + 1) + c] : 0.f;
+  }
+  const float *plsrc = p.ploc + (size_t)b * L * L * SD, *prsrc = p.probs + ((size_t)b * H + h) * L * L;
+  const int pn = L * L * SD, qn4 = (L * L) >> 2;
+  const bool pvec = (reinterpret_cast<uintptr_t>(plsrc) & 15u) == 0 && (pn & 3) == 0;
+  const bool qvec = (reinterpret_cast<uintptr_t>(prsrc) & 15u) == 0 && (L & 3) == 0;
+  float4 prv[2], plv[10];
+  // (hipcc drains every load in flight at a __syncthreads: the slab is asked for WITH the planes, not behind them)
+  if (pvec) {
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const int e = tid + 512 * k;
+      plv[k] = e < (pn >> 2) ? reinterpret_cast<const float4 *>(plsrc)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  if (qvec) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = tid + 512 * k;
+      prv[k] = e < qn4 ? reinterpret_cast<const float4 *>(prsrc)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  {
+    const int row = tid >> 3, c4 = (tid & 7) * 4;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) st4(sq + t * TM * LD32 + row * LD32 + c4, tq[t]);
+    scond[tid] = tc;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const int q = tid + 512 * k;
+      const int plane = q >> 11, row2 = (q >> 5) & 63, c8 = q & 31;
+      *reinterpret_cast<uint4 *>(xs + plane * PLANE + row2 * PITCH + c8 * 8) = xv[k];
+    }
+  }
+  // (the planes' registers are free) the rest of product 1's pieces
+#pragma unroll
+  for (int q = 4; q < 8; ++q) load_wpiece(ring1[q], w1, q, 0);
+  SB_STAMP(1);
+  __syncthreads();
+  SB_STAMP(2);
+  const XRows xr = make_xrows(xs, PITCH, TM, lane);
+  // product 2's stream: the head's gathered rows of W_qkvc as [k = 128 head columns][n = 256]: [4 slabs][16 tiles]
+  const WStream w2 = make_wstream(p.w2 + (size_t)h * (4 * 16 * kPieceBytes / 2), 4 * 16 * kPieceBytes, 16, 0, 2 * wave, lane);
+  {
+    // d ctx_h = d_fc Wfc[:, 32 h : 32 h + 32]: wave (rt, ct) owns row tile rt and column tile ct
+    const int rt = wave >> 1;
+    f32x4 acc[1][1];
+    zero_acc3(acc);
+    gemm_split3<true, 1, 1, KS1, 8>(xr, rt, w1, acc, ring1);
+    const int row = 16 * rt + j;
+    const float4 v = row < L ? make_float4(acc[0][0][0], acc[0][0][1], acc[0][0][2], acc[0][0][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    st4(sdo + row * LD32 + 16 * (wave & 1) + 4 * g, v);
+  }
+  SB_STAMP(3);
+  WPiece ring2[RING];
+  preload_wring<2, RING>(ring2, w2);
+  __syncthreads();                         // planes free; q / k / v / cond / d ctx visible
+  float *sp = reinterpret_cast<float *>(xs);
+  float *spl = sp + TM * LDP;
+  if (qvec) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = tid + 512 * k;
+      if (e < qn4) {
+        const int idx = 4 * e, row = idx / L, col = idx - row * L;
+        *reinterpret_cast<float4 *>(sp + row * LDP + col) = prv[k];
+      }
+    }
+    for (int e = tid; e < 64 * 64; e += 512) {
+      const int row = e >> 6, col = e & 63;
+      if (row >= L || col >= L) sp[row * LDP + col] = 0.f;
+    }
+  } else {
+    msr3d_attn::load_probs_tile<TM>(prsrc, L, sp);
+  }
+  const float *plb = spl;
+  if (pvec) {
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const int e = tid + 512 * k;
+      if (e < (pn >> 2)) reinterpret_cast<float4 *>(spl)[e] = plv[k];
+    }
+  } else {
+    plb = msr3d_attn::stage_ploc<TM>(p.ploc, b, L, spl);
+  }
+  __syncthreads();
+  SB_STAMP(5);
+  // ---- the core: wave (t, kh) ----
+  const int t = wave & 3, kh = wave >> 2, row0 = 16 * t, i = j;
+  f32x4 oq[1], ok[1], ov[1];
+  {
+    f32x4 dP[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    msr3d_attn::strip_mma<MSR3D_MMA_F32, 2, DH, true, true>(sdo, LD32, sv + 32 * kh * LD32, LD32, row0, dP, lane);
+    ov[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    msr3d_attn::strip_mma<MSR3D_MMA_F32, 1, TM, false, false, true>(sp, LDP, sdo + 16 * kh, LD32, row0, ov, lane);
+    __syncthreads();                       // every wave is done reading P as a matrix operand
+    const unsigned char *pad_b = p.pad + (size_t)b * L;
+    bool keyok[2];
+#pragma unroll
+    for (int rn = 0; rn < 2; ++rn) {
+      const int col = 32 * kh + 16 * rn + i;
+      keyok[rn] = col < L && !pad_b[min(col, L - 1)];
+    }
+    float pr[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * g + r;
+      float dot = 0.f;
+#pragma unroll
+      for (int rn = 0; rn < 2; ++rn) {
+        pr[r][rn] = sp[row * LDP + 32 * kh + 16 * rn + i];
+        dot = fmaf(pr[r][rn], dP[rn][r], dot);
+      }
+      dot = msr3d_attn::row16_sum(dot);
+      if (i == 0) xdot[kh * 64 + row] = dot;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * g + r;
+      const float dot = xdot[row] + xdot[64 + row];
+      const msr3d_attn::RowCond c = msr3d_attn::load_cond(scond, 8, L, row);
+      float gb = 0.f, gw[SD];
+#pragma unroll
+      for (int d = 0; d < SD; ++d) gw[d] = 0.f;
+#pragma unroll
+      for (int rn = 0; rn < 2; ++rn) {
+        const int col = 32 * kh + 16 * rn + i;
+        const float dlogit = pr[r][rn] * (dP[rn][r] - dot);          // softmax backward
+        sp[row * LDP + col] = dlogit;                                // in place: this lane owns the element
+        if (row < L && keyok[rn]) {
+          const float *pl = plb + ((size_t)row * L + col) * SD;
+          float z = c.bias;
+#pragma unroll
+          for (int d = 0; d < SD; ++d) z = fmaf(c.w[d], pl[d], z);
+          const float loc = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+          const float dz = (loc >= 1e-6f) ? dlogit * (1.0f - loc) : 0.f;   // (attn_core.h: d log(max(loc, 1e-6)) / dz)
+          gb += dz;
+#pragma unroll
+          for (int d = 0; d < SD; ++d) gw[d] = fmaf(dz, pl[d], gw[d]);
+        }
+      }
+      gb = msr3d_attn::row16_sum(gb);
+#pragma unroll
+      for (int d = 0; d < SD; ++d) gw[d] = msr3d_attn::row16_sum(gw[d]);
+      if (i == 0) {
+        float *o = xg + (size_t)(kh * 64 + row) * 8;
+        o[0] = gb;
+#pragma unroll
+        for (int d = 0; d < SD; ++d) o[1 + d] = gw[d];
+      }
+    }
+    __syncthreads();                       // d S complete; the pairwise slab is dead; the cond partials visible
+    oq[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ok[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    msr3d_attn::strip_mma<MSR3D_MMA_F32, 1, TM, true, false, true>(sp, LDP, sk + 16 * kh, LD32, row0, oq, lane);
+    msr3d_attn::strip_mma<MSR3D_MMA_F32, 1, TM, false, false, true>(sp, LDP, sq + 16 * kh, LD32, row0, ok, lane);
+  }
+  SB_STAMP(6);
+  // product 2's operand (FRAG planes, 4 slabs: [dq | dk | dv | dcond, 0]) on top of the dead pairwise slab; side outputs
+  unsigned char *mid = reinterpret_cast<unsigned char *>(spl);
+  {
+    const int row = row0 + j;
+    const bool okr = row < L;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const f32x4 &src = a == 0 ? oq[0] : a == 1 ? ok[0] : ov[0];
+      const float sc = a < 2 ? kInvSqrtDh : 1.0f;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = okr ? src[r] * sc : 0.f;
+      if (okr) st4(p.dqkvc + (size_t)(row_base + row) * ldq + a * KD + h * DH + 16 * kh + 4 * g, make_float4(v[0], v[1], v[2], v[3]));
+      uint2 pl[3];
+      sm_split4(v, pl);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        *reinterpret_cast<uint2 *>(mid + frag_off4<4>(t, j, 32 * a + 16 * kh + 4 * g, k)) = pl[k];
+    }
+  }
+  if (tid < TM) {                          // slab 3 of row `tid`: the six cond gradients (half 0 + half 1), zeros behind them
+    const int row = tid;
+    float dc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dc[c] = (row < L && c < SD + 1) ? xg[row * 8 + c] + xg[(64 + row) * 8 + c] : 0.f;
+    if (row < L) {
+#pragma unroll
+      for (int c = 0; c < SD + 1; ++c) p.dqkvc[(size_t)(row_base + row) * ldq + 3 * KD + h * (SD + 1) + c] = dc[c];
+    }
+    uint4 pl[3];
+    sm_split8(dc, pl);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      unsigned char *d = mid + (((3 * 4 + (row >> 4)) * 3 + k) * 64 + (row & 15)) * 16;
+      *reinterpret_cast<uint4 *>(d) = pl[k];
+#pragma unroll
+      for (int gg = 1; gg < 4; ++gg) *reinterpret_cast<uint4 *>(d + gg * 256) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  __syncthreads();
+  f32x4 acc2[2][4];
+  zero_acc3(acc2);
+  const XFrag<4> xm{reinterpret_cast<const unsigned short *>(mid) + lane * 8};
+  gemm_split3<true, 2, 4, 4, RING>(xm, 0, w2, acc2, ring2);
+  SB_STAMP(7);
+  store_partials<2>(acc2, slab, row_base, L, 32 * wave, lane);
+  SB_STAMP(8);
+}
+
 template <int KIND, int NW = 4>
 int launch_block(const SB &p, int slices, hipStream_t s) {
   constexpr int lds = lds_bytes<KIND>();
@@ -1111,8 +1372,17 @@ int msr3d_scene_block(const msr3d_scene_block_t *pp, msr3d_stream_t stream) {
       if (p.H != 8 || !p.w2 || !p.qkvc || !p.dqkvc || !p.ploc || !p.pad || !p.probs || p.ldq % 4) return MSR3D_EINVAL;
       if (p.w1_bytes < 8u * 16u * kPieceBytes || p.w2_bytes < 8u * 4u * 16u * kPieceBytes) return MSR3D_EINVAL;
       {
+        // 3 (default): eight waves, the core split over all of them; 2: scene_attn_bwd2_kernel; 0: scene_block_kernel<ATTN_BWD>
+        static const int ver = [] { const char *v = getenv("MSR3D_ATTN_BWD"); return (v && v[0] >= '0' && v[0] <= '3') ? v[0] - '0' : 3; }();
+        if (ver == 3) {
+          static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&scene_attn_bwd3_kernel),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, kAttnBwd3Lds);
+          if (attr != hipSuccess) return (int)attr;
+          scene_attn_bwd3_kernel<<<dim3(8, p.B), 512, kAttnBwd3Lds, s>>>(p);
+          return (int)hipGetLastError();
+        }
         static const bool v2 = [] { const char *v = getenv("MSR3D_ATTN_BWD_V2"); return !(v && v[0] == '0'); }();
-        if (v2) {
+        if (v2 && ver != 0) {
           static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&scene_attn_bwd2_kernel),
                                                              hipFuncAttributeMaxDynamicSharedMemorySize,
                                                              lds_bytes<MSR3D_BLK_ATTN_BWD>());
