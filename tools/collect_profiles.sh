@@ -36,7 +36,8 @@ v env MSR3D_SA3_TILE=2 python bench.py --no-cpu-baseline
 v env MSR3D_WGRAD_HALVES=1 python bench.py --no-cpu-baseline
 v env MSR3D_ATTN_FWD_WAVES=4 MSR3D_ATTN_FWD_SPLIT=0 python bench.py --no-cpu-baseline
 v env MSR3D_ATTN_FWD_SPLIT=0 python bench.py --no-cpu-baseline
-v env MSR3D_ATTN_BWD_V2=0 python bench.py --no-cpu-baseline
+v env MSR3D_ATTN_BWD=2 python bench.py --no-cpu-baseline
+v env MSR3D_ATTN_BWD=0 python bench.py --no-cpu-baseline
 v env MSR3D_FC_SPLIT=0 python bench.py --no-cpu-baseline
 v env MSR3D_FFN_WAVES=4 python bench.py --no-cpu-baseline
 v env MSR3D_SA_PLAN12=0 python bench.py --no-cpu-baseline
