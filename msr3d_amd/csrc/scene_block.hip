@@ -1001,7 +1001,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const bool pvec = (reinterpret_cast<uintptr_t>(plsrc) & 15u) == 0 && (pn & 3) == 0;
   const bool qvec = (reinterpret_cast<uintptr_t>(prsrc) & 15u) == 0 && (L & 3) == 0;
   float4 prv[2], plv[10];
-  // (hipcc drains every load in flight at a __syncthreads: the slab is asked for WITH the planes, not behind them)
+  // (the slab is asked for WITH the planes: behind them and ahead of product 1's last pieces it was waited for with those
+  //  pieces -- loads complete in order)
   if (pvec) {
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
