@@ -76,10 +76,15 @@ def parse():
                     "a bench step is then one OPTIMISER step = accum micro-batches")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", action="store_true", help="overlap the frozen encoder of batch "
-                    "k+1 (side stream) with the trainable part of batch k: +5 %% samples/s, but the "
-                    "encoder kernels then share the chip and their event-timed durations (the "
-                    "roofline leg) stretch by ~15 %%, so it is off by default")
+    ap.add_argument("--pipeline", action="store_true", help="(default since round 6) overlap the frozen encoder of batch "
+                    "k+1 (side stream) with the trainable part of batch k; every step still encodes one batch and "
+                    "trains one batch.  The roofline leg no longer times kernels inside the timed region: they are "
+                    "event-timed in an eager, un-pipelined census pass after it (roofline.timed)")
+    ap.add_argument("--no-pipeline", action="store_true", help="encoder and trainable part of a batch back to back on "
+                    "one stream (rounds 1-5's default)")
+    ap.add_argument("--census-steps", type=int, default=5, help="steps of the kernel census (0: no roofline leg)")
+    ap.add_argument("--dense", action="store_true", help="variant line: the distinct-row kernels' WORST case -- every "
+                    "ball query of both levels finds >= 32 different points, no padding slots (synth_batch(dense=True))")
     ap.add_argument("--from-store", action="store_true", help="also build every step's batch on the "
                     "device from HBM-resident scans (msr3d_amd.data: object selection, rotation, "
                     "subsample, normalise, padding) inside the timed region; default: batches "
@@ -138,6 +143,7 @@ def parse():
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 4 if args.full_step else 16
+    args.pipeline = not args.no_pipeline
     return args
 
 
@@ -269,6 +275,9 @@ def cpu_baseline(args, seconds):
         return {"value": 1.0 / q(0.5), "unit": "samples/s", "cores": cores, "kind": "port",
                 "median_s_per_sample": q(0.5), "p10_s": q(0.10), "p90_s": q(0.90), "mean_value": n / el,
                 "one_thread_value": 1.0 / one[len(one) // 2], "one_thread_steps": len(one),
+                "thread_scaling_note": (f"{cores} of {avail} available hardware threads: {q(0.5) and (one[len(one) // 2] / q(0.5)):.2f}x the "
+                                        "one-thread rate -- a batch-1 step is small GEMMs (60 x 256 tokens) and the serial FPS chain, "
+                                        "which stop scaling after a few cores; a stated port, a baseline, never the target"),
                 "host": {"cpu": host, "hw_threads": os.cpu_count(), "threads_available": avail},
                 "sample": f"{n} steps of batch 1 ({O} obj x {P} pts) in {el:.1f}s after 3 warm-ups: C oracle "
                           "(OpenMP) for the 9 ops + torch-CPU mirror, fwd+bwd+AdamW; value = 1 / median step"}
@@ -584,6 +593,174 @@ def llm_stack_line(args):
         dist.destroy_process_group()
 
 
+def kernel_census(tr, batches, steps, run_window, first):
+    """-> {entry key: {"us": mean launch duration, "per_step": launches per step}}"""
+    from msr3d_amd import _lib
+    st = tr.stepper
+    graph, st.graph = st.graph, None                 # eager issue: __call__ takes _train_part() / _micro_step()
+    saved_step = tr.step
+    plain = lambda b, nb=None: saved_step(b, None)   # noqa: E731 -- un-pipelined: no next batch on the side stream
+    tr.step = plain
+    sink = {}
+    try:
+        run_window(first)                            # one untimed eager step (lazy allocations of the eager path)
+        torch.cuda.synchronize()
+        _lib.set_timing_sink(sink, census=True)
+        for i in range(steps):
+            run_window(first + 1 + i)
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_timing_sink(None)
+        st.graph, tr.step = graph, saved_step
+    return {k: {"us": 1e3 * sum(a.elapsed_time(b) for a, b in v) / len(v), "per_step": len(v) / steps}
+            for k, v in sink.items() if v}
+
+
+# entry key -> the HIP kernel it launches at the bench shape (names as rocprofv3 prints them, for the PMC summaries)
+CENSUS_KERNELS = {
+    "msr3d_sa_fps2_query_flags": "fps_query_kernel", "msr3d_sa_plan12": "sa12_plan_kernel",
+    "msr3d_sa_level1_rows": "sa1_rows_kernel", "msr3d_sa_level2_rows": "sa2_rows_kernel",
+    "msr3d_sa_level_split[1]": "sa1_split_kernel", "msr3d_sa_level_split[2]": "sa2_split_kernel",
+    "msr3d_sa_level_split[3]": "sa3_split4_kernel", "msr3d_rows_linear_split": "rows_linear_kernel",
+    "msr3d_split_pack_begin": "split_pack_kernel", "msr3d_gemm_multi_f32": "panel_multi_kernel",
+    "msr3d_pos_embed_fwd": "pos_embed_fwd_kernel", "msr3d_pos_embed_bwd": "pos_embed_bwd_kernel",
+    "msr3d_scene_block[attn_fwd]": "scene_attn_fwd2_kernel", "msr3d_scene_block[attn_bwd]": "scene_attn_bwd3_kernel",
+    "msr3d_scene_block[ffn_fwd]": "scene_block_kernel<1, 8>", "msr3d_scene_block[ffn_bwd]": "scene_block_kernel<2, 8>",
+    "msr3d_scene_block[linear]": "scene_block_kernel<4, 4>", "msr3d_scene_block[linear_ksplit]": "scene_block_kernel<5, 4>",
+    "msr3d_wgrad_split_mixed": "wgrad_mixed_kernel", "msr3d_wgrad_split_colsum": "wgrad_split_kernel",
+    "msr3d_wgrad_split": "wgrad_split_kernel", "msr3d_wgrad_pipe": "wgrad_pipe_kernel",
+    "msr3d_adamw_flat_scaled": "adamw_kernel (+ sumsq_kernel)", "msr3d_dot_f32": "dot_kernel",
+    "msr3d_scene_prologue": "scene_prologue_kernel",
+}
+
+
+def pmc_counters_from_profiles():
+    """{kernel name: {counter: value}} from the NEWEST committed PMC summaries (profiles/*pmc_blocks*.txt, *pmc_sa*.txt:
+    tools/pmc_blocks.sh / pmc_sa.sh, counters in their own rocprofv3 --pmc passes) + the files they came from."""
+    import glob
+    import re
+    out, used = {}, []
+    for pat in ("*pmc_sa*.txt", "*pmc_blocks*.txt"):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
+        if not files:
+            continue
+        used.append(os.path.relpath(files[-1], ROOT))
+        block = None
+        for line in open(files[-1]):
+            if not line.startswith((" ", "#")) and line.strip():
+                block = line.strip()
+                out.setdefault(block, {})
+            m = re.match(r"\s+([A-Za-z0-9_]+)\s+([0-9.eE+]+)", line)
+            if m and block:
+                out[block][m.group(1)] = float(m.group(2))
+    return out, used
+
+
+def census_table(census, model, world_rows, E, level_flops):
+    """One row per entry point: duration, launches per step, the FLOPs the RESULT needs (fp32 products counted once,
+    whatever the number of bf16 MFMA products each takes), their rate against the fp32-accurate roof (2500 / 6 TFLOP/s),
+    the matrix-pipe busy fraction of the newest committed PMC pass."""
+    sched = getattr(model, "_schedule", None)
+    dm = getattr(sched, "dims", None) or {}
+    Bs, L, M, D, W, H, FF = (dm.get(k, 0) for k in ("B", "L", "M", "D", "W", "H", "FF"))
+    KE = dm.get("KE", 768)
+    flop = dict(level_flops)
+    if M:
+        core = 2.0 * Bs * H * L * L * (D // max(H, 1))                       # one (L x L x 32) product per head and scene
+        flop.update({
+            "msr3d_scene_block[attn_fwd]": 2.0 * M * D * W + 2 * core + 2.0 * M * D * D,        # qkvc | QK^T, PV | out-proj
+            "msr3d_scene_block[attn_bwd]": 2.0 * M * D * D + 4 * core + 2.0 * M * W * D,        # d ctx | dP dV dQ dK | d x
+            "msr3d_scene_block[ffn_fwd]": 4.0 * M * D * FF, "msr3d_scene_block[ffn_bwd]": 4.0 * M * D * FF,
+            "msr3d_scene_block[linear]": 2.0 * M * D * E, "msr3d_scene_block[linear_ksplit]": 2.0 * M * D * E,
+            "msr3d_gemm_multi_f32": 2.0 * M * KE * D,
+        })
+        wg = getattr(sched, "wgrad", None)
+        if wg is not None:
+            f = sum(2.0 * p.M * p.n_out * p.k_in for p in wg.probs)
+            for k in ("msr3d_wgrad_split_mixed", "msr3d_wgrad_split_colsum", "msr3d_wgrad_split", "msr3d_wgrad_pipe"):
+                flop[k] = f
+    flop["msr3d_rows_linear_split"] = 2.0 * world_rows * 768 * 768
+    pmc, pmc_files = pmc_counters_from_profiles()
+    peak = MFMA_BF16_PEAK_TF / SPLIT_PRODUCTS
+    rows = {}
+    for k, v in census.items():
+        kern = CENSUS_KERNELS.get(k, k)
+        r = {"kernel": kern, "us": round(v["us"], 2), "launches_per_step": v["per_step"]}
+        if k in flop and v["us"] > 0:
+            tf = flop[k] / (v["us"] * 1e-6) / 1e12
+            r.update({"useful_gflop": round(flop[k] / 1e9, 3), "achieved_tflops": round(tf, 2), "frac": round(tf / peak, 4)})
+        for name, c in pmc.items():
+            if kern.split(" ")[0] in name and "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("GRBM_GUI_ACTIVE", 0) > 0:
+                # busy cycles summed over the chip's 1024 SIMDs / (1024 x the launch's cycles; GRBM_GUI_ACTIVE sums 8 XCDs)
+                r["mfma_busy_pmc"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0), 4)
+                if "FETCH_SIZE" in c and "WRITE_SIZE" in c:      # KiB; FETCH_SIZE x 2: the gfx950 calibration of the guide
+                    r["hbm_bytes_pmc"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+                break
+        rows[k] = r
+    return rows, pmc_files
+
+
+def measure_variant(args, device, steps=12, warmup=3, **over):
+    """The default step on other inputs (bench.py's extra.* lines): fresh model, trainer and batches -> ms per step."""
+    import copy
+    from msr3d_amd.synth import synth_batch
+    a = copy.copy(args)
+    for k, v in over.items():
+        setattr(a, k, v)
+    from msr3d_amd import scene_blocks
+    prev_mma = scene_blocks.set_train_mma(getattr(a, "train_mma", None)) if getattr(a, "train_mma", None) else None
+    model = build(a, device)
+    batches = [synth_batch(7000 + i, a.batch, O=O, P=P, device=device, dense=a.dense) for i in range(4)]
+    tr = Trainer(model, device, batches[0], a.llm_hidden, use_graph=True)
+    nxt = (lambda i: batches[(i + 1) % 4]) if a.pipeline else (lambda i: None)
+    for i in range(warmup):
+        tr.step(batches[i % 4], nxt(i))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.step(batches[(warmup + i) % 4], nxt(warmup + i))
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    from msr3d_amd.pointnet2 import fused as _fused
+    net = model.visual_prompter.obj_encoder.pcd_net
+    st = _fused.row_statistics(net, batches[0]["obj_fts"].reshape(-1, P, 6))
+    res = {"value": a.batch * steps / el, "unit": "samples/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": warmup,
+           "distinct_rows_per_launch": {f"level{l}": st[l]["distinct_rows"] for l in (1, 2)},
+           "nominal_rows_per_launch": {f"level{l}": st[l]["nominal_rows"] for l in (1, 2)},
+           "constant_objects": st["constant_objects"],
+           "schedule": "blocks" if getattr(getattr(model, "_schedule", None), "_ran_blocks", False) else "strips/modular"}
+    if getattr(a, "train_mma", None):
+        # how far the reduced variant's outputs are from the fp32-accurate path: same weights, same batch, dropout off
+        res["rel_l2_vs_f32"] = train_mma_distance(model, batches[0])
+        scene_blocks.set_train_mma(prev_mma)
+    del tr, model, batches
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
+def train_mma_distance(model, batch):
+    """rel-L2 of obj_tokens / scene_embeds of the CURRENT trainable-part arithmetic against the fp32-accurate blocks."""
+    from msr3d_amd import scene_blocks
+    outs = {}
+    cur = scene_blocks.train_mma()
+    drops = [(m, m.p) for m in model.modules() if isinstance(m, torch.nn.Dropout)]
+    try:
+        for m, _ in drops:          # (the schedule reads the modules' p: masks are keyed by a per-forward salt, so the two
+            m.p = 0.0               #  passes could not draw the same ones)
+        for mode in (cur, "f32"):
+            scene_blocks.set_train_mma(mode)
+            out = model(dict(batch))
+            outs[mode] = (out["obj_tokens"].detach().double().clone(), out["scene_embeds"].detach().double().clone())
+    finally:
+        scene_blocks.set_train_mma(cur)
+        for m, p0 in drops:
+            m.p = p0
+    a, b = outs[cur], outs["f32"]
+    return {"obj_tokens": float((a[0] - b[0]).norm() / b[0].norm()), "scene_embeds": float((a[1] - b[1]).norm() / b[1].norm())}
+
+
 def main():
     global O, P
     args = parse()
@@ -652,7 +829,7 @@ def main():
     calls = 1 if wstep else args.accum                    # step calls per optimiser step
     Bcall = B * args.accum if wstep else B                # scenes per call
     n_resident = 4 if calls == 1 else max(4, 2 * calls)     # (a window's micro-batches are distinct)
-    batches = [synth_batch(1000 * rank + i, Bcall, O=O, P=P, device=device) for i in range(n_resident)]
+    batches = [synth_batch(1000 * rank + i, Bcall, O=O, P=P, device=device, dense=args.dense) for i in range(n_resident)]
     tr = Trainer(model, device, batches[0], args.llm_hidden, use_graph=not args.no_graph, accum=calls,
                  micro=args.accum if wstep else 1)
 
@@ -755,19 +932,13 @@ def main():
         tr.dp.comm_events.clear()
         tr.dp.wait_events.clear()
 
-    # the roofline leg needs the dominant kernel's duration, measured inside the timed region
-    # (the three SharedMLP levels are within ~30 % of one another since the distinct-row kernels of round 5: all three
-    #  are timed and the slowest is the line's roofline kernel)
-    timed = (["msr3d_sa_fps2", "msr3d_sa_level1", "msr3d_sa_level2", "msr3d_sa_level3"]
-             if args.time_all_kernels else ["msr3d_sa_level1", "msr3d_sa_level2", "msr3d_sa_level3"])
-    sink = {k: [] for k in timed}
+    # The timed region carries NO per-kernel instrumentation (round 6): an event pair idles the GPU for ~12 us around a
+    # launch and, with the next batch's encoder on the side stream, would time kernels that share the chip.  The
+    # roofline leg's durations come from the kernel census below, after the timed region.
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
-    # (event-timed on every 6th step: an event pair idles the GPU for ~12 us around the launch)
-    time_every = 1 if (args.time_all_kernels or args.steps < 16) else 6
-    _lib.set_timing_sink(sink, every=time_every)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step spread
     t0 = time.perf_counter()
     marks[0].record()
@@ -779,7 +950,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    _lib.set_timing_sink(None)
+
+    # Kernel census: `--census-steps` more steps of the SAME work, eagerly issued (no graph), un-pipelined, EVERY launch
+    # of the library bracketed by HIP events on the launching stream (msr3d_amd/_lib.py::_Entry) -> mean duration per
+    # entry point and launches per step.  Run on every rank (the steps hold the gradient exchange), read on rank 0.
+    census = kernel_census(tr, batches, args.census_steps, run_window, args.warmup + args.steps) if args.census_steps > 0 else {}
 
     # MSR3D_DP_GRAPH_COMM=1: the RCCL call was captured with the rest, the step is one graph at N > 1 as well
     whole_graph = tr.stepper.graph is not None and not tr.stepper.split
@@ -813,9 +988,17 @@ def main():
         value = B * args.accum * world * args.steps / elapsed
         per_step = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
         pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]   # noqa: E731
-        # Per-launch durations from HIP events on the launching stream (msr3d_amd/_lib.py).
-        kern_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / len(v) if v else None)
-                   for k, v in sink.items()}
+        # Per-launch durations: the census after the timed region (eager, un-pipelined, HIP events around every launch).
+        cus = lambda k: census.get(k, {}).get("us", 0.0)               # noqa: E731
+        rows_keys = {1: ("msr3d_sa_plan12", "msr3d_sa_level1_rows"), 2: ("msr3d_sa_level2_rows",), 3: ("msr3d_sa_level_split[3]",)}
+        kern_ms = {}
+        for lvl in (1, 2, 3):
+            t = sum(cus(k) for k in rows_keys[lvl])
+            if lvl < 3 and not cus(rows_keys[lvl][-1]):                  # the all-rows kernels (MSR3D_SA_ROWS=0 / f32 MFMA path)
+                t = cus(f"msr3d_sa_level_split[{lvl}]") or cus(f"msr3d_sa_level[{lvl}]")
+            if lvl == 3 and not t:
+                t = cus("msr3d_sa_level[3]")
+            kern_ms[f"msr3d_sa_level{lvl}"] = t / 1e3 if t else None
         # Roofline leg: the three SharedMLP levels of the frozen encoder (98 % of the path's FLOPs), each priced as
         #   frac = FLOPs of the DISTINCT rows the result needs / launch time / peak
         # with the nominal figure of SURVEY.md 8(d) (every one of the 32 neighbourhood slots multiplied: 512 x
@@ -853,6 +1036,10 @@ def main():
                     "nominal_tflops": tf(nom), "mfma_executed_tflops": tf(pip) * (SPLIT_PRODUCTS if split else 1),
                     "mfma_pipe_frac": (tf(pip) * SPLIT_PRODUCTS / MFMA_BF16_PEAK_TF) if split else tf(pip) / MFMA_F32_PEAK_TF}
             dom = max(levels, key=lambda k: levels[k]["kernel_ms"])
+            level_flops = {}
+            for lvl in (1, 2, 3):                                     # the census rows of the level kernels: distinct-row FLOPs
+                for k in rows_keys[lvl][-1:] + (f"msr3d_sa_level_split[{lvl}]", f"msr3d_sa_level[{lvl}]"):
+                    level_flops[k] = levels[f"level{lvl}"]["achieved_tflops"] * 1e12 * levels[f"level{lvl}"]["kernel_ms"] * 1e-3
             names = {"level1": "sa1_rows_kernel (+ sa1_plan_kernel; msr3d_sa_level1_rows)" if rows_on else "sa1_split_kernel",
                      "level2": "sa2_rows_kernel (+ sa2_plan_kernel; msr3d_sa_level2_rows)" if rows_on else "sa2_split_kernel",
                      "level3": "sa3_split4_kernel (msr3d_sa_level_split level 3)"}
@@ -880,8 +1067,32 @@ def main():
                     "levels": levels, "constant_objects_per_launch": scale * sum(st["constant_objects"] for st in stats) / len(stats),
                     "traffic": traffic_per_obj * objs_per_launch if traffic_per_obj else None,
                     "traffic_unit": f"bytes/launch (PMC passes of tools/pmc_sa.sh, {traffic_src})",
-                    "kernel_ms": d["kernel_ms"], "launches": len(sink[f"msr3d_sa_{dom}"]),
-                    "timed": f"HIP events around every {time_every}{'st' if time_every == 1 else 'th'} launch inside the timed region"}
+                    "kernel_ms": d["kernel_ms"]}
+            # The line's kernel is the LONGEST kernel of the step, whichever part it is in (round 5's line looked at the
+            # three levels only and missed the weight-gradient launch); `kernels`: every launch >= 15 us.
+            table, pmc_files = census_table(census, model, objs_per_launch, args.llm_hidden, level_flops)
+            big = {k: r for k, r in table.items() if r["us"] >= 15.0}
+            rated = {k: r for k, r in big.items() if "frac" in r}
+            if rated and split:
+                top = max(rated, key=lambda k: rated[k]["us"])
+                r = rated[top]
+                roof.update({"kernel": f"{r['kernel']} ({top})", "achieved": r["achieved_tflops"], "frac": r["frac"],
+                             "kernel_ms": r["us"] / 1e3, "useful_gflop_per_launch": r["useful_gflop"],
+                             "mfma_busy_pmc": r.get("mfma_busy_pmc"),
+                             "traffic": r.get("hbm_bytes_pmc", roof["traffic"] if top in level_flops else None)})
+                if top not in level_flops:
+                    roof["achieved_note"] = ("fp32 FLOPs the result needs (each counted once, whatever the number of bf16 MFMA "
+                                             "products it takes) / the launch's duration")
+                    roof["traffic_unit"] = "bytes/launch (FETCH_SIZE x 2 + WRITE_SIZE of the newest PMC pass) or null"
+                    for k in ("nominal_tflops", "mfma_executed_tflops", "mfma_pipe_frac", "vs_f32_mfma_peak"):
+                        roof.pop(k, None)
+            roof["kernels"] = big
+            roof["kernels_note"] = ("every launch of the step >= 15 us: mean duration, launches per step, fp32-equivalent useful "
+                                    "GFLOP per launch, frac of 2500 / 6 TFLOP/s; mfma_busy_pmc = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs "
+                                    f"x GRBM_GUI_ACTIVE / 8) of the newest committed counter pass ({', '.join(pmc_files) or 'none'})")
+            roof["timed"] = (f"kernel census: {args.census_steps} eager (no graph), un-pipelined steps after the timed region, HIP "
+                             "events on the launching stream around EVERY launch; the timed region itself carries no events")
+            roof["step_launch_us_sum"] = sum(r["us"] * r["launches_per_step"] for r in table.values())
         else:
             # variant line: the fused frozen-encoder launches are not on this path (the SharedMLPs run as
             # group_rows -> token GEMM -> BatchNorm(train) kernels under autograd); no roofline leg
@@ -920,13 +1131,16 @@ def main():
             "roofline": roof,
             "kernels_ms": kern_ms,
         }
+        if census:
+            line["census_us"] = {k: [round(v["us"], 2), v["per_step"]] for k, v in sorted(census.items())}
         if comm is not None:
             line["comm"] = comm
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
-        plain = not (dist_on or args.unfrozen or args.skip_padded or args.pipeline or args.from_store or args.host_inputs
-                     or args.accum > 1 or args.no_graph or args.time_all_kernels or (O, P) != (60, 1024)
-                     or args.llm_hidden != 4096 or args.batch != 16 or args.no_cpu_baseline)
+        plain = not (dist_on or args.unfrozen or args.skip_padded or args.no_pipeline or args.from_store or args.host_inputs
+                     or args.accum > 1 or args.no_graph or args.time_all_kernels or (O, P) != (60, 1024) or args.dense
+                     or args.llm_hidden != 4096 or args.batch != 16 or args.no_cpu_baseline
+                     or args.situation_type != "as_transform_for_objects")
         if reduced and not args.unfrozen:
             # how far the reduced variant's encoder output is from the fp32-accurate path, on the first resident batch
             net = model.visual_prompter.obj_encoder.pcd_net
@@ -941,7 +1155,31 @@ def main():
             # SURVEY 8(f) rank 4, where > 99 % of a real step's time lives: the FULL step of BASELINE configs[1] (prompter ->
             # llm_proj -> scatter -> 32 LoRA-Llama layers at the Vicuna-7B shapes -> head -> CE -> backward into the
             # prompter -> clip + AdamW), in this process, after the headline: labelled secondary figures, never `value`
-            line["extra"] = {"full_step": full_step_extra(args, tr, model, batches, device)}
+            extra = line.setdefault("extra", {})
+            # the object-attention kernels' place against north_star's ">= 50 % MFMA utilisation" clause, in the record
+            kt = (roof or {}).get("kernels", {})
+            extra["object_attention"] = {
+                k.split("[")[1][:-1]: {q: kt[k].get(q) for q in ("kernel", "us", "useful_gflop", "frac", "mfma_busy_pmc")}
+                for k in ("msr3d_scene_block[attn_fwd]", "msr3d_scene_block[attn_bwd]") if k in kt}
+            extra["object_attention"]["note"] = ("fp32-accurate form (6 bf16 MFMA products per product); frac: useful fp32 FLOPs / "
+                                                 "time / (2500 / 6 TFLOP/s); mfma_busy_pmc: matrix-pipe busy cycles of the newest "
+                                                 "committed counter pass.  60 tokens x 32 channels a head: DESIGN.md 4.2c")
+            variants = [("dense_neighbourhoods", dict(dense=True),
+                         "the distinct-row kernels' worst case: every ball query finds >= 32 different points, all 60 slots real"),
+                        ("as_object", dict(situation_type="as_object"),
+                         "configs/leo_3_dataset_pure_txt.yaml's prompter (anchor token, L = 61) at 60 x 1024"),
+                        ("no_pipeline", dict(no_pipeline=True, pipeline=False),
+                         "encoder and trainable part back to back on one stream (rounds 1-5's default schedule)")]
+            if os.environ.get("MSR3D_TRAIN_MMA", "f32") == "f32":
+                variants.append(("bf16_trainable", dict(train_mma="bf16"),
+                                 "LABELLED reduced variant (MSR3D_TRAIN_MMA=bf16): the trainable part's products on ONE bf16 MFMA "
+                                 "product of bf16-rounded operands (fp32 accumulate) instead of six -- not fp32 accuracy"))
+            for name, over, note in variants:
+                try:
+                    extra[name] = dict(measure_variant(args, device, **over), note=note)
+                except Exception as e:                 # noqa: BLE001 -- the headline line must still be printed
+                    extra[name] = {"error": repr(e)[:300], "note": note}
+            extra["full_step"] = full_step_extra(args, tr, model, batches, device)
     else:
         line = None
     if dist_on:

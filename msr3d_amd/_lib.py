@@ -271,8 +271,42 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = ctypes.c_size_t if name.endswith("_ws_bytes") else _c_int
+        if argtypes and argtypes[-1] is _ptr and not name.endswith("_ws_bytes"):
+            setattr(lib, name, _Entry(name, fn))      # (a launch: can be bracketed by events, see set_timing_sink)
     _lib = lib
     return lib
+
+
+_BLK_NAMES = {0: "attn_fwd", 1: "ffn_fwd", 2: "ffn_bwd", 3: "attn_bwd", 4: "linear", 5: "linear_ksplit"}
+_PRO_NAMES = {0: "plain", 1: "add", 2: "ln", 3: "ln2", 4: "lnbwd", 5: "ln2bwd"}
+
+
+class _Entry:
+    """A launching entry point of the library.  Transparent (one attribute test per call) unless bench.py's kernel census
+    is on (`set_timing_sink(sink, census=True)`): then EVERY launch is bracketed by HIP events on torch's current stream
+    -- the stream the callers launch on -- and recorded under the entry's name; msr3d_scene_block / msr3d_scene_rows
+    are keyed by the struct's kind / prologue as well (their kernels differ)."""
+    __slots__ = ("name", "fn")
+
+    def __init__(self, name, fn):
+        self.name, self.fn = name, fn
+
+    def __call__(self, *a):
+        if not _timing_census or _timing_sink is None:
+            return self.fn(*a)
+        key = self.name
+        if key == "msr3d_scene_block":
+            key += "[" + _BLK_NAMES.get(a[0]._obj.kind, "?") + "]"
+        elif key == "msr3d_scene_rows":
+            key += "[" + _PRO_NAMES.get(a[0]._obj.pro, "?") + "]"
+        elif key in ("msr3d_sa_level_split", "msr3d_sa_level"):
+            key += f"[{int(a[0])}]"
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = self.fn(*a)
+        e1.record()
+        _timing_sink.setdefault(key, []).append((e0, e1))
+        return rc
 
 
 _lib_split2 = None
@@ -291,12 +325,68 @@ def load_split2():
         if not os.path.exists(_build.LIB_SPLIT2):
             _build.build()
         lib = ctypes.CDLL(_build.LIB_SPLIT2)
+        ver = getattr(lib, "msr3d_abi_version", None)
+        if ver is not None:
+            ver.restype = _c_int
+        if ver is None or ver() != ABI_VERSION:
+            # built from an older header: the entry points' arguments may have moved
+            raise ImportError(
+                f"msr3d_amd: {_build.LIB_SPLIT2} has ABI version {ver() if ver is not None else 'none (pre-v27 build)'}, this "
+                f"package binds version {ABI_VERSION} (include/msr3d_hip.h). Rebuild it with `python -m msr3d_amd.build`.")
+        lib.msr3d_set_reserved_cus.argtypes = [_c_int]
+        lib.msr3d_set_reserved_cus.restype = _c_int
+        if _reserved_cus[0]:                         # (its kernels size their grids from their OWN copy of the setting)
+            check(lib.msr3d_set_reserved_cus(_reserved_cus[0]), "msr3d_set_reserved_cus (split2)")
         for name in _SPLIT2_ENTRIES:
             fn = getattr(lib, name)
             fn.argtypes = _SIGNATURES[name]
             fn.restype = ctypes.c_size_t if name.endswith("_ws_bytes") else _c_int
         _lib_split2 = lib
     return _lib_split2
+
+
+_lib_bf16 = None
+_BF16_ENTRIES = ("msr3d_scene_block", "msr3d_wgrad_split", "msr3d_wgrad_split_colsum", "msr3d_wgrad_split_halves",
+                 "msr3d_wgrad_split_mixed")
+
+
+def load_bf16():
+    """libmsr3d_hip_bf16.so: csrc/scene_block.hip + csrc/wgrad_split.hip compiled with MSR3D_TRAIN_PLANES=1 -- the
+    LABELLED reduced variant MSR3D_TRAIN_MMA=bf16 / scene_blocks.set_train_mma("bf16") of the trainable part: one bf16
+    MFMA product of bf16-rounded operands per product instead of six, fp32 accumulate.  Same entry names, signatures and
+    buffer layouts as the main library's; loaded only on request."""
+    global _lib_bf16
+    if _lib_bf16 is None:
+        load()
+        from . import build as _build
+        if not os.path.exists(_build.LIB_BF16):
+            _build.build()
+        lib = ctypes.CDLL(_build.LIB_BF16)
+        lib.msr3d_abi_version.restype = _c_int
+        if lib.msr3d_abi_version() != ABI_VERSION:
+            raise ImportError(
+                f"msr3d_amd: {_build.LIB_BF16} has ABI version {lib.msr3d_abi_version()}, this package binds version "
+                f"{ABI_VERSION} (include/msr3d_hip.h). Rebuild it with `python -m msr3d_amd.build`.")
+        for name in _BF16_ENTRIES:
+            fn = getattr(lib, name)
+            fn.argtypes = _SIGNATURES[name]
+            fn.restype = _c_int
+            setattr(lib, name, _Entry(name, fn))
+        _lib_bf16 = lib
+    return _lib_bf16
+
+
+_reserved_cus = [0]
+
+
+def set_reserved_cus(n):
+    """msr3d_set_reserved_cus on EVERY loaded library: the split2 variant library has its own copy of the setting (and
+    of usable_cus()), and takes the current value when it is loaded later."""
+    n = int(n)
+    check(load().msr3d_set_reserved_cus(n), "msr3d_set_reserved_cus")
+    _reserved_cus[0] = n
+    if _lib_split2 is not None:
+        check(_lib_split2.msr3d_set_reserved_cus(n), "msr3d_set_reserved_cus (split2)")
 
 
 def check(status, what):
@@ -316,15 +406,17 @@ def current_stream_ptr(device=None):
 _timing_sink = None
 _timing_every = 1
 _timing_calls = {}
+_timing_census = False
 
 
-def set_timing_sink(sink, every=1):
+def set_timing_sink(sink, every=1, census=False):
     """every = k: only every k-th launch of a name is bracketed by events.  An event pair costs the GPU ~6 us of idle
     time on either side of the launch (a barrier packet each): timing EVERY launch of the dominant kernel put 12 us --
     1 % -- of measurement overhead into each timed step."""
-    global _timing_sink, _timing_every
+    global _timing_sink, _timing_every, _timing_census
     _timing_sink = sink
     _timing_every = max(1, int(every))
+    _timing_census = bool(census) and sink is not None
     _timing_calls.clear()
 
 
@@ -332,7 +424,7 @@ class kernel_timer:
     __slots__ = ("rec", "e0")
 
     def __init__(self, name):
-        self.rec = _timing_sink.get(name) if _timing_sink is not None else None
+        self.rec = _timing_sink.get(name) if (_timing_sink is not None and not _timing_census) else None
         if self.rec is not None and _timing_every > 1:
             c = _timing_calls.get(name, 0)
             _timing_calls[name] = c + 1

@@ -16,6 +16,9 @@ LIB = os.path.join(HERE, "libmsr3d_hip.so")
 # the labelled reduced-split variant of the set-abstraction SharedMLPs (MSR3D_SA_MMA=split2): csrc/sa_split.hip alone,
 # compiled with MSR3D_SPLIT_TERMS=3, under the same entry names
 LIB_SPLIT2 = os.path.join(HERE, "libmsr3d_hip_split2.so")
+# the labelled bf16 variant of the trainable part (MSR3D_TRAIN_MMA=bf16): csrc/scene_block.hip + csrc/wgrad_split.hip
+# compiled with MSR3D_TRAIN_PLANES=1 (one bf16 MFMA product per product instead of six), under the same entry names
+LIB_BF16 = os.path.join(HERE, "libmsr3d_hip_bf16.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 ARCH = "gfx950"
@@ -103,6 +106,12 @@ def build(force=False, verbose=False, sqdist_contract=None):
     s2 = os.path.join(CSRC, "sa_split.hip")
     if force or not os.path.exists(LIB_SPLIT2) or os.path.getmtime(LIB_SPLIT2) < max(os.path.getmtime(s2), hdr_t):
         cmd = [cc] + COMMON + ["-ffp-contract=off", "-DMSR3D_SPLIT_TERMS=3"] + contract_flag + ["-shared", s2, "-o", LIB_SPLIT2]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    srcs = [os.path.join(CSRC, "scene_block.hip"), os.path.join(CSRC, "wgrad_split.hip")]
+    if force or not os.path.exists(LIB_BF16) or os.path.getmtime(LIB_BF16) < max([os.path.getmtime(x) for x in srcs] + [hdr_t]):
+        cmd = [cc] + COMMON + ["-DMSR3D_TRAIN_PLANES=1", "-shared"] + srcs + ["-o", LIB_BF16]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -69,7 +69,7 @@ template <int MMA, int RN, int KD, bool A_KC, bool B_KC, bool SWAP = false>
 __device__ __forceinline__ void strip_mma(const float *As, int lda, const float *Bs, int ldb,
                                           int row0, f32x4 (&acc)[RN], int lane) {
   const int i = lane & 15, g = lane >> 4;
-  static_assert(!SWAP || MMA == MSR3D_MMA_F32, "swapped roles: f32 operand map only");
+  static_assert(!SWAP || MMA != MSR3D_MMA_FP8, "swapped roles: f32 and bf16 operand maps");
   if (MMA == MSR3D_MMA_F32) {
 #pragma unroll
     for (int k0 = 0; k0 < KD; k0 += 4) {
@@ -93,7 +93,8 @@ __device__ __forceinline__ void strip_mma(const float *As, int lda, const float 
 #pragma unroll
         for (int rn = 0; rn < RN; ++rn) {
           frag8<B_KC>(Bs, ldb, rn * 16 + i, k0 + 8 * g, fb);
-          acc[rn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pack_bf16(fb), acc[rn], 0, 0, 0);
+          acc[rn] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(pack_bf16(fb), a, acc[rn], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pack_bf16(fb), acc[rn], 0, 0, 0);
         }
       } else {
         const long a = pack_fp8(fa);

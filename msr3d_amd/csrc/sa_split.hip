@@ -2172,3 +2172,9 @@ extern "C" int msr3d_set_reserved_cus(int n) {
   g_reserved_cus.store(n, std::memory_order_relaxed);
   return 0;
 }
+
+#if MSR3D_SPLIT_TERMS == 3
+// libmsr3d_hip_split2.so is this file alone: it carries the version of the header it was compiled against, so that
+// msr3d_amd/_lib.py::load_split2 can refuse a stale build (the main library exports this from pn2_ops.hip)
+extern "C" int msr3d_abi_version(void) { return MSR3D_ABI_VERSION; }
+#endif

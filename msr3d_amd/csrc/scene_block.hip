@@ -57,6 +57,8 @@ constexpr int PITCH = KD + 16;          // bf16 units: 544 B rows, conflict-free
 constexpr int PLANE = TM * PITCH;       // bf16 units per plane
 constexpr int XS_BYTES = 3 * PLANE * 2; // 104,448
 constexpr int RING = 4;                 // weight pieces in flight per wave (12 KB)
+// the attention core's operand form: f32-input MFMA, or (MSR3D_TRAIN_PLANES = 1, the labelled bf16 variant) bf16 operands
+constexpr int kCoreMma = MSR3D_TRAIN_PLANES == 1 ? MSR3D_MMA_BF16 : MSR3D_MMA_F32;
 constexpr int MID_BYTES = 4 * 4 * 3 * 1024;   // FRAG planes of a 64 x 128 middle: 49,152
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -95,7 +97,7 @@ __device__ __forceinline__ float gelu_as_grad(float x) {
 template <int NTHR = 256>
 __device__ __forceinline__ void stage_planes(const unsigned short *__restrict__ xp, unsigned short *xs, int b) {
   const uint4 *src = reinterpret_cast<const uint4 *>(xp + (size_t)b * 3 * TM * KD);
-  constexpr int NV = 24 * 256 / NTHR;
+  constexpr int NV = 8 * kPlanes * 256 / NTHR;        // (kPlanes = 1: the first plane's 2048 uint4 only)
   uint4 v[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) v[k] = src[threadIdx.x + NTHR * k];
@@ -112,11 +114,11 @@ __device__ __forceinline__ void stage_planes(const unsigned short *__restrict__ 
 __device__ __forceinline__ void planes_fetch(const unsigned short *__restrict__ xp, int b, uint4 (&v)[24]) {
   const uint4 *src = reinterpret_cast<const uint4 *>(xp + (size_t)b * 3 * TM * KD);
 #pragma unroll
-  for (int k = 0; k < 24; ++k) v[k] = src[threadIdx.x + 256 * k];
+  for (int k = 0; k < 8 * kPlanes; ++k) v[k] = src[threadIdx.x + 256 * k];
 }
 __device__ __forceinline__ void planes_store(unsigned short *xs, const uint4 (&v)[24]) {
 #pragma unroll
-  for (int k = 0; k < 24; ++k) {
+  for (int k = 0; k < 8 * kPlanes; ++k) {
     const int q = threadIdx.x + 256 * k;
     const int plane = q >> 11, row = (q >> 5) & 63, c8 = q & 31;
     *reinterpret_cast<uint4 *>(xs + plane * PLANE + row * PITCH + c8 * 8) = v[k];
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(64 * NW) void scene_block_kernel(const SB p) {
     __syncthreads();
     SB_STAMP(5);
     f32x4 o[2];
-    msr3d_attn::attn_fwd_core<TM, MSR3D_MMA_F32>(L, sq, sk, sv, sp, plb, scond, 8, p.pad + (size_t)b * L,
+    msr3d_attn::attn_fwd_core<TM, kCoreMma>(L, sq, sk, sv, sp, plb, scond, 8, p.pad + (size_t)b * L,
                                                  p.probs ? p.probs + ((size_t)b * H + h) * L * L : nullptr, o);
     // ctx_h: side output + product 2's operand (FRAG planes, one slab; row tile = wave)
     if (wave < 4) {
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(64 * NW) void scene_block_kernel(const SB p) {
     __syncthreads();
     SB_STAMP(5);
     f32x4 oq[2], ok[2], ov[2];
-    msr3d_attn::attn_bwd_core<TM, MSR3D_MMA_F32>(L, sq, sk, sv, sdo, sp, plb, scond, 8, p.pad + (size_t)b * L, sdc, 8,
+    msr3d_attn::attn_bwd_core<TM, kCoreMma>(L, sq, sk, sv, sdo, sp, plb, scond, 8, p.pad + (size_t)b * L, sdc, 8,
                                                  oq, ok, ov);
     SB_STAMP(6);
     // every wave is past the core's last barrier: the pairwise slab is dead, product 2's operand
@@ -579,12 +581,12 @@ __global__ __launch_bounds__(512) void scene_attn_fwd2_kernel(const SB p) {
       const int r0 = 32 * (part == 0 ? qh : 1 - qh);
       uint4 v[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
+      for (int k = 0; k < 2 * kPlanes; ++k) {
         const int q = tid + 512 * k, plane = q >> 10, row = r0 + ((q >> 5) & 31), c8 = q & 31;
         v[k] = src[plane * 2048 + row * 32 + c8];
       }
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
+      for (int k = 0; k < 2 * kPlanes; ++k) {
         const int q = tid + 512 * k, plane = q >> 10, row = r0 + ((q >> 5) & 31), c8 = q & 31;
         *reinterpret_cast<uint4 *>(xs + plane * PLANE + row * PITCH + c8 * 8) = v[k];
       }
@@ -694,7 +696,7 @@ __global__ __launch_bounds__(512) void scene_attn_fwd2_kernel(const SB p) {
     const int qt = wave & 1, kq = wave >> 1;
     const int i = j;
     f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-    msr3d_attn::strip_mma<MSR3D_MMA_F32, 1, DH, true, true>(sq, LD32, sk + 16 * kq * LD32, LD32, q0 + 16 * qt, acc, lane);
+    msr3d_attn::strip_mma<kCoreMma, 1, DH, true, true>(sq, LD32, sk + 16 * kq * LD32, LD32, q0 + 16 * qt, acc, lane);
     const int col = 16 * kq + i;
     const unsigned char *pad_b = p.pad + (size_t)b * L;
     const bool keyok = col < L && !pad_b[min(col, L - 1)];
@@ -742,7 +744,7 @@ __global__ __launch_bounds__(512) void scene_attn_fwd2_kernel(const SB p) {
     if (wave < 4) {
       const int dt = wave >> 1;
       f32x4 o[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-      msr3d_attn::strip_mma<MSR3D_MMA_F32, 1, TM, true, false>(sp, LDP, sv + 16 * dt, LD32, 16 * qt, o, lane);
+      msr3d_attn::strip_mma<kCoreMma, 1, TM, true, false>(sp, LDP, sv + 16 * dt, LD32, 16 * qt, o, lane);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rr = 4 * g + r, row = q0 + 16 * qt + rr, kk = 16 * dt + i;
@@ -883,7 +885,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();
     SB_STAMP(5);
     f32x4 oq[2], ok[2], ov[2];
-    msr3d_attn::attn_bwd_core<TM, MSR3D_MMA_F32, true>(L, sq, sk, sv, sdo, sp, plb, scond, 8, p.pad + (size_t)b * L, sdc, 8,
+    msr3d_attn::attn_bwd_core<TM, kCoreMma, true>(L, sq, sk, sv, sdo, sp, plb, scond, 8, p.pad + (size_t)b * L, sdc, 8,
                                                        oq, ok, ov);
     SB_STAMP(6);
     // every wave is past the core's last barrier: the pairwise slab is dead, product 2's operand
@@ -982,7 +984,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   {
     const uint4 *src = reinterpret_cast<const uint4 *>(p.xp + (size_t)b * 3 * TM * KD);
 #pragma unroll
-    for (int k = 0; k < 12; ++k) xv[k] = src[tid + 512 * k];
+    for (int k = 0; k < 4 * kPlanes; ++k) xv[k] = src[tid + 512 * k];
   }
   float4 tq[3];
   {
@@ -1023,7 +1025,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int t = 0; t < 3; ++t) st4(sq + t * TM * LD32 + row * LD32 + c4, tq[t]);
     scond[tid] = tc;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) {
+    for (int k = 0; k < 4 * kPlanes; ++k) {
       const int q = tid + 512 * k;
       const int plane = q >> 11, row2 = (q >> 5) & 63, c8 = q & 31;
       *reinterpret_cast<uint4 *>(xs + plane * PLANE + row2 * PITCH + c8 * 8) = xv[k];
@@ -1087,9 +1089,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   f32x4 oq[1], ok[1], ov[1];
   {
     f32x4 dP[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    msr3d_attn::strip_mma<MSR3D_MMA_F32, 2, DH, true, true>(sdo, LD32, sv + 32 * kh * LD32, LD32, row0, dP, lane);
+    msr3d_attn::strip_mma<kCoreMma, 2, DH, true, true>(sdo, LD32, sv + 32 * kh * LD32, LD32, row0, dP, lane);
     ov[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    msr3d_attn::strip_mma<MSR3D_MMA_F32, 1, TM, false, false, true>(sp, LDP, sdo + 16 * kh, LD32, row0, ov, lane);
+    msr3d_attn::strip_mma<kCoreMma, 1, TM, false, false, true>(sp, LDP, sdo + 16 * kh, LD32, row0, ov, lane);
     __syncthreads();                       // every wave is done reading P as a matrix operand
     const unsigned char *pad_b = p.pad + (size_t)b * L;
     bool keyok[2];
@@ -1150,8 +1152,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();                       // d S complete; the pairwise slab is dead; the cond partials visible
     oq[0] = f32x4{0.f, 0.f, 0.f, 0.f};
     ok[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    msr3d_attn::strip_mma<MSR3D_MMA_F32, 1, TM, true, false, true>(sp, LDP, sk + 16 * kh, LD32, row0, oq, lane);
-    msr3d_attn::strip_mma<MSR3D_MMA_F32, 1, TM, false, false, true>(sp, LDP, sq + 16 * kh, LD32, row0, ok, lane);
+    msr3d_attn::strip_mma<kCoreMma, 1, TM, true, false, true>(sp, LDP, sk + 16 * kh, LD32, row0, oq, lane);
+    msr3d_attn::strip_mma<kCoreMma, 1, TM, false, false, true>(sp, LDP, sq + 16 * kh, LD32, row0, ok, lane);
   }
   SB_STAMP(6);
   // product 2's operand (FRAG planes, 4 slabs: [dq | dk | dv | dcond, 0]) on top of the dead pairwise slab; side outputs
@@ -1404,5 +1406,11 @@ int msr3d_scene_block(const msr3d_scene_block_t *pp, msr3d_stream_t stream) {
       return MSR3D_EINVAL;
   }
 }
+
+#if MSR3D_TRAIN_PLANES == 1
+// libmsr3d_hip_bf16.so (this file + wgrad_split.hip, MSR3D_TRAIN_PLANES = 1) carries the version of the header it was
+// compiled against: msr3d_amd/_lib.py::load_bf16 refuses a stale build (the main library exports this from pn2_ops.hip)
+int msr3d_abi_version(void) { return MSR3D_ABI_VERSION; }
+#endif
 
 }  // extern "C"

@@ -29,6 +29,20 @@ typedef int sm_i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kPieceBytes = 3 * 1024;       // one (slab, tile): three planes of 64 lanes x 16 B
 
+// MSR3D_TRAIN_PLANES = 1 (python -m msr3d_amd.build builds libmsr3d_hip_bf16.so from scene_block.hip and wgrad_split.hip
+// with it): the LABELLED reduced variant MSR3D_TRAIN_MMA=bf16 of the trainable part -- every operand is its FIRST plane
+// only (= the value rounded to bf16, nearest even) and every product ONE v_mfma_f32_16x16x32_bf16 instead of six, fp32
+// accumulate; the attention core's QK^T / PV / backward products take bf16 operands as well (attn_core.h's bf16 operand
+// map).  Memory layouts are unchanged (the planes nobody reads are still written by their producers), so the two
+// libraries work on the same buffers.  Not fp32 accuracy: tests/test_train_bf16_gpu.py states the tolerance.
+#ifndef MSR3D_TRAIN_PLANES
+#define MSR3D_TRAIN_PLANES 3
+#endif
+#if MSR3D_TRAIN_PLANES != 3 && MSR3D_TRAIN_PLANES != 1
+#error "MSR3D_TRAIN_PLANES must be 3 or 1"
+#endif
+constexpr int kPlanes = MSR3D_TRAIN_PLANES;  // planes of an operand that are fetched and multiplied
+
 // ---- exact three-way split -----------------------------------------------------------------------------
 __device__ __forceinline__ unsigned sm_pk_bf16(float a, float b) {       // v_cvt_pk_bf16_f32 (RNE)
   const sm_f32x2 v = {a, b};
@@ -100,7 +114,7 @@ __device__ __forceinline__ WStream make_wstream(const unsigned short *pack, unsi
 __device__ __forceinline__ void load_wpiece(WPiece &f, const WStream &st, int s, int rn) {
   const int piece = st.soff + (s * st.nt + rn) * kPieceBytes;
 #pragma unroll
-  for (int p = 0; p < 3; ++p) {
+  for (int p = 0; p < kPlanes; ++p) {
     const sm_i32x4 r = __builtin_amdgcn_raw_buffer_load_b128(st.rsrc, st.voff, piece + p * 1024, 0);
     f.v[p] = *reinterpret_cast<const bf16x8 *>(&r);
   }
@@ -165,18 +179,20 @@ __device__ __forceinline__ void gemm_split3(const XF &xf, int mt0, const WStream
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) x[mt][p] = xf(mt0 + mt, s, p);
+        for (int p = 0; p < kPlanes; ++p) x[mt][p] = xf(mt0 + mt, s, p);
     }
     __builtin_amdgcn_sched_barrier(0);          // .. and above its own
 #define MSR3D_TERM(PW, PX)                                                                                  \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                       \
         acc[rn][mt] = W_FIRST ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[q].v[PW], x[mt][PX], acc[rn][mt], 0, 0, 0) \
                               : __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[mt][PX], w[q].v[PW], acc[rn][mt], 0, 0, 0);
+#if MSR3D_TRAIN_PLANES == 3
     MSR3D_TERM(2, 0)
     MSR3D_TERM(0, 2)
     MSR3D_TERM(1, 1)
     MSR3D_TERM(1, 0)
     MSR3D_TERM(0, 1)
+#endif
     MSR3D_TERM(0, 0)
 #undef MSR3D_TERM
   }

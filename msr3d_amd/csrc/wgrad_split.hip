@@ -262,11 +262,13 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
       _Pragma("unroll") for (int a = 0; a < 4; ++a)                                              \
       _Pragma("unroll") for (int b = 0; b < 2; ++b)                                              \
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][PA], fb[b][PB], acc[a][b], 0, 0, 0);
+#if MSR3D_TRAIN_PLANES == 3
       MSR3D_TERM(2, 0)
       MSR3D_TERM(0, 2)
       MSR3D_TERM(1, 1)
       MSR3D_TERM(1, 0)
       MSR3D_TERM(0, 1)
+#endif
       MSR3D_TERM(0, 0)
 #undef MSR3D_TERM
     }

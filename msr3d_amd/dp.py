@@ -67,7 +67,7 @@ class FlatGradAllReduce:
             n = int(os.environ.get("MSR3D_RESERVE_CUS", os.environ.get("NCCL_MAX_NCHANNELS", "16")))
             try:
                 from . import _lib
-                _lib.check(_lib.load().msr3d_set_reserved_cus(max(0, min(n, 128))), "msr3d_set_reserved_cus")
+                _lib.set_reserved_cus(max(0, min(n, 128)))
                 self.reserved_cus = max(0, min(n, 128))
             except (OSError, RuntimeError):
                 self.reserved_cus = 0

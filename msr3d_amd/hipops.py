@@ -769,6 +769,11 @@ def _conv_is_pointwise(conv):
             and conv.groups == 1 and conv.padding_mode == "zeros")
 
 
+# element-by-element activations: the same values on token-major rows as on the (B, C, H, W) tensor
+_ROWWISE_ACTIVATIONS = (torch.nn.ReLU, torch.nn.LeakyReLU, torch.nn.GELU, torch.nn.SiLU, torch.nn.Identity,
+                        torch.nn.Tanh, torch.nn.Sigmoid, torch.nn.ELU, torch.nn.ReLU6)
+
+
 def shared_mlp_rows_supported(mlp, x):
     """GPU fp32 (B, C, H, W) input and a stack of [1x1 conv | BatchNorm2d | activation] layers."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
@@ -781,6 +786,10 @@ def shared_mlp_rows_supported(mlp, x):
             elif isinstance(m, torch.nn.Sequential):
                 if not (len(m) == 1 and isinstance(m[0], torch.nn.BatchNorm2d)):
                     return False
+            elif not isinstance(m, _ROWWISE_ACTIVATIONS):
+                # applied to (B*H*W, C) rows here: anything that looks at spatial dimensions or at dim=-1 of the
+                # (B, C, H, W) tensor (Softmax, Dropout2d, instance norms ...) would compute something else
+                return False
     return True
 
 

@@ -18,6 +18,31 @@ from ._lib import BLK, PRO, PackJob, SceneBlock, SceneRows, WgradProblem
 _vp = ctypes.c_void_p
 PIECE = 3 * 1024          # bytes of one (slab, tile): three planes of 64 lanes x 16 B
 
+# Arithmetic of the blocks' and the weight gradients' products:
+#   "f32"   (default) every product as six bf16 MFMA products of exactly split operands: fp32 accuracy
+#   "bf16"  LABELLED reduced variant (MSR3D_TRAIN_MMA=bf16): operands rounded to bf16, ONE MFMA product per product, fp32
+#           accumulate, fp32 storage of every activation -- what `torch.autocast(bfloat16)` linears compute; the kernels are
+#           the same sources compiled with MSR3D_TRAIN_PLANES=1 (libmsr3d_hip_bf16.so).  Never the headline.
+_TRAIN_MMA = [os.environ.get("MSR3D_TRAIN_MMA", "f32")]
+if _TRAIN_MMA[0] not in ("f32", "bf16"):
+    raise ValueError("MSR3D_TRAIN_MMA must be 'f32' or 'bf16'")
+
+
+def train_mma():
+    return _TRAIN_MMA[0]
+
+
+def set_train_mma(name):
+    if name not in ("f32", "bf16"):
+        raise ValueError("train mma must be 'f32' or 'bf16'")
+    prev, _TRAIN_MMA[0] = _TRAIN_MMA[0], name
+    return prev
+
+
+def _klib():
+    """The library whose block / weight-gradient kernels run."""
+    return _lib.load_bf16() if _TRAIN_MMA[0] == "bf16" else _lib.load()
+
 
 def _device_bytes(ctypes_array, device, pinned=None):
     raw = bytes(ctypes_array)
@@ -212,7 +237,7 @@ class WgradTable:
             if self._ws is None:
                 self._ws = torch.empty(self.prefix[-1] * HALF_SLOT_FLOATS, dtype=torch.float32, device=self.device)
                 self._sync = torch.zeros(2 * self.prefix[-1], dtype=torch.int32, device=self.device)
-            rc = _lib.load().msr3d_wgrad_split_halves(len(self.probs), _vp(self._table.data_ptr()), _vp(self._pfx.data_ptr()),
+            rc = _klib().msr3d_wgrad_split_halves(len(self.probs), _vp(self._table.data_ptr()), _vp(self._pfx.data_ptr()),
                                                       self.prefix[-1], _vp(self._ws.data_ptr()), self._ws.numel(),
                                                       _vp(self._sync.data_ptr()), stream)
             _lib.check(rc, "msr3d_wgrad_split_halves")
@@ -223,20 +248,26 @@ class WgradTable:
         if whole < self.prefix[-1]:
             H = self.prefix[-1] - whole
             if self._ws is None or self._ws.numel() < H * HALF_SLOT_FLOATS:
-                self._ws = torch.empty(H * HALF_SLOT_FLOATS, dtype=torch.float32, device=self.device)
-                self._sync = torch.zeros(2 * H, dtype=torch.int32, device=self.device)
+                # sized ONCE for the worst case (every tile halved), so that a later launch whose problems' token counts
+                # -- and with them the whole / halved cut -- differ never moves the buffers a captured graph points at
+                if self._ws is not None and torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("WgradTable: the hand-over workspace would have to grow inside a graph capture "
+                                       "(problems were added after the table's first launch)")
+                T = self.prefix[-1]
+                self._ws = torch.empty(T * HALF_SLOT_FLOATS, dtype=torch.float32, device=self.device)
+                self._sync = torch.zeros(2 * T, dtype=torch.int32, device=self.device)
             nj, jt = (colsum[0], _vp(colsum[1].data_ptr())) if colsum is not None else (0, _vp(0))
-            rc = _lib.load().msr3d_wgrad_split_mixed(len(self.probs), _vp(self._table.data_ptr()), _vp(self._pfx.data_ptr()),
+            rc = _klib().msr3d_wgrad_split_mixed(len(self.probs), _vp(self._table.data_ptr()), _vp(self._pfx.data_ptr()),
                                                      self.prefix[-1], whole, nj, jt, _vp(self._ws.data_ptr()),
                                                      self._ws.numel(), _vp(self._sync.data_ptr()), stream)
             _lib.check(rc, "msr3d_wgrad_split_mixed")
             return
         if colsum is not None:
-            rc = _lib.load().msr3d_wgrad_split_colsum(len(self.probs), _vp(self._table.data_ptr()), _vp(self._pfx.data_ptr()),
+            rc = _klib().msr3d_wgrad_split_colsum(len(self.probs), _vp(self._table.data_ptr()), _vp(self._pfx.data_ptr()),
                                                       self.prefix[-1], colsum[0], _vp(colsum[1].data_ptr()), stream)
             _lib.check(rc, "msr3d_wgrad_split_colsum")
             return
-        rc = _lib.load().msr3d_wgrad_split(len(self.probs), _vp(self._table.data_ptr()), _vp(self._pfx.data_ptr()),
+        rc = _klib().msr3d_wgrad_split(len(self.probs), _vp(self._table.data_ptr()), _vp(self._pfx.data_ptr()),
                                            self.prefix[-1], stream)
         _lib.check(rc, "msr3d_wgrad_split")
 
@@ -249,7 +280,7 @@ def launch_block(stream, **kw):
         elif isinstance(v, _vp):
             v = v.value
         setattr(s, k, v if v is not None else 0)
-    rc = _lib.load().msr3d_scene_block(ctypes.byref(s), stream)
+    rc = _klib().msr3d_scene_block(ctypes.byref(s), stream)
     if rc:
         fields = ", ".join(f"{n}={getattr(s, n)!r}" for n, _ in s._fields_ if getattr(s, n))
         _lib.check(rc, f"msr3d_scene_block({fields})")

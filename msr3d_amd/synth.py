@@ -18,9 +18,13 @@ import torch
 ROOM = np.array([8.0, 8.0, 3.0])
 
 
-def synth_scene(rng, O=60, P=1024, n_valid=None):
+def synth_scene(rng, O=60, P=1024, n_valid=None, dense=False):
+    """dense=True: the WORST case of the distinct-row set-abstraction kernels, not a dataset-like scene -- every slot a
+    real object (no padding clouds), P different points inside a ball of radius 0.095 (not rescaled to max-norm 1), so
+    that every ball query of both levels (radii 0.2 / 0.4, configs/msr3d.yaml:155) finds at least its 32 samples and
+    no neighbourhood row is a copy of another."""
     if n_valid is None:
-        n_valid = int(rng.integers(min(20, O), O + 1))
+        n_valid = O if dense else int(rng.integers(min(20, O), O + 1))
     fts = np.ones((O, P, 6), np.float32)
     locs = np.zeros((O, 6), np.float32)
     mask = np.zeros((O,), bool)
@@ -35,6 +39,10 @@ def synth_scene(rng, O=60, P=1024, n_valid=None):
         box_s = raw.max(0) - raw.min(0)
         pts = pts - pts.mean(0)
         pts = pts / max(float(np.sqrt((pts ** 2).sum(1)).max()), 1e-6)
+        if dense:
+            d = rng.normal(size=(P, 3))
+            d /= np.sqrt((d ** 2).sum(1, keepdims=True))
+            pts = (d * (0.095 * rng.uniform(0, 1, (P, 1)) ** (1.0 / 3.0))).astype(np.float32)
         fts[o, :, :3] = pts
         fts[o, :, 3:] = rng.uniform(-1, 1, (P, 3))
         locs[o, :3] = box_c
@@ -46,14 +54,14 @@ def synth_scene(rng, O=60, P=1024, n_valid=None):
     return fts, mask, locs, anchor, quat
 
 
-def synth_batch(seed, B, O=60, P=1024, n_valid=None, device="cpu"):
+def synth_batch(seed, B, O=60, P=1024, n_valid=None, device="cpu", dense=False):
     """-> dict of torch tensors: obj_fts (B,O,P,6) f32, obj_masks (B,O) bool, obj_locs (B,O,6),
-    anchor_locs (B,3), anchor_orientation (B,4).  `n_valid`: int or per-sample list."""
+    anchor_locs (B,3), anchor_orientation (B,4).  `n_valid`: int or per-sample list.  dense: synth_scene."""
     rng = np.random.default_rng(seed)
     cols = [[], [], [], [], []]
     for i in range(B):
         nv = n_valid[i] if isinstance(n_valid, (list, tuple)) else n_valid
-        for c, v in zip(cols, synth_scene(rng, O, P, nv)):
+        for c, v in zip(cols, synth_scene(rng, O, P, nv, dense=dense)):
             c.append(v)
     names = ["obj_fts", "obj_masks", "obj_locs", "anchor_locs", "anchor_orientation"]
     return {n: torch.from_numpy(np.stack(c)).to(device) for n, c in zip(names, cols)}

@@ -447,6 +447,10 @@ class HotPathTrainStep:
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=getattr(self.dp, "group", None))
         return bool(t.item())
 
+    def _sync(self):
+        if self.static["obj_embeds"].is_cuda:
+            torch.cuda.synchronize()
+
     def _capture_checked(self, batch):
         """world > 1, MSR3D_DP_GRAPH_COMM unset: take the one-graph step (exchange captured) if it survives a
         self-check, the eager exchange otherwise.  The check, from one saved state: after two replays of the captured
@@ -454,54 +458,91 @@ class HotPathTrainStep:
         sums, shows here, bit for bit -- and (b) they lie where two eager steps (real collectives) put them, up to what
         a step can move: AdamW's first updates are lr * g / (|g| + eps), so a parameter whose gradient is ~0 follows the
         run-to-run rounding of its gradient by up to 2 lr a step, eager against eager as well; the bound is twice the
-        distance the eager steps travelled, not a rounding tolerance."""
+        distance the eager steps travelled, not a rounding tolerance.
+
+        Every rank must issue the SAME sequence of collectives whatever happens to it locally, so the check runs in
+        phases and the ranks agree (one MIN all-reduce) at the end of each: a capture is host-side work only -- it records
+        the exchange, it does not run it -- so a rank whose capture raised reaches the first agreement while no peer is
+        inside a replayed collective, and all of them fall back together.  The replays and the eager reference steps
+        follow only once every rank holds a graph."""
         import sys
-        why = None
+        state = {"why": None}
         snap = self._snapshot()
         self._graph_comm = True
-        try:
-            start = self._state_vector()
+
+        def phase(fn):
+            """Run `fn` here unless this rank has already failed; never raise; -> every rank is still fine."""
+            if state["why"] is None:
+                try:
+                    fn()
+                except Exception as e:      # noqa: BLE001 -- a capture that fails must not take the run with it
+                    state["why"] = f"{type(e).__name__}: {e}"
+            return self._all_ranks_agree(state["why"] is None)
+
+        res = {}
+
+        def p_capture():
+            res["start"] = self._state_vector()
             self._capture_graph(batch)
+
+        def p_replay():
             for _ in range(2):
                 self.graph.replay()
-            torch.cuda.synchronize()
-            got = self._state_vector()
-            _, spread = self.dp.replica_checksum(got)
+            self._sync()
+            res["got"] = self._state_vector()
+
+        def p_spread():
+            _, res["spread"] = self.dp.replica_checksum(res["got"])
+
+        def p_eager():
             self._restore(snap)
             saved_defer = self.dp.defer_comm
-            for _ in range(2):
-                self._load(batch)
-                self._train_part()
-            torch.cuda.synchronize()
-            want = self._state_vector()
-            self.dp.defer_comm = saved_defer
+            try:
+                for _ in range(2):
+                    self._load(batch)
+                    self._train_part()
+                self._sync()
+            finally:
+                self.dp.defer_comm = saved_defer
+            res["want"] = self._state_vector()
+
+        ok = phase(p_capture) and phase(p_replay) and phase(p_spread) and phase(p_eager)
+        if ok:
+            got, want, start, spread = res["got"], res["want"], res["start"], res["spread"]
             diff = float((got - want).abs().max())
             moved = float((want - start).abs().max())
             scale = float(want.abs().max())
             if spread != 0.0:
-                why = f"replicas differ after two captured steps: checksum spread {spread:.3e}"
+                state["why"] = f"replicas differ after two captured steps: checksum spread {spread:.3e}"
             elif not bool(torch.isfinite(got).all()) or not (diff <= 2.0 * moved + 1e-6 * max(scale, 1e-30)):
-                why = (f"two captured steps end {diff:.3e} from two eager ones, which moved the weights by {moved:.3e} "
-                       f"(scale {scale:.3e})")
+                state["why"] = (f"two captured steps end {diff:.3e} from two eager ones, which moved the weights by "
+                                f"{moved:.3e} (scale {scale:.3e})")
             self.graph_comm_check = {"captured": True, "max_abs_diff": diff, "eager_moved": moved, "scale": scale,
                                      "replica_checksum_spread": spread}
-        except Exception as e:      # noqa: BLE001 -- a capture that fails must not take the run with it
-            why = f"{type(e).__name__}: {e}"
-        if not self._all_ranks_agree(why is None):
-            why = why or "another rank's check failed"
+            ok = self._all_ranks_agree(state["why"] is None)
+        if not ok:
+            why = state["why"] or "another rank's check failed"
             print(f"[msr3d] captured gradient exchange NOT taken ({why}); falling back to the eager exchange",
                   file=sys.stderr, flush=True)
             self.graph_comm_check = {"captured": False, "why": why}
             self._graph_comm = False
             self.graph = None
-            torch.cuda.synchronize()
+            self._sync()
             self._restore(snap)
-            torch.cuda.synchronize()
+            self._sync()
             self._capture_graph(batch)
             return
         self._restore(snap)
-        torch.cuda.synchronize()
+        self._sync()
         self._load(batch)
+
+    def _replay_whole(self):
+        """Replay a graph that holds the optimiser: the captured AdamW kernel writes the parameters behind autograd's
+        back and no host code of opt.step() runs on a replay, so the version counters that the caches are keyed on
+        (pointnet2/fused.get_plan's state key, LoRA shadows, FrozenLinear packs) are bumped here, as full_step.py does."""
+        self.graph.replay()
+        if hasattr(self.opt, "mark_written"):
+            self.opt.mark_written()
 
     def _capture_graph(self, batch):
         self.graph = torch.cuda.CUDAGraph()
@@ -556,7 +597,7 @@ class HotPathTrainStep:
         if self.graph is not None:
             if self.split:
                 return self._micro_step(lambda: (self.graph.replay(), self.loss)[1], between)
-            self.graph.replay()
+            self._replay_whole()
             return self.loss
         if self.accum_steps > 1 or hide_comm:
             self.loss = self._micro_step(lambda: self._fwd_bwd(zero=False), between)

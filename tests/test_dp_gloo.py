@@ -233,3 +233,87 @@ def test_exchange_leaves_the_sum_when_the_optimiser_does_the_averaging():
         assert np.abs(mean).max() > 0
         assert np.allclose(total, world * mean, rtol=1e-6, atol=1e-7)
     assert np.array_equal(res[0][1], res[1][1])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# HotPathTrainStep._capture_checked: every rank issues the same collectives whatever happens to it locally.
+# The capture itself needs a GPU; its control flow does not: a step object whose capture / replay / eager
+# phases are stand-ins, rank 1's capture raising -> BOTH ranks fall back (no rank left inside a collective).
+# ---------------------------------------------------------------------------------------------------------
+def _checked_worker(rank, world, port, q, fail_rank):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from msr3d_amd.train_step import HotPathTrainStep
+
+    class _DP:
+        distributed, group, defer_comm = True, None, False
+
+        def replica_checksum(self, t):
+            s = t.double().sum().reshape(1)
+            lo, hi = s.clone(), s.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            return float(s), float(hi - lo)
+
+    calls = []
+    step = HotPathTrainStep.__new__(HotPathTrainStep)
+    step.dp, step.static, step.graph, step.graph_comm_check = _DP(), {"obj_embeds": torch.zeros(1)}, None, None
+    state = torch.zeros(4)
+
+    class _Graph:
+        def replay(self):
+            calls.append("replay")
+            t = torch.ones(1)
+            dist.all_reduce(t)                       # (a captured collective runs on replay)
+            state.add_(1.0)
+
+    def capture_graph(batch):
+        calls.append("capture" if step._graph_comm else "capture_eager")
+        if step._graph_comm and rank == fail_rank:
+            raise RuntimeError("capture failed on this rank only")
+        step.graph = _Graph()
+
+    def train_part():
+        calls.append("eager")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        state.add_(1.0)
+
+    step._snapshot = lambda: state.clone()
+    step._restore = lambda snap: state.copy_(snap)
+    step._state_vector = lambda: state.clone()
+    step._capture_graph = capture_graph
+    step._load = lambda batch: None
+    step._train_part = train_part
+    step._capture_checked(None)
+    q.put((rank, dict(step.graph_comm_check), calls, step._graph_comm))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [-1, 1])
+def test_capture_check_phases_agree_across_ranks(fail_rank):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_checked_worker, args=(r, world, port, q, fail_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, chk, calls, gc = q.get(timeout=120)      # a hang (mismatched collectives) fails here
+        res[rank] = (chk, calls, gc)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        chk, calls, gc = res[rank]
+        if fail_rank < 0:
+            assert chk["captured"] and gc and calls.count("replay") == 2 and calls.count("eager") == 2
+            assert chk["replica_checksum_spread"] == 0.0 and chk["max_abs_diff"] == 0.0
+        else:
+            # nobody replayed (the failing rank never held a graph), everybody re-captured for the eager exchange
+            assert not chk["captured"] and not gc and "replay" not in calls and calls[-1] == "capture_eager"
+    if fail_rank >= 0:
+        assert "capture failed" in res[fail_rank][0]["why"] and "another rank" in res[1 - fail_rank][0]["why"]
