@@ -951,10 +951,6 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    # Kernel census: `--census-steps` more steps of the SAME work, eagerly issued (no graph), un-pipelined, EVERY launch
-    # of the library bracketed by HIP events on the launching stream (msr3d_amd/_lib.py::_Entry) -> mean duration per
-    # entry point and launches per step.  Run on every rank (the steps hold the gradient exchange), read on rank 0.
-    census = kernel_census(tr, batches, args.census_steps, run_window, args.warmup + args.steps) if args.census_steps > 0 else {}
 
     # MSR3D_DP_GRAPH_COMM=1: the RCCL call was captured with the rest, the step is one graph at N > 1 as well
     whole_graph = tr.stepper.graph is not None and not tr.stepper.split
@@ -982,6 +978,12 @@ def main():
                 "graph_comm_check": getattr(tr.stepper, "graph_comm_check", None)}
         assert ranks_seen == world, f"RCCL saw {ranks_seen} ranks, expected {world}"
         assert spread == 0.0, f"replicas diverged: checksum spread {spread}"
+
+    # Kernel census: `--census-steps` more steps of the SAME work, eagerly issued (no graph), un-pipelined, EVERY launch
+    # of the library bracketed by HIP events on the launching stream (msr3d_amd/_lib.py::_Entry) -> mean duration per
+    # entry point and launches per step.  Run on every rank (the steps hold the gradient exchange), read on rank 0;
+    # after the exchange statistics above were taken (its steps exchange gradients too).
+    census = kernel_census(tr, batches, args.census_steps, run_window, args.warmup + args.steps) if args.census_steps > 0 else {}
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -1078,6 +1080,7 @@ def main():
                 r = rated[top]
                 roof.update({"kernel": f"{r['kernel']} ({top})", "achieved": r["achieved_tflops"], "frac": r["frac"],
                              "kernel_ms": r["us"] / 1e3, "useful_gflop_per_launch": r["useful_gflop"],
+                             "launches": int(round(r["launches_per_step"] * args.census_steps)),
                              "mfma_busy_pmc": r.get("mfma_busy_pmc"),
                              "traffic": r.get("hbm_bytes_pmc", roof["traffic"] if top in level_flops else None)})
                 if top not in level_flops:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 26
+#define MSR3D_ABI_VERSION 27
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -783,6 +783,13 @@ int msr3d_wgrad_split_halves(int n, const msr3d_wgrad_problem_t *problems, const
 int msr3d_wgrad_split_mixed(int n, const msr3d_wgrad_problem_t *problems, const int *tile_prefix, int total_tiles,
                             int whole_tiles, int n_jobs, const msr3d_colsum_job_t *jobs, float *workspace,
                             long long workspace_floats, int *sync, msr3d_stream_t stream);
+
+/* Which tile kernel the three launches above run: 1 (default; MSR3D_WGRAD_PIPE=0 in the environment selects 0 at first
+ * use) = eight waves that each load, split, stash and multiply, the next half-slab's fragment reads under the current
+ * half-slab's MFMAs (round 6); 0 = rounds 4-5's eight loader + eight multiplier waves.  Same sums in the same order:
+ * bit-identical results.  form = 0 / 1 selects, -1 only queries; returns the form in force (process-wide, takes effect at
+ * the next launch), MSR3D_EINVAL for another value. */
+int msr3d_wgrad_form(int form);
 
 /* dW (n_out, k_in) (+)= dy^T x over M rows for TALL operands (the SharedMLP weight gradients of an unfrozen
  * backbone: up to ~10^6 rows), the arithmetic and tile kernel of msr3d_wgrad_split: the rows are cut into up to

@@ -16,6 +16,7 @@
 // Register-prefetched three slabs ahead, LDS double-buffered over slabs of 32 tokens: one barrier per slab.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "../../include/msr3d_hip.h"
@@ -333,9 +334,318 @@ __device__ __forceinline__ void wgrad_tile(const WP &pr, int ntile, int ktile, u
   WG_STAMP(6);
 }
 
+// =====================================================================================================
+// PIPE (round 6): the same 128 x 128 tile, whole reduction, by EIGHT waves (two per SIMD, 256-register budget) that
+// each load, split, stash AND multiply -- no loader waves -- with the fragment reads of the NEXT half-slab issued
+// under the CURRENT half-slab's MFMAs inside every wave.
+//
+// What this replaces: 8 loader + 8 multiplier waves met at one barrier per slab, so all eight multipliers read their 18
+// fragments (147 KB of LDS traffic a slab: 1.1 k cycles of the CU's 128 B / clk) and THEN issued their 48 MFMAs (1.5 k
+// cycles of the SIMD's pipe), one after the other in every wave at the same time: 3.1 k cycles a slab, 59 us a tile
+// against 23 us of MFMA issue (profiles/r05_v2_wgrad_forms.txt; 16 waves = 128 registers a wave left no room for a
+// second fragment set).  Here a slab is two UNITS of 24 MFMAs (output row tiles 0-1 | 2-3 of the wave's 64 x 32 piece):
+//
+//     slab s, stage s & 1:      read A(2,3)(s) | MFMA unit (s, 0) | lgkmcnt(0) + barrier |
+//                               read A(0,1)(s+1), B(s+1) from the other stage | MFMA unit (s, 1) |
+//                               split + stash slab s+2 into THIS stage | fetch slab s+4
+//
+// one barrier per slab as before: it says both that every wave is done reading stage s & 1 (free for slab s+2) and
+// that slab s+1's planes, stashed a slab earlier, are complete.  Registers: two B fragment sets + two A half sets (96),
+// 32 accumulators, two slabs of fetched rows (32).  Loads / split / stash are the loader waves' code (same units: wave w
+// feeds operand w >> 2, token octet w & 3; 8 tokens x 2 columns per lane) and the products and their order are the
+// multiplier waves': the SAME bits as wgrad_tile (tests/test_scene_blocks_gpu.py compares the two forms).
+// =====================================================================================================
+constexpr int NTHREADS_PIPE = 512;
+#ifndef WGP_ABLATE
+#define WGP_ABLATE 0        // tools/ablate_wgrad.sh builds 1..5: the pipe tile without its MFMAs / split / loads / fragment reads / stash
+#endif
+
+template <bool HALVES = false>
+__device__ __forceinline__ void wgrad_tile_pipe(const WP &pr, int ntile, int ktile, unsigned char *smem,
+                                                Half hf = Half{0, 0, -1, 0, nullptr, nullptr}) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = ntile * TN, k0 = ktile * TK;
+  const int M = pr.M;
+  const int s_lo = HALVES ? hf.s0 : 0;
+  const int nslab = HALVES ? hf.s1 : ((M + 63) >> 6) << 1;          // even, padded (slabs past M read zeros)
+  WG_STAMP(0);
+
+  // ---- loader role: operand isx, token octet o, column pair P ----
+  const bool isx = wave >= 4;
+  const float *src = isx ? pr.x : pr.dy;
+  const int ld = isx ? pr.ldx : pr.ldy, ncol = isx ? pr.k_in : pr.n_out, c0 = isx ? k0 : n0;
+  const int P = lane, o = wave & 3;
+  const int col = c0 + 2 * P;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, (int)((size_t)M * ld * 4),
+                                                                       0x00020000);
+  const bool vec = (reinterpret_cast<uintptr_t>(src) & 7u) == 0 && (ld & 1) == 0;   // wave-uniform
+  float cm[2];
+  int cb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { cm[i] = col + i < ncol ? 1.f : 0.f; cb[i] = 4 * min(col + i, ncol - 1); }
+  float cs[2] = {0.f, 0.f};
+  struct Slab { float v[8][2]; };
+  unsigned char *const stash_base = smem + (isx ? OP_BYTES : 0) + (P >> 3) * TILE_BYTES;
+  int slot_w[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) slot_w[i] = frag_slot(2 * (P & 7) + i, o);
+
+  // ---- multiplier role: wave (wr, wc) owns output rows 64 wr .. x input columns 32 wc .. ----
+  const int wr = (wave >> 2) & 1, wc = wave & 3;
+  const int slot_r = frag_slot(lane & 15, lane >> 4);
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto run = [&](auto vec_tag) {
+    constexpr bool VEC = decltype(vec_tag)::value;
+    auto fetch = [&](Slab &s_, int s) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int row = ((32 * s + e) + 8 * o) * ld * 4;
+        if constexpr (VEC) {
+#if WGP_ABLATE == 3
+          s_.v[e][0] = (float)row; s_.v[e][1] = 1.f;
+#else
+          const sm_f32x2 r = __builtin_bit_cast(sm_f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, cb[0] + row, 0, 0));
+          s_.v[e][0] = r.x; s_.v[e][1] = r.y;
+#endif
+        } else {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            s_.v[e][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cb[i] + row, 0, 0));
+        }
+      }
+    };
+    // split: a fetched slab's 8 tokens x 2 columns -> three bf16 planes per column, kept in registers (+ the column sums);
+    // put: their six 16-byte stores, fragment order.  `live`: false for a slab past the reduction (nothing may enter db)
+    auto split = [&](Slab &s_, uint4 (&pl)[2][3], bool live) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        // (columns past the matrix -- an 8-byte load reads on into the row -- times 0: a multiply, not a branch per lane)
+        float c8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { c8[e] = s_.v[e][i] * cm[i]; cs[i] += live ? c8[e] : 0.f; }
+#if WGP_ABLATE == 2
+        pl[i][0] = make_uint4(__float_as_uint(c8[0]), __float_as_uint(c8[1]), __float_as_uint(c8[2]), __float_as_uint(c8[3]));
+        pl[i][1] = make_uint4(__float_as_uint(c8[4]), __float_as_uint(c8[5]), __float_as_uint(c8[6]), __float_as_uint(c8[7]));
+        pl[i][2] = pl[i][0];
+#else
+        sm_split8(c8, pl[i]);
+#endif
+      }
+    };
+    auto put = [&](const uint4 (&pl)[2][3], int buf) {
+      unsigned char *T = stash_base + buf * STAGE;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#if WGP_ABLATE == 5
+        asm volatile("" ::"v"(pl[i][0].x), "v"(pl[i][1].y), "v"(pl[i][2].z));
+#else
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<uint4 *>(T + k * 1024 + slot_w[i]) = pl[i][k];
+#endif
+      }
+    };
+    // fragments: A = dy^T tile (output rows), B = x tile (input columns)
+    auto read_a = [&](bf16x8 (&fa)[2][3], int buf, int half) {
+#if WGP_ABLATE == 4
+      return;
+#endif
+      const unsigned char *A = smem + buf * STAGE + slot_r;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < kPlanes; ++q)
+          fa[a][q] = *reinterpret_cast<const bf16x8 *>(A + (4 * wr + 2 * half + a) * TILE_BYTES + q * 1024);
+    };
+    auto read_b = [&](bf16x8 (&fb)[2][3], int buf) {
+#if WGP_ABLATE == 4
+      return;
+#endif
+      const unsigned char *Bs = smem + buf * STAGE + OP_BYTES + slot_r;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < kPlanes; ++q)
+          fb[b][q] = *reinterpret_cast<const bf16x8 *>(Bs + (2 * wc + b) * TILE_BYTES + q * 1024);
+    };
+    auto unit = [&](const bf16x8 (&fa)[2][3], const bf16x8 (&fb)[2][3], int half) {
+#if WGP_ABLATE == 1
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) asm volatile("" ::"v"(fa[a][q]), "v"(fb[a][q]));
+      return;
+#endif
+#define MSR3D_TERM(PA, PB)                                                                       \
+      _Pragma("unroll") for (int a = 0; a < 2; ++a)                                              \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b)                                              \
+          acc[2 * half + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][PA], fb[b][PB], acc[2 * half + a][b], 0, 0, 0);
+#if MSR3D_TRAIN_PLANES == 3
+      MSR3D_TERM(2, 0)
+      MSR3D_TERM(0, 2)
+      MSR3D_TERM(1, 1)
+      MSR3D_TERM(1, 0)
+      MSR3D_TERM(0, 1)
+#endif
+      MSR3D_TERM(0, 0)
+#undef MSR3D_TERM
+    };
+
+    Slab g0, g1;                                   // fetched rows of the slabs two and three ahead of the multiply
+    bf16x8 fa0[2][3], fa1[2][3], fb0[2][3], fb1[2][3];
+    uint4 pl[2][3];
+#if WGP_ABLATE == 4
+    for (int a = 0; a < 2; ++a)
+      for (int q = 0; q < 3; ++q) {
+        const bf16x8 c = {(short)(lane + a), (short)q, 1, 2, 3, 4, 5, 6};
+        fa0[a][q] = fa1[a][q] = fb0[a][q] = fb1[a][q] = c;
+      }
+#endif
+    // ---- prologue: slabs s_lo, s_lo + 1 stashed, s_lo + 2, s_lo + 3 in flight, slab s_lo's first fragments read ----
+    fetch(g0, s_lo);
+    fetch(g1, s_lo + 1);
+    split(g0, pl, true);
+    put(pl, 0);
+    fetch(g0, s_lo + 2);
+    split(g1, pl, true);
+    put(pl, 1);
+    fetch(g1, s_lo + 3);
+    __syncthreads();
+    read_a(fa0, 0, 0);
+    read_b(fb0, 0);
+    // One slab; `cur` = its stage, fbc / fbn = the B fragments of this / the next slab, g = the fetched rows of slab s + 2.
+    // No branch inside (a junk slab stashed or read past the end is never multiplied).
+    auto slab_body = [&](int s, int cur, bf16x8 (&fbc)[2][3], bf16x8 (&fbn)[2][3], Slab &g) {
+      read_a(fa1, cur, 1);                         // this slab's second half, under unit 0
+      __builtin_amdgcn_sched_barrier(0);
+      unit(fa0, fbc, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                             // stage `cur` read by everyone; slab s + 1 complete in the other stage
+      read_a(fa0, cur ^ 1, 0);                     // the next slab's first fragments ..
+      read_b(fbn, cur ^ 1);
+      split(g, pl, s + 2 < nslab);                 // .. and slab s + 2's planes (registers), under unit 1
+      unit(fa1, fbc, 1);
+#if defined(WGP_GROUPS)
+      // (measured and NOT kept: forcing one MFMA : five VALU with sched_group_barrier so that the split rides between the
+      //  wave's own products -- 120 us a launch against 106 with the compiler's order: profiles/r06_wgrad_ablation.txt)
+      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+      for (int q = 0; q < 24; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      put(pl, cur);                                // slab s + 2 into the stage this slab has left
+      fetch(g, s + 4);                             // (past the end: zeros, or rows nobody multiplies)
+    };
+    for (int s = s_lo; s < nslab; s += 2) {
+      slab_body(s, 0, fb0, fb1, g0);
+      slab_body(s + 1, 1, fb1, fb0, g1);
+    }
+  };
+  if (vec) run(std::true_type{});
+  else run(std::false_type{});
+  WG_STAMP(5);
+
+  __syncthreads();                                 // the last slab has been multiplied: LDS is free
+  float *red = reinterpret_cast<float *>(smem);    // [4 octets][128]: bias gradient = column sums of dy
+  if (!isx) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) red[o * TN + 2 * P + i] = cs[i];
+  }
+  if (HALVES && hf.role == 1) {
+    // the other half's image must be there: its owner took its ticket before this unit did, so it is running (or done)
+    if (tid == 0)
+      while (__hip_atomic_load(hf.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+  }
+  __syncthreads();
+  if (HALVES && hf.role == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (pr.db && ktile == 0 && tid < TN) {
+    const int c = tid;
+    float t = (red[c] + red[TN + c]) + (red[2 * TN + c] + red[3 * TN + c]);
+    if (HALVES && hf.role == 0) {
+      hf.ws[TN * TK + c] = t;
+    } else {
+      if (HALVES && hf.role == 1) {
+        const float o2 = hf.ws[TN * TK + c];
+        t = hf.second ? o2 + t : t + o2;           // first half + second half
+      }
+      if (n0 + c < pr.n_out) pr.db[n0 + c] += t;
+    }
+  }
+  // D[n][k]: lane (j = k column, g): rows n = 4 g + r.  dW holds the value to add to; this workgroup is the tile's
+  // only writer.
+  const int j = lane & 15, g = lane >> 4;
+  if (HALVES && hf.role == 0) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        *reinterpret_cast<f32x4 *>(hf.ws + (((wave * 4 + a) * 2 + b) * 64 + lane) * 4) = acc[a][b];
+  } else {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        if (HALVES && hf.role == 1) {
+          const f32x4 o2 = *reinterpret_cast<const f32x4 *>(hf.ws + (((wave * 4 + a) * 2 + b) * 64 + lane) * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc[a][b][r] = hf.second ? o2[r] + acc[a][b][r] : acc[a][b][r] + o2[r];     // first half + second half
+        }
+      }
+    // dW += acc: all 32 reads of the lane in flight together, then the stores (a read-add-write per element waits for
+    // each read in turn: 32 dependent round trips at the end of every tile)
+    float old[4][2][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int kk = k0 + 32 * wc + 16 * b + j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + 64 * wr + 16 * a + 4 * g + r;
+          const bool ok = n < pr.n_out && kk < pr.k_in;
+          old[a][b][r] = ok ? pr.dW[(size_t)n * pr.ldw + kk] : 0.f;
+        }
+      }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int kk = k0 + 32 * wc + 16 * b + j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + 64 * wr + 16 * a + 4 * g + r;
+          if (n < pr.n_out && kk < pr.k_in) pr.dW[(size_t)n * pr.ldw + kk] = old[a][b][r] + acc[a][b][r];
+        }
+      }
+  }
+  if (HALVES) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                               // every wave's image stores (and column sums) have left the CU
+    if (tid == 0) {
+      if (hf.role == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(hf.flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (hf.role == 1) {
+        __hip_atomic_store(hf.flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // clean for the next launch
+      }
+    }
+  }
+  WG_STAMP(6);
+}
+
 // workgroups past `tiles` (msr3d_wgrad_split_colsum): one column-sum job each -- the LayerNorm parameter gradients'
 // second stage rides in the weight-gradient launch's second round instead of a launch of its own
-__global__ __launch_bounds__(NTHREADS) void wgrad_split_kernel(int nprob, const WP *__restrict__ probs,
+template <bool PIPE>
+__global__ __launch_bounds__(PIPE ? NTHREADS_PIPE : NTHREADS) void wgrad_split_kernel(int nprob, const WP *__restrict__ probs,
                                                           const int *__restrict__ prefix, int tiles,
                                                           const msr3d_colsum_job_t *__restrict__ cjobs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -360,7 +670,8 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_split_kernel(int nprob, const 
   const int local = ((lb - pr.xcd_rot) & 7) * (nb >> 3) + (lb >> 3);
   const int nkt = (pr.k_in + TK - 1) / TK;
   if (local >= ((pr.n_out + TN - 1) / TN) * nkt) return;
-  wgrad_tile<false>(pr, local / nkt, local % nkt, smem);
+  if constexpr (PIPE) wgrad_tile_pipe<false>(pr, local / nkt, local % nkt, smem);
+  else wgrad_tile<false>(pr, local / nkt, local % nkt, smem);
 }
 
 // The same tiles as wgrad_split_kernel, each as TWO units (gridDim.x = 2 x padded tiles): workgroups [0, T) hold the
@@ -416,7 +727,8 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_halves_kernel(int nprob, const
 // of 8: both halves on one XCD), so the second round lasts half a tile time.  Same ticket protocol as above (the unit
 // that STARTS first parks, the second adds first + second in that order: bit-reproducible); workgroups past W + 2 H
 // run the column-sum jobs.  sync: [H] tickets | [H] flags, zero between launches; ws: H slots.
-__global__ __launch_bounds__(NTHREADS) void wgrad_mixed_kernel(int nprob, const WP *__restrict__ probs,
+template <bool PIPE>
+__global__ __launch_bounds__(PIPE ? NTHREADS_PIPE : NTHREADS) void wgrad_mixed_kernel(int nprob, const WP *__restrict__ probs,
                                                                const int *__restrict__ prefix, int tiles, int W,
                                                                float *__restrict__ ws, int *__restrict__ sync,
                                                                const msr3d_colsum_job_t *__restrict__ cjobs) {
@@ -441,7 +753,8 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_mixed_kernel(int nprob, const 
   const int nkt = (pr.k_in + TK - 1) / TK;
   if (local >= ((pr.n_out + TN - 1) / TN) * nkt) return;
   if (!halved) {
-    wgrad_tile<false>(pr, local / nkt, local % nkt, smem);
+    if constexpr (PIPE) wgrad_tile_pipe<false>(pr, local / nkt, local % nkt, smem);
+    else wgrad_tile<false>(pr, local / nkt, local % nkt, smem);
     return;
   }
   const int nslab = ((pr.M + 63) >> 6) << 1;
@@ -466,7 +779,8 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_mixed_kernel(int nprob, const 
     __syncthreads();
     hf.role = role_s;
   }
-  wgrad_tile<false, false, false, true>(pr, local / nkt, local % nkt, smem, 0, 0, nullptr, hf);
+  if constexpr (PIPE) wgrad_tile_pipe<true>(pr, local / nkt, local % nkt, smem, hf);
+  else wgrad_tile<false, false, false, true>(pr, local / nkt, local % nkt, smem, 0, 0, nullptr, hf);
 }
 
 // TALL problems (an unfrozen backbone's SharedMLP layers: dW (<= 256 x <= 256) over 10^5 .. 10^6 rows): the rows are
@@ -535,18 +849,46 @@ __global__ __launch_bounds__(256) void wgrad_rows_reduce_kernel(int n_out, int k
   *d = accumulate ? *d + t : t;
 }
 
+// MSR3D_WGRAD_PIPE=0: the 16-wave loader / multiplier form of rounds 4-5 (wgrad_tile); default: wgrad_tile_pipe
+int g_pipe_form = -1;             // -1: not chosen yet (environment at first use)
+bool pipe_form() {
+  if (g_pipe_form < 0) {
+    const char *v = getenv("MSR3D_WGRAD_PIPE");
+    g_pipe_form = (v && v[0] == '0') ? 0 : 1;
+  }
+  return g_pipe_form != 0;
+}
+
+int launch_split(int n, const WP *problems, const int *tile_prefix, int total_tiles, int n_jobs,
+                 const msr3d_colsum_job_t *jobs, hipStream_t stream) {
+  if (pipe_form()) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_split_kernel<true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (attr != hipSuccess) return (int)attr;
+    wgrad_split_kernel<true><<<total_tiles + n_jobs, NTHREADS_PIPE, LDS_BYTES, stream>>>(n, problems, tile_prefix, total_tiles, jobs);
+    return (int)hipGetLastError();
+  }
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_split_kernel<false>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (attr != hipSuccess) return (int)attr;
+  wgrad_split_kernel<false><<<total_tiles + n_jobs, NTHREADS, LDS_BYTES, stream>>>(n, problems, tile_prefix, total_tiles, jobs);
+  return (int)hipGetLastError();
+}
+
 }  // namespace
+
+extern "C" int msr3d_wgrad_form(int form) {
+  if (form == 0 || form == 1) g_pipe_form = form;
+  else if (form != -1) return MSR3D_EINVAL;
+  return pipe_form() ? 1 : 0;
+}
 
 extern "C" int msr3d_wgrad_split(int n, const msr3d_wgrad_problem_t *problems, const int *tile_prefix,
                                  int total_tiles, msr3d_stream_t stream) {
   if (n < 0 || total_tiles < 0) return MSR3D_EINVAL;
   if (n == 0 || total_tiles == 0) return 0;
   if (!problems || !tile_prefix) return MSR3D_EINVAL;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_split_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  if (attr != hipSuccess) return (int)attr;
-  wgrad_split_kernel<<<total_tiles, NTHREADS, LDS_BYTES, (hipStream_t)stream>>>(n, problems, tile_prefix, total_tiles, nullptr);
-  return (int)hipGetLastError();
+  return launch_split(n, problems, tile_prefix, total_tiles, 0, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int msr3d_wgrad_split_colsum(int n, const msr3d_wgrad_problem_t *problems, const int *tile_prefix,
@@ -555,12 +897,7 @@ extern "C" int msr3d_wgrad_split_colsum(int n, const msr3d_wgrad_problem_t *prob
   if (n < 0 || total_tiles < 0 || n_jobs < 0) return MSR3D_EINVAL;
   if ((n == 0 || total_tiles == 0) && n_jobs == 0) return 0;
   if ((total_tiles > 0 && (!problems || !tile_prefix)) || (n_jobs > 0 && !jobs)) return MSR3D_EINVAL;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_split_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  if (attr != hipSuccess) return (int)attr;
-  wgrad_split_kernel<<<total_tiles + n_jobs, NTHREADS, LDS_BYTES, (hipStream_t)stream>>>(n, problems, tile_prefix,
-                                                                                        total_tiles, jobs);
-  return (int)hipGetLastError();
+  return launch_split(n, problems, tile_prefix, total_tiles, n_jobs, jobs, (hipStream_t)stream);
 }
 
 extern "C" int msr3d_wgrad_split_halves(int n, const msr3d_wgrad_problem_t *problems, const int *tile_prefix,
@@ -586,10 +923,18 @@ extern "C" int msr3d_wgrad_split_mixed(int n, const msr3d_wgrad_problem_t *probl
   const int H = total_tiles - whole_tiles;
   if ((total_tiles > 0 && (!problems || !tile_prefix)) || (n_jobs > 0 && !jobs) || (H & 7) || (whole_tiles & 7)) return MSR3D_EINVAL;
   if (H > 0 && (!workspace || !sync || workspace_floats < (long long)H * MSR3D_WGRAD_HALF_SLOT_FLOATS)) return MSR3D_EINVAL;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_mixed_kernel),
+  if (pipe_form()) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_mixed_kernel<true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (attr != hipSuccess) return (int)attr;
+    wgrad_mixed_kernel<true><<<whole_tiles + 2 * H + n_jobs, NTHREADS_PIPE, LDS_BYTES, (hipStream_t)stream>>>(
+        n, problems, tile_prefix, total_tiles, whole_tiles, workspace, sync, jobs);
+    return (int)hipGetLastError();
+  }
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_mixed_kernel<false>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (attr != hipSuccess) return (int)attr;
-  wgrad_mixed_kernel<<<whole_tiles + 2 * H + n_jobs, NTHREADS, LDS_BYTES, (hipStream_t)stream>>>(
+  wgrad_mixed_kernel<false><<<whole_tiles + 2 * H + n_jobs, NTHREADS, LDS_BYTES, (hipStream_t)stream>>>(
       n, problems, tile_prefix, total_tiles, whole_tiles, workspace, sync, jobs);
   return (int)hipGetLastError();
 }

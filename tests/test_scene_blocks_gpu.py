@@ -95,6 +95,49 @@ def test_wgrad_split_vs_float64(M, n_out, k_in, halves):
     assert torch.equal(dW, dW2) and torch.equal(db, db2)
 
 
+@pytest.mark.parametrize("mixed", [False, True])
+def test_wgrad_pipe_form_gives_the_bits_of_the_loader_multiplier_form(mixed):
+    """Round 6's tile kernel (eight waves that load, split, stash AND multiply; the next half-slab's fragment reads under
+    the current half-slab's MFMAs) against rounds 4-5's eight loader + eight multiplier waves, on the bench step's problem
+    set (whole tiles, and the mixed launch with its half-reductions): the same products summed in the same order --
+    torch.equal on every dW and db, odd shapes and unaligned rows included."""
+    from msr3d_amd import _lib
+    from msr3d_amd.scene_blocks import WgradTable
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    shapes = [(960, 4096, 256), (960, 256, 2048), (960, 2048, 256), (960, 816, 256), (960, 256, 256), (960, 256, 63),
+              (960, 256, 3), (957, 256, 768)]
+    torch.manual_seed(5)
+    ops = []
+    for M, n_out, k_in in shapes:
+        dy = torch.randn(M, n_out, device=dev)
+        xw = torch.randn(M, k_in + 5, device=dev)
+        ops.append((dy, xw, xw[:, 1:1 + k_in] if k_in % 2 else xw[:, 2:2 + k_in], torch.randn(n_out, k_in, device=dev),
+                    torch.randn(n_out, device=dev)))
+    prev = lib.msr3d_wgrad_form(-1)
+    out = {}
+    try:
+        for form in (0, 1):
+            assert lib.msr3d_wgrad_form(form) == form
+            t = WgradTable(dev)
+            t.mixed = mixed
+            res = []
+            for dy, xw, x, dW0, db0 in ops:
+                dW, db = dW0.clone(), db0.clone()
+                res.append((dW, db))
+                t.add(dy.data_ptr(), dy.shape[1], dy.shape[1], x.data_ptr(), xw.stride(0), x.shape[1], dy.shape[0],
+                      dW.data_ptr(), x.shape[1], db.data_ptr())
+            t.launch(_lib.current_stream_ptr(dev))
+            torch.cuda.synchronize()
+            out[form] = res
+    finally:
+        lib.msr3d_wgrad_form(prev)
+    for (dy, xw, x, dW0, db0), (a, ab), (b, bb) in zip(ops, out[0], out[1]):
+        assert torch.equal(a, b) and torch.equal(ab, bb), (dy.shape, x.shape)
+        want = dW0.double() + dy.double().t() @ x.double()
+        assert float((b.double() - want).norm() / want.norm()) < 2e-6
+
+
 def _rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 

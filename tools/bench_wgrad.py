@@ -33,20 +33,23 @@ def build(mixed, halves=False):
 
 
 st = _lib.current_stream_ptr(dev)
-for name, kw in (("whole tiles", dict(mixed=False)), ("mixed", dict(mixed=True)), ("all halved", dict(mixed=False, halves=True))):
-    t, keep = build(**kw)
-    if "WHOLE" in os.environ and kw.get("mixed"):
-        t._whole_tiles()
-        t._whole = int(os.environ["WHOLE"])
-    for _ in range(5):
-        t.launch(st)
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(30):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); t.launch(st); e1.record()
-        torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1) * 1e3)
-    ts.sort()
-    extra = f" whole {t._whole_tiles()} of {t.prefix[-1]} workgroups, xcd load {t.xcd_load}" if kw.get("mixed") else ""
-    print(f"{name:12s} median {ts[len(ts) // 2]:7.1f} us  min {ts[0]:7.1f} us{extra}")
+for form in (0, 1):
+  _lib.load().msr3d_wgrad_form(form)
+  print("tile kernel:", "pipe (8 waves, round 6)" if form else "loader + multiplier waves (rounds 4-5)")
+  for name, kw in (("whole tiles", dict(mixed=False)), ("mixed", dict(mixed=True)), ("all halved", dict(mixed=False, halves=True))):
+      t, keep = build(**kw)
+      if "WHOLE" in os.environ and kw.get("mixed"):
+          t._whole_tiles()
+          t._whole = int(os.environ["WHOLE"])
+      for _ in range(5):
+          t.launch(st)
+      torch.cuda.synchronize()
+      ts = []
+      for _ in range(30):
+          e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+          e0.record(); t.launch(st); e1.record()
+          torch.cuda.synchronize()
+          ts.append(e0.elapsed_time(e1) * 1e3)
+      ts.sort()
+      extra = f" whole {t._whole_tiles()} of {t.prefix[-1]} workgroups, xcd load {t.xcd_load}" if kw.get("mixed") else ""
+      print(f"{name:12s} median {ts[len(ts) // 2]:7.1f} us  min {ts[0]:7.1f} us{extra}")
