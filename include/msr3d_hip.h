@@ -590,6 +590,18 @@ int msr3d_scene_prologue(int B, int L, const float *obj_locs, const unsigned cha
                          unsigned char *valid_out, float *anchor_loc_out, float *anchor_ori_out,
                          msr3d_stream_t stream);
 
+/* msr3d_scene_prologue for situation_type 'as_object' (/root/reference/model/ose3d_situation.py:334-349): every scene gets
+ * the AGENT as token 0 -- box [anchor_loc | agent_size (3 floats: the module's constant anchor_size)], always valid --
+ * in front of its O objects; outputs are over L = O + 1 tokens (pairwise (B,L,L,5), locs (B,L,6), pad / valid (B,L);
+ * fourier_out (B,L,3 + 6 nb): Fourier rows of the raw centres, no agent-frame transform -- this configuration does not read
+ * them), and quat_fourier_out (B, 4 + 8 nb), optional, receives generate_fourier_features of the orientation quaternion:
+ * the orientation encoder's input. */
+int msr3d_scene_prologue_agent(int B, int O, const float *obj_locs, const unsigned char *obj_valid,
+                               const float *anchor_loc, const float *anchor_ori, const float *agent_size,
+                               const float *freqs, int num_bands, float eps, float *pairwise_out, float *fourier_out,
+                               float *locs_out, unsigned char *pad_out, unsigned char *valid_out, float *quat_fourier_out,
+                               float *anchor_loc_out, float *anchor_ori_out, msr3d_stream_t stream);
+
 /* zero_region[0..n_floats) = 0 (n_floats % 4 == 0) and, if seed != NULL, the dropout seed bump of
  * msr3d_bump_seed -- the step's one fill for all split-K meeting points. */
 int msr3d_step_begin(float *zero_region, long long n_floats, unsigned long long *seed,
@@ -612,6 +624,31 @@ int msr3d_pos_embed_bwd(int M, const float *d0, const float *d1, const float *d2
                         const float *stats_b, const float *gamma_b, float *d_lin_a, float *d_lin_b,
                         float *dgamma_a, float *dbeta_a, float *dgamma_b, float *dbeta_b,
                         float *colsum1, float *colsum2, msr3d_stream_t stream);
+
+/* The front of the situated encoder when the AGENT IS A TOKEN (situation_type 'as_object', /root/reference/model/
+ * ose3d_situation.py:334-353,384-386: configs/leo_3_dataset_pure_txt.yaml's prompter), rows (B, L) with row (b, 0) the
+ * agent and rows (b, 1..L-1) the scene's objects:
+ *     v    = (anchor_feat + a_ori[b]) + type_emb[1]                 agent row   (a_ori (B,256) = orientation_encoder output)
+ *          = (x0[row] + ori_feat) + type_emb[0]                     object rows (x0 (B L,256) = obj_linear_projection
+ *                                                                   output; its agent rows are not read; ori_feat may be NULL)
+ *     pos  = LayerNorm(loc6[row] W_loc^T + b_loc)                   loc_layers[0]: W_loc (256,6), loc6 (B L,6)
+ *     xin0 = v + pos, also written as the first attention block's operand planes (planes: (B,3,64,256) bf16, or NULL;
+ *            L <= 64 with planes)
+ * pos, s_lin (the pre-norm linear output), stats (B L,2) are kept for the later layers ('same_all') and the backward. */
+int msr3d_anchor_front_fwd(int B, int L, const float *x0, const float *a_ori, const float *anchor_feat,
+                           const float *type_emb, const float *ori_feat, const float *loc6, const float *W_loc,
+                           const float *b_loc, const float *gamma, const float *beta, float eps, float *pos,
+                           float *s_lin, float *stats, float *xin0, unsigned short *planes, msr3d_stream_t stream);
+/* Its row-wise backward.  d pos = d0 + d1 + d2 (d1, d2: the later layers' input gradients, optional), d v = d0.
+ * d_lin (B L,256) = gradient of the location layer's output (LayerNorm backward of d pos); dgamma / dbeta accumulated;
+ * the column sum of d0 over the OBJECT rows is added to obj_sum_a / _b / _c (type_embedding[0], object_orientation_feat,
+ * obj_linear_projection.bias) and over the AGENT rows to agent_sum_a / _b (type_embedding[1], anchor_feat); each optional.
+ * (The orientation encoder's and the projection's weight gradients read d0 itself: agent rows at stride L * 256, and all
+ * rows against a feature matrix whose agent rows are zero.)  Float atomics: not bit-reproducible. */
+int msr3d_anchor_front_bwd(int B, int L, const float *d0, const float *d1, const float *d2, const float *s_lin,
+                           const float *stats, const float *gamma, float *d_lin, float *dgamma, float *dbeta,
+                           float *obj_sum_a, float *obj_sum_b, float *obj_sum_c, float *agent_sum_a,
+                           float *agent_sum_b, msr3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * The trainable part as SCENE-LOCAL fused blocks on the bf16 matrix pipe at fp32 accuracy

@@ -47,6 +47,7 @@ SOURCES = [
     ("llm_layer.hip", []),
     ("llm_attn.hip", []),
     ("prompter_rows.hip", ["-ffp-contract=off"]),
+    ("anchor_front.hip", ["-ffp-contract=off"]),
     ("scene_block.hip", []),
     ("scene_rows.hip", []),
     ("wgrad_split.hip", []),

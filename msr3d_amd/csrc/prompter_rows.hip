@@ -36,7 +36,11 @@ __global__ __launch_bounds__(256) void scene_prologue_kernel(
     const float *__restrict__ anchor_loc, const float *__restrict__ anchor_ori,
     const float *__restrict__ freqs, int nb, int transform, float eps, float *__restrict__ pw,
     float *__restrict__ ff, float *__restrict__ loc_out, unsigned char *__restrict__ pad,
-    unsigned char *__restrict__ valid_out, float *__restrict__ anchor_loc_out, float *__restrict__ anchor_ori_out) {
+    unsigned char *__restrict__ valid_out, float *__restrict__ anchor_loc_out, float *__restrict__ anchor_ori_out,
+    const float *__restrict__ agent_size, float *__restrict__ quat_ff) {
+  // agent_size != NULL (msr3d_scene_prologue_agent): token 0 of every scene is the AGENT -- box = [anchor_loc | agent_size],
+  // always valid -- and tokens 1 .. L-1 are the scene's L-1 objects (loc, valid: (B, L-1, ..)); quat_ff (B, 4 + 8 nb)
+  // receives the Fourier rows of the orientation quaternion (generate_fourier_features of a (B,1,4) input)
   __shared__ float cx[128], cy[128], cz[128];
   __shared__ float wmax[4];
   // grid (B, parts): the blocks of a sample each find the sample's largest distance (cheap, all pairs; a maximum,
@@ -48,16 +52,40 @@ __global__ __launch_bounds__(256) void scene_prologue_kernel(
     if (tid < 3) { if (anchor_loc_out && anchor_loc) anchor_loc_out[b * 3 + tid] = anchor_loc[b * 3 + tid]; }
     else if (anchor_ori_out && anchor_ori) anchor_ori_out[b * 4 + tid - 3] = anchor_ori[b * 4 + tid - 3];
   }
+  const int LO = agent_size ? L - 1 : L, off = agent_size ? 1 : 0;       // objects per scene; first object token
   for (int i = tid; i < L; i += 256) {
-    const float *p = loc + ((size_t)b * L + i) * 6;
-    const float x = p[0], y = p[1], z = p[2];
-    cx[i] = x; cy[i] = y; cz[i] = z;
+    float bx[6];
+    unsigned char ok = 1;
+    if (i < off) {
+      bx[0] = anchor_loc[b * 3]; bx[1] = anchor_loc[b * 3 + 1]; bx[2] = anchor_loc[b * 3 + 2];
+      bx[3] = agent_size[0]; bx[4] = agent_size[1]; bx[5] = agent_size[2];
+    } else {
+      const float *p = loc + ((size_t)b * LO + i - off) * 6;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) bx[k] = p[k];
+      ok = valid[(size_t)b * LO + i - off] ? 1 : 0;
+    }
+    cx[i] = bx[0]; cy[i] = bx[1]; cz[i] = bx[2];
     if (part == 0) {
       float *q = loc_out + ((size_t)b * L + i) * 6;
-      q[0] = x; q[1] = y; q[2] = z; q[3] = p[3]; q[4] = p[4]; q[5] = p[5];
-      const unsigned char ok = valid[(size_t)b * L + i] ? 1 : 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) q[k] = bx[k];
       pad[(size_t)b * L + i] = ok ^ 1;
       if (valid_out) valid_out[(size_t)b * L + i] = ok;
+    }
+  }
+  if (quat_ff && part == 1 % parts) {
+    // [q (4) | sin(pi q_c f_k), (c, k) flattened (4 nb) | cos(..) (4 nb)]: ose3d_situation.py:31-59 on a (B,1,4) input
+    const float pi = 3.14159265358979323846f;
+    const int Wq = 4 + 8 * nb;
+    for (int e = tid; e < 4 * nb; e += 256) {
+      const int c = e / nb, k = e - c * nb;
+      const float v = anchor_ori[b * 4 + c];
+      float *o = quat_ff + (size_t)b * Wq;
+      if (k == 0) o[c] = v;
+      const float sarg = pi * (v * freqs[k]);
+      o[4 + c * nb + k] = sinf(sarg);
+      o[4 + 4 * nb + c * nb + k] = cosf(sarg);
     }
   }
   __syncthreads();
@@ -280,7 +308,24 @@ int msr3d_scene_prologue(int B, int L, const float *obj_locs, const unsigned cha
   scene_prologue_kernel<<<dim3(B, 16), 256, 0, (hipStream_t)stream>>>(L, obj_locs, obj_valid, anchor_loc, anchor_ori,
                                                            freqs, num_bands, transform, eps, pairwise_out,
                                                            fourier_out, locs_out, pad_out, valid_out, anchor_loc_out,
-                                                           anchor_ori_out);
+                                                           anchor_ori_out, nullptr, nullptr);
+  return (int)hipGetLastError();
+}
+
+int msr3d_scene_prologue_agent(int B, int O, const float *obj_locs, const unsigned char *obj_valid,
+                               const float *anchor_loc, const float *anchor_ori, const float *agent_size,
+                               const float *freqs, int num_bands, float eps, float *pairwise_out, float *fourier_out,
+                               float *locs_out, unsigned char *pad_out, unsigned char *valid_out, float *quat_fourier_out,
+                               float *anchor_loc_out, float *anchor_ori_out, msr3d_stream_t stream) {
+  if (B < 0 || O <= 0 || O + 1 > 128 || num_bands <= 0) return MSR3D_EINVAL;
+  if (B == 0) return 0;
+  if (!obj_locs || !obj_valid || !anchor_loc || !anchor_ori || !agent_size || !freqs || !pairwise_out || !fourier_out ||
+      !locs_out || !pad_out)
+    return MSR3D_EINVAL;
+  scene_prologue_kernel<<<dim3(B, 16), 256, 0, (hipStream_t)stream>>>(O + 1, obj_locs, obj_valid, anchor_loc, anchor_ori,
+                                                           freqs, num_bands, 0, eps, pairwise_out, fourier_out, locs_out,
+                                                           pad_out, valid_out, anchor_loc_out, anchor_ori_out, agent_size,
+                                                           quat_fourier_out);
   return (int)hipGetLastError();
 }
 

@@ -170,6 +170,26 @@ __device__ __forceinline__ void store_partials(const f32x4 (&acc)[RN][4], float 
     }
 }
 
+// A dense fp32 slab (the scene's pairwise features, a head's probabilities) whose start is 4- but not 16-byte aligned --
+// L = 61: the agent token of situation_type 'as_object' -- still travels as 16-byte vectors: the loads start at the
+// 16-byte boundary below it (`mis` floats early) through a buffer descriptor that ends with the slab (the tail's lanes
+// past it read 0, nothing outside [start - mis, end) is touched), and the consumer finds element i at position i + mis.
+struct Slab4 {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int mis, n4;                           // floats in front of the slab; 16-byte vectors covering mis + n floats
+};
+__device__ __forceinline__ Slab4 make_slab4(const float *src, int n) {
+  Slab4 s;
+  s.mis = (int)((reinterpret_cast<uintptr_t>(src) >> 2) & 3u);
+  s.n4 = (s.mis + n + 3) >> 2;
+  s.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src - s.mis), 0, (s.mis + n) * 4, 0x00020000);
+  return s;
+}
+__device__ __forceinline__ float4 slab4_load(const Slab4 &s, int e) {
+  const sm_i32x4 r = __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, e * 16, 0, 0);       // (e >= n4: out of range, zeros)
+  return make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
+}
+
 // LDS carve-up behind the ROWS planes, by kind
 constexpr int kTile = TM * LD32 * 4;                       // one [64][36] fp32 head tile: 9,216 B
 constexpr int kAttnFwdAux = 3 * kTile + 2048 + 4 * 3 * 1024;          // q k v | cond [64][8] | ctx FRAG (1 slab)
@@ -569,7 +589,8 @@ __global__ __launch_bounds__(512) void scene_attn_fwd2_kernel(const SB p) {
   const int nq = min(32, L - q0);
   const float *plsrc = p.ploc + ((size_t)b * L + q0) * L * SD;
   const int pn = nq * L * SD;
-  const bool pvec = (reinterpret_cast<uintptr_t>(plsrc) & 15u) == 0 && (pn & 3) == 0;
+  const Slab4 pls = make_slab4(plsrc, pn);
+  constexpr bool pvec = true;            // (any alignment, any count: Slab4)
   float4 plv[kPloc2Regs];
   // The scene's planes, THIS half's 32 rows first and the other half's only when those have arrived: the pair's two
   // workgroups (same XCD) then miss on disjoint halves and hit, in L2, on what the partner has fetched -- all 64 rows
@@ -599,10 +620,7 @@ __global__ __launch_bounds__(512) void scene_attn_fwd2_kernel(const SB p) {
         __builtin_amdgcn_sched_barrier(0);
         if (pvec && !kv) {
 #pragma unroll
-          for (int k2 = 0; k2 < kPloc2Regs; ++k2) {
-            const int e = tid - 256 + 256 * k2;
-            plv[k2] = e < (pn >> 2) ? reinterpret_cast<const float4 *>(plsrc)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-          }
+          for (int k2 = 0; k2 < kPloc2Regs; ++k2) plv[k2] = slab4_load(pls, tid - 256 + 256 * k2);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -678,17 +696,14 @@ __global__ __launch_bounds__(512) void scene_attn_fwd2_kernel(const SB p) {
   constexpr int LDP = TM + 4;
   float *sp = reinterpret_cast<float *>(xs);                                // P [32][68], then the half's pairwise slab
   float *spl = sp + 32 * LDP;
-  if (pvec) {
-    if (!kv) {
+  if (!kv) {
 #pragma unroll
-      for (int k = 0; k < kPloc2Regs; ++k) {
-        const int e = tid - 256 + 256 * k;
-        if (e < (pn >> 2)) reinterpret_cast<float4 *>(spl)[e] = plv[k];
-      }
+    for (int k = 0; k < kPloc2Regs; ++k) {
+      const int e = tid - 256 + 256 * k;
+      if (e < pls.n4) reinterpret_cast<float4 *>(spl)[e] = plv[k];
     }
-  } else {
-    for (int e = tid; e < pn; e += 512) spl[e] = plsrc[e];
   }
+  spl += pls.mis;                                                           // (element i of the slab)
   __syncthreads();
   SB_STAMP(5);
   // ---- the core: wave (qt, kq) ----
@@ -999,26 +1014,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     tc = (row < L && c < SD + 1) ? p.qkvc[(size_t)(row_base + row) * ldq + 3 * KD + h * (SD + 1) + c] : 0.f;
   }
   const float *plsrc = p.ploc + (size_t)b * L * L * SD, *prsrc = p.probs + ((size_t)b * H + h) * L * L;
-  const int pn = L * L * SD, qn4 = (L * L) >> 2;
-  const bool pvec = (reinterpret_cast<uintptr_t>(plsrc) & 15u) == 0 && (pn & 3) == 0;
-  const bool qvec = (reinterpret_cast<uintptr_t>(prsrc) & 15u) == 0 && (L & 3) == 0;
+  const int pn = L * L * SD, qn = L * L;
+  // both slabs as 16-byte vectors whatever their alignment (L = 61: the agent token of 'as_object'): Slab4
+  const Slab4 pls = make_slab4(plsrc, pn), prs = make_slab4(prsrc, qn);
+  const bool qrow4 = prs.mis == 0 && (L & 3) == 0;      // a vector of probabilities never straddles a row
   float4 prv[2], plv[10];
   // (the slab is asked for WITH the planes: behind them and ahead of product 1's last pieces it was waited for with those
   //  pieces -- loads complete in order)
-  if (pvec) {
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
-      const int e = tid + 512 * k;
-      plv[k] = e < (pn >> 2) ? reinterpret_cast<const float4 *>(plsrc)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  if (qvec) {
+  for (int k = 0; k < 10; ++k) plv[k] = slab4_load(pls, tid + 512 * k);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int e = tid + 512 * k;
-      prv[k] = e < qn4 ? reinterpret_cast<const float4 *>(prsrc)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
+  for (int k = 0; k < 2; ++k) prv[k] = slab4_load(prs, tid + 512 * k);
   {
     const int row = tid >> 3, c4 = (tid & 7) * 4;
 #pragma unroll
@@ -1056,32 +1062,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __syncthreads();                         // planes free; q / k / v / cond / d ctx visible
   float *sp = reinterpret_cast<float *>(xs);
   float *spl = sp + TM * LDP;
-  if (qvec) {
+  if (qrow4) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int e = tid + 512 * k;
-      if (e < qn4) {
+      if (e < prs.n4) {
         const int idx = 4 * e, row = idx / L, col = idx - row * L;
         *reinterpret_cast<float4 *>(sp + row * LDP + col) = prv[k];
       }
     }
-    for (int e = tid; e < 64 * 64; e += 512) {
-      const int row = e >> 6, col = e & 63;
-      if (row >= L || col >= L) sp[row * LDP + col] = 0.f;
-    }
   } else {
-    msr3d_attn::load_probs_tile<TM>(prsrc, L, sp);
-  }
-  const float *plb = spl;
-  if (pvec) {
+    const float invL = 1.0f / (float)L;
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
+    for (int k = 0; k < 2; ++k) {
       const int e = tid + 512 * k;
-      if (e < (pn >> 2)) reinterpret_cast<float4 *>(spl)[e] = plv[k];
+      const float v4[4] = {prv[k].x, prv[k].y, prv[k].z, prv[k].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx = 4 * e + q - prs.mis;
+        if (idx >= 0 && idx < qn) {
+          const int row = (int)(((float)idx + 0.5f) * invL);      // exact for idx < 2^22: idx / L
+          sp[row * LDP + idx - row * L] = v4[q];
+        }
+      }
     }
-  } else {
-    plb = msr3d_attn::stage_ploc<TM>(p.ploc, b, L, spl);
   }
+  for (int e = tid; e < 64 * 64; e += 512) {
+    const int row = e >> 6, col = e & 63;
+    if (row >= L || col >= L) sp[row * LDP + col] = 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    const int e = tid + 512 * k;
+    if (e < pls.n4) reinterpret_cast<float4 *>(spl)[e] = plv[k];
+  }
+  const float *plb = spl + pls.mis;
   __syncthreads();
   SB_STAMP(5);
   // ---- the core: wave (t, kh) ----

@@ -122,7 +122,7 @@ class PrompterSchedule:
             # bit-reproducible mode (ordered split-K, ordered LayerNorm-gradient sums) lives in the
             # per-layer path; this schedule's K-splits and column sums meet by float atomics
             return False
-        if not (pr.situation_type == "as_transform_for_objects" and cfg.use_spatial_attn
+        if not (pr.situation_type in ("as_transform_for_objects", "as_object") and cfg.use_spatial_attn
                 and se.obj_loc_encoding in ("same_all", "same_0") and se.pairwise_rel_type == "center"
                 and se.spatial_dist_norm and se.spatial_dim == 5 and cfg.hidden_size == 256
                 and se.spatial_attn_fusion == "cond" and se.activation == "gelu"
@@ -131,6 +131,14 @@ class PrompterSchedule:
         B, L = e.shape[:2]
         if L > 128 or e.shape[-1] % 4 or cfg.loc_fourier_dim > 64:
             return False
+        if pr.situation_type == "as_object":
+            # the agent as a token of its own (round 6): on the scene-block schedule only, frozen encoder only
+            l0 = pr.spatial_encoder[0]
+            if not (self.anchor and _MODE[0] == "blocks" and hipops._attn_mma[0] == "f32" and not e.requires_grad
+                    and self._blocks_capable(L + 1, l0.linear1.out_features, l0.self_attn.n_head)
+                    and d.get("anchor_locs") is not None and d.get("anchor_orientation") is not None
+                    and (not pr.use_orientation or pr.orientation_encoder.in_features == 84)):   # 4 + 8 x 10 bands
+                return False
         # msr3d_pos_embed_bwd sums the positional gradient of at most three layers; the mask is read as bytes
         if not 1 <= len(pr.spatial_encoder) <= 3:
             return False
@@ -145,14 +153,26 @@ class PrompterSchedule:
                 return False
         return _direct(self.dp, self._params())
 
+    @property
+    def anchor(self):
+        """situation_type 'as_object': the agent is a token in front of the scene's objects (L = O + 1)."""
+        return self.pr.situation_type == "as_object" and bool(self.pr.use_anchor)
+
     def _params(self):
         pr, m = self.pr, self.model
-        ps = [pr.obj_linear_projection.weight, pr.obj_linear_projection.bias, pr.object_type_embedding.weight,
-              pr.loc_embedding_encoder[0].weight, pr.loc_embedding_encoder[0].bias,
-              pr.loc_embedding_encoder[1].weight, pr.loc_embedding_encoder[1].bias,
-              pr.size_embedding_encoder[0].weight, pr.size_embedding_encoder[0].bias,
-              pr.size_embedding_encoder[1].weight, pr.size_embedding_encoder[1].bias,
-              m.llm_proj.weight, m.llm_proj.bias]
+        if self.anchor:
+            ll = pr.loc_layers[0]
+            ps = [pr.obj_linear_projection.weight, pr.obj_linear_projection.bias, pr.object_type_embedding.weight,
+                  ll[0].weight, ll[0].bias, ll[1].weight, ll[1].bias, pr.anchor_feat, m.llm_proj.weight, m.llm_proj.bias]
+            if pr.use_orientation:
+                ps += [pr.orientation_encoder.weight, pr.orientation_encoder.bias]
+        else:
+            ps = [pr.obj_linear_projection.weight, pr.obj_linear_projection.bias, pr.object_type_embedding.weight,
+                  pr.loc_embedding_encoder[0].weight, pr.loc_embedding_encoder[0].bias,
+                  pr.loc_embedding_encoder[1].weight, pr.loc_embedding_encoder[1].bias,
+                  pr.size_embedding_encoder[0].weight, pr.size_embedding_encoder[0].bias,
+                  pr.size_embedding_encoder[1].weight, pr.size_embedding_encoder[1].bias,
+                  m.llm_proj.weight, m.llm_proj.bias]
         if pr.use_orientation:
             ps.append(pr.object_orientation_feat)
         for layer in pr.spatial_encoder:
@@ -165,7 +185,7 @@ class PrompterSchedule:
 
     # ------------------------------------------------------------------ storage
     def _ensure(self, B, L, KE, device):
-        key = (B, L, KE, str(device))
+        key = (B, L, KE, str(device), self.anchor)
         if self.shape == key:
             # The block tables hold RAW addresses of every parameter, every .grad view and the arena.  Anything
             # that re-points parameter storage after the tables were built -- FlatAdamW constructed later, a new
@@ -176,6 +196,8 @@ class PrompterSchedule:
                 self._build_block_tables()
             return
         pr, m = self.pr, self.model
+        LO = L                                  # objects per scene; L from here on = TOKENS per scene
+        L = LO + (1 if self.anchor else 0)
         D, M = 256, B * L
         nl = len(pr.spatial_encoder)
         sa0 = pr.spatial_encoder[0].self_attn
@@ -183,9 +205,15 @@ class PrompterSchedule:
         H = sa0.n_head
         FF = pr.spatial_encoder[0].linear1.out_features
         E = m.llm_proj.out_features
-        KF = pr.loc_embedding_encoder[0].in_features
+        KF = 63 if self.anchor else pr.loc_embedding_encoder[0].in_features    # (anchor: the prologue's Fourier rows, unread)
         a = _Arena(device)
         a.want("x0", M, D, zero=True)
+        if self.anchor:
+            QF = pr.orientation_encoder.in_features if pr.use_orientation else 4
+            a.want("a_ori", B, D, zero=True)     # orientation_encoder(fourier(quaternion)): one row per scene
+            a.want("e61", M, KE)                 # the object features with a ZERO row in front of every scene (never written)
+            a.want("qf", B, QF)                  # fourier(quaternion) rows
+
         for i in range(nl):
             a.want(f"ffn{i}", M, D, zero=True)
         a.want("d_tok", M, D, zero=True)
@@ -223,7 +251,8 @@ class PrompterSchedule:
         self.pad = torch.zeros(M, dtype=torch.uint8, device=device)
         self.valid = torch.zeros((B, L), dtype=torch.bool, device=device)      # static copy of obj_masks
         self.freqs = torch.linspace(1.0, 15, steps=10, device=device)
-        self.dims = dict(B=B, L=L, M=M, D=D, W=W, H=H, FF=FF, E=E, KF=KF, KE=KE, nl=nl)
+        self.dims = dict(B=B, L=L, LO=LO, M=M, D=D, W=W, H=H, FF=FF, E=E, KF=KF, KE=KE, nl=nl)
+
         self.shape = key
         self.staged_for = None
         self.packs = self.wgrad = None
@@ -290,14 +319,30 @@ class PrompterSchedule:
             wg.add(a[f"d_qkvc{i}"].data_ptr(), W, W, a[f"xin{i}"].data_ptr(), D, D, M, gwv.data_ptr(), D, gbv.data_ptr())
             wg.add(a[f"d_fc{i}"].data_ptr(), D, D, a[f"ctx{i}"].data_ptr(), D, D, M,
                    sa.fc.weight.grad.data_ptr(), D, sa.fc.bias.grad.data_ptr())
-        le, se = pr.loc_embedding_encoder, pr.size_embedding_encoder
-        wg.add(a["d_la"].data_ptr(), D, D, a["ff"].data_ptr(), KF, KF, M, le[0].weight.grad.data_ptr(), KF,
-               le[0].bias.grad.data_ptr())
-        wg.add(a["d_lb"].data_ptr(), D, D, a["loc6"].data_ptr() + 12, 6, 3, M, se[0].weight.grad.data_ptr(), 3,
-               se[0].bias.grad.data_ptr())
         lpj = pr.obj_linear_projection
-        self.wg_proj = wg.add(a["d_xacc0"].data_ptr(), D, D, 0, KE, KE, M, lpj.weight.grad.data_ptr(), KE,
-                              lpj.bias.grad.data_ptr())
+        if self.anchor:
+            L = dm["L"]
+            ll = pr.loc_layers[0]
+            wg.add(a["d_la"].data_ptr(), D, D, a["loc6"].data_ptr(), 6, 6, M, ll[0].weight.grad.data_ptr(), 6,
+                   ll[0].bias.grad.data_ptr())
+            if pr.use_orientation:
+                # dy = the AGENT rows of d xin0 (one per scene: row stride L * 256), x = fourier(quaternion)
+                oe = pr.orientation_encoder
+                QF = oe.in_features
+                wg.add(a["d_xacc0"].data_ptr(), L * D, D, a["qf"].data_ptr(), QF, QF, dm["B"], oe.weight.grad.data_ptr(), QF,
+                       oe.bias.grad.data_ptr())
+            # x = the features with a zero row per agent: those rows add nothing to dW; the bias gradient (object rows
+            # only) comes from msr3d_anchor_front_bwd
+            self.wg_proj = wg.add(a["d_xacc0"].data_ptr(), D, D, a["e61"].data_ptr(), KE, KE, M, lpj.weight.grad.data_ptr(),
+                                  KE, 0)
+        else:
+            le, se = pr.loc_embedding_encoder, pr.size_embedding_encoder
+            wg.add(a["d_la"].data_ptr(), D, D, a["ff"].data_ptr(), KF, KF, M, le[0].weight.grad.data_ptr(), KF,
+                   le[0].bias.grad.data_ptr())
+            wg.add(a["d_lb"].data_ptr(), D, D, a["loc6"].data_ptr() + 12, 6, 3, M, se[0].weight.grad.data_ptr(), 3,
+                   se[0].bias.grad.data_ptr())
+            self.wg_proj = wg.add(a["d_xacc0"].data_ptr(), D, D, 0, KE, KE, M, lpj.weight.grad.data_ptr(), KE,
+                                  lpj.bias.grad.data_ptr())
         self.packs, self.wgrad = pk, wg
 
     def forward_blocks(self, embeds):
@@ -311,8 +356,14 @@ class PrompterSchedule:
         self.stream = st = _lib.current_stream_ptr(dev)
         train = m.training
         seed = hipops.seed_word(dev)
-        e2 = embeds.reshape(M, KE)
-        e2 = e2 if e2.is_contiguous() else e2.contiguous()
+        anchor = self.anchor
+        if anchor:
+            # object features behind a zero agent row per scene (one strided copy; the agent rows are never written)
+            a["e61"].view(B, L, KE)[:, 1:].copy_(embeds.reshape(B, L - 1, KE))
+            e2 = a["e61"]
+        else:
+            e2 = embeds.reshape(M, KE)
+            e2 = e2 if e2.is_contiguous() else e2.contiguous()
         self.saved_embeds = e2
         layers = list(pr.spatial_encoder)
         self.salts = [[hipops._next_salt() for _ in range(4)] for _ in layers]
@@ -334,21 +385,40 @@ class PrompterSchedule:
                 _lib.check(rc, "msr3d_step_begin")
                 pk.launch(st)
             lp = pr.obj_linear_projection
-            self._multi([dict(a_kc=1, b_kc=1, M=M, N=D, K=KE, A=e2, lda=KE, B=lp.weight, ldb=KE, C=a["x0"], ldc=D,
-                              bias=lp.bias, beta=1.0)])
-            le, se = pr.loc_embedding_encoder, pr.size_embedding_encoder
-            rc = lib.msr3d_pos_embed_fwd(M, KF, _ptr(a["ff"]), _ptr(a["loc6"]), _ptr(le[0].weight), _ptr(le[0].bias),
-                                         _ptr(le[1].weight), _ptr(le[1].bias), ctypes.c_float(le[1].eps),
-                                         _ptr(se[0].weight), _ptr(se[0].bias), _ptr(se[1].weight), _ptr(se[1].bias),
-                                         ctypes.c_float(se[1].eps), _ptr(a["pos"]), _ptr(a["sa"]), _ptr(a["sta"]),
-                                         _ptr(a["sb"]), _ptr(a["stb"]), st)
-            _lib.check(rc, "msr3d_pos_embed_fwd")
+            front = [dict(a_kc=1, b_kc=1, M=M, N=D, K=KE, A=e2, lda=KE, B=lp.weight, ldb=KE, C=a["x0"], ldc=D,
+                          bias=lp.bias, beta=1.0)]
+            if anchor:
+                if pr.use_orientation:       # the agent's orientation term, one row per scene, in the projection's launch
+                    oe = pr.orientation_encoder
+                    front.append(dict(a_kc=1, b_kc=1, M=B, N=D, K=oe.in_features, A=a["qf"], lda=oe.in_features, B=oe.weight,
+                                      ldb=oe.in_features, C=a["a_ori"], ldc=D, bias=oe.bias, beta=1.0))
+                self._multi(front)
+                ll = pr.loc_layers[0]
+                # agent / object rows assembled, LN(loc_layers[0]) added, -> xin0 and the first block's planes: one launch
+                rc = lib.msr3d_anchor_front_fwd(B, L, _ptr(a["x0"]), _ptr(a["a_ori"]), _ptr(pr.anchor_feat),
+                                                _ptr(pr.object_type_embedding.weight),
+                                                _ptr(pr.object_orientation_feat) if pr.use_orientation else None,
+                                                _ptr(a["loc6"]), _ptr(ll[0].weight), _ptr(ll[0].bias), _ptr(ll[1].weight),
+                                                _ptr(ll[1].bias), ctypes.c_float(ll[1].eps), _ptr(a["pos"]), _ptr(a["sa"]),
+                                                _ptr(a["sta"]), _ptr(a["xin0"]), _vp(xp.data_ptr()), st)
+                _lib.check(rc, "msr3d_anchor_front_fwd")
+            else:
+                self._multi(front)
+                le, se = pr.loc_embedding_encoder, pr.size_embedding_encoder
+                rc = lib.msr3d_pos_embed_fwd(M, KF, _ptr(a["ff"]), _ptr(a["loc6"]), _ptr(le[0].weight), _ptr(le[0].bias),
+                                             _ptr(le[1].weight), _ptr(le[1].bias), ctypes.c_float(le[1].eps),
+                                             _ptr(se[0].weight), _ptr(se[0].bias), _ptr(se[1].weight), _ptr(se[1].bias),
+                                             ctypes.c_float(se[1].eps), _ptr(a["pos"]), _ptr(a["sa"]), _ptr(a["sta"]),
+                                             _ptr(a["sb"]), _ptr(a["stb"]), st)
+                _lib.check(rc, "msr3d_pos_embed_fwd")
             for i, layer in enumerate(layers):
                 sa = layer.self_attn
                 bv = sa._packed[1]
                 p_attn, p1, p2, p_ffn = self.ps[i]
                 s_attn, s_1, s_2, s_ffn = self.salts[i]
-                if i == 0:      # layer input = tokens + positional term + the two constant embedding rows
+                if i == 0 and anchor:
+                    pass        # (msr3d_anchor_front_fwd wrote xin0 and its planes)
+                elif i == 0:    # layer input = tokens + positional term + the two constant embedding rows
                     rows(st, M=M, L=L, pro=PRO["add"], a0=a["x0"], a1=a["pos"], g1=_ptr(pr.object_type_embedding.weight),
                          b1=_ptr(pr.object_orientation_feat) if pr.use_orientation else None, o1=a["xin0"], xp=xp)
                 else:           # previous layer's closing norm (+ the positional term)
@@ -447,16 +517,27 @@ class PrompterSchedule:
                     probs=a[f"probs{i}"], H=H)
                 src = dict(part=part, nslab=H, part_stride=MD, extra=a["res"])
             rows(st, M=M, L=L, pro=PRO["plain"], sum_out=a["d_xacc0"], **src)      # d_xin0, whole
-            le, se = pr.loc_embedding_encoder, pr.size_embedding_encoder
             more = same_all and nl > 1
-            rc = lib.msr3d_pos_embed_bwd(
-                M, _ptr(a["d_xacc0"]), _ptr(a["d_xacc1"]) if more else None,
-                _ptr(a["d_xacc2"]) if (more and nl > 2) else None, _ptr(a["sa"]), _ptr(a["sta"]), _ptr(le[1].weight),
-                _ptr(a["sb"]), _ptr(a["stb"]), _ptr(se[1].weight), _ptr(a["d_la"]), _ptr(a["d_lb"]),
-                _ptr(le[1].weight.grad), _ptr(le[1].bias.grad), _ptr(se[1].weight.grad), _ptr(se[1].bias.grad),
-                _ptr(pr.object_type_embedding.weight.grad),
-                _ptr(pr.object_orientation_feat.grad) if pr.use_orientation else None, st)
-            _lib.check(rc, "msr3d_pos_embed_bwd")
+            if self.anchor:
+                ll = pr.loc_layers[0]
+                tg = pr.object_type_embedding.weight.grad
+                rc = lib.msr3d_anchor_front_bwd(
+                    B, L, _ptr(a["d_xacc0"]), _ptr(a["d_xacc1"]) if more else None,
+                    _ptr(a["d_xacc2"]) if (more and nl > 2) else None, _ptr(a["sa"]), _ptr(a["sta"]), _ptr(ll[1].weight),
+                    _ptr(a["d_la"]), _ptr(ll[1].weight.grad), _ptr(ll[1].bias.grad), _ptr(tg),
+                    _ptr(pr.object_orientation_feat.grad) if pr.use_orientation else None,
+                    _ptr(pr.obj_linear_projection.bias.grad), _ptr(tg, D), _ptr(pr.anchor_feat.grad), st)
+                _lib.check(rc, "msr3d_anchor_front_bwd")
+            else:
+                le, se = pr.loc_embedding_encoder, pr.size_embedding_encoder
+                rc = lib.msr3d_pos_embed_bwd(
+                    M, _ptr(a["d_xacc0"]), _ptr(a["d_xacc1"]) if more else None,
+                    _ptr(a["d_xacc2"]) if (more and nl > 2) else None, _ptr(a["sa"]), _ptr(a["sta"]), _ptr(le[1].weight),
+                    _ptr(a["sb"]), _ptr(a["stb"]), _ptr(se[1].weight), _ptr(a["d_la"]), _ptr(a["d_lb"]),
+                    _ptr(le[1].weight.grad), _ptr(le[1].bias.grad), _ptr(se[1].weight.grad), _ptr(se[1].bias.grad),
+                    _ptr(pr.object_type_embedding.weight.grad),
+                    _ptr(pr.object_orientation_feat.grad) if pr.use_orientation else None, st)
+                _lib.check(rc, "msr3d_pos_embed_bwd")
             wg.set_ptr(self.wg_proj, "x", self.saved_embeds.data_ptr())
             if _MERGE:
                 # every weight gradient + (as extra workgroups) the ordered LayerNorm-gradient column sums: one launch
@@ -533,6 +614,21 @@ class PrompterSchedule:
         valid = d["obj_masks"].contiguous().view(torch.uint8)
         al, ao = d["anchor_locs"].contiguous(), d["anchor_orientation"].contiguous()
         lib = _lib.load()
+        if self.anchor:
+            # the agent's row in front of every scene's (position + the constant anchor_size, always valid:
+            # ose3d_situation.py:336-345) and its orientation as Fourier rows for the orientation encoder (:346-349): the
+            # same one launch
+            pr = self.pr
+            with torch.cuda.device(dev):
+                rc = lib.msr3d_scene_prologue_agent(B, L, _ptr(loc), _ptr(valid), _ptr(al), _ptr(ao), _ptr(pr.anchor_size),
+                                                    _ptr(self.freqs), 10, ctypes.c_float(1e-10), _ptr(a["pw"]), _ptr(a["ff"]),
+                                                    _ptr(a["loc6"]), _ptr(self.pad), _ptr(self.valid),
+                                                    _ptr(a["qf"]) if pr.use_orientation else None,
+                                                    _ptr(anchor_out[0]) if anchor_out else None,
+                                                    _ptr(anchor_out[1]) if anchor_out else None,
+                                                    _lib.current_stream_ptr(dev))
+            _lib.check(rc, "msr3d_scene_prologue_agent")
+            return
         with torch.cuda.device(dev):
             rc = lib.msr3d_scene_prologue(B, L, _ptr(loc), _ptr(valid), _ptr(al), _ptr(ao), _ptr(self.freqs), 10, 1,
                                           ctypes.c_float(1e-10), _ptr(a["pw"]), _ptr(a["ff"]), _ptr(a["loc6"]),
@@ -736,6 +832,8 @@ def run(model, d):
     if not d.get("_staged", False):
         sched.stage(d)
     tok, scene = _PrompterFn.apply(sched, e, *sched._params())
+    if sched.anchor:
+        d["obj_masks"] = sched.valid          # (B, O + 1): the agent's token is always valid
     d["oatt"] = None
     d["obj_tokens"] = tok
     d["scene_embeds"] = scene

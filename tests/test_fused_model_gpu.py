@@ -15,7 +15,7 @@ def rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
 
-def _setup(dropout, seed=0, B=3, O=20, E=128):
+def _setup(dropout, seed=0, B=3, O=20, E=128, situation_type="as_transform_for_objects"):
     import msr3d_amd.model  # noqa: F401
     import msr3d_amd.modules  # noqa: F401
     from msr3d_amd import hipops
@@ -25,12 +25,14 @@ def _setup(dropout, seed=0, B=3, O=20, E=128):
     from msr3d_amd.optim import FlatAdamW
     from msr3d_amd.synth import synth_batch
     torch.manual_seed(seed)
-    cfg = AttrDict({"prompter": default_prompter_cfg(dropout=dropout), "llm_hidden_size": E,
+    cfg = AttrDict({"prompter": default_prompter_cfg(dropout=dropout, situation_type=situation_type), "llm_hidden_size": E,
                     "model": {"name": "MSR3DHotPath"}})
     model = build_model(cfg).cuda().train()
     # the zero-initialised constants would hide their gradient paths' forward effect
     with torch.no_grad():
         model.visual_prompter.object_orientation_feat.normal_(std=0.5)
+        if situation_type == "as_object":
+            model.visual_prompter.anchor_size.uniform_(0.5, 1.5)      # (a constant the module never trains)
     params = [p for p in model.parameters() if p.requires_grad]
     dp = FlatGradAllReduce(params, pack_groups=hipops.collect_pack_groups(model))
     opt = FlatAdamW(dp, lr=1e-3)
@@ -142,3 +144,41 @@ def test_train_step_through_the_schedule_in_a_graph():
         if k.endswith("w_ks.bias"):
             continue
         assert torch.allclose(p0[k], p1[k], rtol=1e-3, atol=3e-3), k
+
+
+@pytest.mark.parametrize("B,O,E", [(3, 20, 128), (2, 60, 256), (5, 13, 128), (16, 60, 4096), (2, 63, 256)])
+def test_as_object_schedule_matches_the_modular_path(B, O, E):
+    """situation_type 'as_object' (configs/leo_3_dataset_pure_txt.yaml's prompter: the agent is a token of its own in
+    front of the objects, /root/reference/model/ose3d_situation.py:334-353) on the scene-block schedule (round 6:
+    msr3d_anchor_front_fwd / _bwd + the blocks) against the per-module path under autograd: outputs, the returned mask
+    and EVERY parameter gradient -- anchor_feat, orientation_encoder, loc_layers and both rows of the type table among
+    them.  O = 63: L = 64, a full block."""
+    model, dp, batch = _setup(0.0, B=B, O=O, E=E, situation_type="as_object")
+    sched = model._schedule
+    assert sched.anchor and sched.eligible(dict(batch))
+    a = _run(model, dp, batch, "schedule")
+    assert sched._ran_blocks and sched.dims["L"] == O + 1 and a[1].shape[1] == O + 1
+    mask_s = model(dict(batch))["obj_masks"].clone()
+    b = _run(model, dp, batch, "modular")
+    sched.enabled = False
+    mask_m = model(dict(batch))["obj_masks"].clone()
+    assert torch.equal(mask_s, mask_m) and mask_s.shape == (B, O + 1) and bool(mask_s[:, 0].all())
+    for k in ("anchor_feat", "orientation_encoder.weight", "loc_layers.0.0.weight", "object_type_embedding.weight"):
+        assert float(b[2]["visual_prompter." + k].abs().max()) > 0, k
+    # (E = 4096: the modular path meets its K-splits by float atomics over a 4096-wide reduction)
+    _compare(a, b, 2e-5 if E <= 512 else 1.5e-4)
+
+
+def test_as_object_schedule_with_dropout_draws_the_same_masks_from_the_same_seed():
+    """Dropout on: two runs from the same seed word and salts draw the same masks -> the same values up to the
+    projection's split-K arrival order (float atomics: ~1e-7), and they differ from the dropout-free result."""
+    model, dp, batch = _setup(0.1, B=4, O=60, E=256, situation_type="as_object")
+    a = _run(model, dp, batch, "schedule")
+    b = _run(model, dp, batch, "schedule")
+    assert model._schedule._ran_blocks and bool(torch.isfinite(a[0]).all())
+    _compare(a, b, 2e-5)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    c = _run(model, dp, batch, "schedule")
+    assert rel(a[1], c[1]) > 1e-2
