@@ -821,6 +821,28 @@ int msr3d_wgrad_split_mixed(int n, const msr3d_wgrad_problem_t *problems, const 
                             int whole_tiles, int n_jobs, const msr3d_colsum_job_t *jobs, float *workspace,
                             long long workspace_floats, int *sync, msr3d_stream_t stream);
 
+/* STREAM form (round 6): the launch's tiles as one sequence of slab pairs dealt evenly to n_wgs PERSISTENT workgroups
+ * (one per CU): workgroup w runs pieces [wg_first[w], wg_first[w + 1]) one after the other.  A piece is a whole tile
+ * (slot < 0), one of the two parts of a tile cut at slab s0 / s1 (even; slot = the tile's workspace slot), or a column-sum
+ * job (kind = 1, prob = its index in `jobs`).  The parts of a cut tile do not meet inside the launch: the part with the
+ * EARLIER slabs (second = 0) parks its 128 x 128 partial + column sums in the slot, the part with the later slabs
+ * (second = 1) adds onto dW like a whole tile, and a second, small launch adds the parked partials --
+ * dW = (dW + later) + earlier, a fixed order: bit-reproducible, no atomics, no flags (an in-kernel hand-over between CUs
+ * costs more than the kernel boundary: profiles/r06_last_arriver_probe.txt).  slot_piece[s] = index of slot s's parking
+ * piece.  The planner (msr3d_amd/scene_blocks.py::WgradTable) cuts a tile at most once.  workspace: n_slots x
+ * MSR3D_WGRAD_HALF_SLOT_FLOATS floats.  problems, pieces, wg_first (n_wgs + 1 ints), slot_piece, jobs: DEVICE memory. */
+typedef struct msr3d_wgrad_piece {
+  int kind;                 /* 0: (part of) a tile, 1: column-sum job */
+  int prob;                 /* problem index, or job index */
+  int ntile, ktile;         /* the 128 x 128 tile */
+  int s0, s1;               /* slab range [s0, s1) of a cut tile's part (32 tokens a slab, both even) */
+  int second;               /* the part with the later slabs */
+  int slot;                 /* workspace slot of a cut tile; -1: whole tile */
+} msr3d_wgrad_piece_t;
+int msr3d_wgrad_stream(int n, const msr3d_wgrad_problem_t *problems, int n_pieces, const msr3d_wgrad_piece_t *pieces,
+                       const int *wg_first, int n_wgs, int n_slots, const int *slot_piece, float *workspace,
+                       long long workspace_floats, const msr3d_colsum_job_t *jobs, msr3d_stream_t stream);
+
 /* Which tile kernel the three launches above run: 1 (default; MSR3D_WGRAD_PIPE=0 in the environment selects 0 at first
  * use) = eight waves that each load, split, stash and multiply, the next half-slab's fragment reads under the current
  * half-slab's MFMAs (round 6); 0 = rounds 4-5's eight loader + eight multiplier waves.  Same sums in the same order:

@@ -87,6 +87,11 @@ class ColsumJob(ctypes.Structure):
     _fields_ = [("part", _ptr), ("dst", _ptr), ("n", _c_int), ("reserved", _c_int)]
 
 
+class WgradPiece(ctypes.Structure):
+    """msr3d_wgrad_piece_t (include/msr3d_hip.h)."""
+    _fields_ = [(k, _c_int) for k in ("kind", "prob", "ntile", "ktile", "s0", "s1", "second", "slot")]
+
+
 class WgradProblem(ctypes.Structure):
     """msr3d_wgrad_problem_t (include/msr3d_hip.h)."""
     _fields_ = [("dy", _ptr), ("ldy", _c_int), ("n_out", _c_int), ("x", _ptr), ("ldx", _c_int), ("k_in", _c_int),
@@ -115,6 +120,7 @@ _SIGNATURES = {
                                _ptr, _c_int, _ptr],
     "msr3d_wgrad_split_halves": [_c_int, _ptr, _ptr, _c_int, _ptr, ctypes.c_longlong, _ptr, _ptr],
     "msr3d_wgrad_split_mixed": [_c_int, _ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _ptr, ctypes.c_longlong, _ptr, _ptr],
+    "msr3d_wgrad_stream": [_c_int, _ptr, _c_int, _ptr, _ptr, _c_int, _c_int, _ptr, _ptr, ctypes.c_longlong, _ptr, _ptr],
     "msr3d_wgrad_rows_split": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _ptr,
                                ctypes.c_longlong, _ptr, _ptr],
     "msr3d_rows_gemm_split": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr,
@@ -352,7 +358,7 @@ def load_split2():
 
 _lib_bf16 = None
 _BF16_ENTRIES = ("msr3d_scene_block", "msr3d_wgrad_split", "msr3d_wgrad_split_colsum", "msr3d_wgrad_split_halves",
-                 "msr3d_wgrad_split_mixed")
+                 "msr3d_wgrad_split_mixed", "msr3d_wgrad_stream")
 
 
 def load_bf16():

@@ -630,7 +630,7 @@ __device__ __forceinline__ void wgrad_tile_pipe(const WP &pr, int ntile, int kti
   if (HALVES) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                               // every wave's image stores (and column sums) have left the CU
-    if (tid == 0) {
+    if (tid == 0 && hf.flag) {                     // (flag == nullptr: the stream launch -- nobody waits inside the launch)
       if (hf.role == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_store(hf.flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -781,6 +781,85 @@ __global__ __launch_bounds__(PIPE ? NTHREADS_PIPE : NTHREADS) void wgrad_mixed_k
   }
   if constexpr (PIPE) wgrad_tile_pipe<true>(pr, local / nkt, local % nkt, smem, hf);
   else wgrad_tile<false, false, false, true>(pr, local / nkt, local % nkt, smem, 0, 0, nullptr, hf);
+}
+
+// STREAM (round 6): the launch's tiles as ONE sequence of slab pairs dealt evenly to a persistent grid (one workgroup per
+// CU).  ~330 tiles of 30 slabs on 256 CUs are 1.3 rounds: whole tiles last two tile times, the mixed launch 1.5 -- here
+// every workgroup gets 1/256 of the slab pairs (+ a fixed charge per piece), i.e. up to three PIECES: the tail of one
+// tile, whole tiles, the head of another.  A tile is cut at most once (the host deals at least one tile's worth to every
+// workgroup).  The two parts of a cut tile do NOT meet inside the launch: an in-kernel hand-over between CUs costs an
+// agent-scope release + acquire -- 23-27 k cycles, profiles/r06_last_arriver_probe.txt; every tile halved with tickets is
+// the slowest form of all -- while a kernel boundary is ~2 us.  So the part with the EARLIER slabs parks its accumulator
+// image (+ column sums) in the tile's workspace slot with plain stores, the part with the later slabs adds onto dW like
+// a whole tile, and wgrad_fixup_kernel, launched behind, adds the parked images: dW = (dW + later) + earlier, a fixed
+// order: bit-reproducible, no atomics, no flags, no spinning.  The column-sum jobs ride as pieces of the least loaded
+// workgroups.  pieces / wg_first / slot_piece: msr3d_amd/scene_blocks.py.
+using PC = msr3d_wgrad_piece_t;
+__global__ __launch_bounds__(NTHREADS_PIPE) void wgrad_stream_kernel(const WP *__restrict__ probs, const PC *__restrict__ pieces,
+                                                                     const int *__restrict__ wg_first, float *__restrict__ ws,
+                                                                     const msr3d_colsum_job_t *__restrict__ cjobs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int p0 = wg_first[blockIdx.x], p1 = wg_first[blockIdx.x + 1];
+  for (int i = p0; i < p1; ++i) {
+    const PC pc = pieces[i];
+    if (i > p0) __syncthreads();                   // the previous piece's tail is done with the LDS
+    if (pc.kind == 1) {
+      colsum_job(cjobs[pc.prob], reinterpret_cast<float *>(smem));
+      continue;
+    }
+    const WP pr = probs[pc.prob];
+    if (pc.slot < 0) {
+      wgrad_tile_pipe<false>(pr, pc.ntile, pc.ktile, smem);
+      continue;
+    }
+    Half hf;
+    hf.second = pc.second;
+    hf.s0 = pc.s0;
+    hf.s1 = pc.s1;
+    hf.ws = ws + (size_t)pc.slot * kHalfSlot;
+    hf.flag = nullptr;                             // no in-kernel hand-over: the parked image waits for the fixup launch
+    hf.role = pc.second ? -1 : 0;                  // later slabs: onto dW; earlier slabs: parked
+    wgrad_tile_pipe<true>(pr, pc.ntile, pc.ktile, smem, hf);
+  }
+}
+
+// dW += parked image, db += parked column sums, one workgroup per cut tile; the image is the multiplier waves' register
+// layout (wgrad_tile_pipe's epilogue): image[(wave, a, b)][lane] float4 = rows 64 wr + 16 a + 4 g + r, column 32 wc + 16 b + j
+__global__ __launch_bounds__(NTHREADS_PIPE) void wgrad_fixup_kernel(const WP *__restrict__ probs, const PC *__restrict__ pieces,
+                                                                    const int *__restrict__ slot_piece,
+                                                                    const float *__restrict__ ws) {
+  const PC pc = pieces[slot_piece[blockIdx.x]];
+  const WP pr = probs[pc.prob];
+  const float *img = ws + (size_t)pc.slot * kHalfSlot;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = (wave >> 2) & 1, wc = wave & 3, j = lane & 15, g = lane >> 4;
+  const int n0 = pc.ntile * TN, k0 = pc.ktile * TK;
+  f32x4 v[4][2];
+  float old[4][2][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      v[a][b] = *reinterpret_cast<const f32x4 *>(img + (((wave * 4 + a) * 2 + b) * 64 + lane) * 4);
+      const int kk = k0 + 32 * wc + 16 * b + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 64 * wr + 16 * a + 4 * g + r;
+        old[a][b][r] = (n < pr.n_out && kk < pr.k_in) ? pr.dW[(size_t)n * pr.ldw + kk] : 0.f;
+      }
+    }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int kk = k0 + 32 * wc + 16 * b + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 64 * wr + 16 * a + 4 * g + r;
+        if (n < pr.n_out && kk < pr.k_in) pr.dW[(size_t)n * pr.ldw + kk] = old[a][b][r] + v[a][b][r];
+      }
+    }
+  if (pr.db && pc.ktile == 0 && tid < TN && n0 + tid < pr.n_out) pr.db[n0 + tid] += img[TN * TK + tid];
 }
 
 // TALL problems (an unfrozen backbone's SharedMLP layers: dW (<= 256 x <= 256) over 10^5 .. 10^6 rows): the rows are
@@ -936,6 +1015,25 @@ extern "C" int msr3d_wgrad_split_mixed(int n, const msr3d_wgrad_problem_t *probl
   if (attr != hipSuccess) return (int)attr;
   wgrad_mixed_kernel<false><<<whole_tiles + 2 * H + n_jobs, NTHREADS, LDS_BYTES, (hipStream_t)stream>>>(
       n, problems, tile_prefix, total_tiles, whole_tiles, workspace, sync, jobs);
+  return (int)hipGetLastError();
+}
+
+extern "C" int msr3d_wgrad_stream(int n, const msr3d_wgrad_problem_t *problems, int n_pieces,
+                                  const msr3d_wgrad_piece_t *pieces, const int *wg_first, int n_wgs, int n_slots,
+                                  const int *slot_piece, float *workspace, long long workspace_floats,
+                                  const msr3d_colsum_job_t *jobs, msr3d_stream_t stream) {
+  if (n < 0 || n_pieces < 0 || n_wgs < 0 || n_slots < 0) return MSR3D_EINVAL;
+  if (n_pieces == 0 || n_wgs == 0) return 0;
+  if (!pieces || !wg_first || (n > 0 && !problems)) return MSR3D_EINVAL;
+  if (n_slots > 0 && (!workspace || !slot_piece || workspace_floats < (long long)n_slots * MSR3D_WGRAD_HALF_SLOT_FLOATS))
+    return MSR3D_EINVAL;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_stream_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (attr != hipSuccess) return (int)attr;
+  wgrad_stream_kernel<<<n_wgs, NTHREADS_PIPE, LDS_BYTES, (hipStream_t)stream>>>(problems, pieces, wg_first, workspace, jobs);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || n_slots == 0) return (int)e;
+  wgrad_fixup_kernel<<<n_slots, NTHREADS_PIPE, 0, (hipStream_t)stream>>>(problems, pieces, slot_piece, workspace);
   return (int)hipGetLastError();
 }
 

@@ -47,6 +47,10 @@ def set_mode(name):
 
 # MSR3D_MERGE_LAUNCHES=0: the step's zero fill and the LayerNorm-gradient column sums as launches of their own (round 3)
 _MERGE = os.environ.get("MSR3D_MERGE_LAUNCHES", "1") != "0"
+# MSR3D_PACK_FORK=1 (round 6, measured, default off unless it pays: DESIGN.md 4.2d): the step's weight split / pack launch
+# (24 us, needed first by the first attention block) on a forked stream beside the launches that do not read the packs --
+# the object projection, the positional encoders, the first rows launch (~30 us): one fork and one join in the graph
+_PACK_FORK = os.environ.get("MSR3D_PACK_FORK", "0") == "1"
 
 _vp = ctypes.c_void_p
 
@@ -108,6 +112,7 @@ class PrompterSchedule:
         # and drops its own msr3d_bump_seed launch); off: the caller owns the seed
         self.bump_seed = False
         self.need_d_embeds = False   # set per backward: the object features come from an unfrozen encoder
+        self._pack_stream = None
         self._ln_job_buf = None
 
     # ------------------------------------------------------------------ eligibility
@@ -376,8 +381,19 @@ class PrompterSchedule:
         pk, xp, part, MD = self.packs, self.xp, a["part"], M * D
         blk, rows = scene_blocks.launch_block, scene_blocks.launch_rows
         nff = FF // 128
+        join = None
         with torch.cuda.device(dev):
-            if _MERGE:
+            if _PACK_FORK:
+                rc = lib.msr3d_step_begin(_ptr(a.buf), a.zero_floats, _ptr(seed) if self.bump_seed else None, st)
+                _lib.check(rc, "msr3d_step_begin")
+                if self._pack_stream is None:
+                    self._pack_stream = torch.cuda.Stream(device=dev)
+                side = self._pack_stream
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    pk.launch(_lib.current_stream_ptr(dev))
+                join = side
+            elif _MERGE:
                 # ONE launch: this step's weights split and fragment-packed + the arena's zero fill + the seed bump
                 pk.launch(st, begin=(a.buf, a.zero_floats, seed if self.bump_seed else None))
             else:
@@ -428,6 +444,9 @@ class PrompterSchedule:
                          g1=prev.norm2.weight, b1=prev.norm2.bias, eps1=prev.norm2.eps, p1=self.ps[i - 1][2],
                          salt1=self.salts[i - 1][2], seed=seed, o0=a[f"s3_{i-1}"], ost1=a[f"st3_{i-1}"],
                          o1=a[f"xin{i}"], xp=xp)
+                if join is not None:        # the packs are needed from here on
+                    torch.cuda.current_stream(dev).wait_stream(join)
+                    join = None
                 blk(st, kind=BLK["attn_fwd"], B=B, L=L, xp=xp, w1=pk.bufs[f"qkvc{i}"], w1_bytes=pk.nbytes(f"qkvc{i}"),
                     bias1=bv, w2=pk.bufs[f"fc{i}"], w2_bytes=pk.nbytes(f"fc{i}"), part=part, part_stride=MD,
                     qkvc=a[f"qkvc{i}"], ldq=W, ploc=a["pw"], pad=self.pad, probs=a[f"probs{i}"], ctx=a[f"ctx{i}"], H=H)

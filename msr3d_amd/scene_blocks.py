@@ -13,7 +13,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import BLK, PRO, PackJob, SceneBlock, SceneRows, WgradProblem
+from ._lib import BLK, PRO, PackJob, SceneBlock, SceneRows, WgradPiece, WgradProblem
 
 _vp = ctypes.c_void_p
 PIECE = 3 * 1024          # bytes of one (slab, tile): three planes of 64 lanes x 16 B
@@ -142,6 +142,15 @@ class WgradTable:
         self.mixed = os.environ.get("MSR3D_WGRAD_MIXED", "1") != "0" and not self.halves
         self._ws = self._sync = None
         self._real = []                       # real (non-padding) tiles of each problem
+        # Round 6, opt-in (MSR3D_WGRAD_STREAM=1): the tiles as one sequence of slab pairs dealt evenly to a persistent grid,
+        # one workgroup per CU, cut tiles completed by a small second launch (msr3d_wgrad_stream).  Built to turn the
+        # step's ~1.3 tiles per CU into 1.3 tile times; measured EQUAL to the mixed launch (96.7-100.7 us against
+        # 98.5-99.8, same box, tools/bench_wgrad.py): ~2.5 pieces per workgroup each pay a prologue (two dependent
+        # round trips before the first product) and a write-back, which is what the even deal saves.  Kept, tested
+        # (bit-reproducible), not the default.  Needs the pipe tile kernel (msr3d_wgrad_form 1).
+        self.stream = os.environ.get("MSR3D_WGRAD_STREAM", "0") == "1" and not self.halves
+        self._stream_key = None
+        self._stream_plan = None
 
     def add(self, dy, ldy, n_out, x, ldx, k_in, M, dW, ldw, db):
         p = WgradProblem()
@@ -200,6 +209,95 @@ class WgradTable:
         self._whole_key, self._whole = key, whole
         return whole
 
+    PIECE_CHARGE = 2          # what a piece costs besides its slab pairs (prologue + write-back), in slab pairs
+
+    def _plan_stream(self, n_jobs, cus=None, upload=True):
+        """-> (pieces tensor, wg_first tensor, n_pieces, n_wgs, n_slots) for msr3d_wgrad_stream, or None when the problem set
+        is too small to deal (fewer slab pairs than one tile's worth per workgroup: the plain launch is already one round).
+        Rebuilt when a problem's token count changes (llm_proj's is 0 in a step without an upstream gradient)."""
+        key = (tuple((p.M, p.n_out, p.k_in) for p in self.probs), n_jobs)
+        if self._stream_key == key:
+            return self._stream_plan
+        C = self.PIECE_CHARGE
+        tiles = []                           # (problem, ntile, ktile, slab pairs): consecutive k tiles share a dy block
+        for pi, p in enumerate(self.probs):
+            if p.M <= 0:
+                continue
+            pairs = (p.M + 63) >> 6
+            for nt in range(-(-p.n_out // self.TN)):
+                for kt in range(-(-p.k_in // self.TK)):
+                    tiles.append((pi, nt, kt, pairs))
+        plan = None
+        if cus is None:
+            cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if tiles:
+            total = sum(t[3] + C for t in tiles)
+            heaviest = max(t[3] + C for t in tiles)
+            n_wgs = min(cus, total // heaviest)       # every workgroup's share >= the heaviest tile: a tile is cut at most once
+            if n_wgs >= 8 and len(tiles) > n_wgs // 2:
+                n_wgs -= n_wgs % 8
+                lists = [[] for _ in range(n_wgs)]
+                slots, c, filled, rem = 0, 0, 0.0, float(total + C * (n_wgs - 1))   # (+ the charge of a cut per chunk boundary)
+                target = rem / n_wgs                 # re-derived at every chunk start from what is left (cuts add charges)
+
+                def next_chunk():
+                    nonlocal c, filled, target
+                    c += 1
+                    filled = 0.0
+                    target = rem / (n_wgs - c)
+
+                for pi, nt, kt, pairs in tiles:
+                    w = pairs + C
+                    while True:
+                        room = target - filled
+                        if c == n_wgs - 1 or w <= room + 0.5:          # the whole tile fits this chunk (or it is the last)
+                            lists[c].append(WgradPiece(0, pi, nt, kt, 0, 2 * pairs, 0, -1))
+                            filled += w
+                            rem -= w
+                            break
+                        first = int(round(room - C))                    # slab pairs of the part that stays in this chunk
+                        if pairs < 2 or first < 1:                      # nothing worth leaving behind: the tile opens the next
+                            next_chunk()
+                            continue
+                        first = min(first, pairs - 1)
+                        lists[c].append(WgradPiece(0, pi, nt, kt, 0, 2 * first, 0, slots))
+                        rem -= first + C
+                        next_chunk()
+                        lists[c].append(WgradPiece(0, pi, nt, kt, 2 * first, 2 * pairs, 1, slots))
+                        slots += 1
+                        filled += pairs - first + C
+                        rem -= pairs - first + C
+                        break
+                    if filled >= target - 0.5 and c < n_wgs - 1:
+                        next_chunk()
+                load = [sum((q.s1 - q.s0) // 2 + C for q in l) for l in lists]
+                for j in range(n_jobs):                                # column-sum jobs: to the lightest workgroups
+                    k = min(range(n_wgs), key=lambda i: load[i])
+                    lists[k].append(WgradPiece(1, j, 0, 0, 0, 0, 0, -1))
+                    load[k] += 1
+                # chunk -> workgroup: consecutive chunks on ONE XCD (workgroup b runs on XCD b % 8), so the tiles that share a
+                # dy block read it through one L2
+                per = n_wgs // 8
+                order = [None] * n_wgs
+                for ch in range(n_wgs):
+                    order[(ch % per) * 8 + ch // per] = lists[ch]
+                flat, first_idx = [], [0]
+                for l in order:
+                    flat.extend(l)
+                    first_idx.append(len(flat))
+                slot_piece = [0] * slots
+                for i, q in enumerate(flat):
+                    if q.kind == 0 and q.slot >= 0 and not q.second:
+                        slot_piece[q.slot] = i
+                arr = (WgradPiece * len(flat))(*flat)
+                if not upload:                      # (tests of the deal itself, no device)
+                    return order, slots, load
+                plan = (_device_bytes(arr, self.device), torch.tensor(first_idx, dtype=torch.int32).to(self.device),
+                        len(flat), n_wgs, slots, max(load), min(load),
+                        torch.tensor(slot_piece or [0], dtype=torch.int32).to(self.device))
+        self._stream_key, self._stream_plan = key, plan
+        return plan
+
     def set_ptr(self, idx, field, ptr):
         if getattr(self.probs[idx], field) != ptr:
             setattr(self.probs[idx], field, ptr)
@@ -244,6 +342,26 @@ class WgradTable:
             if colsum is not None:
                 _lib.check(_lib.load().msr3d_colsum_partials(colsum[0], _vp(colsum[1].data_ptr()), stream), "msr3d_colsum_partials")
             return
+        if self.stream and _klib().msr3d_wgrad_form(-1) == 1:
+            if torch.cuda.is_current_stream_capturing() and self._stream_key != (
+                    tuple((p.M, p.n_out, p.k_in) for p in self.probs), colsum[0] if colsum is not None else 0):
+                raise RuntimeError("WgradTable: the stream plan must exist before a graph capture (launch once eagerly)")
+            plan = self._plan_stream(colsum[0] if colsum is not None else 0)
+            if plan is not None:
+                pieces, first, n_pieces, n_wgs, slots = plan[:5]
+                if slots and (self._ws is None or self._ws.numel() < slots * HALF_SLOT_FLOATS):
+                    if self._ws is not None and torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError("WgradTable: the workspace would have to grow inside a graph capture")
+                    T = max(self.prefix[-1], slots)
+                    self._ws = torch.empty(T * HALF_SLOT_FLOATS, dtype=torch.float32, device=self.device)
+                    self._sync = torch.zeros(2 * T, dtype=torch.int32, device=self.device)
+                rc = _klib().msr3d_wgrad_stream(len(self.probs), _vp(self._table.data_ptr()), n_pieces, _vp(pieces.data_ptr()),
+                                                _vp(first.data_ptr()), n_wgs, slots, _vp(plan[7].data_ptr()),
+                                                _vp(self._ws.data_ptr()) if slots else None,
+                                                self._ws.numel() if slots else 0,
+                                                _vp(colsum[1].data_ptr()) if colsum is not None else None, stream)
+                _lib.check(rc, "msr3d_wgrad_stream")
+                return
         whole = self._whole_tiles() if self.mixed else self.prefix[-1]
         if whole < self.prefix[-1]:
             H = self.prefix[-1] - whole

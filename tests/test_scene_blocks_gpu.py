@@ -95,7 +95,7 @@ def test_wgrad_split_vs_float64(M, n_out, k_in, halves):
     assert torch.equal(dW, dW2) and torch.equal(db, db2)
 
 
-@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("mixed", [False, True, "stream"])
 def test_wgrad_pipe_form_gives_the_bits_of_the_loader_multiplier_form(mixed):
     """Round 6's tile kernel (eight waves that load, split, stash AND multiply; the next half-slab's fragment reads under
     the current half-slab's MFMAs) against rounds 4-5's eight loader + eight multiplier waves, on the bench step's problem
@@ -120,7 +120,8 @@ def test_wgrad_pipe_form_gives_the_bits_of_the_loader_multiplier_form(mixed):
         for form in (0, 1):
             assert lib.msr3d_wgrad_form(form) == form
             t = WgradTable(dev)
-            t.mixed = mixed
+            t.mixed = bool(mixed)
+            t.stream = mixed == "stream" and form == 1      # (the stream launch: the pipe tile dealt to a persistent grid)
             res = []
             for dy, xw, x, dW0, db0 in ops:
                 dW, db = dW0.clone(), db0.clone()
@@ -129,13 +130,45 @@ def test_wgrad_pipe_form_gives_the_bits_of_the_loader_multiplier_form(mixed):
                       dW.data_ptr(), x.shape[1], db.data_ptr())
             t.launch(_lib.current_stream_ptr(dev))
             torch.cuda.synchronize()
+            if t.stream:
+                assert t._stream_plan is not None and t._stream_plan[4] > 100       # (it ran the deal, with cut tiles)
             out[form] = res
     finally:
         lib.msr3d_wgrad_form(prev)
     for (dy, xw, x, dW0, db0), (a, ab), (b, bb) in zip(ops, out[0], out[1]):
-        assert torch.equal(a, b) and torch.equal(ab, bb), (dy.shape, x.shape)
+        if mixed != "stream":        # (the stream deal cuts other tiles at other slabs than the mixed launch: other sums)
+            assert torch.equal(a, b) and torch.equal(ab, bb), (dy.shape, x.shape)
         want = dW0.double() + dy.double().t() @ x.double()
         assert float((b.double() - want).norm() / want.norm()) < 2e-6
+        wantb = db0.double() + dy.double().sum(0)
+        assert float((bb.double() - wantb).norm() / wantb.norm()) < 2e-6
+
+
+def test_wgrad_stream_launch_is_bit_reproducible():
+    """msr3d_wgrad_stream twice on the same operands: identical bits (parked partials are added by the fixup launch in a
+    fixed order: no atomics, no arrival order anywhere)."""
+    from msr3d_amd import _lib
+    from msr3d_amd.scene_blocks import WgradTable
+    dev = torch.device("cuda")
+    torch.manual_seed(11)
+    shapes = [(960, 4096, 256), (960, 256, 2048), (960, 2048, 256), (960, 816, 256), (960, 256, 768)]
+    ops = [(torch.randn(M, n, device=dev), torch.randn(M, k, device=dev)) for M, n, k in shapes]
+    outs = []
+    for rep in range(2):
+        t = WgradTable(dev)
+        t.stream = True
+        res = []
+        for dy, x in ops:
+            dW, db = torch.ones(dy.shape[1], x.shape[1], device=dev), torch.ones(dy.shape[1], device=dev)
+            res.append((dW, db))
+            t.add(dy.data_ptr(), dy.shape[1], dy.shape[1], x.data_ptr(), x.shape[1], x.shape[1], dy.shape[0], dW.data_ptr(),
+                  x.shape[1], db.data_ptr())
+        t.launch(_lib.current_stream_ptr(dev))
+        torch.cuda.synchronize()
+        assert t.stream and t._stream_plan is not None and t._stream_plan[4] > 50
+        outs.append(res)
+    for (a, ab), (b, bb) in zip(*outs):
+        assert torch.equal(a, b) and torch.equal(ab, bb)
 
 
 def _rel(a, b):

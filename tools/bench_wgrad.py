@@ -36,8 +36,13 @@ st = _lib.current_stream_ptr(dev)
 for form in (0, 1):
   _lib.load().msr3d_wgrad_form(form)
   print("tile kernel:", "pipe (8 waves, round 6)" if form else "loader + multiplier waves (rounds 4-5)")
-  for name, kw in (("whole tiles", dict(mixed=False)), ("mixed", dict(mixed=True)), ("all halved", dict(mixed=False, halves=True))):
+  for name, kw in (("whole tiles", dict(mixed=False)), ("mixed", dict(mixed=True)), ("all halved", dict(mixed=False, halves=True)),
+                   ("stream", dict(mixed=True, stream=True))):
+      if kw.get("stream") and not form:
+          continue
+      want_stream = kw.pop("stream", False)
       t, keep = build(**kw)
+      t.stream = want_stream
       if "WHOLE" in os.environ and kw.get("mixed"):
           t._whole_tiles()
           t._whole = int(os.environ["WHOLE"])
@@ -52,4 +57,6 @@ for form in (0, 1):
           ts.append(e0.elapsed_time(e1) * 1e3)
       ts.sort()
       extra = f" whole {t._whole_tiles()} of {t.prefix[-1]} workgroups, xcd load {t.xcd_load}" if kw.get("mixed") else ""
+      if t.stream and t._stream_plan:
+          extra = f" {t._stream_plan[3]} workgroups, {t._stream_plan[2]} pieces, {t._stream_plan[4]} cut tiles, load {t._stream_plan[6]}..{t._stream_plan[5]} slab pairs"
       print(f"{name:12s} median {ts[len(ts) // 2]:7.1f} us  min {ts[0]:7.1f} us{extra}")
