@@ -615,6 +615,16 @@ int msr3d_pos_embed_fwd(int M, int KF, const float *fourier, const float *locs, 
                         const float *Wb, const float *bb, const float *gamma_b, const float *beta_b,
                         float eps_b, float *pos, float *s_a, float *stats_a, float *s_b,
                         float *stats_b, msr3d_stream_t stream);
+/* msr3d_pos_embed_fwd + the first layer's input in the same launch (round 6; what msr3d_scene_rows' MSR3D_PRO_ADD launch
+ * did behind it): xin0 (M,256) = ((x0 + pos) + type_row) + orientation_row -- x0 = obj_linear_projection's output, the two
+ * constant 256-vectors of ose3d_situation.py:356-360 (orientation_row optional) -- also written as the first attention
+ * block's operand planes (planes: (M / L scenes, 3, 64, 256) bf16 or NULL; L tokens a scene, L <= 64 with planes). */
+int msr3d_pos_embed_tokens_fwd(int M, int L, int KF, const float *fourier, const float *locs, const float *Wa,
+                               const float *ba, const float *gamma_a, const float *beta_a, float eps_a,
+                               const float *Wb, const float *bb, const float *gamma_b, const float *beta_b,
+                               float eps_b, float *pos, float *s_a, float *stats_a, float *s_b, float *stats_b,
+                               const float *x0, const float *type_row, const float *orientation_row, float *xin0,
+                               unsigned short *planes, msr3d_stream_t stream);
 
 /* Row-wise backward of msr3d_pos_embed_fwd: d pos = d0 + d1 + d2 (d1, d2 optional);
  * d_lin_a / d_lin_b (M,256) = gradients of the two linear outputs; the LayerNorm parameter

@@ -169,6 +169,7 @@ _SIGNATURES = {
     "msr3d_scene_prologue_agent": [_c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_float] + [_ptr] * 8 + [_ptr],
     "msr3d_step_begin": [_ptr, ctypes.c_longlong, _ptr, _ptr],
     "msr3d_pos_embed_fwd": [_c_int, _c_int] + [_ptr] * 6 + [_c_float] + [_ptr] * 4 + [_c_float] + [_ptr] * 5 + [_ptr],
+    "msr3d_pos_embed_tokens_fwd": [_c_int, _c_int, _c_int] + [_ptr] * 6 + [_c_float] + [_ptr] * 4 + [_c_float] + [_ptr] * 10 + [_ptr],
     "msr3d_pos_embed_bwd": [_c_int] + [_ptr] * 17 + [_ptr],
     "msr3d_anchor_front_fwd": [_c_int, _c_int] + [_ptr] * 10 + [_c_float] + [_ptr] * 5 + [_ptr],
     "msr3d_anchor_front_bwd": [_c_int, _c_int] + [_ptr] * 14 + [_ptr],

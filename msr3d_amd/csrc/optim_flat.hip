@@ -85,21 +85,22 @@ __global__ __launch_bounds__(kDotThreads) void dot_kernel(long long n4, const fl
     float blk = 0.f;
 #pragma unroll
     for (int w = 0; w < NWAVE; ++w) blk += part[w];          // fixed order
-    __hip_atomic_store(partial + blockIdx.x, blk, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-    // the partial must be visible to the LAST block, possibly on another XCD, before the ticket is: an
-    // agent-scope release (a workgroup-scope fence orders nothing another CU can observe) ...
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The partial must be visible to the LAST block, possibly on another XCD, before the ticket is.  An agent-scope
+    // release fence does that by writing the XCD's whole L2 back (buffer_wbl2): 23-27 k cycles a block
+    // (profiles/r06_last_arriver_probe.txt), most of this kernel's 12 us.  Instead the partial itself travels by a
+    // RETURNING read-modify-write -- device-scope atomics execute at the memory side of the fabric on this part
+    // (TCC_EA0_ATOMIC == TCC_ATOMIC), and its return value says it has -- the ticket is taken only then, and the last
+    // block reads the partials back the same way (an atomic OR of 0): no cache is written back or invalidated.
+    const int prev = __hip_atomic_exchange(reinterpret_cast<int *>(partial) + blockIdx.x, __float_as_int(blk), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(prev) : "memory");
     ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // ... and an agent-scope acquire on the reader before it loads the others' partials
-    if (ticket == (int)gridDim.x - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
   if (ticket != (int)gridDim.x - 1) return;
   float tot = 0.f;
   for (int i = threadIdx.x; i < (int)gridDim.x; i += kDotThreads)
-    tot += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tot += __int_as_float(__hip_atomic_fetch_or(reinterpret_cast<int *>(partial) + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = tot;
@@ -168,6 +169,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(long long n4, float4 *__rest
   __syncthreads();
   const float lr = sh[0], step_size = sh[1], bc2s = sh[2], coef = sh[3];
   const float decay = 1.0f - lr * wd, w1 = 1.0f - beta1, w2 = 1.0f - beta2;
+  // (measured and not kept, round 6: four float4 of every buffer in flight per thread before the first update -- 16
+  //  concurrent streams a thread -- 48-55 us against 38-43 for this one-at-a-time loop, same box)
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n4;
        t += (long long)gridDim.x * blockDim.x) {
     if (active && !active[t]) {      // a parameter that receives no gradient: untouched, as torch.optim.AdamW

@@ -20,6 +20,7 @@
 
 #include "../../include/msr3d_hip.h"
 #include "rowmath.h"
+#include "split_mma.h"
 
 namespace {
 
@@ -164,7 +165,10 @@ __global__ __launch_bounds__(256) void pos_embed_fwd_kernel(
     const float *__restrict__ bta, float epsa, const float *__restrict__ Wb,
     const float *__restrict__ bb, const float *__restrict__ gb, const float *__restrict__ btb,
     float epsb, float *__restrict__ pos, float *__restrict__ sa, float *__restrict__ sta,
-    float *__restrict__ sb, float *__restrict__ stb) {
+    float *__restrict__ sb, float *__restrict__ stb, const float *__restrict__ x0, const float *__restrict__ c0,
+    const float *__restrict__ c1, float *__restrict__ xin0, unsigned short *__restrict__ xp, int L) {
+  // x0 != NULL (msr3d_pos_embed_tokens_fwd): the first layer's input in the same launch -- xin0 = ((x0 + pos) + c0) + c1
+  // (c0 / c1: the constant type / orientation rows, c1 optional), also as the first attention block's operand planes
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float *WT = sm;                    // [64][257]  k-major copy of Wa (row stride 257: the transposing
                                      //            stores of consecutive k land in consecutive banks)
@@ -221,10 +225,26 @@ __global__ __launch_bounds__(256) void pos_embed_fwd_kernel(
     const float4 ya = row_ln(va, g1, b1, epsa, m1, s1);
     const float4 yb = row_ln(vb, g2, b2, epsb, m2, s2);
     const size_t o = (size_t)row * 256 + c;
-    st4(pos + o, f4_add(ya, yb));
+    const float4 pv = f4_add(ya, yb);
+    st4(pos + o, pv);
     st4(sa + o, va);
     st4(sb + o, vb);
     if (lane == 0) { sta[row * 2] = m1; sta[row * 2 + 1] = s1; stb[row * 2] = m2; stb[row * 2 + 1] = s2; }
+    if (x0) {
+      // the operation order of msr3d_scene_rows' MSR3D_PRO_ADD: ((a0 + a1) + g1) + b1
+      float4 a = f4_add(f4_add(ld4(x0 + o), pv), ld4(c0 + c));
+      if (c1) a = f4_add(a, ld4(c1 + c));
+      st4(xin0 + o, a);
+      if (xp) {
+        const int b = row / L, rr = row - b * L;
+        const float f[4] = {a.x, a.y, a.z, a.w};
+        uint2 pl[3];
+        msr3d::sm_split4(f, pl);
+        unsigned short *d = xp + ((size_t)b * 3 * 64 + rr) * 256 + c;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2 *>(d + (size_t)k * 64 * 256) = pl[k];
+      }
+    }
   }
 }
 
@@ -342,11 +362,12 @@ int msr3d_step_begin(float *zero_region, long long n_floats, unsigned long long 
   return (int)hipGetLastError();
 }
 
-int msr3d_pos_embed_fwd(int M, int KF, const float *fourier, const float *locs, const float *Wa,
-                        const float *ba, const float *gamma_a, const float *beta_a, float eps_a,
-                        const float *Wb, const float *bb, const float *gamma_b, const float *beta_b,
-                        float eps_b, float *pos, float *s_a, float *stats_a, float *s_b,
-                        float *stats_b, msr3d_stream_t stream) {
+static int pos_embed_fwd_launch(int M, int KF, const float *fourier, const float *locs, const float *Wa,
+                                const float *ba, const float *gamma_a, const float *beta_a, float eps_a,
+                                const float *Wb, const float *bb, const float *gamma_b, const float *beta_b,
+                                float eps_b, float *pos, float *s_a, float *stats_a, float *s_b,
+                                float *stats_b, const float *x0, const float *c0, const float *c1, float *xin0,
+                                unsigned short *xp, int L, msr3d_stream_t stream) {
   if (M < 0 || KF <= 0 || KF > 64) return MSR3D_EINVAL;
   if (M == 0) return 0;
   if (!fourier || !locs || !Wa || !ba || !gamma_a || !beta_a || !Wb || !bb || !gamma_b || !beta_b || !pos ||
@@ -366,11 +387,33 @@ int msr3d_pos_embed_fwd(int M, int KF, const float *fourier, const float *locs, 
     }                                                                                                    \
     pos_embed_fwd_kernel<PR><<<(M + PR - 1) / PR, 256, lds, (hipStream_t)stream>>>(                      \
         M, KF, fourier, locs, Wa, ba, gamma_a, beta_a, eps_a, Wb, bb, gamma_b, beta_b, eps_b, pos, s_a,  \
-        stats_a, s_b, stats_b);                                                                          \
+        stats_a, s_b, stats_b, x0, c0, c1, xin0, xp, L);                                                 \
   } while (0)
   if (M > 16 * 192) LAUNCH_POS(16); else if (M > 8 * 192) LAUNCH_POS(8); else LAUNCH_POS(4);
 #undef LAUNCH_POS
   return (int)hipGetLastError();
+}
+
+int msr3d_pos_embed_fwd(int M, int KF, const float *fourier, const float *locs, const float *Wa,
+                        const float *ba, const float *gamma_a, const float *beta_a, float eps_a,
+                        const float *Wb, const float *bb, const float *gamma_b, const float *beta_b,
+                        float eps_b, float *pos, float *s_a, float *stats_a, float *s_b,
+                        float *stats_b, msr3d_stream_t stream) {
+  return pos_embed_fwd_launch(M, KF, fourier, locs, Wa, ba, gamma_a, beta_a, eps_a, Wb, bb, gamma_b, beta_b, eps_b, pos,
+                              s_a, stats_a, s_b, stats_b, nullptr, nullptr, nullptr, nullptr, nullptr, 1, stream);
+}
+
+int msr3d_pos_embed_tokens_fwd(int M, int L, int KF, const float *fourier, const float *locs, const float *Wa,
+                               const float *ba, const float *gamma_a, const float *beta_a, float eps_a,
+                               const float *Wb, const float *bb, const float *gamma_b, const float *beta_b,
+                               float eps_b, float *pos, float *s_a, float *stats_a, float *s_b, float *stats_b,
+                               const float *x0, const float *type_row, const float *orientation_row, float *xin0,
+                               unsigned short *planes, msr3d_stream_t stream) {
+  if (!x0 || !type_row || !xin0 || L <= 0 || (planes && L > 64)) return MSR3D_EINVAL;
+  if (!al16(x0) || !al16(type_row) || !al16(orientation_row) || !al16(xin0) || (reinterpret_cast<uintptr_t>(planes) & 7u))
+    return MSR3D_EINVAL;
+  return pos_embed_fwd_launch(M, KF, fourier, locs, Wa, ba, gamma_a, beta_a, eps_a, Wb, bb, gamma_b, beta_b, eps_b, pos,
+                              s_a, stats_a, s_b, stats_b, x0, type_row, orientation_row, xin0, planes, L, stream);
 }
 
 int msr3d_pos_embed_bwd(int M, const float *d0, const float *d1, const float *d2, const float *s_a,

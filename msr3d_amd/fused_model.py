@@ -421,22 +421,22 @@ class PrompterSchedule:
             else:
                 self._multi(front)
                 le, se = pr.loc_embedding_encoder, pr.size_embedding_encoder
-                rc = lib.msr3d_pos_embed_fwd(M, KF, _ptr(a["ff"]), _ptr(a["loc6"]), _ptr(le[0].weight), _ptr(le[0].bias),
-                                             _ptr(le[1].weight), _ptr(le[1].bias), ctypes.c_float(le[1].eps),
-                                             _ptr(se[0].weight), _ptr(se[0].bias), _ptr(se[1].weight), _ptr(se[1].bias),
-                                             ctypes.c_float(se[1].eps), _ptr(a["pos"]), _ptr(a["sa"]), _ptr(a["sta"]),
-                                             _ptr(a["sb"]), _ptr(a["stb"]), st)
-                _lib.check(rc, "msr3d_pos_embed_fwd")
+                # positional term + the layer input (tokens + positional term + the two constant rows) and its planes: one
+                # launch (the MSR3D_PRO_ADD rows launch of rounds 3-5 rides in it)
+                rc = lib.msr3d_pos_embed_tokens_fwd(
+                    M, L, KF, _ptr(a["ff"]), _ptr(a["loc6"]), _ptr(le[0].weight), _ptr(le[0].bias), _ptr(le[1].weight),
+                    _ptr(le[1].bias), ctypes.c_float(le[1].eps), _ptr(se[0].weight), _ptr(se[0].bias), _ptr(se[1].weight),
+                    _ptr(se[1].bias), ctypes.c_float(se[1].eps), _ptr(a["pos"]), _ptr(a["sa"]), _ptr(a["sta"]), _ptr(a["sb"]),
+                    _ptr(a["stb"]), _ptr(a["x0"]), _ptr(pr.object_type_embedding.weight),
+                    _ptr(pr.object_orientation_feat) if pr.use_orientation else None, _ptr(a["xin0"]), _vp(xp.data_ptr()), st)
+                _lib.check(rc, "msr3d_pos_embed_tokens_fwd")
             for i, layer in enumerate(layers):
                 sa = layer.self_attn
                 bv = sa._packed[1]
                 p_attn, p1, p2, p_ffn = self.ps[i]
                 s_attn, s_1, s_2, s_ffn = self.salts[i]
-                if i == 0 and anchor:
-                    pass        # (msr3d_anchor_front_fwd wrote xin0 and its planes)
-                elif i == 0:    # layer input = tokens + positional term + the two constant embedding rows
-                    rows(st, M=M, L=L, pro=PRO["add"], a0=a["x0"], a1=a["pos"], g1=_ptr(pr.object_type_embedding.weight),
-                         b1=_ptr(pr.object_orientation_feat) if pr.use_orientation else None, o1=a["xin0"], xp=xp)
+                if i == 0:
+                    pass        # (msr3d_pos_embed_tokens_fwd / msr3d_anchor_front_fwd wrote xin0 and its planes)
                 else:           # previous layer's closing norm (+ the positional term)
                     prev = layers[i - 1]
                     rows(st, M=M, L=L, pro=PRO["ln"], part=part, nslab=nff, part_stride=MD, a0_bias=prev.linear2.bias,

@@ -10,10 +10,13 @@ ROOT=$(pwd)
 mkdir -p "$OUT"
 python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 tail -c 400 "$OUT/${TAG}_bench.err"
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/kt" -- python "$ROOT/bench.py" --no-cpu-baseline > "$ROOT/$OUT/kt.log" 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/kt" -- python "$ROOT/bench.py" --no-cpu-baseline --no-extra > "$ROOT/$OUT/kt.log" 2>&1)
 F=$(ls "$OUT"/kt/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$F" ] && cp "$F" "$OUT/${TAG}_bench_kernel_stats.csv"
-F=$(ls "$OUT"/kt/*/*kernel_trace.csv 2>/dev/null | head -1); [ -n "$F" ] && python tools/trace_step.py "$F" > "$OUT/${TAG}_step_timeline.txt"
 rm -rf "$OUT/kt"
+# one step's launches in order: the un-pipelined schedule (one stream), census off (no event pairs between the kernels)
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$ROOT/$OUT/kt1" -- python "$ROOT/bench.py" --no-cpu-baseline --no-extra --no-pipeline --census-steps 0 > "$ROOT/$OUT/kt1.log" 2>&1)
+F=$(ls "$OUT"/kt1/*/*kernel_trace.csv 2>/dev/null | head -1); [ -n "$F" ] && python tools/trace_step.py "$F" > "$OUT/${TAG}_step_timeline.txt"
+rm -rf "$OUT/kt1"
 bash tools/pmc_step.sh "$OUT/pmc_step" > /dev/null 2>&1; cp "$OUT/pmc_step/summary.txt" "$OUT/${TAG}_pmc_step.txt"; rm -rf "$OUT/pmc_step"
 bash tools/pmc_sa.sh "$OUT/pmc_sa" > /dev/null 2>&1; cp "$OUT/pmc_sa/summary.txt" "$OUT/${TAG}_pmc_sa.txt"; rm -rf "$OUT/pmc_sa"
 bash tools/pmc_blocks.sh "$OUT/pmc_blocks" > /dev/null 2>&1; cp "$OUT/pmc_blocks/summary.txt" "$OUT/${TAG}_pmc_blocks.txt"; rm -rf "$OUT/pmc_blocks"
@@ -23,7 +26,10 @@ v python bench.py --no-cpu-baseline --batch 4 --accum 5
 v python bench.py --no-cpu-baseline --batch 4 --accum 5 --micro-steps
 v python bench.py --no-cpu-baseline --batch 4 --accum 5 --micro-steps --no-window
 v python bench.py --no-cpu-baseline --skip-padded
-v python bench.py --no-cpu-baseline --pipeline
+v python bench.py --no-cpu-baseline --no-pipeline
+v python bench.py --no-cpu-baseline --situation-type as_object
+v python bench.py --no-cpu-baseline --dense
+v env MSR3D_TRAIN_MMA=bf16 python bench.py --no-cpu-baseline
 v python bench.py --no-cpu-baseline --from-store
 v python bench.py --no-cpu-baseline --host-inputs
 v python bench.py --no-cpu-baseline --objects 120 --points 2048 --llm-hidden 5120 --batch 8 --situation-type as_object
@@ -32,6 +38,9 @@ v env MSR3D_SA_MMA=f32 python bench.py --no-cpu-baseline
 v env MSR3D_SA_ROWS=0 python bench.py --no-cpu-baseline
 v env MSR3D_SA_MMA=split2 python bench.py --no-cpu-baseline
 v env MSR3D_WGRAD_MIXED=0 python bench.py --no-cpu-baseline
+v env MSR3D_WGRAD_PIPE=0 python bench.py --no-cpu-baseline
+v env MSR3D_WGRAD_STREAM=1 python bench.py --no-cpu-baseline
+v env MSR3D_PACK_FORK=1 python bench.py --no-cpu-baseline
 v env MSR3D_SA3_TILE=2 python bench.py --no-cpu-baseline
 v env MSR3D_WGRAD_HALVES=1 python bench.py --no-cpu-baseline
 v env MSR3D_ATTN_FWD_WAVES=4 MSR3D_ATTN_FWD_SPLIT=0 python bench.py --no-cpu-baseline
@@ -72,6 +81,7 @@ python -m pytest tests/test_seq_ce_gpu.py -q -s -k roofline 2>/dev/null | grep s
 python bench.py --cpu-ops --round-tag "$TAG" > "$OUT/${TAG}_cpu_ops.log" 2>&1; cp "profiles/${TAG}_cpu_ops.json" "$OUT/${TAG}_cpu_ops.json"
 timeout 300 python tools/prof_blocks.py > "$OUT/${TAG}_block_stamps.txt" 2>&1
 timeout 300 python tools/prof_sa_rows.py > "$OUT/${TAG}_sa_rows_stamps.txt" 2>&1
-timeout 120 python tools/bench_wgrad.py > "$OUT/${TAG}_wgrad_forms.txt" 2>&1
+timeout 200 python tools/bench_wgrad.py > "$OUT/${TAG}_wgrad_forms.txt" 2>&1
+[ -x tools/_prof/last_arriver ] && timeout 60 tools/_prof/last_arriver > "$OUT/${TAG}_last_arriver.txt" 2>&1
 timeout 120 python tools/bench_sa.py > "$OUT/${TAG}_encoder_kernels.txt" 2>&1
 ls -la "$OUT"

@@ -19,6 +19,8 @@ run p4 SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 run p5 SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM
 run p6 TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
 run p7 TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum
+run p8 FETCH_SIZE
+run p9 WRITE_SIZE
 python - "$ROOT/$OUT" <<'PY'
 import csv, glob, re, sys, collections
 out = sys.argv[1]
@@ -32,7 +34,7 @@ names = sorted({c for v in agg.values() for c in v})
 with open(out + "/summary.txt", "w") as fo:
     fo.write("# per-launch means; SQ_* summed over all waves / SEs; GRBM_GUI_ACTIVE summed over the 8 XCDs\n")
     for k, cs in sorted(agg.items()):
-        if not any(t in k for t in ("scene_block", "scene_attn", "wgrad", "split_pack", "sa2", "rows_linear")):
+        if not any(t in k for t in ("scene_block", "scene_attn", "wgrad", "split_pack", "sa2", "rows_linear", "anchor_front", "pos_embed")):
             continue
         fo.write(k + "\n")
         for c in names:
