@@ -628,7 +628,7 @@ CENSUS_KERNELS = {
     "msr3d_scene_block[ffn_fwd]": "scene_block_kernel<1, 8>", "msr3d_scene_block[ffn_bwd]": "scene_block_kernel<2, 8>",
     "msr3d_scene_block[linear]": "scene_block_kernel<4, 4>", "msr3d_scene_block[linear_ksplit]": "scene_block_kernel<5, 4>",
     "msr3d_wgrad_split_mixed": "wgrad_mixed_kernel", "msr3d_wgrad_split_colsum": "wgrad_split_kernel",
-    "msr3d_wgrad_split": "wgrad_split_kernel", "msr3d_wgrad_pipe": "wgrad_pipe_kernel",
+    "msr3d_wgrad_split": "wgrad_split_kernel", "msr3d_wgrad_stream": "wgrad_stream_kernel (+ wgrad_fixup_kernel)",
     "msr3d_adamw_flat_scaled": "adamw_kernel (+ sumsq_kernel)", "msr3d_dot_f32": "dot_kernel",
     "msr3d_scene_prologue": "scene_prologue_kernel",
 }
@@ -677,7 +677,7 @@ def census_table(census, model, world_rows, E, level_flops):
         wg = getattr(sched, "wgrad", None)
         if wg is not None:
             f = sum(2.0 * p.M * p.n_out * p.k_in for p in wg.probs)
-            for k in ("msr3d_wgrad_split_mixed", "msr3d_wgrad_split_colsum", "msr3d_wgrad_split", "msr3d_wgrad_pipe"):
+            for k in ("msr3d_wgrad_split_mixed", "msr3d_wgrad_split_colsum", "msr3d_wgrad_split", "msr3d_wgrad_stream"):
                 flop[k] = f
     flop["msr3d_rows_linear_split"] = 2.0 * world_rows * 768 * 768
     pmc, pmc_files = pmc_counters_from_profiles()
@@ -700,7 +700,7 @@ def census_table(census, model, world_rows, E, level_flops):
     return rows, pmc_files
 
 
-def measure_variant(args, device, steps=12, warmup=3, **over):
+def measure_variant(args, device, steps=30, warmup=5, **over):
     """The default step on other inputs (bench.py's extra.* lines): fresh model, trainer and batches -> ms per step."""
     import copy
     from msr3d_amd.synth import synth_batch
@@ -709,6 +709,11 @@ def measure_variant(args, device, steps=12, warmup=3, **over):
         setattr(a, k, v)
     from msr3d_amd import scene_blocks
     prev_mma = scene_blocks.set_train_mma(getattr(a, "train_mma", None)) if getattr(a, "train_mma", None) else None
+    if getattr(a, "train_mma", None):
+        from msr3d_amd import _lib as _lib_mod
+        _lib_mod.load_bf16()
+    if "MSR3D_ATTN_FWD_SPLIT" not in os.environ:
+        scene_blocks.set_attn_fwd_form(split=not a.pipeline)
     model = build(a, device)
     batches = [synth_batch(7000 + i, a.batch, O=O, P=P, device=device, dense=a.dense) for i in range(4)]
     tr = Trainer(model, device, batches[0], a.llm_hidden, use_graph=True)
@@ -729,6 +734,8 @@ def measure_variant(args, device, steps=12, warmup=3, **over):
            "nominal_rows_per_launch": {f"level{l}": st[l]["nominal_rows"] for l in (1, 2)},
            "constant_objects": st["constant_objects"],
            "schedule": "blocks" if getattr(getattr(model, "_schedule", None), "_ran_blocks", False) else "strips/modular"}
+    if "MSR3D_ATTN_FWD_SPLIT" not in os.environ:
+        scene_blocks.set_attn_fwd_form(split=not args.pipeline)
     if getattr(a, "train_mma", None):
         # how far the reduced variant's outputs are from the fp32-accurate path: same weights, same batch, dropout off
         res["rel_l2_vs_f32"] = train_mma_distance(model, batches[0])
@@ -819,6 +826,13 @@ def main():
 
     from msr3d_amd import _lib
     from msr3d_amd.synth import synth_batch
+    if os.environ.get("MSR3D_BENCH_RESERVE_CUS"):       # experiment knob: CUs the persistent encoder kernels leave free
+        _lib.set_reserved_cus(int(os.environ["MSR3D_BENCH_RESERVE_CUS"]))
+    if "MSR3D_ATTN_FWD_SPLIT" not in os.environ:
+        # the attention forward block as ONE workgroup per (scene, head) when the next batch's encoder runs beside the
+        # trainable part (it takes the CUs that form leaves: 0.851 against 0.863 ms), as two otherwise (0.900 against 0.914)
+        from msr3d_amd import scene_blocks
+        scene_blocks.set_attn_fwd_form(split=not (args.pipeline and not dist_on and not args.unfrozen))
     model = build(args, device)
     if args.skip_padded:
         model.visual_prompter.obj_encoder.skip_padded = True

@@ -749,6 +749,13 @@ typedef struct msr3d_scene_block {
 } msr3d_scene_block_t;
 
 int msr3d_scene_block(const msr3d_scene_block_t *p, msr3d_stream_t stream);
+/* The attention forward block's launch form: 1 (the library's default; MSR3D_ATTN_FWD_SPLIT=0 in the environment selects 0
+ * at first use) = two workgroups per (scene, head), each 32 query rows, keys split over eight waves: the faster form when
+ * the step has the chip to itself; 0 = one workgroup per (scene, head) -- 128 workgroups at the bench shape: slower alone
+ * (19.3 against 16 us), FASTER in the pipelined schedule, where the next batch's frozen encoder runs beside the trainable
+ * part and takes the CUs this form leaves (round 6: 0.851 against 0.863 ms a step).  Same values either way.
+ * form = 0 / 1 selects, -1 only queries; returns the form in force, MSR3D_EINVAL for another value. */
+int msr3d_attn_fwd_form(int form);
 
 /* One wave per token row: a0 = sum_s part[s] (+ extra) (+ a0_bias) in slab order (nslab == 0: a0 itself),
  * optionally stored whole (sum_out); then the MSR3D_PRO_* chain with the operands / outputs of

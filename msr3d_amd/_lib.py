@@ -249,7 +249,7 @@ _lib = None
 
 def exported_symbols():
     """Every symbol include/msr3d_hip.h declares (checked by the CPU test-suite)."""
-    return ["msr3d_abi_version", "msr3d_status_string", "msr3d_sqdist_contract", "msr3d_wgrad_form"] + list(_SIGNATURES)
+    return ["msr3d_abi_version", "msr3d_status_string", "msr3d_sqdist_contract", "msr3d_wgrad_form", "msr3d_attn_fwd_form"] + list(_SIGNATURES)
 
 
 ABI_VERSION = 27        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
@@ -277,6 +277,8 @@ def load():
     lib.msr3d_sqdist_contract.restype = _c_int
     lib.msr3d_wgrad_form.restype = _c_int
     lib.msr3d_wgrad_form.argtypes = [_c_int]
+    lib.msr3d_attn_fwd_form.restype = _c_int
+    lib.msr3d_attn_fwd_form.argtypes = [_c_int]
     lib.msr3d_status_string.restype = ctypes.c_char_p
     lib.msr3d_status_string.argtypes = [_c_int]
     for name, argtypes in _SIGNATURES.items():
@@ -381,6 +383,8 @@ def load_bf16():
                 f"{ABI_VERSION} (include/msr3d_hip.h). Rebuild it with `python -m msr3d_amd.build`.")
         lib.msr3d_wgrad_form.restype = _c_int
         lib.msr3d_wgrad_form.argtypes = [_c_int]
+        lib.msr3d_attn_fwd_form.restype = _c_int
+        lib.msr3d_attn_fwd_form.argtypes = [_c_int]
         for name in _BF16_ENTRIES:
             fn = getattr(lib, name)
             fn.argtypes = _SIGNATURES[name]

@@ -1308,9 +1308,26 @@ __global__ __launch_bounds__(256) void split_pack_kernel(int njobs, const msr3d_
   }
 }
 
+// the attention forward block's form: -1 not chosen yet (environment at first use), 0 one workgroup per (scene, head),
+// 1 two (msr3d_attn_fwd_form)
+int g_attn_fwd_form = -1;
+bool attn_fwd_split() {
+  if (g_attn_fwd_form < 0) {
+    const char *v = getenv("MSR3D_ATTN_FWD_SPLIT");
+    g_attn_fwd_form = (v && v[0] == '0') ? 0 : 1;
+  }
+  return g_attn_fwd_form != 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+int msr3d_attn_fwd_form(int form) {
+  if (form == 0 || form == 1) g_attn_fwd_form = form;
+  else if (form != -1) return MSR3D_EINVAL;
+  return attn_fwd_split() ? 1 : 0;
+}
 
 int msr3d_split_pack(int njobs, const msr3d_pack_job_t *jobs, const int *piece_prefix, int total_pieces,
                      msr3d_stream_t stream) {
@@ -1353,10 +1370,9 @@ int msr3d_scene_block(const msr3d_scene_block_t *pp, msr3d_stream_t stream) {
       if (p.H != 8 || !p.w2 || !p.qkvc || !p.ploc || !p.pad || !p.ctx || !p.bias1 || p.ldq % 4) return MSR3D_EINVAL;
       if (p.w1_bytes < 8u * 8u * 8u * kPieceBytes || p.w2_bytes < 8u * 16u * kPieceBytes) return MSR3D_EINVAL;
       {
-        // two workgroups per (scene, head), keys split over the core's eight waves (round 5): default;
-        // MSR3D_ATTN_FWD_SPLIT=0 restores one workgroup per (scene, head)
-        static const bool split = [] { const char *v = getenv("MSR3D_ATTN_FWD_SPLIT"); return !(v && v[0] == '0'); }();
-        if (split) {
+        // two workgroups per (scene, head), keys split over the core's eight waves (round 5): the library's default;
+        // MSR3D_ATTN_FWD_SPLIT=0 / msr3d_attn_fwd_form(0): one workgroup per (scene, head)
+        if (attn_fwd_split()) {
           static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&scene_attn_fwd2_kernel),
                                                              hipFuncAttributeMaxDynamicSharedMemorySize, kAttnFwd2Lds);
           if (attr != hipSuccess) return (int)attr;

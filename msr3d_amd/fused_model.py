@@ -137,10 +137,9 @@ class PrompterSchedule:
         if L > 128 or e.shape[-1] % 4 or cfg.loc_fourier_dim > 64:
             return False
         if pr.situation_type == "as_object":
-            # the agent as a token of its own (round 6): on the scene-block schedule only, frozen encoder only
-            l0 = pr.spatial_encoder[0]
-            if not (self.anchor and _MODE[0] == "blocks" and hipops._attn_mma[0] == "f32" and not e.requires_grad
-                    and self._blocks_capable(L + 1, l0.linear1.out_features, l0.self_attn.n_head)
+            # the agent as a token of its own (round 6): frozen encoder only
+            # (a scene of more than 64 tokens -- BASELINE's stress configuration, L = 121 -- takes the strip schedule)
+            if not (self.anchor and not e.requires_grad and L + 1 <= 128
                     and d.get("anchor_locs") is not None and d.get("anchor_orientation") is not None
                     and (not pr.use_orientation or pr.orientation_encoder.in_features == 84)):   # 4 + 8 x 10 bands
                 return False
@@ -668,8 +667,13 @@ class PrompterSchedule:
         self.stream = st = _lib.current_stream_ptr(dev)
         train = m.training
         seed = hipops.seed_word(dev)
-        e2 = embeds.reshape(M, KE)
-        e2 = e2 if e2.is_contiguous() else e2.contiguous()
+        anchor = self.anchor
+        if anchor:
+            a["e61"].view(B, L, KE)[:, 1:].copy_(embeds.reshape(B, L - 1, KE))
+            e2 = a["e61"]
+        else:
+            e2 = embeds.reshape(M, KE)
+            e2 = e2 if e2.is_contiguous() else e2.contiguous()
         self.saved_embeds = e2
         layers = list(pr.spatial_encoder)
         self.salts = [[hipops._next_salt() for _ in range(4)] for _ in layers]
@@ -683,21 +687,40 @@ class PrompterSchedule:
             rc = lib.msr3d_step_begin(_ptr(a.buf), a.zero_floats, _ptr(seed) if self.bump_seed else None, st)
             _lib.check(rc, "msr3d_step_begin")
             lp = pr.obj_linear_projection
-            self._multi([dict(a_kc=1, b_kc=1, M=M, N=D, K=KE, A=e2, lda=KE, B=lp.weight, ldb=KE, C=a["x0"], ldc=D,
-                              bias=lp.bias, beta=1.0)])
-            le, se = pr.loc_embedding_encoder, pr.size_embedding_encoder
-            rc = lib.msr3d_pos_embed_fwd(M, KF, _ptr(a["ff"]), _ptr(a["loc6"]), _ptr(le[0].weight), _ptr(le[0].bias),
-                                         _ptr(le[1].weight), _ptr(le[1].bias), ctypes.c_float(le[1].eps),
-                                         _ptr(se[0].weight), _ptr(se[0].bias), _ptr(se[1].weight), _ptr(se[1].bias),
-                                         ctypes.c_float(se[1].eps), _ptr(a["pos"]), _ptr(a["sa"]), _ptr(a["sta"]),
-                                         _ptr(a["sb"]), _ptr(a["stb"]), st)
-            _lib.check(rc, "msr3d_pos_embed_fwd")
+            front = [dict(a_kc=1, b_kc=1, M=M, N=D, K=KE, A=e2, lda=KE, B=lp.weight, ldb=KE, C=a["x0"], ldc=D,
+                          bias=lp.bias, beta=1.0)]
+            if anchor:
+                if pr.use_orientation:
+                    oe = pr.orientation_encoder
+                    front.append(dict(a_kc=1, b_kc=1, M=B, N=D, K=oe.in_features, A=a["qf"], lda=oe.in_features, B=oe.weight,
+                                      ldb=oe.in_features, C=a["a_ori"], ldc=D, bias=oe.bias, beta=1.0))
+                self._multi(front)
+                ll = pr.loc_layers[0]
+                rc = lib.msr3d_anchor_front_fwd(B, L, _ptr(a["x0"]), _ptr(a["a_ori"]), _ptr(pr.anchor_feat),
+                                                _ptr(pr.object_type_embedding.weight),
+                                                _ptr(pr.object_orientation_feat) if pr.use_orientation else None,
+                                                _ptr(a["loc6"]), _ptr(ll[0].weight), _ptr(ll[0].bias), _ptr(ll[1].weight),
+                                                _ptr(ll[1].bias), ctypes.c_float(ll[1].eps), _ptr(a["pos"]), _ptr(a["sa"]),
+                                                _ptr(a["sta"]), _ptr(a["xin0"]), None, st)
+                _lib.check(rc, "msr3d_anchor_front_fwd")
+            else:
+                self._multi(front)
+                le, se = pr.loc_embedding_encoder, pr.size_embedding_encoder
+                rc = lib.msr3d_pos_embed_fwd(M, KF, _ptr(a["ff"]), _ptr(a["loc6"]), _ptr(le[0].weight), _ptr(le[0].bias),
+                                             _ptr(le[1].weight), _ptr(le[1].bias), ctypes.c_float(le[1].eps),
+                                             _ptr(se[0].weight), _ptr(se[0].bias), _ptr(se[1].weight), _ptr(se[1].bias),
+                                             ctypes.c_float(se[1].eps), _ptr(a["pos"]), _ptr(a["sa"]), _ptr(a["sta"]),
+                                             _ptr(a["sb"]), _ptr(a["stb"]), st)
+                _lib.check(rc, "msr3d_pos_embed_fwd")
             for i, layer in enumerate(layers):
                 sa = layer.self_attn
                 wv, bv = sa._packed[0], sa._packed[1]
                 p_attn, p1, p2, p_ffn = self.ps[i]
                 s_attn, s_1, s_2, s_ffn = self.salts[i]
-                if i == 0:
+                if i == 0 and anchor:       # (msr3d_anchor_front_fwd wrote the layer input)
+                    self._strip(M=M, N=W, pro=PRO["plain"], epi=EPI["bias"], b_kc=1, a0=a["xin0"], W=wv, ldw=D, bias=bv,
+                                C=a["qkvc0"], ldc=W)
+                elif i == 0:
                     self._strip(M=M, N=W, pro=PRO["add"], epi=EPI["bias"], b_kc=1, a0=a["x0"], a1=a["pos"],
                                 g1=_ptr(pr.object_type_embedding.weight),        # row 0: every object has type id 0
                                 b1=_ptr(pr.object_orientation_feat) if pr.use_orientation else None,
@@ -790,8 +813,34 @@ class PrompterSchedule:
                              self._dw(gq, W, a[f"xin{i}"], D, M, gwv, gbv),
                              self._dw(a["d_fc"], D, a[f"ctx{i}"], D, M, sa.fc.weight.grad, sa.fc.bias.grad)])
                 d_out = a[f"d_xin{i}"]
-            le, se = pr.loc_embedding_encoder, pr.size_embedding_encoder
             more = same_all and nl > 1
+            if self.anchor:
+                ll = pr.loc_layers[0]
+                tg = pr.object_type_embedding.weight.grad
+                lp = pr.obj_linear_projection
+                rc = lib.msr3d_anchor_front_bwd(
+                    B, L, _ptr(a["d_xin0"]), _ptr(a["d_xin1"]) if more else None,
+                    _ptr(a["d_xin2"]) if (more and nl > 2) else None, _ptr(a["sa"]), _ptr(a["sta"]), _ptr(ll[1].weight),
+                    _ptr(a["d_la"]), _ptr(ll[1].weight.grad), _ptr(ll[1].bias.grad), _ptr(tg),
+                    _ptr(pr.object_orientation_feat.grad) if pr.use_orientation else None, _ptr(lp.bias.grad), _ptr(tg, D),
+                    _ptr(pr.anchor_feat.grad), st)
+                _lib.check(rc, "msr3d_anchor_front_bwd")
+                # loc_layers[0][0] (6 -> 256), the orientation encoder over the agent rows of d xin0 (row stride L * 256),
+                # the projection against the features with a zero row per agent (its bias gradient came from the launch above)
+                last = [dict(a_kc=0, b_kc=0, M=D, N=6, K=M, A=a["d_la"], lda=D, B=a["loc6"], ldb=6, C=ll[0].weight.grad, ldc=6,
+                             beta=1.0, colsum=ll[0].bias.grad),
+                        dict(a_kc=0, b_kc=0, M=D, N=KE, K=M, A=a["d_xin0"], lda=D, B=self.saved_embeds, ldb=KE,
+                             C=lp.weight.grad, ldc=KE, beta=1.0)]
+                if pr.use_orientation:
+                    oe = pr.orientation_encoder
+                    QF = oe.in_features
+                    last.append(dict(a_kc=0, b_kc=0, M=D, N=QF, K=B, A=a["d_xin0"], lda=L * D, B=a["qf"], ldb=QF,
+                                     C=oe.weight.grad, ldc=QF, beta=1.0, colsum=oe.bias.grad))
+                self._multi(last)
+                for p in self._params():
+                    self.dp.mark_ready(p)
+                return
+            le, se = pr.loc_embedding_encoder, pr.size_embedding_encoder
             rc = lib.msr3d_pos_embed_bwd(
                 M, _ptr(a["d_xin0"]), _ptr(a["d_xin1"]) if more else None,
                 _ptr(a["d_xin2"]) if (more and nl > 2) else None, _ptr(a["sa"]), _ptr(a["sta"]), _ptr(le[1].weight),

@@ -39,6 +39,16 @@ def set_train_mma(name):
     return prev
 
 
+def set_attn_fwd_form(split):
+    """The attention forward block as two workgroups per (scene, head) (True: the library's default, best when the step has
+    the chip to itself) or one (False: best in the pipelined schedule, where the next batch's encoder runs beside the
+    trainable part); applies to every loaded library; takes effect at the next launch (a captured graph keeps its form)."""
+    form = 1 if split else 0
+    for lib in (_lib.load(), _lib._lib_bf16):
+        if lib is not None:
+            lib.msr3d_attn_fwd_form(form)
+
+
 def _klib():
     """The library whose block / weight-gradient kernels run."""
     return _lib.load_bf16() if _TRAIN_MMA[0] == "bf16" else _lib.load()
@@ -142,13 +152,13 @@ class WgradTable:
         self.mixed = os.environ.get("MSR3D_WGRAD_MIXED", "1") != "0" and not self.halves
         self._ws = self._sync = None
         self._real = []                       # real (non-padding) tiles of each problem
-        # Round 6, opt-in (MSR3D_WGRAD_STREAM=1): the tiles as one sequence of slab pairs dealt evenly to a persistent grid,
-        # one workgroup per CU, cut tiles completed by a small second launch (msr3d_wgrad_stream).  Built to turn the
-        # step's ~1.3 tiles per CU into 1.3 tile times; measured EQUAL to the mixed launch (96.7-100.7 us against
-        # 98.5-99.8, same box, tools/bench_wgrad.py): ~2.5 pieces per workgroup each pay a prologue (two dependent
-        # round trips before the first product) and a write-back, which is what the even deal saves.  Kept, tested
-        # (bit-reproducible), not the default.  Needs the pipe tile kernel (msr3d_wgrad_form 1).
-        self.stream = os.environ.get("MSR3D_WGRAD_STREAM", "0") == "1" and not self.halves
+        # Round 6 (default; MSR3D_WGRAD_STREAM=0 turns it off): the tiles as one sequence of slab pairs dealt evenly to a
+        # persistent grid, one workgroup per CU, cut tiles completed by a small second launch (msr3d_wgrad_stream).  Alone
+        # it is EQUAL to the mixed launch (96.7-100.7 us against 98.5-99.8, same box, tools/bench_wgrad.py: ~2.5 pieces
+        # per workgroup each pay a prologue and a write-back, which is what the even deal saves); IN THE STEP it is 8-12 us
+        # faster (0.851 against 0.862 ms, three interleaved pairs: profiles/r06_v2_ab.txt).  Bit-reproducible.  Needs the
+        # pipe tile kernel (msr3d_wgrad_form 1).
+        self.stream = os.environ.get("MSR3D_WGRAD_STREAM", "1") != "0" and not self.halves
         self._stream_key = None
         self._stream_plan = None
 

@@ -146,18 +146,20 @@ def test_train_step_through_the_schedule_in_a_graph():
         assert torch.allclose(p0[k], p1[k], rtol=1e-3, atol=3e-3), k
 
 
-@pytest.mark.parametrize("B,O,E", [(3, 20, 128), (2, 60, 256), (5, 13, 128), (16, 60, 4096), (2, 63, 256)])
+@pytest.mark.parametrize("B,O,E", [(3, 20, 128), (2, 60, 256), (5, 13, 128), (16, 60, 4096), (2, 63, 256), (2, 120, 256),
+                                   (3, 64, 128)])
 def test_as_object_schedule_matches_the_modular_path(B, O, E):
     """situation_type 'as_object' (configs/leo_3_dataset_pure_txt.yaml's prompter: the agent is a token of its own in
     front of the objects, /root/reference/model/ose3d_situation.py:334-353) on the scene-block schedule (round 6:
     msr3d_anchor_front_fwd / _bwd + the blocks) against the per-module path under autograd: outputs, the returned mask
     and EVERY parameter gradient -- anchor_feat, orientation_encoder, loc_layers and both rows of the type table among
-    them.  O = 63: L = 64, a full block."""
+    them.  O = 63: L = 64, a full block; O = 64, 120 (BASELINE's stress configuration): more tokens than a block holds --
+    the strip schedule with the same front and back."""
     model, dp, batch = _setup(0.0, B=B, O=O, E=E, situation_type="as_object")
     sched = model._schedule
     assert sched.anchor and sched.eligible(dict(batch))
     a = _run(model, dp, batch, "schedule")
-    assert sched._ran_blocks and sched.dims["L"] == O + 1 and a[1].shape[1] == O + 1
+    assert sched._ran_blocks == (O + 1 <= 64) and sched.dims["L"] == O + 1 and a[1].shape[1] == O + 1
     mask_s = model(dict(batch))["obj_masks"].clone()
     b = _run(model, dp, batch, "modular")
     sched.enabled = False
