@@ -364,10 +364,13 @@ __global__ __launch_bounds__(64 * NW) void scene_block_kernel(const SB p) {
     // the scene's pairwise slab is headed for the LDS the planes occupy: fetched into registers now (threads 0..255)
     const float *plsrc = p.ploc + (size_t)b * L * L * SD;
     const int pn = L * L * SD;
-    const bool pvec = (reinterpret_cast<uintptr_t>(plsrc) & 15u) == 0 && (pn & 3) == 0;
+    const Slab4 pls = make_slab4(plsrc, pn);          // (16-byte vectors at any alignment: L = 61)
     const bool plt = NW == 4 || tid < 256;
     float4 plv[msr3d_attn::kPlocRegs];
-    if (pvec && plt) msr3d_attn::ploc_fetch(plsrc, pn >> 2, plv);
+    if (plt) {
+#pragma unroll
+      for (int k = 0; k < msr3d_attn::kPlocRegs; ++k) plv[k] = slab4_load(pls, tid + 256 * k);
+    }
     f32x4 acc[RN1][4];
     zero_acc3(acc);
     gemm_split3<true, RN1, 4, KS1, RING>(xr, 0, w1, acc, ring1);
@@ -414,9 +417,14 @@ __global__ __launch_bounds__(64 * NW) void scene_block_kernel(const SB p) {
     SB_STAMP(4);
     __syncthreads();                       // every wave is done with the ROWS planes; q / k / v / cond visible
     float *sp = reinterpret_cast<float *>(xs);                      // P [64][68], then the pairwise slab
-    const float *plb = sp + TM * (TM + 4);
-    if (pvec) { if (plt) msr3d_attn::ploc_store(sp + TM * (TM + 4), pn >> 2, plv); }
-    else plb = msr3d_attn::stage_ploc<TM>(p.ploc, b, L, sp + TM * (TM + 4));
+    const float *plb = sp + TM * (TM + 4) + pls.mis;
+    if (plt) {
+#pragma unroll
+      for (int k = 0; k < msr3d_attn::kPlocRegs; ++k) {
+        const int e = tid + 256 * k;
+        if (e < pls.n4) reinterpret_cast<float4 *>(sp + TM * (TM + 4))[e] = plv[k];
+      }
+    }
     __syncthreads();
     SB_STAMP(5);
     f32x4 o[2];

@@ -31,6 +31,21 @@ import torch
 from . import hipops
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """ONE encoder side stream per device for the whole process.  HIP streams share a handful of hardware queues
+    (GPU_MAX_HW_QUEUES, four by default), handed out as streams are created: a step object that made a stream of its own
+    could land on the queue the compute stream uses, and its prefetched encoder then ran IN LINE with the step instead
+    of beside it (measured: the second and later step objects of a process 7-12 % slower than the first, same kernels,
+    same kernel times: bench.py's extra.* variants).  The first stream made is the one every step object uses."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 class HotPathTrainStep:
     def __init__(self, model, optimizer, dp, loss_fn, example_batch, use_graph=True, accum_steps=1,
                  zero_in_optimizer=False, micro_batches=1):
@@ -103,7 +118,7 @@ class HotPathTrainStep:
         self._probed = False
         self.unused_parameters = []
         # encoder prefetch (software pipelining over steps)
-        self._enc_stream = torch.cuda.Stream() if self.static["obj_embeds"].is_cuda else None
+        self._enc_stream = _side_stream(self.static["obj_embeds"].device) if self.static["obj_embeds"].is_cuda else None
         self._pref = {"key": None, "feats": torch.empty_like(self.static["obj_embeds"]), "event": None}
         self._win = {"feats": None, "index": {}, "B": 0}        # encode_window(): features of a whole accumulation window
 
