@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 27
+#define MSR3D_ABI_VERSION 28
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -725,7 +725,7 @@ int msr3d_rows_linear_split(int M, int N, int K, const float *a, int lda, const 
 typedef struct msr3d_scene_block {
   int kind, B, L;               /* scenes, token rows per scene (L <= 64) */
   const unsigned short *xp;     /* (B, 3, 64, 256) bf16 planes of the input rows */
-  const float *a0; int lda0;    /* LINEAR_KSPLIT only: (M, lda0) f32, lda0 % 256 == 0, lda0 <= 4096 */
+  const float *a0; int lda0;    /* LINEAR_KSPLIT only: (M, lda0) f32, lda0 % 256 == 0, lda0 <= 5120 */
   const unsigned short *w1; unsigned w1_bytes;   /* packed operand of product 1 (see the table above) */
   const float *bias1;           /* product 1's bias: ATTN_FWD the packed [q|k|v|cond] bias, FFN_FWD b1, LINEAR b */
   const unsigned short *w2; unsigned w2_bytes;   /* packed operand of product 2 */
@@ -746,6 +746,11 @@ typedef struct msr3d_scene_block {
   int H;                        /* 8 */
   /* LINEAR */
   float *C; int ldc; int N;     /* N % 256 == 0 */
+  /* Row tiles that ignore scene boundaries (round 6; the FFN_* / LINEAR* kinds, whose work is row-local): rows_total > 0
+   * says the token matrix has that many rows in all, cut into B tiles of L rows (L = 64, B = ceil(rows_total / L)), the
+   * last one shorter -- a scene of more than 64 tokens (BASELINE's stress configuration: 121) then still runs its
+   * feed-forward and projector halves on these kernels.  0: B scenes of exactly L rows. */
+  int rows_total;
 } msr3d_scene_block_t;
 
 int msr3d_scene_block(const msr3d_scene_block_t *p, msr3d_stream_t stream);
@@ -762,7 +767,7 @@ int msr3d_attn_fwd_form(int form);
  * the msr3d_strip_gemm_t struct -- in the backward codes o1 = the residual gradient, STORED, to be passed
  * as the next sum's `extra`; the chain's result goes to `xp` (B, 3, 64, 256) bf16 as three exactly-split planes
  * (optional).  MSR3D_PRO_PLAIN: sum only.  LayerNorm parameter gradients are accumulated (atomicAdd,
- * one per column and four rows) or stored as per-workgroup partials (grad_partials).  nslab <= 16. */
+ * one per column and four rows) or stored as per-workgroup partials (grad_partials).  nslab <= 20. */
 typedef struct msr3d_scene_rows {
   int M, L, pro;
   const float *a0;

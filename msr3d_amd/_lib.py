@@ -68,7 +68,7 @@ class SceneBlock(ctypes.Structure):
                 ("seed", _ptr),
                 ("qkvc", _ptr), ("ldq", _c_int), ("dqkvc", _ptr), ("ploc", _ptr), ("pad", _ptr),
                 ("probs", _ptr), ("ctx", _ptr), ("H", _c_int),
-                ("C", _ptr), ("ldc", _c_int), ("N", _c_int)]
+                ("C", _ptr), ("ldc", _c_int), ("N", _c_int), ("rows_total", _c_int)]
 
 
 class SceneRows(ctypes.Structure):
@@ -252,7 +252,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string", "msr3d_sqdist_contract", "msr3d_wgrad_form", "msr3d_attn_fwd_form"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 27        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 28        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():

@@ -211,8 +211,10 @@ __global__ __launch_bounds__(64 * NW) void scene_block_kernel(const SB p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned short *xs = reinterpret_cast<unsigned short *>(smem);
   unsigned char *aux = smem + XS_BYTES;
-  const int slice = blockIdx.x, b = blockIdx.y, L = p.L;
-  const int row_base = b * L;
+  // (rows_total > 0: row tiles that ignore scene boundaries -- tile b holds rows [b L, min((b + 1) L, rows_total)))
+  const int slice = blockIdx.x, b = blockIdx.y;
+  const int row_base = b * p.L;
+  const int L = p.rows_total > 0 ? min(p.L, p.rows_total - row_base) : p.L;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
@@ -1370,7 +1372,10 @@ int msr3d_scene_block(const msr3d_scene_block_t *pp, msr3d_stream_t stream) {
   if (p.B == 0) return 0;
   if (!p.w1) return MSR3D_EINVAL;
   if (p.kind == MSR3D_BLK_LINEAR_KSPLIT ? !p.a0 : !p.xp) return MSR3D_EINVAL;
-  if (p.kind != MSR3D_BLK_LINEAR && (!p.part || p.part_stride < (long long)p.B * p.L * KD)) return MSR3D_EINVAL;
+  const long long rows_all = p.rows_total > 0 ? p.rows_total : (long long)p.B * p.L;
+  if (p.rows_total < 0 || (p.rows_total > 0 && (p.rows_total > p.B * p.L || p.rows_total <= (p.B - 1) * p.L))) return MSR3D_EINVAL;
+  if (p.rows_total > 0 && (p.kind == MSR3D_BLK_ATTN_FWD || p.kind == MSR3D_BLK_ATTN_BWD)) return MSR3D_EINVAL;
+  if (p.kind != MSR3D_BLK_LINEAR && (!p.part || p.part_stride < rows_all * KD)) return MSR3D_EINVAL;
   if (p.p_drop > 0.f && !p.seed) return MSR3D_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   switch (p.kind) {
@@ -1438,7 +1443,7 @@ int msr3d_scene_block(const msr3d_scene_block_t *pp, msr3d_stream_t stream) {
       if (p.N <= 0 || p.N % 256 || !p.C || p.ldc % 4 || p.w1_bytes < (unsigned)(8 * (p.N / 16)) * kPieceBytes) return MSR3D_EINVAL;
       return launch_block<MSR3D_BLK_LINEAR>(p, p.N / 256, s);
     case MSR3D_BLK_LINEAR_KSPLIT:
-      if (p.lda0 <= 0 || p.lda0 % 256 || p.lda0 / 256 > 16) return MSR3D_EINVAL;
+      if (p.lda0 <= 0 || p.lda0 % 256 || p.lda0 / 256 > 20) return MSR3D_EINVAL;
       if (p.w1_bytes < (unsigned)((p.lda0 / 32) * 16) * kPieceBytes) return MSR3D_EINVAL;
       return launch_block<MSR3D_BLK_LINEAR_KSPLIT>(p, p.lda0 / 256, s);
     default:

@@ -34,7 +34,7 @@ using SR = msr3d_scene_rows_t;
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 
-constexpr int MAXS = 16;
+constexpr int MAXS = 20;
 
 template <int PRO>
 __global__ __launch_bounds__(256) void scene_rows_kernel(const SR p) {

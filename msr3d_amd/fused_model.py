@@ -112,6 +112,7 @@ class PrompterSchedule:
         # and drops its own msr3d_bump_seed launch); off: the caller owns the seed
         self.bump_seed = False
         self.need_d_embeds = False   # set per backward: the object features come from an unfrozen encoder
+        self.hybrid, self.tiles = False, 0
         self._pack_stream = None
         self._ln_job_buf = None
 
@@ -227,7 +228,7 @@ class PrompterSchedule:
                 a.want(f"fcacc{i}", M, D); a.want(f"d_t{i}", M, D); a.want(f"d_xacc{i}", M, D)
                 a.want(f"d_ffn{i}", M, D); a.want(f"d_pre{i}", M, FF); a.want(f"d_fc{i}", M, D)
                 a.want(f"d_qkvc{i}", M, W)
-            a.want("part", 16, M, D)       # a block's partial products, one slab per slice
+            a.want("part", 20, M, D)       # a block's partial products, one slab per slice
             # LayerNorm parameter gradients: per-workgroup column sums of the backward row kernels (4 rows each),
             # added up in order by ONE launch at the end of backward (instead of 240 x 256 x 18 float atomics)
             a.want("lnpart", nl * 6, (M + 3) // 4, D)
@@ -263,14 +264,19 @@ class PrompterSchedule:
         self._ptr_key = None
         if blocks:
             # the blocks' input rows as three bf16 planes per scene; rows past L are never written (stay zero)
-            self.xp = torch.zeros(B * 3 * 64 * 256, dtype=torch.int16, device=device)
+            self.hybrid = L > 64
+            self.tiles = (M + 63) // 64 if self.hybrid else B         # 64-row tiles of the token matrix | scenes
+            self.xp = torch.zeros(self.tiles * 3 * 64 * 256, dtype=torch.int16, device=device)
             self._build_block_tables()
 
 
     # ------------------------------------------------------------------ scene-local fused blocks (round 3)
     def _blocks_capable(self, L, FF, H):
-        # (the arena's `part` has 16 partial slabs and msr3d_scene_block rejects more slices than that)
-        return L <= 64 and FF % 128 == 0 and FF // 128 <= 16 and H == 8
+        # (the arena's `part` has 20 partial slabs and msr3d_scene_block rejects more slices than that).  L <= 64: a scene is
+        # a block.  64 < L <= 128 (round 6, BASELINE's stress configuration): the HYBRID schedule -- the row-local halves
+        # (feed-forward, projector, every rows launch, the weight gradients) on the block kernels over 64-row tiles that
+        # ignore scene boundaries (msr3d_scene_block_t.rows_total), the attention on the strip kernels
+        return L <= 128 and FF % 128 == 0 and FF // 128 <= 16 and H == 8
 
     def use_blocks(self):
         # (the blocks' attention core multiplies on the bf16x3 split = fp32 accuracy; a reduced-precision attention
@@ -292,7 +298,7 @@ class PrompterSchedule:
         wg = scene_blocks.WgradTable(dev)
         PIECE = scene_blocks.PIECE
         lp = m.llm_proj
-        self.llm_blocks = E % 256 == 0 and E // 256 <= 16      # (16 partial slabs; wider projectors take the strip GEMM)
+        self.llm_blocks = E % 256 == 0 and E // 256 <= 20      # (20 partial slabs; wider projectors take the strip GEMM)
         if self.llm_blocks:
             pk.add("llm", lp.weight, E, D, False)                   # scene = tok W^T
             pk.add("llm_t", lp.weight, D, E, True)                  # d tok = d scene W
@@ -301,17 +307,18 @@ class PrompterSchedule:
             sa = layer.self_attn
             wv, bv, gwv, gbv, _dp = sa._packed
             l1, l2 = layer.linear1, layer.linear2
-            head_rows = 8 * 8 * PIECE // 2              # int16 elements of one head's [8 slabs][8 tiles]
-            buf = torch.empty(H * head_rows, dtype=torch.int16, device=dev)
-            pk.bufs[f"qkvc{i}"] = buf
-            buf_t = torch.empty(H * (4 * 16 * PIECE // 2), dtype=torch.int16, device=dev)
-            pk.bufs[f"qkvc_t{i}"] = buf_t
-            for h in range(H):
-                segs = scene_blocks.head_segments(h)
-                pk.add(None, wv, 128, D, False, segs, out=buf, out_offset=h * head_rows * 2)
-                pk.add(None, wv, D, 128, True, segs, out=buf_t, out_offset=h * 4 * 16 * PIECE)
-            pk.add(f"fc{i}", sa.fc.weight, D, D, False)             # acc += ctx_h Wfc[:, h]^T
-            pk.add(f"fc_t{i}", sa.fc.weight, D, D, True)            # d ctx = d_fc Wfc
+            if not self.hybrid:                         # (hybrid: the attention half reads the fp32 weights, strip kernels)
+                head_rows = 8 * 8 * PIECE // 2              # int16 elements of one head's [8 slabs][8 tiles]
+                buf = torch.empty(H * head_rows, dtype=torch.int16, device=dev)
+                pk.bufs[f"qkvc{i}"] = buf
+                buf_t = torch.empty(H * (4 * 16 * PIECE // 2), dtype=torch.int16, device=dev)
+                pk.bufs[f"qkvc_t{i}"] = buf_t
+                for h in range(H):
+                    segs = scene_blocks.head_segments(h)
+                    pk.add(None, wv, 128, D, False, segs, out=buf, out_offset=h * head_rows * 2)
+                    pk.add(None, wv, D, 128, True, segs, out=buf_t, out_offset=h * 4 * 16 * PIECE)
+                pk.add(f"fc{i}", sa.fc.weight, D, D, False)             # acc += ctx_h Wfc[:, h]^T
+                pk.add(f"fc_t{i}", sa.fc.weight, D, D, True)            # d ctx = d_fc Wfc
             pk.add(f"w1_{i}", l1.weight, FF, D, False)              # pre = t W1^T
             pk.add(f"w1_t{i}", l1.weight, D, FF, True)              # d t += d_pre W1
             pk.add(f"w2_{i}", l2.weight, D, FF, False)              # ffn += h W2^T
@@ -378,7 +385,13 @@ class PrompterSchedule:
                             float(layer.dropout2.p) if train else 0.0, float(layer.dropout.p) if train else 0.0))
         same_all = pr.cfg.spatial_encoder.obj_loc_encoding == "same_all"
         pk, xp, part, MD = self.packs, self.xp, a["part"], M * D
-        blk, rows = scene_blocks.launch_block, scene_blocks.launch_rows
+        hyb = self.hybrid
+        # hybrid: Bt tiles of Lt = 64 rows over the whole token matrix instead of B scenes of L rows
+        Bt, Lt, RT = (self.tiles, 64, M) if hyb else (B, L, 0)
+
+        def blk(st_, **kw):
+            scene_blocks.launch_block(st_, rows_total=RT, **kw)
+        rows = scene_blocks.launch_rows
         nff = FF // 128
         join = None
         with torch.cuda.device(dev):
@@ -415,7 +428,7 @@ class PrompterSchedule:
                                                 _ptr(pr.object_orientation_feat) if pr.use_orientation else None,
                                                 _ptr(a["loc6"]), _ptr(ll[0].weight), _ptr(ll[0].bias), _ptr(ll[1].weight),
                                                 _ptr(ll[1].bias), ctypes.c_float(ll[1].eps), _ptr(a["pos"]), _ptr(a["sa"]),
-                                                _ptr(a["sta"]), _ptr(a["xin0"]), _vp(xp.data_ptr()), st)
+                                                _ptr(a["sta"]), _ptr(a["xin0"]), None if hyb else _vp(xp.data_ptr()), st)
                 _lib.check(rc, "msr3d_anchor_front_fwd")
             else:
                 self._multi(front)
@@ -427,7 +440,8 @@ class PrompterSchedule:
                     _ptr(le[1].bias), ctypes.c_float(le[1].eps), _ptr(se[0].weight), _ptr(se[0].bias), _ptr(se[1].weight),
                     _ptr(se[1].bias), ctypes.c_float(se[1].eps), _ptr(a["pos"]), _ptr(a["sa"]), _ptr(a["sta"]), _ptr(a["sb"]),
                     _ptr(a["stb"]), _ptr(a["x0"]), _ptr(pr.object_type_embedding.weight),
-                    _ptr(pr.object_orientation_feat) if pr.use_orientation else None, _ptr(a["xin0"]), _vp(xp.data_ptr()), st)
+                    _ptr(pr.object_orientation_feat) if pr.use_orientation else None, _ptr(a["xin0"]),
+                    None if hyb else _vp(xp.data_ptr()), st)
                 _lib.check(rc, "msr3d_pos_embed_tokens_fwd")
             for i, layer in enumerate(layers):
                 sa = layer.self_attn
@@ -438,34 +452,53 @@ class PrompterSchedule:
                     pass        # (msr3d_pos_embed_tokens_fwd / msr3d_anchor_front_fwd wrote xin0 and its planes)
                 else:           # previous layer's closing norm (+ the positional term)
                     prev = layers[i - 1]
-                    rows(st, M=M, L=L, pro=PRO["ln"], part=part, nslab=nff, part_stride=MD, a0_bias=prev.linear2.bias,
+                    rows(st, M=M, L=Lt, pro=PRO["ln"], part=part, nslab=nff, part_stride=MD, a0_bias=prev.linear2.bias,
                          sum_out=a[f"ffn{i-1}"], a1=a[f"t{i-1}"], a2=a["pos"] if same_all else None,
                          g1=prev.norm2.weight, b1=prev.norm2.bias, eps1=prev.norm2.eps, p1=self.ps[i - 1][2],
                          salt1=self.salts[i - 1][2], seed=seed, o0=a[f"s3_{i-1}"], ost1=a[f"st3_{i-1}"],
-                         o1=a[f"xin{i}"], xp=xp)
+                         o1=a[f"xin{i}"], xp=None if hyb else xp)
                 if join is not None:        # the packs are needed from here on
                     torch.cuda.current_stream(dev).wait_stream(join)
                     join = None
-                blk(st, kind=BLK["attn_fwd"], B=B, L=L, xp=xp, w1=pk.bufs[f"qkvc{i}"], w1_bytes=pk.nbytes(f"qkvc{i}"),
-                    bias1=bv, w2=pk.bufs[f"fc{i}"], w2_bytes=pk.nbytes(f"fc{i}"), part=part, part_stride=MD,
-                    qkvc=a[f"qkvc{i}"], ldq=W, ploc=a["pw"], pad=self.pad, probs=a[f"probs{i}"], ctx=a[f"ctx{i}"], H=H)
-                # attention tail's LayerNorm, then norm1 over the same residual -> the feed-forward block's input
-                rows(st, M=M, L=L, pro=PRO["ln2"], part=part, nslab=H, part_stride=MD, a0_bias=sa.fc.bias,
-                     sum_out=a[f"fcacc{i}"], a1=a[f"xin{i}"], g1=sa.layer_norm.weight, b1=sa.layer_norm.bias,
-                     eps1=sa.layer_norm.eps, p1=p_attn, salt1=s_attn, g2=layer.norm1.weight, b2=layer.norm1.bias,
-                     eps2=layer.norm1.eps, p2=p1, salt2=s_1, seed=seed, o0=a[f"s1_{i}"], ost1=a[f"st1_{i}"],
-                     o2=a[f"s2_{i}"], ost2=a[f"st2_{i}"], o1=a[f"t{i}"], xp=xp)
-                blk(st, kind=BLK["ffn_fwd"], B=B, L=L, xp=xp, w1=pk.bufs[f"w1_{i}"], w1_bytes=pk.nbytes(f"w1_{i}"),
+                if hyb:
+                    # the attention half on the strip kernels (a scene of more than 64 tokens does not fit a block):
+                    # q | k | v | cond projection, attention, out-projection (+ bias) -> fcacc
+                    wv = sa._packed[0]
+                    self._strip(M=M, N=W, pro=PRO["plain"], epi=EPI["bias"], b_kc=1, a0=a[f"xin{i}"], W=wv, ldw=D, bias=bv,
+                                C=a[f"qkvc{i}"], ldc=W)
+                    q = a[f"qkvc{i}"]
+                    base, fs = q.data_ptr(), 4
+                    rc = lib.msr3d_spatial_attn_fwd(B, L, H, D // H, 5, _vp(base), _vp(base + D * fs), _vp(base + 2 * D * fs),
+                                                    W, _vp(base + 3 * D * fs), W, _ptr(a["pw"]), _ptr(self.pad),
+                                                    _ptr(a[f"ctx{i}"]), _ptr(a[f"probs{i}"]), hipops.attention_mma(True), st)
+                    _lib.check(rc, "msr3d_spatial_attn_fwd")
+                    self._strip(M=M, N=D, pro=PRO["plain"], epi=EPI["bias"], b_kc=1, a0=a[f"ctx{i}"], W=sa.fc.weight,
+                                ldw=D, bias=sa.fc.bias, C=a[f"fcacc{i}"], ldc=D)
+                    rows(st, M=M, L=Lt, pro=PRO["ln2"], a0=a[f"fcacc{i}"], nslab=0, a1=a[f"xin{i}"],
+                         g1=sa.layer_norm.weight, b1=sa.layer_norm.bias, eps1=sa.layer_norm.eps, p1=p_attn, salt1=s_attn,
+                         g2=layer.norm1.weight, b2=layer.norm1.bias, eps2=layer.norm1.eps, p2=p1, salt2=s_1, seed=seed,
+                         o0=a[f"s1_{i}"], ost1=a[f"st1_{i}"], o2=a[f"s2_{i}"], ost2=a[f"st2_{i}"], o1=a[f"t{i}"], xp=xp)
+                else:
+                    blk(st, kind=BLK["attn_fwd"], B=B, L=L, xp=xp, w1=pk.bufs[f"qkvc{i}"], w1_bytes=pk.nbytes(f"qkvc{i}"),
+                        bias1=bv, w2=pk.bufs[f"fc{i}"], w2_bytes=pk.nbytes(f"fc{i}"), part=part, part_stride=MD,
+                        qkvc=a[f"qkvc{i}"], ldq=W, ploc=a["pw"], pad=self.pad, probs=a[f"probs{i}"], ctx=a[f"ctx{i}"], H=H)
+                    # attention tail's LayerNorm, then norm1 over the same residual -> the feed-forward block's input
+                    rows(st, M=M, L=L, pro=PRO["ln2"], part=part, nslab=H, part_stride=MD, a0_bias=sa.fc.bias,
+                         sum_out=a[f"fcacc{i}"], a1=a[f"xin{i}"], g1=sa.layer_norm.weight, b1=sa.layer_norm.bias,
+                         eps1=sa.layer_norm.eps, p1=p_attn, salt1=s_attn, g2=layer.norm1.weight, b2=layer.norm1.bias,
+                         eps2=layer.norm1.eps, p2=p1, salt2=s_1, seed=seed, o0=a[f"s1_{i}"], ost1=a[f"st1_{i}"],
+                         o2=a[f"s2_{i}"], ost2=a[f"st2_{i}"], o1=a[f"t{i}"], xp=xp)
+                blk(st, kind=BLK["ffn_fwd"], B=Bt, L=Lt, xp=xp, w1=pk.bufs[f"w1_{i}"], w1_bytes=pk.nbytes(f"w1_{i}"),
                     bias1=layer.linear1.bias, w2=pk.bufs[f"w2_{i}"], w2_bytes=pk.nbytes(f"w2_{i}"), part=part,
                     part_stride=MD, pre=a[f"pre{i}"], h=a[f"h{i}"], ff=FF, p_drop=p_ffn, salt=s_ffn, seed=seed)
             last = layers[-1]
-            tail = dict(M=M, L=L, pro=PRO["ln"], part=part, nslab=nff, part_stride=MD, a0_bias=last.linear2.bias,
+            tail = dict(M=M, L=Lt, pro=PRO["ln"], part=part, nslab=nff, part_stride=MD, a0_bias=last.linear2.bias,
                         sum_out=a[f"ffn{nl-1}"], a1=a[f"t{nl-1}"], g1=last.norm2.weight, b1=last.norm2.bias,
                         eps1=last.norm2.eps, p1=self.ps[-1][2], salt1=self.salts[-1][2], seed=seed,
                         o0=a[f"s3_{nl-1}"], ost1=a[f"st3_{nl-1}"], o1=a["tok"])
             if self.llm_blocks:
                 rows(st, xp=xp, **tail)
-                blk(st, kind=BLK["linear"], B=B, L=L, xp=xp, w1=pk.bufs["llm"], w1_bytes=pk.nbytes("llm"),
+                blk(st, kind=BLK["linear"], B=Bt, L=Lt, xp=xp, w1=pk.bufs["llm"], w1_bytes=pk.nbytes("llm"),
                     bias1=m.llm_proj.bias, C=a["scene"], ldc=E, N=E)
             else:
                 rows(st, **tail)
@@ -485,7 +518,12 @@ class PrompterSchedule:
         layers = list(pr.spatial_encoder)
         same_all = pr.cfg.spatial_encoder.obj_loc_encoding == "same_all"
         pk, wg, xp, part, MD = self.packs, self.wgrad, self.xp, a["part"], M * D
-        blk, rows = scene_blocks.launch_block, scene_blocks.launch_rows
+        hyb = self.hybrid
+        Bt, Lt, RT = (self.tiles, 64, M) if hyb else (B, L, 0)
+
+        def blk(st_, **kw):
+            scene_blocks.launch_block(st_, rows_total=RT, **kw)
+        rows = scene_blocks.launch_rows
         nff = FF // 128
         with torch.cuda.device(dev):
             lp = m.llm_proj
@@ -498,7 +536,7 @@ class PrompterSchedule:
                 g = g if g.is_contiguous() else g.contiguous()
                 self._g_keep = g
                 if self.llm_blocks:
-                    blk(st, kind=BLK["linear_ksplit"], B=B, L=L, a0=g, lda0=E, w1=pk.bufs["llm_t"],
+                    blk(st, kind=BLK["linear_ksplit"], B=Bt, L=Lt, a0=g, lda0=E, w1=pk.bufs["llm_t"],
                         w1_bytes=pk.nbytes("llm_t"), part=part, part_stride=MD)
                     src = dict(part=part, nslab=E // 256, part_stride=MD, extra=a["d_tok"] if g_tok is not None else None)
                 else:
@@ -515,26 +553,45 @@ class PrompterSchedule:
                 s_attn, s_1, s_2, s_ffn = self.salts[i]
                 # d_out (sum) -> LN(norm2)-bwd: residual gradient -> res, dropout-bwd -> d_ffn (+ planes)
                 lnp = a["lnpart"]
-                rows(st, M=M, L=L, pro=PRO["lnbwd"], a1=a[f"s3_{i}"], st1=a[f"st3_{i}"], g1=layer.norm2.weight,
+                rows(st, M=M, L=Lt, pro=PRO["lnbwd"], a1=a[f"s3_{i}"], st1=a[f"st3_{i}"], g1=layer.norm2.weight,
                      p1=p2, salt1=s_2, seed=seed, o0=a[f"d_ffn{i}"], o1=a["res"], dg1=lnp[6 * i], db1=lnp[6 * i + 1],
                      grad_partials=1, sum_out=a[f"d_xacc{i+1}"] if i + 1 < nl else None, xp=xp, **src)
                 # d_h = d_ffn W2 -> GELU-bwd -> d_pre; partials of d_pre W1
-                blk(st, kind=BLK["ffn_bwd"], B=B, L=L, xp=xp, w1=pk.bufs[f"w2_t{i}"], w1_bytes=pk.nbytes(f"w2_t{i}"),
+                blk(st, kind=BLK["ffn_bwd"], B=Bt, L=Lt, xp=xp, w1=pk.bufs[f"w2_t{i}"], w1_bytes=pk.nbytes(f"w2_t{i}"),
                     w2=pk.bufs[f"w1_t{i}"], w2_bytes=pk.nbytes(f"w1_t{i}"), part=part, part_stride=MD,
                     pre=a[f"pre{i}"], h=a[f"d_pre{i}"], ff=FF, p_drop=p_ffn, salt=s_ffn, seed=seed)
                 # d_t = residual + sum -> LN(norm1), LN(attention tail) bwd: residual -> res, d_fc (+ planes)
-                rows(st, M=M, L=L, pro=PRO["ln2bwd"], part=part, nslab=nff, part_stride=MD, extra=a["res"],
+                rows(st, M=M, L=Lt, pro=PRO["ln2bwd"], part=part, nslab=nff, part_stride=MD, extra=a["res"],
                      sum_out=a[f"d_t{i}"], a1=a[f"s1_{i}"], a2=a[f"s2_{i}"], st1=a[f"st1_{i}"], st2=a[f"st2_{i}"],
                      g1=sa.layer_norm.weight, g2=layer.norm1.weight, p1=p_attn, salt1=s_attn, p2=p1, salt2=s_1,
-                     seed=seed, o0=a[f"d_fc{i}"], o1=a["res"], dg1=lnp[6 * i + 2], db1=lnp[6 * i + 3],
-                     dg2=lnp[6 * i + 4], db2=lnp[6 * i + 5], grad_partials=1, xp=xp)
-                # d_ctx = d_fc Wfc; attention bwd; partials of d[q|k|v|cond] W
-                blk(st, kind=BLK["attn_bwd"], B=B, L=L, xp=xp, w1=pk.bufs[f"fc_t{i}"], w1_bytes=pk.nbytes(f"fc_t{i}"),
-                    w2=pk.bufs[f"qkvc_t{i}"], w2_bytes=pk.nbytes(f"qkvc_t{i}"), part=part, part_stride=MD,
-                    qkvc=a[f"qkvc{i}"], ldq=W, dqkvc=a[f"d_qkvc{i}"], ploc=a["pw"], pad=self.pad,
-                    probs=a[f"probs{i}"], H=H)
-                src = dict(part=part, nslab=H, part_stride=MD, extra=a["res"])
-            rows(st, M=M, L=L, pro=PRO["plain"], sum_out=a["d_xacc0"], **src)      # d_xin0, whole
+                     seed=seed, o0=a[f"d_fc{i}"], o1=a[f"d_xin{i}"] if hyb else a["res"], dg1=lnp[6 * i + 2],
+                     db1=lnp[6 * i + 3], dg2=lnp[6 * i + 4], db2=lnp[6 * i + 5], grad_partials=1,
+                     xp=None if hyb else xp)
+                if hyb:
+                    # the attention half on the strip kernels: d ctx = d_fc Wfc | attention backward | d xin += d[q|k|v|cond] W
+                    # (the residual gradient is already in d_xin)
+                    wv = sa._packed[0]
+                    self._strip(M=M, N=D, pro=PRO["plain"], epi=EPI["bias"], b_kc=0, a0=a[f"d_fc{i}"], W=sa.fc.weight, ldw=D,
+                                C=a["d_ctx"], ldc=D)
+                    q, gq = a[f"qkvc{i}"], a[f"d_qkvc{i}"]
+                    base, gb, fs = q.data_ptr(), gq.data_ptr(), 4
+                    rc = lib.msr3d_spatial_attn_bwd(B, L, H, D // H, 5, _vp(base), _vp(base + D * fs), _vp(base + 2 * D * fs),
+                                                    W, _vp(base + 3 * D * fs), W, _ptr(a["pw"]), _ptr(self.pad),
+                                                    _ptr(a[f"probs{i}"]), _ptr(a["d_ctx"]), _vp(gb), _vp(gb + D * fs),
+                                                    _vp(gb + 2 * D * fs), W, _vp(gb + 3 * D * fs), W,
+                                                    hipops.attention_mma(True), st)
+                    _lib.check(rc, "msr3d_spatial_attn_bwd")
+                    self._multi([dict(a_kc=1, b_kc=0, M=M, N=D, K=W, A=gq, lda=W, B=wv, ldb=D, C=a[f"d_xin{i}"], ldc=D,
+                                      beta=1.0)])
+                    src = dict(a0=a[f"d_xin{i}"])
+                else:
+                    # d_ctx = d_fc Wfc; attention bwd; partials of d[q|k|v|cond] W
+                    blk(st, kind=BLK["attn_bwd"], B=B, L=L, xp=xp, w1=pk.bufs[f"fc_t{i}"], w1_bytes=pk.nbytes(f"fc_t{i}"),
+                        w2=pk.bufs[f"qkvc_t{i}"], w2_bytes=pk.nbytes(f"qkvc_t{i}"), part=part, part_stride=MD,
+                        qkvc=a[f"qkvc{i}"], ldq=W, dqkvc=a[f"d_qkvc{i}"], ploc=a["pw"], pad=self.pad,
+                        probs=a[f"probs{i}"], H=H)
+                    src = dict(part=part, nslab=H, part_stride=MD, extra=a["res"])
+            rows(st, M=M, L=Lt, pro=PRO["plain"], sum_out=a["d_xacc0"], **src)     # d_xin0, whole
             more = same_all and nl > 1
             if self.anchor:
                 ll = pr.loc_layers[0]

@@ -154,12 +154,14 @@ def test_as_object_schedule_matches_the_modular_path(B, O, E):
     msr3d_anchor_front_fwd / _bwd + the blocks) against the per-module path under autograd: outputs, the returned mask
     and EVERY parameter gradient -- anchor_feat, orientation_encoder, loc_layers and both rows of the type table among
     them.  O = 63: L = 64, a full block; O = 64, 120 (BASELINE's stress configuration): more tokens than a block holds --
-    the strip schedule with the same front and back."""
+    the hybrid schedule with the same front and back."""
     model, dp, batch = _setup(0.0, B=B, O=O, E=E, situation_type="as_object")
     sched = model._schedule
     assert sched.anchor and sched.eligible(dict(batch))
     a = _run(model, dp, batch, "schedule")
-    assert sched._ran_blocks == (O + 1 <= 64) and sched.dims["L"] == O + 1 and a[1].shape[1] == O + 1
+    # O + 1 <= 64: a scene is a block; beyond: the hybrid schedule (row-local halves on the block kernels over 64-row tiles,
+    # attention on the strip kernels)
+    assert sched._ran_blocks and sched.hybrid == (O + 1 > 64) and sched.dims["L"] == O + 1 and a[1].shape[1] == O + 1
     mask_s = model(dict(batch))["obj_masks"].clone()
     b = _run(model, dp, batch, "modular")
     sched.enabled = False
@@ -184,3 +186,28 @@ def test_as_object_schedule_with_dropout_draws_the_same_masks_from_the_same_seed
             m.p = 0.0
     c = _run(model, dp, batch, "schedule")
     assert rel(a[1], c[1]) > 1e-2
+
+
+@pytest.mark.parametrize("situation_type", ["as_object", "as_transform_for_objects"])
+@pytest.mark.parametrize("B,O,E", [(2, 120, 256), (3, 70, 128), (8, 120, 5120)])
+def test_hybrid_and_strip_schedules_match_the_modular_path_beyond_64_tokens(situation_type, B, O, E):
+    """A scene of more than 64 tokens (BASELINE's stress configuration: 120 objects, E = 5120): the HYBRID schedule
+    (feed-forward / projector halves, every rows launch and the weight gradients on the block kernels over 64-row tiles
+    that ignore scene boundaries -- msr3d_scene_block_t.rows_total; the attention on the strip kernels) and round 2's
+    strip schedule, each against the per-module path: outputs and every parameter gradient.  (8, 120, 5120): 968 rows =
+    15 whole tiles + one of 8 rows, a 20-slab projector."""
+    from msr3d_amd import fused_model
+    model, dp, batch = _setup(0.0, B=B, O=O, E=E, situation_type=situation_type)
+    sched = model._schedule
+    ref = _run(model, dp, batch, "modular")
+    tol = 2e-5 if E <= 512 else 1.5e-4
+    try:
+        hy = _run(model, dp, batch, "schedule")
+        assert sched._ran_blocks and sched.hybrid and sched.tiles == (B * sched.dims["L"] + 63) // 64
+        _compare(hy, ref, tol)
+        fused_model.set_mode("strips")
+        st = _run(model, dp, batch, "schedule")
+        assert not sched._ran_blocks
+        _compare(st, ref, tol)
+    finally:
+        fused_model.set_mode("blocks")
