@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <type_traits>
 
 namespace msr3d {
 
@@ -30,6 +31,38 @@ __device__ __forceinline__ float sq3(float a, float b, float c) {
 #else
   return __builtin_fmaf(c, c, __builtin_fmaf(a, a, b * b));
 #endif
+}
+
+// Two points a lane at once: the same chain on both halves of a register pair (v_pk_add_f32 / v_pk_mul_f32 /
+// v_pk_fma_f32: every half is the IEEE operation of the scalar instruction, so sq3x2(a, b, c)[h] == sq3(a[h], b[h], c[h])
+// bit for bit under every contract above).
+#ifndef MSR3D_FPS_SCALAR
+#define MSR3D_FPS_SCALAR 0   // 1: round 5's scan (one point an instruction, fminf), for A/B timing (tools/bench_fps.py)
+#endif
+#ifndef MSR3D_FPS_QW
+#define MSR3D_FPS_QW 3
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 sq3x2(f32x2 a, f32x2 b, f32x2 c) {
+#if MSR3D_SQDIST_CONTRACT == 1
+  const f32x2 aa = a * a, bb = b * b, cc = c * c;
+  const f32x2 s = aa + bb;
+  return s + cc;
+#elif MSR3D_SQDIST_CONTRACT == 2
+  return __builtin_elementwise_fma(c, c, __builtin_elementwise_fma(b, b, a * a));
+#elif MSR3D_SQDIST_CONTRACT == 3
+  return __builtin_elementwise_fma(a, a, __builtin_elementwise_fma(b, b, c * c));
+#else
+  return __builtin_elementwise_fma(c, c, __builtin_elementwise_fma(a, a, b * b));
+#endif
+}
+
+// fminf without the canonicalising v_max the compiler puts in front of it: both operands here are results of
+// arithmetic instructions or constants (never a signalling NaN), for which v_min_f32 IS fminf.
+__device__ __forceinline__ float min_arith(float a, float b) {
+  float r;
+  asm("v_min_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 
 // ---- wave64 integer max, all lanes -> uniform ---------------------------------
@@ -149,14 +182,31 @@ __device__ __forceinline__ void fps_level(const float *src, int ps, int n, int m
   for (int jj = 1; jj < m; ++jj) {
     float best = -1.0f;
     int bk = 0;
+    if (PPT % 2 == 0 && !MSR3D_FPS_SCALAR) {
+      const f32x2 o_x = {ox, ox}, o_y = {oy, oy}, o_z = {oz, oz};
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const float d = sq3(px[i] - ox, py[i] - oy, pz[i] - oz);
-      const float d2 = fminf(d, tmp[i]);
-      tmp[i] = d2;
-      const bool gt = d2 > best;
-      bk = gt ? kk[i] : bk;
-      best = gt ? d2 : best;
+      for (int i = 0; i + 1 < PPT; i += 2) {
+        const f32x2 x2 = {px[i], px[i + 1]}, y2 = {py[i], py[i + 1]}, z2 = {pz[i], pz[i + 1]};
+        const f32x2 d = sq3x2(x2 - o_x, y2 - o_y, z2 - o_z);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float d2 = min_arith(d[h], tmp[i + h]);
+          tmp[i + h] = d2;
+          const bool gt = d2 > best;
+          bk = gt ? kk[i + h] : bk;
+          best = gt ? d2 : best;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        const float d = sq3(px[i] - ox, py[i] - oy, pz[i] - oz);
+        const float d2 = MSR3D_FPS_SCALAR ? fminf(d, tmp[i]) : min_arith(d, tmp[i]);
+        tmp[i] = d2;
+        const bool gt = d2 > best;
+        bk = gt ? kk[i] : bk;
+        best = gt ? d2 : best;
+      }
     }
     const int bits = __float_as_int(best);   // >= +0.0 or -1.0f: int order == float order
     int vmax = wave_max_i32(bits);
@@ -307,6 +357,7 @@ __global__ __launch_bounds__(kWave * (1 + QW)) void fps_query_kernel(
                       new_xyz2 ? new_xyz2 + (size_t)obj * m2 * 3 : nullptr, nullptr);
     return;
   }
+#if MSR3D_FPS_SCALAR
   const unsigned long long lt = (1ull << lane) - 1ull;
   for (int j = wave - 1; j < m; j += QW) {
     while (__hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= j) __builtin_amdgcn_s_sleep(2);
@@ -329,6 +380,60 @@ __global__ __launch_bounds__(kWave * (1 + QW)) void fps_query_kernel(
     const int fill = cnt > 0 ? first : 0;
     for (int l = filled + lane; l < nsample; l += kWave) row[l] = fill;
   }
+#else
+  // A query wave's centre: 256 points a round (four chunks of 64 in index order; the lane's four points are fetched
+  // together and their distances are two packed chains), a ballot per chunk, the hits' slots from the lanes below
+  // (v_mbcnt) into the wave's row in LDS; the row leaves as ONE store of nsample consecutive words with the fill
+  // (its slot 0 is the first hit: ball_query_gpu.cu:35-39).
+  int *lrow = reinterpret_cast<int *>(sx + (size_t)n * ps) + (wave - 1) * nsample;
+  int at[4];                                              // the lane's four points of round 0 (float offsets in sx)
+#pragma unroll
+  for (int c = 0; c < 4; ++c) at[c] = (c * kWave + lane) * ps;
+  for (int j = wave - 1; j < m; j += QW) {
+    while (__hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= j) __builtin_amdgcn_s_sleep(2);
+    const float cx = keep[j * 3 + 0], cy = keep[j * 3 + 1], cz = keep[j * 3 + 2];
+    const f32x2 c_x = {cx, cx}, c_y = {cy, cy}, c_z = {cz, cz};
+    int cnt = 0;
+    auto round = [&](int base, auto whole_t) {
+      constexpr bool WHOLE = decltype(whole_t)::value;      // every lane's four points exist
+      const int off = base * ps;
+      float x[4], y[4], z[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int o = WHOLE ? at[c] + off : min(base + c * kWave + lane, n - 1) * ps;
+        x[c] = sx[o + 0]; y[c] = sx[o + 1]; z[c] = sx[o + 2];
+      }
+      float d[4];
+#pragma unroll
+      for (int c = 0; c < 4; c += 2) {
+        const f32x2 x2 = {x[c], x[c + 1]}, y2 = {y[c], y[c + 1]}, z2 = {z[c], z[c + 1]};
+        const f32x2 dd = sq3x2(c_x - x2, c_y - y2, c_z - z2);
+        d[c] = dd[0]; d[c + 1] = dd[1];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = base + c * kWave + lane;
+        const bool hit = WHOLE ? d[c] < radius2 : (k < n && d[c] < radius2);
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+        const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, cnt));
+        if (hit && slot < nsample) lrow[slot] = k;
+        cnt += __popcll(mask);
+      }
+    };
+    int base = 0;
+    for (; base + 4 * kWave <= n && cnt < nsample; base += 4 * kWave) round(base, std::true_type{});
+    if (base < n && cnt < nsample) round(base, std::false_type{});
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int filled = cnt < nsample ? cnt : nsample;
+    const int fill = cnt > 0 ? lrow[0] : 0;
+    int *row = ball_idx + ((size_t)obj * m + j) * nsample;
+    for (int l = lane; l < nsample; l += kWave) row[l] = l < filled ? lrow[l] : fill;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (the next centre's hits overwrite the row)
+    __builtin_amdgcn_wave_barrier();
+  }
+#endif
 }
 
 // -> hipErrorInvalidValue for a shape the fused kernel does not take (the caller then runs the two launches)
@@ -337,7 +442,7 @@ inline hipError_t launch_fps_query(int b, int n, int ps, int m, const float *pts
                                    hipStream_t st, const unsigned char *valid, unsigned char *constant_out = nullptr) {
   const FpsShape s = fps_shape(n);
   const size_t cloud = (size_t)n * ps * sizeof(float);
-  if (s.slots > 1024 || s.slots <= 256 || cloud > 48 * 1024 || m > 64 || (m2 > 0 && m2 > m) || !ball_idx || nsample <= 0)
+  if (s.slots > 1024 || s.slots <= 256 || cloud > 48 * 1024 || m > 64 || (m2 > 0 && m2 > m) || !ball_idx || nsample <= 0 || nsample > 256)
     return hipErrorInvalidValue;
   int bs2 = 1, log2bs2 = 0;
   if (m2 > 0) {
@@ -345,8 +450,8 @@ inline hipError_t launch_fps_query(int b, int n, int ps, int m, const float *pts
     bs2 = s2.bs;
     log2bs2 = s2.log2bs;
   }
-  constexpr int QW = 3;
-  const size_t lds = sizeof(int) * 8 + sizeof(float) * 64 * 3 + cloud;
+  constexpr int QW = MSR3D_FPS_QW;
+  const size_t lds = sizeof(int) * 8 + sizeof(float) * 64 * 3 + cloud + sizeof(int) * QW * (size_t)nsample;
   fps_query_kernel<16, QW><<<b, kWave * (1 + QW), lds, st>>>(s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, bs2,
                                                             log2bs2, idx2, new_xyz2, valid, radius2, nsample, ball_idx,
                                                             constant_out);
