@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdint>
 #include <type_traits>
 
 namespace msr3d {
@@ -36,12 +37,6 @@ __device__ __forceinline__ float sq3(float a, float b, float c) {
 // Two points a lane at once: the same chain on both halves of a register pair (v_pk_add_f32 / v_pk_mul_f32 /
 // v_pk_fma_f32: every half is the IEEE operation of the scalar instruction, so sq3x2(a, b, c)[h] == sq3(a[h], b[h], c[h])
 // bit for bit under every contract above).
-#ifndef MSR3D_FPS_SCALAR
-#define MSR3D_FPS_SCALAR 0   // 1: round 5's scan (one point an instruction, fminf), for A/B timing (tools/bench_fps.py)
-#endif
-#ifndef MSR3D_FPS_QW
-#define MSR3D_FPS_QW 3
-#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 sq3x2(f32x2 a, f32x2 b, f32x2 c) {
 #if MSR3D_SQDIST_CONTRACT == 1
@@ -66,17 +61,26 @@ __device__ __forceinline__ float min_arith(float a, float b) {
 }
 
 // ---- wave64 integer max, all lanes -> uniform ---------------------------------
-template <int CTRL>
-__device__ __forceinline__ int dpp_max_i32(int v) {
-  const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
-  return o > v ? o : v;
-}
+// One step: max(v, v of the partner lane) as ONE v_max_i32 with the DPP control on its first operand (through
+// __builtin_amdgcn_update_dpp the compiler emits v_mov + s_nop + v_mov_dpp + v_max: twice the dependent latency, and
+// this reduction sits on the sampling chain once per pick).  The s_nop covers "VALU writes a VGPR, DPP reads it".
+#define MSR3D_DPP_MAX(name, ctrl)                                                                     \
+  __device__ __forceinline__ int name(int v) {                                                        \
+    int r;                                                                                            \
+    asm("s_nop 1\n\tv_max_i32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v)); \
+    return r;                                                                                         \
+  }
+MSR3D_DPP_MAX(dpp_max_xor1, "quad_perm:[1,0,3,2]")
+MSR3D_DPP_MAX(dpp_max_xor2, "quad_perm:[2,3,0,1]")
+MSR3D_DPP_MAX(dpp_max_half_mirror, "row_half_mirror")
+MSR3D_DPP_MAX(dpp_max_mirror, "row_mirror")
+#undef MSR3D_DPP_MAX
 
 __device__ __forceinline__ int wave_max_i32(int v) {
-  v = dpp_max_i32<0xB1>(v);   // quad_perm [1,0,3,2]
-  v = dpp_max_i32<0x4E>(v);   // quad_perm [2,3,0,1]
-  v = dpp_max_i32<0x141>(v);  // row_half_mirror
-  v = dpp_max_i32<0x140>(v);  // row_mirror  -> every lane holds its 16-lane row max
+  v = dpp_max_xor1(v);
+  v = dpp_max_xor2(v);
+  v = dpp_max_half_mirror(v);
+  v = dpp_max_mirror(v);      // every lane holds its 16-lane row max
   const int r0 = __builtin_amdgcn_readlane(v, 0);
   const int r1 = __builtin_amdgcn_readlane(v, 16);
   const int r2 = __builtin_amdgcn_readlane(v, 32);
@@ -168,21 +172,23 @@ __device__ __forceinline__ void fps_level(const float *src, int ps, int n, int m
     tmp[i] = live ? 1e10f : -INFINITY;
   }
 
+  // A pick is a dependent chain: scan -> wave maximum -> winner's lane -> its coordinates (LDS).  What is written
+  // about winner j - 1 (out_idx / out_xyz, `keep`, the counter the query waves poll) is ISSUED before pick j's scan
+  // and nothing waits for it there: the counter's release store comes after the scan, when those writes have long
+  // retired (measured: equal to publishing in front of the scan -- the launch is issue-bound, not bound by this wait).
   int old = 0;
   float ox = src[0], oy = src[1], oz = src[2];
-  if (tid == 0) {
-    if (out_idx) out_idx[0] = 0;
-    if (out_xyz) { out_xyz[0] = ox; out_xyz[1] = oy; out_xyz[2] = oz; }
-    if (keep) { keep[0] = ox; keep[1] = oy; keep[2] = oz; }
-    // (fps_query_kernel: the query waves of this workgroup start on a winner as soon as it is in `keep`)
-    if (progress) __hip_atomic_store(progress, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-
   int par = 0;
-  for (int jj = 1; jj < m; ++jj) {
+  for (int jj = 1;; ++jj) {
+    if (tid == 0) {
+      if (out_idx) out_idx[jj - 1] = old;
+      if (out_xyz) { out_xyz[(jj - 1) * 3 + 0] = ox; out_xyz[(jj - 1) * 3 + 1] = oy; out_xyz[(jj - 1) * 3 + 2] = oz; }
+      if (keep) { keep[(jj - 1) * 3 + 0] = ox; keep[(jj - 1) * 3 + 1] = oy; keep[(jj - 1) * 3 + 2] = oz; }
+    }
+    if (jj >= m) break;
     float best = -1.0f;
     int bk = 0;
-    if (PPT % 2 == 0 && !MSR3D_FPS_SCALAR) {
+    if (PPT % 2 == 0) {
       const f32x2 o_x = {ox, ox}, o_y = {oy, oy}, o_z = {oz, oz};
 #pragma unroll
       for (int i = 0; i + 1 < PPT; i += 2) {
@@ -201,7 +207,7 @@ __device__ __forceinline__ void fps_level(const float *src, int ps, int n, int m
 #pragma unroll
       for (int i = 0; i < PPT; ++i) {
         const float d = sq3(px[i] - ox, py[i] - oy, pz[i] - oz);
-        const float d2 = MSR3D_FPS_SCALAR ? fminf(d, tmp[i]) : min_arith(d, tmp[i]);
+        const float d2 = min_arith(d, tmp[i]);
         tmp[i] = d2;
         const bool gt = d2 > best;
         bk = gt ? kk[i] : bk;
@@ -209,6 +215,8 @@ __device__ __forceinline__ void fps_level(const float *src, int ps, int n, int m
       }
     }
     const int bits = __float_as_int(best);   // >= +0.0 or -1.0f: int order == float order
+    // (fps_query_kernel: the query waves of this workgroup start on a winner as soon as it is in `keep`)
+    if (tid == 0 && progress) __hip_atomic_store(progress, jj, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     int vmax = wave_max_i32(bits);
     const unsigned long long hit = __ballot(bits == vmax);
     const int first = __ffsll((long long)hit) - 1;
@@ -232,16 +240,12 @@ __device__ __forceinline__ void fps_level(const float *src, int ps, int n, int m
       par ^= 1;
     }
     old = vmax < 0 ? 0 : kw;   // every candidate skipped: all threads report (-1, 0)
-    ox = src[old * ps + 0];
-    oy = src[old * ps + 1];
-    oz = src[old * ps + 2];
-    if (tid == 0) {
-      if (out_idx) out_idx[jj] = old;
-      if (out_xyz) { out_xyz[jj * 3 + 0] = ox; out_xyz[jj * 3 + 1] = oy; out_xyz[jj * 3 + 2] = oz; }
-      if (keep) { keep[jj * 3 + 0] = ox; keep[jj * 3 + 1] = oy; keep[jj * 3 + 2] = oz; }
-      if (progress) __hip_atomic_store(progress, jj + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    const int o = __mul24(old, ps);   // (indices and strides < 2^23: v_mul_i32_i24 is full rate, v_mul_lo_u32 a quarter)
+    ox = src[o + 0];
+    oy = src[o + 1];
+    oz = src[o + 2];
   }
+  if (tid == 0 && progress) __hip_atomic_store(progress, m, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // Cloud -> LDS by the whole workgroup (ends on a barrier); returns non-zero (to every thread) unless ALL points of the
@@ -250,6 +254,35 @@ __device__ __forceinline__ void fps_level(const float *src, int ps, int n, int m
 // patterns: +0 / -0 or two NaN payloads are different points.
 __device__ __forceinline__ int stage_cloud(const float *__restrict__ P, float *sx, int count, int ps, int tid, int threads) {
   int differs = 0;
+  if ((reinterpret_cast<uintptr_t>(P) & 15u) == 0 && (count & 3) == 0 && ps <= 12 && 12 % ps == 0) {
+    // 16 bytes a lane, up to eight fetches in flight.  The first point repeated is a pattern of period 12 floats
+    // (ps divides 12): three different float4, chosen by the vector's index mod 3.
+    const float4 *P4 = reinterpret_cast<const float4 *>(P);
+    float4 *s4 = reinterpret_cast<float4 *>(sx);          // (16-byte aligned: kFpsLdsFixed and the fused kernel's header)
+    const int c4 = count >> 2;
+    float f[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) f[e] = P[e % ps];        // (e % ps < count: count >= ps)
+    for (int i0 = tid; i0 < c4; i0 += 8 * threads) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * threads < c4) v[u] = P4[i0 + u * threads];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * threads;
+        if (i < c4) {
+          s4[i] = v[u];
+          const int ph = i % 3;
+          const float a0 = ph == 0 ? f[0] : ph == 1 ? f[4] : f[8], a1 = ph == 0 ? f[1] : ph == 1 ? f[5] : f[9];
+          const float a2 = ph == 0 ? f[2] : ph == 1 ? f[6] : f[10], a3 = ph == 0 ? f[3] : ph == 1 ? f[7] : f[11];
+          differs |= (__float_as_int(v[u].x) ^ __float_as_int(a0)) | (__float_as_int(v[u].y) ^ __float_as_int(a1)) |
+                     (__float_as_int(v[u].z) ^ __float_as_int(a2)) | (__float_as_int(v[u].w) ^ __float_as_int(a3));
+        }
+      }
+    }
+    return __syncthreads_or(differs);
+  }
   for (int i = tid; i < count; i += threads) {
     const float v = P[i];
     sx[i] = v;
@@ -324,18 +357,25 @@ inline hipError_t launch_fps(int b, const FpsShape &s, int ps, int m, const floa
 // One cloud per block, FPS by wave 0 as above (one wave, <= 1024 rank slots, cloud staged) -- and BESIDE it the ball query
 // of the level whose centres the FPS picks (ball_query_gpu.cu:9-44, the loop of ball_query_kernel below): QW more waves
 // take the winners as wave 0 publishes them (a counter in LDS, release / acquire at workgroup scope) and each scans the
-// staged cloud for its centre.  FPS is a dependent chain per pick (~1 us: 33 us for 32 picks of 1024 points) that leaves
-// the CU's other wave slots idle; the query (24 us as a launch of its own) fits under it -- mostly: the FPS chain
-// stretches to ~46 us with three query waves beside it (one: 91 us, the queries become the chain; seven: 51; a packed
-// xyz copy for the query waves: 54), against 33 + 24 for the two launches.
-template <int PPT, int QW>
+// staged cloud for its centre.  FPS is a dependent chain per pick (~0.5 us: 31 us for the launch of its own) that leaves
+// the CU's other wave slots idle; the query fits under it.
+// Round 6 (49.8 -> 35.0 us for 960 clouds of 1024 points; stamps of the FPS wave, 2.15 GHz: staging 8.0 -> 5.2 k cycles,
+// level 1 36 k = 31 picks of ~1.15 k, level 2 7.5 k = 15 picks of ~0.5 k -- a pick of ONE point a lane is ~500 cycles of
+// reduce -> readlane -> LDS latency): the launch as a whole was instruction-issue-bound on the query waves, which issued
+// four times the FPS wave's instructions.  (a) the query in rounds of 256 points, packed distances, slots by v_mbcnt into
+// a row in LDS and one row store: -12.6 us; (b) the FPS scan packed, fminf without its canonicalising v_max: in the
+// same step; (c) the cloud staged with 16-byte loads, eight in flight: -1.8; (d) point pairs fetched as pairs
+// (ds_read2st64_b32): -1.0.  Measured and without effect here: the winner's bookkeeping deferred past the scan, one
+// or two query waves (60 / 43 us), five (49).
+template <int PPT, int QW, int PS>      // PS: the point stride when it is 3 or 6 (constant LDS offsets), 0 = `ps_arg`
 __global__ __launch_bounds__(kWave * (1 + QW)) void fps_query_kernel(
-    int n, int ps, int m, int bs, int log2bs, int q, const float *__restrict__ pts,
+    int n, int ps_arg, int m, int bs, int log2bs, int q, const float *__restrict__ pts,
     int *__restrict__ idxs, float *__restrict__ new_xyz,
     int m2, int bs2, int log2bs2, int *__restrict__ idxs2, float *__restrict__ new_xyz2,
     const unsigned char *__restrict__ valid, float radius2, int nsample, int *__restrict__ ball_idx,
     unsigned char *__restrict__ constant_out) {
   if (valid && !valid[blockIdx.x]) return;
+  const int ps = PS ? PS : ps_arg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int *red_bits = reinterpret_cast<int *>(smem);          // [2] (unused with one FPS wave)
   int *red_k = red_bits + 2;                              // [2]
@@ -351,41 +391,17 @@ __global__ __launch_bounds__(kWave * (1 + QW)) void fps_query_kernel(
     __builtin_amdgcn_s_setprio(3);                        // the chain everything waits for
     fps_level<PPT, 1>(sx, ps, n, m, bs, log2bs, q, red_bits, red_k, idxs ? idxs + (size_t)obj * m : nullptr,
                       new_xyz ? new_xyz + (size_t)obj * m * 3 : nullptr, keep, progress);
-    __builtin_amdgcn_s_setprio(0);
     if (m2 > 0)                                           // (one wave: its own LDS writes are in order, no barrier)
       fps_level<1, 1>(keep, 3, m, m2, bs2, log2bs2, 1, red_bits, red_k, idxs2 ? idxs2 + (size_t)obj * m2 : nullptr,
                       new_xyz2 ? new_xyz2 + (size_t)obj * m2 * 3 : nullptr, nullptr);
     return;
   }
-#if MSR3D_FPS_SCALAR
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  for (int j = wave - 1; j < m; j += QW) {
-    while (__hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= j) __builtin_amdgcn_s_sleep(2);
-    const float cx = keep[j * 3 + 0], cy = keep[j * 3 + 1], cz = keep[j * 3 + 2];
-    int *row = ball_idx + ((size_t)obj * m + j) * nsample;
-    int cnt = 0, first = 0;
-    for (int base = 0; base < n && cnt < nsample; base += kWave) {
-      const int k = base + lane;
-      bool hit = false;
-      if (k < n) hit = sq3(cx - sx[k * ps + 0], cy - sx[k * ps + 1], cz - sx[k * ps + 2]) < radius2;
-      const unsigned long long mask = __ballot(hit);
-      if (mask) {
-        if (cnt == 0) first = base + __ffsll((long long)mask) - 1;
-        const int slot = cnt + __popcll(mask & lt);
-        if (hit && slot < nsample) row[slot] = k;
-        cnt += __popcll(mask);
-      }
-    }
-    const int filled = cnt < nsample ? cnt : nsample;
-    const int fill = cnt > 0 ? first : 0;
-    for (int l = filled + lane; l < nsample; l += kWave) row[l] = fill;
-  }
-#else
   // A query wave's centre: 256 points a round (four chunks of 64 in index order; the lane's four points are fetched
   // together and their distances are two packed chains), a ballot per chunk, the hits' slots from the lanes below
   // (v_mbcnt) into the wave's row in LDS; the row leaves as ONE store of nsample consecutive words with the fill
   // (its slot 0 is the first hit: ball_query_gpu.cu:35-39).
   int *lrow = reinterpret_cast<int *>(sx + (size_t)n * ps) + (wave - 1) * nsample;
+  const unsigned lds_sx = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)sx;   // sx as an LDS byte address
   int at[4];                                              // the lane's four points of round 0 (float offsets in sx)
 #pragma unroll
   for (int c = 0; c < 4; ++c) at[c] = (c * kWave + lane) * ps;
@@ -397,18 +413,37 @@ __global__ __launch_bounds__(kWave * (1 + QW)) void fps_query_kernel(
     auto round = [&](int base, auto whole_t) {
       constexpr bool WHOLE = decltype(whole_t)::value;      // every lane's four points exist
       const int off = base * ps;
-      float x[4], y[4], z[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int o = WHOLE ? at[c] + off : min(base + c * kWave + lane, n - 1) * ps;
-        x[c] = sx[o + 0]; y[c] = sx[o + 1]; z[c] = sx[o + 2];
-      }
       float d[4];
+      if constexpr (WHOLE && PS != 0) {
+        // x of points k and k + 64 as ONE register pair (ds_read2st64_b32: two dwords 64 * PS dwords apart), so the
+        // packed chains take the fetched pairs as they arrive (through C the compiler fetches (x, y) of a point
+        // together and spends three v_mov a pair of points on re-pairing them).  The waits name what they release.
+        const unsigned a0 = lds_sx + 4u * (unsigned)(at[0] + off);
+        f32x2 x01, y01, z01, x23, y23, z23;
+        asm volatile("ds_read2st64_b32 %0, %1 offset1:%2" : "=v"(x01) : "v"(a0), "n"(PS));
+        asm volatile("ds_read2st64_b32 %0, %1 offset1:%2" : "=v"(y01) : "v"(a0 + 4u), "n"(PS));
+        asm volatile("ds_read2st64_b32 %0, %1 offset1:%2" : "=v"(z01) : "v"(a0 + 8u), "n"(PS));
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(x23) : "v"(a0), "n"(2 * PS), "n"(3 * PS));
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(y23) : "v"(a0 + 4u), "n"(2 * PS), "n"(3 * PS));
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(z23) : "v"(a0 + 8u), "n"(2 * PS), "n"(3 * PS));
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(x01), "+v"(y01), "+v"(z01));
+        const f32x2 d01 = sq3x2(c_x - x01, c_y - y01, c_z - z01);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x23), "+v"(y23), "+v"(z23));
+        const f32x2 d23 = sq3x2(c_x - x23, c_y - y23, c_z - z23);
+        d[0] = d01[0]; d[1] = d01[1]; d[2] = d23[0]; d[3] = d23[1];
+      } else {
+        float x[4], y[4], z[4];
 #pragma unroll
-      for (int c = 0; c < 4; c += 2) {
-        const f32x2 x2 = {x[c], x[c + 1]}, y2 = {y[c], y[c + 1]}, z2 = {z[c], z[c + 1]};
-        const f32x2 dd = sq3x2(c_x - x2, c_y - y2, c_z - z2);
-        d[c] = dd[0]; d[c + 1] = dd[1];
+        for (int c = 0; c < 4; ++c) {
+          const int o = WHOLE ? at[c] + off : min(base + c * kWave + lane, n - 1) * ps;
+          x[c] = sx[o + 0]; y[c] = sx[o + 1]; z[c] = sx[o + 2];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c += 2) {
+          const f32x2 x2 = {x[c], x[c + 1]}, y2 = {y[c], y[c + 1]}, z2 = {z[c], z[c + 1]};
+          const f32x2 dd = sq3x2(c_x - x2, c_y - y2, c_z - z2);
+          d[c] = dd[0]; d[c + 1] = dd[1];
+        }
       }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -433,7 +468,6 @@ __global__ __launch_bounds__(kWave * (1 + QW)) void fps_query_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (the next centre's hits overwrite the row)
     __builtin_amdgcn_wave_barrier();
   }
-#endif
 }
 
 // -> hipErrorInvalidValue for a shape the fused kernel does not take (the caller then runs the two launches)
@@ -450,11 +484,16 @@ inline hipError_t launch_fps_query(int b, int n, int ps, int m, const float *pts
     bs2 = s2.bs;
     log2bs2 = s2.log2bs;
   }
-  constexpr int QW = MSR3D_FPS_QW;
+  constexpr int QW = 3;
   const size_t lds = sizeof(int) * 8 + sizeof(float) * 64 * 3 + cloud + sizeof(int) * QW * (size_t)nsample;
-  fps_query_kernel<16, QW><<<b, kWave * (1 + QW), lds, st>>>(s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, bs2,
-                                                            log2bs2, idx2, new_xyz2, valid, radius2, nsample, ball_idx,
-                                                            constant_out);
+#define MSR3D_FQ(PS)                                                                                              \
+  fps_query_kernel<16, QW, PS><<<b, kWave * (1 + QW), lds, st>>>(s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, \
+                                                                bs2, log2bs2, idx2, new_xyz2, valid, radius2, nsample,  \
+                                                                ball_idx, constant_out)
+  if (ps == 6) MSR3D_FQ(6);
+  else if (ps == 3) MSR3D_FQ(3);
+  else MSR3D_FQ(0);
+#undef MSR3D_FQ
   return hipGetLastError();
 }
 
