@@ -621,7 +621,7 @@ CENSUS_KERNELS = {
     "msr3d_sa_fps2_query_flags": "fps_query_kernel", "msr3d_sa_plan12": "sa12_plan_kernel",
     "msr3d_sa_level1_rows": "sa1_rows_kernel", "msr3d_sa_level2_rows": "sa2_rows_kernel",
     "msr3d_sa_level_split[1]": "sa1_split_kernel", "msr3d_sa_level_split[2]": "sa2_split_kernel",
-    "msr3d_sa_level_split[3]": "sa3_split4_kernel", "msr3d_rows_linear_split": "rows_linear_kernel",
+    "msr3d_sa_level_split[3]": "sa3_split4_kernel", "msr3d_sa_level3_tiles": "sa3_tiles_kernel", "msr3d_rows_linear_split": "rows_linear_kernel",
     "msr3d_split_pack_begin": "split_pack_kernel", "msr3d_gemm_multi_f32": "panel_multi_kernel",
     "msr3d_pos_embed_fwd": "pos_embed_fwd_kernel", "msr3d_pos_embed_bwd": "pos_embed_bwd_kernel",
     "msr3d_scene_block[attn_fwd]": "scene_attn_fwd2_kernel", "msr3d_scene_block[attn_bwd]": "scene_attn_bwd3_kernel",
@@ -1018,14 +1018,14 @@ def main():
         pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]   # noqa: E731
         # Per-launch durations: the census after the timed region (eager, un-pipelined, HIP events around every launch).
         cus = lambda k: census.get(k, {}).get("us", 0.0)               # noqa: E731
-        rows_keys = {1: ("msr3d_sa_plan12", "msr3d_sa_level1_rows"), 2: ("msr3d_sa_level2_rows",), 3: ("msr3d_sa_level_split[3]",)}
+        rows_keys = {1: ("msr3d_sa_plan12", "msr3d_sa_level1_rows"), 2: ("msr3d_sa_level2_rows",), 3: ("msr3d_sa_level3_tiles",)}
         kern_ms = {}
         for lvl in (1, 2, 3):
             t = sum(cus(k) for k in rows_keys[lvl])
             if lvl < 3 and not cus(rows_keys[lvl][-1]):                  # the all-rows kernels (MSR3D_SA_ROWS=0 / f32 MFMA path)
                 t = cus(f"msr3d_sa_level_split[{lvl}]") or cus(f"msr3d_sa_level[{lvl}]")
             if lvl == 3 and not t:
-                t = cus("msr3d_sa_level[3]")
+                t = cus("msr3d_sa_level_split[3]") or cus("msr3d_sa_level[3]")
             kern_ms[f"msr3d_sa_level{lvl}"] = t / 1e3 if t else None
         # Roofline leg: the three SharedMLP levels of the frozen encoder (98 % of the path's FLOPs), each priced as
         #   frac = FLOPs of the DISTINCT rows the result needs / launch time / peak
@@ -1070,7 +1070,7 @@ def main():
                     level_flops[k] = levels[f"level{lvl}"]["achieved_tflops"] * 1e12 * levels[f"level{lvl}"]["kernel_ms"] * 1e-3
             names = {"level1": "sa1_rows_kernel (+ sa1_plan_kernel; msr3d_sa_level1_rows)" if rows_on else "sa1_split_kernel",
                      "level2": "sa2_rows_kernel (+ sa2_plan_kernel; msr3d_sa_level2_rows)" if rows_on else "sa2_split_kernel",
-                     "level3": "sa3_split4_kernel (msr3d_sa_level_split level 3)"}
+                     "level3": "sa3_tiles_kernel (msr3d_sa_level3_tiles)" if cus("msr3d_sa_level3_tiles") else "sa3_split4_kernel (msr3d_sa_level_split level 3)"}
             if not split:
                 names = {k: f"sa{k[-1]}_kernel (msr3d_sa_level, f32-input MFMA)" for k in names}
             d = levels[dom]

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSR3D_ABI_VERSION 28
+#define MSR3D_ABI_VERSION 29
 #define MSR3D_EINVAL (-22)
 
 typedef void *msr3d_stream_t; /* hipStream_t */
@@ -464,6 +464,20 @@ int msr3d_sa_level_split(int level, int b, int n, int m, float radius, const flo
                          const float *new_xyz, const void *w1, const float *affine1, const void *w2,
                          const float *affine2, const void *w3, const float *affine3, float *out,
                          int *dbg_ball_idx, const unsigned char *valid, msr3d_stream_t stream);
+
+/* Level 3 of msr3d_sa_level_split (group-all: xyz (b, 16, 3), feat (b, 16, 256) -> out (b, 768); the same packed
+ * weights and affines) dealt over the objects' FLAGS instead of four consecutive objects a workgroup (round 6, ABI v29;
+ * pointnet2_modules.py:34-75 with the GroupAll grouper, pytorch_utils.py:11-36).  `constant` (b bytes, may be NULL) is
+ * what msr3d_sa_fps2*_flags wrote: 1 for an object whose cloud is one repeated point (the dataset's padding slot,
+ * dataset_wrapper.py:156-158) -- its sixteen level-3 rows are one row.  Decided on the device, no read-back: with R real
+ * objects (valid, not constant) and C constant ones, if ceil(R / 3) + ceil(C / 48) workgroups fit the launch, a
+ * workgroup takes THREE real objects (48 rows) or 48 constant objects (one row each, no maximum); otherwise four
+ * consecutive objects, as msr3d_sa_level_split.  Every row's arithmetic is that entry's and max over sixteen
+ * identical rows is the row: the same bits (tests/test_sa_rows_gpu.py).  Objects with valid[o] == 0 are not written.
+ * Not in the reduced variant library (MSR3D_EINVAL there). */
+int msr3d_sa_level3_tiles(int b, const float *xyz, const float *feat, const void *w1, const float *affine1, const void *w2,
+                          const float *affine2, const void *w3, const float *affine3, float *out,
+                          const unsigned char *valid, const unsigned char *constant, msr3d_stream_t stream);
 
 /* Level 2 of msr3d_sa_level_split over the DISTINCT rows of each neighbourhood (round 5).  ball_query fills a
  * neighbourhood with fewer than nsample hits by repeating its first hit (ball_query_gpu.cu:35-39), the SharedMLP

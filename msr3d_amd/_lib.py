@@ -159,6 +159,7 @@ _SIGNATURES = {
     "msr3d_sa_level2_rows": [_c_int, _c_int, _c_int, _c_float] + [_ptr] * 14 + [_c_int, _ptr],
     "msr3d_sa_level2_rows_ws_bytes": [_c_int],
     "msr3d_sa_level1_rows": [_c_int, _c_int, _c_int] + [_ptr] * 13 + [_c_int, _ptr],
+    "msr3d_sa_level3_tiles": [_c_int] + [_ptr] * 12,
     "msr3d_sa_plan12": [_c_int, _c_int, _ptr, _ptr, _c_int, _c_int, _c_float] + [_ptr] * 8,
     "msr3d_sa_level1_rows_ws_bytes": [_c_int, _c_int],
     "msr3d_seq_ce_fwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
@@ -252,7 +253,7 @@ def exported_symbols():
     return ["msr3d_abi_version", "msr3d_status_string", "msr3d_sqdist_contract", "msr3d_wgrad_form", "msr3d_attn_fwd_form"] + list(_SIGNATURES)
 
 
-ABI_VERSION = 28        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
+ABI_VERSION = 29        # MSR3D_ABI_VERSION of include/msr3d_hip.h these signatures were written for
 
 
 def load():

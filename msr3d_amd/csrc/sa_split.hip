@@ -1189,6 +1189,7 @@ __device__ __forceinline__ void gemm_split_rolled(const unsigned short *xs, int 
 #undef MSR3D_TERM
   };
   fetch(wa, 0);
+#pragma clang loop unroll(disable)      // (unrolled -- it is, at three row tiles -- every slab's pieces are hoisted: 3.8 KB of scratch a lane)
   for (int s = 0; s < KS; s += 2) {
     fetch(wb, s + 1 < KS ? s + 1 : s);          // (odd slab counts: a harmless re-read)
     __builtin_amdgcn_sched_barrier(0);
@@ -1427,6 +1428,244 @@ __global__ __launch_bounds__(256, 1) void sa3_split4_kernel(int b, const float *
     group_reduce<6, MT, 1>(acc3b, sc, sh, gm);
     group_finish<6, MT>(gm, out + (size_t)obj0 * k3N3, k3N3, (t3 + 6) * 16, groups, lane);
   }
+}
+
+// ---- level 3 over a LIST of objects: three real objects a tile, the constant ones one row each (round 6) -----------
+// A tile's duration is ~11 us + ~19.5 us per 16-row tile of it (two-object tiles 50 us, four-object tiles 89 us): the
+// launch is one round of tiles either way, and the weights' stream past a CU costs the same whatever the tile holds.
+// A third of the bench's object slots are the dataset's padding cloud (dataset_wrapper.py:156-158): one repeated point,
+// sixteen identical rows here.  So when the objects allow it the launch is dealt differently, decided ON THE DEVICE from
+// the flags the sampling launch left (msr3d_sa_fps2*_flags) -- no host read-back:
+//   every workgroup ranks the objects for itself (ballots of the flags -> two bit masks per 64 objects in LDS, ~1 us):
+//   R real objects (valid, not constant), C constant ones; if ceil(R / 3) + ceil(C / 48) <= gridDim.x
+//     workgroup k < ceil(R / 3)       three real objects (ranks 3 k ..), 48 rows, group maximum over each object's 16 rows
+//     the next ceil(C / 48)           48 constant objects each: ONE row an object (its point 0), no maximum
+//   else (dense batches)              four consecutive objects a workgroup, as sa3_split4_kernel.
+// A row's arithmetic is the same in every form (same gather, same split, the same MFMA sequence per row; which rows
+// share a 16-row tile enters no result) and max over sixteen identical rows is that row: the same bits.
+template <int RN, int NG>
+__device__ __forceinline__ void group_finish_ids(float (&m)[RN][NG][4], float *__restrict__ out, int ldo, int n0,
+                                                 const int *s_obj, int lane) {
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) {
+      row16_max4(m[rn][gq]);
+      const int obj = s_obj[gq * 16];
+      if (j == 0 && obj >= 0)
+        *reinterpret_cast<float4 *>(out + (size_t)obj * ldo + n0 + rn * 16 + 4 * g) =
+            make_float4(m[rn][gq][0], m[rn][gq][1], m[rn][gq][2], m[rn][gq][3]);
+    }
+}
+// every row an object of its own: relu(acc * scale + shift) of row 16 mt + j -> out[s_obj[16 mt + j]]
+template <int RN, int MT>
+__device__ __forceinline__ void rows_finish_ids(const f32x4 (&acc)[RN][MT], const float4 (&sc)[RN], const float4 (&sh)[RN],
+                                                float *__restrict__ out, int ldo, int n0, const int *s_obj, int lane) {
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int obj = s_obj[mt * 16 + j];
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn) {
+      const float s4[4] = {sc[rn].x, sc[rn].y, sc[rn].z, sc[rn].w};
+      const float h4[4] = {sh[rn].x, sh[rn].y, sh[rn].z, sh[rn].w};
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fmaxf(0.f, __builtin_fmaf(acc[rn][mt][r], s4[r], h4[r]));
+      if (obj >= 0) *reinterpret_cast<float4 *>(out + (size_t)obj * ldo + n0 + rn * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+// position of the k-th (0-based) set bit of m (k < popcount(m))
+__device__ __forceinline__ int kth_set_bit(unsigned long long m, int k) {
+  int pos = 0;
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) {
+    const unsigned long long low = m & ((1ull << w) - 1ull);
+    const int c = __popcll(low);
+    if (k >= c) { k -= c; m >>= w; pos += w; } else { m = low; }
+  }
+  return pos;
+}
+
+// One tile of 16 MT rows: row r is point (ONE_ROW ? 0 : r & 15) of object s_obj[r] (-1: an empty row, zeros).  The
+// layer chain of sa3_split4_kernel (layer 2 in registers, layer 3 over the two K halves) with MT row tiles.
+template <int MT, bool one_row>
+__device__ __forceinline__ void sa3_tile(const int *s_obj, unsigned short *buf, const float *aff,
+                                                   const float *__restrict__ xyz, const float *__restrict__ feat, const LayerS &l1,
+                                                   const LayerS &l2, const LayerS &l3, float *__restrict__ out) {
+  constexpr int TM = 16 * MT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const float *sc1 = aff, *sh1 = aff + k3N1, *sc2 = aff + 2 * k3N1, *sh2 = sc2 + k3N2, *sc3 = aff + 2 * (k3N1 + k3N2), *sh3 = sc3 + k3N3;
+  const WStream w1 = make_stream<0>(l1.w, k3K0 * k3N1 * 6, 0, lane);
+  const WStream w2 = make_stream<0>(l2.w, k3N1 * k3N2 * 6, 0, lane);
+  const WStream w3 = make_stream<0>(l3.w, k3N2 * k3N3 * 6, 0, lane);
+  {   // operand: TM rows x [feat(256), x, y, z, 0 ...]; all loads first, then split + LDS stores
+    constexpr int IT = TM * 64 / 256;
+    float4 val[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = tid + it * 256, row = e >> 6, obj = s_obj[row];
+      val[it] = obj >= 0 ? *reinterpret_cast<const float4 *>(feat + ((size_t)obj * 16 + (one_row ? 0 : (row & 15))) * 256 + (e & 63) * 4)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (tid < TM) {
+      const int obj = s_obj[tid];
+      if (obj >= 0) {
+        const float *q = xyz + ((size_t)obj * 16 + (one_row ? 0 : (tid & 15))) * 3;
+        px = q[0]; py = q[1]; pz = q[2];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = tid + it * 256;
+      const float v[4] = {val[it].x, val[it].y, val[it].z, val[it].w};
+      uint2 p[3];
+      split4(v, p);
+      unsigned short *d = buf + (e >> 6) * k4LdIn + (e & 63) * 4;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2 *>(d + k * k4PlaneIn) = p[k];
+    }
+    if (tid < TM) {
+      const float v[4] = {px, py, pz, 0.f};
+      uint2 p[3];
+      split4(v, p);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        unsigned short *d = buf + k * k4PlaneIn + tid * k4LdIn + 256;
+        *reinterpret_cast<uint2 *>(d) = p[k];
+#pragma unroll
+        for (int c = 4; c < 32; c += 4) *reinterpret_cast<uint2 *>(d + c) = make_uint2(0u, 0u);
+      }
+    }
+  }
+  __syncthreads();
+  {   // layer 1: 288 -> 256, each wave 4 column tiles
+    f32x4 acc[4][MT];
+    zero_acc(acc);
+    gemm_split_rolled<4, MT, k3N1 / 16>(buf, k4LdIn, k4PlaneIn, w1, wave_u * 4, k3K0 / 32, acc, lane);
+    float4 sc[4], sh[4];
+    load_affine4<4>(sc1, sh1, wave * 64, lane, sc, sh);
+    __syncthreads();                                            // every wave is done reading the operand
+    store_split<4, MT>(acc, sc, sh, buf, k4Ld, k4Plane, wave * 64, lane);
+  }
+  __syncthreads();
+  // layer 2: 256 -> 512, all of it in registers: tiles 4 w .. 4 w + 3 of the first half, 16 + 4 w .. of the second
+  f32x4 acc2b[4][MT];
+  {
+    f32x4 acc2a[4][MT];
+    zero_acc(acc2a);
+    gemm_split_rolled<4, MT, k3N2 / 16>(buf, k4Ld, k4Plane, w2, wave_u * 4, k3N1 / 32, acc2a, lane);
+    zero_acc(acc2b);
+    gemm_split_rolled<4, MT, k3N2 / 16>(buf, k4Ld, k4Plane, w2, 16 + wave_u * 4, k3N1 / 32, acc2b, lane);
+    float4 sc[4], sh[4];
+    load_affine4<4>(sc2, sh2, wave * 64, lane, sc, sh);
+    __syncthreads();                                            // layer 1's image has been read by everyone
+    store_split<4, MT>(acc2a, sc, sh, buf, k4Ld, k4Plane, wave * 64, lane);
+  }
+  __syncthreads();
+  // layer 3 over the first K half (weight slabs 0..7), the wave's 12 column tiles as 6 + 6
+  f32x4 acc3a[6][MT], acc3b[6][MT];
+  zero_acc(acc3a);
+  zero_acc(acc3b);
+  const int t3 = wave_u * 12;
+  gemm_split_rolled<6, MT, k3N3 / 16>(buf, k4Ld, k4Plane, w3, t3, 8, acc3a, lane, 0);
+  gemm_split_rolled<6, MT, k3N3 / 16>(buf, k4Ld, k4Plane, w3, t3 + 6, 8, acc3b, lane, 0);
+  {
+    float4 sc[4], sh[4];
+    load_affine4<4>(sc2, sh2, 256 + wave * 64, lane, sc, sh);
+    __syncthreads();                                            // the first half has been read by everyone
+    store_split<4, MT>(acc2b, sc, sh, buf, k4Ld, k4Plane, wave * 64, lane);
+  }
+  __syncthreads();
+  gemm_split_rolled<6, MT, k3N3 / 16>(buf, k4Ld, k4Plane, w3, t3, 8, acc3a, lane, 8);
+  gemm_split_rolled<6, MT, k3N3 / 16>(buf, k4Ld, k4Plane, w3, t3 + 6, 8, acc3b, lane, 8);
+  float4 sc[6], sh[6];
+  if (one_row) {
+    load_affine4<6>(sc3, sh3, t3 * 16, lane, sc, sh);
+    rows_finish_ids<6, MT>(acc3a, sc, sh, out, k3N3, t3 * 16, s_obj, lane);
+    load_affine4<6>(sc3, sh3, (t3 + 6) * 16, lane, sc, sh);
+    rows_finish_ids<6, MT>(acc3b, sc, sh, out, k3N3, (t3 + 6) * 16, s_obj, lane);
+  } else {
+    float gm[6][MT][4];
+    load_affine4<6>(sc3, sh3, t3 * 16, lane, sc, sh);
+    group_reduce<6, MT, 1>(acc3a, sc, sh, gm);
+    group_finish_ids<6, MT>(gm, out, k3N3, t3 * 16, s_obj, lane);
+    load_affine4<6>(sc3, sh3, (t3 + 6) * 16, lane, sc, sh);
+    group_reduce<6, MT, 1>(acc3b, sc, sh, gm);
+    group_finish_ids<6, MT>(gm, out, k3N3, (t3 + 6) * 16, s_obj, lane);
+  }
+}
+
+constexpr int kSa3MaxGroups = 64;            // objects are ranked on the device up to 64 x 64 of them
+
+__global__ __launch_bounds__(256, 1) void sa3_tiles_kernel(int b, const float *__restrict__ xyz, const float *__restrict__ feat,
+                                                           LayerS l1, LayerS l2, LayerS l3, float *__restrict__ out,
+                                                           const unsigned char *__restrict__ valid,
+                                                           const unsigned char *__restrict__ constant) {
+  __shared__ unsigned long long s_real[kSa3MaxGroups], s_const[kSa3MaxGroups];
+  __shared__ int s_obj[64];
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  unsigned short *buf = smem;
+  float *aff = reinterpret_cast<float *>(smem + 3 * k4PlaneIn);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int groups = (b + 63) >> 6;
+  int tiles_r = 0, tiles_c = 0, R = 0, C = 0;
+  bool listed = false;
+  if (groups <= kSa3MaxGroups) {
+    for (int g = wave; g < groups; g += 4) {
+      const int o = g * 64 + lane;
+      int cls = 0;
+      if (o < b && (!valid || valid[o])) cls = (constant && constant[o]) ? 2 : 1;
+      const unsigned long long mr = __builtin_amdgcn_ballot_w64(cls == 1), mc = __builtin_amdgcn_ballot_w64(cls == 2);
+      if (lane == 0) { s_real[g] = mr; s_const[g] = mc; }
+    }
+    __syncthreads();
+    for (int g = 0; g < groups; ++g) { R += __popcll(s_real[g]); C += __popcll(s_const[g]); }
+    tiles_r = (R + 2) / 3;
+    tiles_c = (C + 47) / 48;
+    listed = tiles_r + tiles_c <= (int)gridDim.x;
+  }
+  const int k = blockIdx.x;
+  bool one_row = false;
+  if (listed) {
+    if (k >= tiles_r + tiles_c) return;
+    one_row = k >= tiles_r;
+    if (tid < 48) {
+      const int want = one_row ? 48 * (k - tiles_r) + tid : 3 * k + tid / 16;
+      const unsigned long long *m = one_row ? s_const : s_real;
+      int id = -1;
+      if (want < (one_row ? C : R)) {
+        int cum = 0;
+        for (int g = 0; g < groups; ++g) {
+          const int c = __popcll(m[g]);
+          if (want < cum + c) { id = g * 64 + kth_set_bit(m[g], want - cum); break; }
+          cum += c;
+        }
+      }
+      s_obj[tid] = id;
+    }
+  } else {
+    const int obj0 = k * 4;
+    if (obj0 >= b) return;
+    if (valid) {                                             // (any valid object: the others ride along)
+      bool any = false;
+      for (int q = 0; q < 4; ++q) any = any || (obj0 + q < b && valid[obj0 + q]);
+      if (!any) return;
+    }
+    if (tid < 64) s_obj[tid] = obj0 + (tid >> 4) < b ? obj0 + (tid >> 4) : -1;
+  }
+  for (int i = tid; i < k3N1; i += 256) { aff[i] = l1.scale[i]; aff[k3N1 + i] = l1.shift[i]; }
+  for (int i = tid; i < k3N2; i += 256) { aff[2 * k3N1 + i] = l2.scale[i]; aff[2 * k3N1 + k3N2 + i] = l2.shift[i]; }
+  for (int i = tid; i < k3N3; i += 256) { aff[2 * (k3N1 + k3N2) + i] = l3.scale[i]; aff[2 * (k3N1 + k3N2) + k3N3 + i] = l3.shift[i]; }
+  __syncthreads();
+  if (!listed) sa3_tile<4, false>(s_obj, buf, aff, xyz, feat, l1, l2, l3, out);
+  else if (one_row) sa3_tile<3, true>(s_obj, buf, aff, xyz, feat, l1, l2, l3, out);
+  else sa3_tile<3, false>(s_obj, buf, aff, xyz, feat, l1, l2, l3, out);
 }
 
 // =====================================================================================================
@@ -2044,6 +2283,28 @@ extern "C" int msr3d_sa_level_split(int level, int b, int n, int m, float radius
   e = hipGetLastError();
   if (wq && e == hipSuccess) wq->suspect = false;
   return (int)e;
+}
+
+// Level 3 over the objects' flags (see sa3_tiles_kernel): valid (b) / constant (b) may be NULL.
+extern "C" int msr3d_sa_level3_tiles(int b, const float *xyz, const float *feat, const void *w1, const float *affine1,
+                                     const void *w2, const float *affine2, const void *w3, const float *affine3, float *out, const unsigned char *valid,
+                                     const unsigned char *constant, msr3d_stream_t stream) {
+#if MSR3D_SPLIT_TERMS == 3
+  return MSR3D_EINVAL;        // (the reduced variant keeps its two-object tile: msr3d_sa_level_split(3, ...))
+#else
+  if (b < 0) return MSR3D_EINVAL;
+  if (b == 0) return 0;
+  if (!xyz || !feat || !w1 || !affine1 || !w2 || !affine2 || !w3 || !affine3 || !out) return MSR3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e;
+  if ((e = allow_lds(sa3_tiles_kernel, kSa3x4Lds)) != hipSuccess) return (int)e;
+  const int cus = usable_cus();
+  const int four = (b + 3) / 4, listed = (b + 2) / 3 + (b + 47) / 48;
+  const int grid = four > (listed < cus ? listed : cus) ? four : (listed < cus ? listed : cus);
+  sa3_tiles_kernel<<<grid, 256, kSa3x4Lds, st>>>(b, xyz, feat, make_layer(w1, affine1, 256), make_layer(w2, affine2, 512),
+                                                make_layer(w3, affine3, 768), out, valid, constant);
+  return (int)hipGetLastError();
+#endif
 }
 
 inline size_t plan_costs_bytes(int b) { return ((size_t)b * sizeof(int) + 15) & ~(size_t)15; }

@@ -206,8 +206,17 @@ _PLAN12 = _os.environ.get("MSR3D_SA_PLAN12", "1") != "0"
 _FC_SPLIT = _os.environ.get("MSR3D_FC_SPLIT", "1") != "0"
 
 
+# level 3 dealt over the objects' flags (msr3d_sa_level3_tiles); MSR3D_SA3_TILES=0: four consecutive objects a workgroup
+_sa3_tiles = [_os.environ.get("MSR3D_SA3_TILES", "1") != "0"]
+
+
 def set_sa_rows(on):
     prev, _sa_rows[0] = _sa_rows[0], bool(on)
+    return prev
+
+
+def set_sa3_tiles(on):
+    prev, _sa3_tiles[0] = _sa3_tiles[0], bool(on)
     return prev
 
 
@@ -333,7 +342,13 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
                                         _p(L[1][2]), _p(feat2), _p(dbg.get("ball2")), _p(vmask), st)
         _lib.check(rc, "msr3d_sa_level(2)")
         with _lib.kernel_timer("msr3d_sa_level3"):
-            if split and m2 == 16:
+            if split and m2 == 16 and slib is lib and constant is not None and _sa3_tiles[0]:
+                # three real objects a workgroup, the constant (padding) objects one row each: chosen on the device
+                # from the flags of the sampling launch (csrc/sa_split.hip::sa3_tiles_kernel); same bits
+                S = plan["split3"]
+                rc = lib.msr3d_sa_level3_tiles(b, _p(new2), _p(feat2), _p(S[0][0]), _p(S[0][1]), _p(S[1][0]), _p(S[1][1]),
+                                               _p(S[2][0]), _p(S[2][1]), _p(pooled), _p(vmask), _p(constant), st)
+            elif split and m2 == 16:
                 S = plan["split3"]
                 rc = slib.msr3d_sa_level_split(3, b, m2, 1, ctypes.c_float(0.0), _p(new2), _p(feat2), _p(None),
                                               _p(S[0][0]), _p(S[0][1]), _p(S[1][0]), _p(S[1][1]), _p(S[2][0]),
@@ -425,7 +440,14 @@ def row_statistics(net, pts):
             pipe_rows = int(((R // 64) * 64 + ((R % 64 + 15) // 16) * 16).sum()) + 16 * int(const.sum())
         out[lvl] = {"nominal_rows": b * m * ns, "distinct_rows": distinct, "pipe_rows": pipe_rows}
     n3 = dbg["feat2"].shape[1]
-    out[3] = {"nominal_rows": b * n3, "distinct_rows": n3 * int(real.sum()) + int(const.sum()), "pipe_rows": b * n3}
+    R, C = int(real.sum()), int(const.sum())
+    pipe3 = b * n3
+    if dbg.get("constant") is not None and _sa3_tiles[0] and _sa_mma[0] == "split":
+        cus = torch.cuda.get_device_properties(pts.device).multi_processor_count
+        grid = max((b + 3) // 4, min(cus, (b + 2) // 3 + (b + 47) // 48))
+        if (R + 2) // 3 + (C + 47) // 48 <= grid:          # msr3d_sa_level3_tiles' device-side choice: 48-row tiles
+            pipe3 = 48 * ((R + 2) // 3 + (C + 47) // 48)
+    out[3] = {"nominal_rows": b * n3, "distinct_rows": n3 * R + C, "pipe_rows": pipe3}
     for lvl in (1, 2, 3):
         for k in ("nominal", "distinct", "pipe"):
             out[lvl][k + "_flop"] = 2.0 * _ROW_MACS[lvl - 1] * out[lvl][k + "_rows"]

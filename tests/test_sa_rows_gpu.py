@@ -245,3 +245,43 @@ def test_planned_call_without_a_plan_is_refused():
     assert rc == -22
     torch.cuda.synchronize()
     del st, S, feat, ctr, out
+
+
+@pytest.mark.parametrize("b,const_frac,valid_frac", [(960, 0.33, None), (960, 0.0, None), (960, 1.0, None), (5, 0.4, None),
+                                                     (61, 0.5, 0.7), (770, 0.03, None), (4100, 0.5, None), (1, 0.0, None),
+                                                     (1, 1.0, None), (49, 1.0, 0.5)])
+def test_level3_tiles_against_four_object_tiles(b, const_frac, valid_frac):
+    """msr3d_sa_level3_tiles (three real objects a workgroup, constant objects one row each, chosen on the device from
+    the flags) against msr3d_sa_level_split(level 3): the same bits -- listed and fall-back forms (960 real objects need
+    more workgroups than the launch has; 4100 objects are more than the device-side ranking takes), flags that LIE
+    are not tested: `constant` is what the sampling launch reports, a constant object's sixteen rows are one row."""
+    from msr3d_amd import _lib
+    from msr3d_amd.pointnet2 import fused
+    net = _net(5)
+    lib = _lib.load()
+    S = fused.get_plan(net)["split3"]
+    g = torch.Generator().manual_seed(b * 7 + int(const_frac * 100))
+    xyz = torch.rand(b, 16, 3, generator=g).cuda()
+    feat = torch.randn(b, 16, 256, generator=g).cuda()
+    const = (torch.rand(b, generator=g) < const_frac) if 0.0 < const_frac < 1.0 else torch.full((b,), const_frac >= 1.0)
+    const = const.cuda()
+    xyz[const] = xyz[const][:, :1]                          # a constant object: sixteen identical rows
+    feat[const] = feat[const][:, :1]
+    valid = None
+    if valid_frac is not None:
+        valid = (torch.rand(b, generator=g) < valid_frac).cuda()
+        valid[0] = True
+    p = lambda t: None if t is None else t.data_ptr()       # noqa: E731
+    vm = None if valid is None else valid.view(torch.uint8)
+    cm = const.view(torch.uint8).contiguous()
+    st = _lib.current_stream_ptr()
+    ref = torch.full((b, 768), float("nan"), device="cuda")
+    _lib.check(lib.msr3d_sa_level_split(3, b, 16, 1, ctypes.c_float(0.0), p(xyz), p(feat), None, p(S[0][0]), p(S[0][1]),
+                                        p(S[1][0]), p(S[1][1]), p(S[2][0]), p(S[2][1]), p(ref), None, p(vm), st), "level_split(3)")
+    for flags in (cm, None):                                # without flags: every valid object is a real one
+        out = torch.full((b, 768), float("nan"), device="cuda")
+        _lib.check(lib.msr3d_sa_level3_tiles(b, p(xyz), p(feat), p(S[0][0]), p(S[0][1]), p(S[1][0]), p(S[1][1]), p(S[2][0]),
+                                             p(S[2][1]), p(out), p(vm), p(flags), st), "level3_tiles")
+        keep = torch.ones(b, dtype=torch.bool, device="cuda") if valid is None else valid
+        assert torch.equal(out[keep], ref[keep])
+        assert not torch.isnan(out[keep]).any()
