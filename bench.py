@@ -618,7 +618,8 @@ def kernel_census(tr, batches, steps, run_window, first):
 
 # entry key -> the HIP kernel it launches at the bench shape (names as rocprofv3 prints them, for the PMC summaries)
 CENSUS_KERNELS = {
-    "msr3d_sa_fps2_query_flags": "fps_query_kernel", "msr3d_sa_plan12": "sa12_plan_kernel",
+    "msr3d_sa_fps2_query_flags": "fps_query_kernel", "msr3d_sa_fps2_query_plan": "fps_query_plan_kernel",
+    "msr3d_sa_plan12": "sa12_plan_kernel",
     "msr3d_sa_level1_rows": "sa1_rows_kernel", "msr3d_sa_level2_rows": "sa2_rows_kernel",
     "msr3d_sa_level_split[1]": "sa1_split_kernel", "msr3d_sa_level_split[2]": "sa2_split_kernel",
     "msr3d_sa_level_split[3]": "sa3_split4_kernel", "msr3d_sa_level3_tiles": "sa3_tiles_kernel", "msr3d_rows_linear_split": "rows_linear_kernel",

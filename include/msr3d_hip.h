@@ -142,6 +142,21 @@ int msr3d_sa_fps2_query_flags(int b, int n, int point_stride, int m1, int m2, co
                               float *new_xyz1, int *idx2, float *new_xyz2, const unsigned char *valid, float radius1,
                               int nsample1, int *ball_idx1, unsigned char *constant_out, msr3d_stream_t stream);
 
+/* msr3d_sa_fps2_query_flags AND msr3d_sa_plan12 (below) as ONE launch (round 6, ABI v29): what the planners of the
+ * distinct-row levels read -- the object's ball rows, its two sets of centres -- is in the sampling launch's LDS when it
+ * ends.  Level 1's task list is written by the last query wave of the workgroup to finish (beside the FPS wave's second
+ * level), level 2's row lists by the FPS wave when its chain ends; tasks are appended with one atomic an object (the
+ * order of the list is not reproducible; no result depends on it).  Arguments: those of msr3d_sa_fps2_query_flags
+ * (constant_out REQUIRED), then task_ws1 (msr3d_sa_level1_rows_ws_bytes), level 2's radius, its output out2 (b, m2, 256:
+ * rows of objects cut over several workgroups are zeroed here), dbg_ball_idx2 (may be NULL) and plan_ws2
+ * (msr3d_sa_level2_rows_ws_bytes).  The caller then passes planned = 1 to msr3d_sa_level1_rows / msr3d_sa_level2_rows
+ * on the same stream.  nsample1 = 32, m1 <= 64, m2 <= 16, n * point_stride a multiple of 4, and the shapes of
+ * msr3d_sa_fps2_query; MSR3D_EINVAL otherwise (make the two calls). */
+int msr3d_sa_fps2_query_plan(int b, int n, int point_stride, int m1, int m2, const float *pts, int *idx1, float *new_xyz1,
+                             int *idx2, float *new_xyz2, const unsigned char *valid, float radius1, int nsample1,
+                             int *ball_idx1, unsigned char *constant_out, void *task_ws1, float radius_l2, float *out2,
+                             int *dbg_ball_idx2, void *plan_ws2, msr3d_stream_t stream);
+
 /* One fused level.  `dims` = {C_in(+3), C1, C2, C3} must be one of the shipped
  * configurations (configs/msr3d.yaml:198-201) else MSR3D_EINVAL:
  *   level 1: dims {6,64,64,128};    pts (b,n,6) [xyz,rgb], feat = NULL, new_xyz (b,m,3),

@@ -160,6 +160,8 @@ _SIGNATURES = {
     "msr3d_sa_level2_rows_ws_bytes": [_c_int],
     "msr3d_sa_level1_rows": [_c_int, _c_int, _c_int] + [_ptr] * 13 + [_c_int, _ptr],
     "msr3d_sa_level3_tiles": [_c_int] + [_ptr] * 12,
+    "msr3d_sa_fps2_query_plan": [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_int,
+                                 _ptr, _ptr, _ptr, _c_float, _ptr, _ptr, _ptr, _ptr],
     "msr3d_sa_plan12": [_c_int, _c_int, _ptr, _ptr, _c_int, _c_int, _c_float] + [_ptr] * 8,
     "msr3d_sa_level1_rows_ws_bytes": [_c_int, _c_int],
     "msr3d_seq_ce_fwd": [_c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],

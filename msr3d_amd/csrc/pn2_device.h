@@ -367,24 +367,49 @@ inline hipError_t launch_fps(int b, const FpsShape &s, int ps, int m, const floa
 // same step; (c) the cloud staged with 16-byte loads, eight in flight: -1.8; (d) point pairs fetched as pairs
 // (ds_read2st64_b32): -1.0.  Measured and without effect here: the winner's bookkeeping deferred past the scan, one
 // or two query waves (60 / 43 us), five (49).
-template <int PPT, int QW, int PS>      // PS: the point stride when it is 3 or 6 (constant LDS offsets), 0 = `ps_arg`
-__global__ __launch_bounds__(kWave * (1 + QW)) void fps_query_kernel(
+// What a caller may hang on the sampling launch (sa_split.hip: the level-1 / level-2 PLANS of the distinct-row kernels):
+//   kOn            all m rows of the object stay in LDS (m * nsample words) instead of one row a query wave
+//   kLdsInts       words of LDS behind the rows that are the plan's own
+//   skipped(obj, lane)                                   wave 0 of an object the valid mask skips
+//   after_queries(obj, lane, m, nsample, rows, is_const)   ONE query wave, once every row of the object is complete
+//                  (rows: LDS; beside the FPS wave's second level)
+//   after_sampling(obj, lane, m, m2, keep, keep2, scratch, is_const)   the FPS wave, after the second level (keep / keep2:
+//                  the two levels' winners in LDS, packed xyz; scratch: kLdsInts words)
+struct FpsNoPlan {
+  static constexpr bool kOn = false;
+  static constexpr int kLdsInts = 0;
+  __device__ void skipped(int, int) const {}
+  __device__ void after_queries(int, int, int, int, const int *, bool) const {}
+  __device__ void after_sampling(int, int, int, int, const float *, const float *, int *, bool) const {}
+};
+
+template <int PPT, int QW, int PS, class Plan>      // PS: the point stride when it is 3 or 6 (constant LDS offsets), 0 = `ps_arg`
+__device__ __forceinline__ void fps_query_body(
     int n, int ps_arg, int m, int bs, int log2bs, int q, const float *__restrict__ pts,
     int *__restrict__ idxs, float *__restrict__ new_xyz,
     int m2, int bs2, int log2bs2, int *__restrict__ idxs2, float *__restrict__ new_xyz2,
     const unsigned char *__restrict__ valid, float radius2, int nsample, int *__restrict__ ball_idx,
-    unsigned char *__restrict__ constant_out) {
-  if (valid && !valid[blockIdx.x]) return;
+    unsigned char *__restrict__ constant_out, char *smem, const Plan &plan) {
+  const int obj = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  if (valid && !valid[obj]) {
+    if (Plan::kOn && wave == 0) plan.skipped(obj, lane);
+    return;
+  }
   const int ps = PS ? PS : ps_arg;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   int *red_bits = reinterpret_cast<int *>(smem);          // [2] (unused with one FPS wave)
   int *red_k = red_bits + 2;                              // [2]
   int *progress = red_k + 2;                              // winners published so far
   float *keep = reinterpret_cast<float *>(progress + 4);  // [64 * 3] winners
   float *sx = keep + 64 * 3;                              // [n * ps]
-  const int obj = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  int *rows = reinterpret_cast<int *>(sx + (size_t)n * ps);            // [QW][nsample], or [m][nsample] with a plan
+  int *extra = rows + (size_t)(Plan::kOn ? m : QW) * nsample;          // plan: done | - | - | - | keep2 [16 * 3] | scratch
+  float *keep2 = reinterpret_cast<float *>(extra + 4);
+  int *scratch = extra + 4 + 48;
   const float *P = pts + (size_t)obj * n * ps;
-  if (tid == 0) *progress = 0;
+  if (tid == 0) {
+    *progress = 0;
+    if (Plan::kOn) extra[0] = 0;
+  }
   const int differs = stage_cloud(P, sx, n * ps, ps, tid, kWave * (1 + QW));
   if (tid == 0 && constant_out) constant_out[obj] = differs ? 0 : 1;
   if (wave == 0) {
@@ -393,19 +418,25 @@ __global__ __launch_bounds__(kWave * (1 + QW)) void fps_query_kernel(
                       new_xyz ? new_xyz + (size_t)obj * m * 3 : nullptr, keep, progress);
     if (m2 > 0)                                           // (one wave: its own LDS writes are in order, no barrier)
       fps_level<1, 1>(keep, 3, m, m2, bs2, log2bs2, 1, red_bits, red_k, idxs2 ? idxs2 + (size_t)obj * m2 : nullptr,
-                      new_xyz2 ? new_xyz2 + (size_t)obj * m2 * 3 : nullptr, nullptr);
+                      new_xyz2 ? new_xyz2 + (size_t)obj * m2 * 3 : nullptr, Plan::kOn ? keep2 : nullptr);
+    if (Plan::kOn) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      plan.after_sampling(obj, lane, m, m2, keep, keep2, scratch, differs == 0);
+    }
     return;
   }
   // A query wave's centre: 256 points a round (four chunks of 64 in index order; the lane's four points are fetched
   // together and their distances are two packed chains), a ballot per chunk, the hits' slots from the lanes below
-  // (v_mbcnt) into the wave's row in LDS; the row leaves as ONE store of nsample consecutive words with the fill
+  // (v_mbcnt) into the centre's row in LDS; the row leaves as ONE store of nsample consecutive words with the fill
   // (its slot 0 is the first hit: ball_query_gpu.cu:35-39).
-  int *lrow = reinterpret_cast<int *>(sx + (size_t)n * ps) + (wave - 1) * nsample;
   const unsigned lds_sx = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)sx;   // sx as an LDS byte address
   int at[4];                                              // the lane's four points of round 0 (float offsets in sx)
 #pragma unroll
   for (int c = 0; c < 4; ++c) at[c] = (c * kWave + lane) * ps;
   for (int j = wave - 1; j < m; j += QW) {
+    int *lrow = rows + (size_t)(Plan::kOn ? j : wave - 1) * nsample;
     while (__hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= j) __builtin_amdgcn_s_sleep(2);
     const float cx = keep[j * 3 + 0], cy = keep[j * 3 + 1], cz = keep[j * 3 + 2];
     const f32x2 c_x = {cx, cx}, c_y = {cy, cy}, c_z = {cz, cz};
@@ -464,10 +495,38 @@ __global__ __launch_bounds__(kWave * (1 + QW)) void fps_query_kernel(
     const int filled = cnt < nsample ? cnt : nsample;
     const int fill = cnt > 0 ? lrow[0] : 0;
     int *row = ball_idx + ((size_t)obj * m + j) * nsample;
-    for (int l = lane; l < nsample; l += kWave) row[l] = l < filled ? lrow[l] : fill;
+    for (int l = lane; l < nsample; l += kWave) {
+      const int v = l < filled ? lrow[l] : fill;
+      row[l] = v;
+      if (Plan::kOn) lrow[l] = v;                          // (the plan reads whole rows)
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (the next centre's hits overwrite the row)
     __builtin_amdgcn_wave_barrier();
   }
+  if (Plan::kOn) {
+    // the last query wave to finish plans over the object's rows (beside the FPS wave's second level)
+    int last = 0;
+    if (lane == 0) last = __hip_atomic_fetch_add(extra, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == QW - 1;
+    if (__builtin_amdgcn_readfirstlane(last)) plan.after_queries(obj, lane, m, nsample, rows, differs == 0);
+  }
+}
+
+template <int PPT, int QW, int PS>
+__global__ __launch_bounds__(kWave * (1 + QW)) void fps_query_kernel(
+    int n, int ps_arg, int m, int bs, int log2bs, int q, const float *__restrict__ pts,
+    int *__restrict__ idxs, float *__restrict__ new_xyz,
+    int m2, int bs2, int log2bs2, int *__restrict__ idxs2, float *__restrict__ new_xyz2,
+    const unsigned char *__restrict__ valid, float radius2, int nsample, int *__restrict__ ball_idx,
+    unsigned char *__restrict__ constant_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  fps_query_body<PPT, QW, PS>(n, ps_arg, m, bs, log2bs, q, pts, idxs, new_xyz, m2, bs2, log2bs2, idxs2, new_xyz2, valid,
+                              radius2, nsample, ball_idx, constant_out, smem, FpsNoPlan{});
+}
+
+// LDS of the sampling launch: header + winners + cloud + rows (+ the plan's words)
+inline size_t fps_query_lds(int n, int ps, int m, int nsample, int qw, bool plan, int plan_ints) {
+  return sizeof(int) * 8 + sizeof(float) * 64 * 3 + (size_t)n * ps * sizeof(float) +
+         sizeof(int) * (size_t)(plan ? m : qw) * nsample + (plan ? sizeof(int) * (4 + 48 + (size_t)plan_ints) : 0);
 }
 
 // -> hipErrorInvalidValue for a shape the fused kernel does not take (the caller then runs the two launches)
@@ -485,7 +544,7 @@ inline hipError_t launch_fps_query(int b, int n, int ps, int m, const float *pts
     log2bs2 = s2.log2bs;
   }
   constexpr int QW = 3;
-  const size_t lds = sizeof(int) * 8 + sizeof(float) * 64 * 3 + cloud + sizeof(int) * QW * (size_t)nsample;
+  const size_t lds = fps_query_lds(n, ps, m, nsample, QW, false, 0);
 #define MSR3D_FQ(PS)                                                                                              \
   fps_query_kernel<16, QW, PS><<<b, kWave * (1 + QW), lds, st>>>(s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, \
                                                                 bs2, log2bs2, idx2, new_xyz2, valid, radius2, nsample,  \

@@ -698,35 +698,15 @@ struct Sa2PlanArgs {
   float *out;
 };
 
-// (`blk`: the workgroup's index among the level-2 planners -- blockIdx.x of sa2_plan_kernel, an offset one in sa12_plan_kernel)
-__device__ __forceinline__ void sa2_plan_body(const int blk, const int b, const int n, const int m, const float radius2,
-                                              const float *__restrict__ xyz, const float *__restrict__ new_xyz,
-                                              int *__restrict__ rows_of, unsigned char *__restrict__ plan,
-                                              int *__restrict__ dbg_idx, const unsigned char *__restrict__ valid,
-                                              const unsigned char *__restrict__ constant, float *__restrict__ out) {
-  __shared__ float s_x[4][64 * 3];
-  __shared__ int s_f[4][kRowsMaxM];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int obj = blk * 4 + wave;
-  if (obj >= b) return;                                  // (no block barrier below: every wave is on its own)
+// The plan of ONE object by ONE wave, its n <= 64 points in LDS (sx: packed xyz) and this lane's centre (lane 4 c + q:
+// centre c) in registers; fcnt: kRowsMaxM words of LDS of the wave's own.
+__device__ __forceinline__ void sa2_plan_wave(const int obj, const int lane, const int n, const int m, const float radius2,
+                                              const float *sx, const float cx, const float cy, const float cz, int *fcnt,
+                                              const bool is_const, int *__restrict__ rows_of, unsigned char *__restrict__ plan,
+                                              int *__restrict__ dbg_idx, float *__restrict__ out) {
   int *hdr = reinterpret_cast<int *>(plan + (size_t)obj * kPlanBytes);
   unsigned short *list = reinterpret_cast<unsigned short *>(plan + (size_t)obj * kPlanBytes + 32);
-  if (valid && !valid[obj]) {
-    if (lane == 0) hdr[0] = rows_of[obj] = 0;
-    return;
-  }
-  float *sx = s_x[wave];
-  int *fcnt = s_f[wave];
   const int c = lane >> 2, q = lane & 3;
-  for (int i = lane; i < n * 3; i += kWave) sx[i] = xyz[(size_t)obj * n * 3 + i];
-  float cx = 0.f, cy = 0.f, cz = 0.f;
-  if (c < m) {
-    const float *ct = new_xyz + ((size_t)obj * m + c) * 3;
-    cx = ct[0]; cy = ct[1]; cz = ct[2];
-  }
-  const bool is_const = constant && constant[obj];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
   const int ppl = (n + 3) >> 2;
   unsigned long long mask = 0ull;
   if (c < m)
@@ -787,6 +767,36 @@ __device__ __forceinline__ void sa2_plan_body(const int blk, const int b, const 
     float4 *o = reinterpret_cast<float4 *>(out + (size_t)obj * m * kN3);
     for (int i = lane; i < m * kN3 / 4; i += kWave) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+}
+
+// (`blk`: the workgroup's index among the level-2 planners -- blockIdx.x of sa2_plan_kernel, an offset one in sa12_plan_kernel)
+__device__ __forceinline__ void sa2_plan_body(const int blk, const int b, const int n, const int m, const float radius2,
+                                              const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                              int *__restrict__ rows_of, unsigned char *__restrict__ plan,
+                                              int *__restrict__ dbg_idx, const unsigned char *__restrict__ valid,
+                                              const unsigned char *__restrict__ constant, float *__restrict__ out) {
+  __shared__ float s_x[4][64 * 3];
+  __shared__ int s_f[4][kRowsMaxM];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int obj = blk * 4 + wave;
+  if (obj >= b) return;                                  // (no block barrier below: every wave is on its own)
+  if (valid && !valid[obj]) {
+    if (lane == 0) *reinterpret_cast<int *>(plan + (size_t)obj * kPlanBytes) = rows_of[obj] = 0;
+    return;
+  }
+  float *sx = s_x[wave];
+  int *fcnt = s_f[wave];
+  const int c = lane >> 2;
+  for (int i = lane; i < n * 3; i += kWave) sx[i] = xyz[(size_t)obj * n * 3 + i];
+  float cx = 0.f, cy = 0.f, cz = 0.f;
+  if (c < m) {
+    const float *ct = new_xyz + ((size_t)obj * m + c) * 3;
+    cx = ct[0]; cy = ct[1]; cz = ct[2];
+  }
+  const bool is_const = constant && constant[obj];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  sa2_plan_wave(obj, lane, n, m, radius2, sx, cx, cy, cz, fcnt, is_const, rows_of, plan, dbg_idx, out);
 }
 
 __global__ __launch_bounds__(256) void sa2_plan_kernel(const Sa2PlanArgs a) {
@@ -1924,31 +1934,12 @@ __global__ __launch_bounds__(64 * k1Waves, 1) void sa1_split_kernel(int n, int m
 // =====================================================================================================
 constexpr int kTaskBig = 0, kTaskPair = 1, kTaskConst = 2;      // header: kind | obj << 2 | cA << 20 | cB << 26
 
-__device__ __forceinline__ void sa1_plan_body(const int blk, const int b, const int m, const int *__restrict__ ball_idx,
-                                              int *__restrict__ total, int *__restrict__ thdr, int *__restrict__ trow,
-                                              const unsigned char *__restrict__ valid,
-                                              const unsigned char *__restrict__ constant) {
-  __shared__ int s_n[4], s_base;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int obj = blk * 4 + wave;
-  const bool live = obj < b && !(valid && !valid[obj]);
-  const bool is_const = live && constant && constant[obj];
-  const int *row = ball_idx + ((size_t)(live ? obj : 0) * m + (lane < m ? lane : 0)) * kNS;
-  bool small = false;
-  if (live && lane < m) small = row[16] == row[0];
+// The tasks of one object, its tasks' first index `base` known: lane = centre (lane < m, the object live); `src`: the
+// centre's 32 indices (global or LDS).
+__device__ __forceinline__ void sa1_emit_tasks(const int obj, const int lane, const bool is_const, const bool small,
+                                               const unsigned long long bigs, const unsigned long long smalls, const int nbig,
+                                               const int base, const int4 *src, int *__restrict__ thdr, int *__restrict__ trow) {
   const unsigned long long lt = (1ull << lane) - 1ull;
-  const unsigned long long in = (live && lane < m && !is_const) ? ~0ull : 0ull;
-  const unsigned long long bigs = __ballot(in && !small), smalls = __ballot(in && small);
-  const int nbig = __popcll(bigs), nsmall = __popcll(smalls);
-  const int ntask = !live ? 0 : (is_const ? 1 : nbig + ((nsmall + 1) >> 1));
-  if (lane == 0) s_n[wave] = ntask;
-  __syncthreads();
-  if (threadIdx.x == 0) s_base = atomicAdd(total, s_n[0] + s_n[1] + s_n[2] + s_n[3]);
-  __syncthreads();
-  if (!live || lane >= m) return;
-  int base = s_base;
-  for (int w = 0; w < wave; ++w) base += s_n[w];
-  const int4 *src = reinterpret_cast<const int4 *>(row);
   if (is_const) {
     if (lane == 0) {
       thdr[base] = kTaskConst | (obj << 2);
@@ -1976,6 +1967,32 @@ __device__ __forceinline__ void sa1_plan_body(const int blk, const int b, const 
   }
 }
 
+__device__ __forceinline__ void sa1_plan_body(const int blk, const int b, const int m, const int *__restrict__ ball_idx,
+                                              int *__restrict__ total, int *__restrict__ thdr, int *__restrict__ trow,
+                                              const unsigned char *__restrict__ valid,
+                                              const unsigned char *__restrict__ constant) {
+  __shared__ int s_n[4], s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int obj = blk * 4 + wave;
+  const bool live = obj < b && !(valid && !valid[obj]);
+  const bool is_const = live && constant && constant[obj];
+  const int *row = ball_idx + ((size_t)(live ? obj : 0) * m + (lane < m ? lane : 0)) * kNS;
+  bool small = false;
+  if (live && lane < m) small = row[16] == row[0];
+  const unsigned long long in = (live && lane < m && !is_const) ? ~0ull : 0ull;
+  const unsigned long long bigs = __ballot(in && !small), smalls = __ballot(in && small);
+  const int nbig = __popcll(bigs), nsmall = __popcll(smalls);
+  const int ntask = !live ? 0 : (is_const ? 1 : nbig + ((nsmall + 1) >> 1));
+  if (lane == 0) s_n[wave] = ntask;
+  __syncthreads();
+  if (threadIdx.x == 0) s_base = atomicAdd(total, s_n[0] + s_n[1] + s_n[2] + s_n[3]);
+  __syncthreads();
+  if (!live || lane >= m) return;
+  int base = s_base;
+  for (int w = 0; w < wave; ++w) base += s_n[w];
+  sa1_emit_tasks(obj, lane, is_const, small, bigs, smalls, nbig, base, reinterpret_cast<const int4 *>(row), thdr, trow);
+}
+
 struct Sa1PlanArgs {
   int b, m;
   const int *ball_idx;
@@ -1996,6 +2013,56 @@ __global__ __launch_bounds__(256) void sa12_plan_kernel(const Sa1PlanArgs a1, co
   else
     sa2_plan_body(blockIdx.x - nb1, a2.b, a2.n, a2.m, a2.radius2, a2.xyz, a2.new_xyz, a2.rows_of, a2.plan, a2.dbg_idx, a2.valid,
                   a2.constant, a2.out);
+}
+
+// Both plans INSIDE the sampling launch (msr3d_sa_fps2_query_plan, round 6): what the planners read is in that
+// launch's LDS when it ends -- the object's 32 ball rows, its two sets of centres -- and its waves have time: level 1's
+// plan is run by the last query wave to finish, beside the FPS wave's second level (a dependent chain of one wave); level
+// 2's by the FPS wave itself when that chain ends.  One atomic an object appends its tasks to the list (its order is not
+// reproducible; no result depends on it).  The 9 us launch of sa12_plan_kernel is gone; the sampling launch is ~1 us longer.
+struct FpsPlan12 {
+  static constexpr bool kOn = true;
+  static constexpr int kLdsInts = kRowsMaxM;             // sa2_plan_wave's fcnt
+  int *total, *thdr, *trow;                              // level 1 (Sa1PlanArgs)
+  float radius2_l2;                                      // level 2 (Sa2PlanArgs)
+  int *rows_of;
+  unsigned char *plan;
+  int *dbg_idx2;
+  float *out2;
+  __device__ void skipped(int obj, int lane) const {
+    if (lane == 0) *reinterpret_cast<int *>(plan + (size_t)obj * kPlanBytes) = rows_of[obj] = 0;
+  }
+  __device__ void after_queries(int obj, int lane, int m, int nsample, const int *rows, bool is_const) const {
+    const int *row = rows + (size_t)(lane < m ? lane : 0) * nsample;
+    const bool small = lane < m && row[16] == row[0];
+    const unsigned long long in = (lane < m && !is_const) ? ~0ull : 0ull;
+    const unsigned long long bigs = __ballot(in && !small), smalls = __ballot(in && small);
+    const int nbig = __popcll(bigs), nsmall = __popcll(smalls);
+    const int ntask = is_const ? 1 : nbig + ((nsmall + 1) >> 1);
+    int base = 0;
+    if (lane == 0) base = atomicAdd(total, ntask);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (lane >= m) return;
+    sa1_emit_tasks(obj, lane, is_const, small, bigs, smalls, nbig, base, reinterpret_cast<const int4 *>(row), thdr, trow);
+  }
+  __device__ void after_sampling(int obj, int lane, int m, int m2, const float *keep, const float *keep2, int *scratch,
+                                 bool is_const) const {
+    const int c = lane >> 2;
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    if (c < m2) { cx = keep2[c * 3 + 0]; cy = keep2[c * 3 + 1]; cz = keep2[c * 3 + 2]; }
+    sa2_plan_wave(obj, lane, m, m2, radius2_l2, keep, cx, cy, cz, scratch, is_const, rows_of, plan, dbg_idx2, out2);
+  }
+};
+
+template <int PS>
+__global__ __launch_bounds__(kWave * 4) void fps_query_plan_kernel(
+    int n, int ps_arg, int m, int bs, int log2bs, int q, const float *__restrict__ pts, int *__restrict__ idxs,
+    float *__restrict__ new_xyz, int m2, int bs2, int log2bs2, int *__restrict__ idxs2, float *__restrict__ new_xyz2,
+    const unsigned char *__restrict__ valid, float radius2, int nsample, int *__restrict__ ball_idx,
+    unsigned char *__restrict__ constant_out, const FpsPlan12 plan) {
+  extern __shared__ __attribute__((aligned(16))) char fq_smem[];
+  fps_query_body<16, 3, PS>(n, ps_arg, m, bs, log2bs, q, pts, idxs, new_xyz, m2, bs2, log2bs2, idxs2, new_xyz2, valid, radius2,
+                            nsample, ball_idx, constant_out, fq_smem, plan);
 }
 
 __global__ __launch_bounds__(64 * k1RowsWaves, 1) void sa1_rows_kernel(int n, int m, int *__restrict__ queue,
@@ -2389,6 +2456,54 @@ extern "C" int msr3d_sa_plan12(int b, int m1, const int *ball_idx1, void *task_w
   }
   const int nb = (b + 3) / 4;
   sa12_plan_kernel<<<2 * nb, 256, 0, st>>>(a1, a2, nb);
+  if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+  wq->suspect = false;
+  wq->planned = true;
+  return 0;
+}
+
+// msr3d_sa_fps2_query_flags AND msr3d_sa_plan12 as one launch (see FpsPlan12): the caller then passes planned = 1 to
+// msr3d_sa_level1_rows / msr3d_sa_level2_rows on the same stream.  MSR3D_EINVAL for a shape the fused sampling kernel or
+// the planners do not take (the caller then makes the two calls).
+extern "C" int msr3d_sa_fps2_query_plan(int b, int n, int point_stride, int m1, int m2, const float *pts, int *idx1,
+                                        float *new_xyz1, int *idx2, float *new_xyz2, const unsigned char *valid,
+                                        float radius1, int nsample1, int *ball_idx1, unsigned char *constant_out,
+                                        void *task_ws1, float radius_l2, float *out2, int *dbg_ball_idx2, void *plan_ws2,
+                                        msr3d_stream_t stream) {
+  if (b < 0 || n <= 0 || m1 <= 0 || m2 <= 0 || point_stride < 3 || !(radius1 > 0.f)) return MSR3D_EINVAL;
+  if (b == 0) return 0;
+  if (!pts || !new_xyz1 || !new_xyz2 || !ball_idx1 || !constant_out) return MSR3D_EINVAL;
+  // the planners' shapes: 32 slots a row, a lane a centre, <= 16 centres of <= 64 points at level 2; rows read 16 bytes at a time
+  if (nsample1 != kNS || m1 > 64 || m2 > kRowsMaxM || m2 > m1 || ((long long)n * point_stride) % 4) return MSR3D_EINVAL;
+  const FpsShape s = fps_shape(n);
+  const size_t cloud = (size_t)n * point_stride * sizeof(float);
+  if (s.slots > 1024 || s.slots <= 256 || cloud > 48 * 1024) return MSR3D_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e;
+  WorkQueue *wq = work_queue(st, 5, &e);
+  if (!wq) return (int)e;
+  Sa1PlanArgs a1;
+  Sa2PlanArgs a2;
+  if (!sa1_plan_args(b, m1, ball_idx1, valid, constant_out, task_ws1, wq, &a1)) return MSR3D_EINVAL;
+  if (!sa2_plan_args(b, m1, m2, radius_l2, new_xyz1, new_xyz2, out2, dbg_ball_idx2, valid, constant_out, plan_ws2, &a2))
+    return MSR3D_EINVAL;
+  if (wq->planned) {                  // a plan nobody consumed: its task count is still in the queue
+    if ((e = hipMemsetAsync(wq->q, 0, 4 * sizeof(int), st)) != hipSuccess) return (int)e;
+    wq->planned = false;
+  }
+  FpsPlan12 plan;
+  plan.total = a1.total; plan.thdr = a1.thdr; plan.trow = a1.trow;
+  plan.radius2_l2 = a2.radius2; plan.rows_of = a2.rows_of; plan.plan = a2.plan; plan.dbg_idx2 = a2.dbg_idx; plan.out2 = a2.out;
+  const FpsShape s2 = fps_shape(m1);
+  const size_t lds = fps_query_lds(n, point_stride, m1, nsample1, 3, true, FpsPlan12::kLdsInts);
+#define MSR3D_FQP(PS)                                                                                                  \
+  fps_query_plan_kernel<PS><<<b, kWave * 4, lds, st>>>(s.n, point_stride, m1, s.bs, s.log2bs, s.q, pts, idx1, new_xyz1, m2, \
+                                                      s2.bs, s2.log2bs, idx2, new_xyz2, valid, radius1 * radius1, nsample1, \
+                                                      ball_idx1, constant_out, plan)
+  if (point_stride == 6) MSR3D_FQP(6);
+  else if (point_stride == 3) MSR3D_FQP(3);
+  else MSR3D_FQP(0);
+#undef MSR3D_FQP
   if ((e = hipGetLastError()) != hipSuccess) return (int)e;
   wq->suspect = false;
   wq->planned = true;

@@ -202,6 +202,8 @@ if _sa_mma[0] not in ("f32", "split", "split2"):
 _sa_rows = [_os.environ.get("MSR3D_SA_ROWS", "1") != "0"]
 # the planning launches of levels 1 and 2 as one (msr3d_sa_plan12); MSR3D_SA_PLAN12=0: each level plans in its own call
 _PLAN12 = _os.environ.get("MSR3D_SA_PLAN12", "1") != "0"
+# ... and both of them inside the sampling launch (msr3d_sa_fps2_query_plan); MSR3D_SA_PLAN_IN_SAMPLING=0: msr3d_sa_plan12
+_PLAN_IN_SAMPLING = _os.environ.get("MSR3D_SA_PLAN_IN_SAMPLING", "1") != "0"
 # the encoder's `fc` on msr3d_rows_linear_split (bf16 x 3 split) instead of the f32-input MFMA panel kernel
 _FC_SPLIT = _os.environ.get("MSR3D_FC_SPLIT", "1") != "0"
 
@@ -278,8 +280,24 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
         # query's 24 us sit under the FPS chain's 33); clouds the fused kernel does not take: the two launches
         r1 = float(sa1.groupers[0].radius)
         queried = _FPS_QUERY and 256 < n <= 1024 and m1 <= 64
+        L = plan["levels"]
+        rows1 = split and _sa_rows[0] and m1 <= 64 and b < (1 << 18)
+        rows2 = split and _sa_rows[0] and m1 <= 64 and m2 <= 16
+        planned = 1 if (rows1 and rows2 and _PLAN12) else 0
+        ws1 = ws2 = None
+        in_launch = False                 # both plans written by the sampling launch itself (msr3d_sa_fps2_query_plan)
         with _lib.kernel_timer("msr3d_sa_fps2"):
-            if queried:
+            if queried and planned and _PLAN_IN_SAMPLING and slib is lib and constant is not None:
+                ws1 = torch.empty((int(lib.msr3d_sa_level1_rows_ws_bytes(b, m1)),), dtype=torch.uint8, device=dev)
+                ws2 = torch.empty((int(lib.msr3d_sa_level2_rows_ws_bytes(b)),), dtype=torch.uint8, device=dev)
+                rc = lib.msr3d_sa_fps2_query_plan(b, n, 6, m1, m2, _p(pts), _p(dbg.get("idx1")), _p(new1), _p(dbg.get("idx2")),
+                                                  _p(new2), _p(vmask), ctypes.c_float(r1), _NSAMPLE, _p(ball1), _p(constant),
+                                                  _p(ws1), ctypes.c_float(sa2.groupers[0].radius), _p(feat2),
+                                                  _p(dbg.get("ball2")), _p(ws2), st)
+                in_launch = rc == 0
+                if rc not in (0, -22):                          # (MSR3D_EINVAL: not its shape -- the separate calls below)
+                    _lib.check(rc, "msr3d_sa_fps2_query_plan")
+            if queried and not in_launch:
                 rc = lib.msr3d_sa_fps2_query_flags(b, n, 6, m1, m2, _p(pts), _p(dbg.get("idx1")), _p(new1),
                                                    _p(dbg.get("idx2")), _p(new2), _p(vmask), ctypes.c_float(r1), _NSAMPLE,
                                                    _p(ball1), _p(constant), st)
@@ -291,18 +309,15 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
         _lib.check(rc, "msr3d_sa_fps2")
         if queried:
             r1 = 0.0                                            # level 1: ball1 already holds the neighbour lists
-        L = plan["levels"]
-        rows1 = split and _sa_rows[0] and m1 <= 64 and b < (1 << 18)
-        rows2 = split and _sa_rows[0] and m1 <= 64 and m2 <= 16
-        planned = 1 if (rows1 and rows2 and _PLAN12) else 0
         with _lib.kernel_timer("msr3d_sa_level1"):
             if rows1:
                 S = plan["split1"]
                 if r1 > 0.0:                                    # (not queried beside the sampling: the query's own launch)
                     _lib.check(lib.msr3d_ball_query(b, n, m1, ctypes.c_float(r1), _NSAMPLE, _p(new1), _p(pts[..., :3].contiguous()),
                                                     _p(ball1), st), "msr3d_ball_query")
-                ws1 = torch.empty((int(slib.msr3d_sa_level1_rows_ws_bytes(b, m1)),), dtype=torch.uint8, device=dev)
-                if planned:
+                if ws1 is None:
+                    ws1 = torch.empty((int(slib.msr3d_sa_level1_rows_ws_bytes(b, m1)),), dtype=torch.uint8, device=dev)
+                if planned and not in_launch:
                     # both levels' planning launches as one (each reads only what the sampling launch wrote); timed with
                     # level 1 -- level 2's timer then holds its products' launch alone
                     ws2 = torch.empty((int(slib.msr3d_sa_level2_rows_ws_bytes(b)),), dtype=torch.uint8, device=dev)

@@ -220,6 +220,40 @@ def test_one_planning_launch_for_both_levels_is_the_two_planning_launches():
     _same(outs[False], outs[True])
 
 
+@pytest.mark.parametrize("scenes,masked", [(16, False), (3, False), (2, True)])
+def test_plans_written_by_the_sampling_launch_are_the_planning_launch(scenes, masked):
+    """msr3d_sa_fps2_query_plan (default: the level-1 task list and the level-2 row lists written inside the sampling
+    launch) against msr3d_sa_fps2_query_flags + msr3d_sa_plan12: every internal and the output, same bits; the path
+    taken is checked through the entries that ran."""
+    from msr3d_amd import _lib
+    from msr3d_amd.pointnet2 import fused
+    from msr3d_amd.synth import synth_batch
+    net = _net(4)
+    batch = synth_batch(78, scenes, device="cuda")
+    pts = batch["obj_fts"].reshape(-1, 1024, 6).contiguous()
+    valid = batch["obj_masks"].reshape(-1) if masked else None
+    outs, ran = {}, {}
+    for inside in (False, True):
+        prev, fused._PLAN_IN_SAMPLING = fused._PLAN_IN_SAMPLING, inside
+        sink = {}
+        _lib.set_timing_sink(sink, census=True)
+        try:
+            with torch.no_grad():
+                outs[inside] = fused.forward(net, pts, return_internals=True, valid=valid)
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_timing_sink(None)
+            fused._PLAN_IN_SAMPLING = prev
+        ran[inside] = set(sink)
+    assert "msr3d_sa_fps2_query_plan" in ran[True] and "msr3d_sa_plan12" not in ran[True]
+    assert "msr3d_sa_plan12" in ran[False] and "msr3d_sa_fps2_query_plan" not in ran[False]
+    _same(outs[False], outs[True], valid=valid)
+    for rep in range(3):                                   # the task list's order differs run to run; the results do not
+        with torch.no_grad():
+            again = fused.forward(net, pts, return_internals=True, valid=valid)
+        _same(outs[True], again, valid=valid)
+
+
 def test_planned_call_without_a_plan_is_refused():
     from msr3d_amd import _lib
     from msr3d_amd.pointnet2 import fused
