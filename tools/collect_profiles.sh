@@ -50,6 +50,8 @@ v env MSR3D_ATTN_BWD=0 python bench.py --no-cpu-baseline
 v env MSR3D_FC_SPLIT=0 python bench.py --no-cpu-baseline
 v env MSR3D_FFN_WAVES=4 python bench.py --no-cpu-baseline
 v env MSR3D_SA_PLAN12=0 python bench.py --no-cpu-baseline
+v env MSR3D_SA_PLAN_IN_SAMPLING=0 python bench.py --no-cpu-baseline
+v env MSR3D_SA3_TILES=0 python bench.py --no-cpu-baseline
 v env MSR3D_FPS_QUERY=0 python bench.py --no-cpu-baseline
 v env MSR3D_BENCH_FORCE_DIST=1 MSR3D_DP_GRAPH_COMM=0 python bench.py --no-cpu-baseline
 v env MSR3D_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline
@@ -84,4 +86,5 @@ timeout 300 python tools/prof_sa_rows.py > "$OUT/${TAG}_sa_rows_stamps.txt" 2>&1
 timeout 200 python tools/bench_wgrad.py > "$OUT/${TAG}_wgrad_forms.txt" 2>&1
 [ -x tools/_prof/last_arriver ] && timeout 60 tools/_prof/last_arriver > "$OUT/${TAG}_last_arriver.txt" 2>&1
 timeout 120 python tools/bench_sa.py > "$OUT/${TAG}_encoder_kernels.txt" 2>&1
+timeout 120 python tools/bench_fps.py > "$OUT/${TAG}_sampling_launch.txt" 2>&1
 ls -la "$OUT"

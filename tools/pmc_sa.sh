@@ -25,7 +25,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         for key in ("sa1_kernel", "sa1_split_kernel", "sa1_rows_kernel", "sa1_plan_kernel", "sa2_kernel", "sa2_split_kernel", "sa2_rows_kernel",
-                    "sa2_plan_kernel", "sa3_kernel", "sa3_split_kernel", "sa3_split4_kernel", "fps_kernel", "fps_query_kernel", "ball_query_kernel"):
+                    "sa2_plan_kernel", "sa3_kernel", "sa3_split_kernel", "sa3_split4_kernel", "sa3_tiles_kernel", "fps_kernel", "fps_query_kernel", "fps_query_plan_kernel",
+                    "ball_query_kernel"):
             if key in r["Kernel_Name"]:
                 agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as fo:
