@@ -212,6 +212,24 @@ _FC_SPLIT = _os.environ.get("MSR3D_FC_SPLIT", "1") != "0"
 _sa3_tiles = [_os.environ.get("MSR3D_SA3_TILES", "1") != "0"]
 
 
+_plan_ws = {}
+
+
+def _plan_workspaces(lib, dev, st, b, m1):
+    """The two planning workspaces of a pass, kept per (device, stream, shape): they are arguments of the pass's FIRST
+    launch now, and two allocator calls in front of it are host time the GPU idles through in the un-pipelined schedule.
+    (Per stream: passes on different streams may overlap; passes on one stream are ordered.)"""
+    key = (str(dev), int(st.value) if hasattr(st, "value") and st.value else 0, b, m1)
+    ws = _plan_ws.get(key)
+    if ws is None:
+        if len(_plan_ws) > 16:
+            _plan_ws.clear()
+        ws = (torch.empty((int(lib.msr3d_sa_level1_rows_ws_bytes(b, m1)),), dtype=torch.uint8, device=dev),
+              torch.empty((int(lib.msr3d_sa_level2_rows_ws_bytes(b)),), dtype=torch.uint8, device=dev))
+        _plan_ws[key] = ws
+    return ws
+
+
 def set_sa_rows(on):
     prev, _sa_rows[0] = _sa_rows[0], bool(on)
     return prev
@@ -288,8 +306,7 @@ def forward(net, pts, return_internals=False, valid=None, out=None):
         in_launch = False                 # both plans written by the sampling launch itself (msr3d_sa_fps2_query_plan)
         with _lib.kernel_timer("msr3d_sa_fps2"):
             if queried and planned and _PLAN_IN_SAMPLING and slib is lib and constant is not None:
-                ws1 = torch.empty((int(lib.msr3d_sa_level1_rows_ws_bytes(b, m1)),), dtype=torch.uint8, device=dev)
-                ws2 = torch.empty((int(lib.msr3d_sa_level2_rows_ws_bytes(b)),), dtype=torch.uint8, device=dev)
+                ws1, ws2 = _plan_workspaces(lib, dev, st, b, m1)
                 rc = lib.msr3d_sa_fps2_query_plan(b, n, 6, m1, m2, _p(pts), _p(dbg.get("idx1")), _p(new1), _p(dbg.get("idx2")),
                                                   _p(new2), _p(vmask), ctypes.c_float(r1), _NSAMPLE, _p(ball1), _p(constant),
                                                   _p(ws1), ctypes.c_float(sa2.groupers[0].radius), _p(feat2),

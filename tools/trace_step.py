@@ -2,7 +2,7 @@
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'fps_kernel' in r['Kernel_Name'] or 'fps_query_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'fps_kernel' in r['Kernel_Name'] or 'fps_query' in r['Kernel_Name']]
 # a training step = a sampling launch followed (before the next one) by the optimiser's kernel; the passes after the
 # timed region (bench.py's untimed row statistics, the CPU-baseline leg's device work) have no optimiser launch
 steps = [(i, j) for i, j in zip(idx[:-1], idx[1:]) if any('adamw' in r['Kernel_Name'] for r in rows[i:j])]
