@@ -298,7 +298,7 @@ template <int PPT, int NW, bool STAGE>
 __global__ __launch_bounds__(kWave * NW) void fps_kernel(
     int n, int ps, int m, int bs, int log2bs, int q, const float *__restrict__ pts,
     int *__restrict__ idxs, float *__restrict__ new_xyz,
-    int m2, int bs2, int log2bs2, int *__restrict__ idxs2, float *__restrict__ new_xyz2,
+    int m2, int bs2, int log2bs2, int q2, int *__restrict__ idxs2, float *__restrict__ new_xyz2,
     const unsigned char *__restrict__ valid, unsigned char *__restrict__ constant_out) {
   if (valid && !valid[blockIdx.x]) return;                // padding object: nothing downstream reads it
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(kWave * NW) void fps_kernel(
   if (m2 > 0) {
     __syncthreads();                 // `keep` written by thread 0
     if (tid < kWave) {
-      fps_level<1, 1>(keep, 3, m, m2, bs2, log2bs2, 1, red_bits, red_k,
+      fps_level<1, 1>(keep, 3, m, m2, bs2, log2bs2, q2, red_bits, red_k,
                       idxs2 ? idxs2 + (size_t)obj * m2 : nullptr,
                       new_xyz2 ? new_xyz2 + (size_t)obj * m2 * 3 : nullptr, nullptr);
     }
@@ -338,18 +338,19 @@ inline hipError_t launch_fps(int b, const FpsShape &s, int ps, int m, const floa
                              hipStream_t st, const unsigned char *valid, unsigned char *constant_out) {
   const size_t cloud = (size_t)s.n * ps * sizeof(float);
   const bool stage = cloud <= 64 * 1024;
-  int bs2 = 1, log2bs2 = 0;
+  int bs2 = 1, log2bs2 = 0, q2 = 1;      // the second level's launch of the reference: m points, its own block size
   if (m2 > 0) {
     const FpsShape s2 = fps_shape(m);
     bs2 = s2.bs;
     log2bs2 = s2.log2bs;
+    q2 = s2.q;
   }
   if (stage) {
     fps_kernel<PPT, NW, true><<<b, kWave * NW, kFpsLdsFixed(NW) + cloud, st>>>(
-        s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, bs2, log2bs2, idx2, new_xyz2, valid, constant_out);
+        s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, bs2, log2bs2, q2, idx2, new_xyz2, valid, constant_out);
   } else {
     fps_kernel<PPT, NW, false><<<b, kWave * NW, kFpsLdsFixed(NW), st>>>(
-        s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, bs2, log2bs2, idx2, new_xyz2, valid, constant_out);
+        s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, bs2, log2bs2, q2, idx2, new_xyz2, valid, constant_out);
   }
   return hipGetLastError();
 }
@@ -387,7 +388,7 @@ template <int PPT, int QW, int PS, class Plan>      // PS: the point stride when
 __device__ __forceinline__ void fps_query_body(
     int n, int ps_arg, int m, int bs, int log2bs, int q, const float *__restrict__ pts,
     int *__restrict__ idxs, float *__restrict__ new_xyz,
-    int m2, int bs2, int log2bs2, int *__restrict__ idxs2, float *__restrict__ new_xyz2,
+    int m2, int bs2, int log2bs2, int q2, int *__restrict__ idxs2, float *__restrict__ new_xyz2,
     const unsigned char *__restrict__ valid, float radius2, int nsample, int *__restrict__ ball_idx,
     unsigned char *__restrict__ constant_out, char *smem, const Plan &plan) {
   const int obj = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
@@ -417,7 +418,7 @@ __device__ __forceinline__ void fps_query_body(
     fps_level<PPT, 1>(sx, ps, n, m, bs, log2bs, q, red_bits, red_k, idxs ? idxs + (size_t)obj * m : nullptr,
                       new_xyz ? new_xyz + (size_t)obj * m * 3 : nullptr, keep, progress);
     if (m2 > 0)                                           // (one wave: its own LDS writes are in order, no barrier)
-      fps_level<1, 1>(keep, 3, m, m2, bs2, log2bs2, 1, red_bits, red_k, idxs2 ? idxs2 + (size_t)obj * m2 : nullptr,
+      fps_level<1, 1>(keep, 3, m, m2, bs2, log2bs2, q2, red_bits, red_k, idxs2 ? idxs2 + (size_t)obj * m2 : nullptr,
                       new_xyz2 ? new_xyz2 + (size_t)obj * m2 * 3 : nullptr, Plan::kOn ? keep2 : nullptr);
     if (Plan::kOn) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -515,11 +516,11 @@ template <int PPT, int QW, int PS>
 __global__ __launch_bounds__(kWave * (1 + QW)) void fps_query_kernel(
     int n, int ps_arg, int m, int bs, int log2bs, int q, const float *__restrict__ pts,
     int *__restrict__ idxs, float *__restrict__ new_xyz,
-    int m2, int bs2, int log2bs2, int *__restrict__ idxs2, float *__restrict__ new_xyz2,
+    int m2, int bs2, int log2bs2, int q2, int *__restrict__ idxs2, float *__restrict__ new_xyz2,
     const unsigned char *__restrict__ valid, float radius2, int nsample, int *__restrict__ ball_idx,
     unsigned char *__restrict__ constant_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  fps_query_body<PPT, QW, PS>(n, ps_arg, m, bs, log2bs, q, pts, idxs, new_xyz, m2, bs2, log2bs2, idxs2, new_xyz2, valid,
+  fps_query_body<PPT, QW, PS>(n, ps_arg, m, bs, log2bs, q, pts, idxs, new_xyz, m2, bs2, log2bs2, q2, idxs2, new_xyz2, valid,
                               radius2, nsample, ball_idx, constant_out, smem, FpsNoPlan{});
 }
 
@@ -537,17 +538,18 @@ inline hipError_t launch_fps_query(int b, int n, int ps, int m, const float *pts
   const size_t cloud = (size_t)n * ps * sizeof(float);
   if (s.slots > 1024 || s.slots <= 256 || cloud > 48 * 1024 || m > 64 || (m2 > 0 && m2 > m) || !ball_idx || nsample <= 0 || nsample > 256)
     return hipErrorInvalidValue;
-  int bs2 = 1, log2bs2 = 0;
+  int bs2 = 1, log2bs2 = 0, q2 = 1;      // the second level's launch of the reference: m points, its own block size
   if (m2 > 0) {
     const FpsShape s2 = fps_shape(m);
     bs2 = s2.bs;
     log2bs2 = s2.log2bs;
+    q2 = s2.q;
   }
   constexpr int QW = 3;
   const size_t lds = fps_query_lds(n, ps, m, nsample, QW, false, 0);
 #define MSR3D_FQ(PS)                                                                                              \
   fps_query_kernel<16, QW, PS><<<b, kWave * (1 + QW), lds, st>>>(s.n, ps, m, s.bs, s.log2bs, s.q, pts, idx, new_xyz, m2, \
-                                                                bs2, log2bs2, idx2, new_xyz2, valid, radius2, nsample,  \
+                                                                bs2, log2bs2, q2, idx2, new_xyz2, valid, radius2, nsample, \
                                                                 ball_idx, constant_out)
   if (ps == 6) MSR3D_FQ(6);
   else if (ps == 3) MSR3D_FQ(3);

@@ -2057,11 +2057,11 @@ struct FpsPlan12 {
 template <int PS>
 __global__ __launch_bounds__(kWave * 4) void fps_query_plan_kernel(
     int n, int ps_arg, int m, int bs, int log2bs, int q, const float *__restrict__ pts, int *__restrict__ idxs,
-    float *__restrict__ new_xyz, int m2, int bs2, int log2bs2, int *__restrict__ idxs2, float *__restrict__ new_xyz2,
+    float *__restrict__ new_xyz, int m2, int bs2, int log2bs2, int q2, int *__restrict__ idxs2, float *__restrict__ new_xyz2,
     const unsigned char *__restrict__ valid, float radius2, int nsample, int *__restrict__ ball_idx,
     unsigned char *__restrict__ constant_out, const FpsPlan12 plan) {
   extern __shared__ __attribute__((aligned(16))) char fq_smem[];
-  fps_query_body<16, 3, PS>(n, ps_arg, m, bs, log2bs, q, pts, idxs, new_xyz, m2, bs2, log2bs2, idxs2, new_xyz2, valid, radius2,
+  fps_query_body<16, 3, PS>(n, ps_arg, m, bs, log2bs, q, pts, idxs, new_xyz, m2, bs2, log2bs2, q2, idxs2, new_xyz2, valid, radius2,
                             nsample, ball_idx, constant_out, fq_smem, plan);
 }
 
@@ -2498,8 +2498,8 @@ extern "C" int msr3d_sa_fps2_query_plan(int b, int n, int point_stride, int m1, 
   const size_t lds = fps_query_lds(n, point_stride, m1, nsample1, 3, true, FpsPlan12::kLdsInts);
 #define MSR3D_FQP(PS)                                                                                                  \
   fps_query_plan_kernel<PS><<<b, kWave * 4, lds, st>>>(s.n, point_stride, m1, s.bs, s.log2bs, s.q, pts, idx1, new_xyz1, m2, \
-                                                      s2.bs, s2.log2bs, idx2, new_xyz2, valid, radius1 * radius1, nsample1, \
-                                                      ball_idx1, constant_out, plan)
+                                                      s2.bs, s2.log2bs, s2.q, idx2, new_xyz2, valid, radius1 * radius1,  \
+                                                      nsample1, ball_idx1, constant_out, plan)
   if (point_stride == 6) MSR3D_FQP(6);
   else if (point_stride == 3) MSR3D_FQP(3);
   else MSR3D_FQP(0);

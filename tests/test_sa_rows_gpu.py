@@ -58,6 +58,16 @@ def test_bench_batch_is_bit_identical():
     assert torch.equal(new[1]["constant"].bool(), ~batch["obj_masks"].reshape(-1))
 
 
+@pytest.mark.parametrize("points", [300, 512, 1000])
+def test_other_cloud_sizes_are_bit_identical(points):
+    """Clouds that are not a multiple of the ball query's 256-point round (its clamped last round) and the plans written
+    inside the sampling launch for them."""
+    from msr3d_amd.synth import synth_batch
+    net = _net(9)
+    pts = synth_batch(points, 1, O=24, P=points, n_valid=19, device="cuda")["obj_fts"][0].contiguous()
+    _same(*_both(net, pts))
+
+
 def test_constant_flag_is_bitwise():
     """One repeated point -> 1; a single differing bit anywhere (last point's last channel; -0.0 against +0.0) -> 0."""
     from msr3d_amd.pointnet2 import fused
