@@ -1162,6 +1162,13 @@ def main():
             "roofline": roof,
             "kernels_ms": kern_ms,
         }
+        from msr3d_amd import hipops as _hipops
+        if _hipops._attn_mma[0] != "f32":     # a LABELLED reduced-precision object attention (never the headline)
+            line["dtype"] = (f"VARIANT (MSR3D_ATTN_MMA={_hipops._attn_mma[0]}): object-attention QK^T / PV "
+                             + {"bf16": "and the backward's products on one bf16 MFMA product",
+                                "fp8_bf16": "on OCP e4m3 MFMA (v_mfma_f32_16x16x32_fp8_fp8), the backward's products on bf16",
+                                "fp8": "on OCP e4m3 MFMA"}.get(_hipops._attn_mma[0], "") + "; otherwise " + line["dtype"])
+            line["config"]["attention_mma"] = _hipops._attn_mma[0]
         if census:
             line["census_us"] = {k: [round(v["us"], 2), v["per_step"]] for k, v in sorted(census.items())}
         if comm is not None:

@@ -160,7 +160,7 @@ class _SpatialLayerFn(torch.autograd.Function):
             rc = lib.msr3d_spatial_attn_fwd(
                 B, L, H, D // H, pl.shape[-1], vp(base), vp(base + D * fs), vp(base + 2 * D * fs), W,
                 vp(base + 3 * D * fs), W, _p(pl), _p(pad), _p(attn), _p(probs),
-                hipops.attention_mma(True), _lib.current_stream_ptr(dev))
+                hipops.attention_mma(False, training=True), _lib.current_stream_ptr(dev))
         _lib.check(rc, "msr3d_spatial_attn_fwd")
         _gemm(True, True, M, D, D, attn, D, sa.fc.weight, D, fc_out, D, bias=sa.fc.bias, beta=1.0)
         if D in (256, 512):     # transformers.py:250-251 then :324-325, one launch

@@ -281,7 +281,8 @@ class PrompterSchedule:
     def use_blocks(self):
         # (the blocks' attention core multiplies on the bf16x3 split = fp32 accuracy; a reduced-precision attention
         # mode, hipops.set_attention_mma("bf16"), is honoured by the strip schedule's attention kernels)
-        return _MODE[0] == "blocks" and self.packs is not None and hipops._attn_mma[0] == "f32"
+        # (... and by the HYBRID schedule, whose attention half IS those kernels: scenes of more than 64 tokens)
+        return _MODE[0] == "blocks" and self.packs is not None and (hipops._attn_mma[0] == "f32" or self.hybrid)
 
     def _pointer_key(self):
         """Addresses the block tables captured: every parameter and its gradient view."""
@@ -470,7 +471,7 @@ class PrompterSchedule:
                     base, fs = q.data_ptr(), 4
                     rc = lib.msr3d_spatial_attn_fwd(B, L, H, D // H, 5, _vp(base), _vp(base + D * fs), _vp(base + 2 * D * fs),
                                                     W, _vp(base + 3 * D * fs), W, _ptr(a["pw"]), _ptr(self.pad),
-                                                    _ptr(a[f"ctx{i}"]), _ptr(a[f"probs{i}"]), hipops.attention_mma(True), st)
+                                                    _ptr(a[f"ctx{i}"]), _ptr(a[f"probs{i}"]), hipops.attention_mma(False, training=True), st)
                     _lib.check(rc, "msr3d_spatial_attn_fwd")
                     self._strip(M=M, N=D, pro=PRO["plain"], epi=EPI["bias"], b_kc=1, a0=a[f"ctx{i}"], W=sa.fc.weight,
                                 ldw=D, bias=sa.fc.bias, C=a[f"fcacc{i}"], ldc=D)
@@ -793,7 +794,7 @@ class PrompterSchedule:
                 base, fs = q.data_ptr(), 4
                 rc = lib.msr3d_spatial_attn_fwd(B, L, H, D // H, 5, _vp(base), _vp(base + D * fs), _vp(base + 2 * D * fs),
                                                 W, _vp(base + 3 * D * fs), W, _ptr(a["pw"]), _ptr(self.pad),
-                                                _ptr(a[f"ctx{i}"]), _ptr(a[f"probs{i}"]), hipops.attention_mma(True), st)
+                                                _ptr(a[f"ctx{i}"]), _ptr(a[f"probs{i}"]), hipops.attention_mma(False, training=True), st)
                 _lib.check(rc, "msr3d_spatial_attn_fwd")
                 self._strip(M=M, N=D, pro=PRO["plain"], epi=EPI["bias"], b_kc=1, a0=a[f"ctx{i}"], W=sa.fc.weight,
                             ldw=D, bias=sa.fc.bias, C=a[f"fc{i}"], ldc=D)

@@ -891,16 +891,18 @@ def sa_level_train(mlp, xyz, new_xyz, feats, idx):
 # fused spatial attention core ('cond' fusion)
 # ---------------------------------------------------------------------------------------
 # Operand precision of the attention kernels' matrix products (include/msr3d_hip.h, MSR3D_MMA_*).
-# "f32" is the reference's arithmetic and the default; "bf16" (forward + backward) and "fp8"
-# (OCP e4m3, forward only) are opt-in: MSR3D_ATTN_MMA=bf16 or set_attention_mma("bf16").
-ATTN_MMA = {"f32": 0, "bf16": 1, "fp8": 2}
+# "f32" is the reference's arithmetic and the default; opt-in, labelled: "bf16" (forward + backward), "fp8" (OCP e4m3,
+# forward only: inference) and "fp8_bf16" (round 6: the TRAINING form of BASELINE.json configs[4]'s "fp8 MFMA
+# object-attention" -- QK^T / PV of the forward on v_mfma_f32_16x16x32_fp8_fp8, the backward's four products on bf16
+# operands; softmax, the spatial term and every accumulation stay fp32).  MSR3D_ATTN_MMA=... or set_attention_mma(...).
+ATTN_MMA = {"f32": 0, "bf16": 1, "fp8": 2, "fp8_bf16": 2}
 _attn_mma = [_os.environ.get("MSR3D_ATTN_MMA", "f32")]
 if _attn_mma[0] not in ATTN_MMA:
     raise ValueError("MSR3D_ATTN_MMA must be one of %s" % sorted(ATTN_MMA))
 
 
 def set_attention_mma(name):
-    """Select the operand precision of QK^T / PV (and the backward products): 'f32' | 'bf16' | 'fp8'.
+    """Select the operand precision of QK^T / PV (and the backward products): 'f32' | 'bf16' | 'fp8' | 'fp8_bf16'.
     Returns the previous setting."""
     if name not in ATTN_MMA:
         raise ValueError("attention mma must be one of %s" % sorted(ATTN_MMA))
@@ -908,11 +910,15 @@ def set_attention_mma(name):
     return prev
 
 
-def attention_mma(backward=False):
-    """The MSR3D_MMA_* code to pass to the kernels."""
-    if backward and _attn_mma[0] == "fp8":
-        raise RuntimeError("fp8 attention is forward-only (inference); train with 'f32' or 'bf16'")
-    return ATTN_MMA[_attn_mma[0]]
+def attention_mma(backward=False, training=False):
+    """The MSR3D_MMA_* code to pass to the kernels.  training: a forward whose backward will follow (the fused
+    schedules): 'fp8' has none."""
+    mode = _attn_mma[0]
+    if mode == "fp8_bf16":
+        return ATTN_MMA["bf16"] if backward else ATTN_MMA["fp8"]
+    if (backward or training) and mode == "fp8":
+        raise RuntimeError("fp8 attention is forward-only (inference); train with 'f32', 'bf16' or 'fp8_bf16'")
+    return ATTN_MMA[mode]
 
 
 class _SpatialAttnCond(torch.autograd.Function):

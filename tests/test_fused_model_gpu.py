@@ -211,3 +211,38 @@ def test_hybrid_and_strip_schedules_match_the_modular_path_beyond_64_tokens(situ
         _compare(st, ref, tol)
     finally:
         fused_model.set_mode("blocks")
+
+
+@pytest.mark.parametrize("mode,tol_out,tol_grad", [("bf16", 2e-2, 6e-2), ("fp8_bf16", 5e-2, 1.5e-1)])
+def test_labelled_reduced_precision_attention_on_the_hybrid_schedule(mode, tol_out, tol_grad):
+    """BASELINE.json configs[4] names "fp8 MFMA object-attention" for the stress shape (120 objects + the agent: L = 121).
+    `hipops.set_attention_mma('fp8_bf16')` is its TRAINING form -- QK^T / PV of the forward on OCP e4m3 MFMA, the
+    backward's four products on bf16 operands, softmax / spatial term / accumulation fp32 -- and 'bf16' north_star's
+    wording; both are LABELLED variants (never the default), honoured by the hybrid schedule's attention half (the strip
+    kernels).  Stated tolerances against the fp32-accurate path: outputs 2e-2 (BASELINE.md's figure) / 5e-2, parameter
+    gradients 6e-2 / 1.5e-1 rel-L2; and they must differ from it (the variant really ran)."""
+    from msr3d_amd import hipops
+    model, dp, batch = _setup(0.0, B=2, O=120, E=256, situation_type="as_object")
+    sched = model._schedule
+    ref = _run(model, dp, batch, "schedule")
+    assert sched._ran_blocks and sched.hybrid
+    prev = hipops.set_attention_mma(mode)
+    try:
+        got = _run(model, dp, batch, "schedule")
+        assert sched._ran_blocks and sched.hybrid
+    finally:
+        hipops.set_attention_mma(prev)
+    assert 1e-6 < rel(got[0], ref[0]) < tol_out and rel(got[1], ref[1]) < tol_out
+    worst = 0.0
+    for k, g in ref[2].items():
+        if k.endswith("w_ks.bias") or g.abs().max() == 0:
+            continue
+        worst = max(worst, rel(got[2][k], g))
+    assert worst < tol_grad, worst
+    # the inference-only form still refuses a schedule that will run backward
+    prev = hipops.set_attention_mma("fp8")
+    try:
+        with pytest.raises(RuntimeError, match="forward-only"):
+            _run(model, dp, batch, "schedule")
+    finally:
+        hipops.set_attention_mma(prev)

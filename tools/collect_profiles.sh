@@ -33,6 +33,8 @@ v env MSR3D_TRAIN_MMA=bf16 python bench.py --no-cpu-baseline
 v python bench.py --no-cpu-baseline --from-store
 v python bench.py --no-cpu-baseline --host-inputs
 v python bench.py --no-cpu-baseline --objects 120 --points 2048 --llm-hidden 5120 --batch 8 --situation-type as_object
+v env MSR3D_ATTN_MMA=bf16 python bench.py --no-cpu-baseline --objects 120 --points 2048 --llm-hidden 5120 --batch 8 --situation-type as_object
+v env MSR3D_ATTN_MMA=fp8_bf16 python bench.py --no-cpu-baseline --objects 120 --points 2048 --llm-hidden 5120 --batch 8 --situation-type as_object
 v env MSR3D_TRAINABLE=strips python bench.py --no-cpu-baseline
 v env MSR3D_SA_MMA=f32 python bench.py --no-cpu-baseline
 v env MSR3D_SA_ROWS=0 python bench.py --no-cpu-baseline
