@@ -329,3 +329,55 @@ def test_level3_tiles_against_four_object_tiles(b, const_frac, valid_frac):
         keep = torch.ones(b, dtype=torch.bool, device="cuda") if valid is None else valid
         assert torch.equal(out[keep], ref[keep])
         assert not torch.isnan(out[keep]).any()
+
+
+@pytest.mark.parametrize("n,m1,m2,radius1", [(1024, 20, 7, 0.2), (512, 64, 16, 0.15), (768, 33, 16, 0.3), (300, 48, 9, 0.5),
+                                             (1024, 32, 16, 1e-3)])
+def test_in_launch_plans_for_other_centre_counts_feed_the_rows_kernels(n, m1, m2, radius1):
+    """The plans msr3d_sa_fps2_query_plan writes, CONSUMED: msr3d_sa_level1_rows / msr3d_sa_level2_rows with planned = 1
+    behind it against the same two calls planning for themselves behind msr3d_sa_fps2_query_flags -- centre counts other
+    than the encoder's 32 / 16 (a lane a centre up to 64; level 2's quad per centre up to 16), clouds with a clamped last
+    query round, a radius that catches nothing (every centre one row), a constant cloud and a skipped one."""
+    from msr3d_amd import _lib
+    from msr3d_amd.pointnet2 import fused
+    net = _net(8)
+    lib = _lib.load()
+    S1, S2 = fused.get_plan(net)["split1"], fused.get_plan(net)["split2"]
+    b = 7
+    g = torch.Generator().manual_seed(n + m1)
+    pts = (torch.rand(b, n, 6, generator=g) - 0.5).cuda()
+    pts[:, :, :3] += 0.7
+    pts[3] = pts[3, :1]                                                       # a constant cloud
+    valid = torch.tensor([1, 1, 0, 1, 1, 1, 1], dtype=torch.bool, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else 0)     # noqa: E731
+    st = _lib.current_stream_ptr()
+    i32 = dict(dtype=torch.int32, device="cuda")
+    r2 = 0.4
+    res = {}
+    for inside in (True, False):
+        new1, new2 = torch.zeros(b, m1, 3, device="cuda"), torch.zeros(b, m2, 3, device="cuda")
+        ball1, ball2 = torch.zeros(b, m1, 32, **i32), torch.zeros(b, m2, 32, **i32)
+        const = torch.zeros(b, dtype=torch.uint8, device="cuda")
+        feat1 = torch.zeros(b, m1, 128, device="cuda")
+        feat2 = torch.zeros(b, m2, 256, device="cuda")
+        ws1 = torch.empty((int(lib.msr3d_sa_level1_rows_ws_bytes(b, m1)),), dtype=torch.uint8, device="cuda")
+        ws2 = torch.empty((int(lib.msr3d_sa_level2_rows_ws_bytes(b)),), dtype=torch.uint8, device="cuda")
+        vm = valid.view(torch.uint8)
+        if inside:
+            _lib.check(lib.msr3d_sa_fps2_query_plan(b, n, 6, m1, m2, p(pts), None, p(new1), None, p(new2), p(vm),
+                                                    ctypes.c_float(radius1), 32, p(ball1), p(const), p(ws1), ctypes.c_float(r2),
+                                                    p(feat2), p(ball2), p(ws2), st), "fps2_query_plan")
+        else:
+            _lib.check(lib.msr3d_sa_fps2_query_flags(b, n, 6, m1, m2, p(pts), None, p(new1), None, p(new2), p(vm),
+                                                     ctypes.c_float(radius1), 32, p(ball1), p(const), st), "fps2_query_flags")
+        planned = 1 if inside else 0
+        _lib.check(lib.msr3d_sa_level1_rows(b, n, m1, p(pts), p(new1), p(ball1), p(S1[0][0]), p(S1[0][1]), p(S1[1][0]), p(S1[1][1]),
+                                            p(S1[2][0]), p(S1[2][1]), p(feat1), p(vm), p(const), p(ws1), planned, st), "level1_rows")
+        _lib.check(lib.msr3d_sa_level2_rows(b, m1, m2, ctypes.c_float(r2), p(new1), p(feat1), p(new2), p(S2[0][0]), p(S2[0][1]),
+                                            p(S2[1][0]), p(S2[1][1]), p(S2[2][0]), p(S2[2][1]), p(feat2), p(ball2), p(vm),
+                                            p(const), p(ws2), planned, st), "level2_rows")
+        torch.cuda.synchronize()
+        res[inside] = dict(new1=new1, new2=new2, ball1=ball1, ball2=ball2, const=const, feat1=feat1, feat2=feat2)
+    for k in res[True]:
+        assert torch.equal(res[True][k][valid], res[False][k][valid]), k
+    assert res[True]["const"].tolist()[3] == 1 and float(res[True]["feat2"][valid].abs().max()) > 0
