@@ -1453,6 +1453,8 @@ __global__ __launch_bounds__(256, 1) void sa3_split4_kernel(int b, const float *
 //   else (dense batches)              four consecutive objects a workgroup, as sa3_split4_kernel.
 // A row's arithmetic is the same in every form (same gather, same split, the same MFMA sequence per row; which rows
 // share a 16-row tile enters no result) and max over sixteen identical rows is that row: the same bits.
+// (Measured and not kept: THREE stages of weight pieces in flight instead of two at three row tiles -- the registers are
+// there -- 84-86 us against 78-81: the tile is not short of loads in flight.)
 template <int RN, int NG>
 __device__ __forceinline__ void group_finish_ids(float (&m)[RN][NG][4], float *__restrict__ out, int ldo, int n0,
                                                  const int *s_obj, int lane) {
