@@ -219,6 +219,9 @@ def _plan_workspaces(lib, dev, st, b, m1):
     """The two planning workspaces of a pass, kept per (device, stream, shape): they are arguments of the pass's FIRST
     launch now, and two allocator calls in front of it are host time the GPU idles through in the un-pipelined schedule.
     (Per stream: passes on different streams may overlap; passes on one stream are ordered.)"""
+    if torch.cuda.is_current_stream_capturing():      # (a capture's allocations live in its own pool: never kept)
+        return (torch.empty((int(lib.msr3d_sa_level1_rows_ws_bytes(b, m1)),), dtype=torch.uint8, device=dev),
+                torch.empty((int(lib.msr3d_sa_level2_rows_ws_bytes(b)),), dtype=torch.uint8, device=dev))
     key = (str(dev), int(st.value) if hasattr(st, "value") and st.value else 0, b, m1)
     ws = _plan_ws.get(key)
     if ws is None:
