@@ -25,8 +25,13 @@
 //
 // Why partial slabs and not atomics: scene_rows.hip.
 //
-// Workgroup -> XCD: blockIdx.x = slice and gridDim.x in {8, 16}, so all scenes' workgroups of a slice
-// land on the XCD (slice mod 8): a slice's weights are fetched into ONE L2 (speed only).
+// Workgroup -> XCD (speed only; a workgroup runs on XCD (linear id mod 8)).  Feed-forward / projector blocks:
+// blockIdx.x = slice and gridDim.x = 16, so all scenes' workgroups of a slice land on the XCD (slice mod 8) -- a slice's
+// weights (0.4 MB) are fetched into ONE L2, every L2 sees every scene's planes (1.5 MB).  ATTENTION blocks (round 6,
+// MSR3D_ATTN_SCENE_XCD): the other way round -- a scene's eight (sixteen) workgroups on XCD (scene mod 8) when the
+// batch is a multiple of eight scenes: a head's weights are 0.15-0.2 MB, so every L2 holding all heads (1.6 MB) and two
+// scenes' planes + pairwise rows (0.3 MB) is less fabric traffic than one head and sixteen scenes (2.7 MB): 7-9 us a
+// step (profiles/r06_v4_ab_attn_xcd.txt); results do not depend on it.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -39,6 +44,10 @@
 // phase marks: empty here; tools/prof/scene_block_stamped.hip defines SB_STAMP and includes this file
 #ifndef SB_STAMP
 #define SB_STAMP(i)
+#endif
+
+#ifndef MSR3D_ATTN_SCENE_XCD
+#define MSR3D_ATTN_SCENE_XCD 1
 #endif
 
 namespace {
@@ -212,7 +221,13 @@ __global__ __launch_bounds__(64 * NW) void scene_block_kernel(const SB p) {
   unsigned short *xs = reinterpret_cast<unsigned short *>(smem);
   unsigned char *aux = smem + XS_BYTES;
   // (rows_total > 0: row tiles that ignore scene boundaries -- tile b holds rows [b L, min((b + 1) L, rows_total)))
-  const int slice = blockIdx.x, b = blockIdx.y;
+  int slice = blockIdx.x, b = blockIdx.y;
+#if MSR3D_ATTN_SCENE_XCD
+  if ((KIND == MSR3D_BLK_ATTN_FWD || KIND == MSR3D_BLK_ATTN_BWD) && gridDim.x == 8 && (gridDim.y & 7) == 0) {
+    const int id = blockIdx.y * 8 + blockIdx.x, jj = id >> 3;   // (a scene's eight heads on ONE XCD: see the file's head)
+    b = (id & 7) + 8 * (jj >> 3); slice = jj & 7;
+  }
+#endif
   const int row_base = b * p.L;
   const int L = p.rows_total > 0 ? min(p.L, p.rows_total - row_base) : p.L;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -575,7 +590,16 @@ __global__ __launch_bounds__(512) void scene_attn_fwd2_kernel(const SB p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned short *xs = reinterpret_cast<unsigned short *>(smem);
   unsigned char *aux = smem + XS_BYTES;
+#if MSR3D_ATTN_SCENE_XCD
+  int h, qh, b;
+  if ((gridDim.y & 7) == 0) {                // a scene's sixteen workgroups on ONE XCD (workgroup id mod 8)
+    const int id = blockIdx.y * 16 + blockIdx.x, c = id & 7, jj = id >> 3, x = jj & 15;
+    b = c + 8 * (jj >> 4); h = x & 7; qh = x >> 3;
+  } else { h = blockIdx.x & 7; qh = blockIdx.x >> 3; b = blockIdx.y; }
+  const int L = p.L, H = p.H, ldq = p.ldq;
+#else
   const int h = blockIdx.x & 7, qh = blockIdx.x >> 3, b = blockIdx.y, L = p.L, H = p.H, ldq = p.ldq;
+#endif
   const int q0 = 32 * qh;
   if (q0 >= L) return;                       // (a scene of <= 32 tokens: the first workgroup owns every row)
   const int row_base = b * L;
@@ -988,7 +1012,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned short *xs = reinterpret_cast<unsigned short *>(smem);
   unsigned char *aux = smem + XS_BYTES;
+#if MSR3D_ATTN_SCENE_XCD
+  int h, b;
+  if ((gridDim.y & 7) == 0) {
+    const int id = blockIdx.y * 8 + blockIdx.x, c = id & 7, jj = id >> 3;
+    b = c + 8 * (jj >> 3); h = jj & 7;
+  } else { h = blockIdx.x; b = blockIdx.y; }
+  const int L = p.L, H = p.H, ldq = p.ldq;
+#else
   const int h = blockIdx.x, b = blockIdx.y, L = p.L, H = p.H, ldq = p.ldq;
+#endif
   const int row_base = b * L;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
