@@ -39,6 +39,17 @@ namespace {
 
 using namespace msr3d_attn;
 
+// (scene, head) of a workgroup.  Speed only: a workgroup runs on XCD (linear id mod 8); with eight heads and a multiple of
+// eight scenes a scene's heads are put on ONE XCD -- they share the scene's pairwise rows (L L 5 floats: 293 KB at the
+// stress shape's 121 tokens), which every L2 otherwise pulls for every scene (csrc/scene_block.hip's head has the figures).
+__device__ __forceinline__ void scene_head(int &h, int &b) {
+  h = blockIdx.x; b = blockIdx.y;
+  if (gridDim.x == 8 && (gridDim.y & 7) == 0) {
+    const int id = blockIdx.y * 8 + blockIdx.x, jj = id >> 3;
+    b = (id & 7) + 8 * (jj >> 3); h = jj & 7;
+  }
+}
+
 // =================================================================================
 // forward.  grid (H, B), LT/16 waves; wave w owns query rows [16w, 16w+16).
 // =================================================================================
@@ -56,7 +67,8 @@ __global__ __launch_bounds__(LT * 4) void attn_fwd_kernel(int B, int L, int H,
   constexpr float kPScale = (MMA == MSR3D_MMA_FP8) ? 256.f : 1.f;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *sq = smem, *sk = sq + LT * LD32, *sv = sk + LT * LD32, *sp = sv + LT * LD32;
-  const int h = blockIdx.x, b = blockIdx.y;
+  int h, b;
+  scene_head(h, b);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4, row0 = wave * 16;
   load_head_tile<LT>(q, ldqkv, b, h, L, sq);
@@ -100,8 +112,9 @@ __global__ __launch_bounds__(LT * 4) void attn_bwd_kernel(int B, int L, int H,
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *sq = smem, *sk = sq + LT * LD32, *sv = sk + LT * LD32, *sdo = sv + LT * LD32;
   float *sp = sdo + LT * LD32;                    // P, then dS in place
-  const float *plb = stage_ploc<LT>(ploc, blockIdx.y, L, sp + LT * LDP);
-  const int h = blockIdx.x, b = blockIdx.y;
+  int h, b;
+  scene_head(h, b);
+  const float *plb = stage_ploc<LT>(ploc, b, L, sp + LT * LDP);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4, row0 = wave * 16;
   load_head_tile<LT>(q, ldqkv, b, h, L, sq);
