@@ -713,8 +713,6 @@ def measure_variant(args, device, steps=30, warmup=5, **over):
     if getattr(a, "train_mma", None):
         from msr3d_amd import _lib as _lib_mod
         _lib_mod.load_bf16()
-    if "MSR3D_ATTN_FWD_SPLIT" not in os.environ:
-        scene_blocks.set_attn_fwd_form(split=not a.pipeline)
     model = build(a, device)
     # (the headline's resident batches: the encoder's time depends on the scenes -- distinct rows, padding slots)
     batches = [synth_batch(i, a.batch, O=O, P=P, device=device, dense=a.dense) for i in range(4)]
@@ -736,8 +734,6 @@ def measure_variant(args, device, steps=30, warmup=5, **over):
            "nominal_rows_per_launch": {f"level{l}": st[l]["nominal_rows"] for l in (1, 2)},
            "constant_objects": st["constant_objects"],
            "schedule": "blocks" if getattr(getattr(model, "_schedule", None), "_ran_blocks", False) else "strips/modular"}
-    if "MSR3D_ATTN_FWD_SPLIT" not in os.environ:
-        scene_blocks.set_attn_fwd_form(split=not args.pipeline)
     if getattr(a, "train_mma", None):
         # how far the reduced variant's outputs are from the fp32-accurate path: same weights, same batch, dropout off
         res["rel_l2_vs_f32"] = train_mma_distance(model, batches[0])
@@ -830,11 +826,9 @@ def main():
     from msr3d_amd.synth import synth_batch
     if os.environ.get("MSR3D_BENCH_RESERVE_CUS"):       # experiment knob: CUs the persistent encoder kernels leave free
         _lib.set_reserved_cus(int(os.environ["MSR3D_BENCH_RESERVE_CUS"]))
-    if "MSR3D_ATTN_FWD_SPLIT" not in os.environ:
-        # the attention forward block as ONE workgroup per (scene, head) when the next batch's encoder runs beside the
-        # trainable part (it takes the CUs that form leaves: 0.851 against 0.863 ms), as two otherwise (0.900 against 0.914)
-        from msr3d_amd import scene_blocks
-        scene_blocks.set_attn_fwd_form(split=not (args.pipeline and not dist_on and not args.unfrozen))
+    # (the attention forward block's form is the library's default in every schedule -- two workgroups per (scene, head):
+    #  with a scene's workgroups on one XCD it is the faster one pipelined as well, 0.846 against 0.855 ms;
+    #  MSR3D_ATTN_FWD_SPLIT=0 selects one workgroup)
     model = build(args, device)
     if args.skip_padded:
         model.visual_prompter.obj_encoder.skip_padded = True
