@@ -31,7 +31,9 @@
 // MSR3D_ATTN_SCENE_XCD): the other way round -- a scene's eight (sixteen) workgroups on XCD (scene mod 8) when the
 // batch is a multiple of eight scenes: a head's weights are 0.15-0.2 MB, so every L2 holding all heads (1.6 MB) and two
 // scenes' planes + pairwise rows (0.3 MB) is less fabric traffic than one head and sixteen scenes (2.7 MB): 7-9 us a
-// step (profiles/r06_v4_ab_attn_xcd.txt); results do not depend on it.
+// step (profiles/r06_v4_ab_attn_xcd.txt); results do not depend on it.  The same placement for the feed-forward blocks
+// (MSR3D_FFN_SCENE_XCD=1 at build time: all sixteen slices' weights, 6.3 MB, past every 4 MB L2) is neutral on the day's
+// fast boxes and 14 us a step slower on the others: off.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -48,6 +50,9 @@
 
 #ifndef MSR3D_ATTN_SCENE_XCD
 #define MSR3D_ATTN_SCENE_XCD 1
+#endif
+#ifndef MSR3D_FFN_SCENE_XCD
+#define MSR3D_FFN_SCENE_XCD 0
 #endif
 
 namespace {
@@ -226,6 +231,12 @@ __global__ __launch_bounds__(64 * NW) void scene_block_kernel(const SB p) {
   if ((KIND == MSR3D_BLK_ATTN_FWD || KIND == MSR3D_BLK_ATTN_BWD) && gridDim.x == 8 && (gridDim.y & 7) == 0) {
     const int id = blockIdx.y * 8 + blockIdx.x, jj = id >> 3;   // (a scene's eight heads on ONE XCD: see the file's head)
     b = (id & 7) + 8 * (jj >> 3); slice = jj & 7;
+  }
+#endif
+#if MSR3D_FFN_SCENE_XCD
+  if ((KIND == MSR3D_BLK_FFN_FWD || KIND == MSR3D_BLK_FFN_BWD) && gridDim.x == 16 && (gridDim.y & 7) == 0 && p.rows_total == 0) {
+    const int id = blockIdx.y * 16 + blockIdx.x, jj = id >> 3;
+    b = (id & 7) + 8 * (jj >> 4); slice = jj & 15;
   }
 #endif
   const int row_base = b * p.L;
